@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/sec of the PQN hot path, MinAtar-Breakout 4096 envs.
+
+A "step" is ONE PQN update of the full loop (rollout of NUM_STEPS x NUM_ENVS
+env-steps + Q(lambda) targets + NUM_EPOCHS x NUM_MINIBATCHES optimizer steps),
+the unit the reference's own SPS figures count
+(purejaxql/pqn_mujoco_playground.py:658-668).  value = env-steps/s over all ranks.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task prompt), incl. `roofline`
+(dominant kernel, HIP-event timed live) and `cpu_baseline` (the CPU oracle, timed
+on this box's host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENV_STEP_BYTES = 1926.0      # algorithmic bytes of one env.step (f32 obs surface)
+LOOP_FLOP = 2.367e6          # algorithmic FLOP per env-step of the whole loop
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA/vector peak
+
+
+def workload_config(num_envs: int, mode: str):
+    from purejaxql_amd.config_loader import flatten, load_config
+    cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", f"alg.NUM_ENVS={num_envs}",
+                               "alg.TEST_DURING_TRAINING=False"]))
+    return cfg
+
+
+def cpu_baseline(cfg, theta0, max_seconds=45.0):
+    """The CPU oracle (numpy/C restatement, kind="port") on one update of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import pqn_oracle as oracle
+    ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+    n, t = int(ocfg["NUM_ENVS"]), int(ocfg["NUM_STEPS"])
+    # bounded sample: 1 update at a reduced env count if the full one would take too long
+    sample_envs = n
+    cores = os.cpu_count() or 1
+    ocfg["NUM_ENVS"] = sample_envs
+    ocfg["TOTAL_TIMESTEPS"] = ocfg["TOTAL_TIMESTEPS_DECAY"] = 1e7
+    train = oracle.make_train(ocfg)
+    t0 = time.perf_counter()
+    train(12345, theta0, max_updates=1)
+    dt = time.perf_counter() - t0
+    return {"value": sample_envs * t / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 full PQN update (rollout+Q(lambda)+{ocfg['NUM_EPOCHS']}x{ocfg['NUM_MINIBATCHES']} SGD steps) "
+                      f"at NUM_ENVS={sample_envs}, NUM_STEPS={t}: {sample_envs * t} env-steps in {dt:.1f}s; "
+                      "oracle/pqn_oracle.py (C env/eps-greedy/Q(lambda)/RAdam + numpy-BLAS network), not JAX"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--num-envs", type=int, default=4096)
+    ap.add_argument("--mode", default="seeds", choices=["seeds", "envs"],
+                    help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
+                         "(RCCL gradient all-reduce per optimizer step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: purejaxql_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from purejaxql_amd import _lib
+    _lib.load()
+    from purejaxql_amd.pqn import make_train, seed_keys
+    from purejaxql_amd import dist as pdist
+
+    cfg = workload_config(args.num_envs, args.mode)
+    cfg["TOTAL_TIMESTEPS"] = (args.steps + args.warmup + 1) * cfg["NUM_ENVS"] * cfg["NUM_STEPS"]
+    grad_hook = None
+    if world > 1 and args.mode == "envs":
+        grad_hook = pdist.make_grad_allreduce_hook()
+    seed_index = rank if args.mode == "seeds" else 0
+    key = seed_keys(0, world)[seed_index]
+    if args.mode == "envs" and world > 1:
+        cfg["_ENV_SHARD"] = (rank, world)
+    train = make_train(cfg, device=str(dev), grad_hook=grad_hook)
+    update, finish = train.make_runner(key)
+
+    for u in range(args.warmup):
+        update(u)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for u in range(args.warmup, args.warmup + args.steps):
+        update(u)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    env_steps = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * args.steps * world
+    sps = env_steps / dt
+
+    if rank == 0:
+        roof = train.roofline() if hasattr(train, "roofline") else None
+        if roof is None:
+            from purejaxql_amd.profiling import time_env_step_kernel
+            k_ms = time_env_step_kernel(cfg["NUM_ENVS"], dev)
+            achieved = ENV_STEP_BYTES * cfg["NUM_ENVS"] / (k_ms * 1e-3) / 1e9
+            roof = {"kernel": "minatar_kernel<Breakout> (env.step, f32 obs surface)", "bound": "hbm",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "avg_launch_us": k_ms * 1e3}
+        out = {
+            "metric": "env-steps/sec (whole node), MinAtar-Breakout 4096 envs", "value": sps, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Breakout-MinAtar PQN full loop, NUM_ENVS={cfg['NUM_ENVS']} NUM_STEPS={cfg['NUM_STEPS']} "
+                                   f"NUM_MINIBATCHES={cfg['NUM_MINIBATCHES']} NUM_EPOCHS={cfg['NUM_EPOCHS']} per GPU",
+                       "seeds_per_gpu": 1, "parallelism": f"{args.mode}x{world}",
+                       "loop_tflops": sps * LOOP_FLOP / 1e12, "loop_frac_f32_peak": sps * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            theta0 = finish()["runner_state"]["network"].init(1).cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(cfg, theta0)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * pqn_hotpath.h -- C ABI of the MI355X-native PQN hot path (libpqn_hip.so).
+ *
+ * The reference (mttga/purejaxql) has no FFI: its boundary is the Python-level
+ * gymnax functional env API consumed by make_train
+ * (purejaxql/pqn_minatar.py:103-112,151,157) plus the algorithm closures of
+ * make_train itself.  Each entry point below replaces one of those call sites;
+ * the reference line it stands in for is cited next to it.  Python binds this
+ * with ctypes (purejaxql_amd/_lib.py); see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (HBM) owned by the caller unless marked
+ *    "host".  The library never allocates, frees or synchronises on the hot
+ *    path: calls only enqueue kernels on `stream` (a hipStream_t passed as
+ *    void*; NULL = the default stream), so they are hipGraph-capturable.
+ *  - Every function returns 0 on success or a negative PQN_E_* code; the
+ *    message is available from pqn_last_error() (thread-local).  No C++
+ *    exception crosses the ABI.
+ *  - Keys: a PRNG key is a uint64 (k0<<32|k1) for threefry2x32-20.  Element i
+ *    of a batched call draws threefry(key, (i, stream_id)); there is no RNG
+ *    state in memory.  pqn_fold_in(key, d) = threefry(key, (0, d)) replaces
+ *    jax.random.split.
+ *  - Env state is struct-of-arrays of 32-bit words: state[w * n + e] is word w
+ *    of env e (coalesced across envs).  Word meaning per env: pqn_env_spec().
+ *    The last PQN_LOG_WORDS words are the LogWrapper record
+ *    (utils/craftax_wrappers.py:151-158).
+ *  - Packed observations ("obs_bits"): MinAtar observations are {0,1} grids;
+ *    bit (y*10+x)*C+c of env e lives in obs_bits[e*obs_words + b/32] bit b%32
+ *    (flatten order h,w,c of pqn_minatar.py:47).  obs_words is padded to a
+ *    multiple of 4 words (16-B loads).
+ */
+#ifndef PQN_HOTPATH_H
+#define PQN_HOTPATH_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQN_OK 0
+#define PQN_E_INVALID (-1)   /* bad argument (null pointer, bad size, unknown env) */
+#define PQN_E_HIP (-2)       /* HIP runtime error at launch */
+#define PQN_E_UNSUPPORTED (-3)
+
+#define PQN_LOG_WORDS 5 /* episode_returns f32, episode_lengths i32, returned_episode_returns f32,
+                           returned_episode_lengths i32, timestep i32 */
+
+enum {
+  PQN_ENV_BREAKOUT = 0,      /* "Breakout-MinAtar"      */
+  PQN_ENV_CARTPOLE = 1,      /* "CartPole-v1"           */
+  PQN_ENV_ASTERIX = 2,       /* "Asterix-MinAtar"       */
+  PQN_ENV_FREEWAY = 3,       /* "Freeway-MinAtar"       */
+  PQN_ENV_SPACEINVADERS = 4, /* "SpaceInvaders-MinAtar" */
+};
+
+/* What gymnax.make(name) -> (env, env_params) exposes to make_train
+ * (pqn_minatar.py:103-105,151,157,333). */
+typedef struct {
+  int32_t obs_dim[3];   /* (H, W, C); flat envs: (D, 0, 0) */
+  int32_t obs_size;     /* floats per observation */
+  int32_t num_actions;  /* env.action_space(params).n */
+  int32_t max_steps;    /* params.max_steps_in_episode */
+  int32_t state_words;  /* u32 words per env in the SoA state, INCLUDING PQN_LOG_WORDS */
+  int32_t obs_words;    /* u32 words per env of packed obs (0 if the env has none) */
+  int32_t canon_si;     /* int32 words per env in the canonical (export) layout */
+  int32_t canon_sf;     /* f32 words per env in the canonical (export) layout */
+} pqn_env_spec_t;
+
+/* Outputs of one batched env.step (all device pointers, any may be NULL except
+ * reward/done).  Matches the gymnax step tuple + LogWrapper info keys
+ * (utils/craftax_wrappers.py:194-199) + gymnax's info["discount"]. */
+typedef struct {
+  float *obs;                        /* [n, obs_size] f32 */
+  uint32_t *obs_bits;                /* [n, obs_words] packed (MinAtar only) */
+  float *reward;                     /* [n] */
+  uint8_t *done;                     /* [n] */
+  float *discount;                   /* [n] info["discount"] */
+  float *returned_episode_returns;   /* [n] */
+  int32_t *returned_episode_lengths; /* [n] */
+  int32_t *timestep;                 /* [n] */
+} pqn_step_out_t;
+
+const char *pqn_last_error(void);
+int pqn_version(void);
+
+/* ---- PRNG (host helpers; same functions the kernels evaluate) ---------- */
+void pqn_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]); /* host */
+uint64_t pqn_fold_in(uint64_t key, uint32_t data);                                    /* host */
+
+/* ---- environment: replaces gymnax.make / vmap_reset / vmap_step -------- */
+int pqn_env_id(const char *name); /* "Breakout-MinAtar" -> PQN_ENV_BREAKOUT, <0 if unknown */
+int pqn_env_spec(int env_id, pqn_env_spec_t *spec /* host */);
+
+/* vmap_reset(n)(key) -- pqn_minatar.py:107-109,397,419.  Also zeroes the
+ * LogWrapper record (LogWrapper.reset, craftax_wrappers.py:168-171). */
+int pqn_env_reset(int env_id, int32_t n, uint64_t key, uint32_t *state, float *obs,
+                  uint32_t *obs_bits, void *stream);
+
+/* vmap_step(n)(key, state, action) with LogWrapper -- pqn_minatar.py:110-112,
+ * 198-200,391-393.  gymnax auto-reset semantics (craftax_wrappers.py:59-80).
+ * state_in may equal state_out (in-place). */
+int pqn_env_step(int env_id, int32_t n, uint64_t key, const uint32_t *state_in,
+                 uint32_t *state_out, const int32_t *action, const pqn_step_out_t *out /* host */,
+                 void *stream);
+
+/* Canonical <-> packed state (tests, checkpoints).  Canonical layout per env:
+ * si int32[canon_si], sf f32[canon_sf] (env-major), log f32/i32 [n,5]. */
+int pqn_env_export_state(int env_id, int32_t n, const uint32_t *state, int32_t *si, float *sf,
+                         uint32_t *log, void *stream);
+int pqn_env_import_state(int env_id, int32_t n, const int32_t *si, const float *sf,
+                         const uint32_t *log, uint32_t *state, void *stream);
+
+/* ---- algorithm pieces of make_train ------------------------------------ */
+/* jax.vmap(eps_greedy_exploration) -- pqn_minatar.py:115-128,194-196.  Also
+ * emits max_a q (the only use of Transition.q_val, :249). qmax may be NULL. */
+int pqn_eps_greedy(const float *q, int32_t m, int32_t a, float eps, uint64_t key,
+                   int32_t *action, float *qmax, void *stream);
+
+/* Q(lambda) targets -- pqn_minatar.py:237-260 (quirk=1) or the
+ * pqn_atari.py:280-302 form (quirk=0).  All arrays time-major [T, m]. */
+int pqn_q_lambda(const float *reward, const uint8_t *done, const float *qmax, const float *last_q,
+                 float gamma, float lambda, int32_t t_len, int32_t m, int32_t quirk,
+                 float *target, void *stream);
+
+/* Sort keys for the per-epoch shuffle -- pqn_minatar.py:299-315. */
+int pqn_shuffle_keys(uint64_t key, int32_t n, int64_t *keys, void *stream);
+
+/* optax.chain(clip_by_global_norm, radam) on a flat f32 buffer --
+ * pqn_minatar.py:159-162,292.  `count` (device int32[1]) is the number of
+ * previous steps; it is read, used for the LR schedule and bias corrections,
+ * then incremented on the device.  lr(count) = linear(lr_init -> lr_end over
+ * lr_steps) if lr_steps > 0 else lr_init (:140-147).  scratch: >= 1024 floats.
+ * gnorm_out (nullable): pre-clip global norm. */
+int pqn_radam_clip_step(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count,
+                        float lr_init, float lr_end, float lr_steps, float max_norm,
+                        float *scratch, float *gnorm_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,412 @@
+/*
+ * pqn_oracle.c -- CPU ORACLE (test infrastructure, never shipped, never on the
+ * product path).  See pqn_oracle.h for scope and parity status.
+ *
+ * Every function cites the reference line range it restates
+ * (paths relative to the reference tree, mttga/purejaxql @ 2025-11-14).
+ * Env dynamics follow gymnax==0.0.6 (third-party, absent from the reference
+ * tree; pinned at reference pyproject.toml:51) -> "parity unpinned".
+ */
+#include "pqn_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* PRNG: threefry2x32, 20 rounds (Salmon et al. 2011, Random123).  jax.random
+ * (reference pqn_minatar.py:116-125,183,194,213,303) is built on the same
+ * block function; the key-derivation convention below is this build's own.  */
+/* ------------------------------------------------------------------------ */
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+void pqn_oracle_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) {
+  static const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  uint32_t ks[3] = {key[0], key[1], key[0] ^ key[1] ^ 0x1BD11BDAu};
+  uint32_t x0 = ctr[0] + ks[0];
+  uint32_t x1 = ctr[1] + ks[1];
+  for (int g = 0; g < 5; ++g) {
+    const int *rot = R[g & 1];
+    for (int i = 0; i < 4; ++i) {
+      x0 += x1;
+      x1 = rotl32(x1, rot[i]);
+      x1 ^= x0;
+    }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  out[0] = x0;
+  out[1] = x1;
+}
+
+/* key64 = (k0 << 32) | k1.  PRNGKey(seed) = (seed >> 32, seed & 0xffffffff). */
+uint64_t pqn_oracle_prng_key(uint64_t seed) { return seed; }
+
+/* fold_in(key, d) = threefry(key, (0, d)) -- the counter convention of
+ * jax.random.fold_in.  Used where the reference calls jax.random.split. */
+uint64_t pqn_oracle_fold_in(uint64_t key, uint32_t data) {
+  uint32_t k[2] = {(uint32_t)(key >> 32), (uint32_t)key};
+  uint32_t c[2] = {0u, data};
+  uint32_t o[2];
+  pqn_oracle_threefry2x32(k, c, o);
+  return ((uint64_t)o[0] << 32) | o[1];
+}
+
+/* Per-element randomness: element `index` of a vmapped call draws
+ * threefry(key, (index, stream)).  Replaces split(rng, n)[index]. */
+void pqn_oracle_env_bits(uint64_t key, uint32_t index, uint32_t stream, uint32_t out[2]) {
+  uint32_t k[2] = {(uint32_t)(key >> 32), (uint32_t)key};
+  uint32_t c[2] = {index, stream};
+  pqn_oracle_threefry2x32(k, c, out);
+}
+
+/* jax.random.uniform's bit trick: 23 mantissa bits, value in [0,1). */
+float pqn_oracle_bits_to_uniform(uint32_t bits) {
+  union { uint32_t u; float f; } v;
+  v.u = (bits >> 9) | 0x3f800000u;
+  return v.f - 1.0f;
+}
+
+/* Sort keys for the minibatch shuffle (pqn_minatar.py:299-315:
+ * jax.random.permutation is sort-based).  key_i = (bits_i >> 1) << 32 | i is
+ * unique, so argsort(key) is a well-defined permutation on every backend. */
+void pqn_oracle_sort_keys(uint64_t key, int32_t n, int64_t *out) {
+  for (int32_t i = 0; i < n; ++i) {
+    uint32_t o[2];
+    pqn_oracle_env_bits(key, (uint32_t)i, 0u, o);
+    out[i] = (int64_t)(((uint64_t)(o[0] >> 1) << 32) | (uint32_t)i);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Breakout-MinAtar (gymnax 0.0.6 environments/minatar/breakout.py; original
+ * rules: MinAtar breakout.py).  Canonical int state, 109 words per env:
+ *   [0] ball_y [1] ball_x [2] ball_dir [3] pos [4] strike [5] last_y
+ *   [6] last_x [7] time [8] terminal [9..108] brick_map[y*10+x]           */
+/* ------------------------------------------------------------------------ */
+#define BO_SI 109
+enum { BO_BALL_Y, BO_BALL_X, BO_DIR, BO_POS, BO_STRIKE, BO_LAST_Y, BO_LAST_X, BO_TIME, BO_TERM, BO_MAP };
+
+static void breakout_reset_one(uint32_t bits, int32_t *s) {
+  /* reset_env: ball_start = choice([0,1]); ball_x=[0,9][start]; dir=[2,3][start] */
+  int start = (int)(bits & 1u);
+  memset(s, 0, sizeof(int32_t) * BO_SI);
+  s[BO_BALL_Y] = 3;
+  s[BO_BALL_X] = start ? 9 : 0;
+  s[BO_DIR] = start ? 3 : 2;
+  s[BO_POS] = 4;
+  s[BO_STRIKE] = 0;
+  s[BO_LAST_Y] = 3;
+  s[BO_LAST_X] = s[BO_BALL_X];
+  s[BO_TIME] = 0;
+  s[BO_TERM] = 0;
+  for (int y = 1; y < 4; ++y)
+    for (int x = 0; x < 10; ++x) s[BO_MAP + y * 10 + x] = 1;
+}
+
+static void breakout_obs_one(const int32_t *s, float *obs) {
+  /* get_obs: ch0 paddle [9,pos]; ch1 ball; ch2 trail; ch3 brick_map. (10,10,4) */
+  memset(obs, 0, sizeof(float) * 400);
+  obs[(9 * 10 + s[BO_POS]) * 4 + 0] = 1.0f;
+  obs[(s[BO_BALL_Y] * 10 + s[BO_BALL_X]) * 4 + 1] = 1.0f;
+  obs[(s[BO_LAST_Y] * 10 + s[BO_LAST_X]) * 4 + 2] = 1.0f;
+  for (int i = 0; i < 100; ++i)
+    if (s[BO_MAP + i]) obs[i * 4 + 3] = 1.0f;
+}
+
+/* step_env: minimal action set [n,l,r] -> full-set codes [0,1,3]. */
+static void breakout_step_one(int32_t *s, int32_t action, int32_t max_steps, float *reward, int *done) {
+  static const int ACT[3] = {0, 1, 3};
+  static const int FLIP_X[4] = {1, 0, 3, 2};
+  static const int FLIP_Y[4] = {3, 2, 1, 0};
+  static const int FLIP_XY[4] = {2, 3, 0, 1};
+  int a = ACT[action];
+  float r = 0.0f;
+  /* step_agent */
+  int pos = s[BO_POS];
+  if (a == 1) pos = pos - 1 < 0 ? 0 : pos - 1;
+  else if (a == 3) pos = pos + 1 > 9 ? 9 : pos + 1;
+  int last_x = s[BO_BALL_X], last_y = s[BO_BALL_Y];
+  int dir = s[BO_DIR];
+  int new_x, new_y;
+  switch (dir) { /* 0 up-left, 1 up-right, 2 down-right, 3 down-left */
+    case 0: new_x = last_x - 1; new_y = last_y - 1; break;
+    case 1: new_x = last_x + 1; new_y = last_y - 1; break;
+    case 2: new_x = last_x + 1; new_y = last_y + 1; break;
+    default: new_x = last_x - 1; new_y = last_y + 1; break;
+  }
+  if (new_x < 0 || new_x > 9) {
+    new_x = new_x < 0 ? 0 : 9;
+    dir = FLIP_X[dir];
+  }
+  /* step_ball_brick */
+  int terminal = 0;
+  int strike_toggle = 0;
+  if (new_y < 0) {
+    new_y = 0;
+    dir = FLIP_Y[dir];
+  } else if (s[BO_MAP + new_y * 10 + new_x] == 1) {
+    strike_toggle = 1;
+    if (!s[BO_STRIKE]) {
+      r += 1.0f;
+      s[BO_MAP + new_y * 10 + new_x] = 0;
+      new_y = last_y;
+      dir = FLIP_Y[dir];
+    }
+  } else if (new_y == 9) {
+    int any = 0;
+    for (int i = 0; i < 100; ++i) any |= s[BO_MAP + i];
+    if (!any)
+      for (int y = 1; y < 4; ++y)
+        for (int x = 0; x < 10; ++x) s[BO_MAP + y * 10 + x] = 1;
+    if (last_x == pos) { /* old ball_x vs NEW paddle pos */
+      dir = FLIP_Y[dir];
+      new_y = last_y;
+    } else if (new_x == pos) {
+      dir = FLIP_XY[dir];
+      new_y = last_y;
+    } else {
+      terminal = 1;
+    }
+  }
+  s[BO_STRIKE] = strike_toggle;
+  s[BO_POS] = pos;
+  s[BO_LAST_X] = last_x;
+  s[BO_LAST_Y] = last_y;
+  s[BO_DIR] = dir;
+  s[BO_BALL_X] = new_x;
+  s[BO_BALL_Y] = new_y;
+  s[BO_TIME] += 1;
+  int d = terminal || (s[BO_TIME] >= max_steps);
+  s[BO_TERM] = d;
+  *reward = r;
+  *done = d;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CartPole-v1 (gymnax 0.0.6 environments/classic_control/cartpole.py).
+ * Canonical state: sf = [x, x_dot, theta, theta_dot], si = [time].        */
+/* ------------------------------------------------------------------------ */
+static void cartpole_reset_one(uint64_t key, uint32_t e, int32_t *si, float *sf) {
+  /* uniform(minval=-0.05, maxval=0.05, shape=(4,)): 4 draws = streams 1,2 x 2 words */
+  uint32_t o[2];
+  pqn_oracle_env_bits(key, e, 1u, o);
+  sf[0] = pqn_oracle_bits_to_uniform(o[0]) * 0.1f - 0.05f;
+  sf[1] = pqn_oracle_bits_to_uniform(o[1]) * 0.1f - 0.05f;
+  pqn_oracle_env_bits(key, e, 2u, o);
+  sf[2] = pqn_oracle_bits_to_uniform(o[0]) * 0.1f - 0.05f;
+  sf[3] = pqn_oracle_bits_to_uniform(o[1]) * 0.1f - 0.05f;
+  si[0] = 0;
+}
+
+static int cartpole_terminal(const int32_t *si, const float *sf, int32_t max_steps) {
+  const float x_thr = 2.4f;
+  const float th_thr = (float)(12.0 * 2.0 * 3.14159265358979323846 / 360.0);
+  int d1 = (sf[0] < -x_thr) || (sf[0] > x_thr);
+  int d2 = (sf[2] < -th_thr) || (sf[2] > th_thr);
+  return d1 || d2 || (si[0] >= max_steps);
+}
+
+static void cartpole_step_one(int32_t *si, float *sf, int32_t action, int32_t max_steps, float *reward,
+                              int *done) {
+  const float gravity = 9.8f, masspole = 0.1f, total_mass = 1.1f, length = 0.5f;
+  const float polemass_length = 0.05f, force_mag = 10.0f, tau = 0.02f;
+  int prev_terminal = cartpole_terminal(si, sf, max_steps);
+  float force = force_mag * (float)action - force_mag * (float)(1 - action);
+  float costheta = cosf(sf[2]);
+  float sintheta = sinf(sf[2]);
+  float temp = (force + polemass_length * (sf[3] * sf[3]) * sintheta) / total_mass;
+  float thetaacc = (gravity * sintheta - costheta * temp) /
+                   (length * (4.0f / 3.0f - masspole * (costheta * costheta) / total_mass));
+  float xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+  float x = sf[0] + tau * sf[1];
+  float x_dot = sf[1] + tau * xacc;
+  float theta = sf[2] + tau * sf[3];
+  float theta_dot = sf[3] + tau * thetaacc;
+  sf[0] = x; sf[1] = x_dot; sf[2] = theta; sf[3] = theta_dot;
+  si[0] += 1;
+  *reward = 1.0f - (float)prev_terminal;
+  *done = cartpole_terminal(si, sf, max_steps);
+}
+
+/* ------------------------------------------------------------------------ */
+int pqn_oracle_env_spec(int env_id, pqn_oracle_spec_t *spec) {
+  memset(spec, 0, sizeof(*spec));
+  switch (env_id) {
+    case PQN_ORACLE_ENV_BREAKOUT:
+      spec->obs_dim[0] = 10; spec->obs_dim[1] = 10; spec->obs_dim[2] = 4;
+      spec->obs_size = 400; spec->num_actions = 3; spec->max_steps = 1000;
+      spec->si = BO_SI; spec->sf = 0;
+      return 0;
+    case PQN_ORACLE_ENV_CARTPOLE:
+      spec->obs_dim[0] = 4; spec->obs_dim[1] = 0; spec->obs_dim[2] = 0;
+      spec->obs_size = 4; spec->num_actions = 2; spec->max_steps = 500;
+      spec->si = 1; spec->sf = 4;
+      return 0;
+    default:
+      return -1;
+  }
+}
+
+static void obs_one(int env_id, const int32_t *si, const float *sf, float *obs) {
+  if (env_id == PQN_ORACLE_ENV_BREAKOUT) breakout_obs_one(si, obs);
+  else if (env_id == PQN_ORACLE_ENV_CARTPOLE) memcpy(obs, sf, 4 * sizeof(float));
+}
+
+static void reset_one(int env_id, uint64_t key, uint32_t e, int32_t *si, float *sf) {
+  if (env_id == PQN_ORACLE_ENV_BREAKOUT) {
+    uint32_t o[2];
+    pqn_oracle_env_bits(key, e, 1u, o);
+    breakout_reset_one(o[0], si);
+  } else if (env_id == PQN_ORACLE_ENV_CARTPOLE) {
+    cartpole_reset_one(key, e, si, sf);
+  }
+}
+
+int pqn_oracle_env_obs(int env_id, int32_t n, const int32_t *si, const float *sf, float *obs) {
+  pqn_oracle_spec_t sp;
+  if (pqn_oracle_env_spec(env_id, &sp)) return -1;
+  for (int32_t e = 0; e < n; ++e)
+    obs_one(env_id, si + (size_t)e * sp.si, sf ? sf + (size_t)e * sp.sf : 0, obs + (size_t)e * sp.obs_size);
+  return 0;
+}
+
+/* vmap_reset (pqn_minatar.py:107-109): per-env reset_env with per-env keys. */
+int pqn_oracle_env_reset(int env_id, int32_t n, uint64_t key, int32_t *si, float *sf, float *obs) {
+  pqn_oracle_spec_t sp;
+  if (pqn_oracle_env_spec(env_id, &sp)) return -1;
+#pragma omp parallel for schedule(static)
+  for (int32_t e = 0; e < n; ++e) {
+    int32_t *s = si + (size_t)e * sp.si;
+    float *f = sf ? sf + (size_t)e * sp.sf : 0;
+    reset_one(env_id, key, (uint32_t)e, s, f);
+    if (obs) obs_one(env_id, s, f, obs + (size_t)e * sp.obs_size);
+  }
+  return 0;
+}
+
+/* vmap_step (pqn_minatar.py:110-112) over gymnax Environment.step, whose
+ * auto-reset semantics are stated in-tree by utils/craftax_wrappers.py:59-80:
+ * step_env, reset_env, then select(done, reset, stepped) for obs and state. */
+int pqn_oracle_env_step(int env_id, int32_t n, uint64_t key, int32_t *si, float *sf,
+                        const int32_t *action, int autoreset, float *obs, float *reward,
+                        uint8_t *done, float *discount) {
+  pqn_oracle_spec_t sp;
+  if (pqn_oracle_env_spec(env_id, &sp)) return -1;
+#pragma omp parallel for schedule(static)
+  for (int32_t e = 0; e < n; ++e) {
+    int32_t *s = si + (size_t)e * sp.si;
+    float *f = sf ? sf + (size_t)e * sp.sf : 0;
+    float r = 0.0f;
+    int d = 0;
+    if (env_id == PQN_ORACLE_ENV_BREAKOUT) breakout_step_one(s, action[e], sp.max_steps, &r, &d);
+    else cartpole_step_one(s, f, action[e], sp.max_steps, &r, &d);
+    if (d && autoreset) reset_one(env_id, key, (uint32_t)e, s, f);
+    if (obs) obs_one(env_id, s, f, obs + (size_t)e * sp.obs_size);
+    reward[e] = r;
+    done[e] = (uint8_t)d;
+    if (discount) discount[e] = d ? 0.0f : 1.0f; /* info["discount"] */
+  }
+  return 0;
+}
+
+/* LogWrapper.step, utils/craftax_wrappers.py:173-200. */
+void pqn_oracle_log_step(int32_t n, const float *reward, const uint8_t *done, float *ep_ret,
+                         int32_t *ep_len, float *ret_ret, int32_t *ret_len, int32_t *timestep) {
+  for (int32_t e = 0; e < n; ++e) {
+    float new_ret = ep_ret[e] + reward[e];
+    int32_t new_len = ep_len[e] + 1;
+    int d = done[e] ? 1 : 0;
+    ep_ret[e] = new_ret * (float)(1 - d);
+    ep_len[e] = new_len * (1 - d);
+    ret_ret[e] = ret_ret[e] * (float)(1 - d) + new_ret * (float)d;
+    ret_len[e] = ret_len[e] * (1 - d) + new_len * d;
+    timestep[e] += 1;
+  }
+}
+
+/* eps_greedy_exploration, pqn_minatar.py:115-128 (vmapped at :196).
+ * argmax = first maximal index (jnp.argmax).  Also emits max_a q. */
+void pqn_oracle_eps_greedy(const float *q, int32_t m, int32_t a, float eps, uint64_t key,
+                           int32_t *action, float *qmax) {
+  for (int32_t i = 0; i < m; ++i) {
+    const float *qi = q + (size_t)i * a;
+    int best = 0;
+    float bv = qi[0];
+    for (int j = 1; j < a; ++j)
+      if (qi[j] > bv) { bv = qi[j]; best = j; }
+    uint32_t o[2];
+    pqn_oracle_env_bits(key, (uint32_t)i, 0u, o);
+    float u = pqn_oracle_bits_to_uniform(o[0]);            /* rng_e */
+    int rnd = (int)(((uint64_t)o[1] * (uint64_t)a) >> 32); /* rng_a: randint(0, A) */
+    action[i] = (u < eps) ? rnd : best;
+    if (qmax) qmax[i] = bv;
+  }
+}
+
+/* Q(lambda) targets.  quirk=1: pqn_minatar.py:237-260 (initial next_q carry is
+ * last_q*(1-done[T-1])).  quirk=0: pqn_atari.py:280-302 (initial
+ * next_q = max_a q_val[T-1]).  Layout [T][M], f32 arithmetic as in A.8. */
+void pqn_oracle_q_lambda(const float *reward, const uint8_t *done, const float *qmax,
+                         const float *last_q, float gamma, float lambda, int32_t t_len,
+                         int32_t m, int32_t quirk, float *target) {
+  for (int32_t e = 0; e < m; ++e) {
+    size_t last = (size_t)(t_len - 1) * m + e;
+    float lq = last_q[e] * (float)(1 - (int)done[last]);
+    float lr = reward[last] + gamma * lq;
+    float nq = quirk ? lq : qmax[last];
+    target[last] = lr;
+    for (int32_t t = t_len - 2; t >= 0; --t) {
+      size_t i = (size_t)t * m + e;
+      float d = (float)done[i];
+      float tb = reward[i] + gamma * (1.0f - d) * nq;
+      float delta = lr - nq;
+      lr = tb + gamma * lambda * delta;
+      lr = (1.0f - d) * lr + d * reward[i];
+      nq = qmax[i];
+      target[i] = lr;
+    }
+  }
+}
+
+/* optax.linear_schedule (A.5), used at pqn_minatar.py:134-147. */
+double pqn_oracle_linear_schedule(double init, double end, double transition_steps, double count) {
+  if (transition_steps <= 0) return end;
+  double c = count < 0 ? 0 : (count > transition_steps ? transition_steps : count);
+  double frac = 1.0 - c / transition_steps;
+  return (init - end) * frac + end;
+}
+
+/* optax.chain(clip_by_global_norm(max_norm), radam(lr)) -- pqn_minatar.py:159-162
+ * -- one optimizer step on a flat parameter vector.  `count` = number of
+ * previous steps (0-based); lr is already evaluated at `count` by the caller.
+ * Returns the pre-clip global norm. */
+float pqn_oracle_radam_clip_step(float *p, float *g, float *m, float *v, int64_t n,
+                                 int64_t count, float lr, float max_norm) {
+  const double b1 = 0.9, b2 = 0.999, eps = 1e-8, threshold = 5.0;
+  double ss = 0.0;
+  for (int64_t i = 0; i < n; ++i) ss += (double)g[i] * (double)g[i];
+  float gnorm = (float)sqrt(ss);
+  int clip = !(gnorm < max_norm);
+  double t = (double)(count + 1);
+  double b1t = pow(b1, t), b2t = pow(b2, t);
+  double ro_inf = 2.0 / (1.0 - b2) - 1.0;
+  double ro = ro_inf - 2.0 * t * b2t / (1.0 - b2t);
+  float bc1 = (float)(1.0 - b1t); /* bias_correction: m / (1 - decay**count) */
+  float bc2 = (float)(1.0 - b2t);
+  int rect = ro >= threshold;
+  float r = rect ? (float)sqrt((ro - 4.0) * (ro - 2.0) * ro_inf / ((ro_inf - 4.0) * (ro_inf - 2.0) * ro)) : 0.0f;
+  for (int64_t i = 0; i < n; ++i) {
+    float gi = g[i];
+    if (clip) gi = (gi / gnorm) * max_norm;
+    float mi = (float)(1.0 - b1) * gi + (float)b1 * m[i];
+    float vi = (float)(1.0 - b2) * (gi * gi) + (float)b2 * v[i];
+    m[i] = mi;
+    v[i] = vi;
+    float mh = mi / bc1;
+    float vh = vi / bc2;
+    float u = rect ? r * mh / (sqrtf(vh) + (float)eps) : mh;
+    p[i] = p[i] - lr * u;
+  }
+  return gnorm;
+}

@@ -1,0 +1,437 @@
+"""CPU ORACLE, Python side -- TEST INFRASTRUCTURE ONLY.
+
+ctypes loader for oracle/libpqn_oracle.so (plain-C restatement, see
+pqn_oracle.h) plus a numpy restatement of the Q-networks and of the whole
+make_train loop of the reference:
+
+    purejaxql/pqn_minatar.py:24-69,89-431   (CNN + loop)
+    purejaxql/pqn_gymnax.py:29-58,78-424    (MLP + loop)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  purejaxql_amd never does.
+
+PARITY STATUS: the reference has no tests/golden vectors and cannot be imported
+in the build container (no jax/flax/optax/gymnax).  Algorithm pieces are pinned
+by the hand-derived known-answer vectors of SURVEY.md 8(c) (tests/golden/);
+env dynamics and flax/optax numerics are restated from third-party recollection
+-> **parity unpinned** for those.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+from collections import OrderedDict
+from typing import Any, Dict
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpqn_oracle.so")
+_lib = None
+
+ENV_IDS = {"Breakout-MinAtar": 0, "CartPole-v1": 1, "Asterix-MinAtar": 2, "Freeway-MinAtar": 3,
+           "SpaceInvaders-MinAtar": 4}
+
+
+class Spec(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32 * 3), ("obs_size", C.c_int32), ("num_actions", C.c_int32),
+                ("max_steps", C.c_int32), ("si", C.c_int32), ("sf", C.c_int32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.pqn_oracle_fold_in.restype = C.c_uint64
+        L.pqn_oracle_fold_in.argtypes = [C.c_uint64, C.c_uint32]
+        L.pqn_oracle_bits_to_uniform.restype = C.c_float
+        L.pqn_oracle_bits_to_uniform.argtypes = [C.c_uint32]
+        L.pqn_oracle_linear_schedule.restype = C.c_double
+        L.pqn_oracle_linear_schedule.argtypes = [C.c_double] * 4
+        L.pqn_oracle_radam_clip_step.restype = C.c_float
+        L.pqn_oracle_radam_clip_step.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_float, C.c_float]
+        L.pqn_oracle_env_reset.argtypes = [C.c_int, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pqn_oracle_env_step.argtypes = [C.c_int, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pqn_oracle_env_obs.argtypes = [C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pqn_oracle_log_step.argtypes = [C.c_int32] + [C.c_void_p] * 7
+        L.pqn_oracle_eps_greedy.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p,
+                                            C.c_void_p]
+        L.pqn_oracle_q_lambda.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32,
+                                                             C.c_void_p]
+        L.pqn_oracle_sort_keys.argtypes = [C.c_uint64, C.c_int32, C.c_void_p]
+        L.pqn_oracle_env_bits.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.pqn_oracle_threefry2x32.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.pqn_oracle_env_spec.argtypes = [C.c_int, C.POINTER(Spec)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- PRNG ---------------------------------------------------------------------------
+def threefry2x32(key, ctr):
+    k = (C.c_uint32 * 2)(*key)
+    c = (C.c_uint32 * 2)(*ctr)
+    o = (C.c_uint32 * 2)()
+    lib().pqn_oracle_threefry2x32(k, c, o)
+    return int(o[0]), int(o[1])
+
+
+def fold_in(key: int, data: int) -> int:
+    return int(lib().pqn_oracle_fold_in(C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(data & 0xFFFFFFFF)))
+
+
+def env_bits(key, index, stream):
+    o = (C.c_uint32 * 2)()
+    lib().pqn_oracle_env_bits(C.c_uint64(key), index, stream, o)
+    return int(o[0]), int(o[1])
+
+
+def permutation(key: int, n: int) -> np.ndarray:
+    keys = np.empty(n, dtype=np.int64)
+    lib().pqn_oracle_sort_keys(C.c_uint64(key), n, _p(keys))
+    return np.argsort(keys, kind="stable")
+
+
+# ---- envs ---------------------------------------------------------------------------
+class OracleEnv:
+    """Batched gymnax-style env + LogWrapper on the C oracle (canonical state)."""
+
+    def __init__(self, name: str):
+        self.name = name
+        self.env_id = ENV_IDS[name]
+        sp = Spec()
+        assert lib().pqn_oracle_env_spec(self.env_id, C.byref(sp)) == 0, f"oracle has no env {name}"
+        self.spec = sp
+        d = tuple(int(x) for x in sp.obs_dim)
+        self.obs_shape = d if d[1] > 0 else (d[0],)
+        self.obs_size = int(sp.obs_size)
+        self.num_actions = int(sp.num_actions)
+        self.max_steps = int(sp.max_steps)
+
+    def reset(self, key: int, n: int):
+        st = {"si": np.zeros((n, int(self.spec.si)), np.int32),
+              "sf": np.zeros((n, max(int(self.spec.sf), 1)), np.float32),
+              "ep_ret": np.zeros(n, np.float32), "ep_len": np.zeros(n, np.int32),
+              "ret_ret": np.zeros(n, np.float32), "ret_len": np.zeros(n, np.int32),
+              "timestep": np.zeros(n, np.int32)}
+        obs = np.zeros((n, *self.obs_shape), np.float32)
+        lib().pqn_oracle_env_reset(self.env_id, n, C.c_uint64(key), _p(st["si"]), _p(st["sf"]), _p(obs))
+        return obs, st
+
+    def step(self, key: int, st, action, autoreset: bool = True):
+        n = st["si"].shape[0]
+        action = np.ascontiguousarray(action, dtype=np.int32)
+        obs = np.zeros((n, *self.obs_shape), np.float32)
+        reward = np.zeros(n, np.float32)
+        done = np.zeros(n, np.uint8)
+        disc = np.zeros(n, np.float32)
+        lib().pqn_oracle_env_step(self.env_id, n, C.c_uint64(key), _p(st["si"]), _p(st["sf"]), _p(action),
+                                  1 if autoreset else 0, _p(obs), _p(reward), _p(done), _p(disc))
+        lib().pqn_oracle_log_step(n, _p(reward), _p(done), _p(st["ep_ret"]), _p(st["ep_len"]), _p(st["ret_ret"]),
+                                  _p(st["ret_len"]), _p(st["timestep"]))
+        info = {"discount": disc, "returned_episode_returns": st["ret_ret"].copy(),
+                "returned_episode_lengths": st["ret_len"].copy(), "timestep": st["timestep"].copy(),
+                "returned_episode": done.astype(bool)}
+        return obs, st, reward, done.astype(bool), info
+
+    def log_words(self, st) -> np.ndarray:
+        """[n,5] u32 bit patterns of the LogWrapper record (product's export layout)."""
+        out = np.zeros((st["si"].shape[0], 5), np.uint32)
+        out[:, 0] = st["ep_ret"].view(np.uint32)
+        out[:, 1] = st["ep_len"].view(np.uint32)
+        out[:, 2] = st["ret_ret"].view(np.uint32)
+        out[:, 3] = st["ret_len"].view(np.uint32)
+        out[:, 4] = st["timestep"].view(np.uint32)
+        return out
+
+
+def eps_greedy(q, eps, key):
+    q = np.ascontiguousarray(q, np.float32)
+    m, a = q.shape
+    action = np.zeros(m, np.int32)
+    qmax = np.zeros(m, np.float32)
+    lib().pqn_oracle_eps_greedy(_p(q), m, a, C.c_float(eps), C.c_uint64(key), _p(action), _p(qmax))
+    return action, qmax
+
+
+def q_lambda(reward, done, qmax, last_q, gamma, lam, quirk=True):
+    reward = np.ascontiguousarray(reward, np.float32)
+    done = np.ascontiguousarray(done).astype(np.uint8)
+    qmax = np.ascontiguousarray(qmax, np.float32)
+    last_q = np.ascontiguousarray(last_q, np.float32)
+    t, m = reward.shape
+    target = np.zeros((t, m), np.float32)
+    lib().pqn_oracle_q_lambda(_p(reward), _p(done), _p(qmax), _p(last_q), C.c_float(gamma), C.c_float(lam), t, m,
+                              1 if quirk else 0, _p(target))
+    return target
+
+
+def linear_schedule(init, end, steps, count):
+    return float(lib().pqn_oracle_linear_schedule(float(init), float(end), float(steps), float(count)))
+
+
+def radam_clip_step(p, g, m, v, count, lr, max_norm):
+    """In-place on p, m, v (float32 contiguous).  Returns the pre-clip global norm."""
+    g = np.ascontiguousarray(g, np.float32).copy()
+    return float(lib().pqn_oracle_radam_clip_step(_p(p), _p(g), _p(m), _p(v), p.size, int(count), C.c_float(lr),
+                                                  C.c_float(max_norm)))
+
+
+# ---- networks (numpy, float32; flax semantics of SURVEY Appendix A) ----------------------
+LN_EPS = np.float32(1e-6)
+
+
+def cnn_shapes(obs_shape, a):
+    h, w, c = obs_shape
+    return OrderedDict([
+        ("BatchNorm_0/scale", (c,)), ("BatchNorm_0/bias", (c,)),
+        ("CNN_0/Conv_0/kernel", (3, 3, c, 16)), ("CNN_0/Conv_0/bias", (16,)),
+        ("CNN_0/LayerNorm_0/scale", (16,)), ("CNN_0/LayerNorm_0/bias", (16,)),
+        ("CNN_0/Dense_0/kernel", ((h - 2) * (w - 2) * 16, 128)), ("CNN_0/Dense_0/bias", (128,)),
+        ("CNN_0/LayerNorm_1/scale", (128,)), ("CNN_0/LayerNorm_1/bias", (128,)),
+        ("Dense_0/kernel", (128, a)), ("Dense_0/bias", (a,)),
+    ])
+
+
+def mlp_shapes(d, a, hidden, layers):
+    s = OrderedDict([("BatchNorm_0/scale", (d,)), ("BatchNorm_0/bias", (d,))])
+    for l in range(layers):
+        s[f"Dense_{l}/kernel"] = (d, hidden)
+        s[f"Dense_{l}/bias"] = (hidden,)
+        s[f"LayerNorm_{l}/scale"] = (hidden,)
+        s[f"LayerNorm_{l}/bias"] = (hidden,)
+        d = hidden
+    s[f"Dense_{layers}/kernel"] = (d, a)
+    s[f"Dense_{layers}/bias"] = (a,)
+    return s
+
+
+def unflatten(theta, shapes):
+    out, off = {}, 0
+    for k, s in shapes.items():
+        n = int(np.prod(s))
+        out[k] = theta[off:off + n].reshape(s)
+        off += n
+    assert off == theta.size
+    return out
+
+
+def _ln_fwd(x, scale, bias):
+    # flax LayerNorm: mean, var = E[x^2]-E[x]^2 (clamped >= 0), eps inside rsqrt (A.3)
+    mu = x.mean(-1, keepdims=True, dtype=np.float32)
+    var = np.maximum((x * x).mean(-1, keepdims=True, dtype=np.float32) - mu * mu, np.float32(0))
+    rstd = (np.float32(1) / np.sqrt(var + LN_EPS)).astype(np.float32)
+    xhat = (x - mu) * rstd
+    return xhat * scale + bias, (xhat, rstd)
+
+
+def _ln_bwd(dy, scale, cache):
+    xhat, rstd = cache
+    dscale = (dy * xhat).reshape(-1, xhat.shape[-1]).sum(0)
+    dbias = dy.reshape(-1, xhat.shape[-1]).sum(0)
+    dxh = dy * scale
+    dx = rstd * (dxh - dxh.mean(-1, keepdims=True) - xhat * (dxh * xhat).mean(-1, keepdims=True))
+    return dx.astype(np.float32), dscale.astype(np.float32), dbias.astype(np.float32)
+
+
+def _patches(x):
+    # NHWC 3x3 VALID windows -> [B, H-2, W-2, 3*3*C] in (ky,kx,c) order
+    b, h, w, c = x.shape
+    s = x.strides
+    v = np.lib.stride_tricks.as_strided(x, (b, h - 2, w - 2, 3, 3, c), (s[0], s[1], s[2], s[1], s[2], s[3]))
+    return v.reshape(b, h - 2, w - 2, 9 * c)
+
+
+def net_forward(kind, p, x, use_ln=True, layers=2, want_cache=False):
+    """QNetwork.apply(train=False/True are identical for layer_norm).  x float32."""
+    cache = {}
+    if kind == "cnn":
+        b = x.shape[0]
+        xs = (x / np.float32(255.0)).astype(np.float32)                   # pqn_minatar.py:66
+        pt = _patches(xs)                                                  # [B,8,8,9C]
+        y = pt @ p["CNN_0/Conv_0/kernel"].reshape(-1, 16) + p["CNN_0/Conv_0/bias"]
+        if use_ln:
+            y, c0 = _ln_fwd(y, p["CNN_0/LayerNorm_0/scale"], p["CNN_0/LayerNorm_0/bias"])
+        h1 = np.maximum(y, 0).reshape(b, -1)                               # (h,w,c) flatten, :47
+        z = h1 @ p["CNN_0/Dense_0/kernel"] + p["CNN_0/Dense_0/bias"]
+        if use_ln:
+            z, c1 = _ln_fwd(z, p["CNN_0/LayerNorm_1/scale"], p["CNN_0/LayerNorm_1/bias"])
+        h2 = np.maximum(z, 0)
+        q = h2 @ p["Dense_0/kernel"] + p["Dense_0/bias"]
+        if want_cache:
+            cache = dict(pt=pt, c0=c0 if use_ln else None, h1=h1, c1=c1 if use_ln else None, h2=h2)
+        return (q.astype(np.float32), cache) if want_cache else q.astype(np.float32)
+    hs, cs = [x.astype(np.float32)], []
+    y = hs[0]
+    for l in range(layers):
+        y = y @ p[f"Dense_{l}/kernel"] + p[f"Dense_{l}/bias"]
+        if use_ln:
+            y, c = _ln_fwd(y, p[f"LayerNorm_{l}/scale"], p[f"LayerNorm_{l}/bias"])
+            cs.append(c)
+        y = np.maximum(y, 0)
+        hs.append(y)
+    q = y @ p[f"Dense_{layers}/kernel"] + p[f"Dense_{layers}/bias"]
+    if want_cache:
+        return q.astype(np.float32), dict(hs=hs, cs=cs)
+    return q.astype(np.float32)
+
+
+def net_loss_grad(kind, p, shapes, x, action, target, use_ln=True, layers=2):
+    """loss = 0.5*mean((q[a]-target)^2) and d loss / d theta (flat), pqn_minatar.py:271-291."""
+    q, cache = net_forward(kind, p, x, use_ln, layers, want_cache=True)
+    b = x.shape[0]
+    chosen = q[np.arange(b), action]
+    diff = (chosen - target).astype(np.float32)
+    loss = np.float32(0.5) * np.mean(diff * diff, dtype=np.float32)
+    dq = np.zeros_like(q)
+    dq[np.arange(b), action] = diff / np.float32(b)
+    g = {k: np.zeros(s, np.float32) for k, s in shapes.items()}
+    if kind == "cnn":
+        g["Dense_0/kernel"] = cache["h2"].T @ dq
+        g["Dense_0/bias"] = dq.sum(0)
+        dz = (dq @ p["Dense_0/kernel"].T) * (cache["h2"] > 0)
+        if use_ln:
+            dz, g["CNN_0/LayerNorm_1/scale"], g["CNN_0/LayerNorm_1/bias"] = _ln_bwd(dz, p["CNN_0/LayerNorm_1/scale"], cache["c1"])
+        g["CNN_0/Dense_0/kernel"] = cache["h1"].T @ dz
+        g["CNN_0/Dense_0/bias"] = dz.sum(0)
+        dh1 = (dz @ p["CNN_0/Dense_0/kernel"].T) * (cache["h1"] > 0)
+        dy = dh1.reshape(b, x.shape[1] - 2, x.shape[2] - 2, 16)
+        if use_ln:
+            dy, g["CNN_0/LayerNorm_0/scale"], g["CNN_0/LayerNorm_0/bias"] = _ln_bwd(dy, p["CNN_0/LayerNorm_0/scale"], cache["c0"])
+        pt = cache["pt"].reshape(-1, cache["pt"].shape[-1])
+        g["CNN_0/Conv_0/kernel"] = (pt.T @ dy.reshape(-1, 16)).reshape(shapes["CNN_0/Conv_0/kernel"])
+        g["CNN_0/Conv_0/bias"] = dy.reshape(-1, 16).sum(0)
+    else:
+        hs, cs = cache["hs"], cache["cs"]
+        g[f"Dense_{layers}/kernel"] = hs[-1].T @ dq
+        g[f"Dense_{layers}/bias"] = dq.sum(0)
+        d = dq @ p[f"Dense_{layers}/kernel"].T
+        for l in reversed(range(layers)):
+            d = d * (hs[l + 1] > 0)
+            if use_ln:
+                d, g[f"LayerNorm_{l}/scale"], g[f"LayerNorm_{l}/bias"] = _ln_bwd(d, p[f"LayerNorm_{l}/scale"], cs[l])
+            g[f"Dense_{l}/kernel"] = hs[l].T @ d
+            g[f"Dense_{l}/bias"] = d.sum(0)
+            d = d @ p[f"Dense_{l}/kernel"].T
+    flat = np.concatenate([g[k].reshape(-1).astype(np.float32) for k in shapes])
+    return loss, chosen, flat
+
+
+# ---- whole loop -----------------------------------------------------------------------------
+INFO_KEYS = ("discount", "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode")
+
+
+def make_train(config: Dict[str, Any]):
+    """numpy/C restatement of make_train (pqn_minatar.py:89-431) with the SAME key
+    schedule as purejaxql_amd.pqn (documented there)."""
+    config["NUM_UPDATES"] = config["TOTAL_TIMESTEPS"] // config["NUM_STEPS"] // config["NUM_ENVS"]
+    config["NUM_UPDATES_DECAY"] = config["TOTAL_TIMESTEPS_DECAY"] // config["NUM_STEPS"] // config["NUM_ENVS"]
+    assert (config["NUM_STEPS"] * config["NUM_ENVS"]) % config["NUM_MINIBATCHES"] == 0
+    env = OracleEnv(config["ENV_NAME"])
+    kind = "cnn" if len(env.obs_shape) == 3 else "mlp"
+    N, T = int(config["NUM_ENVS"]), int(config["NUM_STEPS"])
+    NU, MB, EP = int(config["NUM_UPDATES"]), int(config["NUM_MINIBATCHES"]), int(config["NUM_EPOCHS"])
+    B = N * T // MB
+    A = env.num_actions
+    layers = int(config.get("NUM_LAYERS", 2))
+    use_ln = config["NORM_TYPE"] == "layer_norm"
+    shapes = cnn_shapes(env.obs_shape, A) if kind == "cnn" else mlp_shapes(env.obs_shape[0], A, int(config.get("HIDDEN_SIZE", 128)), layers)
+    test_on = bool(config.get("TEST_DURING_TRAINING", False))
+    test_steps = env.max_steps if kind == "cnn" else int(config.get("TEST_NUM_STEPS", env.max_steps))
+    gamma, lam, rs = float(config["GAMMA"]), float(config["LAMBDA"]), float(config.get("REW_SCALE", 1))
+
+    def train(rng: int, init_theta: np.ndarray, max_updates: int = None):
+        K = int(rng) & 0xFFFFFFFFFFFFFFFF
+        K_init, K_reset, K_test, K_roll, K_shuf = (fold_in(K, i) for i in range(5))
+        theta = np.ascontiguousarray(init_theta, np.float32).copy()
+        m, v = np.zeros_like(theta), np.zeros_like(theta)
+        p = unflatten(theta, shapes)
+        lr_steps = config["NUM_UPDATES_DECAY"] * MB * EP
+        n_updates = grad_steps = timesteps = 0
+        runs = [0]
+
+        def test_metrics_fn():
+            if not test_on:
+                return None
+            k = fold_in(K_test, runs[0])
+            runs[0] += 1
+            nt = int(config["TEST_NUM_ENVS"])
+            obs, st = env.reset(fold_in(k, 0), nt)
+            sums = {kk: 0.0 for kk in INFO_KEYS}
+            cnt = 0.0
+            for t in range(test_steps):
+                sk = fold_in(k, 1 + t)
+                a, _ = eps_greedy(net_forward(kind, p, obs, use_ln, layers), float(config["EPS_TEST"]), sk)
+                obs, st, _r, done, info = env.step(sk, st, a)
+                cnt += float(done.sum())
+                for kk in INFO_KEYS:
+                    sums[kk] += float((info[kk].astype(np.float64) * done).sum())
+            return {kk: np.float32(sums[kk] / cnt) if cnt > 0 else np.float32(np.nan) for kk in INFO_KEYS}
+
+        tm = test_metrics_fn()
+        obs, st = env.reset(K_reset, N)
+        nu = NU if max_updates is None else min(NU, max_updates)
+        metrics = []
+        period = int(NU * config["TEST_INTERVAL"]) if test_on else 0
+        for u in range(nu):
+            eps = linear_schedule(config["EPS_START"], config["EPS_FINISH"], config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"], n_updates)
+            O = np.zeros((T + 1, N, *env.obs_shape), np.float32)
+            O[0] = obs
+            Aa = np.zeros((T, N), np.int32)
+            R = np.zeros((T, N), np.float32)
+            D = np.zeros((T, N), bool)
+            QM = np.zeros((T, N), np.float32)
+            infos = {kk: [] for kk in INFO_KEYS}
+            for t in range(T):
+                sk = fold_in(K_roll, u * T + t)
+                q = net_forward(kind, p, O[t], use_ln, layers)
+                Aa[t], QM[t] = eps_greedy(q, np.float32(eps), sk)
+                O[t + 1], st, r, D[t], info = env.step(sk, st, Aa[t])
+                R[t] = np.float32(rs) * r if rs != 1.0 else r
+                for kk in INFO_KEYS:
+                    infos[kk].append(info[kk])
+            timesteps += T * N
+            last_q = net_forward(kind, p, O[T], use_ln, layers).max(-1)
+            tgt = q_lambda(R, D, QM, last_q, gamma, lam, quirk=True)
+            of, af, tf = O[:T].reshape(T * N, *env.obs_shape), Aa.reshape(-1), tgt.reshape(-1)
+            losses, qvs = [], []
+            for ep in range(EP):
+                perm = permutation(fold_in(K_shuf, u * EP + ep), T * N)
+                for mb in range(MB):
+                    idx = perm[mb * B:(mb + 1) * B]
+                    loss, chosen, g = net_loss_grad(kind, p, shapes, of[idx], af[idx], tf[idx], use_ln, layers)
+                    lr = linear_schedule(config["LR"], 1e-20, lr_steps, grad_steps) if config.get("LR_LINEAR_DECAY", False) else config["LR"]
+                    radam_clip_step(theta, g, m, v, grad_steps, np.float32(lr), np.float32(config["MAX_GRAD_NORM"]))
+                    grad_steps += 1
+                    losses.append(loss)
+                    qvs.append(chosen.mean(dtype=np.float32))
+            obs = O[T]
+            n_updates += 1
+            mm = {"env_step": timesteps, "update_steps": n_updates, "grad_steps": grad_steps,
+                  "td_loss": float(np.mean(losses)), "qvals": float(np.mean(qvs))}
+            if kind == "cnn":
+                mm["env_frame"] = timesteps * env.obs_shape[-1]
+            for kk in INFO_KEYS:
+                mm[kk] = float(np.mean(np.stack(infos[kk]).astype(np.float32)))
+            if test_on:
+                if period > 0 and n_updates % period == 0:
+                    tm = test_metrics_fn()
+                mm.update({f"test/{k}": float(v2) for k, v2 in tm.items()})
+            metrics.append(mm)
+        return {"theta": theta, "metrics": metrics, "env_state": st, "last_obs": obs}
+
+    train.shapes = shapes
+    train.kind = kind
+    return train

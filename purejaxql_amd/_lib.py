@@ -1,0 +1,103 @@
+"""ctypes binding of libpqn_hip.so (the C ABI declared in include/pqn_hotpath.h).
+
+There is NO fallback: if the HIP library is missing the import of any compute
+entry point raises.  The oracle under oracle/ is test infrastructure and is
+never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpqn_hip.so")
+
+c_void_p, c_int, c_int32, c_int64, c_uint32, c_uint64, c_float = (
+    C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float)
+
+
+class EnvSpec(C.Structure):
+    """pqn_env_spec_t"""
+    _fields_ = [("obs_dim", c_int32 * 3), ("obs_size", c_int32), ("num_actions", c_int32),
+                ("max_steps", c_int32), ("state_words", c_int32), ("obs_words", c_int32),
+                ("canon_si", c_int32), ("canon_sf", c_int32)]
+
+
+class StepOut(C.Structure):
+    """pqn_step_out_t"""
+    _fields_ = [("obs", c_void_p), ("obs_bits", c_void_p), ("reward", c_void_p), ("done", c_void_p),
+                ("discount", c_void_p), ("returned_episode_returns", c_void_p),
+                ("returned_episode_lengths", c_void_p), ("timestep", c_void_p)]
+
+
+# name -> (restype, argtypes).  Every symbol include/pqn_hotpath.h declares.
+SIGNATURES = {
+    "pqn_last_error": (C.c_char_p, []),
+    "pqn_version": (c_int, []),
+    "pqn_threefry2x32": (None, [C.POINTER(c_uint32), C.POINTER(c_uint32), C.POINTER(c_uint32)]),
+    "pqn_fold_in": (c_uint64, [c_uint64, c_uint32]),
+    "pqn_env_id": (c_int, [C.c_char_p]),
+    "pqn_env_spec": (c_int, [c_int, C.POINTER(EnvSpec)]),
+    "pqn_env_reset": (c_int, [c_int, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pqn_env_step": (c_int, [c_int, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, C.POINTER(StepOut), c_void_p]),
+    "pqn_env_export_state": (c_int, [c_int, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pqn_env_import_state": (c_int, [c_int, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pqn_eps_greedy": (c_int, [c_void_p, c_int32, c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "pqn_q_lambda": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int32, c_int32, c_int32,
+                             c_void_p, c_void_p]),
+    "pqn_shuffle_keys": (c_int, [c_uint64, c_int32, c_void_p, c_void_p]),
+    "pqn_radam_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float,
+                                    c_float, c_float, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpqn_hip.so or raise loudly.  No CPU fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C purejaxql_amd/csrc`).  purejaxql_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().pqn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what or 'libpqn_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream, as an integer for void*."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def fold_in(key: int, data: int) -> int:
+    return int(load().pqn_fold_in(c_uint64(key & 0xFFFFFFFFFFFFFFFF), c_uint32(data & 0xFFFFFFFF)))
+
+
+def prng_key(seed: int) -> int:
+    """PRNGKey(seed): key words (seed >> 32, seed & 0xffffffff) packed in a uint64."""
+    return int(seed) & 0xFFFFFFFFFFFFFFFF

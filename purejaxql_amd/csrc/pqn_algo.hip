@@ -1,0 +1,230 @@
+// pqn_algo.hip -- the non-network pieces of make_train as gfx950 kernels:
+// eps-greedy action selection, Q(lambda) targets, shuffle keys, and the fused
+// clip_by_global_norm + RAdam step.  Reference lines are cited per entry point
+// in include/pqn_hotpath.h.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "pqn_common.h"
+
+// ---------------------------------------------------------------------------
+// error channel + host PRNG helpers
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void pqn_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int pqn_check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    pqn_set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return PQN_E_HIP;
+  }
+  return PQN_OK;
+}
+
+extern "C" const char *pqn_last_error(void) { return g_err; }
+extern "C" int pqn_version(void) { return 1; }
+
+extern "C" void pqn_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) {
+  pqn_tf2x32(key[0], key[1], ctr[0], ctr[1], out[0], out[1]);
+}
+extern "C" uint64_t pqn_fold_in(uint64_t key, uint32_t data) { return pqn_fold(key, data); }
+
+// ---------------------------------------------------------------------------
+// eps-greedy: one lane per row of q[m, a].  First-max tie rule (jnp.argmax).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eps_greedy_kernel(const float *__restrict__ q, int m, int a, float eps,
+                                                         uint64_t key, int32_t *__restrict__ action,
+                                                         float *__restrict__ qmax) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const float *qi = q + (size_t)i * a;
+  int best = 0;
+  float bv = qi[0];
+  for (int j = 1; j < a; ++j) {
+    const float v = qi[j];
+    if (v > bv) { bv = v; best = j; }
+  }
+  uint32_t o0, o1;
+  pqn_bits(key, (uint32_t)i, PQN_STREAM_ACT, o0, o1);
+  const float u = pqn_uniform(o0);
+  const int rnd = (int)pqn_randint(o1, (uint32_t)a);
+  action[i] = (u < eps) ? rnd : best;
+  if (qmax) qmax[i] = bv;
+}
+
+extern "C" int pqn_eps_greedy(const float *q, int32_t m, int32_t a, float eps, uint64_t key, int32_t *action,
+                              float *qmax, void *stream) {
+  PQN_REQUIRE(q && action, "pqn_eps_greedy: NULL argument");
+  PQN_REQUIRE(m > 0 && a > 0, "pqn_eps_greedy: m and a must be > 0 (m=%d a=%d)", m, a);
+  hipLaunchKernelGGL(eps_greedy_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, m, a, eps, key,
+                     action, qmax);
+  return pqn_check_launch("pqn_eps_greedy");
+}
+
+// ---------------------------------------------------------------------------
+// Q(lambda): one lane per env, serial over T in reverse; [T, m] time-major so
+// every load/store is a coalesced dword across the wave.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void q_lambda_kernel(const float *__restrict__ reward,
+                                                       const uint8_t *__restrict__ done,
+                                                       const float *__restrict__ qmax,
+                                                       const float *__restrict__ last_q, float gamma, float lambda,
+                                                       int t_len, int m, int quirk, float *__restrict__ target) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= m) return;
+  size_t i = (size_t)(t_len - 1) * m + e;
+  const float lq = last_q[e] * (float)(1 - (int)done[i]);
+  float lr = reward[i] + gamma * lq;
+  float nq = quirk ? lq : qmax[i];
+  target[i] = lr;
+  for (int t = t_len - 2; t >= 0; --t) {
+    i -= m;
+    const float d = (float)done[i];
+    const float r = reward[i];
+    const float tb = r + gamma * (1.0f - d) * nq;
+    const float delta = lr - nq;
+    lr = tb + gamma * lambda * delta;
+    lr = (1.0f - d) * lr + d * r;
+    nq = qmax[i];
+    target[i] = lr;
+  }
+}
+
+extern "C" int pqn_q_lambda(const float *reward, const uint8_t *done, const float *qmax, const float *last_q,
+                            float gamma, float lambda, int32_t t_len, int32_t m, int32_t quirk, float *target,
+                            void *stream) {
+  PQN_REQUIRE(reward && done && qmax && last_q && target, "pqn_q_lambda: NULL argument");
+  PQN_REQUIRE(t_len > 0 && m > 0, "pqn_q_lambda: T and m must be > 0 (T=%d m=%d)", t_len, m);
+  hipLaunchKernelGGL(q_lambda_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, reward, done, qmax,
+                     last_q, gamma, lambda, t_len, m, quirk, target);
+  return pqn_check_launch("pqn_q_lambda");
+}
+
+// ---------------------------------------------------------------------------
+// shuffle keys: key_i = (bits_i >> 1) << 32 | i  (unique -> argsort is a
+// well-defined permutation).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shuffle_keys_kernel(uint64_t key, int n, int64_t *__restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t o0, o1;
+  pqn_bits(key, (uint32_t)i, 0u, o0, o1);
+  keys[i] = (int64_t)(((uint64_t)(o0 >> 1) << 32) | (uint32_t)i);
+}
+
+extern "C" int pqn_shuffle_keys(uint64_t key, int32_t n, int64_t *keys, void *stream) {
+  PQN_REQUIRE(keys && n > 0, "pqn_shuffle_keys: NULL keys or n <= 0");
+  hipLaunchKernelGGL(shuffle_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, key, n, keys);
+  return pqn_check_launch("pqn_shuffle_keys");
+}
+
+// ---------------------------------------------------------------------------
+// clip_by_global_norm + RAdam on a flat buffer.  Pass 1: per-block sum of
+// squares -> scratch[block]; block 0 snapshots *count into scratch[1023].
+// Pass 2: every block folds the partials (<=1022), lane 0 derives the step
+// scalars in f64, all lanes apply the update; block 0 bumps *count.
+// ---------------------------------------------------------------------------
+#define PQN_RADAM_MAXB 1022
+
+__global__ __launch_bounds__(256) void radam_norm_kernel(const float *__restrict__ g, int64_t n,
+                                                         const int32_t *__restrict__ count,
+                                                         float *__restrict__ scratch) {
+  __shared__ float s_part[4];
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = g[i];
+    acc = fmaf(v, v, acc);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    scratch[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (blockIdx.x == 0) reinterpret_cast<int32_t *>(scratch)[1023] = *count;
+  }
+}
+
+__global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                          float *__restrict__ m, float *__restrict__ v, int64_t n,
+                                                          int32_t *__restrict__ count, float lr_init, float lr_end,
+                                                          float lr_steps, float max_norm, int nparts,
+                                                          const float *__restrict__ scratch,
+                                                          float *__restrict__ gnorm_out) {
+  __shared__ float s_part[4];
+  __shared__ float s_sc[8];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += scratch[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gnorm = sqrtf((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+    const int32_t c = reinterpret_cast<const int32_t *>(scratch)[1023];
+    const double b1 = 0.9, b2 = 0.999, thr = 5.0;
+    const double t = (double)c + 1.0;
+    const double b1t = pow(b1, t), b2t = pow(b2, t);
+    const double ro_inf = 2.0 / (1.0 - b2) - 1.0;
+    const double ro = ro_inf - 2.0 * t * b2t / (1.0 - b2t);
+    const int rect = ro >= thr;
+    const float r = rect ? (float)sqrt((ro - 4.0) * (ro - 2.0) * ro_inf / ((ro_inf - 4.0) * (ro_inf - 2.0) * ro)) : 0.0f;
+    float lr = lr_init;
+    if (lr_steps > 0.0f) {  // optax.linear_schedule evaluated at the pre-increment count
+      double cc = (double)c;
+      if (cc > (double)lr_steps) cc = (double)lr_steps;
+      lr = (float)(((double)lr_init - (double)lr_end) * (1.0 - cc / (double)lr_steps) + (double)lr_end);
+    }
+    s_sc[0] = gnorm;
+    s_sc[1] = (gnorm < max_norm) ? 0.0f : 1.0f;
+    s_sc[2] = (float)(1.0 - b1t);
+    s_sc[3] = (float)(1.0 - b2t);
+    s_sc[4] = rect ? 1.0f : 0.0f;
+    s_sc[5] = r;
+    s_sc[6] = lr;
+    if (blockIdx.x == 0) {
+      *count = c + 1;
+      if (gnorm_out) *gnorm_out = gnorm;
+    }
+  }
+  __syncthreads();
+  const float gnorm = s_sc[0];
+  const bool clip = s_sc[1] != 0.0f;
+  const float bc1 = s_sc[2], bc2 = s_sc[3];
+  const bool rect = s_sc[4] != 0.0f;
+  const float r = s_sc[5], lr = s_sc[6];
+  const float c1 = (float)(1.0 - 0.9), d1 = (float)0.9, c2 = (float)(1.0 - 0.999), d2 = (float)0.999;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i];
+    if (clip) gi = (gi / gnorm) * max_norm;
+    const float mi = c1 * gi + d1 * m[i];
+    const float vi = c2 * (gi * gi) + d2 * v[i];
+    m[i] = mi;
+    v[i] = vi;
+    const float mh = mi / bc1;
+    const float vh = vi / bc2;
+    const float u = rect ? r * mh / (sqrtf(vh) + 1e-8f) : mh;
+    p[i] = p[i] - lr * u;
+  }
+}
+
+extern "C" int pqn_radam_clip_step(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count,
+                                   float lr_init, float lr_end, float lr_steps, float max_norm, float *scratch,
+                                   float *gnorm_out, void *stream) {
+  PQN_REQUIRE(p && g && m && v && count && scratch, "pqn_radam_clip_step: NULL argument");
+  PQN_REQUIRE(n > 0, "pqn_radam_clip_step: n must be > 0");
+  int64_t blocks = (n + 1023) / 1024;  // 4 elements per lane
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(radam_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, count, scratch);
+  hipLaunchKernelGGL(radam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, count, lr_init,
+                     lr_end, lr_steps, max_norm, (int)blocks, scratch, gnorm_out);
+  return pqn_check_launch("pqn_radam_clip_step");
+}

@@ -1,0 +1,71 @@
+// pqn_common.h -- shared device/host helpers for libpqn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pqn_hotpath.h"
+
+#define PQN_HD __host__ __device__ __forceinline__
+#define PQN_D __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// threefry2x32-20.  Counter-based: no RNG state in HBM, every lane evaluates
+// its own block function from (key, (index, stream)).
+// ---------------------------------------------------------------------------
+PQN_HD uint32_t pqn_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+PQN_HD void pqn_tf2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t &o0, uint32_t &o1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  uint32_t x0 = c0 + k0, x1 = c1 + k1;
+#define PQN_R(r) x0 += x1; x1 = pqn_rotl(x1, r); x1 ^= x0;
+  PQN_R(13) PQN_R(15) PQN_R(26) PQN_R(6)
+  x0 += k1; x1 += k2 + 1u;
+  PQN_R(17) PQN_R(29) PQN_R(16) PQN_R(24)
+  x0 += k2; x1 += k0 + 2u;
+  PQN_R(13) PQN_R(15) PQN_R(26) PQN_R(6)
+  x0 += k0; x1 += k1 + 3u;
+  PQN_R(17) PQN_R(29) PQN_R(16) PQN_R(24)
+  x0 += k1; x1 += k2 + 4u;
+  PQN_R(13) PQN_R(15) PQN_R(26) PQN_R(6)
+  x0 += k2; x1 += k0 + 5u;
+#undef PQN_R
+  o0 = x0;
+  o1 = x1;
+}
+
+PQN_HD void pqn_bits(uint64_t key, uint32_t index, uint32_t stream, uint32_t &o0, uint32_t &o1) {
+  pqn_tf2x32((uint32_t)(key >> 32), (uint32_t)key, index, stream, o0, o1);
+}
+
+PQN_HD uint64_t pqn_fold(uint64_t key, uint32_t data) {
+  uint32_t o0, o1;
+  pqn_tf2x32((uint32_t)(key >> 32), (uint32_t)key, 0u, data, o0, o1);
+  return ((uint64_t)o0 << 32) | o1;
+}
+
+// 23 mantissa bits -> [0,1)
+PQN_HD float pqn_uniform(uint32_t bits) {
+  union { uint32_t u; float f; } v;
+  v.u = (bits >> 9) | 0x3f800000u;
+  return v.f - 1.0f;
+}
+
+PQN_HD uint32_t pqn_randint(uint32_t bits, uint32_t n) { return (uint32_t)(((uint64_t)bits * (uint64_t)n) >> 32); }
+
+// RNG stream ids (second counter word)
+enum { PQN_STREAM_ACT = 0, PQN_STREAM_RESET = 1, PQN_STREAM_RESET2 = 2, PQN_STREAM_ENV = 3 };
+
+// ---------------------------------------------------------------------------
+// error channel
+// ---------------------------------------------------------------------------
+void pqn_set_error(const char *fmt, ...);
+int pqn_check_launch(const char *what);
+
+#define PQN_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      pqn_set_error(__VA_ARGS__);     \
+      return PQN_E_INVALID;           \
+    }                                 \
+  } while (0)

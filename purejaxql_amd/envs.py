@@ -1,0 +1,217 @@
+"""gymnax-shaped environment surface over the HIP env kernels.
+
+Mirrors what make_train consumes from gymnax (reference
+purejaxql/pqn_minatar.py:103-112,151,157,333; purejaxql/pqn_gymnax.py:92-104):
+
+    env, env_params = make("Breakout-MinAtar")
+    env = LogWrapper(env)                       # gymnax.wrappers.purerl.LogWrapper
+    obs, state = env.reset(key, env_params, num_envs=N)
+    obs, state, reward, done, info = env.step(key, state, action, env_params)
+    env.action_space(env_params).n ; env.observation_space(env_params).shape
+    env_params.max_steps_in_episode
+
+Differences from gymnax, by design (MI355X-first):
+  * calls are BATCHED (leading [N]) instead of vmapped per env; `key` is a
+    uint64 threefry key, element e draws threefry(key, (e, stream));
+  * `state` is an EnvState holding one [W, N] int32 tensor (SoA words in HBM);
+    step() is functional (returns a new EnvState) unless inplace=True;
+  * tensors live on the GPU; every call only enqueues kernels on torch's
+    current stream (graph-capturable), nothing synchronises.
+The LogWrapper record is fused into the step kernel (see csrc/pqn_env.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class EnvParams:
+    max_steps_in_episode: int
+
+
+@dataclass(frozen=True)
+class Discrete:
+    n: int
+
+
+@dataclass(frozen=True)
+class Box:
+    shape: Tuple[int, ...]
+
+
+@dataclass
+class EnvState:
+    """Opaque batched env state: words[w, e] (int32 bit patterns), see pqn_env_spec()."""
+    words: torch.Tensor
+
+    @property
+    def num_envs(self) -> int:
+        return self.words.shape[1]
+
+
+class Environment:
+    """Batched functional environment backed by pqn_env_reset / pqn_env_step."""
+
+    def __init__(self, name: str, device: Optional[torch.device] = None):
+        lib = _lib.load()
+        env_id = lib.pqn_env_id(name.encode())
+        _lib.check(min(env_id, 0), f"make({name!r})")
+        self.name = name
+        self.env_id = env_id
+        spec = _lib.EnvSpec()
+        _lib.check(lib.pqn_env_spec(env_id, C.byref(spec)), "pqn_env_spec")
+        self.spec = spec
+        d = tuple(int(x) for x in spec.obs_dim)
+        self.obs_shape = d if d[1] > 0 else (d[0],)
+        self.obs_size = int(spec.obs_size)
+        self.obs_words = int(spec.obs_words)
+        self.state_words = int(spec.state_words)
+        self.num_actions = int(spec.num_actions)
+        self.default_params = EnvParams(max_steps_in_episode=int(spec.max_steps))
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+
+    # -- spaces ----------------------------------------------------------------
+    def action_space(self, params=None) -> Discrete:
+        return Discrete(self.num_actions)
+
+    def observation_space(self, params=None) -> Box:
+        return Box(self.obs_shape)
+
+    # -- reset / step ------------------------------------------------------------
+    def _alloc_obs(self, n, want_obs, want_bits):
+        obs = torch.empty((n, *self.obs_shape), dtype=torch.float32, device=self.device) if want_obs else None
+        bits = None
+        if want_bits:
+            if self.obs_words == 0:
+                raise ValueError(f"{self.name} has no packed observation")
+            bits = torch.empty((n, self.obs_words), dtype=torch.int32, device=self.device)
+        return obs, bits
+
+    def reset(self, key: int, params: Optional[EnvParams] = None, num_envs: int = 1, *, want_obs: bool = True,
+              want_bits: bool = False):
+        lib = _lib.load()
+        n = int(num_envs)
+        words = torch.empty((self.state_words, n), dtype=torch.int32, device=self.device)
+        obs, bits = self._alloc_obs(n, want_obs, want_bits)
+        _lib.check(lib.pqn_env_reset(self.env_id, n, key, _lib.ptr(words), _lib.ptr(obs), _lib.ptr(bits),
+                                     _lib.stream_ptr()), "pqn_env_reset")
+        state = EnvState(words)
+        if want_bits:
+            return (obs, bits), state
+        return obs, state
+
+    def step(self, key: int, state: EnvState, action: torch.Tensor, params: Optional[EnvParams] = None, *,
+             want_obs: bool = True, want_bits: bool = False, inplace: bool = False, log_info: bool = False):
+        lib = _lib.load()
+        n = state.num_envs
+        if action.dtype != torch.int32:
+            action = action.to(torch.int32)
+        if action.numel() != n or not action.is_contiguous():
+            raise ValueError(f"action must be a contiguous [{n}] tensor")
+        dev = self.device
+        new_words = state.words if inplace else torch.empty_like(state.words)
+        obs, bits = self._alloc_obs(n, want_obs, want_bits)
+        reward = torch.empty(n, dtype=torch.float32, device=dev)
+        done = torch.empty(n, dtype=torch.uint8, device=dev)
+        discount = torch.empty(n, dtype=torch.float32, device=dev)
+        out = _lib.StepOut(obs=_lib.ptr(obs), obs_bits=_lib.ptr(bits), reward=_lib.ptr(reward), done=_lib.ptr(done),
+                           discount=_lib.ptr(discount))
+        info = {"discount": discount}
+        if log_info:
+            rer = torch.empty(n, dtype=torch.float32, device=dev)
+            rel = torch.empty(n, dtype=torch.int32, device=dev)
+            ts = torch.empty(n, dtype=torch.int32, device=dev)
+            out.returned_episode_returns = _lib.ptr(rer)
+            out.returned_episode_lengths = _lib.ptr(rel)
+            out.timestep = _lib.ptr(ts)
+        _lib.check(lib.pqn_env_step(self.env_id, n, key, _lib.ptr(state.words), _lib.ptr(new_words),
+                                    _lib.ptr(action), C.byref(out), _lib.stream_ptr()), "pqn_env_step")
+        done_b = done.view(torch.bool)
+        if log_info:
+            info["returned_episode_returns"] = rer
+            info["returned_episode_lengths"] = rel
+            info["timestep"] = ts
+            info["returned_episode"] = done_b
+        new_state = EnvState(new_words)
+        if want_bits:
+            return (obs, bits), new_state, reward, done_b, info
+        return obs, new_state, reward, done_b, info
+
+    # -- canonical state (tests / checkpoints) -----------------------------------
+    def export_state(self, state: EnvState):
+        lib = _lib.load()
+        n = state.num_envs
+        si = torch.empty((n, int(self.spec.canon_si)), dtype=torch.int32, device=self.device)
+        sf = torch.empty((n, max(int(self.spec.canon_sf), 1)), dtype=torch.float32, device=self.device)
+        log = torch.empty((n, 5), dtype=torch.int32, device=self.device)
+        _lib.check(lib.pqn_env_export_state(self.env_id, n, _lib.ptr(state.words), _lib.ptr(si), _lib.ptr(sf),
+                                            _lib.ptr(log), _lib.stream_ptr()), "pqn_env_export_state")
+        return si, sf[:, :int(self.spec.canon_sf)], log
+
+    def import_state(self, si: torch.Tensor, sf: Optional[torch.Tensor] = None, log: Optional[torch.Tensor] = None):
+        lib = _lib.load()
+        n = si.shape[0]
+        si = si.to(self.device, torch.int32).contiguous()
+        sf = sf.to(self.device, torch.float32).contiguous() if sf is not None and sf.numel() else None
+        log = log.to(self.device, torch.int32).contiguous() if log is not None else None
+        words = torch.empty((self.state_words, n), dtype=torch.int32, device=self.device)
+        _lib.check(lib.pqn_env_import_state(self.env_id, n, _lib.ptr(si), _lib.ptr(sf), _lib.ptr(log),
+                                            _lib.ptr(words), _lib.stream_ptr()), "pqn_env_import_state")
+        return EnvState(words)
+
+
+class GymnaxWrapper:
+    """Base wrapper: proxies attribute access (utils/craftax_wrappers.py:10-18)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def __getattr__(self, name):
+        return getattr(self._env, name)
+
+
+class LogWrapper(GymnaxWrapper):
+    """Episode return/length logging (utils/craftax_wrappers.py:161-200).  The
+    record itself is maintained inside the step kernel; this wrapper turns on
+    the info keys returned_episode_returns/_lengths, timestep, returned_episode."""
+
+    def __init__(self, env):
+        super().__init__(env)
+
+    def reset(self, key, params=None, num_envs=1, **kw):
+        return self._env.reset(key, params, num_envs, **kw)
+
+    def step(self, key, state, action, params=None, **kw):
+        return self._env.step(key, state, action, params, log_info=True, **kw)
+
+
+class FlattenObservationWrapper(GymnaxWrapper):
+    """obs.reshape(-1) per env (gymnax purerl wrapper; in-tree twin
+    utils/brax_wrappers.py:40-75), applied at pqn_gymnax.py:93."""
+
+    def observation_space(self, params=None) -> Box:
+        shape = self._env.observation_space(params).shape
+        size = 1
+        for s in shape:
+            size *= s
+        return Box((size,))
+
+    def reset(self, key, params=None, num_envs=1, **kw):
+        obs, state = self._env.reset(key, params, num_envs, **kw)
+        return obs.reshape(obs.shape[0], -1), state
+
+    def step(self, key, state, action, params=None, **kw):
+        obs, state, reward, done, info = self._env.step(key, state, action, params, **kw)
+        return obs.reshape(obs.shape[0], -1), state, reward, done, info
+
+
+def make(env_name: str, device=None, **env_kwargs):
+    """gymnax.make(name) -> (env, env_params)  (pqn_minatar.py:103)."""
+    env = Environment(env_name, device=device)
+    return env, env.default_params

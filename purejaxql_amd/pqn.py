@@ -1,0 +1,278 @@
+"""make_train(config) -- the PQN hot path (rollout + Q(lambda) + minibatch update).
+
+Same surface and control flow as the reference closures
+  purejaxql/pqn_minatar.py:89-431   (CNN, MinAtar)
+  purejaxql/pqn_gymnax.py:78-424    (MLP, gymnax classic control)
+but built MI355X-first: env dynamics, eps-greedy, Q(lambda), shuffle keys and
+clip+RAdam are HIP kernels behind the C ABI (include/pqn_hotpath.h), state is
+SoA in HBM, the rollout record is time-major [T, N, ...] (the reference's scan
+stacking, :214-219), and randomness is counter-based threefry keyed by
+(seed, purpose, update*T+t, env) instead of split/carry chains.
+
+    train = make_train(config)          # config: flat dict, UPPER_CASE keys
+    out = train(seed_key)               # {"runner_state": ..., "metrics": {name: tensor[NUM_UPDATES]}}
+    outs = vmap_train(train, keys)      # jax.vmap(make_train(config))(rngs): leading [S] axis
+
+Key schedule (this build's own; jax streams cannot be reproduced):
+    K_init = fold_in(K, 0); K_reset = fold_in(K, 1); K_test = fold_in(K, 2)
+    K_roll = fold_in(K, 3) -> step key fold_in(K_roll, u*T + t)
+    K_shuf = fold_in(K, 4) -> epoch key fold_in(K_shuf, u*NUM_EPOCHS + ep)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib, ops
+from .envs import FlattenObservationWrapper, LogWrapper, make
+from .networks import FlatParams, QNetwork
+
+INFO_KEYS = ("discount", "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode")
+
+
+def linear_schedule(init_value: float, end_value: float, transition_steps: float) -> Callable[[float], float]:
+    """optax.linear_schedule, used for eps at pqn_minatar.py:134-138."""
+
+    def f(count: float) -> float:
+        if transition_steps <= 0:
+            return end_value
+        c = min(max(float(count), 0.0), float(transition_steps))
+        return (init_value - end_value) * (1.0 - c / float(transition_steps)) + end_value
+
+    return f
+
+
+def derive_config(config: Dict[str, Any]) -> Dict[str, Any]:
+    """The in-place derivations of make_train (pqn_minatar.py:91-101)."""
+    config["NUM_UPDATES"] = config["TOTAL_TIMESTEPS"] // config["NUM_STEPS"] // config["NUM_ENVS"]
+    config["NUM_UPDATES_DECAY"] = config["TOTAL_TIMESTEPS_DECAY"] // config["NUM_STEPS"] // config["NUM_ENVS"]
+    assert (config["NUM_STEPS"] * config["NUM_ENVS"]) % config["NUM_MINIBATCHES"] == 0, \
+        "NUM_MINIBATCHES must divide NUM_STEPS*NUM_ENVS"
+    return config
+
+
+class _Rollout:
+    """Time-major rollout record of one update: the reference's `Transition`
+    (pqn_minatar.py:72-79) with next_obs folded into obs[T] and q_val reduced to
+    max_a q (its only consumer is :249)."""
+
+    def __init__(self, t, n, obs_shape, device):
+        f32, i32 = torch.float32, torch.int32
+        self.obs = torch.empty((t + 1, n, *obs_shape), dtype=f32, device=device)
+        self.action = torch.empty((t, n), dtype=i32, device=device)
+        self.reward = torch.empty((t, n), dtype=f32, device=device)
+        self.done = torch.empty((t, n), dtype=torch.uint8, device=device)
+        self.qmax = torch.empty((t, n), dtype=f32, device=device)
+        self.discount = torch.empty((t, n), dtype=f32, device=device)
+        self.rer = torch.empty((t, n), dtype=f32, device=device)
+        self.rel = torch.empty((t, n), dtype=i32, device=device)
+        self.ts = torch.empty((t, n), dtype=i32, device=device)
+        self.target = torch.empty((t, n), dtype=f32, device=device)
+
+
+def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: Optional[Callable] = None):
+    """Returns train(key).  `grad_hook(flat_grad)` (optional) runs between backward
+    and the optimizer step -- the RCCL all-reduce of env-sharded mode plugs in here."""
+    lib = _lib.load()
+    derive_config(config)
+    dev = torch.device(device or "cuda")
+    if dev.type != "cuda":
+        raise RuntimeError("purejaxql_amd runs on the GPU only (no CPU fallback); got device=%s" % dev)
+
+    env, env_params = make(config["ENV_NAME"], device=dev)
+    kind = "cnn" if len(env.obs_shape) == 3 else "mlp"
+    if kind == "mlp":
+        env = FlattenObservationWrapper(env)      # pqn_gymnax.py:93
+    env = LogWrapper(env)                         # pqn_minatar.py:104
+    base_env = env
+    while hasattr(base_env, "_env"):
+        base_env = base_env._env
+    if kind == "cnn":
+        config["TEST_NUM_STEPS"] = env_params.max_steps_in_episode                      # pqn_minatar.py:105
+    else:
+        config["TEST_NUM_STEPS"] = config.get("TEST_NUM_STEPS", env_params.max_steps_in_episode)  # pqn_gymnax.py:95-97
+
+    N, T = int(config["NUM_ENVS"]), int(config["NUM_STEPS"])
+    NUM_UPDATES = int(config["NUM_UPDATES"])
+    MB, EPOCHS = int(config["NUM_MINIBATCHES"]), int(config["NUM_EPOCHS"])
+    B = (N * T) // MB
+    A = env.action_space(env_params).n
+    obs_shape = env.observation_space(env_params).shape
+    gamma, lam = float(config["GAMMA"]), float(config["LAMBDA"])
+    rew_scale = float(config.get("REW_SCALE", 1))
+    test_on = bool(config.get("TEST_DURING_TRAINING", False))
+    sp = _lib.stream_ptr
+
+    def env_step_into(key, words, action, obs_out, r, d, disc, rer, rel, ts):
+        out = _lib.StepOut(obs=_lib.ptr(obs_out), obs_bits=None, reward=_lib.ptr(r), done=_lib.ptr(d),
+                           discount=_lib.ptr(disc), returned_episode_returns=_lib.ptr(rer),
+                           returned_episode_lengths=_lib.ptr(rel), timestep=_lib.ptr(ts))
+        _lib.check(lib.pqn_env_step(base_env.env_id, words.shape[1], key, _lib.ptr(words), _lib.ptr(words),
+                                    _lib.ptr(action), C.byref(out), sp()), "pqn_env_step")
+
+    def make_runner(rng: int):
+        """Builds the per-seed training state and returns (update, finish): update(u) runs ONE
+        PQN update (rollout + targets + epochs); finish() returns train()'s result dict."""
+        K = int(rng) & 0xFFFFFFFFFFFFFFFF
+        K_init, K_reset, K_test, K_roll, K_shuf = (_lib.fold_in(K, i) for i in range(5))
+        shard = config.get("_ENV_SHARD")  # (rank, world): envs of ONE seed split over ranks
+        if shard is not None:             # same init on every rank, rank-distinct env/shuffle streams
+            K_reset, K_test, K_roll, K_shuf = (_lib.fold_in(k, 1000 + int(shard[0])) for k in
+                                               (K_reset, K_test, K_roll, K_shuf))
+
+        eps_scheduler = linear_schedule(config["EPS_START"], config["EPS_FINISH"],
+                                        config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"])
+        lr_steps = (config["NUM_UPDATES_DECAY"] * MB * EPOCHS) if config.get("LR_LINEAR_DECAY", False) else 0.0
+
+        # INIT NETWORK AND OPTIMIZER (pqn_minatar.py:150-173)
+        network = QNetwork(kind, obs_shape, A, norm_type=config["NORM_TYPE"],
+                           norm_input=config.get("NORM_INPUT", False),
+                           hidden_size=config.get("HIDDEN_SIZE", 128), num_layers=config.get("NUM_LAYERS", 2),
+                           device=dev)
+        theta = config.get("_INIT_PARAMS")
+        theta = network.init(K_init) if theta is None else theta.to(dev, torch.float32).clone()
+        fp = FlatParams(network, theta)
+        opt = ops.FlatRAdam(fp.theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps)
+        counters = {"timesteps": 0, "n_updates": 0, "grad_steps": 0}
+
+        def q_values(obs):
+            with torch.no_grad():
+                return network.apply(fp.leaves, obs)
+
+        # EVAL (pqn_minatar.py:371-413)
+        test_runs = [0]
+
+        def get_test_metrics():
+            if not test_on:
+                return None
+            k = _lib.fold_in(K_test, test_runs[0])
+            test_runs[0] += 1
+            n_t, steps = int(config["TEST_NUM_ENVS"]), int(config["TEST_NUM_STEPS"])
+            obs, state = env.reset(_lib.fold_in(k, 0), env_params, n_t)
+            sums = {kk: torch.zeros((), dtype=torch.float64, device=dev) for kk in INFO_KEYS}
+            cnt = torch.zeros((), dtype=torch.float64, device=dev)
+            for t in range(steps):
+                sk = _lib.fold_in(k, 1 + t)
+                action, _ = ops.eps_greedy(q_values(obs), config["EPS_TEST"], sk)
+                obs, state, _r, done, info = env.step(sk, state, action, env_params, inplace=True)
+                dm = done.to(torch.float64)
+                cnt += dm.sum()
+                for kk in INFO_KEYS:
+                    sums[kk] += (info[kk].to(torch.float64) * dm).sum()
+            # nanmean(where(returned_episode, x, nan)) (:403-412)
+            return {kk: (sums[kk] / cnt).to(torch.float32) for kk in INFO_KEYS}
+
+        tm_box = [get_test_metrics()]
+
+        # reset exploration envs (pqn_minatar.py:418-419)
+        ro = _Rollout(T, N, obs_shape, dev)
+        obs0, state = env.reset(K_reset, env_params, N)
+        words = state.words
+        ro.obs[0].copy_(obs0)
+
+        names = ["env_step", "update_steps", "grad_steps", "td_loss", "qvals"] + list(INFO_KEYS)
+        if kind == "cnn":
+            names.insert(2, "env_frame")
+        if test_on:
+            names += [f"test/{k}" for k in INFO_KEYS]
+        metrics = {k: torch.zeros(NUM_UPDATES, dtype=torch.float32, device=dev) for k in names}
+        n_mb_total = MB * EPOCHS
+        loss_buf = torch.zeros(n_mb_total, dtype=torch.float32, device=dev)
+        qv_buf = torch.zeros(n_mb_total, dtype=torch.float32, device=dev)
+        test_period = int(NUM_UPDATES * config["TEST_INTERVAL"]) if test_on else 0
+
+        def update(u: int):
+            # SAMPLE PHASE (_step_env, pqn_minatar.py:181-220)
+            eps = eps_scheduler(counters["n_updates"])
+            for t in range(T):
+                sk = _lib.fold_in(K_roll, u * T + t)
+                q = q_values(ro.obs[t])
+                ops.eps_greedy(q, eps, sk, ro.action[t], ro.qmax[t])
+                env_step_into(sk, words, ro.action[t], ro.obs[t + 1], ro.reward[t], ro.done[t], ro.discount[t],
+                              ro.rer[t], ro.rel[t], ro.ts[t])
+            counters["timesteps"] += T * N
+            info_means = {
+                "discount": ro.discount.mean(), "returned_episode_returns": ro.rer.mean(),
+                "returned_episode_lengths": ro.rel.to(torch.float32).mean(),
+                "timestep": ro.ts.to(torch.float32).mean(), "returned_episode": ro.done.to(torch.float32).mean(),
+            }
+            if rew_scale != 1.0:
+                ro.reward.mul_(rew_scale)      # REW_SCALE*reward (:205); LogWrapper saw the raw reward
+
+            # Q(lambda) TARGETS (pqn_minatar.py:227-260)
+            last_q = q_values(ro.obs[T]).max(dim=-1).values.contiguous()
+            ops.q_lambda(ro.reward, ro.done, ro.qmax, last_q, gamma, lam, quirk=True, target=ro.target)
+
+            # NETWORKS UPDATE (pqn_minatar.py:263-327)
+            obs_flat = ro.obs[:T].reshape(T * N, *obs_shape)
+            act_flat = ro.action.reshape(-1).to(torch.int64)
+            tgt_flat = ro.target.reshape(-1)
+            i_mb = 0
+            for ep in range(EPOCHS):
+                perm = ops.shuffle_permutation(_lib.fold_in(K_shuf, u * EPOCHS + ep), T * N, dev)
+                for mb in range(MB):
+                    idx = perm[mb * B:(mb + 1) * B]
+                    fp.zero_grad()
+                    qv = network.apply(fp.leaves, obs_flat[idx])
+                    chosen = qv.gather(1, act_flat[idx].unsqueeze(1)).squeeze(1)
+                    loss = 0.5 * torch.square(chosen - tgt_flat[idx]).mean()
+                    loss.backward()
+                    if grad_hook is not None:
+                        grad_hook(fp.grad)
+                    opt.step(fp.grad)
+                    counters["grad_steps"] += 1
+                    loss_buf[i_mb] = loss.detach()
+                    qv_buf[i_mb] = chosen.detach().mean()
+                    i_mb += 1
+            ro.obs[0].copy_(ro.obs[T])  # carry last_obs into the next update
+
+            counters["n_updates"] += 1
+            m = {"env_step": counters["timesteps"], "update_steps": counters["n_updates"],
+                 "grad_steps": counters["grad_steps"], "td_loss": loss_buf.mean(), "qvals": qv_buf.mean()}
+            if kind == "cnn":
+                m["env_frame"] = counters["timesteps"] * obs_shape[-1]
+            m.update(info_means)
+            if test_on:
+                if test_period > 0 and counters["n_updates"] % test_period == 0:
+                    tm_box[0] = get_test_metrics()
+                m.update({f"test/{k}": v for k, v in tm_box[0].items()})
+            for k, v in m.items():
+                metrics[k][u] = v
+            cb = config.get("_CALLBACK")
+            if cb is not None:
+                cb(u, m)
+
+        def finish():
+            runner_state = {"params": network.views(fp.theta), "theta": fp.theta, "opt_count": opt.count,
+                            "opt_mu": opt.m, "opt_nu": opt.v, "env_state": words, "last_obs": ro.obs[0],
+                            "test_metrics": tm_box[0], "network": network, **counters}
+            return {"runner_state": runner_state, "metrics": metrics}
+
+        return update, finish
+
+    def train(rng: int) -> Dict[str, Any]:
+        update, finish = make_runner(rng)
+        for u in range(NUM_UPDATES):
+            update(u)
+        return finish()
+
+    train.make_runner = make_runner
+    train.config = config
+    return train
+
+
+def vmap_train(train: Callable[[int], Dict[str, Any]], keys: List[int]) -> Dict[str, Any]:
+    """jax.vmap(make_train(config))(rngs) (pqn_minatar.py:459-461): independent seeds,
+    outputs stacked on a leading [S] axis where they are tensors."""
+    outs = [train(k) for k in keys]
+    metrics = {k: torch.stack([o["metrics"][k] for o in outs]) for k in outs[0]["metrics"]}
+    return {"runner_state": [o["runner_state"] for o in outs], "metrics": metrics}
+
+
+def seed_keys(seed: int, num_seeds: int) -> List[int]:
+    """rngs = split(PRNGKey(SEED), NUM_SEEDS) (pqn_minatar.py:456-459)."""
+    base = _lib.prng_key(seed)
+    return [_lib.fold_in(base, s) for s in range(int(num_seeds))]

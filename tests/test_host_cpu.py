@@ -1,0 +1,81 @@
+"""CPU tests (-m "not gpu") of the host logic: config grammar, C-ABI exports, and
+the no-fallback rule.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_hydra_grammar_and_flatten():
+    from purejaxql_amd.config_loader import flatten, load_config
+    cfg = load_config(["+alg=pqn_minatar", "alg.NUM_ENVS=4096", "alg.ENV_NAME=Breakout-MinAtar", "SEED=3",
+                       "alg.TOTAL_TIMESTEPS=2e6"])
+    assert cfg["SEED"] == 3 and cfg["alg"]["NUM_ENVS"] == 4096
+    flat = flatten(cfg)                                   # {**config, **config["alg"]} (pqn_minatar.py:437)
+    assert flat["NUM_ENVS"] == 4096 and flat["ENV_NAME"] == "Breakout-MinAtar" and flat["NUM_SEEDS"] == 1
+    assert isinstance(flat["TOTAL_TIMESTEPS_DECAY"], float) and flat["TOTAL_TIMESTEPS_DECAY"] == 1e7   # F9
+    assert flat["TOTAL_TIMESTEPS"] == 2e6
+    assert flat["LR"] == 0.0005 and flat["LAMBDA"] == 0.65 and flat["NUM_MINIBATCHES"] == 32 and flat["NUM_EPOCHS"] == 2
+    cp = flatten(load_config(["+alg=pqn_cartpole"]))
+    assert cp["NUM_STEPS"] == 64 and cp["REW_SCALE"] == 0.1 and cp["HIDDEN_SIZE"] == 256 and cp["LAMBDA"] == 0.95
+    with pytest.raises(FileNotFoundError):
+        load_config(["+alg=nope"])
+
+
+def test_make_train_divisibility_assert():
+    from purejaxql_amd.pqn import derive_config
+    with pytest.raises(AssertionError):   # pqn_minatar.py:99-101
+        derive_config({"TOTAL_TIMESTEPS": 1e4, "TOTAL_TIMESTEPS_DECAY": 1e4, "NUM_STEPS": 3, "NUM_ENVS": 5,
+                       "NUM_MINIBATCHES": 4})
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "pqn_hotpath.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pqn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from purejaxql_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 12
+    assert os.path.exists(_lib.LIB_PATH), "build libpqn_hip.so first (__graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(_lib.SIGNATURES) == syms            # the ctypes table binds exactly the header
+    _lib.load()
+    assert _lib.load().pqn_version() >= 1
+
+
+def test_host_prng_helpers_match_oracle(oracle):
+    from purejaxql_amd import _lib
+    for key, d in [(0, 0), (0x0123456789ABCDEF, 77), (2**64 - 1, 2**32 - 1)]:
+        assert _lib.fold_in(key, d) == oracle.fold_in(key, d)
+
+
+def test_no_cpu_fallback():
+    import torch
+    from purejaxql_amd.pqn import make_train
+    cfg = {"TOTAL_TIMESTEPS": 1e4, "TOTAL_TIMESTEPS_DECAY": 1e4, "NUM_STEPS": 4, "NUM_ENVS": 4, "NUM_MINIBATCHES": 2,
+           "ENV_NAME": "Breakout-MinAtar"}
+    with pytest.raises(RuntimeError):
+        make_train(cfg, device="cpu")
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            make_train(dict(cfg))  # no GPU -> loud failure, never a silent CPU path
+
+
+def test_unknown_env_is_an_error():
+    from purejaxql_amd import _lib
+    lib = _lib.load()
+    assert lib.pqn_env_id(b"Pong-v5") < 0
+    assert b"Pong-v5" in lib.pqn_last_error()
+    spec = _lib.EnvSpec()
+    assert lib.pqn_env_spec(99, ctypes.byref(spec)) < 0
+    assert lib.pqn_env_spec(0, ctypes.byref(spec)) == 0
+    assert tuple(spec.obs_dim) == (10, 10, 4) and spec.num_actions == 3 and spec.max_steps == 1000
+    assert spec.state_words == 7 and spec.obs_words == 16 and spec.canon_si == 109

@@ -1,0 +1,236 @@
+"""CPU tests (-m "not gpu"): the oracle against the known-answer vectors
+(tests/golden/ka_vectors.json), and the oracle's numpy
+network against a plain PyTorch fp32 autograd reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KA = json.load(open(os.path.join(HERE, "golden", "ka_vectors.json")))
+
+
+def test_threefry_known_answers(oracle):
+    # Random123 / jax tests/random_test.py known answers for threefry2x32-20
+    for v in KA["threefry2x32"]:
+        assert list(oracle.threefry2x32(v["key"], v["ctr"])) == v["out"]
+
+
+def test_fold_in_is_counter_0_d(oracle):
+    key = 0x0123456789ABCDEF
+    o = oracle.threefry2x32([key >> 32, key & 0xFFFFFFFF], [0, 77])
+    assert oracle.fold_in(key, 77) == (o[0] << 32) | o[1]
+
+
+def test_q_lambda_known_answers(oracle):  # KA1
+    ka = KA["q_lambda"]
+    r = np.array(ka["reward"], np.float32)[:, None]
+    qm = np.array(ka["qmax"], np.float32)[:, None]
+    lq = np.array([ka["last_q"]], np.float32)
+    for case in ka["cases"]:
+        d = np.array(case["done"], np.uint8)[:, None]
+        got = oracle.q_lambda(r, d, qm, lq, ka["gamma"], ka["lambda"], quirk=True)[:, 0]
+        np.testing.assert_allclose(got, case["minatar"], rtol=1e-6, atol=1e-6)
+        got0 = oracle.q_lambda(r, d, qm, lq, ka["gamma"], ka["lambda"], quirk=False)[:, 0]
+        np.testing.assert_allclose(got0, case["atari"], rtol=1e-6, atol=1e-6)
+
+
+def test_q_lambda_affine_form(oracle):
+    # [DERIVED] G_t = d ? r : r + g(1-l) nq + g l G_{t+1}
+    rng = np.random.default_rng(0)
+    T, M = 32, 50
+    r = rng.random((T, M)).astype(np.float32)
+    d = (rng.random((T, M)) < 0.1).astype(np.uint8)
+    qm = rng.standard_normal((T, M)).astype(np.float32)
+    lq = rng.standard_normal(M).astype(np.float32)
+    g, l = 0.99, 0.65
+    got = oracle.q_lambda(r, d, qm, lq, g, l, quirk=True).astype(np.float64)
+    exp = np.zeros((T, M))
+    lq2 = lq * (1 - d[-1])
+    exp[-1] = r[-1] + g * lq2
+    nq = lq2.astype(np.float64)
+    for t in range(T - 2, -1, -1):
+        exp[t] = np.where(d[t] == 1, r[t], r[t] + g * (1 - l) * nq + g * l * exp[t + 1])
+        nq = qm[t]
+    np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5)
+
+
+def test_num_updates_and_schedules(oracle):  # KA2, KA3
+    from purejaxql_amd.pqn import derive_config, linear_schedule
+    for v in KA["num_updates"]:
+        cfg = derive_config({"TOTAL_TIMESTEPS": v["total"], "TOTAL_TIMESTEPS_DECAY": v["total"],
+                             "NUM_STEPS": v["steps"], "NUM_ENVS": v["envs"], "NUM_MINIBATCHES": 1})
+        assert cfg["NUM_UPDATES"] == v["updates"]
+    assert int(76 * 0.05) == 3 and int(2441 * 0.05) == 122
+    eps = linear_schedule(1.0, 0.05, 0.1 * 2441)
+    assert eps(0) == 1.0 and eps(245) == 0.05 and eps(1e9) == 0.05
+    assert abs(eps(122.05) - (0.95 * 0.5 + 0.05)) < 1e-12
+    for c in (0, 10, 244.1, 300):
+        assert abs(eps(c) - oracle.linear_schedule(1.0, 0.05, 244.1, c)) < 1e-12
+    lr_n = 2441 * 32 * 2
+    assert oracle.linear_schedule(5e-4, 1e-20, lr_n, 0) == 5e-4
+    assert oracle.linear_schedule(5e-4, 1e-20, lr_n, lr_n + 5) == 1e-20
+
+
+def test_log_wrapper_known_answer(oracle):  # KA4
+    ka = KA["log_wrapper"]
+    n = 1
+    st = dict(ep_ret=np.zeros(n, np.float32), ep_len=np.zeros(n, np.int32), ret_ret=np.zeros(n, np.float32),
+              ret_len=np.zeros(n, np.int32), timestep=np.zeros(n, np.int32))
+    for r, d in zip(ka["reward"], ka["done"]):
+        oracle.lib().pqn_oracle_log_step(n, oracle._p(np.array([r], np.float32)), oracle._p(np.array([d], np.uint8)),
+                                         oracle._p(st["ep_ret"]), oracle._p(st["ep_len"]), oracle._p(st["ret_ret"]),
+                                         oracle._p(st["ret_len"]), oracle._p(st["timestep"]))
+    a = ka["after"]
+    assert st["ret_ret"][0] == a["returned_episode_returns"] and st["ret_len"][0] == a["returned_episode_lengths"]
+    assert st["ep_ret"][0] == a["episode_returns"] and st["ep_len"][0] == a["episode_lengths"]
+    assert st["timestep"][0] == a["timestep"]
+
+
+def test_eps_greedy_rules(oracle):  # KA8
+    rng = np.random.default_rng(1)
+    q = rng.standard_normal((4000, 3)).astype(np.float32)
+    q[:100] = 1.0  # ties -> first index
+    a, qm = oracle.eps_greedy(q, 0.0, key=123)
+    assert (a == q.argmax(-1)).all() and (a[:100] == 0).all()
+    np.testing.assert_array_equal(qm, q.max(-1))
+    a1, _ = oracle.eps_greedy(q, 1.0, key=123)
+    assert set(np.unique(a1)) == {0, 1, 2}
+    counts = np.bincount(a1, minlength=3) / len(a1)
+    assert np.abs(counts - 1 / 3).max() < 0.03
+    a5, _ = oracle.eps_greedy(q[100:], 0.3, key=9)
+    frac_greedy = (a5 == q[100:].argmax(-1)).mean()
+    assert abs(frac_greedy - (0.7 + 0.3 / 3)) < 0.03
+
+
+def test_shuffle_is_a_permutation_shared_by_leaves(oracle):  # KA7
+    T, N = 4, 8
+    perm = oracle.permutation(key=42, n=T * N)
+    assert sorted(perm.tolist()) == list(range(T * N))
+    assert (perm != np.arange(T * N)).any()
+    x = np.arange(T * N).reshape(T, N)          # flatten index t*N + e
+    assert x.reshape(-1)[perm[0]] == perm[0] and x[perm[0] // N, perm[0] % N] == perm[0]
+    assert (oracle.permutation(42, T * N) == perm).all() and (oracle.permutation(43, T * N) != perm).any()
+
+
+def test_breakout_hand_derived_trajectories(oracle):
+    env = oracle.OracleEnv("Breakout-MinAtar")
+    for tr in KA["breakout_trajectories"]:
+        key = next(k for k in range(1000) if (oracle.env_bits(k, 0, 1)[0] & 1) == tr["start"])
+        obs, st = env.reset(key, 1)
+        assert obs.shape == (1, 10, 10, 4) and obs.sum() == 1 + 1 + 1 + 30
+        assert st["si"][0, 1] == (9 if tr["start"] else 0) and st["si"][0, 2] == (3 if tr["start"] else 2)
+        for i, a in enumerate(tr["actions"]):
+            obs, st, r, d, info = env.step(0, st, np.array([a]), autoreset=False)
+            assert [int(st["si"][0, 1]), int(st["si"][0, 0])] == tr["ball"][i], (i, st["si"][0, :9])
+            assert r[0] == tr["reward"][i] and int(d[0]) == tr["terminal"][i]
+            assert obs[0, st["si"][0, 0], st["si"][0, 1], 1] == 1 and obs[0, 9, st["si"][0, 3], 0] == 1
+        if "final" in tr:
+            f = tr["final"]
+            assert st["si"][0, 2] == f["dir"] and st["si"][0, 3] == f["pos"] and st["si"][0, 4] == f["strike"]
+            y, x = f["brick_cleared"]
+            assert st["si"][0, 9 + y * 10 + x] == 0 and st["si"][0, 9:].sum() == 29
+
+
+def test_breakout_invariants_random_play(oracle):
+    env = oracle.OracleEnv("Breakout-MinAtar")
+    n = 256
+    rng = np.random.default_rng(3)
+    obs, st = env.reset(7, n)
+    total_r = np.zeros(n)
+    for t in range(1200):
+        before = st["si"][:, 9:].sum(1).copy()
+        a = rng.integers(0, 3, n)
+        obs, st, r, d, info = env.step(1000 + t, st, a)
+        bm = st["si"][:, 9:].reshape(n, 10, 10)
+        assert bm[:, 0].sum() == 0 and bm[:, 4:].sum() == 0          # bricks only in rows 1..3
+        assert ((r == 0) | (r == 1)).all()
+        after = st["si"][:, 9:].sum(1)
+        ok = d | (after == before - r) | (after == 30)                  # one brick per reward (or respawn/reset)
+        assert ok.all()
+        assert (st["si"][d, 7] == 0).all() and (st["si"][:, 7] <= 1000).all()   # auto-reset zeroes time
+        assert (obs.reshape(n, -1).sum(1) == 3 + after).all()
+        assert (info["discount"] == 1 - d).all()
+    assert st["timestep"].min() == 1200
+
+
+def test_cartpole_oracle_basic(oracle):
+    env = oracle.OracleEnv("CartPole-v1")
+    obs, st = env.reset(5, 64)
+    assert obs.shape == (64, 4) and np.abs(obs).max() <= 0.05
+    done_seen = 0
+    for t in range(600):
+        obs, st, r, d, info = env.step(t, st, np.zeros(64, np.int32))   # always push left -> falls
+        assert (r == 1.0).all()                                          # reward 1 - prev_terminal (auto-reset => 1)
+        done_seen += d.sum()
+    assert done_seen > 64 and info["returned_episode_lengths"].max() < 100
+
+
+@pytest.mark.parametrize("kind", ["cnn", "mlp"])
+def test_oracle_network_matches_torch_autograd(oracle, kind):
+    """numpy fwd/bwd restatement vs plain PyTorch fp32 autograd of the same net."""
+    from purejaxql_amd.networks import QNetwork
+    torch.manual_seed(0)
+    if kind == "cnn":
+        net = QNetwork("cnn", (10, 10, 4), 3, device="cpu")
+        x = (torch.rand(32, 10, 10, 4) < 0.2).float()
+        shapes = oracle.cnn_shapes((10, 10, 4), 3)
+        assert net.num_params == KA["breakout_param_count"]  # KA6
+    else:
+        net = QNetwork("mlp", (4,), 2, hidden_size=64, num_layers=2, device="cpu")
+        x = torch.randn(32, 4)
+        shapes = oracle.mlp_shapes(4, 2, 64, 2)
+    theta = net.init(3)
+    theta += 0.05 * torch.randn_like(theta)  # move LN scales/biases off their init
+    leaves = {k: v.clone().requires_grad_(True) for k, v in net.views(theta).items()}
+    action = torch.randint(0, net.action_dim, (32,))
+    target = torch.randn(32)
+    q = net.apply(leaves, x)
+    chosen = q.gather(1, action[:, None])[:, 0]
+    loss = 0.5 * torch.square(chosen - target).mean()  # KA5
+    loss.backward()
+    p = oracle.unflatten(theta.numpy().copy(), shapes)
+    qo = oracle.net_forward(kind, p, x.numpy())
+    np.testing.assert_allclose(qo, q.detach().numpy(), rtol=2e-4, atol=2e-5)
+    lo, ch, g = oracle.net_loss_grad(kind, p, shapes, x.numpy(), action.numpy(), target.numpy())
+    assert abs(lo - loss.item()) < 1e-5
+    gt = torch.cat([(leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])).reshape(-1)
+                    for k in shapes]).numpy()
+    np.testing.assert_allclose(g, gt, rtol=2e-3, atol=2e-6)
+    assert np.abs(g[:2 * x.shape[-1]]).max() == 0  # dummy input BatchNorm never gets gradient
+
+
+def test_oracle_radam_matches_formula(oracle):
+    """optax.radam + clip_by_global_norm formula in float64."""
+    rng = np.random.default_rng(0)
+    n = 1000
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    p64, m64, v64 = p.astype(np.float64), np.zeros(n), np.zeros(n)
+    b1, b2, eps, lr, max_norm = 0.9, 0.999, 1e-8, 1e-3, 10.0
+    ro_inf = 2 / (1 - b2) - 1
+    for count in range(12):
+        g = (rng.standard_normal(n) * (3.0 if count % 3 == 0 else 0.1)).astype(np.float32)
+        gn = oracle.radam_clip_step(p, g, m, v, count, lr, max_norm)
+        g64 = g.astype(np.float64)
+        norm = np.sqrt((g64 ** 2).sum())
+        assert abs(gn - norm) / norm < 1e-5
+        if not norm < max_norm:
+            g64 = g64 / norm * max_norm
+        t = count + 1
+        m64 = b1 * m64 + (1 - b1) * g64
+        v64 = b2 * v64 + (1 - b2) * g64 ** 2
+        ro = ro_inf - 2 * t * b2 ** t / (1 - b2 ** t)
+        mh, vh = m64 / (1 - b1 ** t), v64 / (1 - b2 ** t)
+        if ro >= 5.0:
+            r = np.sqrt((ro - 4) * (ro - 2) * ro_inf / ((ro_inf - 4) * (ro_inf - 2) * ro))
+            u = r * mh / (np.sqrt(vh) + eps)
+        else:
+            u = mh
+        p64 = p64 - lr * u
+        np.testing.assert_allclose(p, p64, rtol=1e-5, atol=1e-6)
+    # the rectified branch is reached from t=6 on (ro_6 = 5.0...): make sure both were exercised
+    assert ro_inf - 2 * 5 * b2 ** 5 / (1 - b2 ** 5) < 5.0 <= ro_inf - 2 * 6 * b2 ** 6 / (1 - b2 ** 6)

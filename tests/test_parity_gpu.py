@@ -1,0 +1,270 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded inputs.  Integer/index work must be bit-exact;
+float tolerances are written at each assert."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KA = json.load(open(os.path.join(HERE, "golden", "ka_vectors.json")))
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _check_state(env, oenv, state, ost):
+    si, sf, log = env.export_state(state)
+    np.testing.assert_array_equal(_np(si), ost["si"])
+    np.testing.assert_array_equal(_np(log).view(np.uint32), oenv.log_words(ost))
+    return sf
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 1000, 4096])
+def test_breakout_step_bit_exact_vs_oracle(gpu, oracle, n):
+    from purejaxql_amd.envs import LogWrapper, make
+    env, params = make("Breakout-MinAtar", device=gpu)
+    env = LogWrapper(env)
+    oenv = oracle.OracleEnv("Breakout-MinAtar")
+    (obs, bits), state = env.reset(11, params, n, want_bits=True)
+    oobs, ost = oenv.reset(11, n)
+    np.testing.assert_array_equal(_np(obs), oobs)
+    _check_state(env, oenv, state, ost)
+    rng = np.random.default_rng(n)
+    steps = 1500 if n <= 1000 else 300
+    for t in range(steps):
+        a = rng.integers(0, 3, n).astype(np.int32)
+        if t % 7 == 0:  # follow the ball sometimes so episodes last and bricks clear
+            a = np.where(ost["si"][:, 1] < ost["si"][:, 3], 1, np.where(ost["si"][:, 1] > ost["si"][:, 3], 2, 0)).astype(np.int32)
+        key = 5000 + t
+        (obs, bits), state, r, d, info = env.step(key, state, torch.from_numpy(a).to(gpu), params, want_bits=True)
+        oobs, ost, orr, od, oinfo = oenv.step(key, ost, a)
+        np.testing.assert_array_equal(_np(r), orr)
+        np.testing.assert_array_equal(_np(d), od)
+        if t % 50 == 0 or t == steps - 1:
+            np.testing.assert_array_equal(_np(obs), oobs)
+            _check_state(env, oenv, state, ost)
+            for k in oinfo:
+                np.testing.assert_array_equal(_np(info[k]), oinfo[k], err_msg=k)
+            # packed observation == f32 observation, bit (y*10+x)*C+c
+            b = _np(bits).view(np.uint32)
+            flat = oobs.reshape(n, -1).astype(np.uint8)
+            unpacked = ((b[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, -1)[:, :400]
+            np.testing.assert_array_equal(unpacked, flat)
+            assert (b[:, 13:] == 0).all() and ((b[:, 12] >> 16) == 0).all()
+    assert ost["ret_len"].max() > 0  # episodes actually finished
+
+
+def test_breakout_hand_derived_trajectories_on_gpu(gpu, oracle):
+    from purejaxql_amd.envs import make
+    env, params = make("Breakout-MinAtar", device=gpu)
+    oenv = oracle.OracleEnv("Breakout-MinAtar")
+    for tr in KA["breakout_trajectories"]:
+        key = next(k for k in range(1000) if (oracle.env_bits(k, 0, 1)[0] & 1) == tr["start"])
+        _, ost = oenv.reset(key, 1)
+        obs, state = env.reset(key, params, 1)
+        for i, a in enumerate(tr["actions"]):
+            # step_env only (auto-reset off in the oracle) == the product while no episode ends
+            obs, state, r, d, _ = env.step(0, state, torch.tensor([a], dtype=torch.int32, device=gpu), params)
+            si, _, _ = env.export_state(state)
+            si = _np(si)[0]
+            if not tr["terminal"][i]:
+                assert [int(si[1]), int(si[0])] == tr["ball"][i]
+            assert float(r[0]) == tr["reward"][i] and int(d[0]) == tr["terminal"][i]
+        if "final" in tr:
+            f = tr["final"]
+            assert si[2] == f["dir"] and si[3] == f["pos"] and si[4] == f["strike"]
+            assert si[9 + f["brick_cleared"][0] * 10 + f["brick_cleared"][1]] == 0 and si[9:].sum() == 29
+
+
+def test_breakout_import_export_round_trip_and_edge_states(gpu, oracle):
+    """Crafted states: last brick about to be cleared (respawn), time limit, ball in corners."""
+    from purejaxql_amd.envs import make
+    env, params = make("Breakout-MinAtar", device=gpu)
+    oenv = oracle.OracleEnv("Breakout-MinAtar")
+    rng = np.random.default_rng(0)
+    n = 2048
+    si = np.zeros((n, 109), np.int32)
+    si[:, 0] = rng.integers(0, 10, n)   # ball_y
+    si[:, 1] = rng.integers(0, 10, n)   # ball_x
+    si[:, 2] = rng.integers(0, 4, n)
+    si[:, 3] = rng.integers(0, 10, n)
+    si[:, 4] = rng.integers(0, 2, n)
+    si[:, 5] = rng.integers(0, 10, n)
+    si[:, 6] = rng.integers(0, 10, n)
+    si[:, 7] = rng.choice([0, 5, 998, 999], n)
+    dens = rng.choice([0.0, 0.03, 0.5, 1.0], n)[:, None]
+    si[:, 9 + 10:9 + 40] = rng.random((n, 30)) < dens
+    state = env.import_state(torch.from_numpy(si))
+    si2, _, log = env.export_state(state)
+    np.testing.assert_array_equal(_np(si2), si)
+    ost = {"si": si.copy(), "sf": np.zeros((n, 1), np.float32), "ep_ret": np.zeros(n, np.float32),
+           "ep_len": np.zeros(n, np.int32), "ret_ret": np.zeros(n, np.float32), "ret_len": np.zeros(n, np.int32),
+           "timestep": np.zeros(n, np.int32)}
+    for t in range(40):
+        a = rng.integers(0, 3, n).astype(np.int32)
+        obs, state, r, d, _ = env.step(77 + t, state, torch.from_numpy(a).to(gpu), params)
+        oobs, ost, orr, od, _ = oenv.step(77 + t, ost, a)
+        np.testing.assert_array_equal(_np(r), orr)
+        np.testing.assert_array_equal(_np(d), od)
+        np.testing.assert_array_equal(_np(obs), oobs)
+        _check_state(env, oenv, state, ost)
+
+
+def test_cartpole_step_vs_oracle(gpu, oracle):
+    """f32 dynamics: sinf/cosf differ between libm and the GPU by <= a few ulp, so the
+    comparison re-synchronises the oracle to the GPU state every step (tolerance 2e-6)."""
+    from purejaxql_amd.envs import FlattenObservationWrapper, LogWrapper, make
+    env, params = make("CartPole-v1", device=gpu)
+    env = LogWrapper(FlattenObservationWrapper(env))
+    oenv = oracle.OracleEnv("CartPole-v1")
+    n = 512
+    obs, state = env.reset(3, params, n)
+    oobs, ost = oenv.reset(3, n)
+    np.testing.assert_array_equal(_np(obs), oobs)   # reset is exact (bit tricks + one fma-free affine map)
+    rng = np.random.default_rng(0)
+    for t in range(700):
+        a = rng.integers(0, 2, n).astype(np.int32)
+        obs, state, r, d, info = env.step(900 + t, state, torch.from_numpy(a).to(gpu), params)
+        oobs, ost, orr, od, oinfo = oenv.step(900 + t, ost, a)
+        g = _np(obs)
+        same_done = _np(d) == od
+        assert same_done.mean() > 0.995   # threshold crossings may flip on the last ulp
+        np.testing.assert_allclose(g[same_done], oobs[same_done], rtol=2e-6, atol=2e-6)
+        np.testing.assert_array_equal(_np(r), orr)
+        # re-sync oracle to the GPU state (canonical export)
+        si, sf, log = env.export_state(state)
+        ost["si"][:] = _np(si)
+        ost["sf"][:] = _np(sf)
+        lw = _np(log).view(np.uint32)
+        ost["ep_ret"][:] = lw[:, 0].view(np.float32)
+        ost["ep_len"][:] = lw[:, 1].view(np.int32)
+        ost["ret_ret"][:] = lw[:, 2].view(np.float32)
+        ost["ret_len"][:] = lw[:, 3].view(np.int32)
+        ost["timestep"][:] = lw[:, 4].view(np.int32)
+    assert ost["ret_len"].max() > 5
+
+
+@pytest.mark.parametrize("m,a", [(1, 2), (1000, 3), (4096, 3), (70001, 6)])
+def test_eps_greedy_bit_exact(gpu, oracle, m, a):
+    from purejaxql_amd import ops
+    rng = np.random.default_rng(m)
+    q = rng.standard_normal((m, a)).astype(np.float32)
+    q[: m // 10] = 0.5  # ties -> first index
+    qt = torch.from_numpy(q).to(gpu)
+    for eps in (0.0, 0.05, 0.5, 1.0):
+        act, qmax = ops.eps_greedy(qt, eps, key=1234 + m)
+        oa, oq = oracle.eps_greedy(q, eps, key=1234 + m)
+        np.testing.assert_array_equal(_np(act), oa)
+        np.testing.assert_array_equal(_np(qmax), oq)
+
+
+def test_q_lambda_known_answers_and_oracle(gpu, oracle):
+    from purejaxql_amd import ops
+    ka = KA["q_lambda"]
+    r = torch.tensor(ka["reward"], dtype=torch.float32, device=gpu)[:, None].contiguous()
+    qm = torch.tensor(ka["qmax"], dtype=torch.float32, device=gpu)[:, None].contiguous()
+    lq = torch.tensor([ka["last_q"]], dtype=torch.float32, device=gpu)
+    for case in ka["cases"]:
+        d = torch.tensor(case["done"], dtype=torch.uint8, device=gpu)[:, None].contiguous()
+        np.testing.assert_allclose(_np(ops.q_lambda(r, d, qm, lq, ka["gamma"], ka["lambda"], quirk=True))[:, 0],
+                                   case["minatar"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(_np(ops.q_lambda(r, d, qm, lq, ka["gamma"], ka["lambda"], quirk=False))[:, 0],
+                                   case["atari"], rtol=1e-6, atol=1e-6)
+    rng = np.random.default_rng(0)
+    for T, M in [(1, 7), (2, 64), (32, 4096), (32, 65536 + 3), (128, 100)]:
+        rr = (rng.random((T, M)) < 0.05).astype(np.float32) * rng.random((T, M)).astype(np.float32)
+        dd = (rng.random((T, M)) < 0.02).astype(np.uint8)
+        qq = rng.standard_normal((T, M)).astype(np.float32)
+        ll = rng.standard_normal(M).astype(np.float32)
+        for quirk in (True, False):
+            got = ops.q_lambda(torch.from_numpy(rr).to(gpu), torch.from_numpy(dd).to(gpu), torch.from_numpy(qq).to(gpu),
+                               torch.from_numpy(ll).to(gpu), 0.99, 0.65, quirk=quirk)
+            exp = oracle.q_lambda(rr, dd, qq, ll, 0.99, 0.65, quirk=quirk)
+            np.testing.assert_array_equal(_np(got), exp)   # same f32 op order, contraction off on both sides
+
+
+def test_shuffle_permutation_bit_exact(gpu, oracle):
+    from purejaxql_amd import ops
+    for n in (1, 2, 1000, 131072):
+        p = ops.shuffle_permutation(99 + n, n, gpu)
+        np.testing.assert_array_equal(_np(p), oracle.permutation(99 + n, n))
+
+
+def test_radam_clip_vs_oracle(gpu, oracle):
+    """f32 elementwise identical; the global norm is a different summation order
+    (tree in f32 vs sequential f64) -> params agree to rtol 2e-6 / atol 1e-7 per step."""
+    from purejaxql_amd import ops
+    rng = np.random.default_rng(0)
+    for n, lr_steps in [(5, 0.0), (132475, 200.0), (1_000_003, 7.0)]:
+        p = rng.standard_normal(n).astype(np.float32)
+        pt = torch.from_numpy(p.copy()).to(gpu)
+        opt = ops.FlatRAdam(pt, 5e-4, 10.0, lr_decay_steps=lr_steps)
+        m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        for count in range(10):
+            scale = 1.0 if count % 2 else 1e-3   # alternate clipped / unclipped steps
+            g = (rng.standard_normal(n) * scale).astype(np.float32)
+            opt.step(torch.from_numpy(g).to(gpu))
+            lr = oracle.linear_schedule(5e-4, 1e-20, lr_steps, count) if lr_steps > 0 else 5e-4
+            gn = oracle.radam_clip_step(p, g, m, v, count, np.float32(lr), 10.0)
+            assert abs(float(opt.gnorm[0]) - gn) <= 2e-6 * gn
+            np.testing.assert_allclose(_np(pt), p, rtol=2e-6, atol=1e-7)
+            np.testing.assert_allclose(_np(opt.m), m, rtol=2e-6, atol=1e-9)
+            np.testing.assert_allclose(_np(opt.v), v, rtol=4e-6, atol=1e-12)
+        assert int(opt.count[0]) == 10
+
+
+def test_product_network_vs_oracle_network(gpu, oracle):
+    """torch-on-GPU fp32 network vs the oracle's numpy network (same theta)."""
+    from purejaxql_amd.networks import QNetwork
+    net = QNetwork("cnn", (10, 10, 4), 3, device=gpu)
+    theta = net.init(1)
+    x = (torch.rand(256, 10, 10, 4, device=gpu) < 0.15).float()
+    q = net.apply(net.views(theta), x)
+    p = oracle.unflatten(_np(theta), oracle.cnn_shapes((10, 10, 4), 3))
+    np.testing.assert_allclose(_np(q), oracle.net_forward("cnn", p, _np(x)), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("alg,env_name,extra", [
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
+    ("pqn_cartpole", "CartPole-v1", {"NUM_ENVS": 4, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
+])
+def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
+    """Whole loop (rollout + Q(lambda) + minibatch updates) vs the oracle loop from the same
+    initial parameters and keys, 3 updates.  Tolerances: params rtol 2e-3 / atol 2e-5
+    (fp32 GEMM summation order differs between rocBLAS and numpy), scalar metrics 1e-3."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys
+    cfg = flatten(load_config([f"+alg={alg}"]))
+    cfg.update(extra)
+    cfg.update({"ENV_NAME": env_name, "TOTAL_TIMESTEPS": 3 * cfg["NUM_ENVS"] * cfg["NUM_STEPS"],
+                "TOTAL_TIMESTEPS_DECAY": 30 * cfg["NUM_ENVS"] * cfg["NUM_STEPS"], "TEST_DURING_TRAINING": False})
+    ocfg = dict(cfg)
+    key = seed_keys(0, 1)[0]
+    torch.manual_seed(0)
+    # shared initial parameters
+    from purejaxql_amd.networks import QNetwork
+    otrain = oracle.make_train(ocfg)
+    n_params = sum(int(np.prod(s)) for s in otrain.shapes.values())
+    kind = otrain.kind
+    env_obs = (10, 10, 4) if kind == "cnn" else (4,)
+    net = QNetwork(kind, env_obs, 3 if kind == "cnn" else 2, hidden_size=cfg.get("HIDDEN_SIZE", 128),
+                   num_layers=cfg.get("NUM_LAYERS", 2), device=gpu)
+    assert net.num_params == n_params
+    theta0 = net.init(123)
+    cfg["_INIT_PARAMS"] = theta0
+    out = make_train(cfg, device="cuda:0")(key)
+    oout = otrain(key, _np(theta0))
+    assert cfg["NUM_UPDATES"] == 3
+    for u in range(3):
+        om = oout["metrics"][u]
+        for k in ("env_step", "update_steps", "grad_steps"):
+            assert float(out["metrics"][k][u]) == om[k]
+        for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "timestep",
+                  "returned_episode", "discount"):
+            assert abs(float(out["metrics"][k][u]) - om[k]) <= 1e-3 * max(1.0, abs(om[k])), (u, k)
+    np.testing.assert_allclose(_np(out["runner_state"]["theta"]), oout["theta"], rtol=2e-3, atol=2e-5)
