@@ -145,7 +145,7 @@ static void breakout_step_one(int32_t *s, int32_t action, int32_t max_steps, flo
   if (new_y < 0) {
     new_y = 0;
     dir = FLIP_Y[dir];
-  } else if (s[BO_MAP + new_y * 10 + new_x] == 1) {
+  } else if (new_y <= 9 && s[BO_MAP + new_y * 10 + new_x] == 1) { /* jnp index clamps; rows >3 hold no bricks */
     strike_toggle = 1;
     if (!s[BO_STRIKE]) {
       r += 1.0f;

@@ -66,6 +66,10 @@ def load():
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C purejaxql_amd/csrc`).  purejaxql_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64.so (soname libamdhip64.so.7).  Import torch FIRST so
+    # our NEEDED libamdhip64.so.7 binds to that already-loaded runtime; loading /opt/rocm's copy
+    # first would put two HIP runtimes in one process (kernels then see "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
