@@ -135,6 +135,50 @@ int pqn_radam_clip_step(float *p, const float *g, float *m, float *v, int64_t n,
                         float lr_init, float lr_end, float lr_steps, float max_norm,
                         float *scratch, float *gnorm_out, void *stream);
 
+/* ---- fused MinAtar CNN Q-network (QNetwork/CNN, pqn_minatar.py:24-69) -------------- */
+/* "Kernel layout" of the CNN parameters in one flat f32 buffer: flax order
+ * (BatchNorm_0 dummy, Conv_0 kernel HWIO + bias, LayerNorm_0, Dense_0, LayerNorm_1,
+ * Dense_0 head), segment starts padded to 16 B, and the fc1 kernel W1[i][o]
+ * (1024 x 128) permuted into MFMA fragment order
+ *   idx(i,o) = ((i/16*8 + o/16)*64 + ((i%16)/4)*16 + o%16)*4 + i%4.
+ * Gradients and RAdam moments use the same layout (the update is elementwise). */
+typedef struct {
+  int32_t c, a;
+  int32_t off_bn, off_wc, off_bc, off_ln0s, off_ln0b, off_w1, off_b1, off_ln1s, off_ln1b, off_w2, off_b2;
+  int32_t total; /* floats in the buffer (>= flax parameter count; pads are zero) */
+} pqn_cnn_layout_t;
+
+int pqn_cnn_layout(int32_t c, int32_t a, pqn_cnn_layout_t *layout /* host */);
+
+/* network.apply(params, obs, train=False) on packed observations, fused with the
+ * eps-greedy draw of pqn_minatar.py:184-196 (and :227-235, :380-390).  Outputs
+ * (each nullable): q [n,A]; action [n] (eps-greedy with `key`, element e draws
+ * threefry(key,(e,0)) exactly as pqn_eps_greedy); qmax [n] = max_a q. */
+int pqn_qnet_cnn_forward(const pqn_cnn_layout_t *layout /* host */, int32_t n, const uint32_t *obs_bits,
+                         const float *theta, float *q, int32_t *action, float *qmax, float eps, uint64_t key,
+                         void *stream);
+
+/* One optimizer step of _learn_phase (pqn_minatar.py:266-297) on the fused CNN, in two halves so a
+ * multi-GPU gradient all-reduce can sit between them (env-sharded mode):
+ *   pqn_qnet_cnn_grad : value_and_grad(_loss_fn) (:271-291) for the minibatch {idx[j]}: sample j reads
+ *       obs_bits[idx[j]], action[idx[j]], target[idx[j]] (the shuffle of :299-315 is never
+ *       materialised).  Writes the flat gradient (kernel layout), loss = 0.5*mean((q_a-target)^2) and
+ *       mean(q_a) (metrics td_loss/qvals, :334-335).  nb must be a multiple of 16.
+ *   pqn_qnet_cnn_apply: optax clip_by_global_norm + radam (:159-162,292) on theta/m/v, plus the refresh
+ *       of w1b, the dgrad-fragment copy of the fc1 kernel that the backward GEMM streams.
+ *       recompute_norm=0 reuses the sums of squares pqn_qnet_cnn_grad left in workspace; pass 1 after
+ *       the gradient was modified (all-reduce).
+ * workspace: pqn_qnet_cnn_workspace_floats(layout, nb) floats, caller-owned. */
+int64_t pqn_qnet_cnn_workspace_floats(const pqn_cnn_layout_t *layout /* host */, int32_t nb);
+int pqn_qnet_cnn_grad(const pqn_cnn_layout_t *layout /* host */, int32_t nb, const int64_t *idx,
+                      const uint32_t *obs_bits, const int32_t *action, const float *target, const float *theta,
+                      const float *w1b, float *grad, const int32_t *count, float *workspace, float *loss_out,
+                      float *qv_out, void *stream);
+int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *layout /* host */, float *theta, float *w1b, const float *grad,
+                       float *m, float *v, int32_t *count, float lr_init, float lr_end, float lr_steps,
+                       float max_norm, float *workspace, float *gnorm_out, int32_t recompute_norm, void *stream);
+int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *layout /* host */, const float *theta, float *w1b, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

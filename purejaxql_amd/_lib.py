@@ -48,6 +48,13 @@ SIGNATURES = {
     "pqn_shuffle_keys": (c_int, [c_uint64, c_int32, c_void_p, c_void_p]),
     "pqn_radam_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float,
                                     c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "pqn_cnn_layout": (c_int, [c_int32, c_int32, c_void_p]),
+    "pqn_qnet_cnn_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                     c_uint64, c_void_p]),
+    "pqn_qnet_cnn_workspace_floats": (c_int64, [c_void_p, c_int32]),
+    "pqn_qnet_cnn_grad": (c_int, [c_void_p, c_int32] + [c_void_p] * 11 + [c_void_p]),
+    "pqn_qnet_cnn_apply": (c_int, [c_void_p] * 7 + [c_float] * 4 + [c_void_p, c_void_p, c_int32, c_void_p]),
+    "pqn_qnet_cnn_pack_w1b": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
                                                           int32_t *__restrict__ count, float lr_init, float lr_end,
                                                           float lr_steps, float max_norm, int nparts,
                                                           const float *__restrict__ scratch,
-                                                          float *__restrict__ gnorm_out) {
+                                                          float *__restrict__ gnorm_out, int w1_off,
+                                                          float *__restrict__ w1b) {
   __shared__ float s_part[4];
   __shared__ float s_sc[8];
   float acc = 0.0f;
@@ -210,8 +211,27 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
     const float mh = mi / bc1;
     const float vh = vi / bc2;
     const float u = rect ? r * mh / (sqrtf(vh) + 1e-8f) : mh;
-    p[i] = p[i] - lr * u;
+    const float pn = p[i] - lr * u;
+    p[i] = pn;
+    if (w1b) {  // keep the dgrad-fragment copy of the CNN fc1 kernel in step (see pqn_qnet.hip)
+      const int64_t j = i - w1_off;
+      if (j >= 0 && j < 1024 * 128) {
+        const int frag = (int)(j >> 8), ln = (int)(j >> 2) & 63, sx = (int)j & 3;
+        const int gi = frag >> 3, cb = frag & 7, kk = ln >> 4, jj = ln & 15;
+        w1b[(((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3)] = pn;
+      }
+    }
   }
+}
+
+int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
+                     float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
+                     float *w1b, int norm_pass, hipStream_t st) {
+  const int blocks = pqn_radam_blocks(n);
+  if (norm_pass) hipLaunchKernelGGL(radam_norm_kernel, dim3(blocks), dim3(256), 0, st, g, n, count, scratch);
+  hipLaunchKernelGGL(radam_apply_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, count, lr_init, lr_end,
+                     lr_steps, max_norm, blocks, scratch, gnorm_out, w1_off, w1b);
+  return pqn_check_launch("radam");
 }
 
 extern "C" int pqn_radam_clip_step(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count,
@@ -219,12 +239,6 @@ extern "C" int pqn_radam_clip_step(float *p, const float *g, float *m, float *v,
                                    float *gnorm_out, void *stream) {
   PQN_REQUIRE(p && g && m && v && count && scratch, "pqn_radam_clip_step: NULL argument");
   PQN_REQUIRE(n > 0, "pqn_radam_clip_step: n must be > 0");
-  int64_t blocks = (n + 1023) / 1024;  // 4 elements per lane
-  if (blocks > 512) blocks = 512;
-  if (blocks < 1) blocks = 1;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(radam_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, count, scratch);
-  hipLaunchKernelGGL(radam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, count, lr_init,
-                     lr_end, lr_steps, max_norm, (int)blocks, scratch, gnorm_out);
-  return pqn_check_launch("pqn_radam_clip_step");
+  return pqn_launch_radam(p, g, m, v, n, count, lr_init, lr_end, lr_steps, max_norm, scratch, gnorm_out, 0, nullptr, 1,
+                          (hipStream_t)stream);
 }

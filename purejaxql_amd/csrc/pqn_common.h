@@ -69,3 +69,12 @@ int pqn_check_launch(const char *what);
       return PQN_E_INVALID;           \
     }                                 \
   } while (0)
+
+// shared between pqn_algo.hip and pqn_qnet.hip
+inline int pqn_radam_blocks(int64_t n) {
+  int64_t b = (n + 1023) / 1024;  // 4 elements per lane
+  return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
+                     float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
+                     float *w1b, int norm_pass, hipStream_t st);

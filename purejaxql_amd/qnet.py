@@ -1,0 +1,121 @@
+"""Fused MinAtar CNN Q-network kernels (csrc/pqn_qnet.hip) -- Python binding.
+
+The kernels keep all parameters of one seed in ONE flat fp32 buffer in "kernel
+layout" (pqn_cnn_layout_t): flax parameter order, 16-B aligned segments and the
+fc1 kernel in MFMA fragment order.  `CnnKernelLayout` converts between that and
+the flax-flat order of networks.QNetwork (used for init, checkpoints and the
+oracle comparison).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+class CnnLayoutStruct(C.Structure):
+    """pqn_cnn_layout_t"""
+    _fields_ = [(n, C.c_int32) for n in ("c", "a", "off_bn", "off_wc", "off_bc", "off_ln0s", "off_ln0b", "off_w1",
+                                         "off_b1", "off_ln1s", "off_ln1b", "off_w2", "off_b2", "total")]
+
+
+class CnnKernelLayout:
+    def __init__(self, channels: int, num_actions: int):
+        lib = _lib.load()
+        self.struct = CnnLayoutStruct()
+        _lib.check(lib.pqn_cnn_layout(channels, num_actions, C.byref(self.struct)), "pqn_cnn_layout")
+        s = self.struct
+        self.c, self.a, self.total = int(s.c), int(s.a), int(s.total)
+        c, a = self.c, self.a
+        i = torch.arange(1024).view(-1, 1)
+        o = torch.arange(128).view(1, -1)
+        fc1 = (((i // 16) * 8 + o // 16) * 64 + ((i % 16) // 4) * 16 + (o % 16)) * 4 + (i % 4)
+        parts = [s.off_bn + torch.arange(2 * c), s.off_wc + torch.arange(9 * c * 16 + 48),
+                 s.off_w1 + fc1.reshape(-1), s.off_b1 + torch.arange(3 * 128),
+                 s.off_w2 + torch.arange(128 * a), s.off_b2 + torch.arange(a)]
+        self.kidx = torch.cat(parts).to(torch.int64)       # flax-flat position -> kernel-flat position
+        self.num_flax = int(self.kidx.numel())
+        assert int(torch.unique(self.kidx).numel()) == self.num_flax
+
+    def to_kernel(self, theta_flax: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros(self.total, dtype=torch.float32, device=theta_flax.device)
+        out[self.kidx.to(theta_flax.device)] = theta_flax.to(torch.float32)
+        return out
+
+    def to_flax(self, theta_k: torch.Tensor) -> torch.Tensor:
+        return theta_k[self.kidx.to(theta_k.device)]
+
+
+def cnn_forward(layout: CnnKernelLayout, obs_bits: torch.Tensor, theta_k: torch.Tensor, *, want_q: bool = True,
+                eps: Optional[float] = None, key: int = 0, q: Optional[torch.Tensor] = None,
+                action: Optional[torch.Tensor] = None, qmax: Optional[torch.Tensor] = None):
+    """q = network.apply(params, obs); optionally the eps-greedy action and max_a q in the same launch."""
+    lib = _lib.load()
+    n = obs_bits.shape[0]
+    dev = obs_bits.device
+    if want_q and q is None:
+        q = torch.empty((n, layout.a), dtype=torch.float32, device=dev)
+    if eps is not None and action is None:
+        action = torch.empty(n, dtype=torch.int32, device=dev)
+    if (eps is not None or not want_q) and qmax is None:
+        qmax = torch.empty(n, dtype=torch.float32, device=dev)
+    _lib.check(lib.pqn_qnet_cnn_forward(C.byref(layout.struct), n, _lib.ptr(obs_bits), _lib.ptr(theta_k), _lib.ptr(q),
+                                        _lib.ptr(action), _lib.ptr(qmax), float(eps or 0.0), key, _lib.stream_ptr()),
+               "pqn_qnet_cnn_forward")
+    return q, action, qmax
+
+
+class CnnTrainer:
+    """Parameters + RAdam state of one seed in kernel layout, and the fused optimizer step
+    (train_state.apply_gradients of pqn_minatar.py:289-296) = pqn_qnet_cnn_grad + pqn_qnet_cnn_apply."""
+
+    def __init__(self, layout: CnnKernelLayout, theta_flax: torch.Tensor, lr: float, max_grad_norm: float,
+                 lr_decay_steps: float = 0.0, lr_end: float = 1e-20, max_minibatch: int = 4096):
+        lib = _lib.load()
+        dev = theta_flax.device
+        self.layout = layout
+        self.theta = layout.to_kernel(theta_flax)
+        self.w1b = torch.empty(1024 * 128, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.theta)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.lr, self.lr_end, self.lr_steps, self.max_norm = float(lr), float(lr_end), float(lr_decay_steps), float(max_grad_norm)
+        self._ws_nb = 0
+        self.ws = None
+        self._ensure_ws(max_minibatch)
+        _lib.check(lib.pqn_qnet_cnn_pack_w1b(C.byref(layout.struct), _lib.ptr(self.theta), _lib.ptr(self.w1b),
+                                             _lib.stream_ptr()), "pqn_qnet_cnn_pack_w1b")
+
+    def _ensure_ws(self, nb: int):
+        if nb > self._ws_nb:
+            n = int(_lib.load().pqn_qnet_cnn_workspace_floats(C.byref(self.layout.struct), nb))
+            self.ws = torch.empty(n, dtype=torch.float32, device=self.theta.device)
+            self._ws_nb = nb
+
+    def compute_grad(self, idx: torch.Tensor, obs_bits: torch.Tensor, action: torch.Tensor, target: torch.Tensor,
+                     loss_out: Optional[torch.Tensor] = None, qv_out: Optional[torch.Tensor] = None):
+        lib = _lib.load()
+        nb = idx.numel()
+        self._ensure_ws(nb)
+        assert idx.dtype == torch.int64 and action.dtype == torch.int32 and target.dtype == torch.float32
+        _lib.check(lib.pqn_qnet_cnn_grad(C.byref(self.layout.struct), nb, _lib.ptr(idx), _lib.ptr(obs_bits),
+                                         _lib.ptr(action), _lib.ptr(target), _lib.ptr(self.theta), _lib.ptr(self.w1b),
+                                         _lib.ptr(self.grad), _lib.ptr(self.count), _lib.ptr(self.ws),
+                                         _lib.ptr(loss_out), _lib.ptr(qv_out), _lib.stream_ptr()), "pqn_qnet_cnn_grad")
+        return self.grad
+
+    def apply(self, recompute_norm: bool = False):
+        lib = _lib.load()
+        _lib.check(lib.pqn_qnet_cnn_apply(C.byref(self.layout.struct), _lib.ptr(self.theta), _lib.ptr(self.w1b),
+                                          _lib.ptr(self.grad), _lib.ptr(self.m), _lib.ptr(self.v), _lib.ptr(self.count),
+                                          self.lr, self.lr_end, self.lr_steps, self.max_norm, _lib.ptr(self.ws),
+                                          _lib.ptr(self.gnorm), 1 if recompute_norm else 0, _lib.stream_ptr()),
+                   "pqn_qnet_cnn_apply")
+
+    def theta_flax(self) -> torch.Tensor:
+        return self.layout.to_flax(self.theta)

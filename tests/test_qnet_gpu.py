@@ -1,0 +1,112 @@
+"""GPU parity tests of the fused CNN Q-network kernels against the oracle's numpy network
+(and therefore, transitively, torch fp32 autograd -- tests/test_oracle_cpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _random_bits(rng, n, c, density):
+    obs = (rng.random((n, 10, 10, c)) < density).astype(np.float32)
+    flat = obs.reshape(n, -1).astype(np.uint64)
+    ow = (((100 * c + 31) // 32) + 3) // 4 * 4
+    padded = np.zeros((n, ow * 32), np.uint64)
+    padded[:, :100 * c] = flat
+    words = (padded.reshape(n, ow, 32) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+    return obs, words
+
+
+@pytest.mark.parametrize("c,a,n", [(4, 3, 16), (4, 3, 1000), (4, 3, 4096), (6, 4, 100), (7, 3, 50), (10, 6, 33)])
+def test_cnn_forward_vs_oracle(gpu, oracle, c, a, n):
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward
+    rng = np.random.default_rng(c * 1000 + n)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    lay = CnnKernelLayout(c, a)
+    assert lay.num_flax == net.num_params
+    theta = net.init(5) + 0.05 * torch.randn(net.num_params, device=gpu)
+    theta_k = lay.to_kernel(theta)
+    torch.testing.assert_close(lay.to_flax(theta_k), theta, rtol=0, atol=0)
+    obs, words = _random_bits(rng, n, c, density=0.15)
+    bits = torch.from_numpy(words.view(np.int32)).to(gpu)
+    p = oracle.unflatten(_np(theta), oracle.cnn_shapes((10, 10, c), a))
+    q_ref = oracle.net_forward("cnn", p, obs)
+    q, action, qmax = cnn_forward(lay, bits, theta_k, eps=0.25, key=77)
+    # f32 everywhere; summation order differs (sparse conv, MFMA K-permutation): rtol 1e-4 / atol 2e-5
+    np.testing.assert_allclose(_np(q), q_ref, rtol=1e-4, atol=2e-5)
+    np.testing.assert_array_equal(_np(qmax), _np(q).max(-1))
+    oa, _ = oracle.eps_greedy(_np(q), 0.25, key=77)       # same q -> identical draws and argmax
+    np.testing.assert_array_equal(_np(action), oa)
+
+
+def test_cnn_forward_on_real_breakout_observations(gpu, oracle):
+    from purejaxql_amd.envs import make
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward
+    env, params = make("Breakout-MinAtar", device=gpu)
+    net = QNetwork("cnn", (10, 10, 4), 3, device=gpu)
+    lay = CnnKernelLayout(4, 3)
+    theta = net.init(0)
+    (obs, bits), state = env.reset(3, params, 777, want_bits=True)
+    for t in range(20):
+        a = torch.randint(0, 3, (777,), dtype=torch.int32, device=gpu)
+        (obs, bits), state, *_ = env.step(t, state, a, params, want_bits=True)
+    q, _, _ = cnn_forward(lay, bits, lay.to_kernel(theta))
+    q_torch = net.apply(net.views(theta), obs)
+    np.testing.assert_allclose(_np(q), _np(q_torch), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 16, 64), (4, 3, 128, 1000), (4, 3, 4096, 20000), (10, 6, 48, 100), (7, 3, 1024, 1024)])
+def test_cnn_grad_vs_oracle(gpu, oracle, c, a, nb, pool):
+    """value_and_grad(_loss_fn) through the fused kernels vs the oracle's numpy backward.
+    Tolerance: rtol 2e-3 + atol 1e-6*max|g| (f32, different summation orders over up to 4096x64 terms)."""
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
+    rng = np.random.default_rng(nb + c)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    lay = CnnKernelLayout(c, a)
+    theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
+    tr = CnnTrainer(lay, theta, 5e-4, 10.0, lr_decay_steps=1000.0)
+    obs, words = _random_bits(rng, pool, c, density=0.12)
+    bits = torch.from_numpy(words.view(np.int32)).to(gpu)
+    action = rng.integers(0, a, pool).astype(np.int32)
+    target = rng.standard_normal(pool).astype(np.float32)
+    idx = rng.permutation(pool)[:nb] if pool >= nb else rng.integers(0, pool, nb)
+    loss_t = torch.zeros(1, device=gpu)
+    qv_t = torch.zeros(1, device=gpu)
+    g = tr.compute_grad(torch.from_numpy(idx.astype(np.int64)).to(gpu), bits, torch.from_numpy(action).to(gpu),
+                        torch.from_numpy(target).to(gpu), loss_t, qv_t)
+    shapes = oracle.cnn_shapes((10, 10, c), a)
+    p = oracle.unflatten(_np(theta), shapes)
+    lo, chosen, g_ref = oracle.net_loss_grad("cnn", p, shapes, obs[idx], action[idx], target[idx])
+    assert abs(float(loss_t) - lo) <= 1e-4 * max(1.0, abs(lo))
+    assert abs(float(qv_t) - chosen.mean()) <= 1e-4
+    g_flax = _np(lay.to_flax(g))
+    np.testing.assert_allclose(g_flax, g_ref, rtol=2e-3, atol=1e-6 * np.abs(g_ref).max() + 1e-9)
+    pads = torch.ones(lay.total, dtype=torch.bool)
+    pads[lay.kidx] = False
+    assert float(g[pads.to(gpu)].abs().sum()) == 0.0
+    # optimizer half: clip + RAdam in kernel layout == oracle step on the flax-flat vector
+    th = _np(theta).copy()
+    m = np.zeros_like(th)
+    v = np.zeros_like(th)
+    for step in range(3):
+        if step:
+            g_flax = _np(lay.to_flax(tr.compute_grad(torch.from_numpy(idx.astype(np.int64)).to(gpu), bits,
+                                                     torch.from_numpy(action).to(gpu), torch.from_numpy(target).to(gpu))))
+        tr.apply()
+        lr = oracle.linear_schedule(5e-4, 1e-20, 1000.0, step)
+        gn = oracle.radam_clip_step(th, g_flax, m, v, step, np.float32(lr), 10.0)
+        assert abs(float(tr.gnorm[0]) - gn) <= 1e-5 * gn
+        np.testing.assert_allclose(_np(tr.theta_flax()), th, rtol=1e-5, atol=1e-7)
+    # the dgrad copy of the fc1 kernel stays in step with theta
+    w1 = _np(tr.theta_flax())[2 * c + 9 * c * 16 + 48:][:1024 * 128].reshape(1024, 128)
+    i = np.arange(1024)[:, None]
+    o = np.arange(128)[None, :]
+    addr = (((o // 16) * 64 + i // 16) * 64 + ((o % 16) // 4) * 16 + (i % 16)) * 4 + (o % 4)
+    np.testing.assert_array_equal(_np(tr.w1b)[addr], w1)
