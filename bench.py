@@ -137,7 +137,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Breakout-MinAtar PQN full loop, NUM_ENVS={cfg['NUM_ENVS']} NUM_STEPS={cfg['NUM_STEPS']} "
                                    f"NUM_MINIBATCHES={cfg['NUM_MINIBATCHES']} NUM_EPOCHS={cfg['NUM_EPOCHS']} per GPU",
-                       "seeds_per_gpu": 1, "parallelism": f"{args.mode}x{world}",
+                       "seeds_per_gpu": 1, "backend": train.backend, "parallelism": f"{args.mode}x{world}",
                        "loop_tflops": sps * LOOP_FLOP / 1e12, "loop_frac_f32_peak": sps * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS},
             "roofline": roof,
         }

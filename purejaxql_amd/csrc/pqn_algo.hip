@@ -226,11 +226,15 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
 
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
                      float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
-                     float *w1b, int norm_pass, hipStream_t st) {
+                     float *w1b, int norm_pass, int nparts, hipStream_t st) {
+  // nparts: number of sum-of-squares partials already in scratch when norm_pass == 0
   const int blocks = pqn_radam_blocks(n);
-  if (norm_pass) hipLaunchKernelGGL(radam_norm_kernel, dim3(blocks), dim3(256), 0, st, g, n, count, scratch);
+  if (norm_pass) {
+    hipLaunchKernelGGL(radam_norm_kernel, dim3(blocks), dim3(256), 0, st, g, n, count, scratch);
+    nparts = blocks;
+  }
   hipLaunchKernelGGL(radam_apply_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, count, lr_init, lr_end,
-                     lr_steps, max_norm, blocks, scratch, gnorm_out, w1_off, w1b);
+                     lr_steps, max_norm, nparts, scratch, gnorm_out, w1_off, w1b);
   return pqn_check_launch("radam");
 }
 
@@ -239,6 +243,6 @@ extern "C" int pqn_radam_clip_step(float *p, const float *g, float *m, float *v,
                                    float *gnorm_out, void *stream) {
   PQN_REQUIRE(p && g && m && v && count && scratch, "pqn_radam_clip_step: NULL argument");
   PQN_REQUIRE(n > 0, "pqn_radam_clip_step: n must be > 0");
-  return pqn_launch_radam(p, g, m, v, n, count, lr_init, lr_end, lr_steps, max_norm, scratch, gnorm_out, 0, nullptr, 1,
+  return pqn_launch_radam(p, g, m, v, n, count, lr_init, lr_end, lr_steps, max_norm, scratch, gnorm_out, 0, nullptr, 1, 0,
                           (hipStream_t)stream);
 }

@@ -77,4 +77,4 @@ inline int pqn_radam_blocks(int64_t n) {
 }
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
                      float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
-                     float *w1b, int norm_pass, hipStream_t st);
+                     float *w1b, int norm_pass, int nparts, hipStream_t st);

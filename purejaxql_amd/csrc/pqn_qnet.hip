@@ -21,6 +21,8 @@
 // dimension permuted so one lane's float4 feeds 4 consecutive MFMAs, and (b) the
 // accumulator layout in which the weight-gradient GEMM produces dW1, so
 // gradient, moments and parameters share one layout and RAdam stays elementwise.
+#include <stdlib.h>
+
 #include "pqn_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -122,6 +124,8 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid) {
 // wave w owns column blocks 2w, 2w+1.  Operand maps (cdna guide 3): A[i=l&15][k=l>>4],
 // B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+reg.
 // ---------------------------------------------------------------------------
+// ablate: 0 = normal; 2 = no global B loads; 3 = no MFMA (loads only).  Profiling hook.
+template <int ABL = 0>
 PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const int cb0 = 2 * wave, cb1 = cb0 + 1;
@@ -141,9 +145,14 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) 
     for (int i = 0; i < PF; ++i) {
       const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 16 * (g + i));
       const f32x4 x0 = b0[i], x1 = b1[i];
-      if (g + i + PF < QN_H1 / 16) {
+      if (ABL != 2 && g + i + PF < QN_H1 / 16) {
         b0[i] = wp[((g + i + PF) * 8 + cb0) * 64 + lane];
         b1[i] = wp[((g + i + PF) * 8 + cb1) * 64 + lane];
+      }
+      if (ABL == 3) {
+        acc0 += x0 + a;
+        acc1 += x1;
+        continue;
       }
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
@@ -246,7 +255,8 @@ template <int C>
 __global__ __launch_bounds__(256) void qnet_cnn_fwd_kernel(int n, const uint32_t *__restrict__ obs_bits,
                                                            const float *__restrict__ theta, pqn_cnn_layout_t L,
                                                            float *__restrict__ q_out, int32_t *__restrict__ action,
-                                                           float *__restrict__ qmax, float eps, uint64_t key) {
+                                                           float *__restrict__ qmax, float eps, uint64_t key,
+                                                           int ablate) {
   using Cfg = CnnCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const CnnSmem s = carve_smem<C>(smem_raw);
@@ -259,9 +269,11 @@ __global__ __launch_bounds__(256) void qnet_cnn_fwd_kernel(int n, const uint32_t
   }
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;  // b[w+1] guard word
   __syncthreads();
-  phase1_conv<C>(s, tid);
+  if (ablate != 1) phase1_conv<C>(s, tid);
   __syncthreads();
-  phase2_fc1(s, theta + L.off_w1, tid);
+  if (ablate == 0 || ablate == 1) phase2_fc1<0>(s, theta + L.off_w1, tid);
+  else if (ablate == 2) phase2_fc1<2>(s, theta + L.off_w1, tid);
+  else if (ablate == 3) phase2_fc1<3>(s, theta + L.off_w1, tid);
   __syncthreads();
   float q[QN_MAXA], h2[8], xh[8], rstd;
   phase3_head(s, theta, L, tid, q, h2, xh, rstd);
@@ -344,7 +356,7 @@ template <int C>
 __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, const float *__restrict__ w1b,
-    pqn_cnn_layout_t L, float inv_b, float *__restrict__ dzT, float *__restrict__ gpart) {
+    pqn_cnn_layout_t L, float inv_b, float *__restrict__ dzT, float *__restrict__ gpart, int ablate) {
   using Cfg = CnnCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const TrainSmem ts = carve_train_smem<C>(smem_raw);
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
   // ---- P1..P3: forward ---------------------------------------------------------------------
   phase1_conv<C>(s, tid);
   __syncthreads();
-  phase2_fc1(s, theta + L.off_w1, tid);
+  phase2_fc1<0>(s, theta + L.off_w1, tid);
   __syncthreads();
   float q[QN_MAXA], h2[8], xh[8], rstd1;
   phase3_head(s, theta, L, tid, q, h2, xh, rstd1);
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
     gp[o_l + 1] = (ts.red[1] + ts.red[49]) + (ts.red[97] + ts.red[145]);
   }
   // ---- P4: dgrad  dh1[m][i] = sum_o dz[m][o] W1[i][o]  (A = dz tile, B = W1 in dgrad fragment order) ----
-  {
+  if (!(ablate & 1)) {
     const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
     f32x4 afr[8];
 #pragma unroll
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
   }
   __syncthreads();
   // ---- P5: LN0 backward per (sample, position); conv bias / ln0 grads; dx tile in place ------------
-  {
+  if (!(ablate & 2)) {
     float gsc[16], gbi[16], gbc[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) { gsc[o] = 0.f; gbi[o] = 0.f; gbc[o] = 0.f; }
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
   // ---- P6: conv weight gradient, sparse over the set cells of each channel plane --------------------
   //   dWc[ky][kx][c][o] = 1/255 * sum_m sum_{cell in plane c(m)} dx[m][cell - (ky,kx)][o]
   // work item = (k, sample quarter); 16 lanes = 16 output channels; partials [KW][4][16] in LDS.
-  {
+  if (!(ablate & 4)) {
     float *part = ts.scr;
     const int o = tid & 15;
     for (;;) {
@@ -693,7 +705,13 @@ __global__ __launch_bounds__(256) void qnet_cnn_wgrad_kernel(int nb, const int64
 // ---------------------------------------------------------------------------
 // T3a: fold partials into the flat gradient (kernel layout) and emit per-block sums of
 // squares + the *count snapshot for radam_apply (same scratch protocol as radam_norm_kernel).
+// Blocks [0, QR_W1_BLOCKS): fc1 region, float4 per lane, sum over the K-splits.
+// Remaining blocks: one WAVE per "small" element, lanes stride over the tiles, fixed-order tree.
 // ---------------------------------------------------------------------------
+#define QR_W1_BLOCKS (QN_H1 * QN_HID / 1024)
+
+__host__ __device__ inline int grad_reduce_blocks(int total) { return QR_W1_BLOCKS + (total - QN_H1 * QN_HID + 3) / 4; }
+
 __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t L, int ntiles, int nks, int rec,
                                                                const float *__restrict__ gpart,
                                                                const float *__restrict__ wpart, float *__restrict__ grad,
@@ -701,41 +719,52 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
                                                                float *__restrict__ scratch, float *__restrict__ loss_out,
                                                                float *__restrict__ qv_out, float inv_b) {
   __shared__ float s_part[4];
-  const int c = L.c;
-  const int convblk = 9 * c * 16 + 48;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ss = 0.0f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < L.total; i += gridDim.x * 256) {
-    float g = 0.0f;
-    if (i >= L.off_w1 && i < L.off_w1 + QN_H1 * QN_HID) {
-      const int j = i - L.off_w1;
-      for (int k = 0; k < nks; ++k) g += wpart[(size_t)k * QN_H1 * QN_HID + j];
-    } else {
-      int r = -1;  // index into the small record
+  if (blockIdx.x < QR_W1_BLOCKS) {
+    const int j4 = blockIdx.x * 256 + threadIdx.x;  // float4 index inside the fc1 region
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nks; ++k) g += reinterpret_cast<const f32x4 *>(wpart + (size_t)k * QN_H1 * QN_HID)[j4];
+    reinterpret_cast<f32x4 *>(grad + L.off_w1)[j4] = g;
+    ss = fmaf(g.x, g.x, fmaf(g.y, g.y, fmaf(g.z, g.z, g.w * g.w)));
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+  } else {
+    const int sidx = (blockIdx.x - QR_W1_BLOCKS) * 4 + wave;  // index among the non-fc1 elements
+    const int i = sidx < L.off_w1 ? sidx : sidx + QN_H1 * QN_HID;
+    if (i < L.total) {
+      const int convblk = 9 * L.c * 16 + 48;
+      int r = -1;  // index into the small record (-1: dummy BatchNorm / padding -> zero gradient)
       if (i >= L.off_wc && i < L.off_wc + convblk) r = i - L.off_wc;
       else if (i >= L.off_b1 && i < L.off_b1 + 384) r = convblk + (i - L.off_b1);
       else if (i >= L.off_w2 && i < L.off_w2 + 128 * L.a) r = convblk + 384 + (i - L.off_w2);
       else if (i >= L.off_b2 && i < L.off_b2 + L.a) r = convblk + 384 + 128 * L.a + (i - L.off_b2);
+      float g = 0.0f;
       if (r >= 0)
-        for (int t = 0; t < ntiles; ++t) g += gpart[(size_t)t * rec + r];
+        for (int t = lane; t < ntiles; t += 64) g += gpart[(size_t)t * rec + r];
+      for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off, 64);
+      if (lane == 0) {
+        grad[i] = g;
+        ss = g * g;
+      }
     }
-    grad[i] = g;
-    ss = fmaf(g, g, ss);
-  }
-  for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    scratch[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    if (blockIdx.x == 0) {
-      reinterpret_cast<int32_t *>(scratch)[1023] = *count;
+    if (blockIdx.x == QR_W1_BLOCKS && wave == 0) {  // metrics td_loss / qvals (pqn_minatar.py:334-335)
       float l = 0.f, qv = 0.f;
-      for (int t = 0; t < ntiles; ++t) {
+      for (int t = lane; t < ntiles; t += 64) {
         l += gpart[(size_t)t * rec + rec - 2];
         qv += gpart[(size_t)t * rec + rec - 1];
       }
-      if (loss_out) *loss_out = l * inv_b;
-      if (qv_out) *qv_out = qv * inv_b;
+      for (int off = 32; off > 0; off >>= 1) { l += __shfl_down(l, off, 64); qv += __shfl_down(qv, off, 64); }
+      if (lane == 0) {
+        if (loss_out) *loss_out = l * inv_b;
+        if (qv_out) *qv_out = qv * inv_b;
+      }
     }
+  }
+  if (lane == 0) s_part[wave] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    scratch[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (blockIdx.x == 0) reinterpret_cast<int32_t *>(scratch)[1023] = *count;
   }
 }
 
@@ -776,8 +805,9 @@ static int launch_fwd(int n, const uint32_t *bits, const float *theta, const pqn
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
+  static const int ablate = getenv("PQN_ABLATE") ? atoi(getenv("PQN_ABLATE")) : 0;  // profiling only
   hipLaunchKernelGGL((qnet_cnn_fwd_kernel<C>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(256), smem, st, n, bits, theta, L,
-                     q, action, qmax, eps, key);
+                     q, action, qmax, eps, key, ablate);
   return pqn_check_launch("pqn_qnet_cnn_forward");
 }
 
@@ -817,11 +847,12 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     attr_set = true;
   }
   const float inv_b = 1.0f / (float)nb;
+  static const int ablate = getenv("PQN_ABLATE_TRAIN") ? atoi(getenv("PQN_ABLATE_TRAIN")) : 0;  // profiling only
   hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles), dim3(256), smem1, st, nb, idx, bits, action, target,
-                     theta, w1b, L, inv_b, dzT, gpart);
+                     theta, w1b, L, inv_b, dzT, gpart, ablate);
   hipLaunchKernelGGL((qnet_cnn_wgrad_kernel<C>), dim3(32, nks), dim3(256), smem2, st, nb, idx, bits, theta, L, dzT,
                      wpart);
-  hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(pqn_radam_blocks(L.total)), dim3(256), 0, st, L, ntiles, nks, rec,
+  hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total)), dim3(256), 0, st, L, ntiles, nks, rec,
                      gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b);
   return pqn_check_launch("pqn_qnet_cnn_grad");
 }
@@ -856,7 +887,7 @@ extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float
                                   void *stream) {
   PQN_REQUIRE(L && theta && w1b && grad && m && v && count && workspace, "pqn_qnet_cnn_apply: NULL argument");
   return pqn_launch_radam(theta, grad, m, v, L->total, count, lr_init, lr_end, lr_steps, max_norm, workspace, gnorm_out,
-                          L->off_w1, w1b, recompute_norm, (hipStream_t)stream);
+                          L->off_w1, w1b, recompute_norm, grad_reduce_blocks(L->total), (hipStream_t)stream);
 }
 
 __global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict__ w1b) {

@@ -56,12 +56,18 @@ def derive_config(config: Dict[str, Any]) -> Dict[str, Any]:
 
 class _Rollout:
     """Time-major rollout record of one update: the reference's `Transition`
-    (pqn_minatar.py:72-79) with next_obs folded into obs[T] and q_val reduced to
-    max_a q (its only consumer is :249)."""
+    (pqn_minatar.py:72-79) with next_obs folded into slot T of the observation buffer and q_val
+    reduced to max_a q (its only consumer is :249).  MinAtar runs keep the observation bit-packed
+    (64 B instead of 1600 B per Breakout frame); flat-obs envs keep f32."""
 
-    def __init__(self, t, n, obs_shape, device):
+    def __init__(self, t, n, obs_shape, obs_words, device):
         f32, i32 = torch.float32, torch.int32
-        self.obs = torch.empty((t + 1, n, *obs_shape), dtype=f32, device=device)
+        if obs_words:
+            self.bits = torch.empty((t + 1, n, obs_words), dtype=i32, device=device)
+            self.obs = None
+        else:
+            self.bits = None
+            self.obs = torch.empty((t + 1, n, *obs_shape), dtype=f32, device=device)
         self.action = torch.empty((t, n), dtype=i32, device=device)
         self.reward = torch.empty((t, n), dtype=f32, device=device)
         self.done = torch.empty((t, n), dtype=torch.uint8, device=device)
@@ -71,6 +77,84 @@ class _Rollout:
         self.rel = torch.empty((t, n), dtype=i32, device=device)
         self.ts = torch.empty((t, n), dtype=i32, device=device)
         self.target = torch.empty((t, n), dtype=f32, device=device)
+        self.last_q = torch.empty(n, dtype=f32, device=device)
+
+
+class _TorchPolicy:
+    """Q-network through torch ops + autograd (plumbing path; the MLP of pqn_gymnax.py:29-58, and the
+    CNN when config["_BACKEND"] == "torch").  Parameters live in one flat buffer, optimizer = HIP RAdam."""
+    packed = False
+
+    def __init__(self, network, theta, config, lr_steps, grad_hook):
+        self.net = network
+        self.fp = FlatParams(network, theta)
+        self.opt = ops.FlatRAdam(self.fp.theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps)
+        self.grad_hook = grad_hook
+
+    def q_values(self, obs):
+        with torch.no_grad():
+            return self.net.apply(self.fp.leaves, obs)
+
+    def act(self, obs, eps, key, action, qmax):
+        ops.eps_greedy(self.q_values(obs), eps, key, action, qmax)
+
+    def max_q(self, obs, out):
+        out.copy_(self.q_values(obs).max(dim=-1).values)
+
+    def sgd_step(self, idx, obs_flat, act_flat, tgt_flat, loss_out, qv_out):
+        self.fp.zero_grad()
+        qv = self.net.apply(self.fp.leaves, obs_flat[idx])
+        chosen = qv.gather(1, act_flat[idx].to(torch.int64).unsqueeze(1)).squeeze(1)
+        loss = 0.5 * torch.square(chosen - tgt_flat[idx]).mean()
+        loss.backward()
+        if self.grad_hook is not None:
+            self.grad_hook(self.fp.grad)
+        self.opt.step(self.fp.grad)
+        loss_out.copy_(loss.detach())
+        qv_out.copy_(chosen.detach().mean())
+
+    def theta_flax(self):
+        return self.fp.theta
+
+    def opt_state(self):
+        return {"opt_count": self.opt.count, "opt_mu": self.opt.m, "opt_nu": self.opt.v}
+
+
+class _FusedCnnPolicy:
+    """The MinAtar CNN through the fused HIP kernels (csrc/pqn_qnet.hip): packed observations in,
+    forward + eps-greedy in one launch, forward+backward+RAdam in four."""
+    packed = True
+
+    def __init__(self, network, theta, config, lr_steps, grad_hook, max_mb):
+        from .qnet import CnnKernelLayout, CnnTrainer, cnn_forward
+        self.net = network
+        self.layout = CnnKernelLayout(network.obs_shape[-1], network.action_dim)
+        self.tr = CnnTrainer(self.layout, theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps,
+                             max_minibatch=max_mb)
+        self.fwd = cnn_forward
+        self.grad_hook = grad_hook
+
+    def q_values(self, bits):
+        return self.fwd(self.layout, bits, self.tr.theta)[0]
+
+    def act(self, bits, eps, key, action, qmax):
+        self.fwd(self.layout, bits, self.tr.theta, want_q=False, eps=eps, key=key, action=action, qmax=qmax)
+
+    def max_q(self, bits, out):
+        self.fwd(self.layout, bits, self.tr.theta, want_q=False, qmax=out)
+
+    def sgd_step(self, idx, bits_flat, act_flat, tgt_flat, loss_out, qv_out):
+        self.tr.compute_grad(idx, bits_flat, act_flat, tgt_flat, loss_out, qv_out)
+        if self.grad_hook is not None:
+            self.grad_hook(self.tr.grad)
+        self.tr.apply(recompute_norm=self.grad_hook is not None)
+
+    def theta_flax(self):
+        return self.tr.theta_flax()
+
+    def opt_state(self):
+        return {"opt_count": self.tr.count, "opt_mu": self.tr.m, "opt_nu": self.tr.v,
+                "kernel_layout": self.layout}
 
 
 def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: Optional[Callable] = None):
@@ -105,9 +189,14 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
     rew_scale = float(config.get("REW_SCALE", 1))
     test_on = bool(config.get("TEST_DURING_TRAINING", False))
     sp = _lib.stream_ptr
+    backend = config.get("_BACKEND")
+    if backend is None:  # fused kernels need the LayerNorm CNN and 16 | minibatch
+        backend = "fused" if (kind == "cnn" and config["NORM_TYPE"] == "layer_norm"
+                              and not config.get("NORM_INPUT", False) and B % 16 == 0) else "torch"
+    packed = backend == "fused"
 
-    def env_step_into(key, words, action, obs_out, r, d, disc, rer, rel, ts):
-        out = _lib.StepOut(obs=_lib.ptr(obs_out), obs_bits=None, reward=_lib.ptr(r), done=_lib.ptr(d),
+    def env_step_into(key, words, action, obs_out, bits_out, r, d, disc, rer, rel, ts):
+        out = _lib.StepOut(obs=_lib.ptr(obs_out), obs_bits=_lib.ptr(bits_out), reward=_lib.ptr(r), done=_lib.ptr(d),
                            discount=_lib.ptr(disc), returned_episode_returns=_lib.ptr(rer),
                            returned_episode_lengths=_lib.ptr(rel), timestep=_lib.ptr(ts))
         _lib.check(lib.pqn_env_step(base_env.env_id, words.shape[1], key, _lib.ptr(words), _lib.ptr(words),
@@ -134,13 +223,11 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                            device=dev)
         theta = config.get("_INIT_PARAMS")
         theta = network.init(K_init) if theta is None else theta.to(dev, torch.float32).clone()
-        fp = FlatParams(network, theta)
-        opt = ops.FlatRAdam(fp.theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps)
+        if packed:
+            policy = _FusedCnnPolicy(network, theta, config, lr_steps, grad_hook, B)
+        else:
+            policy = _TorchPolicy(network, theta, config, lr_steps, grad_hook)
         counters = {"timesteps": 0, "n_updates": 0, "grad_steps": 0}
-
-        def q_values(obs):
-            with torch.no_grad():
-                return network.apply(fp.leaves, obs)
 
         # EVAL (pqn_minatar.py:371-413)
         test_runs = [0]
@@ -151,13 +238,20 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             k = _lib.fold_in(K_test, test_runs[0])
             test_runs[0] += 1
             n_t, steps = int(config["TEST_NUM_ENVS"]), int(config["TEST_NUM_STEPS"])
-            obs, state = env.reset(_lib.fold_in(k, 0), env_params, n_t)
+            obs, state = env.reset(_lib.fold_in(k, 0), env_params, n_t, want_obs=not packed, want_bits=packed)
+            if packed:
+                obs = obs[1]
+            action = torch.empty(n_t, dtype=torch.int32, device=dev)
+            qm = torch.empty(n_t, dtype=torch.float32, device=dev)
             sums = {kk: torch.zeros((), dtype=torch.float64, device=dev) for kk in INFO_KEYS}
             cnt = torch.zeros((), dtype=torch.float64, device=dev)
             for t in range(steps):
                 sk = _lib.fold_in(k, 1 + t)
-                action, _ = ops.eps_greedy(q_values(obs), config["EPS_TEST"], sk)
-                obs, state, _r, done, info = env.step(sk, state, action, env_params, inplace=True)
+                policy.act(obs, config["EPS_TEST"], sk, action, qm)
+                obs, state, _r, done, info = env.step(sk, state, action, env_params, inplace=True,
+                                                      want_obs=not packed, want_bits=packed)
+                if packed:
+                    obs = obs[1]
                 dm = done.to(torch.float64)
                 cnt += dm.sum()
                 for kk in INFO_KEYS:
@@ -168,10 +262,11 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         tm_box = [get_test_metrics()]
 
         # reset exploration envs (pqn_minatar.py:418-419)
-        ro = _Rollout(T, N, obs_shape, dev)
-        obs0, state = env.reset(K_reset, env_params, N)
+        ro = _Rollout(T, N, obs_shape, base_env.obs_words if packed else 0, dev)
+        obuf = ro.bits if packed else ro.obs
+        o0, state = env.reset(K_reset, env_params, N, want_obs=not packed, want_bits=packed)
         words = state.words
-        ro.obs[0].copy_(obs0)
+        obuf[0].copy_(o0[1] if packed else o0)
 
         names = ["env_step", "update_steps", "grad_steps", "td_loss", "qvals"] + list(INFO_KEYS)
         if kind == "cnn":
@@ -183,15 +278,16 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         loss_buf = torch.zeros(n_mb_total, dtype=torch.float32, device=dev)
         qv_buf = torch.zeros(n_mb_total, dtype=torch.float32, device=dev)
         test_period = int(NUM_UPDATES * config["TEST_INTERVAL"]) if test_on else 0
+        flat_shape = (T * N, base_env.obs_words) if packed else (T * N, *obs_shape)
 
         def update(u: int):
             # SAMPLE PHASE (_step_env, pqn_minatar.py:181-220)
             eps = eps_scheduler(counters["n_updates"])
             for t in range(T):
                 sk = _lib.fold_in(K_roll, u * T + t)
-                q = q_values(ro.obs[t])
-                ops.eps_greedy(q, eps, sk, ro.action[t], ro.qmax[t])
-                env_step_into(sk, words, ro.action[t], ro.obs[t + 1], ro.reward[t], ro.done[t], ro.discount[t],
+                policy.act(obuf[t], eps, sk, ro.action[t], ro.qmax[t])
+                env_step_into(sk, words, ro.action[t], None if packed else ro.obs[t + 1],
+                              ro.bits[t + 1] if packed else None, ro.reward[t], ro.done[t], ro.discount[t],
                               ro.rer[t], ro.rel[t], ro.ts[t])
             counters["timesteps"] += T * N
             info_means = {
@@ -203,31 +299,23 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 ro.reward.mul_(rew_scale)      # REW_SCALE*reward (:205); LogWrapper saw the raw reward
 
             # Q(lambda) TARGETS (pqn_minatar.py:227-260)
-            last_q = q_values(ro.obs[T]).max(dim=-1).values.contiguous()
-            ops.q_lambda(ro.reward, ro.done, ro.qmax, last_q, gamma, lam, quirk=True, target=ro.target)
+            policy.max_q(obuf[T], ro.last_q)
+            ops.q_lambda(ro.reward, ro.done, ro.qmax, ro.last_q, gamma, lam, quirk=True, target=ro.target)
 
-            # NETWORKS UPDATE (pqn_minatar.py:263-327)
-            obs_flat = ro.obs[:T].reshape(T * N, *obs_shape)
-            act_flat = ro.action.reshape(-1).to(torch.int64)
+            # NETWORKS UPDATE (pqn_minatar.py:263-327): one shared permutation per epoch (:299-315),
+            # consumed as a gather index -- the shuffled copies are never materialised
+            obs_flat = obuf[:T].reshape(flat_shape)
+            act_flat = ro.action.reshape(-1)
             tgt_flat = ro.target.reshape(-1)
             i_mb = 0
             for ep in range(EPOCHS):
                 perm = ops.shuffle_permutation(_lib.fold_in(K_shuf, u * EPOCHS + ep), T * N, dev)
                 for mb in range(MB):
-                    idx = perm[mb * B:(mb + 1) * B]
-                    fp.zero_grad()
-                    qv = network.apply(fp.leaves, obs_flat[idx])
-                    chosen = qv.gather(1, act_flat[idx].unsqueeze(1)).squeeze(1)
-                    loss = 0.5 * torch.square(chosen - tgt_flat[idx]).mean()
-                    loss.backward()
-                    if grad_hook is not None:
-                        grad_hook(fp.grad)
-                    opt.step(fp.grad)
+                    policy.sgd_step(perm[mb * B:(mb + 1) * B], obs_flat, act_flat, tgt_flat,
+                                    loss_buf[i_mb:i_mb + 1], qv_buf[i_mb:i_mb + 1])
                     counters["grad_steps"] += 1
-                    loss_buf[i_mb] = loss.detach()
-                    qv_buf[i_mb] = chosen.detach().mean()
                     i_mb += 1
-            ro.obs[0].copy_(ro.obs[T])  # carry last_obs into the next update
+            obuf[0].copy_(obuf[T])  # carry last_obs into the next update
 
             counters["n_updates"] += 1
             m = {"env_step": counters["timesteps"], "update_steps": counters["n_updates"],
@@ -246,9 +334,10 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 cb(u, m)
 
         def finish():
-            runner_state = {"params": network.views(fp.theta), "theta": fp.theta, "opt_count": opt.count,
-                            "opt_mu": opt.m, "opt_nu": opt.v, "env_state": words, "last_obs": ro.obs[0],
-                            "test_metrics": tm_box[0], "network": network, **counters}
+            theta_f = policy.theta_flax()
+            runner_state = {"params": network.views(theta_f), "theta": theta_f, "env_state": words,
+                            "last_obs": obuf[0], "test_metrics": tm_box[0], "network": network, "backend": backend,
+                            **policy.opt_state(), **counters}
             return {"runner_state": runner_state, "metrics": metrics}
 
         return update, finish
@@ -261,6 +350,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
 
     train.make_runner = make_runner
     train.config = config
+    train.backend = backend
     return train
 
 

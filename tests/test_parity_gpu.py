@@ -231,20 +231,28 @@ def test_product_network_vs_oracle_network(gpu, oracle):
 
 
 @pytest.mark.parametrize("alg,env_name,extra", [
-    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
+                                         "_BACKEND": "fused"}),
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
+                                         "_BACKEND": "torch"}),
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 1024, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
     ("pqn_cartpole", "CartPole-v1", {"NUM_ENVS": 4, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
 ])
 def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     """Whole loop (rollout + Q(lambda) + minibatch updates) vs the oracle loop from the same
-    initial parameters and keys, 3 updates.  Tolerances: params rtol 2e-3 / atol 2e-5
-    (fp32 GEMM summation order differs between rocBLAS and numpy), scalar metrics 1e-3."""
+    initial parameters and keys.  Tolerances: params rtol 2e-3 / atol 2e-5 (fp32 summation order
+    differs between MFMA / rocBLAS / numpy), scalar metrics 1e-3.  Small configs run 3 updates;
+    the 1024-env config runs 1: once ~1e5 greedy decisions have been taken, a 1e-6 difference in
+    q flips an argmax somewhere and the two trajectories legitimately part ways (RL is chaotic),
+    so multi-update comparisons at that size measure chaos, not correctness."""
+    n_upd = 3 if extra["NUM_ENVS"] <= 64 else 1
     from purejaxql_amd.config_loader import flatten, load_config
     from purejaxql_amd.pqn import make_train, seed_keys
     cfg = flatten(load_config([f"+alg={alg}"]))
     cfg.update(extra)
-    cfg.update({"ENV_NAME": env_name, "TOTAL_TIMESTEPS": 3 * cfg["NUM_ENVS"] * cfg["NUM_STEPS"],
+    cfg.update({"ENV_NAME": env_name, "TOTAL_TIMESTEPS": n_upd * cfg["NUM_ENVS"] * cfg["NUM_STEPS"],
                 "TOTAL_TIMESTEPS_DECAY": 30 * cfg["NUM_ENVS"] * cfg["NUM_STEPS"], "TEST_DURING_TRAINING": False})
-    ocfg = dict(cfg)
+    ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
     key = seed_keys(0, 1)[0]
     torch.manual_seed(0)
     # shared initial parameters
@@ -258,10 +266,12 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     assert net.num_params == n_params
     theta0 = net.init(123)
     cfg["_INIT_PARAMS"] = theta0
-    out = make_train(cfg, device="cuda:0")(key)
+    train = make_train(cfg, device="cuda:0")
+    assert train.backend == extra.get("_BACKEND", "fused" if kind == "cnn" else "torch")
+    out = train(key)
     oout = otrain(key, _np(theta0))
-    assert cfg["NUM_UPDATES"] == 3
-    for u in range(3):
+    assert cfg["NUM_UPDATES"] == n_upd
+    for u in range(n_upd):
         om = oout["metrics"][u]
         for k in ("env_step", "update_steps", "grad_steps"):
             assert float(out["metrics"][k][u]) == om[k]
