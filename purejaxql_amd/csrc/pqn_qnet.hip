@@ -27,13 +27,17 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define QN_TILE 16        // samples per workgroup
+#define QN_TILE 16        // samples per workgroup (= one MFMA M-tile)
+#define QN_WAVES 8        // 512-thread workgroups: 2 waves per SIMD so MFMA / VALU / loads of different waves overlap
+#define QN_THREADS (64 * QN_WAVES)
+#define QN_SPW (QN_TILE / QN_WAVES)   // samples owned by one wave in the per-sample phases
 #define QN_H1 1024        // conv features (8*8*16)
 #define QN_H1S 1032       // LDS row stride of the h1 tile (floats): conflict-free ds_read_b128
 #define QN_HID 128
 #define QN_ZS 132         // LDS row stride of the z tile
 #define QN_LN_EPS 1e-6f   // flax nn.LayerNorm default
 #define QN_MAXA 8
+#define QN_STG 20        // floats per staged point (16 + pad: conflict-free ds_read_b128 across lanes)
 
 template <int C>
 struct CnnCfg {
@@ -46,76 +50,142 @@ struct CnnSmem {
   float *h1;      // [QN_TILE][QN_H1S]
   float *z;       // [QN_TILE][QN_ZS]
   float *wc;      // [KW][16] conv kernel, then bias[16], ln0 scale[16], ln0 bias[16]
+  float *stg;     // [QN_WAVES][64 points][QN_STG] MFMA-layout -> point-per-lane transposition buffer
   uint32_t *bits; // [QN_TILE][OW]
 };
 
-PQN_D float rsqrt_exact(float x) { return 1.0f / sqrtf(x); }
+// v_rsq_f32 (1 ulp) + one Newton step: ~1e-7 relative, a handful of VALU ops instead of the
+// ~25-instruction IEEE sqrt+divide expansion.
+PQN_D float rsqrt_exact(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  const float h = 0.5f * x * y;
+  return fmaf(y, fmaf(-h, y, 0.5f), y);
+}
+
+// all-reduce sum over each 16-lane row with DPP row rotates (VALU speed, no LDS crossbar).
+// Rotating by half the remaining period is a butterfly: every lane ends with bit-identical sums.
+template <int N>
+PQN_D float row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+PQN_D float group16_sum(float v) {
+  v += row_ror<8>(v);
+  v += row_ror<4>(v);
+  v += row_ror<2>(v);
+  v += row_ror<1>(v);
+  return v;
+}
 
 // ---------------------------------------------------------------------------
-// phase 1: conv (sparse over set bits) + LN(16) + relu -> h1 tile in LDS.
-// lane <-> (sample m = p>>6, position pos = p&63); a wave covers one sample.
-// If xhat_out != nullptr the caller wants (pre-relu) normalised values back.
+// conv 3x3xC -> 16 as MFMA.  A 16x16 output tile = 16 "points" (rows) x 16 channels; the
+// reduction runs over the 9C window bits in steps of 4 (v_mfma_f32_16x16x4_f32):
+//   A[i = l&15][kk = l>>4] = bit(point i, k = 4s+kk) ? 1/255 : 0     (built from the packed obs)
+//   B[kk][j = l&15]        = Wc[k = 4s+kk][j]                         (held in registers)
+//   D: lane (channel j = l&15) holds rows 4*(l>>4)+r, r = 0..3.
+// Bit of point (py,px), window element k=(ky,kx,c): ((py+ky)*10 + px+kx)*C + c = base(point) + off(k).
 // ---------------------------------------------------------------------------
 template <int C>
-PQN_D void conv_ln_point(const CnnSmem &s, int m, int pos, float (&y)[16], float (&xhat)[16], float &rstd,
-                         uint32_t (&wmask)[3]) {
-  using Cfg = CnnCfg<C>;
-  const int py = pos >> 3, px = pos & 7;
-  const float *wc = s.wc;
-  const float *bc = s.wc + Cfg::KW * 16;
-  float acc[16];
+struct ConvMfma {
+  static constexpr int NS = (9 * C + 3) / 4;
+  int offk[NS];
+  float wk[NS];
+  PQN_D void init(const float *wc, int lane) {
+    const int kk = lane >> 4, o = lane & 15;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) acc[o] = bc[o];
-  const uint32_t *b = s.bits + m * Cfg::OW;
-  const float inv255 = 1.0f / 255.0f;
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int sb = ((py + ky) * 10 + px) * C;
-    const int w = sb >> 5, sh = sb & 31;
-    const uint64_t v = (((uint64_t)b[w + 1] << 32) | b[w]) >> sh;
-    uint32_t mk = (uint32_t)v & ((1u << Cfg::ROWBITS) - 1u);
-    wmask[ky] = mk;
-    while (mk) {
-      const int bit = __builtin_ctz(mk);
-      mk &= mk - 1;
-      const f32x4 *wr = reinterpret_cast<const f32x4 *>(wc + (ky * Cfg::ROWBITS + bit) * 16);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 wv = wr[q];
-        acc[4 * q + 0] = fmaf(inv255, wv.x, acc[4 * q + 0]);
-        acc[4 * q + 1] = fmaf(inv255, wv.y, acc[4 * q + 1]);
-        acc[4 * q + 2] = fmaf(inv255, wv.z, acc[4 * q + 2]);
-        acc[4 * q + 3] = fmaf(inv255, wv.w, acc[4 * q + 3]);
-      }
+    for (int s = 0; s < NS; ++s) {
+      const int k = 4 * s + kk;
+      const bool ok = k < 9 * C;
+      const int ky = k / (3 * C), kx = (k / C) % 3, c = k % C;
+      offk[s] = ok ? (ky * 10 + kx) * C + c : 0;
+      wk[s] = ok ? wc[k * 16 + o] : 0.0f;
     }
   }
-  // LayerNorm over the 16 channels of this position (flax: var = E[x^2]-E[x]^2, clamped)
+  // two tiles at once (independent accumulators hide the 40-cycle MFMA dependency)
+  PQN_D void tile2(const uint32_t *rowA, int baseA, const uint32_t *rowB, int baseB, f32x4 &dA, f32x4 &dB) const {
+    const float inv255 = 1.0f / 255.0f;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int bA = baseA + offk[s], bB = baseB + offk[s];
+      const float xA = ((rowA[bA >> 5] >> (bA & 31)) & 1u) ? inv255 : 0.0f;
+      const float xB = ((rowB[bB >> 5] >> (bB & 31)) & 1u) ? inv255 : 0.0f;
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xA, wk[s], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xB, wk[s], a1, 0, 0, 0);
+    }
+    dA = a0;
+    dB = a1;
+  }
+};
+
+// MFMA leaves a tile as (channel = lane&15, 4 points per lane); LayerNorm wants all 16 channels of a
+// point in one lane (no cross-lane reductions, no 16x redundant statistics).  Transpose through LDS.
+PQN_D void stage_tile(float *stg, int p0, const f32x4 &d, float bias, int lane) {
+  float *dst = stg + (p0 + 4 * (lane >> 4)) * QN_STG + (lane & 15);
+  dst[0] = d.x + bias;
+  dst[QN_STG] = d.y + bias;
+  dst[2 * QN_STG] = d.z + bias;
+  dst[3 * QN_STG] = d.w + bias;
+}
+
+// LayerNorm(16) statistics of staged point p (flax: var = E[x^2]-E[x]^2, clamped; eps inside rsqrt)
+PQN_D void ln16_point(const float *stg, int p, float (&xhat)[16], float &rstd) {
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(stg + p * QN_STG);
+  float v[16];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const f32x4 t = src[qd];
+    v[4 * qd] = t.x; v[4 * qd + 1] = t.y; v[4 * qd + 2] = t.z; v[4 * qd + 3] = t.w;
+  }
   float sum = 0.f, sq = 0.f;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) { sum += acc[o]; sq = fmaf(acc[o], acc[o], sq); }
+  for (int o = 0; o < 16; ++o) { sum += v[o]; sq = fmaf(v[o], v[o], sq); }
   const float mean = sum * (1.0f / 16.0f);
   const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
   rstd = rsqrt_exact(var + QN_LN_EPS);
-  const float *g0 = bc + 16, *b0 = bc + 32;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    xhat[o] = (acc[o] - mean) * rstd;
-    y[o] = fmaxf(fmaf(xhat[o], g0[o], b0[o]), 0.0f);
+  for (int o = 0; o < 16; ++o) xhat[o] = (v[o] - mean) * rstd;
+}
+
+// conv output (+bias) of all 64 positions of one sample -> this wave's staging buffer
+template <int C>
+PQN_D void conv_sample_to_stage(const ConvMfma<C> &cv, const uint32_t *row, float *stg, float bias, int lane) {
+  const int i = lane & 15;
+#pragma unroll
+  for (int pb = 0; pb < 4; pb += 2) {
+    const int posA = 16 * pb + i, posB = posA + 16;
+    f32x4 dA, dB;
+    cv.tile2(row, ((posA >> 3) * 10 + (posA & 7)) * C, row, ((posB >> 3) * 10 + (posB & 7)) * C, dA, dB);
+    stage_tile(stg, 16 * pb, dA, bias, lane);
+    stage_tile(stg, 16 * pb + 16, dB, bias, lane);
   }
 }
 
+// phase 1: h1 tile [16 samples][64 pos * 16 ch] = relu(LN(conv)).  Wave w owns samples QN_SPW*w ...
 template <int C>
 PQN_D void phase1_conv(const CnnSmem &s, int tid) {
+  using Cfg = CnnCfg<C>;
+  const int lane = tid & 63, wave = tid >> 6;
+  ConvMfma<C> cv;
+  cv.init(s.wc, lane);
+  const float *bc = s.wc + Cfg::KW * 16;
+  const float bias = bc[lane & 15];
+  float *stg = s.stg + wave * 64 * QN_STG;
 #pragma unroll 1
-  for (int r = 0; r < (QN_TILE * 64) / 256; ++r) {
-    const int p = tid + 256 * r;
-    const int m = p >> 6, pos = p & 63;
-    float y[16], xhat[16], rstd;
-    uint32_t wm[3];
-    conv_ln_point<C>(s, m, pos, y, xhat, rstd, wm);
-    f32x4 *dst = reinterpret_cast<f32x4 *>(s.h1 + m * QN_H1S + pos * 16);
+  for (int mm = 0; mm < QN_SPW; ++mm) {
+    const int m = QN_SPW * wave + mm;
+    conv_sample_to_stage<C>(cv, s.bits + m * Cfg::OW, stg, bias, lane);
+    float xhat[16], rstd;
+    ln16_point(stg, lane, xhat, rstd);   // lane = position
+    f32x4 *dst = reinterpret_cast<f32x4 *>(s.h1 + m * QN_H1S + lane * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = f32x4{y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+    for (int qd = 0; qd < 4; ++qd) {
+      f32x4 y;
+      y.x = fmaxf(fmaf(xhat[4 * qd + 0], bc[16 + 4 * qd + 0], bc[32 + 4 * qd + 0]), 0.0f);
+      y.y = fmaxf(fmaf(xhat[4 * qd + 1], bc[16 + 4 * qd + 1], bc[32 + 4 * qd + 1]), 0.0f);
+      y.z = fmaxf(fmaf(xhat[4 * qd + 2], bc[16 + 4 * qd + 2], bc[32 + 4 * qd + 2]), 0.0f);
+      y.w = fmaxf(fmaf(xhat[4 * qd + 3], bc[16 + 4 * qd + 3], bc[32 + 4 * qd + 3]), 0.0f);
+      dst[qd] = y;
+    }
   }
 }
 
@@ -127,60 +197,57 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid) {
 // ablate: 0 = normal; 2 = no global B loads; 3 = no MFMA (loads only).  Profiling hook.
 template <int ABL = 0>
 PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) {
+  constexpr int CBW = 8 / QN_WAVES > 0 ? 8 / QN_WAVES : 1;  // column blocks per wave
+  static_assert(QN_WAVES * CBW == 8, "8 column blocks of 16 outputs");
   const int lane = tid & 63, wave = tid >> 6;
-  const int cb0 = 2 * wave, cb1 = cb0 + 1;
+  const int cb0 = CBW * wave;
   const f32x4 *wp = reinterpret_cast<const f32x4 *>(w1p);
   const float *arow = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  constexpr int PF = 8;
-  f32x4 b0[PF], b1[PF];
+  f32x4 acc[CBW];
 #pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    b0[i] = wp[(i * 8 + cb0) * 64 + lane];
-    b1[i] = wp[(i * 8 + cb1) * 64 + lane];
-  }
+  for (int c = 0; c < CBW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int PF = 8;
+  f32x4 b[PF][CBW];
+#pragma unroll
+  for (int i = 0; i < PF; ++i)
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) b[i][c] = wp[(i * 8 + cb0 + c) * 64 + lane];
 #pragma unroll 1
   for (int g = 0; g < QN_H1 / 16; g += PF) {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 16 * (g + i));
-      const f32x4 x0 = b0[i], x1 = b1[i];
+      f32x4 x[CBW];
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) x[c] = b[i][c];
       if (ABL != 2 && g + i + PF < QN_H1 / 16) {
-        b0[i] = wp[((g + i + PF) * 8 + cb0) * 64 + lane];
-        b1[i] = wp[((g + i + PF) * 8 + cb1) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) b[i][c] = wp[((g + i + PF) * 8 + cb0 + c) * 64 + lane];
       }
       if (ABL == 3) {
-        acc0 += x0 + a;
-        acc1 += x1;
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[c] += x[c] + a;
         continue;
       }
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x0.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x0.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[c].w, acc[c], 0, 0, 0);
     }
   }
   const int col = lane & 15, r0 = 4 * (lane >> 4);
-  s.z[(r0 + 0) * QN_ZS + 16 * cb0 + col] = acc0.x;
-  s.z[(r0 + 1) * QN_ZS + 16 * cb0 + col] = acc0.y;
-  s.z[(r0 + 2) * QN_ZS + 16 * cb0 + col] = acc0.z;
-  s.z[(r0 + 3) * QN_ZS + 16 * cb0 + col] = acc0.w;
-  s.z[(r0 + 0) * QN_ZS + 16 * cb1 + col] = acc1.x;
-  s.z[(r0 + 1) * QN_ZS + 16 * cb1 + col] = acc1.y;
-  s.z[(r0 + 2) * QN_ZS + 16 * cb1 + col] = acc1.z;
-  s.z[(r0 + 3) * QN_ZS + 16 * cb1 + col] = acc1.w;
-}
-
-PQN_D float group16_sum(float v) {
-  v += __shfl_xor(v, 8, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 1, 16);
-  return v;
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) {
+    float *zp = s.z + r0 * QN_ZS + 16 * (cb0 + c) + col;
+    zp[0] = acc[c].x;
+    zp[QN_ZS] = acc[c].y;
+    zp[2 * QN_ZS] = acc[c].z;
+    zp[3 * QN_ZS] = acc[c].w;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -225,7 +292,7 @@ PQN_D void phase3_head(const CnnSmem &s, const float *__restrict__ theta, const 
 template <int C>
 PQN_D void load_tile_common(const CnnSmem &s, const float *__restrict__ theta, const pqn_cnn_layout_t &L, int tid) {
   using Cfg = CnnCfg<C>;
-  for (int i = tid; i < Cfg::KW * 16 + 48; i += 256) s.wc[i] = theta[L.off_wc + i];  // kernel|bias|ln0s|ln0b contiguous
+  for (int i = tid; i < Cfg::KW * 16 + 48; i += QN_THREADS) s.wc[i] = theta[L.off_wc + i];  // kernel|bias|ln0s|ln0b contiguous
 }
 
 template <int C>
@@ -235,14 +302,15 @@ PQN_D CnnSmem carve_smem(char *base) {
   s.h1 = reinterpret_cast<float *>(base);
   s.z = s.h1 + QN_TILE * QN_H1S;
   s.wc = s.z + QN_TILE * QN_ZS;
-  s.bits = reinterpret_cast<uint32_t *>(s.wc + ((Cfg::KW * 16 + 48 + 3) & ~3));
+  s.stg = s.wc + ((Cfg::KW * 16 + 48 + 3) & ~3);
+  s.bits = reinterpret_cast<uint32_t *>(s.stg + QN_WAVES * 64 * QN_STG);
   return s;
 }
 
 template <int C>
 constexpr size_t cnn_smem_bytes() {
   using Cfg = CnnCfg<C>;
-  return sizeof(float) * (QN_TILE * QN_H1S + QN_TILE * QN_ZS + ((Cfg::KW * 16 + 48 + 3) & ~3)) +
+  return sizeof(float) * (QN_TILE * QN_H1S + QN_TILE * QN_ZS + ((Cfg::KW * 16 + 48 + 3) & ~3) + QN_WAVES * 64 * QN_STG) +
          sizeof(uint32_t) * (QN_TILE * Cfg::OW + 4);
 }
 
@@ -252,7 +320,7 @@ constexpr size_t cnn_smem_bytes() {
 //   idx   (nullable): gather -- sample j of the launch reads obs_bits[idx[j]]
 // ---------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(256) void qnet_cnn_fwd_kernel(int n, const uint32_t *__restrict__ obs_bits,
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const uint32_t *__restrict__ obs_bits,
                                                            const float *__restrict__ theta, pqn_cnn_layout_t L,
                                                            float *__restrict__ q_out, int32_t *__restrict__ action,
                                                            float *__restrict__ qmax, float eps, uint64_t key,
@@ -263,7 +331,7 @@ __global__ __launch_bounds__(256) void qnet_cnn_fwd_kernel(int n, const uint32_t
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * QN_TILE;
   load_tile_common<C>(s, theta, L, tid);
-  for (int i = tid; i < QN_TILE * Cfg::OW; i += 256) {
+  for (int i = tid; i < QN_TILE * Cfg::OW; i += QN_THREADS) {
     const int le = i / Cfg::OW;
     s.bits[i] = (e0 + le < n) ? obs_bits[(size_t)e0 * Cfg::OW + i] : 0u;
   }
@@ -275,6 +343,7 @@ __global__ __launch_bounds__(256) void qnet_cnn_fwd_kernel(int n, const uint32_t
   else if (ablate == 2) phase2_fc1<2>(s, theta + L.off_w1, tid);
   else if (ablate == 3) phase2_fc1<3>(s, theta + L.off_w1, tid);
   __syncthreads();
+  if (tid >= 256) return;  // the head needs 16 lanes per sample
   float q[QN_MAXA], h2[8], xh[8], rstd;
   phase3_head(s, theta, L, tid, q, h2, xh, rstd);
   const int m = tid >> 4, sub = tid & 15, e = e0 + m;
@@ -325,11 +394,9 @@ __host__ __device__ inline int small_record_floats(int c, int a) { return 9 * c 
 struct TrainSmem {
   CnnSmem n;
   float *scr;        // 3 x [16][QN_ZS] tiles, later [KW][4][16] conv-wgrad partials
-  uint32_t *planes;  // [16][C][4] per-channel cell masks
   float *gs;         // [16] per-sample loss gradient g_m = (q_a - target)/B
   int *act;          // [16]
-  float *red;        // [4][48] cross-wave reduction of conv bias / ln0 grads
-  int *ctr;          // work-queue head for the conv weight gradient
+  float *red;        // [QN_WAVES][48] cross-wave reduction of conv bias / ln0 grads
 };
 
 template <int C>
@@ -339,21 +406,19 @@ PQN_D TrainSmem carve_train_smem(char *base) {
   t.n = carve_smem<C>(base);
   uint32_t *after_bits = t.n.bits + QN_TILE * Cfg::OW + 4;
   t.scr = reinterpret_cast<float *>(after_bits);
-  t.planes = reinterpret_cast<uint32_t *>(t.scr + TrainCfg<C>::SCR);
-  t.gs = reinterpret_cast<float *>(t.planes + QN_TILE * C * 4);
+  t.gs = t.scr + TrainCfg<C>::SCR;
   t.act = reinterpret_cast<int *>(t.gs + QN_TILE);
   t.red = reinterpret_cast<float *>(t.act + QN_TILE);
-  t.ctr = reinterpret_cast<int *>(t.red + 4 * 48);
   return t;
 }
 
 template <int C>
 constexpr size_t train_smem_bytes() {
-  return cnn_smem_bytes<C>() + sizeof(float) * (TrainCfg<C>::SCR + QN_TILE * C * 4 + 2 * QN_TILE + 4 * 48 + 4);
+  return cnn_smem_bytes<C>() + sizeof(float) * (TrainCfg<C>::SCR + 2 * QN_TILE + QN_WAVES * 48 + 4);
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, const float *__restrict__ w1b,
     pqn_cnn_layout_t L, float inv_b, float *__restrict__ dzT, float *__restrict__ gpart, int ablate) {
@@ -368,51 +433,43 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
 
   // ---- P0: gather inputs -------------------------------------------------------------------
   load_tile_common<C>(s, theta, L, tid);
-  for (int i = tid; i < QN_TILE * Cfg::OW; i += 256) {
+  for (int i = tid; i < QN_TILE * Cfg::OW; i += QN_THREADS) {
     const int le = i / Cfg::OW, w = i - le * Cfg::OW;
     s.bits[i] = (b0 + le < nb) ? obs_bits[(size_t)idx[b0 + le] * Cfg::OW + w] : 0u;
   }
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
-  if (tid == 0) *ts.ctr = 0;
   __syncthreads();
-  // per-channel cell masks (bit `cell` of plane c <=> obs bit cell*C+c), for the conv weight gradient
-  for (int i = tid; i < QN_TILE * C * 4; i += 256) {
-    const int m = i / (C * 4), c = (i / 4) % C, w = i & 3;
-    uint32_t pm = 0u;
-    for (int j = 0; j < 32; ++j) {
-      const int cell = w * 32 + j;
-      if (cell < 100) {
-        const int bit = cell * C + c;
-        pm |= ((s.bits[m * Cfg::OW + (bit >> 5)] >> (bit & 31)) & 1u) << j;
-      }
-    }
-    ts.planes[i] = pm;
-  }
   // ---- P1..P3: forward ---------------------------------------------------------------------
   phase1_conv<C>(s, tid);
   __syncthreads();
   phase2_fc1<0>(s, theta + L.off_w1, tid);
   __syncthreads();
-  float q[QN_MAXA], h2[8], xh[8], rstd1;
-  phase3_head(s, theta, L, tid, q, h2, xh, rstd1);
-  const int m = tid >> 4, sub = tid & 15;
-  const bool valid = (b0 + m) < nb;
-  const int64_t src = valid ? idx[b0 + m] : 0;
-  const int act = valid ? action[src] : 0;
-  float chosen = q[0];
+  // the head (LN1 / fc2 / loss) needs 16 lanes per sample: waves 0..3 only
+  const bool head = tid < 256;
+  const int m = (tid >> 4) & 15, sub = tid & 15;
+  float q[QN_MAXA], h2[8], xh[8], rstd1 = 0.f, chosen = 0.f, diff = 0.f, gm = 0.f;
+  int act = 0;
+  bool valid = false;
+  if (head) {
+    phase3_head(s, theta, L, tid, q, h2, xh, rstd1);
+    valid = (b0 + m) < nb;
+    const int64_t src = valid ? idx[b0 + m] : 0;
+    act = valid ? action[src] : 0;
+    chosen = q[0];
 #pragma unroll
-  for (int a = 1; a < QN_MAXA; ++a)
-    if (a == act) chosen = q[a];
-  const float diff = valid ? (chosen - target[src]) : 0.0f;
-  const float gm = diff * inv_b;  // d loss / d q_a, loss = 0.5*mean(diff^2)  (pqn_minatar.py:285)
-  if (sub == 0) {
-    ts.gs[m] = gm;
-    ts.act[m] = act;
+    for (int a = 1; a < QN_MAXA; ++a)
+      if (a == act) chosen = q[a];
+    diff = valid ? (chosen - target[src]) : 0.0f;
+    gm = diff * inv_b;  // d loss / d q_a, loss = 0.5*mean(diff^2)  (pqn_minatar.py:285)
+    if (sub == 0) {
+      ts.gs[m] = gm;
+      ts.act[m] = act;
+    }
   }
   // ---- head backward: fc2, relu, LN1 ----------------------------------------------------------
   float *tA = ts.scr, *tB = ts.scr + QN_TILE * QN_ZS, *tH = ts.scr + 2 * QN_TILE * QN_ZS;
   __syncthreads();  // everyone is done reading s.z (phase 3) before it is overwritten with dz
-  {
+  if (head) {
     float dxh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -446,7 +503,7 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
       gp[o_b1 + tid] = a1;              // d b1
       gp[o_b1 + 128 + tid] = a2;        // d ln1 scale
       gp[o_b1 + 256 + tid] = a3;        // d ln1 bias
-    } else {
+    } else if (tid < 2 * QN_HID) {
       const int o = tid - QN_HID;       // d w2[o][a] = sum_m [act_m == a] g_m h2[m][o]
       for (int a = 0; a < L.a; ++a) {
         float acc = 0.f;
@@ -455,18 +512,19 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
         gp[o_b1 + 384 + o * L.a + a] = acc;
       }
     }
-    if (tid < L.a) {
+    if (tid >= 256 && tid < 256 + L.a) {
+      const int a = tid - 256;
       float acc = 0.f;
-      for (int mm = 0; mm < QN_TILE; ++mm) acc += (ts.act[mm] == tid) ? ts.gs[mm] : 0.0f;
-      gp[o_b1 + 384 + 128 * L.a + tid] = acc;  // d b2
+      for (int mm = 0; mm < QN_TILE; ++mm) acc += (ts.act[mm] == a) ? ts.gs[mm] : 0.0f;
+      gp[o_b1 + 384 + 128 * L.a + a] = acc;  // d b2
     }
     // loss / chosen-q partials (metrics td_loss, qvals: pqn_minatar.py:334-335)
-    float l = (sub == 0) ? 0.5f * diff * diff : 0.0f, cq = (sub == 0 && valid) ? chosen : 0.0f;
+    float l = (head && sub == 0) ? 0.5f * diff * diff : 0.0f, cq = (head && sub == 0 && valid) ? chosen : 0.0f;
     for (int off = 32; off > 0; off >>= 1) { l += __shfl_down(l, off, 64); cq += __shfl_down(cq, off, 64); }
-    if (lane == 0) { ts.red[wave * 48] = l; ts.red[wave * 48 + 1] = cq; }
+    if (lane == 0 && wave < 4) { ts.red[wave * 48] = l; ts.red[wave * 48 + 1] = cq; }
   }
   // dz^T for the weight-gradient GEMM: dzT[o][b0 + m], 16-B stores
-  for (int i = tid; i < QN_HID * 4; i += 256) {
+  for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
     const int o = i >> 2, mq = i & 3;
     const f32x4 v = {s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], s.z[(4 * mq + 2) * QN_ZS + o],
                      s.z[(4 * mq + 3) * QN_ZS + o]};
@@ -487,20 +545,21 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
       afr[g] = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 16 * g + 4 * (lane >> 4));
     const int col = lane & 15, r0 = 4 * (lane >> 4);
     f32x4 bA[8], bB[8];
-    const int ib_first = 16 * wave;
+    constexpr int IPW = 64 / QN_WAVES / 2;   // pairs of i-blocks per wave
+    const int ib_first = 2 * IPW * wave;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       bA[g] = wb[(g * 64 + ib_first) * 64 + lane];
       bB[g] = wb[(g * 64 + ib_first + 1) * 64 + lane];
     }
 #pragma unroll 1
-    for (int ip = 0; ip < 8; ++ip) {
+    for (int ip = 0; ip < IPW; ++ip) {
       const int ib = ib_first + 2 * ip;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       f32x4 cA[8], cB[8];
 #pragma unroll
       for (int g = 0; g < 8; ++g) { cA[g] = bA[g]; cB[g] = bB[g]; }
-      if (ip + 1 < 8) {
+      if (ip + 1 < IPW) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
           bA[g] = wb[(g * 64 + ib + 2) * 64 + lane];
@@ -530,20 +589,26 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
     }
   }
   __syncthreads();
-  // ---- P5: LN0 backward per (sample, position); conv bias / ln0 grads; dx tile in place ------------
+  // ---- P5: LN0 backward.  conv recomputed (MFMA) and staged; LN stats + backward per point in one
+  // lane; channel sums (d conv-bias, d ln0-scale, d ln0-bias) in (channel = lane&15) layout. -----------
   if (!(ablate & 2)) {
-    float gsc[16], gbi[16], gbc[16];
-#pragma unroll
-    for (int o = 0; o < 16; ++o) { gsc[o] = 0.f; gbi[o] = 0.f; gbc[o] = 0.f; }
-    const float *g0 = s.wc + Cfg::KW * 16 + 16;
+    ConvMfma<C> cv;
+    cv.init(s.wc, lane);
+    const float *bc = s.wc + Cfg::KW * 16;
+    const int o = lane & 15, kk = lane >> 4;
+    const float bias = bc[o];
+    float *stg = s.stg + wave * 64 * QN_STG;
+    float gsc = 0.f, gbi = 0.f, gbc = 0.f;
 #pragma unroll 1
-    for (int r = 0; r < (QN_TILE * 64) / 256; ++r) {
-      const int p = tid + 256 * r;
-      const int mm = p >> 6, pos = p & 63;
-      float y[16], xhat[16], rstd;
-      uint32_t wm[3];
-      conv_ln_point<C>(s, mm, pos, y, xhat, rstd, wm);
-      f32x4 *gptr = reinterpret_cast<f32x4 *>(s.h1 + mm * QN_H1S + pos * 16);
+    for (int mm = 0; mm < QN_SPW; ++mm) {
+      const int msamp = QN_SPW * wave + mm;
+      float *gt = s.h1 + msamp * QN_H1S;                 // d relu-input tile (masked by h1 > 0) -> dx in place
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gbi += gt[(kk + 4 * j) * 16 + o];
+      conv_sample_to_stage<C>(cv, s.bits + msamp * Cfg::OW, stg, bias, lane);
+      float xhat[16], rstd;
+      ln16_point(stg, lane, xhat, rstd);
+      f32x4 *gptr = reinterpret_cast<f32x4 *>(gt + lane * 16);
       float g[16];
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
@@ -552,82 +617,98 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
       }
       float s1 = 0.f, s2 = 0.f, dxh[16];
 #pragma unroll
-      for (int o = 0; o < 16; ++o) {
-        gsc[o] = fmaf(g[o], xhat[o], gsc[o]);
-        gbi[o] += g[o];
-        dxh[o] = g[o] * g0[o];
-        s1 += dxh[o];
-        s2 = fmaf(dxh[o], xhat[o], s2);
+      for (int c = 0; c < 16; ++c) {
+        dxh[c] = g[c] * bc[16 + c];
+        s1 += dxh[c];
+        s2 = fmaf(dxh[c], xhat[c], s2);
       }
       s1 *= (1.0f / 16.0f);
       s2 *= (1.0f / 16.0f);
-      float dx[16];
+      f32x4 *sp = reinterpret_cast<f32x4 *>(stg + lane * QN_STG);
 #pragma unroll
-      for (int o = 0; o < 16; ++o) {
-        dx[o] = rstd * (dxh[o] - s1 - xhat[o] * s2);
-        gbc[o] += dx[o];
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 dx, gx;
+        dx.x = rstd * (dxh[4 * qd + 0] - s1 - xhat[4 * qd + 0] * s2); gx.x = g[4 * qd + 0] * xhat[4 * qd + 0];
+        dx.y = rstd * (dxh[4 * qd + 1] - s1 - xhat[4 * qd + 1] * s2); gx.y = g[4 * qd + 1] * xhat[4 * qd + 1];
+        dx.z = rstd * (dxh[4 * qd + 2] - s1 - xhat[4 * qd + 2] * s2); gx.z = g[4 * qd + 2] * xhat[4 * qd + 2];
+        dx.w = rstd * (dxh[4 * qd + 3] - s1 - xhat[4 * qd + 3] * s2); gx.w = g[4 * qd + 3] * xhat[4 * qd + 3];
+        gptr[qd] = dx;
+        sp[qd] = gx;
       }
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) gptr[qd] = f32x4{dx[4 * qd], dx[4 * qd + 1], dx[4 * qd + 2], dx[4 * qd + 3]};
+      for (int j = 0; j < 16; ++j) {
+        gsc += stg[(kk + 4 * j) * QN_STG + o];
+        gbc += gt[(kk + 4 * j) * 16 + o];
+      }
     }
-    // wave tree reduction, then fixed-order fold of the 4 waves
-#pragma unroll
-    for (int o = 0; o < 16; ++o) {
-      for (int off = 32; off > 0; off >>= 1) {
-        gsc[o] += __shfl_down(gsc[o], off, 64);
-        gbi[o] += __shfl_down(gbi[o], off, 64);
-        gbc[o] += __shfl_down(gbc[o], off, 64);
-      }
-    }
-    __syncthreads();  // ts.red was read by tid 0 above; dx tile complete
-    if (lane == 0) {
-#pragma unroll
-      for (int o = 0; o < 16; ++o) {
-        ts.red[wave * 48 + o] = gbc[o];
-        ts.red[wave * 48 + 16 + o] = gsc[o];
-        ts.red[wave * 48 + 32 + o] = gbi[o];
-      }
+    // fold the 4 position-groups of the wave (lanes o, o+16, o+32, o+48), then the 4 waves in fixed order
+    gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
+    gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
+    gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
+    if (lane < 16) {
+      ts.red[wave * 48 + lane] = gbc;
+      ts.red[wave * 48 + 16 + lane] = gsc;
+      ts.red[wave * 48 + 32 + lane] = gbi;
     }
   }
   __syncthreads();
-  if (tid < 48) gp[Cfg::KW * 16 + tid] = (ts.red[tid] + ts.red[48 + tid]) + (ts.red[96 + tid] + ts.red[144 + tid]);
-  // ---- P6: conv weight gradient, sparse over the set cells of each channel plane --------------------
-  //   dWc[ky][kx][c][o] = 1/255 * sum_m sum_{cell in plane c(m)} dx[m][cell - (ky,kx)][o]
-  // work item = (k, sample quarter); 16 lanes = 16 output channels; partials [KW][4][16] in LDS.
+  if (tid < 48) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < QN_WAVES; ++w) acc += ts.red[w * 48 + tid];
+    gp[Cfg::KW * 16 + tid] = acc;
+  }
+  // ---- P6: conv weight gradient as MFMA:  dWc[k][o] = sum_{m,pos} (bit(m,pos,k)/255) * dx[m][pos][o] ----
+  //   A[i = k row][kk] = bit(m, pos = 4s+kk, k = 16rb+i)/255,  B[kk][o] = dx[m][4s+kk][o]  (LDS, contiguous)
+  //   wave w reduces its samples 4w..4w+3; the 4 wave partials are folded in fixed order.
   if (!(ablate & 4)) {
-    float *part = ts.scr;
-    const int o = tid & 15;
-    for (;;) {
-      int item = 0;
-      if (o == 0) item = atomicAdd(ts.ctr, 1);  // which 16-lane group takes which item does not change the result
-      item = __shfl(item, 0, 16);
-      if (item >= Cfg::KW * 4) break;
-      const int k = item >> 2, mq = item & 3;
-      const int c = k % C, kx = (k / C) % 3, ky = k / (3 * C);
-      float acc = 0.f;
-      for (int mm = 4 * mq; mm < 4 * mq + 4; ++mm) {
-        const uint32_t *pl = ts.planes + (mm * C + c) * 4;
-        const float *dxm = s.h1 + mm * QN_H1S + o;
+    constexpr int NRB = (9 * C + 15) / 16;   // 16-row blocks of k
+    constexpr int RBH = (NRB + 1) / 2;       // row blocks per wave half
+    // wave = (sample quad sq, row-block half rh): samples 4sq..4sq+3, row blocks rh*RBH ..
+    const int sq = wave & 3, rh = wave >> 2;
+    const int i = lane & 15, kk = lane >> 4;
+    int koff[RBH];
+#pragma unroll
+    for (int j = 0; j < RBH; ++j) {
+      const int k = 16 * (rh * RBH + j) + i;
+      koff[j] = (k < 9 * C) ? ((k / (3 * C)) * 10 + (k / C) % 3) * C + k % C : -1;
+    }
+    f32x4 acc[RBH];
+#pragma unroll
+    for (int j = 0; j < RBH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float inv255 = 1.0f / 255.0f;
 #pragma unroll 1
-        for (int w = 0; w < 4; ++w) {
-          uint32_t pm = pl[w];
-          while (pm) {
-            const int cell = w * 32 + __builtin_ctz(pm);
-            pm &= pm - 1;
-            const int y = cell / 10, x = cell - 10 * y;
-            const int py = y - ky, px = x - kx;
-            if ((unsigned)py < 8u && (unsigned)px < 8u) acc += dxm[(py * 8 + px) * 16];
-          }
+    for (int mm = 0; mm < 4; ++mm) {
+      const int msamp = 4 * sq + mm;
+      const uint32_t *row = s.bits + msamp * Cfg::OW;
+      const float *dxm = s.h1 + msamp * QN_H1S + lane;   // + 64*st : element (pos = 4st+kk, o = lane&15)
+#pragma unroll 4
+      for (int st = 0; st < 16; ++st) {
+        const int pos = 4 * st + kk;
+        const int base = ((pos >> 3) * 10 + (pos & 7)) * C;
+        const float b = dxm[64 * st];
+#pragma unroll
+        for (int j = 0; j < RBH; ++j) {
+          const int bit = base + max(koff[j], 0);
+          const float a = (koff[j] >= 0 && ((row[bit >> 5] >> (bit & 31)) & 1u)) ? inv255 : 0.0f;
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
         }
       }
-      part[item * 16 + o] = acc;
     }
-  }
-  __syncthreads();
-  for (int i = tid; i < Cfg::KW * 16; i += 256) {
-    const int k = i >> 4, o = i & 15;
-    const float *pp = ts.scr + (k * 4) * 16 + o;
-    gp[i] = ((pp[0] + pp[16]) + (pp[32] + pp[48])) * (1.0f / 255.0f);
+    float *part = ts.scr;  // [sq][row block][16 rows][16 o]
+#pragma unroll
+    for (int j = 0; j < RBH; ++j) {
+      const int rb = rh * RBH + j;
+      if (rb < NRB) {
+        float *pp = part + ((sq * NRB + rb) * 16 + 4 * kk) * 16 + i;
+        pp[0] = acc[j].x; pp[16] = acc[j].y; pp[32] = acc[j].z; pp[48] = acc[j].w;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < Cfg::KW * 16; e += QN_THREADS) {
+      const float *pp = ts.scr + e;   // e = k*16 + o = (rb*16 + row)*16 + o
+      gp[e] = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
+    }
   }
 }
 
@@ -636,70 +717,92 @@ __global__ __launch_bounds__(256) void qnet_cnn_train_kernel(
 // (= conv positions 2it, 2it+1, recomputed from the packed obs), samples [512 ks, 512 ks + 512).
 // A = h1^T tile from LDS, B = dz^T from L2; output written in fragment layout into wpart[ks].
 // ---------------------------------------------------------------------------
-#define QW_CH 128   // samples per LDS chunk
-#define QW_HS 132   // row stride of the h1^T chunk
+#define QW_CH 256   // samples per LDS chunk
+#define QW_HS 260   // row stride of the h1^T chunk
 
 template <int C>
-__global__ __launch_bounds__(256) void qnet_cnn_wgrad_kernel(int nb, const int64_t *__restrict__ idx,
-                                                             const uint32_t *__restrict__ obs_bits,
-                                                             const float *__restrict__ theta, pqn_cnn_layout_t L,
-                                                             const float *__restrict__ dzT, float *__restrict__ wpart) {
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_wgrad_kernel(int nb, const int64_t *__restrict__ idx,
+                                                                    const uint32_t *__restrict__ obs_bits,
+                                                                    const float *__restrict__ theta, pqn_cnn_layout_t L,
+                                                                    const float *__restrict__ dzT,
+                                                                    float *__restrict__ wpart) {
   using Cfg = CnnCfg<C>;
+  constexpr int BS = Cfg::OW + 1;  // padded row stride of the bits chunk (lanes read different samples)
+  constexpr int NG = QW_CH / 16;   // 16-sample K groups per chunk
+  static_assert(QN_WAVES == 8, "one output column block per wave");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *h1t = reinterpret_cast<float *>(smem_raw);                    // [32][QW_HS]
-  CnnSmem s;
-  s.h1 = nullptr;
-  s.z = nullptr;
-  s.wc = h1t + 32 * QW_HS;
-  s.bits = reinterpret_cast<uint32_t *>(s.wc + ((Cfg::KW * 16 + 48 + 3) & ~3));  // [QW_CH][OW] + guard
+  float *wc = h1t + 32 * QW_HS;
+  float *stg = wc + ((Cfg::KW * 16 + 48 + 3) & ~3);                     // [2*QW_CH points][QN_STG]
+  uint32_t *bits = reinterpret_cast<uint32_t *>(stg + 2 * QW_CH * QN_STG);  // [QW_CH][BS] + guard
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int it = blockIdx.x, ks = blockIdx.y;
-  load_tile_common<C>(s, theta, L, tid);
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int cb0 = 2 * wave;
+  for (int i = tid; i < Cfg::KW * 16 + 48; i += QN_THREADS) wc[i] = theta[L.off_wc + i];
+  __syncthreads();
+  ConvMfma<C> cv;
+  cv.init(wc, lane);
+  const int o = lane & 15;
+  const float bias = wc[Cfg::KW * 16 + o];
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int cb = wave;
   const int bend = min(nb, ks * 512 + 512);
+  const int pp = wave >> 2;                 // conv position handled by this wave: 2*it + pp
+  const int pos = 2 * it + pp;
+  const int base = ((pos >> 3) * 10 + (pos & 7)) * C;
   for (int c0 = ks * 512; c0 < bend; c0 += QW_CH) {
-    __syncthreads();  // previous chunk's MFMA reads are done
-    for (int i = tid; i < QW_CH * Cfg::OW; i += 256) {
-      const int le = i / Cfg::OW, w = i - le * Cfg::OW;
-      s.bits[i] = (c0 + le < nb) ? obs_bits[(size_t)idx[c0 + le] * Cfg::OW + w] : 0u;
-    }
-    if (tid < 4) s.bits[QW_CH * Cfg::OW + tid] = 0u;
-    __syncthreads();
-    {
-      const int bl = tid & (QW_CH - 1), pp = tid >> 7;
-      float y[16], xhat[16], rstd;
-      uint32_t wm[3];
-      conv_ln_point<C>(s, bl, 2 * it + pp, y, xhat, rstd, wm);
+    const int ngroups = min(NG, (bend - c0) / 16);
+    // prefetch this chunk's dz^T fragments (B operand) before the conv so L2 latency hides behind it
+    f32x4 x[NG];
 #pragma unroll
-      for (int o = 0; o < 16; ++o) h1t[(pp * 16 + o) * QW_HS + bl] = y[o];
+    for (int g = 0; g < NG; ++g)
+      if (g < ngroups)
+        x[g] = *reinterpret_cast<const f32x4 *>(dzT + (size_t)(16 * cb + o) * nb + c0 + 16 * g + 4 * (lane >> 4));
+    __syncthreads();  // previous chunk's MFMA reads of h1t / conv reads of bits are done
+    for (int i = tid; i < QW_CH * Cfg::OW; i += QN_THREADS) {
+      const int le = i / Cfg::OW, w = i - le * Cfg::OW;
+      bits[le * BS + w] = (c0 + le < nb) ? obs_bits[(size_t)idx[c0 + le] * Cfg::OW + w] : 0u;
+    }
+    if (tid < QW_CH) bits[tid * BS + Cfg::OW] = 0u;
+    __syncthreads();
+    // conv (MFMA) for the 512 points (sample b, position 2it+pp) of this chunk -> staging -> LN per lane.
+    // wave w: pp = w>>2, sample blocks 4(w&3)..+3  ==  points [64w, 64w+64) of the staging buffer
+#pragma unroll
+    for (int t2 = 0; t2 < 4; t2 += 2) {
+      const int sbA = 4 * (wave & 3) + t2, sbB = sbA + 1;
+      f32x4 dA, dB;
+      cv.tile2(bits + (16 * sbA + o) * BS, base, bits + (16 * sbB + o) * BS, base, dA, dB);
+      stage_tile(stg, pp * QW_CH + 16 * sbA, dA, bias, lane);
+      stage_tile(stg, pp * QW_CH + 16 * sbB, dB, bias, lane);
+    }
+    {
+      float xhat[16], rstd;
+      ln16_point(stg, tid, xhat, rstd);            // point tid = pp*256 + b_local
+      float *dst = h1t + (pp * 16) * QW_HS + (tid & (QW_CH - 1));
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        dst[c * QW_HS] = fmaxf(fmaf(xhat[c], wc[Cfg::KW * 16 + 16 + c], wc[Cfg::KW * 16 + 32 + c]), 0.0f);
     }
     __syncthreads();
-    const int ngroups = min(QW_CH / 16, (bend - c0) / 16);
-    for (int g = 0; g < ngroups; ++g) {
-      const int boff = 16 * g + 4 * (lane >> 4);
-      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(h1t + (lane & 15) * QW_HS + boff);
-      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(h1t + (16 + (lane & 15)) * QW_HS + boff);
-      const f32x4 x0 = *reinterpret_cast<const f32x4 *>(dzT + (size_t)(16 * cb0 + (lane & 15)) * nb + c0 + boff);
-      const f32x4 x1 = *reinterpret_cast<const f32x4 *>(dzT + (size_t)(16 * cb0 + 16 + (lane & 15)) * nb + c0 + boff);
-#define QW_STEP(comp)                                                                             \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.comp, x0.comp, acc[0][0], 0, 0, 0);        \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.comp, x1.comp, acc[0][1], 0, 0, 0);        \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.comp, x0.comp, acc[1][0], 0, 0, 0);        \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.comp, x1.comp, acc[1][1], 0, 0, 0);
-      QW_STEP(x) QW_STEP(y) QW_STEP(z) QW_STEP(w)
-#undef QW_STEP
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g < ngroups) {
+        const int boff = 16 * g + 4 * (lane >> 4);
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(h1t + o * QW_HS + boff);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(h1t + (16 + o) * QW_HS + boff);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, x[g].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, x[g].x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, x[g].y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, x[g].y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, x[g].z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, x[g].z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, x[g].w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, x[g].w, acc[1], 0, 0, 0);
+      }
     }
   }
   f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) out[((2 * it + a) * 8 + cb0 + b) * 64 + lane] = acc[a][b];
+  for (int a = 0; a < 2; ++a) out[((2 * it + a) * 8 + cb) * 64 + lane] = acc[a];
 }
 
 // ---------------------------------------------------------------------------
@@ -806,7 +909,7 @@ static int launch_fwd(int n, const uint32_t *bits, const float *theta, const pqn
     attr_set = true;
   }
   static const int ablate = getenv("PQN_ABLATE") ? atoi(getenv("PQN_ABLATE")) : 0;  // profiling only
-  hipLaunchKernelGGL((qnet_cnn_fwd_kernel<C>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(256), smem, st, n, bits, theta, L,
+  hipLaunchKernelGGL((qnet_cnn_fwd_kernel<C>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n, bits, theta, L,
                      q, action, qmax, eps, key, ablate);
   return pqn_check_launch("pqn_qnet_cnn_forward");
 }
@@ -836,8 +939,8 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   float *gpart = dzT + (size_t)QN_HID * nb;
   float *wpart = gpart + (size_t)ntiles * rec;
   const size_t smem1 = train_smem_bytes<C>();
-  const size_t smem2 = sizeof(float) * (32 * QW_HS + ((CnnCfg<C>::KW * 16 + 48 + 3) & ~3)) +
-                       sizeof(uint32_t) * (QW_CH * CnnCfg<C>::OW + 4);
+  const size_t smem2 = sizeof(float) * (32 * QW_HS + ((CnnCfg<C>::KW * 16 + 48 + 3) & ~3) + 2 * QW_CH * QN_STG) +
+                       sizeof(uint32_t) * (QW_CH * (CnnCfg<C>::OW + 1) + 4);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C>),
@@ -848,9 +951,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   const float inv_b = 1.0f / (float)nb;
   static const int ablate = getenv("PQN_ABLATE_TRAIN") ? atoi(getenv("PQN_ABLATE_TRAIN")) : 0;  // profiling only
-  hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles), dim3(256), smem1, st, nb, idx, bits, action, target,
+  hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles), dim3(QN_THREADS), smem1, st, nb, idx, bits, action, target,
                      theta, w1b, L, inv_b, dzT, gpart, ablate);
-  hipLaunchKernelGGL((qnet_cnn_wgrad_kernel<C>), dim3(32, nks), dim3(256), smem2, st, nb, idx, bits, theta, L, dzT,
+  hipLaunchKernelGGL((qnet_cnn_wgrad_kernel<C>), dim3(32, nks), dim3(QN_THREADS), smem2, st, nb, idx, bits, theta, L, dzT,
                      wpart);
   hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total)), dim3(256), 0, st, L, ntiles, nks, rec,
                      gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b);

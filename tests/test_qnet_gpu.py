@@ -64,7 +64,7 @@ def test_cnn_forward_on_real_breakout_observations(gpu, oracle):
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 16, 64), (4, 3, 128, 1000), (4, 3, 4096, 20000), (10, 6, 48, 100), (7, 3, 1024, 1024)])
 def test_cnn_grad_vs_oracle(gpu, oracle, c, a, nb, pool):
     """value_and_grad(_loss_fn) through the fused kernels vs the oracle's numpy backward.
-    Tolerance: rtol 2e-3 + atol 1e-6*max|g| (f32, different summation orders over up to 4096x64 terms)."""
+    Tolerance: rtol 2e-3 + atol 3e-6*max|g| (f32, different summation orders over up to 4096x64 terms)."""
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
     rng = np.random.default_rng(nb + c)
@@ -87,7 +87,7 @@ def test_cnn_grad_vs_oracle(gpu, oracle, c, a, nb, pool):
     assert abs(float(loss_t) - lo) <= 1e-4 * max(1.0, abs(lo))
     assert abs(float(qv_t) - chosen.mean()) <= 1e-4
     g_flax = _np(lay.to_flax(g))
-    np.testing.assert_allclose(g_flax, g_ref, rtol=2e-3, atol=1e-6 * np.abs(g_ref).max() + 1e-9)
+    np.testing.assert_allclose(g_flax, g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
     pads = torch.ones(lay.total, dtype=torch.bool)
     pads[lay.kidx] = False
     assert float(g[pads.to(gpu)].abs().sum()) == 0.0
