@@ -28,6 +28,10 @@ ENV_STEP_BYTES = 1926.0      # algorithmic bytes of one env.step (f
 LOOP_FLOP = 2.367e6          # algorithmic FLOP per env-step of the whole loop
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA/vector peak
+# Dominant kernel = qnet_cnn_train_kernel (T1: forward + backward except the fc1 weight gradient).
+# Algorithmic FLOP per sample: fwd conv 73,728 + fc1 262,144 + fc2 768; bwd fc2 dgrad+wgrad
+# 1,536 + fc1 dgrad 262,144 + conv wgrad 73,728 (the conv has no input gradient) = 674,048.
+T1_FLOP_PER_SAMPLE = 674048.0
 
 
 def workload_config(num_envs: int, mode: str):
@@ -104,6 +108,10 @@ def main():
 
     for u in range(args.warmup):
         update(u)
+    lib = _lib.load()
+    fused = train.backend == "fused"
+    if fused and rank == 0:
+        _lib.check(lib.pqn_prof_enable(1), "pqn_prof_enable")   # HIP events around the dominant kernel
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -123,7 +131,25 @@ def main():
     sps = env_steps / dt
 
     if rank == 0:
-        roof = train.roofline() if hasattr(train, "roofline") else None
+        roof = None
+        if fused:
+            import ctypes
+            cnt, tot = ctypes.c_int32(0), ctypes.c_float(0.0)
+            _lib.check(lib.pqn_prof_read(ctypes.byref(cnt), ctypes.byref(tot)), "pqn_prof_read")
+            lib.pqn_prof_enable(0)
+            mb = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] // cfg["NUM_MINIBATCHES"]
+            avg_s = tot.value * 1e-3 / max(cnt.value, 1)
+            achieved = T1_FLOP_PER_SAMPLE * mb / avg_s / 1e12
+            traffic, tsrc = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_train_kernel.json")
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                traffic, tsrc = pj.get("hbm_bytes_per_launch"), "profiles/r01_pmc_train_kernel.json (separate rocprofv3 --pmc passes)"
+            roof = {"kernel": "qnet_cnn_train_kernel<4> (fwd + bwd of one 4096-sample minibatch, f32 MFMA)",
+                    "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                    "avg_launch_us": avg_s * 1e6, "launches_timed": cnt.value,
+                    "flop_per_launch": T1_FLOP_PER_SAMPLE * mb}
         if roof is None:
             from purejaxql_amd.profiling import time_env_step_kernel
             k_ms = time_env_step_kernel(cfg["NUM_ENVS"], dev)

@@ -179,6 +179,12 @@ int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *layout /* host */, float *theta, 
                        float max_norm, float *workspace, float *gnorm_out, int32_t recompute_norm, void *stream);
 int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *layout /* host */, const float *theta, float *w1b, void *stream);
 
+/* Kernel timer for bench.py's roofline line: when enabled, pqn_qnet_cnn_grad brackets its dominant
+ * kernel (qnet_cnn_train_kernel) with HIP events on the launch stream; pqn_prof_read synchronises
+ * on them and returns the number of timed launches and their summed duration, then resets. */
+int pqn_prof_enable(int32_t on);
+int pqn_prof_read(int32_t *count /* host */, float *total_ms /* host */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,8 @@ SIGNATURES = {
     "pqn_qnet_cnn_grad": (c_int, [c_void_p, c_int32] + [c_void_p] * 11 + [c_void_p]),
     "pqn_qnet_cnn_apply": (c_int, [c_void_p] * 7 + [c_float] * 4 + [c_void_p, c_void_p, c_int32, c_void_p]),
     "pqn_qnet_cnn_pack_w1b": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pqn_prof_enable": (c_int, [c_int32]),
+    "pqn_prof_read": (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -929,6 +929,49 @@ extern "C" int pqn_qnet_cnn_forward(const pqn_cnn_layout_t *L, int32_t n, const 
   }
 }
 
+// ---------------------------------------------------------------------------
+// kernel timer: HIP events recorded on the launch stream around the dominant kernel (T1), read back
+// by bench.py for the roofline line.  Off by default; costs two event records per launch when on.
+// ---------------------------------------------------------------------------
+#define PQN_PROF_MAX 4096
+static struct {
+  bool on = false, created = false;
+  int n = 0;
+  hipEvent_t s[PQN_PROF_MAX], e[PQN_PROF_MAX];
+} g_prof;
+
+extern "C" int pqn_prof_enable(int32_t on) {
+  if (on && !g_prof.created) {
+    for (int i = 0; i < PQN_PROF_MAX; ++i) {
+      if (hipEventCreate(&g_prof.s[i]) != hipSuccess || hipEventCreate(&g_prof.e[i]) != hipSuccess) {
+        pqn_set_error("pqn_prof_enable: hipEventCreate failed");
+        return PQN_E_HIP;
+      }
+    }
+    g_prof.created = true;
+  }
+  g_prof.on = on != 0;
+  g_prof.n = 0;
+  return PQN_OK;
+}
+
+extern "C" int pqn_prof_read(int32_t *count, float *total_ms) {
+  PQN_REQUIRE(count && total_ms, "pqn_prof_read: NULL argument");
+  float tot = 0.0f;
+  for (int i = 0; i < g_prof.n; ++i) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(g_prof.e[i]) != hipSuccess || hipEventElapsedTime(&ms, g_prof.s[i], g_prof.e[i]) != hipSuccess) {
+      pqn_set_error("pqn_prof_read: event query failed");
+      return PQN_E_HIP;
+    }
+    tot += ms;
+  }
+  *count = g_prof.n;
+  *total_ms = tot;
+  g_prof.n = 0;
+  return PQN_OK;
+}
+
 template <int C>
 static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits,
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
@@ -951,8 +994,11 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   const float inv_b = 1.0f / (float)nb;
   static const int ablate = getenv("PQN_ABLATE_TRAIN") ? atoi(getenv("PQN_ABLATE_TRAIN")) : 0;  // profiling only
+  const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
+  if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
   hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles), dim3(QN_THREADS), smem1, st, nb, idx, bits, action, target,
                      theta, w1b, L, inv_b, dzT, gpart, ablate);
+  if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
   hipLaunchKernelGGL((qnet_cnn_wgrad_kernel<C>), dim3(32, nks), dim3(QN_THREADS), smem2, st, nb, idx, bits, theta, L, dzT,
                      wpart);
   hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total)), dim3(256), 0, st, L, ntiles, nks, rec,
