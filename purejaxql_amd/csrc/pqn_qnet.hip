@@ -37,6 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define QN_ZS 132         // LDS row stride of the z tile
 #define QN_LN_EPS 1e-6f   // flax nn.LayerNorm default
 #define QN_MAXA 8
+#define QN_HP_FLOATS (384 + 128 * QN_MAXA + QN_MAXA)   // head parameters staged in LDS
 #define QN_STG 20        // floats per staged point (16 + pad: conflict-free ds_read_b128 across lanes)
 
 template <int C>
@@ -51,6 +52,7 @@ struct CnnSmem {
   float *z;       // [QN_TILE][QN_ZS]
   float *wc;      // [KW][16] conv kernel, then bias[16], ln0 scale[16], ln0 bias[16]
   float *stg;     // [QN_WAVES][64 points][QN_STG] MFMA-layout -> point-per-lane transposition buffer
+  float *hp;      // head parameters: b1[128] | ln1 scale[128] | ln1 bias[128] | w2[128][A] | b2[A]
   uint32_t *bits; // [QN_TILE][OW]
 };
 
@@ -263,7 +265,7 @@ PQN_D void phase3_head(const CnnSmem &s, const float *__restrict__ theta, const 
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int o = sub + 16 * r;
-    v[r] = s.z[m * QN_ZS + o] + theta[L.off_b1 + o];
+    v[r] = s.z[m * QN_ZS + o] + s.hp[o];
     sum += v[r];
     sq = fmaf(v[r], v[r], sq);
   }
@@ -276,16 +278,16 @@ PQN_D void phase3_head(const CnnSmem &s, const float *__restrict__ theta, const 
   for (int r = 0; r < 8; ++r) {
     const int o = sub + 16 * r;
     xh[r] = (v[r] - mean) * rstd;
-    h2[r] = fmaxf(fmaf(xh[r], theta[L.off_ln1s + o], theta[L.off_ln1b + o]), 0.0f);
+    h2[r] = fmaxf(fmaf(xh[r], s.hp[128 + o], s.hp[256 + o]), 0.0f);
   }
 #pragma unroll
   for (int a = 0; a < QN_MAXA; ++a) {
     float part = 0.f;
     if (a < L.a) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) part = fmaf(h2[r], theta[L.off_w2 + (sub + 16 * r) * L.a + a], part);
+      for (int r = 0; r < 8; ++r) part = fmaf(h2[r], s.hp[384 + (sub + 16 * r) * L.a + a], part);
     }
-    q[a] = group16_sum(part) + (a < L.a ? theta[L.off_b2 + a] : 0.0f);
+    q[a] = group16_sum(part) + (a < L.a ? s.hp[384 + 128 * L.a + a] : 0.0f);
   }
 }
 
@@ -293,6 +295,10 @@ template <int C>
 PQN_D void load_tile_common(const CnnSmem &s, const float *__restrict__ theta, const pqn_cnn_layout_t &L, int tid) {
   using Cfg = CnnCfg<C>;
   for (int i = tid; i < Cfg::KW * 16 + 48; i += QN_THREADS) s.wc[i] = theta[L.off_wc + i];  // kernel|bias|ln0s|ln0b contiguous
+  // head parameters (read long after the prologue: their L2 latency is hidden behind phases 1-2)
+  for (int i = tid; i < 384; i += QN_THREADS) s.hp[i] = theta[L.off_b1 + i];
+  for (int i = tid; i < 128 * L.a; i += QN_THREADS) s.hp[384 + i] = theta[L.off_w2 + i];
+  if (tid < L.a) s.hp[384 + 128 * L.a + tid] = theta[L.off_b2 + tid];
 }
 
 template <int C>
@@ -303,14 +309,16 @@ PQN_D CnnSmem carve_smem(char *base) {
   s.z = s.h1 + QN_TILE * QN_H1S;
   s.wc = s.z + QN_TILE * QN_ZS;
   s.stg = s.wc + ((Cfg::KW * 16 + 48 + 3) & ~3);
-  s.bits = reinterpret_cast<uint32_t *>(s.stg + QN_WAVES * 64 * QN_STG);
+  s.hp = s.stg + QN_WAVES * 64 * QN_STG;
+  s.bits = reinterpret_cast<uint32_t *>(s.hp + QN_HP_FLOATS);
   return s;
 }
 
 template <int C>
 constexpr size_t cnn_smem_bytes() {
   using Cfg = CnnCfg<C>;
-  return sizeof(float) * (QN_TILE * QN_H1S + QN_TILE * QN_ZS + ((Cfg::KW * 16 + 48 + 3) & ~3) + QN_WAVES * 64 * QN_STG) +
+  return sizeof(float) * (QN_TILE * QN_H1S + QN_TILE * QN_ZS + ((Cfg::KW * 16 + 48 + 3) & ~3) + QN_WAVES * 64 * QN_STG +
+                          QN_HP_FLOATS) +
          sizeof(uint32_t) * (QN_TILE * Cfg::OW + 4);
 }
 
@@ -337,12 +345,13 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
   }
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;  // b[w+1] guard word
   __syncthreads();
-  if (ablate != 1) phase1_conv<C>(s, tid);
+  if (ablate != 1 && ablate != 6 && ablate != 7) phase1_conv<C>(s, tid);
   __syncthreads();
-  if (ablate == 0 || ablate == 1) phase2_fc1<0>(s, theta + L.off_w1, tid);
+  if (ablate == 0 || ablate == 1 || ablate == 5) phase2_fc1<0>(s, theta + L.off_w1, tid);
   else if (ablate == 2) phase2_fc1<2>(s, theta + L.off_w1, tid);
   else if (ablate == 3) phase2_fc1<3>(s, theta + L.off_w1, tid);
   __syncthreads();
+  if (ablate == 5 || ablate == 7) return;   // profiling: no head
   if (tid >= 256) return;  // the head needs 16 lanes per sample
   float q[QN_MAXA], h2[8], xh[8], rstd;
   phase3_head(s, theta, L, tid, q, h2, xh, rstd);
@@ -474,12 +483,12 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int o = sub + 16 * r;
-      const float dh2 = gm * theta[L.off_w2 + o * L.a + act];
+      const float dh2 = gm * s.hp[384 + o * L.a + act];
       const float dy = h2[r] > 0.0f ? dh2 : 0.0f;
       tA[m * QN_ZS + o] = dy * xh[r];
       tB[m * QN_ZS + o] = dy;
       tH[m * QN_ZS + o] = h2[r];
-      dxh[r] = dy * theta[L.off_ln1s + o];
+      dxh[r] = dy * s.hp[128 + o];
       s1 += dxh[r];
       s2 = fmaf(dxh[r], xh[r], s2);
     }
@@ -544,48 +553,47 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     for (int g = 0; g < 8; ++g)
       afr[g] = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 16 * g + 4 * (lane >> 4));
     const int col = lane & 15, r0 = 4 * (lane >> 4);
-    f32x4 bA[8], bB[8];
-    constexpr int IPW = 64 / QN_WAVES / 2;   // pairs of i-blocks per wave
+    constexpr int IPW = 64 / QN_WAVES / 2;   // pairs of i-blocks (16 conv features each) per wave
     const int ib_first = 2 * IPW * wave;
+    f32x4 buf[2][2][8];                       // [parity][block of the pair][k group]
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      bA[g] = wb[(g * 64 + ib_first) * 64 + lane];
-      bB[g] = wb[(g * 64 + ib_first + 1) * 64 + lane];
+      buf[0][0][g] = wb[(g * 64 + ib_first) * 64 + lane];
+      buf[0][1][g] = wb[(g * 64 + ib_first + 1) * 64 + lane];
     }
-#pragma unroll 1
+#pragma unroll
     for (int ip = 0; ip < IPW; ++ip) {
       const int ib = ib_first + 2 * ip;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 cA[8], cB[8];
-#pragma unroll
-      for (int g = 0; g < 8; ++g) { cA[g] = bA[g]; cB[g] = bB[g]; }
       if (ip + 1 < IPW) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-          bA[g] = wb[(g * 64 + ib + 2) * 64 + lane];
-          bB[g] = wb[(g * 64 + ib + 3) * 64 + lane];
+          buf[(ip + 1) & 1][0][g] = wb[(g * 64 + ib + 2) * 64 + lane];
+          buf[(ip + 1) & 1][1][g] = wb[(g * 64 + ib + 3) * 64 + lane];
         }
       }
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].x, cA[g].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].x, cB[g].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].y, cA[g].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].y, cB[g].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].z, cA[g].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].z, cB[g].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].w, cA[g].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].w, cB[g].w, acc1, 0, 0, 0);
+        const f32x4 c0 = buf[ip & 1][0][g], c1 = buf[ip & 1][1][g];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].x, c0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].x, c1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].y, c0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].y, c1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].z, c0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].z, c1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].w, c0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].w, c1.w, acc1, 0, 0, 0);
       }
       // relu mask (h1 > 0) and in-place overwrite of the h1 tile with d(pre-relu)
       float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
-      float *p1 = p0 + 16;
-      const float a0[4] = {acc0.x, acc0.y, acc0.z, acc0.w}, a1[4] = {acc1.x, acc1.y, acc1.z, acc1.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p0[r * QN_H1S] = p0[r * QN_H1S] > 0.0f ? a0[r] : 0.0f;
-        p1[r * QN_H1S] = p1[r * QN_H1S] > 0.0f ? a1[r] : 0.0f;
-      }
+      p0[0] = p0[0] > 0.0f ? acc0.x : 0.0f;
+      p0[QN_H1S] = p0[QN_H1S] > 0.0f ? acc0.y : 0.0f;
+      p0[2 * QN_H1S] = p0[2 * QN_H1S] > 0.0f ? acc0.z : 0.0f;
+      p0[3 * QN_H1S] = p0[3 * QN_H1S] > 0.0f ? acc0.w : 0.0f;
+      p0[16] = p0[16] > 0.0f ? acc1.x : 0.0f;
+      p0[QN_H1S + 16] = p0[QN_H1S + 16] > 0.0f ? acc1.y : 0.0f;
+      p0[2 * QN_H1S + 16] = p0[2 * QN_H1S + 16] > 0.0f ? acc1.z : 0.0f;
+      p0[3 * QN_H1S + 16] = p0[3 * QN_H1S + 16] > 0.0f ? acc1.w : 0.0f;
     }
   }
   __syncthreads();
