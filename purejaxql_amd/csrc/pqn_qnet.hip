@@ -391,6 +391,11 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
 // "Small" partial record per tile (floats): [conv kernel KW*16 | conv bias 16 | ln0 scale 16 |
 // ln0 bias 16 | b1 128 | ln1 scale 128 | ln1 bias 128 | w2 128*A | b2 A | loss | sum q_a].
 // ===========================================================================
+#define QW_SLAB 256
+// leading dimension of the transposed operands: nb + 32 floats, so consecutive rows (16 KB apart at
+// nb = 4096) do not all land on the same L2 channel
+__host__ __device__ inline int qw_ld(int nb) { return nb + 32; }
+
 template <int C>
 struct TrainCfg {
   using Cfg = CnnCfg<C>;
@@ -430,7 +435,8 @@ template <int C>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, const float *__restrict__ w1b,
-    pqn_cnn_layout_t L, float inv_b, float *__restrict__ dzT, float *__restrict__ gpart, int ablate) {
+    pqn_cnn_layout_t L, float inv_b, float *__restrict__ dzT, float *__restrict__ h1T, float *__restrict__ gpart,
+    int ablate) {
   using Cfg = CnnCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const TrainSmem ts = carve_train_smem<C>(smem_raw);
@@ -451,6 +457,13 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   // ---- P1..P3: forward ---------------------------------------------------------------------
   phase1_conv<C>(s, tid);
   __syncthreads();
+  // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m], 16-B stores issued before the MFMA phase
+  for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
+    const int i = e >> 2, mq = e & 3;
+    const float *src = s.h1 + (4 * mq) * QN_H1S + i;
+    const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
+    *reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq) = v;
+  }
   phase2_fc1<0>(s, theta + L.off_w1, tid);
   __syncthreads();
   // the head (LN1 / fc2 / loss) needs 16 lanes per sample: waves 0..3 only
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     const int o = i >> 2, mq = i & 3;
     const f32x4 v = {s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], s.z[(4 * mq + 2) * QN_ZS + o],
                      s.z[(4 * mq + 3) * QN_ZS + o]};
-    *reinterpret_cast<f32x4 *>(dzT + (size_t)o * nb + b0 + 4 * mq) = v;
+    *reinterpret_cast<f32x4 *>(dzT + (size_t)o * qw_ld(nb) + b0 + 4 * mq) = v;
   }
   __syncthreads();
   if (tid == 0) {
@@ -721,96 +734,76 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// T2: dW1[i][o] = sum_b h1[b][i] dz[b][o].  Workgroup (it, ks): rows i in [32 it, 32 it + 32)
-// (= conv positions 2it, 2it+1, recomputed from the packed obs), samples [512 ks, 512 ks + 512).
-// A = h1^T tile from LDS, B = dz^T from L2; output written in fragment layout into wpart[ks].
+// T2: dW1[i][o] = sum_b h1[b][i] dz[b][o]  -- a plain MFMA GEMM on the two transposed operands T1
+// left in the workspace (h1T [1024][nb], dzT [128][nb]).  Workgroup (it, ks): 64 rows of i x all
+// 128 o, K-slab of 256 samples; wave w owns column block w and 4 row blocks.  Per 16-sample K group a
+// lane loads 5 dwordx4 (4 A + 1 B fragment) for 16 MFMAs; the output tile is already in the
+// fragment layout of the parameter buffer, one dwordx4 store per block into wpart[ks].
 // ---------------------------------------------------------------------------
-#define QW_CH 256   // samples per LDS chunk
-#define QW_HS 260   // row stride of the h1^T chunk
 
-template <int C>
-__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_wgrad_kernel(int nb, const int64_t *__restrict__ idx,
-                                                                    const uint32_t *__restrict__ obs_bits,
-                                                                    const float *__restrict__ theta, pqn_cnn_layout_t L,
+__global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_kernel(int nb, const float *__restrict__ h1T,
                                                                     const float *__restrict__ dzT,
                                                                     float *__restrict__ wpart) {
-  using Cfg = CnnCfg<C>;
-  constexpr int BS = Cfg::OW + 1;  // padded row stride of the bits chunk (lanes read different samples)
-  constexpr int NG = QW_CH / 16;   // 16-sample K groups per chunk
   static_assert(QN_WAVES == 8, "one output column block per wave");
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *h1t = reinterpret_cast<float *>(smem_raw);                    // [32][QW_HS]
-  float *wc = h1t + 32 * QW_HS;
-  float *stg = wc + ((Cfg::KW * 16 + 48 + 3) & ~3);                     // [2*QW_CH points][QN_STG]
-  uint32_t *bits = reinterpret_cast<uint32_t *>(stg + 2 * QW_CH * QN_STG);  // [QW_CH][BS] + guard
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // operands are staged through LDS so each element is fetched once per workgroup (the 8 waves share
+  // the 64-row A tile); double-buffered, one barrier per 32-sample step.
+  constexpr int KS = 32;                 // samples per step
+  constexpr int ROWS = 64 + 128;         // A rows (i) then B rows (o)
+  constexpr int RS = KS + 4;             // padded LDS row stride (floats): conflict-free b128 fragment reads
+  __shared__ __attribute__((aligned(16))) float tile[2][ROWS * RS];
+  const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6;
   const int it = blockIdx.x, ks = blockIdx.y;
-  for (int i = tid; i < Cfg::KW * 16 + 48; i += QN_THREADS) wc[i] = theta[L.off_wc + i];
-  __syncthreads();
-  ConvMfma<C> cv;
-  cv.init(wc, lane);
-  const int o = lane & 15;
-  const float bias = wc[Cfg::KW * 16 + o];
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  const int cb = wave;
-  const int bend = min(nb, ks * 512 + 512);
-  const int pp = wave >> 2;                 // conv position handled by this wave: 2*it + pp
-  const int pos = 2 * it + pp;
-  const int base = ((pos >> 3) * 10 + (pos & 7)) * C;
-  for (int c0 = ks * 512; c0 < bend; c0 += QW_CH) {
-    const int ngroups = min(NG, (bend - c0) / 16);
-    // prefetch this chunk's dz^T fragments (B operand) before the conv so L2 latency hides behind it
-    f32x4 x[NG];
+  const int o = lane & 15, kq = 4 * (lane >> 4);
+  const int c0 = ks * QW_SLAB;
+  const int nsteps = (min(QW_SLAB, nb - c0) + KS - 1) / KS;   // last step may be half full (nb % 16 == 0)
+  const int ld = qw_ld(nb);
+  // loader mapping: ROWS*KS/4 = 1536 float4 per step = 3 per thread
+  const float *src[3];
+  int dst[3], col[3];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-      if (g < ngroups)
-        x[g] = *reinterpret_cast<const f32x4 *>(dzT + (size_t)(16 * cb + o) * nb + c0 + 16 * g + 4 * (lane >> 4));
-    __syncthreads();  // previous chunk's MFMA reads of h1t / conv reads of bits are done
-    for (int i = tid; i < QW_CH * Cfg::OW; i += QN_THREADS) {
-      const int le = i / Cfg::OW, w = i - le * Cfg::OW;
-      bits[le * BS + w] = (c0 + le < nb) ? obs_bits[(size_t)idx[c0 + le] * Cfg::OW + w] : 0u;
+  for (int j = 0; j < 3; ++j) {
+    const int e = tid + QN_THREADS * j;
+    const int row = e >> 3, c4 = (e & 7) * 4;           // 8 float4 per 32-sample row
+    src[j] = (row < 64 ? h1T + (size_t)(64 * it + row) * ld : dzT + (size_t)(row - 64) * ld) + c0 + c4;
+    dst[j] = row * RS + c4;
+    col[j] = c0 + c4;                                   // sample index of the float4 at step 0
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 pre[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) pre[j] = (col[j] < nb) ? *reinterpret_cast<const f32x4 *>(src[j]) : zero4;
+  for (int st = 0; st < nsteps; ++st) {
+    float *t = tile[st & 1];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4 *>(t + dst[j]) = pre[j];
+    if (st + 1 < nsteps) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        pre[j] = (col[j] + KS * (st + 1) < nb) ? *reinterpret_cast<const f32x4 *>(src[j] + KS * (st + 1)) : zero4;
     }
-    if (tid < QW_CH) bits[tid * BS + Cfg::OW] = 0u;
-    __syncthreads();
-    // conv (MFMA) for the 512 points (sample b, position 2it+pp) of this chunk -> staging -> LN per lane.
-    // wave w: pp = w>>2, sample blocks 4(w&3)..+3  ==  points [64w, 64w+64) of the staging buffer
+    __syncthreads();   // tile[st&1] complete; tile[(st+1)&1] was last read two steps ago
 #pragma unroll
-    for (int t2 = 0; t2 < 4; t2 += 2) {
-      const int sbA = 4 * (wave & 3) + t2, sbB = sbA + 1;
-      f32x4 dA, dB;
-      cv.tile2(bits + (16 * sbA + o) * BS, base, bits + (16 * sbB + o) * BS, base, dA, dB);
-      stage_tile(stg, pp * QW_CH + 16 * sbA, dA, bias, lane);
-      stage_tile(stg, pp * QW_CH + 16 * sbB, dB, bias, lane);
-    }
-    {
-      float xhat[16], rstd;
-      ln16_point(stg, tid, xhat, rstd);            // point tid = pp*256 + b_local
-      float *dst = h1t + (pp * 16) * QW_HS + (tid & (QW_CH - 1));
+    for (int g = 0; g < KS / 16; ++g) {
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(t + (64 + 16 * cb + o) * RS + 16 * g + kq);
+      f32x4 a4[4];
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        dst[c * QW_HS] = fmaxf(fmaf(xhat[c], wc[Cfg::KW * 16 + 16 + c], wc[Cfg::KW * 16 + 32 + c]), 0.0f);
-    }
-    __syncthreads();
+      for (int a = 0; a < 4; ++a) a4[a] = *reinterpret_cast<const f32x4 *>(t + (16 * a + o) * RS + 16 * g + kq);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g < ngroups) {
-        const int boff = 16 * g + 4 * (lane >> 4);
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(h1t + o * QW_HS + boff);
-        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(h1t + (16 + o) * QW_HS + boff);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, x[g].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, x[g].x, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, x[g].y, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, x[g].y, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, x[g].z, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, x[g].z, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, x[g].w, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, x[g].w, acc[1], 0, 0, 0);
-      }
+      for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[a].x, b.x, acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[a].y, b.y, acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[a].z, b.z, acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[a].w, b.w, acc[a], 0, 0, 0);
     }
   }
   f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
 #pragma unroll
-  for (int a = 0; a < 2; ++a) out[((2 * it + a) * 8 + cb) * 64 + lane] = acc[a];
+  for (int a = 0; a < 4; ++a) out[((4 * it + a) * 8 + cb) * 64 + lane] = acc[a];
 }
 
 // ---------------------------------------------------------------------------
@@ -984,20 +977,17 @@ template <int C>
 static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits,
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                         const int32_t *count, float *ws, float *loss_out, float *qv_out, hipStream_t st) {
-  const int ntiles = nb / QN_TILE, nks = (nb + 511) / 512, rec = small_record_floats(C, L.a);
+  const int ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB, rec = small_record_floats(C, L.a);
   float *scratch = ws;
   float *dzT = ws + 1024;
-  float *gpart = dzT + (size_t)QN_HID * nb;
+  float *h1T = dzT + (size_t)QN_HID * qw_ld(nb);
+  float *gpart = h1T + (size_t)QN_H1 * qw_ld(nb);
   float *wpart = gpart + (size_t)ntiles * rec;
   const size_t smem1 = train_smem_bytes<C>();
-  const size_t smem2 = sizeof(float) * (32 * QW_HS + ((CnnCfg<C>::KW * 16 + 48 + 3) & ~3) + 2 * QW_CH * QN_STG) +
-                       sizeof(uint32_t) * (QW_CH * (CnnCfg<C>::OW + 1) + 4);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_wgrad_kernel<C>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
     attr_set = true;
   }
   const float inv_b = 1.0f / (float)nb;
@@ -1005,10 +995,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
   if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
   hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles), dim3(QN_THREADS), smem1, st, nb, idx, bits, action, target,
-                     theta, w1b, L, inv_b, dzT, gpart, ablate);
+                     theta, w1b, L, inv_b, dzT, h1T, gpart, ablate);
   if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
-  hipLaunchKernelGGL((qnet_cnn_wgrad_kernel<C>), dim3(32, nks), dim3(QN_THREADS), smem2, st, nb, idx, bits, theta, L, dzT,
-                     wpart);
+  hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart);
   hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total)), dim3(256), 0, st, L, ntiles, nks, rec,
                      gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b);
   return pqn_check_launch("pqn_qnet_cnn_grad");
@@ -1016,8 +1005,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
 
 extern "C" int64_t pqn_qnet_cnn_workspace_floats(const pqn_cnn_layout_t *L, int32_t nb) {
   if (!L || nb <= 0) return -1;
-  const int64_t ntiles = nb / QN_TILE, nks = (nb + 511) / 512;
-  return 1024 + (int64_t)QN_HID * nb + ntiles * small_record_floats(L->c, L->a) + nks * (int64_t)QN_H1 * QN_HID;
+  const int64_t ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB;
+  return 1024 + (int64_t)(QN_HID + QN_H1) * qw_ld(nb) + ntiles * small_record_floats(L->c, L->a) +
+         nks * (int64_t)QN_H1 * QN_HID;
 }
 
 extern "C" int pqn_qnet_cnn_grad(const pqn_cnn_layout_t *L, int32_t nb, const int64_t *idx, const uint32_t *obs_bits,
