@@ -185,6 +185,48 @@ int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *layout /* host */, const float
 int pqn_prof_enable(int32_t on);
 int pqn_prof_read(int32_t *count /* host */, float *total_ms /* host */);
 
+/* ---- one whole PQN update enqueued from C++ ------------------------------------------------------ */
+/* `_update_step` (pqn_minatar.py:176-369) for the MinAtar CNN: NUM_STEPS x (forward + eps-greedy, env
+ * step), bootstrap forward, Q(lambda), NUM_EPOCHS x (shuffle, NUM_MINIBATCHES x (grad, clip + RAdam)),
+ * metrics.  Everything that varies between updates is derived on the device from clock[0] (the update
+ * index u): step keys fold_in(key_roll, u*T+t), epoch keys fold_in(key_shuf, u*EPOCHS+ep), eps(u), the
+ * metrics row.  The call only enqueues (~340 kernels), so it can be captured once in a hipGraph and
+ * replayed.  All buffers are caller-owned device memory. */
+#define PQN_NUM_METRICS 11 /* env_step, update_steps, env_frame, grad_steps, td_loss, qvals, discount,
+                              returned_episode_returns, returned_episode_lengths, timestep, returned_episode */
+typedef struct {
+  int32_t env_id, num_envs, num_steps, num_minibatches, num_epochs, obs_words, metrics_capacity, reserved;
+  float gamma, lambda, rew_scale;                 /* GAMMA, LAMBDA, REW_SCALE */
+  float eps_start, eps_finish, eps_decay_steps;   /* linear_schedule over updates (:134-138) */
+  float lr_init, lr_end, lr_steps, max_grad_norm; /* :140-147,159-162 */
+  uint64_t key_roll, key_shuf;
+  uint64_t sort_temp_bytes;
+  pqn_cnn_layout_t layout;
+  int32_t *clock;        /* [4]  clock[0] = update index u, advanced by the call */
+  uint64_t *sched_keys;  /* [num_steps + num_epochs] scratch */
+  float *sched_eps;      /* [1] scratch */
+  uint32_t *state;       /* [state_words][N] env state, stepped in place */
+  uint32_t *bits;        /* [T+1][N][obs_words] packed observations; slot 0 = current obs on entry and exit */
+  int32_t *action;       /* [T][N] */
+  float *reward;         /* [T][N] (already scaled by rew_scale) */
+  uint8_t *done;         /* [T][N] */
+  float *qmax;           /* [T][N] max_a q(s_t) */
+  float *discount, *rer; /* [T][N] info["discount"], info["returned_episode_returns"] */
+  int32_t *rel, *ts;     /* [T][N] info["returned_episode_lengths"], info["timestep"] */
+  float *target;         /* [T][N] Q(lambda) targets */
+  float *last_q;         /* [N] */
+  int64_t *sort_keys_in, *sort_keys_out; /* [T*N] */
+  void *sort_temp;       /* pqn_update_sort_temp_bytes(T*N) bytes */
+  float *theta, *w1b, *grad, *m, *v; /* kernel-layout parameter / optimizer buffers (pqn_cnn_layout) */
+  int32_t *count;        /* [1] optimizer step counter */
+  float *workspace;      /* pqn_qnet_cnn_workspace_floats(layout, T*N/num_minibatches) */
+  float *loss_buf, *qv_buf; /* [num_minibatches*num_epochs] per-step td loss / mean chosen q */
+  double *metrics;       /* [metrics_capacity][PQN_NUM_METRICS], row u written by update u */
+} pqn_update_args_t;
+
+int64_t pqn_update_sort_temp_bytes(int32_t n);
+int pqn_cnn_update(const pqn_update_args_t *args /* host */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

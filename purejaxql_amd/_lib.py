@@ -57,6 +57,8 @@ SIGNATURES = {
     "pqn_qnet_cnn_pack_w1b": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_prof_enable": (c_int, [c_int32]),
     "pqn_prof_read": (c_int, [c_void_p, c_void_p]),
+    "pqn_update_sort_temp_bytes": (c_int64, [c_int32]),
+    "pqn_cnn_update": (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None

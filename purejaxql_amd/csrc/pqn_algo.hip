@@ -112,9 +112,11 @@ extern "C" int pqn_q_lambda(const float *reward, const uint8_t *done, const floa
 // shuffle keys: key_i = (bits_i >> 1) << 32 | i  (unique -> argsort is a
 // well-defined permutation).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void shuffle_keys_kernel(uint64_t key, int n, int64_t *__restrict__ keys) {
+__global__ __launch_bounds__(256) void shuffle_keys_kernel(uint64_t key, const uint64_t *__restrict__ key_dev, int n,
+                                                           int64_t *__restrict__ keys) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (key_dev) key = *key_dev;
   uint32_t o0, o1;
   pqn_bits(key, (uint32_t)i, 0u, o0, o1);
   keys[i] = (int64_t)(((uint64_t)(o0 >> 1) << 32) | (uint32_t)i);
@@ -122,7 +124,13 @@ __global__ __launch_bounds__(256) void shuffle_keys_kernel(uint64_t key, int n, 
 
 extern "C" int pqn_shuffle_keys(uint64_t key, int32_t n, int64_t *keys, void *stream) {
   PQN_REQUIRE(keys && n > 0, "pqn_shuffle_keys: NULL keys or n <= 0");
-  hipLaunchKernelGGL(shuffle_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, key, n, keys);
+  hipLaunchKernelGGL(shuffle_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, key, nullptr, n,
+                     keys);
+  return pqn_check_launch("pqn_shuffle_keys");
+}
+
+int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStream_t st) {
+  hipLaunchKernelGGL(shuffle_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, 0, key_dev, n, keys);
   return pqn_check_launch("pqn_shuffle_keys");
 }
 

@@ -78,3 +78,11 @@ inline int pqn_radam_blocks(int64_t n) {
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
                      float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
                      float *w1b, int norm_pass, int nparts, hipStream_t st);
+
+// internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
+int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
+                     const pqn_step_out_t &out, hipStream_t st);
+int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStream_t st);
+int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *obs_bits, const float *theta, float *q,
+                             int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
+                             const uint64_t *key_dev, hipStream_t st);

@@ -265,10 +265,12 @@ struct LogRec {
 // N=4096 -> 256 workgroups at EPB=16 (one per CU).
 // ===========================================================================
 template <class Env, int EPB, bool IS_RESET>
-__global__ __launch_bounds__(256) void minatar_kernel(int n, uint64_t key, const uint32_t *__restrict__ state_in,
+__global__ __launch_bounds__(256) void minatar_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev,
+                                                      float rscale, const uint32_t *__restrict__ state_in,
                                                       uint32_t *__restrict__ state_out,
                                                       const int32_t *__restrict__ action, pqn_step_out_t out) {
   __shared__ __attribute__((aligned(16))) uint32_t s_bits[EPB * Env::OBS_WORDS];
+  if (key_dev) key = *key_dev;  // graph-replayable launches read the step key from device memory
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * EPB;
   const int e = e0 + tid;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void minatar_kernel(int n, uint64_t key, const
       const float reward = env.step(action[e], key, (uint32_t)e, done);
       log.step(reward, done);
       if (done) env.reset(key, (uint32_t)e);  // select(done, reset_env, step_env)
-      out.reward[e] = reward;
+      out.reward[e] = reward * rscale;
       out.done[e] = (uint8_t)done;
       if (out.discount) out.discount[e] = done ? 0.0f : 1.0f;
       if (out.returned_episode_returns) out.returned_episode_returns[e] = log.ret_ret;
@@ -329,9 +331,11 @@ __global__ __launch_bounds__(256) void minatar_kernel(int n, uint64_t key, const
 // Flat-observation kernels (CartPole): one lane per env, float4 obs store.
 // ===========================================================================
 template <class Env, bool IS_RESET>
-__global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const uint32_t *__restrict__ state_in,
+__global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev,
+                                                   float rscale, const uint32_t *__restrict__ state_in,
                                                    uint32_t *__restrict__ state_out,
                                                    const int32_t *__restrict__ action, pqn_step_out_t out) {
+  if (key_dev) key = *key_dev;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   Env env;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const ui
     const float reward = env.step(action[e], key, (uint32_t)e, done);
     log.step(reward, done);
     if (done) env.reset(key, (uint32_t)e);
-    out.reward[e] = reward;
+    out.reward[e] = reward * rscale;
     out.done[e] = (uint8_t)done;
     if (out.discount) out.discount[e] = done ? 0.0f : 1.0f;
     if (out.returned_episode_returns) out.returned_episode_returns[e] = log.ret_ret;
@@ -424,24 +428,27 @@ extern "C" int pqn_env_spec(int env_id, pqn_env_spec_t *spec) {
 }
 
 template <class Env, bool IS_RESET>
-static void launch_minatar(int n, uint64_t key, const uint32_t *si, uint32_t *so, const int32_t *action,
-                           const pqn_step_out_t &out, hipStream_t st) {
+static void launch_minatar(int n, uint64_t key, const uint64_t *key_dev, float rscale, const uint32_t *si,
+                           uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st) {
   // EPB=16 keeps >=256 workgroups at N=4096; larger batches use 64 envs/WG.
   if (n <= 32768) {
-    hipLaunchKernelGGL((minatar_kernel<Env, 16, IS_RESET>), dim3((n + 15) / 16), dim3(256), 0, st, n, key, si, so, action, out);
+    hipLaunchKernelGGL((minatar_kernel<Env, 16, IS_RESET>), dim3((n + 15) / 16), dim3(256), 0, st, n, key, key_dev, rscale,
+                       si, so, action, out);
   } else {
-    hipLaunchKernelGGL((minatar_kernel<Env, 64, IS_RESET>), dim3((n + 63) / 64), dim3(256), 0, st, n, key, si, so, action, out);
+    hipLaunchKernelGGL((minatar_kernel<Env, 64, IS_RESET>), dim3((n + 63) / 64), dim3(256), 0, st, n, key, key_dev, rscale,
+                       si, so, action, out);
   }
 }
 
 template <bool IS_RESET>
-static int dispatch(int env_id, int n, uint64_t key, const uint32_t *si, uint32_t *so, const int32_t *action,
-                    const pqn_step_out_t &out, hipStream_t st) {
+static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, float rscale, const uint32_t *si,
+                    uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st) {
   switch (env_id) {
-    case PQN_ENV_BREAKOUT: launch_minatar<Breakout, IS_RESET>(n, key, si, so, action, out, st); break;
+    case PQN_ENV_BREAKOUT: launch_minatar<Breakout, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st); break;
     case PQN_ENV_CARTPOLE:
       PQN_REQUIRE(out.obs_bits == nullptr, "CartPole-v1 has no packed observation");
-      hipLaunchKernelGGL((flat_kernel<CartPole, IS_RESET>), dim3((n + 255) / 256), dim3(256), 0, st, n, key, si, so, action, out);
+      hipLaunchKernelGGL((flat_kernel<CartPole, IS_RESET>), dim3((n + 255) / 256), dim3(256), 0, st, n, key, key_dev, rscale,
+                         si, so, action, out);
       break;
     default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
   }
@@ -455,7 +462,7 @@ extern "C" int pqn_env_reset(int env_id, int32_t n, uint64_t key, uint32_t *stat
   pqn_step_out_t out = {};
   out.obs = obs;
   out.obs_bits = obs_bits;
-  return dispatch<true>(env_id, n, key, nullptr, state, nullptr, out, (hipStream_t)stream);
+  return dispatch<true>(env_id, n, key, nullptr, 1.0f, nullptr, state, nullptr, out, (hipStream_t)stream);
 }
 
 extern "C" int pqn_env_step(int env_id, int32_t n, uint64_t key, const uint32_t *state_in, uint32_t *state_out,
@@ -463,7 +470,13 @@ extern "C" int pqn_env_step(int env_id, int32_t n, uint64_t key, const uint32_t 
   PQN_REQUIRE(n > 0, "pqn_env_step: n must be > 0 (got %d)", n);
   PQN_REQUIRE(state_in && state_out && action && out, "pqn_env_step: NULL argument");
   PQN_REQUIRE(out->reward && out->done, "pqn_env_step: out->reward and out->done are required");
-  return dispatch<false>(env_id, n, key, state_in, state_out, action, *out, (hipStream_t)stream);
+  return dispatch<false>(env_id, n, key, nullptr, 1.0f, state_in, state_out, action, *out, (hipStream_t)stream);
+}
+
+// internal (pqn_update.hip): step key read from device memory, reward scaled at the source
+int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
+                     const pqn_step_out_t &out, hipStream_t st) {
+  return dispatch<false>(env_id, n, 0, key_dev, rscale, state, state, action, out, st);
 }
 
 template <bool EXPORT>

@@ -332,7 +332,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
                                                            const float *__restrict__ theta, pqn_cnn_layout_t L,
                                                            float *__restrict__ q_out, int32_t *__restrict__ action,
                                                            float *__restrict__ qmax, float eps, uint64_t key,
-                                                           int ablate) {
+                                                           const float *__restrict__ eps_dev,
+                                                           const uint64_t *__restrict__ key_dev, int ablate) {
   using Cfg = CnnCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const CnnSmem s = carve_smem<C>(smem_raw);
@@ -369,6 +370,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
     }
     if (qmax) qmax[e] = bv;
     if (action) {
+      if (key_dev) key = *key_dev;   // graph-replayable launches read key / eps from device memory
+      if (eps_dev) eps = *eps_dev;
       uint32_t o0, o1;
       pqn_bits(key, (uint32_t)e, PQN_STREAM_ACT, o0, o1);
       const float u = pqn_uniform(o0);
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   load_tile_common<C>(s, theta, L, tid);
   for (int i = tid; i < QN_TILE * Cfg::OW; i += QN_THREADS) {
     const int le = i / Cfg::OW, w = i - le * Cfg::OW;
-    s.bits[i] = (b0 + le < nb) ? obs_bits[(size_t)idx[b0 + le] * Cfg::OW + w] : 0u;
+    s.bits[i] = (b0 + le < nb) ? obs_bits[(size_t)(idx[b0 + le] & 0xFFFFFFFFll) * Cfg::OW + w] : 0u;
   }
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
   __syncthreads();
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   if (head) {
     phase3_head(s, theta, L, tid, q, h2, xh, rstd1);
     valid = (b0 + m) < nb;
-    const int64_t src = valid ? idx[b0 + m] : 0;
+    const int64_t src = valid ? (idx[b0 + m] & 0xFFFFFFFFll) : 0;
     act = valid ? action[src] : 0;
     chosen = q[0];
 #pragma unroll
@@ -901,7 +904,8 @@ extern "C" int pqn_cnn_layout(int32_t c, int32_t a, pqn_cnn_layout_t *L) {
 
 template <int C>
 static int launch_fwd(int n, const uint32_t *bits, const float *theta, const pqn_cnn_layout_t &L, float *q,
-                      int32_t *action, float *qmax, float eps, uint64_t key, hipStream_t st) {
+                      int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
+                      const uint64_t *key_dev, hipStream_t st) {
   const size_t smem = cnn_smem_bytes<C>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -911,8 +915,20 @@ static int launch_fwd(int n, const uint32_t *bits, const float *theta, const pqn
   }
   static const int ablate = getenv("PQN_ABLATE") ? atoi(getenv("PQN_ABLATE")) : 0;  // profiling only
   hipLaunchKernelGGL((qnet_cnn_fwd_kernel<C>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n, bits, theta, L,
-                     q, action, qmax, eps, key, ablate);
+                     q, action, qmax, eps, key, eps_dev, key_dev, ablate);
   return pqn_check_launch("pqn_qnet_cnn_forward");
+}
+
+int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *obs_bits, const float *theta, float *q,
+                             int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
+                             const uint64_t *key_dev, hipStream_t st) {
+  switch (L.c) {
+    case 4: return launch_fwd<4>(n, obs_bits, theta, L, q, action, qmax, eps, key, eps_dev, key_dev, st);
+    case 6: return launch_fwd<6>(n, obs_bits, theta, L, q, action, qmax, eps, key, eps_dev, key_dev, st);
+    case 7: return launch_fwd<7>(n, obs_bits, theta, L, q, action, qmax, eps, key, eps_dev, key_dev, st);
+    case 10: return launch_fwd<10>(n, obs_bits, theta, L, q, action, qmax, eps, key, eps_dev, key_dev, st);
+    default: pqn_set_error("pqn_qnet_cnn_forward: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
+  }
 }
 
 extern "C" int pqn_qnet_cnn_forward(const pqn_cnn_layout_t *L, int32_t n, const uint32_t *obs_bits, const float *theta,
@@ -920,14 +936,8 @@ extern "C" int pqn_qnet_cnn_forward(const pqn_cnn_layout_t *L, int32_t n, const 
   PQN_REQUIRE(L && obs_bits && theta, "pqn_qnet_cnn_forward: NULL argument");
   PQN_REQUIRE(n > 0, "pqn_qnet_cnn_forward: n must be > 0");
   PQN_REQUIRE(q || action || qmax, "pqn_qnet_cnn_forward: no output requested");
-  hipStream_t st = (hipStream_t)stream;
-  switch (L->c) {
-    case 4: return launch_fwd<4>(n, obs_bits, theta, *L, q, action, qmax, eps, key, st);
-    case 6: return launch_fwd<6>(n, obs_bits, theta, *L, q, action, qmax, eps, key, st);
-    case 7: return launch_fwd<7>(n, obs_bits, theta, *L, q, action, qmax, eps, key, st);
-    case 10: return launch_fwd<10>(n, obs_bits, theta, *L, q, action, qmax, eps, key, st);
-    default: pqn_set_error("pqn_qnet_cnn_forward: unsupported channel count %d", L->c); return PQN_E_UNSUPPORTED;
-  }
+  return pqn_qnet_cnn_forward_dyn(*L, n, obs_bits, theta, q, action, qmax, eps, key, nullptr, nullptr,
+                                  (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,172 @@
+// pqn_update.hip -- ONE whole PQN update (`_update_step`, purejaxql/pqn_minatar.py:176-369) enqueued from
+// C++: T x (Q-net forward + eps-greedy, env step), bootstrap forward, Q(lambda), NUM_EPOCHS x (shuffle,
+// NUM_MINIBATCHES x (grad, clip+RAdam)), metric reductions.  ~340 kernel launches from one call, no host
+// synchronisation and no host-side state: everything that changes from update to update (step keys,
+// epoch keys, eps, the metrics row) is derived on the DEVICE from a clock word, so the same enqueue is
+// valid for every update and can be captured once in a hipGraph and replayed.
+//
+// Key schedule (identical to purejaxql_amd/pqn.py and the oracle):
+//   step key  (u,t)  = fold_in(key_roll, u*T + t)      epoch key (u,ep) = fold_in(key_shuf, u*EPOCHS + ep)
+//   eps(u) = optax.linear_schedule(eps_start, eps_finish, eps_decay_steps)(u)   (pqn_minatar.py:134-138,195)
+#include <hipcub/hipcub.hpp>
+
+#include "pqn_common.h"
+
+// scalar + mean metrics of one update, in the order of pqn_minatar.py:330-338
+enum { M_ENV_STEP, M_UPDATE_STEPS, M_ENV_FRAME, M_GRAD_STEPS, M_TD_LOSS, M_QVALS, M_DISCOUNT, M_RET_RETURNS,
+       M_RET_LENGTHS, M_TIMESTEP, M_RET_EPISODE, M_COUNT };
+static_assert(M_COUNT == PQN_NUM_METRICS, "metrics row layout");
+
+__global__ void update_sched_kernel(const int32_t *__restrict__ clock, uint64_t key_roll, uint64_t key_shuf, int t_len,
+                                    int epochs, float eps_start, float eps_finish, float eps_decay_steps,
+                                    uint64_t *__restrict__ keys, float *__restrict__ eps) {
+  const int u = clock[0];
+  const int i = threadIdx.x;
+  if (i < t_len) keys[i] = pqn_fold(key_roll, (uint32_t)(u * t_len + i));
+  else if (i < t_len + epochs) keys[i] = pqn_fold(key_shuf, (uint32_t)(u * epochs + (i - t_len)));
+  if (i == 0) {
+    double e = eps_finish;
+    if (eps_decay_steps > 0.0f) {
+      double c = (double)u;
+      if (c > (double)eps_decay_steps) c = (double)eps_decay_steps;
+      e = ((double)eps_start - (double)eps_finish) * (1.0 - c / (double)eps_decay_steps) + (double)eps_finish;
+    }
+    *eps = (float)e;
+  }
+}
+
+// block b reduces one [T*N] info array to its mean (fixed order: per-thread strided sum, wave tree, 4 waves)
+__global__ __launch_bounds__(256) void update_means_kernel(const int32_t *__restrict__ clock, int count,
+                                                           const float *__restrict__ discount,
+                                                           const float *__restrict__ rer, const int32_t *__restrict__ rel,
+                                                           const int32_t *__restrict__ ts,
+                                                           const uint8_t *__restrict__ done, double *__restrict__ metrics,
+                                                           int capacity) {
+  __shared__ double s_part[4];
+  const int which = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) {
+    float v;
+    switch (which) {
+      case 0: v = discount[i]; break;
+      case 1: v = rer[i]; break;
+      case 2: v = (float)rel[i]; break;
+      case 3: v = (float)ts[i]; break;
+      default: v = (float)done[i]; break;
+    }
+    acc += (double)v;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int u = clock[0];
+    if (u < capacity)
+      metrics[(size_t)u * M_COUNT + M_DISCOUNT + which] = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) / (double)count;
+  }
+}
+
+__global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n, int channels, int n_mb_total,
+                                   const float *__restrict__ loss_buf, const float *__restrict__ qv_buf,
+                                   double *__restrict__ metrics, int capacity) {
+  if (threadIdx.x != 0) return;
+  const int u = clock[0];
+  if (u < capacity) {
+    double *row = metrics + (size_t)u * M_COUNT;
+    double l = 0.0, qv = 0.0;
+    for (int i = 0; i < n_mb_total; ++i) { l += (double)loss_buf[i]; qv += (double)qv_buf[i]; }
+    const double steps = (double)(u + 1) * (double)t_len * (double)n;
+    row[M_ENV_STEP] = steps;
+    row[M_UPDATE_STEPS] = (double)(u + 1);
+    row[M_ENV_FRAME] = steps * (double)channels;
+    row[M_GRAD_STEPS] = (double)(u + 1) * (double)n_mb_total;
+    row[M_TD_LOSS] = l / (double)n_mb_total;
+    row[M_QVALS] = qv / (double)n_mb_total;
+  }
+  clock[0] = u + 1;
+}
+
+extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
+  size_t bytes = 0;
+  if (n <= 0) return -1;
+  if (hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long *)nullptr,
+                                        (unsigned long long *)nullptr, n, 0, 63, nullptr) != hipSuccess)
+    return -1;
+  return (int64_t)bytes;
+}
+
+#define UPD_CHECK(call)          \
+  do {                           \
+    const int rc_ = (call);      \
+    if (rc_ != PQN_OK) return rc_; \
+  } while (0)
+
+extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
+  PQN_REQUIRE(a, "pqn_cnn_update: args is NULL");
+  PQN_REQUIRE(a->clock && a->sched_keys && a->sched_eps && a->state && a->bits && a->action && a->reward && a->done &&
+                  a->qmax && a->discount && a->rer && a->rel && a->ts && a->target && a->last_q && a->sort_keys_in &&
+                  a->sort_keys_out && a->sort_temp && a->theta && a->w1b && a->grad && a->m && a->v && a->count &&
+                  a->workspace && a->loss_buf && a->qv_buf && a->metrics,
+              "pqn_cnn_update: NULL buffer in args");
+  const int N = a->num_envs, T = a->num_steps, MB = a->num_minibatches, EP = a->num_epochs;
+  PQN_REQUIRE(N > 0 && T > 0 && MB > 0 && EP > 0 && T + EP <= 1024, "pqn_cnn_update: bad shape N=%d T=%d MB=%d EP=%d", N, T,
+              MB, EP);
+  PQN_REQUIRE(((int64_t)N * T) % MB == 0, "NUM_MINIBATCHES must divide NUM_STEPS*NUM_ENVS");
+  const int B = (int)(((int64_t)N * T) / MB);
+  PQN_REQUIRE(B % 16 == 0, "pqn_cnn_update: minibatch size %d must be a multiple of 16", B);
+  hipStream_t st = (hipStream_t)stream;
+  const pqn_cnn_layout_t &L = a->layout;
+  const int OW = a->obs_words;
+  const size_t bits_stride = (size_t)N * OW;
+
+  hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, T, EP, a->eps_start,
+                     a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
+  // SAMPLE PHASE (_step_env, :181-220)
+  for (int t = 0; t < T; ++t) {
+    const size_t o = (size_t)t * N;
+    UPD_CHECK(pqn_qnet_cnn_forward_dyn(L, N, a->bits + t * bits_stride, a->theta, nullptr, a->action + o, a->qmax + o, 0.0f,
+                                       0, a->sched_eps, a->sched_keys + t, st));
+    pqn_step_out_t out = {};
+    out.obs_bits = a->bits + (t + 1) * bits_stride;
+    out.reward = a->reward + o;
+    out.done = a->done + o;
+    out.discount = a->discount + o;
+    out.returned_episode_returns = a->rer + o;
+    out.returned_episode_lengths = a->rel + o;
+    out.timestep = a->ts + o;
+    UPD_CHECK(pqn_env_step_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->state, a->action + o, out, st));
+  }
+  // Q(lambda) TARGETS (:227-260)
+  UPD_CHECK(pqn_qnet_cnn_forward_dyn(L, N, a->bits + (size_t)T * bits_stride, a->theta, nullptr, nullptr, a->last_q, 0.0f, 0,
+                                     nullptr, nullptr, st));
+  UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, N, 1, a->target, st));
+  // NETWORKS UPDATE (:263-327)
+  int i_mb = 0;
+  for (int ep = 0; ep < EP; ++ep) {
+    UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, N * T, a->sort_keys_in, st));
+    size_t tb = (size_t)a->sort_temp_bytes;
+    if (hipcub::DeviceRadixSort::SortKeys(a->sort_temp, tb, (const unsigned long long *)a->sort_keys_in,
+                                          (unsigned long long *)a->sort_keys_out, N * T, 0, 63, st) != hipSuccess) {
+      pqn_set_error("pqn_cnn_update: radix sort failed (temp bytes %llu)", (unsigned long long)a->sort_temp_bytes);
+      return PQN_E_HIP;
+    }
+    for (int mb = 0; mb < MB; ++mb, ++i_mb) {
+      // low 32 bits of a sorted shuffle key = the transition index (kernels mask idx with 0xffffffff)
+      UPD_CHECK(pqn_qnet_cnn_grad(&L, B, a->sort_keys_out + (size_t)mb * B, a->bits, a->action, a->target, a->theta, a->w1b,
+                                  a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, st));
+      UPD_CHECK(pqn_qnet_cnn_apply(&L, a->theta, a->w1b, a->grad, a->m, a->v, a->count, a->lr_init, a->lr_end, a->lr_steps,
+                                   a->max_grad_norm, a->workspace, nullptr, 0, st));
+    }
+  }
+  // carry last_obs into the next update; metrics (:329-338); advance the clock
+  if (hipMemcpyAsync(a->bits, a->bits + (size_t)T * bits_stride, bits_stride * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                     st) != hipSuccess) {
+    pqn_set_error("pqn_cnn_update: hipMemcpyAsync failed");
+    return PQN_E_HIP;
+  }
+  hipLaunchKernelGGL(update_means_kernel, dim3(5), dim3(256), 0, st, a->clock, N * T, a->discount, a->rer, a->rel, a->ts,
+                     a->done, a->metrics, a->metrics_capacity);
+  hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, L.c, MB * EP, a->loss_buf, a->qv_buf,
+                     a->metrics, a->metrics_capacity);
+  return pqn_check_launch("pqn_cnn_update");
+}

@@ -280,7 +280,41 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         test_period = int(NUM_UPDATES * config["TEST_INTERVAL"]) if test_on else 0
         flat_shape = (T * N, base_env.obs_words) if packed else (T * N, *obs_shape)
 
+        # whole-update C++ enqueue (+ hipGraph replay): the MinAtar CNN path without a gradient hook
+        driver = None
+        if packed and grad_hook is None and config.get("_DRIVER", True):
+            from .qnet import UpdateDriver
+            dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
+                    "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}
+            driver = UpdateDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
+                                  policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True))
+        test_rows = torch.zeros((NUM_UPDATES, len(INFO_KEYS)), dtype=torch.float32, device=dev) if test_on else None
+
+        def driver_update(u: int):
+            if u != driver.calls:
+                raise RuntimeError(f"update({u}) out of order: the device clock is at {driver.calls}")
+            driver.update()
+            counters["timesteps"] += T * N
+            counters["n_updates"] += 1
+            counters["grad_steps"] += MB * EPOCHS
+            if test_on:
+                if test_period > 0 and counters["n_updates"] % test_period == 0:
+                    tm_box[0] = get_test_metrics()
+                test_rows[u] = torch.stack([tm_box[0][k] for k in INFO_KEYS])
+            cb = config.get("_CALLBACK")
+            if cb is not None:
+                row = driver.metrics[u].tolist()   # synchronises: logging is opt-in
+                from .qnet import METRIC_NAMES
+                m = dict(zip(METRIC_NAMES, row))
+                if kind != "cnn":
+                    m.pop("env_frame", None)
+                if test_on:
+                    m.update({f"test/{k}": float(v) for k, v in tm_box[0].items()})
+                cb(u, m)
+
         def update(u: int):
+            if driver is not None:
+                return driver_update(u)
             # SAMPLE PHASE (_step_env, pqn_minatar.py:181-220)
             eps = eps_scheduler(counters["n_updates"])
             for t in range(T):
@@ -334,12 +368,23 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 cb(u, m)
 
         def finish():
+            if driver is not None:
+                from .qnet import METRIC_NAMES
+                for j, name in enumerate(METRIC_NAMES):
+                    if name in metrics:
+                        metrics[name] = driver.metrics[:NUM_UPDATES, j].to(torch.float32)
+                if test_on:
+                    for j, k in enumerate(INFO_KEYS):
+                        metrics[f"test/{k}"] = test_rows[:, j]
             theta_f = policy.theta_flax()
             runner_state = {"params": network.views(theta_f), "theta": theta_f, "env_state": words,
                             "last_obs": obuf[0], "test_metrics": tm_box[0], "network": network, "backend": backend,
+                            "driver": None if driver is None else ("graph" if driver.graph is not None else "eager"),
+                            "driver_graph_error": None if driver is None else driver.graph_error,
                             **policy.opt_state(), **counters}
             return {"runner_state": runner_state, "metrics": metrics}
 
+        update.driver = driver   # bench.py switches graph replay off for its HIP-event timing pass
         return update, finish
 
     def train(rng: int) -> Dict[str, Any]:

@@ -119,3 +119,92 @@ class CnnTrainer:
 
     def theta_flax(self) -> torch.Tensor:
         return self.layout.to_flax(self.theta)
+
+
+class UpdateArgs(C.Structure):
+    """pqn_update_args_t (include/pqn_hotpath.h)"""
+    _fields_ = ([(n, C.c_int32) for n in ("env_id", "num_envs", "num_steps", "num_minibatches", "num_epochs",
+                                           "obs_words", "metrics_capacity", "reserved")] +
+                [(n, C.c_float) for n in ("gamma", "lam", "rew_scale", "eps_start", "eps_finish", "eps_decay_steps",
+                                          "lr_init", "lr_end", "lr_steps", "max_grad_norm")] +
+                [(n, C.c_uint64) for n in ("key_roll", "key_shuf", "sort_temp_bytes")] +
+                [("layout", CnnLayoutStruct)] +
+                [(n, C.c_void_p) for n in ("clock", "sched_keys", "sched_eps", "state", "bits", "action", "reward",
+                                           "done", "qmax", "discount", "rer", "rel", "ts", "target", "last_q",
+                                           "sort_keys_in", "sort_keys_out", "sort_temp", "theta", "w1b", "grad", "m",
+                                           "v", "count", "workspace", "loss_buf", "qv_buf", "metrics")])
+
+
+METRIC_NAMES = ("env_step", "update_steps", "env_frame", "grad_steps", "td_loss", "qvals", "discount",
+                "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode")
+
+
+class UpdateDriver:
+    """Whole-update enqueue (pqn_cnn_update) with optional hipGraph replay.  Holds the scratch buffers the
+    C side needs; all training buffers are the caller's (rollout record, CnnTrainer)."""
+
+    def __init__(self, env_id, n, t, mb, epochs, obs_words, cfg, keys, trainer: CnnTrainer, ro, words, num_updates,
+                 use_graph: bool = True):
+        lib = _lib.load()
+        dev = trainer.theta.device
+        self.dev = dev
+        tn = n * t
+        self.clock = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.sched_keys = torch.zeros(t + epochs, dtype=torch.int64, device=dev)
+        self.sched_eps = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sk_in = torch.empty(tn, dtype=torch.int64, device=dev)
+        self.sk_out = torch.empty(tn, dtype=torch.int64, device=dev)
+        tb = int(lib.pqn_update_sort_temp_bytes(tn))
+        if tb < 0:
+            raise RuntimeError("pqn_update_sort_temp_bytes failed")
+        self.sort_temp = torch.empty(max(tb, 16), dtype=torch.uint8, device=dev)
+        self.loss_buf = torch.zeros(mb * epochs, dtype=torch.float32, device=dev)
+        self.qv_buf = torch.zeros(mb * epochs, dtype=torch.float32, device=dev)
+        self.metrics = torch.zeros((max(num_updates, 1), len(METRIC_NAMES)), dtype=torch.float64, device=dev)
+        trainer._ensure_ws(tn // mb)
+        a = UpdateArgs()
+        a.env_id, a.num_envs, a.num_steps, a.num_minibatches, a.num_epochs = env_id, n, t, mb, epochs
+        a.obs_words, a.metrics_capacity = obs_words, self.metrics.shape[0]
+        a.gamma, a.lam, a.rew_scale = cfg["gamma"], cfg["lam"], cfg["rew_scale"]
+        a.eps_start, a.eps_finish, a.eps_decay_steps = cfg["eps_start"], cfg["eps_finish"], cfg["eps_decay_steps"]
+        a.lr_init, a.lr_end, a.lr_steps, a.max_grad_norm = trainer.lr, trainer.lr_end, trainer.lr_steps, trainer.max_norm
+        a.key_roll, a.key_shuf = keys
+        a.sort_temp_bytes = tb
+        a.layout = trainer.layout.struct
+        p = _lib.ptr
+        a.clock, a.sched_keys, a.sched_eps = p(self.clock), p(self.sched_keys), p(self.sched_eps)
+        a.state, a.bits = p(words), p(ro.bits)
+        a.action, a.reward, a.done, a.qmax = p(ro.action), p(ro.reward), p(ro.done), p(ro.qmax)
+        a.discount, a.rer, a.rel, a.ts = p(ro.discount), p(ro.rer), p(ro.rel), p(ro.ts)
+        a.target, a.last_q = p(ro.target), p(ro.last_q)
+        a.sort_keys_in, a.sort_keys_out, a.sort_temp = p(self.sk_in), p(self.sk_out), p(self.sort_temp)
+        a.theta, a.w1b, a.grad, a.m, a.v = p(trainer.theta), p(trainer.w1b), p(trainer.grad), p(trainer.m), p(trainer.v)
+        a.count, a.workspace = p(trainer.count), p(trainer.ws)
+        a.loss_buf, a.qv_buf, a.metrics = p(self.loss_buf), p(self.qv_buf), p(self.metrics)
+        self.args = a
+        self._keep = (trainer, ro, words)
+        self.use_graph = use_graph
+        self.graph = None
+        self.graph_error = None
+        self.calls = 0
+
+    def _enqueue(self):
+        _lib.check(_lib.load().pqn_cnn_update(C.byref(self.args), _lib.stream_ptr()), "pqn_cnn_update")
+
+    def update(self):
+        """Enqueue (or replay) one update; the update index lives on the device (self.clock[0])."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+            if self.use_graph and self.calls == 0 and self.graph_error is None:
+                # first update ran eagerly (kernel attributes set, caches warm); capture the next one
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._enqueue()
+                    self.graph = g
+                except Exception as exc:  # stay on the eager C++ enqueue (still the HIP path)
+                    self.graph_error = repr(exc)
+                    torch.cuda.synchronize()
+        self.calls += 1

@@ -235,6 +235,10 @@ def test_product_network_vs_oracle_network(gpu, oracle):
                                          "_BACKEND": "fused"}),
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
                                          "_BACKEND": "torch"}),
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
+                                         "_BACKEND": "fused", "_DRIVER": False}),   # per-kernel Python loop (grad_hook path)
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
+                                         "_BACKEND": "fused", "_GRAPH": False}),    # C++ enqueue without hipGraph
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 1024, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
     ("pqn_cartpole", "CartPole-v1", {"NUM_ENVS": 4, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
 ])
@@ -269,6 +273,9 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     train = make_train(cfg, device="cuda:0")
     assert train.backend == extra.get("_BACKEND", "fused" if kind == "cnn" else "torch")
     out = train(key)
+    if train.backend == "fused" and extra.get("_DRIVER", True):
+        want = "eager" if extra.get("_GRAPH", True) is False else "graph"
+        assert out["runner_state"]["driver"] == want, out["runner_state"]["driver_graph_error"]
     oout = otrain(key, _np(theta0))
     assert cfg["NUM_UPDATES"] == n_upd
     for u in range(n_upd):

@@ -10,3 +10,8 @@ echo -n "fwd ablate=$a: "; python $R/tools/rocprof_summary.py /tmp/pf/x_results.
 done
 rocprofv3 --kernel-trace -d /tmp/pt -o x -- python $R/tools/ablate_train.py >/dev/null 2>&1
 python $R/tools/rocprof_summary.py /tmp/pt/x_results.db 8 | grep -E "qnet|radam"
+for a in ${TRAIN_ABLATES:-}; do
+rm -rf /tmp/pt
+PQN_ABLATE_TRAIN=$a rocprofv3 --kernel-trace -d /tmp/pt -o x -- python $R/tools/ablate_train.py >/dev/null 2>&1
+echo -n "train ablate=$a: "; python $R/tools/rocprof_summary.py /tmp/pt/x_results.db 8 | grep -E "qnet_cnn_train" | cut -c1-60
+done
