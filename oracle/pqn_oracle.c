@@ -229,6 +229,237 @@ static void cartpole_step_one(int32_t *si, float *sf, int32_t action, int32_t ma
   *done = cartpole_terminal(si, sf, max_steps);
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* Asterix-MinAtar (rules: MinAtar asterix.py, Young & Tian 2019; gymnax 0.0.6 mirrors them with
+ * selects).  Canonical int state, 43 words: [0] player_x [1] player_y [2] shot_timer [3] spawn_speed
+ * [4] spawn_timer [5] move_speed [6] move_timer [7] ramp_timer [8] ramp_index [9] time [10] terminal
+ * [11+4i..] entity i (row i+1): x, present, moves_right, is_gold.  parity unpinned (third-party). */
+/* ------------------------------------------------------------------------ */
+#define AX_SI 43
+static void asterix_reset_one(int32_t *s) {
+  memset(s, 0, sizeof(int32_t) * AX_SI);
+  s[0] = 5; s[1] = 5; s[3] = 10; s[4] = 10; s[5] = 5; s[6] = 5; s[7] = 100;
+}
+static void asterix_obs_one(const int32_t *s, float *obs) {
+  memset(obs, 0, sizeof(float) * 400);
+  obs[(s[1] * 10 + s[0]) * 4 + 0] = 1.0f;
+  for (int i = 0; i < 8; ++i) {
+    const int32_t *en = s + 11 + 4 * i;
+    if (!en[1]) continue;
+    obs[((i + 1) * 10 + en[0]) * 4 + (en[3] ? 3 : 1)] = 1.0f;
+    int back = en[2] ? en[0] - 1 : en[0] + 1;
+    if (back >= 0 && back <= 9) obs[((i + 1) * 10 + back) * 4 + 2] = 1.0f;
+  }
+}
+static void asterix_step_one(int32_t *s, int32_t action, uint64_t key, uint32_t e, int32_t max_steps, float *reward, int *done) {
+  float r = 0.0f;
+  int terminal = 0;
+  if (s[4] == 0) { /* _spawn_entity */
+    uint32_t o[2], p[2];
+    pqn_oracle_env_bits(key, e, 3u, o);
+    pqn_oracle_env_bits(key, e, 4u, p);
+    int lr = (int)(o[0] & 1u);
+    int gold = pqn_oracle_bits_to_uniform(o[1]) < (1.0f / 3.0f);
+    int nfree = 0;
+    for (int i = 0; i < 8; ++i) nfree += !s[11 + 4 * i + 1];
+    if (nfree > 0) {
+      int k = (int)(((uint64_t)p[0] * (uint64_t)nfree) >> 32);
+      for (int i = 0; i < 8; ++i) {
+        if (s[11 + 4 * i + 1]) continue;
+        if (k-- == 0) { s[11 + 4 * i] = lr ? 0 : 9; s[11 + 4 * i + 1] = 1; s[11 + 4 * i + 2] = lr; s[11 + 4 * i + 3] = gold; break; }
+      }
+    }
+    s[4] = s[3];
+  }
+  if (action == 1) s[0] = s[0] - 1 < 0 ? 0 : s[0] - 1;
+  else if (action == 3) s[0] = s[0] + 1 > 9 ? 9 : s[0] + 1;
+  else if (action == 2) s[1] = s[1] - 1 < 1 ? 1 : s[1] - 1;
+  else if (action == 4) s[1] = s[1] + 1 > 8 ? 8 : s[1] + 1;
+  for (int i = 0; i < 8; ++i) {
+    int32_t *en = s + 11 + 4 * i;
+    if (en[1] && en[0] == s[0] && i + 1 == s[1]) {
+      if (en[3]) { en[1] = 0; r += 1.0f; } else terminal = 1;
+    }
+  }
+  if (s[6] == 0) {
+    s[6] = s[5];
+    for (int i = 0; i < 8; ++i) {
+      int32_t *en = s + 11 + 4 * i;
+      if (!en[1]) continue;
+      en[0] += en[2] ? 1 : -1;
+      if (en[0] < 0 || en[0] > 9) { en[1] = 0; continue; }
+      if (en[0] == s[0] && i + 1 == s[1]) {
+        if (en[3]) { en[1] = 0; r += 1.0f; } else terminal = 1;
+      }
+    }
+  }
+  s[4] -= 1;
+  s[6] -= 1;
+  if (s[3] > 1 || s[5] > 1) { /* ramping */
+    if (s[7] >= 0) s[7] -= 1;
+    else {
+      if (s[5] > 1 && (s[8] % 2)) s[5] -= 1;
+      if (s[3] > 1) s[3] -= 1;
+      s[8] += 1;
+      s[7] = 100;
+    }
+  }
+  for (int i = 0; i < 8; ++i)
+    if (!s[11 + 4 * i + 1]) { s[11 + 4 * i] = 0; s[11 + 4 * i + 2] = 0; s[11 + 4 * i + 3] = 0; } /* canonical empty slot */
+  s[9] += 1;
+  int d = terminal || (s[9] >= max_steps);
+  s[10] = d;
+  *reward = r;
+  *done = d;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Freeway-MinAtar (MinAtar freeway.py).  Canonical, 29 words: [0] pos [1] move_timer
+ * [2] terminate_timer [3] time [4] terminal [5+3i..] car i (row i+1): x, timer, signed speed. */
+/* ------------------------------------------------------------------------ */
+#define FW_SI 29
+static void freeway_randomize(int32_t *s, uint64_t key, uint32_t e, uint32_t stream0, int initialize) {
+  for (int i = 0; i < 8; ++i) {
+    uint32_t o[2];
+    pqn_oracle_env_bits(key, e, stream0 + (uint32_t)i, o);
+    int speed = 1 + (int)(((uint64_t)o[0] * 5u) >> 32);
+    int dir = (o[1] & 1u) ? 1 : -1;
+    if (initialize) s[5 + 3 * i] = 0;
+    s[5 + 3 * i + 1] = speed;
+    s[5 + 3 * i + 2] = speed * dir;
+  }
+}
+static void freeway_reset_one(int32_t *s, uint64_t key, uint32_t e) {
+  memset(s, 0, sizeof(int32_t) * FW_SI);
+  freeway_randomize(s, key, e, 16u, 1);
+  s[0] = 9; s[1] = 3; s[2] = 2500;
+}
+static void freeway_obs_one(const int32_t *s, float *obs) {
+  memset(obs, 0, sizeof(float) * 700);
+  obs[(s[0] * 10 + 4) * 7 + 0] = 1.0f;
+  for (int i = 0; i < 8; ++i) {
+    const int32_t *car = s + 5 + 3 * i;
+    obs[((i + 1) * 10 + car[0]) * 7 + 1] = 1.0f;
+    int back = car[2] > 0 ? car[0] - 1 : car[0] + 1;
+    if (back < 0) back = 9; else if (back > 9) back = 0;
+    int sp = car[2] < 0 ? -car[2] : car[2];
+    obs[((i + 1) * 10 + back) * 7 + 1 + sp] = 1.0f;
+  }
+}
+static void freeway_step_one(int32_t *s, int32_t action, uint64_t key, uint32_t e, int32_t max_steps, float *reward, int *done) {
+  float r = 0.0f;
+  if (action == 1 && s[1] == 0) { s[1] = 3; s[0] = s[0] - 1 < 0 ? 0 : s[0] - 1; }
+  else if (action == 2 && s[1] == 0) { s[1] = 3; s[0] = s[0] + 1 > 9 ? 9 : s[0] + 1; }
+  if (s[0] == 0) { r += 1.0f; freeway_randomize(s, key, e, 32u, 0); s[0] = 9; }
+  for (int i = 0; i < 8; ++i) {
+    int32_t *car = s + 5 + 3 * i;
+    if (car[0] == 4 && i + 1 == s[0]) s[0] = 9;
+    if (car[1] == 0) {
+      car[1] = car[2] < 0 ? -car[2] : car[2];
+      car[0] += car[2] > 0 ? 1 : -1;
+      if (car[0] < 0) car[0] = 9; else if (car[0] > 9) car[0] = 0;
+      if (car[0] == 4 && i + 1 == s[0]) s[0] = 9;
+    } else car[1] -= 1;
+  }
+  s[1] -= s[1] > 0;
+  s[2] -= 1;
+  int terminal = s[2] < 0;
+  s[3] += 1;
+  int d = terminal || (s[3] >= max_steps);
+  s[4] = d;
+  *reward = r;
+  *done = d;
+}
+
+/* ------------------------------------------------------------------------ */
+/* SpaceInvaders-MinAtar (MinAtar space_invaders.py).  Canonical, 309 words: [0] pos [1] alien_dir
+ * [2] enemy_move_interval [3] alien_move_timer [4] alien_shot_timer [5] shot_timer [6] ramp_index
+ * [7] time [8] terminal [9..] alien_map[100] [109..] f_bullet_map[100] [209..] e_bullet_map[100]. */
+/* ------------------------------------------------------------------------ */
+#define SI_SI 309
+static void si_reset_one(int32_t *s) {
+  memset(s, 0, sizeof(int32_t) * SI_SI);
+  s[0] = 5; s[1] = -1; s[2] = 12; s[3] = 12; s[4] = 10;
+  for (int y = 0; y < 4; ++y)
+    for (int x = 2; x < 8; ++x) s[9 + y * 10 + x] = 1;
+}
+static void si_obs_one(const int32_t *s, float *obs) {
+  memset(obs, 0, sizeof(float) * 600);
+  obs[(9 * 10 + s[0]) * 6 + 0] = 1.0f;
+  for (int c = 0; c < 100; ++c) {
+    if (s[9 + c]) { obs[c * 6 + 1] = 1.0f; obs[c * 6 + (s[1] < 0 ? 2 : 3)] = 1.0f; }
+    if (s[109 + c]) obs[c * 6 + 4] = 1.0f;
+    if (s[209 + c]) obs[c * 6 + 5] = 1.0f;
+  }
+}
+static int si_count(const int32_t *m) { int n = 0; for (int c = 0; c < 100; ++c) n += m[c] != 0; return n; }
+static void si_step_one(int32_t *s, int32_t action, int32_t max_steps, float *reward, int *done) {
+  int32_t *al = s + 9, *fb = s + 109, *eb = s + 209;
+  float r = 0.0f;
+  int terminal = 0;
+  if (action == 3 && s[5] == 0) { fb[90 + s[0]] = 1; s[5] = 5; }
+  else if (action == 1) s[0] = s[0] - 1 < 0 ? 0 : s[0] - 1;
+  else if (action == 2) s[0] = s[0] + 1 > 9 ? 9 : s[0] + 1;
+  for (int y = 0; y < 9; ++y) for (int x = 0; x < 10; ++x) fb[y * 10 + x] = fb[(y + 1) * 10 + x]; /* roll up */
+  for (int x = 0; x < 10; ++x) fb[90 + x] = 0;
+  for (int y = 9; y > 0; --y) for (int x = 0; x < 10; ++x) eb[y * 10 + x] = eb[(y - 1) * 10 + x]; /* roll down */
+  for (int x = 0; x < 10; ++x) eb[x] = 0;
+  if (eb[90 + s[0]]) terminal = 1;
+  if (al[90 + s[0]]) terminal = 1;
+  if (s[3] == 0) {
+    int cnt = si_count(al);
+    s[3] = cnt < s[2] ? cnt : s[2];
+    int left = 0, right = 0, bottom = 0;
+    for (int y = 0; y < 10; ++y) { left += al[y * 10]; right += al[y * 10 + 9]; }
+    for (int x = 0; x < 10; ++x) bottom += al[90 + x];
+    if ((left > 0 && s[1] < 0) || (right > 0 && s[1] > 0)) {
+      s[1] = -s[1];
+      if (bottom > 0) terminal = 1;
+      int32_t last[10];
+      for (int x = 0; x < 10; ++x) last[x] = al[90 + x];
+      for (int y = 9; y > 0; --y) for (int x = 0; x < 10; ++x) al[y * 10 + x] = al[(y - 1) * 10 + x];
+      for (int x = 0; x < 10; ++x) al[x] = last[x]; /* np.roll wraps */
+    } else {
+      for (int y = 0; y < 10; ++y) {
+        int32_t row[10];
+        for (int x = 0; x < 10; ++x) row[x] = al[y * 10 + x];
+        for (int x = 0; x < 10; ++x) al[y * 10 + ((x + s[1] + 10) % 10)] = row[x];
+      }
+    }
+    if (al[90 + s[0]]) terminal = 1;
+  }
+  if (s[4] == 0) {
+    s[4] = 10;
+    /* _nearest_alien: columns by |x - pos| (ties: smaller x first), lowest alien in that column */
+    int found = 0;
+    for (int d = 0; d < 10 && !found; ++d) {
+      for (int sgn = -1; sgn <= 1 && !found; sgn += 2) {
+        int x = s[0] + sgn * d;
+        if (d == 0 && sgn == 1) continue;
+        if (x < 0 || x > 9) continue;
+        int ymax = -1;
+        for (int y = 0; y < 10; ++y) if (al[y * 10 + x]) ymax = y;
+        if (ymax >= 0) { eb[ymax * 10 + x] = 1; found = 1; }
+      }
+    }
+  }
+  for (int c = 0; c < 100; ++c)
+    if (al[c] && fb[c]) { r += 1.0f; al[c] = 0; fb[c] = 0; }
+  s[5] -= s[5] > 0;
+  s[3] -= 1;
+  s[4] -= 1;
+  int cnt = si_count(al);
+  if (s[2] > 6 && cnt == 0) { s[2] -= 1; s[6] += 1; }
+  if (cnt == 0)
+    for (int y = 0; y < 4; ++y) for (int x = 2; x < 8; ++x) al[y * 10 + x] = 1;
+  s[7] += 1;
+  int dn = terminal || (s[7] >= max_steps);
+  s[8] = dn;
+  *reward = r;
+  *done = dn;
+}
+
 /* ------------------------------------------------------------------------ */
 int pqn_oracle_env_spec(int env_id, pqn_oracle_spec_t *spec) {
   memset(spec, 0, sizeof(*spec));
@@ -243,6 +474,18 @@ int pqn_oracle_env_spec(int env_id, pqn_oracle_spec_t *spec) {
       spec->obs_size = 4; spec->num_actions = 2; spec->max_steps = 500;
       spec->si = 1; spec->sf = 4;
       return 0;
+    case PQN_ORACLE_ENV_ASTERIX:
+      spec->obs_dim[0] = 10; spec->obs_dim[1] = 10; spec->obs_dim[2] = 4;
+      spec->obs_size = 400; spec->num_actions = 5; spec->max_steps = 1000; spec->si = AX_SI; spec->sf = 0;
+      return 0;
+    case PQN_ORACLE_ENV_FREEWAY:
+      spec->obs_dim[0] = 10; spec->obs_dim[1] = 10; spec->obs_dim[2] = 7;
+      spec->obs_size = 700; spec->num_actions = 3; spec->max_steps = 2500; spec->si = FW_SI; spec->sf = 0;
+      return 0;
+    case PQN_ORACLE_ENV_SPACEINVADERS:
+      spec->obs_dim[0] = 10; spec->obs_dim[1] = 10; spec->obs_dim[2] = 6;
+      spec->obs_size = 600; spec->num_actions = 4; spec->max_steps = 1000; spec->si = SI_SI; spec->sf = 0;
+      return 0;
     default:
       return -1;
   }
@@ -251,6 +494,9 @@ int pqn_oracle_env_spec(int env_id, pqn_oracle_spec_t *spec) {
 static void obs_one(int env_id, const int32_t *si, const float *sf, float *obs) {
   if (env_id == PQN_ORACLE_ENV_BREAKOUT) breakout_obs_one(si, obs);
   else if (env_id == PQN_ORACLE_ENV_CARTPOLE) memcpy(obs, sf, 4 * sizeof(float));
+  else if (env_id == PQN_ORACLE_ENV_ASTERIX) asterix_obs_one(si, obs);
+  else if (env_id == PQN_ORACLE_ENV_FREEWAY) freeway_obs_one(si, obs);
+  else if (env_id == PQN_ORACLE_ENV_SPACEINVADERS) si_obs_one(si, obs);
 }
 
 static void reset_one(int env_id, uint64_t key, uint32_t e, int32_t *si, float *sf) {
@@ -260,6 +506,12 @@ static void reset_one(int env_id, uint64_t key, uint32_t e, int32_t *si, float *
     breakout_reset_one(o[0], si);
   } else if (env_id == PQN_ORACLE_ENV_CARTPOLE) {
     cartpole_reset_one(key, e, si, sf);
+  } else if (env_id == PQN_ORACLE_ENV_ASTERIX) {
+    asterix_reset_one(si);
+  } else if (env_id == PQN_ORACLE_ENV_FREEWAY) {
+    freeway_reset_one(si, key, e);
+  } else if (env_id == PQN_ORACLE_ENV_SPACEINVADERS) {
+    si_reset_one(si);
   }
 }
 
@@ -300,7 +552,10 @@ int pqn_oracle_env_step(int env_id, int32_t n, uint64_t key, int32_t *si, float 
     float r = 0.0f;
     int d = 0;
     if (env_id == PQN_ORACLE_ENV_BREAKOUT) breakout_step_one(s, action[e], sp.max_steps, &r, &d);
-    else cartpole_step_one(s, f, action[e], sp.max_steps, &r, &d);
+    else if (env_id == PQN_ORACLE_ENV_CARTPOLE) cartpole_step_one(s, f, action[e], sp.max_steps, &r, &d);
+    else if (env_id == PQN_ORACLE_ENV_ASTERIX) asterix_step_one(s, action[e], key, (uint32_t)e, sp.max_steps, &r, &d);
+    else if (env_id == PQN_ORACLE_ENV_FREEWAY) freeway_step_one(s, action[e], key, (uint32_t)e, sp.max_steps, &r, &d);
+    else si_step_one(s, action[e], sp.max_steps, &r, &d);
     if (d && autoreset) reset_one(env_id, key, (uint32_t)e, s, f);
     if (obs) obs_one(env_id, s, f, obs + (size_t)e * sp.obs_size);
     reward[e] = r;

@@ -35,17 +35,20 @@ __global__ void update_sched_kernel(const int32_t *__restrict__ clock, uint64_t 
   }
 }
 
-// block b reduces one [T*N] info array to its mean (fixed order: per-thread strided sum, wave tree, 4 waves)
-__global__ __launch_bounds__(256) void update_means_kernel(const int32_t *__restrict__ clock, int count,
-                                                           const float *__restrict__ discount,
+// grid (5 arrays, MEANS_CHUNKS chunks): fixed-order partial sums of the [T*N] info arrays; the tick
+// kernel folds the chunk partials.  (info means of pqn_minatar.py:338)
+#define MEANS_CHUNKS 64
+
+__global__ __launch_bounds__(256) void update_means_kernel(int count, const float *__restrict__ discount,
                                                            const float *__restrict__ rer, const int32_t *__restrict__ rel,
                                                            const int32_t *__restrict__ ts,
-                                                           const uint8_t *__restrict__ done, double *__restrict__ metrics,
-                                                           int capacity) {
+                                                           const uint8_t *__restrict__ done, double *__restrict__ partial) {
   __shared__ double s_part[4];
-  const int which = blockIdx.x;
+  const int which = blockIdx.x, chunk = blockIdx.y;
+  const int per = (count + MEANS_CHUNKS - 1) / MEANS_CHUNKS;
+  const int lo = chunk * per, hi = min(count, lo + per);
   double acc = 0.0;
-  for (int i = threadIdx.x; i < count; i += 256) {
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
     float v;
     switch (which) {
       case 0: v = discount[i]; break;
@@ -59,31 +62,34 @@ __global__ __launch_bounds__(256) void update_means_kernel(const int32_t *__rest
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int u = clock[0];
-    if (u < capacity)
-      metrics[(size_t)u * M_COUNT + M_DISCOUNT + which] = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) / (double)count;
-  }
+  if (threadIdx.x == 0) partial[which * MEANS_CHUNKS + chunk] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
 __global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n, int channels, int n_mb_total,
                                    const float *__restrict__ loss_buf, const float *__restrict__ qv_buf,
-                                   double *__restrict__ metrics, int capacity) {
-  if (threadIdx.x != 0) return;
+                                   const double *__restrict__ partial, double *__restrict__ metrics, int capacity) {
   const int u = clock[0];
   if (u < capacity) {
     double *row = metrics + (size_t)u * M_COUNT;
-    double l = 0.0, qv = 0.0;
-    for (int i = 0; i < n_mb_total; ++i) { l += (double)loss_buf[i]; qv += (double)qv_buf[i]; }
-    const double steps = (double)(u + 1) * (double)t_len * (double)n;
-    row[M_ENV_STEP] = steps;
-    row[M_UPDATE_STEPS] = (double)(u + 1);
-    row[M_ENV_FRAME] = steps * (double)channels;
-    row[M_GRAD_STEPS] = (double)(u + 1) * (double)n_mb_total;
-    row[M_TD_LOSS] = l / (double)n_mb_total;
-    row[M_QVALS] = qv / (double)n_mb_total;
+    if (threadIdx.x < 5) {
+      double s = 0.0;
+      for (int c = 0; c < MEANS_CHUNKS; ++c) s += partial[threadIdx.x * MEANS_CHUNKS + c];
+      row[M_DISCOUNT + threadIdx.x] = s / ((double)t_len * (double)n);
+    }
+    if (threadIdx.x == 5) {
+      double l = 0.0, qv = 0.0;
+      for (int i = 0; i < n_mb_total; ++i) { l += (double)loss_buf[i]; qv += (double)qv_buf[i]; }
+      const double steps = (double)(u + 1) * (double)t_len * (double)n;
+      row[M_ENV_STEP] = steps;
+      row[M_UPDATE_STEPS] = (double)(u + 1);
+      row[M_ENV_FRAME] = steps * (double)channels;
+      row[M_GRAD_STEPS] = (double)(u + 1) * (double)n_mb_total;
+      row[M_TD_LOSS] = l / (double)n_mb_total;
+      row[M_QVALS] = qv / (double)n_mb_total;
+    }
   }
-  clock[0] = u + 1;
+  __syncthreads();
+  if (threadIdx.x == 0) clock[0] = u + 1;
 }
 
 extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
@@ -164,9 +170,10 @@ extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
     pqn_set_error("pqn_cnn_update: hipMemcpyAsync failed");
     return PQN_E_HIP;
   }
-  hipLaunchKernelGGL(update_means_kernel, dim3(5), dim3(256), 0, st, a->clock, N * T, a->discount, a->rer, a->rel, a->ts,
-                     a->done, a->metrics, a->metrics_capacity);
+  double *partial = reinterpret_cast<double *>(a->workspace);  // first 1024 floats: optimizer scratch, idle here
+  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS), dim3(256), 0, st, N * T, a->discount, a->rer, a->rel,
+                     a->ts, a->done, partial);
   hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, L.c, MB * EP, a->loss_buf, a->qv_buf,
-                     a->metrics, a->metrics_capacity);
+                     partial, a->metrics, a->metrics_capacity);
   return pqn_check_launch("pqn_cnn_update");
 }

@@ -59,6 +59,45 @@ def test_breakout_step_bit_exact_vs_oracle(gpu, oracle, n):
     assert ost["ret_len"].max() > 0  # episodes actually finished
 
 
+@pytest.mark.parametrize("name,c,a,n,steps", [("Asterix-MinAtar", 4, 5, 1024, 1500), ("Freeway-MinAtar", 7, 3, 512, 2700),
+                                               ("SpaceInvaders-MinAtar", 6, 4, 1024, 1500), ("Asterix-MinAtar", 4, 5, 37, 400)])
+def test_minatar_suite_step_bit_exact_vs_oracle(gpu, oracle, name, c, a, n, steps):
+    """Asterix / Freeway / SpaceInvaders: HIP packed-state kernels vs the C oracle (MinAtar rules), bit-exact
+    on reward, done, observation (f32 and packed), full state and LogWrapper record."""
+    from purejaxql_amd.envs import LogWrapper, make
+    env, params = make(name, device=gpu)
+    env = LogWrapper(env)
+    oenv = oracle.OracleEnv(name)
+    assert env.obs_shape == (10, 10, c) and env.num_actions == a and params.max_steps_in_episode == oenv.max_steps
+    (obs, bits), state = env.reset(21, params, n, want_bits=True)
+    oobs, ost = oenv.reset(21, n)
+    np.testing.assert_array_equal(_np(obs), oobs)
+    _check_state(env, oenv, state, ost)
+    rng = np.random.default_rng(n + c)
+    ow = bits.shape[1]
+    for t in range(steps):
+        act = rng.integers(0, a, n).astype(np.int32)
+        if name.startswith("Freeway") and t % 3:      # mostly "up" so chickens cross and cars get re-randomised
+            act[: n // 2] = 1
+        if name.startswith("SpaceInvaders") and t % 2:  # fire a lot so waves get cleared (ramping)
+            act[: n // 2] = 3
+        key = 9000 + t
+        (obs, bits), state, r, d, info = env.step(key, state, torch.from_numpy(act).to(gpu), params, want_bits=True)
+        oobs, ost, orr, od, oinfo = oenv.step(key, ost, act)
+        np.testing.assert_array_equal(_np(r), orr, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(_np(d), od, err_msg=f"done t={t}")
+        if t % 25 == 0 or t == steps - 1:
+            np.testing.assert_array_equal(_np(obs), oobs, err_msg=f"obs t={t}")
+            _check_state(env, oenv, state, ost)
+            for k in oinfo:
+                np.testing.assert_array_equal(_np(info[k]), oinfo[k], err_msg=k)
+            b = _np(bits).view(np.uint32)
+            unpacked = ((b[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, -1)
+            np.testing.assert_array_equal(unpacked[:, :100 * c], oobs.reshape(n, -1).astype(np.uint8))
+            assert unpacked[:, 100 * c:].sum() == 0
+    assert ost["ret_len"].max() > 0 and ost["ret_ret"].max() > 0
+
+
 def test_breakout_hand_derived_trajectories_on_gpu(gpu, oracle):
     from purejaxql_amd.envs import make
     env, params = make("Breakout-MinAtar", device=gpu)
@@ -240,6 +279,9 @@ def test_product_network_vs_oracle_network(gpu, oracle):
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
                                          "_BACKEND": "fused", "_GRAPH": False}),    # C++ enqueue without hipGraph
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 1024, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
+    ("pqn_minatar", "Asterix-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
+    ("pqn_minatar", "Freeway-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
+    ("pqn_minatar", "SpaceInvaders-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
     ("pqn_cartpole", "CartPole-v1", {"NUM_ENVS": 4, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
 ])
 def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
@@ -264,8 +306,9 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     otrain = oracle.make_train(ocfg)
     n_params = sum(int(np.prod(s)) for s in otrain.shapes.values())
     kind = otrain.kind
-    env_obs = (10, 10, 4) if kind == "cnn" else (4,)
-    net = QNetwork(kind, env_obs, 3 if kind == "cnn" else 2, hidden_size=cfg.get("HIDDEN_SIZE", 128),
+    oe = oracle.OracleEnv(env_name)
+    env_obs = oe.obs_shape
+    net = QNetwork(kind, env_obs, oe.num_actions, hidden_size=cfg.get("HIDDEN_SIZE", 128),
                    num_layers=cfg.get("NUM_LAYERS", 2), device=gpu)
     assert net.num_params == n_params
     theta0 = net.init(123)
