@@ -227,6 +227,10 @@ typedef struct {
 int64_t pqn_update_sort_temp_bytes(int32_t n);
 int pqn_cnn_update(const pqn_update_args_t *args /* host */, void *stream);
 
+/* Profiling aid (PQN_T1_STAMPS=1): s_memtime stamps at the phase boundaries of qnet_cnn_train_kernel for
+ * workgroups 0..3; 16 slots per workgroup.  Not part of the hot path. */
+int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries */);
+
 #ifdef __cplusplus
 }
 #endif

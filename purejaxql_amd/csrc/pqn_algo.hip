@@ -160,6 +160,17 @@ __global__ __launch_bounds__(256) void radam_norm_kernel(const float *__restrict
   }
 }
 
+// b^t for integer t >= 1 in f64 (<= 2 ulp from pow(); only its f32 cast is used)
+PQN_HD double pqn_powi(double b, int t) {
+  double r = 1.0;
+  while (t > 0) {
+    if (t & 1) r *= b;
+    b *= b;
+    t >>= 1;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                           float *__restrict__ m, float *__restrict__ v, int64_t n,
                                                           int32_t *__restrict__ count, float lr_init, float lr_end,
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
     const int32_t c = reinterpret_cast<const int32_t *>(scratch)[1023];
     const double b1 = 0.9, b2 = 0.999, thr = 5.0;
     const double t = (double)c + 1.0;
-    const double b1t = pow(b1, t), b2t = pow(b2, t);
+    const double b1t = pqn_powi(b1, c + 1), b2t = pqn_powi(b2, c + 1);   // square-and-multiply: ~40 f64 mults, no libm pow
     const double ro_inf = 2.0 / (1.0 - b2) - 1.0;
     const double ro = ro_inf - 2.0 * t * b2t / (1.0 - b2t);
     const int rect = ro >= thr;

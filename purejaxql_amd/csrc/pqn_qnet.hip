@@ -86,10 +86,26 @@ PQN_D float group16_sum(float v) {
 //   D: lane (channel j = l&15) holds rows 4*(l>>4)+r, r = 0..3.
 // Bit of point (py,px), window element k=(ky,kx,c): ((py+ky)*10 + px+kx)*C + c = base(point) + off(k).
 // ---------------------------------------------------------------------------
+// Per-point window masks: for position pos=(py,px) of one sample, word ky holds the 3C bits of window
+// row ky (cells (py+ky, px..px+2), all channels) -- bit j of word ky is window element k = ky*3C + j.
+// Computed once per sample by lane = pos; the MFMA A-operand builders below only shift and test.
+template <int C>
+PQN_D void window_masks(const uint32_t *row_bits, uint32_t *wm, int pos) {
+  const int py = pos >> 3, px = pos & 7;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int sb = ((py + ky) * 10 + px) * C;
+    const int w = sb >> 5, sh = sb & 31;
+    const uint64_t v = (((uint64_t)row_bits[w + 1] << 32) | row_bits[w]) >> sh;
+    wm[pos * 3 + ky] = (uint32_t)v & ((1u << (3 * C)) - 1u);
+  }
+}
+
 template <int C>
 struct ConvMfma {
   static constexpr int NS = (9 * C + 3) / 4;
-  int offk[NS];
+  static constexpr int RB = 3 * C;   // bits per window row
+  int kyS[NS], shS[NS];              // lane constants: window row and bit of k = 4s + (lane>>4)
   float wk[NS];
   PQN_D void init(const float *wc, int lane) {
     const int kk = lane >> 4, o = lane & 15;
@@ -97,22 +113,26 @@ struct ConvMfma {
     for (int s = 0; s < NS; ++s) {
       const int k = 4 * s + kk;
       const bool ok = k < 9 * C;
-      const int ky = k / (3 * C), kx = (k / C) % 3, c = k % C;
-      offk[s] = ok ? (ky * 10 + kx) * C + c : 0;
+      kyS[s] = ok ? k / RB : 0;
+      shS[s] = ok ? k % RB : 0;
       wk[s] = ok ? wc[k * 16 + o] : 0.0f;
     }
   }
-  // two tiles at once (independent accumulators hide the 40-cycle MFMA dependency)
-  PQN_D void tile2(const uint32_t *rowA, int baseA, const uint32_t *rowB, int baseB, f32x4 &dA, f32x4 &dB) const {
-    const float inv255 = 1.0f / 255.0f;
+  PQN_D float a_of(const uint32_t (&m)[3], int s) const {
+    // for C = 4 (RB = 12) the row index is the same for all four kk of a step: compile-time select
+    const uint32_t w = (RB % 4 == 0) ? m[(4 * s) / RB] : (kyS[s] == 0 ? m[0] : (kyS[s] == 1 ? m[1] : m[2]));
+    return ((w >> shS[s]) & 1u) ? (1.0f / 255.0f) : 0.0f;
+  }
+  // two tiles at once (independent accumulators hide the 40-cycle MFMA dependency); pA / pB = the
+  // point (row of the window-mask table) this lane's A row stands for in each tile
+  PQN_D void tile2(const uint32_t *wm, int pA, int pB, f32x4 &dA, f32x4 &dB) const {
+    const uint32_t mA[3] = {wm[pA * 3], wm[pA * 3 + 1], wm[pA * 3 + 2]};
+    const uint32_t mB[3] = {wm[pB * 3], wm[pB * 3 + 1], wm[pB * 3 + 2]};
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const int bA = baseA + offk[s], bB = baseB + offk[s];
-      const float xA = ((rowA[bA >> 5] >> (bA & 31)) & 1u) ? inv255 : 0.0f;
-      const float xB = ((rowB[bB >> 5] >> (bB & 31)) & 1u) ? inv255 : 0.0f;
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xA, wk[s], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xB, wk[s], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_of(mA, s), wk[s], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_of(mB, s), wk[s], a1, 0, 0, 0);
     }
     dA = a0;
     dB = a1;
@@ -148,15 +168,17 @@ PQN_D void ln16_point(const float *stg, int p, float (&xhat)[16], float &rstd) {
   for (int o = 0; o < 16; ++o) xhat[o] = (v[o] - mean) * rstd;
 }
 
-// conv output (+bias) of all 64 positions of one sample -> this wave's staging buffer
+// conv output (+bias) of all 64 positions of one sample -> this wave's staging buffer.
+// wm: this wave's [64][3] window-mask table (filled here, lane = position).
 template <int C>
-PQN_D void conv_sample_to_stage(const ConvMfma<C> &cv, const uint32_t *row, float *stg, float bias, int lane) {
+PQN_D void conv_sample_to_stage(const ConvMfma<C> &cv, const uint32_t *row, uint32_t *wm, float *stg, float bias,
+                                int lane) {
+  window_masks<C>(row, wm, lane);
   const int i = lane & 15;
 #pragma unroll
   for (int pb = 0; pb < 4; pb += 2) {
-    const int posA = 16 * pb + i, posB = posA + 16;
     f32x4 dA, dB;
-    cv.tile2(row, ((posA >> 3) * 10 + (posA & 7)) * C, row, ((posB >> 3) * 10 + (posB & 7)) * C, dA, dB);
+    cv.tile2(wm, 16 * pb + i, 16 * pb + 16 + i, dA, dB);
     stage_tile(stg, 16 * pb, dA, bias, lane);
     stage_tile(stg, 16 * pb + 16, dB, bias, lane);
   }
@@ -172,10 +194,11 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid) {
   const float *bc = s.wc + Cfg::KW * 16;
   const float bias = bc[lane & 15];
   float *stg = s.stg + wave * 64 * QN_STG;
+  uint32_t *wm = reinterpret_cast<uint32_t *>(s.z) + wave * 192;   // z tile is not live yet
 #pragma unroll 1
   for (int mm = 0; mm < QN_SPW; ++mm) {
     const int m = QN_SPW * wave + mm;
-    conv_sample_to_stage<C>(cv, s.bits + m * Cfg::OW, stg, bias, lane);
+    conv_sample_to_stage<C>(cv, s.bits + m * Cfg::OW, wm, stg, bias, lane);
     float xhat[16], rstd;
     ln16_point(stg, lane, xhat, rstd);   // lane = position
     f32x4 *dst = reinterpret_cast<f32x4 *>(s.h1 + m * QN_H1S + lane * 16);
@@ -203,28 +226,34 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) 
   static_assert(QN_WAVES * CBW == 8, "8 column blocks of 16 outputs");
   const int lane = tid & 63, wave = tid >> 6;
   const int cb0 = CBW * wave;
+  // every workgroup streams the same 512 KB of W1: start each one at a different K group (and wrap) so
+  // the CUs of an XCD do not sweep the same L2 channel at the same moment.  The K order only permutes
+  // the f32 summation order of the tile.
+  const int rot = (blockIdx.x * 8 + (blockIdx.x >> 3)) & 63;
   const f32x4 *wp = reinterpret_cast<const f32x4 *>(w1p);
   const float *arow = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
-  f32x4 acc[CBW];
+  // two accumulator sets (even / odd K groups): consecutive MFMAs of a wave are independent, so the
+  // 40-cycle dependent-accumulator latency never gates the 32-cycle issue rate
+  f32x4 acc[CBW], acc2[CBW];
 #pragma unroll
-  for (int c = 0; c < CBW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int PF = 8;
+  for (int c = 0; c < CBW; ++c) { acc[c] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  constexpr int PF = 16;   // K groups in flight per wave (16 KB): covers an L2-miss round trip
   f32x4 b[PF][CBW];
 #pragma unroll
   for (int i = 0; i < PF; ++i)
 #pragma unroll
-    for (int c = 0; c < CBW; ++c) b[i][c] = wp[(i * 8 + cb0 + c) * 64 + lane];
+    for (int c = 0; c < CBW; ++c) b[i][c] = wp[(((i + rot) & 63) * 8 + cb0 + c) * 64 + lane];
 #pragma unroll 1
   for (int g = 0; g < QN_H1 / 16; g += PF) {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 16 * (g + i));
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + rot) & 63));
       f32x4 x[CBW];
 #pragma unroll
       for (int c = 0; c < CBW; ++c) x[c] = b[i][c];
       if (ABL != 2 && g + i + PF < QN_H1 / 16) {
 #pragma unroll
-        for (int c = 0; c < CBW; ++c) b[i][c] = wp[((g + i + PF) * 8 + cb0 + c) * 64 + lane];
+        for (int c = 0; c < CBW; ++c) b[i][c] = wp[(((g + i + PF + rot) & 63) * 8 + cb0 + c) * 64 + lane];
       }
       if (ABL == 3) {
 #pragma unroll
@@ -232,15 +261,16 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) 
         continue;
       }
 #pragma unroll
-      for (int c = 0; c < CBW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[c].x, acc[c], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c < CBW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[c].y, acc[c], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c < CBW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[c].z, acc[c], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c < CBW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[c].w, acc[c], 0, 0, 0);
+      for (int c = 0; c < CBW; ++c) {
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[c].x, acc[c], 0, 0, 0);
+        acc2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[c].y, acc2[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[c].z, acc[c], 0, 0, 0);
+        acc2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[c].w, acc2[c], 0, 0, 0);
+      }
     }
   }
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) acc[c] += acc2[c];
   const int col = lane & 15, r0 = 4 * (lane >> 4);
 #pragma unroll
   for (int c = 0; c < CBW; ++c) {
@@ -434,12 +464,15 @@ constexpr size_t train_smem_bytes() {
   return cnn_smem_bytes<C>() + sizeof(float) * (TrainCfg<C>::SCR + 2 * QN_TILE + QN_WAVES * 48 + 4);
 }
 
+// profiling: per-phase s_memtime stamps of workgroup 0 / wave 0 (PQN_T1_STAMPS=1), read by tools/t1_stamps.py
+#define T1_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.x < 4) stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+
 template <int C>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, const float *__restrict__ w1b,
     pqn_cnn_layout_t L, float inv_b, float *__restrict__ dzT, float *__restrict__ h1T, float *__restrict__ gpart,
-    int ablate) {
+    int ablate, unsigned long long *__restrict__ stamps) {
   using Cfg = CnnCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const TrainSmem ts = carve_train_smem<C>(smem_raw);
@@ -448,6 +481,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   const int b0 = blockIdx.x * QN_TILE;
   const int rec = small_record_floats(C, L.a);
   float *gp = gpart + (size_t)blockIdx.x * rec;
+  T1_STAMP(0);
 
   // ---- P0: gather inputs -------------------------------------------------------------------
   load_tile_common<C>(s, theta, L, tid);
@@ -457,18 +491,22 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   }
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
   __syncthreads();
+  T1_STAMP(1);
   // ---- P1..P3: forward ---------------------------------------------------------------------
   phase1_conv<C>(s, tid);
   __syncthreads();
-  // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m], 16-B stores issued before the MFMA phase
+  T1_STAMP(2);
+  phase2_fc1<0>(s, theta + L.off_w1, tid);
+  // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
+  // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
   for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
     const int i = e >> 2, mq = e & 3;
     const float *src = s.h1 + (4 * mq) * QN_H1S + i;
     const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
     *reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq) = v;
   }
-  phase2_fc1<0>(s, theta + L.off_w1, tid);
   __syncthreads();
+  T1_STAMP(3);
   // the head (LN1 / fc2 / loss) needs 16 lanes per sample: waves 0..3 only
   const bool head = tid < 256;
   const int m = (tid >> 4) & 15, sub = tid & 15;
@@ -561,6 +599,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     gp[o_l] = (ts.red[0] + ts.red[48]) + (ts.red[96] + ts.red[144]);
     gp[o_l + 1] = (ts.red[1] + ts.red[49]) + (ts.red[97] + ts.red[145]);
   }
+  T1_STAMP(4);
   // ---- P4: dgrad  dh1[m][i] = sum_o dz[m][o] W1[i][o]  (A = dz tile, B = W1 in dgrad fragment order) ----
   if (!(ablate & 1)) {
     const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
@@ -571,20 +610,22 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     const int col = lane & 15, r0 = 4 * (lane >> 4);
     constexpr int IPW = 64 / QN_WAVES / 2;   // pairs of i-blocks (16 conv features each) per wave
     const int ib_first = 2 * IPW * wave;
+    const int prot = blockIdx.x & (IPW - 1);  // de-phase the W1 stream across workgroups (see phase2_fc1)
     f32x4 buf[2][2][8];                       // [parity][block of the pair][k group]
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      buf[0][0][g] = wb[(g * 64 + ib_first) * 64 + lane];
-      buf[0][1][g] = wb[(g * 64 + ib_first + 1) * 64 + lane];
+      buf[0][0][g] = wb[(g * 64 + ib_first + 2 * prot) * 64 + lane];
+      buf[0][1][g] = wb[(g * 64 + ib_first + 2 * prot + 1) * 64 + lane];
     }
 #pragma unroll
     for (int ip = 0; ip < IPW; ++ip) {
-      const int ib = ib_first + 2 * ip;
+      const int ib = ib_first + 2 * ((ip + prot) & (IPW - 1));
       if (ip + 1 < IPW) {
+        const int ibn = ib_first + 2 * ((ip + 1 + prot) & (IPW - 1));
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-          buf[(ip + 1) & 1][0][g] = wb[(g * 64 + ib + 2) * 64 + lane];
-          buf[(ip + 1) & 1][1][g] = wb[(g * 64 + ib + 3) * 64 + lane];
+          buf[(ip + 1) & 1][0][g] = wb[(g * 64 + ibn) * 64 + lane];
+          buf[(ip + 1) & 1][1][g] = wb[(g * 64 + ibn + 1) * 64 + lane];
         }
       }
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -613,6 +654,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     }
   }
   __syncthreads();
+  T1_STAMP(5);
   // ---- P5: LN0 backward.  conv recomputed (MFMA) and staged; LN stats + backward per point in one
   // lane; channel sums (d conv-bias, d ln0-scale, d ln0-bias) in (channel = lane&15) layout. -----------
   if (!(ablate & 2)) {
@@ -622,6 +664,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     const int o = lane & 15, kk = lane >> 4;
     const float bias = bc[o];
     float *stg = s.stg + wave * 64 * QN_STG;
+    uint32_t *wm = reinterpret_cast<uint32_t *>(s.z) + wave * 192;   // dz tile is dead after the dgrad
     float gsc = 0.f, gbi = 0.f, gbc = 0.f;
 #pragma unroll 1
     for (int mm = 0; mm < QN_SPW; ++mm) {
@@ -629,7 +672,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       float *gt = s.h1 + msamp * QN_H1S;                 // d relu-input tile (masked by h1 > 0) -> dx in place
 #pragma unroll
       for (int j = 0; j < 16; ++j) gbi += gt[(kk + 4 * j) * 16 + o];
-      conv_sample_to_stage<C>(cv, s.bits + msamp * Cfg::OW, stg, bias, lane);
+      conv_sample_to_stage<C>(cv, s.bits + msamp * Cfg::OW, wm, stg, bias, lane);
       float xhat[16], rstd;
       ln16_point(stg, lane, xhat, rstd);
       f32x4 *gptr = reinterpret_cast<f32x4 *>(gt + lane * 16);
@@ -682,40 +725,48 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     for (int w = 0; w < QN_WAVES; ++w) acc += ts.red[w * 48 + tid];
     gp[Cfg::KW * 16 + tid] = acc;
   }
+  T1_STAMP(6);
   // ---- P6: conv weight gradient as MFMA:  dWc[k][o] = sum_{m,pos} (bit(m,pos,k)/255) * dx[m][pos][o] ----
   //   A[i = k row][kk] = bit(m, pos = 4s+kk, k = 16rb+i)/255,  B[kk][o] = dx[m][4s+kk][o]  (LDS, contiguous)
   //   wave w reduces its samples 4w..4w+3; the 4 wave partials are folded in fixed order.
   if (!(ablate & 4)) {
     constexpr int NRB = (9 * C + 15) / 16;   // 16-row blocks of k
     constexpr int RBH = (NRB + 1) / 2;       // row blocks per wave half
+    constexpr int RB = 3 * C;
     // wave = (sample quad sq, row-block half rh): samples 4sq..4sq+3, row blocks rh*RBH ..
     const int sq = wave & 3, rh = wave >> 2;
     const int i = lane & 15, kk = lane >> 4;
-    int koff[RBH];
+    int kyL[RBH], shL[RBH];                  // lane constants: window row / bit of k = 16*rb + i (-1: padding row)
 #pragma unroll
     for (int j = 0; j < RBH; ++j) {
       const int k = 16 * (rh * RBH + j) + i;
-      koff[j] = (k < 9 * C) ? ((k / (3 * C)) * 10 + (k / C) % 3) * C + k % C : -1;
+      kyL[j] = (k < 9 * C) ? k / RB : -1;
+      shL[j] = (k < 9 * C) ? k % RB : 0;
     }
     f32x4 acc[RBH];
 #pragma unroll
     for (int j = 0; j < RBH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float inv255 = 1.0f / 255.0f;
+    uint32_t *wm = reinterpret_cast<uint32_t *>(s.stg + wave * 64 * QN_STG);   // staging buffer is free now
 #pragma unroll 1
     for (int mm = 0; mm < 4; ++mm) {
       const int msamp = 4 * sq + mm;
-      const uint32_t *row = s.bits + msamp * Cfg::OW;
+      window_masks<C>(s.bits + msamp * Cfg::OW, wm, lane);
       const float *dxm = s.h1 + msamp * QN_H1S + lane;   // + 64*st : element (pos = 4st+kk, o = lane&15)
-#pragma unroll 4
+      float bv[16];
+      uint32_t wv[16][RBH];
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {          // all LDS reads of the sample in flight at once
+        bv[st] = dxm[64 * st];
+#pragma unroll
+        for (int j = 0; j < RBH; ++j) wv[st][j] = wm[(4 * st + kk) * 3 + max(kyL[j], 0)];
+      }
+#pragma unroll
       for (int st = 0; st < 16; ++st) {
-        const int pos = 4 * st + kk;
-        const int base = ((pos >> 3) * 10 + (pos & 7)) * C;
-        const float b = dxm[64 * st];
 #pragma unroll
         for (int j = 0; j < RBH; ++j) {
-          const int bit = base + max(koff[j], 0);
-          const float a = (koff[j] >= 0 && ((row[bit >> 5] >> (bit & 31)) & 1u)) ? inv255 : 0.0f;
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+          const float a = (kyL[j] >= 0 && ((wv[st][j] >> shL[j]) & 1u)) ? inv255 : 0.0f;
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[st], acc[j], 0, 0, 0);
         }
       }
     }
@@ -734,6 +785,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       gp[e] = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
     }
   }
+  T1_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------
@@ -983,6 +1035,14 @@ extern "C" int pqn_prof_read(int32_t *count, float *total_ms) {
   return PQN_OK;
 }
 
+static unsigned long long *g_t1_stamps = nullptr;   // profiling only (PQN_T1_STAMPS=1)
+
+extern "C" int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries */) {
+  if (!g_t1_stamps) return PQN_E_INVALID;
+  if (hipMemcpy(out, g_t1_stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return PQN_E_HIP;
+  return PQN_OK;
+}
+
 template <int C>
 static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits,
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
@@ -1002,10 +1062,13 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   const float inv_b = 1.0f / (float)nb;
   static const int ablate = getenv("PQN_ABLATE_TRAIN") ? atoi(getenv("PQN_ABLATE_TRAIN")) : 0;  // profiling only
+  if (!g_t1_stamps && getenv("PQN_T1_STAMPS")) {
+    if (hipMalloc(&g_t1_stamps, 64 * sizeof(unsigned long long)) != hipSuccess) g_t1_stamps = nullptr;
+  }
   const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
   if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
   hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles), dim3(QN_THREADS), smem1, st, nb, idx, bits, action, target,
-                     theta, w1b, L, inv_b, dzT, h1T, gpart, ablate);
+                     theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps);
   if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
   hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart);
   hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total)), dim3(256), 0, st, L, ntiles, nks, rec,

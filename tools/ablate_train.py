@@ -20,3 +20,14 @@ act = torch.randint(0, 3, (n * T,), dtype=torch.int32, device=dev); tgt = torch.
 ms = time_launches(lambda: tr.compute_grad(idx, bits, act, tgt), iters=200)
 ms2 = time_launches(lambda: tr.apply(), iters=200)
 print("PQN_ABLATE_TRAIN=%s grad(T1+T2+T3a) %.2f us  apply %.2f us" % (os.environ.get("PQN_ABLATE_TRAIN", "0"), ms * 1e3, ms2 * 1e3))
+
+if os.environ.get("PQN_T1_STAMPS"):
+    import ctypes
+    from purejaxql_amd import _lib
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 64)()
+    _lib.check(_lib.load().pqn_debug_t1_stamps(buf), "stamps")
+    names = ["start", "inputs", "conv(phase1)", "h1T+fc1", "head+bwd+dzT", "dgrad", "P5 ln0 bwd", "P6 conv wgrad"]
+    for wg in range(4):
+        s = [buf[wg * 16 + k] for k in range(8)]
+        print("WG%d cycles:" % wg, " ".join("%s=%d" % (names[k + 1], s[k + 1] - s[k]) for k in range(7)), "total=%d" % (s[7] - s[0]))
