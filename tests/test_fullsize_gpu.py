@@ -1,0 +1,141 @@
+"""GPU tests at BASELINE.json's full shape (Breakout-MinAtar, 4096 envs x 32 steps, minibatch 4096) through
+size-independent properties, plus error-path / ragged-shape checks of the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _rollout_bits(gpu, n, t):
+    from purejaxql_amd.envs import make
+    env, params = make("Breakout-MinAtar", device=gpu)
+    (_, bits), state = env.reset(1, params, n, want_bits=True, want_obs=False)
+    out, rewards, dones = [], [], []
+    g = torch.Generator(device=gpu)
+    g.manual_seed(0)
+    for i in range(t + 20):
+        a = torch.randint(0, 3, (n,), dtype=torch.int32, device=gpu, generator=g)
+        (_, bits), state, r, d, _ = env.step(100 + i, state, a, params, want_bits=True, want_obs=False, inplace=True)
+        if i >= 20:
+            out.append(bits)
+            rewards.append(r)
+            dones.append(d.view(torch.uint8))
+    return torch.stack(out), torch.stack(rewards), torch.stack(dones)
+
+
+def test_full_size_gradient_is_linear_in_the_minibatch(gpu):
+    """grad(minibatch of 4096) == mean of the gradients of its two halves (loss is a mean over samples):
+    exercises every kernel of the optimizer step at the bench shape, incl. the 16-slab split-K reduction."""
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
+    n, t = 4096, 32
+    bits, _, _ = _rollout_bits(gpu, n, t)
+    bits = bits.reshape(n * t, -1).contiguous()
+    net = QNetwork("cnn", (10, 10, 4), 3, device=gpu)
+    lay = CnnKernelLayout(4, 3)
+    tr = CnnTrainer(lay, net.init(3) + 0.02 * torch.randn(net.num_params, device=gpu), 5e-4, 10.0)
+    g = torch.Generator(device=gpu)
+    g.manual_seed(1)
+    idx = torch.randperm(n * t, device=gpu, generator=g)[:4096].contiguous()
+    act = torch.randint(0, 3, (n * t,), dtype=torch.int32, device=gpu, generator=g)
+    tgt = torch.randn(n * t, device=gpu, generator=g)
+    loss = torch.zeros(3, device=gpu)
+    g_full = tr.compute_grad(idx, bits, act, tgt, loss[0:1]).clone()
+    g_a = tr.compute_grad(idx[:2048].contiguous(), bits, act, tgt, loss[1:2]).clone()
+    g_b = tr.compute_grad(idx[2048:].contiguous(), bits, act, tgt, loss[2:3]).clone()
+    ref = 0.5 * (g_a + g_b)
+    scale = float(ref.abs().max())
+    # f32 with different summation trees: 1e-5 of the largest gradient entry
+    assert float((g_full - ref).abs().max()) <= 1e-5 * scale
+    assert abs(float(loss[0]) - 0.5 * float(loss[1] + loss[2])) <= 1e-5 * max(1.0, float(loss[0]))
+    # permuting the minibatch changes nothing but the summation order
+    g_perm = tr.compute_grad(idx.flip(0).contiguous(), bits, act, tgt).clone()
+    assert float((g_full - g_perm).abs().max()) <= 1e-5 * scale
+
+
+def test_full_size_forward_is_per_sample(gpu):
+    """q of a sample does not depend on its batch neighbours or position (tiles of 16, 4096 rows)."""
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward
+    bits, _, _ = _rollout_bits(gpu, 4096, 1)
+    bits = bits[0].contiguous()
+    net = QNetwork("cnn", (10, 10, 4), 3, device=gpu)
+    lay = CnnKernelLayout(4, 3)
+    th = lay.to_kernel(net.init(9))
+    q, _, _ = cnn_forward(lay, bits, th)
+    perm = torch.randperm(4096, device=gpu)
+    qp, _, _ = cnn_forward(lay, bits[perm].contiguous(), th)
+    # the fc1 K order is rotated per workgroup, so rows agree to f32 rounding, not bitwise
+    torch.testing.assert_close(qp, q[perm], rtol=1e-5, atol=1e-6)
+    q1, _, _ = cnn_forward(lay, bits[:33].contiguous(), th)          # ragged tail tile
+    torch.testing.assert_close(q1, q[:33], rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_q_lambda_properties(gpu, oracle):
+    from purejaxql_amd import ops
+    _, r, d = _rollout_bits(gpu, 4096, 32)
+    r, d = r.contiguous(), d.contiguous()
+    qm = torch.randn(32, 4096, device=gpu)
+    lq = torch.randn(4096, device=gpu)
+    tgt = ops.q_lambda(r, d, qm, lq, 0.99, 0.65)
+    np.testing.assert_array_equal(_np(tgt), oracle.q_lambda(_np(r), _np(d), _np(qm), _np(lq), 0.99, 0.65))
+    # linearity in (reward, qmax, last_q) for a fixed done pattern
+    t2 = ops.q_lambda(2 * r, d, 2 * qm, 2 * lq, 0.99, 0.65)
+    torch.testing.assert_close(t2, 2 * tgt, rtol=1e-6, atol=1e-6)
+    # lambda = 0 is the 1-step target; an episode end cuts the bootstrap
+    t0 = ops.q_lambda(r, d, qm, lq, 0.99, 0.0)
+    nxt = torch.cat([qm[1:], lq[None]], 0)
+    nxt[30] = lq * (1 - d[31].float())      # the reference's T-2 quirk
+    torch.testing.assert_close(t0, r + 0.99 * (1 - d.float()) * nxt, rtol=1e-6, atol=1e-6)
+    assert torch.equal(tgt[d.bool()], r[d.bool()])
+
+
+def test_full_size_shuffle_is_a_bijection_and_update_is_deterministic(gpu):
+    from purejaxql_amd import ops
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys
+    p = ops.shuffle_permutation(77, 131072, gpu)
+    assert torch.equal(torch.sort(p).values, torch.arange(131072, device=gpu))
+    cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", "alg.NUM_ENVS=4096",
+                               "alg.TEST_DURING_TRAINING=False"]))
+    cfg["TOTAL_TIMESTEPS"] = 3 * 4096 * 32
+    outs = [make_train(dict(cfg), device="cuda:0")(seed_keys(5, 1)[0]) for _ in range(2)]
+    assert outs[0]["runner_state"]["driver"] == "graph"
+    for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode"):
+        assert torch.equal(outs[0]["metrics"][k], outs[1]["metrics"][k]), k      # hipGraph replay is bit-reproducible
+    assert torch.equal(outs[0]["runner_state"]["theta"], outs[1]["runner_state"]["theta"])
+    m = outs[0]["metrics"]
+    assert m["env_step"].tolist() == [131072.0, 262144.0, 393216.0] and m["grad_steps"].tolist() == [64.0, 128.0, 192.0]
+    assert abs(float(m["timestep"][2]) - (64 + 16.5)) < 1e-3 and float(m["returned_episode"][0]) > 0.05
+
+
+def test_c_abi_argument_errors(gpu):
+    """Bad arguments are rejected on the host with a negative code and a message (no launch)."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.qnet import CnnKernelLayout
+    lib = _lib.load()
+    lay = CnnKernelLayout(4, 3)
+    x = torch.zeros(64, dtype=torch.float32, device=gpu)
+    assert lib.pqn_env_step(0, 16, 1, None, None, None, None, None) == -1
+    assert b"NULL" in lib.pqn_last_error()
+    assert lib.pqn_env_reset(0, 0, 1, x.data_ptr(), None, None, None) == -1
+    assert lib.pqn_q_lambda(None, None, None, None, 0.99, 0.65, 4, 4, 1, None, None) == -1
+    assert lib.pqn_eps_greedy(x.data_ptr(), 0, 3, 0.1, 1, x.data_ptr(), None, None) == -1
+    assert lib.pqn_env_reset(99, 4, 1, x.data_ptr(), None, None, None) == -3          # unknown env
+    assert lib.pqn_env_reset(1, 4, 1, x.data_ptr(), None, x.data_ptr(), None) == -1   # CartPole has no packed obs
+    bad = _lib.EnvSpec()
+    assert lib.pqn_env_spec(42, ctypes.byref(bad)) == -3
+    # minibatch sizes must be multiples of the 16-sample MFMA tile
+    rc = lib.pqn_qnet_cnn_grad(ctypes.byref(lay.struct), 24, *([x.data_ptr()] * 11), None)
+    assert rc == -1 and b"multiple of 16" in lib.pqn_last_error()
+    bad_layout = _lib.c_int32(0)
+    from purejaxql_amd.qnet import CnnLayoutStruct
+    s = CnnLayoutStruct()
+    assert lib.pqn_cnn_layout(5, 3, ctypes.byref(s)) == -1 and lib.pqn_cnn_layout(4, 9, ctypes.byref(s)) == -1
