@@ -180,6 +180,11 @@ def main():
                        "loop_tflops": sps * LOOP_FLOP / 1e12, "loop_frac_f32_peak": sps * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS},
             "roofline": roof,
         }
+        out["config"]["loop_gbps_algorithmic"] = sps * 6.77e-6   # 6,770 B per env-step of the loop
+        out["config"]["loop_frac_hbm_peak"] = sps * 6.77e-6 / HBM_PEAK_GBS
+        if world == 1:
+            from purejaxql_amd.profiling import env_step_hbm_roofline
+            out["roofline_env_step"] = [env_step_hbm_roofline(n, dev) for n in (4096, 65536)]
         if not args.no_cpu_baseline and world == 1:
             theta0 = finish()["runner_state"]["network"].init(1).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(cfg, theta0)

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "pqn_common.h"
+#include "pqn_env_rules.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -411,6 +412,103 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
   }
 }
 
+
+// ===========================================================================
+// Persistent rollout: the whole SAMPLE PHASE of one update (`_step_env` scan, pqn_minatar.py:181-220) plus
+// the bootstrap forward (:227-235) in ONE launch.  Envs are independent and the parameters are frozen
+// during the rollout, so a workgroup keeps its 16 envs for all T steps: env + LogWrapper state stay in
+// registers of the 16 owner lanes, the next observation is written as a packed row straight into the LDS
+// tile the next forward reads, and only the transition record goes to HBM.  No kernel boundary, no
+// prologue and no observation round trip between steps.
+// ===========================================================================
+template <int C, class Env>
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
+    int n, int t_len, uint32_t *__restrict__ state, uint32_t *__restrict__ bits_all, const float *__restrict__ theta,
+    pqn_cnn_layout_t L, int32_t *__restrict__ action, float *__restrict__ qmax, float *__restrict__ reward,
+    uint8_t *__restrict__ done, float *__restrict__ discount, float *__restrict__ rer, int32_t *__restrict__ rel,
+    int32_t *__restrict__ ts, float *__restrict__ last_q, const float *__restrict__ eps_dev,
+    const uint64_t *__restrict__ keys, float rscale) {
+  using Cfg = CnnCfg<C>;
+  static_assert(Cfg::OW == Env::OBS_WORDS, "packed observation width");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const CnnSmem s = carve_smem<C>(smem_raw);
+  const int tid = threadIdx.x;
+  const int e0 = blockIdx.x * QN_TILE;
+  const int m = (tid >> 4) & 15, sub = tid & 15, e = e0 + m;
+  const bool owner = tid < 256 && sub == 0 && e < n;   // the lane that owns env e
+  const size_t bstride = (size_t)n * Cfg::OW;
+  load_tile_common<C>(s, theta, L, tid);
+  for (int i = tid; i < QN_TILE * Cfg::OW; i += QN_THREADS) {
+    const int le = i / Cfg::OW;
+    s.bits[i] = (e0 + le < n) ? bits_all[(size_t)e0 * Cfg::OW + i] : 0u;
+  }
+  if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
+  Env env;
+  LogRec log;
+  if (owner) {
+    uint32_t w[Env::ENV_WORDS];
+#pragma unroll
+    for (int i = 0; i < Env::ENV_WORDS; ++i) w[i] = state[(size_t)i * n + e];
+    env.unpack(w);
+    log.load(state, n, e, Env::ENV_WORDS);
+  }
+  const float eps = *eps_dev;
+#pragma unroll 1
+  for (int t = 0; t <= t_len; ++t) {
+    __syncthreads();   // s.bits holds obs_t of the tile (and every previous reader of the tiles is done)
+    phase1_conv<C>(s, tid);
+    __syncthreads();
+    phase2_fc1<0>(s, theta + L.off_w1, tid);
+    __syncthreads();
+    if (tid < 256) {
+      float q[QN_MAXA], h2[8], xh[8], rstd;
+      phase3_head(s, theta, L, tid, q, h2, xh, rstd);
+      if (owner) {
+        int best = 0;
+        float bv = q[0];
+#pragma unroll
+        for (int a = 1; a < QN_MAXA; ++a)
+          if (a < L.a && q[a] > bv) { bv = q[a]; best = a; }
+        if (t == t_len) {
+          last_q[e] = bv;                                  // bootstrap value of obs_T
+        } else {
+          const uint64_t key = keys[t];
+          uint32_t o0, o1;
+          pqn_bits(key, (uint32_t)e, PQN_STREAM_ACT, o0, o1);
+          const int act = (pqn_uniform(o0) < eps) ? (int)pqn_randint(o1, (uint32_t)L.a) : best;
+          int dn = 0;
+          const float r = env.step(act, key, (uint32_t)e, dn);
+          log.step(r, dn);
+          if (dn) env.reset(key, (uint32_t)e);             // gymnax auto-reset
+          const size_t o = (size_t)t * n + e;
+          action[o] = act;
+          qmax[o] = bv;
+          reward[o] = r * rscale;
+          done[o] = (uint8_t)dn;
+          discount[o] = dn ? 0.0f : 1.0f;
+          rer[o] = log.ret_ret;
+          rel[o] = log.ret_len;
+          ts[o] = log.timestep;
+          env.obs_bits(&s.bits[m * Cfg::OW]);              // obs_{t+1} straight into the LDS tile
+        }
+      }
+    }
+    if (t == t_len) break;
+    __syncthreads();
+    // transition record: packed obs_{t+1} of the tile (the training kernels gather from it)
+    for (int i = tid; i < QN_TILE * Cfg::OW; i += QN_THREADS) {
+      const int le = i / Cfg::OW;
+      if (e0 + le < n) bits_all[(size_t)(t + 1) * bstride + (size_t)e0 * Cfg::OW + i] = s.bits[i];
+    }
+  }
+  if (owner) {
+    uint32_t w[Env::ENV_WORDS];
+    env.pack(w);
+#pragma unroll
+    for (int i = 0; i < Env::ENV_WORDS; ++i) state[(size_t)i * n + e] = w[i];
+    log.store(state, n, e, Env::ENV_WORDS);
+  }
+}
 
 // ===========================================================================
 // TRAINING.  One optimizer step of _learn_phase (pqn_minatar.py:266-297) =
@@ -990,6 +1088,48 @@ extern "C" int pqn_qnet_cnn_forward(const pqn_cnn_layout_t *L, int32_t n, const 
   PQN_REQUIRE(q || action || qmax, "pqn_qnet_cnn_forward: no output requested");
   return pqn_qnet_cnn_forward_dyn(*L, n, obs_bits, theta, q, action, qmax, eps, key, nullptr, nullptr,
                                   (hipStream_t)stream);
+}
+
+
+template <int C, class Env>
+static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
+                          const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
+                          const uint64_t *keys, float rscale, hipStream_t st) {
+  const size_t smem = cnn_smem_bytes<C>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_kernel<C, Env>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((qnet_cnn_rollout_kernel<C, Env>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n,
+                     t_len, state, bits, theta, L, action, qmax, rec.reward, rec.done, rec.discount,
+                     rec.returned_episode_returns, rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys,
+                     rscale);
+  return pqn_check_launch("pqn_qnet_cnn_rollout");
+}
+
+// internal (pqn_update.hip): rec.* point at the [T][n] transition arrays
+int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
+                         const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
+                         const float *eps_dev, const uint64_t *keys, float rscale, hipStream_t st) {
+  switch (env_id) {
+    case PQN_ENV_BREAKOUT:
+      if (L.c == 4) return launch_rollout<4, Breakout>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, st);
+      break;
+    case PQN_ENV_ASTERIX:
+      if (L.c == 4) return launch_rollout<4, Asterix>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, st);
+      break;
+    case PQN_ENV_FREEWAY:
+      if (L.c == 7) return launch_rollout<7, Freeway>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, st);
+      break;
+    case PQN_ENV_SPACEINVADERS:
+      if (L.c == 6) return launch_rollout<6, SpaceInvaders>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, st);
+      break;
+    default: break;
+  }
+  pqn_set_error("pqn_qnet_cnn_rollout: env %d / %d channels has no fused rollout", env_id, L.c);
+  return PQN_E_UNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------

@@ -127,24 +127,19 @@ extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
 
   hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, T, EP, a->eps_start,
                      a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
-  // SAMPLE PHASE (_step_env, :181-220)
-  for (int t = 0; t < T; ++t) {
-    const size_t o = (size_t)t * N;
-    UPD_CHECK(pqn_qnet_cnn_forward_dyn(L, N, a->bits + t * bits_stride, a->theta, nullptr, a->action + o, a->qmax + o, 0.0f,
-                                       0, a->sched_eps, a->sched_keys + t, st));
-    pqn_step_out_t out = {};
-    out.obs_bits = a->bits + (t + 1) * bits_stride;
-    out.reward = a->reward + o;
-    out.done = a->done + o;
-    out.discount = a->discount + o;
-    out.returned_episode_returns = a->rer + o;
-    out.returned_episode_lengths = a->rel + o;
-    out.timestep = a->ts + o;
-    UPD_CHECK(pqn_env_step_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->state, a->action + o, out, st));
+  // SAMPLE PHASE (_step_env scan, :181-220) + bootstrap forward (:227-235): one persistent launch
+  {
+    pqn_step_out_t rec = {};
+    rec.reward = a->reward;
+    rec.done = a->done;
+    rec.discount = a->discount;
+    rec.returned_episode_returns = a->rer;
+    rec.returned_episode_lengths = a->rel;
+    rec.timestep = a->ts;
+    UPD_CHECK(pqn_qnet_cnn_rollout(a->env_id, L, N, T, a->state, a->bits, a->theta, rec, a->action, a->qmax, a->last_q,
+                                   a->sched_eps, a->sched_keys, a->rew_scale, st));
   }
-  // Q(lambda) TARGETS (:227-260)
-  UPD_CHECK(pqn_qnet_cnn_forward_dyn(L, N, a->bits + (size_t)T * bits_stride, a->theta, nullptr, nullptr, a->last_q, 0.0f, 0,
-                                     nullptr, nullptr, st));
+  // Q(lambda) TARGETS (:237-260)
   UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, N, 1, a->target, st));
   // NETWORKS UPDATE (:263-327)
   int i_mb = 0;
