@@ -1,7 +1,7 @@
 """Hydra-grammar config loader for the PQN scripts (host side, no hydra dep).
 
 Reproduces what `@hydra.main(config_path="./config", config_name="config")`
-plus `single_run`'s flatten do in the reference
+plus `single_run`'s flatten do in the reference, from ONE table file (config/hyperparameters.yaml)
 (purejaxql/pqn_minatar.py:437,534-541; README.md:170-187):
 
     load_config(["+alg=pqn_minatar", "alg.NUM_ENVS=4096", "SEED=3"])
@@ -53,19 +53,22 @@ def load_yaml(path: str) -> Dict[str, Any]:
         return _cast_tree(yaml.safe_load(f) or {})
 
 
+def _tables(config_dir: str) -> Dict[str, Any]:
+    return load_yaml(os.path.join(config_dir, "hyperparameters.yaml"))
+
+
 def load_config(overrides: Iterable[str] = (), config_dir: str = CONFIG_DIR) -> Dict[str, Any]:
-    """Compose config.yaml + `+alg=<name>` group + `alg.KEY=V` / `KEY=V` overrides."""
-    cfg = load_yaml(os.path.join(config_dir, "config.yaml"))
+    """Compose the base options + the `+alg=<name>` group + `alg.KEY=V` / `KEY=V` overrides."""
+    tables = _tables(config_dir)
+    cfg = copy.deepcopy(tables["base"])
     cfg.setdefault("alg", {})
     overrides = list(overrides)
     for ov in overrides:  # group selection first, as hydra does
         if ov.startswith("+alg=") or ov.startswith("alg="):
             name = ov.split("=", 1)[1]
-            path = os.path.join(config_dir, "alg", name + ".yaml")
-            if not os.path.exists(path):
-                raise FileNotFoundError(f"no alg config '{name}' in {config_dir}/alg")
-            group = load_yaml(path)
-            cfg["alg"] = {**cfg["alg"], **group}
+            if name not in tables["alg"]:
+                raise FileNotFoundError(f"no alg group '{name}' (have: {sorted(tables['alg'])})")
+            cfg["alg"] = {**cfg["alg"], **copy.deepcopy(tables["alg"][name])}
     for ov in overrides:
         if ov.startswith("+alg=") or ov.startswith("alg="):
             continue
