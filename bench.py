@@ -50,7 +50,14 @@ def cpu_baseline(cfg, theta0, max_seconds=45.0):
     n, t = int(ocfg["NUM_ENVS"]), int(ocfg["NUM_STEPS"])
     # bounded sample: 1 update at a reduced env count if the full one would take too long
     sample_envs = n
-    cores = os.cpu_count() or 1
+    # threads actually used: numpy's BLAS pool (the network, most of the time) and OpenMP (C env step)
+    try:
+        from threadpoolctl import threadpool_info
+        pools = threadpool_info()
+        cores = max([p.get("num_threads", 1) for p in pools] + [1])
+        pool_desc = ", ".join(f"{p.get('internal_api')}:{p.get('num_threads')}" for p in pools)
+    except Exception:
+        cores, pool_desc = os.cpu_count() or 1, "unknown"
     ocfg["NUM_ENVS"] = sample_envs
     ocfg["TOTAL_TIMESTEPS"] = ocfg["TOTAL_TIMESTEPS_DECAY"] = 1e7
     train = oracle.make_train(ocfg)
@@ -60,7 +67,8 @@ def cpu_baseline(cfg, theta0, max_seconds=45.0):
     return {"value": sample_envs * t / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"1 full PQN update (rollout+Q(lambda)+{ocfg['NUM_EPOCHS']}x{ocfg['NUM_MINIBATCHES']} SGD steps) "
                       f"at NUM_ENVS={sample_envs}, NUM_STEPS={t}: {sample_envs * t} env-steps in {dt:.1f}s; "
-                      "oracle/pqn_oracle.py (C env/eps-greedy/Q(lambda)/RAdam + numpy-BLAS network), not JAX"}
+                      "oracle/pqn_oracle.py (C env/eps-greedy/Q(lambda)/RAdam + numpy-BLAS network), not JAX; "
+                      f"host has {os.cpu_count()} logical cores, thread pools: {pool_desc}"}
 
 
 def main():

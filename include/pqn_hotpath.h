@@ -231,6 +231,34 @@ int pqn_cnn_update(const pqn_update_args_t *args /* host */, void *stream);
  * workgroups 0..3; 16 slots per workgroup.  Not part of the hot path. */
 int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries */);
 
+/* ---- fused MLP Q-network (QNetwork of pqn_gymnax.py:29-58, layer_norm, NORM_INPUT=False) ----------- */
+/* Parameter buffer in flax order with 16-B aligned segments and natural (in,out) kernels:
+ * BatchNorm_0 dummy [2*D] | per hidden layer l: Dense_l kernel [in][H], bias [H], LayerNorm_l scale [H],
+ * bias [H] | Dense_L kernel [H][A], bias [A]. */
+#define PQN_MLP_MAX_LAYERS 4
+typedef struct {
+  int32_t d, h, layers, a;
+  int32_t off_bn;
+  int32_t off_w[PQN_MLP_MAX_LAYERS], off_b[PQN_MLP_MAX_LAYERS], off_lns[PQN_MLP_MAX_LAYERS], off_lnb[PQN_MLP_MAX_LAYERS];
+  int32_t off_wout, off_bout;
+  int32_t total;
+} pqn_mlp_layout_t;
+
+int pqn_mlp_layout(int32_t d, int32_t h, int32_t layers, int32_t a, pqn_mlp_layout_t *layout /* host */);
+/* network.apply(train=False) + eps-greedy (pqn_gymnax.py:178-190); obs f32 [n, D]; outputs nullable. */
+int pqn_mlp_forward(const pqn_mlp_layout_t *layout /* host */, int32_t n, const float *obs, const float *theta,
+                    float *q, int32_t *action, float *qmax, float eps, uint64_t key, void *stream);
+/* _learn_phase (pqn_gymnax.py:257-288) in two halves, as for the CNN.  `wt`: (layers-1)*H*H floats, the
+ * transposed hidden kernels of layers >= 1, kept in step by pqn_mlp_apply / pqn_mlp_refresh_transposed. */
+int64_t pqn_mlp_workspace_floats(const pqn_mlp_layout_t *layout /* host */, int32_t nb);
+int pqn_mlp_grad(const pqn_mlp_layout_t *layout /* host */, int32_t nb, const int64_t *idx, const float *obs,
+                 const int32_t *action, const float *target, const float *theta, const float *wt, float *grad,
+                 const int32_t *count, float *workspace, float *loss_out, float *qv_out, void *stream);
+int pqn_mlp_apply(const pqn_mlp_layout_t *layout /* host */, float *theta, float *wt, const float *grad, float *m,
+                  float *v, int32_t *count, float lr_init, float lr_end, float lr_steps, float max_norm,
+                  float *workspace, float *gnorm_out, int32_t recompute_norm, void *stream);
+int pqn_mlp_refresh_transposed(const pqn_mlp_layout_t *layout /* host */, const float *theta, float *wt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

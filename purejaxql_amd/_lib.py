@@ -60,6 +60,13 @@ SIGNATURES = {
     "pqn_update_sort_temp_bytes": (c_int64, [c_int32]),
     "pqn_cnn_update": (c_int, [c_void_p, c_void_p]),
     "pqn_debug_t1_stamps": (c_int, [c_void_p]),
+    "pqn_mlp_layout": (c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pqn_mlp_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64,
+                                c_void_p]),
+    "pqn_mlp_workspace_floats": (c_int64, [c_void_p, c_int32]),
+    "pqn_mlp_grad": (c_int, [c_void_p, c_int32] + [c_void_p] * 11 + [c_void_p]),
+    "pqn_mlp_apply": (c_int, [c_void_p] * 7 + [c_float] * 4 + [c_void_p, c_void_p, c_int32, c_void_p]),
+    "pqn_mlp_refresh_transposed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

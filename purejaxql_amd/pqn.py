@@ -157,6 +157,49 @@ class _FusedCnnPolicy:
                 "kernel_layout": self.layout}
 
 
+class _FusedMlpPolicy:
+    """The gymnax MLP Q-network (pqn_gymnax.py:29-58) through the fused HIP kernels of csrc/pqn_mlp.hip."""
+    packed = False
+
+    def __init__(self, network, theta, config, lr_steps, grad_hook, max_mb):
+        from .qnet import MlpKernelLayout, MlpTrainer, mlp_forward
+        self.net = network
+        self.layout = MlpKernelLayout(network.obs_shape[0], network.hidden, network.layers, network.action_dim)
+        self.tr = MlpTrainer(self.layout, theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps,
+                             max_minibatch=max_mb)
+        self.fwd = mlp_forward
+        self.grad_hook = grad_hook
+
+    def q_values(self, obs):
+        return self.fwd(self.layout, obs, self.tr.theta)[0]
+
+    def act(self, obs, eps, key, action, qmax):
+        self.fwd(self.layout, obs, self.tr.theta, want_q=False, eps=eps, key=key, action=action, qmax=qmax)
+
+    def max_q(self, obs, out):
+        self.fwd(self.layout, obs, self.tr.theta, want_q=False, qmax=out)
+
+    def sgd_step(self, idx, obs_flat, act_flat, tgt_flat, loss_out, qv_out):
+        self.tr.compute_grad(idx, obs_flat, act_flat, tgt_flat, loss_out, qv_out)
+        if self.grad_hook is not None:
+            self.grad_hook(self.tr.grad)
+        self.tr.apply(recompute_norm=self.grad_hook is not None)
+
+    def theta_flax(self):
+        return self.tr.theta_flax()
+
+    def opt_state(self):
+        return {"opt_count": self.tr.count, "opt_mu": self.tr.m, "opt_nu": self.tr.v, "kernel_layout": self.layout}
+
+
+def _mlp_fits_fused(obs_dim: int, hidden: int, layers: int) -> bool:
+    """LDS footprint of mlp_train_kernel (csrc/pqn_mlp.hip) must stay under 160 KB."""
+    if hidden % 16 or hidden < 16 or hidden > 1024 or layers < 1 or layers > 4:
+        return False
+    floats = 16 * (obs_dim + 1) + (2 * layers + 2) * 16 * (hidden + 4) + layers * 16 + 32
+    return floats * 4 <= 160 * 1024
+
+
 def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: Optional[Callable] = None):
     """Returns train(key).  `grad_hook(flat_grad)` (optional) runs between backward
     and the optimizer step -- the RCCL all-reduce of env-sharded mode plugs in here."""
@@ -190,10 +233,14 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
     test_on = bool(config.get("TEST_DURING_TRAINING", False))
     sp = _lib.stream_ptr
     backend = config.get("_BACKEND")
-    if backend is None:  # fused kernels need the LayerNorm CNN and 16 | minibatch
-        backend = "fused" if (kind == "cnn" and config["NORM_TYPE"] == "layer_norm"
-                              and not config.get("NORM_INPUT", False) and B % 16 == 0) else "torch"
-    packed = backend == "fused"
+    if backend is None:  # fused kernels: LayerNorm networks; the CNN also needs 16 | minibatch
+        plain_ln = config["NORM_TYPE"] == "layer_norm" and not config.get("NORM_INPUT", False)
+        if kind == "cnn":
+            backend = "fused" if (plain_ln and B % 16 == 0) else "torch"
+        else:
+            backend = "fused" if (plain_ln and _mlp_fits_fused(obs_shape[0], int(config.get("HIDDEN_SIZE", 128)),
+                                                               int(config.get("NUM_LAYERS", 2)))) else "torch"
+    packed = backend == "fused" and kind == "cnn"
 
     def env_step_into(key, words, action, obs_out, bits_out, r, d, disc, rer, rel, ts):
         out = _lib.StepOut(obs=_lib.ptr(obs_out), obs_bits=_lib.ptr(bits_out), reward=_lib.ptr(r), done=_lib.ptr(d),
@@ -225,6 +272,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         theta = network.init(K_init) if theta is None else theta.to(dev, torch.float32).clone()
         if packed:
             policy = _FusedCnnPolicy(network, theta, config, lr_steps, grad_hook, B)
+        elif backend == "fused":
+            policy = _FusedMlpPolicy(network, theta, config, lr_steps, grad_hook, B)
         else:
             policy = _TorchPolicy(network, theta, config, lr_steps, grad_hook)
         counters = {"timesteps": 0, "n_updates": 0, "grad_steps": 0}

@@ -208,3 +208,108 @@ class UpdateDriver:
                     self.graph_error = repr(exc)
                     torch.cuda.synchronize()
         self.calls += 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fused MLP Q-network (csrc/pqn_mlp.hip)
+# ---------------------------------------------------------------------------------------------------------
+class MlpLayoutStruct(C.Structure):
+    """pqn_mlp_layout_t"""
+    _fields_ = [("d", C.c_int32), ("h", C.c_int32), ("layers", C.c_int32), ("a", C.c_int32), ("off_bn", C.c_int32),
+                ("off_w", C.c_int32 * 4), ("off_b", C.c_int32 * 4), ("off_lns", C.c_int32 * 4),
+                ("off_lnb", C.c_int32 * 4), ("off_wout", C.c_int32), ("off_bout", C.c_int32), ("total", C.c_int32)]
+
+
+class MlpKernelLayout:
+    """flax-flat (networks.mlp_param_shapes order) <-> kernel layout (same order, 16-B aligned segments)."""
+
+    def __init__(self, obs_dim: int, hidden: int, layers: int, num_actions: int):
+        lib = _lib.load()
+        self.struct = MlpLayoutStruct()
+        _lib.check(lib.pqn_mlp_layout(obs_dim, hidden, layers, num_actions, C.byref(self.struct)), "pqn_mlp_layout")
+        s = self.struct
+        self.d, self.h, self.layers, self.a, self.total = int(s.d), int(s.h), int(s.layers), int(s.a), int(s.total)
+        parts = [s.off_bn + torch.arange(2 * self.d)]
+        ind = self.d
+        for l in range(self.layers):
+            parts += [s.off_w[l] + torch.arange(ind * self.h), s.off_b[l] + torch.arange(self.h),
+                      s.off_lns[l] + torch.arange(self.h), s.off_lnb[l] + torch.arange(self.h)]
+            ind = self.h
+        parts += [s.off_wout + torch.arange(self.h * self.a), s.off_bout + torch.arange(self.a)]
+        self.kidx = torch.cat(parts).to(torch.int64)
+        self.num_flax = int(self.kidx.numel())
+
+    def to_kernel(self, theta_flax: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros(self.total, dtype=torch.float32, device=theta_flax.device)
+        out[self.kidx.to(theta_flax.device)] = theta_flax.to(torch.float32)
+        return out
+
+    def to_flax(self, theta_k: torch.Tensor) -> torch.Tensor:
+        return theta_k[self.kidx.to(theta_k.device)]
+
+
+def mlp_forward(layout: MlpKernelLayout, obs: torch.Tensor, theta_k: torch.Tensor, *, want_q: bool = True,
+                eps: Optional[float] = None, key: int = 0, q=None, action=None, qmax=None):
+    lib = _lib.load()
+    n = obs.shape[0]
+    dev = obs.device
+    if want_q and q is None:
+        q = torch.empty((n, layout.a), dtype=torch.float32, device=dev)
+    if eps is not None and action is None:
+        action = torch.empty(n, dtype=torch.int32, device=dev)
+    if (eps is not None or not want_q) and qmax is None:
+        qmax = torch.empty(n, dtype=torch.float32, device=dev)
+    _lib.check(lib.pqn_mlp_forward(C.byref(layout.struct), n, _lib.ptr(obs), _lib.ptr(theta_k), _lib.ptr(q),
+                                   _lib.ptr(action), _lib.ptr(qmax), float(eps or 0.0), key, _lib.stream_ptr()),
+               "pqn_mlp_forward")
+    return q, action, qmax
+
+
+class MlpTrainer:
+    """Parameters + RAdam state of one seed for the fused MLP; same interface as CnnTrainer."""
+
+    def __init__(self, layout: MlpKernelLayout, theta_flax: torch.Tensor, lr: float, max_grad_norm: float,
+                 lr_decay_steps: float = 0.0, lr_end: float = 1e-20, max_minibatch: int = 128):
+        lib = _lib.load()
+        dev = theta_flax.device
+        self.layout = layout
+        self.theta = layout.to_kernel(theta_flax)
+        self.wt = torch.zeros(max(layout.layers - 1, 1) * layout.h * layout.h, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.theta)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.lr, self.lr_end, self.lr_steps, self.max_norm = float(lr), float(lr_end), float(lr_decay_steps), float(max_grad_norm)
+        self._ws_nb, self.ws = 0, None
+        self._ensure_ws(max_minibatch)
+        _lib.check(lib.pqn_mlp_refresh_transposed(C.byref(layout.struct), _lib.ptr(self.theta), _lib.ptr(self.wt),
+                                                  _lib.stream_ptr()), "pqn_mlp_refresh_transposed")
+
+    def _ensure_ws(self, nb: int):
+        if nb > self._ws_nb:
+            n = int(_lib.load().pqn_mlp_workspace_floats(C.byref(self.layout.struct), nb))
+            self.ws = torch.empty(n, dtype=torch.float32, device=self.theta.device)
+            self._ws_nb = nb
+
+    def compute_grad(self, idx, obs, action, target, loss_out=None, qv_out=None):
+        lib = _lib.load()
+        nb = idx.numel()
+        self._ensure_ws(nb)
+        assert idx.dtype == torch.int64 and action.dtype == torch.int32 and obs.dtype == torch.float32
+        _lib.check(lib.pqn_mlp_grad(C.byref(self.layout.struct), nb, _lib.ptr(idx), _lib.ptr(obs), _lib.ptr(action),
+                                    _lib.ptr(target), _lib.ptr(self.theta), _lib.ptr(self.wt), _lib.ptr(self.grad),
+                                    _lib.ptr(self.count), _lib.ptr(self.ws), _lib.ptr(loss_out), _lib.ptr(qv_out),
+                                    _lib.stream_ptr()), "pqn_mlp_grad")
+        return self.grad
+
+    def apply(self, recompute_norm: bool = False):
+        lib = _lib.load()
+        _lib.check(lib.pqn_mlp_apply(C.byref(self.layout.struct), _lib.ptr(self.theta), _lib.ptr(self.wt),
+                                     _lib.ptr(self.grad), _lib.ptr(self.m), _lib.ptr(self.v), _lib.ptr(self.count),
+                                     self.lr, self.lr_end, self.lr_steps, self.max_norm, _lib.ptr(self.ws),
+                                     _lib.ptr(self.gnorm), 1 if recompute_norm else 0, _lib.stream_ptr()),
+                   "pqn_mlp_apply")
+
+    def theta_flax(self) -> torch.Tensor:
+        return self.layout.to_flax(self.theta)

@@ -283,6 +283,8 @@ def test_product_network_vs_oracle_network(gpu, oracle):
     ("pqn_minatar", "Freeway-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
     ("pqn_minatar", "SpaceInvaders-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
     ("pqn_cartpole", "CartPole-v1", {"NUM_ENVS": 4, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
+    ("pqn_cartpole", "CartPole-v1", {"NUM_ENVS": 4, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
+                                     "_BACKEND": "torch"}),
 ])
 def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     """Whole loop (rollout + Q(lambda) + minibatch updates) vs the oracle loop from the same
@@ -314,9 +316,9 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     theta0 = net.init(123)
     cfg["_INIT_PARAMS"] = theta0
     train = make_train(cfg, device="cuda:0")
-    assert train.backend == extra.get("_BACKEND", "fused" if kind == "cnn" else "torch")
+    assert train.backend == extra.get("_BACKEND", "fused")
     out = train(key)
-    if train.backend == "fused" and extra.get("_DRIVER", True):
+    if train.backend == "fused" and kind == "cnn" and extra.get("_DRIVER", True):
         want = "eager" if extra.get("_GRAPH", True) is False else "graph"
         assert out["runner_state"]["driver"] == want, out["runner_state"]["driver_graph_error"]
     oout = otrain(key, _np(theta0))

@@ -110,3 +110,48 @@ def test_cnn_grad_vs_oracle(gpu, oracle, c, a, nb, pool):
     o = np.arange(128)[None, :]
     addr = (((o // 16) * 64 + i // 16) * 64 + ((o % 16) // 4) * 16 + (i % 16)) * 4 + (o % 4)
     np.testing.assert_array_equal(_np(tr.w1b)[addr], w1)
+
+
+@pytest.mark.parametrize("d,h,layers,a,n", [(4, 256, 2, 2, 16), (4, 256, 2, 2, 128), (6, 64, 1, 3, 37), (4, 128, 3, 2, 100)])
+def test_mlp_forward_and_grad_vs_oracle(gpu, oracle, d, h, layers, a, n):
+    """Fused MLP kernels (pqn_gymnax.py:29-58) vs the oracle's numpy network: forward 1e-4/2e-5,
+    gradients rtol 2e-3 + 3e-6*max|g|, post-step parameters 1e-5."""
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import MlpKernelLayout, MlpTrainer, mlp_forward
+    rng = np.random.default_rng(d * 100 + n)
+    net = QNetwork("mlp", (d,), a, hidden_size=h, num_layers=layers, device=gpu)
+    lay = MlpKernelLayout(d, h, layers, a)
+    assert lay.num_flax == net.num_params
+    theta = net.init(2) + 0.05 * torch.randn(net.num_params, device=gpu)
+    tr = MlpTrainer(lay, theta, 1e-4, 10.0, lr_decay_steps=500.0, max_minibatch=n)
+    torch.testing.assert_close(tr.theta_flax(), theta, rtol=0, atol=0)
+    pool = 3 * n
+    obs = rng.standard_normal((pool, d)).astype(np.float32)
+    obs_t = torch.from_numpy(obs).to(gpu)
+    shapes = oracle.mlp_shapes(d, a, h, layers)
+    p = oracle.unflatten(_np(theta), shapes)
+    q, action, qmax = mlp_forward(lay, obs_t, tr.theta, eps=0.3, key=5)
+    q_ref = oracle.net_forward("mlp", p, obs, layers=layers)
+    np.testing.assert_allclose(_np(q), q_ref, rtol=1e-4, atol=2e-5)
+    oa, oq = oracle.eps_greedy(_np(q), 0.3, key=5)
+    np.testing.assert_array_equal(_np(action), oa)
+    np.testing.assert_array_equal(_np(qmax), oq)
+    act = rng.integers(0, a, pool).astype(np.int32)
+    tgt = rng.standard_normal(pool).astype(np.float32)
+    idx = rng.permutation(pool)[:n]
+    loss_t, qv_t = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+    args = (torch.from_numpy(idx.astype(np.int64)).to(gpu), obs_t, torch.from_numpy(act).to(gpu), torch.from_numpy(tgt).to(gpu))
+    g = tr.compute_grad(*args, loss_t, qv_t)
+    lo, chosen, g_ref = oracle.net_loss_grad("mlp", p, shapes, obs[idx], act[idx], tgt[idx], layers=layers)
+    assert abs(float(loss_t) - lo) <= 1e-4 * max(1.0, abs(lo)) and abs(float(qv_t) - chosen.mean()) <= 1e-4
+    np.testing.assert_allclose(_np(lay.to_flax(g)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
+    th, m, v = _np(theta).copy(), np.zeros(net.num_params, np.float32), np.zeros(net.num_params, np.float32)
+    for step in range(3):
+        g_flax = _np(lay.to_flax(tr.compute_grad(*args)))
+        tr.apply()
+        lr = oracle.linear_schedule(1e-4, 1e-20, 500.0, step)
+        oracle.radam_clip_step(th, g_flax, m, v, step, np.float32(lr), 10.0)
+        np.testing.assert_allclose(_np(tr.theta_flax()), th, rtol=1e-5, atol=1e-7)
+    if layers > 1:   # transposed hidden kernels track theta
+        w1 = _np(tr.theta)[lay.struct.off_w[1]:lay.struct.off_w[1] + h * h].reshape(h, h)
+        np.testing.assert_array_equal(_np(tr.wt)[:h * h].reshape(h, h), w1.T)
