@@ -220,26 +220,47 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
   const bool rect = s_sc[4] != 0.0f;
   const float r = s_sc[5], lr = s_sc[6];
   const float c1 = (float)(1.0 - 0.9), d1 = (float)0.9, c2 = (float)(1.0 - 0.999), d2 = (float)0.999;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float gi = g[i];
+  auto step1 = [&](float gi, float &mi, float &vi, float pi) -> float {
     if (clip) gi = (gi / gnorm) * max_norm;
-    const float mi = c1 * gi + d1 * m[i];
-    const float vi = c2 * (gi * gi) + d2 * v[i];
-    m[i] = mi;
-    v[i] = vi;
+    mi = c1 * gi + d1 * mi;
+    vi = c2 * (gi * gi) + d2 * vi;
     const float mh = mi / bc1;
     const float vh = vi / bc2;
     const float u = rect ? r * mh / (sqrtf(vh) + 1e-8f) : mh;
-    const float pn = p[i] - lr * u;
-    p[i] = pn;
-    if (w1b) {  // keep the dgrad-fragment copy of the CNN fc1 kernel in step (see pqn_qnet.hip)
-      const int64_t j = i - w1_off;
-      if (j >= 0 && j < 1024 * 128) {
-        const int frag = (int)(j >> 8), ln = (int)(j >> 2) & 63, sx = (int)j & 3;
-        const int gi = frag >> 3, cb = frag & 7, kk = ln >> 4, jj = ln & 15;
-        w1b[(((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3)] = pn;
-      }
+    return pi - lr * u;
+  };
+  auto mirror = [&](int64_t i, float pn) {  // keep the dgrad-fragment copy of the CNN fc1 kernel in step
+    const int64_t j = i - w1_off;
+    if (j >= 0 && j < 1024 * 128) {
+      const int frag = (int)(j >> 8), ln = (int)(j >> 2) & 63, sx = (int)j & 3;
+      const int gi = frag >> 3, cb = frag & 7, kk = ln >> 4, jj = ln & 15;
+      w1b[(((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3)] = pn;
     }
+  };
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t n4 = ((n & 3) == 0 && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0)) ? n / 4 : 0;
+  for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (int64_t)gridDim.x * 256) {
+    const f4 g4 = reinterpret_cast<const f4 *>(g)[i4];
+    const f4 m4 = reinterpret_cast<f4 *>(m)[i4], v4 = reinterpret_cast<f4 *>(v)[i4], p4 = reinterpret_cast<f4 *>(p)[i4];
+    const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
+    float ma[4] = {m4.x, m4.y, m4.z, m4.w}, va[4] = {v4.x, v4.y, v4.z, v4.w}, pa[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pa[c] = step1(ga[c], ma[c], va[c], pa[c]);
+    reinterpret_cast<f4 *>(m)[i4] = f4{ma[0], ma[1], ma[2], ma[3]};
+    reinterpret_cast<f4 *>(v)[i4] = f4{va[0], va[1], va[2], va[3]};
+    reinterpret_cast<f4 *>(p)[i4] = f4{pa[0], pa[1], pa[2], pa[3]};
+    if (w1b) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mirror(4 * i4 + c, pa[c]);
+    }
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float mi = m[i], vi = v[i];
+    const float pn = step1(g[i], mi, vi, p[i]);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pn;
+    if (w1b) mirror(i, pn);
   }
 }
 

@@ -12,7 +12,7 @@ import sqlite3, glob, json, os
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     db = sqlite3.connect(glob.glob(f'/tmp/pmc_{c}/*results.db')[0])
-    for kern in ("qnet_cnn_train_kernel", "qnet_cnn_wgrad_kernel", "qnet_grad_reduce_kernel", "radam_apply_kernel"):
+    for kern in ("qnet_cnn_train_kernel", "qnet_fc1_wgrad_kernel", "qnet_grad_reduce_kernel", "radam_apply_kernel"):
         v = db.execute("select avg(counter_value), count(*) from pmc_events where name like ? and counter_name = ?", ('%'+kern+'%', c)).fetchone()
         out.setdefault(kern, {})[c + "_KB_avg"] = v[0]
         out[kern]["launches"] = v[1]
