@@ -196,7 +196,7 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid) {
   const float bias = bc[lane & 15];
   float *stg = s.stg + wave * 64 * QN_STG;
   uint32_t *wm = reinterpret_cast<uint32_t *>(s.z) + wave * 192;   // z tile is not live yet
-#pragma unroll 1
+#pragma unroll
   for (int mm = 0; mm < QN_SPW; ++mm) {
     const int m = QN_SPW * wave + mm;
     conv_sample_to_stage<C>(cv, s.bits + m * Cfg::OW, wm, stg, bias, lane);
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     float *stg = s.stg + wave * 64 * QN_STG;
     uint32_t *wm = reinterpret_cast<uint32_t *>(s.z) + wave * 192;   // dz tile is dead after the dgrad
     float gsc = 0.f, gbi = 0.f, gbc = 0.f;
-#pragma unroll 1
+#pragma unroll
     for (int mm = 0; mm < QN_SPW; ++mm) {
       const int msamp = QN_SPW * wave + mm;
       float *gt = s.h1 + msamp * QN_H1S;                 // d relu-input tile (masked by h1 > 0) -> dx in place

@@ -54,6 +54,14 @@ def test_vmap_train_seeds_are_independent_and_stacked(gpu):
     again = make_train(dict(cfg), device="cuda:0")(keys[1])    # same seed -> bit-identical rerun (deterministic kernels)
     torch.testing.assert_close(again["metrics"]["td_loss"], m[1], rtol=0, atol=0)
     torch.testing.assert_close(again["runner_state"]["theta"], outs["runner_state"][1]["theta"], rtol=0, atol=0)
+    # seeds on concurrent HIP streams (the default) == seeds one after another, eval included
+    cfg_t = _cfg(TEST_DURING_TRAINING=True, TEST_NUM_ENVS=8)
+    conc = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys)
+    seq = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys, concurrent=False)
+    for k in conc["metrics"]:
+        torch.testing.assert_close(conc["metrics"][k], seq["metrics"][k], rtol=0, atol=0, equal_nan=True)
+    for a, b in zip(conc["runner_state"], seq["runner_state"]):
+        torch.testing.assert_close(a["theta"], b["theta"], rtol=0, atol=0)
 
 
 def test_single_run_saves_reference_format_checkpoints(gpu, tmp_path):
