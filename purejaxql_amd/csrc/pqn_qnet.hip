@@ -23,6 +23,8 @@
 // gradient, moments and parameters share one layout and RAdam stays elementwise.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pqn_common.h"
 #include "pqn_env_rules.h"
 
@@ -102,6 +104,11 @@ PQN_D void window_masks(const uint32_t *row_bits, uint32_t *wm, int pos) {
   }
 }
 
+// bit `sh` of w ? 1/255 : 0 in two VALU ops: v_bfe_i32 (1-bit signed field = 0 / ~0) and v_and_b32
+PQN_D float bit_times_inv255(uint32_t w, int sh) {
+  return __int_as_float(__builtin_amdgcn_sbfe((int)w, (uint32_t)sh, 1u) & __float_as_int(1.0f / 255.0f));
+}
+
 template <int C>
 struct ConvMfma {
   static constexpr int NS = (9 * C + 3) / 4;
@@ -122,7 +129,7 @@ struct ConvMfma {
   PQN_D float a_of(const uint32_t (&m)[3], int s) const {
     // for C = 4 (RB = 12) the row index is the same for all four kk of a step: compile-time select
     const uint32_t w = (RB % 4 == 0) ? m[(4 * s) / RB] : (kyS[s] == 0 ? m[0] : (kyS[s] == 1 ? m[1] : m[2]));
-    return ((w >> shS[s]) & 1u) ? (1.0f / 255.0f) : 0.0f;
+    return bit_times_inv255(w, shS[s]);
   }
   // two tiles at once (independent accumulators hide the 40-cycle MFMA dependency); pA / pB = the
   // point (row of the window-mask table) this lane's A row stands for in each tile
@@ -244,32 +251,41 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) 
   for (int i = 0; i < PF; ++i)
 #pragma unroll
     for (int c = 0; c < CBW; ++c) b[i][c] = wp[(((i + rot) & 63) * 8 + cb0 + c) * 64 + lane];
-#pragma unroll 1
-  for (int g = 0; g < QN_H1 / 16; g += PF) {
+  // the last PF groups are peeled (no prefetch): a conditional prefetch inside the loop makes the
+  // compiler's vmcnt bookkeeping assume it was not issued and drain the ring once per iteration
+  f32x4 a_next = *reinterpret_cast<const f32x4 *>(arow + 16 * (rot & 63));
+  auto group_block = [&](int g, auto more_t) {
+    constexpr bool more = decltype(more_t)::value;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + rot) & 63));
-      f32x4 x[CBW];
+      const f32x4 a = a_next;   // A fragment one group ahead: its LDS latency hides behind the previous group's MFMAs
+      a_next = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 1 + rot) & 63));
+      __builtin_amdgcn_sched_barrier(0);   // the read goes out before this group's MFMAs, not after them
+      if (ABL == 3) {
 #pragma unroll
-      for (int c = 0; c < CBW; ++c) x[c] = b[i][c];
-      if (ABL != 2 && g + i + PF < QN_H1 / 16) {
+        for (int c = 0; c < CBW; ++c) acc[c] += b[i][c] + a;
+      } else {
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[i][c].x, acc[c], 0, 0, 0);
+          acc2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[i][c].y, acc2[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[i][c].z, acc[c], 0, 0, 0);
+          acc2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[i][c].w, acc2[c], 0, 0, 0);
+        }
+      }
+      // reload the ring slot in place, AFTER its consumers were issued: the loop-carried registers are then
+      // the load destinations themselves (no copies that would have to wait for the data), and every wait
+      // is exactly vmcnt(PF-1).  The scheduling barrier pins the reload to its group.
+      if (ABL != 2 && more) {
 #pragma unroll
         for (int c = 0; c < CBW; ++c) b[i][c] = wp[(((g + i + PF + rot) & 63) * 8 + cb0 + c) * 64 + lane];
       }
-      if (ABL == 3) {
-#pragma unroll
-        for (int c = 0; c < CBW; ++c) acc[c] += x[c] + a;
-        continue;
-      }
-#pragma unroll
-      for (int c = 0; c < CBW; ++c) {
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[c].x, acc[c], 0, 0, 0);
-        acc2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[c].y, acc2[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[c].z, acc[c], 0, 0, 0);
-        acc2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[c].w, acc2[c], 0, 0, 0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-  }
+  };
+#pragma unroll 1
+  for (int g = 0; g < QN_H1 / 16 - PF; g += PF) group_block(g, std::true_type{});
+  group_block(QN_H1 / 16 - PF, std::false_type{});
 #pragma unroll
   for (int c = 0; c < CBW; ++c) acc[c] += acc2[c];
   const int col = lane & 15, r0 = 4 * (lane >> 4);
@@ -706,50 +722,47 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     for (int g = 0; g < 8; ++g)
       afr[g] = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 16 * g + 4 * (lane >> 4));
     const int col = lane & 15, r0 = 4 * (lane >> 4);
-    constexpr int IPW = 64 / QN_WAVES / 2;   // pairs of i-blocks (16 conv features each) per wave
-    const int ib_first = 2 * IPW * wave;
-    const int prot = blockIdx.x & (IPW - 1);  // de-phase the W1 stream across workgroups (see phase2_fc1)
-    f32x4 buf[2][2][8];                       // [parity][block of the pair][k group]
+    constexpr int IBW = 64 / QN_WAVES;        // i-blocks (16 conv features each) per wave
+    constexpr int PF = 16;                    // fragments in flight: a rolling ring, one reload per 4 MFMAs
+    const int ib_first = IBW * wave;
+    const int prot = blockIdx.x & (IBW - 1);  // de-phase the W1 stream across workgroups (see phase2_fc1)
+    auto frag = [&](int n) { return wb[((n & 7) * 64 + ib_first + (((n >> 3) + prot) & (IBW - 1))) * 64 + lane]; };
+    f32x4 ring[PF];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      buf[0][0][g] = wb[(g * 64 + ib_first + 2 * prot) * 64 + lane];
-      buf[0][1][g] = wb[(g * 64 + ib_first + 2 * prot + 1) * 64 + lane];
-    }
+    for (int n = 0; n < PF; ++n) ring[n] = frag(n);
+    // a real loop over pairs of i-blocks (ring index = position inside the pair): fully unrolled, the
+    // scheduler sinks the prefetches next to their uses and the ring degenerates to distance 1
+    // (the last pair is peeled: a conditional prefetch inside the loop makes the compiler's vmcnt
+    // bookkeeping assume it was not issued, draining the ring once per iteration)
+    auto pair_step = [&](int ip, auto more_t) {
+      constexpr bool more = decltype(more_t)::value;
 #pragma unroll
-    for (int ip = 0; ip < IPW; ++ip) {
-      const int ib = ib_first + 2 * ((ip + prot) & (IPW - 1));
-      if (ip + 1 < IPW) {
-        const int ibn = ib_first + 2 * ((ip + 1 + prot) & (IPW - 1));
+      for (int h = 0; h < 2; ++h) {
+        const int ib = ib_first + ((2 * ip + h + prot) & (IBW - 1));
+        // relu mask (h1 > 0), read ahead of the MFMAs; the h1 tile is overwritten in place with d(pre-relu)
+        float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
+        const float m0 = p0[0], m1 = p0[QN_H1S], m2 = p0[2 * QN_H1S], m3 = p0[3 * QN_H1S];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-          buf[(ip + 1) & 1][0][g] = wb[(g * 64 + ibn) * 64 + lane];
-          buf[(ip + 1) & 1][1][g] = wb[(g * 64 + ibn + 1) * 64 + lane];
+          const f32x4 c = ring[8 * h + g];
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].x, c.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].y, c.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].z, c.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].w, c.w, acc1, 0, 0, 0);
+          if (more) ring[8 * h + g] = frag(16 * (ip + 1) + 8 * h + g);   // in-place reload after its consumers (see phase2_fc1)
+          __builtin_amdgcn_sched_barrier(0);
         }
+        acc0 += acc1;
+        p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
+        p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
+        p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
+        p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
       }
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const f32x4 c0 = buf[ip & 1][0][g], c1 = buf[ip & 1][1][g];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].x, c0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].x, c1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].y, c0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].y, c1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].z, c0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].z, c1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].w, c0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g].w, c1.w, acc1, 0, 0, 0);
-      }
-      // relu mask (h1 > 0) and in-place overwrite of the h1 tile with d(pre-relu)
-      float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
-      p0[0] = p0[0] > 0.0f ? acc0.x : 0.0f;
-      p0[QN_H1S] = p0[QN_H1S] > 0.0f ? acc0.y : 0.0f;
-      p0[2 * QN_H1S] = p0[2 * QN_H1S] > 0.0f ? acc0.z : 0.0f;
-      p0[3 * QN_H1S] = p0[3 * QN_H1S] > 0.0f ? acc0.w : 0.0f;
-      p0[16] = p0[16] > 0.0f ? acc1.x : 0.0f;
-      p0[QN_H1S + 16] = p0[QN_H1S + 16] > 0.0f ? acc1.y : 0.0f;
-      p0[2 * QN_H1S + 16] = p0[2 * QN_H1S + 16] > 0.0f ? acc1.z : 0.0f;
-      p0[3 * QN_H1S + 16] = p0[3 * QN_H1S + 16] > 0.0f ? acc1.w : 0.0f;
-    }
+    };
+#pragma unroll 1
+    for (int ip = 0; ip < IBW / 2 - 1; ++ip) pair_step(ip, std::true_type{});
+    pair_step(IBW / 2 - 1, std::false_type{});
   }
   __syncthreads();
   T1_STAMP(5);
@@ -829,58 +842,61 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   //   wave w reduces its samples 4w..4w+3; the 4 wave partials are folded in fixed order.
   if (!(ablate & 4)) {
     constexpr int NRB = (9 * C + 15) / 16;   // 16-row blocks of k
-    constexpr int RBH = (NRB + 1) / 2;       // row blocks per wave half
     constexpr int RB = 3 * C;
-    // wave = (sample quad sq, row-block half rh): samples 4sq..4sq+3, row blocks rh*RBH ..
-    const int sq = wave & 3, rh = wave >> 2;
+    // NRB odd (C = 4): wave = sample pair, all row blocks (no padded block);  NRB even: wave = (sample quad,
+    // half of the row blocks).  NPART wave partials per row block are folded in fixed order.
+    constexpr bool PAIR = (NRB % 2) == 1;
+    constexpr int RBW = PAIR ? NRB : NRB / 2;      // row blocks per wave
+    constexpr int SPW6 = PAIR ? 2 : 4;             // samples per wave
+    constexpr int NPART = QN_TILE / SPW6;
+    static_assert(NPART * NRB * 256 <= TrainCfg<C>::SCR, "conv-wgrad partials must fit the scratch tile");
+    const int sg = PAIR ? wave : (wave & 3), rb0 = PAIR ? 0 : (wave >> 2) * RBW;
     const int i = lane & 15, kk = lane >> 4;
-    int kyL[RBH], shL[RBH];                  // lane constants: window row / bit of k = 16*rb + i (-1: padding row)
+    int kyL[RBW], shL[RBW];                  // lane constants: window row / bit of k = 16*rb + i
 #pragma unroll
-    for (int j = 0; j < RBH; ++j) {
-      const int k = 16 * (rh * RBH + j) + i;
-      kyL[j] = (k < 9 * C) ? k / RB : -1;
-      shL[j] = (k < 9 * C) ? k % RB : 0;
+    for (int j = 0; j < RBW; ++j) {
+      const int k = 16 * (rb0 + j) + i;
+      kyL[j] = (k < 9 * C) ? k / RB : 0;
+      shL[j] = (k < 9 * C) ? k % RB : 31;    // padding rows test bit 31, which no window mask has (3C <= 30)
     }
-    f32x4 acc[RBH];
+    f32x4 acc[RBW];
 #pragma unroll
-    for (int j = 0; j < RBH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float inv255 = 1.0f / 255.0f;
+    for (int j = 0; j < RBW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     uint32_t *wm = reinterpret_cast<uint32_t *>(s.stg + wave * 64 * QN_STG);   // staging buffer is free now
 #pragma unroll 1
-    for (int mm = 0; mm < 4; ++mm) {
-      const int msamp = 4 * sq + mm;
+    for (int mm = 0; mm < SPW6; ++mm) {
+      const int msamp = SPW6 * sg + mm;
       window_masks<C>(s.bits + msamp * Cfg::OW, wm, lane);
       const float *dxm = s.h1 + msamp * QN_H1S + lane;   // + 64*st : element (pos = 4st+kk, o = lane&15)
       float bv[16];
-      uint32_t wv[16][RBH];
+      uint32_t wv[16][RBW];
 #pragma unroll
       for (int st = 0; st < 16; ++st) {          // all LDS reads of the sample in flight at once
         bv[st] = dxm[64 * st];
 #pragma unroll
-        for (int j = 0; j < RBH; ++j) wv[st][j] = wm[(4 * st + kk) * 3 + max(kyL[j], 0)];
+        for (int j = 0; j < RBW; ++j) wv[st][j] = wm[(4 * st + kk) * 3 + kyL[j]];
       }
 #pragma unroll
       for (int st = 0; st < 16; ++st) {
 #pragma unroll
-        for (int j = 0; j < RBH; ++j) {
-          const float a = (kyL[j] >= 0 && ((wv[st][j] >> shL[j]) & 1u)) ? inv255 : 0.0f;
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[st], acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < RBW; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bit_times_inv255(wv[st][j], shL[j]), bv[st], acc[j], 0, 0, 0);
       }
     }
-    float *part = ts.scr;  // [sq][row block][16 rows][16 o]
+    float *part = ts.scr;  // [sample group][row block][16 rows][16 o]
 #pragma unroll
-    for (int j = 0; j < RBH; ++j) {
-      const int rb = rh * RBH + j;
-      if (rb < NRB) {
-        float *pp = part + ((sq * NRB + rb) * 16 + 4 * kk) * 16 + i;
-        pp[0] = acc[j].x; pp[16] = acc[j].y; pp[32] = acc[j].z; pp[48] = acc[j].w;
-      }
+    for (int j = 0; j < RBW; ++j) {
+      float *pp = part + ((sg * NRB + rb0 + j) * 16 + 4 * kk) * 16 + i;
+      pp[0] = acc[j].x; pp[16] = acc[j].y; pp[32] = acc[j].z; pp[48] = acc[j].w;
     }
     __syncthreads();
     for (int e = tid; e < Cfg::KW * 16; e += QN_THREADS) {
       const float *pp = ts.scr + e;   // e = k*16 + o = (rb*16 + row)*16 + o
-      gp[e] = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
+      if (NPART == 8)
+        gp[e] = ((pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256])) +
+                ((pp[4 * NRB * 256] + pp[5 * NRB * 256]) + (pp[6 * NRB * 256] + pp[7 * NRB * 256]));
+      else
+        gp[e] = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
     }
   }
   T1_STAMP(7);
