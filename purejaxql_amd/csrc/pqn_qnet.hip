@@ -556,6 +556,7 @@ struct TrainSmem {
   CnnSmem n;
   float *scr;        // 3 x [16][QN_ZS] tiles, later [KW][4][16] conv-wgrad partials
   float *gs;         // [16] per-sample loss gradient g_m = (q_a - target)/B
+  float *tgt;        // [16] per-sample target (gathered at kernel start, consumed by the head)
   int *act;          // [16]
   float *red;        // [QN_WAVES][48] cross-wave reduction of conv bias / ln0 grads
 };
@@ -568,14 +569,146 @@ PQN_D TrainSmem carve_train_smem(char *base) {
   uint32_t *after_bits = t.n.bits + QN_TILE * Cfg::OW + 4;
   t.scr = reinterpret_cast<float *>(after_bits);
   t.gs = t.scr + TrainCfg<C>::SCR;
-  t.act = reinterpret_cast<int *>(t.gs + QN_TILE);
+  t.tgt = t.gs + QN_TILE;
+  t.act = reinterpret_cast<int *>(t.tgt + QN_TILE);
   t.red = reinterpret_cast<float *>(t.act + QN_TILE);
   return t;
 }
 
 template <int C>
 constexpr size_t train_smem_bytes() {
-  return cnn_smem_bytes<C>() + sizeof(float) * (TrainCfg<C>::SCR + 2 * QN_TILE + QN_WAVES * 48 + 4);
+  return cnn_smem_bytes<C>() + sizeof(float) * (TrainCfg<C>::SCR + 3 * QN_TILE + QN_WAVES * 48 + 4);
+}
+
+// all-reduce sum over each aligned group of 32 lanes: DPP butterfly inside the 16-lane rows, then one
+// ds_swizzle (xor 16) across the two rows
+PQN_D float group32_sum(float v) {
+  v = group16_sum(v);
+  return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
+
+// Head of the training kernel.  Forward: z + b1 -> LN(128) -> relu -> fc2 -> q_a -> loss
+// (pqn_minatar.py:271-285); backward through fc2 / relu / LN1 to dz (left in s.z for the dgrad and
+// written transposed for the fc1 weight-gradient GEMM).  32 lanes per sample (all 8 waves): lane
+// `sub` owns features o = sub + 32 r.  The sums over the 16 samples of the tile (d b1, d ln1 scale,
+// d ln1 bias = column sums; d w2 = h2^T x G, G[m][a] = [act_m == a] g_m; d b2 = column sums of G)
+// are MFMAs on the staged tiles -- an all-ones A operand turns a column sum into one 16x16x4 chain.
+// NA: compile-time action count (0 = run-time L.a, up to QN_MAXA).
+template <int C, int NA>
+PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layout_t &L, int tid, int nb, int b0,
+                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT) {
+  constexpr int NAQ = NA ? NA : QN_MAXA;
+  const int na = NA ? NA : L.a;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int m = tid >> 5, sub = tid & 31;
+  float *tA = ts.scr, *tB = ts.scr + QN_TILE * QN_ZS, *tH = ts.scr + 2 * QN_TILE * QN_ZS;
+  float *zrow = s.z + m * QN_ZS;
+  float v[4], xh[4], h2[4];
+  float sum = 0.f, sq = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = sub + 32 * r;
+    v[r] = zrow[o] + s.hp[o];
+    sum += v[r];
+    sq = fmaf(v[r], v[r], sq);
+  }
+  sum = group32_sum(sum);
+  sq = group32_sum(sq);
+  const float mean = sum * (1.0f / QN_HID);
+  const float var = fmaxf(sq * (1.0f / QN_HID) - mean * mean, 0.0f);
+  const float rstd = rsqrt_exact(var + QN_LN_EPS);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = sub + 32 * r;
+    xh[r] = (v[r] - mean) * rstd;
+    h2[r] = fmaxf(fmaf(xh[r], s.hp[128 + o], s.hp[256 + o]), 0.0f);
+  }
+  float qv[NAQ];
+#pragma unroll
+  for (int a = 0; a < NAQ; ++a) {
+    float part = 0.f;
+    if (a < na) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(h2[r], s.hp[384 + (sub + 32 * r) * na + a], part);
+    }
+    qv[a] = part;
+  }
+#pragma unroll
+  for (int a = 0; a < NAQ; ++a) qv[a] = group32_sum(qv[a]) + (a < na ? s.hp[384 + 128 * na + a] : 0.0f);
+  const bool valid = (b0 + m) < nb;
+  const int act = ts.act[m];
+  float chosen = qv[0];
+#pragma unroll
+  for (int a = 1; a < NAQ; ++a)
+    if (a == act) chosen = qv[a];
+  const float diff = valid ? (chosen - ts.tgt[m]) : 0.0f;
+  const float gm = diff * inv_b;  // d loss / d q_a, loss = 0.5*mean(diff^2)  (pqn_minatar.py:285)
+  // backward: fc2, relu, LN1.  Every lane reads and rewrites only its own elements of the z tile.
+  float dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = sub + 32 * r;
+    const float dh2 = gm * s.hp[384 + o * na + act];
+    const float dy = h2[r] > 0.0f ? dh2 : 0.0f;
+    tA[m * QN_ZS + o] = dy * xh[r];
+    tB[m * QN_ZS + o] = dy;
+    tH[m * QN_ZS + o] = h2[r];
+    dxh[r] = dy * s.hp[128 + o];
+    s1 += dxh[r];
+    s2 = fmaf(dxh[r], xh[r], s2);
+  }
+  s1 = group32_sum(s1) * (1.0f / QN_HID);
+  s2 = group32_sum(s2) * (1.0f / QN_HID);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) zrow[sub + 32 * r] = rstd * (dxh[r] - s1 - xh[r] * s2);
+  if (sub == 0) ts.gs[m] = gm;
+  {  // loss / chosen-q partials of the wave's two samples (metrics td_loss, qvals: pqn_minatar.py:334-335)
+    float l = (sub == 0) ? 0.5f * diff * diff : 0.0f, cq = (sub == 0 && valid) ? chosen : 0.0f;
+    l += __shfl_xor(l, 32, 64);
+    cq += __shfl_xor(cq, 32, 64);
+    if (lane == 0) { ts.red[wave * 48] = l; ts.red[wave * 48 + 1] = cq; }
+  }
+  __syncthreads();
+  // sums over the 16 samples as MFMA chains (K = 16 samples in 4 steps); wave w owns feature block 16w..16w+15
+  {
+    const int j = lane & 15, kk = lane >> 4;
+    const int o_b1 = 9 * C * 16 + 48;
+    f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, c3 = c1, cw = c1, cb = c1;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int mr = 4 * st + kk;
+      const int e = mr * QN_ZS + 16 * wave + j;
+      const float gB = (ts.act[mr] == j) ? ts.gs[mr] : 0.0f;   // G[m][a = j]
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, s.z[e], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, tA[e], c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, tB[e], c3, 0, 0, 0);
+      cw = __builtin_amdgcn_mfma_f32_16x16x4f32(tH[e], gB, cw, 0, 0, 0);   // A[i = o][k = m] = h2, B[k = m][j = a] = G
+      if (wave == 0) cb = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, gB, cb, 0, 0, 0);
+    }
+    if (lane < 16) {   // every row of an all-ones chain holds the column sums: row 0 = register x of lanes 0..15
+      gp[o_b1 + 16 * wave + lane] = c1.x;         // d b1
+      gp[o_b1 + 128 + 16 * wave + lane] = c2.x;   // d ln1 scale
+      gp[o_b1 + 256 + 16 * wave + lane] = c3.x;   // d ln1 bias
+    }
+    if (j < na) {      // d w2[o][a]: lane holds column a = j, rows o = 16w + 4kk + reg
+      float *gw = gp + o_b1 + 384 + (16 * wave + 4 * kk) * na + j;
+      gw[0] = cw.x; gw[na] = cw.y; gw[2 * na] = cw.z; gw[3 * na] = cw.w;
+    }
+    if (wave == 0 && lane < na) gp[o_b1 + 384 + 128 * na + lane] = cb.x;   // d b2
+  }
+  // dz^T for the weight-gradient GEMM: dzT[o][b0 + m], 16-B stores
+  for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
+    const int o = i >> 2, mq = i & 3;
+    const f32x4 vv = {s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], s.z[(4 * mq + 2) * QN_ZS + o],
+                      s.z[(4 * mq + 3) * QN_ZS + o]};
+    *reinterpret_cast<f32x4 *>(dzT + (size_t)o * qw_ld(nb) + b0 + 4 * mq) = vv;
+  }
+  if (tid == 0) {
+    const int o_l = 9 * C * 16 + 48 + 384 + 128 * na + na;
+    gp[o_l] = ((ts.red[0] + ts.red[48]) + (ts.red[96] + ts.red[144])) + ((ts.red[192] + ts.red[240]) + (ts.red[288] + ts.red[336]));
+    gp[o_l + 1] = ((ts.red[1] + ts.red[49]) + (ts.red[97] + ts.red[145])) + ((ts.red[193] + ts.red[241]) + (ts.red[289] + ts.red[337]));
+  }
+  __syncthreads();   // dz tile complete (dgrad reads it); ts.red / scratch free again
 }
 
 // profiling: per-phase s_memtime stamps of workgroup 0 / wave 0 (PQN_T1_STAMPS=1), read by tools/t1_stamps.py
@@ -604,6 +737,15 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     s.bits[i] = (b0 + le < nb) ? obs_bits[(size_t)(idx[b0 + le] & 0xFFFFFFFFll) * Cfg::OW + w] : 0u;
   }
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
+  // action / target of the tile's samples: a two-level gather (idx -> transition), issued now so its
+  // latency hides behind the forward pass; parked in LDS after fc1
+  int act_g = 0;
+  float tgt_g = 0.0f;
+  if (tid < QN_TILE && b0 + tid < nb) {
+    const int64_t src = idx[b0 + tid] & 0xFFFFFFFFll;
+    act_g = action[src];
+    tgt_g = target[src];
+  }
   __syncthreads();
   T1_STAMP(1);
   // ---- P1..P3: forward ---------------------------------------------------------------------
@@ -619,99 +761,19 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
     *reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq) = v;
   }
+  if (tid < QN_TILE) {
+    ts.act[tid] = act_g;
+    ts.tgt[tid] = tgt_g;
+  }
   __syncthreads();
   T1_STAMP(3);
-  // the head (LN1 / fc2 / loss) needs 16 lanes per sample: waves 0..3 only
-  const bool head = tid < 256;
-  const int m = (tid >> 4) & 15, sub = tid & 15;
-  float q[QN_MAXA], h2[8], xh[8], rstd1 = 0.f, chosen = 0.f, diff = 0.f, gm = 0.f;
-  int act = 0;
-  bool valid = false;
-  if (head) {
-    phase3_head(s, theta, L, tid, q, h2, xh, rstd1);
-    valid = (b0 + m) < nb;
-    const int64_t src = valid ? (idx[b0 + m] & 0xFFFFFFFFll) : 0;
-    act = valid ? action[src] : 0;
-    chosen = q[0];
-#pragma unroll
-    for (int a = 1; a < QN_MAXA; ++a)
-      if (a == act) chosen = q[a];
-    diff = valid ? (chosen - target[src]) : 0.0f;
-    gm = diff * inv_b;  // d loss / d q_a, loss = 0.5*mean(diff^2)  (pqn_minatar.py:285)
-    if (sub == 0) {
-      ts.gs[m] = gm;
-      ts.act[m] = act;
-    }
-  }
-  // ---- head backward: fc2, relu, LN1 ----------------------------------------------------------
-  float *tA = ts.scr, *tB = ts.scr + QN_TILE * QN_ZS, *tH = ts.scr + 2 * QN_TILE * QN_ZS;
-  __syncthreads();  // everyone is done reading s.z (phase 3) before it is overwritten with dz
-  if (head) {
-    float dxh[8], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int o = sub + 16 * r;
-      const float dh2 = gm * s.hp[384 + o * L.a + act];
-      const float dy = h2[r] > 0.0f ? dh2 : 0.0f;
-      tA[m * QN_ZS + o] = dy * xh[r];
-      tB[m * QN_ZS + o] = dy;
-      tH[m * QN_ZS + o] = h2[r];
-      dxh[r] = dy * s.hp[128 + o];
-      s1 += dxh[r];
-      s2 = fmaf(dxh[r], xh[r], s2);
-    }
-    s1 = group16_sum(s1) * (1.0f / QN_HID);
-    s2 = group16_sum(s2) * (1.0f / QN_HID);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) s.z[m * QN_ZS + sub + 16 * r] = rstd1 * (dxh[r] - s1 - xh[r] * s2);
-  }
-  __syncthreads();
-  // column sums over the 16 samples (fixed order -> deterministic)
-  {
-    const int o_b1 = 9 * C * 16 + 48;
-    if (tid < QN_HID) {
-      float a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-      for (int mm = 0; mm < QN_TILE; ++mm) {
-        a1 += s.z[mm * QN_ZS + tid];
-        a2 += tA[mm * QN_ZS + tid];
-        a3 += tB[mm * QN_ZS + tid];
-      }
-      gp[o_b1 + tid] = a1;              // d b1
-      gp[o_b1 + 128 + tid] = a2;        // d ln1 scale
-      gp[o_b1 + 256 + tid] = a3;        // d ln1 bias
-    } else if (tid < 2 * QN_HID) {
-      const int o = tid - QN_HID;       // d w2[o][a] = sum_m [act_m == a] g_m h2[m][o]
-      for (int a = 0; a < L.a; ++a) {
-        float acc = 0.f;
-#pragma unroll
-        for (int mm = 0; mm < QN_TILE; ++mm) acc += (ts.act[mm] == a) ? ts.gs[mm] * tH[mm * QN_ZS + o] : 0.0f;
-        gp[o_b1 + 384 + o * L.a + a] = acc;
-      }
-    }
-    if (tid >= 256 && tid < 256 + L.a) {
-      const int a = tid - 256;
-      float acc = 0.f;
-      for (int mm = 0; mm < QN_TILE; ++mm) acc += (ts.act[mm] == a) ? ts.gs[mm] : 0.0f;
-      gp[o_b1 + 384 + 128 * L.a + a] = acc;  // d b2
-    }
-    // loss / chosen-q partials (metrics td_loss, qvals: pqn_minatar.py:334-335)
-    float l = (head && sub == 0) ? 0.5f * diff * diff : 0.0f, cq = (head && sub == 0 && valid) ? chosen : 0.0f;
-    for (int off = 32; off > 0; off >>= 1) { l += __shfl_down(l, off, 64); cq += __shfl_down(cq, off, 64); }
-    if (lane == 0 && wave < 4) { ts.red[wave * 48] = l; ts.red[wave * 48 + 1] = cq; }
-  }
-  // dz^T for the weight-gradient GEMM: dzT[o][b0 + m], 16-B stores
-  for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
-    const int o = i >> 2, mq = i & 3;
-    const f32x4 v = {s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], s.z[(4 * mq + 2) * QN_ZS + o],
-                     s.z[(4 * mq + 3) * QN_ZS + o]};
-    *reinterpret_cast<f32x4 *>(dzT + (size_t)o * qw_ld(nb) + b0 + 4 * mq) = v;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const int o_l = 9 * C * 16 + 48 + 384 + 128 * L.a + L.a;
-    gp[o_l] = (ts.red[0] + ts.red[48]) + (ts.red[96] + ts.red[144]);
-    gp[o_l + 1] = (ts.red[1] + ts.red[49]) + (ts.red[97] + ts.red[145]);
+  // ---- head forward + backward (LN1 / fc2 / loss -> dz, parameter-gradient partials, dz^T) ----
+  switch (L.a) {
+    case 3: train_head<C, 3>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
+    case 4: train_head<C, 4>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
+    case 5: train_head<C, 5>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
+    case 6: train_head<C, 6>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
+    default: train_head<C, 0>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
   }
   T1_STAMP(4);
   // ---- P4: dgrad  dh1[m][i] = sum_o dz[m][o] W1[i][o]  (A = dz tile, B = W1 in dgrad fragment order) ----
