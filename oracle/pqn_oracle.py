@@ -193,29 +193,76 @@ def radam_clip_step(p, g, m, v, count, lr, max_norm):
 LN_EPS = np.float32(1e-6)
 
 
-def cnn_shapes(obs_shape, a):
+BN_EPS = np.float32(1e-5)      # flax nn.BatchNorm defaults (A.4): epsilon 1e-5, momentum 0.99
+BN_MOMENTUM = np.float32(0.99)
+
+
+def _norm_kind(norm_type):
+    return norm_type if norm_type in ("layer_norm", "batch_norm") else "none"    # pqn_minatar.py:31-36
+
+
+def cnn_norm_names(norm_type):
+    k = _norm_kind(norm_type)
+    if k == "layer_norm":
+        return "CNN_0/LayerNorm_0", "CNN_0/LayerNorm_1"
+    if k == "batch_norm":
+        return "CNN_0/BatchNorm_0", "CNN_0/BatchNorm_1"
+    return "", ""
+
+
+def mlp_norm_name(norm_type, l):
+    # BatchNorm_0 is the input / dummy BatchNorm (pqn_gymnax.py:39-43): hidden layers get BatchNorm_1..
+    k = _norm_kind(norm_type)
+    return f"LayerNorm_{l}" if k == "layer_norm" else (f"BatchNorm_{l + 1}" if k == "batch_norm" else "")
+
+
+def cnn_shapes(obs_shape, a, norm_type="layer_norm"):
     h, w, c = obs_shape
-    return OrderedDict([
-        ("BatchNorm_0/scale", (c,)), ("BatchNorm_0/bias", (c,)),
-        ("CNN_0/Conv_0/kernel", (3, 3, c, 16)), ("CNN_0/Conv_0/bias", (16,)),
-        ("CNN_0/LayerNorm_0/scale", (16,)), ("CNN_0/LayerNorm_0/bias", (16,)),
-        ("CNN_0/Dense_0/kernel", ((h - 2) * (w - 2) * 16, 128)), ("CNN_0/Dense_0/bias", (128,)),
-        ("CNN_0/LayerNorm_1/scale", (128,)), ("CNN_0/LayerNorm_1/bias", (128,)),
-        ("Dense_0/kernel", (128, a)), ("Dense_0/bias", (a,)),
-    ])
+    n0, n1 = cnn_norm_names(norm_type)
+    s = OrderedDict([("BatchNorm_0/scale", (c,)), ("BatchNorm_0/bias", (c,)),
+                     ("CNN_0/Conv_0/kernel", (3, 3, c, 16)), ("CNN_0/Conv_0/bias", (16,))])
+    if n0:
+        s[n0 + "/scale"], s[n0 + "/bias"] = (16,), (16,)
+    s["CNN_0/Dense_0/kernel"], s["CNN_0/Dense_0/bias"] = ((h - 2) * (w - 2) * 16, 128), (128,)
+    if n1:
+        s[n1 + "/scale"], s[n1 + "/bias"] = (128,), (128,)
+    s["Dense_0/kernel"], s["Dense_0/bias"] = (128, a), (a,)
+    return s
 
 
-def mlp_shapes(d, a, hidden, layers):
+def mlp_shapes(d, a, hidden, layers, norm_type="layer_norm"):
     s = OrderedDict([("BatchNorm_0/scale", (d,)), ("BatchNorm_0/bias", (d,))])
     for l in range(layers):
         s[f"Dense_{l}/kernel"] = (d, hidden)
         s[f"Dense_{l}/bias"] = (hidden,)
-        s[f"LayerNorm_{l}/scale"] = (hidden,)
-        s[f"LayerNorm_{l}/bias"] = (hidden,)
+        n = mlp_norm_name(norm_type, l)
+        if n:
+            s[n + "/scale"] = (hidden,)
+            s[n + "/bias"] = (hidden,)
         d = hidden
     s[f"Dense_{layers}/kernel"] = (d, a)
     s[f"Dense_{layers}/bias"] = (a,)
     return s
+
+
+def init_batch_stats(kind, obs_shape, hidden, layers, norm_type, norm_input):
+    """variables["batch_stats"]: running mean 0 / var 1 of every BatchNorm whose output is used (the
+    dummy input BatchNorm of NORM_INPUT=False, pqn_minatar.py:63-65, is dead state and not tracked)."""
+    feats = OrderedDict()
+    if norm_input:
+        feats["BatchNorm_0"] = int(obs_shape[-1])
+    if _norm_kind(norm_type) == "batch_norm":
+        if kind == "cnn":
+            n0, n1 = cnn_norm_names(norm_type)
+            feats[n0], feats[n1] = 16, 128
+        else:
+            for l in range(layers):
+                feats[mlp_norm_name(norm_type, l)] = hidden
+    st = OrderedDict()
+    for name, f in feats.items():
+        st[name + "/mean"] = np.zeros(f, np.float32)
+        st[name + "/var"] = np.ones(f, np.float32)
+    return st
 
 
 def unflatten(theta, shapes):
@@ -254,43 +301,100 @@ def _patches(x):
     return v.reshape(b, h - 2, w - 2, 9 * c)
 
 
-def net_forward(kind, p, x, use_ln=True, layers=2, want_cache=False):
-    """QNetwork.apply(train=False/True are identical for layer_norm).  x float32."""
+def _bn_fwd(x, scale, bias, name, train, stats, new_stats):
+    """flax nn.BatchNorm(use_running_average=not train) (A.4): moments over every axis but the last, fast
+    variance E[x^2]-E[x]^2 clamped at 0; running <- 0.99 running + 0.01 batch."""
+    f = x.shape[-1]
+    x2 = x.reshape(-1, f)
+    if train:
+        mean = x2.mean(0, dtype=np.float32)
+        var = np.maximum((x2 * x2).mean(0, dtype=np.float32) - mean * mean, np.float32(0))
+        if new_stats is not None:
+            new_stats[name + "/mean"] = (BN_MOMENTUM * stats[name + "/mean"] + (np.float32(1) - BN_MOMENTUM) * mean).astype(np.float32)
+            new_stats[name + "/var"] = (BN_MOMENTUM * stats[name + "/var"] + (np.float32(1) - BN_MOMENTUM) * var).astype(np.float32)
+    else:
+        mean, var = stats[name + "/mean"], stats[name + "/var"]
+    rstd = (np.float32(1) / np.sqrt(var + BN_EPS)).astype(np.float32)
+    xhat = ((x - mean) * rstd).astype(np.float32)
+    return (xhat * scale + bias).astype(np.float32), (xhat, rstd, train)
+
+
+def _bn_bwd(dy, scale, cache):
+    """Backward of the train-mode BatchNorm (batch moments are functions of x)."""
+    xhat, rstd, train = cache
+    f = xhat.shape[-1]
+    dy2, xh2 = dy.reshape(-1, f), xhat.reshape(-1, f)
+    dscale = (dy2 * xh2).sum(0)
+    dbias = dy2.sum(0)
+    dxh = dy2 * scale
+    if train:
+        dx = rstd * (dxh - dxh.mean(0, dtype=np.float32) - xh2 * (dxh * xh2).mean(0, dtype=np.float32))
+    else:
+        dx = rstd * dxh
+    return dx.reshape(dy.shape).astype(np.float32), dscale.astype(np.float32), dbias.astype(np.float32)
+
+
+def _norm_fwd(norm, x, p, name, train, stats, new_stats):
+    if norm == "layer_norm":
+        return _ln_fwd(x, p[name + "/scale"], p[name + "/bias"])
+    if norm == "batch_norm":
+        return _bn_fwd(x, p[name + "/scale"], p[name + "/bias"], name, train, stats, new_stats)
+    return x, None
+
+
+def _norm_bwd(norm, dy, p, name, cache, g):
+    if norm == "layer_norm":
+        dy, g[name + "/scale"], g[name + "/bias"] = _ln_bwd(dy, p[name + "/scale"], cache)
+    elif norm == "batch_norm":
+        dy, g[name + "/scale"], g[name + "/bias"] = _bn_bwd(dy, p[name + "/scale"], cache)
+    return dy
+
+
+def net_forward(kind, p, x, use_ln=True, layers=2, want_cache=False, norm_type=None, norm_input=False,
+                train=False, stats=None, new_stats=None):
+    """QNetwork.apply({"params": p, "batch_stats": stats}, x, train) (pqn_minatar.py:54-69,
+    pqn_gymnax.py:29-58).  x float32.  norm_type defaults to layer_norm / none by `use_ln`."""
+    norm = _norm_kind(norm_type) if norm_type is not None else ("layer_norm" if use_ln else "none")
     cache = {}
+    x = x.astype(np.float32)
+    cin = None
+    if norm_input:                                                         # :61-62 (and no /255 on this branch)
+        x, cin = _bn_fwd(x, p["BatchNorm_0/scale"], p["BatchNorm_0/bias"], "BatchNorm_0", train, stats, new_stats)
     if kind == "cnn":
         b = x.shape[0]
-        xs = (x / np.float32(255.0)).astype(np.float32)                   # pqn_minatar.py:66
-        pt = _patches(xs)                                                  # [B,8,8,9C]
+        xs = x if norm_input else (x / np.float32(255.0)).astype(np.float32)   # pqn_minatar.py:66
+        n0, n1 = cnn_norm_names(norm)
+        pt = _patches(np.ascontiguousarray(xs))                                 # [B,8,8,9C]
         y = pt @ p["CNN_0/Conv_0/kernel"].reshape(-1, 16) + p["CNN_0/Conv_0/bias"]
-        if use_ln:
-            y, c0 = _ln_fwd(y, p["CNN_0/LayerNorm_0/scale"], p["CNN_0/LayerNorm_0/bias"])
+        y, c0 = _norm_fwd(norm, y, p, n0, train, stats, new_stats)
         h1 = np.maximum(y, 0).reshape(b, -1)                               # (h,w,c) flatten, :47
         z = h1 @ p["CNN_0/Dense_0/kernel"] + p["CNN_0/Dense_0/bias"]
-        if use_ln:
-            z, c1 = _ln_fwd(z, p["CNN_0/LayerNorm_1/scale"], p["CNN_0/LayerNorm_1/bias"])
+        z, c1 = _norm_fwd(norm, z, p, n1, train, stats, new_stats)
         h2 = np.maximum(z, 0)
         q = h2 @ p["Dense_0/kernel"] + p["Dense_0/bias"]
         if want_cache:
-            cache = dict(pt=pt, c0=c0 if use_ln else None, h1=h1, c1=c1 if use_ln else None, h2=h2)
+            cache = dict(pt=pt, c0=c0, h1=h1, c1=c1, h2=h2, cin=cin, norm=norm)
         return (q.astype(np.float32), cache) if want_cache else q.astype(np.float32)
-    hs, cs = [x.astype(np.float32)], []
+    hs, cs = [x], []
     y = hs[0]
     for l in range(layers):
         y = y @ p[f"Dense_{l}/kernel"] + p[f"Dense_{l}/bias"]
-        if use_ln:
-            y, c = _ln_fwd(y, p[f"LayerNorm_{l}/scale"], p[f"LayerNorm_{l}/bias"])
-            cs.append(c)
+        y, c = _norm_fwd(norm, y, p, mlp_norm_name(norm, l), train, stats, new_stats)
+        cs.append(c)
         y = np.maximum(y, 0)
         hs.append(y)
     q = y @ p[f"Dense_{layers}/kernel"] + p[f"Dense_{layers}/bias"]
     if want_cache:
-        return q.astype(np.float32), dict(hs=hs, cs=cs)
+        return q.astype(np.float32), dict(hs=hs, cs=cs, cin=cin, norm=norm)
     return q.astype(np.float32)
 
 
-def net_loss_grad(kind, p, shapes, x, action, target, use_ln=True, layers=2):
-    """loss = 0.5*mean((q[a]-target)^2) and d loss / d theta (flat), pqn_minatar.py:271-291."""
-    q, cache = net_forward(kind, p, x, use_ln, layers, want_cache=True)
+def net_loss_grad(kind, p, shapes, x, action, target, use_ln=True, layers=2, norm_type=None, norm_input=False,
+                  stats=None, new_stats=None):
+    """loss = 0.5*mean((q[a]-target)^2) and d loss / d theta (flat), pqn_minatar.py:271-291 (train=True)."""
+    q, cache = net_forward(kind, p, x, use_ln, layers, want_cache=True, norm_type=norm_type, norm_input=norm_input,
+                           train=True, stats=stats, new_stats=new_stats)
+    norm = cache["norm"]
     b = x.shape[0]
     chosen = q[np.arange(b), action]
     diff = (chosen - target).astype(np.float32)
@@ -299,20 +403,27 @@ def net_loss_grad(kind, p, shapes, x, action, target, use_ln=True, layers=2):
     dq[np.arange(b), action] = diff / np.float32(b)
     g = {k: np.zeros(s, np.float32) for k, s in shapes.items()}
     if kind == "cnn":
+        n0, n1 = cnn_norm_names(norm)
         g["Dense_0/kernel"] = cache["h2"].T @ dq
         g["Dense_0/bias"] = dq.sum(0)
         dz = (dq @ p["Dense_0/kernel"].T) * (cache["h2"] > 0)
-        if use_ln:
-            dz, g["CNN_0/LayerNorm_1/scale"], g["CNN_0/LayerNorm_1/bias"] = _ln_bwd(dz, p["CNN_0/LayerNorm_1/scale"], cache["c1"])
+        dz = _norm_bwd(norm, dz, p, n1, cache["c1"], g)
         g["CNN_0/Dense_0/kernel"] = cache["h1"].T @ dz
         g["CNN_0/Dense_0/bias"] = dz.sum(0)
         dh1 = (dz @ p["CNN_0/Dense_0/kernel"].T) * (cache["h1"] > 0)
         dy = dh1.reshape(b, x.shape[1] - 2, x.shape[2] - 2, 16)
-        if use_ln:
-            dy, g["CNN_0/LayerNorm_0/scale"], g["CNN_0/LayerNorm_0/bias"] = _ln_bwd(dy, p["CNN_0/LayerNorm_0/scale"], cache["c0"])
+        dy = _norm_bwd(norm, dy, p, n0, cache["c0"], g)
         pt = cache["pt"].reshape(-1, cache["pt"].shape[-1])
         g["CNN_0/Conv_0/kernel"] = (pt.T @ dy.reshape(-1, 16)).reshape(shapes["CNN_0/Conv_0/kernel"])
         g["CNN_0/Conv_0/bias"] = dy.reshape(-1, 16).sum(0)
+        if norm_input:   # d loss / d (input-BatchNorm output) = conv transposed: scatter the window gradients back
+            wk = p["CNN_0/Conv_0/kernel"].reshape(-1, 16)
+            dpt = (dy.reshape(-1, 16) @ wk.T).reshape(b, x.shape[1] - 2, x.shape[2] - 2, 3, 3, x.shape[3])
+            dxn = np.zeros(x.shape, np.float32)
+            for ky in range(3):
+                for kx in range(3):
+                    dxn[:, ky:ky + x.shape[1] - 2, kx:kx + x.shape[2] - 2, :] += dpt[:, :, :, ky, kx, :]
+            _dx, g["BatchNorm_0/scale"], g["BatchNorm_0/bias"] = _bn_bwd(dxn, p["BatchNorm_0/scale"], cache["cin"])
     else:
         hs, cs = cache["hs"], cache["cs"]
         g[f"Dense_{layers}/kernel"] = hs[-1].T @ dq
@@ -320,11 +431,12 @@ def net_loss_grad(kind, p, shapes, x, action, target, use_ln=True, layers=2):
         d = dq @ p[f"Dense_{layers}/kernel"].T
         for l in reversed(range(layers)):
             d = d * (hs[l + 1] > 0)
-            if use_ln:
-                d, g[f"LayerNorm_{l}/scale"], g[f"LayerNorm_{l}/bias"] = _ln_bwd(d, p[f"LayerNorm_{l}/scale"], cs[l])
+            d = _norm_bwd(norm, d, p, mlp_norm_name(norm, l), cs[l], g)
             g[f"Dense_{l}/kernel"] = hs[l].T @ d
             g[f"Dense_{l}/bias"] = d.sum(0)
             d = d @ p[f"Dense_{l}/kernel"].T
+        if norm_input:
+            _dx, g["BatchNorm_0/scale"], g["BatchNorm_0/bias"] = _bn_bwd(d, p["BatchNorm_0/scale"], cache["cin"])
     flat = np.concatenate([g[k].reshape(-1).astype(np.float32) for k in shapes])
     return loss, chosen, flat
 
@@ -347,7 +459,10 @@ def make_train(config: Dict[str, Any]):
     A = env.num_actions
     layers = int(config.get("NUM_LAYERS", 2))
     use_ln = config["NORM_TYPE"] == "layer_norm"
-    shapes = cnn_shapes(env.obs_shape, A) if kind == "cnn" else mlp_shapes(env.obs_shape[0], A, int(config.get("HIDDEN_SIZE", 128)), layers)
+    norm_type, norm_input = config["NORM_TYPE"], bool(config.get("NORM_INPUT", False))
+    hidden = int(config.get("HIDDEN_SIZE", 128))
+    shapes = cnn_shapes(env.obs_shape, A, norm_type) if kind == "cnn" else mlp_shapes(env.obs_shape[0], A, hidden, layers, norm_type)
+    nkw = dict(norm_type=norm_type, norm_input=norm_input)
     test_on = bool(config.get("TEST_DURING_TRAINING", False))
     test_steps = env.max_steps if kind == "cnn" else int(config.get("TEST_NUM_STEPS", env.max_steps))
     gamma, lam, rs = float(config["GAMMA"]), float(config["LAMBDA"]), float(config.get("REW_SCALE", 1))
@@ -358,6 +473,7 @@ def make_train(config: Dict[str, Any]):
         theta = np.ascontiguousarray(init_theta, np.float32).copy()
         m, v = np.zeros_like(theta), np.zeros_like(theta)
         p = unflatten(theta, shapes)
+        stats = init_batch_stats(kind, env.obs_shape, hidden, layers, norm_type, norm_input)   # train_state.batch_stats
         lr_steps = config["NUM_UPDATES_DECAY"] * MB * EP
         n_updates = grad_steps = timesteps = 0
         runs = [0]
@@ -373,7 +489,7 @@ def make_train(config: Dict[str, Any]):
             cnt = 0.0
             for t in range(test_steps):
                 sk = fold_in(k, 1 + t)
-                a, _ = eps_greedy(net_forward(kind, p, obs, use_ln, layers), float(config["EPS_TEST"]), sk)
+                a, _ = eps_greedy(net_forward(kind, p, obs, use_ln, layers, stats=stats, **nkw), float(config["EPS_TEST"]), sk)
                 obs, st, _r, done, info = env.step(sk, st, a)
                 cnt += float(done.sum())
                 for kk in INFO_KEYS:
@@ -396,14 +512,14 @@ def make_train(config: Dict[str, Any]):
             infos = {kk: [] for kk in INFO_KEYS}
             for t in range(T):
                 sk = fold_in(K_roll, u * T + t)
-                q = net_forward(kind, p, O[t], use_ln, layers)
+                q = net_forward(kind, p, O[t], use_ln, layers, stats=stats, **nkw)
                 Aa[t], QM[t] = eps_greedy(q, np.float32(eps), sk)
                 O[t + 1], st, r, D[t], info = env.step(sk, st, Aa[t])
                 R[t] = np.float32(rs) * r if rs != 1.0 else r
                 for kk in INFO_KEYS:
                     infos[kk].append(info[kk])
             timesteps += T * N
-            last_q = net_forward(kind, p, O[T], use_ln, layers).max(-1)
+            last_q = net_forward(kind, p, O[T], use_ln, layers, stats=stats, **nkw).max(-1)
             tgt = q_lambda(R, D, QM, last_q, gamma, lam, quirk=True)
             of, af, tf = O[:T].reshape(T * N, *env.obs_shape), Aa.reshape(-1), tgt.reshape(-1)
             losses, qvs = [], []
@@ -411,7 +527,10 @@ def make_train(config: Dict[str, Any]):
                 perm = permutation(fold_in(K_shuf, u * EP + ep), T * N)
                 for mb in range(MB):
                     idx = perm[mb * B:(mb + 1) * B]
-                    loss, chosen, g = net_loss_grad(kind, p, shapes, of[idx], af[idx], tf[idx], use_ln, layers)
+                    new_stats = {}
+                    loss, chosen, g = net_loss_grad(kind, p, shapes, of[idx], af[idx], tf[idx], use_ln, layers,
+                                                    stats=stats, new_stats=new_stats, **nkw)
+                    stats.update(new_stats)                                # mutable=["batch_stats"] (:272-277,296)
                     lr = linear_schedule(config["LR"], 1e-20, lr_steps, grad_steps) if config.get("LR_LINEAR_DECAY", False) else config["LR"]
                     radam_clip_step(theta, g, m, v, grad_steps, np.float32(lr), np.float32(config["MAX_GRAD_NORM"]))
                     grad_steps += 1
@@ -430,7 +549,7 @@ def make_train(config: Dict[str, Any]):
                     tm = test_metrics_fn()
                 mm.update({f"test/{k}": float(v2) for k, v2 in tm.items()})
             metrics.append(mm)
-        return {"theta": theta, "metrics": metrics, "env_state": st, "last_obs": obs}
+        return {"theta": theta, "metrics": metrics, "env_state": st, "last_obs": obs, "batch_stats": stats}
 
     train.shapes = shapes
     train.kind = kind

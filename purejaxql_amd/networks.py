@@ -5,7 +5,9 @@ purejaxql/pqn_minatar.py:24-69 and the MLP QNetwork at
 purejaxql/pqn_gymnax.py:29-58 -- with flax/optax numerics:
 kernels in flax layout (conv HWIO, dense (in,out)), NHWC activations, flatten
 order (h,w,c), LayerNorm over the last axis with eps=1e-6, x/255 on the CNN
-input, a dummy input-BatchNorm whose params exist but never receive gradient.
+input, a dummy input-BatchNorm whose params exist but never receive gradient;
+NORM_TYPE = layer_norm | batch_norm | none and NORM_INPUT as in the reference
+(BatchNorm with flax defaults and a `batch_stats` collection of running moments).
 
 All parameters of one seed live in ONE flat buffer (`theta`), with the
 gradient in a matching flat buffer, so the optimizer (ops.FlatRAdam), a
@@ -21,33 +23,82 @@ import torch
 import torch.nn.functional as F
 
 LN_EPS = 1e-6  # flax nn.LayerNorm default (torch's is 1e-5)
+BN_EPS = 1e-5  # flax nn.BatchNorm defaults: epsilon 1e-5, momentum 0.99, statistics over all axes but the last
+BN_MOMENTUM = 0.99
 
 
-def cnn_param_shapes(obs_shape: Tuple[int, int, int], action_dim: int) -> "OrderedDict[str, Tuple[int, ...]]":
+def _norm_kind(norm_type) -> str:
+    return norm_type if norm_type in ("layer_norm", "batch_norm") else "none"   # pqn_minatar.py:31-36
+
+
+def cnn_norm_names(norm_type) -> Tuple[str, str]:
+    """flax auto-names of the two normalize(x) modules inside CNN (pqn_minatar.py:31-50); '' = identity."""
+    k = _norm_kind(norm_type)
+    if k == "layer_norm":
+        return "CNN_0/LayerNorm_0", "CNN_0/LayerNorm_1"
+    if k == "batch_norm":
+        return "CNN_0/BatchNorm_0", "CNN_0/BatchNorm_1"
+    return "", ""
+
+
+def mlp_norm_name(norm_type, l: int) -> str:
+    """normalize(x) of hidden layer l in the MLP QNetwork (pqn_gymnax.py:44-54): BatchNorm_0 is the input /
+    dummy BatchNorm, so the hidden-layer BatchNorms are BatchNorm_1.."""
+    k = _norm_kind(norm_type)
+    return f"LayerNorm_{l}" if k == "layer_norm" else (f"BatchNorm_{l + 1}" if k == "batch_norm" else "")
+
+
+def cnn_param_shapes(obs_shape: Tuple[int, int, int], action_dim: int,
+                     norm_type="layer_norm") -> "OrderedDict[str, Tuple[int, ...]]":
     """Parameter tree of QNetwork(CNN) in flax auto-naming."""
     h, w, c = obs_shape
     flat = (h - 2) * (w - 2) * 16
-    return OrderedDict([
-        ("BatchNorm_0/scale", (c,)), ("BatchNorm_0/bias", (c,)),
-        ("CNN_0/Conv_0/kernel", (3, 3, c, 16)), ("CNN_0/Conv_0/bias", (16,)),
-        ("CNN_0/LayerNorm_0/scale", (16,)), ("CNN_0/LayerNorm_0/bias", (16,)),
-        ("CNN_0/Dense_0/kernel", (flat, 128)), ("CNN_0/Dense_0/bias", (128,)),
-        ("CNN_0/LayerNorm_1/scale", (128,)), ("CNN_0/LayerNorm_1/bias", (128,)),
-        ("Dense_0/kernel", (128, action_dim)), ("Dense_0/bias", (action_dim,)),
-    ])
+    n0, n1 = cnn_norm_names(norm_type)
+    shapes = OrderedDict([("BatchNorm_0/scale", (c,)), ("BatchNorm_0/bias", (c,)),
+                          ("CNN_0/Conv_0/kernel", (3, 3, c, 16)), ("CNN_0/Conv_0/bias", (16,))])
+    if n0:
+        shapes[n0 + "/scale"], shapes[n0 + "/bias"] = (16,), (16,)
+    shapes["CNN_0/Dense_0/kernel"], shapes["CNN_0/Dense_0/bias"] = (flat, 128), (128,)
+    if n1:
+        shapes[n1 + "/scale"], shapes[n1 + "/bias"] = (128,), (128,)
+    shapes["Dense_0/kernel"], shapes["Dense_0/bias"] = (128, action_dim), (action_dim,)
+    return shapes
 
 
-def mlp_param_shapes(obs_dim: int, action_dim: int, hidden: int, layers: int):
+def mlp_param_shapes(obs_dim: int, action_dim: int, hidden: int, layers: int, norm_type="layer_norm"):
     shapes = OrderedDict([("BatchNorm_0/scale", (obs_dim,)), ("BatchNorm_0/bias", (obs_dim,))])
     d = obs_dim
     for l in range(layers):
         shapes[f"Dense_{l}/kernel"] = (d, hidden)
         shapes[f"Dense_{l}/bias"] = (hidden,)
-        shapes[f"LayerNorm_{l}/scale"] = (hidden,)
-        shapes[f"LayerNorm_{l}/bias"] = (hidden,)
+        n = mlp_norm_name(norm_type, l)
+        if n:
+            shapes[n + "/scale"] = (hidden,)
+            shapes[n + "/bias"] = (hidden,)
         d = hidden
     shapes[f"Dense_{layers}/kernel"] = (d, action_dim)
     shapes[f"Dense_{layers}/bias"] = (action_dim,)
+    return shapes
+
+
+def batch_stats_shapes(kind: str, obs_shape, hidden: int, layers: int, norm_type, norm_input: bool):
+    """The `batch_stats` collection (running mean / var of every BatchNorm whose output is used).  The
+    dummy input BatchNorm of NORM_INPUT=False (pqn_minatar.py:63-65) only ever produces dead state -- its
+    output is discarded and checkpoints hold `params` only (:467) -- so its statistics are not tracked."""
+    feats = OrderedDict()
+    if norm_input:
+        feats["BatchNorm_0"] = int(obs_shape[-1])
+    if _norm_kind(norm_type) == "batch_norm":
+        if kind == "cnn":
+            n0, n1 = cnn_norm_names(norm_type)
+            feats[n0], feats[n1] = 16, 128
+        else:
+            for l in range(layers):
+                feats[mlp_norm_name(norm_type, l)] = hidden
+    shapes = OrderedDict()
+    for name, f in feats.items():
+        shapes[name + "/mean"] = (f,)
+        shapes[name + "/var"] = (f,)
     return shapes
 
 
@@ -66,21 +117,22 @@ class QNetwork:
 
     def __init__(self, kind: str, obs_shape, action_dim: int, norm_type: str = "layer_norm",
                  norm_input: bool = False, hidden_size: int = 128, num_layers: int = 2, device="cuda"):
-        if norm_type not in ("layer_norm", "none", None):
-            raise NotImplementedError("NORM_TYPE=batch_norm is outside the current hot-path scope (DESIGN.md)")
-        if norm_input:
-            raise NotImplementedError("NORM_INPUT=True (input BatchNorm) is outside the current scope (DESIGN.md)")
         self.kind = kind
         self.obs_shape = tuple(obs_shape)
         self.action_dim = int(action_dim)
-        self.use_ln = norm_type == "layer_norm"
+        self.norm = _norm_kind(norm_type)
+        self.norm_type = norm_type
+        self.norm_input = bool(norm_input)
+        self.use_ln = self.norm == "layer_norm"
         self.hidden, self.layers = int(hidden_size), int(num_layers)
         if kind == "cnn":
-            self.shapes = cnn_param_shapes(self.obs_shape, action_dim)
+            self.shapes = cnn_param_shapes(self.obs_shape, action_dim, norm_type)
         elif kind == "mlp":
-            self.shapes = mlp_param_shapes(int(self.obs_shape[0]), action_dim, self.hidden, self.layers)
+            self.shapes = mlp_param_shapes(int(self.obs_shape[0]), action_dim, self.hidden, self.layers, norm_type)
         else:
             raise ValueError(kind)
+        self.stats_shapes = batch_stats_shapes(kind, self.obs_shape, self.hidden, self.layers, norm_type, norm_input)
+        self.has_batch_stats = len(self.stats_shapes) > 0
         self.offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
         for k, s in self.shapes.items():
@@ -108,6 +160,11 @@ class QNetwork:
                 theta[off:off + n] = _trunc_normal(s, std, gen).reshape(-1)
         return theta.to(self.device)
 
+    def init_batch_stats(self) -> Dict[str, torch.Tensor]:
+        """variables["batch_stats"] at init: running mean 0, running var 1 (flax nn.BatchNorm)."""
+        return {k: (torch.ones if k.endswith("/var") else torch.zeros)(s, dtype=torch.float32, device=self.device)
+                for k, s in self.stats_shapes.items()}
+
     def views(self, theta: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {k: theta[off:off + n].view(self.shapes[k]) for k, (off, n) in self.offsets.items()}
 
@@ -116,27 +173,54 @@ class QNetwork:
         return {k.replace("/", ","): v.detach().clone().cpu() for k, v in self.views(theta).items()}
 
     # -- forward (torch ops: plumbing path, also the fp32 torch reference) --------------
-    def _ln(self, x, scale, bias):
-        return F.layer_norm(x, (x.shape[-1],), scale, bias, LN_EPS) if self.use_ln else x
+    def _bn(self, x, p, name, train, stats, new_stats):
+        """flax nn.BatchNorm(use_running_average=not train): statistics over every axis but the last, fast
+        variance E[x^2]-E[x]^2 clamped at 0, running <- 0.99*running + 0.01*batch."""
+        if train:
+            axes = tuple(range(x.dim() - 1))
+            mean = x.mean(dim=axes)
+            var = torch.clamp((x * x).mean(dim=axes) - mean * mean, min=0.0)
+            if new_stats is not None:
+                new_stats[name + "/mean"] = BN_MOMENTUM * stats[name + "/mean"] + (1.0 - BN_MOMENTUM) * mean.detach()
+                new_stats[name + "/var"] = BN_MOMENTUM * stats[name + "/var"] + (1.0 - BN_MOMENTUM) * var.detach()
+        else:
+            mean, var = stats[name + "/mean"], stats[name + "/var"]
+        return (x - mean) * (torch.rsqrt(var + BN_EPS) * p[name + "/scale"]) + p[name + "/bias"]
 
-    def apply(self, p: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    def _normalize(self, x, p, name, train, stats, new_stats):
+        if self.norm == "layer_norm":
+            return F.layer_norm(x, (x.shape[-1],), p[name + "/scale"], p[name + "/bias"], LN_EPS)
+        if self.norm == "batch_norm":
+            return self._bn(x, p, name, train, stats, new_stats)
+        return x
+
+    def apply(self, p: Dict[str, torch.Tensor], x: torch.Tensor, train: bool = False,
+              stats: Dict[str, torch.Tensor] = None, new_stats: Dict[str, torch.Tensor] = None) -> torch.Tensor:
+        """network.apply({"params": p, "batch_stats": stats}, x, train=train); with train=True the updated
+        running statistics are written into `new_stats` (mutable=["batch_stats"], pqn_minatar.py:272-277)."""
+        if self.has_batch_stats and stats is None:
+            raise ValueError("this network has BatchNorm layers: pass stats=network.init_batch_stats()")
+        if self.norm_input:
+            x = self._bn(x, p, "BatchNorm_0", train, stats, new_stats)      # (:61-62) -- and no /255 on this branch
         if self.kind == "cnn":
             b = x.shape[0]
             c = x.shape[-1]
-            x = x / 255.0
+            if not self.norm_input:
+                x = x / 255.0                                               # (:66)
+            n0, n1 = cnn_norm_names(self.norm_type)
             # VALID 3x3 conv in NHWC as patches @ kernel (keeps (h,w,c) order, no layout flips)
             patches = x.unfold(1, 3, 1).unfold(2, 3, 1)            # [B,8,8,C,3,3]
             patches = patches.permute(0, 1, 2, 4, 5, 3).reshape(b, -1, 9 * c)  # [B,64,(ky,kx,c)]
             y = patches @ p["CNN_0/Conv_0/kernel"].reshape(9 * c, 16) + p["CNN_0/Conv_0/bias"]
-            y = torch.relu(self._ln(y, p["CNN_0/LayerNorm_0/scale"], p["CNN_0/LayerNorm_0/bias"]))
+            y = torch.relu(self._normalize(y, p, n0, train, stats, new_stats))
             y = y.reshape(b, -1)                                    # (h,w,c) flatten
             y = y @ p["CNN_0/Dense_0/kernel"] + p["CNN_0/Dense_0/bias"]
-            y = torch.relu(self._ln(y, p["CNN_0/LayerNorm_1/scale"], p["CNN_0/LayerNorm_1/bias"]))
+            y = torch.relu(self._normalize(y, p, n1, train, stats, new_stats))
             return y @ p["Dense_0/kernel"] + p["Dense_0/bias"]
         y = x
         for l in range(self.layers):
             y = y @ p[f"Dense_{l}/kernel"] + p[f"Dense_{l}/bias"]
-            y = torch.relu(self._ln(y, p[f"LayerNorm_{l}/scale"], p[f"LayerNorm_{l}/bias"]))
+            y = torch.relu(self._normalize(y, p, mlp_norm_name(self.norm_type, l), train, stats, new_stats))
         return y @ p[f"Dense_{self.layers}/kernel"] + p[f"Dense_{self.layers}/bias"]
 
 

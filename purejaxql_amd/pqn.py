@@ -90,10 +90,15 @@ class _TorchPolicy:
         self.fp = FlatParams(network, theta)
         self.opt = ops.FlatRAdam(self.fp.theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps)
         self.grad_hook = grad_hook
+        # train_state.batch_stats (pqn_minatar.py:81-86,169): running moments of the BatchNorm layers
+        self.stats = network.init_batch_stats() if network.has_batch_stats else None
+        if self.stats is not None and grad_hook is not None:
+            raise NotImplementedError("BatchNorm with the envs of one seed sharded over ranks would need the batch "
+                                      "moments all-reduced as well; use seed sharding (dist.partition_seeds)")
 
     def q_values(self, obs):
-        with torch.no_grad():
-            return self.net.apply(self.fp.leaves, obs)
+        with torch.no_grad():   # train=False: running averages (pqn_minatar.py:184-192)
+            return self.net.apply(self.fp.leaves, obs, train=False, stats=self.stats)
 
     def act(self, obs, eps, key, action, qmax):
         ops.eps_greedy(self.q_values(obs), eps, key, action, qmax)
@@ -103,7 +108,10 @@ class _TorchPolicy:
 
     def sgd_step(self, idx, obs_flat, act_flat, tgt_flat, loss_out, qv_out):
         self.fp.zero_grad()
-        qv = self.net.apply(self.fp.leaves, obs_flat[idx])
+        new_stats = {} if self.stats is not None else None   # train=True, mutable=["batch_stats"] (:272-277)
+        qv = self.net.apply(self.fp.leaves, obs_flat[idx], train=True, stats=self.stats, new_stats=new_stats)
+        if new_stats:
+            self.stats = {**self.stats, **new_stats}          # (:296)
         chosen = qv.gather(1, act_flat[idx].to(torch.int64).unsqueeze(1)).squeeze(1)
         loss = 0.5 * torch.square(chosen - tgt_flat[idx]).mean()
         loss.backward()
@@ -117,7 +125,8 @@ class _TorchPolicy:
         return self.fp.theta
 
     def opt_state(self):
-        return {"opt_count": self.opt.count, "opt_mu": self.opt.m, "opt_nu": self.opt.v}
+        return {"opt_count": self.opt.count, "opt_mu": self.opt.m, "opt_nu": self.opt.v,
+                "batch_stats": self.stats if self.stats is not None else {}}
 
 
 class _FusedCnnPolicy:

@@ -1,0 +1,68 @@
+"""Host-side Q-network (torch ops, the plumbing / non-LayerNorm path) vs the numpy oracle, on CPU:
+every NORM_TYPE x NORM_INPUT combination of pqn_minatar.py:24-69 / pqn_gymnax.py:29-58 -- parameter
+tree, train-mode loss + gradient (torch autograd vs the oracle's hand-written backward), eval-mode
+forward on the running statistics, and the batch_stats update."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pqn_oracle as O
+from purejaxql_amd.networks import FlatParams, QNetwork
+
+CASES = [(k, nt, ni) for k in ("cnn", "mlp") for nt in ("layer_norm", "batch_norm", "none") for ni in (False, True)]
+
+
+@pytest.mark.parametrize("kind,norm_type,norm_input", CASES)
+def test_torch_network_matches_oracle(kind, norm_type, norm_input):
+    obs_shape, A = ((10, 10, 4), 3) if kind == "cnn" else ((4,), 2)
+    gen = torch.Generator().manual_seed(7)
+    net = QNetwork(kind, obs_shape, A, norm_type=norm_type, norm_input=norm_input, hidden_size=32, num_layers=2,
+                   device="cpu")
+    theta = net.init(1)
+    theta = theta + 0.05 * torch.randn(theta.shape, generator=gen)      # non-trivial scales / biases
+    fp = FlatParams(net, theta.clone())
+    B = 24
+    x = ((torch.rand((B, *obs_shape), generator=gen) < 0.3).float() if kind == "cnn"
+         else torch.randn((B, *obs_shape), generator=gen))
+    act = torch.randint(0, A, (B,), generator=gen)
+    tgt = torch.randn(B, generator=gen)
+    stats = None
+    if net.has_batch_stats:
+        stats = {k: v + 0.1 * torch.rand(v.shape, generator=gen) for k, v in net.init_batch_stats().items()}
+    new_stats = {}
+    q = net.apply(fp.leaves, x, train=True, stats=stats, new_stats=new_stats)
+    chosen = q.gather(1, act[:, None]).squeeze(1)
+    loss = 0.5 * ((chosen - tgt) ** 2).mean()
+    loss.backward()
+
+    shapes = (O.cnn_shapes(obs_shape, A, norm_type) if kind == "cnn" else O.mlp_shapes(obs_shape[0], A, 32, 2, norm_type))
+    assert list(shapes.items()) == [(k, tuple(s)) for k, s in net.shapes.items()]       # same flax parameter tree
+    ostats0 = O.init_batch_stats(kind, obs_shape, 32, 2, norm_type, norm_input)
+    assert list(ostats0) == list(net.stats_shapes)
+    p = O.unflatten(theta.numpy().copy(), shapes)
+    ostats = {k: v.numpy().copy() for k, v in (stats or {}).items()}
+    onew = {}
+    ol, _oc, og = O.net_loss_grad(kind, p, shapes, x.numpy(), act.numpy(), tgt.numpy(), norm_type == "layer_norm", 2,
+                                  norm_type=norm_type, norm_input=norm_input, stats=ostats, new_stats=onew)
+    # conv outputs of x/255 inputs are O(1e-3): the fast variance E[x^2]-E[x]^2 of BatchNorm cancels in f32
+    tol = 2e-3 if (kind == "cnn" and norm_type == "batch_norm" and not norm_input) else 2e-5
+    assert abs(float(ol) - float(loss.detach())) <= tol * max(1.0, abs(float(loss.detach())))
+    g = fp.grad.numpy()
+    assert np.abs(og - g).max() <= tol * max(1e-9, np.abs(g).max())
+    assert sorted(onew) == sorted(new_stats)
+    for k in onew:
+        np.testing.assert_allclose(onew[k], new_stats[k].numpy(), rtol=max(1e-5, tol), atol=1e-6)
+    # eval mode: running averages (rollout / test policy)
+    qe = O.net_forward(kind, p, x.numpy(), norm_type == "layer_norm", 2, norm_type=norm_type, norm_input=norm_input,
+                       train=False, stats=ostats)
+    qt = net.apply(fp.leaves, x, train=False, stats=stats).detach().numpy()
+    np.testing.assert_allclose(qe, qt, rtol=1e-4, atol=1e-5)
+
+
+def test_batchnorm_network_requires_stats():
+    net = QNetwork("mlp", (4,), 2, norm_type="batch_norm", device="cpu")
+    theta = net.init(0)
+    with pytest.raises(ValueError):
+        net.apply(net.views(theta), torch.zeros(3, 4))
+    assert set(net.init_batch_stats()) == {"BatchNorm_1/mean", "BatchNorm_1/var", "BatchNorm_2/mean", "BatchNorm_2/var"}
+    assert "BatchNorm_0/scale" in net.shapes and "BatchNorm_2/scale" in net.shapes and "LayerNorm_0/scale" not in net.shapes
