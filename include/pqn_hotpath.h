@@ -86,6 +86,9 @@ int pqn_version(void);
 /* ---- PRNG (host helpers; same functions the kernels evaluate) ---------- */
 void pqn_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]); /* host */
 uint64_t pqn_fold_in(uint64_t key, uint32_t data);                                    /* host */
+/* out[i] = fold_in(key, first + i), i < count, written on the device: the per-step keys of a rollout
+ * (jax.random.split(rng, num_steps) feeding a lax.scan, pqn_minatar.py:181-183,399-401). */
+int pqn_fold_in_range(uint64_t key, uint32_t first, int32_t count, uint64_t *out /* device [count] */, void *stream);
 
 /* ---- environment: replaces gymnax.make / vmap_reset / vmap_step -------- */
 int pqn_env_id(const char *name); /* "Breakout-MinAtar" -> PQN_ENV_BREAKOUT, <0 if unknown */
@@ -226,6 +229,23 @@ typedef struct {
 
 int64_t pqn_update_sort_temp_bytes(int32_t n);
 int pqn_cnn_update(const pqn_update_args_t *args /* host */, void *stream);
+
+/* The rollout scan alone, as ONE persistent launch: num_steps x (Q-network forward, eps-greedy, env.step with
+ * auto-reset + LogWrapper) for every env, then the bootstrap forward of the last observation.  Replaces
+ * jax.lax.scan(_step_env) + the last_q forward (pqn_minatar.py:181-235) and, with eps = EPS_TEST and
+ * store_obs = 0, the evaluation scan of get_test_metrics (:380-401).  Step t uses keys_dev[t] for both the
+ * eps-greedy draw and env.step, exactly as pqn_qnet_cnn_forward + pqn_env_step with that key would.
+ *   state     u32[state_words][n]   in/out (in place)
+ *   obs_bits  store_obs != 0: u32[num_steps+1][n][obs_words], slot 0 = current observation on entry, slot t+1 =
+ *             observation after step t;  store_obs == 0: u32[1][n][obs_words], current observation in / out
+ *   rec       device arrays [num_steps][n] (reward is multiplied by rew_scale; LogWrapper sees the raw reward);
+ *             any pointer may be NULL; rec->obs / rec->obs_bits must be NULL
+ *   action i32[num_steps][n], qmax f32[num_steps][n] (max_a Q(obs_t)), last_q f32[n] (max_a Q(obs_T)): nullable
+ *   eps_dev   device f32[1];  keys_dev device u64[num_steps] (see pqn_fold_in_range) */
+int pqn_cnn_rollout(int env_id, const pqn_cnn_layout_t *layout, int32_t num_envs, int32_t num_steps, uint32_t *state,
+                    uint32_t *obs_bits, int32_t store_obs, const float *theta, const pqn_step_out_t *rec /* host */,
+                    int32_t *action, float *qmax, float *last_q, const float *eps_dev, const uint64_t *keys_dev,
+                    float rew_scale, void *stream);
 
 /* Profiling aid (PQN_T1_STAMPS=1): s_memtime stamps at the phase boundaries of qnet_cnn_train_kernel for
  * workgroups 0..3; 16 slots per workgroup.  Not part of the hot path. */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "pqn_version": (c_int, []),
     "pqn_threefry2x32": (None, [C.POINTER(c_uint32), C.POINTER(c_uint32), C.POINTER(c_uint32)]),
     "pqn_fold_in": (c_uint64, [c_uint64, c_uint32]),
+    "pqn_fold_in_range": (c_int, [c_uint64, c_uint32, c_int32, c_void_p, c_void_p]),
     "pqn_env_id": (c_int, [C.c_char_p]),
     "pqn_env_spec": (c_int, [c_int, C.POINTER(EnvSpec)]),
     "pqn_env_reset": (c_int, [c_int, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -59,6 +60,8 @@ SIGNATURES = {
     "pqn_prof_read": (c_int, [c_void_p, c_void_p]),
     "pqn_update_sort_temp_bytes": (c_int64, [c_int32]),
     "pqn_cnn_update": (c_int, [c_void_p, c_void_p]),
+    "pqn_cnn_rollout": (c_int, [c_int, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "pqn_debug_t1_stamps": (c_int, [c_void_p]),
     "pqn_mlp_layout": (c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pqn_mlp_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64,

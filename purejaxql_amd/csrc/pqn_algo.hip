@@ -37,6 +37,18 @@ extern "C" void pqn_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], u
 }
 extern "C" uint64_t pqn_fold_in(uint64_t key, uint32_t data) { return pqn_fold(key, data); }
 
+__global__ void fold_in_range_kernel(uint64_t key, uint32_t first, int count, uint64_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = pqn_fold(key, first + (uint32_t)i);
+}
+
+extern "C" int pqn_fold_in_range(uint64_t key, uint32_t first, int32_t count, uint64_t *out, void *stream) {
+  PQN_REQUIRE(out && count > 0, "pqn_fold_in_range: bad arguments (count=%d)", count);
+  hipLaunchKernelGGL(fold_in_range_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, key, first, count,
+                     out);
+  return pqn_check_launch("pqn_fold_in_range");
+}
+
 // ---------------------------------------------------------------------------
 // eps-greedy: one lane per row of q[m, a].  First-max tie rule (jnp.argmax).
 // ---------------------------------------------------------------------------

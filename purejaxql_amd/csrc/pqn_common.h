@@ -88,4 +88,4 @@ int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *o
                              const uint64_t *key_dev, hipStream_t st);
 int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
                          const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
-                         const float *eps_dev, const uint64_t *keys, float rscale, hipStream_t st);
+                         const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st);

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
     pqn_cnn_layout_t L, int32_t *__restrict__ action, float *__restrict__ qmax, float *__restrict__ reward,
     uint8_t *__restrict__ done, float *__restrict__ discount, float *__restrict__ rer, int32_t *__restrict__ rel,
     int32_t *__restrict__ ts, float *__restrict__ last_q, const float *__restrict__ eps_dev,
-    const uint64_t *__restrict__ keys, float rscale) {
+    const uint64_t *__restrict__ keys, float rscale, int store_obs) {
   using Cfg = CnnCfg<C>;
   static_assert(Cfg::OW == Env::OBS_WORDS, "packed observation width");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
         for (int a = 1; a < QN_MAXA; ++a)
           if (a < L.a && q[a] > bv) { bv = q[a]; best = a; }
         if (t == t_len) {
-          last_q[e] = bv;                                  // bootstrap value of obs_T
+          if (last_q) last_q[e] = bv;                      // bootstrap value of obs_T
         } else {
           const uint64_t key = keys[t];
           uint32_t o0, o1;
@@ -497,24 +497,28 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
           log.step(r, dn);
           if (dn) env.reset(key, (uint32_t)e);             // gymnax auto-reset
           const size_t o = (size_t)t * n + e;
-          action[o] = act;
-          qmax[o] = bv;
-          reward[o] = r * rscale;
-          done[o] = (uint8_t)dn;
-          discount[o] = dn ? 0.0f : 1.0f;
-          rer[o] = log.ret_ret;
-          rel[o] = log.ret_len;
-          ts[o] = log.timestep;
+          if (action) action[o] = act;
+          if (qmax) qmax[o] = bv;
+          if (reward) reward[o] = r * rscale;
+          if (done) done[o] = (uint8_t)dn;
+          if (discount) discount[o] = dn ? 0.0f : 1.0f;
+          if (rer) rer[o] = log.ret_ret;
+          if (rel) rel[o] = log.ret_len;
+          if (ts) ts[o] = log.timestep;
           env.obs_bits(&s.bits[m * Cfg::OW]);              // obs_{t+1} straight into the LDS tile
         }
       }
     }
     if (t == t_len) break;
     __syncthreads();
-    // transition record: packed obs_{t+1} of the tile (the training kernels gather from it)
-    for (int i = tid; i < QN_TILE * Cfg::OW; i += QN_THREADS) {
-      const int le = i / Cfg::OW;
-      if (e0 + le < n) bits_all[(size_t)(t + 1) * bstride + (size_t)e0 * Cfg::OW + i] = s.bits[i];
+    // transition record: packed obs_{t+1} of the tile (the training kernels gather from it); an evaluation
+    // rollout (store_obs = 0) keeps only the running observation, in slot 0
+    if (store_obs || t + 1 == t_len) {
+      uint32_t *dst = bits_all + (store_obs ? (size_t)(t + 1) * bstride : (size_t)0);
+      for (int i = tid; i < QN_TILE * Cfg::OW; i += QN_THREADS) {
+        const int le = i / Cfg::OW;
+        if (e0 + le < n) dst[(size_t)e0 * Cfg::OW + i] = s.bits[i];
+      }
     }
   }
   if (owner) {
@@ -1172,7 +1176,7 @@ extern "C" int pqn_qnet_cnn_forward(const pqn_cnn_layout_t *L, int32_t n, const 
 template <int C, class Env>
 static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
                           const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
-                          const uint64_t *keys, float rscale, hipStream_t st) {
+                          const uint64_t *keys, float rscale, int store_obs, hipStream_t st) {
   const size_t smem = cnn_smem_bytes<C>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -1183,31 +1187,45 @@ static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t 
   hipLaunchKernelGGL((qnet_cnn_rollout_kernel<C, Env>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n,
                      t_len, state, bits, theta, L, action, qmax, rec.reward, rec.done, rec.discount,
                      rec.returned_episode_returns, rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys,
-                     rscale);
+                     rscale, store_obs);
   return pqn_check_launch("pqn_qnet_cnn_rollout");
 }
 
 // internal (pqn_update.hip): rec.* point at the [T][n] transition arrays
 int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
                          const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
-                         const float *eps_dev, const uint64_t *keys, float rscale, hipStream_t st) {
+                         const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st) {
   switch (env_id) {
     case PQN_ENV_BREAKOUT:
-      if (L.c == 4) return launch_rollout<4, Breakout>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, st);
+      if (L.c == 4) return launch_rollout<4, Breakout>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st);
       break;
     case PQN_ENV_ASTERIX:
-      if (L.c == 4) return launch_rollout<4, Asterix>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, st);
+      if (L.c == 4) return launch_rollout<4, Asterix>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st);
       break;
     case PQN_ENV_FREEWAY:
-      if (L.c == 7) return launch_rollout<7, Freeway>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, st);
+      if (L.c == 7) return launch_rollout<7, Freeway>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st);
       break;
     case PQN_ENV_SPACEINVADERS:
-      if (L.c == 6) return launch_rollout<6, SpaceInvaders>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, st);
+      if (L.c == 6) return launch_rollout<6, SpaceInvaders>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st);
       break;
     default: break;
   }
   pqn_set_error("pqn_qnet_cnn_rollout: env %d / %d channels has no fused rollout", env_id, L.c);
   return PQN_E_UNSUPPORTED;
+}
+
+extern "C" int pqn_cnn_rollout(int env_id, const pqn_cnn_layout_t *layout, int32_t num_envs, int32_t num_steps,
+                               uint32_t *state, uint32_t *obs_bits, int32_t store_obs, const float *theta,
+                               const pqn_step_out_t *rec, int32_t *action, float *qmax, float *last_q,
+                               const float *eps_dev, const uint64_t *keys_dev, float rew_scale, void *stream) {
+  PQN_REQUIRE(layout && state && obs_bits && theta && eps_dev && keys_dev, "pqn_cnn_rollout: NULL argument");
+  PQN_REQUIRE(num_envs > 0 && num_steps > 0, "pqn_cnn_rollout: bad shape n=%d T=%d", num_envs, num_steps);
+  pqn_step_out_t none = {};
+  const pqn_step_out_t &r = rec ? *rec : none;
+  PQN_REQUIRE(r.obs == nullptr && r.obs_bits == nullptr,
+              "pqn_cnn_rollout: observations are recorded through obs_bits[T+1][n][OW], rec->obs / rec->obs_bits must be NULL");
+  return pqn_qnet_cnn_rollout(env_id, *layout, num_envs, num_steps, state, obs_bits, theta, r, action, qmax, last_q, eps_dev,
+                              keys_dev, rew_scale, store_obs != 0, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -137,7 +137,7 @@ extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
     rec.returned_episode_lengths = a->rel;
     rec.timestep = a->ts;
     UPD_CHECK(pqn_qnet_cnn_rollout(a->env_id, L, N, T, a->state, a->bits, a->theta, rec, a->action, a->qmax, a->last_q,
-                                   a->sched_eps, a->sched_keys, a->rew_scale, st));
+                                   a->sched_eps, a->sched_keys, a->rew_scale, 1, st));
   }
   // Q(lambda) TARGETS (:237-260)
   UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, N, 1, a->target, st));

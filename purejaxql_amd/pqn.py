@@ -290,12 +290,42 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         # EVAL (pqn_minatar.py:371-413)
         test_runs = [0]
 
+        eval_buf = {}
+
+        def fused_test_metrics(k, n_t, steps):
+            """The evaluation scan (pqn_minatar.py:380-401) as ONE persistent launch (pqn_cnn_rollout with
+            eps = EPS_TEST, nothing recorded but the info arrays), then the masked means (:403-412)."""
+            if not eval_buf:
+                z = lambda dt: torch.empty((steps, n_t), dtype=dt, device=dev)
+                eval_buf.update(keys=torch.empty(steps, dtype=torch.int64, device=dev),
+                                eps=torch.full((1,), float(config["EPS_TEST"]), dtype=torch.float32, device=dev),
+                                done=z(torch.uint8), discount=z(torch.float32), rer=z(torch.float32),
+                                rel=z(torch.int32), ts=z(torch.int32))
+            b = eval_buf
+            (_o, bits), state = env.reset(_lib.fold_in(k, 0), env_params, n_t, want_obs=False, want_bits=True)
+            _lib.check(lib.pqn_fold_in_range(k, 1, steps, _lib.ptr(b["keys"]), sp()), "pqn_fold_in_range")
+            rec = _lib.StepOut(done=_lib.ptr(b["done"]), discount=_lib.ptr(b["discount"]),
+                               returned_episode_returns=_lib.ptr(b["rer"]), returned_episode_lengths=_lib.ptr(b["rel"]),
+                               timestep=_lib.ptr(b["ts"]))
+            _lib.check(lib.pqn_cnn_rollout(base_env.env_id, C.byref(policy.layout.struct), n_t, steps,
+                                           _lib.ptr(state.words), _lib.ptr(bits), 0, _lib.ptr(policy.tr.theta),
+                                           C.byref(rec), None, None, None, _lib.ptr(b["eps"]), _lib.ptr(b["keys"]),
+                                           1.0, sp()), "pqn_cnn_rollout")
+            dm = b["done"].to(torch.float64)
+            cnt = dm.sum()
+            vals = {"discount": b["discount"], "returned_episode_returns": b["rer"], "returned_episode_lengths": b["rel"],
+                    "timestep": b["ts"], "returned_episode": b["done"]}
+            # nanmean(where(returned_episode, x, nan)) (:403-412)
+            return {kk: ((vals[kk].to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk in INFO_KEYS}
+
         def get_test_metrics():
             if not test_on:
                 return None
             k = _lib.fold_in(K_test, test_runs[0])
             test_runs[0] += 1
             n_t, steps = int(config["TEST_NUM_ENVS"]), int(config["TEST_NUM_STEPS"])
+            if packed:
+                return fused_test_metrics(k, n_t, steps)
             obs, state = env.reset(_lib.fold_in(k, 0), env_params, n_t, want_obs=not packed, want_bits=packed)
             if packed:
                 obs = obs[1]
