@@ -41,6 +41,35 @@ def workload_config(num_envs: int, mode: str):
     return cfg
 
 
+def multi_seed_rate(cfg, seeds, steps, warmup, dev):
+    """`seeds` independent runs of the bench workload (own parameters / optimizer / envs / keys), one HIP
+    stream each, update u of every seed enqueued round-robin (purejaxql_amd.pqn.vmap_train does the same):
+    aggregate env-steps/s.  Reported beside `value`, which stays the single-seed number."""
+    import torch
+    from purejaxql_amd.pqn import make_train, seed_keys
+    c = dict(cfg)
+    c.pop("_ENV_SHARD", None)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(seeds)]
+    runners = []
+    for s, key in zip(streams, seed_keys(1, seeds)):
+        with torch.cuda.stream(s):
+            runners.append(make_train(dict(c), device=str(dev)).make_runner(key)[0])
+
+    def rounds(lo, hi):
+        for u in range(lo, hi):
+            for s, upd in zip(streams, runners):
+                with torch.cuda.stream(s):
+                    upd(u)
+    rounds(0, warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rounds(warmup, warmup + steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"seeds_per_gpu": seeds, "value": seeds * steps * c["NUM_ENVS"] * c["NUM_STEPS"] / dt, "unit": "env-steps/s",
+            "ms_per_round": dt / steps * 1e3, "how": "one hipGraph replay per seed and update on its own HIP stream"}
+
+
 def cpu_baseline(cfg, theta0, max_seconds=45.0):
     """The CPU oracle (numpy/C restatement, kind="port") on one update of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -81,6 +110,9 @@ def main():
                     help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
                          "(RCCL gradient all-reduce per optimizer step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi-seed", type=int, default=4,
+                    help="N=1 only: also report the aggregate rate of this many independent seeds of the same workload "
+                         "on concurrent HIP streams (jax.vmap over seeds, pqn_minatar.py:459-461); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +225,8 @@ def main():
         if world == 1:
             from purejaxql_amd.profiling import env_step_hbm_roofline
             out["roofline_env_step"] = [env_step_hbm_roofline(n, dev) for n in (4096, 65536)]
+        if world == 1 and args.multi_seed > 1 and fused:
+            out["multi_seed"] = multi_seed_rate(cfg, args.multi_seed, args.steps, args.warmup, dev)
         if not args.no_cpu_baseline and world == 1:
             theta0 = finish()["runner_state"]["network"].init(1).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(cfg, theta0)

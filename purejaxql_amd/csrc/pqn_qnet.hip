@@ -193,8 +193,10 @@ PQN_D void conv_sample_to_stage(const ConvMfma<C> &cv, const uint32_t *row, uint
 }
 
 // phase 1: h1 tile [16 samples][64 pos * 16 ch] = relu(LN(conv)).  Wave w owns samples QN_SPW*w ...
-template <int C>
-PQN_D void phase1_conv(const CnnSmem &s, int tid) {
+// KEEP: also return the normalised activations xhat[sample][channel] and 1/std of this lane's point, which the
+// training kernel holds in registers until the LN0 backward (no conv recompute there).
+template <int C, bool KEEP = false>
+PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, float *rkeep = nullptr) {
   using Cfg = CnnCfg<C>;
   const int lane = tid & 63, wave = tid >> 6;
   ConvMfma<C> cv;
@@ -209,6 +211,11 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid) {
     conv_sample_to_stage<C>(cv, s.bits + m * Cfg::OW, wm, stg, bias, lane);
     float xhat[16], rstd;
     ln16_point(stg, lane, xhat, rstd);   // lane = position
+    if (KEEP) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xkeep[mm][c] = xhat[c];
+      rkeep[mm] = rstd;
+    }
     f32x4 *dst = reinterpret_cast<f32x4 *>(s.h1 + m * QN_H1S + lane * 16);
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -734,26 +741,36 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   float *gp = gpart + (size_t)blockIdx.x * rec;
   T1_STAMP(0);
 
-  // ---- P0: gather inputs -------------------------------------------------------------------
+  // ---- P0: gather inputs.  The permutation indices go out first, the parameter block is fetched while
+  // they are in flight, then the dependent gathers: two memory round trips instead of three. ----------
+  constexpr int NBI = (QN_TILE * Cfg::OW + QN_THREADS - 1) / QN_THREADS;
+  int64_t ix[NBI];
+#pragma unroll
+  for (int k = 0; k < NBI; ++k) {
+    const int i = tid + k * QN_THREADS, le = i / Cfg::OW;
+    ix[k] = (i < QN_TILE * Cfg::OW && b0 + le < nb) ? (idx[b0 + le] & 0xFFFFFFFFll) : -1;
+  }
+  const int64_t src16 = (tid < QN_TILE && b0 + tid < nb) ? (idx[b0 + tid] & 0xFFFFFFFFll) : -1;
   load_tile_common<C>(s, theta, L, tid);
-  for (int i = tid; i < QN_TILE * Cfg::OW; i += QN_THREADS) {
-    const int le = i / Cfg::OW, w = i - le * Cfg::OW;
-    s.bits[i] = (b0 + le < nb) ? obs_bits[(size_t)(idx[b0 + le] & 0xFFFFFFFFll) * Cfg::OW + w] : 0u;
+#pragma unroll
+  for (int k = 0; k < NBI; ++k) {
+    const int i = tid + k * QN_THREADS;
+    if (i < QN_TILE * Cfg::OW) s.bits[i] = (ix[k] >= 0) ? obs_bits[(size_t)ix[k] * Cfg::OW + (i % Cfg::OW)] : 0u;
   }
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
-  // action / target of the tile's samples: a two-level gather (idx -> transition), issued now so its
-  // latency hides behind the forward pass; parked in LDS after fc1
+  // action / target of the tile's samples (second level of the gather): consumed by the head, parked
+  // in LDS after fc1 so the latency hides behind the forward pass
   int act_g = 0;
   float tgt_g = 0.0f;
-  if (tid < QN_TILE && b0 + tid < nb) {
-    const int64_t src = idx[b0 + tid] & 0xFFFFFFFFll;
-    act_g = action[src];
-    tgt_g = target[src];
+  if (src16 >= 0) {
+    act_g = action[src16];
+    tgt_g = target[src16];
   }
   __syncthreads();
   T1_STAMP(1);
   // ---- P1..P3: forward ---------------------------------------------------------------------
-  phase1_conv<C>(s, tid);
+  float xkeep[QN_SPW][16], rkeep[QN_SPW];   // LN0 xhat / rstd of (sample QN_SPW*wave + mm, position lane): live until P5
+  phase1_conv<C, true>(s, tid, xkeep, rkeep);
   __syncthreads();
   T1_STAMP(2);
   phase2_fc1<0>(s, theta + L.off_w1, tid);
@@ -832,16 +849,12 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   }
   __syncthreads();
   T1_STAMP(5);
-  // ---- P5: LN0 backward.  conv recomputed (MFMA) and staged; LN stats + backward per point in one
-  // lane; channel sums (d conv-bias, d ln0-scale, d ln0-bias) in (channel = lane&15) layout. -----------
+  // ---- P5: LN0 backward per point in one lane (xhat / rstd kept in registers since the forward conv);
+  // channel sums (d conv-bias, d ln0-scale, d ln0-bias) in (channel = lane&15) layout. -----------
   if (!(ablate & 2)) {
-    ConvMfma<C> cv;
-    cv.init(s.wc, lane);
     const float *bc = s.wc + Cfg::KW * 16;
     const int o = lane & 15, kk = lane >> 4;
-    const float bias = bc[o];
     float *stg = s.stg + wave * 64 * QN_STG;
-    uint32_t *wm = reinterpret_cast<uint32_t *>(s.z) + wave * 192;   // dz tile is dead after the dgrad
     float gsc = 0.f, gbi = 0.f, gbc = 0.f;
 #pragma unroll
     for (int mm = 0; mm < QN_SPW; ++mm) {
@@ -849,9 +862,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       float *gt = s.h1 + msamp * QN_H1S;                 // d relu-input tile (masked by h1 > 0) -> dx in place
 #pragma unroll
       for (int j = 0; j < 16; ++j) gbi += gt[(kk + 4 * j) * 16 + o];
-      conv_sample_to_stage<C>(cv, s.bits + msamp * Cfg::OW, wm, stg, bias, lane);
-      float xhat[16], rstd;
-      ln16_point(stg, lane, xhat, rstd);
+      const float rstd = rkeep[mm];
       f32x4 *gptr = reinterpret_cast<f32x4 *>(gt + lane * 16);
       float g[16];
 #pragma unroll
@@ -864,7 +875,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       for (int c = 0; c < 16; ++c) {
         dxh[c] = g[c] * bc[16 + c];
         s1 += dxh[c];
-        s2 = fmaf(dxh[c], xhat[c], s2);
+        s2 = fmaf(dxh[c], xkeep[mm][c], s2);
       }
       s1 *= (1.0f / 16.0f);
       s2 *= (1.0f / 16.0f);
@@ -872,10 +883,10 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         f32x4 dx, gx;
-        dx.x = rstd * (dxh[4 * qd + 0] - s1 - xhat[4 * qd + 0] * s2); gx.x = g[4 * qd + 0] * xhat[4 * qd + 0];
-        dx.y = rstd * (dxh[4 * qd + 1] - s1 - xhat[4 * qd + 1] * s2); gx.y = g[4 * qd + 1] * xhat[4 * qd + 1];
-        dx.z = rstd * (dxh[4 * qd + 2] - s1 - xhat[4 * qd + 2] * s2); gx.z = g[4 * qd + 2] * xhat[4 * qd + 2];
-        dx.w = rstd * (dxh[4 * qd + 3] - s1 - xhat[4 * qd + 3] * s2); gx.w = g[4 * qd + 3] * xhat[4 * qd + 3];
+        dx.x = rstd * (dxh[4 * qd + 0] - s1 - xkeep[mm][4 * qd + 0] * s2); gx.x = g[4 * qd + 0] * xkeep[mm][4 * qd + 0];
+        dx.y = rstd * (dxh[4 * qd + 1] - s1 - xkeep[mm][4 * qd + 1] * s2); gx.y = g[4 * qd + 1] * xkeep[mm][4 * qd + 1];
+        dx.z = rstd * (dxh[4 * qd + 2] - s1 - xkeep[mm][4 * qd + 2] * s2); gx.z = g[4 * qd + 2] * xkeep[mm][4 * qd + 2];
+        dx.w = rstd * (dxh[4 * qd + 3] - s1 - xkeep[mm][4 * qd + 3] * s2); gx.w = g[4 * qd + 3] * xkeep[mm][4 * qd + 3];
         gptr[qd] = dx;
         sp[qd] = gx;
       }
