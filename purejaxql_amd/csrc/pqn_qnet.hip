@@ -95,11 +95,17 @@ PQN_D float group16_sum(float v) {
 template <int C>
 PQN_D void window_masks(const uint32_t *row_bits, uint32_t *wm, int pos) {
   const int py = pos >> 3, px = pos & 7;
+  uint32_t lo[3], hi[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {   // all six LDS reads in flight before the first (possibly aliasing) store
+    const int w = (((py + ky) * 10 + px) * C) >> 5;
+    lo[ky] = row_bits[w];
+    hi[ky] = row_bits[w + 1];
+  }
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
-    const int sb = ((py + ky) * 10 + px) * C;
-    const int w = sb >> 5, sh = sb & 31;
-    const uint64_t v = (((uint64_t)row_bits[w + 1] << 32) | row_bits[w]) >> sh;
+    const int sh = (((py + ky) * 10 + px) * C) & 31;
+    const uint64_t v = (((uint64_t)hi[ky] << 32) | lo[ky]) >> sh;
     wm[pos * 3 + ky] = (uint32_t)v & ((1u << (3 * C)) - 1u);
   }
 }
@@ -235,7 +241,7 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, 
 // B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+reg.
 // ---------------------------------------------------------------------------
 // ablate: 0 = normal; 2 = no global B loads; 3 = no MFMA (loads only).  Profiling hook.
-template <int ABL = 0>
+template <int ABL = 0, int PF = 16>   // PF: K groups in flight per wave (16 KB at 16: covers an L2-miss round trip)
 PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) {
   constexpr int CBW = 8 / QN_WAVES > 0 ? 8 / QN_WAVES : 1;  // column blocks per wave
   static_assert(QN_WAVES * CBW == 8, "8 column blocks of 16 outputs");
@@ -252,7 +258,6 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) 
   f32x4 acc[CBW], acc2[CBW];
 #pragma unroll
   for (int c = 0; c < CBW; ++c) { acc[c] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  constexpr int PF = 16;   // K groups in flight per wave (16 KB): covers an L2-miss round trip
   f32x4 b[PF][CBW];
 #pragma unroll
   for (int i = 0; i < PF; ++i)
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
     __syncthreads();   // s.bits holds obs_t of the tile (and every previous reader of the tiles is done)
     phase1_conv<C>(s, tid);
     __syncthreads();
-    phase2_fc1<0>(s, theta + L.off_w1, tid);
+    phase2_fc1<0, 8>(s, theta + L.off_w1, tid);   // 8 in flight: the env state lives in registers across this loop
     __syncthreads();
     if (tid < 256) {
       float q[QN_MAXA], h2[8], xh[8], rstd;
@@ -852,7 +857,9 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   // ---- P5: LN0 backward per point in one lane (xhat / rstd kept in registers since the forward conv);
   // channel sums (d conv-bias, d ln0-scale, d ln0-bias) in (channel = lane&15) layout. -----------
   if (!(ablate & 2)) {
-    const float *bc = s.wc + Cfg::KW * 16;
+    float ln0s[16];                                      // LayerNorm_0 scale: wave-uniform scalar loads
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ln0s[c] = theta[L.off_ln0s + c];
     const int o = lane & 15, kk = lane >> 4;
     float *stg = s.stg + wave * 64 * QN_STG;
     float gsc = 0.f, gbi = 0.f, gbc = 0.f;
@@ -873,7 +880,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       float s1 = 0.f, s2 = 0.f, dxh[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        dxh[c] = g[c] * bc[16 + c];
+        dxh[c] = g[c] * ln0s[c];
         s1 += dxh[c];
         s2 = fmaf(dxh[c], xkeep[mm][c], s2);
       }
@@ -940,7 +947,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 #pragma unroll
     for (int j = 0; j < RBW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     uint32_t *wm = reinterpret_cast<uint32_t *>(s.stg + wave * 64 * QN_STG);   // staging buffer is free now
-#pragma unroll 1
+#pragma unroll
     for (int mm = 0; mm < SPW6; ++mm) {
       const int msamp = SPW6 * sg + mm;
       window_masks<C>(s.bits + msamp * Cfg::OW, wm, lane);
