@@ -93,7 +93,18 @@ def cpu_baseline(cfg, theta0, max_seconds=45.0):
     t0 = time.perf_counter()
     train(12345, theta0, max_updates=1)
     dt = time.perf_counter() - t0
+    # env-only rate (uniform-random actions, no network): the C oracle's OpenMP env.step + auto-reset + LogWrapper
+    env = oracle.OracleEnv(ocfg["ENV_NAME"])
+    _obs, st = env.reset(1, sample_envs)
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, env.num_actions, size=(50, sample_envs)).astype(np.int32)
+    env.step(2, st, acts[0])
+    t1 = time.perf_counter()
+    for i in range(50):
+        _o, st, _r, _d, _info = env.step(100 + i, st, acts[i])
+    env_only = 50 * sample_envs / (time.perf_counter() - t1)
     return {"value": sample_envs * t / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "env_only_env_steps_per_s": env_only,
             "sample": f"1 full PQN update (rollout+Q(lambda)+{ocfg['NUM_EPOCHS']}x{ocfg['NUM_MINIBATCHES']} SGD steps) "
                       f"at NUM_ENVS={sample_envs}, NUM_STEPS={t}: {sample_envs * t} env-steps in {dt:.1f}s; "
                       "oracle/pqn_oracle.py (C env/eps-greedy/Q(lambda)/RAdam + numpy-BLAS network), not JAX; "
@@ -103,8 +114,8 @@ def cpu_baseline(cfg, theta0, max_seconds=45.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)    # 20 warm-up updates, then >= 200 timed
+    ap.add_argument("--warmup", type=int, default=20)    # (2.6e7 env-steps between the two stream syncs, ~1 s)
     ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--mode", default="seeds", choices=["seeds", "envs"],
                     help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
