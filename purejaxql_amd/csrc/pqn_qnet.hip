@@ -182,22 +182,6 @@ PQN_D void ln16_point(const float *stg, int p, float (&xhat)[16], float &rstd) {
   for (int o = 0; o < 16; ++o) xhat[o] = (v[o] - mean) * rstd;
 }
 
-// conv output (+bias) of all 64 positions of one sample -> this wave's staging buffer.
-// wm: this wave's [64][3] window-mask table (filled here, lane = position).
-template <int C>
-PQN_D void conv_sample_to_stage(const ConvMfma<C> &cv, const uint32_t *row, uint32_t *wm, float *stg, float bias,
-                                int lane) {
-  window_masks<C>(row, wm, lane);
-  const int i = lane & 15;
-#pragma unroll
-  for (int pb = 0; pb < 4; pb += 2) {
-    f32x4 dA, dB;
-    cv.tile2(wm, 16 * pb + i, 16 * pb + 16 + i, dA, dB);
-    stage_tile(stg, 16 * pb, dA, bias, lane);
-    stage_tile(stg, 16 * pb + 16, dB, bias, lane);
-  }
-}
-
 // phase 1: h1 tile [16 samples][64 pos * 16 ch] = relu(LN(conv)).  Wave w owns samples QN_SPW*w ...
 // KEEP: also return the normalised activations xhat[sample][channel] and 1/std of this lane's point, which the
 // training kernel holds in registers until the LN0 backward (no conv recompute there).
@@ -211,10 +195,23 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, 
   const float bias = bc[lane & 15];
   float *stg = s.stg + wave * 64 * QN_STG;
   uint32_t *wm = reinterpret_cast<uint32_t *>(s.z) + wave * 192;   // z tile is not live yet
+  // Software pipeline over the wave's samples: the conv MFMAs of sample mm+1 are issued before the
+  // LayerNorm / store of sample mm (VALU + LDS only), so the matrix core works in the shadow of the
+  // VALU phase instead of idling while both waves of the SIMD normalise.
+  const int i = lane & 15;
+  f32x4 d[2][4];
+  auto conv_mfma = [&](int mm, f32x4(&out)[4]) {
+    window_masks<C>(s.bits + (QN_SPW * wave + mm) * Cfg::OW, wm, lane);
+    cv.tile2(wm, i, 16 + i, out[0], out[1]);
+    cv.tile2(wm, 32 + i, 48 + i, out[2], out[3]);
+  };
+  conv_mfma(0, d[0]);
 #pragma unroll
   for (int mm = 0; mm < QN_SPW; ++mm) {
     const int m = QN_SPW * wave + mm;
-    conv_sample_to_stage<C>(cv, s.bits + m * Cfg::OW, wm, stg, bias, lane);
+    if (mm + 1 < QN_SPW) conv_mfma(mm + 1, d[(mm + 1) & 1]);
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) stage_tile(stg, 16 * pb, d[mm & 1][pb], bias, lane);
     float xhat[16], rstd;
     ln16_point(stg, lane, xhat, rstd);   // lane = position
     if (KEEP) {
