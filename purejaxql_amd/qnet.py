@@ -68,6 +68,33 @@ def cnn_forward(layout: CnnKernelLayout, obs_bits: torch.Tensor, theta_k: torch.
     return q, action, qmax
 
 
+def cnn_rollout(layout: CnnKernelLayout, env_id: int, state_words: torch.Tensor, obs_bits: torch.Tensor,
+                theta_k: torch.Tensor, keys: torch.Tensor, eps: torch.Tensor, *, store_obs: bool = True,
+                rew_scale: float = 1.0, want_last_q: bool = True):
+    """jax.lax.scan(_step_env) + bootstrap forward (pqn_minatar.py:181-235) as ONE persistent launch
+    (pqn_cnn_rollout).  state_words u32[W][N] is advanced in place; obs_bits is [T+1][N][OW] (slot 0 = the
+    current observation) when store_obs else [1][N][OW]; keys int64[T] device step keys; eps f32[1] device.
+    Returns the [T][N] transition record."""
+    lib = _lib.load()
+    t = int(keys.shape[0])
+    n = int(state_words.shape[1])
+    dev = state_words.device
+    z = lambda dt: torch.empty((t, n), dtype=dt, device=dev)
+    rec = {"action": z(torch.int32), "qmax": z(torch.float32), "reward": z(torch.float32), "done": z(torch.uint8),
+           "discount": z(torch.float32), "returned_episode_returns": z(torch.float32),
+           "returned_episode_lengths": z(torch.int32), "timestep": z(torch.int32),
+           "last_q": torch.empty(n, dtype=torch.float32, device=dev) if want_last_q else None}
+    out = _lib.StepOut(reward=_lib.ptr(rec["reward"]), done=_lib.ptr(rec["done"]), discount=_lib.ptr(rec["discount"]),
+                       returned_episode_returns=_lib.ptr(rec["returned_episode_returns"]),
+                       returned_episode_lengths=_lib.ptr(rec["returned_episode_lengths"]),
+                       timestep=_lib.ptr(rec["timestep"]))
+    _lib.check(lib.pqn_cnn_rollout(env_id, C.byref(layout.struct), n, t, _lib.ptr(state_words), _lib.ptr(obs_bits),
+                                   1 if store_obs else 0, _lib.ptr(theta_k), C.byref(out), _lib.ptr(rec["action"]),
+                                   _lib.ptr(rec["qmax"]), _lib.ptr(rec["last_q"]), _lib.ptr(eps), _lib.ptr(keys),
+                                   float(rew_scale), _lib.stream_ptr()), "pqn_cnn_rollout")
+    return rec
+
+
 class CnnTrainer:
     """Parameters + RAdam state of one seed in kernel layout, and the fused optimizer step
     (train_state.apply_gradients of pqn_minatar.py:289-296) = pqn_qnet_cnn_grad + pqn_qnet_cnn_apply."""

@@ -155,3 +155,66 @@ def test_mlp_forward_and_grad_vs_oracle(gpu, oracle, d, h, layers, a, n):
     if layers > 1:   # transposed hidden kernels track theta
         w1 = _np(tr.theta)[lay.struct.off_w[1]:lay.struct.off_w[1] + h * h].reshape(h, h)
         np.testing.assert_array_equal(_np(tr.wt)[:h * h].reshape(h, h), w1.T)
+
+
+@pytest.mark.parametrize("name,c,a,n,t", [("Breakout-MinAtar", 4, 3, 37, 6), ("Breakout-MinAtar", 4, 3, 256, 40),
+                                          ("Asterix-MinAtar", 4, 5, 50, 12), ("Freeway-MinAtar", 7, 3, 33, 8),
+                                          ("SpaceInvaders-MinAtar", 6, 4, 20, 10)])
+def test_cnn_rollout_equals_step_by_step(gpu, name, c, a, n, t):
+    """pqn_cnn_rollout (persistent scan) == T x (pqn_qnet_cnn_forward with eps-greedy, pqn_env_step) with the
+    same step keys: actions, rewards, dones, LogWrapper info, packed observations and final env state
+    bit-exact; max_a Q to f32 round-off (same kernel code, so in practice identical)."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.envs import LogWrapper, make
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward, cnn_rollout
+    lib = _lib.load()
+    env, params = make(name, device=gpu)
+    env = LogWrapper(env)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    lay = CnnKernelLayout(c, a)
+    theta_k = lay.to_kernel(net.init(3) + 0.05 * torch.randn(net.num_params, device=gpu))
+    (_o, bits0), state = env.reset(11, params, n, want_obs=False, want_bits=True)
+    # play in a little so episodes end inside the window
+    for i in range(30):
+        (_o, bits0), state, *_ = env.step(500 + i, state, torch.randint(0, a, (n,), dtype=torch.int32, device=gpu), params,
+                                          want_obs=False, want_bits=True)
+    K = 0x1234567
+    keys = torch.empty(t, dtype=torch.int64, device=gpu)
+    _lib.check(lib.pqn_fold_in_range(K, 7, t, _lib.ptr(keys), _lib.stream_ptr()), "pqn_fold_in_range")
+    assert [int(k) & 0xFFFFFFFFFFFFFFFF for k in keys.tolist()] == [_lib.fold_in(K, 7 + i) for i in range(t)]
+    eps = torch.full((1,), 0.3, dtype=torch.float32, device=gpu)
+
+    # fused scan
+    words_a = state.words.clone()
+    ow = bits0.shape[1]
+    bits_a = torch.zeros((t + 1, n, ow), dtype=bits0.dtype, device=gpu)
+    bits_a[0] = bits0
+    rec = cnn_rollout(lay, env.env_id if hasattr(env, "env_id") else env._env.env_id, words_a, bits_a, theta_k, keys, eps)
+
+    # step by step
+    st = state
+    bits = bits0
+    for i in range(t):
+        k = _lib.fold_in(K, 7 + i)
+        _q, act, qmax = cnn_forward(lay, bits, theta_k, want_q=False, eps=0.3, key=k)
+        (_o, bits), st, r, d, info = env.step(k, st, act, params, want_obs=False, want_bits=True)
+        assert torch.equal(rec["action"][i], act), i
+        torch.testing.assert_close(rec["qmax"][i], qmax, rtol=1e-6, atol=1e-6)
+        assert torch.equal(rec["reward"][i], r) and torch.equal(rec["done"][i].bool(), d.bool()), i
+        assert torch.equal(rec["returned_episode_returns"][i], info["returned_episode_returns"])
+        assert torch.equal(rec["returned_episode_lengths"][i], info["returned_episode_lengths"].to(torch.int32))
+        assert torch.equal(rec["timestep"][i], info["timestep"].to(torch.int32))
+        assert torch.equal(rec["discount"][i], info["discount"])
+        assert torch.equal(bits_a[i + 1], bits), i
+    assert torch.equal(words_a, st.words)
+    _q, _a, last = cnn_forward(lay, bits, theta_k, want_q=False)
+    torch.testing.assert_close(rec["last_q"], last, rtol=1e-6, atol=1e-6)
+    assert rec["done"].sum() > 0 or t < 10
+
+    # evaluation mode: nothing recorded but the running observation
+    words_b = state.words.clone()
+    bits_b = bits0.clone().unsqueeze(0)
+    rec_b = cnn_rollout(lay, env.env_id if hasattr(env, "env_id") else env._env.env_id, words_b, bits_b, theta_k, keys, eps,
+                        store_obs=False, want_last_q=False)
+    assert torch.equal(words_b, st.words) and torch.equal(bits_b[0], bits) and torch.equal(rec_b["done"], rec["done"])
