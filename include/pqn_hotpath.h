@@ -279,6 +279,41 @@ int pqn_mlp_apply(const pqn_mlp_layout_t *layout /* host */, float *theta, float
                   float *workspace, float *gnorm_out, int32_t recompute_norm, void *stream);
 int pqn_mlp_refresh_transposed(const pqn_mlp_layout_t *layout /* host */, const float *theta, float *wt, void *stream);
 
+/* ONE whole update of the gymnax-classic loop (`_update_step`, pqn_gymnax.py:167-360) enqueued from C++ -- the MLP
+ * twin of pqn_cnn_update, same device-side clock / key schedule / metrics row (env_frame is written as env_step),
+ * hipGraph-capturable.  Observations are f32: obs[T+1][N][D], slot 0 = current observation on entry and exit. */
+typedef struct {
+  int32_t env_id, num_envs, num_steps, num_minibatches, num_epochs, metrics_capacity;
+  float gamma, lambda, rew_scale;
+  float eps_start, eps_finish, eps_decay_steps;
+  float lr_init, lr_end, lr_steps, max_grad_norm;
+  uint64_t key_roll, key_shuf;
+  uint64_t sort_temp_bytes;
+  pqn_mlp_layout_t layout;
+  int32_t *clock;        /* [4] */
+  uint64_t *sched_keys;  /* [num_steps + num_epochs] scratch */
+  float *sched_eps;      /* [1] scratch */
+  uint32_t *state;       /* [state_words][N] */
+  float *obs;            /* [T+1][N][D] */
+  int32_t *action;       /* [T][N] */
+  float *reward;         /* [T][N] (scaled by rew_scale) */
+  uint8_t *done;         /* [T][N] */
+  float *qmax;           /* [T][N] */
+  float *discount, *rer; /* [T][N] */
+  int32_t *rel, *ts;     /* [T][N] */
+  float *target;         /* [T][N] */
+  float *last_q;         /* [N] */
+  int64_t *sort_keys_in, *sort_keys_out; /* [T*N] */
+  void *sort_temp;       /* pqn_update_sort_temp_bytes(T*N) bytes */
+  float *theta, *wt, *grad, *m, *v; /* kernel-layout buffers (pqn_mlp_layout); wt as for pqn_mlp_grad */
+  int32_t *count;        /* [1] */
+  float *workspace;      /* pqn_mlp_workspace_floats(layout, T*N/num_minibatches) */
+  float *loss_buf, *qv_buf; /* [num_minibatches*num_epochs] */
+  double *metrics;       /* [metrics_capacity][PQN_NUM_METRICS] */
+} pqn_mlp_update_args_t;
+
+int pqn_mlp_update(const pqn_mlp_update_args_t *args /* host */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

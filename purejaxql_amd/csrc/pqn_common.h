@@ -86,6 +86,8 @@ int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStrea
 int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *obs_bits, const float *theta, float *q,
                              int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
                              const uint64_t *key_dev, hipStream_t st);
+int pqn_mlp_forward_dyn(const pqn_mlp_layout_t &L, int n, const float *obs, const float *theta, float *q, int32_t *action,
+                        float *qmax, float eps, uint64_t key, const float *eps_dev, const uint64_t *key_dev, hipStream_t st);
 int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
                          const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
                          const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st);

@@ -172,3 +172,75 @@ extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
                      partial, a->metrics, a->metrics_capacity);
   return pqn_check_launch("pqn_cnn_update");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The gymnax-classic twin (pqn_gymnax.py:167-360): f32 observations, MLP Q-network kernels (pqn_mlp.hip).
+// Per rollout step two launches (forward + eps-greedy, env.step); everything else as above.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int pqn_mlp_update(const pqn_mlp_update_args_t *a, void *stream) {
+  PQN_REQUIRE(a, "pqn_mlp_update: args is NULL");
+  PQN_REQUIRE(a->clock && a->sched_keys && a->sched_eps && a->state && a->obs && a->action && a->reward && a->done &&
+                  a->qmax && a->discount && a->rer && a->rel && a->ts && a->target && a->last_q && a->sort_keys_in &&
+                  a->sort_keys_out && a->sort_temp && a->theta && a->grad && a->m && a->v && a->count && a->workspace &&
+                  a->loss_buf && a->qv_buf && a->metrics,
+              "pqn_mlp_update: NULL buffer in args");
+  const int N = a->num_envs, T = a->num_steps, MB = a->num_minibatches, EP = a->num_epochs;
+  PQN_REQUIRE(N > 0 && T > 0 && MB > 0 && EP > 0 && T + EP <= 1024, "pqn_mlp_update: bad shape N=%d T=%d MB=%d EP=%d", N, T,
+              MB, EP);
+  PQN_REQUIRE(((int64_t)N * T) % MB == 0, "NUM_MINIBATCHES must divide NUM_STEPS*NUM_ENVS");
+  const int B = (int)(((int64_t)N * T) / MB);
+  hipStream_t st = (hipStream_t)stream;
+  const pqn_mlp_layout_t &L = a->layout;
+  PQN_REQUIRE(L.layers == 1 || a->wt, "pqn_mlp_update: transposed hidden kernels (wt) required for NUM_LAYERS > 1");
+  const size_t ostride = (size_t)N * L.d;
+
+  hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, T, EP, a->eps_start,
+                     a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
+  // SAMPLE PHASE (_step_env scan, pqn_gymnax.py:172-211)
+  for (int t = 0; t < T; ++t) {
+    const size_t o = (size_t)t * N;
+    UPD_CHECK(pqn_mlp_forward_dyn(L, N, a->obs + t * ostride, a->theta, nullptr, a->action + o, a->qmax + o, 0.0f, 0,
+                                  a->sched_eps, a->sched_keys + t, st));
+    pqn_step_out_t out = {};
+    out.obs = a->obs + (t + 1) * ostride;
+    out.reward = a->reward + o;
+    out.done = a->done + o;
+    out.discount = a->discount + o;
+    out.returned_episode_returns = a->rer + o;
+    out.returned_episode_lengths = a->rel + o;
+    out.timestep = a->ts + o;
+    UPD_CHECK(pqn_env_step_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->state, a->action + o, out, st));
+  }
+  // bootstrap value of the last observation (:218-226) and Q(lambda) targets (:228-251)
+  UPD_CHECK(pqn_mlp_forward_dyn(L, N, a->obs + T * ostride, a->theta, nullptr, nullptr, a->last_q, 0.0f, 0, nullptr, nullptr,
+                                st));
+  UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, N, 1, a->target, st));
+  // NETWORKS UPDATE (:254-318)
+  int i_mb = 0;
+  for (int ep = 0; ep < EP; ++ep) {
+    UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, N * T, a->sort_keys_in, st));
+    size_t tb = (size_t)a->sort_temp_bytes;
+    if (hipcub::DeviceRadixSort::SortKeys(a->sort_temp, tb, (const unsigned long long *)a->sort_keys_in,
+                                          (unsigned long long *)a->sort_keys_out, N * T, 0, 63, st) != hipSuccess) {
+      pqn_set_error("pqn_mlp_update: radix sort failed (temp bytes %llu)", (unsigned long long)a->sort_temp_bytes);
+      return PQN_E_HIP;
+    }
+    for (int mb = 0; mb < MB; ++mb, ++i_mb) {
+      UPD_CHECK(pqn_mlp_grad(&L, B, a->sort_keys_out + (size_t)mb * B, a->obs, a->action, a->target, a->theta, a->wt, a->grad,
+                             a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, st));
+      UPD_CHECK(pqn_mlp_apply(&L, a->theta, a->wt, a->grad, a->m, a->v, a->count, a->lr_init, a->lr_end, a->lr_steps,
+                              a->max_grad_norm, a->workspace, nullptr, 0, st));
+    }
+  }
+  if (hipMemcpyAsync(a->obs, a->obs + (size_t)T * ostride, ostride * sizeof(float), hipMemcpyDeviceToDevice, st) !=
+      hipSuccess) {
+    pqn_set_error("pqn_mlp_update: hipMemcpyAsync failed");
+    return PQN_E_HIP;
+  }
+  double *partial = reinterpret_cast<double *>(a->workspace);  // first 1024 floats: optimizer scratch, idle here
+  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS), dim3(256), 0, st, N * T, a->discount, a->rer, a->rel,
+                     a->ts, a->done, partial);
+  hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, 1, MB * EP, a->loss_buf, a->qv_buf,
+                     partial, a->metrics, a->metrics_capacity);
+  return pqn_check_launch("pqn_mlp_update");
+}

@@ -326,26 +326,31 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             n_t, steps = int(config["TEST_NUM_ENVS"]), int(config["TEST_NUM_STEPS"])
             if packed:
                 return fused_test_metrics(k, n_t, steps)
-            obs, state = env.reset(_lib.fold_in(k, 0), env_params, n_t, want_obs=not packed, want_bits=packed)
-            if packed:
-                obs = obs[1]
-            action = torch.empty(n_t, dtype=torch.int32, device=dev)
-            qm = torch.empty(n_t, dtype=torch.float32, device=dev)
-            sums = {kk: torch.zeros((), dtype=torch.float64, device=dev) for kk in INFO_KEYS}
-            cnt = torch.zeros((), dtype=torch.float64, device=dev)
+            # flat-observation path: per step one forward(+eps-greedy) and one env.step launch writing straight
+            # into row t of the [steps, n] info record; the masked means are taken once at the end
+            if "done" not in eval_buf:
+                z = lambda dt: torch.empty((steps, n_t), dtype=dt, device=dev)
+                eval_buf.update(done=z(torch.uint8), discount=z(torch.float32), rer=z(torch.float32),
+                                rel=z(torch.int32), ts=z(torch.int32), reward=torch.empty(n_t, dtype=torch.float32, device=dev),
+                                action=torch.empty(n_t, dtype=torch.int32, device=dev),
+                                qm=torch.empty(n_t, dtype=torch.float32, device=dev),
+                                obs=torch.empty((2, n_t, *obs_shape), dtype=torch.float32, device=dev))
+            b = eval_buf
+            obs0, state = env.reset(_lib.fold_in(k, 0), env_params, n_t)
+            b["obs"][0].copy_(obs0)
+            words_t = state.words
             for t in range(steps):
                 sk = _lib.fold_in(k, 1 + t)
-                policy.act(obs, config["EPS_TEST"], sk, action, qm)
-                obs, state, _r, done, info = env.step(sk, state, action, env_params, inplace=True,
-                                                      want_obs=not packed, want_bits=packed)
-                if packed:
-                    obs = obs[1]
-                dm = done.to(torch.float64)
-                cnt += dm.sum()
-                for kk in INFO_KEYS:
-                    sums[kk] += (info[kk].to(torch.float64) * dm).sum()
+                cur, nxt = b["obs"][t & 1], b["obs"][(t + 1) & 1]
+                policy.act(cur, config["EPS_TEST"], sk, b["action"], b["qm"])
+                env_step_into(sk, words_t, b["action"], nxt, None, b["reward"], b["done"][t], b["discount"][t],
+                              b["rer"][t], b["rel"][t], b["ts"][t])
+            dm = b["done"].to(torch.float64)
+            cnt = dm.sum()
+            vals = {"discount": b["discount"], "returned_episode_returns": b["rer"], "returned_episode_lengths": b["rel"],
+                    "timestep": b["ts"], "returned_episode": b["done"]}
             # nanmean(where(returned_episode, x, nan)) (:403-412)
-            return {kk: (sums[kk] / cnt).to(torch.float32) for kk in INFO_KEYS}
+            return {kk: ((vals[kk].to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk in INFO_KEYS}
 
         tm_box = [get_test_metrics()]
 
@@ -368,9 +373,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         test_period = int(NUM_UPDATES * config["TEST_INTERVAL"]) if test_on else 0
         flat_shape = (T * N, base_env.obs_words) if packed else (T * N, *obs_shape)
 
-        # whole-update C++ enqueue (+ hipGraph replay): the MinAtar CNN path without a gradient hook
+        # whole-update C++ enqueue (+ hipGraph replay): the fused CNN / MLP paths without a gradient hook
         driver = None
-        if packed and grad_hook is None and config.get("_DRIVER", True):
+        if backend == "fused" and grad_hook is None and config.get("_DRIVER", True):
             from .qnet import UpdateDriver
             dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
                     "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}

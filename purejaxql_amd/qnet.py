@@ -167,14 +167,15 @@ METRIC_NAMES = ("env_step", "update_steps", "env_frame", "grad_steps", "td_loss"
 
 
 class UpdateDriver:
-    """Whole-update enqueue (pqn_cnn_update) with optional hipGraph replay.  Holds the scratch buffers the
-    C side needs; all training buffers are the caller's (rollout record, CnnTrainer)."""
+    """Whole-update enqueue (pqn_cnn_update / pqn_mlp_update) with optional hipGraph replay.  Holds the scratch
+    buffers the C side needs; all training buffers are the caller's (rollout record, Cnn/MlpTrainer)."""
 
-    def __init__(self, env_id, n, t, mb, epochs, obs_words, cfg, keys, trainer: CnnTrainer, ro, words, num_updates,
+    def __init__(self, env_id, n, t, mb, epochs, obs_words, cfg, keys, trainer, ro, words, num_updates,
                  use_graph: bool = True):
         lib = _lib.load()
         dev = trainer.theta.device
         self.dev = dev
+        self.mlp = isinstance(trainer, MlpTrainer)
         tn = n * t
         self.clock = torch.zeros(4, dtype=torch.int32, device=dev)
         self.sched_keys = torch.zeros(t + epochs, dtype=torch.int64, device=dev)
@@ -189,9 +190,9 @@ class UpdateDriver:
         self.qv_buf = torch.zeros(mb * epochs, dtype=torch.float32, device=dev)
         self.metrics = torch.zeros((max(num_updates, 1), len(METRIC_NAMES)), dtype=torch.float64, device=dev)
         trainer._ensure_ws(tn // mb)
-        a = UpdateArgs()
+        a = MlpUpdateArgs() if self.mlp else UpdateArgs()
         a.env_id, a.num_envs, a.num_steps, a.num_minibatches, a.num_epochs = env_id, n, t, mb, epochs
-        a.obs_words, a.metrics_capacity = obs_words, self.metrics.shape[0]
+        a.metrics_capacity = self.metrics.shape[0]
         a.gamma, a.lam, a.rew_scale = cfg["gamma"], cfg["lam"], cfg["rew_scale"]
         a.eps_start, a.eps_finish, a.eps_decay_steps = cfg["eps_start"], cfg["eps_finish"], cfg["eps_decay_steps"]
         a.lr_init, a.lr_end, a.lr_steps, a.max_grad_norm = trainer.lr, trainer.lr_end, trainer.lr_steps, trainer.max_norm
@@ -200,12 +201,16 @@ class UpdateDriver:
         a.layout = trainer.layout.struct
         p = _lib.ptr
         a.clock, a.sched_keys, a.sched_eps = p(self.clock), p(self.sched_keys), p(self.sched_eps)
-        a.state, a.bits = p(words), p(ro.bits)
+        a.state = p(words)
+        if self.mlp:
+            a.obs, a.wt = p(ro.obs), p(trainer.wt)
+        else:
+            a.obs_words, a.bits, a.w1b = obs_words, p(ro.bits), p(trainer.w1b)
         a.action, a.reward, a.done, a.qmax = p(ro.action), p(ro.reward), p(ro.done), p(ro.qmax)
         a.discount, a.rer, a.rel, a.ts = p(ro.discount), p(ro.rer), p(ro.rel), p(ro.ts)
         a.target, a.last_q = p(ro.target), p(ro.last_q)
         a.sort_keys_in, a.sort_keys_out, a.sort_temp = p(self.sk_in), p(self.sk_out), p(self.sort_temp)
-        a.theta, a.w1b, a.grad, a.m, a.v = p(trainer.theta), p(trainer.w1b), p(trainer.grad), p(trainer.m), p(trainer.v)
+        a.theta, a.grad, a.m, a.v = p(trainer.theta), p(trainer.grad), p(trainer.m), p(trainer.v)
         a.count, a.workspace = p(trainer.count), p(trainer.ws)
         a.loss_buf, a.qv_buf, a.metrics = p(self.loss_buf), p(self.qv_buf), p(self.metrics)
         self.args = a
@@ -216,7 +221,11 @@ class UpdateDriver:
         self.calls = 0
 
     def _enqueue(self):
-        _lib.check(_lib.load().pqn_cnn_update(C.byref(self.args), _lib.stream_ptr()), "pqn_cnn_update")
+        lib = _lib.load()
+        if self.mlp:
+            _lib.check(lib.pqn_mlp_update(C.byref(self.args), _lib.stream_ptr()), "pqn_mlp_update")
+        else:
+            _lib.check(lib.pqn_cnn_update(C.byref(self.args), _lib.stream_ptr()), "pqn_cnn_update")
 
     def update(self):
         """Enqueue (or replay) one update; the update index lives on the device (self.clock[0])."""
@@ -245,6 +254,20 @@ class MlpLayoutStruct(C.Structure):
     _fields_ = [("d", C.c_int32), ("h", C.c_int32), ("layers", C.c_int32), ("a", C.c_int32), ("off_bn", C.c_int32),
                 ("off_w", C.c_int32 * 4), ("off_b", C.c_int32 * 4), ("off_lns", C.c_int32 * 4),
                 ("off_lnb", C.c_int32 * 4), ("off_wout", C.c_int32), ("off_bout", C.c_int32), ("total", C.c_int32)]
+
+
+class MlpUpdateArgs(C.Structure):
+    """pqn_mlp_update_args_t (include/pqn_hotpath.h)"""
+    _fields_ = ([(n, C.c_int32) for n in ("env_id", "num_envs", "num_steps", "num_minibatches", "num_epochs",
+                                           "metrics_capacity")] +
+                [(n, C.c_float) for n in ("gamma", "lam", "rew_scale", "eps_start", "eps_finish", "eps_decay_steps",
+                                          "lr_init", "lr_end", "lr_steps", "max_grad_norm")] +
+                [(n, C.c_uint64) for n in ("key_roll", "key_shuf", "sort_temp_bytes")] +
+                [("layout", MlpLayoutStruct)] +
+                [(n, C.c_void_p) for n in ("clock", "sched_keys", "sched_eps", "state", "obs", "action", "reward",
+                                           "done", "qmax", "discount", "rer", "rel", "ts", "target", "last_q",
+                                           "sort_keys_in", "sort_keys_out", "sort_temp", "theta", "wt", "grad", "m",
+                                           "v", "count", "workspace", "loss_buf", "qv_buf", "metrics")])
 
 
 class MlpKernelLayout:

@@ -318,7 +318,7 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     train = make_train(cfg, device="cuda:0")
     assert train.backend == extra.get("_BACKEND", "fused")
     out = train(key)
-    if train.backend == "fused" and kind == "cnn" and extra.get("_DRIVER", True):
+    if train.backend == "fused" and extra.get("_DRIVER", True):
         want = "eager" if extra.get("_GRAPH", True) is False else "graph"
         assert out["runner_state"]["driver"] == want, out["runner_state"]["driver_graph_error"]
     oout = otrain(key, _np(theta0))

@@ -86,3 +86,30 @@ def test_single_run_saves_reference_format_checkpoints(gpu, tmp_path):
     net = QNetwork("cnn", (10, 10, 4), 3, device=gpu)
     theta = params_to_theta(net, p)
     torch.testing.assert_close(theta, outs["runner_state"][1]["theta"].cpu(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("backend", ["fused", "torch"])
+def test_eval_metrics_flat_obs_path_vs_oracle(gpu, oracle, backend):
+    """get_test_metrics on the gymnax-classic path (pqn_gymnax.py:362-404): CartPole-v1, fused MLP kernels and
+    torch-op network, vs the oracle loop (greedy policy, TEST_NUM_STEPS steps, done-masked means)."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.pqn import make_train, seed_keys
+    cfg = flatten(load_config(["+alg=pqn_cartpole"]))
+    cfg.update({"NUM_ENVS": 8, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2, "TOTAL_TIMESTEPS": 2 * 8 * 16,
+                "TOTAL_TIMESTEPS_DECAY": 40 * 8 * 16, "TEST_DURING_TRAINING": True, "TEST_INTERVAL": 0.5,
+                "TEST_NUM_ENVS": 16, "TEST_NUM_STEPS": 120, "_BACKEND": backend})
+    ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+    key = seed_keys(2, 1)[0]
+    net = QNetwork("mlp", (4,), 2, hidden_size=cfg["HIDDEN_SIZE"], num_layers=cfg["NUM_LAYERS"], device=gpu)
+    theta0 = net.init(9)
+    cfg["_INIT_PARAMS"] = theta0
+    train = make_train(cfg, device="cuda:0")
+    assert train.backend == backend
+    out = train(key)
+    oout = oracle.make_train(ocfg)(key, theta0.cpu().numpy())
+    for u in range(2):
+        for k in ("test/returned_episode_returns", "test/returned_episode_lengths", "test/returned_episode",
+                  "test/timestep", "test/discount"):
+            a, b = float(out["metrics"][k][u]), oout["metrics"][u][k]
+            assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (u, k, a, b)
