@@ -3,10 +3,11 @@
 // Network = QNetwork of purejaxql/pqn_gymnax.py:29-58 with NORM_TYPE=layer_norm, NORM_INPUT=False:
 //   x -> [Dense(H) -> LayerNorm(H) -> relu] x NUM_LAYERS -> Dense(A)          (+ the dummy input BatchNorm
 //   whose 2*D parameters exist and never receive gradient, :38-42)
-// One 256-thread workgroup owns a tile of 16 samples; activations live in LDS, weights (flax (in,out)
-// layout, out contiguous) stream from L2 with lanes along `out`.  These layers are small (CartPole:
-// 4-256-256-2, minibatch 16..128), so the kernels are organised for low launch count and determinism
-// (fixed-order per-tile partial gradients), not for MFMA peak; DESIGN.md lists the MFMA version as next.
+// One 256-thread workgroup owns a tile of 16 samples (= one MFMA M-tile); activations live in LDS, weights
+// (flax (in,out) layout, out contiguous) stream from L2.  Hidden x hidden products (forward, input gradient
+// on the transposed copy, weight gradient over the 16 samples) run as v_mfma_f32_16x16x4_f32; the narrow
+// input layer (CartPole: 4 features) and the LayerNorm / head work stay on the VALU.  Per-tile partial
+// gradients are folded in fixed order (deterministic).
 #include <string.h>
 
 #include "pqn_common.h"
@@ -47,6 +48,97 @@ PQN_D void ml_dense(const float *__restrict__ w, const float *__restrict__ b, co
     }
 #pragma unroll
     for (int m = 0; m < ML_TILE; ++m) y[m * ys + o] = acc[m];
+  }
+}
+
+typedef float ml_f32x4 __attribute__((ext_vector_type(4)));
+
+// Same product on the matrix core (in % 16 == 0, out % 16 == 0, xs % 4 == 0): the 16-sample tile is exactly one
+// MFMA M-tile.  v_mfma_f32_16x16x4_f32 operand maps (cdna guide): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D: col = l&15, rows 4*(l>>4)+reg.  K is walked in groups of 16 with lane kk owning k = 16g + 4kk + q, so one
+// ds_read_b128 of the activation row feeds 4 MFMAs; B comes straight from the flax (in,out) kernel: row k,
+// 16 consecutive outputs = one 64-B run per kk.  Wave w owns output blocks w, w+4, ... four at a time.
+PQN_D void ml_dense_mfma(const float *__restrict__ w, const float *__restrict__ b, const float *x, int xs, int in, int out,
+                         float *y, int ys, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const float *arow = x + j * xs + 4 * kk;
+  const int nblk = out >> 4;
+  for (int nb0 = wave; nb0 < nblk; nb0 += 16) {      // blocks nb0, nb0+4, nb0+8, nb0+12
+    ml_f32x4 acc[4];
+    const float *wp[4];
+    bool on[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] = ml_f32x4{0.f, 0.f, 0.f, 0.f};
+      on[c] = nb0 + 4 * c < nblk;
+      wp[c] = w + (size_t)(4 * kk) * out + 16 * (on[c] ? nb0 + 4 * c : nb0) + j;
+    }
+    // weight fragments of K group g+1 are loaded (in place, after their consumers -- see phase2_fc1 in
+    // pqn_qnet.hip) while the 16 MFMAs of group g run; the four accumulators are interleaved so that
+    // consecutive MFMAs are independent
+    float bv[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) bv[c][qd] = wp[c][(size_t)qd * out];
+    ml_f32x4 a_next = *reinterpret_cast<const ml_f32x4 *>(arow);
+    for (int g = 0; g < in; g += 16) {
+      const ml_f32x4 a = a_next;
+      const int gn = (g + 16 < in) ? g + 16 : g;      // last group: harmless reload of itself
+      a_next = *reinterpret_cast<const ml_f32x4 *>(arow + gn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float aq = qd == 0 ? a.x : (qd == 1 ? a.y : (qd == 2 ? a.z : a.w));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bv[c][qd], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bv[c][qd] = wp[c][(size_t)(gn + qd) * out];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (!on[c]) continue;
+      const int o = 16 * (nb0 + 4 * c) + j;
+      const float bo = b ? b[o] : 0.0f;
+      float *yp = y + (4 * kk) * ys + o;
+      yp[0] = acc[c].x + bo;
+      yp[ys] = acc[c].y + bo;
+      yp[2 * ys] = acc[c].z + bo;
+      yp[3 * ys] = acc[c].w + bo;
+    }
+  }
+}
+
+PQN_D void ml_dense_any(const float *__restrict__ w, const float *__restrict__ b, const float *x, int xs, int in, int out,
+                        float *y, int ys, int tid) {
+  if ((in & 15) == 0 && (out & 15) == 0 && (xs & 3) == 0) ml_dense_mfma(w, b, x, xs, in, out, y, ys, tid);
+  else ml_dense(w, b, x, xs, in, out, y, ys, tid);
+}
+
+// dW[k][o] = sum_m in[m][k] dz[m][o] over the 16 samples of the tile, on the matrix core (ind % 16 == 0):
+// A[i = k][kk = m] = in[m][16kb + i], B[kk = m][j = o] = dz[m][16nb + j]; 4 MFMAs (K = 16 samples) per 16x16
+// output block, D row k = 4*(l>>4)+reg, col o.  Wave w owns row blocks w, w+4, ...
+PQN_D void ml_wgrad_mfma(const float *in, int ins, int ind, const float *dz, int dzs, int h, float *__restrict__ gw,
+                         int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  for (int kb = wave; kb < (ind >> 4); kb += 4) {
+    float a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = in[(4 * s + kk) * ins + 16 * kb + j];
+    for (int nb = 0; nb < (h >> 4); ++nb) {
+      ml_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], dz[(4 * s + kk) * dzs + 16 * nb + j], acc, 0, 0, 0);
+      float *gp = gw + (size_t)(16 * kb + 4 * kk) * h + 16 * nb + j;
+      gp[0] = acc.x;
+      gp[h] = acc.y;
+      gp[2 * (size_t)h] = acc.z;
+      gp[3 * (size_t)h] = acc.w;
+    }
   }
 }
 
@@ -95,7 +187,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(int n, const float *__rest
   const float *in = x;
   int ins = DS, ind = L.d;
   for (int l = 0; l < L.layers; ++l) {
-    ml_dense(theta + L.off_w[l], theta + L.off_b[l], in, ins, ind, L.h, y, HS, tid);
+    ml_dense_any(theta + L.off_w[l], theta + L.off_b[l], in, ins, ind, L.h, y, HS, tid);
     __syncthreads();
     ml_ln_relu(y, HS, theta + L.off_lns[l], theta + L.off_lnb[l], L.h, a, nullptr, nullptr, tid);
     __syncthreads();
@@ -166,7 +258,7 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(int nb, const int64_t *_
     const float *in = x;
     int ins = DS, ind = L.d;
     for (int l = 0; l < NL; ++l) {
-      ml_dense(theta + L.off_w[l], theta + L.off_b[l], in, ins, ind, H, y, HS, tid);
+      ml_dense_any(theta + L.off_w[l], theta + L.off_b[l], in, ins, ind, H, y, HS, tid);
       __syncthreads();
       ml_ln_relu(y, HS, theta + L.off_lns[l], theta + L.off_lnb[l], H, act + l * ML_TILE * HS,
                  xhat + l * ML_TILE * HS, rstd + l * ML_TILE, tid);
@@ -256,29 +348,21 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(int nb, const int64_t *_
       gp[L.off_b[l] + o] = a1;
       gp[L.off_lns[l] + o] = a2;
       gp[L.off_lnb[l] + o] = a3;
-      for (int k = 0; k < ind; ++k) {
-        float acc = 0.f;
+      if (ind & 15) {   // narrow input layer (CartPole: 4 features): VALU
+        for (int k = 0; k < ind; ++k) {
+          float acc = 0.f;
 #pragma unroll
-        for (int m = 0; m < ML_TILE; ++m) acc = fmaf(in[m * ins + k], dzo[m], acc);
-        gp[L.off_w[l] + (size_t)k * H + o] = acc;
+          for (int m = 0; m < ML_TILE; ++m) acc = fmaf(in[m * ins + k], dzo[m], acc);
+          gp[L.off_w[l] + (size_t)k * H + o] = acc;
+        }
       }
     }
+    if ((ind & 15) == 0) ml_wgrad_mfma(in, ins, ind, dz, HS, H, gp + L.off_w[l], tid);
     if (l > 0) {
       // d input[m][k] = sum_o dz[m][o] W[k][o]  ->  lanes along k on the transposed copy Wt[o][k]
       const float *wtl = wt + (size_t)(l - 1) * H * H;
       __syncthreads();   // everyone is done reading y (relu-input grads) before it is overwritten
-      for (int k = tid; k < H; k += 256) {
-        float acc[ML_TILE];
-#pragma unroll
-        for (int m = 0; m < ML_TILE; ++m) acc[m] = 0.f;
-        for (int o = 0; o < H; ++o) {
-          const float wv = wtl[(size_t)o * H + k];
-#pragma unroll
-          for (int m = 0; m < ML_TILE; ++m) acc[m] = fmaf(dz[m * HS + o], wv, acc[m]);
-        }
-#pragma unroll
-        for (int m = 0; m < ML_TILE; ++m) y[m * HS + k] = acc[m];
-      }
+      ml_dense_mfma(wtl, nullptr, dz, HS, H, H, y, HS, tid);   // y[m][k] = sum_o dz[m][o] Wt[o][k]
       __syncthreads();
       for (int i = tid; i < ML_TILE * H; i += 256) {
         const int m = i / H, k = i - m * H;
