@@ -230,6 +230,21 @@ typedef struct {
 int64_t pqn_update_sort_temp_bytes(int32_t n);
 int pqn_cnn_update(const pqn_update_args_t *args /* host */, void *stream);
 
+/* jax.vmap(make_train(config))(rngs) (pqn_minatar.py:459-461) inside the launches: num_seeds independent seeds
+ * advance by one update in the SAME kernels (grid.y = seed), one enqueue / one hipGraph for all of them.  Every
+ * buffer of `args` is the stacked allocation of all seeds:
+ *   env-indexed arrays     state u32[W][S*N], bits [T+1][S*N][OW], records / target [T][S*N], last_q [S*N]
+ *                          (seed s owns envs s*N .. s*N+N-1; num_envs stays N, the per-seed count)
+ *   parameter-like arrays  theta, grad, m, v [S][theta_stride]; w1b [S][1024*128]; count i32[S];
+ *                          workspace [S][workspace_stride]; loss_buf, qv_buf [S][MB*EP]
+ *   sched_keys u64[S][T+EP]; sort_keys_in/out i64[S*T*N]; sort_temp: pqn_update_sort_temp_bytes(S*T*N)
+ *   metrics f64[S][metrics_capacity][PQN_NUM_METRICS]; clock, sched_eps shared (same update index and eps)
+ * key_roll_dev / key_shuf_dev: device u64[S] (args->key_roll / key_shuf are ignored when num_seeds > 1).
+ * Results per seed are bit-identical to num_seeds single-seed pqn_cnn_update calls.  Needs NUM_ENVS % 16 == 0,
+ * T*N <= 2^25, num_seeds <= 128; strides in floats, multiples of 4. */
+int pqn_cnn_update_seeds(const pqn_update_args_t *args /* host */, int32_t num_seeds, const uint64_t *key_roll_dev,
+                         const uint64_t *key_shuf_dev, int64_t theta_stride, int64_t workspace_stride, void *stream);
+
 /* The rollout scan alone, as ONE persistent launch: num_steps x (Q-network forward, eps-greedy, env.step with
  * auto-reset + LogWrapper) for every env, then the bootstrap forward of the last observation.  Replaces
  * jax.lax.scan(_step_env) + the last_q forward (pqn_minatar.py:181-235) and, with eps = EPS_TEST and

@@ -146,6 +146,22 @@ int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStrea
   return pqn_check_launch("pqn_shuffle_keys");
 }
 
+__global__ __launch_bounds__(256) void shuffle_keys_seeds_kernel(const uint64_t *__restrict__ key_dev, int key_stride, int n,
+                                                                 int64_t *__restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+  if (i >= n) return;
+  uint32_t o0, o1;
+  pqn_bits(key_dev[(size_t)s * key_stride], (uint32_t)i, 0u, o0, o1);   // the same draw as shuffle_keys_kernel
+  keys[(size_t)s * n + i] = (int64_t)(((uint64_t)s << 56) | ((uint64_t)(o0 >> 1) << 25) | (uint64_t)i);   // 7 | 31 | 25 bits
+}
+
+int pqn_shuffle_keys_seeds(const uint64_t *key_dev, int key_stride, int nseeds, int n, int64_t *keys, hipStream_t st) {
+  PQN_REQUIRE(key_dev && keys && n > 0 && n <= (1 << 25) && nseeds >= 1 && nseeds <= 128,
+              "pqn_shuffle_keys_seeds: bad arguments (n=%d, seeds=%d)", n, nseeds);
+  hipLaunchKernelGGL(shuffle_keys_seeds_kernel, dim3((n + 255) / 256, nseeds), dim3(256), 0, st, key_dev, key_stride, n, keys);
+  return pqn_check_launch("pqn_shuffle_keys_seeds");
+}
+
 // ---------------------------------------------------------------------------
 // clip_by_global_norm + RAdam on a flat buffer.  Pass 1: per-block sum of
 // squares -> scratch[block]; block 0 snapshots *count into scratch[1023].
@@ -189,9 +205,17 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
                                                           float lr_steps, float max_norm, int nparts,
                                                           const float *__restrict__ scratch,
                                                           float *__restrict__ gnorm_out, int w1_off,
-                                                          float *__restrict__ w1b) {
+                                                          float *__restrict__ w1b, long long pstride, long long sstride,
+                                                          long long w1bstride) {
   __shared__ float s_part[4];
   __shared__ float s_sc[8];
+  {  // seed slice (grid.y; all strides 0 for a single seed)
+    const long long sd = blockIdx.y;
+    p += sd * pstride; g += sd * pstride; m += sd * pstride; v += sd * pstride;
+    scratch += sd * sstride;
+    count += sd;
+    if (w1b) w1b += sd * w1bstride;
+  }
   float acc = 0.0f;
   for (int i = threadIdx.x; i < nparts; i += 256) acc += scratch[i];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -278,15 +302,20 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
 
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
                      float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
-                     float *w1b, int norm_pass, int nparts, hipStream_t st) {
+                     float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds, long long pstride,
+                     long long sstride, long long w1bstride) {
   // nparts: number of sum-of-squares partials already in scratch when norm_pass == 0
   const int blocks = pqn_radam_blocks(n);
   if (norm_pass) {
+    if (nseeds != 1) {
+      pqn_set_error("radam: the separate norm pass is single-seed only");
+      return PQN_E_INVALID;
+    }
     hipLaunchKernelGGL(radam_norm_kernel, dim3(blocks), dim3(256), 0, st, g, n, count, scratch);
     nparts = blocks;
   }
-  hipLaunchKernelGGL(radam_apply_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, count, lr_init, lr_end,
-                     lr_steps, max_norm, nparts, scratch, gnorm_out, w1_off, w1b);
+  hipLaunchKernelGGL(radam_apply_kernel, dim3(blocks, nseeds), dim3(256), 0, st, p, g, m, v, n, count, lr_init, lr_end,
+                     lr_steps, max_norm, nparts, scratch, gnorm_out, w1_off, w1b, pstride, sstride, w1bstride);
   return pqn_check_launch("radam");
 }
 

@@ -75,14 +75,44 @@ inline int pqn_radam_blocks(int64_t n) {
   int64_t b = (n + 1023) / 1024;  // 4 elements per lane
   return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
 }
+// Seed batching (jax.vmap over seeds, pqn_minatar.py:459-461): S independent seeds in ONE launch, grid.y (T2: grid.z)
+// = seed.  Every per-seed buffer is a slice of a stacked allocation; these are the slice strides in elements.
+// All-zero strides + nseeds = 1 is the single-seed case (the public single-seed entry points).
+struct pqn_seeds_t {
+  int nseeds;
+  int n_env, n_env_total;        // envs per seed / of all seeds: transition j = t*n_env + e of seed s lives at
+                                 // t*n_env_total + s*n_env + e of the stacked [T][S*N] rollout record
+  long long idx_stride;          // sorted shuffle keys of one seed (T*N)
+  long long theta_stride;        // parameters / gradient / moments
+  long long w1b_stride;          // dgrad-fragment copy of the fc1 kernel
+  long long ws_stride;           // optimizer + training workspace
+  long long lq_stride;           // loss_buf / qv_buf
+  long long idx_mask;            // low bits of a sorted key that hold the local transition index
+};
+inline pqn_seeds_t pqn_one_seed() {
+  pqn_seeds_t s = {};
+  s.nseeds = 1;
+  s.idx_mask = 0xFFFFFFFFll;
+  return s;
+}
+
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
                      float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
-                     float *w1b, int norm_pass, int nparts, hipStream_t st);
+                     float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds = 1, long long pstride = 0,
+                     long long sstride = 0, long long w1bstride = 0);
 
 // internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
                      const pqn_step_out_t &out, hipStream_t st);
 int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStream_t st);
+// seed-batched variant: keys[s*n + i] = (s << 56) | (rand31(i; key_dev[s*key_stride]) << 25) | i  (n <= 2^25, S <= 128):
+// one global radix sort orders every seed's segment exactly as the single-seed keys (rand31 << 32 | i) would
+int pqn_shuffle_keys_seeds(const uint64_t *key_dev, int key_stride, int nseeds, int n, int64_t *keys, hipStream_t st);
+int pqn_cnn_grad_reduce_blocks(int total);   // number of sum-of-squares partials pqn_qnet_cnn_grad leaves in the scratch
+int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
+                            const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
+                            const int32_t *count, float *workspace, float *loss_out, float *qv_out,
+                            const pqn_seeds_t &sd, hipStream_t st);
 int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *obs_bits, const float *theta, float *q,
                              int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
                              const uint64_t *key_dev, hipStream_t st);
@@ -90,4 +120,5 @@ int pqn_mlp_forward_dyn(const pqn_mlp_layout_t &L, int n, const float *obs, cons
                         float *qmax, float eps, uint64_t key, const float *eps_dev, const uint64_t *key_dev, hipStream_t st);
 int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
                          const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
-                         const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st);
+                         const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st,
+                         int n_per_seed = 0, long long theta_stride = 0, int keys_stride = 0);

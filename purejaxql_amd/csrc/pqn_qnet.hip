@@ -452,14 +452,23 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
     pqn_cnn_layout_t L, int32_t *__restrict__ action, float *__restrict__ qmax, float *__restrict__ reward,
     uint8_t *__restrict__ done, float *__restrict__ discount, float *__restrict__ rer, int32_t *__restrict__ rel,
     int32_t *__restrict__ ts, float *__restrict__ last_q, const float *__restrict__ eps_dev,
-    const uint64_t *__restrict__ keys, float rscale, int store_obs) {
+    const uint64_t *__restrict__ keys, float rscale, int store_obs, int n_per_seed, long long theta_stride,
+    int keys_stride) {
   using Cfg = CnnCfg<C>;
   static_assert(Cfg::OW == Env::OBS_WORDS, "packed observation width");
+  int e_off = 0;          // first env of this tile's seed: the RNG counters use the env index inside the seed
+  if (n_per_seed > 0) {   // seed batching: env tile -> seed (n_per_seed % 16 == 0); per-seed parameters and step keys
+    const int seed = (blockIdx.x * QN_TILE) / n_per_seed;
+    theta += seed * theta_stride;
+    keys += (size_t)seed * keys_stride;
+    e_off = seed * n_per_seed;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const CnnSmem s = carve_smem<C>(smem_raw);
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * QN_TILE;
   const int m = (tid >> 4) & 15, sub = tid & 15, e = e0 + m;
+  const int e_rng = e - e_off;
   const bool owner = tid < 256 && sub == 0 && e < n;   // the lane that owns env e
   const size_t bstride = (size_t)n * Cfg::OW;
   load_tile_common<C>(s, theta, L, tid);
@@ -499,12 +508,12 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
         } else {
           const uint64_t key = keys[t];
           uint32_t o0, o1;
-          pqn_bits(key, (uint32_t)e, PQN_STREAM_ACT, o0, o1);
+          pqn_bits(key, (uint32_t)e_rng, PQN_STREAM_ACT, o0, o1);
           const int act = (pqn_uniform(o0) < eps) ? (int)pqn_randint(o1, (uint32_t)L.a) : best;
           int dn = 0;
-          const float r = env.step(act, key, (uint32_t)e, dn);
+          const float r = env.step(act, key, (uint32_t)e_rng, dn);
           log.step(r, dn);
-          if (dn) env.reset(key, (uint32_t)e);             // gymnax auto-reset
+          if (dn) env.reset(key, (uint32_t)e_rng);             // gymnax auto-reset
           const size_t o = (size_t)t * n + e;
           if (action) action[o] = act;
           if (qmax) qmax[o] = bv;
@@ -732,9 +741,23 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, const float *__restrict__ w1b,
     pqn_cnn_layout_t L, float inv_b, float *__restrict__ dzT, float *__restrict__ h1T, float *__restrict__ gpart,
-    int ablate, unsigned long long *__restrict__ stamps) {
+    int ablate, unsigned long long *__restrict__ stamps, pqn_seeds_t sd) {
   using Cfg = CnnCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int seed = blockIdx.y;           // seed slice of the stacked buffers (all strides 0 for a single seed)
+  idx += seed * sd.idx_stride;
+  theta += seed * sd.theta_stride;
+  w1b += seed * sd.w1b_stride;
+  dzT += seed * sd.ws_stride;
+  h1T += seed * sd.ws_stride;
+  gpart += seed * sd.ws_stride;
+  // transition j = t*N + e of this seed -> row of the stacked [T][S*N] rollout record
+  auto row_of = [&](int64_t key) -> int64_t {
+    const uint32_t j = (uint32_t)(key & sd.idx_mask);
+    if (sd.n_env_total == sd.n_env) return (int64_t)j;
+    const uint32_t t = j / (uint32_t)sd.n_env;
+    return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
+  };
   const TrainSmem ts = carve_train_smem<C>(smem_raw);
   const CnnSmem &s = ts.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -750,9 +773,9 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 #pragma unroll
   for (int k = 0; k < NBI; ++k) {
     const int i = tid + k * QN_THREADS, le = i / Cfg::OW;
-    ix[k] = (i < QN_TILE * Cfg::OW && b0 + le < nb) ? (idx[b0 + le] & 0xFFFFFFFFll) : -1;
+    ix[k] = (i < QN_TILE * Cfg::OW && b0 + le < nb) ? row_of(idx[b0 + le]) : -1;
   }
-  const int64_t src16 = (tid < QN_TILE && b0 + tid < nb) ? (idx[b0 + tid] & 0xFFFFFFFFll) : -1;
+  const int64_t src16 = (tid < QN_TILE && b0 + tid < nb) ? row_of(idx[b0 + tid]) : -1;
   load_tile_common<C>(s, theta, L, tid);
 #pragma unroll
   for (int k = 0; k < NBI; ++k) {
@@ -993,8 +1016,11 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 
 __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_kernel(int nb, const float *__restrict__ h1T,
                                                                     const float *__restrict__ dzT,
-                                                                    float *__restrict__ wpart) {
+                                                                    float *__restrict__ wpart, long long ws_stride) {
   static_assert(QN_WAVES == 8, "one output column block per wave");
+  h1T += blockIdx.z * ws_stride;   // seed slice
+  dzT += blockIdx.z * ws_stride;
+  wpart += blockIdx.z * ws_stride;
   // operands are staged through LDS so each element is fetched once per workgroup (the 8 waves share
   // the 64-row A tile); double-buffered, one barrier per 32-sample step.
   constexpr int KS = 32;                 // samples per step
@@ -1071,8 +1097,18 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
                                                                const float *__restrict__ wpart, float *__restrict__ grad,
                                                                const int32_t *__restrict__ count,
                                                                float *__restrict__ scratch, float *__restrict__ loss_out,
-                                                               float *__restrict__ qv_out, float inv_b) {
+                                                               float *__restrict__ qv_out, float inv_b, pqn_seeds_t sd) {
   __shared__ float s_part[4];
+  {  // seed slice
+    const long long s = blockIdx.y;
+    gpart += s * sd.ws_stride;
+    wpart += s * sd.ws_stride;
+    scratch += s * sd.ws_stride;
+    grad += s * sd.theta_stride;
+    count += s;
+    if (loss_out) loss_out += s * sd.lq_stride;
+    if (qv_out) qv_out += s * sd.lq_stride;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ss = 0.0f;
   if (blockIdx.x < QR_W1_BLOCKS) {
@@ -1191,7 +1227,8 @@ extern "C" int pqn_qnet_cnn_forward(const pqn_cnn_layout_t *L, int32_t n, const 
 template <int C, class Env>
 static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
                           const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
-                          const uint64_t *keys, float rscale, int store_obs, hipStream_t st) {
+                          const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed,
+                          long long theta_stride, int keys_stride) {
   const size_t smem = cnn_smem_bytes<C>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -1202,26 +1239,31 @@ static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t 
   hipLaunchKernelGGL((qnet_cnn_rollout_kernel<C, Env>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n,
                      t_len, state, bits, theta, L, action, qmax, rec.reward, rec.done, rec.discount,
                      rec.returned_episode_returns, rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys,
-                     rscale, store_obs);
+                     rscale, store_obs, n_per_seed, theta_stride, keys_stride);
   return pqn_check_launch("pqn_qnet_cnn_rollout");
 }
 
 // internal (pqn_update.hip): rec.* point at the [T][n] transition arrays
 int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
                          const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
-                         const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st) {
+                         const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st,
+                         int n_per_seed, long long theta_stride, int keys_stride) {
+  if (n_per_seed > 0 && n_per_seed % QN_TILE != 0) {
+    pqn_set_error("pqn_qnet_cnn_rollout: seed batching needs NUM_ENVS %% %d == 0 (got %d)", QN_TILE, n_per_seed);
+    return PQN_E_INVALID;
+  }
   switch (env_id) {
     case PQN_ENV_BREAKOUT:
-      if (L.c == 4) return launch_rollout<4, Breakout>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st);
+      if (L.c == 4) return launch_rollout<4, Breakout>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride);
       break;
     case PQN_ENV_ASTERIX:
-      if (L.c == 4) return launch_rollout<4, Asterix>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st);
+      if (L.c == 4) return launch_rollout<4, Asterix>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride);
       break;
     case PQN_ENV_FREEWAY:
-      if (L.c == 7) return launch_rollout<7, Freeway>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st);
+      if (L.c == 7) return launch_rollout<7, Freeway>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride);
       break;
     case PQN_ENV_SPACEINVADERS:
-      if (L.c == 6) return launch_rollout<6, SpaceInvaders>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st);
+      if (L.c == 6) return launch_rollout<6, SpaceInvaders>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride);
       break;
     default: break;
   }
@@ -1297,7 +1339,8 @@ extern "C" int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries *
 template <int C>
 static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits,
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
-                        const int32_t *count, float *ws, float *loss_out, float *qv_out, hipStream_t st) {
+                        const int32_t *count, float *ws, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
+                        hipStream_t st) {
   const int ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB, rec = small_record_floats(C, L.a);
   float *scratch = ws;
   float *dzT = ws + 1024;
@@ -1318,12 +1361,13 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
   if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
-  hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles), dim3(QN_THREADS), smem1, st, nb, idx, bits, action, target,
-                     theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps);
+  hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
+                     target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sd);
   if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
-  hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart);
-  hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total)), dim3(256), 0, st, L, ntiles, nks, rec,
-                     gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b);
+  hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
+                     sd.ws_stride);
+  hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles, nks,
+                     rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd);
   return pqn_check_launch("pqn_qnet_cnn_grad");
 }
 
@@ -1342,15 +1386,25 @@ extern "C" int pqn_qnet_cnn_grad(const pqn_cnn_layout_t *L, int32_t nb, const in
               "pqn_qnet_cnn_grad: NULL argument");
   PQN_REQUIRE(nb > 0 && nb % QN_TILE == 0, "pqn_qnet_cnn_grad: minibatch size %d must be a positive multiple of %d", nb,
               QN_TILE);
-  hipStream_t st = (hipStream_t)stream;
-  switch (L->c) {
-    case 4: return launch_train<4>(*L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, st);
-    case 6: return launch_train<6>(*L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, st);
-    case 7: return launch_train<7>(*L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, st);
-    case 10: return launch_train<10>(*L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, st);
-    default: pqn_set_error("pqn_qnet_cnn_grad: unsupported channel count %d", L->c); return PQN_E_UNSUPPORTED;
+  return pqn_qnet_cnn_grad_seeds(*L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out,
+                                 pqn_one_seed(), (hipStream_t)stream);
+}
+
+// internal (pqn_update.hip): S seeds per launch, buffers = slices of stacked allocations (pqn_seeds_t)
+int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
+                            const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
+                            const int32_t *count, float *workspace, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
+                            hipStream_t st) {
+  switch (L.c) {
+    case 4: return launch_train<4>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st);
+    case 6: return launch_train<6>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st);
+    case 7: return launch_train<7>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st);
+    case 10: return launch_train<10>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st);
+    default: pqn_set_error("pqn_qnet_cnn_grad: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
   }
 }
+
+int pqn_cnn_grad_reduce_blocks(int total) { return grad_reduce_blocks(total); }
 
 extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float *w1b, const float *grad, float *m,
                                   float *v, int32_t *count, float lr_init, float lr_end, float lr_steps,

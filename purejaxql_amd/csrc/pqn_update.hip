@@ -17,14 +17,23 @@ enum { M_ENV_STEP, M_UPDATE_STEPS, M_ENV_FRAME, M_GRAD_STEPS, M_TD_LOSS, M_QVALS
        M_RET_LENGTHS, M_TIMESTEP, M_RET_EPISODE, M_COUNT };
 static_assert(M_COUNT == PQN_NUM_METRICS, "metrics row layout");
 
-__global__ void update_sched_kernel(const int32_t *__restrict__ clock, uint64_t key_roll, uint64_t key_shuf, int t_len,
-                                    int epochs, float eps_start, float eps_finish, float eps_decay_steps,
+// grid = seeds: block s derives the keys of seed s (key_*_dev[s] when given) into keys[s*(t_len+epochs) ...];
+// block 0 also latches the update index into clock[1] for the tick kernel and writes eps
+__global__ void update_sched_kernel(int32_t *__restrict__ clock, uint64_t key_roll, uint64_t key_shuf,
+                                    const uint64_t *__restrict__ key_roll_dev, const uint64_t *__restrict__ key_shuf_dev,
+                                    int t_len, int epochs, float eps_start, float eps_finish, float eps_decay_steps,
                                     uint64_t *__restrict__ keys, float *__restrict__ eps) {
   const int u = clock[0];
   const int i = threadIdx.x;
+  if (key_roll_dev) {
+    key_roll = key_roll_dev[blockIdx.x];
+    key_shuf = key_shuf_dev[blockIdx.x];
+  }
+  keys += (size_t)blockIdx.x * (t_len + epochs);
+  if (blockIdx.x == 0 && i == 0) clock[1] = u;
   if (i < t_len) keys[i] = pqn_fold(key_roll, (uint32_t)(u * t_len + i));
   else if (i < t_len + epochs) keys[i] = pqn_fold(key_shuf, (uint32_t)(u * epochs + (i - t_len)));
-  if (i == 0) {
+  if (blockIdx.x == 0 && i == 0) {
     double e = eps_finish;
     if (eps_decay_steps > 0.0f) {
       double c = (double)u;
@@ -39,16 +48,25 @@ __global__ void update_sched_kernel(const int32_t *__restrict__ clock, uint64_t 
 // kernel folds the chunk partials.  (info means of pqn_minatar.py:338)
 #define MEANS_CHUNKS 64
 
-__global__ __launch_bounds__(256) void update_means_kernel(int count, const float *__restrict__ discount,
+// grid (5, MEANS_CHUNKS, seeds): seed s reads its columns [s*n_env, (s+1)*n_env) of the stacked [T][n_env_total] arrays
+__global__ __launch_bounds__(256) void update_means_kernel(int count, int n_env, int n_env_total,
+                                                           const float *__restrict__ discount,
                                                            const float *__restrict__ rer, const int32_t *__restrict__ rel,
                                                            const int32_t *__restrict__ ts,
-                                                           const uint8_t *__restrict__ done, double *__restrict__ partial) {
+                                                           const uint8_t *__restrict__ done, double *__restrict__ partial,
+                                                           long long partial_stride) {
   __shared__ double s_part[4];
-  const int which = blockIdx.x, chunk = blockIdx.y;
+  const int which = blockIdx.x, chunk = blockIdx.y, seed = blockIdx.z;
+  partial += seed * partial_stride;
   const int per = (count + MEANS_CHUNKS - 1) / MEANS_CHUNKS;
   const int lo = chunk * per, hi = min(count, lo + per);
   double acc = 0.0;
-  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+  for (int j = lo + threadIdx.x; j < hi; j += 256) {
+    size_t i = (size_t)j;
+    if (n_env_total != n_env) {
+      const int t = j / n_env;
+      i = (size_t)t * n_env_total + (size_t)seed * n_env + (j - t * n_env);
+    }
     float v;
     switch (which) {
       case 0: v = discount[i]; break;
@@ -65,10 +83,16 @@ __global__ __launch_bounds__(256) void update_means_kernel(int count, const floa
   if (threadIdx.x == 0) partial[which * MEANS_CHUNKS + chunk] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
+// grid = seeds; the update index was latched into clock[1] by the sched kernel, block 0 advances clock[0]
 __global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n, int channels, int n_mb_total,
                                    const float *__restrict__ loss_buf, const float *__restrict__ qv_buf,
-                                   const double *__restrict__ partial, double *__restrict__ metrics, int capacity) {
-  const int u = clock[0];
+                                   const double *__restrict__ partial, double *__restrict__ metrics, int capacity,
+                                   long long partial_stride) {
+  const int u = clock[1];
+  loss_buf += (size_t)blockIdx.x * n_mb_total;
+  qv_buf += (size_t)blockIdx.x * n_mb_total;
+  partial += blockIdx.x * partial_stride;
+  metrics += (size_t)blockIdx.x * capacity * M_COUNT;
   if (u < capacity) {
     double *row = metrics + (size_t)u * M_COUNT;
     if (threadIdx.x < 5) {
@@ -88,8 +112,7 @@ __global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n
       row[M_QVALS] = qv / (double)n_mb_total;
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) clock[0] = u + 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) clock[0] = u + 1;
 }
 
 extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
@@ -107,7 +130,11 @@ extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
     if (rc_ != PQN_OK) return rc_; \
   } while (0)
 
-extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
+// S seeds per launch (S = 1: the single-seed entry point).  With S > 1 every buffer in `a` is the stacked
+// allocation of all seeds: env-indexed arrays are [..][S*N] (seed s owns envs s*N .. s*N+N-1), parameter-like
+// buffers are [S][stride]; key_roll_dev / key_shuf_dev hold the per-seed keys.
+static int cnn_update_impl(const pqn_update_args_t *a, int S, const uint64_t *key_roll_dev, const uint64_t *key_shuf_dev,
+                           long long theta_stride, long long ws_stride, hipStream_t st) {
   PQN_REQUIRE(a, "pqn_cnn_update: args is NULL");
   PQN_REQUIRE(a->clock && a->sched_keys && a->sched_eps && a->state && a->bits && a->action && a->reward && a->done &&
                   a->qmax && a->discount && a->rer && a->rel && a->ts && a->target && a->last_q && a->sort_keys_in &&
@@ -120,14 +147,28 @@ extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
   PQN_REQUIRE(((int64_t)N * T) % MB == 0, "NUM_MINIBATCHES must divide NUM_STEPS*NUM_ENVS");
   const int B = (int)(((int64_t)N * T) / MB);
   PQN_REQUIRE(B % 16 == 0, "pqn_cnn_update: minibatch size %d must be a multiple of 16", B);
-  hipStream_t st = (hipStream_t)stream;
+  PQN_REQUIRE(S >= 1 && S <= 128 && (S == 1 || (key_roll_dev && key_shuf_dev && N % 16 == 0 && (int64_t)N * T <= (1 << 25))),
+              "pqn_cnn_update: seed batching needs 1 <= seeds <= 128, device key arrays, NUM_ENVS %% 16 == 0, T*N <= 2^25");
   const pqn_cnn_layout_t &L = a->layout;
   const int OW = a->obs_words;
-  const size_t bits_stride = (size_t)N * OW;
+  const int SN = S * N, TN = T * N;
+  const size_t bits_stride = (size_t)SN * OW;
+  pqn_seeds_t sd = pqn_one_seed();
+  if (S > 1) {
+    sd.nseeds = S;
+    sd.n_env = N;
+    sd.n_env_total = SN;
+    sd.idx_stride = TN;
+    sd.theta_stride = theta_stride;
+    sd.w1b_stride = 1024 * 128;
+    sd.ws_stride = ws_stride;
+    sd.lq_stride = (long long)MB * EP;
+    sd.idx_mask = (1ll << 25) - 1;
+  }
 
-  hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, T, EP, a->eps_start,
-                     a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
-  // SAMPLE PHASE (_step_env scan, :181-220) + bootstrap forward (:227-235): one persistent launch
+  hipLaunchKernelGGL(update_sched_kernel, dim3(S), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, key_roll_dev,
+                     key_shuf_dev, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
+  // SAMPLE PHASE (_step_env scan, :181-220) + bootstrap forward (:227-235): one persistent launch over all S*N envs
   {
     pqn_step_out_t rec = {};
     rec.reward = a->reward;
@@ -136,27 +177,32 @@ extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
     rec.returned_episode_returns = a->rer;
     rec.returned_episode_lengths = a->rel;
     rec.timestep = a->ts;
-    UPD_CHECK(pqn_qnet_cnn_rollout(a->env_id, L, N, T, a->state, a->bits, a->theta, rec, a->action, a->qmax, a->last_q,
-                                   a->sched_eps, a->sched_keys, a->rew_scale, 1, st));
+    UPD_CHECK(pqn_qnet_cnn_rollout(a->env_id, L, SN, T, a->state, a->bits, a->theta, rec, a->action, a->qmax, a->last_q,
+                                   a->sched_eps, a->sched_keys, a->rew_scale, 1, st, S > 1 ? N : 0, sd.theta_stride, T + EP));
   }
-  // Q(lambda) TARGETS (:237-260)
-  UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, N, 1, a->target, st));
+  // Q(lambda) TARGETS (:237-260): lane per env over the stacked [T][S*N] record
+  UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, SN, 1, a->target, st));
   // NETWORKS UPDATE (:263-327)
   int i_mb = 0;
   for (int ep = 0; ep < EP; ++ep) {
-    UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, N * T, a->sort_keys_in, st));
     size_t tb = (size_t)a->sort_temp_bytes;
+    if (S == 1) {
+      UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, TN, a->sort_keys_in, st));
+    } else {   // one global sort: the seed id in the top bits keeps every seed's segment in place
+      UPD_CHECK(pqn_shuffle_keys_seeds(a->sched_keys + T + ep, T + EP, S, TN, a->sort_keys_in, st));
+    }
     if (hipcub::DeviceRadixSort::SortKeys(a->sort_temp, tb, (const unsigned long long *)a->sort_keys_in,
-                                          (unsigned long long *)a->sort_keys_out, N * T, 0, 63, st) != hipSuccess) {
+                                          (unsigned long long *)a->sort_keys_out, S * TN, 0, 63, st) != hipSuccess) {
       pqn_set_error("pqn_cnn_update: radix sort failed (temp bytes %llu)", (unsigned long long)a->sort_temp_bytes);
       return PQN_E_HIP;
     }
     for (int mb = 0; mb < MB; ++mb, ++i_mb) {
-      // low 32 bits of a sorted shuffle key = the transition index (kernels mask idx with 0xffffffff)
-      UPD_CHECK(pqn_qnet_cnn_grad(&L, B, a->sort_keys_out + (size_t)mb * B, a->bits, a->action, a->target, a->theta, a->w1b,
-                                  a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, st));
-      UPD_CHECK(pqn_qnet_cnn_apply(&L, a->theta, a->w1b, a->grad, a->m, a->v, a->count, a->lr_init, a->lr_end, a->lr_steps,
-                                   a->max_grad_norm, a->workspace, nullptr, 0, st));
+      // low bits of a sorted shuffle key = the transition index inside the seed (kernels mask with sd.idx_mask)
+      UPD_CHECK(pqn_qnet_cnn_grad_seeds(L, B, a->sort_keys_out + (size_t)mb * B, a->bits, a->action, a->target, a->theta,
+                                        a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, sd, st));
+      UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
+                                 a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, 0, pqn_cnn_grad_reduce_blocks(L.total),
+                                 st, S, sd.theta_stride, sd.ws_stride, sd.w1b_stride));
     }
   }
   // carry last_obs into the next update; metrics (:329-338); advance the clock
@@ -166,11 +212,23 @@ extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
     return PQN_E_HIP;
   }
   double *partial = reinterpret_cast<double *>(a->workspace);  // first 1024 floats: optimizer scratch, idle here
-  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS), dim3(256), 0, st, N * T, a->discount, a->rer, a->rel,
-                     a->ts, a->done, partial);
-  hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, L.c, MB * EP, a->loss_buf, a->qv_buf,
-                     partial, a->metrics, a->metrics_capacity);
+  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS, S), dim3(256), 0, st, TN, N, SN, a->discount, a->rer, a->rel,
+                     a->ts, a->done, partial, sd.ws_stride / 2);
+  hipLaunchKernelGGL(update_tick_kernel, dim3(S), dim3(64), 0, st, a->clock, T, N, L.c, MB * EP, a->loss_buf, a->qv_buf,
+                     partial, a->metrics, a->metrics_capacity, sd.ws_stride / 2);
   return pqn_check_launch("pqn_cnn_update");
+}
+
+extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
+  return cnn_update_impl(a, 1, nullptr, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int pqn_cnn_update_seeds(const pqn_update_args_t *a, int32_t num_seeds, const uint64_t *key_roll_dev,
+                                    const uint64_t *key_shuf_dev, int64_t theta_stride, int64_t workspace_stride,
+                                    void *stream) {
+  PQN_REQUIRE(num_seeds == 1 || (theta_stride > 0 && workspace_stride > 0 && theta_stride % 4 == 0 && workspace_stride % 4 == 0),
+              "pqn_cnn_update_seeds: strides must be positive multiples of 4 floats");
+  return cnn_update_impl(a, num_seeds, key_roll_dev, key_shuf_dev, theta_stride, workspace_stride, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -194,8 +252,9 @@ extern "C" int pqn_mlp_update(const pqn_mlp_update_args_t *a, void *stream) {
   PQN_REQUIRE(L.layers == 1 || a->wt, "pqn_mlp_update: transposed hidden kernels (wt) required for NUM_LAYERS > 1");
   const size_t ostride = (size_t)N * L.d;
 
-  hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, T, EP, a->eps_start,
-                     a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
+  hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf,
+                     (const uint64_t *)nullptr, (const uint64_t *)nullptr, T, EP, a->eps_start, a->eps_finish,
+                     a->eps_decay_steps, a->sched_keys, a->sched_eps);
   // SAMPLE PHASE (_step_env scan, pqn_gymnax.py:172-211)
   for (int t = 0; t < T; ++t) {
     const size_t o = (size_t)t * N;
@@ -238,9 +297,9 @@ extern "C" int pqn_mlp_update(const pqn_mlp_update_args_t *a, void *stream) {
     return PQN_E_HIP;
   }
   double *partial = reinterpret_cast<double *>(a->workspace);  // first 1024 floats: optimizer scratch, idle here
-  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS), dim3(256), 0, st, N * T, a->discount, a->rer, a->rel,
-                     a->ts, a->done, partial);
+  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS, 1), dim3(256), 0, st, N * T, N, N, a->discount, a->rer,
+                     a->rel, a->ts, a->done, partial, 0ll);
   hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, 1, MB * EP, a->loss_buf, a->qv_buf,
-                     partial, a->metrics, a->metrics_capacity);
+                     partial, a->metrics, a->metrics_capacity, 0ll);
   return pqn_check_launch("pqn_mlp_update");
 }
