@@ -42,32 +42,26 @@ def workload_config(num_envs: int, mode: str):
 
 
 def multi_seed_rate(cfg, seeds, steps, warmup, dev):
-    """`seeds` independent runs of the bench workload (own parameters / optimizer / envs / keys), one HIP
-    stream each, update u of every seed enqueued round-robin (purejaxql_amd.pqn.vmap_train does the same):
+    """`seeds` independent runs of the bench workload (own parameters / optimizer / envs / keys) batched into
+    the SAME launches (grid.y = seed, pqn_cnn_update_seeds; purejaxql_amd.pqn.vmap_train does the same):
     aggregate env-steps/s.  Reported beside `value`, which stays the single-seed number."""
     import torch
     from purejaxql_amd.pqn import make_train, seed_keys
     c = dict(cfg)
     c.pop("_ENV_SHARD", None)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(seeds)]
-    runners = []
-    for s, key in zip(streams, seed_keys(1, seeds)):
-        with torch.cuda.stream(s):
-            runners.append(make_train(dict(c), device=str(dev)).make_runner(key)[0])
-
-    def rounds(lo, hi):
-        for u in range(lo, hi):
-            for s, upd in zip(streams, runners):
-                with torch.cuda.stream(s):
-                    upd(u)
-    rounds(0, warmup)
+    train = make_train(c, device=str(dev))
+    update, _finish = train.make_batch_runner(seed_keys(1, seeds))
+    for u in range(warmup):
+        update(u)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rounds(warmup, warmup + steps)
+    for u in range(warmup, warmup + steps):
+        update(u)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"seeds_per_gpu": seeds, "value": seeds * steps * c["NUM_ENVS"] * c["NUM_STEPS"] / dt, "unit": "env-steps/s",
-            "ms_per_round": dt / steps * 1e3, "how": "one hipGraph replay per seed and update on its own HIP stream"}
+            "ms_per_round": dt / steps * 1e3,
+            "how": "all seeds in the same kernel launches (grid.y = seed), one hipGraph replay per update"}
 
 
 def cpu_baseline(cfg, theta0, max_seconds=45.0):
@@ -121,9 +115,10 @@ def main():
                     help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
                          "(RCCL gradient all-reduce per optimizer step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--multi-seed", type=int, default=4,
+    ap.add_argument("--multi-seed", type=int, default=16,
                     help="N=1 only: also report the aggregate rate of this many independent seeds of the same workload "
-                         "on concurrent HIP streams (jax.vmap over seeds, pqn_minatar.py:459-461); 0 = skip")
+                         "batched into the same launches (jax.vmap over seeds, pqn_minatar.py:459-461; 16 per GPU = "
+                         "BASELINE.json configs[3]: 128 seeds over 8 GPUs); 0 = skip")
     args = ap.parse_args()
 
     import torch

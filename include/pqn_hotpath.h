@@ -261,6 +261,14 @@ int pqn_cnn_rollout(int env_id, const pqn_cnn_layout_t *layout, int32_t num_envs
                     uint32_t *obs_bits, int32_t store_obs, const float *theta, const pqn_step_out_t *rec /* host */,
                     int32_t *action, float *qmax, float *last_q, const float *eps_dev, const uint64_t *keys_dev,
                     float rew_scale, void *stream);
+/* The same scan for num_seeds independent seeds in one launch: env e of seed s is column s*envs_per_seed + e of
+ * every array, draws its randomness as env e of a single-seed call with keys_dev[s*keys_stride + t], and is driven by
+ * the parameters theta + s*theta_stride (envs_per_seed % 16 == 0).  Bit-identical to num_seeds pqn_cnn_rollout calls. */
+int pqn_cnn_rollout_seeds(int env_id, const pqn_cnn_layout_t *layout, int32_t num_seeds, int32_t envs_per_seed,
+                          int32_t num_steps, uint32_t *state, uint32_t *obs_bits, int32_t store_obs, const float *theta,
+                          int64_t theta_stride, const pqn_step_out_t *rec /* host */, int32_t *action, float *qmax,
+                          float *last_q, const float *eps_dev, const uint64_t *keys_dev, int32_t keys_stride,
+                          float rew_scale, void *stream);
 
 /* Profiling aid (PQN_T1_STAMPS=1): s_memtime stamps at the phase boundaries of qnet_cnn_train_kernel for
  * workgroups 0..3; 16 slots per workgroup.  Not part of the hot path. */

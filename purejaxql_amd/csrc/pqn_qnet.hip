@@ -239,7 +239,7 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, 
 // ---------------------------------------------------------------------------
 // ablate: 0 = normal; 2 = no global B loads; 3 = no MFMA (loads only).  Profiling hook.
 template <int ABL = 0, int PF = 16>   // PF: K groups in flight per wave (16 KB at 16: covers an L2-miss round trip)
-PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) {
+PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid, int tile = -1) {
   constexpr int CBW = 8 / QN_WAVES > 0 ? 8 / QN_WAVES : 1;  // column blocks per wave
   static_assert(QN_WAVES * CBW == 8, "8 column blocks of 16 outputs");
   const int lane = tid & 63, wave = tid >> 6;
@@ -247,7 +247,10 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid) 
   // every workgroup streams the same 512 KB of W1: start each one at a different K group (and wrap) so
   // the CUs of an XCD do not sweep the same L2 channel at the same moment.  The K order only permutes
   // the f32 summation order of the tile.
-  const int rot = (blockIdx.x * 8 + (blockIdx.x >> 3)) & 63;
+  // (`tile` = index of the tile inside its seed when seeds are batched along grid.x, so that a seed's
+  // summation order -- hence its results, bit for bit -- does not depend on how many seeds share the launch)
+  if (tile < 0) tile = blockIdx.x;
+  const int rot = (tile * 8 + (tile >> 3)) & 63;
   const f32x4 *wp = reinterpret_cast<const f32x4 *>(w1p);
   const float *arow = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
   // two accumulator sets (even / odd K groups): consecutive MFMAs of a wave are independent, so the
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
     __syncthreads();   // s.bits holds obs_t of the tile (and every previous reader of the tiles is done)
     phase1_conv<C>(s, tid);
     __syncthreads();
-    phase2_fc1<0, 8>(s, theta + L.off_w1, tid);   // 8 in flight: the env state lives in registers across this loop
+    phase2_fc1<0, 8>(s, theta + L.off_w1, tid, (e0 - e_off) / QN_TILE);   // 8 in flight: the env state lives in registers across this loop
     __syncthreads();
     if (tid < 256) {
       float q[QN_MAXA], h2[8], xh[8], rstd;
@@ -1283,6 +1286,22 @@ extern "C" int pqn_cnn_rollout(int env_id, const pqn_cnn_layout_t *layout, int32
               "pqn_cnn_rollout: observations are recorded through obs_bits[T+1][n][OW], rec->obs / rec->obs_bits must be NULL");
   return pqn_qnet_cnn_rollout(env_id, *layout, num_envs, num_steps, state, obs_bits, theta, r, action, qmax, last_q, eps_dev,
                               keys_dev, rew_scale, store_obs != 0, (hipStream_t)stream);
+}
+
+extern "C" int pqn_cnn_rollout_seeds(int env_id, const pqn_cnn_layout_t *layout, int32_t num_seeds, int32_t envs_per_seed,
+                                     int32_t num_steps, uint32_t *state, uint32_t *obs_bits, int32_t store_obs,
+                                     const float *theta, int64_t theta_stride, const pqn_step_out_t *rec, int32_t *action,
+                                     float *qmax, float *last_q, const float *eps_dev, const uint64_t *keys_dev,
+                                     int32_t keys_stride, float rew_scale, void *stream) {
+  PQN_REQUIRE(layout && state && obs_bits && theta && eps_dev && keys_dev, "pqn_cnn_rollout_seeds: NULL argument");
+  PQN_REQUIRE(num_seeds >= 1 && envs_per_seed > 0 && num_steps > 0 && keys_stride >= num_steps && theta_stride >= 0,
+              "pqn_cnn_rollout_seeds: bad shape seeds=%d n=%d T=%d", num_seeds, envs_per_seed, num_steps);
+  pqn_step_out_t none = {};
+  const pqn_step_out_t &r = rec ? *rec : none;
+  PQN_REQUIRE(r.obs == nullptr && r.obs_bits == nullptr, "pqn_cnn_rollout_seeds: rec->obs / rec->obs_bits must be NULL");
+  return pqn_qnet_cnn_rollout(env_id, *layout, num_seeds * envs_per_seed, num_steps, state, obs_bits, theta, r, action, qmax,
+                              last_q, eps_dev, keys_dev, rew_scale, store_obs != 0, (hipStream_t)stream, envs_per_seed,
+                              theta_stride, keys_stride);
 }
 
 // ---------------------------------------------------------------------------

@@ -258,6 +258,32 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         _lib.check(lib.pqn_env_step(base_env.env_id, words.shape[1], key, _lib.ptr(words), _lib.ptr(words),
                                     _lib.ptr(action), C.byref(out), sp()), "pqn_env_step")
 
+    def fused_eval(layout, theta_k, k, n_t, steps, buf):
+        """The evaluation scan (pqn_minatar.py:380-401) as ONE persistent launch (pqn_cnn_rollout with
+        eps = EPS_TEST, nothing recorded but the info arrays), then the masked means (:403-412)."""
+        if "keys" not in buf:
+            z = lambda dt: torch.empty((steps, n_t), dtype=dt, device=dev)
+            buf.update(keys=torch.empty(steps, dtype=torch.int64, device=dev),
+                       eps=torch.full((1,), float(config["EPS_TEST"]), dtype=torch.float32, device=dev),
+                       done=z(torch.uint8), discount=z(torch.float32), rer=z(torch.float32),
+                       rel=z(torch.int32), ts=z(torch.int32))
+        b = buf
+        (_o, bits), state = env.reset(_lib.fold_in(k, 0), env_params, n_t, want_obs=False, want_bits=True)
+        _lib.check(lib.pqn_fold_in_range(k, 1, steps, _lib.ptr(b["keys"]), sp()), "pqn_fold_in_range")
+        rec = _lib.StepOut(done=_lib.ptr(b["done"]), discount=_lib.ptr(b["discount"]),
+                           returned_episode_returns=_lib.ptr(b["rer"]), returned_episode_lengths=_lib.ptr(b["rel"]),
+                           timestep=_lib.ptr(b["ts"]))
+        _lib.check(lib.pqn_cnn_rollout(base_env.env_id, C.byref(layout.struct), n_t, steps,
+                                       _lib.ptr(state.words), _lib.ptr(bits), 0, _lib.ptr(theta_k),
+                                       C.byref(rec), None, None, None, _lib.ptr(b["eps"]), _lib.ptr(b["keys"]),
+                                       1.0, sp()), "pqn_cnn_rollout")
+        dm = b["done"].to(torch.float64)
+        cnt = dm.sum()
+        vals = {"discount": b["discount"], "returned_episode_returns": b["rer"], "returned_episode_lengths": b["rel"],
+                "timestep": b["ts"], "returned_episode": b["done"]}
+        # nanmean(where(returned_episode, x, nan)) (:403-412)
+        return {kk: ((vals[kk].to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk in INFO_KEYS}
+
     def make_runner(rng: int):
         """Builds the per-seed training state and returns (update, finish): update(u) runs ONE
         PQN update (rollout + targets + epochs); finish() returns train()'s result dict."""
@@ -293,30 +319,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         eval_buf = {}
 
         def fused_test_metrics(k, n_t, steps):
-            """The evaluation scan (pqn_minatar.py:380-401) as ONE persistent launch (pqn_cnn_rollout with
-            eps = EPS_TEST, nothing recorded but the info arrays), then the masked means (:403-412)."""
-            if not eval_buf:
-                z = lambda dt: torch.empty((steps, n_t), dtype=dt, device=dev)
-                eval_buf.update(keys=torch.empty(steps, dtype=torch.int64, device=dev),
-                                eps=torch.full((1,), float(config["EPS_TEST"]), dtype=torch.float32, device=dev),
-                                done=z(torch.uint8), discount=z(torch.float32), rer=z(torch.float32),
-                                rel=z(torch.int32), ts=z(torch.int32))
-            b = eval_buf
-            (_o, bits), state = env.reset(_lib.fold_in(k, 0), env_params, n_t, want_obs=False, want_bits=True)
-            _lib.check(lib.pqn_fold_in_range(k, 1, steps, _lib.ptr(b["keys"]), sp()), "pqn_fold_in_range")
-            rec = _lib.StepOut(done=_lib.ptr(b["done"]), discount=_lib.ptr(b["discount"]),
-                               returned_episode_returns=_lib.ptr(b["rer"]), returned_episode_lengths=_lib.ptr(b["rel"]),
-                               timestep=_lib.ptr(b["ts"]))
-            _lib.check(lib.pqn_cnn_rollout(base_env.env_id, C.byref(policy.layout.struct), n_t, steps,
-                                           _lib.ptr(state.words), _lib.ptr(bits), 0, _lib.ptr(policy.tr.theta),
-                                           C.byref(rec), None, None, None, _lib.ptr(b["eps"]), _lib.ptr(b["keys"]),
-                                           1.0, sp()), "pqn_cnn_rollout")
-            dm = b["done"].to(torch.float64)
-            cnt = dm.sum()
-            vals = {"discount": b["discount"], "returned_episode_returns": b["rer"], "returned_episode_lengths": b["rel"],
-                    "timestep": b["ts"], "returned_episode": b["done"]}
-            # nanmean(where(returned_episode, x, nan)) (:403-412)
-            return {kk: ((vals[kk].to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk in INFO_KEYS}
+            return fused_eval(policy.layout, policy.tr.theta, k, n_t, steps, eval_buf)
 
         def get_test_metrics():
             if not test_on:
@@ -480,6 +483,126 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         update.driver = driver   # bench.py switches graph replay off for its HIP-event timing pass
         return update, finish
 
+    def make_batch_runner(rngs: List[int]):
+        """jax.vmap(train)(rngs) inside the launches: all seeds advance in the same kernels (grid.y = seed,
+        pqn_cnn_update_seeds), one hipGraph replay per update for all of them.  Same key schedule, same
+        kernels and summation orders as make_runner, so every seed's result is bit-identical to its solo run.
+        Returns (update, finish); finish() -> list of per-seed result dicts."""
+        from .qnet import METRIC_NAMES, CnnKernelLayout, SeedsUpdateDriver
+        S = len(rngs)
+        if not (packed and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25) and 1 <= S <= 128):
+            raise RuntimeError("seed batching needs the fused CNN path, no gradient hook, NUM_ENVS % 16 == 0, <= 128 seeds")
+        layout = CnnKernelLayout(obs_shape[-1], A)
+        Ks = []
+        for rng in rngs:
+            K = int(rng) & 0xFFFFFFFFFFFFFFFF
+            Ks.append(tuple(_lib.fold_in(K, i) for i in range(5)))     # K_init, K_reset, K_test, K_roll, K_shuf
+        lr_steps = (config["NUM_UPDATES_DECAY"] * MB * EPOCHS) if config.get("LR_LINEAR_DECAY", False) else 0.0
+        network = QNetwork(kind, obs_shape, A, norm_type=config["NORM_TYPE"], norm_input=False, device=dev)
+        ro = _Rollout(T, S * N, obs_shape, base_env.obs_words, dev)
+        words = None
+        dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
+                "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}
+        drv = None
+        theta_init = config.get("_INIT_PARAMS")
+        for s, (K_init, K_reset, _kt, _kr, _ks) in enumerate(Ks):
+            (_o, bits0), st = env.reset(K_reset, env_params, N, want_obs=False, want_bits=True)   # (:418-419)
+            if words is None:
+                words = torch.empty((st.words.shape[0], S * N), dtype=st.words.dtype, device=dev)
+                drv = SeedsUpdateDriver(layout, base_env.env_id, S, N, T, MB, EPOCHS, base_env.obs_words, dcfg,
+                                        [k[3] for k in Ks], [k[4] for k in Ks], config["LR"], 1e-20, lr_steps,
+                                        config["MAX_GRAD_NORM"], ro, words, NUM_UPDATES, dev,
+                                        use_graph=config.get("_GRAPH", True))
+            words[:, s * N:(s + 1) * N] = st.words
+            ro.bits[0, s * N:(s + 1) * N] = bits0
+            th = network.init(K_init) if theta_init is None else theta_init.to(dev, torch.float32)   # (:150-173)
+            drv.set_params(s, th)
+        eval_buf = {}
+        runs = [0]
+
+        def test_all():
+            """get_test_metrics of every seed (pqn_minatar.py:371-413) in ONE persistent launch: S x TEST_NUM_ENVS
+            envs, seed s greedy under its own parameters and keys (pqn_cnn_rollout_seeds)."""
+            if not test_on:
+                return [None] * S
+            n_t, steps = int(config["TEST_NUM_ENVS"]), int(config["TEST_NUM_STEPS"])
+            if n_t % 16 != 0:   # ragged test batch: one launch per seed
+                out = [fused_eval(layout, drv.theta_k(s), _lib.fold_in(Ks[s][2], runs[0]), n_t, steps,
+                                  eval_buf.setdefault(("solo", s), {})) for s in range(S)]
+                runs[0] += 1
+                return out
+            if "keys" not in eval_buf:
+                z = lambda dt: torch.empty((steps, S * n_t), dtype=dt, device=dev)
+                eval_buf.update(keys=torch.empty((S, steps), dtype=torch.int64, device=dev),
+                                eps=torch.full((1,), float(config["EPS_TEST"]), dtype=torch.float32, device=dev),
+                                done=z(torch.uint8), discount=z(torch.float32), rer=z(torch.float32),
+                                rel=z(torch.int32), ts=z(torch.int32), words=None,
+                                bits=torch.empty((S * n_t, base_env.obs_words), dtype=torch.int32, device=dev))
+            b = eval_buf
+            for s in range(S):
+                k = _lib.fold_in(Ks[s][2], runs[0])
+                (_o, bits), state = env.reset(_lib.fold_in(k, 0), env_params, n_t, want_obs=False, want_bits=True)
+                if b["words"] is None:
+                    b["words"] = torch.empty((state.words.shape[0], S * n_t), dtype=state.words.dtype, device=dev)
+                b["words"][:, s * n_t:(s + 1) * n_t] = state.words
+                b["bits"][s * n_t:(s + 1) * n_t] = bits
+                _lib.check(lib.pqn_fold_in_range(k, 1, steps, _lib.ptr(b["keys"][s]), sp()), "pqn_fold_in_range")
+            runs[0] += 1
+            rec = _lib.StepOut(done=_lib.ptr(b["done"]), discount=_lib.ptr(b["discount"]),
+                               returned_episode_returns=_lib.ptr(b["rer"]), returned_episode_lengths=_lib.ptr(b["rel"]),
+                               timestep=_lib.ptr(b["ts"]))
+            _lib.check(lib.pqn_cnn_rollout_seeds(base_env.env_id, C.byref(layout.struct), S, n_t, steps, _lib.ptr(b["words"]),
+                                                 _lib.ptr(b["bits"]), 0, _lib.ptr(drv.theta), drv.stride, C.byref(rec), None,
+                                                 None, None, _lib.ptr(b["eps"]), _lib.ptr(b["keys"]), steps, 1.0, sp()),
+                       "pqn_cnn_rollout_seeds")
+            dm = b["done"].to(torch.float64).view(steps, S, n_t)
+            cnt = dm.sum(dim=(0, 2))
+            vals = {"discount": b["discount"], "returned_episode_returns": b["rer"], "returned_episode_lengths": b["rel"],
+                    "timestep": b["ts"], "returned_episode": b["done"]}
+            # nanmean(where(returned_episode, x, nan)) per seed (:403-412)
+            means = {kk: ((vals[kk].to(torch.float64).view(steps, S, n_t) * dm).sum(dim=(0, 2)) / cnt).to(torch.float32)
+                     for kk in INFO_KEYS}
+            return [{kk: means[kk][s] for kk in INFO_KEYS} for s in range(S)]
+
+        tm_box = [test_all()]
+        test_period = int(NUM_UPDATES * config["TEST_INTERVAL"]) if test_on else 0
+        test_rows = torch.zeros((S, NUM_UPDATES, len(INFO_KEYS)), dtype=torch.float32, device=dev) if test_on else None
+        counters = {"timesteps": 0, "n_updates": 0, "grad_steps": 0}
+
+        def update(u: int):
+            if u != drv.calls:
+                raise RuntimeError(f"update({u}) out of order: the device clock is at {drv.calls}")
+            drv.update()
+            counters["timesteps"] += T * N
+            counters["n_updates"] += 1
+            counters["grad_steps"] += MB * EPOCHS
+            if test_on:
+                if test_period > 0 and counters["n_updates"] % test_period == 0:
+                    tm_box[0] = test_all()
+                test_rows[:, u] = torch.stack([torch.stack([tm_box[0][s][k] for k in INFO_KEYS]) for s in range(S)])
+
+        def finish():
+            names = ["env_step", "update_steps", "env_frame", "grad_steps", "td_loss", "qvals"] + list(INFO_KEYS)
+            outs = []
+            for s in range(S):
+                metrics = {name: drv.metrics[s, :NUM_UPDATES, METRIC_NAMES.index(name)].to(torch.float32) for name in names}
+                if test_on:
+                    for j, k in enumerate(INFO_KEYS):
+                        metrics[f"test/{k}"] = test_rows[s, :, j]
+                theta_f = layout.to_flax(drv.theta_k(s))
+                sl = slice(s * N, (s + 1) * N)
+                runner_state = {"params": network.views(theta_f), "theta": theta_f, "env_state": words[:, sl].contiguous(),
+                                "last_obs": ro.bits[0, sl], "test_metrics": tm_box[0][s], "network": network,
+                                "backend": backend, "driver": "graph" if drv.graph is not None else "eager",
+                                "driver_graph_error": drv.graph_error, "opt_count": drv.count[s:s + 1],
+                                "opt_mu": drv.m[s, :layout.total], "opt_nu": drv.v[s, :layout.total],
+                                "kernel_layout": layout, "seed_batch": S, **counters}
+                outs.append({"runner_state": runner_state, "metrics": metrics})
+            return outs
+
+        update.driver = drv
+        return update, finish
+
     def train(rng: int) -> Dict[str, Any]:
         update, finish = make_runner(rng)
         for u in range(NUM_UPDATES):
@@ -487,6 +610,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         return finish()
 
     train.make_runner = make_runner
+    train.make_batch_runner = make_batch_runner
+    train.can_batch_seeds = bool(packed and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25)
+                                 and config.get("_DRIVER", True) and config.get("_CALLBACK") is None)
     train.config = config
     train.backend = backend
     return train
@@ -496,34 +622,47 @@ def vmap_train(train: Callable[[int], Dict[str, Any]], keys: List[int], concurre
     """jax.vmap(make_train(config))(rngs) (pqn_minatar.py:459-461): independent seeds, outputs stacked on
     a leading [S] axis where they are tensors.
 
-    Seeds share nothing (own parameters, optimizer, envs, RNG streams), so on one GPU they run as S
-    independent HIP streams: update u of every seed is enqueued round-robin (one hipGraph replay each) and
-    the hardware overlaps them -- a 128-env seed leaves most of the 256 CUs idle, a 4096-env seed leaves
-    its latency-bound tails.  Results are identical to running the seeds one after another."""
+    Seeds share nothing (own parameters, optimizer, envs, RNG streams).  On the fused CNN path they are batched
+    INTO the launches (grid.y = seed, pqn_cnn_update_seeds): one hipGraph replay advances every seed, so ten
+    128-env seeds cost about as much as one.  Other paths (MLP, torch-op networks) run the seeds as concurrent
+    HIP streams (`concurrent="streams"` forces that mode).  Either way each seed's result is bit-identical to
+    its solo run (`concurrent=False`)."""
     keys = list(keys)
     on_gpu = torch.cuda.is_available()
     if not concurrent or len(keys) <= 1 or not on_gpu or not hasattr(train, "make_runner"):
         outs = [train(k) for k in keys]
+    elif concurrent == "streams" or not getattr(train, "can_batch_seeds", False) or len(keys) > 128:
+        outs = _vmap_streams(train, keys)
     else:
-        num_updates = int(train.config["NUM_UPDATES"])
-        main = torch.cuda.current_stream()
-        streams = [torch.cuda.Stream() for _ in keys]
-        runners = []
-        for s, k in zip(streams, keys):
-            s.wait_stream(main)
-            with torch.cuda.stream(s):
-                runners.append(train.make_runner(k))
-        for u in range(num_updates):
-            for s, (update, _finish) in zip(streams, runners):
-                with torch.cuda.stream(s):
-                    update(u)
-        outs = []
-        for s, (_update, finish) in zip(streams, runners):
-            with torch.cuda.stream(s):
-                outs.append(finish())
-            main.wait_stream(s)
+        # the fused CNN path batches the seeds INTO the launches (grid.y = seed): one hipGraph replay per update
+        update, finish = train.make_batch_runner(keys)
+        for u in range(int(train.config["NUM_UPDATES"])):
+            update(u)
+        outs = finish()
     metrics = {k: torch.stack([o["metrics"][k] for o in outs]) for k in outs[0]["metrics"]}
     return {"runner_state": [o["runner_state"] for o in outs], "metrics": metrics}
+
+
+def _vmap_streams(train, keys):
+    """Seeds as concurrent HIP streams (paths without seed-batched kernels: MLP, torch-op networks)."""
+    num_updates = int(train.config["NUM_UPDATES"])
+    main = torch.cuda.current_stream()
+    streams = [torch.cuda.Stream() for _ in keys]
+    runners = []
+    for s, k in zip(streams, keys):
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            runners.append(train.make_runner(k))
+    for u in range(num_updates):
+        for s, (update, _finish) in zip(streams, runners):
+            with torch.cuda.stream(s):
+                update(u)
+    outs = []
+    for s, (_update, finish) in zip(streams, runners):
+        with torch.cuda.stream(s):
+            outs.append(finish())
+        main.wait_stream(s)
+    return outs
 
 
 def seed_keys(seed: int, num_seeds: int) -> List[int]:

@@ -54,14 +54,22 @@ def test_vmap_train_seeds_are_independent_and_stacked(gpu):
     again = make_train(dict(cfg), device="cuda:0")(keys[1])    # same seed -> bit-identical rerun (deterministic kernels)
     torch.testing.assert_close(again["metrics"]["td_loss"], m[1], rtol=0, atol=0)
     torch.testing.assert_close(again["runner_state"]["theta"], outs["runner_state"][1]["theta"], rtol=0, atol=0)
-    # seeds on concurrent HIP streams (the default) == seeds one after another, eval included
-    cfg_t = _cfg(TEST_DURING_TRAINING=True, TEST_NUM_ENVS=8)
-    conc = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys)
-    seq = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys, concurrent=False)
-    for k in conc["metrics"]:
-        torch.testing.assert_close(conc["metrics"][k], seq["metrics"][k], rtol=0, atol=0, equal_nan=True)
-    for a, b in zip(conc["runner_state"], seq["runner_state"]):
-        torch.testing.assert_close(a["theta"], b["theta"], rtol=0, atol=0)
+    assert outs["runner_state"][0]["seed_batch"] == 3           # the seeds went through pqn_cnn_update_seeds
+    # seeds batched into the launches (the default) == seeds on concurrent streams == seeds one after another,
+    # evaluation included (batched eval rollout for TEST_NUM_ENVS % 16 == 0, per-seed launches otherwise)
+    for n_test in (16, 8):
+        cfg_t = _cfg(TEST_DURING_TRAINING=True, TEST_NUM_ENVS=n_test)
+        conc = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys)
+        seq = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys, concurrent=False)
+        streams = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys, concurrent="streams")
+        assert conc["runner_state"][0].get("seed_batch") == 3 and "seed_batch" not in streams["runner_state"][0]
+        for other in (seq, streams):
+            for k in conc["metrics"]:
+                torch.testing.assert_close(conc["metrics"][k], other["metrics"][k], rtol=0, atol=0, equal_nan=True)
+            for a, b in zip(conc["runner_state"], other["runner_state"]):
+                torch.testing.assert_close(a["theta"], b["theta"], rtol=0, atol=0)
+                torch.testing.assert_close(a["opt_mu"], b["opt_mu"], rtol=0, atol=0)
+                assert torch.equal(a["env_state"], b["env_state"])
 
 
 def test_single_run_saves_reference_format_checkpoints(gpu, tmp_path):
