@@ -350,6 +350,44 @@ PQN_D void phase3_head(const CnnSmem &s, const float *__restrict__ theta, const 
   }
 }
 
+// The same block in two halves: all global loads first (into registers), LDS stores later -- the training kernel
+// issues its dependent observation gather in between, so the two latencies overlap.
+template <int C>
+struct TileParams {
+  using Cfg = CnnCfg<C>;
+  static constexpr int NWC = (Cfg::KW * 16 + 48 + QN_THREADS - 1) / QN_THREADS;
+  static constexpr int NW2 = (128 * QN_MAXA + QN_THREADS - 1) / QN_THREADS;
+  float wc[NWC], hp, w2[NW2], b2;
+  PQN_D void load(const float *__restrict__ theta, const pqn_cnn_layout_t &L, int tid) {
+#pragma unroll
+    for (int k = 0; k < NWC; ++k) {
+      const int i = tid + k * QN_THREADS;
+      wc[k] = i < Cfg::KW * 16 + 48 ? theta[L.off_wc + i] : 0.0f;
+    }
+    hp = tid < 384 ? theta[L.off_b1 + tid] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < NW2; ++k) {
+      const int i = tid + k * QN_THREADS;
+      w2[k] = i < 128 * L.a ? theta[L.off_w2 + i] : 0.0f;
+    }
+    b2 = tid < L.a ? theta[L.off_b2 + tid] : 0.0f;
+  }
+  PQN_D void store(const CnnSmem &s, const pqn_cnn_layout_t &L, int tid) const {
+#pragma unroll
+    for (int k = 0; k < NWC; ++k) {
+      const int i = tid + k * QN_THREADS;
+      if (i < Cfg::KW * 16 + 48) s.wc[i] = wc[k];
+    }
+    if (tid < 384) s.hp[tid] = hp;
+#pragma unroll
+    for (int k = 0; k < NW2; ++k) {
+      const int i = tid + k * QN_THREADS;
+      if (i < 128 * L.a) s.hp[384 + i] = w2[k];
+    }
+    if (tid < L.a) s.hp[384 + 128 * L.a + tid] = b2;
+  }
+};
+
 template <int C>
 PQN_D void load_tile_common(const CnnSmem &s, const float *__restrict__ theta, const pqn_cnn_layout_t &L, int tid) {
   using Cfg = CnnCfg<C>;
@@ -779,13 +817,14 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     ix[k] = (i < QN_TILE * Cfg::OW && b0 + le < nb) ? row_of(idx[b0 + le]) : -1;
   }
   const int64_t src16 = (tid < QN_TILE && b0 + tid < nb) ? row_of(idx[b0 + tid]) : -1;
-  load_tile_common<C>(s, theta, L, tid);
+  TileParams<C> tp;
+  tp.load(theta, L, tid);               // in flight together with the index loads above
+  uint32_t gb[NBI];
 #pragma unroll
-  for (int k = 0; k < NBI; ++k) {
+  for (int k = 0; k < NBI; ++k) {       // needs only the (older) index loads: goes out while the parameters travel
     const int i = tid + k * QN_THREADS;
-    if (i < QN_TILE * Cfg::OW) s.bits[i] = (ix[k] >= 0) ? obs_bits[(size_t)ix[k] * Cfg::OW + (i % Cfg::OW)] : 0u;
+    gb[k] = (i < QN_TILE * Cfg::OW && ix[k] >= 0) ? obs_bits[(size_t)ix[k] * Cfg::OW + (i % Cfg::OW)] : 0u;
   }
-  if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
   // action / target of the tile's samples (second level of the gather): consumed by the head, parked
   // in LDS after fc1 so the latency hides behind the forward pass
   int act_g = 0;
@@ -794,6 +833,13 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     act_g = action[src16];
     tgt_g = target[src16];
   }
+  tp.store(s, L, tid);
+#pragma unroll
+  for (int k = 0; k < NBI; ++k) {
+    const int i = tid + k * QN_THREADS;
+    if (i < QN_TILE * Cfg::OW) s.bits[i] = gb[k];
+  }
+  if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
   __syncthreads();
   T1_STAMP(1);
   // ---- P1..P3: forward ---------------------------------------------------------------------
