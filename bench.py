@@ -115,6 +115,8 @@ def main():
                     help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
                          "(RCCL gradient all-reduce per optimizer step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--matmul-dtype", default="f32", choices=["f32", "f16"],
+                    help="operand type of the fc1 products (config MATMUL_DTYPE); f16 = fp16 operands, f32 accumulation")
     ap.add_argument("--multi-seed", type=int, default=16,
                     help="N=1 only: also report the aggregate rate of this many independent seeds of the same workload "
                          "batched into the same launches (jax.vmap over seeds, pqn_minatar.py:459-461; 16 per GPU = "
@@ -141,6 +143,7 @@ def main():
     from purejaxql_amd import dist as pdist
 
     cfg = workload_config(args.num_envs, args.mode)
+    cfg["MATMUL_DTYPE"] = args.matmul_dtype
     cfg["TOTAL_TIMESTEPS"] = (args.steps + args.warmup + 3) * cfg["NUM_ENVS"] * cfg["NUM_STEPS"]
     grad_hook = None
     if world > 1 and args.mode == "envs":

@@ -148,10 +148,20 @@ int pqn_radam_clip_step(float *p, const float *g, float *m, float *v, int64_t n,
 typedef struct {
   int32_t c, a;
   int32_t off_bn, off_wc, off_bc, off_ln0s, off_ln0b, off_w1, off_b1, off_ln1s, off_ln1b, off_w2, off_b2;
-  int32_t total; /* floats in the buffer (>= flax parameter count; pads are zero) */
+  int32_t total; /* floats that are parameters (>= flax parameter count; pads are zero): the span of grad / m / v */
+  /* Matmul operand precision of the two big layers.  0: f32 MFMA everywhere (the reference's arithmetic type).
+   * 1: the fc1 products (forward, input gradient, weight gradient: 78 % of the FLOPs) take fp16 operands with
+   * f32 accumulation (v_mfma_f32_16x16x16_f16) -- the 10-bit mantissa of the TF32 mode JAX uses for f32
+   * matmuls on the reference's A40; master weights, optimizer, LayerNorm, conv, head and loss stay f32.
+   * The theta buffer then carries two fp16 fragment-order copies of the fc1 kernel behind the parameters
+   * (kept in step by pqn_qnet_cnn_apply / pqn_qnet_cnn_pack_w1b): allocate `alloc` floats for theta. */
+  int32_t matmul_f16;
+  int32_t off_w1h; /* float offset of the fp16 forward copy (131072 halves), the dgrad copy follows it */
+  int32_t alloc;   /* floats to allocate for theta (== total when matmul_f16 == 0) */
 } pqn_cnn_layout_t;
 
-int pqn_cnn_layout(int32_t c, int32_t a, pqn_cnn_layout_t *layout /* host */);
+int pqn_cnn_layout(int32_t c, int32_t a, pqn_cnn_layout_t *layout /* host */);           /* matmul_f16 = 0 */
+int pqn_cnn_layout_ex(int32_t c, int32_t a, int32_t matmul_f16, pqn_cnn_layout_t *layout /* host */);
 
 /* network.apply(params, obs, train=False) on packed observations, fused with the
  * eps-greedy draw of pqn_minatar.py:184-196 (and :227-235, :380-390).  Outputs
@@ -180,7 +190,9 @@ int pqn_qnet_cnn_grad(const pqn_cnn_layout_t *layout /* host */, int32_t nb, con
 int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *layout /* host */, float *theta, float *w1b, const float *grad,
                        float *m, float *v, int32_t *count, float lr_init, float lr_end, float lr_steps,
                        float max_norm, float *workspace, float *gnorm_out, int32_t recompute_norm, void *stream);
-int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *layout /* host */, const float *theta, float *w1b, void *stream);
+/* (re)derive the copies of the fc1 kernel from theta: w1b (f32 dgrad fragments, 131072 floats; NULL = skip) and,
+ * for a matmul_f16 layout, the two fp16 copies in theta's own tail.  Call after writing parameters by hand. */
+int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *layout /* host */, float *theta, float *w1b, void *stream);
 
 /* Kernel timer for bench.py's roofline line: when enabled, pqn_qnet_cnn_grad brackets its dominant
  * kernel (qnet_cnn_train_kernel) with HIP events on the launch stream; pqn_prof_read synchronises

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pqn_radam_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float,
                                     c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "pqn_cnn_layout": (c_int, [c_int32, c_int32, c_void_p]),
+    "pqn_cnn_layout_ex": (c_int, [c_int32, c_int32, c_int32, c_void_p]),
     "pqn_qnet_cnn_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                      c_uint64, c_void_p]),
     "pqn_qnet_cnn_workspace_floats": (c_int64, [c_void_p, c_int32]),

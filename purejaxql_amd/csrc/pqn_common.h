@@ -99,7 +99,7 @@ inline pqn_seeds_t pqn_one_seed() {
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
                      float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
                      float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds = 1, long long pstride = 0,
-                     long long sstride = 0, long long w1bstride = 0);
+                     long long sstride = 0, long long w1bstride = 0, int half_off = 0);
 
 // internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,

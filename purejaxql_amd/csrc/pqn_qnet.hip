@@ -311,6 +311,56 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid, 
   }
 }
 
+// fp16-operand variant (pqn_cnn_layout_t.matmul_f16): same tile, same fragment order, one
+// v_mfma_f32_16x16x16_f16 per 16-wide K group instead of four f32 MFMAs.  Lane (i = l&15, kk = l>>4) holds
+// k = 16g + 4kk + 0..3 of its row as 4 halves -- exactly the 4 floats of the f32 fragment, so the A operand is
+// the same ds_read_b128 converted on the fly and the B operand is the 8-byte half of the f32 fragment
+// (w1h, kept in step by the optimizer).  Accumulation is f32.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+PQN_D f16x4 to_f16x4(const f32x4 v) { return f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
+
+template <int PF = 16>
+PQN_D void phase2_fc1_f16(const CnnSmem &s, const _Float16 *__restrict__ w1h, int tid, int tile = -1) {
+  static_assert(QN_WAVES == 8, "one column block of 16 outputs per wave");
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tile < 0) tile = blockIdx.x;
+  const int rot = (tile * 8 + (tile >> 3)) & 63;
+  const f16x4 *wp = reinterpret_cast<const f16x4 *>(w1h);
+  const float *arow = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  f16x4 b[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) b[i] = wp[(((i + rot) & 63) * 8 + wave) * 64 + lane];
+  f32x4 a_next = *reinterpret_cast<const f32x4 *>(arow + 16 * (rot & 63));
+  auto group_block = [&](int g, auto more_t) {
+    constexpr bool more = decltype(more_t)::value;
+#pragma unroll
+    for (int i = 0; i < PF; i += 2) {
+      const f32x4 a0 = a_next;
+      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 1 + rot) & 63));
+      a_next = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 2 + rot) & 63));
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x16f16(to_f16x4(a0), b[i], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x16f16(to_f16x4(a1), b[i + 1], acc2, 0, 0, 0);
+      if (more) {
+        b[i] = wp[(((g + i + PF + rot) & 63) * 8 + wave) * 64 + lane];
+        b[i + 1] = wp[(((g + i + 1 + PF + rot) & 63) * 8 + wave) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#pragma unroll 1
+  for (int g = 0; g < QN_H1 / 16 - PF; g += PF) group_block(g, std::true_type{});
+  group_block(QN_H1 / 16 - PF, std::false_type{});
+  acc += acc2;
+  const int col = lane & 15, r0 = 4 * (lane >> 4);
+  float *zp = s.z + r0 * QN_ZS + 16 * wave + col;
+  zp[0] = acc.x;
+  zp[QN_ZS] = acc.y;
+  zp[2 * QN_ZS] = acc.z;
+  zp[3 * QN_ZS] = acc.w;
+}
+
 // ---------------------------------------------------------------------------
 // phase 3: per sample m (16 lanes each): z+b1 -> LN(128) -> relu -> fc2 -> q[A].
 // Every lane of the 16-lane group ends up with all q values.  xh/rstd returned
@@ -445,7 +495,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
   __syncthreads();
   if (ablate != 1 && ablate != 6 && ablate != 7) phase1_conv<C>(s, tid);
   __syncthreads();
-  if (ablate == 0 || ablate == 1 || ablate == 5) phase2_fc1<0>(s, theta + L.off_w1, tid);
+  if (L.matmul_f16) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
+  else if (ablate == 0 || ablate == 1 || ablate == 5) phase2_fc1<0>(s, theta + L.off_w1, tid);
   else if (ablate == 2) phase2_fc1<2>(s, theta + L.off_w1, tid);
   else if (ablate == 3) phase2_fc1<3>(s, theta + L.off_w1, tid);
   __syncthreads();
@@ -533,7 +584,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
     __syncthreads();   // s.bits holds obs_t of the tile (and every previous reader of the tiles is done)
     phase1_conv<C>(s, tid);
     __syncthreads();
-    phase2_fc1<0, 8>(s, theta + L.off_w1, tid, (e0 - e_off) / QN_TILE);   // 8 in flight: the env state lives in registers across this loop
+    if (L.matmul_f16) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid, (e0 - e_off) / QN_TILE);
+    else phase2_fc1<0, 8>(s, theta + L.off_w1, tid, (e0 - e_off) / QN_TILE);   // 8 in flight: the env state lives in registers across this loop
     __syncthreads();
     if (tid < 256) {
       float q[QN_MAXA], h2[8], xh[8], rstd;
@@ -847,7 +899,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   phase1_conv<C, true>(s, tid, xkeep, rkeep);
   __syncthreads();
   T1_STAMP(2);
-  phase2_fc1<0>(s, theta + L.off_w1, tid);
+  if (L.matmul_f16) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
+  else phase2_fc1<0>(s, theta + L.off_w1, tid);
   // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
   // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
   for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
@@ -872,7 +925,54 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   }
   T1_STAMP(4);
   // ---- P4: dgrad  dh1[m][i] = sum_o dz[m][o] W1[i][o]  (A = dz tile, B = W1 in dgrad fragment order) ----
-  if (!(ablate & 1)) {
+  if (L.matmul_f16) {
+    // fp16 operands, f32 accumulation: one v_mfma_f32_16x16x16_f16 per 16-wide K group.  dz is O(1/B): it is
+    // scaled by a power of two (>= B/2) into fp16's normal range and the product scaled back in f32.
+    const float sc = exp2f(floorf(log2f(1.0f / inv_b))), isc = 1.0f / sc;
+    const f16x4 *wb = reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(theta + L.off_w1h) + QN_H1 * QN_HID);
+    f16x4 afr[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 16 * g + 4 * (lane >> 4));
+      afr[g] = to_f16x4(v * sc);
+    }
+    const int col = lane & 15, r0 = 4 * (lane >> 4);
+    constexpr int IBW = 64 / QN_WAVES;
+    const int ib_first = IBW * wave;
+    const int prot = blockIdx.x & (IBW - 1);
+    auto frag = [&](int n) { return wb[((n & 7) * 64 + ib_first + (((n >> 3) + prot) & (IBW - 1))) * 64 + lane]; };
+    f16x4 ring[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) ring[n] = frag(n);
+    auto pair_step = [&](int ip, auto more_t) {
+      constexpr bool more = decltype(more_t)::value;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ib = ib_first + ((2 * ip + h + prot) & (IBW - 1));
+        float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
+        const float m0 = p0[0], m1 = p0[QN_H1S], m2 = p0[2 * QN_H1S], m3 = p0[3 * QN_H1S];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 8; g += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(afr[g], ring[8 * h + g], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(afr[g + 1], ring[8 * h + g + 1], acc1, 0, 0, 0);
+          if (more) {
+            ring[8 * h + g] = frag(16 * (ip + 1) + 8 * h + g);
+            ring[8 * h + g + 1] = frag(16 * (ip + 1) + 8 * h + g + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        acc0 = (acc0 + acc1) * isc;
+        p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
+        p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
+        p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
+        p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
+      }
+    };
+#pragma unroll 1
+    for (int ip = 0; ip < IBW / 2 - 1; ++ip) pair_step(ip, std::true_type{});
+    pair_step(IBW / 2 - 1, std::false_type{});
+  } else if (!(ablate & 1)) {
     const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
     f32x4 afr[8];
 #pragma unroll
@@ -1212,7 +1312,9 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
 // ===========================================================================
 static int align4(int x) { return (x + 3) & ~3; }
 
-extern "C" int pqn_cnn_layout(int32_t c, int32_t a, pqn_cnn_layout_t *L) {
+extern "C" int pqn_cnn_layout(int32_t c, int32_t a, pqn_cnn_layout_t *L) { return pqn_cnn_layout_ex(c, a, 0, L); }
+
+extern "C" int pqn_cnn_layout_ex(int32_t c, int32_t a, int32_t matmul_f16, pqn_cnn_layout_t *L) {
   PQN_REQUIRE(L, "pqn_cnn_layout: layout is NULL");
   PQN_REQUIRE(c == 4 || c == 6 || c == 7 || c == 10, "pqn_cnn_layout: unsupported channel count %d", c);
   PQN_REQUIRE(a >= 1 && a <= QN_MAXA, "pqn_cnn_layout: num_actions %d out of range [1,%d]", a, QN_MAXA);
@@ -1231,6 +1333,9 @@ extern "C" int pqn_cnn_layout(int32_t c, int32_t a, pqn_cnn_layout_t *L) {
   L->off_w2 = off; off = align4(off + QN_HID * a);
   L->off_b2 = off; off = align4(off + a);
   L->total = off;
+  L->matmul_f16 = matmul_f16 ? 1 : 0;
+  L->off_w1h = off;                                        // 2 x 131072 halves = 131072 floats behind the parameters
+  L->alloc = matmul_f16 ? off + QN_H1 * QN_HID : off;
   return PQN_OK;
 }
 
@@ -1477,20 +1582,30 @@ extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float
                                   void *stream) {
   PQN_REQUIRE(L && theta && w1b && grad && m && v && count && workspace, "pqn_qnet_cnn_apply: NULL argument");
   return pqn_launch_radam(theta, grad, m, v, L->total, count, lr_init, lr_end, lr_steps, max_norm, workspace, gnorm_out,
-                          L->off_w1, w1b, recompute_norm, grad_reduce_blocks(L->total), (hipStream_t)stream);
+                          L->off_w1, w1b, recompute_norm, grad_reduce_blocks(L->total), (hipStream_t)stream, 1, 0, 0, 0,
+                          L->matmul_f16 ? L->off_w1h : 0);
 }
 
-__global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict__ w1b) {
+// w1b: f32 dgrad-fragment copy (nullable);  w1h: fp16 forward-fragment copy + fp16 dgrad-fragment copy (nullable)
+__global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict__ w1b, _Float16 *__restrict__ w1h) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= QN_H1 * QN_HID) return;
   const int frag = j >> 8, ln = (j >> 2) & 63, sx = j & 3;
   const int gi = frag >> 3, cb = frag & 7, kk = ln >> 4, jj = ln & 15;
-  w1b[(((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3)] = w1p[j];
+  const int jb = (((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3);
+  const float w = w1p[j];
+  if (w1b) w1b[jb] = w;
+  if (w1h) {
+    w1h[j] = (_Float16)w;
+    w1h[QN_H1 * QN_HID + jb] = (_Float16)w;
+  }
 }
 
-extern "C" int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *L, const float *theta, float *w1b, void *stream) {
-  PQN_REQUIRE(L && theta && w1b, "pqn_qnet_cnn_pack_w1b: NULL argument");
-  hipLaunchKernelGGL(pack_w1b_kernel, dim3(QN_H1 * QN_HID / 256), dim3(256), 0, (hipStream_t)stream,
-                     theta + L->off_w1, w1b);
+// theta is written only in its tail (the fp16 copies of a matmul_f16 layout); pass w1b = NULL to refresh just those
+extern "C" int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *L, float *theta, float *w1b, void *stream) {
+  PQN_REQUIRE(L && theta, "pqn_qnet_cnn_pack_w1b: NULL argument");
+  PQN_REQUIRE(w1b || L->matmul_f16, "pqn_qnet_cnn_pack_w1b: nothing to do");
+  hipLaunchKernelGGL(pack_w1b_kernel, dim3(QN_H1 * QN_HID / 256), dim3(256), 0, (hipStream_t)stream, theta + L->off_w1, w1b,
+                     L->matmul_f16 ? reinterpret_cast<_Float16 *>(theta + L->off_w1h) : (_Float16 *)nullptr);
   return pqn_check_launch("pqn_qnet_cnn_pack_w1b");
 }

@@ -202,7 +202,7 @@ static int cnn_update_impl(const pqn_update_args_t *a, int S, const uint64_t *ke
                                         a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, sd, st));
       UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
                                  a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, 0, pqn_cnn_grad_reduce_blocks(L.total),
-                                 st, S, sd.theta_stride, sd.ws_stride, sd.w1b_stride));
+                                 st, S, sd.theta_stride, sd.ws_stride, sd.w1b_stride, L.matmul_f16 ? L.off_w1h : 0));
     }
   }
   // carry last_obs into the next update; metrics (:329-338); advance the clock

@@ -137,7 +137,8 @@ class _FusedCnnPolicy:
     def __init__(self, network, theta, config, lr_steps, grad_hook, max_mb):
         from .qnet import CnnKernelLayout, CnnTrainer, cnn_forward
         self.net = network
-        self.layout = CnnKernelLayout(network.obs_shape[-1], network.action_dim)
+        self.layout = CnnKernelLayout(network.obs_shape[-1], network.action_dim,
+                                      matmul_f16=str(config.get("MATMUL_DTYPE", "f32")).lower() in ("f16", "fp16", "float16"))
         self.tr = CnnTrainer(self.layout, theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps,
                              max_minibatch=max_mb)
         self.fwd = cnn_forward
@@ -492,7 +493,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         S = len(rngs)
         if not (packed and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25) and 1 <= S <= 128):
             raise RuntimeError("seed batching needs the fused CNN path, no gradient hook, NUM_ENVS % 16 == 0, <= 128 seeds")
-        layout = CnnKernelLayout(obs_shape[-1], A)
+        layout = CnnKernelLayout(obs_shape[-1], A,
+                                 matmul_f16=str(config.get("MATMUL_DTYPE", "f32")).lower() in ("f16", "fp16", "float16"))
         Ks = []
         for rng in rngs:
             K = int(rng) & 0xFFFFFFFFFFFFFFFF

@@ -19,16 +19,23 @@ from . import _lib
 class CnnLayoutStruct(C.Structure):
     """pqn_cnn_layout_t"""
     _fields_ = [(n, C.c_int32) for n in ("c", "a", "off_bn", "off_wc", "off_bc", "off_ln0s", "off_ln0b", "off_w1",
-                                         "off_b1", "off_ln1s", "off_ln1b", "off_w2", "off_b2", "total")]
+                                         "off_b1", "off_ln1s", "off_ln1b", "off_w2", "off_b2", "total", "matmul_f16",
+                                         "off_w1h", "alloc")]
 
 
 class CnnKernelLayout:
-    def __init__(self, channels: int, num_actions: int):
+    """pqn_cnn_layout_t + the flax <-> kernel index map.  matmul_f16: the fc1 products (forward, input gradient,
+    weight gradient) take fp16 operands with f32 accumulation (config MATMUL_DTYPE: "f16"); the parameter buffer
+    then carries two fp16 copies of the fc1 kernel behind the `total` parameter floats (`alloc` floats in all)."""
+
+    def __init__(self, channels: int, num_actions: int, matmul_f16: bool = False):
         lib = _lib.load()
         self.struct = CnnLayoutStruct()
-        _lib.check(lib.pqn_cnn_layout(channels, num_actions, C.byref(self.struct)), "pqn_cnn_layout")
+        _lib.check(lib.pqn_cnn_layout_ex(channels, num_actions, 1 if matmul_f16 else 0, C.byref(self.struct)),
+                   "pqn_cnn_layout_ex")
         s = self.struct
         self.c, self.a, self.total = int(s.c), int(s.a), int(s.total)
+        self.alloc, self.matmul_f16 = int(s.alloc), bool(s.matmul_f16)
         c, a = self.c, self.a
         i = torch.arange(1024).view(-1, 1)
         o = torch.arange(128).view(1, -1)
@@ -41,9 +48,16 @@ class CnnKernelLayout:
         assert int(torch.unique(self.kidx).numel()) == self.num_flax
 
     def to_kernel(self, theta_flax: torch.Tensor) -> torch.Tensor:
-        out = torch.zeros(self.total, dtype=torch.float32, device=theta_flax.device)
+        out = torch.zeros(self.alloc, dtype=torch.float32, device=theta_flax.device)
         out[self.kidx.to(theta_flax.device)] = theta_flax.to(torch.float32)
+        self.refresh_copies(out)
         return out
+
+    def refresh_copies(self, theta_k: torch.Tensor, w1b: Optional[torch.Tensor] = None):
+        """Re-derive the fragment-order copies of the fc1 kernel (w1b: f32 dgrad copy; fp16 copies in theta's tail)."""
+        if theta_k.is_cuda and (w1b is not None or self.matmul_f16):
+            _lib.check(_lib.load().pqn_qnet_cnn_pack_w1b(C.byref(self.struct), _lib.ptr(theta_k), _lib.ptr(w1b),
+                                                         _lib.stream_ptr()), "pqn_qnet_cnn_pack_w1b")
 
     def to_flax(self, theta_k: torch.Tensor) -> torch.Tensor:
         return theta_k[self.kidx.to(theta_k.device)]
@@ -115,8 +129,7 @@ class CnnTrainer:
         self._ws_nb = 0
         self.ws = None
         self._ensure_ws(max_minibatch)
-        _lib.check(lib.pqn_qnet_cnn_pack_w1b(C.byref(layout.struct), _lib.ptr(self.theta), _lib.ptr(self.w1b),
-                                             _lib.stream_ptr()), "pqn_qnet_cnn_pack_w1b")
+        layout.refresh_copies(self.theta, self.w1b)
 
     def _ensure_ws(self, nb: int):
         if nb > self._ws_nb:
@@ -258,7 +271,7 @@ class SeedsUpdateDriver:
         self.layout, self.s, self.n = layout, int(s), int(n)
         tn = n * t
         f32 = torch.float32
-        self.stride = (layout.total + 3) // 4 * 4
+        self.stride = (layout.alloc + 3) // 4 * 4
         ws = int(lib.pqn_qnet_cnn_workspace_floats(C.byref(layout.struct), tn // mb))
         if ws < 0:
             raise RuntimeError("pqn_qnet_cnn_workspace_floats failed")
@@ -305,9 +318,8 @@ class SeedsUpdateDriver:
         self.use_graph, self.graph, self.graph_error, self.calls = use_graph, None, None, 0
 
     def set_params(self, seed: int, theta_flax: torch.Tensor):
-        self.theta[seed, :self.layout.total] = self.layout.to_kernel(theta_flax)
-        _lib.check(_lib.load().pqn_qnet_cnn_pack_w1b(C.byref(self.layout.struct), _lib.ptr(self.theta[seed]),
-                                                     _lib.ptr(self.w1b[seed]), _lib.stream_ptr()), "pqn_qnet_cnn_pack_w1b")
+        self.theta[seed, :self.layout.alloc] = self.layout.to_kernel(theta_flax)
+        self.layout.refresh_copies(self.theta[seed], self.w1b[seed])
 
     def theta_k(self, seed: int) -> torch.Tensor:
         return self.theta[seed, :self.layout.total]
