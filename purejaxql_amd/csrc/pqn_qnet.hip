@@ -317,6 +317,7 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid, 
 // the same ds_read_b128 converted on the fly and the B operand is the 8-byte half of the f32 fragment
 // (w1h, kept in step by the optimizer).  Accumulation is f32.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 PQN_D f16x4 to_f16x4(const f32x4 v) { return f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
 
 template <int PF = 16>
@@ -711,7 +712,7 @@ PQN_D float group32_sum(float v) {
 // NA: compile-time action count (0 = run-time L.a, up to QN_MAXA).
 template <int C, int NA>
 PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layout_t &L, int tid, int nb, int b0,
-                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT) {
+                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT, float dz_scale) {
   constexpr int NAQ = NA ? NA : QN_MAXA;
   const int na = NA ? NA : L.a;
   const int lane = tid & 63, wave = tid >> 6;
@@ -811,7 +812,18 @@ PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layou
     }
     if (wave == 0 && lane < na) gp[o_b1 + 384 + 128 * na + lane] = cb.x;   // d b2
   }
-  // dz^T for the weight-gradient GEMM: dzT[o][b0 + m], 16-B stores
+  // dz^T for the weight-gradient GEMM: dzT[o][b0 + m], 16-B stores (matmul_f16: tile-major fp16, scaled into
+  // fp16's normal range by dz_scale)
+  if (L.matmul_f16) {
+    _Float16 *dzP = reinterpret_cast<_Float16 *>(dzT) + (size_t)blockIdx.x * QN_HID * QN_TILE;
+    if (tid < QN_HID * 2) {
+      const int o = tid >> 1, hh = tid & 1;
+      f16x8 v;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = (_Float16)(s.z[(8 * hh + r) * QN_ZS + o] * dz_scale);
+      *reinterpret_cast<f16x8 *>(dzP + (size_t)o * QN_TILE + 8 * hh) = v;
+    }
+  } else
   for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
     const int o = i >> 2, mq = i & 3;
     const f32x4 vv = {s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], s.z[(4 * mq + 2) * QN_ZS + o],
@@ -834,7 +846,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, const float *__restrict__ w1b,
     pqn_cnn_layout_t L, float inv_b, float *__restrict__ dzT, float *__restrict__ h1T, float *__restrict__ gpart,
-    int ablate, unsigned long long *__restrict__ stamps, pqn_seeds_t sd) {
+    int ablate, unsigned long long *__restrict__ stamps, pqn_seeds_t sd, float dz_scale) {
   using Cfg = CnnCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int seed = blockIdx.y;           // seed slice of the stacked buffers (all strides 0 for a single seed)
@@ -903,6 +915,18 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   else phase2_fc1<0>(s, theta + L.off_w1, tid);
   // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
   // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
+  if (L.matmul_f16) {
+    // fp16 operands for T2, tile-major: h1P[tile][i][16 samples] halves -- the wave writes 2 KB contiguous
+    _Float16 *h1P = reinterpret_cast<_Float16 *>(h1T) + (size_t)blockIdx.x * QN_H1 * QN_TILE;
+    for (int e = tid; e < QN_H1 * 2; e += QN_THREADS) {
+      const int i = e >> 1, hh = e & 1;
+      const float *src = s.h1 + (8 * hh) * QN_H1S + i;
+      f16x8 v;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = (_Float16)src[r * QN_H1S];
+      *reinterpret_cast<f16x8 *>(h1P + (size_t)i * QN_TILE + 8 * hh) = v;
+    }
+  } else
   for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
     const int i = e >> 2, mq = e & 3;
     const float *src = s.h1 + (4 * mq) * QN_H1S + i;
@@ -917,18 +941,18 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   T1_STAMP(3);
   // ---- head forward + backward (LN1 / fc2 / loss -> dz, parameter-gradient partials, dz^T) ----
   switch (L.a) {
-    case 3: train_head<C, 3>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
-    case 4: train_head<C, 4>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
-    case 5: train_head<C, 5>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
-    case 6: train_head<C, 6>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
-    default: train_head<C, 0>(s, ts, L, tid, nb, b0, inv_b, gp, dzT); break;
+    case 3: train_head<C, 3>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+    case 4: train_head<C, 4>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+    case 5: train_head<C, 5>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+    case 6: train_head<C, 6>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+    default: train_head<C, 0>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
   }
   T1_STAMP(4);
   // ---- P4: dgrad  dh1[m][i] = sum_o dz[m][o] W1[i][o]  (A = dz tile, B = W1 in dgrad fragment order) ----
   if (L.matmul_f16) {
     // fp16 operands, f32 accumulation: one v_mfma_f32_16x16x16_f16 per 16-wide K group.  dz is O(1/B): it is
     // scaled by a power of two (>= B/2) into fp16's normal range and the product scaled back in f32.
-    const float sc = exp2f(floorf(log2f(1.0f / inv_b))), isc = 1.0f / sc;
+    const float sc = dz_scale, isc = 1.0f / sc;
     const f16x4 *wb = reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(theta + L.off_w1h) + QN_H1 * QN_HID);
     f16x4 afr[8];
 #pragma unroll
@@ -1231,6 +1255,80 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_kernel(int nb, cons
   for (int a = 0; a < 4; ++a) out[((4 * it + a) * 8 + cb) * 64 + lane] = acc[a];
 }
 
+// fp16-operand variant (matmul_f16): operands packed tile-major by T1 (h1P[tile][1024][16], dzP[tile][128][16]
+// halves, dz pre-scaled by dz_scale), one v_mfma_f32_16x16x16_f16 per row block and 16-sample tile, f32
+// accumulation, result scaled back.  Same grid and output layout as the f32 kernel.
+__global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_f16_kernel(int nb, const float *__restrict__ h1T,
+                                                                        const float *__restrict__ dzT,
+                                                                        float *__restrict__ wpart, long long ws_stride,
+                                                                        float inv_scale) {
+  constexpr int TS = 4;                  // 16-sample tiles per step (64 samples)
+  constexpr int ROWS = 64 + 128;
+  constexpr int RS = TS * 16 + 8;        // LDS row stride in halves (144 B): conflict-free 8-B fragment reads
+  __shared__ __attribute__((aligned(16))) _Float16 tile[2][ROWS * RS];
+  const _Float16 *h1P = reinterpret_cast<const _Float16 *>(h1T + blockIdx.z * ws_stride);
+  const _Float16 *dzP = reinterpret_cast<const _Float16 *>(dzT + blockIdx.z * ws_stride);
+  wpart += blockIdx.z * ws_stride;
+  const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6;
+  const int it = blockIdx.x, ks = blockIdx.y;
+  const int o = lane & 15, kq = 4 * (lane >> 4);
+  const int ntiles = nb / QN_TILE;
+  const int t0 = ks * (QW_SLAB / QN_TILE);
+  const int tiles = min(QW_SLAB / QN_TILE, ntiles - t0);
+  const int nsteps = (tiles + TS - 1) / TS;
+  // loader: 1536 16-B pieces per step (A: 64 rows x 4 tiles x 2, B: 128 rows x 4 tiles x 2) = 3 per thread
+  const _Float16 *src[3];
+  int dst[3], tl[3];
+  size_t adv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int u = tid + QN_THREADS * j;
+    if (u < 512) {
+      const int t = u >> 7, rem = u & 127, r = rem >> 1, hh = rem & 1;
+      src[j] = h1P + ((size_t)(t0 + t) * QN_H1 + 64 * it + r) * QN_TILE + 8 * hh;
+      dst[j] = r * RS + t * 16 + 8 * hh;
+      tl[j] = t;
+      adv[j] = (size_t)TS * QN_H1 * QN_TILE;
+    } else {
+      const int v = u - 512, t = v >> 8, rem = v & 255, r = rem >> 1, hh = rem & 1;
+      src[j] = dzP + ((size_t)(t0 + t) * QN_HID + r) * QN_TILE + 8 * hh;
+      dst[j] = (64 + r) * RS + t * 16 + 8 * hh;
+      tl[j] = t;
+      adv[j] = (size_t)TS * QN_HID * QN_TILE;
+    }
+  }
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f32x4 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x8 pre[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) pre[j] = (tl[j] < tiles) ? *reinterpret_cast<const f16x8 *>(src[j]) : zero8;
+  for (int st = 0; st < nsteps; ++st) {
+    _Float16 *t = tile[st & 1];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<f16x8 *>(t + dst[j]) = pre[j];
+    if (st + 1 < nsteps) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        pre[j] = (tl[j] + TS * (st + 1) < tiles) ? *reinterpret_cast<const f16x8 *>(src[j] + adv[j] * (st + 1)) : zero8;
+    }
+    __syncthreads();   // tile[st&1] complete; tile[(st+1)&1] was last read two steps ago
+#pragma unroll
+    for (int g = 0; g < TS; ++g) {
+      const f16x4 b = *reinterpret_cast<const f16x4 *>(t + (64 + 16 * cb + o) * RS + 16 * g + kq);
+      f16x4 a4[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) a4[a] = *reinterpret_cast<const f16x4 *>(t + (16 * a + o) * RS + 16 * g + kq);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[a], b, acc[a], 0, 0, 0);
+    }
+  }
+  f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) out[((4 * it + a) * 8 + cb) * 64 + lane] = acc[a] * inv_scale;
+}
+
 // ---------------------------------------------------------------------------
 // T3a: fold partials into the flat gradient (kernel layout) and emit per-block sums of
 // squares + the *count snapshot for radam_apply (same scratch protocol as radam_norm_kernel).
@@ -1531,11 +1629,17 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
   if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
+  // matmul_f16: dz (O(1/nb)) is scaled by a power of two into fp16's normal range; products are scaled back in f32
+  const float dz_scale = exp2f(floorf(log2f((float)nb)));
   hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
-                     target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sd);
+                     target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sd, dz_scale);
   if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
-  hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
-                     sd.ws_stride);
+  if (L.matmul_f16)
+    hipLaunchKernelGGL(qnet_fc1_wgrad_f16_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
+                       sd.ws_stride, 1.0f / dz_scale);
+  else
+    hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
+                       sd.ws_stride);
   hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles, nks,
                      rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd);
   return pqn_check_launch("pqn_qnet_cnn_grad");

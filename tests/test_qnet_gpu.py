@@ -26,6 +26,7 @@ def test_cnn_forward_vs_oracle(gpu, oracle, c, a, n):
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward
     rng = np.random.default_rng(c * 1000 + n)
+    torch.manual_seed(1234)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
     lay = CnnKernelLayout(c, a)
     assert lay.num_flax == net.num_params
@@ -68,6 +69,7 @@ def test_cnn_grad_vs_oracle(gpu, oracle, c, a, nb, pool):
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
     rng = np.random.default_rng(nb + c)
+    torch.manual_seed(1234)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
     lay = CnnKernelLayout(c, a)
     theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
@@ -119,6 +121,7 @@ def test_mlp_forward_and_grad_vs_oracle(gpu, oracle, d, h, layers, a, n):
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import MlpKernelLayout, MlpTrainer, mlp_forward
     rng = np.random.default_rng(d * 100 + n)
+    torch.manual_seed(1234)
     net = QNetwork("mlp", (d,), a, hidden_size=h, num_layers=layers, device=gpu)
     lay = MlpKernelLayout(d, h, layers, a)
     assert lay.num_flax == net.num_params
@@ -144,7 +147,7 @@ def test_mlp_forward_and_grad_vs_oracle(gpu, oracle, d, h, layers, a, n):
     g = tr.compute_grad(*args, loss_t, qv_t)
     lo, chosen, g_ref = oracle.net_loss_grad("mlp", p, shapes, obs[idx], act[idx], tgt[idx], layers=layers)
     assert abs(float(loss_t) - lo) <= 1e-4 * max(1.0, abs(lo)) and abs(float(qv_t) - chosen.mean()) <= 1e-4
-    np.testing.assert_allclose(_np(lay.to_flax(g)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
+    np.testing.assert_allclose(_np(lay.to_flax(g)), g_ref, rtol=2e-3, atol=1e-5 * np.abs(g_ref).max() + 1e-9)
     th, m, v = _np(theta).copy(), np.zeros(net.num_params, np.float32), np.zeros(net.num_params, np.float32)
     for step in range(3):
         g_flax = _np(lay.to_flax(tr.compute_grad(*args)))
@@ -230,6 +233,7 @@ def test_cnn_f16_matmul_mode_vs_oracle(gpu, oracle, c, a, nb, pool):
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer, cnn_forward
     rng = np.random.default_rng(nb + c)
+    torch.manual_seed(1234)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
     lay = CnnKernelLayout(c, a, matmul_f16=True)
     assert lay.matmul_f16 and lay.alloc == lay.total + 1024 * 128
