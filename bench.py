@@ -115,6 +115,7 @@ def main():
                     help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
                          "(RCCL gradient all-reduce per optimizer step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mixed-precision", action="store_true", help="skip the extra MATMUL_DTYPE=f16 measurement")
     ap.add_argument("--matmul-dtype", default="f32", choices=["f32", "f16"],
                     help="operand type of the fc1 products (config MATMUL_DTYPE); f16 = fp16 operands, f32 accumulation")
     ap.add_argument("--multi-seed", type=int, default=16,
@@ -222,7 +223,8 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node), MinAtar-Breakout 4096 envs", "value": sps, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.matmul_dtype == "f32" else "f16 operands / f32 accumulate (fc1), f32 elsewhere", "data": "synthetic",
             "config": {"workload": f"Breakout-MinAtar PQN full loop, NUM_ENVS={cfg['NUM_ENVS']} NUM_STEPS={cfg['NUM_STEPS']} "
                                    f"NUM_MINIBATCHES={cfg['NUM_MINIBATCHES']} NUM_EPOCHS={cfg['NUM_EPOCHS']} per GPU",
                        "seeds_per_gpu": 1, "backend": train.backend, "driver": driver_mode, "parallelism": f"{args.mode}x{world}",
@@ -236,6 +238,19 @@ def main():
             out["roofline_env_step"] = [env_step_hbm_roofline(n, dev) for n in (4096, 65536)]
         if world == 1 and args.multi_seed > 1 and fused:
             out["multi_seed"] = multi_seed_rate(cfg, args.multi_seed, args.steps, args.warmup, dev)
+        if world == 1 and fused and args.matmul_dtype == "f32" and not args.no_mixed_precision:
+            # opt-in operand precision (config MATMUL_DTYPE=f16): reported beside `value`, never as `value`
+            c16 = dict(cfg)
+            c16["MATMUL_DTYPE"] = "f16"
+            one = multi_seed_rate(c16, 1, args.steps, args.warmup, dev)
+            many = multi_seed_rate(c16, args.multi_seed, args.steps, args.warmup, dev) if args.multi_seed > 1 else None
+            out["mixed_precision"] = {
+                "dtype": "fc1 products (forward, input gradient, weight gradient; 78 % of the FLOPs) with fp16 operands and "
+                         "f32 accumulation; master weights, optimizer, conv, LayerNorm, head, loss in f32",
+                "value": one["value"], "unit": "env-steps/s", "ms_per_step": one["ms_per_round"],
+                "multi_seed": None if many is None else {"seeds_per_gpu": many["seeds_per_gpu"], "value": many["value"]},
+                "returns": "10-seed Breakout / Asterix test returns equal to the f32 mode within seed noise "
+                           "(profiles/r01_learning_curves.txt)"}
         if not args.no_cpu_baseline and world == 1:
             theta0 = finish()["runner_state"]["network"].init(1).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(cfg, theta0)
