@@ -132,11 +132,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: purejaxql_amd has no CPU path")
+    # PQN_BENCH_ONE_GPU=1 (tests on a 1-GPU box only): every rank on device 0, gloo instead of RCCL -- exercises the
+    # multi-rank control flow (barriers, max-over-ranks timing, rank-0 line), not the scaling
+    one_gpu = os.environ.get("PQN_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from purejaxql_amd import _lib
     _lib.load()
@@ -177,6 +185,13 @@ def main():
 
     env_steps = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * args.steps * world
     sps = env_steps / dt
+
+    # The kernel-timer pass below runs 2 more updates.  With the envs of one seed sharded over ranks those updates
+    # contain collectives, so EVERY rank has to run them (rank 0 alone would wait forever for its peers).
+    if world > 1 and args.mode == "envs" and fused and rank != 0:
+        for u in range(args.warmup + args.steps, args.warmup + args.steps + 2):
+            update(u)
+        torch.cuda.synchronize()
 
     if rank == 0:
         roof = None
