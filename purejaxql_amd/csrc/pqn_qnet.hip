@@ -5,14 +5,19 @@
 //         -> Dense(128) -> LayerNorm(128) -> relu -> Dense(A)
 // The kernels never see the f32 [10,10,C] observation: they read the bit-packed
 // grid (include/pqn_hotpath.h "obs_bits", 64 B/obs for Breakout instead of
-// 1600 B) and evaluate the conv as a sum over the SET bits of each 3x3xC window.
+// 1600 B) and build the conv's MFMA A operand from the window bits.
 //
-// Work decomposition (one 256-thread workgroup = 16 samples = one MFMA M-tile):
-//   phase 1  conv+LN+relu, one lane per (sample, output position); h1 tile -> LDS
+// Work decomposition (one 512-thread workgroup = 16 samples = one MFMA M-tile):
+//   phase 1  conv as v_mfma_f32_16x16x4_f32 (16 positions x 16 channels per tile,
+//            K = the 9C window bits), LDS transposition to one lane per position,
+//            LayerNorm(16) + relu; h1 tile -> LDS
 //   phase 2  fc1 as v_mfma_f32_16x16x4_f32: A = h1 tile (LDS, ds_read_b128),
 //            B = fc1 kernel streamed from L2 in MFMA-fragment order (1 KB per
-//            wave-instruction, global_load_dwordx4); 4 waves x 2 column blocks
-//   phase 3  LN(128)+relu+fc2 (+ eps-greedy epilogue), 16 lanes per sample
+//            wave-instruction, global_load_dwordx4) through a 16-deep register ring;
+//            8 waves x 1 column block.  (matmul_f16 layouts: v_mfma_f32_16x16x16_f16)
+//   phase 3  LN(128)+relu+fc2 (+ eps-greedy epilogue), 16 / 32 lanes per sample
+// The same phases run inside the persistent rollout kernel (one workgroup owns 16
+// envs for all T steps) and as the forward half of the training kernel.
 //
 // Parameter layout ("kernel layout", pqn_cnn_layout): flax order, segment starts
 // padded to 16 B, and the fc1 kernel W1[i][o] stored in MFMA C/D-fragment order
@@ -647,10 +652,13 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
 //   T1 qnet_cnn_train_kernel   per 16-sample tile: forward, loss gradient, backward through
 //                              head / LN1 / fc1 (dgrad MFMA) / relu / LN0 / conv; emits dz^T
 //                              and per-tile partial sums of every "small" gradient
-//   T2 qnet_cnn_wgrad_kernel   dW1 = h1^T x dz as MFMA, h1 recomputed from the packed obs,
-//                              split-K over 512-sample slabs, output in fragment layout
-//   T3 pqn_grad_reduce_kernel  deterministic fold of the partials into the flat gradient
+//   T2 qnet_fc1_wgrad_kernel   dW1 = h1^T x dz as an LDS-staged MFMA GEMM on the operands T1 left in the
+//                              workspace, split-K over 256-sample slabs, output in fragment layout
+//                              (matmul_f16: qnet_fc1_wgrad_f16_kernel on tile-major fp16 operands)
+//   T3 qnet_grad_reduce_kernel deterministic fold of the partials into the flat gradient
 //                              (+ block sums of squares), then radam_apply (pqn_algo.hip).
+// With seed batching (pqn_seeds_t) grid.y (T2: grid.z) is the seed and every pointer is offset by the
+// seed's slice of the stacked buffers.
 // "Small" partial record per tile (floats): [conv kernel KW*16 | conv bias 16 | ln0 scale 16 |
 // ln0 bias 16 | b1 128 | ln1 scale 128 | ln1 bias 128 | w2 128*A | b2 A | loss | sum q_a].
 // ===========================================================================
