@@ -234,3 +234,19 @@ def test_oracle_radam_matches_formula(oracle):
         np.testing.assert_allclose(p, p64, rtol=1e-5, atol=1e-6)
     # the rectified branch is reached from t=6 on (ro_6 = 5.0...): make sure both were exercised
     assert ro_inf - 2 * 5 * b2 ** 5 / (1 - b2 ** 5) < 5.0 <= ro_inf - 2 * 6 * b2 ** 6 / (1 - b2 ** 6)
+
+
+def test_oracle_regression_pins():
+    """The oracle's outputs on seeded inputs still hash to the committed digests (tests/golden/regression_pins.json):
+    env rules + RNG streams of all five envs, eps-greedy, shuffle, Q(lambda) both forms, fold_in.  Self-regression
+    pins, not reference goldens (the reference cannot run here)."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_regression_pins", os.path.join(here, "golden", "make_regression_pins.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "golden", "regression_pins.json")))
+    got = mod.pins()
+    assert got == want

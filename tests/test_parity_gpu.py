@@ -385,3 +385,38 @@ def test_make_train_norm_variants_vs_oracle(gpu, oracle, alg, env_name, norm_typ
     assert sorted(bs) == sorted(oout["batch_stats"])
     for k, v in oout["batch_stats"].items():
         assert np.abs(_np(bs[k]) - v).max() <= 10 * tol * max(np.abs(v).max(), 1e-3), k   # running moments, per-array scale
+
+
+@pytest.mark.parametrize("name", ["Breakout-MinAtar", "Asterix-MinAtar", "Freeway-MinAtar", "SpaceInvaders-MinAtar"])
+def test_hip_envs_hash_to_regression_pins(gpu, name):
+    """The HIP env kernels (reset / step / auto-reset / LogWrapper, f32 observation surface) reproduce the committed
+    SHA-256 digests of tests/golden/regression_pins.json on the pinned keys and actions -- no oracle in the loop.
+    (CartPole is excluded: its sinf / cosf differ from libm in the last ulp, see test_cartpole_step_vs_oracle.)"""
+    import hashlib
+    import importlib.util
+    import json
+    import os
+    from purejaxql_amd import _lib
+    from purejaxql_amd.envs import LogWrapper, make
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_regression_pins", os.path.join(here, "golden", "make_regression_pins.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pin = json.load(open(os.path.join(here, "golden", "regression_pins.json")))["envs"][name]
+    n, steps, key = pin["n"], pin["steps"], pin["key"]
+    env, params = make(name, device=gpu)
+    env = LogWrapper(env)
+    rng = np.random.default_rng(7)
+    obs, state = env.reset(key, params, n)
+    h = hashlib.sha256(mod.digest(_np(obs)).encode())
+    tot_r, tot_d = 0.0, 0
+    num_actions = env.action_space(params).n
+    for t in range(steps):
+        a = rng.integers(0, num_actions, n).astype(np.int32)
+        obs, state, r, d, info = env.step(_lib.fold_in(key, 1 + t), state, torch.from_numpy(a).to(gpu), params, inplace=True)
+        h.update(mod.digest(_np(obs), _np(r), _np(d).astype(bool), _np(info["returned_episode_returns"]),
+                            _np(info["returned_episode_lengths"]).astype(np.int32),
+                            _np(info["timestep"]).astype(np.int32)).encode())
+        tot_r += float(r.sum())
+        tot_d += int(d.sum())
+    assert (h.hexdigest(), tot_r, tot_d) == (pin["sha256"], pin["sum_reward"], pin["num_done"])
