@@ -250,3 +250,64 @@ def test_oracle_regression_pins():
     want = json.load(open(os.path.join(here, "golden", "regression_pins.json")))
     got = mod.pins()
     assert got == want
+
+
+def test_minatar_suite_hand_derived_steps(oracle):
+    """Known answers derived by hand from the published MinAtar rules (Young & Tian 2019: asterix.py, freeway.py,
+    space_invaders.py) for the deterministic part of each game -- the pieces that need no random draw.
+    Pins of the oracle, not reference-generated goldens."""
+    # --- Asterix: player starts at (5,5); spawn timer 10, move timer 5, ramp timer 100; moves clamp to x 0..9, y 1..8
+    env = oracle.OracleEnv("Asterix-MinAtar")
+    _obs, st = env.reset(1, 1)
+    s = st["si"][0]
+    assert list(s[:11]) == [5, 5, 0, 10, 10, 5, 5, 100, 0, 0, 0] and s[11:].sum() == 0
+    for t in range(5):
+        _o, st, r, d, _i = env.step(10 + t, st, np.array([0], np.int32), autoreset=False)
+        assert r[0] == 0 and not d[0]
+    s = st["si"][0]
+    assert (s[4], s[6], s[9]) == (5, 0, 5)                     # spawn timer 10-5, move timer 5-5, time
+    for a, want in ((1, (4, 5)), (1, (3, 5)), (2, (3, 4)), (4, (3, 5)), (3, (4, 5))):    # left, left, up, down, right
+        _o, st, _r, _d, _i = env.step(99, st, np.array([a], np.int32), autoreset=False)
+        assert (st["si"][0][0], st["si"][0][1]) == want
+    for _ in range(12):                                          # up is clamped at row 1, left at column 0
+        _o, st, _r, d, _i = env.step(99, st, np.array([2], np.int32), autoreset=False)
+        if d[0]:
+            break
+    assert d[0] or st["si"][0][1] == 1
+    # --- Freeway: chicken starts at row 9 with a 3-frame move cooldown, terminate timer 2500; 'up' (action 1) moves
+    # one row every 4th frame at most; rows stay in 0..9; reward only on reaching row 0
+    env = oracle.OracleEnv("Freeway-MinAtar")
+    _obs, st = env.reset(5, 1)
+    s = st["si"][0]
+    assert (s[0], s[1], s[2], s[3], s[4]) == (9, 3, 2500, 0, 0)
+    speeds = s[5 + 2:29:3]
+    assert all(1 <= abs(int(v)) <= 5 for v in speeds) and list(s[5:29:3]) == [0] * 8      # 8 cars at x=0, speed 1..5
+    rows = []
+    for t in range(8):
+        _o, st, r, d, _i = env.step(50 + t, st, np.array([1], np.int32), autoreset=False)
+        rows.append(int(st["si"][0][0]))
+        assert r[0] == 0 and not d[0]
+    # cooldown 3 -> the first move happens on the 4th 'up' frame, the next one 4 frames later (unless a car on row 8/7
+    # at x=4 sends the chicken back to row 9, which cannot happen in the first 8 frames: cars start at x=0 and need
+    # >= 4 moves of >= 1 frame each... the fastest car reaches x=4 at frame 4, on its own row only)
+    assert rows[:3] == [9, 9, 9] and rows[3] in (8, 9) and all(7 <= v <= 9 for v in rows)
+    assert st["si"][0][2] == 2500 - 8 and st["si"][0][3] == 8
+    # --- SpaceInvaders: cannon at x=5, 4x6 alien block at rows 0..3, columns 2..7, moving left (-1) every 12 frames;
+    # 'fire' (minimal action set: 0 noop, 1 left, 2 right, 3 fire) puts a friendly bullet on row 8 above the cannon
+    env = oracle.OracleEnv("SpaceInvaders-MinAtar")
+    _obs, st = env.reset(9, 1)
+    s = st["si"][0]
+    assert (s[0], s[1], s[2], s[3], s[4]) == (5, -1, 12, 12, 10)
+    al = s[9:109].reshape(10, 10)
+    assert al.sum() == 24 and al[:4, 2:8].all()
+    _o, st, r, d, _i = env.step(1, st, np.array([3], np.int32), autoreset=False)
+    s = st["si"][0]
+    fb = s[109:209].reshape(10, 10)
+    assert fb.sum() == 1 and fb[8, 5] == 1 and r[0] == 0 and not d[0]
+    for t in range(4):                                           # the bullet climbs one row per frame
+        _o, st, _r, _d, _i = env.step(2 + t, st, np.array([0], np.int32), autoreset=False)
+    fb = st["si"][0][109:209].reshape(10, 10)
+    assert fb.sum() == 1 and fb[4, 5] == 1
+    _o, st, r, _d, _i = env.step(7, st, np.array([0], np.int32), autoreset=False)
+    s = st["si"][0]
+    assert r[0] == 1.0 and s[109:209].sum() == 0 and s[9:109].sum() == 23     # hits the alien at (3,5): +1, both removed
