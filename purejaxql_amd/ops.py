@@ -5,7 +5,6 @@ computes on the host and nothing falls back to torch/CPU math.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import torch

@@ -21,7 +21,6 @@ Key schedule (this build's own; jax streams cannot be reproduced):
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
