@@ -348,6 +348,11 @@ typedef struct {
 } pqn_mlp_update_args_t;
 
 int pqn_mlp_update(const pqn_mlp_update_args_t *args /* host */, void *stream);
+/* num_seeds independent seeds in the same launches, buffers stacked exactly as for pqn_cnn_update_seeds (obs
+ * [T+1][S*N][D]; wt [S][wt_stride]); per-seed results bit-identical to single-seed calls. */
+int pqn_mlp_update_seeds(const pqn_mlp_update_args_t *args /* host */, int32_t num_seeds, const uint64_t *key_roll_dev,
+                         const uint64_t *key_shuf_dev, int64_t theta_stride, int64_t workspace_stride, int64_t wt_stride,
+                         void *stream);
 
 #ifdef __cplusplus
 }

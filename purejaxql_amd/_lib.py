@@ -62,6 +62,7 @@ SIGNATURES = {
     "pqn_update_sort_temp_bytes": (c_int64, [c_int32]),
     "pqn_cnn_update": (c_int, [c_void_p, c_void_p]),
     "pqn_mlp_update": (c_int, [c_void_p, c_void_p]),
+    "pqn_mlp_update_seeds": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "pqn_cnn_rollout_seeds": (c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float,
                                       c_void_p]),

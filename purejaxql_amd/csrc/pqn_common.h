@@ -103,7 +103,7 @@ int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, in
 
 // internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
-                     const pqn_step_out_t &out, hipStream_t st);
+                     const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0, int key_stride = 0);
 int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStream_t st);
 // seed-batched variant: keys[s*n + i] = (s << 56) | (rand31(i; key_dev[s*key_stride]) << 25) | i  (n <= 2^25, S <= 128):
 // one global radix sort orders every seed's segment exactly as the single-seed keys (rand31 << 32 | i) would
@@ -117,7 +117,14 @@ int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *o
                              int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
                              const uint64_t *key_dev, hipStream_t st);
 int pqn_mlp_forward_dyn(const pqn_mlp_layout_t &L, int n, const float *obs, const float *theta, float *q, int32_t *action,
-                        float *qmax, float eps, uint64_t key, const float *eps_dev, const uint64_t *key_dev, hipStream_t st);
+                        float *qmax, float eps, uint64_t key, const float *eps_dev, const uint64_t *key_dev, hipStream_t st,
+                        int n_per_seed = 0, long long theta_stride = 0, int key_stride = 0);
+int pqn_mlp_grad_seeds(const pqn_mlp_layout_t &L, int nb, const int64_t *idx, const float *obs, const int32_t *action,
+                       const float *target, const float *theta, const float *wt, float *grad, const int32_t *count,
+                       float *workspace, float *loss_out, float *qv_out, const pqn_seeds_t &sd, long long wt_stride,
+                       hipStream_t st);
+int pqn_mlp_refresh_transposed_seeds(const pqn_mlp_layout_t &L, const float *theta, float *wt, int nseeds,
+                                     long long theta_stride, long long wt_stride, hipStream_t st);
 int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
                          const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
                          const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st,

@@ -87,14 +87,18 @@ template <class Env, bool IS_RESET>
 __global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev,
                                                    float rscale, const uint32_t *__restrict__ state_in,
                                                    uint32_t *__restrict__ state_out,
-                                                   const int32_t *__restrict__ action, pqn_step_out_t out) {
-  if (key_dev) key = *key_dev;
+                                                   const int32_t *__restrict__ action, pqn_step_out_t out,
+                                                   int n_per_seed, int key_stride) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  // seed batching: env e of the stacked batch is env e_rng of seed e / n_per_seed, driven by that seed's key
+  const int seed = n_per_seed > 0 ? e / n_per_seed : 0;
+  const int e_rng = e - seed * n_per_seed;
+  if (key_dev) key = key_dev[(size_t)seed * key_stride];
   Env env;
   LogRec log;
   if (IS_RESET) {
-    env.reset(key, (uint32_t)e);
+    env.reset(key, (uint32_t)e_rng);
     log.zero();
   } else {
     uint32_t w[Env::ENV_WORDS];
@@ -103,9 +107,9 @@ __global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const ui
     env.unpack(w);
     log.load(state_in, n, e, Env::ENV_WORDS);
     int done = 0;
-    const float reward = env.step(action[e], key, (uint32_t)e, done);
+    const float reward = env.step(action[e], key, (uint32_t)e_rng, done);
     log.step(reward, done);
-    if (done) env.reset(key, (uint32_t)e);
+    if (done) env.reset(key, (uint32_t)e_rng);
     out.reward[e] = reward * rscale;
     out.done[e] = (uint8_t)done;
     if (out.discount) out.discount[e] = done ? 0.0f : 1.0f;
@@ -201,7 +205,13 @@ static void launch_minatar(int n, uint64_t key, const uint64_t *key_dev, float r
 
 template <bool IS_RESET>
 static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, float rscale, const uint32_t *si,
-                    uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st) {
+                    uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0,
+                    int key_stride = 0) {
+  if (n_per_seed > 0 && env_id != PQN_ENV_CARTPOLE) {
+    pqn_set_error("seed-batched env.step is implemented for the flat-observation envs (the MinAtar path batches seeds "
+                  "inside pqn_cnn_rollout_seeds)");
+    return PQN_E_UNSUPPORTED;
+  }
   switch (env_id) {
     case PQN_ENV_BREAKOUT: launch_minatar<Breakout, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st); break;
     case PQN_ENV_ASTERIX: launch_minatar<Asterix, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st); break;
@@ -212,7 +222,7 @@ static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, fl
     case PQN_ENV_CARTPOLE:
       PQN_REQUIRE(out.obs_bits == nullptr, "CartPole-v1 has no packed observation");
       hipLaunchKernelGGL((flat_kernel<CartPole, IS_RESET>), dim3((n + 255) / 256), dim3(256), 0, st, n, key, key_dev, rscale,
-                         si, so, action, out);
+                         si, so, action, out, n_per_seed, key_stride);
       break;
     default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
   }
@@ -239,8 +249,8 @@ extern "C" int pqn_env_step(int env_id, int32_t n, uint64_t key, const uint32_t 
 
 // internal (pqn_update.hip): step key read from device memory, reward scaled at the source
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
-                     const pqn_step_out_t &out, hipStream_t st) {
-  return dispatch<false>(env_id, n, 0, key_dev, rscale, state, state, action, out, st);
+                     const pqn_step_out_t &out, hipStream_t st, int n_per_seed, int key_stride) {
+  return dispatch<false>(env_id, n, 0, key_dev, rscale, state, state, action, out, st, n_per_seed, key_stride);
 }
 
 template <bool EXPORT>

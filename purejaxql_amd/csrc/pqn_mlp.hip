@@ -174,9 +174,17 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(int n, const float *__rest
                                                       pqn_mlp_layout_t L, float *__restrict__ q_out,
                                                       int32_t *__restrict__ action, float *__restrict__ qmax, float eps,
                                                       uint64_t key, const float *__restrict__ eps_dev,
-                                                      const uint64_t *__restrict__ key_dev) {
+                                                      const uint64_t *__restrict__ key_dev, int n_per_seed,
+                                                      long long theta_stride, int key_stride) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, e0 = blockIdx.x * ML_TILE;
+  int e_off = 0;   // seed batching: tile -> seed (n_per_seed % 16 == 0): that seed's parameters, key and env numbering
+  if (n_per_seed > 0) {
+    const int seed = e0 / n_per_seed;
+    theta += seed * theta_stride;
+    if (key_dev) key_dev += (size_t)seed * key_stride;
+    e_off = seed * n_per_seed;
+  }
   const int DS = L.d + 1, HS = L.h + 4;
   float *x = sm, *a = x + ML_TILE * DS, *y = a + ML_TILE * HS;
   for (int i = tid; i < ML_TILE * L.d; i += 256) {
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(int n, const float *__rest
       if (key_dev) key = *key_dev;
       if (eps_dev) eps = *eps_dev;
       uint32_t o0, o1;
-      pqn_bits(key, (uint32_t)e, PQN_STREAM_ACT, o0, o1);
+      pqn_bits(key, (uint32_t)(e - e_off), PQN_STREAM_ACT, o0, o1);
       action[e] = (pqn_uniform(o0) < eps) ? (int)pqn_randint(o1, (uint32_t)L.a) : best;
     }
   }
@@ -234,9 +242,22 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(int nb, const int64_t *_
                                                         const float *__restrict__ obs, const int32_t *__restrict__ action,
                                                         const float *__restrict__ target, const float *__restrict__ theta,
                                                         const float *__restrict__ wt, pqn_mlp_layout_t L, float inv_b,
-                                                        float *__restrict__ gpart, float *__restrict__ lq) {
+                                                        float *__restrict__ gpart, float *__restrict__ lq, pqn_seeds_t sd,
+                                                        long long wt_stride) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, b0 = blockIdx.x * ML_TILE;
+  const int seed = blockIdx.y;           // seed slice of the stacked buffers (all strides 0 for a single seed)
+  idx += seed * sd.idx_stride;
+  theta += seed * sd.theta_stride;
+  if (wt) wt += seed * wt_stride;
+  gpart += seed * sd.ws_stride;
+  lq += seed * sd.ws_stride;
+  auto row_of = [&](int64_t key) -> int64_t {   // transition t*N+e of this seed -> row of the stacked [T][S*N] record
+    const uint32_t j = (uint32_t)(key & sd.idx_mask);
+    if (sd.n_env_total == sd.n_env) return (int64_t)j;
+    const uint32_t t = j / (uint32_t)sd.n_env;
+    return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
+  };
   const int DS = L.d + 1, HS = L.h + 4, H = L.h, NL = L.layers;
   float *x = sm;
   float *act = x + ML_TILE * DS;                   // [NL][16][HS]
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(int nb, const int64_t *_
   for (int i = tid; i < L.total; i += 256) gp[i] = 0.0f;   // dummy BatchNorm + padding keep zero gradient
   for (int i = tid; i < ML_TILE * L.d; i += 256) {
     const int m = i / L.d, k = i - m * L.d;
-    x[m * DS + k] = (b0 + m < nb) ? obs[(size_t)(idx[b0 + m] & 0xFFFFFFFFll) * L.d + k] : 0.0f;
+    x[m * DS + k] = (b0 + m < nb) ? obs[(size_t)row_of(idx[b0 + m]) * L.d + k] : 0.0f;
   }
   __syncthreads();
   // ---- forward, keeping every layer's input, xhat and rstd ------------------------------------------------
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(int nb, const int64_t *_
   {
     const int m = tid >> 4, sub = tid & 15;
     const bool valid = (b0 + m) < nb;
-    const int64_t src = valid ? (idx[b0 + m] & 0xFFFFFFFFll) : 0;
+    const int64_t src = valid ? row_of(idx[b0 + m]) : 0;
     const int am = valid ? action[src] : 0;
     float part = 0.f;
     for (int k = sub; k < H; k += 16) part = fmaf(hl[m * HS + k], theta[L.off_wout + k * L.a + am], part);
@@ -379,8 +400,18 @@ __global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(int total, int nti
                                                               const float *__restrict__ lq, float *__restrict__ grad,
                                                               const int32_t *__restrict__ count,
                                                               float *__restrict__ scratch, float *__restrict__ loss_out,
-                                                              float *__restrict__ qv_out, float inv_b) {
+                                                              float *__restrict__ qv_out, float inv_b, pqn_seeds_t sd) {
   __shared__ float s_part[4];
+  {  // seed slice
+    const long long s = blockIdx.y;
+    gpart += s * sd.ws_stride;
+    lq += s * sd.ws_stride;
+    scratch += s * sd.ws_stride;
+    grad += s * sd.theta_stride;
+    count += s;
+    if (loss_out) loss_out += s * sd.lq_stride;
+    if (qv_out) qv_out += s * sd.lq_stride;
+  }
   float ss = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     float g = 0.f;
@@ -404,7 +435,10 @@ __global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(int total, int nti
 }
 
 // wt[l-1][o][k] = W_l[k][o] for hidden layers l >= 1
-__global__ void mlp_transpose_kernel(const float *__restrict__ theta, pqn_mlp_layout_t L, float *__restrict__ wt) {
+__global__ void mlp_transpose_kernel(const float *__restrict__ theta, pqn_mlp_layout_t L, float *__restrict__ wt,
+                                     long long theta_stride, long long wt_stride) {
+  theta += blockIdx.z * theta_stride;   // seed slice
+  wt += blockIdx.z * wt_stride;
   const int H = L.h;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int l = blockIdx.y + 1;
@@ -449,13 +483,14 @@ static size_t ml_train_smem(const pqn_mlp_layout_t &L) {
 
 int pqn_mlp_forward_dyn(const pqn_mlp_layout_t &L, int n, const float *obs, const float *theta, float *q, int32_t *action,
                         float *qmax, float eps, uint64_t key, const float *eps_dev, const uint64_t *key_dev,
-                        hipStream_t st) {
+                        hipStream_t st, int n_per_seed, long long theta_stride, int key_stride) {
+  PQN_REQUIRE(n_per_seed == 0 || n_per_seed % ML_TILE == 0, "pqn_mlp_forward: seed batching needs NUM_ENVS %% %d == 0", ML_TILE);
   const size_t smem = ml_fwd_smem(L);
   PQN_REQUIRE(smem <= 160 * 1024, "pqn_mlp_forward: layer width %d needs %zu B of LDS", L.h, smem);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
   hipLaunchKernelGGL(mlp_fwd_kernel, dim3((n + ML_TILE - 1) / ML_TILE), dim3(256), smem, st, n, obs, theta, L, q, action,
-                     qmax, eps, key, eps_dev, key_dev);
+                     qmax, eps, key, eps_dev, key_dev, n_per_seed, theta_stride, key_stride);
   return pqn_check_launch("pqn_mlp_forward");
 }
 
@@ -476,30 +511,43 @@ extern "C" int pqn_mlp_grad(const pqn_mlp_layout_t *L, int32_t nb, const int64_t
                             const int32_t *action, const float *target, const float *theta, const float *wt, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out, void *stream) {
   PQN_REQUIRE(L && idx && obs && action && target && theta && grad && count && workspace, "pqn_mlp_grad: NULL argument");
+  return pqn_mlp_grad_seeds(*L, nb, idx, obs, action, target, theta, wt, grad, count, workspace, loss_out, qv_out,
+                            pqn_one_seed(), 0, (hipStream_t)stream);
+}
+
+// internal (pqn_update.hip): S seeds per launch, buffers = slices of stacked allocations (pqn_seeds_t)
+int pqn_mlp_grad_seeds(const pqn_mlp_layout_t &L, int nb, const int64_t *idx, const float *obs, const int32_t *action,
+                       const float *target, const float *theta, const float *wt, float *grad, const int32_t *count,
+                       float *workspace, float *loss_out, float *qv_out, const pqn_seeds_t &sd, long long wt_stride,
+                       hipStream_t st) {
   PQN_REQUIRE(nb > 0, "pqn_mlp_grad: minibatch size must be > 0");
-  PQN_REQUIRE(L->layers == 1 || wt, "pqn_mlp_grad: transposed hidden kernels (wt) required for NUM_LAYERS > 1");
-  const size_t smem = ml_train_smem(*L);
-  PQN_REQUIRE(smem <= 160 * 1024, "pqn_mlp_grad: %d layers of width %d need %zu B of LDS (limit 160 KB)", L->layers, L->h,
+  PQN_REQUIRE(L.layers == 1 || wt, "pqn_mlp_grad: transposed hidden kernels (wt) required for NUM_LAYERS > 1");
+  const size_t smem = ml_train_smem(L);
+  PQN_REQUIRE(smem <= 160 * 1024, "pqn_mlp_grad: %d layers of width %d need %zu B of LDS (limit 160 KB)", L.layers, L.h,
               smem);
-  hipStream_t st = (hipStream_t)stream;
   const int ntiles = (nb + ML_TILE - 1) / ML_TILE;
-  float *scratch = workspace, *gpart = workspace + 1024, *lq = gpart + (size_t)ntiles * L->total;
+  float *scratch = workspace, *gpart = workspace + 1024, *lq = gpart + (size_t)ntiles * L.total;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_train_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
   const float inv_b = 1.0f / (float)nb;
-  hipLaunchKernelGGL(mlp_train_kernel, dim3(ntiles), dim3(256), smem, st, nb, idx, obs, action, target, theta, wt, *L, inv_b,
-                     gpart, lq);
-  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3(pqn_radam_blocks(L->total)), dim3(256), 0, st, L->total, ntiles, gpart, lq,
-                     grad, count, scratch, loss_out, qv_out, inv_b);
+  hipLaunchKernelGGL(mlp_train_kernel, dim3(ntiles, sd.nseeds), dim3(256), smem, st, nb, idx, obs, action, target, theta, wt,
+                     L, inv_b, gpart, lq, sd, wt_stride);
+  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3(pqn_radam_blocks(L.total), sd.nseeds), dim3(256), 0, st, L.total, ntiles,
+                     gpart, lq, grad, count, scratch, loss_out, qv_out, inv_b, sd);
   return pqn_check_launch("pqn_mlp_grad");
 }
 
 extern "C" int pqn_mlp_refresh_transposed(const pqn_mlp_layout_t *L, const float *theta, float *wt, void *stream) {
   PQN_REQUIRE(L && theta, "pqn_mlp_refresh_transposed: NULL argument");
-  if (L->layers <= 1) return PQN_OK;
+  return pqn_mlp_refresh_transposed_seeds(*L, theta, wt, 1, 0, 0, (hipStream_t)stream);
+}
+
+int pqn_mlp_refresh_transposed_seeds(const pqn_mlp_layout_t &L, const float *theta, float *wt, int nseeds,
+                                     long long theta_stride, long long wt_stride, hipStream_t st) {
+  if (L.layers <= 1) return PQN_OK;
   PQN_REQUIRE(wt, "pqn_mlp_refresh_transposed: wt is NULL");
-  hipLaunchKernelGGL(mlp_transpose_kernel, dim3((L->h * L->h + 255) / 256, L->layers - 1), dim3(256), 0, (hipStream_t)stream,
-                     theta, *L, wt);
+  hipLaunchKernelGGL(mlp_transpose_kernel, dim3((L.h * L.h + 255) / 256, L.layers - 1, nseeds), dim3(256), 0, st, theta, L, wt,
+                     theta_stride, wt_stride);
   return pqn_check_launch("pqn_mlp_refresh_transposed");
 }
 

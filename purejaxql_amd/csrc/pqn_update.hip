@@ -235,7 +235,8 @@ extern "C" int pqn_cnn_update_seeds(const pqn_update_args_t *a, int32_t num_seed
 // The gymnax-classic twin (pqn_gymnax.py:167-360): f32 observations, MLP Q-network kernels (pqn_mlp.hip).
 // Per rollout step two launches (forward + eps-greedy, env.step); everything else as above.
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int pqn_mlp_update(const pqn_mlp_update_args_t *a, void *stream) {
+static int mlp_update_impl(const pqn_mlp_update_args_t *a, int S, const uint64_t *key_roll_dev, const uint64_t *key_shuf_dev,
+                           long long theta_stride, long long ws_stride, long long wt_stride, hipStream_t st) {
   PQN_REQUIRE(a, "pqn_mlp_update: args is NULL");
   PQN_REQUIRE(a->clock && a->sched_keys && a->sched_eps && a->state && a->obs && a->action && a->reward && a->done &&
                   a->qmax && a->discount && a->rer && a->rel && a->ts && a->target && a->last_q && a->sort_keys_in &&
@@ -246,20 +247,33 @@ extern "C" int pqn_mlp_update(const pqn_mlp_update_args_t *a, void *stream) {
   PQN_REQUIRE(N > 0 && T > 0 && MB > 0 && EP > 0 && T + EP <= 1024, "pqn_mlp_update: bad shape N=%d T=%d MB=%d EP=%d", N, T,
               MB, EP);
   PQN_REQUIRE(((int64_t)N * T) % MB == 0, "NUM_MINIBATCHES must divide NUM_STEPS*NUM_ENVS");
+  PQN_REQUIRE(S >= 1 && S <= 128 && (S == 1 || (key_roll_dev && key_shuf_dev && N % 16 == 0 && (int64_t)N * T <= (1 << 25))),
+              "pqn_mlp_update: seed batching needs 1 <= seeds <= 128, device key arrays, NUM_ENVS %% 16 == 0, T*N <= 2^25");
   const int B = (int)(((int64_t)N * T) / MB);
-  hipStream_t st = (hipStream_t)stream;
   const pqn_mlp_layout_t &L = a->layout;
   PQN_REQUIRE(L.layers == 1 || a->wt, "pqn_mlp_update: transposed hidden kernels (wt) required for NUM_LAYERS > 1");
-  const size_t ostride = (size_t)N * L.d;
+  const int SN = S * N, TN = T * N;
+  const size_t ostride = (size_t)SN * L.d;
+  pqn_seeds_t sd = pqn_one_seed();
+  if (S > 1) {
+    sd.nseeds = S;
+    sd.n_env = N;
+    sd.n_env_total = SN;
+    sd.idx_stride = TN;
+    sd.theta_stride = theta_stride;
+    sd.ws_stride = ws_stride;
+    sd.lq_stride = (long long)MB * EP;
+    sd.idx_mask = (1ll << 25) - 1;
+  }
+  const int nps = S > 1 ? N : 0;   // envs per seed for the seed-aware kernels (0 = single seed)
 
-  hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf,
-                     (const uint64_t *)nullptr, (const uint64_t *)nullptr, T, EP, a->eps_start, a->eps_finish,
-                     a->eps_decay_steps, a->sched_keys, a->sched_eps);
-  // SAMPLE PHASE (_step_env scan, pqn_gymnax.py:172-211)
+  hipLaunchKernelGGL(update_sched_kernel, dim3(S), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, key_roll_dev,
+                     key_shuf_dev, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
+  // SAMPLE PHASE (_step_env scan, pqn_gymnax.py:172-211) over all S*N envs
   for (int t = 0; t < T; ++t) {
-    const size_t o = (size_t)t * N;
-    UPD_CHECK(pqn_mlp_forward_dyn(L, N, a->obs + t * ostride, a->theta, nullptr, a->action + o, a->qmax + o, 0.0f, 0,
-                                  a->sched_eps, a->sched_keys + t, st));
+    const size_t o = (size_t)t * SN;
+    UPD_CHECK(pqn_mlp_forward_dyn(L, SN, a->obs + t * ostride, a->theta, nullptr, a->action + o, a->qmax + o, 0.0f, 0,
+                                  a->sched_eps, a->sched_keys + t, st, nps, sd.theta_stride, T + EP));
     pqn_step_out_t out = {};
     out.obs = a->obs + (t + 1) * ostride;
     out.reward = a->reward + o;
@@ -268,27 +282,33 @@ extern "C" int pqn_mlp_update(const pqn_mlp_update_args_t *a, void *stream) {
     out.returned_episode_returns = a->rer + o;
     out.returned_episode_lengths = a->rel + o;
     out.timestep = a->ts + o;
-    UPD_CHECK(pqn_env_step_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->state, a->action + o, out, st));
+    UPD_CHECK(pqn_env_step_dyn(a->env_id, SN, a->sched_keys + t, a->rew_scale, a->state, a->action + o, out, st, nps, T + EP));
   }
   // bootstrap value of the last observation (:218-226) and Q(lambda) targets (:228-251)
-  UPD_CHECK(pqn_mlp_forward_dyn(L, N, a->obs + T * ostride, a->theta, nullptr, nullptr, a->last_q, 0.0f, 0, nullptr, nullptr,
-                                st));
-  UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, N, 1, a->target, st));
+  UPD_CHECK(pqn_mlp_forward_dyn(L, SN, a->obs + T * ostride, a->theta, nullptr, nullptr, a->last_q, 0.0f, 0, nullptr, nullptr,
+                                st, nps, sd.theta_stride, 0));
+  UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, SN, 1, a->target, st));
   // NETWORKS UPDATE (:254-318)
   int i_mb = 0;
   for (int ep = 0; ep < EP; ++ep) {
-    UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, N * T, a->sort_keys_in, st));
+    if (S == 1) {
+      UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, TN, a->sort_keys_in, st));
+    } else {
+      UPD_CHECK(pqn_shuffle_keys_seeds(a->sched_keys + T + ep, T + EP, S, TN, a->sort_keys_in, st));
+    }
     size_t tb = (size_t)a->sort_temp_bytes;
     if (hipcub::DeviceRadixSort::SortKeys(a->sort_temp, tb, (const unsigned long long *)a->sort_keys_in,
-                                          (unsigned long long *)a->sort_keys_out, N * T, 0, 63, st) != hipSuccess) {
+                                          (unsigned long long *)a->sort_keys_out, S * TN, 0, 63, st) != hipSuccess) {
       pqn_set_error("pqn_mlp_update: radix sort failed (temp bytes %llu)", (unsigned long long)a->sort_temp_bytes);
       return PQN_E_HIP;
     }
     for (int mb = 0; mb < MB; ++mb, ++i_mb) {
-      UPD_CHECK(pqn_mlp_grad(&L, B, a->sort_keys_out + (size_t)mb * B, a->obs, a->action, a->target, a->theta, a->wt, a->grad,
-                             a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, st));
-      UPD_CHECK(pqn_mlp_apply(&L, a->theta, a->wt, a->grad, a->m, a->v, a->count, a->lr_init, a->lr_end, a->lr_steps,
-                              a->max_grad_norm, a->workspace, nullptr, 0, st));
+      UPD_CHECK(pqn_mlp_grad_seeds(L, B, a->sort_keys_out + (size_t)mb * B, a->obs, a->action, a->target, a->theta, a->wt,
+                                   a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, sd, wt_stride, st));
+      UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
+                                 a->max_grad_norm, a->workspace, nullptr, 0, nullptr, 0, pqn_radam_blocks(L.total), st, S,
+                                 sd.theta_stride, sd.ws_stride, 0));
+      UPD_CHECK(pqn_mlp_refresh_transposed_seeds(L, a->theta, a->wt, S, sd.theta_stride, wt_stride, st));
     }
   }
   if (hipMemcpyAsync(a->obs, a->obs + (size_t)T * ostride, ostride * sizeof(float), hipMemcpyDeviceToDevice, st) !=
@@ -297,9 +317,22 @@ extern "C" int pqn_mlp_update(const pqn_mlp_update_args_t *a, void *stream) {
     return PQN_E_HIP;
   }
   double *partial = reinterpret_cast<double *>(a->workspace);  // first 1024 floats: optimizer scratch, idle here
-  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS, 1), dim3(256), 0, st, N * T, N, N, a->discount, a->rer,
-                     a->rel, a->ts, a->done, partial, 0ll);
-  hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, 1, MB * EP, a->loss_buf, a->qv_buf,
-                     partial, a->metrics, a->metrics_capacity, 0ll);
+  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS, S), dim3(256), 0, st, TN, N, SN, a->discount, a->rer, a->rel,
+                     a->ts, a->done, partial, sd.ws_stride / 2);
+  hipLaunchKernelGGL(update_tick_kernel, dim3(S), dim3(64), 0, st, a->clock, T, N, 1, MB * EP, a->loss_buf, a->qv_buf,
+                     partial, a->metrics, a->metrics_capacity, sd.ws_stride / 2);
   return pqn_check_launch("pqn_mlp_update");
+}
+
+extern "C" int pqn_mlp_update(const pqn_mlp_update_args_t *a, void *stream) {
+  return mlp_update_impl(a, 1, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int pqn_mlp_update_seeds(const pqn_mlp_update_args_t *a, int32_t num_seeds, const uint64_t *key_roll_dev,
+                                    const uint64_t *key_shuf_dev, int64_t theta_stride, int64_t workspace_stride,
+                                    int64_t wt_stride, void *stream) {
+  PQN_REQUIRE(num_seeds == 1 || (theta_stride > 0 && workspace_stride > 0 && theta_stride % 4 == 0 && workspace_stride % 4 == 0),
+              "pqn_mlp_update_seeds: strides must be positive multiples of 4 floats");
+  return mlp_update_impl(a, num_seeds, key_roll_dev, key_shuf_dev, theta_stride, workspace_stride, wt_stride,
+                         (hipStream_t)stream);
 }
