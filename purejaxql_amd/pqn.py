@@ -284,6 +284,34 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         # nanmean(where(returned_episode, x, nan)) (:403-412)
         return {kk: ((vals[kk].to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk in INFO_KEYS}
 
+    def flat_eval(act, k, n_t, steps, buf):
+        """Flat-observation evaluation scan (pqn_gymnax.py:362-404): per step one forward(+eps-greedy) launch
+        (`act(obs, eps, key, action_out, qmax_out)`) and one env.step launch writing straight into row t of the
+        [steps, n] info record; the masked means are taken once at the end."""
+        if "done" not in buf:
+            z = lambda dt: torch.empty((steps, n_t), dtype=dt, device=dev)
+            buf.update(done=z(torch.uint8), discount=z(torch.float32), rer=z(torch.float32),
+                       rel=z(torch.int32), ts=z(torch.int32), reward=torch.empty(n_t, dtype=torch.float32, device=dev),
+                       action=torch.empty(n_t, dtype=torch.int32, device=dev),
+                       qm=torch.empty(n_t, dtype=torch.float32, device=dev),
+                       obs=torch.empty((2, n_t, *obs_shape), dtype=torch.float32, device=dev))
+        b = buf
+        obs0, state = env.reset(_lib.fold_in(k, 0), env_params, n_t)
+        b["obs"][0].copy_(obs0)
+        words_t = state.words
+        for t in range(steps):
+            sk = _lib.fold_in(k, 1 + t)
+            cur, nxt = b["obs"][t & 1], b["obs"][(t + 1) & 1]
+            act(cur, config["EPS_TEST"], sk, b["action"], b["qm"])
+            env_step_into(sk, words_t, b["action"], nxt, None, b["reward"], b["done"][t], b["discount"][t],
+                          b["rer"][t], b["rel"][t], b["ts"][t])
+        dm = b["done"].to(torch.float64)
+        cnt = dm.sum()
+        vals = {"discount": b["discount"], "returned_episode_returns": b["rer"], "returned_episode_lengths": b["rel"],
+                "timestep": b["ts"], "returned_episode": b["done"]}
+        # nanmean(where(returned_episode, x, nan)) (:403-412)
+        return {kk: ((vals[kk].to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk in INFO_KEYS}
+
     def make_runner(rng: int):
         """Builds the per-seed training state and returns (update, finish): update(u) runs ONE
         PQN update (rollout + targets + epochs); finish() returns train()'s result dict."""
@@ -329,31 +357,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             n_t, steps = int(config["TEST_NUM_ENVS"]), int(config["TEST_NUM_STEPS"])
             if packed:
                 return fused_test_metrics(k, n_t, steps)
-            # flat-observation path: per step one forward(+eps-greedy) and one env.step launch writing straight
-            # into row t of the [steps, n] info record; the masked means are taken once at the end
-            if "done" not in eval_buf:
-                z = lambda dt: torch.empty((steps, n_t), dtype=dt, device=dev)
-                eval_buf.update(done=z(torch.uint8), discount=z(torch.float32), rer=z(torch.float32),
-                                rel=z(torch.int32), ts=z(torch.int32), reward=torch.empty(n_t, dtype=torch.float32, device=dev),
-                                action=torch.empty(n_t, dtype=torch.int32, device=dev),
-                                qm=torch.empty(n_t, dtype=torch.float32, device=dev),
-                                obs=torch.empty((2, n_t, *obs_shape), dtype=torch.float32, device=dev))
-            b = eval_buf
-            obs0, state = env.reset(_lib.fold_in(k, 0), env_params, n_t)
-            b["obs"][0].copy_(obs0)
-            words_t = state.words
-            for t in range(steps):
-                sk = _lib.fold_in(k, 1 + t)
-                cur, nxt = b["obs"][t & 1], b["obs"][(t + 1) & 1]
-                policy.act(cur, config["EPS_TEST"], sk, b["action"], b["qm"])
-                env_step_into(sk, words_t, b["action"], nxt, None, b["reward"], b["done"][t], b["discount"][t],
-                              b["rer"][t], b["rel"][t], b["ts"][t])
-            dm = b["done"].to(torch.float64)
-            cnt = dm.sum()
-            vals = {"discount": b["discount"], "returned_episode_returns": b["rer"], "returned_episode_lengths": b["rel"],
-                    "timestep": b["ts"], "returned_episode": b["done"]}
-            # nanmean(where(returned_episode, x, nan)) (:403-412)
-            return {kk: ((vals[kk].to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk in INFO_KEYS}
+            return flat_eval(policy.act, k, n_t, steps, eval_buf)
 
         tm_box = [get_test_metrics()]
 
@@ -488,26 +492,30 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         pqn_cnn_update_seeds), one hipGraph replay per update for all of them.  Same key schedule, same
         kernels and summation orders as make_runner, so every seed's result is bit-identical to its solo run.
         Returns (update, finish); finish() -> list of per-seed result dicts."""
-        from .qnet import METRIC_NAMES, CnnKernelLayout, SeedsUpdateDriver
+        from .qnet import METRIC_NAMES, CnnKernelLayout, MlpKernelLayout, SeedsUpdateDriver, mlp_forward
         S = len(rngs)
-        if not (packed and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25) and 1 <= S <= 128):
-            raise RuntimeError("seed batching needs the fused CNN path, no gradient hook, NUM_ENVS % 16 == 0, <= 128 seeds")
-        layout = CnnKernelLayout(obs_shape[-1], A,
-                                 matmul_f16=str(config.get("MATMUL_DTYPE", "f32")).lower() in ("f16", "fp16", "float16"))
+        if not (backend == "fused" and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25) and 1 <= S <= 128):
+            raise RuntimeError("seed batching needs a fused path, no gradient hook, NUM_ENVS % 16 == 0, <= 128 seeds")
+        if packed:
+            layout = CnnKernelLayout(obs_shape[-1], A,
+                                     matmul_f16=str(config.get("MATMUL_DTYPE", "f32")).lower() in ("f16", "fp16", "float16"))
+        else:
+            layout = MlpKernelLayout(obs_shape[0], int(config.get("HIDDEN_SIZE", 128)), int(config.get("NUM_LAYERS", 2)), A)
         Ks = []
         for rng in rngs:
             K = int(rng) & 0xFFFFFFFFFFFFFFFF
             Ks.append(tuple(_lib.fold_in(K, i) for i in range(5)))     # K_init, K_reset, K_test, K_roll, K_shuf
         lr_steps = (config["NUM_UPDATES_DECAY"] * MB * EPOCHS) if config.get("LR_LINEAR_DECAY", False) else 0.0
-        network = QNetwork(kind, obs_shape, A, norm_type=config["NORM_TYPE"], norm_input=False, device=dev)
-        ro = _Rollout(T, S * N, obs_shape, base_env.obs_words, dev)
+        network = QNetwork(kind, obs_shape, A, norm_type=config["NORM_TYPE"], norm_input=False,
+                           hidden_size=config.get("HIDDEN_SIZE", 128), num_layers=config.get("NUM_LAYERS", 2), device=dev)
+        ro = _Rollout(T, S * N, obs_shape, base_env.obs_words if packed else 0, dev)
         words = None
         dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
                 "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}
         drv = None
         theta_init = config.get("_INIT_PARAMS")
         for s, (K_init, K_reset, _kt, _kr, _ks) in enumerate(Ks):
-            (_o, bits0), st = env.reset(K_reset, env_params, N, want_obs=False, want_bits=True)   # (:418-419)
+            o0, st = env.reset(K_reset, env_params, N, want_obs=not packed, want_bits=packed)   # (:418-419)
             if words is None:
                 words = torch.empty((st.words.shape[0], S * N), dtype=st.words.dtype, device=dev)
                 drv = SeedsUpdateDriver(layout, base_env.env_id, S, N, T, MB, EPOCHS, base_env.obs_words, dcfg,
@@ -515,7 +523,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                                         config["MAX_GRAD_NORM"], ro, words, NUM_UPDATES, dev,
                                         use_graph=config.get("_GRAPH", True))
             words[:, s * N:(s + 1) * N] = st.words
-            ro.bits[0, s * N:(s + 1) * N] = bits0
+            (ro.bits if packed else ro.obs)[0, s * N:(s + 1) * N] = o0[1] if packed else o0
             th = network.init(K_init) if theta_init is None else theta_init.to(dev, torch.float32)   # (:150-173)
             drv.set_params(s, th)
         eval_buf = {}
@@ -527,6 +535,14 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             if not test_on:
                 return [None] * S
             n_t, steps = int(config["TEST_NUM_ENVS"]), int(config["TEST_NUM_STEPS"])
+            if not packed:      # flat-observation path: the per-seed scan of make_runner, on that seed's parameter slice
+                def act_of(s):
+                    return lambda obs, eps, key, action, qm: mlp_forward(layout, obs, drv.theta_k(s), want_q=False, eps=eps,
+                                                                         key=key, action=action, qmax=qm)
+                out = [flat_eval(act_of(s), _lib.fold_in(Ks[s][2], runs[0]), n_t, steps, eval_buf.setdefault(("solo", s), {}))
+                       for s in range(S)]
+                runs[0] += 1
+                return out
             if n_t % 16 != 0:   # ragged test batch: one launch per seed
                 out = [fused_eval(layout, drv.theta_k(s), _lib.fold_in(Ks[s][2], runs[0]), n_t, steps,
                                   eval_buf.setdefault(("solo", s), {})) for s in range(S)]
@@ -583,7 +599,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 test_rows[:, u] = torch.stack([torch.stack([tm_box[0][s][k] for k in INFO_KEYS]) for s in range(S)])
 
         def finish():
-            names = ["env_step", "update_steps", "env_frame", "grad_steps", "td_loss", "qvals"] + list(INFO_KEYS)
+            names = ["env_step", "update_steps", "grad_steps", "td_loss", "qvals"] + list(INFO_KEYS)
+            if kind == "cnn":
+                names.insert(2, "env_frame")
             outs = []
             for s in range(S):
                 metrics = {name: drv.metrics[s, :NUM_UPDATES, METRIC_NAMES.index(name)].to(torch.float32) for name in names}
@@ -593,7 +611,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 theta_f = layout.to_flax(drv.theta_k(s))
                 sl = slice(s * N, (s + 1) * N)
                 runner_state = {"params": network.views(theta_f), "theta": theta_f, "env_state": words[:, sl].contiguous(),
-                                "last_obs": ro.bits[0, sl], "test_metrics": tm_box[0][s], "network": network,
+                                "last_obs": (ro.bits if packed else ro.obs)[0, sl], "test_metrics": tm_box[0][s],
+                                "network": network,
                                 "backend": backend, "driver": "graph" if drv.graph is not None else "eager",
                                 "driver_graph_error": drv.graph_error, "opt_count": drv.count[s:s + 1],
                                 "opt_mu": drv.m[s, :layout.total], "opt_nu": drv.v[s, :layout.total],
@@ -612,7 +631,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
 
     train.make_runner = make_runner
     train.make_batch_runner = make_batch_runner
-    train.can_batch_seeds = bool(packed and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25)
+    train.can_batch_seeds = bool(backend == "fused" and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25)
                                  and config.get("_DRIVER", True) and config.get("_CALLBACK") is None)
     train.config = config
     train.backend = backend
@@ -623,23 +642,26 @@ def vmap_train(train: Callable[[int], Dict[str, Any]], keys: List[int], concurre
     """jax.vmap(make_train(config))(rngs) (pqn_minatar.py:459-461): independent seeds, outputs stacked on
     a leading [S] axis where they are tensors.
 
-    Seeds share nothing (own parameters, optimizer, envs, RNG streams).  On the fused CNN path they are batched
-    INTO the launches (grid.y = seed, pqn_cnn_update_seeds): one hipGraph replay advances every seed, so ten
-    128-env seeds cost about as much as one.  Other paths (MLP, torch-op networks) run the seeds as concurrent
-    HIP streams (`concurrent="streams"` forces that mode).  Either way each seed's result is bit-identical to
+    Seeds share nothing (own parameters, optimizer, envs, RNG streams).  On the fused paths (MinAtar CNN, gymnax
+    MLP) they are batched INTO the launches (grid.y = seed, pqn_cnn_update_seeds / pqn_mlp_update_seeds): one
+    hipGraph replay advances every seed, so ten 128-env seeds cost about as much as one.  The torch-op network
+    path runs the seeds as concurrent HIP streams (`concurrent="streams"` forces that mode).  Either way each seed's result is bit-identical to
     its solo run (`concurrent=False`)."""
     keys = list(keys)
     on_gpu = torch.cuda.is_available()
     if not concurrent or len(keys) <= 1 or not on_gpu or not hasattr(train, "make_runner"):
         outs = [train(k) for k in keys]
-    elif concurrent == "streams" or not getattr(train, "can_batch_seeds", False) or len(keys) > 128:
+    elif concurrent == "streams" or not getattr(train, "can_batch_seeds", False):
         outs = _vmap_streams(train, keys)
     else:
-        # the fused CNN path batches the seeds INTO the launches (grid.y = seed): one hipGraph replay per update
-        update, finish = train.make_batch_runner(keys)
-        for u in range(int(train.config["NUM_UPDATES"])):
-            update(u)
-        outs = finish()
+        # the fused paths batch the seeds INTO the launches (grid.y = seed): one hipGraph replay per update
+        # advances up to 128 seeds (7 seed bits in the shuffle keys); more seeds run as consecutive groups
+        outs = []
+        for g in range(0, len(keys), 128):
+            update, finish = train.make_batch_runner(keys[g:g + 128])
+            for u in range(int(train.config["NUM_UPDATES"])):
+                update(u)
+            outs.extend(finish())
     metrics = {k: torch.stack([o["metrics"][k] for o in outs]) for k in outs[0]["metrics"]}
     return {"runner_state": [o["runner_state"] for o in outs], "metrics": metrics}
 

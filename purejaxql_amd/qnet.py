@@ -260,25 +260,34 @@ class UpdateDriver:
 
 
 class SeedsUpdateDriver:
-    """jax.vmap over seeds inside the launches (pqn_cnn_update_seeds): S independent seeds advance by one update
-    in the same kernels (grid.y = seed) -- one enqueue, one hipGraph.  Owns the stacked parameter / optimizer
-    storage ([S, stride]); the caller provides the stacked rollout record ([T][S*N] arrays) and env state."""
+    """jax.vmap over seeds inside the launches (pqn_cnn_update_seeds / pqn_mlp_update_seeds): S independent seeds
+    advance by one update in the same kernels (grid.y = seed) -- one enqueue, one hipGraph.  Owns the stacked
+    parameter / optimizer storage ([S, stride]); the caller provides the stacked rollout record ([T][S*N] arrays)
+    and env state."""
 
-    def __init__(self, layout: CnnKernelLayout, env_id, s, n, t, mb, epochs, obs_words, cfg, keys_roll, keys_shuf,
+    def __init__(self, layout, env_id, s, n, t, mb, epochs, obs_words, cfg, keys_roll, keys_shuf,
                  lr, lr_end, lr_steps, max_norm, ro, words, num_updates, device, use_graph: bool = True):
         lib = _lib.load()
         dev = torch.device(device)
         self.layout, self.s, self.n = layout, int(s), int(n)
+        self.mlp = isinstance(layout, MlpKernelLayout)
         tn = n * t
         f32 = torch.float32
-        self.stride = (layout.alloc + 3) // 4 * 4
-        ws = int(lib.pqn_qnet_cnn_workspace_floats(C.byref(layout.struct), tn // mb))
+        alloc = layout.total if self.mlp else layout.alloc
+        self.stride = (alloc + 3) // 4 * 4
+        wsf = lib.pqn_mlp_workspace_floats if self.mlp else lib.pqn_qnet_cnn_workspace_floats
+        ws = int(wsf(C.byref(layout.struct), tn // mb))
         if ws < 0:
-            raise RuntimeError("pqn_qnet_cnn_workspace_floats failed")
+            raise RuntimeError("workspace size query failed")
         self.ws_stride = (ws + 3) // 4 * 4
         self.theta = torch.zeros((s, self.stride), dtype=f32, device=dev)
         self.grad, self.m, self.v = (torch.zeros_like(self.theta) for _ in range(3))
-        self.w1b = torch.empty((s, 1024 * 128), dtype=f32, device=dev)
+        if self.mlp:
+            self.wt_stride = max(layout.layers - 1, 1) * layout.h * layout.h
+            self.wt = torch.zeros((s, self.wt_stride), dtype=f32, device=dev)
+            self.w1b = None
+        else:
+            self.w1b = torch.empty((s, 1024 * 128), dtype=f32, device=dev)
         self.count = torch.zeros(s, dtype=torch.int32, device=dev)
         self.ws = torch.empty((s, self.ws_stride), dtype=f32, device=dev)
         self.clock = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -295,9 +304,9 @@ class SeedsUpdateDriver:
         self.metrics = torch.zeros((s, max(num_updates, 1), len(METRIC_NAMES)), dtype=torch.float64, device=dev)
         to_i64 = lambda ks: torch.tensor([k - (1 << 64) if k >= (1 << 63) else k for k in ks], dtype=torch.int64, device=dev)
         self.key_roll, self.key_shuf = to_i64(keys_roll), to_i64(keys_shuf)
-        a = UpdateArgs()
+        a = MlpUpdateArgs() if self.mlp else UpdateArgs()
         a.env_id, a.num_envs, a.num_steps, a.num_minibatches, a.num_epochs = env_id, n, t, mb, epochs
-        a.obs_words, a.metrics_capacity = obs_words, self.metrics.shape[1]
+        a.metrics_capacity = self.metrics.shape[1]
         a.gamma, a.lam, a.rew_scale = cfg["gamma"], cfg["lam"], cfg["rew_scale"]
         a.eps_start, a.eps_finish, a.eps_decay_steps = cfg["eps_start"], cfg["eps_finish"], cfg["eps_decay_steps"]
         a.lr_init, a.lr_end, a.lr_steps, a.max_grad_norm = float(lr), float(lr_end), float(lr_steps), float(max_norm)
@@ -305,12 +314,16 @@ class SeedsUpdateDriver:
         a.layout = layout.struct
         p = _lib.ptr
         a.clock, a.sched_keys, a.sched_eps = p(self.clock), p(self.sched_keys), p(self.sched_eps)
-        a.state, a.bits = p(words), p(ro.bits)
+        a.state = p(words)
+        if self.mlp:
+            a.obs, a.wt = p(ro.obs), p(self.wt)
+        else:
+            a.obs_words, a.bits, a.w1b = obs_words, p(ro.bits), p(self.w1b)
         a.action, a.reward, a.done, a.qmax = p(ro.action), p(ro.reward), p(ro.done), p(ro.qmax)
         a.discount, a.rer, a.rel, a.ts = p(ro.discount), p(ro.rer), p(ro.rel), p(ro.ts)
         a.target, a.last_q = p(ro.target), p(ro.last_q)
         a.sort_keys_in, a.sort_keys_out, a.sort_temp = p(self.sk_in), p(self.sk_out), p(self.sort_temp)
-        a.theta, a.w1b, a.grad, a.m, a.v = p(self.theta), p(self.w1b), p(self.grad), p(self.m), p(self.v)
+        a.theta, a.grad, a.m, a.v = p(self.theta), p(self.grad), p(self.m), p(self.v)
         a.count, a.workspace = p(self.count), p(self.ws)
         a.loss_buf, a.qv_buf, a.metrics = p(self.loss_buf), p(self.qv_buf), p(self.metrics)
         self.args = a
@@ -318,16 +331,27 @@ class SeedsUpdateDriver:
         self.use_graph, self.graph, self.graph_error, self.calls = use_graph, None, None, 0
 
     def set_params(self, seed: int, theta_flax: torch.Tensor):
-        self.theta[seed, :self.layout.alloc] = self.layout.to_kernel(theta_flax)
-        self.layout.refresh_copies(self.theta[seed], self.w1b[seed])
+        th = self.layout.to_kernel(theta_flax)
+        self.theta[seed, :th.numel()] = th
+        if self.mlp:
+            _lib.check(_lib.load().pqn_mlp_refresh_transposed(C.byref(self.layout.struct), _lib.ptr(self.theta[seed]),
+                                                              _lib.ptr(self.wt[seed]), _lib.stream_ptr()),
+                       "pqn_mlp_refresh_transposed")
+        else:
+            self.layout.refresh_copies(self.theta[seed], self.w1b[seed])
 
     def theta_k(self, seed: int) -> torch.Tensor:
         return self.theta[seed, :self.layout.total]
 
     def _enqueue(self):
-        _lib.check(_lib.load().pqn_cnn_update_seeds(C.byref(self.args), self.s, _lib.ptr(self.key_roll),
-                                                    _lib.ptr(self.key_shuf), self.stride, self.ws_stride,
-                                                    _lib.stream_ptr()), "pqn_cnn_update_seeds")
+        lib = _lib.load()
+        if self.mlp:
+            _lib.check(lib.pqn_mlp_update_seeds(C.byref(self.args), self.s, _lib.ptr(self.key_roll), _lib.ptr(self.key_shuf),
+                                                self.stride, self.ws_stride, self.wt_stride, _lib.stream_ptr()),
+                       "pqn_mlp_update_seeds")
+        else:
+            _lib.check(lib.pqn_cnn_update_seeds(C.byref(self.args), self.s, _lib.ptr(self.key_roll), _lib.ptr(self.key_shuf),
+                                                self.stride, self.ws_stride, _lib.stream_ptr()), "pqn_cnn_update_seeds")
 
     update = UpdateDriver.update
 

@@ -121,3 +121,27 @@ def test_eval_metrics_flat_obs_path_vs_oracle(gpu, oracle, backend):
                   "test/timestep", "test/discount"):
             a, b = float(out["metrics"][k][u]), oout["metrics"][u][k]
             assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (u, k, a, b)
+
+
+def test_vmap_train_mlp_seeds_batched_equal_solo(gpu):
+    """The gymnax MLP path with seeds batched into the launches (pqn_mlp_update_seeds) == seeds on streams == seeds one
+    after another, bit for bit (metrics incl. eval, parameters, optimizer moments, env state)."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys, vmap_train
+    cfg = flatten(load_config(["+alg=pqn_cartpole"]))
+    cfg.update({"NUM_ENVS": 16, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2, "TOTAL_TIMESTEPS": 4 * 16 * 16,
+                "TOTAL_TIMESTEPS_DECAY": 40 * 16 * 16, "TEST_DURING_TRAINING": True, "TEST_INTERVAL": 0.5,
+                "TEST_NUM_ENVS": 16, "TEST_NUM_STEPS": 60})
+    keys = seed_keys(4, 3)
+    conc = vmap_train(make_train(dict(cfg), device="cuda:0"), keys)
+    assert conc["runner_state"][0].get("seed_batch") == 3 and conc["runner_state"][0]["backend"] == "fused"
+    for mode in (False, "streams"):
+        other = vmap_train(make_train(dict(cfg), device="cuda:0"), keys, concurrent=mode)
+        assert "seed_batch" not in other["runner_state"][0]
+        for k in conc["metrics"]:
+            torch.testing.assert_close(conc["metrics"][k], other["metrics"][k], rtol=0, atol=0, equal_nan=True)
+        for a, b in zip(conc["runner_state"], other["runner_state"]):
+            torch.testing.assert_close(a["theta"], b["theta"], rtol=0, atol=0)
+            torch.testing.assert_close(a["opt_mu"], b["opt_mu"], rtol=0, atol=0)
+            assert torch.equal(a["env_state"], b["env_state"])
+    assert not torch.equal(conc["metrics"]["td_loss"][0], conc["metrics"]["td_loss"][1])
