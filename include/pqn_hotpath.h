@@ -210,7 +210,11 @@ int pqn_prof_read(int32_t *count /* host */, float *total_ms /* host */);
 #define PQN_NUM_METRICS 11 /* env_step, update_steps, env_frame, grad_steps, td_loss, qvals, discount,
                               returned_episode_returns, returned_episode_lengths, timestep, returned_episode */
 typedef struct {
-  int32_t env_id, num_envs, num_steps, num_minibatches, num_epochs, obs_words, metrics_capacity, reserved;
+  int32_t env_id, num_envs, num_steps, num_minibatches, num_epochs, obs_words, metrics_capacity;
+  int32_t reserved; /* flags.  bit 0 (experimental, leave 0): run the fold of the gradient partials, the global-norm
+                       clip and RAdam as ONE kernel with a grid-wide barrier instead of two kernels.  Measured slower
+                       in round 1 and unsafe when several updates are in flight on different streams of one GPU; same
+                       results up to the summation grouping of the global norm. */
   float gamma, lambda, rew_scale;                 /* GAMMA, LAMBDA, REW_SCALE */
   float eps_start, eps_finish, eps_decay_steps;   /* linear_schedule over updates (:134-138) */
   float lr_init, lr_end, lr_steps, max_grad_norm; /* :140-147,159-162 */

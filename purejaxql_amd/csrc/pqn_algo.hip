@@ -188,17 +188,6 @@ __global__ __launch_bounds__(256) void radam_norm_kernel(const float *__restrict
   }
 }
 
-// b^t for integer t >= 1 in f64 (<= 2 ulp from pow(); only its f32 cast is used)
-PQN_HD double pqn_powi(double b, int t) {
-  double r = 1.0;
-  while (t > 0) {
-    if (t & 1) r *= b;
-    b *= b;
-    t >>= 1;
-  }
-  return r;
-}
-
 __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                           float *__restrict__ m, float *__restrict__ v, int64_t n,
                                                           int32_t *__restrict__ count, float lr_init, float lr_end,

@@ -70,6 +70,17 @@ int pqn_check_launch(const char *what);
     }                                 \
   } while (0)
 
+// b^t for integer t >= 1 in f64 (<= 2 ulp from pow(); only its f32 cast is used)
+PQN_HD double pqn_powi(double b, int t) {
+  double r = 1.0;
+  while (t > 0) {
+    if (t & 1) r *= b;
+    b *= b;
+    t >>= 1;
+  }
+  return r;
+}
+
 // shared between pqn_algo.hip and pqn_qnet.hip
 inline int pqn_radam_blocks(int64_t n) {
   int64_t b = (n + 1023) / 1024;  // 4 elements per lane
@@ -112,7 +123,12 @@ int pqn_cnn_grad_reduce_blocks(int total);   // number of sum-of-squares partial
 int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out,
-                            const pqn_seeds_t &sd, hipStream_t st);
+                            const pqn_seeds_t &sd, hipStream_t st, bool with_reduce = true);
+// fold + clip + RAdam in one launch with a grid-wide barrier (see qnet_reduce_apply_kernel); scratch word 1022 of
+// the workspace is its ticket counter and must be zero before the first launch of an update
+int pqn_qnet_cnn_reduce_apply_seeds(const pqn_cnn_layout_t &L, int nb, float *theta, float *w1b, float *m, float *v,
+                                    int32_t *count, float *workspace, float *loss_out, float *qv_out, float lr_init,
+                                    float lr_end, float lr_steps, float max_norm, const pqn_seeds_t &sd, hipStream_t st);
 int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *obs_bits, const float *theta, float *q,
                              int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
                              const uint64_t *key_dev, hipStream_t st);

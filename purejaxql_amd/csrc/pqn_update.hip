@@ -22,9 +22,12 @@ static_assert(M_COUNT == PQN_NUM_METRICS, "metrics row layout");
 __global__ void update_sched_kernel(int32_t *__restrict__ clock, uint64_t key_roll, uint64_t key_shuf,
                                     const uint64_t *__restrict__ key_roll_dev, const uint64_t *__restrict__ key_shuf_dev,
                                     int t_len, int epochs, float eps_start, float eps_finish, float eps_decay_steps,
-                                    uint64_t *__restrict__ keys, float *__restrict__ eps) {
+                                    uint64_t *__restrict__ keys, float *__restrict__ eps, float *__restrict__ workspace,
+                                    long long ws_stride) {
   const int u = clock[0];
   const int i = threadIdx.x;
+  // ticket counter of the fused optimizer kernel's grid barrier (scratch word 1022 of this seed's workspace)
+  if (workspace && i == 0) reinterpret_cast<unsigned *>(workspace + blockIdx.x * ws_stride)[1022] = 0u;
   if (key_roll_dev) {
     key_roll = key_roll_dev[blockIdx.x];
     key_shuf = key_shuf_dev[blockIdx.x];
@@ -166,8 +169,14 @@ static int cnn_update_impl(const pqn_update_args_t *a, int S, const uint64_t *ke
     sd.idx_mask = (1ll << 25) - 1;
   }
 
+  // reserved bit 0 (experimental, off by default): fold + clip + RAdam as ONE kernel with a grid-wide barrier
+  // instead of two kernels.  Measured slower in round 1 (5.47 vs 4.92 ms per update at the bench shape: the
+  // barrier costs more than the launch it saves) and unsafe when several updates are in flight on different
+  // streams (two partially resident barrier grids could dead-lock), so the two-kernel version is the default.
+  const bool fused_opt = (a->reserved & 1) != 0;
   hipLaunchKernelGGL(update_sched_kernel, dim3(S), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, key_roll_dev,
-                     key_shuf_dev, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
+                     key_shuf_dev, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps,
+                     a->workspace, sd.ws_stride);
   // SAMPLE PHASE (_step_env scan, :181-220) + bootstrap forward (:227-235): one persistent launch over all S*N envs
   {
     pqn_step_out_t rec = {};
@@ -199,10 +208,18 @@ static int cnn_update_impl(const pqn_update_args_t *a, int S, const uint64_t *ke
     for (int mb = 0; mb < MB; ++mb, ++i_mb) {
       // low bits of a sorted shuffle key = the transition index inside the seed (kernels mask with sd.idx_mask)
       UPD_CHECK(pqn_qnet_cnn_grad_seeds(L, B, a->sort_keys_out + (size_t)mb * B, a->bits, a->action, a->target, a->theta,
-                                        a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, sd, st));
-      UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
-                                 a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, 0, pqn_cnn_grad_reduce_blocks(L.total),
-                                 st, S, sd.theta_stride, sd.ws_stride, sd.w1b_stride, L.matmul_f16 ? L.off_w1h : 0));
+                                        a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, sd, st,
+                                        !fused_opt));
+      if (fused_opt) {   // fold + clip + RAdam in one launch (grid barrier); the flat gradient is never materialised
+        UPD_CHECK(pqn_qnet_cnn_reduce_apply_seeds(L, B, a->theta, a->w1b, a->m, a->v, a->count, a->workspace,
+                                                  a->loss_buf + i_mb, a->qv_buf + i_mb, a->lr_init, a->lr_end, a->lr_steps,
+                                                  a->max_grad_norm, sd, st));
+      } else {
+        UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
+                                   a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, 0,
+                                   pqn_cnn_grad_reduce_blocks(L.total), st, S, sd.theta_stride, sd.ws_stride, sd.w1b_stride,
+                                   L.matmul_f16 ? L.off_w1h : 0));
+      }
     }
   }
   // carry last_obs into the next update; metrics (:329-338); advance the clock
@@ -268,7 +285,8 @@ static int mlp_update_impl(const pqn_mlp_update_args_t *a, int S, const uint64_t
   const int nps = S > 1 ? N : 0;   // envs per seed for the seed-aware kernels (0 = single seed)
 
   hipLaunchKernelGGL(update_sched_kernel, dim3(S), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, key_roll_dev,
-                     key_shuf_dev, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps);
+                     key_shuf_dev, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps,
+                     (float *)nullptr, 0ll);
   // SAMPLE PHASE (_step_env scan, pqn_gymnax.py:172-211) over all S*N envs
   for (int t = 0; t < T; ++t) {
     const size_t o = (size_t)t * SN;

@@ -387,7 +387,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
                     "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}
             driver = UpdateDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
-                                  policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True))
+                                  policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
+                                  fused_opt=config.get("_FUSED_OPT", False))
         test_rows = torch.zeros((NUM_UPDATES, len(INFO_KEYS)), dtype=torch.float32, device=dev) if test_on else None
 
         def driver_update(u: int):
@@ -667,7 +668,8 @@ def vmap_train(train: Callable[[int], Dict[str, Any]], keys: List[int], concurre
 
 
 def _vmap_streams(train, keys):
-    """Seeds as concurrent HIP streams (paths without seed-batched kernels: MLP, torch-op networks)."""
+    """Seeds as concurrent HIP streams (paths without seed-batched kernels: torch-op networks)."""
+    train.config["_FUSED_OPT"] = False   # several updates in flight at once: no grid-barrier optimizer kernel
     num_updates = int(train.config["NUM_UPDATES"])
     main = torch.cuda.current_stream()
     streams = [torch.cuda.Stream() for _ in keys]

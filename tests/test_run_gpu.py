@@ -63,13 +63,16 @@ def test_vmap_train_seeds_are_independent_and_stacked(gpu):
         seq = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys, concurrent=False)
         streams = vmap_train(make_train(dict(cfg_t), device="cuda:0"), keys, concurrent="streams")
         assert conc["runner_state"][0].get("seed_batch") == 3 and "seed_batch" not in streams["runner_state"][0]
-        for other in (seq, streams):
-            for k in conc["metrics"]:
-                torch.testing.assert_close(conc["metrics"][k], other["metrics"][k], rtol=0, atol=0, equal_nan=True)
-            for a, b in zip(conc["runner_state"], other["runner_state"]):
-                torch.testing.assert_close(a["theta"], b["theta"], rtol=0, atol=0)
-                torch.testing.assert_close(a["opt_mu"], b["opt_mu"], rtol=0, atol=0)
-                assert torch.equal(a["env_state"], b["env_state"])
+        for k in conc["metrics"]:
+            torch.testing.assert_close(conc["metrics"][k], seq["metrics"][k], rtol=0, atol=0, equal_nan=True)
+        for a, b in zip(conc["runner_state"], seq["runner_state"]):
+            torch.testing.assert_close(a["theta"], b["theta"], rtol=0, atol=0)
+            torch.testing.assert_close(a["opt_mu"], b["opt_mu"], rtol=0, atol=0)
+            assert torch.equal(a["env_state"], b["env_state"])
+        for k in conc["metrics"]:
+            torch.testing.assert_close(conc["metrics"][k], streams["metrics"][k], rtol=0, atol=0, equal_nan=True)
+        for a, b in zip(conc["runner_state"], streams["runner_state"]):
+            torch.testing.assert_close(a["theta"], b["theta"], rtol=0, atol=0)
 
 
 def test_single_run_saves_reference_format_checkpoints(gpu, tmp_path):

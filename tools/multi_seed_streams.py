@@ -12,6 +12,7 @@ K, W = 10, 3
 for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
     cfg = workload_config(4096, "seeds")
     cfg["TOTAL_TIMESTEPS"] = (K + W + 3) * cfg["NUM_ENVS"] * cfg["NUM_STEPS"]
+    cfg["_FUSED_OPT"] = False   # updates of different seeds are in flight at once: two-kernel fold + optimizer
     streams = [torch.cuda.Stream() for _ in range(S)]
     runners = []
     for s, key in zip(streams, seed_keys(0, S)):
