@@ -334,6 +334,59 @@ def _bn_bwd(dy, scale, cache):
     return dx.reshape(dy.shape).astype(np.float32), dscale.astype(np.float32), dbias.astype(np.float32)
 
 
+# BatchRenorm (purejaxql/utils/batch_renorm.py:19-131, used by pqn_craftax.py:44-53): eps 1e-3, momentum 0.999,
+# r_max 3, d_max 5, renormalisation active once steps >= 1000.  r and d carry no gradient (stop_gradient, :100-103).
+BRN_EPS, BRN_MOMENTUM, BRN_R_MAX, BRN_D_MAX, BRN_WARMUP = np.float32(1e-3), np.float32(0.999), np.float32(3.0), np.float32(5.0), 1000
+
+
+def brn_fwd(x, scale, bias, stats, train, new_stats=None):
+    f = x.shape[-1]
+    x2 = x.reshape(-1, f).astype(np.float32)
+    if not train:
+        mean, var = stats["mean"], stats["var"]
+        cache = None
+    else:
+        bmean = x2.mean(0, dtype=np.float32)
+        bvar = np.maximum((x2 * x2).mean(0, dtype=np.float32) - bmean * bmean, np.float32(0))
+        mean, var = bmean, bvar
+        r = d = None
+        if int(stats["steps"]) >= BRN_WARMUP:
+            ra_std = np.sqrt(stats["var"] + BRN_EPS)
+            r = np.clip(np.sqrt(bvar + BRN_EPS) / ra_std, 1 / BRN_R_MAX, BRN_R_MAX).astype(np.float32)   # :100-101
+            d = np.clip((bmean - stats["mean"]) / ra_std, -BRN_D_MAX, BRN_D_MAX).astype(np.float32)      # :102-103
+            var = (bvar / (r * r)).astype(np.float32)                                                    # :104
+            mean = (bmean - d * np.sqrt(bvar) / r).astype(np.float32)                                    # :105
+        if new_stats is not None:                                                                         # :112-116
+            new_stats["mean"] = (BRN_MOMENTUM * stats["mean"] + (1 - BRN_MOMENTUM) * bmean).astype(np.float32)
+            new_stats["var"] = (BRN_MOMENTUM * stats["var"] + (1 - BRN_MOMENTUM) * bvar).astype(np.float32)
+            new_stats["steps"] = int(stats["steps"]) + 1
+        cache = (x2, bmean, bvar, mean, var, r, d)
+    k = (1.0 / np.sqrt(var + BRN_EPS)).astype(np.float32)
+    y = ((x2 - mean) * (k * scale) + bias).astype(np.float32)
+    return y.reshape(x.shape), cache
+
+
+def brn_bwd(dy, scale, cache):
+    """d/dx, d/dscale, d/dbias of the train-mode BatchRenorm (batch moments are functions of x; r, d are constants)."""
+    x2, bmean, bvar, cm, cv, r, d = cache
+    n = x2.shape[0]
+    dy2 = dy.reshape(x2.shape).astype(np.float32)
+    k = 1.0 / np.sqrt(cv + BRN_EPS)
+    xc = x2 - cm
+    dscale = (dy2 * xc * k).sum(0)
+    dbias = dy2.sum(0)
+    dyh = dy2 * scale
+    g_cm = -k * dyh.sum(0)
+    g_cv = -0.5 * k ** 3 * (dyh * xc).sum(0)
+    if r is None:
+        g_mean, g_var = g_cm, g_cv
+    else:
+        g_mean = g_cm
+        g_var = g_cv / (r * r) + g_cm * (-(d / r) / (2.0 * np.sqrt(bvar)))
+    dx = dyh * k + g_mean / n + g_var * 2.0 * (x2 - bmean) / n
+    return dx.reshape(dy.shape).astype(np.float32), dscale.astype(np.float32), dbias.astype(np.float32)
+
+
 def _norm_fwd(norm, x, p, name, train, stats, new_stats):
     if norm == "layer_norm":
         return _ln_fwd(x, p[name + "/scale"], p[name + "/bias"])

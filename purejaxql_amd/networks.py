@@ -102,6 +102,36 @@ def batch_stats_shapes(kind: str, obs_shape, hidden: int, layers: int, norm_type
     return shapes
 
 
+# BatchRenorm of the Craftax script (purejaxql/utils/batch_renorm.py:19-131; pqn_craftax.py:44-53): BatchNorm whose
+# train-mode moments are pulled towards the running ones by clipped, gradient-free factors r, d once 1000 steps of
+# warm-up have passed.  Building block of the Craftax row; not selected by the MinAtar / gymnax yaml.
+BRN_EPS, BRN_MOMENTUM, BRN_R_MAX, BRN_D_MAX, BRN_WARMUP = 1e-3, 0.999, 3.0, 5.0, 1000
+
+
+def batch_renorm(x: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, stats: Dict[str, torch.Tensor], train: bool,
+                 new_stats: Dict[str, torch.Tensor] = None) -> torch.Tensor:
+    """stats: {"mean", "var", "steps"} (running moments, step counter).  train=True normalises with the (renormalised)
+    batch moments and writes the updated statistics into new_stats; train=False uses the running moments."""
+    if not train:
+        mean, var = stats["mean"], stats["var"]
+    else:
+        axes = tuple(range(x.dim() - 1))
+        bmean = x.mean(dim=axes)
+        bvar = torch.clamp((x * x).mean(dim=axes) - bmean * bmean, min=0.0)        # flax fast variance
+        mean, var = bmean, bvar
+        if int(stats["steps"]) >= BRN_WARMUP:
+            ra_std = torch.sqrt(stats["var"] + BRN_EPS)
+            r = torch.clamp((torch.sqrt(bvar + BRN_EPS) / ra_std).detach(), 1.0 / BRN_R_MAX, BRN_R_MAX)
+            d = torch.clamp(((bmean - stats["mean"]) / ra_std).detach(), -BRN_D_MAX, BRN_D_MAX)
+            var = bvar / (r * r)
+            mean = bmean - d * torch.sqrt(bvar) / r
+        if new_stats is not None:
+            new_stats["mean"] = BRN_MOMENTUM * stats["mean"] + (1.0 - BRN_MOMENTUM) * bmean.detach()
+            new_stats["var"] = BRN_MOMENTUM * stats["var"] + (1.0 - BRN_MOMENTUM) * bvar.detach()
+            new_stats["steps"] = stats["steps"] + 1
+    return (x - mean) * (torch.rsqrt(var + BRN_EPS) * scale) + bias
+
+
 def _trunc_normal(shape, std, gen):
     # variance_scaling(..., "truncated_normal"): truncnorm(-2,2) * std / 0.87962566
     t = torch.empty(shape, dtype=torch.float32)

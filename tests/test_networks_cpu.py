@@ -66,3 +66,38 @@ def test_batchnorm_network_requires_stats():
         net.apply(net.views(theta), torch.zeros(3, 4))
     assert set(net.init_batch_stats()) == {"BatchNorm_1/mean", "BatchNorm_1/var", "BatchNorm_2/mean", "BatchNorm_2/var"}
     assert "BatchNorm_0/scale" in net.shapes and "BatchNorm_2/scale" in net.shapes and "LayerNorm_0/scale" not in net.shapes
+
+
+@pytest.mark.parametrize("steps", [0, 999, 1000, 5000])
+def test_batch_renorm_torch_vs_oracle(steps):
+    """BatchRenorm (purejaxql/utils/batch_renorm.py:19-131, the Craftax script's normaliser): torch-autograd version vs
+    the oracle's hand-written forward / backward, before and after the 1000-step warm-up, plus the running update."""
+    from purejaxql_amd.networks import batch_renorm
+    gen = torch.Generator().manual_seed(3 + steps)
+    B, F = 64, 12
+    x = (1.5 * torch.randn((B, F), generator=gen) + 0.7).requires_grad_(True)
+    scale = (1.0 + 0.2 * torch.randn(F, generator=gen)).requires_grad_(True)
+    bias = (0.1 * torch.randn(F, generator=gen)).requires_grad_(True)
+    stats = {"mean": 0.5 * torch.randn(F, generator=gen), "var": 0.5 + torch.rand(F, generator=gen), "steps": steps}
+    w = torch.randn((B, F), generator=gen)
+    new = {}
+    y = batch_renorm(x, scale, bias, stats, True, new)
+    (y * w).sum().backward()
+    ostats = {"mean": stats["mean"].numpy(), "var": stats["var"].numpy(), "steps": steps}
+    onew = {}
+    oy, cache = O.brn_fwd(x.detach().numpy(), scale.detach().numpy(), bias.detach().numpy(), ostats, True, onew)
+    dx, dscale, dbias = O.brn_bwd(w.numpy(), scale.detach().numpy(), cache)
+    np.testing.assert_allclose(oy, y.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dx, x.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dscale, scale.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(dbias, bias.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(onew["mean"], new["mean"].numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(onew["var"], new["var"].numpy(), rtol=1e-6, atol=1e-7)
+    assert onew["steps"] == steps + 1 == int(new["steps"])
+    # r / d really are active after the warm-up (the two regimes differ) and eval mode uses the running moments
+    if steps >= 1000:
+        y_plain = batch_renorm(x.detach(), scale.detach(), bias.detach(), {**stats, "steps": 0}, True)
+        assert (y_plain - y.detach()).abs().max() > 1e-3
+    ye = batch_renorm(x.detach(), scale.detach(), bias.detach(), stats, False)
+    oye, _ = O.brn_fwd(x.detach().numpy(), scale.detach().numpy(), bias.detach().numpy(), ostats, False)
+    np.testing.assert_allclose(oye, ye.numpy(), rtol=1e-5, atol=1e-5)
