@@ -83,3 +83,20 @@ def test_unknown_env_is_an_error():
     assert lib.pqn_env_spec(0, ctypes.byref(spec)) == 0
     assert tuple(spec.obs_dim) == (10, 10, 4) and spec.num_actions == 3 and spec.max_steps == 1000
     assert spec.state_words == 7 and spec.obs_words == 16 and spec.canon_si == 109
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/pqn_hotpath.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch / HIP types) and a
+    C translation unit must be able to reference every declared entry point."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "pqn_hotpath.h")
+    names = sorted(set(re.findall(r"\b(pqn_[a-z0-9_]+)\s*\(", open(hdr).read())))
+    src = tmp_path / "use.c"
+    src.write_text('#include "pqn_hotpath.h"\nvoid *table[] = {' + ", ".join(f"(void *){n}" for n in names) + "};\n")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(root, "include"), "-c", str(src),
+                    "-o", str(tmp_path / "use.o")], check=True)
