@@ -100,3 +100,31 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "pqn_hotpath.h"\nvoid *table[] = {' + ", ".join(f"(void *){n}" for n in names) + "};\n")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(root, "include"), "-c", str(src),
                     "-o", str(tmp_path / "use.o")], check=True)
+
+
+def test_integration_md_ctypes_stub_runs_against_the_library():
+    """The ctypes stub printed in INTEGRATION.md is real: its struct definitions match the library (host-only entry
+    points are called; the device entry points only get their argtypes)."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = text.split("```python")[1].split("```")[0]
+    head = block.split("env = lib.pqn_env_id")[0]                    # definitions + argtypes, no device calls
+    head = head.replace('C.CDLL("purejaxql_amd/csrc/libpqn_hip.so")',
+                        'C.CDLL(%r)' % os.path.join(root, "purejaxql_amd", "csrc", "libpqn_hip.so"))
+    import torch  # noqa: F401  (the library must see torch's HIP runtime first, as the stub's comment says)
+    ns = {}
+    exec(head, ns)
+    lib, EnvSpec = ns["lib"], ns["EnvSpec"]
+    env = lib.pqn_env_id(b"Breakout-MinAtar")
+    assert env >= 0 and lib.pqn_env_id(b"NoSuchEnv-v0") < 0
+    spec = EnvSpec()
+    lib.pqn_env_spec.argtypes = [C.c_int, C.POINTER(EnvSpec)]
+    assert lib.pqn_env_spec(env, C.byref(spec)) == 0
+    assert list(spec.obs_dim) == [10, 10, 4] and spec.obs_size == 400 and spec.num_actions == 3 and spec.max_steps == 1000
+    assert spec.obs_words == 16 and spec.state_words == 2 + 5
+    lib.pqn_fold_in.restype = C.c_uint64
+    lib.pqn_fold_in.argtypes = [C.c_uint64, C.c_uint32]
+    from purejaxql_amd import _lib
+    assert lib.pqn_fold_in(42, 7) == _lib.fold_in(42, 7)
+    assert b"unknown" in lib.pqn_last_error().lower() or lib.pqn_last_error() is not None
