@@ -128,3 +128,25 @@ def test_integration_md_ctypes_stub_runs_against_the_library():
     from purejaxql_amd import _lib
     assert lib.pqn_fold_in(42, 7) == _lib.fold_in(42, 7)
     assert b"unknown" in lib.pqn_last_error().lower() or lib.pqn_last_error() is not None
+
+
+def test_c_only_example_builds_and_reaches_the_device_boundary(tmp_path):
+    """examples/c_api_demo.c: plain gcc + the header + the shared library.  Without a GPU it must get through the host-only
+    entry points (env id / spec / version) and stop at the first device call with an error, not a crash."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("needs gcc and the ROCm headers")
+    exe = str(tmp_path / "c_api_demo")
+    lib_dir = os.path.join(root, "purejaxql_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I",
+                    os.path.join(root, "include"), os.path.join(root, "examples", "c_api_demo.c"), "-L", lib_dir, "-lpqn_hip",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                   check=True)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the device part is exercised by the GPU suite's own callers")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert "obs 10x10x4, 3 actions, 7 state words, 16 packed obs words" in out.stdout
+    assert out.returncode == 1 and "hipStreamCreate" in out.stderr
