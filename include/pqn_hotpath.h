@@ -135,7 +135,7 @@ int pqn_shuffle_keys(uint64_t key, int32_t n, int64_t *keys, void *stream);
  * lr_steps) if lr_steps > 0 else lr_init (:140-147).  scratch: >= 1024 floats.
  * gnorm_out (nullable): pre-clip global norm. */
 int pqn_radam_clip_step(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count,
-                        float lr_init, float lr_end, float lr_steps, float max_norm,
+                        float lr_init, float lr_end, double lr_steps, float max_norm,
                         float *scratch, float *gnorm_out, void *stream);
 
 /* ---- fused MinAtar CNN Q-network (QNetwork/CNN, pqn_minatar.py:24-69) -------------- */
@@ -188,7 +188,7 @@ int pqn_qnet_cnn_grad(const pqn_cnn_layout_t *layout /* host */, int32_t nb, con
                       const float *w1b, float *grad, const int32_t *count, float *workspace, float *loss_out,
                       float *qv_out, void *stream);
 int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *layout /* host */, float *theta, float *w1b, const float *grad,
-                       float *m, float *v, int32_t *count, float lr_init, float lr_end, float lr_steps,
+                       float *m, float *v, int32_t *count, float lr_init, float lr_end, double lr_steps,
                        float max_norm, float *workspace, float *gnorm_out, int32_t recompute_norm, void *stream);
 /* (re)derive the copies of the fc1 kernel from theta: w1b (f32 dgrad fragments, 131072 floats; NULL = skip) and,
  * for a matmul_f16 layout, the two fp16 copies in theta's own tail.  Call after writing parameters by hand. */
@@ -216,8 +216,10 @@ typedef struct {
                        in round 1 and unsafe when several updates are in flight on different streams of one GPU; same
                        results up to the summation grouping of the global norm. */
   float gamma, lambda, rew_scale;                 /* GAMMA, LAMBDA, REW_SCALE */
-  float eps_start, eps_finish, eps_decay_steps;   /* linear_schedule over updates (:134-138) */
-  float lr_init, lr_end, lr_steps, max_grad_norm; /* :140-147,159-162 */
+  float eps_start, eps_finish;                    /* linear_schedule over updates (:134-138) */
+  float lr_init, lr_end, max_grad_norm;           /* :140-147,159-162 */
+  double eps_decay_steps, lr_steps;               /* schedule lengths, in f64 like the reference's Python floats
+                                                     (EPS_DECAY*NUM_UPDATES_DECAY may be fractional, e.g. 244.1) */
   uint64_t key_roll, key_shuf;
   uint64_t sort_temp_bytes;
   pqn_cnn_layout_t layout;
@@ -245,6 +247,19 @@ typedef struct {
 
 int64_t pqn_update_sort_temp_bytes(int32_t n);
 int pqn_cnn_update(const pqn_update_args_t *args /* host */, void *stream);
+
+/* The same update enqueued one PHASE at a time, so that the caller can put a collective between the gradient
+ * and the optimizer step of every minibatch: the envs of ONE seed sharded over ranks (SURVEY 8(e);
+ * pqn_minatar.py:159-162,285-292 -- clip + RAdam must see the gradient averaged over the global minibatch).
+ *   BEGIN            step keys / eps from the clock, rollout scan + bootstrap forward, Q(lambda) targets (:181-260)
+ *   SHUFFLE index=ep epoch permutation (:299-315)
+ *   GRAD    index=i  i = ep*num_minibatches + mb: forward + backward -> args->grad (flat, kernel layout) (:271-291)
+ *   APPLY   index=i  global norm of args->grad (recomputed: the caller may have all-reduced it), clip + RAdam (:292)
+ *   END              carry last_obs, metrics row, clock tick (:329-338)
+ * pqn_cnn_update(args) == BEGIN, then per epoch SHUFFLE and per minibatch GRAD, APPLY, then END (up to the
+ * summation order of the global norm).  Single seed; every phase only enqueues (hipGraph-capturable). */
+enum { PQN_PHASE_BEGIN = 0, PQN_PHASE_SHUFFLE = 1, PQN_PHASE_GRAD = 2, PQN_PHASE_APPLY = 3, PQN_PHASE_END = 4 };
+int pqn_cnn_update_phase(const pqn_update_args_t *args /* host */, int32_t phase, int32_t index, void *stream);
 
 /* jax.vmap(make_train(config))(rngs) (pqn_minatar.py:459-461) inside the launches: num_seeds independent seeds
  * advance by one update in the SAME kernels (grid.y = seed), one enqueue / one hipGraph for all of them.  Every
@@ -314,7 +329,7 @@ int pqn_mlp_grad(const pqn_mlp_layout_t *layout /* host */, int32_t nb, const in
                  const int32_t *action, const float *target, const float *theta, const float *wt, float *grad,
                  const int32_t *count, float *workspace, float *loss_out, float *qv_out, void *stream);
 int pqn_mlp_apply(const pqn_mlp_layout_t *layout /* host */, float *theta, float *wt, const float *grad, float *m,
-                  float *v, int32_t *count, float lr_init, float lr_end, float lr_steps, float max_norm,
+                  float *v, int32_t *count, float lr_init, float lr_end, double lr_steps, float max_norm,
                   float *workspace, float *gnorm_out, int32_t recompute_norm, void *stream);
 int pqn_mlp_refresh_transposed(const pqn_mlp_layout_t *layout /* host */, const float *theta, float *wt, void *stream);
 
@@ -324,8 +339,9 @@ int pqn_mlp_refresh_transposed(const pqn_mlp_layout_t *layout /* host */, const 
 typedef struct {
   int32_t env_id, num_envs, num_steps, num_minibatches, num_epochs, metrics_capacity;
   float gamma, lambda, rew_scale;
-  float eps_start, eps_finish, eps_decay_steps;
-  float lr_init, lr_end, lr_steps, max_grad_norm;
+  float eps_start, eps_finish;
+  float lr_init, lr_end, max_grad_norm;
+  double eps_decay_steps, lr_steps;
   uint64_t key_roll, key_shuf;
   uint64_t sort_temp_bytes;
   pqn_mlp_layout_t layout;

@@ -626,7 +626,7 @@ void pqn_oracle_q_lambda(const float *reward, const uint8_t *done, const float *
 
 /* optax.linear_schedule (A.5), used at pqn_minatar.py:134-147. */
 double pqn_oracle_linear_schedule(double init, double end, double transition_steps, double count) {
-  if (transition_steps <= 0) return end;
+  if (transition_steps <= 0) return init;  /* optax: non-positive transition_steps = constant init_value */
   double c = count < 0 ? 0 : (count > transition_steps ? transition_steps : count);
   double frac = 1.0 - c / transition_steps;
   return (init - end) * frac + end;

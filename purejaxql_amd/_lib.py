@@ -48,19 +48,20 @@ SIGNATURES = {
                              c_void_p, c_void_p]),
     "pqn_shuffle_keys": (c_int, [c_uint64, c_int32, c_void_p, c_void_p]),
     "pqn_radam_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float,
-                                    c_float, c_float, c_void_p, c_void_p, c_void_p]),
+                                    C.c_double, c_float, c_void_p, c_void_p, c_void_p]),
     "pqn_cnn_layout": (c_int, [c_int32, c_int32, c_void_p]),
     "pqn_cnn_layout_ex": (c_int, [c_int32, c_int32, c_int32, c_void_p]),
     "pqn_qnet_cnn_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                      c_uint64, c_void_p]),
     "pqn_qnet_cnn_workspace_floats": (c_int64, [c_void_p, c_int32]),
     "pqn_qnet_cnn_grad": (c_int, [c_void_p, c_int32] + [c_void_p] * 11 + [c_void_p]),
-    "pqn_qnet_cnn_apply": (c_int, [c_void_p] * 7 + [c_float] * 4 + [c_void_p, c_void_p, c_int32, c_void_p]),
+    "pqn_qnet_cnn_apply": (c_int, [c_void_p] * 7 + [c_float, c_float, C.c_double, c_float] + [c_void_p, c_void_p, c_int32, c_void_p]),
     "pqn_qnet_cnn_pack_w1b": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_prof_enable": (c_int, [c_int32]),
     "pqn_prof_read": (c_int, [c_void_p, c_void_p]),
     "pqn_update_sort_temp_bytes": (c_int64, [c_int32]),
     "pqn_cnn_update": (c_int, [c_void_p, c_void_p]),
+    "pqn_cnn_update_phase": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "pqn_mlp_update": (c_int, [c_void_p, c_void_p]),
     "pqn_mlp_update_seeds": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "pqn_cnn_rollout_seeds": (c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
@@ -75,7 +76,7 @@ SIGNATURES = {
                                 c_void_p]),
     "pqn_mlp_workspace_floats": (c_int64, [c_void_p, c_int32]),
     "pqn_mlp_grad": (c_int, [c_void_p, c_int32] + [c_void_p] * 11 + [c_void_p]),
-    "pqn_mlp_apply": (c_int, [c_void_p] * 7 + [c_float] * 4 + [c_void_p, c_void_p, c_int32, c_void_p]),
+    "pqn_mlp_apply": (c_int, [c_void_p] * 7 + [c_float, c_float, C.c_double, c_float] + [c_void_p, c_void_p, c_int32, c_void_p]),
     "pqn_mlp_refresh_transposed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -121,44 +121,52 @@ extern "C" int pqn_q_lambda(const float *reward, const uint8_t *done, const floa
 }
 
 // ---------------------------------------------------------------------------
-// shuffle keys: key_i = (bits_i >> 1) << 32 | i  (unique -> argsort is a
-// well-defined permutation).
+// shuffle keys: key_i = rand31_i << ib | i  (unique -> argsort is a well-defined permutation: transitions
+// ordered by (rand31, i)).  The public entry point uses ib = 32; the whole-update driver packs the index into
+// ib = ceil(log2 n) bits so its radix sort only has to visit the 31 + ib significant bits.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void shuffle_keys_kernel(uint64_t key, const uint64_t *__restrict__ key_dev, int n,
-                                                           int64_t *__restrict__ keys) {
+                                                           int ib, int64_t *__restrict__ keys) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (key_dev) key = *key_dev;
   uint32_t o0, o1;
   pqn_bits(key, (uint32_t)i, 0u, o0, o1);
-  keys[i] = (int64_t)(((uint64_t)(o0 >> 1) << 32) | (uint32_t)i);
+  keys[i] = (int64_t)(((uint64_t)(o0 >> 1) << ib) | (uint32_t)i);
 }
 
 extern "C" int pqn_shuffle_keys(uint64_t key, int32_t n, int64_t *keys, void *stream) {
   PQN_REQUIRE(keys && n > 0, "pqn_shuffle_keys: NULL keys or n <= 0");
-  hipLaunchKernelGGL(shuffle_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, key, nullptr, n,
+  hipLaunchKernelGGL(shuffle_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, key, nullptr, n, 32,
                      keys);
   return pqn_check_launch("pqn_shuffle_keys");
 }
 
+int pqn_index_bits(int n) {
+  int ib = 1;
+  while (ib < 31 && (1ll << ib) < (long long)n) ++ib;
+  return ib;
+}
+
 int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStream_t st) {
-  hipLaunchKernelGGL(shuffle_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, 0, key_dev, n, keys);
+  hipLaunchKernelGGL(shuffle_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, 0, key_dev, n, pqn_index_bits(n), keys);
   return pqn_check_launch("pqn_shuffle_keys");
 }
 
 __global__ __launch_bounds__(256) void shuffle_keys_seeds_kernel(const uint64_t *__restrict__ key_dev, int key_stride, int n,
-                                                                 int64_t *__restrict__ keys) {
+                                                                 int ib, int64_t *__restrict__ keys) {
   const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
   if (i >= n) return;
   uint32_t o0, o1;
   pqn_bits(key_dev[(size_t)s * key_stride], (uint32_t)i, 0u, o0, o1);   // the same draw as shuffle_keys_kernel
-  keys[(size_t)s * n + i] = (int64_t)(((uint64_t)s << 56) | ((uint64_t)(o0 >> 1) << 25) | (uint64_t)i);   // 7 | 31 | 25 bits
+  keys[(size_t)s * n + i] = (int64_t)(((uint64_t)s << (31 + ib)) | ((uint64_t)(o0 >> 1) << ib) | (uint64_t)i);   // 7 | 31 | ib bits
 }
 
 int pqn_shuffle_keys_seeds(const uint64_t *key_dev, int key_stride, int nseeds, int n, int64_t *keys, hipStream_t st) {
   PQN_REQUIRE(key_dev && keys && n > 0 && n <= (1 << 25) && nseeds >= 1 && nseeds <= 128,
               "pqn_shuffle_keys_seeds: bad arguments (n=%d, seeds=%d)", n, nseeds);
-  hipLaunchKernelGGL(shuffle_keys_seeds_kernel, dim3((n + 255) / 256, nseeds), dim3(256), 0, st, key_dev, key_stride, n, keys);
+  hipLaunchKernelGGL(shuffle_keys_seeds_kernel, dim3((n + 255) / 256, nseeds), dim3(256), 0, st, key_dev, key_stride, n,
+                     pqn_index_bits(n), keys);
   return pqn_check_launch("pqn_shuffle_keys_seeds");
 }
 
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void radam_norm_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                           float *__restrict__ m, float *__restrict__ v, int64_t n,
                                                           int32_t *__restrict__ count, float lr_init, float lr_end,
-                                                          float lr_steps, float max_norm, int nparts,
+                                                          double lr_steps, float max_norm, int nparts,
                                                           const float *__restrict__ scratch,
                                                           float *__restrict__ gnorm_out, int w1_off,
                                                           float *__restrict__ w1b, long long pstride, long long sstride,
@@ -221,10 +229,10 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
     const int rect = ro >= thr;
     const float r = rect ? (float)sqrt((ro - 4.0) * (ro - 2.0) * ro_inf / ((ro_inf - 4.0) * (ro_inf - 2.0) * ro)) : 0.0f;
     float lr = lr_init;
-    if (lr_steps > 0.0f) {  // optax.linear_schedule evaluated at the pre-increment count
+    if (lr_steps > 0.0) {  // optax.linear_schedule evaluated at the pre-increment count
       double cc = (double)c;
-      if (cc > (double)lr_steps) cc = (double)lr_steps;
-      lr = (float)(((double)lr_init - (double)lr_end) * (1.0 - cc / (double)lr_steps) + (double)lr_end);
+      if (cc > lr_steps) cc = lr_steps;
+      lr = (float)(((double)lr_init - (double)lr_end) * (1.0 - cc / lr_steps) + (double)lr_end);
     }
     s_sc[0] = gnorm;
     s_sc[1] = (gnorm < max_norm) ? 0.0f : 1.0f;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
 }
 
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
-                     float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
+                     float lr_end, double lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
                      float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds, long long pstride,
                      long long sstride, long long w1bstride, int half_off) {
   // nparts: number of sum-of-squares partials already in scratch when norm_pass == 0
@@ -315,7 +323,7 @@ int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, in
 }
 
 extern "C" int pqn_radam_clip_step(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count,
-                                   float lr_init, float lr_end, float lr_steps, float max_norm, float *scratch,
+                                   float lr_init, float lr_end, double lr_steps, float max_norm, float *scratch,
                                    float *gnorm_out, void *stream) {
   PQN_REQUIRE(p && g && m && v && count && scratch, "pqn_radam_clip_step: NULL argument");
   PQN_REQUIRE(n > 0, "pqn_radam_clip_step: n must be > 0");

@@ -108,16 +108,19 @@ inline pqn_seeds_t pqn_one_seed() {
 }
 
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
-                     float lr_end, float lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
+                     float lr_end, double lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
                      float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds = 1, long long pstride = 0,
                      long long sstride = 0, long long w1bstride = 0, int half_off = 0);
 
 // internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
                      const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0, int key_stride = 0);
+// shuffle keys of the whole-update driver: keys[i] = rand31(i; *key_dev) << ib | i with ib = pqn_index_bits(n) --
+// the same order as the public pqn_shuffle_keys (rand31 << 32 | i), packed so the sort visits 31 + ib bits only
+int pqn_index_bits(int n);
 int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStream_t st);
-// seed-batched variant: keys[s*n + i] = (s << 56) | (rand31(i; key_dev[s*key_stride]) << 25) | i  (n <= 2^25, S <= 128):
-// one global radix sort orders every seed's segment exactly as the single-seed keys (rand31 << 32 | i) would
+// seed-batched variant: keys[s*n + i] = (s << (31+ib)) | (rand31(i; key_dev[s*key_stride]) << ib) | i  (n <= 2^25,
+// S <= 128): one global radix sort orders every seed's segment exactly as its single-seed keys would be
 int pqn_shuffle_keys_seeds(const uint64_t *key_dev, int key_stride, int nseeds, int n, int64_t *keys, hipStream_t st);
 int pqn_cnn_grad_reduce_blocks(int total);   // number of sum-of-squares partials pqn_qnet_cnn_grad leaves in the scratch
 int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
@@ -128,7 +131,7 @@ int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t &L, int nb, const int64_t *id
 // the workspace is its ticket counter and must be zero before the first launch of an update
 int pqn_qnet_cnn_reduce_apply_seeds(const pqn_cnn_layout_t &L, int nb, float *theta, float *w1b, float *m, float *v,
                                     int32_t *count, float *workspace, float *loss_out, float *qv_out, float lr_init,
-                                    float lr_end, float lr_steps, float max_norm, const pqn_seeds_t &sd, hipStream_t st);
+                                    float lr_end, double lr_steps, float max_norm, const pqn_seeds_t &sd, hipStream_t st);
 int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *obs_bits, const float *theta, float *q,
                              int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
                              const uint64_t *key_dev, hipStream_t st);

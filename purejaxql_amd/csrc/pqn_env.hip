@@ -23,8 +23,8 @@
 // ===========================================================================
 template <class Env, int EPB, bool IS_RESET>
 __global__ __launch_bounds__(256) void minatar_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev,
-                                                      float rscale, const uint32_t *__restrict__ state_in,
-                                                      uint32_t *__restrict__ state_out,
+                                                      float rscale, const uint32_t *state_in,
+                                                      uint32_t *state_out,   // may alias (in-place step)
                                                       const int32_t *__restrict__ action, pqn_step_out_t out) {
   __shared__ __attribute__((aligned(16))) uint32_t s_bits[EPB * Env::OBS_WORDS];
   if (key_dev) key = *key_dev;  // graph-replayable launches read the step key from device memory
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void minatar_kernel(int n, uint64_t key, const
 // ===========================================================================
 template <class Env, bool IS_RESET>
 __global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev,
-                                                   float rscale, const uint32_t *__restrict__ state_in,
-                                                   uint32_t *__restrict__ state_out,
+                                                   float rscale, const uint32_t *state_in,
+                                                   uint32_t *state_out,   // may alias (in-place step)
                                                    const int32_t *__restrict__ action, pqn_step_out_t out,
                                                    int n_per_seed, int key_stride) {
   const int e = blockIdx.x * 256 + threadIdx.x;

@@ -552,7 +552,7 @@ int pqn_mlp_refresh_transposed_seeds(const pqn_mlp_layout_t &L, const float *the
 }
 
 extern "C" int pqn_mlp_apply(const pqn_mlp_layout_t *L, float *theta, float *wt, const float *grad, float *m, float *v,
-                             int32_t *count, float lr_init, float lr_end, float lr_steps, float max_norm, float *workspace,
+                             int32_t *count, float lr_init, float lr_end, double lr_steps, float max_norm, float *workspace,
                              float *gnorm_out, int32_t recompute_norm, void *stream) {
   PQN_REQUIRE(L && theta && grad && m && v && count && workspace, "pqn_mlp_apply: NULL argument");
   const int rc = pqn_launch_radam(theta, grad, m, v, L->total, count, lr_init, lr_end, lr_steps, max_norm, workspace,

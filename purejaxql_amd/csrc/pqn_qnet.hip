@@ -1707,7 +1707,7 @@ int pqn_cnn_grad_reduce_blocks(int total) { return grad_reduce_blocks(total); }
 __global__ __launch_bounds__(512) void qnet_reduce_apply_kernel(
     pqn_cnn_layout_t L, int ntiles, int nks, int rec, const float *__restrict__ gpart, const float *__restrict__ wpart,
     float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ count, float *scratch,
-    float *__restrict__ loss_out, float *__restrict__ qv_out, float inv_b, float lr_init, float lr_end, float lr_steps,
+    float *__restrict__ loss_out, float *__restrict__ qv_out, float inv_b, float lr_init, float lr_end, double lr_steps,
     float max_norm, float *__restrict__ w1b, pqn_seeds_t sd) {
   __shared__ float s_part[8];
   __shared__ float s_np[QRA_G];
@@ -1797,10 +1797,10 @@ __global__ __launch_bounds__(512) void qnet_reduce_apply_kernel(
     const int rect = ro >= thr;
     const float r = rect ? (float)sqrt((ro - 4.0) * (ro - 2.0) * ro_inf / ((ro_inf - 4.0) * (ro_inf - 2.0) * ro)) : 0.0f;
     float lr = lr_init;
-    if (lr_steps > 0.0f) {  // optax.linear_schedule evaluated at the pre-increment count
+    if (lr_steps > 0.0) {  // optax.linear_schedule evaluated at the pre-increment count
       double cc = (double)c;
-      if (cc > (double)lr_steps) cc = (double)lr_steps;
-      lr = (float)(((double)lr_init - (double)lr_end) * (1.0 - cc / (double)lr_steps) + (double)lr_end);
+      if (cc > lr_steps) cc = lr_steps;
+      lr = (float)(((double)lr_init - (double)lr_end) * (1.0 - cc / lr_steps) + (double)lr_end);
     }
     s_sc[0] = gnorm;
     s_sc[1] = (gnorm < max_norm) ? 0.0f : 1.0f;
@@ -1866,7 +1866,7 @@ __global__ __launch_bounds__(512) void qnet_reduce_apply_kernel(
 
 int pqn_qnet_cnn_reduce_apply_seeds(const pqn_cnn_layout_t &L, int nb, float *theta, float *w1b, float *m, float *v,
                                     int32_t *count, float *workspace, float *loss_out, float *qv_out, float lr_init,
-                                    float lr_end, float lr_steps, float max_norm, const pqn_seeds_t &sd, hipStream_t st) {
+                                    float lr_end, double lr_steps, float max_norm, const pqn_seeds_t &sd, hipStream_t st) {
   const int ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB, rec = small_record_floats(L.c, L.a);
   PQN_REQUIRE(L.total - QN_H1 * QN_HID <= QRA_G * 4 * QRA_NKQ, "pqn_qnet_cnn_reduce_apply: %d small parameters exceed the kernel's plan",
               L.total - QN_H1 * QN_HID);
@@ -1883,7 +1883,7 @@ int pqn_qnet_cnn_reduce_apply_seeds(const pqn_cnn_layout_t &L, int nb, float *th
 
 
 extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float *w1b, const float *grad, float *m,
-                                  float *v, int32_t *count, float lr_init, float lr_end, float lr_steps,
+                                  float *v, int32_t *count, float lr_init, float lr_end, double lr_steps,
                                   float max_norm, float *workspace, float *gnorm_out, int32_t recompute_norm,
                                   void *stream) {
   PQN_REQUIRE(L && theta && w1b && grad && m && v && count && workspace, "pqn_qnet_cnn_apply: NULL argument");

@@ -8,7 +8,7 @@
 // Key schedule (identical to purejaxql_amd/pqn.py and the oracle):
 //   step key  (u,t)  = fold_in(key_roll, u*T + t)      epoch key (u,ep) = fold_in(key_shuf, u*EPOCHS + ep)
 //   eps(u) = optax.linear_schedule(eps_start, eps_finish, eps_decay_steps)(u)   (pqn_minatar.py:134-138,195)
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "pqn_common.h"
 
@@ -21,7 +21,7 @@ static_assert(M_COUNT == PQN_NUM_METRICS, "metrics row layout");
 // block 0 also latches the update index into clock[1] for the tick kernel and writes eps
 __global__ void update_sched_kernel(int32_t *__restrict__ clock, uint64_t key_roll, uint64_t key_shuf,
                                     const uint64_t *__restrict__ key_roll_dev, const uint64_t *__restrict__ key_shuf_dev,
-                                    int t_len, int epochs, float eps_start, float eps_finish, float eps_decay_steps,
+                                    int t_len, int epochs, float eps_start, float eps_finish, double eps_decay_steps,
                                     uint64_t *__restrict__ keys, float *__restrict__ eps, float *__restrict__ workspace,
                                     long long ws_stride) {
   const int u = clock[0];
@@ -37,11 +37,11 @@ __global__ void update_sched_kernel(int32_t *__restrict__ clock, uint64_t key_ro
   if (i < t_len) keys[i] = pqn_fold(key_roll, (uint32_t)(u * t_len + i));
   else if (i < t_len + epochs) keys[i] = pqn_fold(key_shuf, (uint32_t)(u * epochs + (i - t_len)));
   if (blockIdx.x == 0 && i == 0) {
-    double e = eps_finish;
-    if (eps_decay_steps > 0.0f) {
+    double e = eps_start;   // optax.linear_schedule with transition_steps <= 0: a constant schedule at init_value
+    if (eps_decay_steps > 0.0) {
       double c = (double)u;
-      if (c > (double)eps_decay_steps) c = (double)eps_decay_steps;
-      e = ((double)eps_start - (double)eps_finish) * (1.0 - c / (double)eps_decay_steps) + (double)eps_finish;
+      if (c > eps_decay_steps) c = eps_decay_steps;
+      e = ((double)eps_start - (double)eps_finish) * (1.0 - c / eps_decay_steps) + (double)eps_finish;
     }
     *eps = (float)e;
   }
@@ -118,13 +118,34 @@ __global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n
   if (blockIdx.x == 0 && threadIdx.x == 0) clock[0] = u + 1;
 }
 
+// The epoch shuffle's sort: rocPRIM's device radix sort called directly (ROCm-native API, no CUB-compatibility
+// layer), restricted to the significant key bits: 31 random bits + the index bits (+ 7 seed bits when seeds are
+// batched) instead of all 64.  Keys are unique, so the result does not depend on the sort's stability.
 extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
   size_t bytes = 0;
   if (n <= 0) return -1;
-  if (hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long *)nullptr,
-                                        (unsigned long long *)nullptr, n, 0, 63, nullptr) != hipSuccess)
+  if (rocprim::radix_sort_keys(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                               (unsigned int)n, 0u, 64u, (hipStream_t) nullptr) != hipSuccess)
     return -1;
   return (int64_t)bytes;
+}
+
+// n = keys of ALL seeds, n_per_seed = T*N of one seed
+static int pqn_sort_keys(void *temp, size_t temp_bytes, const int64_t *in, int64_t *out, int n, int nseeds, int n_per_seed,
+                         hipStream_t st) {
+  const unsigned end_bit = (unsigned)(31 + pqn_index_bits(n_per_seed) + (nseeds > 1 ? 7 : 0));
+  size_t need = 0;
+  if (rocprim::radix_sort_keys(nullptr, need, (const unsigned long long *)in, (unsigned long long *)out, (unsigned int)n, 0u,
+                               end_bit, st) != hipSuccess || need > temp_bytes) {
+    pqn_set_error("radix sort: %llu temp bytes provided, %llu needed", (unsigned long long)temp_bytes, (unsigned long long)need);
+    return PQN_E_INVALID;
+  }
+  if (rocprim::radix_sort_keys(temp, need, (const unsigned long long *)in, (unsigned long long *)out, (unsigned int)n, 0u, end_bit,
+                               st) != hipSuccess) {
+    pqn_set_error("radix sort failed (temp bytes %llu)", (unsigned long long)temp_bytes);
+    return PQN_E_HIP;
+  }
+  return PQN_OK;
 }
 
 #define UPD_CHECK(call)          \
@@ -136,108 +157,167 @@ extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
 // S seeds per launch (S = 1: the single-seed entry point).  With S > 1 every buffer in `a` is the stacked
 // allocation of all seeds: env-indexed arrays are [..][S*N] (seed s owns envs s*N .. s*N+N-1), parameter-like
 // buffers are [S][stride]; key_roll_dev / key_shuf_dev hold the per-seed keys.
-static int cnn_update_impl(const pqn_update_args_t *a, int S, const uint64_t *key_roll_dev, const uint64_t *key_shuf_dev,
-                           long long theta_stride, long long ws_stride, hipStream_t st) {
+//
+// The update is enqueued in PHASES (pqn_cnn_update = all of them in order; pqn_cnn_update_phase = one at a time, so
+// that a caller can put a collective between the gradient and the optimizer step of every minibatch -- the envs of
+// one seed sharded over ranks):
+//   BEGIN    clock -> step keys / eps; the rollout scan + bootstrap forward; Q(lambda) targets
+//   SHUFFLE  (ep)    epoch permutation (threefry sort keys + radix sort)
+//   GRAD     (i_mb)  forward + backward of minibatch i_mb -> flat gradient a->grad (+ its sum-of-squares partials)
+//   APPLY    (i_mb)  clip_by_global_norm + RAdam from a->grad (norm recomputed when the caller changed the gradient)
+//   END      carry last_obs, metrics row, clock tick
+struct UpdCtx {
+  int N, T, MB, EP, B, S, SN, TN, OW;
+  pqn_seeds_t sd;
+  bool fused_opt;
+};
+
+static int upd_ctx(const pqn_update_args_t *a, int S, const uint64_t *key_roll_dev, const uint64_t *key_shuf_dev,
+                   long long theta_stride, long long ws_stride, UpdCtx &c) {
   PQN_REQUIRE(a, "pqn_cnn_update: args is NULL");
   PQN_REQUIRE(a->clock && a->sched_keys && a->sched_eps && a->state && a->bits && a->action && a->reward && a->done &&
                   a->qmax && a->discount && a->rer && a->rel && a->ts && a->target && a->last_q && a->sort_keys_in &&
                   a->sort_keys_out && a->sort_temp && a->theta && a->w1b && a->grad && a->m && a->v && a->count &&
                   a->workspace && a->loss_buf && a->qv_buf && a->metrics,
               "pqn_cnn_update: NULL buffer in args");
-  const int N = a->num_envs, T = a->num_steps, MB = a->num_minibatches, EP = a->num_epochs;
-  PQN_REQUIRE(N > 0 && T > 0 && MB > 0 && EP > 0 && T + EP <= 1024, "pqn_cnn_update: bad shape N=%d T=%d MB=%d EP=%d", N, T,
-              MB, EP);
-  PQN_REQUIRE(((int64_t)N * T) % MB == 0, "NUM_MINIBATCHES must divide NUM_STEPS*NUM_ENVS");
-  const int B = (int)(((int64_t)N * T) / MB);
-  PQN_REQUIRE(B % 16 == 0, "pqn_cnn_update: minibatch size %d must be a multiple of 16", B);
-  PQN_REQUIRE(S >= 1 && S <= 128 && (S == 1 || (key_roll_dev && key_shuf_dev && N % 16 == 0 && (int64_t)N * T <= (1 << 25))),
+  c.N = a->num_envs; c.T = a->num_steps; c.MB = a->num_minibatches; c.EP = a->num_epochs;
+  PQN_REQUIRE(c.N > 0 && c.T > 0 && c.MB > 0 && c.EP > 0 && c.T + c.EP <= 1024, "pqn_cnn_update: bad shape N=%d T=%d MB=%d EP=%d",
+              c.N, c.T, c.MB, c.EP);
+  PQN_REQUIRE(((int64_t)c.N * c.T) % c.MB == 0, "NUM_MINIBATCHES must divide NUM_STEPS*NUM_ENVS");
+  c.B = (int)(((int64_t)c.N * c.T) / c.MB);
+  PQN_REQUIRE(c.B % 16 == 0, "pqn_cnn_update: minibatch size %d must be a multiple of 16", c.B);
+  PQN_REQUIRE(S >= 1 && S <= 128 && (S == 1 || (key_roll_dev && key_shuf_dev && c.N % 16 == 0 && (int64_t)c.N * c.T <= (1 << 25))),
               "pqn_cnn_update: seed batching needs 1 <= seeds <= 128, device key arrays, NUM_ENVS %% 16 == 0, T*N <= 2^25");
-  const pqn_cnn_layout_t &L = a->layout;
-  const int OW = a->obs_words;
-  const int SN = S * N, TN = T * N;
-  const size_t bits_stride = (size_t)SN * OW;
-  pqn_seeds_t sd = pqn_one_seed();
+  c.S = S;
+  c.OW = a->obs_words;
+  c.SN = S * c.N;
+  c.TN = c.T * c.N;
+  c.sd = pqn_one_seed();
   if (S > 1) {
-    sd.nseeds = S;
-    sd.n_env = N;
-    sd.n_env_total = SN;
-    sd.idx_stride = TN;
-    sd.theta_stride = theta_stride;
-    sd.w1b_stride = 1024 * 128;
-    sd.ws_stride = ws_stride;
-    sd.lq_stride = (long long)MB * EP;
-    sd.idx_mask = (1ll << 25) - 1;
+    c.sd.nseeds = S;
+    c.sd.n_env = c.N;
+    c.sd.n_env_total = c.SN;
+    c.sd.idx_stride = c.TN;
+    c.sd.theta_stride = theta_stride;
+    c.sd.w1b_stride = 1024 * 128;
+    c.sd.ws_stride = ws_stride;
+    c.sd.lq_stride = (long long)c.MB * c.EP;
   }
-
+  c.sd.idx_mask = (1ll << pqn_index_bits(c.TN)) - 1;   // low bits of a sorted shuffle key = the transition index
   // reserved bit 0 (experimental, off by default): fold + clip + RAdam as ONE kernel with a grid-wide barrier
   // instead of two kernels.  Measured slower in round 1 (5.47 vs 4.92 ms per update at the bench shape: the
   // barrier costs more than the launch it saves) and unsafe when several updates are in flight on different
   // streams (two partially resident barrier grids could dead-lock), so the two-kernel version is the default.
-  const bool fused_opt = (a->reserved & 1) != 0;
-  hipLaunchKernelGGL(update_sched_kernel, dim3(S), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, key_roll_dev,
-                     key_shuf_dev, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps,
-                     a->workspace, sd.ws_stride);
+  c.fused_opt = (a->reserved & 1) != 0;
+  return PQN_OK;
+}
+
+static int upd_begin(const pqn_update_args_t *a, const UpdCtx &c, const uint64_t *key_roll_dev, const uint64_t *key_shuf_dev,
+                     hipStream_t st) {
+  const pqn_cnn_layout_t &L = a->layout;
+  hipLaunchKernelGGL(update_sched_kernel, dim3(c.S), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, key_roll_dev,
+                     key_shuf_dev, c.T, c.EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps,
+                     a->workspace, c.sd.ws_stride);
   // SAMPLE PHASE (_step_env scan, :181-220) + bootstrap forward (:227-235): one persistent launch over all S*N envs
-  {
-    pqn_step_out_t rec = {};
-    rec.reward = a->reward;
-    rec.done = a->done;
-    rec.discount = a->discount;
-    rec.returned_episode_returns = a->rer;
-    rec.returned_episode_lengths = a->rel;
-    rec.timestep = a->ts;
-    UPD_CHECK(pqn_qnet_cnn_rollout(a->env_id, L, SN, T, a->state, a->bits, a->theta, rec, a->action, a->qmax, a->last_q,
-                                   a->sched_eps, a->sched_keys, a->rew_scale, 1, st, S > 1 ? N : 0, sd.theta_stride, T + EP));
-  }
+  pqn_step_out_t rec = {};
+  rec.reward = a->reward;
+  rec.done = a->done;
+  rec.discount = a->discount;
+  rec.returned_episode_returns = a->rer;
+  rec.returned_episode_lengths = a->rel;
+  rec.timestep = a->ts;
+  UPD_CHECK(pqn_qnet_cnn_rollout(a->env_id, L, c.SN, c.T, a->state, a->bits, a->theta, rec, a->action, a->qmax, a->last_q,
+                                 a->sched_eps, a->sched_keys, a->rew_scale, 1, st, c.S > 1 ? c.N : 0, c.sd.theta_stride,
+                                 c.T + c.EP));
   // Q(lambda) TARGETS (:237-260): lane per env over the stacked [T][S*N] record
-  UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, SN, 1, a->target, st));
-  // NETWORKS UPDATE (:263-327)
-  int i_mb = 0;
-  for (int ep = 0; ep < EP; ++ep) {
-    size_t tb = (size_t)a->sort_temp_bytes;
-    if (S == 1) {
-      UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, TN, a->sort_keys_in, st));
-    } else {   // one global sort: the seed id in the top bits keeps every seed's segment in place
-      UPD_CHECK(pqn_shuffle_keys_seeds(a->sched_keys + T + ep, T + EP, S, TN, a->sort_keys_in, st));
-    }
-    if (hipcub::DeviceRadixSort::SortKeys(a->sort_temp, tb, (const unsigned long long *)a->sort_keys_in,
-                                          (unsigned long long *)a->sort_keys_out, S * TN, 0, 63, st) != hipSuccess) {
-      pqn_set_error("pqn_cnn_update: radix sort failed (temp bytes %llu)", (unsigned long long)a->sort_temp_bytes);
-      return PQN_E_HIP;
-    }
-    for (int mb = 0; mb < MB; ++mb, ++i_mb) {
-      // low bits of a sorted shuffle key = the transition index inside the seed (kernels mask with sd.idx_mask)
-      UPD_CHECK(pqn_qnet_cnn_grad_seeds(L, B, a->sort_keys_out + (size_t)mb * B, a->bits, a->action, a->target, a->theta,
-                                        a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, sd, st,
-                                        !fused_opt));
-      if (fused_opt) {   // fold + clip + RAdam in one launch (grid barrier); the flat gradient is never materialised
-        UPD_CHECK(pqn_qnet_cnn_reduce_apply_seeds(L, B, a->theta, a->w1b, a->m, a->v, a->count, a->workspace,
-                                                  a->loss_buf + i_mb, a->qv_buf + i_mb, a->lr_init, a->lr_end, a->lr_steps,
-                                                  a->max_grad_norm, sd, st));
-      } else {
-        UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
-                                   a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, 0,
-                                   pqn_cnn_grad_reduce_blocks(L.total), st, S, sd.theta_stride, sd.ws_stride, sd.w1b_stride,
-                                   L.matmul_f16 ? L.off_w1h : 0));
-      }
-    }
+  return pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, c.T, c.SN, 1, a->target, st);
+}
+
+// one shared permutation per epoch (:299-315), consumed as a gather index
+static int upd_shuffle(const pqn_update_args_t *a, const UpdCtx &c, int ep, hipStream_t st) {
+  size_t tb = (size_t)a->sort_temp_bytes;
+  if (c.S == 1) {
+    UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + c.T + ep, c.TN, a->sort_keys_in, st));
+  } else {   // one global sort: the seed id in the top bits keeps every seed's segment in place
+    UPD_CHECK(pqn_shuffle_keys_seeds(a->sched_keys + c.T + ep, c.T + c.EP, c.S, c.TN, a->sort_keys_in, st));
   }
-  // carry last_obs into the next update; metrics (:329-338); advance the clock
-  if (hipMemcpyAsync(a->bits, a->bits + (size_t)T * bits_stride, bits_stride * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+  return pqn_sort_keys(a->sort_temp, tb, a->sort_keys_in, a->sort_keys_out, c.S * c.TN, c.S, c.TN, st);
+}
+
+static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool with_reduce, hipStream_t st) {
+  const int mb = i_mb % c.MB;
+  // low bits of a sorted shuffle key = the transition index inside the seed (kernels mask with sd.idx_mask)
+  return pqn_qnet_cnn_grad_seeds(a->layout, c.B, a->sort_keys_out + (size_t)mb * c.B, a->bits, a->action, a->target, a->theta,
+                                 a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, c.sd, st,
+                                 with_reduce);
+}
+
+static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool norm_pass, hipStream_t st) {
+  const pqn_cnn_layout_t &L = a->layout;
+  if (c.fused_opt && !norm_pass)   // fold + clip + RAdam in one launch (grid barrier); the flat gradient is never materialised
+    return pqn_qnet_cnn_reduce_apply_seeds(L, c.B, a->theta, a->w1b, a->m, a->v, a->count, a->workspace, a->loss_buf + i_mb,
+                                           a->qv_buf + i_mb, a->lr_init, a->lr_end, a->lr_steps, a->max_grad_norm, c.sd, st);
+  return pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
+                          a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, norm_pass ? 1 : 0,
+                          pqn_cnn_grad_reduce_blocks(L.total), st, c.S, c.sd.theta_stride, c.sd.ws_stride, c.sd.w1b_stride,
+                          L.matmul_f16 ? L.off_w1h : 0);
+}
+
+// carry last_obs into the next update; metrics (:329-338); advance the clock
+static int upd_end(const pqn_update_args_t *a, const UpdCtx &c, hipStream_t st) {
+  const size_t bits_stride = (size_t)c.SN * c.OW;
+  if (hipMemcpyAsync(a->bits, a->bits + (size_t)c.T * bits_stride, bits_stride * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                      st) != hipSuccess) {
     pqn_set_error("pqn_cnn_update: hipMemcpyAsync failed");
     return PQN_E_HIP;
   }
   double *partial = reinterpret_cast<double *>(a->workspace);  // first 1024 floats: optimizer scratch, idle here
-  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS, S), dim3(256), 0, st, TN, N, SN, a->discount, a->rer, a->rel,
-                     a->ts, a->done, partial, sd.ws_stride / 2);
-  hipLaunchKernelGGL(update_tick_kernel, dim3(S), dim3(64), 0, st, a->clock, T, N, L.c, MB * EP, a->loss_buf, a->qv_buf,
-                     partial, a->metrics, a->metrics_capacity, sd.ws_stride / 2);
+  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS, c.S), dim3(256), 0, st, c.TN, c.N, c.SN, a->discount, a->rer,
+                     a->rel, a->ts, a->done, partial, c.sd.ws_stride / 2);
+  hipLaunchKernelGGL(update_tick_kernel, dim3(c.S), dim3(64), 0, st, a->clock, c.T, c.N, a->layout.c, c.MB * c.EP, a->loss_buf,
+                     a->qv_buf, partial, a->metrics, a->metrics_capacity, c.sd.ws_stride / 2);
   return pqn_check_launch("pqn_cnn_update");
+}
+
+static int cnn_update_impl(const pqn_update_args_t *a, int S, const uint64_t *key_roll_dev, const uint64_t *key_shuf_dev,
+                           long long theta_stride, long long ws_stride, hipStream_t st) {
+  UpdCtx c;
+  UPD_CHECK(upd_ctx(a, S, key_roll_dev, key_shuf_dev, theta_stride, ws_stride, c));
+  UPD_CHECK(upd_begin(a, c, key_roll_dev, key_shuf_dev, st));
+  // NETWORKS UPDATE (:263-327)
+  int i_mb = 0;
+  for (int ep = 0; ep < c.EP; ++ep) {
+    UPD_CHECK(upd_shuffle(a, c, ep, st));
+    for (int mb = 0; mb < c.MB; ++mb, ++i_mb) {
+      UPD_CHECK(upd_grad(a, c, i_mb, !c.fused_opt, st));
+      UPD_CHECK(upd_apply(a, c, i_mb, false, st));
+    }
+  }
+  return upd_end(a, c, st);
 }
 
 extern "C" int pqn_cnn_update(const pqn_update_args_t *a, void *stream) {
   return cnn_update_impl(a, 1, nullptr, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int pqn_cnn_update_phase(const pqn_update_args_t *a, int32_t phase, int32_t index, void *stream) {
+  UpdCtx c;
+  UPD_CHECK(upd_ctx(a, 1, nullptr, nullptr, 0, 0, c));
+  hipStream_t st = (hipStream_t)stream;
+  switch (phase) {
+    case PQN_PHASE_BEGIN: return upd_begin(a, c, nullptr, nullptr, st);
+    case PQN_PHASE_SHUFFLE:
+      PQN_REQUIRE(index >= 0 && index < c.EP, "pqn_cnn_update_phase: epoch %d out of range [0,%d)", index, c.EP);
+      return upd_shuffle(a, c, index, st);
+    case PQN_PHASE_GRAD:
+      PQN_REQUIRE(index >= 0 && index < c.MB * c.EP, "pqn_cnn_update_phase: minibatch step %d out of range [0,%d)", index, c.MB * c.EP);
+      return upd_grad(a, c, index, true, st);
+    case PQN_PHASE_APPLY:
+      PQN_REQUIRE(index >= 0 && index < c.MB * c.EP, "pqn_cnn_update_phase: minibatch step %d out of range [0,%d)", index, c.MB * c.EP);
+      return upd_apply(a, c, index, true, st);   // the caller may have all-reduced a->grad: recompute its norm
+    case PQN_PHASE_END: return upd_end(a, c, st);
+    default: pqn_set_error("pqn_cnn_update_phase: unknown phase %d", phase); return PQN_E_INVALID;
+  }
 }
 
 extern "C" int pqn_cnn_update_seeds(const pqn_update_args_t *a, int32_t num_seeds, const uint64_t *key_roll_dev,
@@ -280,8 +360,8 @@ static int mlp_update_impl(const pqn_mlp_update_args_t *a, int S, const uint64_t
     sd.theta_stride = theta_stride;
     sd.ws_stride = ws_stride;
     sd.lq_stride = (long long)MB * EP;
-    sd.idx_mask = (1ll << 25) - 1;
   }
+  sd.idx_mask = (1ll << pqn_index_bits(TN)) - 1;
   const int nps = S > 1 ? N : 0;   // envs per seed for the seed-aware kernels (0 = single seed)
 
   hipLaunchKernelGGL(update_sched_kernel, dim3(S), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, key_roll_dev,
@@ -314,12 +394,7 @@ static int mlp_update_impl(const pqn_mlp_update_args_t *a, int S, const uint64_t
     } else {
       UPD_CHECK(pqn_shuffle_keys_seeds(a->sched_keys + T + ep, T + EP, S, TN, a->sort_keys_in, st));
     }
-    size_t tb = (size_t)a->sort_temp_bytes;
-    if (hipcub::DeviceRadixSort::SortKeys(a->sort_temp, tb, (const unsigned long long *)a->sort_keys_in,
-                                          (unsigned long long *)a->sort_keys_out, S * TN, 0, 63, st) != hipSuccess) {
-      pqn_set_error("pqn_mlp_update: radix sort failed (temp bytes %llu)", (unsigned long long)a->sort_temp_bytes);
-      return PQN_E_HIP;
-    }
+    UPD_CHECK(pqn_sort_keys(a->sort_temp, (size_t)a->sort_temp_bytes, a->sort_keys_in, a->sort_keys_out, S * TN, S, TN, st));
     for (int mb = 0; mb < MB; ++mb, ++i_mb) {
       UPD_CHECK(pqn_mlp_grad_seeds(L, B, a->sort_keys_out + (size_t)mb * B, a->obs, a->action, a->target, a->theta, a->wt,
                                    a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, sd, wt_stride, st));

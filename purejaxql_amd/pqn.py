@@ -36,8 +36,8 @@ def linear_schedule(init_value: float, end_value: float, transition_steps: float
     """optax.linear_schedule, used for eps at pqn_minatar.py:134-138."""
 
     def f(count: float) -> float:
-        if transition_steps <= 0:
-            return end_value
+        if transition_steps <= 0:      # optax.polynomial_schedule: a constant schedule at init_value
+            return init_value
         c = min(max(float(count), 0.0), float(transition_steps))
         return (init_value - end_value) * (1.0 - c / float(transition_steps)) + end_value
 
@@ -209,9 +209,12 @@ def _mlp_fits_fused(obs_dim: int, hidden: int, layers: int) -> bool:
     return floats * 4 <= 160 * 1024
 
 
-def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: Optional[Callable] = None):
+def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: Optional[Callable] = None,
+               metrics_hook: Optional[Callable] = None):
     """Returns train(key).  `grad_hook(flat_grad)` (optional) runs between backward
-    and the optimizer step -- the RCCL all-reduce of env-sharded mode plugs in here."""
+    and the optimizer step -- the RCCL all-reduce of env-sharded mode plugs in here.
+    `metrics_hook(values)` (optional; dist.allreduce_mean_scalars) turns the per-rank metric means of an update
+    into means over all env shards (pqn_minatar.py:330-338 take them over ALL envs)."""
     lib = _lib.load()
     derive_config(config)
     dev = torch.device(device or "cuda")
@@ -250,6 +253,11 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             backend = "fused" if (plain_ln and _mlp_fits_fused(obs_shape[0], int(config.get("HIDDEN_SIZE", 128)),
                                                                int(config.get("NUM_LAYERS", 2)))) else "torch"
     packed = backend == "fused" and kind == "cnn"
+    # shape limits of the whole-update C++ enqueue (pqn_cnn_update / pqn_mlp_update: the schedule kernel derives the
+    # T + EPOCHS keys of an update with one 1024-thread block) and of seed batching (25 index bits in the shuffle
+    # keys); configs outside them run the per-kernel Python loop / per-seed streams instead of failing at run time
+    driver_shape_ok = T + EPOCHS <= 1024
+    seeds_shape_ok = driver_shape_ok and N % 16 == 0 and T * N <= (1 << 25)
 
     def env_step_into(key, words, action, obs_out, bits_out, r, d, disc, rer, rel, ts):
         out = _lib.StepOut(obs=_lib.ptr(obs_out), obs_bits=_lib.ptr(bits_out), reward=_lib.ptr(r), done=_lib.ptr(d),
@@ -382,19 +390,39 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
 
         # whole-update C++ enqueue (+ hipGraph replay): the fused CNN / MLP paths without a gradient hook
         driver = None
-        if backend == "fused" and grad_hook is None and config.get("_DRIVER", True):
+        if backend == "fused" and grad_hook is None and config.get("_DRIVER", True) and driver_shape_ok:
             from .qnet import UpdateDriver
             dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
                     "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}
             driver = UpdateDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
                                   policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
                                   fused_opt=config.get("_FUSED_OPT", False))
+        elif packed and grad_hook is not None and config.get("_DRIVER", True) and driver_shape_ok:
+            # envs of one seed sharded over ranks: the same C++ enqueue, split at the gradient / optimizer boundary
+            from .qnet import EnvShardDriver
+            dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
+                    "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}
+            driver = EnvShardDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
+                                    policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
+                                    grad_hook=grad_hook)
         test_rows = torch.zeros((NUM_UPDATES, len(INFO_KEYS)), dtype=torch.float32, device=dev) if test_on else None
+        shard_world = int(shard[1]) if shard is not None else 1
+
+        def share_metrics_row(row):
+            """Env-sharded mode: the means of an update are over ALL env shards, the step counts over all envs."""
+            from .qnet import METRIC_NAMES
+            i0 = METRIC_NAMES.index("td_loss")
+            if metrics_hook is not None:
+                row[i0:] = metrics_hook(row[i0:].clone())
+            for name in ("env_step", "env_frame"):
+                row[METRIC_NAMES.index(name)] *= shard_world
 
         def driver_update(u: int):
             if u != driver.calls:
                 raise RuntimeError(f"update({u}) out of order: the device clock is at {driver.calls}")
             driver.update()
+            if shard_world > 1 or metrics_hook is not None:
+                share_metrics_row(driver.metrics[u])
             counters["timesteps"] += T * N
             counters["n_updates"] += 1
             counters["grad_steps"] += MB * EPOCHS
@@ -458,6 +486,15 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             if kind == "cnn":
                 m["env_frame"] = counters["timesteps"] * obs_shape[-1]
             m.update(info_means)
+            if metrics_hook is not None or shard_world > 1:   # env-sharded mode: means over all shards, counts over all envs
+                mean_keys = ["td_loss", "qvals"] + list(INFO_KEYS)
+                vals = torch.stack([torch.as_tensor(m[k], dtype=torch.float32, device=dev) for k in mean_keys])
+                if metrics_hook is not None:
+                    vals = metrics_hook(vals)
+                m.update({k: vals[i] for i, k in enumerate(mean_keys)})
+                for k in ("env_step", "env_frame"):
+                    if k in m:
+                        m[k] = m[k] * shard_world
             if test_on:
                 if test_period > 0 and counters["n_updates"] % test_period == 0:
                     tm_box[0] = get_test_metrics()
@@ -495,7 +532,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         Returns (update, finish); finish() -> list of per-seed result dicts."""
         from .qnet import METRIC_NAMES, CnnKernelLayout, MlpKernelLayout, SeedsUpdateDriver, mlp_forward
         S = len(rngs)
-        if not (backend == "fused" and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25) and 1 <= S <= 128):
+        if not (backend == "fused" and grad_hook is None and seeds_shape_ok and 1 <= S <= 128):
             raise RuntimeError("seed batching needs a fused path, no gradient hook, NUM_ENVS % 16 == 0, <= 128 seeds")
         if packed:
             layout = CnnKernelLayout(obs_shape[-1], A,
@@ -632,7 +669,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
 
     train.make_runner = make_runner
     train.make_batch_runner = make_batch_runner
-    train.can_batch_seeds = bool(backend == "fused" and grad_hook is None and N % 16 == 0 and T * N <= (1 << 25)
+    train.can_batch_seeds = bool(backend == "fused" and grad_hook is None and seeds_shape_ok
                                  and config.get("_DRIVER", True) and config.get("_CALLBACK") is None)
     train.config = config
     train.backend = backend

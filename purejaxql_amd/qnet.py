@@ -165,8 +165,9 @@ class UpdateArgs(C.Structure):
     """pqn_update_args_t (include/pqn_hotpath.h)"""
     _fields_ = ([(n, C.c_int32) for n in ("env_id", "num_envs", "num_steps", "num_minibatches", "num_epochs",
                                            "obs_words", "metrics_capacity", "reserved")] +
-                [(n, C.c_float) for n in ("gamma", "lam", "rew_scale", "eps_start", "eps_finish", "eps_decay_steps",
-                                          "lr_init", "lr_end", "lr_steps", "max_grad_norm")] +
+                [(n, C.c_float) for n in ("gamma", "lam", "rew_scale", "eps_start", "eps_finish",
+                                          "lr_init", "lr_end", "max_grad_norm")] +
+                [(n, C.c_double) for n in ("eps_decay_steps", "lr_steps")] +
                 [(n, C.c_uint64) for n in ("key_roll", "key_shuf", "sort_temp_bytes")] +
                 [("layout", CnnLayoutStruct)] +
                 [(n, C.c_void_p) for n in ("clock", "sched_keys", "sched_eps", "state", "bits", "action", "reward",
@@ -258,6 +259,70 @@ class UpdateDriver:
                 except Exception as exc:  # stay on the eager C++ enqueue (still the HIP path)
                     self.graph_error = repr(exc)
                     torch.cuda.synchronize()
+        self.calls += 1
+
+
+PHASE_BEGIN, PHASE_SHUFFLE, PHASE_GRAD, PHASE_APPLY, PHASE_END = range(5)
+
+
+class EnvShardDriver(UpdateDriver):
+    """One update of ONE seed whose envs are sharded over ranks: the C++ enqueue split at the
+    gradient / optimizer boundary of every minibatch (pqn_cnn_update_phase), `grad_hook(flat_grad)` -- the RCCL
+    all-reduce -- issued from the host between the segments.  Segment k = [APPLY(k-1)] [SHUFFLE] GRAD(k) ...; each
+    segment is captured once in its own hipGraph (the device clock makes every segment replayable), so per update the
+    host issues NUM_MINIBATCHES*NUM_EPOCHS + 1 graph launches and as many collectives instead of ~300 kernels."""
+
+    def __init__(self, *args, grad_hook=None, **kw):
+        super().__init__(*args, **kw)
+        if self.mlp:
+            raise RuntimeError("EnvShardDriver: CNN path only")
+        if grad_hook is None:
+            raise ValueError("EnvShardDriver needs a grad_hook")
+        self.grad_hook = grad_hook
+        mb, ep = int(self.args.num_minibatches), int(self.args.num_epochs)
+        n = mb * ep
+        segs = [[(PHASE_BEGIN, 0), (PHASE_SHUFFLE, 0), (PHASE_GRAD, 0)]]
+        for i in range(n - 1):
+            s = [(PHASE_APPLY, i)]
+            if (i + 1) % mb == 0:
+                s.append((PHASE_SHUFFLE, (i + 1) // mb))
+            s.append((PHASE_GRAD, i + 1))
+            segs.append(s)
+        segs.append([(PHASE_APPLY, n - 1), (PHASE_END, 0)])
+        self.segments = segs
+        self.graphs = None
+
+    def _enqueue_segment(self, seg):
+        lib = _lib.load()
+        for phase, index in seg:
+            _lib.check(lib.pqn_cnn_update_phase(C.byref(self.args), phase, index, _lib.stream_ptr()), "pqn_cnn_update_phase")
+
+    def update(self):
+        trainer = self._keep[0]
+        capture = self.use_graph and self.calls == 1 and self.graphs is None and self.graph_error is None
+        new_graphs = []
+        for k, seg in enumerate(self.segments):
+            if self.graphs is not None:
+                self.graphs[k].replay()
+            elif capture and self.graph_error is None:
+                # the first update ran eagerly (kernel attributes set, caches warm); capture while running the second
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._enqueue_segment(seg)
+                    g.replay()
+                    new_graphs.append(g)
+                except Exception as exc:  # stay on the eager C++ enqueue (still the HIP path)
+                    self.graph_error = repr(exc)
+                    torch.cuda.synchronize()
+                    self._enqueue_segment(seg)
+            else:
+                self._enqueue_segment(seg)
+            if k + 1 < len(self.segments):
+                self.grad_hook(trainer.grad)
+        if capture and self.graph_error is None and len(new_graphs) == len(self.segments):
+            self.graphs = new_graphs
+            self.graph = new_graphs[0]   # "graph" in runner_state["driver"]
         self.calls += 1
 
 
@@ -372,8 +437,9 @@ class MlpUpdateArgs(C.Structure):
     """pqn_mlp_update_args_t (include/pqn_hotpath.h)"""
     _fields_ = ([(n, C.c_int32) for n in ("env_id", "num_envs", "num_steps", "num_minibatches", "num_epochs",
                                            "metrics_capacity")] +
-                [(n, C.c_float) for n in ("gamma", "lam", "rew_scale", "eps_start", "eps_finish", "eps_decay_steps",
-                                          "lr_init", "lr_end", "lr_steps", "max_grad_norm")] +
+                [(n, C.c_float) for n in ("gamma", "lam", "rew_scale", "eps_start", "eps_finish",
+                                          "lr_init", "lr_end", "max_grad_norm")] +
+                [(n, C.c_double) for n in ("eps_decay_steps", "lr_steps")] +
                 [(n, C.c_uint64) for n in ("key_roll", "key_shuf", "sort_temp_bytes")] +
                 [("layout", MlpLayoutStruct)] +
                 [(n, C.c_void_p) for n in ("clock", "sched_keys", "sched_eps", "state", "obs", "action", "reward",

@@ -1,46 +1,83 @@
 """single_run(config): the launcher half of the reference scripts (purejaxql/pqn_minatar.py:435-483,
 534-545) on top of make_train: seeds = independent runs (jax.vmap(make_train) at :459-461), wall-clock
 line (:462), per-seed .safetensors + resolved config yaml (:464-483).  wandb is not available offline:
-WANDB_MODE other than "disabled" logs metrics as JSON lines to stdout instead."""
+WANDB_MODE other than "disabled" logs metrics as JSON lines to stdout instead.
+
+Multi-GPU (one process per GPU, `python -m torch.distributed.run --nproc-per-node G -m purejaxql_amd.pqn_minatar ...`):
+the reference's seed axis is sharded over the ranks -- rank r trains partition_seeds(NUM_SEEDS, G, r), batched
+into its launches, with NO data-path collective; the [S, NUM_UPDATES] metrics are gathered on every rank and
+each rank writes the checkpoints of its own seeds under their GLOBAL vmap index.  `SHARD: envs` (this build only)
+instead splits the NUM_ENVS of every seed over the ranks with a gradient all-reduce per optimizer step."""
 from __future__ import annotations
 
 import json
 import os
 import time
-from typing import Any, Dict, List
+from typing import Any, Callable, Dict, List, Optional
 
 import torch
 import yaml
 
+from . import dist as pdist
 from .config_loader import flatten, load_config
-from .pqn import make_train, seed_keys, vmap_train
 from .save_load import save_params
 
 
-def single_run(config: Dict[str, Any], device: str = "cuda") -> Dict[str, Any]:
+def single_run(config: Dict[str, Any], device: Optional[str] = None, make_train_fn: Optional[Callable] = None,
+               vmap_fn: Optional[Callable] = None, seed_keys_fn: Optional[Callable] = None) -> Dict[str, Any]:
+    """make_train_fn / vmap_fn / seed_keys_fn default to the product's (purejaxql_amd.pqn); the CPU tests of the
+    multi-rank control flow inject stand-ins (no GPU there)."""
+    if make_train_fn is None or vmap_fn is None or seed_keys_fn is None:
+        from .pqn import make_train, seed_keys, vmap_train
+        make_train_fn, vmap_fn, seed_keys_fn = make_train_fn or make_train, vmap_fn or vmap_train, seed_keys_fn or seed_keys
     config = flatten(config)                       # {**config, **config["alg"]} (:437)
     alg_name = config.get("ALG_NAME", "pqn")
     env_name = config["ENV_NAME"]
+    rank, world, local_rank = pdist.init_from_env()
+    if device is None:
+        device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda"
     if config.get("WANDB_MODE", "disabled") != "disabled":
         def cb(u, m):
             print(json.dumps({k: (float(v) if torch.is_tensor(v) else v) for k, v in m.items()}), flush=True)
         config["_CALLBACK"] = cb
-    keys = seed_keys(config["SEED"], config["NUM_SEEDS"])      # split(PRNGKey(SEED), NUM_SEEDS) (:456-459)
+    num_seeds = int(config["NUM_SEEDS"])
+    keys = seed_keys_fn(config["SEED"], num_seeds)      # split(PRNGKey(SEED), NUM_SEEDS) (:456-459)
+    shard_mode = str(config.get("SHARD", "seeds")).lower()
     t0 = time.time()
-    train = make_train(config, device=device)
-    outs = vmap_train(train, keys)
-    torch.cuda.synchronize()
-    print(f"Took {time.time() - t0} seconds to complete.")      # (:462)
+    if world > 1 and shard_mode == "envs":
+        # every rank runs ALL seeds on its share of the envs; gradients are averaged over ranks per optimizer step
+        cfg = pdist.shard_env_config(config, rank, world)
+        train = make_train_fn(cfg, device=device, grad_hook=pdist.make_grad_allreduce_hook(),
+                              metrics_hook=pdist.allreduce_mean_scalars)
+        mine = list(range(num_seeds))
+        outs = vmap_fn(train, keys, concurrent=False)
+        metrics = outs["metrics"]
+        saver = rank == 0
+    else:
+        mine = pdist.partition_seeds(num_seeds, world, rank) if world > 1 else list(range(num_seeds))
+        train = make_train_fn(dict(config), device=device)
+        outs = vmap_fn(train, [keys[i] for i in mine]) if mine else {"runner_state": [], "metrics": {}}
+        metrics = pdist.gather_seed_metrics(outs["metrics"]) if world > 1 else outs["metrics"]
+        saver = True
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        print(f"Took {time.time() - t0} seconds to complete.")      # (:462)
     if config.get("SAVE_PATH", None) is not None:
         save_dir = os.path.join(config["SAVE_PATH"], env_name)
         os.makedirs(save_dir, exist_ok=True)
-        clean = {k: v for k, v in config.items() if not k.startswith("_")}
-        with open(os.path.join(save_dir, f'{alg_name}_{env_name}_seed{config["SEED"]}_config.yaml'), "w") as f:
-            yaml.safe_dump(clean, f)
-        for i, rs in enumerate(outs["runner_state"]):
-            save_params(rs["params"], os.path.join(
-                save_dir, f'{alg_name}_{env_name}_seed{config["SEED"]}_vmap{i}.safetensors'))
-    return outs
+        if rank == 0:
+            clean = {k: v for k, v in config.items() if not k.startswith("_")}
+            with open(os.path.join(save_dir, f'{alg_name}_{env_name}_seed{config["SEED"]}_config.yaml'), "w") as f:
+                yaml.safe_dump(clean, f)
+        if saver:
+            for i, rs in zip(mine, outs["runner_state"]):      # i = GLOBAL seed index: the vmap axis of :464-483
+                save_params(rs["params"], os.path.join(
+                    save_dir, f'{alg_name}_{env_name}_seed{config["SEED"]}_vmap{i}.safetensors'))
+    return {"runner_state": outs["runner_state"], "seed_indices": mine, "metrics": metrics,
+            "rank": rank, "world_size": world}
 
 
 def main(argv: List[str], default_alg: str) -> Dict[str, Any]:
@@ -49,11 +86,17 @@ def main(argv: List[str], default_alg: str) -> Dict[str, Any]:
     if not any(o.startswith("+alg=") or o.startswith("alg=") for o in overrides):
         overrides.insert(0, f"+alg={default_alg}")
     config = load_config(overrides)
-    print("Config:\n", yaml.safe_dump(config))
+    rank, _world, _lr = pdist.world_info()
+    if rank == 0:
+        print("Config:\n", yaml.safe_dump(config))
     if config.get("HYP_TUNE", False):
         raise SystemExit("HYP_TUNE (wandb sweep, pqn_minatar.py:486-531) needs the wandb service: out of scope offline")
     outs = single_run(config)
-    m = outs["metrics"]
-    last = {k: [round(float(x), 4) for x in v[:, -1]] for k, v in m.items()}
-    print("final metrics per seed:", json.dumps(last))
+    if outs["rank"] == 0:
+        m = outs["metrics"]
+        last = {k: [round(float(x), 4) for x in v[:, -1]] for k, v in m.items()}
+        print("final metrics per seed:", json.dumps(last))
+    if outs["world_size"] > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     return outs

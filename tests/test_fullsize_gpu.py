@@ -139,3 +139,28 @@ def test_c_abi_argument_errors(gpu):
     from purejaxql_amd.qnet import CnnLayoutStruct
     s = CnnLayoutStruct()
     assert lib.pqn_cnn_layout(5, 3, ctypes.byref(s)) == -1 and lib.pqn_cnn_layout(4, 9, ctypes.byref(s)) == -1
+
+
+def test_c4_per_gpu_share_16_seeds_x_4096_envs_equals_solo_runs(gpu):
+    """BASELINE.json configs[3] (128 seeds x 4096 envs over 8 GPUs) = 16 seeds per GPU: all 16 seeds of the headline
+    shape advance in the same launches (pqn_cnn_update_seeds, grid.y = seed; pqn_minatar.py:459-461) for 2 updates
+    (the second one a hipGraph replay); seeds 0 / 7 / 15 must be bit-identical to their solo runs."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys, vmap_train
+    cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", "alg.NUM_ENVS=4096",
+                               "alg.TEST_DURING_TRAINING=False"]))
+    cfg["TOTAL_TIMESTEPS"] = 2 * 4096 * 32
+    keys = seed_keys(0, 16)
+    outs = vmap_train(make_train(dict(cfg), device="cuda:0"), keys)
+    rs = outs["runner_state"]
+    assert len(rs) == 16 and rs[0]["seed_batch"] == 16 and rs[0]["driver"] == "graph", rs[0]["driver_graph_error"]
+    assert outs["metrics"]["td_loss"].shape == (16, 2)
+    for s in (0, 7, 15):
+        solo = make_train(dict(cfg), device="cuda:0")(keys[s])
+        for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "returned_episode", "timestep"):
+            assert torch.equal(outs["metrics"][k][s], solo["metrics"][k]), (s, k)
+        assert torch.equal(rs[s]["theta"], solo["runner_state"]["theta"]), s
+        assert torch.equal(rs[s]["opt_mu"], solo["runner_state"]["opt_mu"][:rs[s]["opt_mu"].numel()]), s
+        assert torch.equal(rs[s]["env_state"], solo["runner_state"]["env_state"]), s
+    # different seeds are different runs
+    assert not torch.equal(outs["metrics"]["td_loss"][0], outs["metrics"]["td_loss"][1])

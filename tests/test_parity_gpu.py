@@ -60,7 +60,10 @@ def test_breakout_step_bit_exact_vs_oracle(gpu, oracle, n):
 
 
 @pytest.mark.parametrize("name,c,a,n,steps", [("Asterix-MinAtar", 4, 5, 1024, 1500), ("Freeway-MinAtar", 7, 3, 512, 2700),
-                                               ("SpaceInvaders-MinAtar", 6, 4, 1024, 1500), ("Asterix-MinAtar", 4, 5, 37, 400)])
+                                               ("SpaceInvaders-MinAtar", 6, 4, 1024, 1500), ("Asterix-MinAtar", 4, 5, 37, 400),
+                                               # BASELINE.json configs[2]: the suite at 4096 envs each
+                                               ("Asterix-MinAtar", 4, 5, 4096, 300), ("Freeway-MinAtar", 7, 3, 4096, 200),
+                                               ("SpaceInvaders-MinAtar", 6, 4, 4096, 300)])
 def test_minatar_suite_step_bit_exact_vs_oracle(gpu, oracle, name, c, a, n, steps):
     """Asterix / Freeway / SpaceInvaders: HIP packed-state kernels vs the C oracle (MinAtar rules), bit-exact
     on reward, done, observation (f32 and packed), full state and LogWrapper record."""
@@ -95,7 +98,10 @@ def test_minatar_suite_step_bit_exact_vs_oracle(gpu, oracle, name, c, a, n, step
             unpacked = ((b[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, -1)
             np.testing.assert_array_equal(unpacked[:, :100 * c], oobs.reshape(n, -1).astype(np.uint8))
             assert unpacked[:, 100 * c:].sum() == 0
-    assert ost["ret_len"].max() > 0 and ost["ret_ret"].max() > 0
+    if not (name.startswith("Freeway") and steps < 2500):   # Freeway episodes only end at the 2500-step limit
+        assert ost["ret_len"].max() > 0 and ost["ret_ret"].max() > 0
+    else:
+        assert ost["ep_ret"].max() > 0                       # chickens did cross
 
 
 def test_breakout_hand_derived_trajectories_on_gpu(gpu, oracle):
@@ -279,6 +285,9 @@ def test_product_network_vs_oracle_network(gpu, oracle):
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
                                          "_BACKEND": "fused", "_GRAPH": False}),    # C++ enqueue without hipGraph
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 1024, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
+    # the headline shape itself (BASELINE.json metric; bench.py's workload): one whole update, fused + hipGraph
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 4096, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
+    ("pqn_minatar", "Asterix-MinAtar", {"NUM_ENVS": 4096, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
     ("pqn_minatar", "Asterix-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
     ("pqn_minatar", "Freeway-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
     ("pqn_minatar", "SpaceInvaders-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
