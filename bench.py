@@ -41,38 +41,16 @@ def workload_config(num_envs: int, mode: str):
     return cfg
 
 
-def multi_seed_rate(cfg, seeds, steps, warmup, dev):
-    """`seeds` independent runs of the bench workload (own parameters / optimizer / envs / keys) batched into
-    the SAME launches (grid.y = seed, pqn_cnn_update_seeds; purejaxql_amd.pqn.vmap_train does the same):
-    aggregate env-steps/s.  Reported beside `value`, which stays the single-seed number."""
-    import torch
-    from purejaxql_amd.pqn import make_train, seed_keys
-    c = dict(cfg)
-    c.pop("_ENV_SHARD", None)
-    train = make_train(c, device=str(dev))
-    update, _finish = train.make_batch_runner(seed_keys(1, seeds))
-    for u in range(warmup):
-        update(u)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for u in range(warmup, warmup + steps):
-        update(u)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"seeds_per_gpu": seeds, "value": seeds * steps * c["NUM_ENVS"] * c["NUM_STEPS"] / dt, "unit": "env-steps/s",
-            "ms_per_round": dt / steps * 1e3,
-            "how": "all seeds in the same kernel launches (grid.y = seed), one hipGraph replay per update"}
-
-
-def cpu_baseline(cfg, theta0, max_seconds=45.0):
-    """The CPU oracle (numpy/C restatement, kind="port") on one update of the same workload."""
+def cpu_baseline(cfg, theta0):
+    """The CPU oracle (numpy/C restatement, kind="port") on a bounded sample of the same workload: 1 warm-up +
+    3 timed whole updates (rollout + Q(lambda) + NUM_EPOCHS x NUM_MINIBATCHES optimizer steps) at NUM_ENVS=1024
+    (same NUM_STEPS / minibatch count / epochs; a quarter of the env count keeps the leg within ~20 s)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import pqn_oracle as oracle
     ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
-    n, t = int(ocfg["NUM_ENVS"]), int(ocfg["NUM_STEPS"])
-    # bounded sample: 1 update at a reduced env count if the full one would take too long
-    sample_envs = n
+    t = int(ocfg["NUM_STEPS"])
+    sample_envs, warm, timed = 1024, 1, 3
     # threads actually used: numpy's BLAS pool (the network, most of the time) and OpenMP (C env step)
     try:
         from threadpoolctl import threadpool_info
@@ -83,151 +61,190 @@ def cpu_baseline(cfg, theta0, max_seconds=45.0):
         cores, pool_desc = os.cpu_count() or 1, "unknown"
     ocfg["NUM_ENVS"] = sample_envs
     ocfg["TOTAL_TIMESTEPS"] = ocfg["TOTAL_TIMESTEPS_DECAY"] = 1e7
-    train = oracle.make_train(ocfg)
-    t0 = time.perf_counter()
-    train(12345, theta0, max_updates=1)
-    dt = time.perf_counter() - t0
+
+    class _Clock:   # wall time of updates warm .. warm+timed-1: the loop calls linear_schedule(eps) once per update
+        pass
+    marks = []
+    orig = oracle.linear_schedule
+
+    def tick(init, end, steps, count):
+        if init == ocfg["EPS_START"] and end == ocfg["EPS_FINISH"]:
+            marks.append(time.perf_counter())
+        return orig(init, end, steps, count)
+    oracle.linear_schedule = tick
+    try:
+        train = oracle.make_train(ocfg)
+        train(12345, theta0, max_updates=warm + timed)
+        t_end = time.perf_counter()
+    finally:
+        oracle.linear_schedule = orig
+    assert len(marks) == warm + timed
+    dt = t_end - marks[warm]
     # env-only rate (uniform-random actions, no network): the C oracle's OpenMP env.step + auto-reset + LogWrapper
     env = oracle.OracleEnv(ocfg["ENV_NAME"])
-    _obs, st = env.reset(1, sample_envs)
+    n_env_only = int(cfg["NUM_ENVS"])
+    _obs, st = env.reset(1, n_env_only)
     rng = np.random.default_rng(0)
-    acts = rng.integers(0, env.num_actions, size=(50, sample_envs)).astype(np.int32)
+    acts = rng.integers(0, env.num_actions, size=(50, n_env_only)).astype(np.int32)
     env.step(2, st, acts[0])
     t1 = time.perf_counter()
     for i in range(50):
         _o, st, _r, _d, _info = env.step(100 + i, st, acts[i])
-    env_only = 50 * sample_envs / (time.perf_counter() - t1)
-    return {"value": sample_envs * t / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    env_only = 50 * n_env_only / (time.perf_counter() - t1)
+    return {"value": timed * sample_envs * t / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "env_only_env_steps_per_s": env_only,
-            "sample": f"1 full PQN update (rollout+Q(lambda)+{ocfg['NUM_EPOCHS']}x{ocfg['NUM_MINIBATCHES']} SGD steps) "
-                      f"at NUM_ENVS={sample_envs}, NUM_STEPS={t}: {sample_envs * t} env-steps in {dt:.1f}s; "
+            "sample": f"{warm} warm-up + {timed} timed full PQN updates (rollout+Q(lambda)+{ocfg['NUM_EPOCHS']}x{ocfg['NUM_MINIBATCHES']} "
+                      f"SGD steps) at NUM_ENVS={sample_envs}, NUM_STEPS={t}: {timed * sample_envs * t} env-steps in {dt:.1f}s; "
                       "oracle/pqn_oracle.py (C env/eps-greedy/Q(lambda)/RAdam + numpy-BLAS network), not JAX; "
                       f"host has {os.cpu_count()} logical cores, thread pools: {pool_desc}"}
+
+
+def timed_updates(update, steps, warmup, first=0, barrier=None):
+    """`warmup` untimed + `steps` timed updates between two stream syncs; returns seconds."""
+    import torch
+    for u in range(first, first + warmup):
+        update(u)
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for u in range(first + warmup, first + warmup + steps):
+        update(u)
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0
+
+
+def kernel_timer_pass(lib, update, first, mb_samples, seeds):
+    """HIP-event timing of the dominant kernel on its launch stream.  Events recorded while a hipGraph is being
+    captured cannot be read back on ROCm 7, so the timed region runs the graph and this pass re-runs 2 more
+    updates of the same workload through the eager C++ enqueue with the kernel timer on (same kernels, shapes,
+    buffers).  Returns (avg seconds per launch, launches)."""
+    import ctypes
+    import torch
+    from purejaxql_amd import _lib
+    drv = getattr(update, "driver", None)
+    if drv is not None:
+        drv.graph, drv.use_graph = None, False
+        if hasattr(drv, "graphs"):
+            drv.graphs = None
+    _lib.check(lib.pqn_prof_enable(1), "pqn_prof_enable")
+    for u in range(first, first + 2):
+        update(u)
+    torch.cuda.synchronize()
+    cnt, tot = ctypes.c_int32(0), ctypes.c_float(0.0)
+    _lib.check(lib.pqn_prof_read(ctypes.byref(cnt), ctypes.byref(tot)), "pqn_prof_read")
+    lib.pqn_prof_enable(0)
+    if cnt.value == 0:
+        raise SystemExit("kernel timer recorded nothing")
+    return tot.value * 1e-3 / cnt.value, cnt.value
+
+
+def t1_roofline(avg_s, launches, mb_samples, seeds, matmul):
+    achieved = T1_FLOP_PER_SAMPLE * mb_samples * seeds / avg_s / 1e12
+    traffic, tsrc = None, None
+    for name in ("r02_pmc_train_kernel.json", "r01_pmc_train_kernel.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            if pj.get("seeds_per_launch", 1) == seeds and pj.get("matmul", "f32") == matmul:
+                traffic = pj.get("hbm_bytes_per_launch")
+                tsrc = f"from file profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; not measured in this run)"
+                break
+    return {"kernel": f"qnet_cnn_train_kernel<4> (fwd + bwd of one {mb_samples}-sample minibatch of each of {seeds} seed(s) per launch)",
+            "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+            "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
+            "flop_per_launch": T1_FLOP_PER_SAMPLE * mb_samples * seeds,
+            "peak_note": "f32 MFMA / vector peak of MI355X (157.3 TFLOP/s); algorithmic f32 FLOPs of the kernel"}
+
+
+DTYPE_LABEL = {"f32": "f32",
+               "bf16x3": "f32 (bf16x3 split operands, 6 bf16 MFMA products per f32 product, f32 accumulate)",
+               "f16": "f16 operands / f32 accumulate (fc1), f32 elsewhere"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)    # 20 warm-up updates, then >= 200 timed
-    ap.add_argument("--warmup", type=int, default=20)    # (2.6e7 env-steps between the two stream syncs, ~1 s)
+    ap.add_argument("--steps", type=int, default=100)    # 16 seeds x 131,072 env-steps per update: 2.1e8 env-steps timed
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--num-envs", type=int, default=4096)
+    ap.add_argument("--seeds-per-gpu", type=int, default=16,
+                    help="independent seeds of the workload per GPU, batched into the same launches (jax.vmap over seeds, "
+                         "pqn_minatar.py:459-461).  16 = BASELINE.json configs[3]: 128 seeds x 4096 envs over 8 GPUs")
     ap.add_argument("--mode", default="seeds", choices=["seeds", "envs"],
                     help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
                          "(RCCL gradient all-reduce per optimizer step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mixed-precision", action="store_true", help="skip the extra MATMUL_DTYPE=f16 measurement")
-    ap.add_argument("--matmul-dtype", default="f32", choices=["f32", "f16"],
-                    help="operand type of the fc1 products (config MATMUL_DTYPE); f16 = fp16 operands, f32 accumulation")
-    ap.add_argument("--multi-seed", type=int, default=16,
-                    help="N=1 only: also report the aggregate rate of this many independent seeds of the same workload "
-                         "batched into the same launches (jax.vmap over seeds, pqn_minatar.py:459-461; 16 per GPU = "
-                         "BASELINE.json configs[3]: 128 seeds over 8 GPUs); 0 = skip")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only")
+    ap.add_argument("--matmul-dtype", default=None, choices=["f32", "bf16x3", "f16"],
+                    help="operand type of the fc1 products (config MATMUL_DTYPE; default: the config's)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: purejaxql_amd has no CPU path")
+    from purejaxql_amd import _lib
+    from purejaxql_amd import dist as pdist
     # PQN_BENCH_ONE_GPU=1 (tests on a 1-GPU box only): every rank on device 0, gloo instead of RCCL -- exercises the
     # multi-rank control flow (barriers, max-over-ranks timing, rank-0 line), not the scaling
-    one_gpu = os.environ.get("PQN_BENCH_ONE_GPU", "0") == "1"
-    if one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    from purejaxql_amd import _lib
-    _lib.load()
+    if os.environ.get("PQN_BENCH_ONE_GPU", "0") == "1":
+        os.environ.setdefault("PQN_DIST_BACKEND", "gloo")
+    rank, world, local_rank = pdist.init_from_env()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lib = _lib.load()
     from purejaxql_amd.pqn import make_train, seed_keys
-    from purejaxql_amd import dist as pdist
 
     cfg = workload_config(args.num_envs, args.mode)
-    cfg["MATMUL_DTYPE"] = args.matmul_dtype
-    cfg["TOTAL_TIMESTEPS"] = (args.steps + args.warmup + 3) * cfg["NUM_ENVS"] * cfg["NUM_STEPS"]
-    grad_hook = None
-    if world > 1 and args.mode == "envs":
-        grad_hook = pdist.make_grad_allreduce_hook()
-    seed_index = rank if args.mode == "seeds" else 0
-    key = seed_keys(0, world)[seed_index]
-    if args.mode == "envs" and world > 1:
-        cfg["_ENV_SHARD"] = (rank, world)
-    train = make_train(cfg, device=str(dev), grad_hook=grad_hook)
-    update, finish = train.make_runner(key)
-
-    lib = _lib.load()
+    if args.matmul_dtype:
+        cfg["MATMUL_DTYPE"] = args.matmul_dtype
+    matmul = str(cfg.get("MATMUL_DTYPE", "f32")).lower()
+    n_total = args.steps + args.warmup + 3
+    cfg["TOTAL_TIMESTEPS"] = n_total * cfg["NUM_ENVS"] * cfg["NUM_STEPS"]
+    barrier = dist.barrier if world > 1 else None
+    spg = max(1, args.seeds_per_gpu)
+    if args.mode == "envs":
+        # the envs of ONE seed split over the ranks, gradient all-reduce per optimizer step
+        spg = 1
+        scfg = pdist.shard_env_config(cfg, rank, world) if world > 1 else dict(cfg)
+        train = make_train(scfg, device=str(dev), grad_hook=pdist.make_grad_allreduce_hook() if world > 1 else None,
+                           metrics_hook=pdist.allreduce_mean_scalars if world > 1 else None)
+        update, finish = train.make_runner(seed_keys(0, 1)[0])
+        env_steps_per_update = cfg["NUM_ENVS"] * cfg["NUM_STEPS"]          # the global env count, all ranks together
+        scaling = "strong"
+    else:
+        # seeds are independent runs: rank r trains seeds [r*spg, (r+1)*spg) of seed_keys(0, world*spg), no collective
+        train = make_train(dict(cfg), device=str(dev))
+        keys = seed_keys(0, world * spg)[rank * spg:(rank + 1) * spg]
+        if spg > 1:
+            update, finish = train.make_batch_runner(keys)
+        else:
+            update, finish = train.make_runner(keys[0])
+        env_steps_per_update = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * spg * world
+        scaling = "weak"
     fused = train.backend == "fused"
-    for u in range(args.warmup):
-        update(u)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for u in range(args.warmup, args.warmup + args.steps):
-        update(u)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_updates(update, args.steps, args.warmup, 0, barrier)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    sps = env_steps_per_update * args.steps / dt
 
-    env_steps = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * args.steps * world
-    sps = env_steps / dt
-
-    # The kernel-timer pass below runs 2 more updates.  With the envs of one seed sharded over ranks those updates
+    # The kernel-timer pass runs 2 more updates.  With the envs of one seed sharded over ranks those updates
     # contain collectives, so EVERY rank has to run them (rank 0 alone would wait forever for its peers).
-    if world > 1 and args.mode == "envs" and fused and rank != 0:
-        for u in range(args.warmup + args.steps, args.warmup + args.steps + 2):
-            update(u)
-        torch.cuda.synchronize()
+    roof = None
+    mb = train.config["NUM_ENVS"] * cfg["NUM_STEPS"] // cfg["NUM_MINIBATCHES"]   # minibatch per rank and seed
+    drv0 = getattr(update, "driver", None)
+    driver_mode = None if drv0 is None else ("hipGraph replay" if drv0.graph is not None else "C++ enqueue (eager)")
+    if fused and (rank == 0 or (world > 1 and args.mode == "envs")):
+        avg_s, launches = kernel_timer_pass(lib, update, args.warmup + args.steps, mb, spg)
+        roof = t1_roofline(avg_s, launches, mb, spg, matmul)
 
     if rank == 0:
-        roof = None
-        drv0 = getattr(update, "driver", None)
-        driver_mode = None if drv0 is None else ("hipGraph replay" if drv0.graph is not None else "C++ enqueue (eager)")
-        if fused:
-            import ctypes
-            # HIP-event timing of the dominant kernel on its launch stream.  Events recorded while a hipGraph
-            # is being captured cannot be read back on ROCm 7, so the timed region above runs the graph and
-            # this pass re-runs 2 more updates of the same workload through the eager C++ enqueue with the
-            # kernel timer on (same kernels, same shapes, same buffers).
-            drv = getattr(update, "driver", None)
-            if drv is not None:
-                drv.graph, drv.use_graph = None, False
-            _lib.check(lib.pqn_prof_enable(1), "pqn_prof_enable")
-            for u in range(args.warmup + args.steps, args.warmup + args.steps + 2):
-                update(u)
-            torch.cuda.synchronize()
-            cnt, tot = ctypes.c_int32(0), ctypes.c_float(0.0)
-            _lib.check(lib.pqn_prof_read(ctypes.byref(cnt), ctypes.byref(tot)), "pqn_prof_read")
-            lib.pqn_prof_enable(0)
-            mb = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] // cfg["NUM_MINIBATCHES"]
-            if cnt.value == 0:
-                raise SystemExit("kernel timer recorded nothing")
-            avg_s = tot.value * 1e-3 / cnt.value
-            achieved = T1_FLOP_PER_SAMPLE * mb / avg_s / 1e12
-            traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_train_kernel.json")
-            if os.path.exists(pmc):
-                pj = json.load(open(pmc))
-                traffic, tsrc = pj.get("hbm_bytes_per_launch"), "profiles/r01_pmc_train_kernel.json (separate rocprofv3 --pmc passes)"
-            roof = {"kernel": "qnet_cnn_train_kernel<4> (fwd + bwd of one 4096-sample minibatch, f32 MFMA)",
-                    "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
-                    "avg_launch_us": avg_s * 1e6, "launches_timed": cnt.value,
-                    "flop_per_launch": T1_FLOP_PER_SAMPLE * mb}
         if roof is None:
             from purejaxql_amd.profiling import time_env_step_kernel
             k_ms = time_env_step_kernel(cfg["NUM_ENVS"], dev)
@@ -238,11 +255,16 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node), MinAtar-Breakout 4096 envs", "value": sps, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.matmul_dtype == "f32" else "f16 operands / f32 accumulate (fc1), f32 elsewhere", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": DTYPE_LABEL.get(matmul, matmul), "data": "synthetic",
             "config": {"workload": f"Breakout-MinAtar PQN full loop, NUM_ENVS={cfg['NUM_ENVS']} NUM_STEPS={cfg['NUM_STEPS']} "
-                                   f"NUM_MINIBATCHES={cfg['NUM_MINIBATCHES']} NUM_EPOCHS={cfg['NUM_EPOCHS']} per GPU",
-                       "seeds_per_gpu": 1, "backend": train.backend, "driver": driver_mode, "parallelism": f"{args.mode}x{world}",
+                                   f"NUM_MINIBATCHES={cfg['NUM_MINIBATCHES']} NUM_EPOCHS={cfg['NUM_EPOCHS']}, "
+                                   + (f"{spg} independent seed(s) per GPU batched into the launches "
+                                      f"(BASELINE.json configs[3] = 128 seeds x 4096 envs over 8 GPUs is 16 per GPU)"
+                                      if args.mode == "seeds" else f"ONE seed, its envs sharded over {world} rank(s)"),
+                       "seeds_per_gpu": spg, "seeds_total": spg * world if args.mode == "seeds" else 1,
+                       "env_steps_per_step": env_steps_per_update, "matmul_dtype": matmul,
+                       "backend": train.backend, "driver": driver_mode, "parallelism": f"{args.mode}x{world}",
                        "loop_tflops": sps * LOOP_FLOP / 1e12, "loop_frac_f32_peak": sps * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS},
             "roofline": roof,
         }
@@ -256,28 +278,45 @@ def main():
                 out[name] = {"error": repr(exc)[:300]}
                 torch.cuda.synchronize()
 
-        if world == 1:
+        extras = world == 1 and not args.no_extras
+        if extras and fused and spg > 1:
+            def single_seed():
+                c1 = dict(cfg)
+                tr1 = make_train(c1, device=str(dev))
+                upd1, _fin1 = tr1.make_runner(seed_keys(0, 1)[0])
+                d1 = timed_updates(upd1, args.steps, args.warmup)
+                a1, l1 = kernel_timer_pass(lib, upd1, args.warmup + args.steps, mb, 1)
+                v1 = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * args.steps / d1
+                return {"seeds_per_gpu": 1, "value": v1, "unit": "env-steps/s", "ms_per_step": d1 / args.steps * 1e3,
+                        "loop_frac_f32_peak": v1 * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS,
+                        "roofline": t1_roofline(a1, l1, mb, 1, matmul),
+                        "note": "ONE seed of 4096 envs alone on the GPU (round 1's headline configuration)"}
+            guarded("single_seed", single_seed)
+        if extras:
             from purejaxql_amd.profiling import env_step_hbm_roofline
             guarded("roofline_env_step", lambda: [env_step_hbm_roofline(n, dev) for n in (4096, 65536)])
-        if world == 1 and args.multi_seed > 1 and fused:
-            guarded("multi_seed", lambda: multi_seed_rate(cfg, args.multi_seed, args.steps, args.warmup, dev))
-        if world == 1 and fused and args.matmul_dtype == "f32" and not args.no_mixed_precision:
-            # opt-in operand precision (config MATMUL_DTYPE=f16): reported beside `value`, never as `value`
-            def mixed():
-                c16 = dict(cfg)
-                c16["MATMUL_DTYPE"] = "f16"
-                one = multi_seed_rate(c16, 1, args.steps, args.warmup, dev)
-                many = multi_seed_rate(c16, args.multi_seed, args.steps, args.warmup, dev) if args.multi_seed > 1 else None
-                return {
-                    "dtype": "fc1 products (forward, input gradient, weight gradient; 78 % of the FLOPs) with fp16 operands and "
-                             "f32 accumulation; master weights, optimizer, conv, LayerNorm, head, loss in f32",
-                    "value": one["value"], "unit": "env-steps/s", "ms_per_step": one["ms_per_round"],
-                    "multi_seed": None if many is None else {"seeds_per_gpu": many["seeds_per_gpu"], "value": many["value"]},
-                    "returns": "10-seed Breakout / Asterix test returns equal to the f32 mode within seed noise "
-                               "(profiles/r01_learning_curves.txt)"}
-            guarded("mixed_precision", mixed)
-        if not args.no_cpu_baseline and world == 1:
-            guarded("cpu_baseline", lambda: cpu_baseline(cfg, finish()["runner_state"]["network"].init(1).cpu().numpy()))
+        if extras and fused:
+            def other_modes():
+                res = {}
+                for md in ("f32", "bf16x3", "f16"):
+                    if md == matmul:
+                        continue
+                    c2 = dict(cfg)
+                    c2["MATMUL_DTYPE"] = md
+                    tr2 = make_train(c2, device=str(dev))
+                    k2 = seed_keys(0, spg)
+                    upd2, _f2 = tr2.make_batch_runner(k2) if spg > 1 else tr2.make_runner(k2[0])
+                    d2 = timed_updates(upd2, max(10, args.steps // 4), max(3, args.warmup // 2))
+                    res[md] = {"dtype": DTYPE_LABEL[md], "seeds_per_gpu": spg,
+                               "value": cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * spg * max(10, args.steps // 4) / d2,
+                               "unit": "env-steps/s"}
+                res["note"] = ("the same workload under the other operand modes of the fc1 products; f16 = fp16 operands "
+                               "(narrower than the reference's f32: reported, never the headline)")
+                return res
+            guarded("matmul_modes", other_modes)
+        if extras and not args.no_cpu_baseline:
+            from purejaxql_amd.networks import QNetwork
+            guarded("cpu_baseline", lambda: cpu_baseline(cfg, QNetwork("cnn", (10, 10, 4), 3, device=dev).init(1).cpu().numpy()))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

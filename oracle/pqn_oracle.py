@@ -520,9 +520,19 @@ def make_train(config: Dict[str, Any]):
     test_steps = env.max_steps if kind == "cnn" else int(config.get("TEST_NUM_STEPS", env.max_steps))
     gamma, lam, rs = float(config["GAMMA"]), float(config["LAMBDA"]), float(config.get("REW_SCALE", 1))
 
-    def train(rng: int, init_theta: np.ndarray, max_updates: int = None):
+    def train(rng: int, init_theta: np.ndarray, max_updates: int = None, shard_world: int = 1):
+        """shard_world > 1: the envs of this ONE seed sharded over that many ranks (`config` is the
+        per-rank config, NUM_ENVS = the rank's share): every rank rolls out its own envs under the shared
+        parameters with rank-distinct env / shuffle streams (fold_in(K, 1000 + rank), as purejaxql_amd.pqn), and
+        every optimizer step uses the gradient averaged over the ranks' minibatches (pqn_minatar.py:159-162,285-292
+        on the global minibatch).  Metric means are means over the shards, step counts are over all envs."""
         K = int(rng) & 0xFFFFFFFFFFFFFFFF
         K_init, K_reset, K_test, K_roll, K_shuf = (fold_in(K, i) for i in range(5))
+        W = int(shard_world)
+        if W > 1:
+            Kr = [tuple(fold_in(k, 1000 + r) for k in (K_reset, K_test, K_roll, K_shuf)) for r in range(W)]
+        else:
+            Kr = [(K_reset, K_test, K_roll, K_shuf)]
         theta = np.ascontiguousarray(init_theta, np.float32).copy()
         m, v = np.zeros_like(theta), np.zeros_like(theta)
         p = unflatten(theta, shapes)
@@ -534,7 +544,7 @@ def make_train(config: Dict[str, Any]):
         def test_metrics_fn():
             if not test_on:
                 return None
-            k = fold_in(K_test, runs[0])
+            k = fold_in(Kr[0][1], runs[0])
             runs[0] += 1
             nt = int(config["TEST_NUM_ENVS"])
             obs, st = env.reset(fold_in(k, 0), nt)
@@ -550,59 +560,73 @@ def make_train(config: Dict[str, Any]):
             return {kk: np.float32(sums[kk] / cnt) if cnt > 0 else np.float32(np.nan) for kk in INFO_KEYS}
 
         tm = test_metrics_fn()
-        obs, st = env.reset(K_reset, N)
+        shards = []
+        for r in range(W):
+            obs, st = env.reset(Kr[r][0], N)
+            shards.append({"obs": obs, "st": st})
         nu = NU if max_updates is None else min(NU, max_updates)
         metrics = []
         period = int(NU * config["TEST_INTERVAL"]) if test_on else 0
         for u in range(nu):
             eps = linear_schedule(config["EPS_START"], config["EPS_FINISH"], config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"], n_updates)
-            O = np.zeros((T + 1, N, *env.obs_shape), np.float32)
-            O[0] = obs
-            Aa = np.zeros((T, N), np.int32)
-            R = np.zeros((T, N), np.float32)
-            D = np.zeros((T, N), bool)
-            QM = np.zeros((T, N), np.float32)
-            infos = {kk: [] for kk in INFO_KEYS}
-            for t in range(T):
-                sk = fold_in(K_roll, u * T + t)
-                q = net_forward(kind, p, O[t], use_ln, layers, stats=stats, **nkw)
-                Aa[t], QM[t] = eps_greedy(q, np.float32(eps), sk)
-                O[t + 1], st, r, D[t], info = env.step(sk, st, Aa[t])
-                R[t] = np.float32(rs) * r if rs != 1.0 else r
+            info_means = {kk: [] for kk in INFO_KEYS}
+            for r, sh in enumerate(shards):
+                O = np.zeros((T + 1, N, *env.obs_shape), np.float32)
+                O[0] = sh["obs"]
+                Aa = np.zeros((T, N), np.int32)
+                R = np.zeros((T, N), np.float32)
+                D = np.zeros((T, N), bool)
+                QM = np.zeros((T, N), np.float32)
+                infos = {kk: [] for kk in INFO_KEYS}
+                for t in range(T):
+                    sk = fold_in(Kr[r][2], u * T + t)
+                    q = net_forward(kind, p, O[t], use_ln, layers, stats=stats, **nkw)
+                    Aa[t], QM[t] = eps_greedy(q, np.float32(eps), sk)
+                    O[t + 1], sh["st"], rr, D[t], info = env.step(sk, sh["st"], Aa[t])
+                    R[t] = np.float32(rs) * rr if rs != 1.0 else rr
+                    for kk in INFO_KEYS:
+                        infos[kk].append(info[kk])
+                last_q = net_forward(kind, p, O[T], use_ln, layers, stats=stats, **nkw).max(-1)
+                tgt = q_lambda(R, D, QM, last_q, gamma, lam, quirk=True)
+                sh["of"], sh["af"], sh["tf"] = O[:T].reshape(T * N, *env.obs_shape), Aa.reshape(-1), tgt.reshape(-1)
+                sh["obs"] = O[T]
                 for kk in INFO_KEYS:
-                    infos[kk].append(info[kk])
-            timesteps += T * N
-            last_q = net_forward(kind, p, O[T], use_ln, layers, stats=stats, **nkw).max(-1)
-            tgt = q_lambda(R, D, QM, last_q, gamma, lam, quirk=True)
-            of, af, tf = O[:T].reshape(T * N, *env.obs_shape), Aa.reshape(-1), tgt.reshape(-1)
+                    info_means[kk].append(float(np.mean(np.stack(infos[kk]).astype(np.float32))))
+            timesteps += T * N * W
             losses, qvs = [], []
             for ep in range(EP):
-                perm = permutation(fold_in(K_shuf, u * EP + ep), T * N)
+                perms = [permutation(fold_in(Kr[r][3], u * EP + ep), T * N) for r in range(W)]
                 for mb in range(MB):
-                    idx = perm[mb * B:(mb + 1) * B]
-                    new_stats = {}
-                    loss, chosen, g = net_loss_grad(kind, p, shapes, of[idx], af[idx], tf[idx], use_ln, layers,
-                                                    stats=stats, new_stats=new_stats, **nkw)
+                    gs, ls, cs = [], [], []
+                    for r, sh in enumerate(shards):
+                        idx = perms[r][mb * B:(mb + 1) * B]
+                        new_stats = {}
+                        loss, chosen, g = net_loss_grad(kind, p, shapes, sh["of"][idx], sh["af"][idx], sh["tf"][idx], use_ln,
+                                                        layers, stats=stats, new_stats=new_stats, **nkw)
+                        gs.append(g)
+                        ls.append(loss)
+                        cs.append(chosen.mean(dtype=np.float32))
                     stats.update(new_stats)                                # mutable=["batch_stats"] (:272-277,296)
+                    g = gs[0] if W == 1 else (np.sum(gs, axis=0, dtype=np.float32) / np.float32(W)).astype(np.float32)
                     lr = linear_schedule(config["LR"], 1e-20, lr_steps, grad_steps) if config.get("LR_LINEAR_DECAY", False) else config["LR"]
                     radam_clip_step(theta, g, m, v, grad_steps, np.float32(lr), np.float32(config["MAX_GRAD_NORM"]))
                     grad_steps += 1
-                    losses.append(loss)
-                    qvs.append(chosen.mean(dtype=np.float32))
-            obs = O[T]
+                    losses.append(ls[0] if W == 1 else np.float32(np.mean(ls)))
+                    qvs.append(cs[0] if W == 1 else np.float32(np.mean(cs)))
             n_updates += 1
             mm = {"env_step": timesteps, "update_steps": n_updates, "grad_steps": grad_steps,
                   "td_loss": float(np.mean(losses)), "qvals": float(np.mean(qvs))}
             if kind == "cnn":
                 mm["env_frame"] = timesteps * env.obs_shape[-1]
             for kk in INFO_KEYS:
-                mm[kk] = float(np.mean(np.stack(infos[kk]).astype(np.float32)))
+                mm[kk] = float(np.mean(info_means[kk]))
             if test_on:
                 if period > 0 and n_updates % period == 0:
                     tm = test_metrics_fn()
                 mm.update({f"test/{k}": float(v2) for k, v2 in tm.items()})
             metrics.append(mm)
-        return {"theta": theta, "metrics": metrics, "env_state": st, "last_obs": obs, "batch_stats": stats}
+        return {"theta": theta, "metrics": metrics, "env_state": shards[0]["st"], "last_obs": shards[0]["obs"],
+                "batch_stats": stats, "shards": shards}
 
     train.shapes = shapes
     train.kind = kind

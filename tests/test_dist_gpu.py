@@ -1,0 +1,96 @@
+"""GPU test of the env-sharded multi-rank training step (-m gpu): two ranks share the one GPU of the box over gloo
+(one process per rank, as `torch.distributed.run` would start them), each owning half of the envs of ONE seed, with
+the per-minibatch gradient all-reduce between pqn_cnn_update_phase(GRAD) and (APPLY).  RCCL itself needs >= 2 GPUs;
+the control flow, the phase split, the segment hipGraphs and the arithmetic are what this covers."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg(num_envs_global, n_upd):
+    from purejaxql_amd.config_loader import flatten, load_config
+    cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar"]))
+    cfg.update({"NUM_ENVS": num_envs_global, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
+                "TOTAL_TIMESTEPS": n_upd * num_envs_global * 8, "TOTAL_TIMESTEPS_DECAY": 30 * num_envs_global * 8,
+                "TEST_DURING_TRAINING": False})
+    return cfg
+
+
+def _rank_main(rank, world, port, q, num_envs_global, n_upd, theta0, use_driver):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1")
+    import torch.distributed as dist
+    from purejaxql_amd import dist as pdist
+    from purejaxql_amd.pqn import make_train, seed_keys
+    pdist.init_from_env()
+    cfg = pdist.shard_env_config(_cfg(num_envs_global, n_upd), rank, world)
+    cfg["_INIT_PARAMS"] = torch.from_numpy(theta0).to("cuda:0")
+    cfg["_DRIVER"] = use_driver
+    train = make_train(cfg, device="cuda:0", grad_hook=pdist.make_grad_allreduce_hook(),
+                       metrics_hook=pdist.allreduce_mean_scalars)
+    out = train(seed_keys(0, 1)[0])
+    torch.cuda.synchronize()
+    rs = out["runner_state"]
+    q.put((rank, rs["theta"].cpu().numpy(), {k: v.cpu().numpy() for k, v in out["metrics"].items()}, rs["driver"],
+           rs["driver_graph_error"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_driver", [True, False])
+def test_two_rank_env_sharded_training_matches_oracle_with_averaged_gradients(gpu, oracle, use_driver):
+    """3 updates of make_train(grad_hook = all-reduce mean) on 2 ranks x 32 envs: theta identical on both ranks and
+    equal (bulk rtol 2e-3, worst element < lr: the criterion of test_make_train_end_to_end_vs_oracle) to the oracle loop
+    that averages the two shards' gradients per optimizer step; metric means are means over both shards.
+    use_driver: the phase-split C++ enqueue with per-segment hipGraphs (update 0 eager, 1 captured, 2 replayed) /
+    the per-kernel Python loop."""
+    from purejaxql_amd.dist import shard_env_config
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.pqn import seed_keys
+    world, n_glob, n_upd = 2, 64, 3
+    theta0 = QNetwork("cnn", (10, 10, 4), 3, device=gpu).init(17).cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, n_glob, n_upd, theta0, use_driver)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, th0, m0, drv0, err0), (_, th1, m1, _drv1, _err1) = res
+    if use_driver:
+        assert drv0 == "graph", err0
+    else:
+        assert drv0 is None
+    np.testing.assert_array_equal(th0, th1)                   # both ranks applied the same averaged gradients
+    for k in m0:
+        np.testing.assert_array_equal(m0[k], m1[k], err_msg=k)
+    ocfg = {k: v for k, v in shard_env_config(_cfg(n_glob, n_upd), 0, world).items() if not k.startswith("_")}
+    oout = oracle.make_train(ocfg)(seed_keys(0, 1)[0], theta0, shard_world=world)
+    assert len(oout["metrics"]) == n_upd
+    for u in range(n_upd):
+        om = oout["metrics"][u]
+        assert float(m0["env_step"][u]) == om["env_step"] == (u + 1) * n_glob * 8
+        assert float(m0["grad_steps"][u]) == om["grad_steps"]
+        for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "timestep",
+                  "returned_episode", "discount"):
+            assert abs(float(m0[k][u]) - om[k]) <= 1e-3 * max(1.0, abs(om[k])), (u, k, float(m0[k][u]), om[k])
+    d = np.abs(th0 - oout["theta"])
+    bad = d > (2e-5 + 2e-3 * np.abs(oout["theta"]))
+    assert bad.mean() < 1e-3 and d.max() < 5e-4, (int(bad.sum()), float(d.max()))
