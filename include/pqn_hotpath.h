@@ -113,6 +113,18 @@ int pqn_env_export_state(int env_id, int32_t n, const uint32_t *state, int32_t *
 int pqn_env_import_state(int env_id, int32_t n, const int32_t *si, const float *sf,
                          const uint32_t *log, uint32_t *state, void *stream);
 
+/* OptimisticResetVecEnvWrapper(LogWrapper(env), num_envs = n, reset_ratio).step (utils/craftax_wrappers.py:83-148;
+ * the wrapper order of pqn_craftax.py:99-108): every env steps; only n / reset_ratio fresh states exist, reset j =
+ * reset_env(fold_in(key, 1), j); the finished envs are ranked by a per-env random sort key (fold_in(key, 2)) -- a
+ * uniformly random ordered subset, the reference's choice(p=done, replace=False) -- the first n / reset_ratio of
+ * them take a reset of their own (rank r -> reset r), later ones share the default slot e / reset_ratio; a finished
+ * env's whole LogWrapper record restarts from zero (LogWrapper sits INSIDE this wrapper), `out` info arrays hold the
+ * stepped record.  scratch: u64[n].  slot_out (nullable): i32[n], the reset an env took, -1 if it did not finish.
+ * reset_ratio must divide n (:96-98).  In-place stepping (state_in == state_out) is supported. */
+int pqn_env_step_optimistic(int env_id, int32_t n, uint64_t key, int32_t reset_ratio, const uint32_t *state_in,
+                            uint32_t *state_out, const int32_t *action, const pqn_step_out_t *out /* host */,
+                            uint64_t *scratch, int32_t *slot_out, void *stream);
+
 /* ---- algorithm pieces of make_train ------------------------------------ */
 /* jax.vmap(eps_greedy_exploration) -- pqn_minatar.py:115-128,194-196.  Also
  * emits max_a q (the only use of Transition.q_val, :249). qmax may be NULL. */

@@ -8,6 +8,7 @@
  * tree; pinned at reference pyproject.toml:51) -> "parity unpinned".
  */
 #include "pqn_oracle.h"
+#include <stdlib.h>
 
 #include <math.h>
 #include <stdlib.h>
@@ -562,6 +563,62 @@ int pqn_oracle_env_step(int env_id, int32_t n, uint64_t key, int32_t *si, float 
     done[e] = (uint8_t)d;
     if (discount) discount[e] = d ? 0.0f : 1.0f; /* info["discount"] */
   }
+  return 0;
+}
+
+/* OptimisticResetVecEnvWrapper.step (utils/craftax_wrappers.py:111-148) over LogWrapper(env) -- the wrapper order
+ * of pqn_craftax.py:99-108, so the WHOLE LogEnvState of a finished env is replaced by LogWrapper.reset's zeros
+ * (:165-171), returned_* and timestep included; info is the stepped LogWrapper's (:184-199).
+ *   1. step every env, no reset                                            (:114-116; LogWrapper :173-199)
+ *   2. num_resets = n / reset_ratio fresh states: reset j = reset_env(key_re, j)          (:118-120)
+ *   3. being_reset = choice(arange(n), (num_resets,), p=done, replace=False) (:125-131): a uniformly random ordered
+ *      subset of the finished envs.  This build's own draw (jax streams cannot be reproduced): finished env e gets the
+ *      sort key rand31(key_ch, e) << 32 | e; its rank r among the finished envs is its position in being_reset
+ *   4. finished env e takes reset r if r < num_resets (a reset of its own), else reset e / reset_ratio (the default
+ *      slot, possibly shared with other envs)                               (:122,132,134-135)
+ *   5. select(done, reset, stepped) for state and obs                     (:137-146)
+ * key_re = fold_in(key, 1), key_ch = fold_in(key, 2); the env's own step draws use `key` as in pqn_oracle_env_step.
+ * Log arrays (ep_ret ... timestep) may be NULL (no LogWrapper). */
+int pqn_oracle_env_step_optimistic(int env_id, int32_t n, uint64_t key, int32_t reset_ratio, int32_t *si, float *sf,
+                                   const int32_t *action, float *obs, float *reward, uint8_t *done, float *discount,
+                                   float *ep_ret, int32_t *ep_len, float *ret_ret, int32_t *ret_len, int32_t *timestep,
+                                   float *info_ret_ret, int32_t *info_ret_len, int32_t *info_timestep, int32_t *slot_out) {
+  pqn_oracle_spec_t sp;
+  if (pqn_oracle_env_spec(env_id, &sp)) return -1;
+  if (reset_ratio <= 0 || n % reset_ratio) return -1;            /* :96-98 */
+  const int32_t num_resets = n / reset_ratio;
+  if (pqn_oracle_env_step(env_id, n, key, si, sf, action, 0, obs, reward, done, discount)) return -1;
+  if (ep_ret) {
+    pqn_oracle_log_step(n, reward, done, ep_ret, ep_len, ret_ret, ret_len, timestep);
+    for (int32_t e = 0; e < n; ++e) {
+      if (info_ret_ret) info_ret_ret[e] = ret_ret[e];
+      if (info_ret_len) info_ret_len[e] = ret_len[e];
+      if (info_timestep) info_timestep[e] = timestep[e];
+    }
+  }
+  const uint64_t key_re = pqn_oracle_fold_in(key, 1u), key_ch = pqn_oracle_fold_in(key, 2u);
+  uint64_t *ck = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+  if (!ck) return -1;
+  for (int32_t e = 0; e < n; ++e) {
+    uint32_t o[2];
+    pqn_oracle_env_bits(key_ch, (uint32_t)e, 0u, o);
+    ck[e] = done[e] ? (((uint64_t)(o[0] >> 1) << 32) | (uint32_t)e) : ~(uint64_t)0;
+  }
+  for (int32_t e = 0; e < n; ++e) {
+    int32_t slot = -1;
+    if (done[e]) {
+      int32_t rank = 0;
+      for (int32_t j = 0; j < n; ++j) rank += ck[j] < ck[e];
+      slot = rank < num_resets ? rank : e / reset_ratio;
+      int32_t *s = si + (size_t)e * sp.si;
+      float *f = sf ? sf + (size_t)e * sp.sf : 0;
+      reset_one(env_id, key_re, (uint32_t)slot, s, f);
+      if (obs) obs_one(env_id, s, f, obs + (size_t)e * sp.obs_size);
+      if (ep_ret) { ep_ret[e] = 0.0f; ep_len[e] = 0; ret_ret[e] = 0.0f; ret_len[e] = 0; timestep[e] = 0; }
+    }
+    if (slot_out) slot_out[e] = slot;
+  }
+  free(ck);
   return 0;
 }
 

@@ -64,6 +64,11 @@ int pqn_oracle_env_step(int env_id, int32_t n, uint64_t key, int32_t *si, float 
                         const int32_t *action, int autoreset, float *obs, float *reward,
                         uint8_t *done, float *discount);
 int pqn_oracle_env_obs(int env_id, int32_t n, const int32_t *si, const float *sf, float *obs);
+/* OptimisticResetVecEnvWrapper(LogWrapper(env)).step (utils/craftax_wrappers.py:83-148, order of pqn_craftax.py:99-108) */
+int pqn_oracle_env_step_optimistic(int env_id, int32_t n, uint64_t key, int32_t reset_ratio, int32_t *si, float *sf,
+                                   const int32_t *action, float *obs, float *reward, uint8_t *done, float *discount,
+                                   float *ep_ret, int32_t *ep_len, float *ret_ret, int32_t *ret_len, int32_t *timestep,
+                                   float *info_ret_ret, int32_t *info_ret_len, int32_t *info_timestep, int32_t *slot_out);
 
 /* LogWrapper (utils/craftax_wrappers.py:151-200) on arrays */
 void pqn_oracle_log_step(int32_t n, const float *reward, const uint8_t *done, float *ep_ret,

@@ -61,6 +61,7 @@ def lib():
         L.pqn_oracle_env_reset.argtypes = [C.c_int, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pqn_oracle_env_step.argtypes = [C.c_int, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pqn_oracle_env_step_optimistic.argtypes = [C.c_int, C.c_int32, C.c_uint64, C.c_int32] + [C.c_void_p] * 16
         L.pqn_oracle_env_obs.argtypes = [C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pqn_oracle_log_step.argtypes = [C.c_int32] + [C.c_void_p] * 7
         L.pqn_oracle_eps_greedy.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p,
@@ -144,6 +145,22 @@ class OracleEnv:
         info = {"discount": disc, "returned_episode_returns": st["ret_ret"].copy(),
                 "returned_episode_lengths": st["ret_len"].copy(), "timestep": st["timestep"].copy(),
                 "returned_episode": done.astype(bool)}
+        return obs, st, reward, done.astype(bool), info
+
+    def step_optimistic(self, key: int, st, action, reset_ratio: int):
+        """OptimisticResetVecEnvWrapper(LogWrapper(env), n, reset_ratio).step (utils/craftax_wrappers.py:83-148)."""
+        n = st["si"].shape[0]
+        action = np.ascontiguousarray(action, dtype=np.int32)
+        obs = np.zeros((n, *self.obs_shape), np.float32)
+        reward, done, disc = np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.float32)
+        irr, irl, its, slot = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        rc = lib().pqn_oracle_env_step_optimistic(self.env_id, n, C.c_uint64(key), int(reset_ratio), _p(st["si"]), _p(st["sf"]),
+                                                  _p(action), _p(obs), _p(reward), _p(done), _p(disc), _p(st["ep_ret"]),
+                                                  _p(st["ep_len"]), _p(st["ret_ret"]), _p(st["ret_len"]), _p(st["timestep"]),
+                                                  _p(irr), _p(irl), _p(its), _p(slot))
+        assert rc == 0, "reset ratio must perfectly divide num envs"
+        info = {"discount": disc, "returned_episode_returns": irr, "returned_episode_lengths": irl, "timestep": its,
+                "returned_episode": done.astype(bool), "reset_slot": slot}
         return obs, st, reward, done.astype(bool), info
 
     def log_words(self, st) -> np.ndarray:

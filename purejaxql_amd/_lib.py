@@ -41,6 +41,8 @@ SIGNATURES = {
     "pqn_env_spec": (c_int, [c_int, C.POINTER(EnvSpec)]),
     "pqn_env_reset": (c_int, [c_int, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_env_step": (c_int, [c_int, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, C.POINTER(StepOut), c_void_p]),
+    "pqn_env_step_optimistic": (c_int, [c_int, c_int32, c_uint64, c_int32, c_void_p, c_void_p, c_void_p, C.POINTER(StepOut),
+                                        c_void_p, c_void_p, c_void_p]),
     "pqn_env_export_state": (c_int, [c_int, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_env_import_state": (c_int, [c_int, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_eps_greedy": (c_int, [c_void_p, c_int32, c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),

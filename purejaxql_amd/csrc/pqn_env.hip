@@ -17,6 +17,63 @@
 #include "pqn_env_rules.h"
 
 // ===========================================================================
+// Optimistic resets (OptimisticResetVecEnvWrapper.step, utils/craftax_wrappers.py:111-148, over LogWrapper(env):
+// the wrapper order of pqn_craftax.py:99-108).  Pass 1 = the step kernels below with opt_keys: every env steps, no
+// reset; a finished env publishes rand31(key_ch, e) << 32 | e, the others ~0.  Pass 2 = opt_reset_kernel: a finished
+// env's rank among the finished ones is its position in `being_reset` (choice(p=done, replace=False), :125-131: a
+// uniformly random ordered subset); rank r < num_resets takes reset r, a later one the default slot e / reset_ratio
+// (:122,132).  Reset j is a pure function reset_env(key_re, j), so the env evaluates it in place -- the N/ratio
+// reset states are never materialised or gathered (:118-120,134-135).  The whole LogEnvState of a finished env
+// becomes LogWrapper.reset's zeros (:165-171); info was written by pass 1 from the stepped record (:184-199).
+// ===========================================================================
+PQN_D uint64_t opt_choice_key(uint64_t key, uint32_t e, int done) {
+  if (!done) return ~(uint64_t)0;
+  uint32_t o0, o1;
+  pqn_bits(pqn_fold(key, 2u), e, 0u, o0, o1);
+  return ((uint64_t)(o0 >> 1) << 32) | e;
+}
+
+template <class Env, bool MINATAR>
+__global__ __launch_bounds__(256) void opt_reset_kernel(int n, uint64_t key, int reset_ratio,
+                                                        const uint64_t *__restrict__ opt_keys, uint32_t *state,
+                                                        pqn_step_out_t out, int32_t *__restrict__ slot_out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const uint64_t mine = opt_keys[e];
+  int slot = -1;
+  if (mine != ~(uint64_t)0) {
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += opt_keys[j] < mine;   // wave-uniform address: one broadcast load per step
+    const int num_resets = n / reset_ratio;
+    slot = rank < num_resets ? rank : e / reset_ratio;
+    Env env;
+    env.reset(pqn_fold(key, 1u), (uint32_t)slot);
+    LogRec log;
+    log.zero();
+    uint32_t w[Env::ENV_WORDS];
+    env.pack(w);
+#pragma unroll
+    for (int i = 0; i < Env::ENV_WORDS; ++i) state[(size_t)i * n + e] = w[i];
+    log.store(state, n, e, Env::ENV_WORDS);
+    if constexpr (MINATAR) {
+      uint32_t b[Env::OBS_WORDS];
+      env.obs_bits(b);
+      if (out.obs_bits)
+        for (int i = 0; i < Env::OBS_WORDS; ++i) out.obs_bits[(size_t)e * Env::OBS_WORDS + i] = b[i];
+      if (out.obs)
+        for (int i = 0; i < Env::OBS_SIZE; ++i) out.obs[(size_t)e * Env::OBS_SIZE + i] = (float)((b[i >> 5] >> (i & 31)) & 1u);
+    } else {
+      if (out.obs) {
+        float o[Env::OBS_SIZE];
+        env.obs_f32(o);
+        for (int i = 0; i < Env::OBS_SIZE; ++i) out.obs[(size_t)e * Env::OBS_SIZE + i] = o[i];
+      }
+    }
+  }
+  if (slot_out) slot_out[e] = slot;
+}
+
+// ===========================================================================
 // MinAtar kernels: EPB envs per 256-thread workgroup.  Lanes [0,EPB) run the
 // transition rule; then all 256 lanes expand the packed grid from LDS to f32.
 // N=4096 -> 256 workgroups at EPB=16 (one per CU).
@@ -25,7 +82,10 @@ template <class Env, int EPB, bool IS_RESET>
 __global__ __launch_bounds__(256) void minatar_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev,
                                                       float rscale, const uint32_t *state_in,
                                                       uint32_t *state_out,   // may alias (in-place step)
-                                                      const int32_t *__restrict__ action, pqn_step_out_t out) {
+                                                      const int32_t *__restrict__ action, pqn_step_out_t out,
+                                                      uint64_t *__restrict__ opt_keys) {
+  // opt_keys != NULL: the step half of OptimisticResetVecEnvWrapper.step -- no reset here, finished envs publish the
+  // sort key that ranks them for the reset pass (opt_reset_kernel)
   __shared__ __attribute__((aligned(16))) uint32_t s_bits[EPB * Env::OBS_WORDS];
   if (key_dev) key = *key_dev;  // graph-replayable launches read the step key from device memory
   const int tid = threadIdx.x;
@@ -46,7 +106,8 @@ __global__ __launch_bounds__(256) void minatar_kernel(int n, uint64_t key, const
       int done = 0;
       const float reward = env.step(action[e], key, (uint32_t)e, done);
       log.step(reward, done);
-      if (done) env.reset(key, (uint32_t)e);  // select(done, reset_env, step_env)
+      if (opt_keys) opt_keys[e] = opt_choice_key(key, (uint32_t)e, done);
+      else if (done) env.reset(key, (uint32_t)e);  // select(done, reset_env, step_env)
       out.reward[e] = reward * rscale;
       out.done[e] = (uint8_t)done;
       if (out.discount) out.discount[e] = done ? 0.0f : 1.0f;
@@ -88,7 +149,7 @@ __global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const ui
                                                    float rscale, const uint32_t *state_in,
                                                    uint32_t *state_out,   // may alias (in-place step)
                                                    const int32_t *__restrict__ action, pqn_step_out_t out,
-                                                   int n_per_seed, int key_stride) {
+                                                   int n_per_seed, int key_stride, uint64_t *__restrict__ opt_keys) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   // seed batching: env e of the stacked batch is env e_rng of seed e / n_per_seed, driven by that seed's key
@@ -109,7 +170,8 @@ __global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const ui
     int done = 0;
     const float reward = env.step(action[e], key, (uint32_t)e_rng, done);
     log.step(reward, done);
-    if (done) env.reset(key, (uint32_t)e_rng);
+    if (opt_keys) opt_keys[e] = opt_choice_key(key, (uint32_t)e, done);
+    else if (done) env.reset(key, (uint32_t)e_rng);
     out.reward[e] = reward * rscale;
     out.done[e] = (uint8_t)done;
     if (out.discount) out.discount[e] = done ? 0.0f : 1.0f;
@@ -192,37 +254,38 @@ extern "C" int pqn_env_spec(int env_id, pqn_env_spec_t *spec) {
 
 template <class Env, bool IS_RESET>
 static void launch_minatar(int n, uint64_t key, const uint64_t *key_dev, float rscale, const uint32_t *si,
-                           uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st) {
+                           uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st,
+                           uint64_t *opt_keys = nullptr) {
   // EPB=16 keeps >=256 workgroups at N=4096; larger batches use 64 envs/WG.
   if (n <= 32768) {
     hipLaunchKernelGGL((minatar_kernel<Env, 16, IS_RESET>), dim3((n + 15) / 16), dim3(256), 0, st, n, key, key_dev, rscale,
-                       si, so, action, out);
+                       si, so, action, out, opt_keys);
   } else {
     hipLaunchKernelGGL((minatar_kernel<Env, 64, IS_RESET>), dim3((n + 63) / 64), dim3(256), 0, st, n, key, key_dev, rscale,
-                       si, so, action, out);
+                       si, so, action, out, opt_keys);
   }
 }
 
 template <bool IS_RESET>
 static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, float rscale, const uint32_t *si,
                     uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0,
-                    int key_stride = 0) {
+                    int key_stride = 0, uint64_t *opt_keys = nullptr) {
   if (n_per_seed > 0 && env_id != PQN_ENV_CARTPOLE) {
     pqn_set_error("seed-batched env.step is implemented for the flat-observation envs (the MinAtar path batches seeds "
                   "inside pqn_cnn_rollout_seeds)");
     return PQN_E_UNSUPPORTED;
   }
   switch (env_id) {
-    case PQN_ENV_BREAKOUT: launch_minatar<Breakout, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st); break;
-    case PQN_ENV_ASTERIX: launch_minatar<Asterix, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st); break;
-    case PQN_ENV_FREEWAY: launch_minatar<Freeway, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st); break;
+    case PQN_ENV_BREAKOUT: launch_minatar<Breakout, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st, opt_keys); break;
+    case PQN_ENV_ASTERIX: launch_minatar<Asterix, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st, opt_keys); break;
+    case PQN_ENV_FREEWAY: launch_minatar<Freeway, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st, opt_keys); break;
     case PQN_ENV_SPACEINVADERS:
-      launch_minatar<SpaceInvaders, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st);
+      launch_minatar<SpaceInvaders, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st, opt_keys);
       break;
     case PQN_ENV_CARTPOLE:
       PQN_REQUIRE(out.obs_bits == nullptr, "CartPole-v1 has no packed observation");
       hipLaunchKernelGGL((flat_kernel<CartPole, IS_RESET>), dim3((n + 255) / 256), dim3(256), 0, st, n, key, key_dev, rscale,
-                         si, so, action, out, n_per_seed, key_stride);
+                         si, so, action, out, n_per_seed, key_stride, opt_keys);
       break;
     default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
   }
@@ -245,6 +308,29 @@ extern "C" int pqn_env_step(int env_id, int32_t n, uint64_t key, const uint32_t 
   PQN_REQUIRE(state_in && state_out && action && out, "pqn_env_step: NULL argument");
   PQN_REQUIRE(out->reward && out->done, "pqn_env_step: out->reward and out->done are required");
   return dispatch<false>(env_id, n, key, nullptr, 1.0f, state_in, state_out, action, *out, (hipStream_t)stream);
+}
+
+extern "C" int pqn_env_step_optimistic(int env_id, int32_t n, uint64_t key, int32_t reset_ratio, const uint32_t *state_in,
+                                       uint32_t *state_out, const int32_t *action, const pqn_step_out_t *out,
+                                       uint64_t *scratch, int32_t *slot_out, void *stream) {
+  PQN_REQUIRE(n > 0, "pqn_env_step_optimistic: n must be > 0 (got %d)", n);
+  PQN_REQUIRE(state_in && state_out && action && out && scratch, "pqn_env_step_optimistic: NULL argument");
+  PQN_REQUIRE(out->reward && out->done, "pqn_env_step_optimistic: out->reward and out->done are required");
+  PQN_REQUIRE(reset_ratio > 0 && n % reset_ratio == 0,
+              "pqn_env_step_optimistic: reset ratio %d must perfectly divide num envs %d", reset_ratio, n);   // :96-98
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = dispatch<false>(env_id, n, key, nullptr, 1.0f, state_in, state_out, action, *out, st, 0, 0, scratch);
+  if (rc != PQN_OK) return rc;
+  const dim3 g((n + 255) / 256), b(256);
+  switch (env_id) {
+    case PQN_ENV_BREAKOUT: hipLaunchKernelGGL((opt_reset_kernel<Breakout, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
+    case PQN_ENV_ASTERIX: hipLaunchKernelGGL((opt_reset_kernel<Asterix, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
+    case PQN_ENV_FREEWAY: hipLaunchKernelGGL((opt_reset_kernel<Freeway, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
+    case PQN_ENV_SPACEINVADERS: hipLaunchKernelGGL((opt_reset_kernel<SpaceInvaders, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
+    case PQN_ENV_CARTPOLE: hipLaunchKernelGGL((opt_reset_kernel<CartPole, false>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
+    default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
+  }
+  return pqn_check_launch("pqn_env_step_optimistic");
 }
 
 // internal (pqn_update.hip): step key read from device memory, reward scaled at the source

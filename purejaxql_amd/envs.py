@@ -211,6 +211,82 @@ class FlattenObservationWrapper(GymnaxWrapper):
         return obs.reshape(obs.shape[0], -1), state, reward, done, info
 
 
+class BatchEnvWrapper(GymnaxWrapper):
+    """utils/craftax_wrappers.py:21-45: reset / step of `num_envs` envs with ONE key (the reference vmaps the wrapped
+    env over split keys; here the env kernels are batched already and element e draws threefry(key, (e, stream)))."""
+
+    def __init__(self, env, num_envs: int):
+        super().__init__(env)
+        self.num_envs = int(num_envs)
+
+    def reset(self, rng, params=None, **kw):
+        return self._env.reset(rng, params, self.num_envs, **kw)
+
+    def step(self, rng, state, action, params=None, **kw):
+        return self._env.step(rng, state, action, params, **kw)
+
+
+class OptimisticResetVecEnvWrapper(GymnaxWrapper):
+    """utils/craftax_wrappers.py:83-148: every env steps, only num_envs / reset_ratio fresh states are generated per
+    step and handed to the envs that finished (pqn_env_step_optimistic).  Wrap LogWrapper(env), as pqn_craftax.py:99-108
+    does: the LogWrapper record of a finished env then restarts from zero with the rest of its state."""
+
+    def __init__(self, env, num_envs: int, reset_ratio: int):
+        super().__init__(env)
+        self.num_envs, self.reset_ratio = int(num_envs), int(reset_ratio)
+        assert self.num_envs % self.reset_ratio == 0, "Reset ratio must perfectly divide num envs."   # (:96-98)
+        self.num_resets = self.num_envs // self.reset_ratio
+        self._scratch = None
+
+    def reset(self, rng, params=None, **kw):
+        return self._env.reset(rng, params, self.num_envs, **kw)
+
+    def step(self, rng, state, action, params=None, *, want_obs: bool = True, want_bits: bool = False,
+             inplace: bool = False, want_slots: bool = False):
+        base = self._env
+        log_info = False
+        while not isinstance(base, Environment):
+            log_info = log_info or isinstance(base, LogWrapper)
+            base = base._env
+        lib = _lib.load()
+        n, dev = state.num_envs, base.device
+        if n != self.num_envs:
+            raise ValueError(f"state holds {n} envs, the wrapper was built for {self.num_envs}")
+        if action.dtype != torch.int32:
+            action = action.to(torch.int32)
+        if self._scratch is None or self._scratch.device != state.words.device:
+            self._scratch = torch.empty(n, dtype=torch.int64, device=dev)
+        new_words = state.words if inplace else torch.empty_like(state.words)
+        obs, bits = base._alloc_obs(n, want_obs, want_bits)
+        reward = torch.empty(n, dtype=torch.float32, device=dev)
+        done = torch.empty(n, dtype=torch.uint8, device=dev)
+        discount = torch.empty(n, dtype=torch.float32, device=dev)
+        out = _lib.StepOut(obs=_lib.ptr(obs), obs_bits=_lib.ptr(bits), reward=_lib.ptr(reward), done=_lib.ptr(done),
+                           discount=_lib.ptr(discount))
+        info = {"discount": discount}
+        if log_info:
+            rer = torch.empty(n, dtype=torch.float32, device=dev)
+            rel = torch.empty(n, dtype=torch.int32, device=dev)
+            ts = torch.empty(n, dtype=torch.int32, device=dev)
+            out.returned_episode_returns, out.returned_episode_lengths, out.timestep = _lib.ptr(rer), _lib.ptr(rel), _lib.ptr(ts)
+        slots = torch.empty(n, dtype=torch.int32, device=dev) if want_slots else None
+        _lib.check(lib.pqn_env_step_optimistic(base.env_id, n, rng, self.reset_ratio, _lib.ptr(state.words),
+                                               _lib.ptr(new_words), _lib.ptr(action), C.byref(out),
+                                               _lib.ptr(self._scratch), _lib.ptr(slots), _lib.stream_ptr()),
+                   "pqn_env_step_optimistic")
+        done_b = done.view(torch.bool)
+        if log_info:
+            info.update(returned_episode_returns=rer, returned_episode_lengths=rel, timestep=ts, returned_episode=done_b)
+        if want_slots:
+            info["reset_slot"] = slots
+        new_state = EnvState(new_words)
+        if isinstance(self._env, FlattenObservationWrapper) and obs is not None:
+            obs = obs.reshape(n, -1)
+        if want_bits:
+            return (obs, bits), new_state, reward, done_b, info
+        return obs, new_state, reward, done_b, info
+
+
 def make(env_name: str, device=None, **env_kwargs):
     """gymnax.make(name) -> (env, env_params)  (pqn_minatar.py:103)."""
     env = Environment(env_name, device=device)
