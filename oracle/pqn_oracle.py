@@ -227,10 +227,15 @@ def cnn_norm_names(norm_type):
     return "", ""
 
 
-def mlp_norm_name(norm_type, l):
+def bn_module(renorm):
+    # nn.BatchNorm in pqn_minatar.py / pqn_gymnax.py, BatchRenorm in pqn_craftax.py:33-62 (flax auto-name stems)
+    return "BatchRenorm" if renorm else "BatchNorm"
+
+
+def mlp_norm_name(norm_type, l, renorm=False):
     # BatchNorm_0 is the input / dummy BatchNorm (pqn_gymnax.py:39-43): hidden layers get BatchNorm_1..
     k = _norm_kind(norm_type)
-    return f"LayerNorm_{l}" if k == "layer_norm" else (f"BatchNorm_{l + 1}" if k == "batch_norm" else "")
+    return f"LayerNorm_{l}" if k == "layer_norm" else (f"{bn_module(renorm)}_{l + 1}" if k == "batch_norm" else "")
 
 
 def cnn_shapes(obs_shape, a, norm_type="layer_norm"):
@@ -247,12 +252,12 @@ def cnn_shapes(obs_shape, a, norm_type="layer_norm"):
     return s
 
 
-def mlp_shapes(d, a, hidden, layers, norm_type="layer_norm"):
-    s = OrderedDict([("BatchNorm_0/scale", (d,)), ("BatchNorm_0/bias", (d,))])
+def mlp_shapes(d, a, hidden, layers, norm_type="layer_norm", renorm=False):
+    s = OrderedDict([(bn_module(renorm) + "_0/scale", (d,)), (bn_module(renorm) + "_0/bias", (d,))])
     for l in range(layers):
         s[f"Dense_{l}/kernel"] = (d, hidden)
         s[f"Dense_{l}/bias"] = (hidden,)
-        n = mlp_norm_name(norm_type, l)
+        n = mlp_norm_name(norm_type, l, renorm)
         if n:
             s[n + "/scale"] = (hidden,)
             s[n + "/bias"] = (hidden,)
@@ -262,23 +267,25 @@ def mlp_shapes(d, a, hidden, layers, norm_type="layer_norm"):
     return s
 
 
-def init_batch_stats(kind, obs_shape, hidden, layers, norm_type, norm_input):
+def init_batch_stats(kind, obs_shape, hidden, layers, norm_type, norm_input, renorm=False):
     """variables["batch_stats"]: running mean 0 / var 1 of every BatchNorm whose output is used (the
     dummy input BatchNorm of NORM_INPUT=False, pqn_minatar.py:63-65, is dead state and not tracked)."""
     feats = OrderedDict()
     if norm_input:
-        feats["BatchNorm_0"] = int(obs_shape[-1])
+        feats[bn_module(renorm) + "_0"] = int(obs_shape[-1])
     if _norm_kind(norm_type) == "batch_norm":
         if kind == "cnn":
             n0, n1 = cnn_norm_names(norm_type)
             feats[n0], feats[n1] = 16, 128
         else:
             for l in range(layers):
-                feats[mlp_norm_name(norm_type, l)] = hidden
+                feats[mlp_norm_name(norm_type, l, renorm)] = hidden
     st = OrderedDict()
     for name, f in feats.items():
         st[name + "/mean"] = np.zeros(f, np.float32)
         st[name + "/var"] = np.ones(f, np.float32)
+        if renorm:
+            st[name + "/steps"] = 0      # utils/batch_renorm.py:71-76
     return st
 
 
@@ -404,11 +411,36 @@ def brn_bwd(dy, scale, cache):
     return dx.reshape(dy.shape).astype(np.float32), dscale.astype(np.float32), dbias.astype(np.float32)
 
 
-def _norm_fwd(norm, x, p, name, train, stats, new_stats):
+def _brn_named_fwd(x, scale, bias, name, train, stats, new_stats):
+    """BatchRenorm module `name` of the Craftax network (pqn_craftax.py:43-51) on the flat batch_stats dict."""
+    st = {k: stats[name + "/" + k] for k in ("mean", "var", "steps")}
+    ns = {} if (train and new_stats is not None) else None
+    y, cache = brn_fwd(x, scale, bias, st, train, ns)
+    if ns:
+        new_stats.update({name + "/" + k: v for k, v in ns.items()})
+    return y, ("brn", cache, train)
+
+
+def _batchnorm_fwd(x, scale, bias, name, train, stats, new_stats, renorm):
+    if renorm:
+        return _brn_named_fwd(x, scale, bias, name, train, stats, new_stats)
+    return _bn_fwd(x, scale, bias, name, train, stats, new_stats)
+
+
+def _batchnorm_bwd(dy, scale, cache):
+    if isinstance(cache, tuple) and len(cache) == 3 and isinstance(cache[0], str) and cache[0] == "brn":
+        _tag, c, train = cache
+        if not train:
+            raise ValueError("backward through an eval-mode BatchRenorm is not used on this path")
+        return brn_bwd(dy, scale, c)
+    return _bn_bwd(dy, scale, cache)
+
+
+def _norm_fwd(norm, x, p, name, train, stats, new_stats, renorm=False):
     if norm == "layer_norm":
         return _ln_fwd(x, p[name + "/scale"], p[name + "/bias"])
     if norm == "batch_norm":
-        return _bn_fwd(x, p[name + "/scale"], p[name + "/bias"], name, train, stats, new_stats)
+        return _batchnorm_fwd(x, p[name + "/scale"], p[name + "/bias"], name, train, stats, new_stats, renorm)
     return x, None
 
 
@@ -416,20 +448,21 @@ def _norm_bwd(norm, dy, p, name, cache, g):
     if norm == "layer_norm":
         dy, g[name + "/scale"], g[name + "/bias"] = _ln_bwd(dy, p[name + "/scale"], cache)
     elif norm == "batch_norm":
-        dy, g[name + "/scale"], g[name + "/bias"] = _bn_bwd(dy, p[name + "/scale"], cache)
+        dy, g[name + "/scale"], g[name + "/bias"] = _batchnorm_bwd(dy, p[name + "/scale"], cache)
     return dy
 
 
 def net_forward(kind, p, x, use_ln=True, layers=2, want_cache=False, norm_type=None, norm_input=False,
-                train=False, stats=None, new_stats=None):
+                train=False, stats=None, new_stats=None, renorm=False):
     """QNetwork.apply({"params": p, "batch_stats": stats}, x, train) (pqn_minatar.py:54-69,
     pqn_gymnax.py:29-58).  x float32.  norm_type defaults to layer_norm / none by `use_ln`."""
     norm = _norm_kind(norm_type) if norm_type is not None else ("layer_norm" if use_ln else "none")
     cache = {}
     x = x.astype(np.float32)
     cin = None
+    bn0 = bn_module(renorm) + "_0"
     if norm_input:                                                         # :61-62 (and no /255 on this branch)
-        x, cin = _bn_fwd(x, p["BatchNorm_0/scale"], p["BatchNorm_0/bias"], "BatchNorm_0", train, stats, new_stats)
+        x, cin = _batchnorm_fwd(x, p[bn0 + "/scale"], p[bn0 + "/bias"], bn0, train, stats, new_stats, renorm)
     if kind == "cnn":
         b = x.shape[0]
         xs = x if norm_input else (x / np.float32(255.0)).astype(np.float32)   # pqn_minatar.py:66
@@ -449,28 +482,54 @@ def net_forward(kind, p, x, use_ln=True, layers=2, want_cache=False, norm_type=N
     y = hs[0]
     for l in range(layers):
         y = y @ p[f"Dense_{l}/kernel"] + p[f"Dense_{l}/bias"]
-        y, c = _norm_fwd(norm, y, p, mlp_norm_name(norm, l), train, stats, new_stats)
+        y, c = _norm_fwd(norm, y, p, mlp_norm_name(norm, l, renorm), train, stats, new_stats, renorm)
         cs.append(c)
         y = np.maximum(y, 0)
         hs.append(y)
     q = y @ p[f"Dense_{layers}/kernel"] + p[f"Dense_{layers}/bias"]
     if want_cache:
-        return q.astype(np.float32), dict(hs=hs, cs=cs, cin=cin, norm=norm)
+        return q.astype(np.float32), dict(hs=hs, cs=cs, cin=cin, norm=norm, renorm=renorm)
     return q.astype(np.float32)
 
 
 def net_loss_grad(kind, p, shapes, x, action, target, use_ln=True, layers=2, norm_type=None, norm_input=False,
-                  stats=None, new_stats=None):
+                  stats=None, new_stats=None, renorm=False):
     """loss = 0.5*mean((q[a]-target)^2) and d loss / d theta (flat), pqn_minatar.py:271-291 (train=True)."""
     q, cache = net_forward(kind, p, x, use_ln, layers, want_cache=True, norm_type=norm_type, norm_input=norm_input,
-                           train=True, stats=stats, new_stats=new_stats)
-    norm = cache["norm"]
+                           train=True, stats=stats, new_stats=new_stats, renorm=renorm)
     b = x.shape[0]
     chosen = q[np.arange(b), action]
     diff = (chosen - target).astype(np.float32)
     loss = np.float32(0.5) * np.mean(diff * diff, dtype=np.float32)
     dq = np.zeros_like(q)
     dq[np.arange(b), action] = diff / np.float32(b)
+    return loss, chosen, _net_backward(kind, p, shapes, x, cache, dq, layers, norm_input)
+
+
+def net_loss_grad_1step(kind, p, shapes, x, x_next, action, reward, done, gamma, use_ln=True, layers=2, norm_type=None,
+                        norm_input=False, stats=None, new_stats=None, renorm=False):
+    """The `Q_LAMBDA: False` branch of _loss_fn (pqn_craftax.py:287-304): obs and next_obs go through the train-mode
+    network as ONE batch (batch statistics over both halves), q_next carries no gradient,
+    target = reward + (1 - done) * gamma * max_a q_next, loss = 0.5 * mean((q[a] - target)^2) over the obs half."""
+    b = x.shape[0]
+    xx = np.concatenate((x, x_next)).astype(np.float32)                   # :296
+    q_all, cache = net_forward(kind, p, xx, use_ln, layers, want_cache=True, norm_type=norm_type, norm_input=norm_input,
+                               train=True, stats=stats, new_stats=new_stats, renorm=renorm)
+    q, q_next = q_all[:b], q_all[b:]                                       # :300
+    target = (reward + (np.float32(1) - done.astype(np.float32)) * np.float32(gamma) * q_next.max(-1)).astype(np.float32)   # :301-306
+    chosen = q[np.arange(b), action]
+    diff = (chosen - target).astype(np.float32)
+    loss = np.float32(0.5) * np.mean(diff * diff, dtype=np.float32)
+    dq = np.zeros_like(q_all)                                              # stop_gradient(q_next): zero rows
+    dq[np.arange(b), action] = diff / np.float32(b)
+    return loss, chosen, _net_backward(kind, p, shapes, xx, cache, dq, layers, norm_input)
+
+
+def _net_backward(kind, p, shapes, x, cache, dq, layers, norm_input):
+    """d (sum of q * dq) / d theta, flat in `shapes` order, from the forward cache of net_forward(want_cache=True)."""
+    norm = cache["norm"]
+    renorm = cache.get("renorm", False)
+    b = x.shape[0]
     g = {k: np.zeros(s, np.float32) for k, s in shapes.items()}
     if kind == "cnn":
         n0, n1 = cnn_norm_names(norm)
@@ -495,34 +554,39 @@ def net_loss_grad(kind, p, shapes, x, action, target, use_ln=True, layers=2, nor
                     dxn[:, ky:ky + x.shape[1] - 2, kx:kx + x.shape[2] - 2, :] += dpt[:, :, :, ky, kx, :]
             _dx, g["BatchNorm_0/scale"], g["BatchNorm_0/bias"] = _bn_bwd(dxn, p["BatchNorm_0/scale"], cache["cin"])
     else:
+        bn0 = bn_module(renorm) + "_0"
         hs, cs = cache["hs"], cache["cs"]
         g[f"Dense_{layers}/kernel"] = hs[-1].T @ dq
         g[f"Dense_{layers}/bias"] = dq.sum(0)
         d = dq @ p[f"Dense_{layers}/kernel"].T
         for l in reversed(range(layers)):
             d = d * (hs[l + 1] > 0)
-            d = _norm_bwd(norm, d, p, mlp_norm_name(norm, l), cs[l], g)
+            d = _norm_bwd(norm, d, p, mlp_norm_name(norm, l, renorm), cs[l], g)
             g[f"Dense_{l}/kernel"] = hs[l].T @ d
             g[f"Dense_{l}/bias"] = d.sum(0)
             d = d @ p[f"Dense_{l}/kernel"].T
         if norm_input:
-            _dx, g["BatchNorm_0/scale"], g["BatchNorm_0/bias"] = _bn_bwd(d, p["BatchNorm_0/scale"], cache["cin"])
-    flat = np.concatenate([g[k].reshape(-1).astype(np.float32) for k in shapes])
-    return loss, chosen, flat
+            _dx, g[bn0 + "/scale"], g[bn0 + "/bias"] = _batchnorm_bwd(d, p[bn0 + "/scale"], cache["cin"])
+    return np.concatenate([g[k].reshape(-1).astype(np.float32) for k in shapes])
 
 
 # ---- whole loop -----------------------------------------------------------------------------
 INFO_KEYS = ("discount", "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode")
 
 
-def make_train(config: Dict[str, Any]):
+def make_train(config: Dict[str, Any], script: str = "gymnax"):
     """numpy/C restatement of make_train (pqn_minatar.py:89-431) with the SAME key
-    schedule as purejaxql_amd.pqn (documented there)."""
+    schedule as purejaxql_amd.pqn (documented there).
+    script="craftax": the twin of pqn_craftax.py:82-468 -- flat observations into the BatchRenorm MLP (:33-62), the env
+    batched by OptimisticResetVecEnvWrapper(LogWrapper(env)) or BatchEnvWrapper(LogWrapper(auto-reset env)) (:96-114), the
+    `Q_LAMBDA` switch of the loss (:277-304) and done-weighted info means (:364-369, :433-437)."""
+    craftax = script == "craftax"
     config["NUM_UPDATES"] = config["TOTAL_TIMESTEPS"] // config["NUM_STEPS"] // config["NUM_ENVS"]
     config["NUM_UPDATES_DECAY"] = config["TOTAL_TIMESTEPS_DECAY"] // config["NUM_STEPS"] // config["NUM_ENVS"]
     assert (config["NUM_STEPS"] * config["NUM_ENVS"]) % config["NUM_MINIBATCHES"] == 0
     env = OracleEnv(config["ENV_NAME"])
-    kind = "cnn" if len(env.obs_shape) == 3 else "mlp"
+    kind = "cnn" if len(env.obs_shape) == 3 and not craftax else "mlp"
+    obs_shape = env.obs_shape if kind == "cnn" else (int(np.prod(env.obs_shape)),)   # the Craftax network sees flat observations
     N, T = int(config["NUM_ENVS"]), int(config["NUM_STEPS"])
     NU, MB, EP = int(config["NUM_UPDATES"]), int(config["NUM_MINIBATCHES"]), int(config["NUM_EPOCHS"])
     B = N * T // MB
@@ -531,10 +595,22 @@ def make_train(config: Dict[str, Any]):
     use_ln = config["NORM_TYPE"] == "layer_norm"
     norm_type, norm_input = config["NORM_TYPE"], bool(config.get("NORM_INPUT", False))
     hidden = int(config.get("HIDDEN_SIZE", 128))
-    shapes = cnn_shapes(env.obs_shape, A, norm_type) if kind == "cnn" else mlp_shapes(env.obs_shape[0], A, hidden, layers, norm_type)
-    nkw = dict(norm_type=norm_type, norm_input=norm_input)
+    shapes = cnn_shapes(env.obs_shape, A, norm_type) if kind == "cnn" else mlp_shapes(obs_shape[0], A, hidden, layers, norm_type, craftax)
+    nkw = dict(norm_type=norm_type, norm_input=norm_input, renorm=craftax)
     test_on = bool(config.get("TEST_DURING_TRAINING", False))
-    test_steps = env.max_steps if kind == "cnn" else int(config.get("TEST_NUM_STEPS", env.max_steps))
+    test_steps = env.max_steps if (kind == "cnn" and not craftax) else int(config.get("TEST_NUM_STEPS", env.max_steps))
+    q_lambda_loss = bool(config.get("Q_LAMBDA", False)) if craftax else True      # pqn_craftax.py:277
+    optimistic = craftax and bool(config.get("USE_OPTIMISTIC_RESETS", False))
+    ratio = int(config.get("OPTIMISTIC_RESET_RATIO", 16))
+
+    def flat(o):
+        return o.reshape(o.shape[0], -1) if kind == "mlp" else o
+
+    def env_step(key, st, action, n):
+        """the batched env of pqn_craftax.py:96-114 / the vmapped gymnax env of pqn_minatar.py:110-112"""
+        if optimistic:
+            return env.step_optimistic(key, st, action, min(ratio, n))
+        return env.step(key, st, action)
     gamma, lam, rs = float(config["GAMMA"]), float(config["LAMBDA"]), float(config.get("REW_SCALE", 1))
 
     def train(rng: int, init_theta: np.ndarray, max_updates: int = None, shard_world: int = 1):
@@ -553,7 +629,7 @@ def make_train(config: Dict[str, Any]):
         theta = np.ascontiguousarray(init_theta, np.float32).copy()
         m, v = np.zeros_like(theta), np.zeros_like(theta)
         p = unflatten(theta, shapes)
-        stats = init_batch_stats(kind, env.obs_shape, hidden, layers, norm_type, norm_input)   # train_state.batch_stats
+        stats = init_batch_stats(kind, obs_shape, hidden, layers, norm_type, norm_input, craftax)   # train_state.batch_stats
         lr_steps = config["NUM_UPDATES_DECAY"] * MB * EP
         n_updates = grad_steps = timesteps = 0
         runs = [0]
@@ -569,8 +645,8 @@ def make_train(config: Dict[str, Any]):
             cnt = 0.0
             for t in range(test_steps):
                 sk = fold_in(k, 1 + t)
-                a, _ = eps_greedy(net_forward(kind, p, obs, use_ln, layers, stats=stats, **nkw), float(config["EPS_TEST"]), sk)
-                obs, st, _r, done, info = env.step(sk, st, a)
+                a, _ = eps_greedy(net_forward(kind, p, flat(obs), use_ln, layers, stats=stats, **nkw), float(config["EPS_TEST"]), sk)
+                obs, st, _r, done, info = env_step(sk, st, a, nt)
                 cnt += float(done.sum())
                 for kk in INFO_KEYS:
                     sums[kk] += float((info[kk].astype(np.float64) * done).sum())
@@ -588,8 +664,8 @@ def make_train(config: Dict[str, Any]):
             eps = linear_schedule(config["EPS_START"], config["EPS_FINISH"], config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"], n_updates)
             info_means = {kk: [] for kk in INFO_KEYS}
             for r, sh in enumerate(shards):
-                O = np.zeros((T + 1, N, *env.obs_shape), np.float32)
-                O[0] = sh["obs"]
+                O = np.zeros((T + 1, N, *obs_shape), np.float32)
+                O[0] = flat(sh["obs"])
                 Aa = np.zeros((T, N), np.int32)
                 R = np.zeros((T, N), np.float32)
                 D = np.zeros((T, N), bool)
@@ -599,16 +675,24 @@ def make_train(config: Dict[str, Any]):
                     sk = fold_in(Kr[r][2], u * T + t)
                     q = net_forward(kind, p, O[t], use_ln, layers, stats=stats, **nkw)
                     Aa[t], QM[t] = eps_greedy(q, np.float32(eps), sk)
-                    O[t + 1], sh["st"], rr, D[t], info = env.step(sk, sh["st"], Aa[t])
+                    o_next, sh["st"], rr, D[t], info = env_step(sk, sh["st"], Aa[t], N)
+                    O[t + 1] = flat(o_next)
                     R[t] = np.float32(rs) * rr if rs != 1.0 else rr
                     for kk in INFO_KEYS:
                         infos[kk].append(info[kk])
                 last_q = net_forward(kind, p, O[T], use_ln, layers, stats=stats, **nkw).max(-1)
                 tgt = q_lambda(R, D, QM, last_q, gamma, lam, quirk=True)
-                sh["of"], sh["af"], sh["tf"] = O[:T].reshape(T * N, *env.obs_shape), Aa.reshape(-1), tgt.reshape(-1)
+                sh["of"], sh["af"], sh["tf"] = O[:T].reshape(T * N, *obs_shape), Aa.reshape(-1), tgt.reshape(-1)
+                sh["nf"], sh["rf"], sh["df"] = O[1:].reshape(T * N, *obs_shape), R.reshape(-1), D.reshape(-1)
                 sh["obs"] = O[T]
+                dmask = np.stack(infos["returned_episode"]).astype(np.float64)
                 for kk in INFO_KEYS:
-                    info_means[kk].append(float(np.mean(np.stack(infos[kk]).astype(np.float32))))
+                    x = np.stack(infos[kk])
+                    if craftax:   # (x * returned_episode).sum() / returned_episode.sum()  (pqn_craftax.py:364-369)
+                        with np.errstate(invalid="ignore", divide="ignore"):
+                            info_means[kk].append(float((x.astype(np.float64) * dmask).sum() / dmask.sum()))
+                    else:
+                        info_means[kk].append(float(np.mean(x.astype(np.float32))))
             timesteps += T * N * W
             losses, qvs = [], []
             for ep in range(EP):
@@ -618,8 +702,13 @@ def make_train(config: Dict[str, Any]):
                     for r, sh in enumerate(shards):
                         idx = perms[r][mb * B:(mb + 1) * B]
                         new_stats = {}
-                        loss, chosen, g = net_loss_grad(kind, p, shapes, sh["of"][idx], sh["af"][idx], sh["tf"][idx], use_ln,
-                                                        layers, stats=stats, new_stats=new_stats, **nkw)
+                        if q_lambda_loss:
+                            loss, chosen, g = net_loss_grad(kind, p, shapes, sh["of"][idx], sh["af"][idx], sh["tf"][idx], use_ln,
+                                                            layers, stats=stats, new_stats=new_stats, **nkw)
+                        else:
+                            loss, chosen, g = net_loss_grad_1step(kind, p, shapes, sh["of"][idx], sh["nf"][idx], sh["af"][idx],
+                                                                  sh["rf"][idx], sh["df"][idx], gamma, use_ln, layers,
+                                                                  stats=stats, new_stats=new_stats, **nkw)
                         gs.append(g)
                         ls.append(loss)
                         cs.append(chosen.mean(dtype=np.float32))
@@ -643,7 +732,7 @@ def make_train(config: Dict[str, Any]):
                 mm.update({f"test/{k}": float(v2) for k, v2 in tm.items()})
             metrics.append(mm)
         return {"theta": theta, "metrics": metrics, "env_state": shards[0]["st"], "last_obs": shards[0]["obs"],
-                "batch_stats": stats, "shards": shards}
+                "batch_stats": stats, "shards": shards, "opt_mu": m, "opt_nu": v}
 
     train.shapes = shapes
     train.kind = kind

@@ -244,9 +244,10 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
     def step(self, rng, state, action, params=None, *, want_obs: bool = True, want_bits: bool = False,
              inplace: bool = False, want_slots: bool = False):
         base = self._env
-        log_info = False
+        log_info = flatten = False
         while not isinstance(base, Environment):
             log_info = log_info or isinstance(base, LogWrapper)
+            flatten = flatten or isinstance(base, FlattenObservationWrapper)
             base = base._env
         lib = _lib.load()
         n, dev = state.num_envs, base.device
@@ -280,7 +281,7 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
         if want_slots:
             info["reset_slot"] = slots
         new_state = EnvState(new_words)
-        if isinstance(self._env, FlattenObservationWrapper) and obs is not None:
+        if flatten and obs is not None:
             obs = obs.reshape(n, -1)
         if want_bits:
             return (obs, bits), new_state, reward, done_b, info

@@ -41,11 +41,17 @@ def cnn_norm_names(norm_type) -> Tuple[str, str]:
     return "", ""
 
 
-def mlp_norm_name(norm_type, l: int) -> str:
+def bn_module(renorm: bool) -> str:
+    """flax auto-name stem of the batch normalisation module: nn.BatchNorm in pqn_minatar.py / pqn_gymnax.py,
+    BatchRenorm (utils/batch_renorm.py) in pqn_craftax.py:33-62."""
+    return "BatchRenorm" if renorm else "BatchNorm"
+
+
+def mlp_norm_name(norm_type, l: int, renorm: bool = False) -> str:
     """normalize(x) of hidden layer l in the MLP QNetwork (pqn_gymnax.py:44-54): BatchNorm_0 is the input /
-    dummy BatchNorm, so the hidden-layer BatchNorms are BatchNorm_1.."""
+    dummy BatchNorm, so the hidden-layer BatchNorms are BatchNorm_1..  (BatchRenorm_* in the Craftax script.)"""
     k = _norm_kind(norm_type)
-    return f"LayerNorm_{l}" if k == "layer_norm" else (f"BatchNorm_{l + 1}" if k == "batch_norm" else "")
+    return f"LayerNorm_{l}" if k == "layer_norm" else (f"{bn_module(renorm)}_{l + 1}" if k == "batch_norm" else "")
 
 
 def cnn_param_shapes(obs_shape: Tuple[int, int, int], action_dim: int,
@@ -65,13 +71,14 @@ def cnn_param_shapes(obs_shape: Tuple[int, int, int], action_dim: int,
     return shapes
 
 
-def mlp_param_shapes(obs_dim: int, action_dim: int, hidden: int, layers: int, norm_type="layer_norm"):
-    shapes = OrderedDict([("BatchNorm_0/scale", (obs_dim,)), ("BatchNorm_0/bias", (obs_dim,))])
+def mlp_param_shapes(obs_dim: int, action_dim: int, hidden: int, layers: int, norm_type="layer_norm", renorm=False):
+    bn0 = bn_module(renorm) + "_0"
+    shapes = OrderedDict([(bn0 + "/scale", (obs_dim,)), (bn0 + "/bias", (obs_dim,))])
     d = obs_dim
     for l in range(layers):
         shapes[f"Dense_{l}/kernel"] = (d, hidden)
         shapes[f"Dense_{l}/bias"] = (hidden,)
-        n = mlp_norm_name(norm_type, l)
+        n = mlp_norm_name(norm_type, l, renorm)
         if n:
             shapes[n + "/scale"] = (hidden,)
             shapes[n + "/bias"] = (hidden,)
@@ -81,24 +88,26 @@ def mlp_param_shapes(obs_dim: int, action_dim: int, hidden: int, layers: int, no
     return shapes
 
 
-def batch_stats_shapes(kind: str, obs_shape, hidden: int, layers: int, norm_type, norm_input: bool):
+def batch_stats_shapes(kind: str, obs_shape, hidden: int, layers: int, norm_type, norm_input: bool, renorm: bool = False):
     """The `batch_stats` collection (running mean / var of every BatchNorm whose output is used).  The
     dummy input BatchNorm of NORM_INPUT=False (pqn_minatar.py:63-65) only ever produces dead state -- its
     output is discarded and checkpoints hold `params` only (:467) -- so its statistics are not tracked."""
     feats = OrderedDict()
     if norm_input:
-        feats["BatchNorm_0"] = int(obs_shape[-1])
+        feats[bn_module(renorm) + "_0"] = int(obs_shape[-1])
     if _norm_kind(norm_type) == "batch_norm":
         if kind == "cnn":
             n0, n1 = cnn_norm_names(norm_type)
             feats[n0], feats[n1] = 16, 128
         else:
             for l in range(layers):
-                feats[mlp_norm_name(norm_type, l)] = hidden
+                feats[mlp_norm_name(norm_type, l, renorm)] = hidden
     shapes = OrderedDict()
     for name, f in feats.items():
         shapes[name + "/mean"] = (f,)
         shapes[name + "/var"] = (f,)
+        if renorm:   # BatchRenorm also counts its train-mode calls (utils/batch_renorm.py:71-76,116); r_max / d_max are constants
+            shapes[name + "/steps"] = ()
     return shapes
 
 
@@ -118,13 +127,13 @@ def batch_renorm(x: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, stats
         axes = tuple(range(x.dim() - 1))
         bmean = x.mean(dim=axes)
         bvar = torch.clamp((x * x).mean(dim=axes) - bmean * bmean, min=0.0)        # flax fast variance
-        mean, var = bmean, bvar
-        if int(stats["steps"]) >= BRN_WARMUP:
-            ra_std = torch.sqrt(stats["var"] + BRN_EPS)
-            r = torch.clamp((torch.sqrt(bvar + BRN_EPS) / ra_std).detach(), 1.0 / BRN_R_MAX, BRN_R_MAX)
-            d = torch.clamp(((bmean - stats["mean"]) / ra_std).detach(), -BRN_D_MAX, BRN_D_MAX)
-            var = bvar / (r * r)
-            mean = bmean - d * torch.sqrt(bvar) / r
+        ra_std = torch.sqrt(stats["var"] + BRN_EPS)
+        r = torch.clamp((torch.sqrt(bvar + BRN_EPS) / ra_std).detach(), 1.0 / BRN_R_MAX, BRN_R_MAX)    # (:100-101)
+        d = torch.clamp(((bmean - stats["mean"]) / ra_std).detach(), -BRN_D_MAX, BRN_D_MAX)             # (:102-103)
+        # blended on the device like the reference (:107-109): no host read of the step counter
+        warmed = (torch.as_tensor(stats["steps"], device=x.device) >= BRN_WARMUP).to(x.dtype)
+        var = warmed * (bvar / (r * r)) + (1.0 - warmed) * bvar
+        mean = warmed * (bmean - d * torch.sqrt(bvar) / r) + (1.0 - warmed) * bmean
         if new_stats is not None:
             new_stats["mean"] = BRN_MOMENTUM * stats["mean"] + (1.0 - BRN_MOMENTUM) * bmean.detach()
             new_stats["var"] = BRN_MOMENTUM * stats["var"] + (1.0 - BRN_MOMENTUM) * bvar.detach()
@@ -146,7 +155,8 @@ class QNetwork:
     """
 
     def __init__(self, kind: str, obs_shape, action_dim: int, norm_type: str = "layer_norm",
-                 norm_input: bool = False, hidden_size: int = 128, num_layers: int = 2, device="cuda"):
+                 norm_input: bool = False, hidden_size: int = 128, num_layers: int = 2, device="cuda",
+                 renorm: bool = False):
         self.kind = kind
         self.obs_shape = tuple(obs_shape)
         self.action_dim = int(action_dim)
@@ -155,13 +165,17 @@ class QNetwork:
         self.norm_input = bool(norm_input)
         self.use_ln = self.norm == "layer_norm"
         self.hidden, self.layers = int(hidden_size), int(num_layers)
+        # renorm: the QNetwork of pqn_craftax.py:33-62 -- BatchRenorm wherever the gymnax script has nn.BatchNorm
+        self.renorm = bool(renorm)
+        if self.renorm and kind != "mlp":
+            raise ValueError("BatchRenorm is the Craftax script's MLP Q-network (pqn_craftax.py:33-62)")
         if kind == "cnn":
             self.shapes = cnn_param_shapes(self.obs_shape, action_dim, norm_type)
         elif kind == "mlp":
-            self.shapes = mlp_param_shapes(int(self.obs_shape[0]), action_dim, self.hidden, self.layers, norm_type)
+            self.shapes = mlp_param_shapes(int(self.obs_shape[0]), action_dim, self.hidden, self.layers, norm_type, self.renorm)
         else:
             raise ValueError(kind)
-        self.stats_shapes = batch_stats_shapes(kind, self.obs_shape, self.hidden, self.layers, norm_type, norm_input)
+        self.stats_shapes = batch_stats_shapes(kind, self.obs_shape, self.hidden, self.layers, norm_type, norm_input, self.renorm)
         self.has_batch_stats = len(self.stats_shapes) > 0
         self.offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
@@ -192,7 +206,8 @@ class QNetwork:
 
     def init_batch_stats(self) -> Dict[str, torch.Tensor]:
         """variables["batch_stats"] at init: running mean 0, running var 1 (flax nn.BatchNorm)."""
-        return {k: (torch.ones if k.endswith("/var") else torch.zeros)(s, dtype=torch.float32, device=self.device)
+        return {k: (torch.ones if k.endswith("/var") else torch.zeros)(
+                    s, dtype=torch.int32 if k.endswith("/steps") else torch.float32, device=self.device)
                 for k, s in self.stats_shapes.items()}
 
     def views(self, theta: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -205,7 +220,14 @@ class QNetwork:
     # -- forward (torch ops: plumbing path, also the fp32 torch reference) --------------
     def _bn(self, x, p, name, train, stats, new_stats):
         """flax nn.BatchNorm(use_running_average=not train): statistics over every axis but the last, fast
-        variance E[x^2]-E[x]^2 clamped at 0, running <- 0.99*running + 0.01*batch."""
+        variance E[x^2]-E[x]^2 clamped at 0, running <- 0.99*running + 0.01*batch.  (BatchRenorm in the Craftax network.)"""
+        if self.renorm:
+            st = {k: stats[name + "/" + k] for k in ("mean", "var", "steps")}
+            ns = {} if (train and new_stats is not None) else None
+            y = batch_renorm(x, p[name + "/scale"], p[name + "/bias"], st, train, ns)
+            if ns:
+                new_stats.update({name + "/" + k: v for k, v in ns.items()})
+            return y
         if train:
             axes = tuple(range(x.dim() - 1))
             mean = x.mean(dim=axes)
@@ -231,7 +253,7 @@ class QNetwork:
         if self.has_batch_stats and stats is None:
             raise ValueError("this network has BatchNorm layers: pass stats=network.init_batch_stats()")
         if self.norm_input:
-            x = self._bn(x, p, "BatchNorm_0", train, stats, new_stats)      # (:61-62) -- and no /255 on this branch
+            x = self._bn(x, p, bn_module(self.renorm) + "_0", train, stats, new_stats)   # (:61-62) -- and no /255 on this branch
         if self.kind == "cnn":
             b = x.shape[0]
             c = x.shape[-1]
@@ -250,7 +272,7 @@ class QNetwork:
         y = x
         for l in range(self.layers):
             y = y @ p[f"Dense_{l}/kernel"] + p[f"Dense_{l}/bias"]
-            y = torch.relu(self._normalize(y, p, mlp_norm_name(self.norm_type, l), train, stats, new_stats))
+            y = torch.relu(self._normalize(y, p, mlp_norm_name(self.norm_type, l, self.renorm), train, stats, new_stats))
         return y @ p[f"Dense_{self.layers}/kernel"] + p[f"Dense_{self.layers}/bias"]
 
 

@@ -26,7 +26,7 @@ from typing import Any, Callable, Dict, List, Optional
 import torch
 
 from . import _lib, ops
-from .envs import FlattenObservationWrapper, LogWrapper, make
+from .envs import BatchEnvWrapper, FlattenObservationWrapper, LogWrapper, OptimisticResetVecEnvWrapper, make
 from .networks import FlatParams, QNetwork
 
 INFO_KEYS = ("discount", "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode")
@@ -113,6 +113,28 @@ class _TorchPolicy:
             self.stats = {**self.stats, **new_stats}          # (:296)
         chosen = qv.gather(1, act_flat[idx].to(torch.int64).unsqueeze(1)).squeeze(1)
         loss = 0.5 * torch.square(chosen - tgt_flat[idx]).mean()
+        loss.backward()
+        if self.grad_hook is not None:
+            self.grad_hook(self.fp.grad)
+        self.opt.step(self.fp.grad)
+        loss_out.copy_(loss.detach())
+        qv_out.copy_(chosen.detach().mean())
+
+    def sgd_step_1step(self, idx, obs_all_flat, n_env, act_flat, rew_flat, done_flat, gamma, loss_out, qv_out):
+        """The `Q_LAMBDA: False` branch of _loss_fn (pqn_craftax.py:287-304): obs and next_obs through the train-mode
+        network as ONE batch, q_next without gradient, target = reward + (1 - done) * gamma * max_a q_next.
+        obs_all_flat: the [T+1][N] observation record flattened -- next_obs of transition j is row j + N."""
+        self.fp.zero_grad()
+        new_stats = {} if self.stats is not None else None
+        b = idx.numel()
+        x = torch.cat((obs_all_flat[idx], obs_all_flat[idx + n_env]))                                   # (:296)
+        q_all = self.net.apply(self.fp.leaves, x, train=True, stats=self.stats, new_stats=new_stats)
+        if new_stats:
+            self.stats = {**self.stats, **new_stats}
+        qv, q_next = q_all[:b], q_all[b:].detach()                                                      # (:300-301)
+        target = rew_flat[idx] + (1.0 - done_flat[idx].to(torch.float32)) * gamma * q_next.max(dim=-1).values   # (:302-306)
+        chosen = qv.gather(1, act_flat[idx].to(torch.int64).unsqueeze(1)).squeeze(1)
+        loss = 0.5 * torch.square(chosen - target).mean()
         loss.backward()
         if self.grad_hook is not None:
             self.grad_hook(self.fp.grad)
@@ -210,11 +232,18 @@ def _mlp_fits_fused(obs_dim: int, hidden: int, layers: int) -> bool:
 
 
 def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: Optional[Callable] = None,
-               metrics_hook: Optional[Callable] = None):
+               metrics_hook: Optional[Callable] = None, script: str = "gymnax"):
     """Returns train(key).  `grad_hook(flat_grad)` (optional) runs between backward
     and the optimizer step -- the RCCL all-reduce of env-sharded mode plugs in here.
     `metrics_hook(values)` (optional; dist.allreduce_mean_scalars) turns the per-rank metric means of an update
-    into means over all env shards (pqn_minatar.py:330-338 take them over ALL envs)."""
+    into means over all env shards (pqn_minatar.py:330-338 take them over ALL envs).
+    script="craftax": the third twin, purejaxql/pqn_craftax.py:82-468 -- the env batched by
+    OptimisticResetVecEnvWrapper(LogWrapper(env)) / BatchEnvWrapper(LogWrapper(env)) (:96-114), the BatchRenorm MLP
+    (:33-62), the `Q_LAMBDA` switch of the loss (:277-304: with False, obs and next_obs go through the train-mode
+    network as one batch and the 1-step target carries no gradient), done-weighted info means (:364-369)."""
+    craftax = script == "craftax"
+    if script not in ("gymnax", "craftax"):
+        raise ValueError(f"unknown script variant {script!r}")
     lib = _lib.load()
     derive_config(config)
     dev = torch.device(device or "cuda")
@@ -222,14 +251,28 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         raise RuntimeError("purejaxql_amd runs on the GPU only (no CPU fallback); got device=%s" % dev)
 
     env, env_params = make(config["ENV_NAME"], device=dev)
-    kind = "cnn" if len(env.obs_shape) == 3 else "mlp"
+    kind = "cnn" if (len(env.obs_shape) == 3 and not craftax) else "mlp"
     if kind == "mlp":
-        env = FlattenObservationWrapper(env)      # pqn_gymnax.py:93
-    env = LogWrapper(env)                         # pqn_minatar.py:104
+        env = FlattenObservationWrapper(env)      # pqn_gymnax.py:93 (the Craftax symbolic observation is flat already)
+    env = LogWrapper(env)                         # pqn_minatar.py:104 / pqn_craftax.py:100
     base_env = env
     while hasattr(base_env, "_env"):
         base_env = base_env._env
-    if kind == "cnn":
+    test_env = None
+    if craftax:                                   # pqn_craftax.py:101-114: the env is batched by a wrapper
+        n_test = int(config.get("TEST_NUM_ENVS", 128))
+        if config.get("USE_OPTIMISTIC_RESETS", False):
+            ratio = int(config.get("OPTIMISTIC_RESET_RATIO", 16))
+            log_env = env
+            env = OptimisticResetVecEnvWrapper(log_env, num_envs=int(config["NUM_ENVS"]),
+                                               reset_ratio=min(ratio, int(config["NUM_ENVS"])))
+            test_env = OptimisticResetVecEnvWrapper(log_env, num_envs=n_test, reset_ratio=min(ratio, n_test))
+        else:
+            log_env = env
+            env = BatchEnvWrapper(log_env, num_envs=int(config["NUM_ENVS"]))
+            test_env = BatchEnvWrapper(log_env, num_envs=n_test)
+        config["TEST_NUM_STEPS"] = int(config.get("TEST_NUM_STEPS", env_params.max_steps_in_episode))
+    elif kind == "cnn":
         config["TEST_NUM_STEPS"] = env_params.max_steps_in_episode                      # pqn_minatar.py:105
     else:
         config["TEST_NUM_STEPS"] = config.get("TEST_NUM_STEPS", env_params.max_steps_in_episode)  # pqn_gymnax.py:95-97
@@ -244,7 +287,12 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
     rew_scale = float(config.get("REW_SCALE", 1))
     test_on = bool(config.get("TEST_DURING_TRAINING", False))
     sp = _lib.stream_ptr
+    q_lambda_loss = bool(config.get("Q_LAMBDA", False)) if craftax else True     # pqn_craftax.py:277
     backend = config.get("_BACKEND")
+    if craftax:          # BatchRenorm network + wrapper-batched env: torch-op network over the HIP env / RAdam kernels
+        if backend not in (None, "torch"):
+            raise ValueError("the Craftax script variant runs the torch-op network (BatchRenorm, 1-step loss)")
+        backend = "torch"
     if backend is None:  # fused kernels: LayerNorm networks; the CNN also needs 16 | minibatch
         plain_ln = config["NORM_TYPE"] == "layer_norm" and not config.get("NORM_INPUT", False)
         if kind == "cnn":
@@ -320,6 +368,25 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         # nanmean(where(returned_episode, x, nan)) (:403-412)
         return {kk: ((vals[kk].to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk in INFO_KEYS}
 
+    def wrapped_eval(act, k, steps):
+        """get_test_metrics of the Craftax script (pqn_craftax.py:399-437): the wrapper-batched test env, TEST_NUM_STEPS
+        steps under eps = EPS_TEST, done-weighted info means."""
+        obs, state = test_env.reset(_lib.fold_in(k, 0), env_params)
+        n_t = test_env.num_envs
+        action = torch.empty(n_t, dtype=torch.int32, device=dev)
+        qm = torch.empty(n_t, dtype=torch.float32, device=dev)
+        sums = {kk: torch.zeros((), dtype=torch.float64, device=dev) for kk in INFO_KEYS}
+        cnt = torch.zeros((), dtype=torch.float64, device=dev)
+        for t in range(steps):
+            sk = _lib.fold_in(k, 1 + t)
+            act(obs, config["EPS_TEST"], sk, action, qm)
+            obs, state, _r, d, info = test_env.step(sk, state, action, env_params, inplace=True)
+            dm = d.to(torch.float64)
+            cnt += dm.sum()
+            for kk in INFO_KEYS:
+                sums[kk] += (info[kk].to(torch.float64) * dm).sum()
+        return {kk: (sums[kk] / cnt).to(torch.float32) for kk in INFO_KEYS}
+
     def make_runner(rng: int):
         """Builds the per-seed training state and returns (update, finish): update(u) runs ONE
         PQN update (rollout + targets + epochs); finish() returns train()'s result dict."""
@@ -338,7 +405,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         network = QNetwork(kind, obs_shape, A, norm_type=config["NORM_TYPE"],
                            norm_input=config.get("NORM_INPUT", False),
                            hidden_size=config.get("HIDDEN_SIZE", 128), num_layers=config.get("NUM_LAYERS", 2),
-                           device=dev)
+                           device=dev, renorm=craftax)
         theta = config.get("_INIT_PARAMS")
         theta = network.init(K_init) if theta is None else theta.to(dev, torch.float32).clone()
         if packed:
@@ -365,6 +432,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             n_t, steps = int(config["TEST_NUM_ENVS"]), int(config["TEST_NUM_STEPS"])
             if packed:
                 return fused_test_metrics(k, n_t, steps)
+            if craftax:
+                return wrapped_eval(policy.act, k, steps)
             return flat_eval(policy.act, k, n_t, steps, eval_buf)
 
         tm_box = [get_test_metrics()]
@@ -372,7 +441,10 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         # reset exploration envs (pqn_minatar.py:418-419)
         ro = _Rollout(T, N, obs_shape, base_env.obs_words if packed else 0, dev)
         obuf = ro.bits if packed else ro.obs
-        o0, state = env.reset(K_reset, env_params, N, want_obs=not packed, want_bits=packed)
+        if craftax:
+            o0, state = env.reset(K_reset, env_params)                                    # pqn_craftax.py:446-447
+        else:
+            o0, state = env.reset(K_reset, env_params, N, want_obs=not packed, want_bits=packed)
         words = state.words
         obuf[0].copy_(o0[1] if packed else o0)
 
@@ -449,15 +521,32 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             for t in range(T):
                 sk = _lib.fold_in(K_roll, u * T + t)
                 policy.act(obuf[t], eps, sk, ro.action[t], ro.qmax[t])
-                env_step_into(sk, words, ro.action[t], None if packed else ro.obs[t + 1],
-                              ro.bits[t + 1] if packed else None, ro.reward[t], ro.done[t], ro.discount[t],
-                              ro.rer[t], ro.rel[t], ro.ts[t])
+                if craftax:   # the wrapper-batched env (pqn_craftax.py:202-204)
+                    o_n, _st, r_n, d_n, info_n = env.step(sk, state, ro.action[t], env_params, inplace=True)
+                    ro.obs[t + 1].copy_(o_n)
+                    ro.reward[t].copy_(r_n)
+                    ro.done[t].copy_(d_n.view(torch.uint8))
+                    ro.discount[t].copy_(info_n["discount"])
+                    ro.rer[t].copy_(info_n["returned_episode_returns"])
+                    ro.rel[t].copy_(info_n["returned_episode_lengths"])
+                    ro.ts[t].copy_(info_n["timestep"])
+                else:
+                    env_step_into(sk, words, ro.action[t], None if packed else ro.obs[t + 1],
+                                  ro.bits[t + 1] if packed else None, ro.reward[t], ro.done[t], ro.discount[t],
+                                  ro.rer[t], ro.rel[t], ro.ts[t])
             counters["timesteps"] += T * N
-            info_means = {
-                "discount": ro.discount.mean(), "returned_episode_returns": ro.rer.mean(),
-                "returned_episode_lengths": ro.rel.to(torch.float32).mean(),
-                "timestep": ro.ts.to(torch.float32).mean(), "returned_episode": ro.done.to(torch.float32).mean(),
-            }
+            if craftax:   # (x * returned_episode).sum() / returned_episode.sum()  (pqn_craftax.py:364-369)
+                dm = ro.done.to(torch.float64)
+                cnt = dm.sum()
+                info_means = {kk: ((vv.to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk, vv in
+                              (("discount", ro.discount), ("returned_episode_returns", ro.rer),
+                               ("returned_episode_lengths", ro.rel), ("timestep", ro.ts), ("returned_episode", ro.done))}
+            else:
+                info_means = {
+                    "discount": ro.discount.mean(), "returned_episode_returns": ro.rer.mean(),
+                    "returned_episode_lengths": ro.rel.to(torch.float32).mean(),
+                    "timestep": ro.ts.to(torch.float32).mean(), "returned_episode": ro.done.to(torch.float32).mean(),
+                }
             if rew_scale != 1.0:
                 ro.reward.mul_(rew_scale)      # REW_SCALE*reward (:205); LogWrapper saw the raw reward
 
@@ -474,8 +563,13 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             for ep in range(EPOCHS):
                 perm = ops.shuffle_permutation(_lib.fold_in(K_shuf, u * EPOCHS + ep), T * N, dev)
                 for mb in range(MB):
-                    policy.sgd_step(perm[mb * B:(mb + 1) * B], obs_flat, act_flat, tgt_flat,
-                                    loss_buf[i_mb:i_mb + 1], qv_buf[i_mb:i_mb + 1])
+                    if q_lambda_loss:
+                        policy.sgd_step(perm[mb * B:(mb + 1) * B], obs_flat, act_flat, tgt_flat,
+                                        loss_buf[i_mb:i_mb + 1], qv_buf[i_mb:i_mb + 1])
+                    else:
+                        policy.sgd_step_1step(perm[mb * B:(mb + 1) * B], obuf.reshape((T + 1) * N, *obs_shape), N, act_flat,
+                                              ro.reward.reshape(-1), ro.done.reshape(-1), gamma,
+                                              loss_buf[i_mb:i_mb + 1], qv_buf[i_mb:i_mb + 1])
                     counters["grad_steps"] += 1
                     i_mb += 1
             obuf[0].copy_(obuf[T])  # carry last_obs into the next update
@@ -502,8 +596,10 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             for k, v in m.items():
                 metrics[k][u] = v
             cb = config.get("_CALLBACK")
-            if cb is not None:
-                cb(u, m)
+            # the Craftax script logs every WANDB_LOG_INTERVAL-th update only (pqn_craftax.py:394-397)
+            if cb is not None and (not craftax or counters["n_updates"] % int(config.get("WANDB_LOG_INTERVAL", 128)) == 0):
+                cb(u, {k: v for k, v in m.items() if config.get("LOG_ACHIEVEMENTS", False) or "achievement" not in k.lower()}
+                   if craftax else m)
 
         def finish():
             if driver is not None:

@@ -24,11 +24,14 @@ from .save_load import save_params
 
 
 def single_run(config: Dict[str, Any], device: Optional[str] = None, make_train_fn: Optional[Callable] = None,
-               vmap_fn: Optional[Callable] = None, seed_keys_fn: Optional[Callable] = None) -> Dict[str, Any]:
+               vmap_fn: Optional[Callable] = None, seed_keys_fn: Optional[Callable] = None, script: str = "gymnax") -> Dict[str, Any]:
     """make_train_fn / vmap_fn / seed_keys_fn default to the product's (purejaxql_amd.pqn); the CPU tests of the
     multi-rank control flow inject stand-ins (no GPU there)."""
     if make_train_fn is None or vmap_fn is None or seed_keys_fn is None:
         from .pqn import make_train, seed_keys, vmap_train
+        if make_train_fn is None and script != "gymnax":   # pqn_craftax.py's make_train
+            from functools import partial
+            make_train_fn = partial(make_train, script=script)
         make_train_fn, vmap_fn, seed_keys_fn = make_train_fn or make_train, vmap_fn or vmap_train, seed_keys_fn or seed_keys
     config = flatten(config)                       # {**config, **config["alg"]} (:437)
     alg_name = config.get("ALG_NAME", "pqn")
@@ -80,7 +83,7 @@ def single_run(config: Dict[str, Any], device: Optional[str] = None, make_train_
             "rank": rank, "world_size": world}
 
 
-def main(argv: List[str], default_alg: str) -> Dict[str, Any]:
+def main(argv: List[str], default_alg: str, script: str = "gymnax") -> Dict[str, Any]:
     """`python -m purejaxql_amd.pqn_minatar +alg=pqn_minatar alg.KEY=V KEY=V` (README.md:170-187)."""
     overrides = list(argv)
     if not any(o.startswith("+alg=") or o.startswith("alg=") for o in overrides):
@@ -91,7 +94,7 @@ def main(argv: List[str], default_alg: str) -> Dict[str, Any]:
         print("Config:\n", yaml.safe_dump(config))
     if config.get("HYP_TUNE", False):
         raise SystemExit("HYP_TUNE (wandb sweep, pqn_minatar.py:486-531) needs the wandb service: out of scope offline")
-    outs = single_run(config)
+    outs = single_run(config, script=script)
     if outs["rank"] == 0:
         m = outs["metrics"]
         last = {k: [round(float(x), 4) for x in v[:, -1]] for k, v in m.items()}

@@ -101,3 +101,62 @@ def test_batch_renorm_torch_vs_oracle(steps):
     ye = batch_renorm(x.detach(), scale.detach(), bias.detach(), stats, False)
     oye, _ = O.brn_fwd(x.detach().numpy(), scale.detach().numpy(), bias.detach().numpy(), ostats, False)
     np.testing.assert_allclose(oye, ye.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("norm_type,norm_input,steps,q_lambda", [
+    ("layer_norm", True, 0, False), ("layer_norm", True, 2000, False),      # pqn_craftax.yaml: BatchRenorm input, LayerNorm hidden
+    ("batch_norm", True, 2000, False), ("batch_norm", False, 0, True), ("none", False, 0, False)])
+def test_craftax_network_and_loss_branches_match_oracle(norm_type, norm_input, steps, q_lambda):
+    """QNetwork of pqn_craftax.py:33-62 (BatchRenorm wherever the gymnax script has BatchNorm) and both branches of its
+    _loss_fn (:277-304): Q_LAMBDA=True (targets are inputs) and False (obs || next_obs as ONE train-mode batch, q_next
+    without gradient) -- torch autograd vs the oracle's hand-written backward, incl. the batch_stats update."""
+    D, A, H, L, B = 11, 5, 32, 3, 16
+    gen = torch.Generator().manual_seed(11 + steps)
+    net = QNetwork("mlp", (D,), A, norm_type=norm_type, norm_input=norm_input, hidden_size=H, num_layers=L, device="cpu",
+                   renorm=True)
+    assert "BatchRenorm_0/scale" in net.shapes and "BatchNorm_0/scale" not in net.shapes
+    theta = net.init(2)
+    theta = theta + 0.05 * torch.randn(theta.shape, generator=gen)
+    fp = FlatParams(net, theta.clone())
+    x, xn = torch.randn((B, D), generator=gen) * 2 + 1, torch.randn((B, D), generator=gen) * 2 + 1
+    act = torch.randint(0, A, (B,), generator=gen)
+    rew, tgt = torch.randn(B, generator=gen), torch.randn(B, generator=gen)
+    done = torch.rand(B, generator=gen) < 0.3
+    stats = None
+    if net.has_batch_stats:
+        stats = {}
+        for k, v in net.init_batch_stats().items():
+            stats[k] = torch.tensor(steps, dtype=torch.int32) if k.endswith("/steps") else v + 0.1 * torch.rand(v.shape, generator=gen)
+    new_stats = {}
+    if q_lambda:
+        q = net.apply(fp.leaves, x, train=True, stats=stats, new_stats=new_stats)
+        target = tgt
+    else:
+        q_all = net.apply(fp.leaves, torch.cat((x, xn)), train=True, stats=stats, new_stats=new_stats)
+        q, q_next = q_all[:B], q_all[B:].detach()
+        target = rew + (1.0 - done.float()) * 0.99 * q_next.max(-1).values
+    chosen = q.gather(1, act[:, None]).squeeze(1)
+    loss = 0.5 * ((chosen - target) ** 2).mean()
+    loss.backward()
+
+    shapes = O.mlp_shapes(D, A, H, L, norm_type, renorm=True)
+    assert list(shapes.items()) == [(k, tuple(s)) for k, s in net.shapes.items()]
+    assert list(O.init_batch_stats("mlp", (D,), H, L, norm_type, norm_input, renorm=True)) == list(net.stats_shapes)
+    p = O.unflatten(theta.numpy().copy(), shapes)
+    ostats = {k: (int(v) if k.endswith("/steps") else v.numpy().copy()) for k, v in (stats or {}).items()}
+    onew = {}
+    kw = dict(norm_type=norm_type, norm_input=norm_input, stats=ostats, new_stats=onew, renorm=True)
+    if q_lambda:
+        ol, oc, og = O.net_loss_grad("mlp", p, shapes, x.numpy(), act.numpy(), tgt.numpy(), norm_type == "layer_norm", L, **kw)
+    else:
+        ol, oc, og = O.net_loss_grad_1step("mlp", p, shapes, x.numpy(), xn.numpy(), act.numpy(), rew.numpy(), done.numpy(), 0.99,
+                                           norm_type == "layer_norm", L, **kw)
+    assert abs(float(ol) - float(loss.detach())) <= 2e-5 * max(1.0, abs(float(loss.detach())))
+    np.testing.assert_allclose(oc, chosen.detach().numpy(), rtol=1e-4, atol=1e-5)
+    g = fp.grad.numpy()
+    assert np.abs(og - g).max() <= 1e-4 * max(1e-9, np.abs(g).max())
+    assert sorted(onew) == sorted(new_stats)
+    for k in onew:
+        np.testing.assert_allclose(np.asarray(onew[k], dtype=np.float64), new_stats[k].numpy().astype(np.float64), rtol=1e-5, atol=1e-6)
+    if stats:
+        assert int(new_stats[[k for k in new_stats if k.endswith("/steps")][0]]) == steps + 1
