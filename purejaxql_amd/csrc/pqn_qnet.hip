@@ -368,6 +368,111 @@ PQN_D void phase2_fc1_f16(const CnnSmem &s, const _Float16 *__restrict__ w1h, in
 }
 
 // ---------------------------------------------------------------------------
+// bf16x3 split-operand products (pqn_cnn_layout_t.matmul_f16 == 2, config MATMUL_DTYPE: bf16x3).
+// gfx950 has no tf32/xf32 path and its f32-input MFMA runs at the vector rate (1/16 of the bf16 rate), so an
+// f32 x f32 product is evaluated on the bf16 matrix core from EXACT three-way splits: x = hi + mid + lo with
+// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (8 + 8 + 8 significand bits; both subtractions are
+// exact in f32), and a*b ~= ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh -- the three dropped terms are
+// <= 2^-23 |a b|, i.e. f32 rounding level; every partial product is exact in the f32 accumulator's input and
+// the accumulation is f32.  6 x v_mfma_f32_16x16x32_bf16 (K = 32) replace 8 x v_mfma_f32_16x16x4_f32: ~5x
+// fewer matrix-pipe cycles.  Measured error vs an f64 dot product (K = 1024, tools/ubench/bf16x3.hip):
+// 1.7e-7 * sum|a b|, against 0.9e-7 for the f32 fma chain.
+// The split is 9 VALU ops per pair of values (v_cvt_pk_bf16_f32, shift / mask back to f32, v_pk_add_f32).
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+PQN_D void x3_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+  const f32x2 x = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+  const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xFFFF0000u)};
+  const f32x2 r1 = x - hf;
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+  const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xFFFF0000u)};
+  const f32x2 r2 = r1 - mf;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+}
+
+// one MFMA operand fragment (8 k-values per lane) as three bf16 planes
+struct X3Frag {
+  u32x4 h, m, l;
+};
+// k-values 0..3 = a, 4..7 = b (the two float4 halves a lane holds of a 32-wide K step)
+PQN_D X3Frag x3_split8(const f32x4 a, const f32x4 b) {
+  unsigned h[4], m[4], l[4];
+  x3_split2(a.x, a.y, h[0], m[0], l[0]);
+  x3_split2(a.z, a.w, h[1], m[1], l[1]);
+  x3_split2(b.x, b.y, h[2], m[2], l[2]);
+  x3_split2(b.z, b.w, h[3], m[3], l[3]);
+  X3Frag f;
+  f.h = u32x4{h[0], h[1], h[2], h[3]};
+  f.m = u32x4{m[0], m[1], m[2], m[3]};
+  f.l = u32x4{l[0], l[1], l[2], l[3]};
+  return f;
+}
+#define X3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, B), C, 0, 0, 0)
+// acc_s takes the three small cross terms, acc_b the three leading ones: two independent dependency chains, and the
+// small terms are summed among themselves before they meet the large ones
+PQN_D void x3_mfma6(const X3Frag &a, const X3Frag &b, f32x4 &acc_b, f32x4 &acc_s) {
+  acc_s = X3_MFMA(a.l, b.h, acc_s);
+  acc_b = X3_MFMA(a.m, b.h, acc_b);
+  acc_s = X3_MFMA(a.h, b.l, acc_s);
+  acc_b = X3_MFMA(a.h, b.m, acc_b);
+  acc_s = X3_MFMA(a.m, b.m, acc_s);
+  acc_b = X3_MFMA(a.h, b.h, acc_b);
+}
+
+// phase 2, bf16x3: same tile, same work split (wave w owns column block w), the SAME f32 weight fragments streamed
+// through the same 16-deep register ring as phase2_fc1 -- two consecutive 16-wide K groups form one 32-wide MFMA
+// step: lane (col = l&15, kk = l>>4) holds k = 32 s + 4 kk + {0..3} and 32 s + 16 + 4 kk + {0..3} of both operands.
+// Operands are split in registers (no extra copies of the kernel in HBM, the optimizer stays untouched).
+template <int PF = 16>
+PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ w1p, int tid, int tile = -1) {
+  static_assert(QN_WAVES == 8 && PF % 2 == 0, "one column block of 16 outputs per wave; the ring is consumed in pairs");
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tile < 0) tile = blockIdx.x;
+  const int rot = ((tile * 8 + (tile >> 3)) & 63) & ~1;   // even: K-group pairs stay aligned
+  const f32x4 *wp = reinterpret_cast<const f32x4 *>(w1p);
+  const float *arow = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
+  f32x4 acc_b = {0.f, 0.f, 0.f, 0.f}, acc_s = {0.f, 0.f, 0.f, 0.f};
+  f32x4 b[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) b[i] = wp[(((i + rot) & 63) * 8 + wave) * 64 + lane];
+  f32x4 a0n = *reinterpret_cast<const f32x4 *>(arow + 16 * (rot & 63));
+  f32x4 a1n = *reinterpret_cast<const f32x4 *>(arow + 16 * ((rot + 1) & 63));
+  auto group_block = [&](int g, auto more_t) {
+    constexpr bool more = decltype(more_t)::value;
+#pragma unroll
+    for (int i = 0; i < PF; i += 2) {
+      const f32x4 a0 = a0n, a1 = a1n;   // A fragments one step ahead: the LDS latency hides behind this step's work
+      a0n = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 2 + rot) & 63));
+      a1n = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 3 + rot) & 63));
+      __builtin_amdgcn_sched_barrier(0);
+      const X3Frag af = x3_split8(a0, a1);
+      const X3Frag bf = x3_split8(b[i], b[i + 1]);
+      if (more) {   // in-place reload right after the last read of the slot (see phase2_fc1)
+        b[i] = wp[(((g + i + PF + rot) & 63) * 8 + wave) * 64 + lane];
+        b[i + 1] = wp[(((g + i + 1 + PF + rot) & 63) * 8 + wave) * 64 + lane];
+      }
+      x3_mfma6(af, bf, acc_b, acc_s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#pragma unroll 1
+  for (int g = 0; g < QN_H1 / 16 - PF; g += PF) group_block(g, std::true_type{});
+  group_block(QN_H1 / 16 - PF, std::false_type{});
+  const f32x4 acc = acc_b + acc_s;
+  const int col = lane & 15, r0 = 4 * (lane >> 4);
+  float *zp = s.z + r0 * QN_ZS + 16 * wave + col;
+  zp[0] = acc.x;
+  zp[QN_ZS] = acc.y;
+  zp[2 * QN_ZS] = acc.z;
+  zp[3 * QN_ZS] = acc.w;
+}
+
+// ---------------------------------------------------------------------------
 // phase 3: per sample m (16 lanes each): z+b1 -> LN(128) -> relu -> fc2 -> q[A].
 // Every lane of the 16-lane group ends up with all q values.  xh/rstd returned
 // for the backward pass (lane owns features o = sub + 16 r).
@@ -501,7 +606,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
   __syncthreads();
   if (ablate != 1 && ablate != 6 && ablate != 7) phase1_conv<C>(s, tid);
   __syncthreads();
-  if (L.matmul_f16) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
+  if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
+  else if (L.matmul_f16 == 2) phase2_fc1_x3<16>(s, theta + L.off_w1, tid);
   else if (ablate == 0 || ablate == 1 || ablate == 5) phase2_fc1<0>(s, theta + L.off_w1, tid);
   else if (ablate == 2) phase2_fc1<2>(s, theta + L.off_w1, tid);
   else if (ablate == 3) phase2_fc1<3>(s, theta + L.off_w1, tid);
@@ -590,7 +696,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
     __syncthreads();   // s.bits holds obs_t of the tile (and every previous reader of the tiles is done)
     phase1_conv<C>(s, tid);
     __syncthreads();
-    if (L.matmul_f16) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid, (e0 - e_off) / QN_TILE);
+    if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid, (e0 - e_off) / QN_TILE);
+    else if (L.matmul_f16 == 2) phase2_fc1_x3<8>(s, theta + L.off_w1, tid, (e0 - e_off) / QN_TILE);
     else phase2_fc1<0, 8>(s, theta + L.off_w1, tid, (e0 - e_off) / QN_TILE);   // 8 in flight: the env state lives in registers across this loop
     __syncthreads();
     if (tid < 256) {
@@ -822,7 +929,7 @@ PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layou
   }
   // dz^T for the weight-gradient GEMM: dzT[o][b0 + m], 16-B stores (matmul_f16: tile-major fp16, scaled into
   // fp16's normal range by dz_scale)
-  if (L.matmul_f16) {
+  if (L.matmul_f16 == 1) {
     _Float16 *dzP = reinterpret_cast<_Float16 *>(dzT) + (size_t)blockIdx.x * QN_HID * QN_TILE;
     if (tid < QN_HID * 2) {
       const int o = tid >> 1, hh = tid & 1;
@@ -919,11 +1026,12 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   phase1_conv<C, true>(s, tid, xkeep, rkeep);
   __syncthreads();
   T1_STAMP(2);
-  if (L.matmul_f16) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
+  if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
+  else if (L.matmul_f16 == 2) phase2_fc1_x3<16>(s, theta + L.off_w1, tid);
   else phase2_fc1<0>(s, theta + L.off_w1, tid);
   // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
   // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
-  if (L.matmul_f16) {
+  if (L.matmul_f16 == 1) {
     // fp16 operands for T2, tile-major: h1P[tile][i][16 samples] halves -- the wave writes 2 KB contiguous
     _Float16 *h1P = reinterpret_cast<_Float16 *>(h1T) + (size_t)blockIdx.x * QN_H1 * QN_TILE;
     for (int e = tid; e < QN_H1 * 2; e += QN_THREADS) {
@@ -957,7 +1065,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   }
   T1_STAMP(4);
   // ---- P4: dgrad  dh1[m][i] = sum_o dz[m][o] W1[i][o]  (A = dz tile, B = W1 in dgrad fragment order) ----
-  if (L.matmul_f16) {
+  if (L.matmul_f16 == 1) {
     // fp16 operands, f32 accumulation: one v_mfma_f32_16x16x16_f16 per 16-wide K group.  dz is O(1/B): it is
     // scaled by a power of two (>= B/2) into fp16's normal range and the product scaled back in f32.
     const float sc = dz_scale, isc = 1.0f / sc;
@@ -995,6 +1103,54 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
           __builtin_amdgcn_sched_barrier(0);
         }
         acc0 = (acc0 + acc1) * isc;
+        p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
+        p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
+        p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
+        p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
+      }
+    };
+#pragma unroll 1
+    for (int ip = 0; ip < IBW / 2 - 1; ++ip) pair_step(ip, std::true_type{});
+    pair_step(IBW / 2 - 1, std::false_type{});
+  } else if (L.matmul_f16 == 2) {
+    // bf16x3 split operands (see phase2_fc1_x3): the same dgrad-order f32 fragments of the fc1 kernel, split in
+    // registers; the dz tile is split once per wave (4 K steps of 32 outputs) and stays in registers.
+    const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
+    X3Frag afr[4];
+#pragma unroll
+    for (int sK = 0; sK < 4; ++sK) {
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 32 * sK + 4 * (lane >> 4));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 32 * sK + 16 + 4 * (lane >> 4));
+      afr[sK] = x3_split8(lo, hi);
+    }
+    const int col = lane & 15, r0 = 4 * (lane >> 4);
+    constexpr int IBW = 64 / QN_WAVES;
+    constexpr int PF = 16;
+    const int ib_first = IBW * wave;
+    const int prot = blockIdx.x & (IBW - 1);
+    auto frag = [&](int n) { return wb[((n & 7) * 64 + ib_first + (((n >> 3) + prot) & (IBW - 1))) * 64 + lane]; };
+    f32x4 ring[PF];
+#pragma unroll
+    for (int n = 0; n < PF; ++n) ring[n] = frag(n);
+    auto pair_step = [&](int ip, auto more_t) {
+      constexpr bool more = decltype(more_t)::value;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ib = ib_first + ((2 * ip + h + prot) & (IBW - 1));
+        float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
+        const float m0 = p0[0], m1 = p0[QN_H1S], m2 = p0[2 * QN_H1S], m3 = p0[3 * QN_H1S];
+        f32x4 acc_b = {0.f, 0.f, 0.f, 0.f}, acc_s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sK = 0; sK < 4; ++sK) {
+          const X3Frag bf = x3_split8(ring[8 * h + 2 * sK], ring[8 * h + 2 * sK + 1]);
+          if (more) {
+            ring[8 * h + 2 * sK] = frag(16 * (ip + 1) + 8 * h + 2 * sK);
+            ring[8 * h + 2 * sK + 1] = frag(16 * (ip + 1) + 8 * h + 2 * sK + 1);
+          }
+          x3_mfma6(afr[sK], bf, acc_b, acc_s);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const f32x4 acc0 = acc_b + acc_s;
         p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
         p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
         p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
@@ -1263,6 +1419,107 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_kernel(int nb, cons
   for (int a = 0; a < 4; ++a) out[((4 * it + a) * 8 + cb) * 64 + lane] = acc[a];
 }
 
+// bf16x3 split-operand variant (matmul_f16 == 2; see phase2_fc1_x3): the same f32 operands T1 leaves in the
+// workspace, the same grid and output layout; every element is split into its three bf16 planes ONCE per workgroup
+// when it is staged into LDS (3 planes x 192 rows x 32 samples per step, double-buffered), and the waves read bf16
+// fragments: 6 x v_mfma_f32_16x16x32_bf16 per 16x16 output tile and 32-sample step.  Wave w owns a 2 x 2 block of
+// tiles (row blocks 2(w>>2), +1; column blocks 2(w&3), +1): 12 ds_read_b128 for 24 MFMAs.  LDS row stride 96 B
+// (32 samples + 16 B pad... 24 dwords): conflict-free for the four 16-lane groups of ds_read_b128.
+#define QX_KS 32
+#define QX_ROWS 192
+#define QX_RSB 96                         // bytes per LDS row
+#define QX_PLANE (QX_ROWS * QX_RSB)       // 18,432 B
+#define QX_BUF (3 * QX_PLANE)             // 55,296 B; two buffers = 110,592 B (dynamic LDS)
+__global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, const float *__restrict__ h1T,
+                                                                       const float *__restrict__ dzT,
+                                                                       float *__restrict__ wpart, long long ws_stride) {
+  static_assert(QN_WAVES == 8, "2 x 2 tiles per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+  h1T += blockIdx.z * ws_stride;   // seed slice
+  dzT += blockIdx.z * ws_stride;
+  wpart += blockIdx.z * ws_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int it = blockIdx.x, ks = blockIdx.y;
+  const int r = lane & 15, kg = lane >> 4;
+  const int rp = wave >> 2, cq = wave & 3;
+  const int c0 = ks * QW_SLAB;
+  const int nsteps = (min(QW_SLAB, nb - c0) + QX_KS - 1) / QX_KS;
+  const int ld = qw_ld(nb);
+  // loader mapping: ROWS * KS / 4 = 1536 float4 per step = 3 per thread
+  const float *src[3];
+  int dst[3], col[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int e = tid + QN_THREADS * j;
+    const int row = e >> 3, c4 = (e & 7) * 4;           // 8 float4 per 32-sample row
+    src[j] = (row < 64 ? h1T + (size_t)(64 * it + row) * ld : dzT + (size_t)(row - 64) * ld) + c0 + c4;
+    dst[j] = row * QX_RSB + c4 * 2;                     // byte offset inside a plane (bf16)
+    col[j] = c0 + c4;
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc_b[2][2], acc_s[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { acc_b[a][c] = zero4; acc_s[a][c] = zero4; }
+  f32x4 pre[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) pre[j] = (col[j] < nb) ? *reinterpret_cast<const f32x4 *>(src[j]) : zero4;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  for (int st = 0; st < nsteps; ++st) {
+    char *t = smem_x3 + (st & 1) * QX_BUF;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {   // split once per element, store the three planes
+      unsigned h0, m0, l0, h1, m1, l1;
+      x3_split2(pre[j].x, pre[j].y, h0, m0, l0);
+      x3_split2(pre[j].z, pre[j].w, h1, m1, l1);
+      *reinterpret_cast<u32x2 *>(t + dst[j]) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2 *>(t + QX_PLANE + dst[j]) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2 *>(t + 2 * QX_PLANE + dst[j]) = u32x2{l0, l1};
+    }
+    if (st + 1 < nsteps) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        pre[j] = (col[j] + QX_KS * (st + 1) < nb) ? *reinterpret_cast<const f32x4 *>(src[j] + QX_KS * (st + 1)) : zero4;
+    }
+    __syncthreads();   // buffer st&1 complete; buffer (st+1)&1 was last read two steps ago
+    X3Frag af[2], bf[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const char *pa = t + (16 * (2 * rp + a) + r) * QX_RSB + kg * 16;
+      af[a].h = *reinterpret_cast<const u32x4 *>(pa);
+      af[a].m = *reinterpret_cast<const u32x4 *>(pa + QX_PLANE);
+      af[a].l = *reinterpret_cast<const u32x4 *>(pa + 2 * QX_PLANE);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const char *pb = t + (64 + 16 * (2 * cq + c) + r) * QX_RSB + kg * 16;
+      bf[c].h = *reinterpret_cast<const u32x4 *>(pb);
+      bf[c].m = *reinterpret_cast<const u32x4 *>(pb + QX_PLANE);
+      bf[c].l = *reinterpret_cast<const u32x4 *>(pb + 2 * QX_PLANE);
+    }
+    // the four tiles interleaved product by product: consecutive MFMAs never share an accumulator
+#define QX_ALL(AP, BP, ACC)                                   \
+    ACC[0][0] = X3_MFMA(af[0].AP, bf[0].BP, ACC[0][0]);       \
+    ACC[0][1] = X3_MFMA(af[0].AP, bf[1].BP, ACC[0][1]);       \
+    ACC[1][0] = X3_MFMA(af[1].AP, bf[0].BP, ACC[1][0]);       \
+    ACC[1][1] = X3_MFMA(af[1].AP, bf[1].BP, ACC[1][1]);
+    QX_ALL(l, h, acc_s)
+    QX_ALL(h, l, acc_s)
+    QX_ALL(m, m, acc_s)
+    QX_ALL(m, h, acc_b)
+    QX_ALL(h, m, acc_b)
+    QX_ALL(h, h, acc_b)
+#undef QX_ALL
+  }
+  f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      out[((4 * it + 2 * rp + a) * 8 + 2 * cq + c) * 64 + lane] = acc_b[a][c] + acc_s[a][c];
+}
+
 // fp16-operand variant (matmul_f16): operands packed tile-major by T1 (h1P[tile][1024][16], dzP[tile][128][16]
 // halves, dz pre-scaled by dz_scale), one v_mfma_f32_16x16x16_f16 per row block and 16-sample tile, f32
 // accumulation, result scaled back.  Same grid and output layout as the f32 kernel.
@@ -1439,9 +1696,10 @@ extern "C" int pqn_cnn_layout_ex(int32_t c, int32_t a, int32_t matmul_f16, pqn_c
   L->off_w2 = off; off = align4(off + QN_HID * a);
   L->off_b2 = off; off = align4(off + a);
   L->total = off;
-  L->matmul_f16 = matmul_f16 ? 1 : 0;
-  L->off_w1h = off;                                        // 2 x 131072 halves = 131072 floats behind the parameters
-  L->alloc = matmul_f16 ? off + QN_H1 * QN_HID : off;
+  PQN_REQUIRE(matmul_f16 >= 0 && matmul_f16 <= 2, "pqn_cnn_layout_ex: operand mode %d (0 f32, 1 f16, 2 bf16x3)", matmul_f16);
+  L->matmul_f16 = matmul_f16;                              // 0: f32 MFMA; 1: fp16 operands; 2: bf16x3 split operands
+  L->off_w1h = off;                                        // mode 1: 2 x 131072 halves = 131072 floats behind the parameters
+  L->alloc = matmul_f16 == 1 ? off + QN_H1 * QN_HID : off;
   return PQN_OK;
 }
 
@@ -1642,10 +1900,19 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
                      target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sd, dz_scale);
   if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
-  if (L.matmul_f16)
+  if (L.matmul_f16 == 1)
     hipLaunchKernelGGL(qnet_fc1_wgrad_f16_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
                        sd.ws_stride, 1.0f / dz_scale);
-  else
+  else if (L.matmul_f16 == 2) {
+    static bool x3_attr = false;
+    if (!x3_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QX_BUF);
+      x3_attr = true;
+    }
+    hipLaunchKernelGGL(qnet_fc1_wgrad_x3_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 2 * QX_BUF, st, nb, h1T, dzT,
+                       wpart, sd.ws_stride);
+  } else
     hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
                        sd.ws_stride);
   if (with_reduce)
@@ -1838,7 +2105,7 @@ __global__ __launch_bounds__(512) void qnet_reduce_apply_kernel(
     *m4 = f32x4{ma[0], ma[1], ma[2], ma[3]};
     *v4 = f32x4{va[0], va[1], va[2], va[3]};
     *p4 = f32x4{pa[0], pa[1], pa[2], pa[3]};
-    _Float16 *w1h = L.matmul_f16 ? reinterpret_cast<_Float16 *>(p + L.off_w1h) : nullptr;
+    _Float16 *w1h = L.matmul_f16 == 1 ? reinterpret_cast<_Float16 *>(p + L.off_w1h) : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // keep the fragment-order copies of the fc1 kernel in step (as radam_apply_kernel)
       const int j = 4 * j4 + k;
@@ -1889,7 +2156,7 @@ extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float
   PQN_REQUIRE(L && theta && w1b && grad && m && v && count && workspace, "pqn_qnet_cnn_apply: NULL argument");
   return pqn_launch_radam(theta, grad, m, v, L->total, count, lr_init, lr_end, lr_steps, max_norm, workspace, gnorm_out,
                           L->off_w1, w1b, recompute_norm, grad_reduce_blocks(L->total), (hipStream_t)stream, 1, 0, 0, 0,
-                          L->matmul_f16 ? L->off_w1h : 0);
+                          L->matmul_f16 == 1 ? L->off_w1h : 0);
 }
 
 // w1b: f32 dgrad-fragment copy (nullable);  w1h: fp16 forward-fragment copy + fp16 dgrad-fragment copy (nullable)
@@ -1910,8 +2177,8 @@ __global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict
 // theta is written only in its tail (the fp16 copies of a matmul_f16 layout); pass w1b = NULL to refresh just those
 extern "C" int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *L, float *theta, float *w1b, void *stream) {
   PQN_REQUIRE(L && theta, "pqn_qnet_cnn_pack_w1b: NULL argument");
-  PQN_REQUIRE(w1b || L->matmul_f16, "pqn_qnet_cnn_pack_w1b: nothing to do");
+  PQN_REQUIRE(w1b || L->matmul_f16 == 1, "pqn_qnet_cnn_pack_w1b: nothing to do");
   hipLaunchKernelGGL(pack_w1b_kernel, dim3(QN_H1 * QN_HID / 256), dim3(256), 0, (hipStream_t)stream, theta + L->off_w1, w1b,
-                     L->matmul_f16 ? reinterpret_cast<_Float16 *>(theta + L->off_w1h) : (_Float16 *)nullptr);
+                     L->matmul_f16 == 1 ? reinterpret_cast<_Float16 *>(theta + L->off_w1h) : (_Float16 *)nullptr);
   return pqn_check_launch("pqn_qnet_cnn_pack_w1b");
 }

@@ -156,10 +156,10 @@ class _FusedCnnPolicy:
     packed = True
 
     def __init__(self, network, theta, config, lr_steps, grad_hook, max_mb):
-        from .qnet import CnnKernelLayout, CnnTrainer, cnn_forward
+        from .qnet import CnnKernelLayout, CnnTrainer, cnn_forward, matmul_mode
         self.net = network
         self.layout = CnnKernelLayout(network.obs_shape[-1], network.action_dim,
-                                      matmul_f16=str(config.get("MATMUL_DTYPE", "f32")).lower() in ("f16", "fp16", "float16"))
+                                      matmul_f16=matmul_mode(config.get("MATMUL_DTYPE", "f32")))
         self.tr = CnnTrainer(self.layout, theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps,
                              max_minibatch=max_mb)
         self.fwd = cnn_forward
@@ -626,13 +626,13 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         pqn_cnn_update_seeds), one hipGraph replay per update for all of them.  Same key schedule, same
         kernels and summation orders as make_runner, so every seed's result is bit-identical to its solo run.
         Returns (update, finish); finish() -> list of per-seed result dicts."""
-        from .qnet import METRIC_NAMES, CnnKernelLayout, MlpKernelLayout, SeedsUpdateDriver, mlp_forward
+        from .qnet import METRIC_NAMES, CnnKernelLayout, MlpKernelLayout, SeedsUpdateDriver, matmul_mode, mlp_forward
         S = len(rngs)
         if not (backend == "fused" and grad_hook is None and seeds_shape_ok and 1 <= S <= 128):
             raise RuntimeError("seed batching needs a fused path, no gradient hook, NUM_ENVS % 16 == 0, <= 128 seeds")
         if packed:
             layout = CnnKernelLayout(obs_shape[-1], A,
-                                     matmul_f16=str(config.get("MATMUL_DTYPE", "f32")).lower() in ("f16", "fp16", "float16"))
+                                     matmul_f16=matmul_mode(config.get("MATMUL_DTYPE", "f32")))
         else:
             layout = MlpKernelLayout(obs_shape[0], int(config.get("HIDDEN_SIZE", 128)), int(config.get("NUM_LAYERS", 2)), A)
         Ks = []

@@ -23,19 +23,32 @@ class CnnLayoutStruct(C.Structure):
                                          "off_w1h", "alloc")]
 
 
-class CnnKernelLayout:
-    """pqn_cnn_layout_t + the flax <-> kernel index map.  matmul_f16: the fc1 products (forward, input gradient,
-    weight gradient) take fp16 operands with f32 accumulation (config MATMUL_DTYPE: "f16"); the parameter buffer
-    then carries two fp16 copies of the fc1 kernel behind the `total` parameter floats (`alloc` floats in all)."""
+MATMUL_MODES = {"f32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "bf16x3": 2}
 
-    def __init__(self, channels: int, num_actions: int, matmul_f16: bool = False):
+
+def matmul_mode(config_value) -> int:
+    """config MATMUL_DTYPE -> pqn_cnn_layout_t.matmul_f16: 0 = f32-input MFMA (exact f32 fma chains), 1 = fp16 operands
+    (opt-in, narrower than the reference's f32), 2 = bf16x3 split operands (f32-grade products on the bf16 matrix core)."""
+    key = str(config_value if config_value is not None else "f32").lower()
+    if key not in MATMUL_MODES:
+        raise ValueError(f"MATMUL_DTYPE={config_value!r}: expected one of {sorted(set(MATMUL_MODES))}")
+    return MATMUL_MODES[key]
+
+
+class CnnKernelLayout:
+    """pqn_cnn_layout_t + the flax <-> kernel index map.  matmul_f16 = the operand mode of the fc1 products (forward,
+    input gradient, weight gradient), see matmul_mode(): True / 1 = fp16 operands with f32 accumulation (the parameter
+    buffer then carries two fp16 copies of the fc1 kernel behind the `total` parameter floats, `alloc` floats in all);
+    2 = bf16x3 split operands (no extra copies: operands are split in registers)."""
+
+    def __init__(self, channels: int, num_actions: int, matmul_f16=False):
         lib = _lib.load()
         self.struct = CnnLayoutStruct()
-        _lib.check(lib.pqn_cnn_layout_ex(channels, num_actions, 1 if matmul_f16 else 0, C.byref(self.struct)),
+        _lib.check(lib.pqn_cnn_layout_ex(channels, num_actions, int(matmul_f16), C.byref(self.struct)),
                    "pqn_cnn_layout_ex")
         s = self.struct
         self.c, self.a, self.total = int(s.c), int(s.a), int(s.total)
-        self.alloc, self.matmul_f16 = int(s.alloc), bool(s.matmul_f16)
+        self.alloc, self.mode, self.matmul_f16 = int(s.alloc), int(s.matmul_f16), int(s.matmul_f16) == 1
         c, a = self.c, self.a
         i = torch.arange(1024).view(-1, 1)
         o = torch.arange(128).view(1, -1)

@@ -19,7 +19,7 @@ def _np(t):
 CASES = [
     # (env, overrides, updates)
     ("CartPole-v1", dict(NUM_ENVS=16, NUM_STEPS=1, NUM_MINIBATCHES=1, NUM_EPOCHS=1, Q_LAMBDA=False, NORM_INPUT=True,
-                         NORM_TYPE="layer_norm", USE_OPTIMISTIC_RESETS=False), 8),
+                         NORM_TYPE="layer_norm", USE_OPTIMISTIC_RESETS=False), 40),   # T = 1: episodes need ~10-40 updates to end
     ("CartPole-v1", dict(NUM_ENVS=16, NUM_STEPS=8, NUM_MINIBATCHES=2, NUM_EPOCHS=2, Q_LAMBDA=True, NORM_INPUT=True,
                          NORM_TYPE="batch_norm", USE_OPTIMISTIC_RESETS=False), 3),
     ("Breakout-MinAtar", dict(NUM_ENVS=32, NUM_STEPS=8, NUM_MINIBATCHES=2, NUM_EPOCHS=1, Q_LAMBDA=False, NORM_INPUT=True,

@@ -285,6 +285,13 @@ def test_product_network_vs_oracle_network(gpu, oracle):
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
                                          "_BACKEND": "fused", "_GRAPH": False}),    # C++ enqueue without hipGraph
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 1024, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
+    # bf16x3 split-operand fc1 products: the same tolerances as the f32-MFMA mode
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
+                                         "MATMUL_DTYPE": "bf16x3"}),
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 1024, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2,
+                                         "MATMUL_DTYPE": "bf16x3"}),
+    ("pqn_minatar", "Freeway-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
+                                        "MATMUL_DTYPE": "bf16x3"}),
     # the headline shape itself (BASELINE.json metric; bench.py's workload): one whole update, fused + hipGraph
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 4096, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
     ("pqn_minatar", "Asterix-MinAtar", {"NUM_ENVS": 4096, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),

@@ -21,14 +21,20 @@ def _random_bits(rng, n, c, density):
     return obs, words
 
 
+# operand modes of the fc1 products that claim f32-grade results: both are held to the SAME tolerances below
+F32_MODES = ["f32", "bf16x3"]
+
+
+@pytest.mark.parametrize("mode", F32_MODES)
 @pytest.mark.parametrize("c,a,n", [(4, 3, 16), (4, 3, 1000), (4, 3, 4096), (6, 4, 100), (7, 3, 50), (10, 6, 33)])
-def test_cnn_forward_vs_oracle(gpu, oracle, c, a, n):
+def test_cnn_forward_vs_oracle(gpu, oracle, c, a, n, mode):
     from purejaxql_amd.networks import QNetwork
-    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward, matmul_mode
     rng = np.random.default_rng(c * 1000 + n)
     torch.manual_seed(1234)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
-    lay = CnnKernelLayout(c, a)
+    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode(mode))
+    assert lay.alloc == lay.total      # no operand copies in HBM for either mode
     assert lay.num_flax == net.num_params
     theta = net.init(5) + 0.05 * torch.randn(net.num_params, device=gpu)
     theta_k = lay.to_kernel(theta)
@@ -62,16 +68,17 @@ def test_cnn_forward_on_real_breakout_observations(gpu, oracle):
     np.testing.assert_allclose(_np(q), _np(q_torch), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("mode", F32_MODES)
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 16, 64), (4, 3, 128, 1000), (4, 3, 4096, 20000), (10, 6, 48, 100), (7, 3, 1024, 1024)])
-def test_cnn_grad_vs_oracle(gpu, oracle, c, a, nb, pool):
+def test_cnn_grad_vs_oracle(gpu, oracle, c, a, nb, pool, mode):
     """value_and_grad(_loss_fn) through the fused kernels vs the oracle's numpy backward.
     Tolerance: rtol 2e-3 + atol 3e-6*max|g| (f32, different summation orders over up to 4096x64 terms)."""
     from purejaxql_amd.networks import QNetwork
-    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer, matmul_mode
     rng = np.random.default_rng(nb + c)
     torch.manual_seed(1234)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
-    lay = CnnKernelLayout(c, a)
+    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode(mode))
     theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
     tr = CnnTrainer(lay, theta, 5e-4, 10.0, lr_decay_steps=1000.0)
     obs, words = _random_bits(rng, pool, c, density=0.12)
@@ -163,19 +170,20 @@ def test_mlp_forward_and_grad_vs_oracle(gpu, oracle, d, h, layers, a, n):
 @pytest.mark.parametrize("name,c,a,n,t", [("Breakout-MinAtar", 4, 3, 37, 6), ("Breakout-MinAtar", 4, 3, 256, 40),
                                           ("Asterix-MinAtar", 4, 5, 50, 12), ("Freeway-MinAtar", 7, 3, 33, 8),
                                           ("SpaceInvaders-MinAtar", 6, 4, 20, 10)])
-def test_cnn_rollout_equals_step_by_step(gpu, name, c, a, n, t):
+@pytest.mark.parametrize("mode", F32_MODES)
+def test_cnn_rollout_equals_step_by_step(gpu, name, c, a, n, t, mode):
     """pqn_cnn_rollout (persistent scan) == T x (pqn_qnet_cnn_forward with eps-greedy, pqn_env_step) with the
     same step keys: actions, rewards, dones, LogWrapper info, packed observations and final env state
     bit-exact; max_a Q to f32 round-off (same kernel code, so in practice identical)."""
     from purejaxql_amd import _lib
     from purejaxql_amd.envs import LogWrapper, make
     from purejaxql_amd.networks import QNetwork
-    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward, cnn_rollout
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward, cnn_rollout, matmul_mode
     lib = _lib.load()
     env, params = make(name, device=gpu)
     env = LogWrapper(env)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
-    lay = CnnKernelLayout(c, a)
+    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode(mode))
     torch.manual_seed(0)
     theta_k = lay.to_kernel(net.init(3) + 0.05 * torch.randn(net.num_params, device=gpu))
     (_o, bits0), state = env.reset(11, params, n, want_obs=False, want_bits=True)
