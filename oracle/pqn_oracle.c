@@ -200,6 +200,23 @@ static void cartpole_reset_one(uint64_t key, uint32_t e, int32_t *si, float *sf)
   si[0] = 0;
 }
 
+/* sin / cos as explicit f32 arithmetic (Cody-Waite reduction by pi/2 + Cephes sinf / cosf polynomials): libm's
+ * sinf / cosf and the GPU's differ in the last ulp; a fixed sequence of IEEE operations (compiled with
+ * -ffp-contract=off) is reproducible bit for bit by any implementation, which turns the CartPole comparison into an
+ * exact trajectory test.  Within 1 ulp of libm on the range the dynamics visit (|theta| < 0.25 rad). */
+static void oracle_sincos_f32(float x, float *s, float *c) {
+  const float k = rintf(x * 0.636619772367581343f);
+  float r = x - k * 1.5703125f;
+  r = r - k * 4.837512969970703125e-4f;
+  r = r - k * 7.54978995489188216e-8f;
+  const float z = r * r;
+  const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+  const float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+  const int q = ((int)k) & 3;
+  *s = (q == 0) ? sp : (q == 1) ? cp : (q == 2) ? -sp : -cp;
+  *c = (q == 0) ? cp : (q == 1) ? -sp : (q == 2) ? -cp : sp;
+}
+
 static int cartpole_terminal(const int32_t *si, const float *sf, int32_t max_steps) {
   const float x_thr = 2.4f;
   const float th_thr = (float)(12.0 * 2.0 * 3.14159265358979323846 / 360.0);
@@ -214,8 +231,8 @@ static void cartpole_step_one(int32_t *si, float *sf, int32_t action, int32_t ma
   const float polemass_length = 0.05f, force_mag = 10.0f, tau = 0.02f;
   int prev_terminal = cartpole_terminal(si, sf, max_steps);
   float force = force_mag * (float)action - force_mag * (float)(1 - action);
-  float costheta = cosf(sf[2]);
-  float sintheta = sinf(sf[2]);
+  float costheta, sintheta;
+  oracle_sincos_f32(sf[2], &sintheta, &costheta);
   float temp = (force + polemass_length * (sf[3] * sf[3]) * sintheta) / total_mass;
   float thetaacc = (gravity * sintheta - costheta * temp) /
                    (length * (4.0f / 3.0f - masspole * (costheta * costheta) / total_mass));

@@ -546,6 +546,27 @@ struct SpaceInvaders {
 };
 
 // ===========================================================================
+// sin / cos for the classic-control dynamics, as explicit f32 arithmetic: Cody-Waite reduction by pi/2 in three
+// pieces + the Cephes sinf / cosf minimax polynomials on [-pi/4, pi/4] (< 1 ulp-ish of libm on that range).  Device
+// sinf / cosf and the host libm differ in the last ulp, which made GPU / CPU CartPole trajectories part ways after a
+// few hundred steps; this sequence of IEEE mul / add / sub (no contraction: -ffp-contract=off) and one
+// round-to-nearest-even gives the SAME bits on both sides (the oracle restates the identical sequence), so the
+// CartPole parity tests are bit-exact trajectory tests.  gymnax's jnp.sin / jnp.cos differ from it by <= 1 ulp.
+// ===========================================================================
+PQN_HD void pqn_sincos_f32(float x, float &s, float &c) {
+  const float k = __builtin_rintf(x * 0.636619772367581343f);
+  float r = x - k * 1.5703125f;
+  r = r - k * 4.837512969970703125e-4f;
+  r = r - k * 7.54978995489188216e-8f;
+  const float z = r * r;
+  const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+  const float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+  const int q = ((int)k) & 3;
+  s = (q == 0) ? sp : (q == 1) ? cp : (q == 2) ? -sp : -cp;
+  c = (q == 0) ? cp : (q == 1) ? -sp : (q == 2) ? -cp : sp;
+}
+
+// ===========================================================================
 // CartPole-v1.  5 state words: x, x_dot, theta, theta_dot (f32 bits), time.
 // ===========================================================================
 struct CartPole {
@@ -590,8 +611,8 @@ struct CartPole {
     const float polemass_length = 0.05f, force_mag = 10.0f, tau = 0.02f;
     const int prev_terminal = is_terminal();
     const float force = force_mag * (float)action - force_mag * (float)(1 - action);
-    const float costheta = cosf(theta);
-    const float sintheta = sinf(theta);
+    float sintheta, costheta;
+    pqn_sincos_f32(theta, sintheta, costheta);
     const float temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
     const float thetaacc = (gravity * sintheta - costheta * temp) /
                            (length * (4.0f / 3.0f - masspole * (costheta * costheta) / total_mass));

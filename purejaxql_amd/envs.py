@@ -84,6 +84,13 @@ class Environment:
         return Box(self.obs_shape)
 
     # -- reset / step ------------------------------------------------------------
+    def _check_params(self, params):
+        """The episode limit is compiled into the transition kernels (Env::MAX_STEPS): a non-default EnvParams is
+        rejected loudly instead of being silently ignored."""
+        if params is not None and int(params.max_steps_in_episode) != self.default_params.max_steps_in_episode:
+            raise ValueError(f"{self.name}: max_steps_in_episode={params.max_steps_in_episode} is not supported "
+                             f"(the kernels are built for {self.default_params.max_steps_in_episode})")
+
     def _alloc_obs(self, n, want_obs, want_bits):
         obs = torch.empty((n, *self.obs_shape), dtype=torch.float32, device=self.device) if want_obs else None
         bits = None
@@ -96,6 +103,7 @@ class Environment:
     def reset(self, key: int, params: Optional[EnvParams] = None, num_envs: int = 1, *, want_obs: bool = True,
               want_bits: bool = False):
         lib = _lib.load()
+        self._check_params(params)
         n = int(num_envs)
         words = torch.empty((self.state_words, n), dtype=torch.int32, device=self.device)
         obs, bits = self._alloc_obs(n, want_obs, want_bits)
@@ -109,6 +117,7 @@ class Environment:
     def step(self, key: int, state: EnvState, action: torch.Tensor, params: Optional[EnvParams] = None, *,
              want_obs: bool = True, want_bits: bool = False, inplace: bool = False, log_info: bool = False):
         lib = _lib.load()
+        self._check_params(params)
         n = state.num_envs
         if action.dtype != torch.int32:
             action = action.to(torch.int32)
@@ -289,6 +298,9 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
 
 
 def make(env_name: str, device=None, **env_kwargs):
-    """gymnax.make(name) -> (env, env_params)  (pqn_minatar.py:103)."""
+    """gymnax.make(name) -> (env, env_params)  (pqn_minatar.py:103).  ENV_KWARGS other than {} are rejected: the
+    reference passes them to the env constructor, none of the envs built here has a constructor option."""
+    if env_kwargs:
+        raise ValueError(f"make({env_name!r}): unsupported ENV_KWARGS {sorted(env_kwargs)}")
     env = Environment(env_name, device=device)
     return env, env.default_params

@@ -250,7 +250,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
     if dev.type != "cuda":
         raise RuntimeError("purejaxql_amd runs on the GPU only (no CPU fallback); got device=%s" % dev)
 
-    env, env_params = make(config["ENV_NAME"], device=dev)
+    env, env_params = make(config["ENV_NAME"], device=dev, **(config.get("ENV_KWARGS") or {}))
     kind = "cnn" if (len(env.obs_shape) == 3 and not craftax) else "mlp"
     if kind == "mlp":
         env = FlattenObservationWrapper(env)      # pqn_gymnax.py:93 (the Craftax symbolic observation is flat already)

@@ -150,3 +150,26 @@ def test_c_only_example_builds_and_reaches_the_device_boundary(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert "obs 10x10x4, 3 actions, 7 state words, 16 packed obs words" in out.stdout
     assert out.returncode == 1 and "hipStreamCreate" in out.stderr
+
+
+def test_non_default_env_options_are_rejected_loudly():
+    """EnvParams.max_steps_in_episode and ENV_KWARGS are compiled into / absent from the kernels: asking for anything
+    but the defaults raises instead of being silently ignored (the check runs before any kernel launch)."""
+    import pytest
+    from purejaxql_amd.envs import EnvParams, Environment, make
+    with pytest.raises(ValueError):
+        make("Breakout-MinAtar", device="cpu", use_minimal_action_set=False)
+    env = Environment.__new__(Environment)
+    env.name, env.default_params = "Breakout-MinAtar", EnvParams(max_steps_in_episode=1000)
+    env._check_params(None)
+    env._check_params(EnvParams(max_steps_in_episode=1000))
+    with pytest.raises(ValueError):
+        env._check_params(EnvParams(max_steps_in_episode=500))
+
+
+def test_degenerate_linear_schedule_is_constant_init_value(oracle):
+    """optax.linear_schedule with transition_steps <= 0 (EPS_DECAY = 0) is a constant schedule at init_value."""
+    from purejaxql_amd.pqn import linear_schedule
+    assert linear_schedule(1.0, 0.05, 0.0)(7) == 1.0 and linear_schedule(1.0, 0.05, -3)(0) == 1.0
+    assert oracle.linear_schedule(1.0, 0.05, 0.0, 7) == 1.0
+    assert abs(linear_schedule(1.0, 0.05, 244.1)(122.05) - 0.525) < 1e-12 and linear_schedule(1.0, 0.05, 244.1)(1e9) == 0.05

@@ -161,8 +161,10 @@ def test_breakout_import_export_round_trip_and_edge_states(gpu, oracle):
 
 
 def test_cartpole_step_vs_oracle(gpu, oracle):
-    """f32 dynamics: sinf/cosf differ between libm and the GPU by <= a few ulp, so the
-    comparison re-synchronises the oracle to the GPU state every step (tolerance 2e-6)."""
+    """f32 dynamics, bit-exact TRAJECTORIES: sin / cos are a fixed sequence of IEEE f32 operations shared by the rule
+    (pqn_env_rules.h pqn_sincos_f32) and the oracle's restatement, divisions are correctly rounded on both sides and
+    contraction is off, so 700 free-running steps of 512 envs (no re-synchronisation) agree in every bit: observations,
+    rewards, dones, info, state."""
     from purejaxql_amd.envs import FlattenObservationWrapper, LogWrapper, make
     env, params = make("CartPole-v1", device=gpu)
     env = LogWrapper(FlattenObservationWrapper(env))
@@ -170,27 +172,22 @@ def test_cartpole_step_vs_oracle(gpu, oracle):
     n = 512
     obs, state = env.reset(3, params, n)
     oobs, ost = oenv.reset(3, n)
-    np.testing.assert_array_equal(_np(obs), oobs)   # reset is exact (bit tricks + one fma-free affine map)
+    np.testing.assert_array_equal(_np(obs), oobs)
     rng = np.random.default_rng(0)
     for t in range(700):
         a = rng.integers(0, 2, n).astype(np.int32)
         obs, state, r, d, info = env.step(900 + t, state, torch.from_numpy(a).to(gpu), params)
         oobs, ost, orr, od, oinfo = oenv.step(900 + t, ost, a)
-        g = _np(obs)
-        same_done = _np(d) == od
-        assert same_done.mean() > 0.995   # threshold crossings may flip on the last ulp
-        np.testing.assert_allclose(g[same_done], oobs[same_done], rtol=2e-6, atol=2e-6)
+        np.testing.assert_array_equal(_np(d), od, err_msg=f"done t={t}")
+        np.testing.assert_array_equal(_np(obs), oobs, err_msg=f"obs t={t}")
         np.testing.assert_array_equal(_np(r), orr)
-        # re-sync oracle to the GPU state (canonical export)
-        si, sf, log = env.export_state(state)
-        ost["si"][:] = _np(si)
-        ost["sf"][:] = _np(sf)
-        lw = _np(log).view(np.uint32)
-        ost["ep_ret"][:] = lw[:, 0].view(np.float32)
-        ost["ep_len"][:] = lw[:, 1].view(np.int32)
-        ost["ret_ret"][:] = lw[:, 2].view(np.float32)
-        ost["ret_len"][:] = lw[:, 3].view(np.int32)
-        ost["timestep"][:] = lw[:, 4].view(np.int32)
+        if t % 50 == 0 or t == 699:
+            for k in oinfo:
+                np.testing.assert_array_equal(_np(info[k]), oinfo[k], err_msg=k)
+            si, sf, log = env.export_state(state)
+            np.testing.assert_array_equal(_np(si), ost["si"])
+            np.testing.assert_array_equal(_np(sf), ost["sf"])
+            np.testing.assert_array_equal(_np(log).view(np.uint32), oenv.log_words(ost))
     assert ost["ret_len"].max() > 5
 
 
@@ -348,9 +345,24 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
             assert abs(float(out["metrics"][k][u]) - om[k]) <= 1e-3 * max(1.0, abs(om[k])), (u, k)
     # RAdam steps are scale-free: an element whose gradient is at rounding-noise level still moves by
     # ~lr*r_t per step, so isolated elements may differ by O(lr) between two f32 implementations.
-    d = np.abs(_np(out["runner_state"]["theta"]) - oout["theta"])
-    bad = d > (2e-5 + 2e-3 * np.abs(oout["theta"]))
-    assert bad.mean() < 1e-3 and d.max() < cfg["LR"], (int(bad.sum()), float(d.max()))
+    th, oth, th0 = _np(out["runner_state"]["theta"]), oout["theta"], _np(theta0)
+    d = np.abs(th - oth)
+    bad = d > (2e-5 + 2e-3 * np.abs(oth))
+    if cfg["NUM_ENVS"] * cfg["NUM_STEPS"] < 100000:
+        assert bad.mean() < 1e-3 and d.max() < cfg["LR"], (int(bad.sum()), float(d.max()))
+    else:
+        # 64 optimizer steps on 4096-sample minibatches: a gradient element that is a cancelling sum of 4096 x 64 terms
+        # carries an ABSOLUTE f32 rounding error of ~1e-5 max|g| (measured per step AT THE SAME theta by
+        # test_full_size_sgd_trajectory_gradients_match_oracle_at_same_theta: <= 1e-4), which for the smallest elements is
+        # a large RELATIVE error; RAdam's m_hat / sqrt(v_hat) turns exactly those into lr-sized steps of implementation-
+        # dependent sign.  The fused kernels, the torch-op network and the numpy oracle are three such implementations:
+        # the two GPU paths end 2.4e-3 of the update apart, either is 3.9e-2 from numpy (tools/debug_e2e_groups.py,
+        # tools/debug_epoch2.py; gpurun_out r2b / r2e).  So the whole-update criterion at this size is on the update
+        # vector: direction (cosine), relative L2, the share of elements outside the element-wise band, worst element.
+        upd, oupd = th - th0, oth - th0
+        cos = float(np.dot(upd, oupd) / (np.linalg.norm(upd) * np.linalg.norm(oupd)))
+        rel = float(np.linalg.norm(upd - oupd) / np.linalg.norm(oupd))
+        assert cos > 0.998 and rel < 6e-2 and bad.mean() < 1e-2 and d.max() < 4 * cfg["LR"], (cos, rel, float(bad.mean()), float(d.max()))
 
 
 @pytest.mark.parametrize("alg,env_name,norm_type,norm_input", [
@@ -403,11 +415,11 @@ def test_make_train_norm_variants_vs_oracle(gpu, oracle, alg, env_name, norm_typ
         assert np.abs(_np(bs[k]) - v).max() <= 10 * tol * max(np.abs(v).max(), 1e-3), k   # running moments, per-array scale
 
 
-@pytest.mark.parametrize("name", ["Breakout-MinAtar", "Asterix-MinAtar", "Freeway-MinAtar", "SpaceInvaders-MinAtar"])
+@pytest.mark.parametrize("name", ["Breakout-MinAtar", "Asterix-MinAtar", "Freeway-MinAtar", "SpaceInvaders-MinAtar", "CartPole-v1"])
 def test_hip_envs_hash_to_regression_pins(gpu, name):
     """The HIP env kernels (reset / step / auto-reset / LogWrapper, f32 observation surface) reproduce the committed
     SHA-256 digests of tests/golden/regression_pins.json on the pinned keys and actions -- no oracle in the loop.
-    (CartPole is excluded: its sinf / cosf differ from libm in the last ulp, see test_cartpole_step_vs_oracle.)"""
+    (CartPole included: its sin / cos are explicit f32 arithmetic shared with the oracle, see test_cartpole_step_vs_oracle.)"""
     import hashlib
     import importlib.util
     import json
@@ -469,14 +481,7 @@ def test_optimistic_reset_wrapper_bit_exact_vs_oracle(gpu, oracle, name, n, rati
         np.testing.assert_array_equal(_np(info["reset_slot"]), oinfo["reset_slot"])
         for k in ("discount", "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode"):
             np.testing.assert_array_equal(_np(info[k]), oinfo[k], err_msg=k)
-        if flat:   # CartPole: device sinf / cosf differ from libm in the last ulp -> re-sync the oracle (see above)
-            same = _np(d) == od
-            assert same.all()
-            si, sf, log = inner.export_state(state)
-            np.testing.assert_allclose(_np(sf), ost["sf"], rtol=2e-6, atol=2e-6)
-            ost["sf"][:] = _np(sf)
-        else:
-            np.testing.assert_array_equal(_np(obs), oobs)
+        np.testing.assert_array_equal(_np(obs), oobs)
         if t % 20 == 0 or t == steps - 1:
             sf = _check_state(inner, oenv, state, ost)
         sl = oinfo["reset_slot"][od]

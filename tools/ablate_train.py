@@ -13,7 +13,7 @@ for t in range(T + 30):
     (obs, bits), state, *_ = env.step(t, state, torch.randint(0, 3, (n,), dtype=torch.int32, device=dev), params, want_bits=True, want_obs=False)
     if t >= 30: allbits.append(bits)
 bits = torch.cat(allbits)
-net = QNetwork("cnn", (10, 10, 4), 3, device=dev); lay = CnnKernelLayout(4, 3, matmul_f16=bool(int(os.environ.get("PQN_F16", "0"))))
+net = QNetwork("cnn", (10, 10, 4), 3, device=dev); lay = CnnKernelLayout(4, 3, matmul_f16=int(os.environ.get("PQN_MODE", os.environ.get("PQN_F16", "0"))))   # 0 f32, 1 f16, 2 bf16x3
 tr = CnnTrainer(lay, net.init(0), 5e-4, 10.0)
 idx = torch.randperm(n * T, device=dev)[:4096].contiguous()
 act = torch.randint(0, 3, (n * T,), dtype=torch.int32, device=dev); tgt = torch.randn(n * T, device=dev)
