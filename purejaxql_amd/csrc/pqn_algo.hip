@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
                                                           const float *__restrict__ scratch,
                                                           float *__restrict__ gnorm_out, int w1_off,
                                                           float *__restrict__ w1b, long long pstride, long long sstride,
-                                                          long long w1bstride, int half_off) {
+                                                          long long w1bstride, int half_off, int copy_mode) {
   __shared__ float s_part[4];
   __shared__ float s_sc[8];
   {  // seed slice (grid.y; all strides 0 for a single seed)
@@ -268,6 +268,10 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
       const int frag = (int)(j >> 8), ln = (int)(j >> 2) & 63, sx = (int)j & 3;
       const int gi = frag >> 3, cb = frag & 7, kk = ln >> 4, jj = ln & 15;
       const int jb = (((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3);
+      if (half_off && copy_mode == 2) {   // bf16x3 layout: the six bf16 planes in the tail of the parameter buffer
+        pqn_x3_store_planes(reinterpret_cast<unsigned short *>(p + half_off), 16 * gi + 4 * kk + sx, 16 * cb + jj, pn);
+        return;
+      }
       w1b[jb] = pn;
       if (half_off) {   // fp16 operand copies of a matmul_f16 layout, in the tail of the parameter buffer itself
         _Float16 *w1h = reinterpret_cast<_Float16 *>(p + half_off);
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
                      float lr_end, double lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
                      float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds, long long pstride,
-                     long long sstride, long long w1bstride, int half_off) {
+                     long long sstride, long long w1bstride, int half_off, int copy_mode) {
   // nparts: number of sum-of-squares partials already in scratch when norm_pass == 0
   const int blocks = pqn_radam_blocks(n);
   if (norm_pass) {
@@ -318,7 +322,7 @@ int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, in
     nparts = blocks;
   }
   hipLaunchKernelGGL(radam_apply_kernel, dim3(blocks, nseeds), dim3(256), 0, st, p, g, m, v, n, count, lr_init, lr_end,
-                     lr_steps, max_norm, nparts, scratch, gnorm_out, w1_off, w1b, pstride, sstride, w1bstride, half_off);
+                     lr_steps, max_norm, nparts, scratch, gnorm_out, w1_off, w1b, pstride, sstride, w1bstride, half_off, copy_mode);
   return pqn_check_launch("radam");
 }
 

@@ -70,6 +70,34 @@ int pqn_check_launch(const char *what);
     }                                 \
   } while (0)
 
+// bf16x3 weight planes (pqn_qnet.hip): x = hi + mid + lo exactly, each a bf16 (round to nearest even); element (i, o)
+// of the fc1 kernel goes to the forward-order and dgrad-order slot of every plane.  Plane = 131072 bf16; the six
+// planes are [3 forward | 3 dgrad].
+PQN_HD unsigned short pqn_bf16_rne(float x) {
+  union { float f; uint32_t u; } v;
+  v.f = x;
+  return (unsigned short)((v.u + 0x7FFFu + ((v.u >> 16) & 1u)) >> 16);
+}
+PQN_HD float pqn_bf16_to_f32(unsigned short b) {
+  union { float f; uint32_t u; } v;
+  v.u = (uint32_t)b << 16;
+  return v.f;
+}
+PQN_HD void pqn_x3_store_planes(unsigned short *planes, int i, int o, float w) {
+  const unsigned short h = pqn_bf16_rne(w);
+  const float r1 = w - pqn_bf16_to_f32(h);
+  const unsigned short m = pqn_bf16_rne(r1);
+  const float r2 = r1 - pqn_bf16_to_f32(m);
+  const unsigned short l = pqn_bf16_rne(r2);
+  const int s = i >> 5, hh = (i >> 4) & 1, kk = (i >> 2) & 3, sx = i & 3;
+  const int jf = ((((s * 8 + (o >> 4)) * 64) + kk * 16 + (o & 15)) << 3) + 4 * hh + sx;
+  const int sK = o >> 5, hd = (o >> 4) & 1, kd = (o >> 2) & 3, sd = o & 3;
+  const int jd = (((((i >> 4) * 4 + sK) * 64) + kd * 16 + (i & 15)) << 3) + 4 * hd + sd;
+  const int P = 1024 * 128;
+  planes[jf] = h; planes[P + jf] = m; planes[2 * P + jf] = l;
+  planes[3 * P + jd] = h; planes[4 * P + jd] = m; planes[5 * P + jd] = l;
+}
+
 // b^t for integer t >= 1 in f64 (<= 2 ulp from pow(); only its f32 cast is used)
 PQN_HD double pqn_powi(double b, int t) {
   double r = 1.0;
@@ -110,7 +138,9 @@ inline pqn_seeds_t pqn_one_seed() {
 int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count, float lr_init,
                      float lr_end, double lr_steps, float max_norm, float *scratch, float *gnorm_out, int w1_off,
                      float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds = 1, long long pstride = 0,
-                     long long sstride = 0, long long w1bstride = 0, int half_off = 0);
+                     long long sstride = 0, long long w1bstride = 0, int half_off = 0, int copy_mode = 1);
+// half_off: float offset of the operand-copy region behind the parameters (pqn_cnn_layout_t.off_w1h; 0 = none);
+// copy_mode: 1 = two fp16 copies of the fc1 kernel (matmul_f16), 2 = six bf16 planes (bf16x3)
 
 // internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,

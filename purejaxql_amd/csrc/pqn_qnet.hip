@@ -424,52 +424,123 @@ PQN_D void x3_mfma6(const X3Frag &a, const X3Frag &b, f32x4 &acc_b, f32x4 &acc_s
   acc_b = X3_MFMA(a.h, b.h, acc_b);
 }
 
-// phase 2, bf16x3: same tile, same work split (wave w owns column block w), the SAME f32 weight fragments streamed
-// through the same 16-deep register ring as phase2_fc1 -- two consecutive 16-wide K groups form one 32-wide MFMA
-// step: lane (col = l&15, kk = l>>4) holds k = 32 s + 4 kk + {0..3} and 32 s + 16 + 4 kk + {0..3} of both operands.
-// Operands are split in registers (no extra copies of the kernel in HBM, the optimizer stays untouched).
-template <int PF = 16>
-PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ w1p, int tid, int tile = -1) {
-  static_assert(QN_WAVES == 8 && PF % 2 == 0, "one column block of 16 outputs per wave; the ring is consumed in pairs");
+// Weight operands of the bf16x3 mode: the fc1 kernel's three bf16 planes, kept in the tail of the parameter buffer
+// (pqn_cnn_layout_t.off_w1h, 6 x 131072 bf16 = 393216 floats) by the optimizer kernel, in the two fragment orders the
+// kernels stream:
+//   forward  Wf[p][s][cb][lane][8]    lane = kk*16 + o%16, slot j: i = 32 s + 16 (j>>2) + 4 kk + (j&3), o = 16 cb + o%16
+//   dgrad    Wd[p][ib][sK][lane][8]   lane = kd*16 + i%16, slot j: o = 32 sK + 16 (j>>2) + 4 kd + (j&3), i = 16 ib + i%16
+// (one dwordx4 per lane = the 8 k-values of a 32-wide MFMA step; 1 KB per wave-instruction).  Splitting the weights
+// once per optimizer step instead of once per use leaves the kernels with the A-operand split only.
+#define X3_PLANE (QN_H1 * QN_HID)                 // bf16 elements per plane
+PQN_HD int x3_fwd_index(int i, int o) {           // element offset inside one forward plane
+  const int s = i >> 5, h = (i >> 4) & 1, kk = (i >> 2) & 3, sx = i & 3;
+  return ((((s * 8 + (o >> 4)) * 64) + kk * 16 + (o & 15)) << 3) + 4 * h + sx;
+}
+PQN_HD int x3_dgrad_index(int i, int o) {         // element offset inside one dgrad plane
+  const int sK = o >> 5, h = (o >> 4) & 1, kd = (o >> 2) & 3, sx = o & 3;
+  return (((((i >> 4) * 4 + sK) * 64) + kd * 16 + (i & 15)) << 3) + 4 * h + sx;
+}
+
+// phase 2, bf16x3: z[16][128] = h1 x W1 on the bf16 matrix core.  Wave w = (K half kh = w&1, column-block pair
+// cp = w>>1): 16 K steps of 32, per step ONE split of the h1 fragment (shared by the two column blocks) and 12 MFMAs;
+// weight planes streamed through a PF-step register ring (6 dwordx4 per step).  The two K halves are added through
+// LDS (the staging buffer is idle here).  Contains one __syncthreads(): every thread of the workgroup must call it.
+template <int PF = 3>
+PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int tid, int tile = -1) {
+  static_assert(QN_WAVES == 8, "2 K halves x 4 column-block pairs");
+  constexpr int NS = 16;   // K steps per wave
   const int lane = tid & 63, wave = tid >> 6;
+  const int kh = wave & 1, cp = wave >> 1;
   if (tile < 0) tile = blockIdx.x;
-  const int rot = ((tile * 8 + (tile >> 3)) & 63) & ~1;   // even: K-group pairs stay aligned
-  const f32x4 *wp = reinterpret_cast<const f32x4 *>(w1p);
+  const int rot = (tile * 5 + (tile >> 4)) & (NS - 1);   // de-phase the weight stream across workgroups
+  const u32x4 *wf = reinterpret_cast<const u32x4 *>(planes);
   const float *arow = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
-  f32x4 acc_b = {0.f, 0.f, 0.f, 0.f}, acc_s = {0.f, 0.f, 0.f, 0.f};
-  f32x4 b[PF];
+  auto wfrag = [&](int p, int st, int c) {   // plane p, K step st (global), column block 2cp + c
+    return wf[(size_t)p * (X3_PLANE / 8) + ((st * 8 + 2 * cp + c) * 64 + lane)];
+  };
+  f32x4 acc_b[2], acc_s[2];
 #pragma unroll
-  for (int i = 0; i < PF; ++i) b[i] = wp[(((i + rot) & 63) * 8 + wave) * 64 + lane];
-  f32x4 a0n = *reinterpret_cast<const f32x4 *>(arow + 16 * (rot & 63));
-  f32x4 a1n = *reinterpret_cast<const f32x4 *>(arow + 16 * ((rot + 1) & 63));
-  auto group_block = [&](int g, auto more_t) {
+  for (int c = 0; c < 2; ++c) { acc_b[c] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_s[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  u32x4 ring[PF][2][3];
+#pragma unroll
+  for (int i = 0; i < PF; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, NS * kh + ((i + rot) & (NS - 1)), c);
+  const int st0 = NS * kh + (rot & (NS - 1));
+  f32x4 a0n = *reinterpret_cast<const f32x4 *>(arow + 32 * st0);
+  f32x4 a1n = *reinterpret_cast<const f32x4 *>(arow + 32 * st0 + 16);
+  auto step_block = [&](int g, auto more_t) {
     constexpr bool more = decltype(more_t)::value;
 #pragma unroll
-    for (int i = 0; i < PF; i += 2) {
-      const f32x4 a0 = a0n, a1 = a1n;   // A fragments one step ahead: the LDS latency hides behind this step's work
-      a0n = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 2 + rot) & 63));
-      a1n = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 3 + rot) & 63));
+    for (int i = 0; i < PF; ++i) {
+      const f32x4 a0 = a0n, a1 = a1n;
+      const int stn = NS * kh + ((g + i + 1 + rot) & (NS - 1));   // next step's A fragment (wraps harmlessly at the end)
+      a0n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn);
+      a1n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn + 16);
       __builtin_amdgcn_sched_barrier(0);
       const X3Frag af = x3_split8(a0, a1);
-      const X3Frag bf = x3_split8(b[i], b[i + 1]);
-      if (more) {   // in-place reload right after the last read of the slot (see phase2_fc1)
-        b[i] = wp[(((g + i + PF + rot) & 63) * 8 + wave) * 64 + lane];
-        b[i + 1] = wp[(((g + i + 1 + PF + rot) & 63) * 8 + wave) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        X3Frag bf;
+        bf.h = ring[i][c][0]; bf.m = ring[i][c][1]; bf.l = ring[i][c][2];
+        x3_mfma6(af, bf, acc_b[c], acc_s[c]);
+        if (more) {
+          const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, st, c);
+        }
       }
-      x3_mfma6(af, bf, acc_b, acc_s);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  static_assert((NS - PF) % PF == 0 || true, "");
+  int g = 0;
 #pragma unroll 1
-  for (int g = 0; g < QN_H1 / 16 - PF; g += PF) group_block(g, std::true_type{});
-  group_block(QN_H1 / 16 - PF, std::false_type{});
-  const f32x4 acc = acc_b + acc_s;
-  const int col = lane & 15, r0 = 4 * (lane >> 4);
-  float *zp = s.z + r0 * QN_ZS + 16 * wave + col;
-  zp[0] = acc.x;
-  zp[QN_ZS] = acc.y;
-  zp[2 * QN_ZS] = acc.z;
-  zp[3 * QN_ZS] = acc.w;
+  for (; g + 2 * PF <= NS; g += PF) step_block(g, std::true_type{});
+  // tail: the remaining NS - g steps; reload only while a later step still needs the slot
+  for (; g < NS; g += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      if (g + i >= NS) break;
+      const f32x4 a0 = a0n, a1 = a1n;
+      const int stn = NS * kh + ((g + i + 1 + rot) & (NS - 1));
+      a0n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn);
+      a1n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn + 16);
+      const X3Frag af = x3_split8(a0, a1);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        X3Frag bf;
+        bf.h = ring[i][c][0]; bf.m = ring[i][c][1]; bf.l = ring[i][c][2];
+        x3_mfma6(af, bf, acc_b[c], acc_s[c]);
+        if (g + i + PF < NS) {
+          const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, st, c);
+        }
+      }
+    }
+  }
+  // fold the two K halves: kh = 1 parks its partial tiles in the (idle) staging buffer, kh = 0 adds and writes z
+  f32x4 *park = reinterpret_cast<f32x4 *>(s.stg);
+  if (kh == 1) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) park[(cp * 2 + c) * 64 + lane] = acc_b[c] + acc_s[c];
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const int col = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const f32x4 acc = (acc_b[c] + acc_s[c]) + park[(cp * 2 + c) * 64 + lane];
+      float *zp = s.z + r0 * QN_ZS + 16 * (2 * cp + c) + col;
+      zp[0] = acc.x;
+      zp[QN_ZS] = acc.y;
+      zp[2 * QN_ZS] = acc.z;
+      zp[3 * QN_ZS] = acc.w;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -607,7 +678,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
   if (ablate != 1 && ablate != 6 && ablate != 7) phase1_conv<C>(s, tid);
   __syncthreads();
   if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
-  else if (L.matmul_f16 == 2) phase2_fc1_x3<16>(s, theta + L.off_w1, tid);
+  else if (L.matmul_f16 == 2) phase2_fc1_x3<3>(s, theta + L.off_w1h, tid);
   else if (ablate == 0 || ablate == 1 || ablate == 5) phase2_fc1<0>(s, theta + L.off_w1, tid);
   else if (ablate == 2) phase2_fc1<2>(s, theta + L.off_w1, tid);
   else if (ablate == 3) phase2_fc1<3>(s, theta + L.off_w1, tid);
@@ -697,7 +768,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
     phase1_conv<C>(s, tid);
     __syncthreads();
     if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid, (e0 - e_off) / QN_TILE);
-    else if (L.matmul_f16 == 2) phase2_fc1_x3<8>(s, theta + L.off_w1, tid, (e0 - e_off) / QN_TILE);
+    else if (L.matmul_f16 == 2) phase2_fc1_x3<2>(s, theta + L.off_w1h, tid, (e0 - e_off) / QN_TILE);
     else phase2_fc1<0, 8>(s, theta + L.off_w1, tid, (e0 - e_off) / QN_TILE);   // 8 in flight: the env state lives in registers across this loop
     __syncthreads();
     if (tid < 256) {
@@ -1027,7 +1098,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   __syncthreads();
   T1_STAMP(2);
   if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
-  else if (L.matmul_f16 == 2) phase2_fc1_x3<16>(s, theta + L.off_w1, tid);
+  else if (L.matmul_f16 == 2) phase2_fc1_x3<3>(s, theta + L.off_w1h, tid);
   else phase2_fc1<0>(s, theta + L.off_w1, tid);
   // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
   // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
@@ -1113,9 +1184,9 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     for (int ip = 0; ip < IBW / 2 - 1; ++ip) pair_step(ip, std::true_type{});
     pair_step(IBW / 2 - 1, std::false_type{});
   } else if (L.matmul_f16 == 2) {
-    // bf16x3 split operands (see phase2_fc1_x3): the same dgrad-order f32 fragments of the fc1 kernel, split in
-    // registers; the dz tile is split once per wave (4 K steps of 32 outputs) and stays in registers.
-    const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
+    // bf16x3 split operands (see phase2_fc1_x3): the dz tile is split once per wave (4 K steps of 32 outputs, kept in
+    // registers), the fc1 kernel's dgrad-order bf16 planes are streamed one i-block (12 dwordx4) ahead.
+    const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
     X3Frag afr[4];
 #pragma unroll
     for (int sK = 0; sK < 4; ++sK) {
@@ -1125,41 +1196,43 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     }
     const int col = lane & 15, r0 = 4 * (lane >> 4);
     constexpr int IBW = 64 / QN_WAVES;
-    constexpr int PF = 16;
     const int ib_first = IBW * wave;
     const int prot = blockIdx.x & (IBW - 1);
-    auto frag = [&](int n) { return wb[((n & 7) * 64 + ib_first + (((n >> 3) + prot) & (IBW - 1))) * 64 + lane]; };
-    f32x4 ring[PF];
+    auto frag = [&](int pl, int ibk, int sK) {   // plane pl, the wave's ibk-th i-block (rotated), K step sK
+      const int ib = ib_first + ((ibk + prot) & (IBW - 1));
+      return wd[(size_t)pl * (X3_PLANE / 8) + ((ib * 4 + sK) * 64 + lane)];
+    };
+    u32x4 ring[4][3];
 #pragma unroll
-    for (int n = 0; n < PF; ++n) ring[n] = frag(n);
-    auto pair_step = [&](int ip, auto more_t) {
+    for (int sK = 0; sK < 4; ++sK)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, 0, sK);
+    auto ib_step = [&](int ibk, auto more_t) {
       constexpr bool more = decltype(more_t)::value;
+      const int ib = ib_first + ((ibk + prot) & (IBW - 1));
+      float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
+      const float m0 = p0[0], m1 = p0[QN_H1S], m2 = p0[2 * QN_H1S], m3 = p0[3 * QN_H1S];   // relu mask, read ahead
+      f32x4 acc_b = {0.f, 0.f, 0.f, 0.f}, acc_s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ib = ib_first + ((2 * ip + h + prot) & (IBW - 1));
-        float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
-        const float m0 = p0[0], m1 = p0[QN_H1S], m2 = p0[2 * QN_H1S], m3 = p0[3 * QN_H1S];
-        f32x4 acc_b = {0.f, 0.f, 0.f, 0.f}, acc_s = {0.f, 0.f, 0.f, 0.f};
+      for (int sK = 0; sK < 4; ++sK) {
+        X3Frag bf;
+        bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
+        x3_mfma6(afr[sK], bf, acc_b, acc_s);
+        if (more) {
 #pragma unroll
-        for (int sK = 0; sK < 4; ++sK) {
-          const X3Frag bf = x3_split8(ring[8 * h + 2 * sK], ring[8 * h + 2 * sK + 1]);
-          if (more) {
-            ring[8 * h + 2 * sK] = frag(16 * (ip + 1) + 8 * h + 2 * sK);
-            ring[8 * h + 2 * sK + 1] = frag(16 * (ip + 1) + 8 * h + 2 * sK + 1);
-          }
-          x3_mfma6(afr[sK], bf, acc_b, acc_s);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, ibk + 1, sK);
         }
-        const f32x4 acc0 = acc_b + acc_s;
-        p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
-        p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
-        p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
-        p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
       }
+      const f32x4 acc0 = acc_b + acc_s;
+      p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
+      p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
+      p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
+      p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
     };
 #pragma unroll 1
-    for (int ip = 0; ip < IBW / 2 - 1; ++ip) pair_step(ip, std::true_type{});
-    pair_step(IBW / 2 - 1, std::false_type{});
+    for (int ibk = 0; ibk < IBW - 1; ++ibk) ib_step(ibk, std::true_type{});
+    ib_step(IBW - 1, std::false_type{});
   } else if (!(ablate & 1)) {
     const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
     f32x4 afr[8];
@@ -1699,7 +1772,8 @@ extern "C" int pqn_cnn_layout_ex(int32_t c, int32_t a, int32_t matmul_f16, pqn_c
   PQN_REQUIRE(matmul_f16 >= 0 && matmul_f16 <= 2, "pqn_cnn_layout_ex: operand mode %d (0 f32, 1 f16, 2 bf16x3)", matmul_f16);
   L->matmul_f16 = matmul_f16;                              // 0: f32 MFMA; 1: fp16 operands; 2: bf16x3 split operands
   L->off_w1h = off;                                        // mode 1: 2 x 131072 halves = 131072 floats behind the parameters
-  L->alloc = matmul_f16 == 1 ? off + QN_H1 * QN_HID : off;
+  L->alloc = matmul_f16 == 1 ? off + QN_H1 * QN_HID            // two fp16 copies
+                             : (matmul_f16 == 2 ? off + 3 * QN_H1 * QN_HID : off);   // mode 2: 6 bf16 planes (3 forward + 3 dgrad order)
   return PQN_OK;
 }
 
@@ -2156,11 +2230,13 @@ extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float
   PQN_REQUIRE(L && theta && w1b && grad && m && v && count && workspace, "pqn_qnet_cnn_apply: NULL argument");
   return pqn_launch_radam(theta, grad, m, v, L->total, count, lr_init, lr_end, lr_steps, max_norm, workspace, gnorm_out,
                           L->off_w1, w1b, recompute_norm, grad_reduce_blocks(L->total), (hipStream_t)stream, 1, 0, 0, 0,
-                          L->matmul_f16 == 1 ? L->off_w1h : 0);
+                          L->matmul_f16 != 0 ? L->off_w1h : 0, L->matmul_f16);
 }
 
-// w1b: f32 dgrad-fragment copy (nullable);  w1h: fp16 forward-fragment copy + fp16 dgrad-fragment copy (nullable)
-__global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict__ w1b, _Float16 *__restrict__ w1h) {
+// w1b: f32 dgrad-fragment copy (nullable);  w1h: fp16 forward-fragment copy + fp16 dgrad-fragment copy (nullable);
+// x3: the six bf16 planes of the bf16x3 mode (nullable)
+__global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict__ w1b, _Float16 *__restrict__ w1h,
+                                unsigned short *__restrict__ x3) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= QN_H1 * QN_HID) return;
   const int frag = j >> 8, ln = (j >> 2) & 63, sx = j & 3;
@@ -2172,13 +2248,15 @@ __global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict
     w1h[j] = (_Float16)w;
     w1h[QN_H1 * QN_HID + jb] = (_Float16)w;
   }
+  if (x3) pqn_x3_store_planes(x3, 16 * gi + 4 * kk + sx, 16 * cb + jj, w);
 }
 
 // theta is written only in its tail (the fp16 copies of a matmul_f16 layout); pass w1b = NULL to refresh just those
 extern "C" int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *L, float *theta, float *w1b, void *stream) {
   PQN_REQUIRE(L && theta, "pqn_qnet_cnn_pack_w1b: NULL argument");
-  PQN_REQUIRE(w1b || L->matmul_f16 == 1, "pqn_qnet_cnn_pack_w1b: nothing to do");
+  PQN_REQUIRE(w1b || L->matmul_f16 != 0, "pqn_qnet_cnn_pack_w1b: nothing to do");
   hipLaunchKernelGGL(pack_w1b_kernel, dim3(QN_H1 * QN_HID / 256), dim3(256), 0, (hipStream_t)stream, theta + L->off_w1, w1b,
-                     L->matmul_f16 == 1 ? reinterpret_cast<_Float16 *>(theta + L->off_w1h) : (_Float16 *)nullptr);
+                     L->matmul_f16 == 1 ? reinterpret_cast<_Float16 *>(theta + L->off_w1h) : (_Float16 *)nullptr,
+                     L->matmul_f16 == 2 ? reinterpret_cast<unsigned short *>(theta + L->off_w1h) : (unsigned short *)nullptr);
   return pqn_check_launch("pqn_qnet_cnn_pack_w1b");
 }

@@ -67,8 +67,9 @@ class CnnKernelLayout:
         return out
 
     def refresh_copies(self, theta_k: torch.Tensor, w1b: Optional[torch.Tensor] = None):
-        """Re-derive the fragment-order copies of the fc1 kernel (w1b: f32 dgrad copy; fp16 copies in theta's tail)."""
-        if theta_k.is_cuda and (w1b is not None or self.matmul_f16):
+        """Re-derive the fragment-order copies of the fc1 kernel (w1b: f32 dgrad copy; fp16 copies / bf16x3 planes in
+        theta's tail, by operand mode)."""
+        if theta_k.is_cuda and (w1b is not None or self.mode != 0):
             _lib.check(_lib.load().pqn_qnet_cnn_pack_w1b(C.byref(self.struct), _lib.ptr(theta_k), _lib.ptr(w1b),
                                                          _lib.stream_ptr()), "pqn_qnet_cnn_pack_w1b")
 

@@ -34,7 +34,7 @@ def test_cnn_forward_vs_oracle(gpu, oracle, c, a, n, mode):
     torch.manual_seed(1234)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
     lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode(mode))
-    assert lay.alloc == lay.total      # no operand copies in HBM for either mode
+    assert lay.alloc == lay.total + (3 * 1024 * 128 if mode == "bf16x3" else 0)   # bf16x3: six bf16 planes of the fc1 kernel
     assert lay.num_flax == net.num_params
     theta = net.init(5) + 0.05 * torch.randn(net.num_params, device=gpu)
     theta_k = lay.to_kernel(theta)
@@ -113,12 +113,22 @@ def test_cnn_grad_vs_oracle(gpu, oracle, c, a, nb, pool, mode):
         gn = oracle.radam_clip_step(th, g_flax, m, v, step, np.float32(lr), 10.0)
         assert abs(float(tr.gnorm[0]) - gn) <= 1e-5 * gn
         np.testing.assert_allclose(_np(tr.theta_flax()), th, rtol=1e-5, atol=1e-7)
-    # the dgrad copy of the fc1 kernel stays in step with theta
+    # the operand copies of the fc1 kernel stay in step with theta
     w1 = _np(tr.theta_flax())[2 * c + 9 * c * 16 + 48:][:1024 * 128].reshape(1024, 128)
     i = np.arange(1024)[:, None]
     o = np.arange(128)[None, :]
-    addr = (((o // 16) * 64 + i // 16) * 64 + ((o % 16) // 4) * 16 + (i % 16)) * 4 + (o % 4)
-    np.testing.assert_array_equal(_np(tr.w1b)[addr], w1)
+    if mode == "f32":     # f32 dgrad-fragment copy
+        addr = (((o // 16) * 64 + i // 16) * 64 + ((o % 16) // 4) * 16 + (i % 16)) * 4 + (o % 4)
+        np.testing.assert_array_equal(_np(tr.w1b)[addr], w1)
+    else:                 # bf16x3: hi + mid + lo == w EXACTLY, in the forward- and the dgrad-order planes
+        planes = _np(tr.theta[lay.total:lay.total + 3 * 1024 * 128].view(torch.int16)).view(np.uint16).reshape(6, 1024 * 128)
+        to_f32 = lambda b: (b.astype(np.uint32) << 16).view(np.float32)
+        jf = ((((i // 32) * 8 + o // 16) * 64 + ((i % 16) // 4) * 16 + o % 16) * 8) + 4 * ((i // 16) % 2) + i % 4
+        jd = ((((i // 16) * 4 + o // 32) * 64 + ((o % 16) // 4) * 16 + i % 16) * 8) + 4 * ((o // 16) % 2) + o % 4
+        for base, j in ((0, jf), (3, jd)):
+            h, m, l = (to_f32(planes[base + k][j]) for k in range(3))
+            np.testing.assert_array_equal((h.astype(np.float64) + m + l).astype(np.float32), w1)
+            assert np.abs(m).max() <= np.abs(h).max() * 2.0 ** -7 and np.abs(l).max() <= np.abs(h).max() * 2.0 ** -15
 
 
 @pytest.mark.parametrize("d,h,layers,a,n", [(4, 256, 2, 2, 16), (4, 256, 2, 2, 128), (6, 64, 1, 3, 37), (4, 128, 3, 2, 100)])
