@@ -213,14 +213,18 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
     count += sd;
     if (w1b) w1b += sd * w1bstride;
   }
-  float acc = 0.0f;
-  for (int i = threadIdx.x; i < nparts; i += 256) acc += scratch[i];
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float gnorm = sqrtf((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
-    const int32_t c = reinterpret_cast<const int32_t *>(scratch)[1023];
+  // the step-count-dependent scalars (f64: two integer powers, a square root, the schedule) are derived by lane 0 of
+  // wave 3 while the norm partials are in flight: the f64 chain is off the critical path
+  int32_t c_snap = 0;
+  if (threadIdx.x == 192) c_snap = reinterpret_cast<const int32_t *>(scratch)[1023];
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {   // nparts <= 1022: all loads of a lane issued before any is consumed
+    const int i = threadIdx.x + 256 * q;
+    if (i < nparts) part[q] = scratch[i];
+  }
+  if (threadIdx.x == 192) {
+    const int32_t c = c_snap;
     const double b1 = 0.9, b2 = 0.999, thr = 5.0;
     const double t = (double)c + 1.0;
     const double b1t = pqn_powi(b1, c + 1), b2t = pqn_powi(b2, c + 1);   // square-and-multiply: ~40 f64 mults, no libm pow
@@ -234,17 +238,22 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
       if (cc > lr_steps) cc = lr_steps;
       lr = (float)(((double)lr_init - (double)lr_end) * (1.0 - cc / lr_steps) + (double)lr_end);
     }
-    s_sc[0] = gnorm;
-    s_sc[1] = (gnorm < max_norm) ? 0.0f : 1.0f;
     s_sc[2] = (float)(1.0 - b1t);
     s_sc[3] = (float)(1.0 - b2t);
     s_sc[4] = rect ? 1.0f : 0.0f;
     s_sc[5] = r;
     s_sc[6] = lr;
-    if (blockIdx.x == 0) {
-      *count = c + 1;
-      if (gnorm_out) *gnorm_out = gnorm;
-    }
+    if (blockIdx.x == 0) *count = c + 1;
+  }
+  float acc = ((part[0] + part[1]) + part[2]) + part[3];   // == the strided loop's order
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gnorm = sqrtf((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+    s_sc[0] = gnorm;
+    s_sc[1] = (gnorm < max_norm) ? 0.0f : 1.0f;
+    if (blockIdx.x == 0 && gnorm_out) *gnorm_out = gnorm;
   }
   __syncthreads();
   const float gnorm = s_sc[0];

@@ -1699,7 +1699,16 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
   if (blockIdx.x < QR_W1_BLOCKS) {
     const int j4 = blockIdx.x * 256 + threadIdx.x;  // float4 index inside the fc1 region
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nks; ++k) g += reinterpret_cast<const f32x4 *>(wpart + (size_t)k * QN_H1 * QN_HID)[j4];
+    // 8 slab loads in flight at a time (a plain loop serialises 16 dependent L2 round trips), added in slab order
+    for (int k0 = 0; k0 < nks; k0 += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        t[q] = (k0 + q < nks) ? reinterpret_cast<const f32x4 *>(wpart + (size_t)(k0 + q) * QN_H1 * QN_HID)[j4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (k0 + q < nks) g += t[q];
+    }
     reinterpret_cast<f32x4 *>(grad + L.off_w1)[j4] = g;
     ss = fmaf(g.x, g.x, fmaf(g.y, g.y, fmaf(g.z, g.z, g.w * g.w)));
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
