@@ -51,6 +51,8 @@ enum {
   PQN_ENV_ASTERIX = 2,       /* "Asterix-MinAtar"       */
   PQN_ENV_FREEWAY = 3,       /* "Freeway-MinAtar"       */
   PQN_ENV_SPACEINVADERS = 4, /* "SpaceInvaders-MinAtar" */
+  PQN_ENV_CRAFTAX_CLASSIC = 5, /* "Craftax-Classic-Symbolic-v1": flat symbolic observation f32[1345], 17 actions
+                                  (make_craftax_env_from_name, pqn_craftax.py:96-98; rules restated, csrc/pqn_craftax.hip) */
 };
 
 /* What gymnax.make(name) -> (env, env_params) exposes to make_train

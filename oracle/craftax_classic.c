@@ -212,11 +212,11 @@ static float cc_step_one(int32_t *si, float *sf, int32_t action, uint64_t key, u
     const int damage = inv[I_IRON_SWORD] ? 5 : (inv[I_STONE_SWORD] ? 3 : (inv[I_WOOD_SWORD] ? 2 : 1));
     int hit = 0;
     for (int i = 0; i < CC_NZ && !hit; ++i) { int32_t *z = s + 20 + 5 * i;
-      if (z[4] && z[0] == tr && z[1] == tc) { hit = 1; z[2] -= damage; if (z[2] <= 0) { z[4] = 0; give(s, ACH_DEFEAT_ZOMBIE); } } }
+      if (z[4] && z[0] == tr && z[1] == tc) { hit = 1; z[2] -= damage; if (z[2] <= 0) { z[2] = 0; z[4] = 0; give(s, ACH_DEFEAT_ZOMBIE); } } }
     for (int i = 0; i < CC_NC && !hit; ++i) { int32_t *w = s + 35 + 4 * i;
-      if (w[3] && w[0] == tr && w[1] == tc) { hit = 1; w[2] -= damage; if (w[2] <= 0) { w[3] = 0; s[4] = imin(s[4] + 6, 9); sf[1] = 0.0f; give(s, ACH_EAT_COW); } } }
+      if (w[3] && w[0] == tr && w[1] == tc) { hit = 1; w[2] -= damage; if (w[2] <= 0) { w[2] = 0; w[3] = 0; s[4] = imin(s[4] + 6, 9); sf[1] = 0.0f; give(s, ACH_EAT_COW); } } }
     for (int i = 0; i < CC_NS && !hit; ++i) { int32_t *k = s + 47 + 5 * i;
-      if (k[4] && k[0] == tr && k[1] == tc) { hit = 1; k[2] -= damage; if (k[2] <= 0) { k[4] = 0; give(s, ACH_DEFEAT_SKELETON); } } }
+      if (k[4] && k[0] == tr && k[1] == tc) { hit = 1; k[2] -= damage; if (k[2] <= 0) { k[2] = 0; k[4] = 0; give(s, ACH_DEFEAT_SKELETON); } } }
     if (!hit) {
       int32_t *cell = map + tr * CC_MAP + tc;
       switch (*cell) {

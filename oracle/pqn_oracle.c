@@ -504,10 +504,19 @@ int pqn_oracle_env_spec(int env_id, pqn_oracle_spec_t *spec) {
       spec->obs_dim[0] = 10; spec->obs_dim[1] = 10; spec->obs_dim[2] = 6;
       spec->obs_size = 600; spec->num_actions = 4; spec->max_steps = 1000; spec->si = SI_SI; spec->sf = 0;
       return 0;
+    case PQN_ORACLE_ENV_CRAFTAX_CLASSIC:   /* flat symbolic observation (craftax_classic.c) */
+      spec->obs_dim[0] = 1345; spec->obs_dim[1] = 0; spec->obs_dim[2] = 0;
+      spec->obs_size = 1345; spec->num_actions = 17; spec->max_steps = 10000; spec->si = 4096 + 111; spec->sf = 4;
+      return 0;
     default:
       return -1;
   }
 }
+
+/* Craftax-Classic (craftax_classic.c) */
+void cc_reset_one(uint64_t key, uint32_t e, int32_t *si, float *sf);
+void cc_obs_one(const int32_t *si, float *obs);
+float cc_step_env(int32_t *si, float *sf, int32_t action, uint64_t key, uint32_t e, int *done);
 
 static void obs_one(int env_id, const int32_t *si, const float *sf, float *obs) {
   if (env_id == PQN_ORACLE_ENV_BREAKOUT) breakout_obs_one(si, obs);
@@ -515,6 +524,7 @@ static void obs_one(int env_id, const int32_t *si, const float *sf, float *obs) 
   else if (env_id == PQN_ORACLE_ENV_ASTERIX) asterix_obs_one(si, obs);
   else if (env_id == PQN_ORACLE_ENV_FREEWAY) freeway_obs_one(si, obs);
   else if (env_id == PQN_ORACLE_ENV_SPACEINVADERS) si_obs_one(si, obs);
+  else if (env_id == PQN_ORACLE_ENV_CRAFTAX_CLASSIC) cc_obs_one(si, obs);
 }
 
 static void reset_one(int env_id, uint64_t key, uint32_t e, int32_t *si, float *sf) {
@@ -530,6 +540,8 @@ static void reset_one(int env_id, uint64_t key, uint32_t e, int32_t *si, float *
     freeway_reset_one(si, key, e);
   } else if (env_id == PQN_ORACLE_ENV_SPACEINVADERS) {
     si_reset_one(si);
+  } else if (env_id == PQN_ORACLE_ENV_CRAFTAX_CLASSIC) {
+    cc_reset_one(key, e, si, sf);
   }
 }
 
@@ -573,6 +585,7 @@ int pqn_oracle_env_step(int env_id, int32_t n, uint64_t key, int32_t *si, float 
     else if (env_id == PQN_ORACLE_ENV_CARTPOLE) cartpole_step_one(s, f, action[e], sp.max_steps, &r, &d);
     else if (env_id == PQN_ORACLE_ENV_ASTERIX) asterix_step_one(s, action[e], key, (uint32_t)e, sp.max_steps, &r, &d);
     else if (env_id == PQN_ORACLE_ENV_FREEWAY) freeway_step_one(s, action[e], key, (uint32_t)e, sp.max_steps, &r, &d);
+    else if (env_id == PQN_ORACLE_ENV_CRAFTAX_CLASSIC) r = cc_step_env(s, f, action[e], key, (uint32_t)e, &d);
     else si_step_one(s, action[e], sp.max_steps, &r, &d);
     if (d && autoreset) reset_one(env_id, key, (uint32_t)e, s, f);
     if (obs) obs_one(env_id, s, f, obs + (size_t)e * sp.obs_size);

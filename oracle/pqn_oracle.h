@@ -36,6 +36,7 @@ enum {
   PQN_ORACLE_ENV_ASTERIX = 2,       /* Asterix-MinAtar       */
   PQN_ORACLE_ENV_FREEWAY = 3,       /* Freeway-MinAtar       */
   PQN_ORACLE_ENV_SPACEINVADERS = 4, /* SpaceInvaders-MinAtar */
+  PQN_ORACLE_ENV_CRAFTAX_CLASSIC = 5, /* Craftax-Classic-Symbolic-v1 (craftax_classic.c; third-party rules, parity unpinned) */
 };
 
 typedef struct {

@@ -142,6 +142,13 @@ int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, in
 // half_off: float offset of the operand-copy region behind the parameters (pqn_cnn_layout_t.off_w1h; 0 = none);
 // copy_mode: 1 = two fp16 copies of the fc1 kernel (matmul_f16), 2 = six bf16 planes (bf16x3)
 
+// Craftax-Classic (pqn_craftax.hip); reset_ratio 0 = gymnax auto-reset, > 0 = optimistic resets (scratch u64[n])
+void pqn_craftax_spec(pqn_env_spec_t *s);
+int pqn_craftax_reset(int n, uint64_t key, uint32_t *state, float *obs, hipStream_t st);
+int pqn_craftax_step(int n, uint64_t key, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
+                     const pqn_step_out_t &out, int reset_ratio, uint64_t *scratch, int32_t *slot_out, hipStream_t st);
+int pqn_craftax_canon(int n, int do_export, uint32_t *state, int32_t *si, float *sf, uint32_t *log, hipStream_t st);
+
 // internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
                      const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0, int key_stride = 0);

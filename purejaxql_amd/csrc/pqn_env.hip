@@ -236,6 +236,7 @@ extern "C" int pqn_env_id(const char *name) {
   if (!strcmp(name, "Asterix-MinAtar")) return PQN_ENV_ASTERIX;
   if (!strcmp(name, "Freeway-MinAtar")) return PQN_ENV_FREEWAY;
   if (!strcmp(name, "SpaceInvaders-MinAtar")) return PQN_ENV_SPACEINVADERS;
+  if (!strcmp(name, "Craftax-Classic-Symbolic-v1")) return PQN_ENV_CRAFTAX_CLASSIC;
   pqn_set_error("unknown or unsupported env name '%s'", name);
   return PQN_E_UNSUPPORTED;
 }
@@ -248,6 +249,7 @@ extern "C" int pqn_env_spec(int env_id, pqn_env_spec_t *spec) {
     case PQN_ENV_ASTERIX: fill_spec<Asterix>(spec, 10, 10, 4); return PQN_OK;
     case PQN_ENV_FREEWAY: fill_spec<Freeway>(spec, 10, 10, 7); return PQN_OK;
     case PQN_ENV_SPACEINVADERS: fill_spec<SpaceInvaders>(spec, 10, 10, 6); return PQN_OK;
+    case PQN_ENV_CRAFTAX_CLASSIC: pqn_craftax_spec(spec); return PQN_OK;
     default: pqn_set_error("pqn_env_spec: unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
   }
 }
@@ -274,6 +276,12 @@ static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, fl
     pqn_set_error("seed-batched env.step is implemented for the flat-observation envs (the MinAtar path batches seeds "
                   "inside pqn_cnn_rollout_seeds)");
     return PQN_E_UNSUPPORTED;
+  }
+  if (env_id == PQN_ENV_CRAFTAX_CLASSIC) {   // map-in-memory env: its own kernels, stepped in place
+    PQN_REQUIRE(IS_RESET || si == so, "Craftax-Classic steps its state in place: state_in must equal state_out");
+    PQN_REQUIRE(!opt_keys, "Craftax-Classic: use pqn_env_step_optimistic");
+    if (IS_RESET) return pqn_craftax_reset(n, key, so, out.obs, st);
+    return pqn_craftax_step(n, key, key_dev, rscale, so, action, out, 0, nullptr, nullptr, st);
   }
   switch (env_id) {
     case PQN_ENV_BREAKOUT: launch_minatar<Breakout, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st, opt_keys); break;
@@ -319,6 +327,10 @@ extern "C" int pqn_env_step_optimistic(int env_id, int32_t n, uint64_t key, int3
   PQN_REQUIRE(reset_ratio > 0 && n % reset_ratio == 0,
               "pqn_env_step_optimistic: reset ratio %d must perfectly divide num envs %d", reset_ratio, n);   // :96-98
   hipStream_t st = (hipStream_t)stream;
+  if (env_id == PQN_ENV_CRAFTAX_CLASSIC) {
+    PQN_REQUIRE(state_in == state_out, "Craftax-Classic steps its state in place: state_in must equal state_out");
+    return pqn_craftax_step(n, key, nullptr, 1.0f, state_out, action, *out, reset_ratio, scratch, slot_out, st);
+  }
   const int rc = dispatch<false>(env_id, n, key, nullptr, 1.0f, state_in, state_out, action, *out, st, 0, 0, scratch);
   if (rc != PQN_OK) return rc;
   const dim3 g((n + 255) / 256), b(256);
@@ -342,6 +354,7 @@ int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, u
 template <bool EXPORT>
 static int canon(int env_id, int n, uint32_t *state, int32_t *si, float *sf, uint32_t *log, hipStream_t st) {
   PQN_REQUIRE(n > 0 && state && si, "canonical state: NULL argument or n <= 0");
+  if (env_id == PQN_ENV_CRAFTAX_CLASSIC) return pqn_craftax_canon(n, EXPORT ? 1 : 0, state, si, sf, log, st);
   const dim3 g((n + 127) / 128), b(128);
   switch (env_id) {
     case PQN_ENV_BREAKOUT: hipLaunchKernelGGL((canon_kernel<Breakout, EXPORT>), g, b, 0, st, n, state, si, sf, log); break;

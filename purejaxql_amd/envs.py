@@ -74,6 +74,7 @@ class Environment:
         self.state_words = int(spec.state_words)
         self.num_actions = int(spec.num_actions)
         self.default_params = EnvParams(max_steps_in_episode=int(spec.max_steps))
+        self.in_place_only = name.startswith("Craftax")
         self.device = torch.device(device) if device is not None else torch.device("cuda")
 
     # -- spaces ----------------------------------------------------------------
@@ -124,7 +125,12 @@ class Environment:
         if action.numel() != n or not action.is_contiguous():
             raise ValueError(f"action must be a contiguous [{n}] tensor")
         dev = self.device
-        new_words = state.words if inplace else torch.empty_like(state.words)
+        src_words = state.words
+        if self.in_place_only:      # map-in-memory envs (Craftax) step their state in place: functional calls copy first
+            new_words = state.words if inplace else state.words.clone()
+            src_words = new_words
+        else:
+            new_words = state.words if inplace else torch.empty_like(state.words)
         obs, bits = self._alloc_obs(n, want_obs, want_bits)
         reward = torch.empty(n, dtype=torch.float32, device=dev)
         done = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -139,7 +145,7 @@ class Environment:
             out.returned_episode_returns = _lib.ptr(rer)
             out.returned_episode_lengths = _lib.ptr(rel)
             out.timestep = _lib.ptr(ts)
-        _lib.check(lib.pqn_env_step(self.env_id, n, key, _lib.ptr(state.words), _lib.ptr(new_words),
+        _lib.check(lib.pqn_env_step(self.env_id, n, key, _lib.ptr(src_words), _lib.ptr(new_words),
                                     _lib.ptr(action), C.byref(out), _lib.stream_ptr()), "pqn_env_step")
         done_b = done.view(torch.bool)
         if log_info:
@@ -266,7 +272,12 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
             action = action.to(torch.int32)
         if self._scratch is None or self._scratch.device != state.words.device:
             self._scratch = torch.empty(n, dtype=torch.int64, device=dev)
-        new_words = state.words if inplace else torch.empty_like(state.words)
+        src_words = state.words
+        if base.in_place_only:
+            new_words = state.words if inplace else state.words.clone()
+            src_words = new_words
+        else:
+            new_words = state.words if inplace else torch.empty_like(state.words)
         obs, bits = base._alloc_obs(n, want_obs, want_bits)
         reward = torch.empty(n, dtype=torch.float32, device=dev)
         done = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -280,7 +291,7 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
             ts = torch.empty(n, dtype=torch.int32, device=dev)
             out.returned_episode_returns, out.returned_episode_lengths, out.timestep = _lib.ptr(rer), _lib.ptr(rel), _lib.ptr(ts)
         slots = torch.empty(n, dtype=torch.int32, device=dev) if want_slots else None
-        _lib.check(lib.pqn_env_step_optimistic(base.env_id, n, rng, self.reset_ratio, _lib.ptr(state.words),
+        _lib.check(lib.pqn_env_step_optimistic(base.env_id, n, rng, self.reset_ratio, _lib.ptr(src_words),
                                                _lib.ptr(new_words), _lib.ptr(action), C.byref(out),
                                                _lib.ptr(self._scratch), _lib.ptr(slots), _lib.stream_ptr()),
                    "pqn_env_step_optimistic")
