@@ -662,9 +662,12 @@ struct LogRec {
   PQN_D void step(float reward, int done) {
     const float new_ret = ep_ret + reward;
     const int new_len = ep_len + 1;
-    ep_ret = done ? 0.0f : new_ret;
+    // the arithmetic form of the reference (utils/craftax_wrappers.py:186-194), not selects: with negative rewards
+    // (Craftax) x * 0 is -0.0 and the record must carry the same bits
+    const float keep = (float)(1 - done), take = (float)done;
+    ep_ret = new_ret * keep;
     ep_len = done ? 0 : new_len;
-    ret_ret = done ? new_ret : ret_ret;
+    ret_ret = ret_ret * keep + new_ret * take;
     ret_len = done ? new_len : ret_len;
     timestep += 1;
   }
