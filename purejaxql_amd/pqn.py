@@ -53,6 +53,37 @@ def derive_config(config: Dict[str, Any]) -> Dict[str, Any]:
     return config
 
 
+class TrainState:
+    """The fields of the reference's CustomTrainState a caller reads (pqn_minatar.py:82-86): params (flax tree keyed by
+    "/"-joined names), batch_stats, timesteps, n_updates, grad_steps, plus the optimizer state of this build."""
+
+    def __init__(self, rs):
+        self.params, self.batch_stats = rs["params"], rs.get("batch_stats", {})
+        self.timesteps, self.n_updates, self.grad_steps = rs["timesteps"], rs["n_updates"], rs["grad_steps"]
+        self.opt_state = {k: rs[k] for k in ("opt_count", "opt_mu", "opt_nu") if k in rs}
+
+
+class RunnerState(dict):
+    """train()'s `runner_state`.  A dict of named entries (this build's form) that ALSO answers the reference's tuple
+    protocol (pqn_minatar.py:420-424: `(train_state, (obs, env_state), test_metrics, rng)`), so that code written
+    against the reference -- `runner_state[0].params`, `train_state, expl_state, test_metrics, rng = runner_state` --
+    keeps working."""
+
+    def _tuple(self):
+        return (TrainState(self), (self["last_obs"], self["env_state"]), self.get("test_metrics"), self.get("rng"))
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return self._tuple()[k]
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        return iter(self._tuple())
+
+    def __len__(self):
+        return 4
+
+
 class _Rollout:
     """Time-major rollout record of one update: the reference's `Transition`
     (pqn_minatar.py:72-79) with next_obs folded into slot T of the observation buffer and q_val
@@ -611,11 +642,11 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                     for j, k in enumerate(INFO_KEYS):
                         metrics[f"test/{k}"] = test_rows[:, j]
             theta_f = policy.theta_flax()
-            runner_state = {"params": network.views(theta_f), "theta": theta_f, "env_state": words,
+            runner_state = RunnerState({"params": network.views(theta_f), "theta": theta_f, "env_state": words,
                             "last_obs": obuf[0], "test_metrics": tm_box[0], "network": network, "backend": backend,
                             "driver": None if driver is None else ("graph" if driver.graph is not None else "eager"),
-                            "driver_graph_error": None if driver is None else driver.graph_error,
-                            **policy.opt_state(), **counters}
+                            "driver_graph_error": None if driver is None else driver.graph_error, "rng": K,
+                            **policy.opt_state(), **counters})
             return {"runner_state": runner_state, "metrics": metrics}
 
         update.driver = driver   # bench.py switches graph replay off for its HIP-event timing pass
@@ -744,13 +775,13 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                         metrics[f"test/{k}"] = test_rows[s, :, j]
                 theta_f = layout.to_flax(drv.theta_k(s))
                 sl = slice(s * N, (s + 1) * N)
-                runner_state = {"params": network.views(theta_f), "theta": theta_f, "env_state": words[:, sl].contiguous(),
+                runner_state = RunnerState({"params": network.views(theta_f), "theta": theta_f, "env_state": words[:, sl].contiguous(),
                                 "last_obs": (ro.bits if packed else ro.obs)[0, sl], "test_metrics": tm_box[0][s],
-                                "network": network,
+                                "network": network, "rng": int(rngs[s]) & 0xFFFFFFFFFFFFFFFF,
                                 "backend": backend, "driver": "graph" if drv.graph is not None else "eager",
                                 "driver_graph_error": drv.graph_error, "opt_count": drv.count[s:s + 1],
                                 "opt_mu": drv.m[s, :layout.total], "opt_nu": drv.v[s, :layout.total],
-                                "kernel_layout": layout, "seed_batch": S, **counters}
+                                "kernel_layout": layout, "seed_batch": S, **counters})
                 outs.append({"runner_state": runner_state, "metrics": metrics})
             return outs
 

@@ -173,3 +173,14 @@ def test_degenerate_linear_schedule_is_constant_init_value(oracle):
     assert linear_schedule(1.0, 0.05, 0.0)(7) == 1.0 and linear_schedule(1.0, 0.05, -3)(0) == 1.0
     assert oracle.linear_schedule(1.0, 0.05, 0.0, 7) == 1.0
     assert abs(linear_schedule(1.0, 0.05, 244.1)(122.05) - 0.525) < 1e-12 and linear_schedule(1.0, 0.05, 244.1)(1e9) == 0.05
+
+
+def test_runner_state_answers_the_reference_tuple_protocol():
+    """pqn_minatar.py:420-424: runner_state = (train_state, (obs, env_state), test_metrics, rng)."""
+    from purejaxql_amd.pqn import RunnerState
+    rs = RunnerState({"params": {"Dense_0/kernel": 1}, "theta": 2, "env_state": "S", "last_obs": "O", "test_metrics": {"a": 1},
+                      "rng": 7, "timesteps": 10, "n_updates": 2, "grad_steps": 128, "opt_count": 3})
+    train_state, (obs, env_state), test_metrics, rng = rs
+    assert rs[0].params == {"Dense_0/kernel": 1} and train_state.grad_steps == 128 and train_state.n_updates == 2
+    assert (obs, env_state) == ("O", "S") and test_metrics == {"a": 1} and rng == 7 and len(rs) == 4
+    assert rs["theta"] == 2 and "driver" not in rs and rs[1] == ("O", "S")
