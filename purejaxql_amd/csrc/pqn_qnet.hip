@@ -87,6 +87,82 @@ PQN_D float group16_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------
+// bf16x3 split-operand products (pqn_cnn_layout_t.matmul_f16 == 2, config MATMUL_DTYPE: bf16x3).
+// gfx950 has no tf32/xf32 path and its f32-input MFMA runs at the vector rate (1/16 of the bf16 rate), so an
+// f32 x f32 product is evaluated on the bf16 matrix core from EXACT three-way splits: x = hi + mid + lo with
+// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (8 + 8 + 8 significand bits; both subtractions are
+// exact in f32), and a*b ~= ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh -- the three dropped terms are
+// <= 2^-23 |a b|, i.e. f32 rounding level; every partial product is exact in the f32 accumulator's input and
+// the accumulation is f32.  6 x v_mfma_f32_16x16x32_bf16 (K = 32) replace 8 x v_mfma_f32_16x16x4_f32: ~5x
+// fewer matrix-pipe cycles.  Measured error vs an f64 dot product (K = 1024, tools/ubench/bf16x3.hip):
+// 1.7e-7 * sum|a b|, against 0.9e-7 for the f32 fma chain.
+// The split is 9 VALU ops per pair of values (v_cvt_pk_bf16_f32, shift / mask back to f32, v_pk_add_f32).
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+PQN_D void x3_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+  const f32x2 x = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+  const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xFFFF0000u)};
+  const f32x2 r1 = x - hf;
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+  const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xFFFF0000u)};
+  const f32x2 r2 = r1 - mf;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+}
+
+// one MFMA operand fragment (8 k-values per lane) as three bf16 planes
+struct X3Frag {
+  u32x4 h, m, l;
+};
+// k-values 0..3 = a, 4..7 = b (the two float4 halves a lane holds of a 32-wide K step)
+PQN_D X3Frag x3_split8(const f32x4 a, const f32x4 b) {
+  unsigned h[4], m[4], l[4];
+  x3_split2(a.x, a.y, h[0], m[0], l[0]);
+  x3_split2(a.z, a.w, h[1], m[1], l[1]);
+  x3_split2(b.x, b.y, h[2], m[2], l[2]);
+  x3_split2(b.z, b.w, h[3], m[3], l[3]);
+  X3Frag f;
+  f.h = u32x4{h[0], h[1], h[2], h[3]};
+  f.m = u32x4{m[0], m[1], m[2], m[3]};
+  f.l = u32x4{l[0], l[1], l[2], l[3]};
+  return f;
+}
+// v_mfma_f32_16x16x32_bf16 with the accumulator TIED (D and C the same register tuple), as inline asm.
+// Why not the builtin: ROCm 7.2's register allocator gives the builtin a destination tuple that partially overlaps its
+// own accumulator input (e.g. D = v[16:19], C = v[14:17]) when C was produced by an MFMA issued just before; on gfx950
+// that instruction then returns wrong values in a timing-dependent way (measured: run-to-run different conv outputs,
+// only in builds whose assembly contains such an instruction -- tools/check_mfma_overlap.py scans for them).
+// Inline asm carries its own wait states (the compiler pads nothing inside the string):
+//   - `s_nop 1` ahead of the MFMA covers a VALU write of an operand in the two preceding issue slots;
+//   - the result is consumed only by the next tied MFMA of the chain (no wait states needed) or after x3_drain*.
+PQN_D f32x4 x3_mfma_tied(const u32x4 &a, const u32x4 &b, f32x4 c) {
+  asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+}
+#define X3_MFMA(A, B, C) x3_mfma_tied(A, B, C)
+// end of an accumulation chain: 16 wait states (an MFMA result may not be read by anything but a tied MFMA earlier)
+PQN_D void x3_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a)); }
+PQN_D void x3_drain(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b)); }
+PQN_D void x3_drain(f32x4 &a, f32x4 &b, f32x4 &c) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c)); }
+PQN_D void x3_drain(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+// acc_s takes the three small cross terms, acc_b the three leading ones: two independent dependency chains, and the
+// small terms are summed among themselves before they meet the large ones
+PQN_D void x3_mfma6(const X3Frag &a, const X3Frag &b, f32x4 &acc_b, f32x4 &acc_s) {
+  acc_s = X3_MFMA(a.l, b.h, acc_s);
+  acc_b = X3_MFMA(a.m, b.h, acc_b);
+  acc_s = X3_MFMA(a.h, b.l, acc_s);
+  acc_b = X3_MFMA(a.h, b.m, acc_b);
+  acc_s = X3_MFMA(a.m, b.m, acc_s);
+  acc_b = X3_MFMA(a.h, b.h, acc_b);
+}
+
+// ---------------------------------------------------------------------------
 // conv 3x3xC -> 16 as MFMA.  A 16x16 output tile = 16 "points" (rows) x 16 channels; the
 // reduction runs over the 9C window bits in steps of 4 (v_mfma_f32_16x16x4_f32):
 //   A[i = l&15][kk = l>>4] = bit(point i, k = 4s+kk) ? 1/255 : 0     (built from the packed obs)
@@ -158,6 +234,68 @@ struct ConvMfma {
   }
 };
 
+// The same conv on the bf16 matrix core (operand mode 2).  The observation bits are exact in bf16, so the A operand is
+// ONE plane; the kernel Wc is split exactly into three bf16 planes (x3_split2) when the workgroup starts, and
+//   out = sum_k bit_k * (Wh + Wm + Wl)[k]   -- 3 x v_mfma_f32_16x16x32_bf16 per 32 window bits, f32 accumulate
+// has no rounding beyond the f32 accumulation itself (the f32-operand path rounds bit/255 * w per product instead).
+// K slot (kq = lane>>4, j) of step s stands for window element k = 32 s + 8 kq + j.  A "set" bit is written as the
+// bf16 value 2.0 (0x4000: a single bit, so a pair of slots is two shifts and two masks); the 1/255 input scale and
+// the 1/2 are applied once to the accumulator.
+template <int C>
+struct ConvX3 {
+  static constexpr int NK = 9 * C, NS = (NK + 31) / 32, RB = 3 * C;
+  static constexpr float OUT_SCALE = 0.5f / 255.0f;
+  X3Frag w[NS];
+  PQN_D void init(const float *wc, int lane) {
+    const int kq = lane >> 4, o = lane & 15;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * s + 8 * kq + j;
+        v[j] = (k < NK) ? wc[k * 16 + o] : 0.0f;
+      }
+      w[s] = x3_split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+    }
+  }
+  // bits [32 s, 32 s + 32) of the 9C-bit window string m0 | m1 << RB | m2 << 2 RB (compile-time shifts)
+  static PQN_D uint32_t word(const uint32_t (&m)[3], int s) {
+    uint32_t wv = 0u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int off = r * RB - 32 * s;
+      if (off >= 0 && off < 32) wv |= m[r] << off;
+      else if (off < 0 && off > -32) wv |= m[r] >> (-off);
+    }
+    return wv;
+  }
+  // 8 bits -> 8 bf16 slots (2.0 or 0): y carries bit 2jj at 2jj and bit 2jj+1 at 2jj+16; one shift + mask per pair
+  static PQN_D u32x4 expand8(uint32_t byte) {
+    const uint32_t y = (byte << 15) | byte;
+    return u32x4{(y << 14) & 0x40004000u, (y << 12) & 0x40004000u, (y << 10) & 0x40004000u, (y << 8) & 0x40004000u};
+  }
+  PQN_D void tile2(const uint32_t *wm, int pA, int pB, int kq, f32x4 &dA, f32x4 &dB) const {
+    const uint32_t mA[3] = {wm[pA * 3], wm[pA * 3 + 1], wm[pA * 3 + 2]};
+    const uint32_t mB[3] = {wm[pB * 3], wm[pB * 3 + 1], wm[pB * 3 + 2]};
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pl = 2; pl >= 0; --pl) {   // small planes first
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const u32x4 fa = expand8(__builtin_amdgcn_ubfe(word(mA, s), 8u * kq, 8u));
+        const u32x4 fb = expand8(__builtin_amdgcn_ubfe(word(mB, s), 8u * kq, 8u));
+        const u32x4 &bw = pl == 2 ? w[s].l : (pl == 1 ? w[s].m : w[s].h);
+        a0 = X3_MFMA(fa, bw, a0);
+        a1 = X3_MFMA(fb, bw, a1);
+      }
+    }
+    x3_drain(a0, a1);
+    dA = a0 * OUT_SCALE;
+    dB = a1 * OUT_SCALE;
+  }
+};
+
 // MFMA leaves a tile as (channel = lane&15, 4 points per lane); LayerNorm wants all 16 channels of a
 // point in one lane (no cross-lane reductions, no 16x redundant statistics).  Transpose through LDS.
 PQN_D void stage_tile(float *stg, int p0, const f32x4 &d, float bias, int lane) {
@@ -190,11 +328,11 @@ PQN_D void ln16_point(const float *stg, int p, float (&xhat)[16], float &rstd) {
 // phase 1: h1 tile [16 samples][64 pos * 16 ch] = relu(LN(conv)).  Wave w owns samples QN_SPW*w ...
 // KEEP: also return the normalised activations xhat[sample][channel] and 1/std of this lane's point, which the
 // training kernel holds in registers until the LN0 backward (no conv recompute there).
-template <int C, bool KEEP = false>
+template <int C, bool KEEP = false, bool X3 = false>
 PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, float *rkeep = nullptr) {
   using Cfg = CnnCfg<C>;
   const int lane = tid & 63, wave = tid >> 6;
-  ConvMfma<C> cv;
+  typename std::conditional<X3, ConvX3<C>, ConvMfma<C>>::type cv;
   cv.init(s.wc, lane);
   const float *bc = s.wc + Cfg::KW * 16;
   const float bias = bc[lane & 15];
@@ -207,8 +345,13 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, 
   f32x4 d[2][4];
   auto conv_mfma = [&](int mm, f32x4(&out)[4]) {
     window_masks<C>(s.bits + (QN_SPW * wave + mm) * Cfg::OW, wm, lane);
-    cv.tile2(wm, i, 16 + i, out[0], out[1]);
-    cv.tile2(wm, 32 + i, 48 + i, out[2], out[3]);
+    if constexpr (X3) {
+      cv.tile2(wm, i, 16 + i, lane >> 4, out[0], out[1]);
+      cv.tile2(wm, 32 + i, 48 + i, lane >> 4, out[2], out[3]);
+    } else {
+      cv.tile2(wm, i, 16 + i, out[0], out[1]);
+      cv.tile2(wm, 32 + i, 48 + i, out[2], out[3]);
+    }
   };
   conv_mfma(0, d[0]);
 #pragma unroll
@@ -367,63 +510,6 @@ PQN_D void phase2_fc1_f16(const CnnSmem &s, const _Float16 *__restrict__ w1h, in
   zp[3 * QN_ZS] = acc.w;
 }
 
-// ---------------------------------------------------------------------------
-// bf16x3 split-operand products (pqn_cnn_layout_t.matmul_f16 == 2, config MATMUL_DTYPE: bf16x3).
-// gfx950 has no tf32/xf32 path and its f32-input MFMA runs at the vector rate (1/16 of the bf16 rate), so an
-// f32 x f32 product is evaluated on the bf16 matrix core from EXACT three-way splits: x = hi + mid + lo with
-// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (8 + 8 + 8 significand bits; both subtractions are
-// exact in f32), and a*b ~= ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh -- the three dropped terms are
-// <= 2^-23 |a b|, i.e. f32 rounding level; every partial product is exact in the f32 accumulator's input and
-// the accumulation is f32.  6 x v_mfma_f32_16x16x32_bf16 (K = 32) replace 8 x v_mfma_f32_16x16x4_f32: ~5x
-// fewer matrix-pipe cycles.  Measured error vs an f64 dot product (K = 1024, tools/ubench/bf16x3.hip):
-// 1.7e-7 * sum|a b|, against 0.9e-7 for the f32 fma chain.
-// The split is 9 VALU ops per pair of values (v_cvt_pk_bf16_f32, shift / mask back to f32, v_pk_add_f32).
-// ---------------------------------------------------------------------------
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-PQN_D void x3_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-  const f32x2 x = {x0, x1};
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
-  const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xFFFF0000u)};
-  const f32x2 r1 = x - hf;
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
-  const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xFFFF0000u)};
-  const f32x2 r2 = r1 - mf;
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
-}
-
-// one MFMA operand fragment (8 k-values per lane) as three bf16 planes
-struct X3Frag {
-  u32x4 h, m, l;
-};
-// k-values 0..3 = a, 4..7 = b (the two float4 halves a lane holds of a 32-wide K step)
-PQN_D X3Frag x3_split8(const f32x4 a, const f32x4 b) {
-  unsigned h[4], m[4], l[4];
-  x3_split2(a.x, a.y, h[0], m[0], l[0]);
-  x3_split2(a.z, a.w, h[1], m[1], l[1]);
-  x3_split2(b.x, b.y, h[2], m[2], l[2]);
-  x3_split2(b.z, b.w, h[3], m[3], l[3]);
-  X3Frag f;
-  f.h = u32x4{h[0], h[1], h[2], h[3]};
-  f.m = u32x4{m[0], m[1], m[2], m[3]};
-  f.l = u32x4{l[0], l[1], l[2], l[3]};
-  return f;
-}
-#define X3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, B), C, 0, 0, 0)
-// acc_s takes the three small cross terms, acc_b the three leading ones: two independent dependency chains, and the
-// small terms are summed among themselves before they meet the large ones
-PQN_D void x3_mfma6(const X3Frag &a, const X3Frag &b, f32x4 &acc_b, f32x4 &acc_s) {
-  acc_s = X3_MFMA(a.l, b.h, acc_s);
-  acc_b = X3_MFMA(a.m, b.h, acc_b);
-  acc_s = X3_MFMA(a.h, b.l, acc_s);
-  acc_b = X3_MFMA(a.h, b.m, acc_b);
-  acc_s = X3_MFMA(a.m, b.m, acc_s);
-  acc_b = X3_MFMA(a.h, b.h, acc_b);
-}
-
 // Weight operands of the bf16x3 mode: the fc1 kernel's three bf16 planes, kept in the tail of the parameter buffer
 // (pqn_cnn_layout_t.off_w1h, 6 x 131072 bf16 = 393216 floats) by the optimizer kernel, in the two fragment orders the
 // kernels stream:
@@ -523,6 +609,7 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
     }
   }
   // fold the two K halves: kh = 1 parks its partial tiles in the (idle) staging buffer, kh = 0 adds and writes z
+  x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
   f32x4 *park = reinterpret_cast<f32x4 *>(s.stg);
   if (kh == 1) {
 #pragma unroll
@@ -675,7 +762,10 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
   }
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;  // b[w+1] guard word
   __syncthreads();
-  if (ablate != 1 && ablate != 6 && ablate != 7) phase1_conv<C>(s, tid);
+  if (ablate != 1 && ablate != 6 && ablate != 7) {
+    if (L.matmul_f16 == 2) phase1_conv<C, false, true>(s, tid);
+    else phase1_conv<C>(s, tid);
+  }
   __syncthreads();
   if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
   else if (L.matmul_f16 == 2) phase2_fc1_x3<3>(s, theta + L.off_w1h, tid);
@@ -765,7 +855,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
 #pragma unroll 1
   for (int t = 0; t <= t_len; ++t) {
     __syncthreads();   // s.bits holds obs_t of the tile (and every previous reader of the tiles is done)
-    phase1_conv<C>(s, tid);
+    if (L.matmul_f16 == 2) phase1_conv<C, false, true>(s, tid);
+    else phase1_conv<C>(s, tid);
     __syncthreads();
     if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid, (e0 - e_off) / QN_TILE);
     else if (L.matmul_f16 == 2) phase2_fc1_x3<2>(s, theta + L.off_w1h, tid, (e0 - e_off) / QN_TILE);
@@ -1027,7 +1118,7 @@ PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layou
 // profiling: per-phase s_memtime stamps of workgroup 0 / wave 0 (PQN_T1_STAMPS=1), read by tools/t1_stamps.py
 #define T1_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.x < 4) stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 
-template <int C>
+template <int C, int MODE>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, const float *__restrict__ w1b,
@@ -1094,15 +1185,15 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   T1_STAMP(1);
   // ---- P1..P3: forward ---------------------------------------------------------------------
   float xkeep[QN_SPW][16], rkeep[QN_SPW];   // LN0 xhat / rstd of (sample QN_SPW*wave + mm, position lane): live until P5
-  phase1_conv<C, true>(s, tid, xkeep, rkeep);
+  phase1_conv<C, true, MODE == 2>(s, tid, xkeep, rkeep);
   __syncthreads();
   T1_STAMP(2);
-  if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
-  else if (L.matmul_f16 == 2) phase2_fc1_x3<3>(s, theta + L.off_w1h, tid);
+  if (MODE == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
+  else if (MODE == 2) phase2_fc1_x3<3>(s, theta + L.off_w1h, tid);
   else phase2_fc1<0>(s, theta + L.off_w1, tid);
   // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
   // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
-  if (L.matmul_f16 == 1) {
+  if (MODE == 1) {
     // fp16 operands for T2, tile-major: h1P[tile][i][16 samples] halves -- the wave writes 2 KB contiguous
     _Float16 *h1P = reinterpret_cast<_Float16 *>(h1T) + (size_t)blockIdx.x * QN_H1 * QN_TILE;
     for (int e = tid; e < QN_H1 * 2; e += QN_THREADS) {
@@ -1136,7 +1227,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   }
   T1_STAMP(4);
   // ---- P4: dgrad  dh1[m][i] = sum_o dz[m][o] W1[i][o]  (A = dz tile, B = W1 in dgrad fragment order) ----
-  if (L.matmul_f16 == 1) {
+  if (MODE == 1) {
     // fp16 operands, f32 accumulation: one v_mfma_f32_16x16x16_f16 per 16-wide K group.  dz is O(1/B): it is
     // scaled by a power of two (>= B/2) into fp16's normal range and the product scaled back in f32.
     const float sc = dz_scale, isc = 1.0f / sc;
@@ -1183,7 +1274,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 #pragma unroll 1
     for (int ip = 0; ip < IBW / 2 - 1; ++ip) pair_step(ip, std::true_type{});
     pair_step(IBW / 2 - 1, std::false_type{});
-  } else if (L.matmul_f16 == 2) {
+  } else if (MODE == 2) {
     // bf16x3 split operands (see phase2_fc1_x3): the dz tile is split once per wave (4 K steps of 32 outputs, kept in
     // registers), the fc1 kernel's dgrad-order bf16 planes are streamed one i-block (12 dwordx4) ahead.
     const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
@@ -1224,6 +1315,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      x3_drain(acc_b, acc_s);
       const f32x4 acc0 = acc_b + acc_s;
       p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
       p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
@@ -1377,6 +1469,54 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 #pragma unroll
     for (int j = 0; j < RBW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     uint32_t *wm = reinterpret_cast<uint32_t *>(s.stg + wave * 64 * QN_STG);   // staging buffer is free now
+    if constexpr (MODE == 2) {
+      // bf16 matrix core: A = window bits (exact in bf16, written as 2.0 = 0x4000), B = dx split exactly into three
+      // bf16 planes; 2 K steps of 32 positions per sample, K slot (kq = kk, j) <-> position 32 st + 4 j + kk so that
+      // the B reads stay the conflict-free dxm[64 * (8 st + j)] of the f32 path.  3 MFMAs per (step, row block)
+      // instead of 8 at 1/4 the cycles each; 0.5/255 applied once to the accumulators.
+#pragma unroll
+      for (int mm = 0; mm < SPW6; ++mm) {
+        const int msamp = SPW6 * sg + mm;
+        window_masks<C>(s.bits + msamp * Cfg::OW, wm, lane);
+        const float *dxm = s.h1 + msamp * QN_H1S + lane;
+        float bv[16];
+        uint32_t wv[16][RBW];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {           // q = 8 st + j: all LDS reads of the sample in flight at once
+          bv[q] = dxm[64 * q];
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) wv[q][j] = wm[(4 * q + kk) * 3 + kyL[j]];
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const float *b = bv + 8 * st;
+          const X3Frag bf = x3_split8(f32x4{b[0], b[1], b[2], b[3]}, f32x4{b[4], b[5], b[6], b[7]});
+          u32x4 af[RBW];
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) {
+            uint32_t d[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const uint32_t b0 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj][j], (uint32_t)shL[j], 1u);
+              const uint32_t b1 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj + 1][j], (uint32_t)shL[j], 1u);
+              d[jj] = ((b1 << 16) | b0) << 14;
+            }
+            af[j] = u32x4{d[0], d[1], d[2], d[3]};
+          }
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.l, acc[j]);
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.m, acc[j]);
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.h, acc[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RBW; ++j) {
+        x3_drain(acc[j]);
+        acc[j] = acc[j] * (0.5f / 255.0f);
+      }
+    } else
 #pragma unroll
     for (int mm = 0; mm < SPW6; ++mm) {
       const int msamp = SPW6 * sg + mm;
@@ -1585,6 +1725,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, c
     QX_ALL(h, h, acc_b)
 #undef QX_ALL
   }
+  x3_drain(acc_b[0][0], acc_b[0][1], acc_b[1][0], acc_b[1][1]);
+  x3_drain(acc_s[0][0], acc_s[0][1], acc_s[1][0], acc_s[1][1]);
   f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -1967,7 +2109,11 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   const size_t smem1 = train_smem_bytes<C>();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
     attr_set = true;
   }
@@ -1980,7 +2126,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
   // matmul_f16: dz (O(1/nb)) is scaled by a power of two into fp16's normal range; products are scaled back in f32
   const float dz_scale = exp2f(floorf(log2f((float)nb)));
-  hipLaunchKernelGGL((qnet_cnn_train_kernel<C>), dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
+  // one instantiation per operand mode of the fc1 / conv products (pqn_cnn_layout_t.matmul_f16)
+  auto t1 = L.matmul_f16 == 2 ? &qnet_cnn_train_kernel<C, 2> : (L.matmul_f16 == 1 ? &qnet_cnn_train_kernel<C, 1> : &qnet_cnn_train_kernel<C, 0>);
+  hipLaunchKernelGGL(t1, dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
                      target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sd, dz_scale);
   if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
   if (L.matmul_f16 == 1)
