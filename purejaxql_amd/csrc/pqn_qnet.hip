@@ -114,6 +114,23 @@ PQN_D void x3_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) 
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
 
+// the same split in three stages (4 + 4 + 1 VALU ops), for kernels that interleave it with MFMAs by hand
+struct X3Split {
+  f32x2 x, r;
+  unsigned h, m, l;
+};
+PQN_D void x3_stage1(X3Split &s) {
+  s.h = __builtin_bit_cast(unsigned, __builtin_convertvector(s.x, bf16x2_t));
+  const f32x2 hf = {__uint_as_float(s.h << 16), __uint_as_float(s.h & 0xFFFF0000u)};
+  s.r = s.x - hf;
+}
+PQN_D void x3_stage2(X3Split &s) {
+  s.m = __builtin_bit_cast(unsigned, __builtin_convertvector(s.r, bf16x2_t));
+  const f32x2 mf = {__uint_as_float(s.m << 16), __uint_as_float(s.m & 0xFFFF0000u)};
+  s.r = s.r - mf;
+}
+PQN_D void x3_stage3(X3Split &s) { s.l = __builtin_bit_cast(unsigned, __builtin_convertvector(s.r, bf16x2_t)); }
+
 // one MFMA operand fragment (8 k-values per lane) as three bf16 planes
 struct X3Frag {
   u32x4 h, m, l;
@@ -935,6 +952,15 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
 // leading dimension of the transposed operands: nb + 32 floats, so consecutive rows (16 KB apart at
 // nb = 4096) do not all land on the same L2 channel
 __host__ __device__ inline int qw_ld(int nb) { return nb + 32; }
+// columns reserved per h1 feature row in the workspace: the sample-major layout needs nb + 32, the slab-major layout
+// of the bf16x3 mode (h1s_index) whole 256-sample slabs
+__host__ __device__ inline int qw_h1_cols(int nb) { return max(nb + 32, (nb + QW_SLAB - 1) / QW_SLAB * QW_SLAB); }
+// bf16x3 mode: h1 is handed from T1 to T2 slab-major, [slab ks][row block it][step u][64 rows][32 samples] -- the tile
+// a T2 workgroup consumes per step is 8 KB contiguous, a workgroup's whole stream 64 KB x G contiguous (the sample-major
+// layout made every 128-B line of that stream a different DRAM page: ~3.6 TB/s with no compute at all)
+__host__ __device__ inline size_t h1s_index(int i, int b) {
+  return ((((size_t)(b >> 8) * 16 + (i >> 6)) * 8 + ((b >> 5) & 7)) * 64 + (i & 63)) * 32 + (b & 31);
+}
 
 template <int C>
 struct TrainCfg {
@@ -1189,7 +1215,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   __syncthreads();
   T1_STAMP(2);
   if (MODE == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
-  else if (MODE == 2) phase2_fc1_x3<3>(s, theta + L.off_w1h, tid);
+  else if (MODE == 2) phase2_fc1_x3<4>(s, theta + L.off_w1h, tid);
   else phase2_fc1<0>(s, theta + L.off_w1, tid);
   // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
   // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
@@ -1209,7 +1235,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     const int i = e >> 2, mq = e & 3;
     const float *src = s.h1 + (4 * mq) * QN_H1S + i;
     const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
-    *reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq) = v;
+    if (MODE == 2) *reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0 + 4 * mq)) = v;
+    else *reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq) = v;
   }
   if (tid < QN_TILE) {
     ts.act[tid] = act_g;
@@ -1632,107 +1659,166 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_kernel(int nb, cons
   for (int a = 0; a < 4; ++a) out[((4 * it + a) * 8 + cb) * 64 + lane] = acc[a];
 }
 
-// bf16x3 split-operand variant (matmul_f16 == 2; see phase2_fc1_x3): the same f32 operands T1 leaves in the
-// workspace, the same grid and output layout; every element is split into its three bf16 planes ONCE per workgroup
-// when it is staged into LDS (3 planes x 192 rows x 32 samples per step, double-buffered), and the waves read bf16
-// fragments: 6 x v_mfma_f32_16x16x32_bf16 per 16x16 output tile and 32-sample step.  Wave w owns a 2 x 2 block of
-// tiles (row blocks 2(w>>2), +1; column blocks 2(w&3), +1): 12 ds_read_b128 for 24 MFMAs.  LDS row stride 96 B
-// (32 samples + 16 B pad... 24 dwords): conflict-free for the four 16-lane groups of ds_read_b128.
-#define QX_KS 32
-#define QX_ROWS 192
-#define QX_RSB 96                         // bytes per LDS row
-#define QX_PLANE (QX_ROWS * QX_RSB)       // 18,432 B
-#define QX_BUF (3 * QX_PLANE)             // 55,296 B; two buffers = 110,592 B (dynamic LDS)
+// bf16x3 split-operand variant (matmul_f16 == 2; see phase2_fc1_x3): the same f32 operands T1 leaves in the workspace
+// and the same output layout as the f32 kernel.  Design, from measurements on MI355X (profiles/r02_t2_*):
+//   - operand traffic, not the matrix core, bounded the first version (both operands streamed per (it, ks) workgroup:
+//     805 MB of loads per 16-seed launch, 2/3 of them the dz slab re-read by all 16 row blocks);
+//   - VALU work issued between MFMAs is NOT hidden behind them (tools/ubench/mfma_issue.hip: ~2.8 counter ticks per
+//     VALU op on top of ~10 per MFMA at two waves per SIMD), so splitting dz fragments at every use cost more than
+//     the MFMAs themselves.
+// Hence "dz in registers": wave w owns output column block w (16 of the 128 fc1 outputs) for the workgroup's whole
+// 256-sample slab.  Its dz fragments -- 8 steps x 8 values per lane -- are loaded from global memory straight in MFMA
+// operand layout, split into the three bf16 planes ONCE, and stay in 96 VGPRs while the workgroup walks over G row
+// blocks `it` of h1T (G = 16 when the launch has enough seeds: dz is then read from memory exactly once).  Per step
+// only the 64 x 32 h1T tile moves: one float4 per thread, 8 steps (64 KB per CU) in flight in registers, split by the
+// loading thread and staged as planes in LDS (3 x 64 rows x 64 B per step; a ring of two 4-step groups, 96 KB); a wave
+// reads the 4 row-block fragments (12 ds_read_b128) for its 24 MFMAs.
+// K slot (kg = lane>>4, j) of a 32-sample step stands for sample 16 (j>>2) + 4 kg + (j&3) (two float4 per lane of a
+// dz row); the A planes are stored in that order with an XOR swizzle of the 16-B quads, quad = kg ^ {0,3,2,1}[(row>>2)&3],
+// which makes the unpadded 64-B rows conflict-free for the four 16-lane groups of ds_read_b128 (MI355X guide).
+#define QY_SLAB QW_SLAB
+#define QY_KS 32
+#define QY_APL (64 * 64)                     // one A plane: 64 rows x 32 bf16
+#define QY_ABUF (3 * QY_APL)                 // 12,288 B
+#define QY_LDS (8 * QY_ABUF)                  // 98,304 B (dynamic LDS)
+static_assert(QY_SLAB == 256, "8 steps of 32 samples");
+PQN_D int qy_swz(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
 __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, const float *__restrict__ h1T,
                                                                        const float *__restrict__ dzT,
-                                                                       float *__restrict__ wpart, long long ws_stride) {
-  static_assert(QN_WAVES == 8, "2 x 2 tiles per wave");
-  extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+                                                                       float *__restrict__ wpart, long long ws_stride,
+                                                                       int G, unsigned long long *__restrict__ stamps) {
+#define T2_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) stamps[k] = __builtin_readcyclecounter(); } while (0)
+  static_assert(QN_WAVES == 8, "one column block per wave");
+  extern __shared__ __attribute__((aligned(16))) char abuf[];   // QY_LDS: two groups x four step tiles
+  T2_STAMP(0);
   h1T += blockIdx.z * ws_stride;   // seed slice
   dzT += blockIdx.z * ws_stride;
   wpart += blockIdx.z * ws_stride;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int it = blockIdx.x, ks = blockIdx.y;
+  const int it0 = blockIdx.x * G, ks = blockIdx.y;
   const int r = lane & 15, kg = lane >> 4;
-  const int rp = wave >> 2, cq = wave & 3;
-  const int c0 = ks * QW_SLAB;
-  const int nsteps = (min(QW_SLAB, nb - c0) + QX_KS - 1) / QX_KS;
+  const int c0 = ks * QY_SLAB;
   const int ld = qw_ld(nb);
-  // loader mapping: ROWS * KS / 4 = 1536 float4 per step = 3 per thread
-  const float *src[3];
-  int dst[3], col[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int e = tid + QN_THREADS * j;
-    const int row = e >> 3, c4 = (e & 7) * 4;           // 8 float4 per 32-sample row
-    src[j] = (row < 64 ? h1T + (size_t)(64 * it + row) * ld : dzT + (size_t)(row - 64) * ld) + c0 + c4;
-    dst[j] = row * QX_RSB + c4 * 2;                     // byte offset inside a plane (bf16)
-    col[j] = c0 + c4;
-  }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc_b[2][2], acc_s[2][2];
+  constexpr int NST = QY_SLAB / QY_KS;   // 8 steps per row block = the prefetch distance
+  // h1T loader: thread -> (row, 4 consecutive samples) of the 64 x 32 step tile
+  const int arow = tid >> 3, q8 = tid & 7;
+  const int a_col = c0 + 4 * q8;
+  const int a_dst = arow * 64 + (((q8 & 3) ^ qy_swz(arow)) << 4) + ((q8 >> 2) << 3);
+  // Every prefetch is UNCONDITIONAL (row block and column clamped into range, the value masked when it is consumed):
+  // a load under a condition, or a select right behind it, makes the compiler drain the whole queue
+  // (s_waitcnt vmcnt(0)) at every step, which serialises the HBM round trips.
+  auto fetch = [&](int itn, int u) -> f32x4 {   // h1 slab-major (h1s_index): step tile = 8 KB contiguous, 16 B per thread
+    return *reinterpret_cast<const f32x4 *>(h1T + ((((size_t)ks * 16 + it0 + min(itn, G - 1)) * 8 + u) * 2048 + 4 * tid));
+  };
+  auto masked = [&](const f32x4 &v, int u) -> f32x4 { return (a_col + QY_KS * u < nb) ? v : zero4; };
+  f32x4 pre[NST];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int u = 0; u < NST; ++u) pre[u] = fetch(0, u);
+  // the wave's dz fragments for the whole slab: row o = 16 wave + r, samples c0 + 32 u + {4 kg .. +3, 16 + 4 kg .. +3}
+  X3Frag bp[NST];
+  {
+    const float *drow = dzT + (size_t)(16 * wave + r) * ld;
+    f32x4 lo[NST], hi[NST];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { acc_b[a][c] = zero4; acc_s[a][c] = zero4; }
-  f32x4 pre[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) pre[j] = (col[j] < nb) ? *reinterpret_cast<const f32x4 *>(src[j]) : zero4;
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  for (int st = 0; st < nsteps; ++st) {
-    char *t = smem_x3 + (st & 1) * QX_BUF;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {   // split once per element, store the three planes
-      unsigned h0, m0, l0, h1, m1, l1;
-      x3_split2(pre[j].x, pre[j].y, h0, m0, l0);
-      x3_split2(pre[j].z, pre[j].w, h1, m1, l1);
-      *reinterpret_cast<u32x2 *>(t + dst[j]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2 *>(t + QX_PLANE + dst[j]) = u32x2{m0, m1};
-      *reinterpret_cast<u32x2 *>(t + 2 * QX_PLANE + dst[j]) = u32x2{l0, l1};
-    }
-    if (st + 1 < nsteps) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        pre[j] = (col[j] + QX_KS * (st + 1) < nb) ? *reinterpret_cast<const f32x4 *>(src[j] + QX_KS * (st + 1)) : zero4;
-    }
-    __syncthreads();   // buffer st&1 complete; buffer (st+1)&1 was last read two steps ago
-    X3Frag af[2], bf[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const char *pa = t + (16 * (2 * rp + a) + r) * QX_RSB + kg * 16;
-      af[a].h = *reinterpret_cast<const u32x4 *>(pa);
-      af[a].m = *reinterpret_cast<const u32x4 *>(pa + QX_PLANE);
-      af[a].l = *reinterpret_cast<const u32x4 *>(pa + 2 * QX_PLANE);
+    for (int u = 0; u < NST; ++u) {
+      const int cl = c0 + QY_KS * u + 4 * kg, ch = cl + 16;
+      lo[u] = *reinterpret_cast<const f32x4 *>(drow + min(cl, nb - 4));
+      hi[u] = *reinterpret_cast<const f32x4 *>(drow + min(ch, nb - 4));
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const char *pb = t + (64 + 16 * (2 * cq + c) + r) * QX_RSB + kg * 16;
-      bf[c].h = *reinterpret_cast<const u32x4 *>(pb);
-      bf[c].m = *reinterpret_cast<const u32x4 *>(pb + QX_PLANE);
-      bf[c].l = *reinterpret_cast<const u32x4 *>(pb + 2 * QX_PLANE);
+    for (int u = 0; u < NST; ++u) {
+      const int cl = c0 + QY_KS * u + 4 * kg, ch = cl + 16;
+      bp[u] = x3_split8(cl < nb ? lo[u] : zero4, ch < nb ? hi[u] : zero4);
     }
-    // the four tiles interleaved product by product: consecutive MFMAs never share an accumulator
-#define QX_ALL(AP, BP, ACC)                                   \
-    ACC[0][0] = X3_MFMA(af[0].AP, bf[0].BP, ACC[0][0]);       \
-    ACC[0][1] = X3_MFMA(af[0].AP, bf[1].BP, ACC[0][1]);       \
-    ACC[1][0] = X3_MFMA(af[1].AP, bf[0].BP, ACC[1][0]);       \
-    ACC[1][1] = X3_MFMA(af[1].AP, bf[1].BP, ACC[1][1]);
-    QX_ALL(l, h, acc_s)
-    QX_ALL(h, l, acc_s)
-    QX_ALL(m, m, acc_s)
-    QX_ALL(m, h, acc_b)
-    QX_ALL(h, m, acc_b)
-    QX_ALL(h, h, acc_b)
-#undef QX_ALL
   }
-  x3_drain(acc_b[0][0], acc_b[0][1], acc_b[1][0], acc_b[1][1]);
-  x3_drain(acc_s[0][0], acc_s[0][1], acc_s[1][0], acc_s[1][1]);
-  f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
+  int a_off[4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a) {
+    const int row = 16 * a + r;
+    a_off[a] = row * 64 + ((kg ^ qy_swz(row)) << 4);
+  }
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto stage_a = [&](char *t, const f32x4 &v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    x3_split2(v.x, v.y, h0, m0, l0);
+    x3_split2(v.z, v.w, h1, m1, l1);
+    *reinterpret_cast<u32x2 *>(t + a_dst) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2 *>(t + QY_APL + a_dst) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2 *>(t + 2 * QY_APL + a_dst) = u32x2{l0, l1};
+  };
+  u32x4 ah[4], am[4], al[4];
+  auto load_plane = [&](const char *t, int plane, u32x4 (&dst)[4]) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-      out[((4 * it + 2 * rp + a) * 8 + 2 * cq + c) * 64 + lane] = acc_b[a][c] + acc_s[a][c];
+    for (int a = 0; a < 4; ++a) dst[a] = *reinterpret_cast<const u32x4 *>(t + plane * QY_APL + a_off[a]);
+  };
+  // Steps are grouped in fours (128 samples): ONE barrier per group.  A per-step barrier keeps all eight waves in
+  // lockstep -- MFMA bursts, splits and LDS latency then add up instead of overlapping, measured 420 of 1310 counter
+  // ticks per step -- so a group's planes (4 x 12 KB) are staged while the previous group computes, into the other half
+  // of an 8-tile LDS ring; within a group a wave runs free: it reloads each fragment plane from the NEXT step's tile
+  // as soon as the current step's MFMAs on that plane have issued.
+  auto tile = [&](int half, int slot) -> char * { return abuf + (half * 4 + slot) * QY_ABUF; };
+  // prologue: group 0 of the first row block
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    stage_a(tile(0, u), masked(pre[u], u));
+    pre[u] = fetch(1, u);
+  }
+  __syncthreads();
+  load_plane(tile(0, 0), 2, al);
+  load_plane(tile(0, 0), 1, am);
+  load_plane(tile(0, 0), 0, ah);
+  T2_STAMP(1);
+  f32x4 acc_b[4], acc_s[4];
+  for (int itl = 0; itl < G; ++itl) {
+    const int it = it0 + itl;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { acc_b[a] = zero4; acc_s[a] = zero4; }
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      // All NST steps always run (samples past nb are zeros in both operands) and the last group of the last row
+      // block stages / reads harmless extra tiles: no data-dependent control flow inside the pipeline.
+      const int half = (u >> 2) & 1, slot = u & 3;
+      const bool last = (slot == 3);                          // last step of its group: the next tile is behind the barrier
+      const char *tnext = last ? tile(half ^ 1, 0) : tile(half, slot + 1);
+      const int us = (u + 4) % NST, its = itl + (u + 4) / NST;   // step staged now: same slot of the next group
+#define QX_ROW(AP, BP, ACC)                           \
+      ACC[0] = X3_MFMA(AP[0], bp[u].BP, ACC[0]);      \
+      ACC[1] = X3_MFMA(AP[1], bp[u].BP, ACC[1]);      \
+      ACC[2] = X3_MFMA(AP[2], bp[u].BP, ACC[2]);      \
+      ACC[3] = X3_MFMA(AP[3], bp[u].BP, ACC[3]);
+      QX_ROW(al, h, acc_s)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) load_plane(tnext, 2, al);
+      __builtin_amdgcn_sched_barrier(0);
+      QX_ROW(am, m, acc_s)
+      QX_ROW(am, h, acc_b)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) load_plane(tnext, 1, am);
+      __builtin_amdgcn_sched_barrier(0);
+      QX_ROW(ah, l, acc_s)
+      QX_ROW(ah, m, acc_b)
+      QX_ROW(ah, h, acc_b)
+#undef QX_ROW
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) load_plane(tnext, 0, ah);
+      stage_a(tile(half ^ 1, slot), masked(pre[us], us));   // split once, stored as planes
+      pre[us] = fetch(its + 1, us);                          // refill the slot: the same step one row block further down
+      if (last) {
+        __syncthreads();   // the next group's planes complete; this group's half may be overwritten from now on
+        load_plane(tnext, 2, al);
+        load_plane(tnext, 1, am);
+        load_plane(tnext, 0, ah);
+      }
+      if (itl == 0) T2_STAMP(2 + u);
+    }
+    x3_drain(acc_b[0], acc_b[1], acc_b[2], acc_b[3]);
+    x3_drain(acc_s[0], acc_s[1], acc_s[2], acc_s[3]);
+    f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) out[((4 * it + a) * 8 + wave) * 64 + lane] = acc_b[a] + acc_s[a];
+    T2_STAMP(10 + itl);
+  }
 }
 
 // fp16-operand variant (matmul_f16): operands packed tile-major by T1 (h1P[tile][1024][16], dzP[tile][128][16]
@@ -2088,6 +2174,12 @@ extern "C" int pqn_prof_read(int32_t *count, float *total_ms) {
 }
 
 static unsigned long long *g_t1_stamps = nullptr;   // profiling only (PQN_T1_STAMPS=1)
+static unsigned long long *g_t2_stamps = nullptr;   // likewise, bf16x3 T2: [0] start, [1] slab resident, [2..9] steps of the first row block, [10..] row blocks
+extern "C" int pqn_debug_t2_stamps(unsigned long long *out /* host, 32 entries */) {
+  if (!g_t2_stamps) return PQN_E_INVALID;
+  if (hipMemcpy(out, g_t2_stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return PQN_E_HIP;
+  return PQN_OK;
+}
 
 extern "C" int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries */) {
   if (!g_t1_stamps) return PQN_E_INVALID;
@@ -2100,11 +2192,12 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                         const int32_t *count, float *ws, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
                         hipStream_t st, bool with_reduce) {
-  const int ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB, rec = small_record_floats(C, L.a);
+  const int ntiles = nb / QN_TILE, rec = small_record_floats(C, L.a);
+  const int nks = (nb + QW_SLAB - 1) / QW_SLAB;
   float *scratch = ws;
   float *dzT = ws + 1024;
   float *h1T = dzT + (size_t)QN_HID * qw_ld(nb);
-  float *gpart = h1T + (size_t)QN_H1 * qw_ld(nb);
+  float *gpart = h1T + (size_t)QN_H1 * qw_h1_cols(nb);
   float *wpart = gpart + (size_t)ntiles * rec;
   const size_t smem1 = train_smem_bytes<C>();
   static bool attr_set = false;
@@ -2138,11 +2231,17 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     static bool x3_attr = false;
     if (!x3_attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QX_BUF);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, QY_LDS);
       x3_attr = true;
     }
-    hipLaunchKernelGGL(qnet_fc1_wgrad_x3_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 2 * QX_BUF, st, nb, h1T, dzT,
-                       wpart, sd.ws_stride);
+    // row blocks per workgroup: as many as still leave one workgroup per CU (16 = the dz slab is read once)
+    int G = 16;
+    while (G > 1 && (16 / G) * nks * sd.nseeds < 256) G >>= 1;
+    if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
+      if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;
+    }
+    hipLaunchKernelGGL(qnet_fc1_wgrad_x3_kernel, dim3(16 / G, nks, sd.nseeds), dim3(QN_THREADS), QY_LDS, st, nb, h1T, dzT,
+                       wpart, sd.ws_stride, G, g_t2_stamps);
   } else
     hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
                        sd.ws_stride);
@@ -2155,7 +2254,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
 extern "C" int64_t pqn_qnet_cnn_workspace_floats(const pqn_cnn_layout_t *L, int32_t nb) {
   if (!L || nb <= 0) return -1;
   const int64_t ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB;
-  return 1024 + (int64_t)(QN_HID + QN_H1) * qw_ld(nb) + ntiles * small_record_floats(L->c, L->a) +
+  return 1024 + (int64_t)QN_HID * qw_ld(nb) + (int64_t)QN_H1 * qw_h1_cols(nb) + ntiles * small_record_floats(L->c, L->a) +
          nks * (int64_t)QN_H1 * QN_HID;
 }
 
@@ -2371,7 +2470,7 @@ int pqn_qnet_cnn_reduce_apply_seeds(const pqn_cnn_layout_t &L, int nb, float *th
   float *scratch = workspace;
   float *dzT = workspace + 1024;
   float *h1T = dzT + (size_t)QN_HID * qw_ld(nb);
-  float *gpart = h1T + (size_t)QN_H1 * qw_ld(nb);
+  float *gpart = h1T + (size_t)QN_H1 * qw_h1_cols(nb);
   float *wpart = gpart + (size_t)ntiles * rec;
   hipLaunchKernelGGL(qnet_reduce_apply_kernel, dim3(QRA_G, sd.nseeds), dim3(512), 0, st, L, ntiles, nks, rec, gpart, wpart,
                      theta, m, v, count, scratch, loss_out, qv_out, 1.0f / (float)nb, lr_init, lr_end, lr_steps, max_norm, w1b,

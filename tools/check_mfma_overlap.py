@@ -26,7 +26,7 @@ def scan(asm_path):
 
 
 def main():
-    files = sys.argv[1:] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    files = [os.path.abspath(f) for f in sys.argv[1:]] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     bad = 0
     for f in files:
         with tempfile.TemporaryDirectory() as td:

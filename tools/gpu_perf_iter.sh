@@ -12,3 +12,8 @@ import json
 d = json.loads(open("gpurun_out/iter/bench_$NAME.json").read().strip().splitlines()[-1])
 print("value %.4g  ms/step %.2f  T1 us %.1f frac %.3f" % (d["value"], d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"]))
 PY
+if [ "$2" = prof ]; then
+  R=$PWD; cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pi
+  rocprofv3 --kernel-trace -d /tmp/pi -o x -- python $R/bench.py --steps 6 --warmup 2 --no-extras --matmul-dtype $NAME > /dev/null 2>&1
+  python $R/tools/rocprof_summary.py /tmp/pi/x_results.db 8 | cut -c1-150 | tee $R/gpurun_out/iter/kernel_stats_$NAME.txt
+fi
