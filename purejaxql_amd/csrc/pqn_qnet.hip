@@ -148,16 +148,21 @@ PQN_D X3Frag x3_split8(const f32x4 a, const f32x4 b) {
   f.l = u32x4{l[0], l[1], l[2], l[3]};
   return f;
 }
-// v_mfma_f32_16x16x32_bf16 with the accumulator TIED (D and C the same register tuple), as inline asm.
-// Why not the builtin: ROCm 7.2's register allocator gives the builtin a destination tuple that partially overlaps its
-// own accumulator input (e.g. D = v[16:19], C = v[14:17]) when C was produced by an MFMA issued just before; on gfx950
-// that instruction then returns wrong values in a timing-dependent way (measured: run-to-run different conv outputs,
-// only in builds whose assembly contains such an instruction -- tools/check_mfma_overlap.py scans for them).
+// v_mfma_f32_16x16x32_bf16 with the accumulator TIED (D and C the same register tuple), as VOLATILE inline asm.
+// Why not the builtin, and why volatile: with ROCm 7.2 the builtin form of this instruction produced run-to-run
+// DIFFERENT results in the conv phase of the training kernel (only in builds whose assembly gave the MFMA a destination
+// tuple partially overlapping its accumulator input -- tools/check_mfma_overlap.py scans for that), and so did the
+// tied but NON-volatile asm once the compiler was free to re-order it (10-channel / 7-channel / 6-channel kernels,
+// conv phase only; the 4-channel kernel never showed it).  The hardware hazards one might suspect were measured and
+// ruled out (tools/ubench/mfma_war.hip: overwriting A / B right behind the MFMA is safe, a VALU-written operand needs
+// ONE wait state, dependent chains at any distance are exact), so the root cause is left as "compiler scheduling of
+// this new instruction"; what is relied on is what was verified: source-order issue (volatile), tied accumulators,
+// the pads below, and tests/test_qnet_gpu.py::test_bf16x3_is_deterministic_and_matches_f32_mode over all channel counts.
 // Inline asm carries its own wait states (the compiler pads nothing inside the string):
-//   - `s_nop 1` ahead of the MFMA covers a VALU write of an operand in the two preceding issue slots;
+//   - `s_nop 1` ahead of the MFMA covers a VALU write of an operand in the preceding issue slots (1 state needed);
 //   - the result is consumed only by the next tied MFMA of the chain (no wait states needed) or after x3_drain*.
 PQN_D f32x4 x3_mfma_tied(const u32x4 &a, const u32x4 &b, f32x4 c) {
-  asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
   return c;
 }
 #define X3_MFMA(A, B, C) x3_mfma_tied(A, B, C)
@@ -292,24 +297,33 @@ struct ConvX3 {
     const uint32_t y = (byte << 15) | byte;
     return u32x4{(y << 14) & 0x40004000u, (y << 12) & 0x40004000u, (y << 10) & 0x40004000u, (y << 8) & 0x40004000u};
   }
-  PQN_D void tile2(const uint32_t *wm, int pA, int pB, int kq, f32x4 &dA, f32x4 &dB) const {
-    const uint32_t mA[3] = {wm[pA * 3], wm[pA * 3 + 1], wm[pA * 3 + 2]};
-    const uint32_t mB[3] = {wm[pB * 3], wm[pB * 3 + 1], wm[pB * 3 + 2]};
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  // the four 16-point tiles of one sample at once: eight independent accumulators ({h plane, m + l planes} per tile),
+  // reuse distance >= 4 in issue order (a dependent MFMA issues ~90 counter ticks after its producer)
+  PQN_D void tile4(const uint32_t *wm, int i, int kq, f32x4 (&d)[4]) const {
+    u32x4 fa[4][NS];
 #pragma unroll
-    for (int pl = 2; pl >= 0; --pl) {   // small planes first
+    for (int t = 0; t < 4; ++t) {
+      const int p = 16 * t + i;
+      const uint32_t m[3] = {wm[p * 3], wm[p * 3 + 1], wm[p * 3 + 2]};
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const u32x4 fa = expand8(__builtin_amdgcn_ubfe(word(mA, s), 8u * kq, 8u));
-        const u32x4 fb = expand8(__builtin_amdgcn_ubfe(word(mB, s), 8u * kq, 8u));
-        const u32x4 &bw = pl == 2 ? w[s].l : (pl == 1 ? w[s].m : w[s].h);
-        a0 = X3_MFMA(fa, bw, a0);
-        a1 = X3_MFMA(fb, bw, a1);
-      }
+      for (int s = 0; s < NS; ++s) fa[t][s] = expand8(__builtin_amdgcn_ubfe(word(m, s), 8u * kq, 8u));
     }
-    x3_drain(a0, a1);
-    dA = a0 * OUT_SCALE;
-    dB = a1 * OUT_SCALE;
+    f32x4 ab[4], as[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { ab[t] = f32x4{0.f, 0.f, 0.f, 0.f}; as[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) as[t] = X3_MFMA(fa[t][s], w[s].l, as[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ab[t] = X3_MFMA(fa[t][s], w[s].h, ab[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) as[t] = X3_MFMA(fa[t][s], w[s].m, as[t]);
+    }
+    x3_drain(ab[0], ab[1], ab[2], ab[3]);
+    x3_drain(as[0], as[1], as[2], as[3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) d[t] = (ab[t] + as[t]) * OUT_SCALE;
   }
 };
 
@@ -363,8 +377,7 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, 
   auto conv_mfma = [&](int mm, f32x4(&out)[4]) {
     window_masks<C>(s.bits + (QN_SPW * wave + mm) * Cfg::OW, wm, lane);
     if constexpr (X3) {
-      cv.tile2(wm, i, 16 + i, lane >> 4, out[0], out[1]);
-      cv.tile2(wm, 32 + i, 48 + i, lane >> 4, out[2], out[3]);
+      cv.tile4(wm, i, lane >> 4, out);
     } else {
       cv.tile2(wm, i, 16 + i, out[0], out[1]);
       cv.tile2(wm, 32 + i, 48 + i, out[2], out[3]);
@@ -559,11 +572,35 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(planes);
   const float *arow = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
   auto wfrag = [&](int p, int st, int c) {   // plane p, K step st (global), column block 2cp + c
+#ifdef T1_NO_WLOAD
+    return wf[(size_t)p * (X3_PLANE / 8) + ((0 * 8 + 2 * cp + c) * 64 + lane)];
+#else
     return wf[(size_t)p * (X3_PLANE / 8) + ((st * 8 + 2 * cp + c) * 64 + lane)];
+#endif
   };
-  f32x4 acc_b[2], acc_s[2];
+  // Eight independent accumulators (column block x {small, leading terms} x 2): a dependent v_mfma_f32_16x16x32_bf16
+  // issues ~90 counter ticks after its producer, the pipe takes one per ~10 (tools/ubench/mfma_issue.hip), so the
+  // twelve MFMAs of a step are ordered with reuse distance 8 -- with the two-accumulator chains of the first version
+  // the phase was issue-bound at 71 ticks per MFMA.
+  f32x4 acc_b[2][2], acc_s[2][2];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) { acc_b[c] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_s[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { acc_b[c][k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_s[c][k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  auto step_mfma = [&](const X3Frag &af, const X3Frag &b0, const X3Frag &b1) {
+    acc_s[0][0] = X3_MFMA(af.l, b0.h, acc_s[0][0]);
+    acc_s[1][0] = X3_MFMA(af.l, b1.h, acc_s[1][0]);
+    acc_b[0][0] = X3_MFMA(af.m, b0.h, acc_b[0][0]);
+    acc_b[1][0] = X3_MFMA(af.m, b1.h, acc_b[1][0]);
+    acc_s[0][1] = X3_MFMA(af.h, b0.l, acc_s[0][1]);
+    acc_s[1][1] = X3_MFMA(af.h, b1.l, acc_s[1][1]);
+    acc_b[0][1] = X3_MFMA(af.h, b0.m, acc_b[0][1]);
+    acc_b[1][1] = X3_MFMA(af.h, b1.m, acc_b[1][1]);
+    acc_s[0][0] = X3_MFMA(af.m, b0.m, acc_s[0][0]);
+    acc_s[1][0] = X3_MFMA(af.m, b1.m, acc_s[1][0]);
+    acc_b[0][0] = X3_MFMA(af.h, b0.h, acc_b[0][0]);
+    acc_b[1][0] = X3_MFMA(af.h, b1.h, acc_b[1][0]);
+  };
   u32x4 ring[PF][2][3];
 #pragma unroll
   for (int i = 0; i < PF; ++i)
@@ -584,16 +621,16 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
       a1n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn + 16);
       __builtin_amdgcn_sched_barrier(0);
       const X3Frag af = x3_split8(a0, a1);
+      X3Frag b0, b1;
+      b0.h = ring[i][0][0]; b0.m = ring[i][0][1]; b0.l = ring[i][0][2];
+      b1.h = ring[i][1][0]; b1.m = ring[i][1][1]; b1.l = ring[i][1][2];
+      step_mfma(af, b0, b1);
+      if (more) {
+        const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        X3Frag bf;
-        bf.h = ring[i][c][0]; bf.m = ring[i][c][1]; bf.l = ring[i][c][2];
-        x3_mfma6(af, bf, acc_b[c], acc_s[c]);
-        if (more) {
-          const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, st, c);
-        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -612,32 +649,36 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
       a0n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn);
       a1n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn + 16);
       const X3Frag af = x3_split8(a0, a1);
+      X3Frag b0, b1;
+      b0.h = ring[i][0][0]; b0.m = ring[i][0][1]; b0.l = ring[i][0][2];
+      b1.h = ring[i][1][0]; b1.m = ring[i][1][1]; b1.l = ring[i][1][2];
+      step_mfma(af, b0, b1);
+      if (g + i + PF < NS) {
+        const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        X3Frag bf;
-        bf.h = ring[i][c][0]; bf.m = ring[i][c][1]; bf.l = ring[i][c][2];
-        x3_mfma6(af, bf, acc_b[c], acc_s[c]);
-        if (g + i + PF < NS) {
-          const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, st, c);
-        }
       }
     }
   }
   // fold the two K halves: kh = 1 parks its partial tiles in the (idle) staging buffer, kh = 0 adds and writes z
-  x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
+  x3_drain(acc_b[0][0], acc_s[0][0], acc_b[1][0], acc_s[1][0]);
+  x3_drain(acc_b[0][1], acc_s[0][1], acc_b[1][1], acc_s[1][1]);
+  f32x4 tot[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) tot[c] = (acc_b[c][0] + acc_b[c][1]) + (acc_s[c][0] + acc_s[c][1]);
   f32x4 *park = reinterpret_cast<f32x4 *>(s.stg);
   if (kh == 1) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) park[(cp * 2 + c) * 64 + lane] = acc_b[c] + acc_s[c];
+    for (int c = 0; c < 2; ++c) park[(cp * 2 + c) * 64 + lane] = tot[c];
   }
   __syncthreads();
   if (kh == 0) {
     const int col = lane & 15, r0 = 4 * (lane >> 4);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const f32x4 acc = (acc_b[c] + acc_s[c]) + park[(cp * 2 + c) * 64 + lane];
+      const f32x4 acc = tot[c] + park[(cp * 2 + c) * 64 + lane];
       float *zp = s.z + r0 * QN_ZS + 16 * (2 * cp + c) + col;
       zp[0] = acc.x;
       zp[QN_ZS] = acc.y;
@@ -828,7 +869,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
 // tile the next forward reads, and only the transition record goes to HBM.  No kernel boundary, no
 // prologue and no observation round trip between steps.
 // ===========================================================================
-template <int C, class Env>
+template <int C, class Env, int MODE>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
     int n, int t_len, uint32_t *__restrict__ state, uint32_t *__restrict__ bits_all, const float *__restrict__ theta,
     pqn_cnn_layout_t L, int32_t *__restrict__ action, float *__restrict__ qmax, float *__restrict__ reward,
@@ -872,11 +913,11 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
 #pragma unroll 1
   for (int t = 0; t <= t_len; ++t) {
     __syncthreads();   // s.bits holds obs_t of the tile (and every previous reader of the tiles is done)
-    if (L.matmul_f16 == 2) phase1_conv<C, false, true>(s, tid);
+    if (MODE == 2) phase1_conv<C, false, true>(s, tid);
     else phase1_conv<C>(s, tid);
     __syncthreads();
-    if (L.matmul_f16 == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid, (e0 - e_off) / QN_TILE);
-    else if (L.matmul_f16 == 2) phase2_fc1_x3<2>(s, theta + L.off_w1h, tid, (e0 - e_off) / QN_TILE);
+    if (MODE == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid, (e0 - e_off) / QN_TILE);
+    else if (MODE == 2) phase2_fc1_x3<2>(s, theta + L.off_w1h, tid, (e0 - e_off) / QN_TILE);
     else phase2_fc1<0, 8>(s, theta + L.off_w1, tid, (e0 - e_off) / QN_TILE);   // 8 in flight: the env state lives in registers across this loop
     __syncthreads();
     if (tid < 256) {
@@ -1215,7 +1256,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   __syncthreads();
   T1_STAMP(2);
   if (MODE == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
-  else if (MODE == 2) phase2_fc1_x3<4>(s, theta + L.off_w1h, tid);
+  else if (MODE == 2) phase2_fc1_x3<3>(s, theta + L.off_w1h, tid);
   else phase2_fc1<0>(s, theta + L.off_w1, tid);
   // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
   // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
@@ -1231,6 +1272,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       *reinterpret_cast<f16x8 *>(h1P + (size_t)i * QN_TILE + 8 * hh) = v;
     }
   } else
+#ifndef T1_NO_H1T
   for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
     const int i = e >> 2, mq = e & 3;
     const float *src = s.h1 + (4 * mq) * QN_H1S + i;
@@ -1238,6 +1280,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     if (MODE == 2) *reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0 + 4 * mq)) = v;
     else *reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq) = v;
   }
+#endif
   if (tid < QN_TILE) {
     ts.act[tid] = act_g;
     ts.tgt[tid] = tgt_g;
@@ -1317,7 +1360,11 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     const int ib_first = IBW * wave;
     const int prot = blockIdx.x & (IBW - 1);
     auto frag = [&](int pl, int ibk, int sK) {   // plane pl, the wave's ibk-th i-block (rotated), K step sK
+#ifdef T1_NO_WLOAD
+      const int ib = ib_first;
+#else
       const int ib = ib_first + ((ibk + prot) & (IBW - 1));
+#endif
       return wd[(size_t)pl * (X3_PLANE / 8) + ((ib * 4 + sK) * 64 + lane)];
     };
     u32x4 ring[4][3];
@@ -1330,20 +1377,29 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       const int ib = ib_first + ((ibk + prot) & (IBW - 1));
       float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
       const float m0 = p0[0], m1 = p0[QN_H1S], m2 = p0[2 * QN_H1S], m3 = p0[3 * QN_H1S];   // relu mask, read ahead
-      f32x4 acc_b = {0.f, 0.f, 0.f, 0.f}, acc_s = {0.f, 0.f, 0.f, 0.f};
+      // four accumulators per K parity ({small, leading} x 2): reuse distance 6 in issue order (see phase2_fc1_x3)
+      f32x4 acc_b[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc_c[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int sK = 0; sK < 4; ++sK) {
         X3Frag bf;
         bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
-        x3_mfma6(afr[sK], bf, acc_b, acc_s);
+        const X3Frag &a = afr[sK];
+        acc_s[0] = X3_MFMA(a.l, bf.h, acc_s[0]);
+        acc_b[0] = X3_MFMA(a.m, bf.h, acc_b[0]);
+        acc_s[1] = X3_MFMA(a.h, bf.l, acc_s[1]);
+        acc_b[1] = X3_MFMA(a.h, bf.m, acc_b[1]);
+        acc_c[0] = X3_MFMA(a.m, bf.m, acc_c[0]);
+        acc_c[1] = X3_MFMA(a.h, bf.h, acc_c[1]);
         if (more) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, ibk + 1, sK);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      x3_drain(acc_b, acc_s);
-      const f32x4 acc0 = acc_b + acc_s;
+      x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
+      x3_drain(acc_c[0], acc_c[1]);
+      const f32x4 acc0 = ((acc_b[0] + acc_b[1]) + acc_c[1]) + ((acc_s[0] + acc_s[1]) + acc_c[0]);
       p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
       p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
       p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
@@ -1497,6 +1553,9 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     for (int j = 0; j < RBW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     uint32_t *wm = reinterpret_cast<uint32_t *>(s.stg + wave * 64 * QN_STG);   // staging buffer is free now
     if constexpr (MODE == 2) {
+      f32x4 accs[RBW];
+#pragma unroll
+      for (int j = 0; j < RBW; ++j) accs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       // bf16 matrix core: A = window bits (exact in bf16, written as 2.0 = 0x4000), B = dx split exactly into three
       // bf16 planes; 2 K steps of 32 positions per sample, K slot (kq = kk, j) <-> position 32 st + 4 j + kk so that
       // the B reads stay the conflict-free dxm[64 * (8 st + j)] of the f32 path.  3 MFMAs per (step, row block)
@@ -1530,18 +1589,19 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
             }
             af[j] = u32x4{d[0], d[1], d[2], d[3]};
           }
+          // {h plane} and {m + l planes} accumulate separately: 2 RBW independent chains (see phase2_fc1_x3)
 #pragma unroll
-          for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.l, acc[j]);
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.m, acc[j]);
+          for (int j = 0; j < RBW; ++j) accs[j] = X3_MFMA(af[j], bf.l, accs[j]);
 #pragma unroll
           for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.h, acc[j]);
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) accs[j] = X3_MFMA(af[j], bf.m, accs[j]);
         }
       }
 #pragma unroll
       for (int j = 0; j < RBW; ++j) {
-        x3_drain(acc[j]);
-        acc[j] = acc[j] * (0.5f / 255.0f);
+        x3_drain(acc[j], accs[j]);
+        acc[j] = (acc[j] + accs[j]) * (0.5f / 255.0f);
       }
     } else
 #pragma unroll
@@ -1927,15 +1987,18 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
   if (blockIdx.x < QR_W1_BLOCKS) {
     const int j4 = blockIdx.x * 256 + threadIdx.x;  // float4 index inside the fc1 region
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    // 8 slab loads in flight at a time (a plain loop serialises 16 dependent L2 round trips), added in slab order
-    for (int k0 = 0; k0 < nks; k0 += 8) {
-      f32x4 t[8];
+    // 16 slab loads in flight at a time, UNCONDITIONAL (slab index clamped, the surplus masked in the add: a load under
+    // a condition makes the compiler wait for the whole queue), added in slab order
+    for (int k0 = 0; k0 < nks; k0 += 16) {
+      f32x4 t[16];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        t[q] = (k0 + q < nks) ? reinterpret_cast<const f32x4 *>(wpart + (size_t)(k0 + q) * QN_H1 * QN_HID)[j4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 16; ++q)
+        t[q] = reinterpret_cast<const f32x4 *>(wpart + (size_t)min(k0 + q, nks - 1) * QN_H1 * QN_HID)[j4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (k0 + q < nks) g += t[q];
+      for (int q = 0; q < 16; ++q) {
+        const float keep = (k0 + q < nks) ? 1.0f : 0.0f;
+        g += t[q] * keep;
+      }
     }
     reinterpret_cast<f32x4 *>(grad + L.off_w1)[j4] = g;
     ss = fmaf(g.x, g.x, fmaf(g.y, g.y, fmaf(g.z, g.z, g.w * g.w)));
@@ -2061,11 +2124,19 @@ static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t 
   const size_t smem = cnn_smem_bytes<C>();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_kernel<C, Env>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_kernel<C, Env, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_kernel<C, Env, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_kernel<C, Env, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((qnet_cnn_rollout_kernel<C, Env>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n,
+  // one instantiation per operand mode (as the training kernel): the env state lives in registers across the T-step
+  // loop, and carrying all three fc1 / conv variants in one kernel cost 27 spilled VGPRs
+  auto kern = L.matmul_f16 == 2 ? &qnet_cnn_rollout_kernel<C, Env, 2>
+                                : (L.matmul_f16 == 1 ? &qnet_cnn_rollout_kernel<C, Env, 1> : &qnet_cnn_rollout_kernel<C, Env, 0>);
+  hipLaunchKernelGGL(kern, dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n,
                      t_len, state, bits, theta, L, action, qmax, rec.reward, rec.done, rec.discount,
                      rec.returned_episode_returns, rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys,
                      rscale, store_obs, n_per_seed, theta_stride, keys_stride);

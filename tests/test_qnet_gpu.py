@@ -289,3 +289,39 @@ def test_cnn_f16_matmul_mode_vs_oracle(gpu, oracle, c, a, nb, pool):
     w1k = tr.theta[int(lay.struct.off_w1):int(lay.struct.off_w1) + 1024 * 128]
     assert torch.equal(tail[:1024 * 128], w1k.to(torch.float16))             # forward fragments: same order as the f32 kernel
     assert torch.equal(tail[1024 * 128:].float().sort().values, w1k.to(torch.float16).float().sort().values)   # dgrad copy: a permutation
+
+
+@pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 128, 1000), (4, 3, 4096, 20000), (6, 4, 1024, 2000), (7, 3, 1024, 1024), (10, 6, 1024, 2000)])
+def test_bf16x3_is_deterministic_and_matches_f32_mode(gpu, c, a, nb, pool):
+    """Guard for the bf16x3 MFMA issue path (csrc/pqn_qnet.hip, x3_mfma_tied): the training kernels in bf16x3 mode must
+    give bit-identical gradients on repeated launches and agree with the f32-MFMA mode of the same kernels to f32
+    rounding, for every channel count.  (The builtin form of v_mfma_f32_16x16x32_bf16, and a re-orderable inline-asm
+    form, produced run-to-run different forward results in the conv phase for c = 6, 7, 10.)"""
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
+    rng = np.random.default_rng(nb + c)
+    torch.manual_seed(1234)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
+    obs, words = _random_bits(rng, pool, c, density=0.12)
+    bits = torch.from_numpy(words.view(np.int32)).to(gpu)
+    action = torch.from_numpy(rng.integers(0, a, pool).astype(np.int32)).to(gpu)
+    target = torch.from_numpy(rng.standard_normal(pool).astype(np.float32)).to(gpu)
+    idx = torch.from_numpy(rng.permutation(pool)[:nb].astype(np.int64)).to(gpu)
+    out = {}
+    for mode in (0, 2):
+        lay = CnnKernelLayout(c, a, matmul_f16=mode)
+        tr = CnnTrainer(lay, theta, 5e-4, 10.0, lr_decay_steps=1000.0)
+        reps = []
+        for _ in range(4):
+            lo = torch.zeros(1, device=gpu)
+            qv = torch.zeros(1, device=gpu)
+            g = tr.compute_grad(idx, bits, action, target, lo, qv)[:lay.total].clone()
+            reps.append((float(lo), float(qv), g))
+        for r in reps[1:]:
+            assert r[0] == reps[0][0] and r[1] == reps[0][1]
+            assert torch.equal(r[2], reps[0][2])
+        out[mode] = reps[0]
+    assert abs(out[0][1] - out[2][1]) <= 2e-6 and abs(out[0][0] - out[2][0]) <= 2e-6 * max(1.0, abs(out[0][0]))
+    scale = float(out[0][2].abs().max())
+    assert float((out[0][2] - out[2][2]).abs().max()) <= 2e-5 * scale

@@ -5,7 +5,7 @@ from test_qnet_gpu import _random_bits
 from purejaxql_amd.networks import QNetwork
 from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
 dev = torch.device("cuda:0")
-for (c, a, nb, pool) in [(4, 3, 16, 64), (4, 3, 128, 1000), (4, 3, 4096, 20000)]:
+for (c, a, nb, pool) in [(4, 3, 16, 64), (4, 3, 128, 1000), (4, 3, 4096, 20000), (6, 4, 1024, 2000), (7, 3, 1024, 1024), (10, 6, 1024, 2000)]:
     rng = np.random.default_rng(nb + c); torch.manual_seed(1234)
     net = QNetwork("cnn", (10, 10, c), a, device=dev)
     theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=dev)
@@ -14,6 +14,7 @@ for (c, a, nb, pool) in [(4, 3, 16, 64), (4, 3, 128, 1000), (4, 3, 4096, 20000)]
     action = torch.from_numpy(rng.integers(0, a, pool).astype(np.int32)).to(dev)
     target = torch.from_numpy(rng.standard_normal(pool).astype(np.float32)).to(dev)
     idx = torch.from_numpy((rng.permutation(pool)[:nb]).astype(np.int64)).to(dev)
+    if os.environ.get("BRIEF"): print("C", c, "nb", nb, end=": ")
     res = {}
     for mode in (0, 2):
         lay = CnnKernelLayout(c, a, matmul_f16=mode)
@@ -24,8 +25,14 @@ for (c, a, nb, pool) in [(4, 3, 16, 64), (4, 3, 128, 1000), (4, 3, 4096, 20000)]
             g = tr.compute_grad(idx, bits, action, target, lo, qv)[:lay.total].clone()
             outs.append((float(lo), float(qv), g))
         res[mode] = (lay, outs)
+        if os.environ.get("BRIEF"):
+            if mode == 2:
+                d02 = float((res[0][1][0][2] - outs[0][2]).abs().max())
+                print("qv f32 %.7f x3 %s rep-to-rep max|dg| %.2e  max|g_x3 - g_f32| %.2e" % (res[0][1][0][1], [round(o[1], 7) for o in outs], max(float((outs[0][2] - o[2]).abs().max()) for o in outs[1:]), d02))
+            continue
         print("nb", nb, "mode", mode, "loss/qv per rep:", [(round(o[0], 7), round(o[1], 7)) for o in outs],
               "rep-to-rep max|dg|", max(float((outs[0][2] - o[2]).abs().max()) for o in outs[1:]))
+    if os.environ.get("BRIEF"): continue
     lay, o2 = res[2]; _, o0 = res[0]
     d = (o2[0][2] - o0[0][2]).abs()
     names = [n for n in dir(lay.struct) if n.startswith("off_")]
