@@ -28,6 +28,7 @@ ENV_STEP_BYTES = 1926.0      # algorithmic bytes of one env.step (f
 LOOP_FLOP = 2.367e6          # algorithmic FLOP per env-step of the whole loop
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA/vector peak
+BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # Dominant kernel = qnet_cnn_train_kernel (T1: forward + backward except the fc1 weight gradient).
 # Algorithmic FLOP per sample: fwd conv 73,728 + fc1 262,144 + fc2 768; bwd fc2 dgrad+wgrad
 # 1,536 + fc1 dgrad 262,144 + conv wgrad 73,728 (the conv has no input gradient) = 674,048.
@@ -144,20 +145,33 @@ def kernel_timer_pass(lib, update, first, mb_samples, seeds):
 def t1_roofline(avg_s, launches, mb_samples, seeds, matmul):
     achieved = T1_FLOP_PER_SAMPLE * mb_samples * seeds / avg_s / 1e12
     traffic, tsrc = None, None
-    for name in ("r02_pmc_train_kernel.json", "r01_pmc_train_kernel.json"):
+    for name in (f"r02_pmc_train_kernel_{matmul}.json", "r01_pmc_train_kernel.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             pj = json.load(open(pmc))
-            if pj.get("seeds_per_launch", 1) == seeds and pj.get("matmul", "f32") == matmul:
-                traffic = pj.get("hbm_bytes_per_launch")
-                tsrc = f"from file profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; not measured in this run)"
+            if pj.get("matmul", "f32") == matmul and pj.get("hbm_bytes_per_launch"):
+                ps = max(1, int(pj.get("seeds_per_launch", 1)))
+                traffic = pj["hbm_bytes_per_launch"] * seeds / ps       # every seed of a launch moves the same bytes
+                tsrc = (f"from file profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
+                        f"{ps}-seed launch of this kernel, gfx950-corrected as MI355X_MICROARCH.md prescribes"
+                        + (f", x{seeds // ps} for the {seeds} seeds of this launch" if seeds != ps else "")
+                        + "; not measured in this run")
                 break
-    return {"kernel": f"qnet_cnn_train_kernel<4> (fwd + bwd of one {mb_samples}-sample minibatch of each of {seeds} seed(s) per launch)",
-            "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
-            "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
-            "flop_per_launch": T1_FLOP_PER_SAMPLE * mb_samples * seeds,
-            "peak_note": "f32 MFMA / vector peak of MI355X (157.3 TFLOP/s); algorithmic f32 FLOPs of the kernel"}
+    out = {"kernel": f"qnet_cnn_train_kernel<4> (fwd + bwd of one {mb_samples}-sample minibatch of each of {seeds} seed(s) per launch)",
+           "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+           "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
+           "flop_per_launch": T1_FLOP_PER_SAMPLE * mb_samples * seeds,
+           "peak_note": "f32 MFMA / vector peak of MI355X (157.3 TFLOP/s); algorithmic f32 FLOPs of the kernel"}
+    if matmul == "bf16x3":
+        # the same f32 products, evaluated as 6 bf16 MFMA products each (3 for the conv phases, whose bit operand is
+        # exact in bf16): also priced against the pipe they actually run on
+        out["bf16_pipe"] = {"issued_tflops": achieved * 6.0, "peak": BF16_PEAK_TFLOPS, "frac": achieved * 6.0 / BF16_PEAK_TFLOPS,
+                            "note": "upper bound on the bf16 MFMA FLOPs issued (6 per algorithmic f32 FLOP) against the dense "
+                                    "bf16 peak: the kernel is NOT matrix-pipe bound in this mode -- what bounds fc1 / dgrad is the "
+                                    "64 B/clk/CU vector-memory path streaming the 1.5 MB of weight planes per 16-sample tile "
+                                    "(DESIGN.md section 5)"}
+    return out
 
 
 DTYPE_LABEL = {"f32": "f32",
@@ -179,8 +193,10 @@ def main():
                          "(RCCL gradient all-reduce per optimizer step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only")
-    ap.add_argument("--matmul-dtype", default=None, choices=["f32", "bf16x3", "f16"],
-                    help="operand type of the fc1 products (config MATMUL_DTYPE; default: the config's)")
+    ap.add_argument("--matmul-dtype", default="bf16x3", choices=["f32", "bf16x3", "f16"],
+                    help="operand mode of the fc1 / conv products (config MATMUL_DTYPE).  bf16x3 (default here) evaluates "
+                         "every f32 product exactly-split on the bf16 matrix core with f32 accumulation and is held to "
+                         "the same f32 tolerances as the f32-MFMA mode by the parity tests; the package default stays f32")
     args = ap.parse_args()
 
     import torch

@@ -127,6 +127,7 @@ struct pqn_seeds_t {
   long long ws_stride;           // optimizer + training workspace
   long long lq_stride;           // loss_buf / qv_buf
   long long idx_mask;            // low bits of a sorted key that hold the local transition index
+  int seed_base;                 // first seed of this launch (seed = blockIdx.y + seed_base): launches over seed groups
 };
 inline pqn_seeds_t pqn_one_seed() {
   pqn_seeds_t s = {};

@@ -2258,6 +2258,14 @@ extern "C" int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries *
   return PQN_OK;
 }
 
+// seeds per T1 -> T2 launch pair (see launch_train); also how many seeds one timed T1 launch covers (pqn_prof_read)
+extern "C" int pqn_cnn_seed_group(int matmul_mode, int nseeds) {
+  static const int env_gs = getenv("PQN_SEED_GROUP") ? atoi(getenv("PQN_SEED_GROUP")) : 0;   // profiling override
+  if (env_gs > 0) return min(env_gs, nseeds);
+  (void)matmul_mode;
+  return nseeds;   // measured (16 seeds x 4096 samples, bf16x3): groups of 16 / 8 / 4 / 2 -> 50.4 / 50.7 / 51.3 / 55.5 ms per update
+}
+
 template <int C>
 static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits,
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
@@ -2286,36 +2294,46 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   if (!g_t1_stamps && getenv("PQN_T1_STAMPS")) {
     if (hipMalloc(&g_t1_stamps, 64 * sizeof(unsigned long long)) != hipSuccess) g_t1_stamps = nullptr;
   }
-  const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
-  if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
   // matmul_f16: dz (O(1/nb)) is scaled by a power of two into fp16's normal range; products are scaled back in f32
   const float dz_scale = exp2f(floorf(log2f((float)nb)));
   // one instantiation per operand mode of the fc1 / conv products (pqn_cnn_layout_t.matmul_f16)
   auto t1 = L.matmul_f16 == 2 ? &qnet_cnn_train_kernel<C, 2> : (L.matmul_f16 == 1 ? &qnet_cnn_train_kernel<C, 1> : &qnet_cnn_train_kernel<C, 0>);
-  hipLaunchKernelGGL(t1, dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
-                     target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sd, dz_scale);
-  if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
-  if (L.matmul_f16 == 1)
-    hipLaunchKernelGGL(qnet_fc1_wgrad_f16_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
-                       sd.ws_stride, 1.0f / dz_scale);
-  else if (L.matmul_f16 == 2) {
-    static bool x3_attr = false;
-    if (!x3_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, QY_LDS);
-      x3_attr = true;
-    }
-    // row blocks per workgroup: as many as still leave one workgroup per CU (16 = the dz slab is read once)
-    int G = 16;
-    while (G > 1 && (16 / G) * nks * sd.nseeds < 256) G >>= 1;
-    if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
-      if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;
-    }
-    hipLaunchKernelGGL(qnet_fc1_wgrad_x3_kernel, dim3(16 / G, nks, sd.nseeds), dim3(QN_THREADS), QY_LDS, st, nb, h1T, dzT,
-                       wpart, sd.ws_stride, G, g_t2_stamps);
-  } else
-    hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, sd.nseeds), dim3(QN_THREADS), 0, st, nb, h1T, dzT, wpart,
-                       sd.ws_stride);
+  // Seed groups: the launches can be cut into T1 -> T2 pairs over groups of seeds (PQN_SEED_GROUP, profiling) so that
+  // the h1 a group hands from T1 to T2 (16 MB per seed at a 4096-sample minibatch) stays inside the 256 MB Infinity
+  // Cache.  Measured, it does not pay (see pqn_cnn_seed_group): the default is one group.
+  const int gs_max = pqn_cnn_seed_group(L.matmul_f16, sd.nseeds);
+  for (int s0 = 0; s0 < sd.nseeds; s0 += gs_max) {
+    const int gs = min(gs_max, sd.nseeds - s0);
+    pqn_seeds_t sg = sd;
+    sg.seed_base = s0;
+    const long long wo = (long long)s0 * sd.ws_stride;
+    const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
+    if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
+    hipLaunchKernelGGL(t1, dim3(ntiles, gs), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
+                       target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sg, dz_scale);
+    if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
+    if (L.matmul_f16 == 1)
+      hipLaunchKernelGGL(qnet_fc1_wgrad_f16_kernel, dim3(16, nks, gs), dim3(QN_THREADS), 0, st, nb, h1T + wo, dzT + wo, wpart + wo,
+                         sd.ws_stride, 1.0f / dz_scale);
+    else if (L.matmul_f16 == 2) {
+      static bool x3_attr = false;
+      if (!x3_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, QY_LDS);
+        x3_attr = true;
+      }
+      // row blocks per workgroup: as many as still leave one workgroup per CU (16 = the dz slab is read once)
+      int G = 16;
+      while (G > 1 && (16 / G) * nks * gs < 256) G >>= 1;
+      if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
+        if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;
+      }
+      hipLaunchKernelGGL(qnet_fc1_wgrad_x3_kernel, dim3(16 / G, nks, gs), dim3(QN_THREADS), QY_LDS, st, nb, h1T + wo, dzT + wo,
+                         wpart + wo, sd.ws_stride, G, g_t2_stamps);
+    } else
+      hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, gs), dim3(QN_THREADS), 0, st, nb, h1T + wo, dzT + wo, wpart + wo,
+                         sd.ws_stride);
+  }
   if (with_reduce)
     hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles, nks,
                        rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd);

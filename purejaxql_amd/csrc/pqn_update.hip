@@ -195,6 +195,7 @@ static int upd_ctx(const pqn_update_args_t *a, int S, const uint64_t *key_roll_d
   c.sd = pqn_one_seed();
   if (S > 1) {
     c.sd.nseeds = S;
+    c.sd.seed_base = 0;
     c.sd.n_env = c.N;
     c.sd.n_env_total = c.SN;
     c.sd.idx_stride = c.TN;
