@@ -1185,6 +1185,284 @@ PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layou
 // profiling: per-phase s_memtime stamps of workgroup 0 / wave 0 (PQN_T1_STAMPS=1), read by tools/t1_stamps.py
 #define T1_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.x < 4) stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 
+// ---- P4 (bf16x3): dgrad  dh1[m][i] = relu'(h1[m][i]) * sum_o dz[m][o] W1[i][o]  written to out[m][i] (row stride
+// QN_H1S).  A = the dz tile zt, split once per wave; B = the fc1 kernel's dgrad-order bf16 planes, streamed one
+// i-block (12 dwordx4) ahead.  The relu mask is either the h1 tile itself, overwritten in place (out == the h1 tile,
+// MASKBITS false), or a packed bit array (the pair kernel: the second tile's h1 region is reused before its backward).
+template <bool MASKBITS>
+PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const float *__restrict__ theta,
+                       const pqn_cnn_layout_t &L, int lane, int wave, int prot) {
+    // bf16x3 split operands (see phase2_fc1_x3): the dz tile is split once per wave (4 K steps of 32 outputs, kept in
+    // registers), the fc1 kernel's dgrad-order bf16 planes are streamed one i-block (12 dwordx4) ahead.
+    const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
+    X3Frag afr[4];
+#pragma unroll
+    for (int sK = 0; sK < 4; ++sK) {
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(zt + (lane & 15) * QN_ZS + 32 * sK + 4 * (lane >> 4));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(zt + (lane & 15) * QN_ZS + 32 * sK + 16 + 4 * (lane >> 4));
+      afr[sK] = x3_split8(lo, hi);
+    }
+    const int col = lane & 15, r0 = 4 * (lane >> 4);
+    constexpr int IBW = 64 / QN_WAVES;
+    const int ib_first = IBW * wave;
+    auto frag = [&](int pl, int ibk, int sK) {   // plane pl, the wave's ibk-th i-block (rotated), K step sK
+#ifdef T1_NO_WLOAD
+      const int ib = ib_first;
+#else
+      const int ib = ib_first + ((ibk + prot) & (IBW - 1));
+#endif
+      return wd[(size_t)pl * (X3_PLANE / 8) + ((ib * 4 + sK) * 64 + lane)];
+    };
+    u32x4 ring[4][3];
+#pragma unroll
+    for (int sK = 0; sK < 4; ++sK)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, 0, sK);
+    auto ib_step = [&](int ibk, auto more_t) {
+      constexpr bool more = decltype(more_t)::value;
+      const int ib = ib_first + ((ibk + prot) & (IBW - 1));
+      float *p0 = out + r0 * QN_H1S + 16 * ib + col;
+      float m0, m1, m2, m3;   // relu mask (h1 > 0), read ahead of the MFMAs
+      if (MASKBITS) {         // packed by t1_pack_relu_mask: bit (i & 31) of word [m][i >> 5]
+        const int wsel = ib >> 1, bsel = 16 * (ib & 1) + col;
+        m0 = (float)((mask[(r0 + 0) * 32 + wsel] >> bsel) & 1u);
+        m1 = (float)((mask[(r0 + 1) * 32 + wsel] >> bsel) & 1u);
+        m2 = (float)((mask[(r0 + 2) * 32 + wsel] >> bsel) & 1u);
+        m3 = (float)((mask[(r0 + 3) * 32 + wsel] >> bsel) & 1u);
+      } else {
+        m0 = p0[0]; m1 = p0[QN_H1S]; m2 = p0[2 * QN_H1S]; m3 = p0[3 * QN_H1S];
+      }
+      // four accumulators per K parity ({small, leading} x 2): reuse distance 6 in issue order (see phase2_fc1_x3)
+      f32x4 acc_b[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc_c[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int sK = 0; sK < 4; ++sK) {
+        X3Frag bf;
+        bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
+        const X3Frag &a = afr[sK];
+        acc_s[0] = X3_MFMA(a.l, bf.h, acc_s[0]);
+        acc_b[0] = X3_MFMA(a.m, bf.h, acc_b[0]);
+        acc_s[1] = X3_MFMA(a.h, bf.l, acc_s[1]);
+        acc_b[1] = X3_MFMA(a.h, bf.m, acc_b[1]);
+        acc_c[0] = X3_MFMA(a.m, bf.m, acc_c[0]);
+        acc_c[1] = X3_MFMA(a.h, bf.h, acc_c[1]);
+        if (more) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, ibk + 1, sK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
+      x3_drain(acc_c[0], acc_c[1]);
+      const f32x4 acc0 = ((acc_b[0] + acc_b[1]) + acc_c[1]) + ((acc_s[0] + acc_s[1]) + acc_c[0]);
+      p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
+      p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
+      p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
+      p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
+    };
+#pragma unroll 1
+    for (int ibk = 0; ibk < IBW - 1; ++ibk) ib_step(ibk, std::true_type{});
+    ib_step(IBW - 1, std::false_type{});
+}
+
+// ---- P5: LN0 backward of one 16-sample tile, in place on dh1 (d relu-input -> dx); ends with the workgroup barrier
+// after which dx is complete and the 48 channel sums are in gp.  stg_base: QN_WAVES x 64 x QN_STG floats of scratch.
+template <int C>
+PQN_D void t1_ln0_bwd(float *dh1, float *stg_base, float *red, const float *__restrict__ theta, const pqn_cnn_layout_t &L,
+                      const float (*xkeep)[16], const float *rkeep, float *__restrict__ gp, int tid, int ablate) {
+  using Cfg = CnnCfg<C>;
+  const int lane = tid & 63, wave = tid >> 6;
+  // ---- P5: LN0 backward per point in one lane (xhat / rstd kept in registers since the forward conv);
+  // channel sums (d conv-bias, d ln0-scale, d ln0-bias) in (channel = lane&15) layout. -----------
+  if (!(ablate & 2)) {
+    float ln0s[16];                                      // LayerNorm_0 scale: wave-uniform scalar loads
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ln0s[c] = theta[L.off_ln0s + c];
+    const int o = lane & 15, kk = lane >> 4;
+    float *stg = stg_base + wave * 64 * QN_STG;
+    float gsc = 0.f, gbi = 0.f, gbc = 0.f;
+#pragma unroll
+    for (int mm = 0; mm < QN_SPW; ++mm) {
+      const int msamp = QN_SPW * wave + mm;
+      float *gt = dh1 + msamp * QN_H1S;                 // d relu-input tile (masked by h1 > 0) -> dx in place
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gbi += gt[(kk + 4 * j) * 16 + o];
+      const float rstd = rkeep[mm];
+      f32x4 *gptr = reinterpret_cast<f32x4 *>(gt + lane * 16);
+      float g[16];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = gptr[qd];
+        g[4 * qd] = v.x; g[4 * qd + 1] = v.y; g[4 * qd + 2] = v.z; g[4 * qd + 3] = v.w;
+      }
+      float s1 = 0.f, s2 = 0.f, dxh[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        dxh[c] = g[c] * ln0s[c];
+        s1 += dxh[c];
+        s2 = fmaf(dxh[c], xkeep[mm][c], s2);
+      }
+      s1 *= (1.0f / 16.0f);
+      s2 *= (1.0f / 16.0f);
+      f32x4 *sp = reinterpret_cast<f32x4 *>(stg + lane * QN_STG);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 dx, gx;
+        dx.x = rstd * (dxh[4 * qd + 0] - s1 - xkeep[mm][4 * qd + 0] * s2); gx.x = g[4 * qd + 0] * xkeep[mm][4 * qd + 0];
+        dx.y = rstd * (dxh[4 * qd + 1] - s1 - xkeep[mm][4 * qd + 1] * s2); gx.y = g[4 * qd + 1] * xkeep[mm][4 * qd + 1];
+        dx.z = rstd * (dxh[4 * qd + 2] - s1 - xkeep[mm][4 * qd + 2] * s2); gx.z = g[4 * qd + 2] * xkeep[mm][4 * qd + 2];
+        dx.w = rstd * (dxh[4 * qd + 3] - s1 - xkeep[mm][4 * qd + 3] * s2); gx.w = g[4 * qd + 3] * xkeep[mm][4 * qd + 3];
+        gptr[qd] = dx;
+        sp[qd] = gx;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        gsc += stg[(kk + 4 * j) * QN_STG + o];
+        gbc += gt[(kk + 4 * j) * 16 + o];
+      }
+    }
+    // fold the 4 position-groups of the wave (lanes o, o+16, o+32, o+48), then the 4 waves in fixed order
+    gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
+    gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
+    gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
+    if (lane < 16) {
+      red[wave * 48 + lane] = gbc;
+      red[wave * 48 + 16 + lane] = gsc;
+      red[wave * 48 + 32 + lane] = gbi;
+    }
+  }
+  __syncthreads();
+  if (tid < 48) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < QN_WAVES; ++w) acc += red[w * 48 + tid];
+    gp[Cfg::KW * 16 + tid] = acc;
+  }
+}
+
+// ---- P6: conv weight gradient of one tile from dx (in the h1 region) and the packed observation bits; writes the
+// tile's [KW][16] partial to gp.  wm_base: QN_WAVES x 192 words for the window masks; scr: TrainCfg<C>::SCR floats.
+template <int C, int MODE>
+PQN_D void t1_conv_wgrad(const float *dx, const uint32_t *bits, uint32_t *wm_base, float *scr, float *__restrict__ gp,
+                         int tid, int ablate) {
+  using Cfg = CnnCfg<C>;
+  const int lane = tid & 63, wave = tid >> 6;
+  // ---- P6: conv weight gradient as MFMA:  dWc[k][o] = sum_{m,pos} (bit(m,pos,k)/255) * dx[m][pos][o] ----
+  //   A[i = k row][kk] = bit(m, pos = 4s+kk, k = 16rb+i)/255,  B[kk][o] = dx[m][4s+kk][o]  (LDS, contiguous)
+  //   wave w reduces its samples 4w..4w+3; the 4 wave partials are folded in fixed order.
+  if (!(ablate & 4)) {
+    constexpr int NRB = (9 * C + 15) / 16;   // 16-row blocks of k
+    constexpr int RB = 3 * C;
+    // NRB odd (C = 4): wave = sample pair, all row blocks (no padded block);  NRB even: wave = (sample quad,
+    // half of the row blocks).  NPART wave partials per row block are folded in fixed order.
+    constexpr bool PAIR = (NRB % 2) == 1;
+    constexpr int RBW = PAIR ? NRB : NRB / 2;      // row blocks per wave
+    constexpr int SPW6 = PAIR ? 2 : 4;             // samples per wave
+    constexpr int NPART = QN_TILE / SPW6;
+    static_assert(NPART * NRB * 256 <= TrainCfg<C>::SCR, "conv-wgrad partials must fit the scratch tile");
+    const int sg = PAIR ? wave : (wave & 3), rb0 = PAIR ? 0 : (wave >> 2) * RBW;
+    const int i = lane & 15, kk = lane >> 4;
+    int kyL[RBW], shL[RBW];                  // lane constants: window row / bit of k = 16*rb + i
+#pragma unroll
+    for (int j = 0; j < RBW; ++j) {
+      const int k = 16 * (rb0 + j) + i;
+      kyL[j] = (k < 9 * C) ? k / RB : 0;
+      shL[j] = (k < 9 * C) ? k % RB : 31;    // padding rows test bit 31, which no window mask has (3C <= 30)
+    }
+    f32x4 acc[RBW];
+#pragma unroll
+    for (int j = 0; j < RBW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint32_t *wm = wm_base + wave * 192;
+    if constexpr (MODE == 2) {
+      f32x4 accs[RBW];
+#pragma unroll
+      for (int j = 0; j < RBW; ++j) accs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // bf16 matrix core: A = window bits (exact in bf16, written as 2.0 = 0x4000), B = dx split exactly into three
+      // bf16 planes; 2 K steps of 32 positions per sample, K slot (kq = kk, j) <-> position 32 st + 4 j + kk so that
+      // the B reads stay the conflict-free dxm[64 * (8 st + j)] of the f32 path.  3 MFMAs per (step, row block)
+      // instead of 8 at 1/4 the cycles each; 0.5/255 applied once to the accumulators.
+#pragma unroll
+      for (int mm = 0; mm < SPW6; ++mm) {
+        const int msamp = SPW6 * sg + mm;
+        window_masks<C>(bits + msamp * Cfg::OW, wm, lane);
+        const float *dxm = dx + msamp * QN_H1S + lane;
+        float bv[16];
+        uint32_t wv[16][RBW];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {           // q = 8 st + j: all LDS reads of the sample in flight at once
+          bv[q] = dxm[64 * q];
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) wv[q][j] = wm[(4 * q + kk) * 3 + kyL[j]];
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const float *b = bv + 8 * st;
+          const X3Frag bf = x3_split8(f32x4{b[0], b[1], b[2], b[3]}, f32x4{b[4], b[5], b[6], b[7]});
+          u32x4 af[RBW];
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) {
+            uint32_t d[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const uint32_t b0 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj][j], (uint32_t)shL[j], 1u);
+              const uint32_t b1 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj + 1][j], (uint32_t)shL[j], 1u);
+              d[jj] = ((b1 << 16) | b0) << 14;
+            }
+            af[j] = u32x4{d[0], d[1], d[2], d[3]};
+          }
+          // {h plane} and {m + l planes} accumulate separately: 2 RBW independent chains (see phase2_fc1_x3)
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) accs[j] = X3_MFMA(af[j], bf.l, accs[j]);
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.h, acc[j]);
+#pragma unroll
+          for (int j = 0; j < RBW; ++j) accs[j] = X3_MFMA(af[j], bf.m, accs[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RBW; ++j) {
+        x3_drain(acc[j], accs[j]);
+        acc[j] = (acc[j] + accs[j]) * (0.5f / 255.0f);
+      }
+    } else
+#pragma unroll
+    for (int mm = 0; mm < SPW6; ++mm) {
+      const int msamp = SPW6 * sg + mm;
+      window_masks<C>(bits + msamp * Cfg::OW, wm, lane);
+      const float *dxm = dx + msamp * QN_H1S + lane;   // + 64*st : element (pos = 4st+kk, o = lane&15)
+      float bv[16];
+      uint32_t wv[16][RBW];
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {          // all LDS reads of the sample in flight at once
+        bv[st] = dxm[64 * st];
+#pragma unroll
+        for (int j = 0; j < RBW; ++j) wv[st][j] = wm[(4 * st + kk) * 3 + kyL[j]];
+      }
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+#pragma unroll
+        for (int j = 0; j < RBW; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bit_times_inv255(wv[st][j], shL[j]), bv[st], acc[j], 0, 0, 0);
+      }
+    }
+    float *part = scr;  // [sample group][row block][16 rows][16 o]
+#pragma unroll
+    for (int j = 0; j < RBW; ++j) {
+      float *pp = part + ((sg * NRB + rb0 + j) * 16 + 4 * kk) * 16 + i;
+      pp[0] = acc[j].x; pp[16] = acc[j].y; pp[32] = acc[j].z; pp[48] = acc[j].w;
+    }
+    __syncthreads();
+    for (int e = tid; e < Cfg::KW * 16; e += QN_THREADS) {
+      const float *pp = scr + e;   // e = k*16 + o = (rb*16 + row)*16 + o
+      if (NPART == 8)
+        gp[e] = ((pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256])) +
+                ((pp[4 * NRB * 256] + pp[5 * NRB * 256]) + (pp[6 * NRB * 256] + pp[7 * NRB * 256]));
+      else
+        gp[e] = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
+    }
+  }
+}
+
 template <int C, int MODE>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
@@ -1345,69 +1623,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     for (int ip = 0; ip < IBW / 2 - 1; ++ip) pair_step(ip, std::true_type{});
     pair_step(IBW / 2 - 1, std::false_type{});
   } else if (MODE == 2) {
-    // bf16x3 split operands (see phase2_fc1_x3): the dz tile is split once per wave (4 K steps of 32 outputs, kept in
-    // registers), the fc1 kernel's dgrad-order bf16 planes are streamed one i-block (12 dwordx4) ahead.
-    const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
-    X3Frag afr[4];
-#pragma unroll
-    for (int sK = 0; sK < 4; ++sK) {
-      const f32x4 lo = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 32 * sK + 4 * (lane >> 4));
-      const f32x4 hi = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 32 * sK + 16 + 4 * (lane >> 4));
-      afr[sK] = x3_split8(lo, hi);
-    }
-    const int col = lane & 15, r0 = 4 * (lane >> 4);
-    constexpr int IBW = 64 / QN_WAVES;
-    const int ib_first = IBW * wave;
-    const int prot = blockIdx.x & (IBW - 1);
-    auto frag = [&](int pl, int ibk, int sK) {   // plane pl, the wave's ibk-th i-block (rotated), K step sK
-#ifdef T1_NO_WLOAD
-      const int ib = ib_first;
-#else
-      const int ib = ib_first + ((ibk + prot) & (IBW - 1));
-#endif
-      return wd[(size_t)pl * (X3_PLANE / 8) + ((ib * 4 + sK) * 64 + lane)];
-    };
-    u32x4 ring[4][3];
-#pragma unroll
-    for (int sK = 0; sK < 4; ++sK)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, 0, sK);
-    auto ib_step = [&](int ibk, auto more_t) {
-      constexpr bool more = decltype(more_t)::value;
-      const int ib = ib_first + ((ibk + prot) & (IBW - 1));
-      float *p0 = s.h1 + r0 * QN_H1S + 16 * ib + col;
-      const float m0 = p0[0], m1 = p0[QN_H1S], m2 = p0[2 * QN_H1S], m3 = p0[3 * QN_H1S];   // relu mask, read ahead
-      // four accumulators per K parity ({small, leading} x 2): reuse distance 6 in issue order (see phase2_fc1_x3)
-      f32x4 acc_b[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      f32x4 acc_c[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int sK = 0; sK < 4; ++sK) {
-        X3Frag bf;
-        bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
-        const X3Frag &a = afr[sK];
-        acc_s[0] = X3_MFMA(a.l, bf.h, acc_s[0]);
-        acc_b[0] = X3_MFMA(a.m, bf.h, acc_b[0]);
-        acc_s[1] = X3_MFMA(a.h, bf.l, acc_s[1]);
-        acc_b[1] = X3_MFMA(a.h, bf.m, acc_b[1]);
-        acc_c[0] = X3_MFMA(a.m, bf.m, acc_c[0]);
-        acc_c[1] = X3_MFMA(a.h, bf.h, acc_c[1]);
-        if (more) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, ibk + 1, sK);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
-      x3_drain(acc_c[0], acc_c[1]);
-      const f32x4 acc0 = ((acc_b[0] + acc_b[1]) + acc_c[1]) + ((acc_s[0] + acc_s[1]) + acc_c[0]);
-      p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
-      p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
-      p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
-      p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
-    };
-#pragma unroll 1
-    for (int ibk = 0; ibk < IBW - 1; ++ibk) ib_step(ibk, std::true_type{});
-    ib_step(IBW - 1, std::false_type{});
+    t1_dgrad_x3<false>(s.z, s.h1, nullptr, theta, L, lane, wave, blockIdx.x & (64 / QN_WAVES - 1));
   } else if (!(ablate & 1)) {
     const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
     f32x4 afr[8];
@@ -1459,187 +1675,11 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   }
   __syncthreads();
   T1_STAMP(5);
-  // ---- P5: LN0 backward per point in one lane (xhat / rstd kept in registers since the forward conv);
-  // channel sums (d conv-bias, d ln0-scale, d ln0-bias) in (channel = lane&15) layout. -----------
-  if (!(ablate & 2)) {
-    float ln0s[16];                                      // LayerNorm_0 scale: wave-uniform scalar loads
-#pragma unroll
-    for (int c = 0; c < 16; ++c) ln0s[c] = theta[L.off_ln0s + c];
-    const int o = lane & 15, kk = lane >> 4;
-    float *stg = s.stg + wave * 64 * QN_STG;
-    float gsc = 0.f, gbi = 0.f, gbc = 0.f;
-#pragma unroll
-    for (int mm = 0; mm < QN_SPW; ++mm) {
-      const int msamp = QN_SPW * wave + mm;
-      float *gt = s.h1 + msamp * QN_H1S;                 // d relu-input tile (masked by h1 > 0) -> dx in place
-#pragma unroll
-      for (int j = 0; j < 16; ++j) gbi += gt[(kk + 4 * j) * 16 + o];
-      const float rstd = rkeep[mm];
-      f32x4 *gptr = reinterpret_cast<f32x4 *>(gt + lane * 16);
-      float g[16];
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const f32x4 v = gptr[qd];
-        g[4 * qd] = v.x; g[4 * qd + 1] = v.y; g[4 * qd + 2] = v.z; g[4 * qd + 3] = v.w;
-      }
-      float s1 = 0.f, s2 = 0.f, dxh[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        dxh[c] = g[c] * ln0s[c];
-        s1 += dxh[c];
-        s2 = fmaf(dxh[c], xkeep[mm][c], s2);
-      }
-      s1 *= (1.0f / 16.0f);
-      s2 *= (1.0f / 16.0f);
-      f32x4 *sp = reinterpret_cast<f32x4 *>(stg + lane * QN_STG);
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        f32x4 dx, gx;
-        dx.x = rstd * (dxh[4 * qd + 0] - s1 - xkeep[mm][4 * qd + 0] * s2); gx.x = g[4 * qd + 0] * xkeep[mm][4 * qd + 0];
-        dx.y = rstd * (dxh[4 * qd + 1] - s1 - xkeep[mm][4 * qd + 1] * s2); gx.y = g[4 * qd + 1] * xkeep[mm][4 * qd + 1];
-        dx.z = rstd * (dxh[4 * qd + 2] - s1 - xkeep[mm][4 * qd + 2] * s2); gx.z = g[4 * qd + 2] * xkeep[mm][4 * qd + 2];
-        dx.w = rstd * (dxh[4 * qd + 3] - s1 - xkeep[mm][4 * qd + 3] * s2); gx.w = g[4 * qd + 3] * xkeep[mm][4 * qd + 3];
-        gptr[qd] = dx;
-        sp[qd] = gx;
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        gsc += stg[(kk + 4 * j) * QN_STG + o];
-        gbc += gt[(kk + 4 * j) * 16 + o];
-      }
-    }
-    // fold the 4 position-groups of the wave (lanes o, o+16, o+32, o+48), then the 4 waves in fixed order
-    gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
-    gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
-    gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
-    if (lane < 16) {
-      ts.red[wave * 48 + lane] = gbc;
-      ts.red[wave * 48 + 16 + lane] = gsc;
-      ts.red[wave * 48 + 32 + lane] = gbi;
-    }
-  }
-  __syncthreads();
-  if (tid < 48) {
-    float acc = 0.f;
-#pragma unroll
-    for (int w = 0; w < QN_WAVES; ++w) acc += ts.red[w * 48 + tid];
-    gp[Cfg::KW * 16 + tid] = acc;
-  }
+  // ---- P5: LN0 backward (t1_ln0_bwd; contains the barrier that ends the phase) ----
+  t1_ln0_bwd<C>(s.h1, s.stg, ts.red, theta, L, xkeep, rkeep, gp, tid, ablate);
   T1_STAMP(6);
-  // ---- P6: conv weight gradient as MFMA:  dWc[k][o] = sum_{m,pos} (bit(m,pos,k)/255) * dx[m][pos][o] ----
-  //   A[i = k row][kk] = bit(m, pos = 4s+kk, k = 16rb+i)/255,  B[kk][o] = dx[m][4s+kk][o]  (LDS, contiguous)
-  //   wave w reduces its samples 4w..4w+3; the 4 wave partials are folded in fixed order.
-  if (!(ablate & 4)) {
-    constexpr int NRB = (9 * C + 15) / 16;   // 16-row blocks of k
-    constexpr int RB = 3 * C;
-    // NRB odd (C = 4): wave = sample pair, all row blocks (no padded block);  NRB even: wave = (sample quad,
-    // half of the row blocks).  NPART wave partials per row block are folded in fixed order.
-    constexpr bool PAIR = (NRB % 2) == 1;
-    constexpr int RBW = PAIR ? NRB : NRB / 2;      // row blocks per wave
-    constexpr int SPW6 = PAIR ? 2 : 4;             // samples per wave
-    constexpr int NPART = QN_TILE / SPW6;
-    static_assert(NPART * NRB * 256 <= TrainCfg<C>::SCR, "conv-wgrad partials must fit the scratch tile");
-    const int sg = PAIR ? wave : (wave & 3), rb0 = PAIR ? 0 : (wave >> 2) * RBW;
-    const int i = lane & 15, kk = lane >> 4;
-    int kyL[RBW], shL[RBW];                  // lane constants: window row / bit of k = 16*rb + i
-#pragma unroll
-    for (int j = 0; j < RBW; ++j) {
-      const int k = 16 * (rb0 + j) + i;
-      kyL[j] = (k < 9 * C) ? k / RB : 0;
-      shL[j] = (k < 9 * C) ? k % RB : 31;    // padding rows test bit 31, which no window mask has (3C <= 30)
-    }
-    f32x4 acc[RBW];
-#pragma unroll
-    for (int j = 0; j < RBW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint32_t *wm = reinterpret_cast<uint32_t *>(s.stg + wave * 64 * QN_STG);   // staging buffer is free now
-    if constexpr (MODE == 2) {
-      f32x4 accs[RBW];
-#pragma unroll
-      for (int j = 0; j < RBW; ++j) accs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // bf16 matrix core: A = window bits (exact in bf16, written as 2.0 = 0x4000), B = dx split exactly into three
-      // bf16 planes; 2 K steps of 32 positions per sample, K slot (kq = kk, j) <-> position 32 st + 4 j + kk so that
-      // the B reads stay the conflict-free dxm[64 * (8 st + j)] of the f32 path.  3 MFMAs per (step, row block)
-      // instead of 8 at 1/4 the cycles each; 0.5/255 applied once to the accumulators.
-#pragma unroll
-      for (int mm = 0; mm < SPW6; ++mm) {
-        const int msamp = SPW6 * sg + mm;
-        window_masks<C>(s.bits + msamp * Cfg::OW, wm, lane);
-        const float *dxm = s.h1 + msamp * QN_H1S + lane;
-        float bv[16];
-        uint32_t wv[16][RBW];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {           // q = 8 st + j: all LDS reads of the sample in flight at once
-          bv[q] = dxm[64 * q];
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) wv[q][j] = wm[(4 * q + kk) * 3 + kyL[j]];
-        }
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          const float *b = bv + 8 * st;
-          const X3Frag bf = x3_split8(f32x4{b[0], b[1], b[2], b[3]}, f32x4{b[4], b[5], b[6], b[7]});
-          u32x4 af[RBW];
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) {
-            uint32_t d[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const uint32_t b0 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj][j], (uint32_t)shL[j], 1u);
-              const uint32_t b1 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj + 1][j], (uint32_t)shL[j], 1u);
-              d[jj] = ((b1 << 16) | b0) << 14;
-            }
-            af[j] = u32x4{d[0], d[1], d[2], d[3]};
-          }
-          // {h plane} and {m + l planes} accumulate separately: 2 RBW independent chains (see phase2_fc1_x3)
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) accs[j] = X3_MFMA(af[j], bf.l, accs[j]);
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.h, acc[j]);
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) accs[j] = X3_MFMA(af[j], bf.m, accs[j]);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < RBW; ++j) {
-        x3_drain(acc[j], accs[j]);
-        acc[j] = (acc[j] + accs[j]) * (0.5f / 255.0f);
-      }
-    } else
-#pragma unroll
-    for (int mm = 0; mm < SPW6; ++mm) {
-      const int msamp = SPW6 * sg + mm;
-      window_masks<C>(s.bits + msamp * Cfg::OW, wm, lane);
-      const float *dxm = s.h1 + msamp * QN_H1S + lane;   // + 64*st : element (pos = 4st+kk, o = lane&15)
-      float bv[16];
-      uint32_t wv[16][RBW];
-#pragma unroll
-      for (int st = 0; st < 16; ++st) {          // all LDS reads of the sample in flight at once
-        bv[st] = dxm[64 * st];
-#pragma unroll
-        for (int j = 0; j < RBW; ++j) wv[st][j] = wm[(4 * st + kk) * 3 + kyL[j]];
-      }
-#pragma unroll
-      for (int st = 0; st < 16; ++st) {
-#pragma unroll
-        for (int j = 0; j < RBW; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bit_times_inv255(wv[st][j], shL[j]), bv[st], acc[j], 0, 0, 0);
-      }
-    }
-    float *part = ts.scr;  // [sample group][row block][16 rows][16 o]
-#pragma unroll
-    for (int j = 0; j < RBW; ++j) {
-      float *pp = part + ((sg * NRB + rb0 + j) * 16 + 4 * kk) * 16 + i;
-      pp[0] = acc[j].x; pp[16] = acc[j].y; pp[32] = acc[j].z; pp[48] = acc[j].w;
-    }
-    __syncthreads();
-    for (int e = tid; e < Cfg::KW * 16; e += QN_THREADS) {
-      const float *pp = ts.scr + e;   // e = k*16 + o = (rb*16 + row)*16 + o
-      if (NPART == 8)
-        gp[e] = ((pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256])) +
-                ((pp[4 * NRB * 256] + pp[5 * NRB * 256]) + (pp[6 * NRB * 256] + pp[7 * NRB * 256]));
-      else
-        gp[e] = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
-    }
-  }
+  // ---- P6: conv weight gradient (t1_conv_wgrad) ----
+  t1_conv_wgrad<C, MODE>(s.h1, s.bits, reinterpret_cast<uint32_t *>(s.stg), ts.scr, gp, tid, ablate);
   T1_STAMP(7);
 }
 
