@@ -329,6 +329,35 @@ struct ConvX3 {
 
 // MFMA leaves a tile as (channel = lane&15, 4 points per lane); LayerNorm wants all 16 channels of a
 // point in one lane (no cross-lane reductions, no 16x redundant statistics).  Transpose through LDS.
+// in-place variant of the two helpers below: the staging slot of point p IS its 64-B output slot in the h1 row (stride
+// 16, no pad); the 16-B quads of a slot are XOR-swizzled with (p >> 2) & 3, which keeps the per-lane ds_read_b128 of
+// ln16 conflict-free without padding (the staged writes are 2-way conflicted b32 stores, 16 per sample)
+PQN_D void stage_tile_inplace(float *row, int p0, const f32x4 &d, float bias, int lane) {
+  const int o = lane & 15;
+  const float v[4] = {d.x + bias, d.y + bias, d.z + bias, d.w + bias};
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int p = p0 + 4 * (lane >> 4) + rr;
+    row[p * 16 + ((((o >> 2) ^ ((p >> 2) & 3))) << 2) + (o & 3)] = v[rr];
+  }
+}
+PQN_D void ln16_point_inplace(const float *row, int p, float (&xhat)[16], float &rstd) {
+  float v[16];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const f32x4 t = *reinterpret_cast<const f32x4 *>(row + p * 16 + ((qd ^ ((p >> 2) & 3)) << 2));
+    v[4 * qd] = t.x; v[4 * qd + 1] = t.y; v[4 * qd + 2] = t.z; v[4 * qd + 3] = t.w;
+  }
+  float sum = 0.f, sq = 0.f;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) { sum += v[o]; sq = fmaf(v[o], v[o], sq); }
+  const float mean = sum * (1.0f / 16.0f);
+  const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
+  rstd = rsqrt_exact(var + QN_LN_EPS);
+#pragma unroll
+  for (int o = 0; o < 16; ++o) xhat[o] = (v[o] - mean) * rstd;
+}
+
 PQN_D void stage_tile(float *stg, int p0, const f32x4 &d, float bias, int lane) {
   float *dst = stg + (p0 + 4 * (lane >> 4)) * QN_STG + (lane & 15);
   dst[0] = d.x + bias;
@@ -359,7 +388,8 @@ PQN_D void ln16_point(const float *stg, int p, float (&xhat)[16], float &rstd) {
 // phase 1: h1 tile [16 samples][64 pos * 16 ch] = relu(LN(conv)).  Wave w owns samples QN_SPW*w ...
 // KEEP: also return the normalised activations xhat[sample][channel] and 1/std of this lane's point, which the
 // training kernel holds in registers until the LN0 backward (no conv recompute there).
-template <int C, bool KEEP = false, bool X3 = false>
+// INPLACE: no staging buffer (s.stg unused) -- see stage_tile_inplace
+template <int C, bool KEEP = false, bool X3 = false, bool INPLACE = false>
 PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, float *rkeep = nullptr) {
   using Cfg = CnnCfg<C>;
   const int lane = tid & 63, wave = tid >> 6;
@@ -388,10 +418,17 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, 
   for (int mm = 0; mm < QN_SPW; ++mm) {
     const int m = QN_SPW * wave + mm;
     if (mm + 1 < QN_SPW) conv_mfma(mm + 1, d[(mm + 1) & 1]);
-#pragma unroll
-    for (int pb = 0; pb < 4; ++pb) stage_tile(stg, 16 * pb, d[mm & 1][pb], bias, lane);
     float xhat[16], rstd;
-    ln16_point(stg, lane, xhat, rstd);   // lane = position
+    if constexpr (INPLACE) {
+      float *row = s.h1 + m * QN_H1S;
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) stage_tile_inplace(row, 16 * pb, d[mm & 1][pb], bias, lane);
+      ln16_point_inplace(row, lane, xhat, rstd);
+    } else {
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) stage_tile(stg, 16 * pb, d[mm & 1][pb], bias, lane);
+      ln16_point(stg, lane, xhat, rstd);   // lane = position
+    }
     if (KEEP) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) xkeep[mm][c] = xhat[c];
@@ -561,16 +598,25 @@ PQN_HD int x3_dgrad_index(int i, int o) {         // element offset inside one d
 // cp = w>>1): 16 K steps of 32, per step ONE split of the h1 fragment (shared by the two column blocks) and 12 MFMAs;
 // weight planes streamed through a PF-step register ring (6 dwordx4 per step).  The two K halves are added through
 // LDS (the staging buffer is idle here).  Contains one __syncthreads(): every thread of the workgroup must call it.
-template <int PF = 3>
-PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int tid, int tile = -1) {
+// NT = 2 (the pair kernel): TWO 16-sample tiles share every weight fragment -- what bounds this phase is the 64 B/clk
+// vector-memory path of the CU streaming the 768 KB of planes, so a second tile costs MFMAs and one more A split but
+// no more weight traffic.  Partial sums of the two K halves are then folded IN PLACE in the z tiles (no park buffer).
+template <int PF = 3, int NT = 1>
+PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int tid, int tile = -1,
+                         const CnnSmem *s2 = nullptr) {
   static_assert(QN_WAVES == 8, "2 K halves x 4 column-block pairs");
   constexpr int NS = 16;   // K steps per wave
+  constexpr int NK = NT == 1 ? 2 : 1;   // accumulator copies per (tile, column block, kind): 8 accumulators either way
   const int lane = tid & 63, wave = tid >> 6;
   const int kh = wave & 1, cp = wave >> 1;
   if (tile < 0) tile = blockIdx.x;
   const int rot = (tile * 5 + (tile >> 4)) & (NS - 1);   // de-phase the weight stream across workgroups
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(planes);
-  const float *arow = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
+  const float *arow[NT];
+  float *zt[NT];
+  arow[0] = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
+  zt[0] = s.z;
+  if (NT == 2) { arow[NT - 1] = s2->h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4); zt[NT - 1] = s2->z; }
   auto wfrag = [&](int p, int st, int c) {   // plane p, K step st (global), column block 2cp + c
 #ifdef T1_NO_WLOAD
     return wf[(size_t)p * (X3_PLANE / 8) + ((0 * 8 + 2 * cp + c) * 64 + lane)];
@@ -578,28 +624,28 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
     return wf[(size_t)p * (X3_PLANE / 8) + ((st * 8 + 2 * cp + c) * 64 + lane)];
 #endif
   };
-  // Eight independent accumulators (column block x {small, leading terms} x 2): a dependent v_mfma_f32_16x16x32_bf16
-  // issues ~90 counter ticks after its producer, the pipe takes one per ~10 (tools/ubench/mfma_issue.hip), so the
-  // twelve MFMAs of a step are ordered with reuse distance 8 -- with the two-accumulator chains of the first version
-  // the phase was issue-bound at 71 ticks per MFMA.
-  f32x4 acc_b[2][2], acc_s[2][2];
+  // Eight independent accumulators ({small, leading terms} x column block x (K parity | tile)): a dependent
+  // v_mfma_f32_16x16x32_bf16 issues ~90 counter ticks after its producer, the pipe takes one per ~10
+  // (tools/ubench/mfma_issue.hip), so the MFMAs of a step are ordered with reuse distance 8.
+  f32x4 acc_b[NT][2][NK], acc_s[NT][2][NK];
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) { acc_b[c][k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_s[c][k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  auto step_mfma = [&](const X3Frag &af, const X3Frag &b0, const X3Frag &b1) {
-    acc_s[0][0] = X3_MFMA(af.l, b0.h, acc_s[0][0]);
-    acc_s[1][0] = X3_MFMA(af.l, b1.h, acc_s[1][0]);
-    acc_b[0][0] = X3_MFMA(af.m, b0.h, acc_b[0][0]);
-    acc_b[1][0] = X3_MFMA(af.m, b1.h, acc_b[1][0]);
-    acc_s[0][1] = X3_MFMA(af.h, b0.l, acc_s[0][1]);
-    acc_s[1][1] = X3_MFMA(af.h, b1.l, acc_s[1][1]);
-    acc_b[0][1] = X3_MFMA(af.h, b0.m, acc_b[0][1]);
-    acc_b[1][1] = X3_MFMA(af.h, b1.m, acc_b[1][1]);
-    acc_s[0][0] = X3_MFMA(af.m, b0.m, acc_s[0][0]);
-    acc_s[1][0] = X3_MFMA(af.m, b1.m, acc_s[1][0]);
-    acc_b[0][0] = X3_MFMA(af.h, b0.h, acc_b[0][0]);
-    acc_b[1][0] = X3_MFMA(af.h, b1.h, acc_b[1][0]);
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) { acc_b[t][c][k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_s[t][c][k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  auto step_mfma = [&](const X3Frag (&af)[NT], const X3Frag (&bq)[2]) {
+    // products in the order (l,h) (m,h) (h,l) (h,m) (m,m) (h,h): small and leading terms alternate
+#define FC1_PROD(AP, BP, ACC, K)                                                          \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                         \
+      _Pragma("unroll") for (int c = 0; c < 2; ++c) ACC[t][c][K] = X3_MFMA(af[t].AP, bq[c].BP, ACC[t][c][K]);
+    FC1_PROD(l, h, acc_s, 0)
+    FC1_PROD(m, h, acc_b, 0)
+    FC1_PROD(h, l, acc_s, NK - 1)
+    FC1_PROD(h, m, acc_b, NK - 1)
+    FC1_PROD(m, m, acc_s, 0)
+    FC1_PROD(h, h, acc_b, 0)
+#undef FC1_PROD
   };
   u32x4 ring[PF][2][3];
 #pragma unroll
@@ -609,81 +655,97 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, NS * kh + ((i + rot) & (NS - 1)), c);
   const int st0 = NS * kh + (rot & (NS - 1));
-  f32x4 a0n = *reinterpret_cast<const f32x4 *>(arow + 32 * st0);
-  f32x4 a1n = *reinterpret_cast<const f32x4 *>(arow + 32 * st0 + 16);
-  auto step_block = [&](int g, auto more_t) {
-    constexpr bool more = decltype(more_t)::value;
+  f32x4 a0n[NT], a1n[NT];
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const f32x4 a0 = a0n, a1 = a1n;
-      const int stn = NS * kh + ((g + i + 1 + rot) & (NS - 1));   // next step's A fragment (wraps harmlessly at the end)
-      a0n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn);
-      a1n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn + 16);
-      __builtin_amdgcn_sched_barrier(0);
-      const X3Frag af = x3_split8(a0, a1);
-      X3Frag b0, b1;
-      b0.h = ring[i][0][0]; b0.m = ring[i][0][1]; b0.l = ring[i][0][2];
-      b1.h = ring[i][1][0]; b1.m = ring[i][1][1]; b1.l = ring[i][1][2];
-      step_mfma(af, b0, b1);
-      if (more) {
-        const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
+  for (int t = 0; t < NT; ++t) {
+    a0n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + 32 * st0);
+    a1n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + 32 * st0 + 16);
+  }
+  auto one_step = [&](int g, int i, bool reload) {
+    f32x4 a0[NT], a1[NT];
+    const int stn = NS * kh + ((g + i + 1 + rot) & (NS - 1));   // next step's A fragments (wraps harmlessly at the end)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, st, c);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < NT; ++t) {
+      a0[t] = a0n[t]; a1[t] = a1n[t];
+      a0n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + 32 * stn);
+      a1n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + 32 * stn + 16);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    X3Frag af[NT], bq[2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) af[t] = x3_split8(a0[t], a1[t]);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { bq[c].h = ring[i][c][0]; bq[c].m = ring[i][c][1]; bq[c].l = ring[i][c][2]; }
+    step_mfma(af, bq);
+    if (reload) {
+      const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, st, c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
-  static_assert((NS - PF) % PF == 0 || true, "");
   int g = 0;
 #pragma unroll 1
-  for (; g + 2 * PF <= NS; g += PF) step_block(g, std::true_type{});
-  // tail: the remaining NS - g steps; reload only while a later step still needs the slot
-  for (; g < NS; g += PF) {
+  for (; g + 2 * PF <= NS; g += PF) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      if (g + i >= NS) break;
-      const f32x4 a0 = a0n, a1 = a1n;
-      const int stn = NS * kh + ((g + i + 1 + rot) & (NS - 1));
-      a0n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn);
-      a1n = *reinterpret_cast<const f32x4 *>(arow + 32 * stn + 16);
-      const X3Frag af = x3_split8(a0, a1);
-      X3Frag b0, b1;
-      b0.h = ring[i][0][0]; b0.m = ring[i][0][1]; b0.l = ring[i][0][2];
-      b1.h = ring[i][1][0]; b1.m = ring[i][1][1]; b1.l = ring[i][1][2];
-      step_mfma(af, b0, b1);
-      if (g + i + PF < NS) {
-        const int st = NS * kh + ((g + i + PF + rot) & (NS - 1));
+    for (int i = 0; i < PF; ++i) one_step(g, i, true);
+  }
+  // tail: the remaining NS - g steps; reload only while a later step still needs the slot (compile-time conditions:
+  // a reload under a run-time condition makes the compiler drain the load queue)
+  const int g0 = g;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+  for (int q = 0; q < 2 * PF; ++q) {
+    const int i = q % PF;
+    if (g0 + q < NS) one_step(g0 + q - i, i, g0 + q + PF < NS);
+  }
+  // fold the two K halves
+  f32x4 tot[NT][2];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, st, c);
+  for (int t = 0; t < NT; ++t) {
+    x3_drain(acc_b[t][0][0], acc_s[t][0][0], acc_b[t][1][0], acc_s[t][1][0]);
+    if (NK == 2) x3_drain(acc_b[t][0][NK - 1], acc_s[t][0][NK - 1], acc_b[t][1][NK - 1], acc_s[t][1][NK - 1]);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      tot[t][c] = NK == 2 ? (acc_b[t][c][0] + acc_b[t][c][NK - 1]) + (acc_s[t][c][0] + acc_s[t][c][NK - 1])
+                          : acc_b[t][c][0] + acc_s[t][c][0];
+  }
+  const int col = lane & 15, r0 = 4 * (lane >> 4);
+  if (NT == 1) {   // kh = 1 parks its partial tiles in the (idle) staging buffer, kh = 0 adds and writes z
+    f32x4 *park = reinterpret_cast<f32x4 *>(s.stg);
+    if (kh == 1) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) park[(cp * 2 + c) * 64 + lane] = tot[0][c];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 acc = tot[0][c] + park[(cp * 2 + c) * 64 + lane];
+        float *zp = s.z + r0 * QN_ZS + 16 * (2 * cp + c) + col;
+        zp[0] = acc.x; zp[QN_ZS] = acc.y; zp[2 * QN_ZS] = acc.z; zp[3 * QN_ZS] = acc.w;
       }
     }
-  }
-  // fold the two K halves: kh = 1 parks its partial tiles in the (idle) staging buffer, kh = 0 adds and writes z
-  x3_drain(acc_b[0][0], acc_s[0][0], acc_b[1][0], acc_s[1][0]);
-  x3_drain(acc_b[0][1], acc_s[0][1], acc_b[1][1], acc_s[1][1]);
-  f32x4 tot[2];
+  } else {         // in place: kh = 1 writes its partial into the z tiles, kh = 0 adds its own on top
+    if (kh == 1) {
 #pragma unroll
-  for (int c = 0; c < 2; ++c) tot[c] = (acc_b[c][0] + acc_b[c][1]) + (acc_s[c][0] + acc_s[c][1]);
-  f32x4 *park = reinterpret_cast<f32x4 *>(s.stg);
-  if (kh == 1) {
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) park[(cp * 2 + c) * 64 + lane] = tot[c];
-  }
-  __syncthreads();
-  if (kh == 0) {
-    const int col = lane & 15, r0 = 4 * (lane >> 4);
+        for (int c = 0; c < 2; ++c) {
+          float *zp = zt[t] + r0 * QN_ZS + 16 * (2 * cp + c) + col;
+          zp[0] = tot[t][c].x; zp[QN_ZS] = tot[t][c].y; zp[2 * QN_ZS] = tot[t][c].z; zp[3 * QN_ZS] = tot[t][c].w;
+        }
+    }
+    __syncthreads();
+    if (kh == 0) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const f32x4 acc = tot[c] + park[(cp * 2 + c) * 64 + lane];
-      float *zp = s.z + r0 * QN_ZS + 16 * (2 * cp + c) + col;
-      zp[0] = acc.x;
-      zp[QN_ZS] = acc.y;
-      zp[2 * QN_ZS] = acc.z;
-      zp[3 * QN_ZS] = acc.w;
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float *zp = zt[t] + r0 * QN_ZS + 16 * (2 * cp + c) + col;
+          zp[0] += tot[t][c].x; zp[QN_ZS] += tot[t][c].y; zp[2 * QN_ZS] += tot[t][c].z; zp[3 * QN_ZS] += tot[t][c].w;
+        }
     }
   }
 }
@@ -1223,12 +1285,14 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
       const int ib = ib_first + ((ibk + prot) & (IBW - 1));
       float *p0 = out + r0 * QN_H1S + 16 * ib + col;
       float m0, m1, m2, m3;   // relu mask (h1 > 0), read ahead of the MFMAs
-      if (MASKBITS) {         // packed by t1_pack_relu_mask: bit (i & 31) of word [m][i >> 5]
-        const int wsel = ib >> 1, bsel = 16 * (ib & 1) + col;
-        m0 = (float)((mask[(r0 + 0) * 32 + wsel] >> bsel) & 1u);
-        m1 = (float)((mask[(r0 + 1) * 32 + wsel] >> bsel) & 1u);
-        m2 = (float)((mask[(r0 + 2) * 32 + wsel] >> bsel) & 1u);
-        m3 = (float)((mask[(r0 + 3) * 32 + wsel] >> bsel) & 1u);
+      if (MASKBITS) {         // packed by the pair kernel's h1^T loop: 64-bit word [16-feature block ib][sample & 3],
+                              // bit (feature & 15) * 4 + (sample >> 2)
+        const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(mask) + ib * 4;
+        const int bsel = col * 4 + (lane >> 4);
+        m0 = (float)((mw[0] >> bsel) & 1ull);
+        m1 = (float)((mw[1] >> bsel) & 1ull);
+        m2 = (float)((mw[2] >> bsel) & 1ull);
+        m3 = (float)((mw[3] >> bsel) & 1ull);
       } else {
         m0 = p0[0]; m1 = p0[QN_H1S]; m2 = p0[2 * QN_H1S]; m3 = p0[3 * QN_H1S];
       }
@@ -1471,7 +1535,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     int ablate, unsigned long long *__restrict__ stamps, pqn_seeds_t sd, float dz_scale) {
   using Cfg = CnnCfg<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int seed = blockIdx.y;           // seed slice of the stacked buffers (all strides 0 for a single seed)
+  const int seed = blockIdx.y + sd.seed_base;   // seed slice of the stacked buffers (all strides 0 for a single seed)
   idx += seed * sd.idx_stride;
   theta += seed * sd.theta_stride;
   w1b += seed * sd.w1b_stride;
@@ -1681,6 +1745,173 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   // ---- P6: conv weight gradient (t1_conv_wgrad) ----
   t1_conv_wgrad<C, MODE>(s.h1, s.bits, reinterpret_cast<uint32_t *>(s.stg), ts.scr, gp, tid, ablate);
   T1_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------
+// T1, pair form (bf16x3 mode): one workgroup runs TWO 16-sample tiles and shares the fc1 weight stream between them
+// (phase2_fc1_x3<.., 2>): the forward fc1 of a tile is bounded by the CU's 64 B/clk vector-memory path moving 768 KB of
+// weight planes, whichever tile they are for.  Everything else is the single-tile code, run once per tile, with the
+// LDS laid out so that both h1 tiles are resident through fc1:
+//   [h1 A 66 KB][h1 B 66 KB][z A][z B][conv / head parameters][obs bits A, B][relu mask bits of B][act/tgt/gs x2][red]
+//   - conv staging is in place in the destination rows (stage_tile_inplace), the window masks live in the z tiles;
+//   - after fc1 and the h1^T stores, tile B's h1 is only needed as relu mask for its dgrad: it is packed to 2 KB of
+//     bits and the 66 KB region becomes the scratch of the heads and of both backward passes;
+//   - backward of A runs in place on h1 A; backward of B writes its dgrad into the (then free) h1 A region.
+// ---------------------------------------------------------------------------
+template <int C>
+struct PairSmem {
+  using Cfg = CnnCfg<C>;
+  static constexpr int WCN = (Cfg::KW * 16 + 48 + 3) & ~3;
+  static constexpr int BITN = QN_TILE * Cfg::OW + 4;
+  static constexpr size_t BYTES = sizeof(float) * (2 * QN_TILE * QN_H1S + 2 * QN_TILE * QN_ZS + WCN + QN_HP_FLOATS) +
+                                  sizeof(uint32_t) * (2 * BITN + QN_TILE * 32) + sizeof(float) * (6 * QN_TILE + QN_WAVES * 48);
+  // the freed h1 B region must hold the head / conv-wgrad scratch followed by the window masks, and the LN0-bwd staging
+  static_assert(TrainCfg<C>::SCR + QN_WAVES * 192 <= QN_TILE * QN_H1S && QN_WAVES * 64 * QN_STG <= QN_TILE * QN_H1S, "scratch must fit h1 B");
+};
+
+template <int C>
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
+    int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
+    const float *__restrict__ target, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
+    float *__restrict__ dzT, float *__restrict__ h1T, float *__restrict__ gpart, int ablate, pqn_seeds_t sd, float dz_scale,
+    unsigned long long *__restrict__ stamps) {
+  using Cfg = CnnCfg<C>;
+  using PS = PairSmem<C>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int seed = blockIdx.y + sd.seed_base;
+  idx += seed * sd.idx_stride;
+  theta += seed * sd.theta_stride;
+  dzT += seed * sd.ws_stride;
+  h1T += seed * sd.ws_stride;
+  gpart += seed * sd.ws_stride;
+  auto row_of = [&](int64_t key) -> int64_t {
+    const uint32_t j = (uint32_t)(key & sd.idx_mask);
+    if (sd.n_env_total == sd.n_env) return (int64_t)j;
+    const uint32_t t = j / (uint32_t)sd.n_env;
+    return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
+  };
+  // ---- LDS ----
+  float *h1A = reinterpret_cast<float *>(smem_raw), *h1B = h1A + QN_TILE * QN_H1S;
+  float *zA = h1B + QN_TILE * QN_H1S, *zB = zA + QN_TILE * QN_ZS;
+  float *wc = zB + QN_TILE * QN_ZS, *hp = wc + PS::WCN;
+  uint32_t *bitsA = reinterpret_cast<uint32_t *>(hp + QN_HP_FLOATS), *bitsB = bitsA + PS::BITN, *maskB = bitsB + PS::BITN;
+  float *small = reinterpret_cast<float *>(maskB + QN_TILE * 32);   // gs[2][16] | tgt[2][16] | act[2][16] | red[8][48]
+  float *red = small + 6 * QN_TILE;
+  float *scr = h1B;                                                 // once h1 B has been packed to maskB
+  uint32_t *wmS = reinterpret_cast<uint32_t *>(h1B + TrainCfg<C>::SCR);
+  CnnSmem sT[2];
+  TrainSmem tsT[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    sT[t].h1 = t ? h1B : h1A; sT[t].z = t ? zB : zA; sT[t].wc = wc; sT[t].stg = h1B; sT[t].hp = hp; sT[t].bits = t ? bitsB : bitsA;
+    tsT[t].n = sT[t]; tsT[t].scr = scr; tsT[t].gs = small + t * QN_TILE; tsT[t].tgt = small + (2 + t) * QN_TILE;
+    tsT[t].act = reinterpret_cast<int *>(small + (4 + t) * QN_TILE); tsT[t].red = red;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rec = small_record_floats(C, L.a);
+  const int tile0 = 2 * blockIdx.x;
+  const int b0T[2] = {tile0 * QN_TILE, (tile0 + 1) * QN_TILE};
+  float *gpT[2] = {gpart + (size_t)tile0 * rec, gpart + (size_t)(tile0 + 1) * rec};
+
+  T1_STAMP(0);
+  // ---- P0: gather the inputs of both tiles (same scheme as the single-tile kernel) ----
+  constexpr int NBI = (QN_TILE * Cfg::OW + QN_THREADS - 1) / QN_THREADS;
+  int64_t ix[2][NBI];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int k = 0; k < NBI; ++k) {
+      const int i = tid + k * QN_THREADS, le = i / Cfg::OW;
+      ix[t][k] = (i < QN_TILE * Cfg::OW && b0T[t] + le < nb) ? row_of(idx[b0T[t] + le]) : -1;
+    }
+  const int b32 = b0T[0] + tid;                                     // tid < 32: sample tid of the pair
+  const int64_t src32 = (tid < 2 * QN_TILE && b32 < nb) ? row_of(idx[b32]) : -1;
+  TileParams<C> tp;
+  tp.load(theta, L, tid);
+  uint32_t gb[2][NBI];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int k = 0; k < NBI; ++k) {
+      const int i = tid + k * QN_THREADS;
+      gb[t][k] = (i < QN_TILE * Cfg::OW && ix[t][k] >= 0) ? obs_bits[(size_t)ix[t][k] * Cfg::OW + (i % Cfg::OW)] : 0u;
+    }
+  int act_g = 0;
+  float tgt_g = 0.0f;
+  if (src32 >= 0) {
+    act_g = action[src32];
+    tgt_g = target[src32];
+  }
+  tp.store(sT[0], L, tid);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int k = 0; k < NBI; ++k) {
+      const int i = tid + k * QN_THREADS;
+      if (i < QN_TILE * Cfg::OW) sT[t].bits[i] = gb[t][k];
+    }
+    if (tid < 4) sT[t].bits[QN_TILE * Cfg::OW + tid] = 0u;
+  }
+  __syncthreads();
+  T1_STAMP(1);
+  // ---- forward: conv of both tiles, then fc1 of both against one pass over the weight planes ----
+  float xkA[QN_SPW][16], rkA[QN_SPW], xkB[QN_SPW][16], rkB[QN_SPW];
+  phase1_conv<C, true, true, true>(sT[0], tid, xkA, rkA);
+  T1_STAMP(2);
+  phase1_conv<C, true, true, true>(sT[1], tid, xkB, rkB);
+  __syncthreads();
+  T1_STAMP(3);
+  phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, blockIdx.x, &sT[1]);
+  T1_STAMP(4);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {   // h1^T for T2, slab-major (h1s_index); tile B also leaves its relu mask as bits
+    for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
+      const int i = e >> 2, mq = e & 3;
+      const float *src = sT[t].h1 + (4 * mq) * QN_H1S + i;
+      const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
+      *reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0T[t] + 4 * mq)) = v;
+      if (t == 1) {
+        // lane = (feature i & 15) * 4 + mq, sample 4 mq + rr: one 64-bit ballot per rr and 16-feature block
+        const unsigned long long bx = __ballot(v.x > 0.0f), by = __ballot(v.y > 0.0f), bz = __ballot(v.z > 0.0f), bw = __ballot(v.w > 0.0f);
+        if (lane == 0) {
+          unsigned long long *mw = reinterpret_cast<unsigned long long *>(maskB) + (i >> 4) * 4;
+          mw[0] = bx; mw[1] = by; mw[2] = bz; mw[3] = bw;
+        }
+      }
+    }
+  }
+  if (tid < 2 * QN_TILE) {
+    tsT[0].act[tid] = act_g;     // act[2][16] / tgt[2][16] are contiguous: sample tid of the pair
+    tsT[0].tgt[tid] = tgt_g;
+  }
+  __syncthreads();   // z tiles complete; h1 B is free from here on (scratch)
+  T1_STAMP(5);
+  // ---- heads ----
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    switch (L.a) {
+      case 3: train_head<C, 3>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale); break;
+      case 4: train_head<C, 4>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale); break;
+      case 6: train_head<C, 6>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale); break;
+      default: train_head<C, 0>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale); break;
+    }
+  }
+  T1_STAMP(6);
+  // ---- backward of A in place on h1 A, then of B into the same region ----
+  const int prot = blockIdx.x & (64 / QN_WAVES - 1);
+  t1_dgrad_x3<false>(zA, h1A, nullptr, theta, L, lane, wave, prot);
+  __syncthreads();
+  T1_STAMP(7);
+  t1_ln0_bwd<C>(h1A, h1B, red, theta, L, xkA, rkA, gpT[0], tid, ablate);
+  t1_conv_wgrad<C, 2>(h1A, bitsA, wmS, scr, gpT[0], tid, ablate);
+  __syncthreads();   // dx of A and the scratch fully consumed
+  T1_STAMP(8);
+  t1_dgrad_x3<true>(zB, h1A, maskB, theta, L, lane, wave, prot);
+  __syncthreads();
+  T1_STAMP(9);
+  t1_ln0_bwd<C>(h1A, h1B, red, theta, L, xkB, rkB, gpT[1], tid, ablate);
+  t1_conv_wgrad<C, 2>(h1A, bitsB, wmS, scr, gpT[1], tid, ablate);
+  T1_STAMP(10);
 }
 
 // ---------------------------------------------------------------------------
@@ -2341,6 +2572,19 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // Seed groups: the launches can be cut into T1 -> T2 pairs over groups of seeds (PQN_SEED_GROUP, profiling) so that
   // the h1 a group hands from T1 to T2 (16 MB per seed at a 4096-sample minibatch) stays inside the 256 MB Infinity
   // Cache.  Measured, it does not pay (see pqn_cnn_seed_group): the default is one group.
+  // pair form of T1 (two tiles per workgroup, shared fc1 weight stream): bf16x3 mode, when its LDS layout fits and the
+  // minibatch has an even number of tiles; PQN_T1_PAIR=0 keeps the single-tile kernel (profiling / A-B runs)
+  static const int pair_env = getenv("PQN_T1_PAIR") ? atoi(getenv("PQN_T1_PAIR")) : 1;
+  const bool use_pair = pair_env && L.matmul_f16 == 2 && PairSmem<C>::BYTES <= 160 * 1024 && ntiles >= 2 && (ntiles % 2) == 0 &&
+                        true;
+  if (use_pair) {
+    static bool pair_attr = false;
+    if (!pair_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem<C>::BYTES);
+      pair_attr = true;
+    }
+  }
   const int gs_max = pqn_cnn_seed_group(L.matmul_f16, sd.nseeds);
   for (int s0 = 0; s0 < sd.nseeds; s0 += gs_max) {
     const int gs = min(gs_max, sd.nseeds - s0);
@@ -2349,6 +2593,10 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     const long long wo = (long long)s0 * sd.ws_stride;
     const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
     if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
+    if (use_pair)
+      hipLaunchKernelGGL(qnet_cnn_train_pair_kernel<C>, dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
+                         action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
+    else
     hipLaunchKernelGGL(t1, dim3(ntiles, gs), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
                        target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sg, dz_scale);
     if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);

@@ -27,7 +27,12 @@ if os.environ.get("PQN_T1_STAMPS"):
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
     _lib.check(_lib.load().pqn_debug_t1_stamps(buf), "stamps")
-    names = ["start", "inputs", "conv(phase1)", "h1T+fc1", "head+bwd+dzT", "dgrad", "P5 ln0 bwd", "P6 conv wgrad"]
+    pair = buf[10] != 0 and os.environ.get("PQN_T1_PAIR", "1") != "0" and int(os.environ.get("PQN_MODE", "0")) == 2
+    if pair:   # qnet_cnn_train_pair_kernel: two tiles per workgroup
+        names = ["start", "inputs", "conv A", "conv B", "fc1 pair", "h1T x2 + mask", "heads A,B", "dgrad A", "P5+P6 A", "dgrad B", "P5+P6 B"]
+    else:
+        names = ["start", "inputs", "conv(phase1)", "h1T+fc1", "head+bwd+dzT", "dgrad", "P5 ln0 bwd", "P6 conv wgrad"]
+    n = len(names)
     for wg in range(4):
-        s = [buf[wg * 16 + k] for k in range(8)]
-        print("WG%d cycles:" % wg, " ".join("%s=%d" % (names[k + 1], s[k + 1] - s[k]) for k in range(7)), "total=%d" % (s[7] - s[0]))
+        s = [buf[wg * 16 + k] for k in range(n)]
+        print("WG%d cycles:" % wg, " ".join("%s=%d" % (names[k + 1], s[k + 1] - s[k]) for k in range(n - 1)), "total=%d" % (s[n - 1] - s[0]))
