@@ -883,7 +883,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_fwd_kernel(int n, const u
   if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;  // b[w+1] guard word
   __syncthreads();
   if (ablate != 1 && ablate != 6 && ablate != 7) {
-    if (L.matmul_f16 == 2) phase1_conv<C, false, true>(s, tid);
+    if (L.matmul_f16 == 2) phase1_conv<C, false, true, true>(s, tid);
     else phase1_conv<C>(s, tid);
   }
   __syncthreads();
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
 #pragma unroll 1
   for (int t = 0; t <= t_len; ++t) {
     __syncthreads();   // s.bits holds obs_t of the tile (and every previous reader of the tiles is done)
-    if (MODE == 2) phase1_conv<C, false, true>(s, tid);
+    if (MODE == 2) phase1_conv<C, false, true, true>(s, tid);
     else phase1_conv<C>(s, tid);
     __syncthreads();
     if (MODE == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid, (e0 - e_off) / QN_TILE);
@@ -1594,7 +1594,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   T1_STAMP(1);
   // ---- P1..P3: forward ---------------------------------------------------------------------
   float xkeep[QN_SPW][16], rkeep[QN_SPW];   // LN0 xhat / rstd of (sample QN_SPW*wave + mm, position lane): live until P5
-  phase1_conv<C, true, MODE == 2>(s, tid, xkeep, rkeep);
+  phase1_conv<C, true, MODE == 2, MODE == 2>(s, tid, xkeep, rkeep);
   __syncthreads();
   T1_STAMP(2);
   if (MODE == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
