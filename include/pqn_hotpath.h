@@ -318,6 +318,12 @@ int pqn_cnn_rollout_seeds(int env_id, const pqn_cnn_layout_t *layout, int32_t nu
 /* Profiling aid (PQN_T1_STAMPS=1): s_memtime stamps at the phase boundaries of qnet_cnn_train_kernel for
  * workgroups 0..3; 16 slots per workgroup.  Not part of the hot path. */
 int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries */);
+/* The same for the bf16x3 fc1 weight-gradient kernel (workgroup 0): [0] start, [1] operands resident, [2..9] the eight
+ * steps of the first row block, [10..25] the row blocks. */
+int pqn_debug_t2_stamps(unsigned long long *out /* host, 32 entries */);
+/* Seeds covered by ONE launch of the training kernel (and therefore by one pqn_prof_read sample) when `nseeds` seeds
+ * are batched: nseeds unless the profiling override PQN_SEED_GROUP cuts the launches into T1 -> T2 pairs per group. */
+int pqn_cnn_seed_group(int matmul_mode, int nseeds);
 
 /* ---- fused MLP Q-network (QNetwork of pqn_gymnax.py:29-58, layer_norm, NORM_INPUT=False) ----------- */
 /* Parameter buffer in flax order with 16-B aligned segments and natural (in,out) kernels:

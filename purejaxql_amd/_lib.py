@@ -73,6 +73,8 @@ SIGNATURES = {
     "pqn_cnn_rollout": (c_int, [c_int, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "pqn_debug_t1_stamps": (c_int, [c_void_p]),
+    "pqn_debug_t2_stamps": (c_int, [c_void_p]),
+    "pqn_cnn_seed_group": (c_int, [c_int, c_int]),
     "pqn_mlp_layout": (c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pqn_mlp_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64,
                                 c_void_p]),
