@@ -157,7 +157,11 @@ def t1_roofline(avg_s, launches, mb_samples, seeds, matmul):
                         + (f", x{seeds // ps} for the {seeds} seeds of this launch" if seeds != ps else "")
                         + "; not measured in this run")
                 break
-    out = {"kernel": f"qnet_cnn_train_kernel<4> (fwd + bwd of one {mb_samples}-sample minibatch of each of {seeds} seed(s) per launch)",
+    # bf16x3 mode runs the pair form of the kernel (two 16-sample tiles per workgroup) whenever that still gives every
+    # CU a workgroup -- the condition of launch_train in csrc/pqn_qnet.hip
+    pair = matmul == "bf16x3" and (mb_samples // 16) % 2 == 0 and (mb_samples // 32) * seeds >= 256
+    kname = "qnet_cnn_train_pair_kernel<4>" if pair else "qnet_cnn_train_kernel<4>"
+    out = {"kernel": f"{kname} (fwd + bwd of one {mb_samples}-sample minibatch of each of {seeds} seed(s) per launch)",
            "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
            "avg_launch_us": avg_s * 1e6, "launches_timed": launches,

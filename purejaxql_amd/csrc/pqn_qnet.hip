@@ -2575,8 +2575,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // pair form of T1 (two tiles per workgroup, shared fc1 weight stream): bf16x3 mode, when its LDS layout fits and the
   // minibatch has an even number of tiles; PQN_T1_PAIR=0 keeps the single-tile kernel (profiling / A-B runs)
   static const int pair_env = getenv("PQN_T1_PAIR") ? atoi(getenv("PQN_T1_PAIR")) : 1;
+  // (and the launch still has a workgroup for every CU: a single 4096-sample seed is 128 pairs, half a chip)
   const bool use_pair = pair_env && L.matmul_f16 == 2 && PairSmem<C>::BYTES <= 160 * 1024 && ntiles >= 2 && (ntiles % 2) == 0 &&
-                        true;
+                        (ntiles / 2) * sd.nseeds >= 256;
   if (use_pair) {
     static bool pair_attr = false;
     if (!pair_attr) {

@@ -1,5 +1,6 @@
-"""The bench line contract (driver-facing): the committed round artefact profiles/r01_v11_bench.json -- the JSON line
-bench.py printed on an MI355X -- carries every field the contract names, with consistent arithmetic."""
+"""The bench line contract (driver-facing): the committed round artefact profiles/r02_v3_bench.json -- the JSON line
+bench.py printed on an MI355X at the end of round 2 -- carries every field the contract names, with consistent
+arithmetic."""
 import json
 import os
 
@@ -7,25 +8,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_v11_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_v3_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"].split(",")[0] == base["metric"].split(",")[0] and "4096 envs" in d["metric"]
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    # the arithmetic type is f32 throughout; the label says how the f32 products are evaluated
+    assert d["dtype"].startswith("f32") and "bf16x3" in d["dtype"] and "f32 accumulate" in d["dtype"]
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    c = d["config"]
+    assert c["seeds_per_gpu"] == 16 and c["env_steps_per_step"] == 16 * 4096 * 32 and c["matmul_dtype"] == "bf16x3"
     # value = env-steps of K updates / time
-    assert abs(d["value"] - 4096 * 32 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert abs(d["value"] - c["env_steps_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) <= 1e-6 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"] > 0
-    c = d["cpu_baseline"]
+    assert r["flop_per_launch"] == 674048 * 4096 * 16
+    assert r["traffic"] is None or (r["traffic"] > 0 and "from file" in r["traffic_source"])
+    assert 0.0 < r["bf16_pipe"]["frac"] < 1.0
+    cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
-    # extras never replace the headline
-    assert d["multi_seed"]["value"] > d["value"] and d["mixed_precision"]["value"] > d["value"]
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    # the extras report the other operand modes and the single-seed run beside the headline, never instead of it
+    assert d["matmul_modes"]["f32"]["value"] < d["value"] < d["matmul_modes"]["f16"]["value"]
+    assert d["single_seed"]["seeds_per_gpu"] == 1 and d["single_seed"]["value"] < d["value"]
