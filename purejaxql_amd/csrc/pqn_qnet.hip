@@ -606,7 +606,10 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
                          const CnnSmem *s2 = nullptr) {
   static_assert(QN_WAVES == 8, "2 K halves x 4 column-block pairs");
   constexpr int NS = 16;   // K steps per wave
-  constexpr int NK = NT == 1 ? 2 : 1;   // accumulator copies per (tile, column block, kind): 8 accumulators either way
+  // accumulator copies per (tile, column block, kind).  ONE for both forms: the single-tile and the pair kernel must sum
+  // in the same order, because a seed trained alone (single-tile kernel) and the same seed inside a 16-seed launch (pair
+  // kernel) are required to agree bit for bit.  Reuse distance is then 4 MFMAs (single) / 8 (pair).
+  constexpr int NK = 1;
   const int lane = tid & 63, wave = tid >> 6;
   const int kh = wave & 1, cp = wave >> 1;
   if (tile < 0) tile = blockIdx.x;
@@ -624,9 +627,10 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
     return wf[(size_t)p * (X3_PLANE / 8) + ((st * 8 + 2 * cp + c) * 64 + lane)];
 #endif
   };
-  // Eight independent accumulators ({small, leading terms} x column block x (K parity | tile)): a dependent
-  // v_mfma_f32_16x16x32_bf16 issues ~90 counter ticks after its producer, the pipe takes one per ~10
-  // (tools/ubench/mfma_issue.hip), so the MFMAs of a step are ordered with reuse distance 8.
+  // Independent accumulators {small, leading terms} x column block x tile: a dependent v_mfma_f32_16x16x32_bf16 issues
+  // ~90 counter ticks after its producer and the pipe takes one per ~10 (tools/ubench/mfma_issue.hip); the MFMAs of a
+  // step are ordered round-robin over them.  (The phase is bound by the weight stream, not by issue: 4 vs 8
+  // accumulators made no measurable difference.)
   f32x4 acc_b[NT][2][NK], acc_s[NT][2][NK];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
