@@ -2581,7 +2581,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   static const int pair_env = getenv("PQN_T1_PAIR") ? atoi(getenv("PQN_T1_PAIR")) : 1;
   // (and the launch still has a workgroup for every CU: a single 4096-sample seed is 128 pairs, half a chip)
   const bool use_pair = pair_env && L.matmul_f16 == 2 && PairSmem<C>::BYTES <= 160 * 1024 && ntiles >= 2 && (ntiles % 2) == 0 &&
-                        (ntiles / 2) * sd.nseeds >= 256;
+                        ((ntiles / 2) * sd.nseeds >= 256 || pair_env == 2);   // PQN_T1_PAIR=2: pair form at any size (tests)
   if (use_pair) {
     static bool pair_attr = false;
     if (!pair_attr) {
