@@ -1106,6 +1106,15 @@ constexpr size_t train_smem_bytes() {
   return cnn_smem_bytes<C>() + sizeof(float) * (TrainCfg<C>::SCR + 3 * QN_TILE + QN_WAVES * 48 + 4);
 }
 
+// dz as bf16 planes for the position-parallel backward (element offsets in bf16 units inside one plane set):
+//   dzA[plane][sample][sK][kq][8]: the 8 values are outputs 32 sK + 16 (j >> 2) + 4 kq + (j & 3) -- one dwordx4 per lane is
+//       the A fragment (row = sample) of a K = 32 dgrad step, in the K-slot order of the optimizer's dgrad planes;
+//   dzB[tile][cb][plane][lane][4], lane = kq * 16 + (o & 15): samples 4 kq .. 4 kq + 3 of the tile for output 16 cb + (o & 15)
+//       -- one dwordx2 per lane is the B fragment (column = output) of a K = 16 step of dW1 = h1^T dz.
+// Plane stride: nb * 128 (dzA), 256 inside a (tile, cb) block (dzB).  dzA occupies 3 nb 128 elements, dzB follows it.
+PQN_HD size_t dz_planes_a(int nb, int sample, int sK, int kq) { (void)nb; return ((size_t)sample * 16 + sK * 4 + kq) * 8; }
+PQN_HD size_t dz_planes_b(int tile, int cb, int lane) { return (((size_t)tile * 8 + cb) * 3 * 64 + lane) * 4; }
+
 // all-reduce sum over each aligned group of 32 lanes: DPP butterfly inside the 16-lane rows, then one
 // ds_swizzle (xor 16) across the two rows
 PQN_D float group32_sum(float v) {
@@ -1122,7 +1131,8 @@ PQN_D float group32_sum(float v) {
 // NA: compile-time action count (0 = run-time L.a, up to QN_MAXA).
 template <int C, int NA>
 PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layout_t &L, int tid, int nb, int b0,
-                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT, float dz_scale) {
+                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT, float dz_scale,
+                      unsigned short *__restrict__ dzp = nullptr) {
   constexpr int NAQ = NA ? NA : QN_MAXA;
   const int na = NA ? NA : L.a;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1232,6 +1242,34 @@ PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layou
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = (_Float16)(s.z[(8 * hh + r) * QN_ZS + o] * dz_scale);
       *reinterpret_cast<f16x8 *>(dzP + (size_t)o * QN_TILE + 8 * hh) = v;
+    }
+  } else if (dzp) {
+    // position-parallel backward (qnet_cnn_bwd_pos_kernel): dz leaves as bf16 planes, already split, in the two MFMA
+    // operand orders that kernel reads -- dzA (A of the dgrad, sample rows) and dzB (B of the dW1 product, 4-sample
+    // K groups); see dz_planes_a / dz_planes_b
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    {
+      const int m = tid >> 5, q = tid & 31;                 // sample, (sK, kq, h) = 4 consecutive outputs
+      const int sK = q >> 3, kq = (q >> 1) & 3, h = q & 1;
+      const float *zr = s.z + m * QN_ZS + 32 * sK + 16 * h + 4 * kq;
+      unsigned hh[2], mm[2], ll[2];
+      x3_split2(zr[0], zr[1], hh[0], mm[0], ll[0]);
+      x3_split2(zr[2], zr[3], hh[1], mm[1], ll[1]);
+      const size_t e = dz_planes_a(nb, b0 + m, sK, kq) + 4 * h;
+      *reinterpret_cast<u2 *>(dzp + e) = u2{hh[0], hh[1]};
+      *reinterpret_cast<u2 *>(dzp + (size_t)nb * QN_HID + e) = u2{mm[0], mm[1]};
+      *reinterpret_cast<u2 *>(dzp + 2 * (size_t)nb * QN_HID + e) = u2{ll[0], ll[1]};
+    }
+    {
+      const int o = tid >> 2, kq = tid & 3;                 // output, samples 4 kq .. 4 kq + 3 of the tile
+      const float *zc = s.z + (4 * kq) * QN_ZS + o;
+      unsigned hh[2], mm[2], ll[2];
+      x3_split2(zc[0], zc[QN_ZS], hh[0], mm[0], ll[0]);
+      x3_split2(zc[2 * QN_ZS], zc[3 * QN_ZS], hh[1], mm[1], ll[1]);
+      unsigned short *pb = dzp + 3 * (size_t)nb * QN_HID + dz_planes_b(b0 / QN_TILE, o >> 4, kq * 16 + (o & 15));
+      *reinterpret_cast<u2 *>(pb) = u2{hh[0], hh[1]};
+      *reinterpret_cast<u2 *>(pb + 256) = u2{mm[0], mm[1]};
+      *reinterpret_cast<u2 *>(pb + 512) = u2{ll[0], ll[1]};
     }
   } else
   for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
@@ -1773,7 +1811,9 @@ struct PairSmem {
   static_assert(TrainCfg<C>::SCR + QN_WAVES * 192 <= QN_TILE * QN_H1S && QN_WAVES * 64 * QN_STG <= QN_TILE * QN_H1S, "scratch must fit h1 B");
 };
 
-template <int C>
+// FWD_ONLY: the forward half for the position-parallel backward -- conv, fc1, heads; dz leaves as bf16 planes in the
+// (then unused) h1^T region; no h1^T, no relu masks, no LN0 state kept, no backward below the heads.
+template <int C, bool FWD_ONLY>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
@@ -1860,13 +1900,15 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   T1_STAMP(1);
   // ---- forward: conv of both tiles, then fc1 of both against one pass over the weight planes ----
   float xkA[QN_SPW][16], rkA[QN_SPW], xkB[QN_SPW][16], rkB[QN_SPW];
-  phase1_conv<C, true, true, true>(sT[0], tid, xkA, rkA);
+  phase1_conv<C, !FWD_ONLY, true, true>(sT[0], tid, xkA, rkA);
   T1_STAMP(2);
-  phase1_conv<C, true, true, true>(sT[1], tid, xkB, rkB);
+  phase1_conv<C, !FWD_ONLY, true, true>(sT[1], tid, xkB, rkB);
   __syncthreads();
   T1_STAMP(3);
-  phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, blockIdx.x, &sT[1]);
+  if (FWD_ONLY) phase2_fc1_x3<3, 2>(sT[0], theta + L.off_w1h, tid, blockIdx.x, &sT[1]);   // no LN0 state alive: room for a 3-deep ring
+  else phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, blockIdx.x, &sT[1]);
   T1_STAMP(4);
+  if (!FWD_ONLY)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {   // h1^T for T2, slab-major (h1s_index); tile B also leaves its relu mask as bits
     for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
@@ -1894,13 +1936,14 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     switch (L.a) {
-      case 3: train_head<C, 3>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale); break;
-      case 4: train_head<C, 4>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale); break;
-      case 6: train_head<C, 6>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale); break;
-      default: train_head<C, 0>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale); break;
+      case 3: train_head<C, 3>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale, FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr); break;
+      case 4: train_head<C, 4>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale, FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr); break;
+      case 6: train_head<C, 6>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale, FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr); break;
+      default: train_head<C, 0>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale, FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr); break;
     }
   }
   T1_STAMP(6);
+  if (FWD_ONLY) return;
   // ---- backward of A in place on h1 A, then of B into the same region ----
   const int prot = blockIdx.x & (64 / QN_WAVES - 1);
   t1_dgrad_x3<false>(zA, h1A, nullptr, theta, L, lane, wave, prot);
@@ -1916,6 +1959,275 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   t1_ln0_bwd<C>(h1A, h1B, red, theta, L, xkB, rkB, gpT[1], tid, ablate);
   t1_conv_wgrad<C, 2>(h1A, bitsB, wmS, scr, gpT[1], tid, ablate);
   T1_STAMP(10);
+}
+
+// ---------------------------------------------------------------------------
+// Position-parallel backward (bf16x3 mode, many seeds per launch).  Everything below fc1 is local to a conv position:
+// h1[m][16 pos + ch] depends only on sample m's 3x3 window at pos, LayerNorm_0 is per point, and the dgrad columns /
+// dW1 rows of a position need only that position's 16 rows of W1.  Workgroup = (seed, group of 4 positions) for ALL
+// samples of the minibatch; wave w = (position 4 pg + (w & 3), sample-tile parity w >> 2).  Per 16-sample tile a wave
+//   a. rebuilds the window masks of its position for the 16 samples (gathered observation bits),
+//   b. recomputes conv + LN0 (D layout: lane = channel, 4 samples per lane; channel sums are DPP row reductions),
+//   c. dgrad  dh1 = dz W1p^T  (A = dz planes from the forward kernel, B = the position's 48 resident plane fragments),
+//   d. relu mask, LN0 backward, running channel sums,
+//   e. conv weight gradient  dWc += bits^T dx   (K = 16 samples, v_mfma_f32_16x16x16_bf16; dx is already in B layout),
+//   f. dW1p += h1^T dz  (h1 is already in A layout; B = dz planes in 4-sample K groups), accumulated in registers over
+//      the whole minibatch: no split-K partial tiles, no h1^T hand-over, no weight-plane stream.
+// The two parities of a position are folded through LDS at the end; conv / LN0 partials of the 8 waves in fixed order.
+// ---------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+PQN_D f32x4 x3_mfma16_tied(const u32x2 &a, const u32x2 &b, f32x4 c) {   // K = 16 form, same rules as x3_mfma_tied
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+}
+struct X3Frag16 {
+  u32x2 h, m, l;
+};
+PQN_D X3Frag16 x3_split4(float x0, float x1, float x2, float x3) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  x3_split2(x0, x1, h0, m0, l0);
+  x3_split2(x2, x3, h1, m1, l1);
+  X3Frag16 f;
+  f.h = u32x2{h0, h1}; f.m = u32x2{m0, m1}; f.l = u32x2{l0, l1};
+  return f;
+}
+
+template <int C>
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
+    int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const float *__restrict__ theta,
+    pqn_cnn_layout_t L, const unsigned short *__restrict__ dzp, float *__restrict__ w1out, float *__restrict__ gpos,
+    pqn_seeds_t sd) {
+  using Cfg = CnnCfg<C>;
+  constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C, CONVBLK = Cfg::KW * 16 + 48;
+  __shared__ __attribute__((aligned(16))) float s_wc[(CONVBLK + 3) & ~3];
+  __shared__ uint32_t s_mk[QN_WAVES][16][4];
+  __shared__ __attribute__((aligned(16))) float s_fold[4 * 8 * 64 * 4];   // dW1 of the odd-parity waves (32 KB), then the conv partials
+  const int seed = blockIdx.y + sd.seed_base;
+  idx += seed * sd.idx_stride;
+  theta += seed * sd.theta_stride;
+  dzp += 2 * seed * sd.ws_stride;     // bf16 units inside a float workspace
+  w1out += seed * sd.ws_stride;
+  gpos += seed * sd.ws_stride;
+  auto row_of = [&](int64_t key) -> int64_t {
+    const uint32_t j = (uint32_t)(key & sd.idx_mask);
+    if (sd.n_env_total == sd.n_env) return (int64_t)j;
+    const uint32_t t = j / (uint32_t)sd.n_env;
+    return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
+  };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pg = blockIdx.x, p = 4 * pg + (wave & 3), par = wave >> 2;
+  const int py = p >> 3, px = p & 7;
+  const int ch = lane & 15, kq = lane >> 4;
+  for (int i = tid; i < CONVBLK; i += QN_THREADS) s_wc[i] = theta[L.off_wc + i];
+  __syncthreads();
+  ConvX3<C> cv;
+  cv.init(s_wc, lane);
+  const float bias = s_wc[Cfg::KW * 16 + ch], g0 = s_wc[Cfg::KW * 16 + 16 + ch], be0 = s_wc[Cfg::KW * 16 + 32 + ch];
+  // the position's 16 rows of W1 as dgrad-order plane fragments (resident for the whole kernel)
+  const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
+  u32x4 wfr[4][3];
+#pragma unroll
+  for (int sK = 0; sK < 4; ++sK)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wfr[sK][pl] = wd[(size_t)pl * (X3_PLANE / 8) + ((p * 4 + sK) * 64 + lane)];
+  int kyL[NRB], shL[NRB];   // conv weight gradient: window row / bit of k = 16 rb + (lane & 15)
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) {
+    const int k = 16 * j + ch;
+    kyL[j] = (k < 9 * C) ? k / RB : 0;
+    shL[j] = (k < 9 * C) ? k % RB : 31;
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // one accumulator per output tile, kept for the whole minibatch (the three small products of a step go in first;
+  // what a running f32 sum cannot hold of them is below its own rounding): 8 + NRB tiles = 44 VGPRs for C = 4
+  f32x4 dw[8], cw[NRB];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) dw[c] = zero4;
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) cw[j] = zero4;
+  float gbi = 0.f, gsc = 0.f, gbc = 0.f;
+  const u32x4 *dza = reinterpret_cast<const u32x4 *>(dzp);                                   // 16-B units
+  const u32x2 *dzb = reinterpret_cast<const u32x2 *>(dzp + 3 * (size_t)nb * QN_HID);         // 8-B units
+  const size_t pa = (size_t)nb * QN_HID / 8;                                                // dzA plane stride (16-B units)
+  const int ntiles = nb / QN_TILE;
+  // window bit position of row ky of this wave's position
+  int bw[3], bs[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int bp = ((py + ky) * 10 + px) * C;
+    bw[ky] = bp >> 5;
+    bs[ky] = bp & 31;
+  }
+  // gather of the next tile's window words is issued one tile ahead
+  uint32_t lo[3], hi[3];
+  auto gather = [&](int tt) {
+    const int64_t src = row_of(idx[tt * QN_TILE + ch]);   // lane & 15 = sample of the tile
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      lo[ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky]];
+      hi[ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky] + 1];
+    }
+  };
+  if (par < ntiles) gather(par);
+#pragma unroll 1
+  for (int tt = par; tt < ntiles; tt += 2) {
+    const int b0 = tt * QN_TILE;
+    uint32_t mk[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+      mk[ky] = (uint32_t)(((((uint64_t)hi[ky]) << 32) | lo[ky]) >> bs[ky]) & ((1u << RB) - 1u);
+    if (tt + 2 < ntiles) gather(tt + 2);
+    // dz fragments of the tile (A of the dgrad), one K step (3 dwordx4) ahead of its use; the first goes out here, over the conv
+    u32x4 az[2][3];
+    auto load_az = [&](int sK, u32x4 (&dst)[3]) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = dza[pl * pa + ((size_t)(b0 + ch) * 16 + sK * 4 + kq)];
+    };
+    load_az(0, az[0]);
+    // window masks to LDS for the conv weight gradient (needs the masks of samples 4 kq .. 4 kq + 3)
+    if (kq == 0) { s_mk[wave][ch][0] = mk[0]; s_mk[wave][ch][1] = mk[1]; s_mk[wave][ch][2] = mk[2]; }
+    // ---- conv + LN0 forward: rows = samples, columns = channels ----
+    f32x4 cb_ = zero4, cs_ = zero4;
+#pragma unroll
+    for (int sx = 0; sx < ConvX3<C>::NS; ++sx) {
+      const u32x4 fa = ConvX3<C>::expand8(__builtin_amdgcn_ubfe(ConvX3<C>::word(mk, sx), 8u * kq, 8u));
+      cs_ = X3_MFMA(fa, cv.w[sx].l, cs_);
+      cb_ = X3_MFMA(fa, cv.w[sx].h, cb_);
+      cs_ = X3_MFMA(fa, cv.w[sx].m, cs_);
+    }
+    x3_drain(cb_, cs_);
+    const f32x4 cvo = (cb_ + cs_) * ConvX3<C>::OUT_SCALE;
+    const float v[4] = {cvo.x + bias, cvo.y + bias, cvo.z + bias, cvo.w + bias};
+    float xh[4], rs[4], h1v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
+      const float mean = sum * (1.0f / 16.0f);
+      const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
+      rs[r] = rsqrt_exact(var + QN_LN_EPS);
+      xh[r] = (v[r] - mean) * rs[r];
+      h1v[r] = fmaxf(fmaf(xh[r], g0, be0), 0.0f);
+    }
+    // ---- dgrad: dh1[sample][feature] ----
+    f32x4 gb[2] = {zero4, zero4}, gs[2] = {zero4, zero4};
+#pragma unroll
+    for (int sK = 0; sK < 4; ++sK) {
+      const u32x4 (&a)[3] = az[sK & 1];
+      if (sK + 1 < 4) load_az(sK + 1, az[(sK + 1) & 1]);
+      gs[0] = X3_MFMA(a[2], wfr[sK][0], gs[0]);
+      gb[0] = X3_MFMA(a[1], wfr[sK][0], gb[0]);
+      gs[1] = X3_MFMA(a[0], wfr[sK][2], gs[1]);
+      gb[1] = X3_MFMA(a[0], wfr[sK][1], gb[1]);
+      gs[0] = X3_MFMA(a[1], wfr[sK][1], gs[0]);
+      gb[0] = X3_MFMA(a[0], wfr[sK][0], gb[0]);
+    }
+    x3_drain(gb[0], gs[0], gb[1], gs[1]);
+    const f32x4 dh4 = (gb[0] + gb[1]) + (gs[0] + gs[1]);
+    const float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
+    // ---- relu mask + LN0 backward (per point = per (kq, r); sums over the 16 channel lanes) ----
+    float dx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float g = h1v[r] > 0.0f ? dh[r] : 0.0f;
+      gbi += g;
+      gsc = fmaf(g, xh[r], gsc);
+      const float dxh = g * g0;
+      const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[r]) * (1.0f / 16.0f);
+      dx[r] = rs[r] * (dxh - s1 - xh[r] * s2);
+      gbc += dx[r];
+    }
+    // ---- conv weight gradient: dWc[k][ch] += sum_samples bit(sample, k) dx[sample][ch] ----
+    {
+      const X3Frag16 bx = x3_split4(dx[0], dx[1], dx[2], dx[3]);
+      u32x2 fa[NRB];
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) {
+        uint32_t wv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[r] = s_mk[wave][4 * kq + r][kyL[j]];
+        const uint32_t b0_ = __builtin_amdgcn_ubfe(wv[0], (uint32_t)shL[j], 1u), b1_ = __builtin_amdgcn_ubfe(wv[1], (uint32_t)shL[j], 1u);
+        const uint32_t b2_ = __builtin_amdgcn_ubfe(wv[2], (uint32_t)shL[j], 1u), b3_ = __builtin_amdgcn_ubfe(wv[3], (uint32_t)shL[j], 1u);
+        fa[j] = u32x2{((b1_ << 16) | b0_) << 14, ((b3_ << 16) | b2_) << 14};   // bit as bf16 2.0
+      }
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) cw[j] = x3_mfma16_tied(fa[j], bx.l, cw[j]);
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) cw[j] = x3_mfma16_tied(fa[j], bx.m, cw[j]);
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) cw[j] = x3_mfma16_tied(fa[j], bx.h, cw[j]);
+    }
+    // ---- dW1p[feature][o] += sum_samples h1[sample][feature] dz[sample][o] ----
+    {
+      const X3Frag16 ah = x3_split4(h1v[0], h1v[1], h1v[2], h1v[3]);
+      // two halves of four column blocks: 12 dwordx2 in flight, six products each, product-major so that an
+      // accumulator is touched every fourth MFMA
+#pragma unroll
+      for (int c0 = 0; c0 < 8; c0 += 4) {
+        u32x2 bh[4], bm[4], bl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const u32x2 *bq = dzb + ((size_t)tt * 8 + c0 + c) * 3 * 64 + lane;
+          bh[c] = bq[0]; bm[c] = bq[64]; bl[c] = bq[128];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.l, bh[c], dw[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.h, bl[c], dw[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.m, bm[c], dw[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.m, bh[c], dw[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.h, bm[c], dw[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.h, bh[c], dw[c0 + c]);
+      }
+    }
+  }
+  // ---- epilogue: fold the two tile parities of each position, write the fc1 block in kernel (fragment) layout ----
+#pragma unroll
+  for (int c = 0; c < 8; c += 4) x3_drain(dw[c], dw[c + 1], dw[c + 2], dw[c + 3]);
+  f32x4 *fold = reinterpret_cast<f32x4 *>(s_fold);
+  if (par == 1) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fold[((wave & 3) * 8 + c) * 64 + lane] = dw[c];
+  }
+  __syncthreads();
+  if (par == 0) {
+    f32x4 *out = reinterpret_cast<f32x4 *>(w1out);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[(p * 8 + c) * 64 + lane] = dw[c] + fold[((wave & 3) * 8 + c) * 64 + lane];
+  }
+  __syncthreads();
+  // conv kernel / bias / ln0 partials of the 8 waves -> LDS, summed in fixed order
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) x3_drain(cw[j]);
+  float *part = s_fold;   // [wave][CONVBLK]
+  gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
+  gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
+  gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) {
+    const f32x4 a = cw[j] * (0.5f / 255.0f);
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * j + 4 * kq + r;
+      if (k < Cfg::KW) part[wave * CONVBLK + k * 16 + ch] = av[r];
+    }
+  }
+  if (lane < 16) {
+    part[wave * CONVBLK + Cfg::KW * 16 + lane] = gbc;
+    part[wave * CONVBLK + Cfg::KW * 16 + 16 + lane] = gsc;
+    part[wave * CONVBLK + Cfg::KW * 16 + 32 + lane] = gbi;
+  }
+  __syncthreads();
+  for (int e = tid; e < CONVBLK; e += QN_THREADS) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < QN_WAVES; ++w) acc += part[w * CONVBLK + e];
+    gpos[(size_t)pg * CONVBLK + e] = acc;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2245,11 +2557,15 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
                                                                const float *__restrict__ wpart, float *__restrict__ grad,
                                                                const int32_t *__restrict__ count,
                                                                float *__restrict__ scratch, float *__restrict__ loss_out,
-                                                               float *__restrict__ qv_out, float inv_b, pqn_seeds_t sd) {
+                                                               float *__restrict__ qv_out, float inv_b, pqn_seeds_t sd,
+                                                               const float *__restrict__ gpos, int npos) {
+  // gpos / npos: the conv-block partials come from the position-parallel backward (npos records of 9C*16+48 floats per
+  // seed) instead of from the per-tile records
   __shared__ float s_part[4];
   {  // seed slice
     const long long s = blockIdx.y;
     gpart += s * sd.ws_stride;
+    if (gpos) gpos += s * sd.ws_stride;
     wpart += s * sd.ws_stride;
     scratch += s * sd.ws_stride;
     grad += s * sd.theta_stride;
@@ -2289,7 +2605,9 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
       else if (i >= L.off_w2 && i < L.off_w2 + 128 * L.a) r = convblk + 384 + (i - L.off_w2);
       else if (i >= L.off_b2 && i < L.off_b2 + L.a) r = convblk + 384 + 128 * L.a + (i - L.off_b2);
       float g = 0.0f;
-      if (r >= 0)
+      if (r >= 0 && r < convblk && gpos) {
+        if (lane < npos) g = gpos[(size_t)lane * convblk + r];
+      } else if (r >= 0)
         for (int t = lane; t < ntiles; t += 64) g += gpart[(size_t)t * rec + r];
       for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off, 64);
       if (lane == 0) {
@@ -2585,9 +2903,23 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   if (use_pair) {
     static bool pair_attr = false;
     if (!pair_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem<C>::BYTES);
       pair_attr = true;
+    }
+  }
+  // position-parallel backward (qnet_cnn_bwd_pos_kernel): the pair kernel runs forward-only and hands dz over as bf16
+  // planes; one workgroup per (seed, 4 positions) then needs >= 16 seeds to fill the chip.  PQN_BWD_POS: 0 off, 1 auto,
+  // 2 at any size (tests)
+  static const int pos_env = getenv("PQN_BWD_POS") ? atoi(getenv("PQN_BWD_POS")) : 0;
+  const bool use_pos = use_pair && pos_env && nb >= 2 * QW_SLAB && (16 * sd.nseeds >= 256 || pos_env == 2);
+  float *gposw = wpart + (size_t)QN_H1 * QN_HID;   // conv-block partials of the 16 position groups (second slab's place)
+  if (use_pos) {
+    static bool fwd_attr = false;
+    if (!fwd_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem<C>::BYTES);
+      fwd_attr = true;
     }
   }
   const int gs_max = pqn_cnn_seed_group(L.matmul_f16, sd.nseeds);
@@ -2598,8 +2930,15 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     const long long wo = (long long)s0 * sd.ws_stride;
     const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
     if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
-    if (use_pair)
-      hipLaunchKernelGGL(qnet_cnn_train_pair_kernel<C>, dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
+    if (use_pos) {
+      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
+                         action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
+      hipLaunchKernelGGL(qnet_cnn_bwd_pos_kernel<C>, dim3(16, gs), dim3(QN_THREADS), 0, st, nb, idx, bits, theta, L,
+                         reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg);
+      if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
+      continue;   // no T2: dW1 was accumulated in registers
+    } else if (use_pair)
+      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
                          action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
     else
     hipLaunchKernelGGL(t1, dim3(ntiles, gs), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
@@ -2628,8 +2967,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
                          sd.ws_stride);
   }
   if (with_reduce)
-    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles, nks,
-                       rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd);
+    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles,
+                       use_pos ? 1 : nks, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd,
+                       use_pos ? gposw : nullptr, use_pos ? 16 : 0);
   return pqn_check_launch("pqn_qnet_cnn_grad");
 }
 
