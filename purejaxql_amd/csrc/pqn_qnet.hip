@@ -1993,15 +1993,26 @@ PQN_D X3Frag16 x3_split4(float x0, float x1, float x2, float x3) {
 }
 
 template <int C>
+constexpr size_t bwd_pos_lds_bytes() {
+  return 16 * (2 * 3072 + 4 * 4 * 3 * 64) + 4 * (((9 * C * 16 + 48) + 3) & ~3) + 4 * QN_WAVES * 16 * 4;
+}
+template <int C>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const float *__restrict__ theta,
     pqn_cnn_layout_t L, const unsigned short *__restrict__ dzp, float *__restrict__ w1out, float *__restrict__ gpos,
     pqn_seeds_t sd) {
   using Cfg = CnnCfg<C>;
   constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C, CONVBLK = Cfg::KW * 16 + 48;
-  __shared__ __attribute__((aligned(16))) float s_wc[(CONVBLK + 3) & ~3];
-  __shared__ uint32_t s_mk[QN_WAVES][16][4];
-  __shared__ __attribute__((aligned(16))) float s_fold[4 * 8 * 64 * 4];   // dW1 of the odd-parity waves (32 KB), then the conv partials
+  // LDS (dynamic, BP_LDS bytes): two 48 KB buffers of dz planes for a 32-sample super-tile (24 KB A order, quads
+  // XOR-swizzled with the sample so that the row-strided fragment reads are conflict-free; 24 KB B order), the four
+  // positions' W1 plane fragments (48 KB), the conv parameters and the window-mask exchange.  The epilogue's fold buffer
+  // reuses the dz buffers.
+  extern __shared__ __attribute__((aligned(16))) char bp_smem[];
+  u32x4 *s_dz = reinterpret_cast<u32x4 *>(bp_smem);                         // [2][3072] 16-B units
+  u32x4 *s_w = s_dz + 2 * 3072;                                              // [4 pos][4 sK][3 pl][64]
+  float *s_wc = reinterpret_cast<float *>(s_w + 4 * 4 * 3 * 64);
+  uint32_t (*s_mk)[16][4] = reinterpret_cast<uint32_t (*)[16][4]>(s_wc + ((CONVBLK + 3) & ~3));
+  float *s_fold = reinterpret_cast<float *>(bp_smem);
   const int seed = blockIdx.y + sd.seed_base;
   idx += seed * sd.idx_stride;
   theta += seed * sd.theta_stride;
@@ -2025,11 +2036,11 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
   const float bias = s_wc[Cfg::KW * 16 + ch], g0 = s_wc[Cfg::KW * 16 + 16 + ch], be0 = s_wc[Cfg::KW * 16 + 32 + ch];
   // the position's 16 rows of W1 as dgrad-order plane fragments (resident for the whole kernel)
   const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
-  u32x4 wfr[4][3];
-#pragma unroll
-  for (int sK = 0; sK < 4; ++sK)
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) wfr[sK][pl] = wd[(size_t)pl * (X3_PLANE / 8) + ((p * 4 + sK) * 64 + lane)];
+  for (int e = tid; e < 4 * 4 * 3 * 64; e += QN_THREADS) {   // [pos][sK][pl][lane]
+    const int ln = e & 63, pl = (e >> 6) % 3, ps = (e >> 6) / 3;   // ps = pos * 4 + sK
+    s_w[e] = wd[(size_t)pl * (X3_PLANE / 8) + (((4 * pg) * 4 + ps) * 64 + ln)];
+  }
+  const u32x4 *wl = s_w + (wave & 3) * (4 * 3 * 64) + lane;   // + (sK * 3 + pl) * 64
   int kyL[NRB], shL[NRB];   // conv weight gradient: window row / bit of k = 16 rb + (lane & 15)
 #pragma unroll
   for (int j = 0; j < NRB; ++j) {
@@ -2047,9 +2058,36 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
   for (int j = 0; j < NRB; ++j) cw[j] = zero4;
   float gbi = 0.f, gsc = 0.f, gbc = 0.f;
   const u32x4 *dza = reinterpret_cast<const u32x4 *>(dzp);                                   // 16-B units
-  const u32x2 *dzb = reinterpret_cast<const u32x2 *>(dzp + 3 * (size_t)nb * QN_HID);         // 8-B units
+  const u32x4 *dzbg = reinterpret_cast<const u32x4 *>(dzp + 3 * (size_t)nb * QN_HID);        // dzB, 16-B units
   const size_t pa = (size_t)nb * QN_HID / 8;                                                // dzA plane stride (16-B units)
-  const int ntiles = nb / QN_TILE;
+  const int ntiles = nb / QN_TILE, nsuper = ntiles / 2;
+  // super-tile j (samples 32 j .. 32 j + 31) = 3072 16-B chunks: 3 planes x 512 of dzA, then 1536 of dzB (two tiles,
+  // contiguous in memory); thread t moves chunks t + 512 k.  Loads are unconditional (j clamped), kept in 24 VGPRs over
+  // the compute of the previous super-tile, then stored to the other LDS buffer.
+  u32x4 pf[6];
+  auto pf_load = [&](int j) {
+    j = min(j, nsuper - 1);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int c = tid + QN_THREADS * q;
+      pf[q] = (q < 3) ? dza[(size_t)q * pa + (size_t)j * 512 + tid] : dzbg[(size_t)j * 1536 + (c - 1536)];
+    }
+  };
+  auto pf_store = [&](int buf) {
+    u32x4 *d = s_dz + buf * 3072;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int c = tid + QN_THREADS * q;
+      if (q < 3) {
+        const int smp = tid >> 4, quad = tid & 15;                     // sample of the super-tile, (sK, kq) quad
+        d[(q * 32 + smp) * 16 + (quad ^ (smp & 15))] = pf[q];
+      } else d[c] = pf[q];
+    }
+  };
+  pf_load(0);
+  pf_store(0);
+  pf_load(1);
+  __syncthreads();
   // window bit position of row ky of this wave's position
   int bw[3], bs[3];
 #pragma unroll
@@ -2068,22 +2106,27 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
       hi[ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky] + 1];
     }
   };
-  if (par < ntiles) gather(par);
+  gather(par);
 #pragma unroll 1
-  for (int tt = par; tt < ntiles; tt += 2) {
-    const int b0 = tt * QN_TILE;
+  for (int js = 0; js < nsuper; ++js) {
+    const int tt = 2 * js + par;
+    const u32x4 *ldA = s_dz + (js & 1) * 3072;                                    // [pl][32 samples][16 quads]
+    const u32x2 *ldB = reinterpret_cast<const u32x2 *>(ldA + 1536) + par * (8 * 3 * 64) + lane;   // + (cb * 3 + pl) * 64
     uint32_t mk[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
       mk[ky] = (uint32_t)(((((uint64_t)hi[ky]) << 32) | lo[ky]) >> bs[ky]) & ((1u << RB) - 1u);
-    if (tt + 2 < ntiles) gather(tt + 2);
+    if (js + 1 < nsuper) gather(tt + 2);
     // dz fragments of the tile (A of the dgrad), one K step (3 dwordx4) ahead of its use; the first goes out here, over the conv
-    u32x4 az[2][3];
-    auto load_az = [&](int sK, u32x4 (&dst)[3]) {
+    u32x4 az[2][3], bw_[2][3];
+    auto load_az = [&](int sK, u32x4 (&dst)[3], u32x4 (&wdst)[3]) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) dst[pl] = dza[pl * pa + ((size_t)(b0 + ch) * 16 + sK * 4 + kq)];
+      for (int pl = 0; pl < 3; ++pl) {
+        dst[pl] = ldA[(pl * 32 + 16 * par + ch) * 16 + ((sK * 4 + kq) ^ ch)];
+        wdst[pl] = wl[(sK * 3 + pl) * 64];
+      }
     };
-    load_az(0, az[0]);
+    load_az(0, az[0], bw_[0]);
     // window masks to LDS for the conv weight gradient (needs the masks of samples 4 kq .. 4 kq + 3)
     if (kq == 0) { s_mk[wave][ch][0] = mk[0]; s_mk[wave][ch][1] = mk[1]; s_mk[wave][ch][2] = mk[2]; }
     // ---- conv + LN0 forward: rows = samples, columns = channels ----
@@ -2113,13 +2156,14 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
 #pragma unroll
     for (int sK = 0; sK < 4; ++sK) {
       const u32x4 (&a)[3] = az[sK & 1];
-      if (sK + 1 < 4) load_az(sK + 1, az[(sK + 1) & 1]);
-      gs[0] = X3_MFMA(a[2], wfr[sK][0], gs[0]);
-      gb[0] = X3_MFMA(a[1], wfr[sK][0], gb[0]);
-      gs[1] = X3_MFMA(a[0], wfr[sK][2], gs[1]);
-      gb[1] = X3_MFMA(a[0], wfr[sK][1], gb[1]);
-      gs[0] = X3_MFMA(a[1], wfr[sK][1], gs[0]);
-      gb[0] = X3_MFMA(a[0], wfr[sK][0], gb[0]);
+      const u32x4 (&wq)[3] = bw_[sK & 1];
+      if (sK + 1 < 4) load_az(sK + 1, az[(sK + 1) & 1], bw_[(sK + 1) & 1]);
+      gs[0] = X3_MFMA(a[2], wq[0], gs[0]);
+      gb[0] = X3_MFMA(a[1], wq[0], gb[0]);
+      gs[1] = X3_MFMA(a[0], wq[2], gs[1]);
+      gb[1] = X3_MFMA(a[0], wq[1], gb[1]);
+      gs[0] = X3_MFMA(a[1], wq[1], gs[0]);
+      gb[0] = X3_MFMA(a[0], wq[0], gb[0]);
     }
     x3_drain(gb[0], gs[0], gb[1], gs[1]);
     const f32x4 dh4 = (gb[0] + gb[1]) + (gs[0] + gs[1]);
@@ -2166,7 +2210,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
         u32x2 bh[4], bm[4], bl[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const u32x2 *bq = dzb + ((size_t)tt * 8 + c0 + c) * 3 * 64 + lane;
+          const u32x2 *bq = ldB + (c0 + c) * 3 * 64;
           bh[c] = bq[0]; bm[c] = bq[64]; bl[c] = bq[128];
         }
 #pragma unroll
@@ -2183,6 +2227,10 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
         for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.h, bh[c], dw[c0 + c]);
       }
     }
+    // the next super-tile: registers -> the other LDS buffer (last read one iteration ago), and the one after that goes out
+    pf_store((js + 1) & 1);
+    pf_load(js + 2);
+    __syncthreads();
   }
   // ---- epilogue: fold the two tile parities of each position, write the fc1 block in kernel (fragment) layout ----
 #pragma unroll
@@ -2917,6 +2965,8 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   if (use_pos) {
     static bool fwd_attr = false;
     if (!fwd_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_bwd_pos_kernel<C>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_pos_lds_bytes<C>());
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem<C>::BYTES);
       fwd_attr = true;
@@ -2933,7 +2983,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     if (use_pos) {
       hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
                          action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
-      hipLaunchKernelGGL(qnet_cnn_bwd_pos_kernel<C>, dim3(16, gs), dim3(QN_THREADS), 0, st, nb, idx, bits, theta, L,
+      hipLaunchKernelGGL(qnet_cnn_bwd_pos_kernel<C>, dim3(16, gs), dim3(QN_THREADS), bwd_pos_lds_bytes<C>(), st, nb, idx, bits, theta, L,
                          reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg);
       if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
       continue;   // no T2: dW1 was accumulated in registers
