@@ -1109,11 +1109,14 @@ constexpr size_t train_smem_bytes() {
 // dz as bf16 planes for the position-parallel backward (element offsets in bf16 units inside one plane set):
 //   dzA[plane][sample][sK][kq][8]: the 8 values are outputs 32 sK + 16 (j >> 2) + 4 kq + (j & 3) -- one dwordx4 per lane is
 //       the A fragment (row = sample) of a K = 32 dgrad step, in the K-slot order of the optimizer's dgrad planes;
-//   dzB[tile][cb][plane][lane][4], lane = kq * 16 + (o & 15): samples 4 kq .. 4 kq + 3 of the tile for output 16 cb + (o & 15)
-//       -- one dwordx2 per lane is the B fragment (column = output) of a K = 16 step of dW1 = h1^T dz.
-// Plane stride: nb * 128 (dzA), 256 inside a (tile, cb) block (dzB).  dzA occupies 3 nb 128 elements, dzB follows it.
+//   dzB[super-tile of 32 samples][cb][plane][lane][tile 0/1][4], lane = kq * 16 + (o & 15): samples 4 kq .. 4 kq + 3 of
+//       each of the two tiles for output 16 cb + (o & 15) -- one dwordx4 per lane is the B fragment (column = output) of
+//       a K = 32 step of dW1 = h1^T dz whose K slot j stands for sample 16 (j >> 2) + 4 kq + (j & 3) of the super-tile.
+// Plane stride: nb * 128 (dzA), 512 inside a (super-tile, cb) block (dzB).  dzA occupies 3 nb 128 elements, dzB follows it.
 PQN_HD size_t dz_planes_a(int nb, int sample, int sK, int kq) { (void)nb; return ((size_t)sample * 16 + sK * 4 + kq) * 8; }
-PQN_HD size_t dz_planes_b(int tile, int cb, int lane) { return (((size_t)tile * 8 + cb) * 3 * 64 + lane) * 4; }
+PQN_HD size_t dz_planes_b(int tile, int cb, int lane) {
+  return (((((size_t)(tile >> 1) * 8 + cb) * 3) * 64 + lane) * 2 + (tile & 1)) * 4;
+}
 
 // all-reduce sum over each aligned group of 32 lanes: DPP butterfly inside the 16-lane rows, then one
 // ds_swizzle (xor 16) across the two rows
@@ -1268,8 +1271,8 @@ PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layou
       x3_split2(zc[2 * QN_ZS], zc[3 * QN_ZS], hh[1], mm[1], ll[1]);
       unsigned short *pb = dzp + 3 * (size_t)nb * QN_HID + dz_planes_b(b0 / QN_TILE, o >> 4, kq * 16 + (o & 15));
       *reinterpret_cast<u2 *>(pb) = u2{hh[0], hh[1]};
-      *reinterpret_cast<u2 *>(pb + 256) = u2{mm[0], mm[1]};
-      *reinterpret_cast<u2 *>(pb + 512) = u2{ll[0], ll[1]};
+      *reinterpret_cast<u2 *>(pb + 512) = u2{mm[0], mm[1]};
+      *reinterpret_cast<u2 *>(pb + 1024) = u2{ll[0], ll[1]};
     }
   } else
   for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
@@ -1992,28 +1995,43 @@ PQN_D X3Frag16 x3_split4(float x0, float x1, float x2, float x3) {
   return f;
 }
 
+// LDS plan of qnet_cnn_bwd_pos_kernel (16-B units unless noted): dzA[2][1536] | dzB[2][1536] | exchange[2][4 pos][6][64]
+// | window masks u32 [2][4][32][4] | conv parameters
 template <int C>
 constexpr size_t bwd_pos_lds_bytes() {
-  return 16 * (2 * 3072 + 4 * 4 * 3 * 64) + 4 * (((9 * C * 16 + 48) + 3) & ~3) + 4 * QN_WAVES * 16 * 4;
+  return 16 * (2 * 1536 + 2 * 1536 + 2 * 4 * 6 * 64) + 4 * (2 * 4 * 32 * 4) + 4 * (((9 * C * 16 + 48) + 3) & ~3);
 }
 template <int C>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const float *__restrict__ theta,
     pqn_cnn_layout_t L, const unsigned short *__restrict__ dzp, float *__restrict__ w1out, float *__restrict__ gpos,
-    pqn_seeds_t sd) {
+    pqn_seeds_t sd, unsigned long long *__restrict__ stamps) {
+#define BP_STAMP(k) do { if (stamps && js == 8 && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == 4)) stamps[(wave ? 16 : 0) + (k)] = __builtin_readcyclecounter(); } while (0)
   using Cfg = CnnCfg<C>;
   constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C, CONVBLK = Cfg::KW * 16 + 48;
-  // LDS (dynamic, BP_LDS bytes): two 48 KB buffers of dz planes for a 32-sample super-tile (24 KB A order, quads
-  // XOR-swizzled with the sample so that the row-strided fragment reads are conflict-free; 24 KB B order), the four
-  // positions' W1 plane fragments (48 KB), the conv parameters and the window-mask exchange.  The epilogue's fold buffer
-  // reuses the dz buffers.
+  constexpr int RBH = (NRB + 1) / 2;     // conv-wgrad row blocks per back wave
   extern __shared__ __attribute__((aligned(16))) char bp_smem[];
-  u32x4 *s_dz = reinterpret_cast<u32x4 *>(bp_smem);                         // [2][3072] 16-B units
-  u32x4 *s_w = s_dz + 2 * 3072;                                              // [4 pos][4 sK][3 pl][64]
-  float *s_wc = reinterpret_cast<float *>(s_w + 4 * 4 * 3 * 64);
-  uint32_t (*s_mk)[16][4] = reinterpret_cast<uint32_t (*)[16][4]>(s_wc + ((CONVBLK + 3) & ~3));
-  float *s_fold = reinterpret_cast<float *>(bp_smem);
-  const int seed = blockIdx.y + sd.seed_base;
+  u32x4 *s_dza = reinterpret_cast<u32x4 *>(bp_smem);          // [2][3 pl][32 samples][16 quads], quads XOR-swizzled with the sample
+  u32x4 *s_dzb = s_dza + 2 * 1536;                             // [2][8 cb][3 pl][64 lanes]
+  u32x4 *s_ex = s_dzb + 2 * 1536;                              // [2][4 pos][h1 h,m,l | dx h,m,l][64 lanes]
+  uint32_t *s_mk = reinterpret_cast<uint32_t *>(s_ex + 2 * 4 * 6 * 64);   // [2][4 pos][32 samples][4]
+  float *s_wc = reinterpret_cast<float *>(s_mk + 2 * 4 * 32 * 4);
+  // XCD-aware placement (speed only): every position group re-reads its seed's dz planes (6 MB per seed), so the 16
+  // workgroups of a seed should share one XCD's L2.  Workgroups are dealt to the 8 XCDs round-robin by linear id, hence
+  // seed and position group are derived from the linear id such that id % 8 determines the seed's XCD.
+  int pg_, sl_;
+  {
+    const int nsl = gridDim.y, lin = blockIdx.x + 16 * blockIdx.y;
+    if ((nsl & 7) == 0) {
+      const int xcd = lin & 7, k = lin >> 3;          // k in [0, 2 nsl)
+      sl_ = xcd * (nsl >> 3) + (k >> 4);
+      pg_ = k & 15;
+    } else {
+      sl_ = blockIdx.y;
+      pg_ = blockIdx.x;
+    }
+  }
+  const int seed = sl_ + sd.seed_base;
   idx += seed * sd.idx_stride;
   theta += seed * sd.theta_stride;
   dzp += 2 * seed * sd.ws_stride;     // bf16 units inside a float workspace
@@ -2026,256 +2044,337 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
     return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
   };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pg = blockIdx.x, p = 4 * pg + (wave & 3), par = wave >> 2;
-  const int py = p >> 3, px = p & 7;
+  const int pg = pg_;
   const int ch = lane & 15, kq = lane >> 4;
+  const bool front = wave < 4;          // waves w and w + 4 share a SIMD: one producer and one consumer each
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int nsuper = nb / (2 * QN_TILE);
+  const u32x4 *dza = reinterpret_cast<const u32x4 *>(dzp);                              // 16-B units
+  const u32x4 *dzbg = reinterpret_cast<const u32x4 *>(dzp + 3 * (size_t)nb * QN_HID);   // dzB, 16-B units
+  const size_t pa = (size_t)nb * QN_HID / 8;                                           // dzA plane stride (16-B units)
   for (int i = tid; i < CONVBLK; i += QN_THREADS) s_wc[i] = theta[L.off_wc + i];
   __syncthreads();
-  ConvX3<C> cv;
-  cv.init(s_wc, lane);
-  const float bias = s_wc[Cfg::KW * 16 + ch], g0 = s_wc[Cfg::KW * 16 + 16 + ch], be0 = s_wc[Cfg::KW * 16 + 32 + ch];
-  // the position's 16 rows of W1 as dgrad-order plane fragments (resident for the whole kernel)
-  const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
-  for (int e = tid; e < 4 * 4 * 3 * 64; e += QN_THREADS) {   // [pos][sK][pl][lane]
-    const int ln = e & 63, pl = (e >> 6) % 3, ps = (e >> 6) / 3;   // ps = pos * 4 + sK
-    s_w[e] = wd[(size_t)pl * (X3_PLANE / 8) + (((4 * pg) * 4 + ps) * 64 + ln)];
-  }
-  const u32x4 *wl = s_w + (wave & 3) * (4 * 3 * 64) + lane;   // + (sK * 3 + pl) * 64
-  int kyL[NRB], shL[NRB];   // conv weight gradient: window row / bit of k = 16 rb + (lane & 15)
+
+  // The two roles are separate code paths with their own loops (same number of barriers on both sides): registers are
+  // allocated for the larger role, not for the union of the two.
+  float gbi = 0.f, gsc = 0.f, gbc = 0.f;                 // producer results needed by the epilogue
+  f32x4 dw[2][4], cw[2][(((9 * C + 15) / 16) + 1) / 2];   // consumer results needed by the epilogue
+  const int bwv = wave & 3, pp = bwv >> 1, ohalf = bwv & 1;
+  if (front) {
+    // =========================== producer state (waves 0..3: one position each) ===========================
+    const int p = 4 * pg + (wave & 3), py = p >> 3, px = p & 7;
+    ConvX3<C> cv;
+    u32x4 wfr[4][3];
+    float bias = 0.f, g0 = 0.f, be0 = 0.f;
+    int bw[3], bs[3];
+    uint32_t lo[2][3], hi[2][3];
+    // Two-stage gather: the permutation indices of super-tile js + 2 are loaded while the window words of js + 1 (whose
+    // indices arrived an iteration ago) go out -- a dependent idx -> obs load chain inside one iteration stalled the
+    // producer for a full memory round trip (4.5k of its 8.7k ticks per super-tile).
+    int64_t key[2];
+    auto load_keys = [&](int js) {
+      js = min(js, nsuper - 1);
 #pragma unroll
-  for (int j = 0; j < NRB; ++j) {
-    const int k = 16 * j + ch;
-    kyL[j] = (k < 9 * C) ? k / RB : 0;
-    shL[j] = (k < 9 * C) ? k % RB : 31;
-  }
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  // one accumulator per output tile, kept for the whole minibatch (the three small products of a step go in first;
-  // what a running f32 sum cannot hold of them is below its own rounding): 8 + NRB tiles = 44 VGPRs for C = 4
-  f32x4 dw[8], cw[NRB];
+      for (int t = 0; t < 2; ++t) key[t] = idx[(2 * js + t) * QN_TILE + ch];
+    };
+    auto gather = [&]() {   // window words of both tiles of the super-tile whose keys are in `key` (lane & 15 = sample)
 #pragma unroll
-  for (int c = 0; c < 8; ++c) dw[c] = zero4;
+      for (int t = 0; t < 2; ++t) {
+        const int64_t src = row_of(key[t]);
 #pragma unroll
-  for (int j = 0; j < NRB; ++j) cw[j] = zero4;
-  float gbi = 0.f, gsc = 0.f, gbc = 0.f;
-  const u32x4 *dza = reinterpret_cast<const u32x4 *>(dzp);                                   // 16-B units
-  const u32x4 *dzbg = reinterpret_cast<const u32x4 *>(dzp + 3 * (size_t)nb * QN_HID);        // dzB, 16-B units
-  const size_t pa = (size_t)nb * QN_HID / 8;                                                // dzA plane stride (16-B units)
-  const int ntiles = nb / QN_TILE, nsuper = ntiles / 2;
-  // super-tile j (samples 32 j .. 32 j + 31) = 3072 16-B chunks: 3 planes x 512 of dzA, then 1536 of dzB (two tiles,
-  // contiguous in memory); thread t moves chunks t + 512 k.  Loads are unconditional (j clamped), kept in 24 VGPRs over
-  // the compute of the previous super-tile, then stored to the other LDS buffer.
-  u32x4 pf[6];
-  auto pf_load = [&](int j) {
-    j = min(j, nsuper - 1);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int c = tid + QN_THREADS * q;
-      pf[q] = (q < 3) ? dza[(size_t)q * pa + (size_t)j * 512 + tid] : dzbg[(size_t)j * 1536 + (c - 1536)];
-    }
-  };
-  auto pf_store = [&](int buf) {
-    u32x4 *d = s_dz + buf * 3072;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int c = tid + QN_THREADS * q;
-      if (q < 3) {
-        const int smp = tid >> 4, quad = tid & 15;                     // sample of the super-tile, (sK, kq) quad
-        d[(q * 32 + smp) * 16 + (quad ^ (smp & 15))] = pf[q];
-      } else d[c] = pf[q];
-    }
-  };
-  pf_load(0);
-  pf_store(0);
-  pf_load(1);
-  __syncthreads();
-  // window bit position of row ky of this wave's position
-  int bw[3], bs[3];
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int bp = ((py + ky) * 10 + px) * C;
-    bw[ky] = bp >> 5;
-    bs[ky] = bp & 31;
-  }
-  // gather of the next tile's window words is issued one tile ahead
-  uint32_t lo[3], hi[3];
-  auto gather = [&](int tt) {
-    const int64_t src = row_of(idx[tt * QN_TILE + ch]);   // lane & 15 = sample of the tile
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      lo[ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky]];
-      hi[ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky] + 1];
-    }
-  };
-  gather(par);
-#pragma unroll 1
-  for (int js = 0; js < nsuper; ++js) {
-    const int tt = 2 * js + par;
-    const u32x4 *ldA = s_dz + (js & 1) * 3072;                                    // [pl][32 samples][16 quads]
-    const u32x2 *ldB = reinterpret_cast<const u32x2 *>(ldA + 1536) + par * (8 * 3 * 64) + lane;   // + (cb * 3 + pl) * 64
-    uint32_t mk[3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-      mk[ky] = (uint32_t)(((((uint64_t)hi[ky]) << 32) | lo[ky]) >> bs[ky]) & ((1u << RB) - 1u);
-    if (js + 1 < nsuper) gather(tt + 2);
-    // dz fragments of the tile (A of the dgrad), one K step (3 dwordx4) ahead of its use; the first goes out here, over the conv
-    u32x4 az[2][3], bw_[2][3];
-    auto load_az = [&](int sK, u32x4 (&dst)[3], u32x4 (&wdst)[3]) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        dst[pl] = ldA[(pl * 32 + 16 * par + ch) * 16 + ((sK * 4 + kq) ^ ch)];
-        wdst[pl] = wl[(sK * 3 + pl) * 64];
+        for (int ky = 0; ky < 3; ++ky) {
+          lo[t][ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky]];
+          hi[t][ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky] + 1];
+        }
       }
     };
-    load_az(0, az[0], bw_[0]);
-    // window masks to LDS for the conv weight gradient (needs the masks of samples 4 kq .. 4 kq + 3)
-    if (kq == 0) { s_mk[wave][ch][0] = mk[0]; s_mk[wave][ch][1] = mk[1]; s_mk[wave][ch][2] = mk[2]; }
-    // ---- conv + LN0 forward: rows = samples, columns = channels ----
-    f32x4 cb_ = zero4, cs_ = zero4;
-#pragma unroll
-    for (int sx = 0; sx < ConvX3<C>::NS; ++sx) {
-      const u32x4 fa = ConvX3<C>::expand8(__builtin_amdgcn_ubfe(ConvX3<C>::word(mk, sx), 8u * kq, 8u));
-      cs_ = X3_MFMA(fa, cv.w[sx].l, cs_);
-      cb_ = X3_MFMA(fa, cv.w[sx].h, cb_);
-      cs_ = X3_MFMA(fa, cv.w[sx].m, cs_);
-    }
-    x3_drain(cb_, cs_);
-    const f32x4 cvo = (cb_ + cs_) * ConvX3<C>::OUT_SCALE;
-    const float v[4] = {cvo.x + bias, cvo.y + bias, cvo.z + bias, cvo.w + bias};
-    float xh[4], rs[4], h1v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
-      const float mean = sum * (1.0f / 16.0f);
-      const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
-      rs[r] = rsqrt_exact(var + QN_LN_EPS);
-      xh[r] = (v[r] - mean) * rs[r];
-      h1v[r] = fmaxf(fmaf(xh[r], g0, be0), 0.0f);
-    }
-    // ---- dgrad: dh1[sample][feature] ----
-    f32x4 gb[2] = {zero4, zero4}, gs[2] = {zero4, zero4};
-#pragma unroll
-    for (int sK = 0; sK < 4; ++sK) {
-      const u32x4 (&a)[3] = az[sK & 1];
-      const u32x4 (&wq)[3] = bw_[sK & 1];
-      if (sK + 1 < 4) load_az(sK + 1, az[(sK + 1) & 1], bw_[(sK + 1) & 1]);
-      gs[0] = X3_MFMA(a[2], wq[0], gs[0]);
-      gb[0] = X3_MFMA(a[1], wq[0], gb[0]);
-      gs[1] = X3_MFMA(a[0], wq[2], gs[1]);
-      gb[1] = X3_MFMA(a[0], wq[1], gb[1]);
-      gs[0] = X3_MFMA(a[1], wq[1], gs[0]);
-      gb[0] = X3_MFMA(a[0], wq[0], gb[0]);
-    }
-    x3_drain(gb[0], gs[0], gb[1], gs[1]);
-    const f32x4 dh4 = (gb[0] + gb[1]) + (gs[0] + gs[1]);
-    const float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
-    // ---- relu mask + LN0 backward (per point = per (kq, r); sums over the 16 channel lanes) ----
-    float dx[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float g = h1v[r] > 0.0f ? dh[r] : 0.0f;
-      gbi += g;
-      gsc = fmaf(g, xh[r], gsc);
-      const float dxh = g * g0;
-      const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[r]) * (1.0f / 16.0f);
-      dx[r] = rs[r] * (dxh - s1 - xh[r] * s2);
-      gbc += dx[r];
-    }
-    // ---- conv weight gradient: dWc[k][ch] += sum_samples bit(sample, k) dx[sample][ch] ----
     {
-      const X3Frag16 bx = x3_split4(dx[0], dx[1], dx[2], dx[3]);
-      u32x2 fa[NRB];
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) {
-        uint32_t wv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wv[r] = s_mk[wave][4 * kq + r][kyL[j]];
-        const uint32_t b0_ = __builtin_amdgcn_ubfe(wv[0], (uint32_t)shL[j], 1u), b1_ = __builtin_amdgcn_ubfe(wv[1], (uint32_t)shL[j], 1u);
-        const uint32_t b2_ = __builtin_amdgcn_ubfe(wv[2], (uint32_t)shL[j], 1u), b3_ = __builtin_amdgcn_ubfe(wv[3], (uint32_t)shL[j], 1u);
-        fa[j] = u32x2{((b1_ << 16) | b0_) << 14, ((b3_ << 16) | b2_) << 14};   // bit as bf16 2.0
+      cv.init(s_wc, lane);
+      bias = s_wc[Cfg::KW * 16 + ch]; g0 = s_wc[Cfg::KW * 16 + 16 + ch]; be0 = s_wc[Cfg::KW * 16 + 32 + ch];
+      const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
+  #pragma unroll
+      for (int sK = 0; sK < 4; ++sK)
+  #pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wfr[sK][pl] = wd[(size_t)pl * (X3_PLANE / 8) + ((p * 4 + sK) * 64 + lane)];
+  #pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int bp = ((py + ky) * 10 + px) * C;
+        bw[ky] = bp >> 5;
+        bs[ky] = bp & 31;
       }
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) cw[j] = x3_mfma16_tied(fa[j], bx.l, cw[j]);
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) cw[j] = x3_mfma16_tied(fa[j], bx.m, cw[j]);
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) cw[j] = x3_mfma16_tied(fa[j], bx.h, cw[j]);
+      load_keys(0);
+      gather();
+      load_keys(1);
     }
-    // ---- dW1p[feature][o] += sum_samples h1[sample][feature] dz[sample][o] ----
-    {
-      const X3Frag16 ah = x3_split4(h1v[0], h1v[1], h1v[2], h1v[3]);
-      // two halves of four column blocks: 12 dwordx2 in flight, six products each, product-major so that an
-      // accumulator is touched every fourth MFMA
+
+    __syncthreads();   // consumers' prologue: dzA of super-tile 0 staged
+#pragma unroll 1
+    for (int js = 0; js <= nsuper; ++js) {
+      if (js < nsuper) {
+
+          BP_STAMP(0);
+          const u32x4 *ldA = s_dza + (js & 1) * 1536;
+          float h1v[2][4], dxv[2][4];
+          uint32_t mk[2][3];
+  #pragma unroll
+          for (int t = 0; t < 2; ++t)
+  #pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+              mk[t][ky] = (uint32_t)(((((uint64_t)hi[t][ky]) << 32) | lo[t][ky]) >> bs[ky]) & ((1u << RB) - 1u);
+          gather();            // super-tile js + 1 (keys loaded last iteration; clamped at the end)
+          load_keys(js + 2);
+          if (kq == 0) {
+            uint32_t *mw = s_mk + (((js & 1) * 4 + (wave & 3)) * 32) * 4;
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) { mw[(16 * t + ch) * 4 + 0] = mk[t][0]; mw[(16 * t + ch) * 4 + 1] = mk[t][1]; mw[(16 * t + ch) * 4 + 2] = mk[t][2]; }
+          }
+          // The two tiles of the super-tile go through every phase TOGETHER: a producer is alone on its SIMD for this
+          // work, and a single tile's chain (conv MFMAs -> drain -> LayerNorm -> dgrad MFMAs -> drain -> LayerNorm
+          // backward) is latency-bound; two independent chains interleaved halve that.
+          // ---- conv: rows = samples, columns = channels ----
+          f32x4 cb_[2] = {zero4, zero4}, cs_[2] = {zero4, zero4};
+  #pragma unroll
+          for (int sx = 0; sx < ConvX3<C>::NS; ++sx) {
+            u32x4 fa[2];
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) fa[t] = ConvX3<C>::expand8(__builtin_amdgcn_ubfe(ConvX3<C>::word(mk[t], sx), 8u * kq, 8u));
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) cs_[t] = X3_MFMA(fa[t], cv.w[sx].l, cs_[t]);
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) cb_[t] = X3_MFMA(fa[t], cv.w[sx].h, cb_[t]);
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) cs_[t] = X3_MFMA(fa[t], cv.w[sx].m, cs_[t]);
+          }
+          // dgrad operands of both tiles from LDS while the conv drains (one K step ahead of its use)
+          u32x4 az[2][2][3];
+          auto load_az = [&](int sK, u32x4 (&dst)[2][3]) {
+  #pragma unroll
+            for (int t = 0; t < 2; ++t)
+  #pragma unroll
+              for (int pl = 0; pl < 3; ++pl) dst[t][pl] = ldA[(pl * 32 + 16 * t + ch) * 16 + ((sK * 4 + kq) ^ ch)];
+          };
+          load_az(0, az[0]);
+          BP_STAMP(1);
+          x3_drain(cb_[0], cs_[0], cb_[1], cs_[1]);
+          float xh[2][4], rs[2][4];
+  #pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const f32x4 cvo = (cb_[t] + cs_[t]) * ConvX3<C>::OUT_SCALE;
+            const float v[4] = {cvo.x + bias, cvo.y + bias, cvo.z + bias, cvo.w + bias};
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
+              const float mean = sum * (1.0f / 16.0f);
+              const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
+              rs[t][r] = rsqrt_exact(var + QN_LN_EPS);
+              xh[t][r] = (v[r] - mean) * rs[t][r];
+              h1v[t][r] = fmaxf(fmaf(xh[t][r], g0, be0), 0.0f);
+            }
+          }
+          BP_STAMP(2);
+          // ---- dgrad: dh1[sample][feature], eight independent accumulators ----
+          f32x4 gb[2][2] = {{zero4, zero4}, {zero4, zero4}}, gs[2][2] = {{zero4, zero4}, {zero4, zero4}};
+  #pragma unroll
+          for (int sK = 0; sK < 4; ++sK) {
+            const u32x4 (&a)[2][3] = az[sK & 1];
+            if (sK + 1 < 4) load_az(sK + 1, az[(sK + 1) & 1]);
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) gs[t][0] = X3_MFMA(a[t][2], wfr[sK][0], gs[t][0]);
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) gb[t][0] = X3_MFMA(a[t][1], wfr[sK][0], gb[t][0]);
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) gs[t][1] = X3_MFMA(a[t][0], wfr[sK][2], gs[t][1]);
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) gb[t][1] = X3_MFMA(a[t][0], wfr[sK][1], gb[t][1]);
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) gs[t][0] = X3_MFMA(a[t][1], wfr[sK][1], gs[t][0]);
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) gb[t][0] = X3_MFMA(a[t][0], wfr[sK][0], gb[t][0]);
+          }
+          BP_STAMP(3);
+          x3_drain(gb[0][0], gs[0][0], gb[0][1], gs[0][1]);
+          x3_drain(gb[1][0], gs[1][0], gb[1][1], gs[1][1]);
+          // ---- relu mask + LN0 backward (per point = per (kq, r); sums over the 16 channel lanes) ----
+  #pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const f32x4 dh4 = (gb[t][0] + gb[t][1]) + (gs[t][0] + gs[t][1]);
+            const float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float g = h1v[t][r] > 0.0f ? dh[r] : 0.0f;
+              gbi += g;
+              gsc = fmaf(g, xh[t][r], gsc);
+              const float dxh = g * g0;
+              const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[t][r]) * (1.0f / 16.0f);
+              dxv[t][r] = rs[t][r] * (dxh - s1 - xh[t][r] * s2);
+              gbc += dxv[t][r];
+            }
+          }
+          BP_STAMP(4);
+          // hand h1 and dx of the 32 samples to the consumers as bf16 planes: K slot j = sample 16 (j >> 2) + 4 kq + (j & 3),
+          // i.e. exactly this lane's eight values -- lane-contiguous 16-B stores, already in MFMA operand layout
+          const X3Frag fh = x3_split8(f32x4{h1v[0][0], h1v[0][1], h1v[0][2], h1v[0][3]}, f32x4{h1v[1][0], h1v[1][1], h1v[1][2], h1v[1][3]});
+          const X3Frag fd = x3_split8(f32x4{dxv[0][0], dxv[0][1], dxv[0][2], dxv[0][3]}, f32x4{dxv[1][0], dxv[1][1], dxv[1][2], dxv[1][3]});
+          u32x4 *ex = s_ex + (((js & 1) * 4 + (wave & 3)) * 6) * 64 + lane;
+          ex[0] = fh.h; ex[64] = fh.m; ex[128] = fh.l; ex[192] = fd.h; ex[256] = fd.m; ex[320] = fd.l;
+          BP_STAMP(5);
+
+      }
+      __syncthreads();
+      BP_STAMP(6);
+    }
+  } else {
+    // =========================== consumer state (waves 4..7: position pair x half of the outputs) ===========================
+    const int bt = tid - 4 * 64;   // bt: thread index among the 256 consumer threads
+  #pragma unroll
+    for (int q = 0; q < 2; ++q) {
+  #pragma unroll
+      for (int c = 0; c < 4; ++c) dw[q][c] = zero4;
+  #pragma unroll
+      for (int j = 0; j < RBH; ++j) cw[q][j] = zero4;
+    }
+    int kyL[RBH], shL[RBH];
+  #pragma unroll
+    for (int j = 0; j < RBH; ++j) {
+      const int rb = ohalf * RBH + j, k = 16 * rb + ch;
+      kyL[j] = (rb < NRB && k < 9 * C) ? k / RB : 0;
+      shL[j] = (rb < NRB && k < 9 * C) ? k % RB : 31;
+    }
+    // the consumers also move the dz planes: per iteration dzA of the NEXT super-tile (for the producers) and dzB of the
+    // CURRENT one (for themselves, one iteration later); 3072 16-B chunks over 256 threads, unconditional (clamped)
+    u32x4 pf[12];
+    const u32x4 *pfa[6], *pfb[6];     // chunk addresses at super-tile 0; a super-tile advances dzA by 512 and dzB by 1536 chunks
 #pragma unroll
-      for (int c0 = 0; c0 < 8; c0 += 4) {
-        u32x2 bh[4], bm[4], bl[4];
+    for (int q = 0; q < 6; ++q) {
+      const int c = bt + 256 * q;
+      pfa[q] = dza + (size_t)(c >> 9) * pa + (c & 511);
+      pfb[q] = dzbg + c;
+    }
+    auto pf_load = [&](int js) {
+      const int ja = min(js + 1, nsuper - 1), jb = min(js, nsuper - 1);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const u32x2 *bq = ldB + (c0 + c) * 3 * 64;
-          bh[c] = bq[0]; bm[c] = bq[64]; bl[c] = bq[128];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.l, bh[c], dw[c0 + c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.h, bl[c], dw[c0 + c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.m, bm[c], dw[c0 + c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.m, bh[c], dw[c0 + c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.h, bm[c], dw[c0 + c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dw[c0 + c] = x3_mfma16_tied(ah.h, bh[c], dw[c0 + c]);
+      for (int q = 0; q < 6; ++q) {
+        pf[q] = pfa[q][(size_t)ja * 512];
+        pf[6 + q] = pfb[q][(size_t)jb * 1536];
+      }
+    };
+    auto pf_store = [&](int js) {
+      u32x4 *da = s_dza + ((js + 1) & 1) * 1536, *db = s_dzb + (js & 1) * 1536;
+  #pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int c = bt + 256 * q, r = c & 511, smp = r >> 4, quad = r & 15;
+        da[((c >> 9) * 32 + smp) * 16 + (quad ^ (smp & 15))] = pf[q];
+        db[c] = pf[6 + q];
+      }
+    };
+    {   // prologue: dzA of super-tile 0
+  #pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int c = bt + 256 * q, r = c & 511, smp = r >> 4, quad = r & 15;
+        s_dza[((c >> 9) * 32 + smp) * 16 + (quad ^ (smp & 15))] = dza[(size_t)(c >> 9) * pa + r];
       }
     }
-    // the next super-tile: registers -> the other LDS buffer (last read one iteration ago), and the one after that goes out
-    pf_store((js + 1) & 1);
-    pf_load(js + 2);
     __syncthreads();
-  }
-  // ---- epilogue: fold the two tile parities of each position, write the fc1 block in kernel (fragment) layout ----
-#pragma unroll
-  for (int c = 0; c < 8; c += 4) x3_drain(dw[c], dw[c + 1], dw[c + 2], dw[c + 3]);
-  f32x4 *fold = reinterpret_cast<f32x4 *>(s_fold);
-  if (par == 1) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) fold[((wave & 3) * 8 + c) * 64 + lane] = dw[c];
-  }
-  __syncthreads();
-  if (par == 0) {
-    f32x4 *out = reinterpret_cast<f32x4 *>(w1out);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) out[(p * 8 + c) * 64 + lane] = dw[c] + fold[((wave & 3) * 8 + c) * 64 + lane];
-  }
-  __syncthreads();
-  // conv kernel / bias / ln0 partials of the 8 waves -> LDS, summed in fixed order
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) x3_drain(cw[j]);
-  float *part = s_fold;   // [wave][CONVBLK]
-  gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
-  gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
-  gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) {
-    const f32x4 a = cw[j] * (0.5f / 255.0f);
-    const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = 16 * j + 4 * kq + r;
-      if (k < Cfg::KW) part[wave * CONVBLK + k * 16 + ch] = av[r];
+#pragma unroll 1
+    for (int js = 0; js <= nsuper; ++js) {
+        BP_STAMP(0);
+        pf_load(js);
+        BP_STAMP(1);
+        if (js >= 1) {
+          const int jb = (js - 1) & 1;
+          const u32x4 *ldB = s_dzb + jb * 1536 + lane;                         // + (cb * 3 + pl) * 64
+  #pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int pos = 2 * pp + q;
+            const u32x4 *ex = s_ex + ((jb * 4 + pos) * 6) * 64 + lane;
+            // ---- dW1[feature][o] += sum over the 32 samples of h1[sample][feature] dz[sample][o] ----
+            const u32x4 ahh = ex[0], ahm = ex[64], ahl = ex[128];
+            u32x4 bh[4], bm[4], bl[4];
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const u32x4 *bq = ldB + ((4 * ohalf + c) * 3) * 64;
+              bh[c] = bq[0]; bm[c] = bq[64]; bl[c] = bq[128];
+            }
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahl, bh[c], dw[q][c]);
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahh, bl[c], dw[q][c]);
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahm, bm[c], dw[q][c]);
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahm, bh[c], dw[q][c]);
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahh, bm[c], dw[q][c]);
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahh, bh[c], dw[q][c]);
+            if (q == 1) BP_STAMP(2);
+            // ---- conv weight gradient: dWc[k][ch] += sum_samples bit(sample, k) dx[sample][ch] ----
+            const u32x4 dxh_ = ex[192], dxm_ = ex[256], dxl_ = ex[320];
+            const uint32_t *mw = s_mk + ((jb * 4 + pos) * 32) * 4;
+            u32x4 fa[RBH];
+  #pragma unroll
+            for (int j = 0; j < RBH; ++j) {
+              uint32_t d[4];
+  #pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {           // K slots 2 jj, 2 jj + 1: samples 16 (jj >> 1) + 4 kq + 2 (jj & 1) + {0, 1}
+                const int s0 = 16 * (jj >> 1) + 4 * kq + 2 * (jj & 1);
+                const uint32_t b0_ = __builtin_amdgcn_ubfe(mw[s0 * 4 + kyL[j]], (uint32_t)shL[j], 1u);
+                const uint32_t b1_ = __builtin_amdgcn_ubfe(mw[(s0 + 1) * 4 + kyL[j]], (uint32_t)shL[j], 1u);
+                d[jj] = ((b1_ << 16) | b0_) << 14;       // bit as bf16 2.0
+              }
+              fa[j] = u32x4{d[0], d[1], d[2], d[3]};
+            }
+  #pragma unroll
+            for (int j = 0; j < RBH; ++j) cw[q][j] = X3_MFMA(fa[j], dxl_, cw[q][j]);
+  #pragma unroll
+            for (int j = 0; j < RBH; ++j) cw[q][j] = X3_MFMA(fa[j], dxm_, cw[q][j]);
+  #pragma unroll
+            for (int j = 0; j < RBH; ++j) cw[q][j] = X3_MFMA(fa[j], dxh_, cw[q][j]);
+          }
+        }
+        BP_STAMP(3);
+        pf_store(js);
+        BP_STAMP(4);
+
+      __syncthreads();
+      BP_STAMP(5);
     }
   }
-  if (lane < 16) {
-    part[wave * CONVBLK + Cfg::KW * 16 + lane] = gbc;
-    part[wave * CONVBLK + Cfg::KW * 16 + 16 + lane] = gsc;
-    part[wave * CONVBLK + Cfg::KW * 16 + 32 + lane] = gbi;
+  // ---- epilogue ----
+  float *part = reinterpret_cast<float *>(bp_smem);   // [4 pos][CONVBLK] conv / LN0 partials (the dz buffers are dead)
+  if (front) {
+    gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
+    gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
+    gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
+    if (lane < 16) {
+      float *pr = part + (wave & 3) * CONVBLK + Cfg::KW * 16;
+      pr[lane] = gbc; pr[16 + lane] = gsc; pr[32 + lane] = gbi;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      x3_drain(dw[q][0], dw[q][1], dw[q][2], dw[q][3]);
+      const int pos = 4 * pg + 2 * pp + q;
+      f32x4 *out = reinterpret_cast<f32x4 *>(w1out);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[(pos * 8 + 4 * ohalf + c) * 64 + lane] = dw[q][c];   // fc1 block, kernel (fragment) layout
+#pragma unroll
+      for (int j = 0; j < RBH; ++j) {
+        x3_drain(cw[q][j]);
+        const int rb = ohalf * RBH + j;
+        const f32x4 a = cw[q][j] * (0.5f / 255.0f);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * rb + 4 * kq + r;
+          if (rb < NRB && k < Cfg::KW) part[(2 * pp + q) * CONVBLK + k * 16 + ch] = av[r];
+        }
+      }
+    }
   }
   __syncthreads();
-  for (int e = tid; e < CONVBLK; e += QN_THREADS) {
-    float acc = 0.f;
-#pragma unroll
-    for (int w = 0; w < QN_WAVES; ++w) acc += part[w * CONVBLK + e];
-    gpos[(size_t)pg * CONVBLK + e] = acc;
-  }
+  for (int e = tid; e < CONVBLK; e += QN_THREADS)
+    gpos[(size_t)pg * CONVBLK + e] = (part[e] + part[CONVBLK + e]) + (part[2 * CONVBLK + e] + part[3 * CONVBLK + e]);
 }
 
 // ---------------------------------------------------------------------------
@@ -2981,10 +3080,13 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
     if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
     if (use_pos) {
+      if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
+        if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;
+      }
       hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
                          action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
       hipLaunchKernelGGL(qnet_cnn_bwd_pos_kernel<C>, dim3(16, gs), dim3(QN_THREADS), bwd_pos_lds_bytes<C>(), st, nb, idx, bits, theta, L,
-                         reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg);
+                         reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg, g_t2_stamps);
       if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
       continue;   // no T2: dW1 was accumulated in registers
     } else if (use_pair)

@@ -347,3 +347,23 @@ def test_pair_form_of_the_training_kernel_at_small_sizes(gpu):
         rep = float(re.search(r"rep-to-rep max\|dg\| ([0-9.e+-]+)", l).group(1))
         dif = float(re.search(r"max\|g_x3 - g_f32\| ([0-9.e+-]+)", l).group(1))
         assert rep == 0.0 and dif < 2e-5, l
+
+
+def test_position_parallel_backward_opt_in_path(gpu):
+    """PQN_BWD_POS=2 (with the pair kernel forced) routes the 4096-sample case through the forward-only pair kernel +
+    qnet_cnn_bwd_pos_kernel + the reduction without split-K slabs: repeats bit-identical, gradient
+    equal to the f32-MFMA mode of the default kernels to f32 rounding.  Opt-in path (it is not faster yet), kept tested."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PQN_T1_PAIR="2", PQN_BWD_POS="2", BRIEF="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_x3_conv.py")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [l for l in out.stdout.splitlines() if l.startswith("C 4 nb 4096")]
+    assert len(rows) == 1, out.stdout
+    rep = float(re.search(r"rep-to-rep max\|dg\| ([0-9.e+-]+)", rows[0]).group(1))
+    dif = float(re.search(r"max\|g_x3 - g_f32\| ([0-9.e+-]+)", rows[0]).group(1))
+    assert rep == 0.0 and dif < 2e-5, rows[0]
