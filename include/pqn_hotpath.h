@@ -53,6 +53,7 @@ enum {
   PQN_ENV_SPACEINVADERS = 4, /* "SpaceInvaders-MinAtar" */
   PQN_ENV_CRAFTAX_CLASSIC = 5, /* "Craftax-Classic-Symbolic-v1": flat symbolic observation f32[1345], 17 actions
                                   (make_craftax_env_from_name, pqn_craftax.py:96-98; rules restated, csrc/pqn_craftax.hip) */
+  PQN_ENV_ACROBOT = 6,       /* "Acrobot-v1": the alternative env named in config/alg/pqn_cartpole.yaml:24; f32[6], 3 actions */
 };
 
 /* What gymnax.make(name) -> (env, env_params) exposes to make_train

@@ -249,6 +249,89 @@ static void cartpole_step_one(int32_t *si, float *sf, int32_t action, int32_t ma
 
 
 /* ------------------------------------------------------------------------ */
+/* Acrobot-v1 (gymnax 0.0.6 environments/classic_control/acrobot.py [3P-RECALL]: the "book" dynamics of Sutton &
+ * Barto integrated with one RK4 step of dt = 0.2, torque in {-1, 0, +1}, no torque noise, angles wrapped to
+ * [-pi, pi), velocities clipped to 4 pi / 9 pi, reward -1 until -cos(t1) - cos(t1 + t2) > 1, 500 steps).
+ * Canonical state: sf = [theta1, theta2, dtheta1, dtheta2], si = [time].  Every sin / cos is oracle_sincos_f32 and
+ * every expression is spelled out operation by operation (the HIP rule repeats them verbatim; both are compiled with
+ * -ffp-contract=off), so the trajectories are bit-exact across the two implementations. */
+/* ------------------------------------------------------------------------ */
+static void acrobot_reset_one(uint64_t key, uint32_t e, int32_t *si, float *sf) {
+  /* uniform(minval=-0.1, maxval=0.1, shape=(4,)) */
+  uint32_t o[2];
+  pqn_oracle_env_bits(key, e, 1u, o);
+  sf[0] = pqn_oracle_bits_to_uniform(o[0]) * 0.2f - 0.1f;
+  sf[1] = pqn_oracle_bits_to_uniform(o[1]) * 0.2f - 0.1f;
+  pqn_oracle_env_bits(key, e, 2u, o);
+  sf[2] = pqn_oracle_bits_to_uniform(o[0]) * 0.2f - 0.1f;
+  sf[3] = pqn_oracle_bits_to_uniform(o[1]) * 0.2f - 0.1f;
+  si[0] = 0;
+}
+
+static void acrobot_dsdt(const float *y, float a, float *dy) {
+  /* m1 = m2 = 1, l1 = 1, lc1 = lc2 = 0.5, I1 = I2 = 1, g = 9.8 */
+  const float half_pi = 1.57079632679489661923f;
+  const float t1 = y[0], t2 = y[1], w1 = y[2], w2 = y[3];
+  float s2, c2, su, c12, c1;
+  oracle_sincos_f32(t2, &s2, &c2);
+  oracle_sincos_f32((t1 + t2) - half_pi, &su, &c12);
+  oracle_sincos_f32(t1 - half_pi, &su, &c1);
+  const float d1 = (0.25f + (1.25f + c2)) + 2.0f;          /* m1 lc1^2 + m2 (l1^2 + lc2^2 + 2 l1 lc2 cos t2) + I1 + I2 */
+  const float d2 = (0.25f + 0.5f * c2) + 1.0f;             /* m2 (lc2^2 + l1 lc2 cos t2) + I2 */
+  const float phi2 = 4.9f * c12;                           /* m2 lc2 g cos(t1 + t2 - pi/2) */
+  const float phi1 = (((-0.5f * (w2 * w2)) * s2 - ((1.0f * w2) * w1) * s2) + 14.7f * c1) + phi2;
+  const float dd2 = (((a + (d2 / d1) * phi1) - (0.5f * (w1 * w1)) * s2) - phi2) / (1.25f - (d2 * d2) / d1);
+  const float dd1 = -((d2 * dd2 + phi1) / d1);
+  dy[0] = w1; dy[1] = w2; dy[2] = dd1; dy[3] = dd2;
+}
+
+static float acrobot_wrap(float x) {   /* gymnax wrap(x, -pi, pi) */
+  const float m = -3.14159265358979323846f, M = 3.14159265358979323846f, diff = M - m;
+  const int up = x < m, down = x >= M;
+  const float how = (float)up * ceilf((m - x) / diff) + (float)down * floorf((x - M) / diff + 1.0f);
+  return (x - (how * diff) * (float)down) + (how * diff) * (float)up;
+}
+
+static int acrobot_done_angle(const float *sf) {
+  float s, c1, c12;
+  oracle_sincos_f32(sf[0], &s, &c1);
+  oracle_sincos_f32(sf[1] + sf[0], &s, &c12);
+  return (-c1 - c12) > 1.0f;
+}
+
+static void acrobot_step_one(int32_t *si, float *sf, int32_t action, int32_t max_steps, float *reward, int *done) {
+  const float dt = 0.2f, a = (float)(action - 1);
+  float k1[4], k2[4], k3[4], k4[4], y[4];
+  int i;
+  acrobot_dsdt(sf, a, k1);
+  for (i = 0; i < 4; ++i) y[i] = sf[i] + (dt * 0.5f) * k1[i];
+  acrobot_dsdt(y, a, k2);
+  for (i = 0; i < 4; ++i) y[i] = sf[i] + (dt * 0.5f) * k2[i];
+  acrobot_dsdt(y, a, k3);
+  for (i = 0; i < 4; ++i) y[i] = sf[i] + dt * k3[i];
+  acrobot_dsdt(y, a, k4);
+  for (i = 0; i < 4; ++i) y[i] = sf[i] + (dt / 6.0f) * (((k1[i] + 2.0f * k2[i]) + 2.0f * k3[i]) + k4[i]);
+  sf[0] = acrobot_wrap(y[0]);
+  sf[1] = acrobot_wrap(y[1]);
+  sf[2] = fminf(fmaxf(y[2], -12.566370614359172f), 12.566370614359172f);    /* 4 pi */
+  sf[3] = fminf(fmaxf(y[3], -28.274333882308138f), 28.274333882308138f);    /* 9 pi */
+  const int da = acrobot_done_angle(sf);
+  *reward = -1.0f * (float)(1 - da);
+  si[0] += 1;
+  *done = da || (si[0] >= max_steps);
+}
+
+static void acrobot_obs_one(const float *sf, float *obs) {
+  float s, c;
+  oracle_sincos_f32(sf[0], &s, &c);
+  obs[0] = c; obs[1] = s;
+  oracle_sincos_f32(sf[1], &s, &c);
+  obs[2] = c; obs[3] = s;
+  obs[4] = sf[2]; obs[5] = sf[3];
+}
+
+
+/* ------------------------------------------------------------------------ */
 /* Asterix-MinAtar (rules: MinAtar asterix.py, Young & Tian 2019; gymnax 0.0.6 mirrors them with
  * selects).  Canonical int state, 43 words: [0] player_x [1] player_y [2] shot_timer [3] spawn_speed
  * [4] spawn_timer [5] move_speed [6] move_timer [7] ramp_timer [8] ramp_index [9] time [10] terminal
@@ -492,6 +575,11 @@ int pqn_oracle_env_spec(int env_id, pqn_oracle_spec_t *spec) {
       spec->obs_size = 4; spec->num_actions = 2; spec->max_steps = 500;
       spec->si = 1; spec->sf = 4;
       return 0;
+    case PQN_ORACLE_ENV_ACROBOT:
+      spec->obs_dim[0] = 6; spec->obs_dim[1] = 0; spec->obs_dim[2] = 0;
+      spec->obs_size = 6; spec->num_actions = 3; spec->max_steps = 500;
+      spec->si = 1; spec->sf = 4;
+      return 0;
     case PQN_ORACLE_ENV_ASTERIX:
       spec->obs_dim[0] = 10; spec->obs_dim[1] = 10; spec->obs_dim[2] = 4;
       spec->obs_size = 400; spec->num_actions = 5; spec->max_steps = 1000; spec->si = AX_SI; spec->sf = 0;
@@ -521,6 +609,7 @@ float cc_step_env(int32_t *si, float *sf, int32_t action, uint64_t key, uint32_t
 static void obs_one(int env_id, const int32_t *si, const float *sf, float *obs) {
   if (env_id == PQN_ORACLE_ENV_BREAKOUT) breakout_obs_one(si, obs);
   else if (env_id == PQN_ORACLE_ENV_CARTPOLE) memcpy(obs, sf, 4 * sizeof(float));
+  else if (env_id == PQN_ORACLE_ENV_ACROBOT) acrobot_obs_one(sf, obs);
   else if (env_id == PQN_ORACLE_ENV_ASTERIX) asterix_obs_one(si, obs);
   else if (env_id == PQN_ORACLE_ENV_FREEWAY) freeway_obs_one(si, obs);
   else if (env_id == PQN_ORACLE_ENV_SPACEINVADERS) si_obs_one(si, obs);
@@ -534,6 +623,8 @@ static void reset_one(int env_id, uint64_t key, uint32_t e, int32_t *si, float *
     breakout_reset_one(o[0], si);
   } else if (env_id == PQN_ORACLE_ENV_CARTPOLE) {
     cartpole_reset_one(key, e, si, sf);
+  } else if (env_id == PQN_ORACLE_ENV_ACROBOT) {
+    acrobot_reset_one(key, e, si, sf);
   } else if (env_id == PQN_ORACLE_ENV_ASTERIX) {
     asterix_reset_one(si);
   } else if (env_id == PQN_ORACLE_ENV_FREEWAY) {
@@ -583,6 +674,7 @@ int pqn_oracle_env_step(int env_id, int32_t n, uint64_t key, int32_t *si, float 
     int d = 0;
     if (env_id == PQN_ORACLE_ENV_BREAKOUT) breakout_step_one(s, action[e], sp.max_steps, &r, &d);
     else if (env_id == PQN_ORACLE_ENV_CARTPOLE) cartpole_step_one(s, f, action[e], sp.max_steps, &r, &d);
+    else if (env_id == PQN_ORACLE_ENV_ACROBOT) acrobot_step_one(s, f, action[e], sp.max_steps, &r, &d);
     else if (env_id == PQN_ORACLE_ENV_ASTERIX) asterix_step_one(s, action[e], key, (uint32_t)e, sp.max_steps, &r, &d);
     else if (env_id == PQN_ORACLE_ENV_FREEWAY) freeway_step_one(s, action[e], key, (uint32_t)e, sp.max_steps, &r, &d);
     else if (env_id == PQN_ORACLE_ENV_CRAFTAX_CLASSIC) r = cc_step_env(s, f, action[e], key, (uint32_t)e, &d);

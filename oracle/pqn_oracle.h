@@ -37,6 +37,7 @@ enum {
   PQN_ORACLE_ENV_FREEWAY = 3,       /* Freeway-MinAtar       */
   PQN_ORACLE_ENV_SPACEINVADERS = 4, /* SpaceInvaders-MinAtar */
   PQN_ORACLE_ENV_CRAFTAX_CLASSIC = 5, /* Craftax-Classic-Symbolic-v1 (craftax_classic.c; third-party rules, parity unpinned) */
+  PQN_ORACLE_ENV_ACROBOT = 6,       /* Acrobot-v1 (the alternative env of config/alg/pqn_cartpole.yaml:24) */
 };
 
 typedef struct {

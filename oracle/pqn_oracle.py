@@ -32,7 +32,7 @@ _LIB_PATH = os.path.join(_HERE, "libpqn_oracle.so")
 _lib = None
 
 ENV_IDS = {"Breakout-MinAtar": 0, "CartPole-v1": 1, "Asterix-MinAtar": 2, "Freeway-MinAtar": 3,
-           "SpaceInvaders-MinAtar": 4, "Craftax-Classic-Symbolic-v1": 5}
+           "SpaceInvaders-MinAtar": 4, "Craftax-Classic-Symbolic-v1": 5, "Acrobot-v1": 6}
 
 
 class Spec(C.Structure):

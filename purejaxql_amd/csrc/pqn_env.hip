@@ -187,8 +187,13 @@ __global__ __launch_bounds__(256) void flat_kernel(int n, uint64_t key, const ui
   if (out.obs) {
     float o[Env::OBS_SIZE];
     env.obs_f32(o);
-    static_assert(Env::OBS_SIZE == 4, "float4 store assumes 4 floats");
-    reinterpret_cast<float4 *>(out.obs)[e] = make_float4(o[0], o[1], o[2], o[3]);
+    if constexpr (Env::OBS_SIZE == 4) reinterpret_cast<float4 *>(out.obs)[e] = make_float4(o[0], o[1], o[2], o[3]);
+    else {
+      static_assert(Env::OBS_SIZE % 2 == 0, "float2 stores");
+#pragma unroll
+      for (int i = 0; i < Env::OBS_SIZE / 2; ++i)
+        reinterpret_cast<float2 *>(out.obs)[(size_t)e * (Env::OBS_SIZE / 2) + i] = make_float2(o[2 * i], o[2 * i + 1]);
+    }
   }
 }
 
@@ -237,6 +242,7 @@ extern "C" int pqn_env_id(const char *name) {
   if (!strcmp(name, "Freeway-MinAtar")) return PQN_ENV_FREEWAY;
   if (!strcmp(name, "SpaceInvaders-MinAtar")) return PQN_ENV_SPACEINVADERS;
   if (!strcmp(name, "Craftax-Classic-Symbolic-v1")) return PQN_ENV_CRAFTAX_CLASSIC;
+  if (!strcmp(name, "Acrobot-v1")) return PQN_ENV_ACROBOT;
   pqn_set_error("unknown or unsupported env name '%s'", name);
   return PQN_E_UNSUPPORTED;
 }
@@ -250,6 +256,7 @@ extern "C" int pqn_env_spec(int env_id, pqn_env_spec_t *spec) {
     case PQN_ENV_FREEWAY: fill_spec<Freeway>(spec, 10, 10, 7); return PQN_OK;
     case PQN_ENV_SPACEINVADERS: fill_spec<SpaceInvaders>(spec, 10, 10, 6); return PQN_OK;
     case PQN_ENV_CRAFTAX_CLASSIC: pqn_craftax_spec(spec); return PQN_OK;
+    case PQN_ENV_ACROBOT: fill_spec<Acrobot>(spec, 6, 0, 0); return PQN_OK;
     default: pqn_set_error("pqn_env_spec: unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
   }
 }
@@ -272,7 +279,7 @@ template <bool IS_RESET>
 static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, float rscale, const uint32_t *si,
                     uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0,
                     int key_stride = 0, uint64_t *opt_keys = nullptr) {
-  if (n_per_seed > 0 && env_id != PQN_ENV_CARTPOLE) {
+  if (n_per_seed > 0 && env_id != PQN_ENV_CARTPOLE && env_id != PQN_ENV_ACROBOT) {
     pqn_set_error("seed-batched env.step is implemented for the flat-observation envs (the MinAtar path batches seeds "
                   "inside pqn_cnn_rollout_seeds)");
     return PQN_E_UNSUPPORTED;
@@ -293,6 +300,11 @@ static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, fl
     case PQN_ENV_CARTPOLE:
       PQN_REQUIRE(out.obs_bits == nullptr, "CartPole-v1 has no packed observation");
       hipLaunchKernelGGL((flat_kernel<CartPole, IS_RESET>), dim3((n + 255) / 256), dim3(256), 0, st, n, key, key_dev, rscale,
+                         si, so, action, out, n_per_seed, key_stride, opt_keys);
+      break;
+    case PQN_ENV_ACROBOT:
+      PQN_REQUIRE(out.obs_bits == nullptr, "Acrobot-v1 has no packed observation");
+      hipLaunchKernelGGL((flat_kernel<Acrobot, IS_RESET>), dim3((n + 255) / 256), dim3(256), 0, st, n, key, key_dev, rscale,
                          si, so, action, out, n_per_seed, key_stride, opt_keys);
       break;
     default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
@@ -340,6 +352,7 @@ extern "C" int pqn_env_step_optimistic(int env_id, int32_t n, uint64_t key, int3
     case PQN_ENV_FREEWAY: hipLaunchKernelGGL((opt_reset_kernel<Freeway, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
     case PQN_ENV_SPACEINVADERS: hipLaunchKernelGGL((opt_reset_kernel<SpaceInvaders, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
     case PQN_ENV_CARTPOLE: hipLaunchKernelGGL((opt_reset_kernel<CartPole, false>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
+    case PQN_ENV_ACROBOT: hipLaunchKernelGGL((opt_reset_kernel<Acrobot, false>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
     default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
   }
   return pqn_check_launch("pqn_env_step_optimistic");
@@ -366,6 +379,10 @@ static int canon(int env_id, int n, uint32_t *state, int32_t *si, float *sf, uin
     case PQN_ENV_CARTPOLE:
       PQN_REQUIRE(sf, "CartPole-v1 canonical state needs sf");
       hipLaunchKernelGGL((canon_kernel<CartPole, EXPORT>), g, b, 0, st, n, state, si, sf, log);
+      break;
+    case PQN_ENV_ACROBOT:
+      PQN_REQUIRE(sf, "Acrobot-v1 canonical state needs sf");
+      hipLaunchKernelGGL((canon_kernel<Acrobot, EXPORT>), g, b, 0, st, n, state, si, sf, log);
       break;
     default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
   }

@@ -636,6 +636,112 @@ struct CartPole {
 };
 
 // ===========================================================================
+// Acrobot-v1 (gymnax 0.0.6 environments/classic_control/acrobot.py [3P-RECALL]; the alternative env named in the
+// reference's config/alg/pqn_cartpole.yaml:24).  "Book" dynamics, one RK4 step of dt = 0.2, torque in {-1, 0, +1}, no
+// torque noise, angles wrapped to [-pi, pi), velocities clipped to 4 pi / 9 pi, reward -1 until
+// -cos(t1) - cos(t1 + t2) > 1, 500 steps.  Every expression is the oracle's (oracle/pqn_oracle.c acrobot_*), operation
+// by operation, on the shared pqn_sincos_f32: bit-exact trajectories.
+// ===========================================================================
+struct Acrobot {
+  static constexpr int ENV_WORDS = 5;
+  static constexpr int OBS_SIZE = 6;
+  static constexpr int OBS_WORDS = 0;
+  static constexpr int NUM_ACTIONS = 3;
+  static constexpr int MAX_STEPS = 500;
+  static constexpr int CANON_SI = 1;
+  static constexpr int CANON_SF = 4;
+
+  float y[4];   // theta1, theta2, dtheta1, dtheta2
+  int time;
+
+  PQN_D void unpack(const uint32_t *w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = __uint_as_float(w[i]);
+    time = (int)w[4];
+  }
+  PQN_D void pack(uint32_t *w) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = __float_as_uint(y[i]);
+    w[4] = (uint32_t)time;
+  }
+  PQN_D void reset(uint64_t key, uint32_t e) {
+    uint32_t a0, a1, b0, b1;
+    pqn_bits(key, e, PQN_STREAM_RESET, a0, a1);
+    pqn_bits(key, e, PQN_STREAM_RESET2, b0, b1);
+    y[0] = pqn_uniform(a0) * 0.2f - 0.1f;
+    y[1] = pqn_uniform(a1) * 0.2f - 0.1f;
+    y[2] = pqn_uniform(b0) * 0.2f - 0.1f;
+    y[3] = pqn_uniform(b1) * 0.2f - 0.1f;
+    time = 0;
+  }
+  static PQN_D void dsdt(const float *q, float a, float *dq) {
+    const float half_pi = 1.57079632679489661923f;
+    const float t1 = q[0], t2 = q[1], w1 = q[2], w2 = q[3];
+    float s2, c2, su, c12, c1;
+    pqn_sincos_f32(t2, s2, c2);
+    pqn_sincos_f32((t1 + t2) - half_pi, su, c12);
+    pqn_sincos_f32(t1 - half_pi, su, c1);
+    const float d1 = (0.25f + (1.25f + c2)) + 2.0f;
+    const float d2 = (0.25f + 0.5f * c2) + 1.0f;
+    const float phi2 = 4.9f * c12;
+    const float phi1 = (((-0.5f * (w2 * w2)) * s2 - ((1.0f * w2) * w1) * s2) + 14.7f * c1) + phi2;
+    const float dd2 = (((a + (d2 / d1) * phi1) - (0.5f * (w1 * w1)) * s2) - phi2) / (1.25f - (d2 * d2) / d1);
+    const float dd1 = -((d2 * dd2 + phi1) / d1);
+    dq[0] = w1; dq[1] = w2; dq[2] = dd1; dq[3] = dd2;
+  }
+  static PQN_D float wrap(float x) {
+    const float m = -3.14159265358979323846f, M = 3.14159265358979323846f, diff = M - m;
+    const int up = x < m, down = x >= M;
+    const float how = (float)up * ceilf((m - x) / diff) + (float)down * floorf((x - M) / diff + 1.0f);
+    return (x - (how * diff) * (float)down) + (how * diff) * (float)up;
+  }
+  PQN_D int done_angle() const {
+    float s, c1, c12;
+    pqn_sincos_f32(y[0], s, c1);
+    pqn_sincos_f32(y[1] + y[0], s, c12);
+    return (-c1 - c12) > 1.0f;
+  }
+  PQN_D float step(int action, uint64_t, uint32_t, int &done) {
+    const float dt = 0.2f, a = (float)(action - 1);
+    float k1[4], k2[4], k3[4], k4[4], q[4];
+    dsdt(y, a, k1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = y[i] + (dt * 0.5f) * k1[i];
+    dsdt(q, a, k2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = y[i] + (dt * 0.5f) * k2[i];
+    dsdt(q, a, k3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = y[i] + dt * k3[i];
+    dsdt(q, a, k4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = y[i] + (dt / 6.0f) * (((k1[i] + 2.0f * k2[i]) + 2.0f * k3[i]) + k4[i]);
+    y[0] = wrap(q[0]);
+    y[1] = wrap(q[1]);
+    y[2] = fminf(fmaxf(q[2], -12.566370614359172f), 12.566370614359172f);
+    y[3] = fminf(fmaxf(q[3], -28.274333882308138f), 28.274333882308138f);
+    const int da = done_angle();
+    time += 1;
+    done = da | (time >= MAX_STEPS);
+    return -1.0f * (float)(1 - da);
+  }
+  PQN_D void obs_f32(float *o) const {
+    float s, c;
+    pqn_sincos_f32(y[0], s, c);
+    o[0] = c; o[1] = s;
+    pqn_sincos_f32(y[1], s, c);
+    o[2] = c; o[3] = s;
+    o[4] = y[2]; o[5] = y[3];
+  }
+  PQN_D void to_canon(int32_t *si, float *sf) const {
+    si[0] = time; sf[0] = y[0]; sf[1] = y[1]; sf[2] = y[2]; sf[3] = y[3];
+  }
+  PQN_D void from_canon(const int32_t *si, const float *sf) {
+    time = si[0]; y[0] = sf[0]; y[1] = sf[1]; y[2] = sf[2]; y[3] = sf[3];
+  }
+};
+
+// ===========================================================================
 // LogWrapper record (utils/craftax_wrappers.py:151-200), fused into the step.
 // ===========================================================================
 struct LogRec {

@@ -73,7 +73,7 @@ def test_unknown_env_is_an_error():
     from purejaxql_amd import _lib
     lib = _lib.load()
     for i, name in enumerate([b"Breakout-MinAtar", b"CartPole-v1", b"Asterix-MinAtar", b"Freeway-MinAtar",
-                              b"SpaceInvaders-MinAtar"]):
+                              b"SpaceInvaders-MinAtar", b"Craftax-Classic-Symbolic-v1", b"Acrobot-v1"]):
         assert lib.pqn_env_id(name) == i
     assert lib.pqn_env_id(b"Seaquest-MinAtar") < 0      # gymnax 0.0.6 cannot make it either
     assert lib.pqn_env_id(b"Pong-v5") < 0

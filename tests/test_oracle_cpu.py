@@ -168,6 +168,35 @@ def test_cartpole_oracle_basic(oracle):
     assert done_seen > 64 and info["returned_episode_lengths"].max() < 100
 
 
+def test_acrobot_oracle_basic(oracle):
+    """Acrobot-v1 restatement (gymnax acrobot.py, book dynamics + RK4): reset range, observation layout, the -1 reward,
+    the 500-step time limit under zero torque (a hanging acrobot that is barely perturbed never reaches the goal
+    height), energy sanity (zero torque from rest at small angles keeps |theta| small), and that pumping the second
+    joint in phase with its velocity does reach the goal."""
+    env = oracle.OracleEnv("Acrobot-v1")
+    n = 64
+    obs, st = env.reset(11, n)
+    assert obs.shape == (n, 6) and np.abs(st["sf"]).max() <= 0.1
+    np.testing.assert_allclose(obs[:, 0], np.cos(st["sf"][:, 0]), atol=2e-7)
+    np.testing.assert_allclose(obs[:, 3], np.sin(st["sf"][:, 1]), atol=2e-7)
+    lens = []
+    for t in range(501):
+        obs, st, r, d, info = env.step(100 + t, st, np.ones(n, np.int32))      # action 1 = zero torque
+        if t < 499:
+            assert (r == -1.0).all() and not d.any() and np.abs(st["sf"][:, :2]).max() < 0.3
+        if d.any():
+            lens.append(int(info["returned_episode_lengths"][d].max()))
+    assert lens and max(lens) == 500                                            # time limit, auto-reset afterwards
+    # energy pumping: torque along the second joint's velocity swings the tip above the bar
+    obs, st = env.reset(12, n)
+    done_any = np.zeros(n, bool)
+    for t in range(400):
+        a = np.where(st["sf"][:, 3] >= 0, 2, 0).astype(np.int32)
+        obs, st, r, d, info = env.step(300 + t, st, a)
+        done_any |= d
+    assert done_any.mean() > 0.9 and info["returned_episode_lengths"].max() < 400
+
+
 @pytest.mark.parametrize("kind", ["cnn", "mlp"])
 def test_oracle_network_matches_torch_autograd(oracle, kind):
     """numpy fwd/bwd restatement vs plain PyTorch fp32 autograd of the same net."""

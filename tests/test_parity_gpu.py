@@ -191,6 +191,40 @@ def test_cartpole_step_vs_oracle(gpu, oracle):
     assert ost["ret_len"].max() > 5
 
 
+def test_acrobot_step_vs_oracle(gpu, oracle):
+    """Acrobot-v1 (the alternative env of config/alg/pqn_cartpole.yaml:24): RK4 of the book dynamics in f32 on the shared
+    explicit sin / cos -- 1200 free-running steps of 256 envs agree with the oracle in every bit (observations, rewards,
+    dones incl. the 500-step limit and goal terminations under a pumping policy, info, exported state)."""
+    from purejaxql_amd.envs import FlattenObservationWrapper, LogWrapper, make
+    env, params = make("Acrobot-v1", device=gpu)
+    env = LogWrapper(FlattenObservationWrapper(env))
+    assert env.action_space(params).n == 3 and tuple(env.observation_space(params).shape) == (6,)
+    oenv = oracle.OracleEnv("Acrobot-v1")
+    n = 256
+    obs, state = env.reset(3, params, n)
+    oobs, ost = oenv.reset(3, n)
+    np.testing.assert_array_equal(_np(obs), oobs)
+    rng = np.random.default_rng(0)
+    ndone = 0
+    for t in range(1200):
+        a = np.where(ost["sf"][:, 3] >= 0, 2, 0).astype(np.int32)            # pump the second joint ...
+        a[: n // 2] = rng.integers(0, 3, n // 2).astype(np.int32)            # ... half of the envs act randomly
+        obs, state, r, d, info = env.step(900 + t, state, torch.from_numpy(a).to(gpu), params)
+        oobs, ost, orr, od, oinfo = oenv.step(900 + t, ost, a)
+        np.testing.assert_array_equal(_np(d), od, err_msg=f"done t={t}")
+        np.testing.assert_array_equal(_np(obs), oobs, err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(_np(r), orr)
+        ndone += int(od.sum())
+        if t % 100 == 0 or t == 1199:
+            for k in oinfo:
+                np.testing.assert_array_equal(_np(info[k]), oinfo[k], err_msg=k)
+            si, sf, log = env.export_state(state)
+            np.testing.assert_array_equal(_np(si), ost["si"])
+            np.testing.assert_array_equal(_np(sf), ost["sf"])
+            np.testing.assert_array_equal(_np(log).view(np.uint32), oenv.log_words(ost))
+    assert ndone > n                                                          # goal terminations and time limits both occurred
+
+
 @pytest.mark.parametrize("m,a", [(1, 2), (1000, 3), (4096, 3), (70001, 6)])
 def test_eps_greedy_bit_exact(gpu, oracle, m, a):
     from purejaxql_amd import ops
@@ -298,6 +332,8 @@ def test_product_network_vs_oracle_network(gpu, oracle):
     ("pqn_cartpole", "CartPole-v1", {"NUM_ENVS": 4, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
     ("pqn_cartpole", "CartPole-v1", {"NUM_ENVS": 4, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
                                      "_BACKEND": "torch"}),
+    # the alternative env of the reference's pqn_cartpole.yaml (fused MLP kernels, 6-float observation, 3 actions)
+    ("pqn_cartpole", "Acrobot-v1", {"NUM_ENVS": 16, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
 ])
 def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     """Whole loop (rollout + Q(lambda) + minibatch updates) vs the oracle loop from the same
@@ -415,7 +451,8 @@ def test_make_train_norm_variants_vs_oracle(gpu, oracle, alg, env_name, norm_typ
         assert np.abs(_np(bs[k]) - v).max() <= 10 * tol * max(np.abs(v).max(), 1e-3), k   # running moments, per-array scale
 
 
-@pytest.mark.parametrize("name", ["Breakout-MinAtar", "Asterix-MinAtar", "Freeway-MinAtar", "SpaceInvaders-MinAtar", "CartPole-v1"])
+@pytest.mark.parametrize("name", ["Breakout-MinAtar", "Asterix-MinAtar", "Freeway-MinAtar", "SpaceInvaders-MinAtar", "CartPole-v1",
+                                  "Acrobot-v1"])
 def test_hip_envs_hash_to_regression_pins(gpu, name):
     """The HIP env kernels (reset / step / auto-reset / LogWrapper, f32 observation surface) reproduce the committed
     SHA-256 digests of tests/golden/regression_pins.json on the pinned keys and actions -- no oracle in the loop.
@@ -452,7 +489,7 @@ def test_hip_envs_hash_to_regression_pins(gpu, name):
 
 @pytest.mark.parametrize("name,n,ratio,steps", [("Breakout-MinAtar", 1024, 16, 400), ("Asterix-MinAtar", 512, 16, 500),
                                                 ("Breakout-MinAtar", 64, 64, 300), ("Breakout-MinAtar", 48, 1, 200),
-                                                ("CartPole-v1", 256, 8, 300)])
+                                                ("CartPole-v1", 256, 8, 300), ("Acrobot-v1", 128, 8, 700)])
 def test_optimistic_reset_wrapper_bit_exact_vs_oracle(gpu, oracle, name, n, ratio, steps):
     """OptimisticResetVecEnvWrapper(LogWrapper(env)) (utils/craftax_wrappers.py:83-148, wrapper order of
     pqn_craftax.py:99-108) as an option of the HIP step kernels, vs the oracle's restatement: reward / done / info /
