@@ -613,7 +613,11 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
   const int lane = tid & 63, wave = tid >> 6;
   const int kh = wave & 1, cp = wave >> 1;
   if (tile < 0) tile = blockIdx.x;
-  const int rot = (tile * 5 + (tile >> 4)) & (NS - 1);   // de-phase the weight stream across workgroups
+  // de-phase the weight stream across workgroups.  The rotation sets the order the K steps are summed in, so it is a
+  // function of the PAIR index in both forms (NT = 1: tile = tile index, NT = 2: tile = pair index): a tile gets the same
+  // bits from the single-tile and from the pair kernels.
+  const int pr = NT == 2 ? tile : tile >> 1;
+  const int rot = (pr * 5 + (pr >> 4)) & (NS - 1);
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(planes);
   const float *arow[NT];
   float *zt[NT];
@@ -1825,7 +1829,17 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   using Cfg = CnnCfg<C>;
   using PS = PairSmem<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int seed = blockIdx.y + sd.seed_base;
+  // XCD-aware (seed, pair) of this workgroup: workgroups go to the 8 XCDs round-robin in dispatch order, so with a plain
+  // (x = pair, y = seed) grid every XCD's L2 sees the weight planes of every seed in flight.  When the seeds of the launch
+  // divide over the XCDs, XCD k runs seeds [k S/8, (k+1) S/8) one after the other and its L2 holds one seed's 1.5 MB of
+  // planes at a time (ablate bit 8 = plain mapping, for measurement).
+  int pair_id = blockIdx.x, seed_l = blockIdx.y;
+  if ((gridDim.y & 7) == 0 && !(ablate & 256)) {
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
+    seed_l = xcd * (gridDim.y >> 3) + slot / gridDim.x;
+    pair_id = slot % gridDim.x;
+  }
+  const int seed = seed_l + sd.seed_base;
   idx += seed * sd.idx_stride;
   theta += seed * sd.theta_stride;
   dzT += seed * sd.ws_stride;
@@ -1856,7 +1870,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rec = small_record_floats(C, L.a);
-  const int tile0 = 2 * blockIdx.x;
+  const int tile0 = 2 * pair_id;
   const int b0T[2] = {tile0 * QN_TILE, (tile0 + 1) * QN_TILE};
   float *gpT[2] = {gpart + (size_t)tile0 * rec, gpart + (size_t)(tile0 + 1) * rec};
 
@@ -1908,8 +1922,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   phase1_conv<C, !FWD_ONLY, true, true>(sT[1], tid, xkB, rkB);
   __syncthreads();
   T1_STAMP(3);
-  if (FWD_ONLY) phase2_fc1_x3<3, 2>(sT[0], theta + L.off_w1h, tid, blockIdx.x, &sT[1]);   // no LN0 state alive: room for a 3-deep ring
-  else phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, blockIdx.x, &sT[1]);
+  if (FWD_ONLY) phase2_fc1_x3<3, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1]);   // no LN0 state alive: room for a 3-deep ring
+  else phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1]);
   T1_STAMP(4);
   if (!FWD_ONLY)
 #pragma unroll
@@ -1948,7 +1962,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   T1_STAMP(6);
   if (FWD_ONLY) return;
   // ---- backward of A in place on h1 A, then of B into the same region ----
-  const int prot = blockIdx.x & (64 / QN_WAVES - 1);
+  const int prot = pair_id & (64 / QN_WAVES - 1);
   t1_dgrad_x3<false>(zA, h1A, nullptr, theta, L, lane, wave, prot);
   __syncthreads();
   T1_STAMP(7);
@@ -1962,6 +1976,123 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   t1_ln0_bwd<C>(h1A, h1B, red, theta, L, xkB, rkB, gpT[1], tid, ablate);
   t1_conv_wgrad<C, 2>(h1A, bitsB, wmS, scr, gpT[1], tid, ablate);
   T1_STAMP(10);
+}
+
+// ---------------------------------------------------------------------------
+// Persistent rollout, pair form (bf16x3 mode): one workgroup owns 32 envs = two 16-env tiles that share every fc1
+// weight fragment (phase2_fc1_x3<.., 2>), as in the training pair kernel; the head, epsilon-greedy draw and transition
+// rule of tile A run on threads 0..255, those of tile B on threads 256..511 (the single-tile kernel leaves that half
+// idle).  Same arithmetic, same draws, same record as qnet_cnn_rollout_kernel -- bit-identical results.
+// ---------------------------------------------------------------------------
+template <int C, class Env>
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_pair_kernel(
+    int n, int t_len, uint32_t *__restrict__ state, uint32_t *__restrict__ bits_all, const float *__restrict__ theta,
+    pqn_cnn_layout_t L, int32_t *__restrict__ action, float *__restrict__ qmax, float *__restrict__ reward,
+    uint8_t *__restrict__ done, float *__restrict__ discount, float *__restrict__ rer, int32_t *__restrict__ rel,
+    int32_t *__restrict__ ts, float *__restrict__ last_q, const float *__restrict__ eps_dev,
+    const uint64_t *__restrict__ keys, float rscale, int store_obs, int n_per_seed, long long theta_stride,
+    int keys_stride) {
+  using Cfg = CnnCfg<C>;
+  using PS = PairSmem<C>;
+  static_assert(Cfg::OW == Env::OBS_WORDS, "packed observation width");
+  int e_off = 0;
+  if (n_per_seed > 0) {   // seed batching: both tiles of a pair belong to one seed (n_per_seed % 32 == 0)
+    const int seed = (blockIdx.x * 2 * QN_TILE) / n_per_seed;
+    theta += seed * theta_stride;
+    keys += (size_t)seed * keys_stride;
+    e_off = seed * n_per_seed;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *h1A = reinterpret_cast<float *>(smem_raw), *h1B = h1A + QN_TILE * QN_H1S;
+  float *zA = h1B + QN_TILE * QN_H1S, *zB = zA + QN_TILE * QN_ZS;
+  float *wc = zB + QN_TILE * QN_ZS, *hp = wc + PS::WCN;
+  uint32_t *bitsA = reinterpret_cast<uint32_t *>(hp + QN_HP_FLOATS), *bitsB = bitsA + PS::BITN;
+  CnnSmem sA, sB;
+  sA.h1 = h1A; sA.z = zA; sA.wc = wc; sA.stg = nullptr; sA.hp = hp; sA.bits = bitsA;
+  sB.h1 = h1B; sB.z = zB; sB.wc = wc; sB.stg = nullptr; sB.hp = hp; sB.bits = bitsB;
+  const int tid = threadIdx.x;
+  const int half = tid >> 8, htid = tid & 255;            // tile (0 = A, 1 = B) and thread index inside its half
+  const int e0 = blockIdx.x * 2 * QN_TILE;                // first env of the pair; tile B starts at e0 + 16
+  const int m = (htid >> 4) & 15, sub = htid & 15, e = e0 + half * QN_TILE + m;
+  const int e_rng = e - e_off;
+  const bool owner = sub == 0 && e < n;                   // the lane that owns env e
+  const CnnSmem &sH = half ? sB : sA;
+  const size_t bstride = (size_t)n * Cfg::OW;
+  load_tile_common<C>(sA, theta, L, tid);
+  for (int i = tid; i < 2 * QN_TILE * Cfg::OW; i += QN_THREADS) {   // the two tiles' rows are contiguous in bits_all
+    const int t = i / (QN_TILE * Cfg::OW), r = i - t * (QN_TILE * Cfg::OW), le = t * QN_TILE + r / Cfg::OW;
+    (t ? bitsB : bitsA)[r] = (e0 + le < n) ? bits_all[(size_t)e0 * Cfg::OW + i] : 0u;
+  }
+  if (tid < 4) { bitsA[QN_TILE * Cfg::OW + tid] = 0u; bitsB[QN_TILE * Cfg::OW + tid] = 0u; }
+  Env env;
+  LogRec log;
+  if (owner) {
+    uint32_t w[Env::ENV_WORDS];
+#pragma unroll
+    for (int i = 0; i < Env::ENV_WORDS; ++i) w[i] = state[(size_t)i * n + e];
+    env.unpack(w);
+    log.load(state, n, e, Env::ENV_WORDS);
+  }
+  const float eps = *eps_dev;
+  const int tile_in_seed = (e0 - e_off) / QN_TILE;        // even: the weight-stream rotation of the pair
+#pragma unroll 1
+  for (int t = 0; t <= t_len; ++t) {
+    __syncthreads();   // the bits tiles hold obs_t (and every previous reader of the tiles is done)
+    phase1_conv<C, false, true, true>(sA, tid);
+    phase1_conv<C, false, true, true>(sB, tid);
+    __syncthreads();
+    phase2_fc1_x3<2, 2>(sA, theta + L.off_w1h, tid, tile_in_seed >> 1, &sB);
+    __syncthreads();
+    {
+      float q[QN_MAXA], h2[8], xh[8], rstd;
+      phase3_head(sH, theta, L, htid, q, h2, xh, rstd);
+      if (owner) {
+        int best = 0;
+        float bv = q[0];
+#pragma unroll
+        for (int a = 1; a < QN_MAXA; ++a)
+          if (a < L.a && q[a] > bv) { bv = q[a]; best = a; }
+        if (t == t_len) {
+          if (last_q) last_q[e] = bv;                      // bootstrap value of obs_T
+        } else {
+          const uint64_t key = keys[t];
+          uint32_t o0, o1;
+          pqn_bits(key, (uint32_t)e_rng, PQN_STREAM_ACT, o0, o1);
+          const int act = (pqn_uniform(o0) < eps) ? (int)pqn_randint(o1, (uint32_t)L.a) : best;
+          int dn = 0;
+          const float r = env.step(act, key, (uint32_t)e_rng, dn);
+          log.step(r, dn);
+          if (dn) env.reset(key, (uint32_t)e_rng);             // gymnax auto-reset
+          const size_t o = (size_t)t * n + e;
+          if (action) action[o] = act;
+          if (qmax) qmax[o] = bv;
+          if (reward) reward[o] = r * rscale;
+          if (done) done[o] = (uint8_t)dn;
+          if (discount) discount[o] = dn ? 0.0f : 1.0f;
+          if (rer) rer[o] = log.ret_ret;
+          if (rel) rel[o] = log.ret_len;
+          if (ts) ts[o] = log.timestep;
+          env.obs_bits(&sH.bits[m * Cfg::OW]);             // obs_{t+1} straight into the LDS tile
+        }
+      }
+    }
+    if (t == t_len) break;
+    __syncthreads();
+    if (store_obs || t + 1 == t_len) {
+      uint32_t *dst = bits_all + (store_obs ? (size_t)(t + 1) * bstride : (size_t)0);
+      for (int i = tid; i < 2 * QN_TILE * Cfg::OW; i += QN_THREADS) {
+        const int tl = i / (QN_TILE * Cfg::OW), r = i - tl * (QN_TILE * Cfg::OW), le = tl * QN_TILE + r / Cfg::OW;
+        if (e0 + le < n) dst[(size_t)e0 * Cfg::OW + i] = (tl ? bitsB : bitsA)[r];
+      }
+    }
+  }
+  if (owner) {
+    uint32_t w[Env::ENV_WORDS];
+    env.pack(w);
+#pragma unroll
+    for (int i = 0; i < Env::ENV_WORDS; ++i) state[(size_t)i * n + e] = w[i];
+    log.store(state, n, e, Env::ENV_WORDS);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2874,6 +3005,26 @@ static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t 
   }
   // one instantiation per operand mode (as the training kernel): the env state lives in registers across the T-step
   // loop, and carrying all three fc1 / conv variants in one kernel cost 27 spilled VGPRs
+  // pair form (32 envs per workgroup, shared fc1 weight stream): bf16x3 mode, when its LDS layout fits, the envs (of
+  // each seed) come in pairs of tiles and the grid still gives every CU a workgroup; PQN_ROLLOUT_PAIR=0 / 2: never / always
+  static const int rp_env = getenv("PQN_ROLLOUT_PAIR") ? atoi(getenv("PQN_ROLLOUT_PAIR")) : 1;
+  constexpr size_t pair_smem = sizeof(float) * (2 * QN_TILE * QN_H1S + 2 * QN_TILE * QN_ZS + PairSmem<C>::WCN + QN_HP_FLOATS) +
+                               sizeof(uint32_t) * 2 * PairSmem<C>::BITN;
+  const bool use_pair = rp_env && L.matmul_f16 == 2 && pair_smem <= 160 * 1024 && n % (2 * QN_TILE) == 0 &&
+                        (n_per_seed <= 0 || n_per_seed % (2 * QN_TILE) == 0) && (n / (2 * QN_TILE) >= 256 || rp_env == 2);
+  if (use_pair) {
+    static bool pattr = false;
+    if (!pattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_pair_kernel<C, Env>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem);
+      pattr = true;
+    }
+    hipLaunchKernelGGL((qnet_cnn_rollout_pair_kernel<C, Env>), dim3(n / (2 * QN_TILE)), dim3(QN_THREADS), pair_smem, st, n,
+                       t_len, state, bits, theta, L, action, qmax, rec.reward, rec.done, rec.discount,
+                       rec.returned_episode_returns, rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys,
+                       rscale, store_obs, n_per_seed, theta_stride, keys_stride);
+    return pqn_check_launch("pqn_qnet_cnn_rollout");
+  }
   auto kern = L.matmul_f16 == 2 ? &qnet_cnn_rollout_kernel<C, Env, 2>
                                 : (L.matmul_f16 == 1 ? &qnet_cnn_rollout_kernel<C, Env, 1> : &qnet_cnn_rollout_kernel<C, Env, 0>);
   hipLaunchKernelGGL(kern, dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n,

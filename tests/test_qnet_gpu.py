@@ -349,6 +349,26 @@ def test_pair_form_of_the_training_kernel_at_small_sizes(gpu):
         assert rep == 0.0 and dif < 2e-5, l
 
 
+def test_pair_form_of_the_rollout_kernel_is_bit_identical(gpu):
+    """qnet_cnn_rollout_pair_kernel (32 envs per workgroup sharing the fc1 weight stream, bf16x3) is chosen when its grid
+    fills the chip; PQN_ROLLOUT_PAIR=2 forces it at every size it supports, =0 disables it.  tools/rollout_digest.py
+    hashes every output of pqn_cnn_rollout (record, final env words, packed observations) for five cases over four
+    games: both forms must print the same digests.  The switch is read when the library loads, hence subprocesses."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v in ("0", "2"):
+        env = dict(os.environ, PQN_ROLLOUT_PAIR=v, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "rollout_digest.py")], env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append([l for l in out.stdout.splitlines() if "MinAtar" in l])
+    assert len(outs[0]) == 5 and outs[0] == outs[1], (outs[0], outs[1])
+    assert all(int(l.split()[-1]) > 0 for l in outs[0][:3])   # episode ends (auto-reset) inside the windows
+
+
 def test_position_parallel_backward_opt_in_path(gpu):
     """PQN_BWD_POS=2 (with the pair kernel forced) routes the 4096-sample case through the forward-only pair kernel +
     qnet_cnn_bwd_pos_kernel + the reduction without split-K slabs: repeats bit-identical, gradient
