@@ -145,7 +145,8 @@ def kernel_timer_pass(lib, update, first, mb_samples, seeds):
 def t1_roofline(avg_s, launches, mb_samples, seeds, matmul):
     achieved = T1_FLOP_PER_SAMPLE * mb_samples * seeds / avg_s / 1e12
     traffic, tsrc = None, None
-    for name in (f"r02_pmc_train_kernel_{matmul}.json", "r01_pmc_train_kernel.json"):
+    for name in (f"r02_pmc_train_kernel_{matmul}_seeds{seeds}.json", f"r02_pmc_train_kernel_{matmul}.json",
+                 "r01_pmc_train_kernel.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             pj = json.load(open(pmc))

@@ -2824,11 +2824,11 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_f16_kernel(int nb, 
 // T3a: fold partials into the flat gradient (kernel layout) and emit per-block sums of
 // squares + the *count snapshot for radam_apply (same scratch protocol as radam_norm_kernel).
 // Blocks [0, QR_W1_BLOCKS): fc1 region, float4 per lane, sum over the K-splits.
-// Remaining blocks: one WAVE per "small" element, lanes stride over the tiles, fixed-order tree.
+// Remaining blocks: 64 "small" elements each (lane = element), the four waves split the tile records, fixed order.
 // ---------------------------------------------------------------------------
 #define QR_W1_BLOCKS (QN_H1 * QN_HID / 1024)
 
-__host__ __device__ inline int grad_reduce_blocks(int total) { return QR_W1_BLOCKS + (total - QN_H1 * QN_HID + 3) / 4; }
+__host__ __device__ inline int grad_reduce_blocks(int total) { return QR_W1_BLOCKS + (total - QN_H1 * QN_HID + 63) / 64; }
 
 __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t L, int ntiles, int nks, int rec,
                                                                const float *__restrict__ gpart,
@@ -2840,6 +2840,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
   // gpos / npos: the conv-block partials come from the position-parallel backward (npos records of 9C*16+48 floats per
   // seed) instead of from the per-tile records
   __shared__ float s_part[4];
+  __shared__ float s_red[4][64];
   {  // seed slice
     const long long s = blockIdx.y;
     gpart += s * sd.ws_stride;
@@ -2873,26 +2874,39 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
     ss = fmaf(g.x, g.x, fmaf(g.y, g.y, fmaf(g.z, g.z, g.w * g.w)));
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
   } else {
-    const int sidx = (blockIdx.x - QR_W1_BLOCKS) * 4 + wave;  // index among the non-fc1 elements
+    // lane = element (64 consecutive non-fc1 elements per block), so that the loads of a wave run along the records
+    // (256 B contiguous) instead of across them; wave w adds records w, w + 4, ... in order, 8 loads in flight
+    // (unconditional: index clamped, surplus masked in the add), and the four waves are folded in fixed order.
+    const int sidx = (blockIdx.x - QR_W1_BLOCKS) * 64 + lane;  // index among the non-fc1 elements
     const int i = sidx < L.off_w1 ? sidx : sidx + QN_H1 * QN_HID;
-    if (i < L.total) {
-      const int convblk = 9 * L.c * 16 + 48;
-      int r = -1;  // index into the small record (-1: dummy BatchNorm / padding -> zero gradient)
-      if (i >= L.off_wc && i < L.off_wc + convblk) r = i - L.off_wc;
-      else if (i >= L.off_b1 && i < L.off_b1 + 384) r = convblk + (i - L.off_b1);
-      else if (i >= L.off_w2 && i < L.off_w2 + 128 * L.a) r = convblk + 384 + (i - L.off_w2);
-      else if (i >= L.off_b2 && i < L.off_b2 + L.a) r = convblk + 384 + 128 * L.a + (i - L.off_b2);
-      float g = 0.0f;
-      if (r >= 0 && r < convblk && gpos) {
-        if (lane < npos) g = gpos[(size_t)lane * convblk + r];
-      } else if (r >= 0)
-        for (int t = lane; t < ntiles; t += 64) g += gpart[(size_t)t * rec + r];
-      for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off, 64);
-      if (lane == 0) {
+    const int convblk = 9 * L.c * 16 + 48;
+    int r = -1;  // index into the small record (-1: dummy BatchNorm / padding -> zero gradient)
+    if (i >= L.off_wc && i < L.off_wc + convblk) r = i - L.off_wc;
+    else if (i >= L.off_b1 && i < L.off_b1 + 384) r = convblk + (i - L.off_b1);
+    else if (i >= L.off_w2 && i < L.off_w2 + 128 * L.a) r = convblk + 384 + (i - L.off_w2);
+    else if (i >= L.off_b2 && i < L.off_b2 + L.a) r = convblk + 384 + 128 * L.a + (i - L.off_b2);
+    const bool from_pos = gpos && r >= 0 && r < convblk;
+    const float *src = (from_pos ? gpos : gpart) + (r >= 0 ? r : 0);
+    const int stride = from_pos ? convblk : rec, n = r < 0 ? 0 : (from_pos ? npos : ntiles);
+    const int n_all = (gpos && npos > ntiles) ? npos : ntiles;   // uniform loop bound
+    float g = 0.0f;
+    for (int t0 = wave; t0 < n_all; t0 += 32) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[(size_t)max(min(t0 + 4 * q, n - 1), 0) * stride];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g += v[q] * ((t0 + 4 * q < n) ? 1.0f : 0.0f);
+    }
+    s_red[wave][lane] = g;
+    __syncthreads();
+    if (wave == 0) {
+      g = (s_red[0][lane] + s_red[1][lane]) + (s_red[2][lane] + s_red[3][lane]);
+      if (i < L.total) {
         grad[i] = g;
         ss = g * g;
       }
-    }
+      for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    } else ss = 0.0f;
     if (blockIdx.x == QR_W1_BLOCKS && wave == 0) {  // metrics td_loss / qvals (pqn_minatar.py:334-335)
       float l = 0.f, qv = 0.f;
       for (int t = lane; t < ntiles; t += 64) {
