@@ -601,9 +601,13 @@ PQN_HD int x3_dgrad_index(int i, int o) {         // element offset inside one d
 // NT = 2 (the pair kernel): TWO 16-sample tiles share every weight fragment -- what bounds this phase is the 64 B/clk
 // vector-memory path of the CU streaming the 768 KB of planes, so a second tile costs MFMAs and one more A split but
 // no more weight traffic.  Partial sums of the two K halves are then folded IN PLACE in the z tiles (no park buffer).
-template <int PF = 3, int NT = 1>
+struct Fc1NoSide { PQN_D void operator()(int, int) const {} };
+// side(j, i), j = 0..15 (i = j % PF, a compile-time value after unrolling): independent work issued once per K step behind
+// the step's weight reload (the pair kernel stores h1^T there: the stores ride in the shadow of the weight stream
+// instead of a phase of their own)
+template <int PF = 3, int NT = 1, class Side = Fc1NoSide>
 PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int tid, int tile = -1,
-                         const CnnSmem *s2 = nullptr) {
+                         const CnnSmem *s2 = nullptr, Side side = Side()) {
   static_assert(QN_WAVES == 8, "2 K halves x 4 column-block pairs");
   constexpr int NS = 16;   // K steps per wave
   // accumulator copies per (tile, column block, kind).  ONE for both forms: the single-tile and the pair kernel must sum
@@ -692,6 +696,7 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) ring[i][c][pl] = wfrag(pl, st, c);
     }
+    side(g + i, i);
     __builtin_amdgcn_sched_barrier(0);
   };
   int g = 0;
@@ -1129,6 +1134,15 @@ PQN_D float group32_sum(float v) {
   return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
 }
 
+// stores of the T1 -> T2 hand-over operands (h1^T, dz^T: 18 MB per seed and launch, never read again by this kernel)
+PQN_D void ws_store(f32x4 *p, const f32x4 &v) {
+#ifdef T1_PLAIN_STORES   // A/B hook
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);   // streaming: keeps the weight planes in L2 (-1 % on the 16-seed launch)
+#endif
+}
+
 // Head of the training kernel.  Forward: z + b1 -> LN(128) -> relu -> fc2 -> q_a -> loss
 // (pqn_minatar.py:271-285); backward through fc2 / relu / LN1 to dz (left in s.z for the dgrad and
 // written transposed for the fc1 weight-gradient GEMM).  32 lanes per sample (all 8 waves): lane
@@ -1283,7 +1297,7 @@ PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layou
     const int o = i >> 2, mq = i & 3;
     const f32x4 vv = {s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], s.z[(4 * mq + 2) * QN_ZS + o],
                       s.z[(4 * mq + 3) * QN_ZS + o]};
-    *reinterpret_cast<f32x4 *>(dzT + (size_t)o * qw_ld(nb) + b0 + 4 * mq) = vv;
+    ws_store(reinterpret_cast<f32x4 *>(dzT + (size_t)o * qw_ld(nb) + b0 + 4 * mq), vv);
   }
   if (tid == 0) {
     const int o_l = 9 * C * 16 + 48 + 384 + 128 * na + na;
@@ -1647,8 +1661,21 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   __syncthreads();
   T1_STAMP(2);
   if (MODE == 1) phase2_fc1_f16<16>(s, reinterpret_cast<const _Float16 *>(theta + L.off_w1h), tid);
-  else if (MODE == 2) phase2_fc1_x3<3>(s, theta + L.off_w1h, tid);
-  else phase2_fc1<0>(s, theta + L.off_w1, tid);
+  else if (MODE == 2) {
+    // h1^T for T2 (slab-major, h1s_index) leaves during fc1, one 512-thread slice at every second K step, in the
+    // shadow of the weight stream (see the pair kernel)
+    auto h1t_slice = [&](int j, int) {
+#ifndef T1_NO_H1T
+      if (!(j & 1)) {
+        const int e = tid + (j >> 1) * QN_THREADS, i = e >> 2, mq = e & 3;
+        const float *src = s.h1 + (4 * mq) * QN_H1S + i;
+        const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
+        ws_store(reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0 + 4 * mq)), v);
+      }
+#endif
+    };
+    phase2_fc1_x3<3>(s, theta + L.off_w1h, tid, -1, nullptr, h1t_slice);
+  } else phase2_fc1<0>(s, theta + L.off_w1, tid);
   // h1^T for the fc1 weight-gradient GEMM (T2): h1T[i][b0 + m].  Issued here so the 64 KB of stores
   // drain while the (VALU-bound) head phase runs instead of queueing in front of the W1 stream.
   if (MODE == 1) {
@@ -1662,16 +1689,16 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       for (int r = 0; r < 8; ++r) v[r] = (_Float16)src[r * QN_H1S];
       *reinterpret_cast<f16x8 *>(h1P + (size_t)i * QN_TILE + 8 * hh) = v;
     }
-  } else
+  } else if (MODE == 0) {
 #ifndef T1_NO_H1T
-  for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
-    const int i = e >> 2, mq = e & 3;
-    const float *src = s.h1 + (4 * mq) * QN_H1S + i;
-    const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
-    if (MODE == 2) *reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0 + 4 * mq)) = v;
-    else *reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq) = v;
-  }
+    for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
+      const int i = e >> 2, mq = e & 3;
+      const float *src = s.h1 + (4 * mq) * QN_H1S + i;
+      const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
+      ws_store(reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq), v);
+    }
 #endif
+  }
   if (tid < QN_TILE) {
     ts.act[tid] = act_g;
     ts.tgt[tid] = tgt_g;
@@ -1923,16 +1950,16 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   __syncthreads();
   T1_STAMP(3);
   if (FWD_ONLY) phase2_fc1_x3<3, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1]);   // no LN0 state alive: room for a 3-deep ring
-  else phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1]);
-  T1_STAMP(4);
-  if (!FWD_ONLY)
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {   // h1^T for T2, slab-major (h1s_index); tile B also leaves its relu mask as bits
-    for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
+  else {
+    // h1^T for T2 (slab-major, h1s_index) leaves DURING fc1: K step j of every wave also stores one 512-thread slice
+    // (tile j & 1, slice j >> 1) of the two h1 tiles, and tile B leaves its relu mask as bits on the way.  h1 is only
+    // read in this phase, so the order against the MFMA operand reads does not matter.
+    auto h1t_slice = [&](int j, int jc) {   // jc = j % 2 at compile time (PF = 2)
+      const int t = jc & 1, e = tid + (j >> 1) * QN_THREADS;
       const int i = e >> 2, mq = e & 3;
-      const float *src = sT[t].h1 + (4 * mq) * QN_H1S + i;
+      const float *src = (t ? h1B : h1A) + (4 * mq) * QN_H1S + i;
       const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
-      *reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0T[t] + 4 * mq)) = v;
+      ws_store(reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0T[0] + QN_TILE * t + 4 * mq)), v);
       if (t == 1) {
         // lane = (feature i & 15) * 4 + mq, sample 4 mq + rr: one 64-bit ballot per rr and 16-feature block
         const unsigned long long bx = __ballot(v.x > 0.0f), by = __ballot(v.y > 0.0f), bz = __ballot(v.z > 0.0f), bw = __ballot(v.w > 0.0f);
@@ -1941,8 +1968,16 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
           mw[0] = bx; mw[1] = by; mw[2] = bz; mw[3] = bw;
         }
       }
-    }
+    };
+#ifdef T1_H1T_AFTER   // A/B hook: the stores as a phase of their own behind fc1
+    phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h1t_slice(j, j & 1);
+#else
+    phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1], h1t_slice);
+#endif
   }
+  T1_STAMP(4);
   if (tid < 2 * QN_TILE) {
     tsT[0].act[tid] = act_g;     // act[2][16] / tgt[2][16] are contiguous: sample tid of the pair
     tsT[0].tgt[tid] = tgt_g;
