@@ -1150,161 +1150,212 @@ PQN_D void ws_store(f32x4 *p, const f32x4 &v) {
 // d ln1 bias = column sums; d w2 = h2^T x G, G[m][a] = [act_m == a] g_m; d b2 = column sums of G)
 // are MFMAs on the staged tiles -- an all-ones A operand turns a column sum into one 16x16x4 chain.
 // NA: compile-time action count (0 = run-time L.a, up to QN_MAXA).
-template <int C, int NA>
-PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layout_t &L, int tid, int nb, int b0,
-                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT, float dz_scale,
-                      unsigned short *__restrict__ dzp = nullptr) {
+// NT = 2 (the pair kernel): the two tiles of the workgroup go through the head TOGETHER -- every thread runs its role
+// for tile A and tile B back to back (two independent dependency chains, half the barriers); the per-sample arithmetic
+// and its order are those of NT = 1, so a tile gets the same bits from both forms.
+template <int C, int NA, int NT>
+PQN_D void train_head_nt(const CnnSmem (&sv)[NT], const TrainSmem (&tv)[NT], const pqn_cnn_layout_t &L, int tid, int nb,
+                         const int (&b0v)[NT], float inv_b, float *const (&gpv)[NT], float *__restrict__ dzT, float dz_scale,
+                         unsigned short *__restrict__ dzp = nullptr) {
   constexpr int NAQ = NA ? NA : QN_MAXA;
   const int na = NA ? NA : L.a;
   const int lane = tid & 63, wave = tid >> 6;
   const int m = tid >> 5, sub = tid & 31;
-  float *tA = ts.scr, *tB = ts.scr + QN_TILE * QN_ZS, *tH = ts.scr + 2 * QN_TILE * QN_ZS;
-  float *zrow = s.z + m * QN_ZS;
-  float v[4], xh[4], h2[4];
-  float sum = 0.f, sq = 0.f;
+  const float *hp = sv[0].hp;   // head parameters: one copy per workgroup
+  float *tA[NT], *tB[NT], *tH[NT], *zrow[NT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = sub + 32 * r;
-    v[r] = zrow[o] + s.hp[o];
-    sum += v[r];
-    sq = fmaf(v[r], v[r], sq);
+  for (int t = 0; t < NT; ++t) {
+    tA[t] = tv[t].scr + t * (3 * QN_TILE * QN_ZS);
+    tB[t] = tA[t] + QN_TILE * QN_ZS;
+    tH[t] = tA[t] + 2 * QN_TILE * QN_ZS;
+    zrow[t] = sv[t].z + m * QN_ZS;
   }
-  sum = group32_sum(sum);
-  sq = group32_sum(sq);
-  const float mean = sum * (1.0f / QN_HID);
-  const float var = fmaxf(sq * (1.0f / QN_HID) - mean * mean, 0.0f);
-  const float rstd = rsqrt_exact(var + QN_LN_EPS);
+  float v[NT][4], xh[NT][4], h2[NT][4], rstd[NT], sum[NT], sq[NT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = sub + 32 * r;
-    xh[r] = (v[r] - mean) * rstd;
-    h2[r] = fmaxf(fmaf(xh[r], s.hp[128 + o], s.hp[256 + o]), 0.0f);
-  }
-  float qv[NAQ];
+  for (int t = 0; t < NT; ++t) {
+    sum[t] = 0.f; sq[t] = 0.f;
 #pragma unroll
-  for (int a = 0; a < NAQ; ++a) {
-    float part = 0.f;
-    if (a < na) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part = fmaf(h2[r], s.hp[384 + (sub + 32 * r) * na + a], part);
+    for (int r = 0; r < 4; ++r) {
+      const int o = sub + 32 * r;
+      v[t][r] = zrow[t][o] + hp[o];
+      sum[t] += v[t][r];
+      sq[t] = fmaf(v[t][r], v[t][r], sq[t]);
     }
-    qv[a] = part;
   }
 #pragma unroll
-  for (int a = 0; a < NAQ; ++a) qv[a] = group32_sum(qv[a]) + (a < na ? s.hp[384 + 128 * na + a] : 0.0f);
-  const bool valid = (b0 + m) < nb;
-  const int act = ts.act[m];
-  float chosen = qv[0];
+  for (int t = 0; t < NT; ++t) { sum[t] = group32_sum(sum[t]); sq[t] = group32_sum(sq[t]); }
 #pragma unroll
-  for (int a = 1; a < NAQ; ++a)
-    if (a == act) chosen = qv[a];
-  const float diff = valid ? (chosen - ts.tgt[m]) : 0.0f;
-  const float gm = diff * inv_b;  // d loss / d q_a, loss = 0.5*mean(diff^2)  (pqn_minatar.py:285)
-  // backward: fc2, relu, LN1.  Every lane reads and rewrites only its own elements of the z tile.
-  float dxh[4], s1 = 0.f, s2 = 0.f;
+  for (int t = 0; t < NT; ++t) {
+    const float mean = sum[t] * (1.0f / QN_HID);
+    const float var = fmaxf(sq[t] * (1.0f / QN_HID) - mean * mean, 0.0f);
+    rstd[t] = rsqrt_exact(var + QN_LN_EPS);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = sub + 32 * r;
-    const float dh2 = gm * s.hp[384 + o * na + act];
-    const float dy = h2[r] > 0.0f ? dh2 : 0.0f;
-    tA[m * QN_ZS + o] = dy * xh[r];
-    tB[m * QN_ZS + o] = dy;
-    tH[m * QN_ZS + o] = h2[r];
-    dxh[r] = dy * s.hp[128 + o];
-    s1 += dxh[r];
-    s2 = fmaf(dxh[r], xh[r], s2);
+    for (int r = 0; r < 4; ++r) {
+      const int o = sub + 32 * r;
+      xh[t][r] = (v[t][r] - mean) * rstd[t];
+      h2[t][r] = fmaxf(fmaf(xh[t][r], hp[128 + o], hp[256 + o]), 0.0f);
+    }
   }
-  s1 = group32_sum(s1) * (1.0f / QN_HID);
-  s2 = group32_sum(s2) * (1.0f / QN_HID);
+  float qv[NT][NAQ];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) zrow[sub + 32 * r] = rstd * (dxh[r] - s1 - xh[r] * s2);
-  if (sub == 0) ts.gs[m] = gm;
-  {  // loss / chosen-q partials of the wave's two samples (metrics td_loss, qvals: pqn_minatar.py:334-335)
-    float l = (sub == 0) ? 0.5f * diff * diff : 0.0f, cq = (sub == 0 && valid) ? chosen : 0.0f;
-    l += __shfl_xor(l, 32, 64);
-    cq += __shfl_xor(cq, 32, 64);
-    if (lane == 0) { ts.red[wave * 48] = l; ts.red[wave * 48 + 1] = cq; }
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int a = 0; a < NAQ; ++a) {
+      float part = 0.f;
+      if (a < na) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(h2[t][r], hp[384 + (sub + 32 * r) * na + a], part);
+      }
+      qv[t][a] = part;
+    }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int a = 0; a < NAQ; ++a) qv[t][a] = group32_sum(qv[t][a]) + (a < na ? hp[384 + 128 * na + a] : 0.0f);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const bool valid = (b0v[t] + m) < nb;
+    const int act = tv[t].act[m];
+    float chosen = qv[t][0];
+#pragma unroll
+    for (int a = 1; a < NAQ; ++a)
+      if (a == act) chosen = qv[t][a];
+    const float diff = valid ? (chosen - tv[t].tgt[m]) : 0.0f;
+    const float gm = diff * inv_b;  // d loss / d q_a, loss = 0.5*mean(diff^2)  (pqn_minatar.py:285)
+    // backward: fc2, relu, LN1.  Every lane reads and rewrites only its own elements of the z tile.
+    float dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = sub + 32 * r;
+      const float dh2 = gm * hp[384 + o * na + act];
+      const float dy = h2[t][r] > 0.0f ? dh2 : 0.0f;
+      tA[t][m * QN_ZS + o] = dy * xh[t][r];
+      tB[t][m * QN_ZS + o] = dy;
+      tH[t][m * QN_ZS + o] = h2[t][r];
+      dxh[r] = dy * hp[128 + o];
+      s1 += dxh[r];
+      s2 = fmaf(dxh[r], xh[t][r], s2);
+    }
+    s1 = group32_sum(s1) * (1.0f / QN_HID);
+    s2 = group32_sum(s2) * (1.0f / QN_HID);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zrow[t][sub + 32 * r] = rstd[t] * (dxh[r] - s1 - xh[t][r] * s2);
+    if (sub == 0) tv[t].gs[m] = gm;
+    {  // loss / chosen-q partials of the wave's two samples (metrics td_loss, qvals: pqn_minatar.py:334-335)
+      float l = (sub == 0) ? 0.5f * diff * diff : 0.0f, cq = (sub == 0 && valid) ? chosen : 0.0f;
+      l += __shfl_xor(l, 32, 64);
+      cq += __shfl_xor(cq, 32, 64);
+      if (lane == 0) { tv[0].red[wave * 48 + 2 * t] = l; tv[0].red[wave * 48 + 2 * t + 1] = cq; }
+    }
   }
   __syncthreads();
   // sums over the 16 samples as MFMA chains (K = 16 samples in 4 steps); wave w owns feature block 16w..16w+15
   {
     const int j = lane & 15, kk = lane >> 4;
     const int o_b1 = 9 * C * 16 + 48;
-    f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, c3 = c1, cw = c1, cb = c1;
+    f32x4 c1[NT], c2[NT], c3[NT], cw[NT], cb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { c1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; c2[t] = c1[t]; c3[t] = c1[t]; cw[t] = c1[t]; cb[t] = c1[t]; }
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const int mr = 4 * st + kk;
-      const int e = mr * QN_ZS + 16 * wave + j;
-      const float gB = (ts.act[mr] == j) ? ts.gs[mr] : 0.0f;   // G[m][a = j]
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, s.z[e], c1, 0, 0, 0);
-      c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, tA[e], c2, 0, 0, 0);
-      c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, tB[e], c3, 0, 0, 0);
-      cw = __builtin_amdgcn_mfma_f32_16x16x4f32(tH[e], gB, cw, 0, 0, 0);   // A[i = o][k = m] = h2, B[k = m][j = a] = G
-      if (wave == 0) cb = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, gB, cb, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int mr = 4 * st + kk;
+        const int e = mr * QN_ZS + 16 * wave + j;
+        const float gB = (tv[t].act[mr] == j) ? tv[t].gs[mr] : 0.0f;   // G[m][a = j]
+        c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, sv[t].z[e], c1[t], 0, 0, 0);
+        c2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, tA[t][e], c2[t], 0, 0, 0);
+        c3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, tB[t][e], c3[t], 0, 0, 0);
+        cw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tH[t][e], gB, cw[t], 0, 0, 0);   // A[i = o][k = m] = h2, B[k = m][j = a] = G
+        if (wave == 0) cb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, gB, cb[t], 0, 0, 0);
+      }
     }
-    if (lane < 16) {   // every row of an all-ones chain holds the column sums: row 0 = register x of lanes 0..15
-      gp[o_b1 + 16 * wave + lane] = c1.x;         // d b1
-      gp[o_b1 + 128 + 16 * wave + lane] = c2.x;   // d ln1 scale
-      gp[o_b1 + 256 + 16 * wave + lane] = c3.x;   // d ln1 bias
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float *gp = gpv[t];
+      if (lane < 16) {   // every row of an all-ones chain holds the column sums: row 0 = register x of lanes 0..15
+        gp[o_b1 + 16 * wave + lane] = c1[t].x;         // d b1
+        gp[o_b1 + 128 + 16 * wave + lane] = c2[t].x;   // d ln1 scale
+        gp[o_b1 + 256 + 16 * wave + lane] = c3[t].x;   // d ln1 bias
+      }
+      if (j < na) {      // d w2[o][a]: lane holds column a = j, rows o = 16w + 4kk + reg
+        float *gw = gp + o_b1 + 384 + (16 * wave + 4 * kk) * na + j;
+        gw[0] = cw[t].x; gw[na] = cw[t].y; gw[2 * na] = cw[t].z; gw[3 * na] = cw[t].w;
+      }
+      if (wave == 0 && lane < na) gp[o_b1 + 384 + 128 * na + lane] = cb[t].x;   // d b2
     }
-    if (j < na) {      // d w2[o][a]: lane holds column a = j, rows o = 16w + 4kk + reg
-      float *gw = gp + o_b1 + 384 + (16 * wave + 4 * kk) * na + j;
-      gw[0] = cw.x; gw[na] = cw.y; gw[2 * na] = cw.z; gw[3 * na] = cw.w;
-    }
-    if (wave == 0 && lane < na) gp[o_b1 + 384 + 128 * na + lane] = cb.x;   // d b2
   }
   // dz^T for the weight-gradient GEMM: dzT[o][b0 + m], 16-B stores (matmul_f16: tile-major fp16, scaled into
   // fp16's normal range by dz_scale)
-  if (L.matmul_f16 == 1) {
-    _Float16 *dzP = reinterpret_cast<_Float16 *>(dzT) + (size_t)blockIdx.x * QN_HID * QN_TILE;
-    if (tid < QN_HID * 2) {
-      const int o = tid >> 1, hh = tid & 1;
-      f16x8 v;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = (_Float16)(s.z[(8 * hh + r) * QN_ZS + o] * dz_scale);
-      *reinterpret_cast<f16x8 *>(dzP + (size_t)o * QN_TILE + 8 * hh) = v;
+  for (int t = 0; t < NT; ++t) {
+    const CnnSmem &s = sv[t];
+    const int b0 = b0v[t];
+    if (L.matmul_f16 == 1) {
+      _Float16 *dzP = reinterpret_cast<_Float16 *>(dzT) + (size_t)(b0 / QN_TILE) * QN_HID * QN_TILE;
+      if (tid < QN_HID * 2) {
+        const int o = tid >> 1, hh = tid & 1;
+        f16x8 vv;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] = (_Float16)(s.z[(8 * hh + r) * QN_ZS + o] * dz_scale);
+        *reinterpret_cast<f16x8 *>(dzP + (size_t)o * QN_TILE + 8 * hh) = vv;
+      }
+    } else if (dzp) {
+      // position-parallel backward (qnet_cnn_bwd_pos_kernel): dz leaves as bf16 planes, already split, in the two MFMA
+      // operand orders that kernel reads -- dzA (A of the dgrad, sample rows) and dzB (B of the dW1 product, 4-sample
+      // K groups); see dz_planes_a / dz_planes_b
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      {
+        const int ms = tid >> 5, q = tid & 31;                // sample, (sK, kq, h) = 4 consecutive outputs
+        const int sK = q >> 3, kq = (q >> 1) & 3, h = q & 1;
+        const float *zr = s.z + ms * QN_ZS + 32 * sK + 16 * h + 4 * kq;
+        unsigned hh[2], mm[2], ll[2];
+        x3_split2(zr[0], zr[1], hh[0], mm[0], ll[0]);
+        x3_split2(zr[2], zr[3], hh[1], mm[1], ll[1]);
+        const size_t e = dz_planes_a(nb, b0 + ms, sK, kq) + 4 * h;
+        *reinterpret_cast<u2 *>(dzp + e) = u2{hh[0], hh[1]};
+        *reinterpret_cast<u2 *>(dzp + (size_t)nb * QN_HID + e) = u2{mm[0], mm[1]};
+        *reinterpret_cast<u2 *>(dzp + 2 * (size_t)nb * QN_HID + e) = u2{ll[0], ll[1]};
+      }
+      {
+        const int o = tid >> 2, kq = tid & 3;                 // output, samples 4 kq .. 4 kq + 3 of the tile
+        const float *zc = s.z + (4 * kq) * QN_ZS + o;
+        unsigned hh[2], mm[2], ll[2];
+        x3_split2(zc[0], zc[QN_ZS], hh[0], mm[0], ll[0]);
+        x3_split2(zc[2 * QN_ZS], zc[3 * QN_ZS], hh[1], mm[1], ll[1]);
+        unsigned short *pb = dzp + 3 * (size_t)nb * QN_HID + dz_planes_b(b0 / QN_TILE, o >> 4, kq * 16 + (o & 15));
+        *reinterpret_cast<u2 *>(pb) = u2{hh[0], hh[1]};
+        *reinterpret_cast<u2 *>(pb + 512) = u2{mm[0], mm[1]};
+        *reinterpret_cast<u2 *>(pb + 1024) = u2{ll[0], ll[1]};
+      }
+    } else
+    for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
+      const int o = i >> 2, mq = i & 3;
+      const f32x4 vv = {s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], s.z[(4 * mq + 2) * QN_ZS + o],
+                        s.z[(4 * mq + 3) * QN_ZS + o]};
+      ws_store(reinterpret_cast<f32x4 *>(dzT + (size_t)o * qw_ld(nb) + b0 + 4 * mq), vv);
     }
-  } else if (dzp) {
-    // position-parallel backward (qnet_cnn_bwd_pos_kernel): dz leaves as bf16 planes, already split, in the two MFMA
-    // operand orders that kernel reads -- dzA (A of the dgrad, sample rows) and dzB (B of the dW1 product, 4-sample
-    // K groups); see dz_planes_a / dz_planes_b
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    {
-      const int m = tid >> 5, q = tid & 31;                 // sample, (sK, kq, h) = 4 consecutive outputs
-      const int sK = q >> 3, kq = (q >> 1) & 3, h = q & 1;
-      const float *zr = s.z + m * QN_ZS + 32 * sK + 16 * h + 4 * kq;
-      unsigned hh[2], mm[2], ll[2];
-      x3_split2(zr[0], zr[1], hh[0], mm[0], ll[0]);
-      x3_split2(zr[2], zr[3], hh[1], mm[1], ll[1]);
-      const size_t e = dz_planes_a(nb, b0 + m, sK, kq) + 4 * h;
-      *reinterpret_cast<u2 *>(dzp + e) = u2{hh[0], hh[1]};
-      *reinterpret_cast<u2 *>(dzp + (size_t)nb * QN_HID + e) = u2{mm[0], mm[1]};
-      *reinterpret_cast<u2 *>(dzp + 2 * (size_t)nb * QN_HID + e) = u2{ll[0], ll[1]};
-    }
-    {
-      const int o = tid >> 2, kq = tid & 3;                 // output, samples 4 kq .. 4 kq + 3 of the tile
-      const float *zc = s.z + (4 * kq) * QN_ZS + o;
-      unsigned hh[2], mm[2], ll[2];
-      x3_split2(zc[0], zc[QN_ZS], hh[0], mm[0], ll[0]);
-      x3_split2(zc[2 * QN_ZS], zc[3 * QN_ZS], hh[1], mm[1], ll[1]);
-      unsigned short *pb = dzp + 3 * (size_t)nb * QN_HID + dz_planes_b(b0 / QN_TILE, o >> 4, kq * 16 + (o & 15));
-      *reinterpret_cast<u2 *>(pb) = u2{hh[0], hh[1]};
-      *reinterpret_cast<u2 *>(pb + 512) = u2{mm[0], mm[1]};
-      *reinterpret_cast<u2 *>(pb + 1024) = u2{ll[0], ll[1]};
-    }
-  } else
-  for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
-    const int o = i >> 2, mq = i & 3;
-    const f32x4 vv = {s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], s.z[(4 * mq + 2) * QN_ZS + o],
-                      s.z[(4 * mq + 3) * QN_ZS + o]};
-    ws_store(reinterpret_cast<f32x4 *>(dzT + (size_t)o * qw_ld(nb) + b0 + 4 * mq), vv);
   }
-  if (tid == 0) {
+  if (tid < NT) {
+    const int t = tid;
+    const float *red = tv[0].red + 2 * t;
     const int o_l = 9 * C * 16 + 48 + 384 + 128 * na + na;
-    gp[o_l] = ((ts.red[0] + ts.red[48]) + (ts.red[96] + ts.red[144])) + ((ts.red[192] + ts.red[240]) + (ts.red[288] + ts.red[336]));
-    gp[o_l + 1] = ((ts.red[1] + ts.red[49]) + (ts.red[97] + ts.red[145])) + ((ts.red[193] + ts.red[241]) + (ts.red[289] + ts.red[337]));
+    float *gp = t ? gpv[NT - 1] : gpv[0];
+    gp[o_l] = ((red[0] + red[48]) + (red[96] + red[144])) + ((red[192] + red[240]) + (red[288] + red[336]));
+    gp[o_l + 1] = ((red[1] + red[49]) + (red[97] + red[145])) + ((red[193] + red[241]) + (red[289] + red[337]));
   }
-  __syncthreads();   // dz tile complete (dgrad reads it); ts.red / scratch free again
+  __syncthreads();   // dz tiles complete (dgrad reads them); ts.red / scratch free again
+}
+
+template <int C, int NA>
+PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layout_t &L, int tid, int nb, int b0,
+                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT, float dz_scale,
+                      unsigned short *__restrict__ dzp = nullptr) {
+  const CnnSmem sv[1] = {s};
+  const TrainSmem tv[1] = {ts};
+  const int b0v[1] = {b0};
+  float *const gpv[1] = {gp};
+  train_head_nt<C, NA, 1>(sv, tv, L, tid, nb, b0v, inv_b, gpv, dzT, dz_scale, dzp);
 }
 
 // profiling: per-phase s_memtime stamps of workgroup 0 / wave 0 (PQN_T1_STAMPS=1), read by tools/t1_stamps.py
@@ -1843,6 +1894,7 @@ struct PairSmem {
                                   sizeof(uint32_t) * (2 * BITN + QN_TILE * 32) + sizeof(float) * (6 * QN_TILE + QN_WAVES * 48);
   // the freed h1 B region must hold the head / conv-wgrad scratch followed by the window masks, and the LN0-bwd staging
   static_assert(TrainCfg<C>::SCR + QN_WAVES * 192 <= QN_TILE * QN_H1S && QN_WAVES * 64 * QN_STG <= QN_TILE * QN_H1S, "scratch must fit h1 B");
+  static_assert(2 * 3 * QN_TILE * QN_ZS <= QN_TILE * QN_H1S, "the staged tiles of both heads (train_head_nt<.., 2>) must fit h1 B");
 };
 
 // FWD_ONLY: the forward half for the position-parallel backward -- conv, fc1, heads; dz leaves as bf16 planes in the
@@ -1984,14 +2036,15 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   }
   __syncthreads();   // z tiles complete; h1 B is free from here on (scratch)
   T1_STAMP(5);
-  // ---- heads ----
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  // ---- heads (both tiles together) ----
+  {
+    float *const gpv[2] = {gpT[0], gpT[1]};
+    unsigned short *dzpl = FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr;
     switch (L.a) {
-      case 3: train_head<C, 3>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale, FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr); break;
-      case 4: train_head<C, 4>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale, FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr); break;
-      case 6: train_head<C, 6>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale, FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr); break;
-      default: train_head<C, 0>(sT[t], tsT[t], L, tid, nb, b0T[t], inv_b, gpT[t], dzT, dz_scale, FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr); break;
+      case 3: train_head_nt<C, 3, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale, dzpl); break;
+      case 4: train_head_nt<C, 4, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale, dzpl); break;
+      case 6: train_head_nt<C, 6, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale, dzpl); break;
+      default: train_head_nt<C, 0, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale, dzpl); break;
     }
   }
   T1_STAMP(6);
