@@ -1,4 +1,4 @@
-"""The bench line contract (driver-facing): the committed round artefact profiles/r02_v3_bench.json -- the JSON line
+"""The bench line contract (driver-facing): the committed round artefact profiles/r02_v4_bench.json -- the JSON line
 bench.py printed on an MI355X at the end of round 2 -- carries every field the contract names, with consistent
 arithmetic."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_v3_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_v4_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
