@@ -2951,7 +2951,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
       f32x4 t[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q)
-        t[q] = reinterpret_cast<const f32x4 *>(wpart + (size_t)min(k0 + q, nks - 1) * QN_H1 * QN_HID)[j4];
+        t[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wpart + (size_t)min(k0 + q, nks - 1) * QN_H1 * QN_HID) + j4);   // read once
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const float keep = (k0 + q < nks) ? 1.0f : 0.0f;

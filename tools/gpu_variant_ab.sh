@@ -11,6 +11,9 @@ import json
 d = json.loads(open("gpurun_out/ab/bench_$1.json").read().strip().splitlines()[-1])
 print("$1: value %.4g  ms/step %.2f  T1 us %.1f frac %.3f" % (d["value"], d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"]))
 PY
+  if [ -n "$PROF" ]; then   # per-kernel averages of this variant
+    (R=$PWD; cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pv; rocprofv3 --kernel-trace -d /tmp/pv -o x -- python $R/bench.py --steps 4 --warmup 2 --no-extras --no-cpu-baseline > /dev/null 2>&1; python $R/tools/rocprof_summary.py /tmp/pv/x_results.db 5 | cut -c1-110 | tail -5)
+  fi
 }
 run default
 for v in "$@"; do
