@@ -1443,6 +1443,332 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
     ib_step(IBW - 1, std::false_type{});
 }
 
+// =====================================================================================================================
+// Opt-in "paired dgrad" form of the pair kernel's backward (PQN_T1_PD2=1).  Pieces:
+//   pd2_dz_planes       tile B's dz tile as pre-split dgrad A fragments in LDS (12 KB over z B + the parameter block)
+//   t1_dgrad_pair2_x3   rolled i-block loop, ONE pass over the dgrad-order planes for both tiles; results in place on
+//                       h1 A and into the h1 B region (which therefore stops being scratch)
+//   t1_ln0_bwd_ns       LN0 backward without the 40 KB staging buffer (channel sums by lane-swap reductions)
+//   t1_conv_wgrad_2r    conv weight gradient with its eight wave partials folded in two rounds of four (12 KB)
+// =====================================================================================================================
+// sum over the 64 lanes of each of 16 per-lane values; afterwards lane l holds, in out[r] (r = 0..3), the wave total of
+// value 8 (l >> 5) + 4 ((l >> 4) & 1) + r -- every lane of a 16-lane row holds the same four totals.  Halving by lane
+// swaps (v_permlane32_swap / v_permlane16_swap: 8 + 4 swaps), then a DPP row sum of the remaining four: fixed order.
+PQN_D void wave_sum16(const float (&v)[16], float (&out)[4]) {
+  float w[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[c]), __float_as_uint(v[c + 8]), false, false);
+    w[c] = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // lanes < 32: value c, lanes >= 32: value c + 8
+  }
+  float u[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[c]), __float_as_uint(w[c + 4]), false, false);
+    u[c] = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // even rows: w[c], odd rows: w[c + 4]
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) out[c] = group16_sum(u[c]);
+}
+
+template <int C>
+PQN_D void t1_ln0_bwd_ns(float *dh1, float *red, const float *__restrict__ theta, const pqn_cnn_layout_t &L,
+                         const float (*xkeep)[16], const float *rkeep, float *__restrict__ gp, int tid) {
+  using Cfg = CnnCfg<C>;
+  const int lane = tid & 63, wave = tid >> 6;
+  float ln0s[16];                                      // LayerNorm_0 scale: wave-uniform scalar loads
+#pragma unroll
+  for (int c = 0; c < 16; ++c) ln0s[c] = theta[L.off_ln0s + c];
+  float G[16], GX[16], DX[16];                         // per lane (= position): sums over the wave's samples
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { G[c] = 0.f; GX[c] = 0.f; DX[c] = 0.f; }
+#pragma unroll
+  for (int mm = 0; mm < QN_SPW; ++mm) {
+    const int msamp = QN_SPW * wave + mm;
+    f32x4 *gptr = reinterpret_cast<f32x4 *>(dh1 + msamp * QN_H1S + lane * 16);   // d relu-input (masked) -> dx in place
+    const float rstd = rkeep[mm];
+    float g[16];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const f32x4 v = gptr[qd];
+      g[4 * qd] = v.x; g[4 * qd + 1] = v.y; g[4 * qd + 2] = v.z; g[4 * qd + 3] = v.w;
+    }
+    float s1 = 0.f, s2 = 0.f, dxh[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      dxh[c] = g[c] * ln0s[c];
+      s1 += dxh[c];
+      s2 = fmaf(dxh[c], xkeep[mm][c], s2);
+    }
+    s1 *= (1.0f / 16.0f);
+    s2 *= (1.0f / 16.0f);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      float d4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * qd + e;
+        d4[e] = rstd * (dxh[c] - s1 - xkeep[mm][c] * s2);
+        G[c] += g[c];
+        GX[c] += g[c] * xkeep[mm][c];
+        DX[c] += d4[e];
+      }
+      gptr[qd] = f32x4{d4[0], d4[1], d4[2], d4[3]};
+    }
+  }
+  float tb[4], ts[4], ti[4];
+  wave_sum16(DX, tb);   // d conv bias
+  wave_sum16(GX, ts);   // d ln0 scale
+  wave_sum16(G, ti);    // d ln0 bias
+  if ((lane & 15) == 0) {
+    const int ch = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave * 48 + ch + r] = tb[r];
+      red[wave * 48 + 16 + ch + r] = ts[r];
+      red[wave * 48 + 32 + ch + r] = ti[r];
+    }
+  }
+  __syncthreads();
+  if (tid < 48) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < QN_WAVES; ++w) acc += red[w * 48 + tid];
+    gp[Cfg::KW * 16 + tid] = acc;
+  }
+}
+
+// conv weight gradient of one tile (bf16x3 operands, the C = 4 shape: wave = sample pair, all three row blocks): the
+// MFMA part of t1_conv_wgrad<C, 2>, the eight wave partials folded through 12 KB in two rounds of four -- the same
+// sum ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).  wm_base: QN_WAVES x 192 words; scr: 4 x NRB x 256 floats.
+template <int C>
+PQN_D void t1_conv_wgrad_2r(const float *dx, const uint32_t *bits, uint32_t *wm_base, float *scr, float *__restrict__ gp, int tid) {
+  using Cfg = CnnCfg<C>;
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C;
+  static_assert((NRB % 2) == 1 && QN_WAVES == 8, "wave = sample pair, all row blocks");
+  const int sg = wave;
+  const int i = lane & 15, kk = lane >> 4;
+  int kyL[NRB], shL[NRB];
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) {
+    const int k = 16 * j + i;
+    kyL[j] = (k < 9 * C) ? k / RB : 0;
+    shL[j] = (k < 9 * C) ? k % RB : 31;
+  }
+  f32x4 acc[NRB], accs[NRB];
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; accs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  uint32_t *wm = wm_base + wave * 192;
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm) {
+    const int msamp = 2 * sg + mm;
+    window_masks<C>(bits + msamp * Cfg::OW, wm, lane);
+    const float *dxm = dx + msamp * QN_H1S + lane;
+    float bv[16];
+    uint32_t wv[16][NRB];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      bv[q] = dxm[64 * q];
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) wv[q][j] = wm[(4 * q + kk) * 3 + kyL[j]];
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const float *b = bv + 8 * st;
+      const X3Frag bf = x3_split8(f32x4{b[0], b[1], b[2], b[3]}, f32x4{b[4], b[5], b[6], b[7]});
+      u32x4 af[NRB];
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) {
+        uint32_t d[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const uint32_t b0 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj][j], (uint32_t)shL[j], 1u);
+          const uint32_t b1 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj + 1][j], (uint32_t)shL[j], 1u);
+          d[jj] = ((b1 << 16) | b0) << 14;
+        }
+        af[j] = u32x4{d[0], d[1], d[2], d[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) accs[j] = X3_MFMA(af[j], bf.l, accs[j]);
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) acc[j] = X3_MFMA(af[j], bf.h, acc[j]);
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) accs[j] = X3_MFMA(af[j], bf.m, accs[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) {
+    x3_drain(acc[j], accs[j]);
+    acc[j] = (acc[j] + accs[j]) * (0.5f / 255.0f);
+  }
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {
+      float *pp = scr + ((slot * NRB + j) * 16 + 4 * kk) * 16 + i;
+      pp[0] = acc[j].x; pp[16] = acc[j].y; pp[32] = acc[j].z; pp[48] = acc[j].w;
+    }
+  };
+  constexpr int NE = Cfg::KW * 16, NEI = (NE + QN_THREADS - 1) / QN_THREADS;
+  float half0[NEI];
+  if (sg < 4) put(sg);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NEI; ++q) {
+    const int e = tid + q * QN_THREADS;
+    const float *pp = scr + min(e, NE - 1);
+    half0[q] = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
+  }
+  __syncthreads();
+  if (sg >= 4) put(sg - 4);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NEI; ++q) {
+    const int e = tid + q * QN_THREADS;
+    const float *pp = scr + min(e, NE - 1);
+    const float half1 = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
+    if (e < NE) gp[e] = half0[q] + half1;
+  }
+}
+
+// xhat[sample][position][16 channels] of a tile parked in global memory between the conv and the LN0 backward (lane =
+// position: 64 contiguous bytes per lane and sample, 4 KB per wave; written and read back by the same lane).  The slot is the tile's share of the split-K slab
+// region of the workspace, which T2 only writes after this kernel: nb x 2 KB per seed on both sides.
+PQN_D void xk_park(float *__restrict__ slot, const float (*xk)[16], int lane, int wave) {
+#pragma unroll
+  for (int mm = 0; mm < QN_SPW; ++mm) {
+    f32x4 *dst = reinterpret_cast<f32x4 *>(slot + ((size_t)(QN_SPW * wave + mm) * 64 + lane) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dst[q] = f32x4{xk[mm][4 * q], xk[mm][4 * q + 1], xk[mm][4 * q + 2], xk[mm][4 * q + 3]};   // L2-resident: streaming stores / loads measured slower
+  }
+}
+PQN_D void xk_fetch(const float *__restrict__ slot, float (*xk)[16], int lane, int wave) {
+#pragma unroll
+  for (int mm = 0; mm < QN_SPW; ++mm) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(slot + ((size_t)(QN_SPW * wave + mm) * 64 + lane) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = src[q];
+      xk[mm][4 * q] = v.x; xk[mm][4 * q + 1] = v.y; xk[mm][4 * q + 2] = v.z; xk[mm][4 * q + 3] = v.w;
+    }
+  }
+}
+
+PQN_D void pd2_dz_planes(const float *zt, u32x4 *planes, int lane, int wave) {   // planes may overlap zt: two barriers inside
+  X3Frag f;
+  if (wave < 4) {
+    const int sK = wave;
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(zt + (lane & 15) * QN_ZS + 32 * sK + 4 * (lane >> 4));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(zt + (lane & 15) * QN_ZS + 32 * sK + 16 + 4 * (lane >> 4));
+    f = x3_split8(lo, hi);
+  }
+  __syncthreads();
+  if (wave < 4) {
+    const int sK = wave;
+    planes[(sK * 3 + 0) * 64 + lane] = f.h; planes[(sK * 3 + 1) * 64 + lane] = f.m; planes[(sK * 3 + 2) * 64 + lane] = f.l;
+  }
+  __syncthreads();
+}
+
+// the dgrad of both tiles against one pass over the planes (see the block comment above).  Per tile and accumulator the
+// MFMA sequence is that of t1_dgrad_x3: same bits.
+PQN_D void t1_dgrad_pair2_x3(const float *ztA, float *outA, const u32x4 *planesB, float *outB, const uint32_t *maskB,
+                             const float *__restrict__ theta, const pqn_cnn_layout_t &L, int lane, int wave, int prot) {
+  const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
+  X3Frag afr[4];
+#pragma unroll
+  for (int sK = 0; sK < 4; ++sK) {
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(ztA + (lane & 15) * QN_ZS + 32 * sK + 4 * (lane >> 4));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(ztA + (lane & 15) * QN_ZS + 32 * sK + 16 + 4 * (lane >> 4));
+    afr[sK] = x3_split8(lo, hi);
+  }
+  const int col = lane & 15, r0 = 4 * (lane >> 4);
+  constexpr int IBW = 64 / QN_WAVES;
+  const int ib_first = IBW * wave;
+  auto frag = [&](int pl, int ibk, int sK) {
+    const int ib = ib_first + ((ibk + prot) & (IBW - 1));
+    return wd[(size_t)pl * (X3_PLANE / 8) + ((ib * 4 + sK) * 64 + lane)];
+  };
+  auto bfrag = [&](int sK) {
+    X3Frag b;
+    b.h = planesB[(sK * 3 + 0) * 64 + lane]; b.m = planesB[(sK * 3 + 1) * 64 + lane]; b.l = planesB[(sK * 3 + 2) * 64 + lane];
+    return b;
+  };
+  u32x4 ring[4][3];
+#pragma unroll
+  for (int sK = 0; sK < 4; ++sK)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, 0, sK);
+  auto ib_step = [&](int ibk, auto more_t) {
+    constexpr bool more = decltype(more_t)::value;
+    const int ib = ib_first + ((ibk + prot) & (IBW - 1));
+    const int off = r0 * QN_H1S + 16 * ib + col;
+    float *pA = outA + off, *pB = outB + off;
+    const float m0 = pA[0], m1 = pA[QN_H1S], m2 = pA[2 * QN_H1S], m3 = pA[3 * QN_H1S];   // tile A: relu mask = its h1, in place
+    const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(maskB) + ib * 4;   // tile B: packed bits
+    const int bsel = col * 4 + (lane >> 4);
+    const unsigned long long w0 = mw[0], w1 = mw[1], w2 = mw[2], w3 = mw[3];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    {   // tile A
+      f32x4 acc_b[2] = {z4, z4}, acc_s[2] = {z4, z4}, acc_c[2] = {z4, z4};
+#pragma unroll
+      for (int sK = 0; sK < 4; ++sK) {
+        X3Frag bf;
+        bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
+        const X3Frag &a = afr[sK];
+        acc_s[0] = X3_MFMA(a.l, bf.h, acc_s[0]);
+        acc_b[0] = X3_MFMA(a.m, bf.h, acc_b[0]);
+        acc_s[1] = X3_MFMA(a.h, bf.l, acc_s[1]);
+        acc_b[1] = X3_MFMA(a.h, bf.m, acc_b[1]);
+        acc_c[0] = X3_MFMA(a.m, bf.m, acc_c[0]);
+        acc_c[1] = X3_MFMA(a.h, bf.h, acc_c[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
+      x3_drain(acc_c[0], acc_c[1]);
+      const f32x4 acc0 = ((acc_b[0] + acc_b[1]) + acc_c[1]) + ((acc_s[0] + acc_s[1]) + acc_c[0]);
+      pA[0] = m0 > 0.0f ? acc0.x : 0.0f;
+      pA[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
+      pA[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
+      pA[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
+    }
+    {   // tile B: the same plane fragments once more, its own dz fragments from LDS one K step ahead
+      f32x4 acc_b[2] = {z4, z4}, acc_s[2] = {z4, z4}, acc_c[2] = {z4, z4};
+      X3Frag bq = bfrag(0);
+#pragma unroll
+      for (int sK = 0; sK < 4; ++sK) {
+        X3Frag bf;
+        bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
+        const X3Frag a = bq;
+        if (sK + 1 < 4) bq = bfrag(sK + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc_s[0] = X3_MFMA(a.l, bf.h, acc_s[0]);
+        acc_b[0] = X3_MFMA(a.m, bf.h, acc_b[0]);
+        acc_s[1] = X3_MFMA(a.h, bf.l, acc_s[1]);
+        acc_b[1] = X3_MFMA(a.h, bf.m, acc_b[1]);
+        acc_c[0] = X3_MFMA(a.m, bf.m, acc_c[0]);
+        acc_c[1] = X3_MFMA(a.h, bf.h, acc_c[1]);
+        if (more) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, ibk + 1, sK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
+      x3_drain(acc_c[0], acc_c[1]);
+      const f32x4 acc0 = ((acc_b[0] + acc_b[1]) + acc_c[1]) + ((acc_s[0] + acc_s[1]) + acc_c[0]);
+      pB[0] = ((w0 >> bsel) & 1ull) ? acc0.x : 0.0f;
+      pB[QN_H1S] = ((w1 >> bsel) & 1ull) ? acc0.y : 0.0f;
+      pB[2 * QN_H1S] = ((w2 >> bsel) & 1ull) ? acc0.z : 0.0f;
+      pB[3 * QN_H1S] = ((w3 >> bsel) & 1ull) ? acc0.w : 0.0f;
+    }
+  };
+#pragma unroll 1
+  for (int ibk = 0; ibk < IBW - 1; ++ibk) ib_step(ibk, std::true_type{});
+  ib_step(IBW - 1, std::false_type{});
+}
+
 // ---- P5: LN0 backward of one 16-sample tile, in place on dh1 (d relu-input -> dx); ends with the workgroup barrier
 // after which dx is complete and the 48 channel sums are in gp.  stg_base: QN_WAVES x 64 x QN_STG floats of scratch.
 template <int C>
@@ -1899,12 +2225,14 @@ struct PairSmem {
 
 // FWD_ONLY: the forward half for the position-parallel backward -- conv, fc1, heads; dz leaves as bf16 planes in the
 // (then unused) h1^T region; no h1^T, no relu masks, no LN0 state kept, no backward below the heads.
-template <int C, bool FWD_ONLY>
+// PD2: the opt-in paired-dgrad backward (see t1_dgrad_pair2_x3); xkws = the seed's split-K slab region of the workspace
+template <int C, bool FWD_ONLY, bool PD2 = false>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
     float *__restrict__ dzT, float *__restrict__ h1T, float *__restrict__ gpart, int ablate, pqn_seeds_t sd, float dz_scale,
-    unsigned long long *__restrict__ stamps) {
+    unsigned long long *__restrict__ stamps, float *__restrict__ xkws = nullptr) {
+  static_assert(!(FWD_ONLY && PD2), "the paired dgrad belongs to the full kernel");
   using Cfg = CnnCfg<C>;
   using PS = PairSmem<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1924,6 +2252,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   dzT += seed * sd.ws_stride;
   h1T += seed * sd.ws_stride;
   gpart += seed * sd.ws_stride;
+  if (PD2) xkws += seed * sd.ws_stride;
   auto row_of = [&](int64_t key) -> int64_t {
     const uint32_t j = (uint32_t)(key & sd.idx_mask);
     if (sd.n_env_total == sd.n_env) return (int64_t)j;
@@ -1999,6 +2328,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   phase1_conv<C, !FWD_ONLY, true, true>(sT[0], tid, xkA, rkA);
   T1_STAMP(2);
   phase1_conv<C, !FWD_ONLY, true, true>(sT[1], tid, xkB, rkB);
+  float *slotB = PD2 ? xkws + (size_t)pair_id * (QN_TILE * 64 * 16) : nullptr;
+  if (PD2) xk_park(slotB, xkB, lane, wave);   // tile B's xhat leaves the register file until its LN0 backward
   __syncthreads();
   T1_STAMP(3);
   if (FWD_ONLY) phase2_fc1_x3<3, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1]);   // no LN0 state alive: room for a 3-deep ring
@@ -2049,8 +2380,35 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   }
   T1_STAMP(6);
   if (FWD_ONLY) return;
-  // ---- backward of A in place on h1 A, then of B into the same region ----
   const int prot = pair_id & (64 / QN_WAVES - 1);
+  if constexpr (PD2) {
+    // ---- backward, paired-dgrad form: dgrad of both tiles in one pass over the planes (A in place on h1 A, B into
+    // the h1 B region), LN0 backward of both without staging, conv weight gradients with their scratch in the dead
+    // z / parameter tiles ----
+    u32x4 *planesB = reinterpret_cast<u32x4 *>(zB);                   // 12 KB over z B | conv parameters | head parameters
+    uint32_t *wm2 = reinterpret_cast<uint32_t *>(zA);                 // 6 KB of window masks ...
+    float *scr2 = zA + QN_WAVES * 192;                                // ... and 12 KB of wave partials, all inside z A .. hp
+    float *redB = reinterpret_cast<float *>(maskB);                   // tile B's cross-wave sums (the mask bits are dead by then)
+    static_assert(sizeof(float) * (QN_WAVES * 192 + 4 * ((9 * C + 15) / 16) * 256) <=
+                      sizeof(float) * (2 * QN_TILE * QN_ZS + PS::WCN + QN_HP_FLOATS), "conv-wgrad scratch must fit z A .. hp");
+    static_assert(12288 <= sizeof(float) * (QN_TILE * QN_ZS + PS::WCN + QN_HP_FLOATS), "dz planes of tile B must fit z B .. hp");
+    static_assert(QN_WAVES * 48 * sizeof(float) <= QN_TILE * 32 * sizeof(uint32_t), "tile B's sums must fit the mask bits");
+    pd2_dz_planes(zB, planesB, lane, wave);
+    t1_dgrad_pair2_x3(zA, h1A, planesB, h1B, maskB, theta, L, lane, wave, prot);
+    __syncthreads();
+    T1_STAMP(7);
+    xk_fetch(slotB, xkB, lane, wave);   // back from L2 while tile A's LN0 backward runs
+    t1_ln0_bwd_ns<C>(h1A, red, theta, L, xkA, rkA, gpT[0], tid);
+    t1_ln0_bwd_ns<C>(h1B, redB, theta, L, xkB, rkB, gpT[1], tid);
+    T1_STAMP(8);
+    t1_conv_wgrad_2r<C>(h1A, bitsA, wm2, scr2, gpT[0], tid);
+    __syncthreads();   // tile A's partials fully read
+    T1_STAMP(9);
+    t1_conv_wgrad_2r<C>(h1B, bitsB, wm2, scr2, gpT[1], tid);
+    T1_STAMP(10);
+    return;
+  }
+  // ---- backward of A in place on h1 A, then of B into the same region ----
   t1_dgrad_x3<false>(zA, h1A, nullptr, theta, L, lane, wave, prot);
   __syncthreads();
   T1_STAMP(7);
@@ -3324,6 +3682,19 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       fwd_attr = true;
     }
   }
+  // opt-in paired-dgrad backward of the pair kernel (PQN_T1_PD2=1; C = 4 only)
+  static const int pd2_env = getenv("PQN_T1_PD2") ? atoi(getenv("PQN_T1_PD2")) : 0;
+  const bool use_pd2 = use_pair && !use_pos && pd2_env && C == 4;
+  if (use_pd2) {
+    if constexpr (C == 4) {
+      static bool pd2_attr = false;
+      if (!pd2_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem<C>::BYTES);
+        pd2_attr = true;
+      }
+    }
+  }
   const int gs_max = pqn_cnn_seed_group(L.matmul_f16, sd.nseeds);
   for (int s0 = 0; s0 < sd.nseeds; s0 += gs_max) {
     const int gs = min(gs_max, sd.nseeds - s0);
@@ -3342,6 +3713,10 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
                          reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg, g_t2_stamps);
       if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
       continue;   // no T2: dW1 was accumulated in registers
+    } else if (use_pair && use_pd2) {
+      if constexpr (C == 4)
+        hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb,
+                           idx, bits, action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps, wpart);
     } else if (use_pair)
       hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
                          action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);

@@ -369,6 +369,28 @@ def test_pair_form_of_the_rollout_kernel_is_bit_identical(gpu):
     assert all(int(l.split()[-1]) > 0 for l in outs[0][:3])   # episode ends (auto-reset) inside the windows
 
 
+def test_paired_dgrad_opt_in_path(gpu):
+    """PQN_T1_PD2=1 (with the pair kernel forced): the dgrad of both tiles against one pass over the weight planes
+    (t1_dgrad_pair2_x3), LN0 backward without its staging buffer, two-round conv-wgrad fold.
+    Repeats bit-identical, gradient equal to the f32-MFMA mode of the default kernels to f32 rounding at 1, 8 and 256
+    pairs.  Opt-in path (not faster under full load yet), kept tested."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PQN_T1_PAIR="2", PQN_T1_PD2="1", BRIEF="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_x3_conv.py")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [l for l in out.stdout.splitlines() if l.startswith("C 4 ")]
+    assert len(rows) == 3, out.stdout
+    for l in rows:
+        rep = float(re.search(r"rep-to-rep max\|dg\| ([0-9.e+-]+)", l).group(1))
+        dif = float(re.search(r"max\|g_x3 - g_f32\| ([0-9.e+-]+)", l).group(1))
+        assert rep == 0.0 and dif < 2e-5, l
+
+
 def test_position_parallel_backward_opt_in_path(gpu):
     """PQN_BWD_POS=2 (with the pair kernel forced) routes the 4096-sample case through the forward-only pair kernel +
     qnet_cnn_bwd_pos_kernel + the reduction without split-K slabs: repeats bit-identical, gradient
