@@ -29,6 +29,11 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) <= 1e-6 * r["achieved"]
     assert r["flop_per_launch"] == 674048 * 4096 * 16
     assert r["traffic"] is None or (r["traffic"] > 0 and "from file" in r["traffic_source"])
+    # the headline's traffic comes from PMC passes of the 16-seed launch shape itself, not from a scaled single-seed pass
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_train_kernel_bf16x3_seeds16.json")))
+    assert pmc["seeds_per_launch"] == 16 and "seeds16" in r["traffic_source"]
+    assert abs(r["traffic"] - pmc["hbm_bytes_per_launch"]) <= 1e-6 * r["traffic"]
+    assert abs(pmc["hbm_bytes_per_launch"] - (2 * pmc["FETCH_SIZE_KB_avg"] + pmc["WRITE_SIZE_KB_avg"]) * 1024.0) < 1.0
     assert 0.0 < r["bf16_pipe"]["frac"] < 1.0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
