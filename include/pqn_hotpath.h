@@ -202,6 +202,19 @@ int pqn_qnet_cnn_grad(const pqn_cnn_layout_t *layout /* host */, int32_t nb, con
                       const uint32_t *obs_bits, const int32_t *action, const float *target, const float *theta,
                       const float *w1b, float *grad, const int32_t *count, float *workspace, float *loss_out,
                       float *qv_out, void *stream);
+/* jax.vmap over seeds (pqn_minatar.py:459-461) of value_and_grad(_loss_fn) (:271-291): num_seeds independent
+ * minibatches of nb samples in the SAME launches (grid.y = seed).  Every per-seed buffer is slice `s` of a stacked
+ * allocation: idx[s*idx_stride + j], theta/grad[s*theta_stride ..], w1b[s*131072 ..], count[s],
+ * workspace[s*ws_stride ..] (ws_stride >= pqn_qnet_cnn_workspace_floats), loss_out[s], qv_out[s].  Transition
+ * idx value j of seed s reads row (j / n_env) * n_env_total + s * n_env + j % n_env of obs_bits / action / target
+ * -- the stacked [T][S*N] rollout record; with n_env_total == n_env all seeds index one shared pool directly.
+ * This is the launch shape of the training kernels inside pqn_cnn_update_seeds (16 seeds x 4096 samples = the
+ * bench's headline launch: pair kernels with the XCD-aware (seed, pair) mapping). */
+int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t *layout /* host */, int32_t num_seeds, int32_t nb, const int64_t *idx,
+                            int64_t idx_stride, int32_t n_env, int32_t n_env_total, const uint32_t *obs_bits,
+                            const int32_t *action, const float *target, const float *theta, int64_t theta_stride,
+                            const float *w1b, float *grad, const int32_t *count, float *workspace, int64_t ws_stride,
+                            float *loss_out, float *qv_out, void *stream);
 int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *layout /* host */, float *theta, float *w1b, const float *grad,
                        float *m, float *v, int32_t *count, float lr_init, float lr_end, double lr_steps,
                        float max_norm, float *workspace, float *gnorm_out, int32_t recompute_norm, void *stream);
@@ -325,6 +338,18 @@ int pqn_debug_t2_stamps(unsigned long long *out /* host, 32 entries */);
 /* Seeds covered by ONE launch of the training kernel (and therefore by one pqn_prof_read sample) when `nseeds` seeds
  * are batched: nseeds unless the profiling override PQN_SEED_GROUP cuts the launches into T1 -> T2 pairs per group. */
 int pqn_cnn_seed_group(int matmul_mode, int nseeds);
+
+/* Run-time switches of the kernel selection (profiling, A/B runs, tests; no reference counterpart -- XLA picks its
+ * fusions itself).  Names: "t1_pair", "rollout_pair" (pair form of the bf16x3 training / rollout kernel: 0 never,
+ * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
+ * variants), "seed_group", "ablate_train", "ablate", "fused_tail".  Each starts from its PQN_<NAME> environment
+ * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
+int pqn_set_option(const char *name, int32_t value);
+int pqn_get_option(const char *name, int32_t *value /* host */);
+/* Which form the LAST enqueued training (pqn_qnet_cnn_grad / pqn_cnn_update*) and rollout (pqn_cnn_rollout*) launch
+ * used: 0 none yet, 1 single-tile kernels, 2 pair kernels, 3 pair + paired dgrad, 4 pair forward + position-parallel
+ * backward.  Lets a test assert in-process that the configuration it means to cover is the one that ran. */
+int pqn_cnn_last_kernel_form(int32_t *train_form /* host, nullable */, int32_t *rollout_form /* host, nullable */);
 
 /* ---- fused MLP Q-network (QNetwork of pqn_gymnax.py:29-58, layer_norm, NORM_INPUT=False) ----------- */
 /* Parameter buffer in flax order with 16-B aligned segments and natural (in,out) kernels:

@@ -57,6 +57,9 @@ SIGNATURES = {
                                      c_uint64, c_void_p]),
     "pqn_qnet_cnn_workspace_floats": (c_int64, [c_void_p, c_int32]),
     "pqn_qnet_cnn_grad": (c_int, [c_void_p, c_int32] + [c_void_p] * 11 + [c_void_p]),
+    "pqn_qnet_cnn_grad_seeds": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                        c_void_p, c_void_p, c_void_p]),
     "pqn_qnet_cnn_apply": (c_int, [c_void_p] * 7 + [c_float, c_float, C.c_double, c_float] + [c_void_p, c_void_p, c_int32, c_void_p]),
     "pqn_qnet_cnn_pack_w1b": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_prof_enable": (c_int, [c_int32]),
@@ -75,6 +78,9 @@ SIGNATURES = {
     "pqn_debug_t1_stamps": (c_int, [c_void_p]),
     "pqn_debug_t2_stamps": (c_int, [c_void_p]),
     "pqn_cnn_seed_group": (c_int, [c_int, c_int]),
+    "pqn_set_option": (c_int, [C.c_char_p, c_int32]),
+    "pqn_get_option": (c_int, [C.c_char_p, c_void_p]),
+    "pqn_cnn_last_kernel_form": (c_int, [c_void_p, c_void_p]),
     "pqn_mlp_layout": (c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pqn_mlp_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64,
                                 c_void_p]),
@@ -139,3 +145,42 @@ def fold_in(key: int, data: int) -> int:
 def prng_key(seed: int) -> int:
     """PRNGKey(seed): key words (seed >> 32, seed & 0xffffffff) packed in a uint64."""
     return int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
+KERNEL_FORMS = {0: "none", 1: "single", 2: "pair", 3: "pair+pd2", 4: "pair+pos"}
+
+
+def set_option(name: str, value: int):
+    """Run-time switch of the kernel selection (include/pqn_hotpath.h: pqn_set_option)."""
+    check(load().pqn_set_option(name.encode(), int(value)), "pqn_set_option")
+
+
+def get_option(name: str) -> int:
+    v = c_int32(0)
+    check(load().pqn_get_option(name.encode(), C.addressof(v)), "pqn_get_option")
+    return int(v.value)
+
+
+def last_kernel_form():
+    """(training, rollout) kernel forms of the last enqueued launches, as names from KERNEL_FORMS."""
+    a, b = c_int32(0), c_int32(0)
+    check(load().pqn_cnn_last_kernel_form(C.addressof(a), C.addressof(b)), "pqn_cnn_last_kernel_form")
+    return KERNEL_FORMS.get(a.value, str(a.value)), KERNEL_FORMS.get(b.value, str(b.value))
+
+
+class options:
+    """Context manager: with _lib.options(t1_pair=2, bwd_pos=0): ... -- restores the previous values on exit."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False

@@ -4,6 +4,7 @@
 // in include/pqn_hotpath.h.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pqn_common.h"
@@ -31,6 +32,54 @@ int pqn_check_launch(const char *what) {
 
 extern "C" const char *pqn_last_error(void) { return g_err; }
 extern "C" int pqn_version(void) { return 1; }
+
+// run-time switches (pqn_common.h): value = environment variable at first use, else the default; pqn_set_option overrides
+static struct {
+  const char *name, *env;
+  int def, value;
+  bool init;
+} g_opts[PQN_OPT_COUNT] = {
+    {"t1_pair", "PQN_T1_PAIR", 1, 0, false},       {"rollout_pair", "PQN_ROLLOUT_PAIR", 1, 0, false},
+    {"t1_pd2", "PQN_T1_PD2", 0, 0, false},         {"bwd_pos", "PQN_BWD_POS", 0, 0, false},
+    {"seed_group", "PQN_SEED_GROUP", 0, 0, false}, {"ablate_train", "PQN_ABLATE_TRAIN", 0, 0, false},
+    {"ablate", "PQN_ABLATE", 0, 0, false},         {"fused_tail", "PQN_FUSED_TAIL", 0, 0, false},
+};
+static int g_forms[2] = {PQN_FORM_NONE, PQN_FORM_NONE};
+
+int pqn_opt(int id) {
+  if (id < 0 || id >= PQN_OPT_COUNT) return 0;
+  if (!g_opts[id].init) {
+    const char *e = getenv(g_opts[id].env);
+    g_opts[id].value = e ? atoi(e) : g_opts[id].def;
+    g_opts[id].init = true;
+  }
+  return g_opts[id].value;
+}
+void pqn_note_kernel_form(int which, int form) { g_forms[which & 1] = form; }
+
+static int opt_index(const char *name) {
+  for (int i = 0; name && i < PQN_OPT_COUNT; ++i)
+    if (!strcmp(name, g_opts[i].name)) return i;
+  return -1;
+}
+extern "C" int pqn_set_option(const char *name, int32_t value) {
+  const int i = opt_index(name);
+  PQN_REQUIRE(i >= 0, "pqn_set_option: unknown option '%s'", name ? name : "(null)");
+  g_opts[i].value = value;
+  g_opts[i].init = true;
+  return PQN_OK;
+}
+extern "C" int pqn_get_option(const char *name, int32_t *value) {
+  const int i = opt_index(name);
+  PQN_REQUIRE(i >= 0 && value, "pqn_get_option: unknown option '%s' or NULL output", name ? name : "(null)");
+  *value = pqn_opt(i);
+  return PQN_OK;
+}
+extern "C" int pqn_cnn_last_kernel_form(int32_t *train_form, int32_t *rollout_form) {
+  if (train_form) *train_form = g_forms[0];
+  if (rollout_form) *rollout_form = g_forms[1];
+  return PQN_OK;
+}
 
 extern "C" void pqn_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) {
   pqn_tf2x32(key[0], key[1], ctr[0], ctr[1], out[0], out[1]);

@@ -70,6 +70,26 @@ int pqn_check_launch(const char *what);
     }                                 \
   } while (0)
 
+// ---------------------------------------------------------------------------
+// run-time switches of the kernel selection (profiling, A/B runs, tests): pqn_set_option / pqn_get_option in
+// include/pqn_hotpath.h.  Each starts from its PQN_* environment variable (read once) or its default.
+// ---------------------------------------------------------------------------
+enum {
+  PQN_OPT_T1_PAIR = 0,    // PQN_T1_PAIR: pair form of the bf16x3 training kernel 0 never / 1 when its grid fills the chip / 2 always
+  PQN_OPT_ROLLOUT_PAIR,   // PQN_ROLLOUT_PAIR: pair form of the bf16x3 rollout kernel, same meaning
+  PQN_OPT_T1_PD2,         // PQN_T1_PD2: opt-in paired-dgrad backward of the pair kernel
+  PQN_OPT_BWD_POS,        // PQN_BWD_POS: position-parallel backward 0 off / 1 with >= 16 seeds / 2 always
+  PQN_OPT_SEED_GROUP,     // PQN_SEED_GROUP: seeds per T1 -> T2 launch pair (0 = all)
+  PQN_OPT_ABLATE_TRAIN,   // PQN_ABLATE_TRAIN: phase ablation mask of the training kernels (profiling)
+  PQN_OPT_ABLATE,         // PQN_ABLATE: phase ablation of the forward kernel (profiling)
+  PQN_OPT_FUSED_TAIL,     // PQN_FUSED_TAIL: optimizer tail 0 = reduce + RAdam kernels / 1 = one ticketed kernel
+  PQN_OPT_COUNT
+};
+int pqn_opt(int id);
+// which form of the training / rollout kernels the last launch used (pqn_cnn_last_kernel_form)
+enum { PQN_FORM_NONE = 0, PQN_FORM_SINGLE = 1, PQN_FORM_PAIR = 2, PQN_FORM_PAIR_PD2 = 3, PQN_FORM_PAIR_POS = 4 };
+void pqn_note_kernel_form(int which /* 0 = training, 1 = rollout */, int form);
+
 // bf16x3 weight planes (pqn_qnet.hip): x = hi + mid + lo exactly, each a bf16 (round to nearest even); element (i, o)
 // of the fc1 kernel goes to the forward-order and dgrad-order slot of every plane.  Plane = 131072 bf16; the six
 // planes are [3 forward | 3 dgrad].
@@ -161,7 +181,7 @@ int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStrea
 // S <= 128): one global radix sort orders every seed's segment exactly as its single-seed keys would be
 int pqn_shuffle_keys_seeds(const uint64_t *key_dev, int key_stride, int nseeds, int n, int64_t *keys, hipStream_t st);
 int pqn_cnn_grad_reduce_blocks(int total);   // number of sum-of-squares partials pqn_qnet_cnn_grad leaves in the scratch
-int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
+int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out,
                             const pqn_seeds_t &sd, hipStream_t st, bool with_reduce = true);

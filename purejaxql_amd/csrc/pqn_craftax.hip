@@ -649,20 +649,36 @@ void pqn_craftax_spec(pqn_env_spec_t *s) {
 }
 
 // scratch for the reset slots: one i32 per env behind the state words is not available (caller-owned layout), so the
-// slots live in a small cached device buffer owned by the library (grown on demand; not on the per-step hot path)
-static int32_t *g_cc_slots = nullptr;
-static int g_cc_slots_n = 0;
-static int32_t *cc_slots(int n) {
-  if (n > g_cc_slots_n) {
-    if (g_cc_slots) (void)hipFree(g_cc_slots);
-    if (hipMalloc(&g_cc_slots, sizeof(int32_t) * (size_t)n) != hipSuccess) { g_cc_slots = nullptr; g_cc_slots_n = 0; return nullptr; }
-    g_cc_slots_n = n;
+// slots live in small device buffers owned by the library -- ONE PER STREAM (grown on demand; not on the per-step hot
+// path): seeds that run as concurrent HIP streams (pqn.py: _vmap_streams) each call reset / step on their own stream, and a
+// shared buffer would let one seed's cc_reset_kernel overwrite the slots another seed's cc_world_kernel is about to read.
+#define CC_MAX_STREAMS 64
+static struct { hipStream_t st; int32_t *p; int n; } g_cc_slots[CC_MAX_STREAMS];
+static int g_cc_nstreams = 0;
+static int32_t *cc_slots(int n, hipStream_t st) {
+  int k = 0;
+  while (k < g_cc_nstreams && g_cc_slots[k].st != st) ++k;
+  if (k == g_cc_nstreams) {
+    if (g_cc_nstreams == CC_MAX_STREAMS) {   // table full: recycle the first entry once its stream has drained
+      k = 0;
+      (void)hipStreamSynchronize(g_cc_slots[0].st);
+    } else {
+      ++g_cc_nstreams;
+      g_cc_slots[k].p = nullptr;
+      g_cc_slots[k].n = 0;
+    }
+    g_cc_slots[k].st = st;
   }
-  return g_cc_slots;
+  if (n > g_cc_slots[k].n) {
+    if (g_cc_slots[k].p) { (void)hipStreamSynchronize(st); (void)hipFree(g_cc_slots[k].p); }
+    if (hipMalloc(&g_cc_slots[k].p, sizeof(int32_t) * (size_t)n) != hipSuccess) { g_cc_slots[k].p = nullptr; g_cc_slots[k].n = 0; return nullptr; }
+    g_cc_slots[k].n = n;
+  }
+  return g_cc_slots[k].p;
 }
 
 int pqn_craftax_reset(int n, uint64_t key, uint32_t *state, float *obs, hipStream_t st) {
-  int32_t *slots = cc_slots(n);
+  int32_t *slots = cc_slots(n, st);
   PQN_REQUIRE(slots, "Craftax-Classic: cannot allocate the reset-slot scratch");
   const dim3 g((n + 255) / 256), b(256);
   hipLaunchKernelGGL(cc_reset_kernel, g, b, 0, st, n, 0, 1, (const uint8_t *)nullptr, (const uint64_t *)nullptr, state, slots);
@@ -674,7 +690,7 @@ int pqn_craftax_reset(int n, uint64_t key, uint32_t *state, float *obs, hipStrea
 // reset_ratio == 0: gymnax-style auto-reset; > 0: OptimisticResetVecEnvWrapper semantics (scratch = u64[n])
 int pqn_craftax_step(int n, uint64_t key, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
                      const pqn_step_out_t &out, int reset_ratio, uint64_t *scratch, int32_t *slot_out, hipStream_t st) {
-  int32_t *slots = slot_out ? slot_out : cc_slots(n);
+  int32_t *slots = slot_out ? slot_out : cc_slots(n, st);
   PQN_REQUIRE(slots, "Craftax-Classic: cannot allocate the reset-slot scratch");
   PQN_REQUIRE(out.obs_bits == nullptr, "Craftax-Classic has no packed observation");
   PQN_REQUIRE(!(reset_ratio > 0 && key_dev), "Craftax-Classic: optimistic resets take the step key by value");

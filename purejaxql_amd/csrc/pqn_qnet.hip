@@ -3419,7 +3419,7 @@ static int launch_fwd(int n, const uint32_t *bits, const float *theta, const pqn
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  static const int ablate = getenv("PQN_ABLATE") ? atoi(getenv("PQN_ABLATE")) : 0;  // profiling only
+  const int ablate = pqn_opt(PQN_OPT_ABLATE);  // profiling only
   hipLaunchKernelGGL((qnet_cnn_fwd_kernel<C>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n, bits, theta, L,
                      q, action, qmax, eps, key, eps_dev, key_dev, ablate);
   return pqn_check_launch("pqn_qnet_cnn_forward");
@@ -3467,7 +3467,7 @@ static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t 
   // loop, and carrying all three fc1 / conv variants in one kernel cost 27 spilled VGPRs
   // pair form (32 envs per workgroup, shared fc1 weight stream): bf16x3 mode, when its LDS layout fits, the envs (of
   // each seed) come in pairs of tiles and the grid still gives every CU a workgroup; PQN_ROLLOUT_PAIR=0 / 2: never / always
-  static const int rp_env = getenv("PQN_ROLLOUT_PAIR") ? atoi(getenv("PQN_ROLLOUT_PAIR")) : 1;
+  const int rp_env = pqn_opt(PQN_OPT_ROLLOUT_PAIR);
   constexpr size_t pair_smem = sizeof(float) * (2 * QN_TILE * QN_H1S + 2 * QN_TILE * QN_ZS + PairSmem<C>::WCN + QN_HP_FLOATS) +
                                sizeof(uint32_t) * 2 * PairSmem<C>::BITN;
   const bool use_pair = rp_env && L.matmul_f16 == 2 && pair_smem <= 160 * 1024 && n % (2 * QN_TILE) == 0 &&
@@ -3483,8 +3483,10 @@ static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t 
                        t_len, state, bits, theta, L, action, qmax, rec.reward, rec.done, rec.discount,
                        rec.returned_episode_returns, rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys,
                        rscale, store_obs, n_per_seed, theta_stride, keys_stride);
+    pqn_note_kernel_form(1, PQN_FORM_PAIR);
     return pqn_check_launch("pqn_qnet_cnn_rollout");
   }
+  pqn_note_kernel_form(1, PQN_FORM_SINGLE);
   auto kern = L.matmul_f16 == 2 ? &qnet_cnn_rollout_kernel<C, Env, 2>
                                 : (L.matmul_f16 == 1 ? &qnet_cnn_rollout_kernel<C, Env, 1> : &qnet_cnn_rollout_kernel<C, Env, 0>);
   hipLaunchKernelGGL(kern, dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n,
@@ -3611,7 +3613,7 @@ extern "C" int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries *
 
 // seeds per T1 -> T2 launch pair (see launch_train); also how many seeds one timed T1 launch covers (pqn_prof_read)
 extern "C" int pqn_cnn_seed_group(int matmul_mode, int nseeds) {
-  static const int env_gs = getenv("PQN_SEED_GROUP") ? atoi(getenv("PQN_SEED_GROUP")) : 0;   // profiling override
+  const int env_gs = pqn_opt(PQN_OPT_SEED_GROUP);   // profiling override
   if (env_gs > 0) return min(env_gs, nseeds);
   (void)matmul_mode;
   return nseeds;   // measured (16 seeds x 4096 samples, bf16x3): groups of 16 / 8 / 4 / 2 -> 50.4 / 50.7 / 51.3 / 55.5 ms per update
@@ -3641,7 +3643,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     attr_set = true;
   }
   const float inv_b = 1.0f / (float)nb;
-  static const int ablate = getenv("PQN_ABLATE_TRAIN") ? atoi(getenv("PQN_ABLATE_TRAIN")) : 0;  // profiling only
+  const int ablate = pqn_opt(PQN_OPT_ABLATE_TRAIN);  // profiling only
   if (!g_t1_stamps && getenv("PQN_T1_STAMPS")) {
     if (hipMalloc(&g_t1_stamps, 64 * sizeof(unsigned long long)) != hipSuccess) g_t1_stamps = nullptr;
   }
@@ -3654,7 +3656,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // Cache.  Measured, it does not pay (see pqn_cnn_seed_group): the default is one group.
   // pair form of T1 (two tiles per workgroup, shared fc1 weight stream): bf16x3 mode, when its LDS layout fits and the
   // minibatch has an even number of tiles; PQN_T1_PAIR=0 keeps the single-tile kernel (profiling / A-B runs)
-  static const int pair_env = getenv("PQN_T1_PAIR") ? atoi(getenv("PQN_T1_PAIR")) : 1;
+  const int pair_env = pqn_opt(PQN_OPT_T1_PAIR);
   // (and the launch still has a workgroup for every CU: a single 4096-sample seed is 128 pairs, half a chip)
   const bool use_pair = pair_env && L.matmul_f16 == 2 && PairSmem<C>::BYTES <= 160 * 1024 && ntiles >= 2 && (ntiles % 2) == 0 &&
                         ((ntiles / 2) * sd.nseeds >= 256 || pair_env == 2);   // PQN_T1_PAIR=2: pair form at any size (tests)
@@ -3669,7 +3671,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // position-parallel backward (qnet_cnn_bwd_pos_kernel): the pair kernel runs forward-only and hands dz over as bf16
   // planes; one workgroup per (seed, 4 positions) then needs >= 16 seeds to fill the chip.  PQN_BWD_POS: 0 off, 1 auto,
   // 2 at any size (tests)
-  static const int pos_env = getenv("PQN_BWD_POS") ? atoi(getenv("PQN_BWD_POS")) : 0;
+  const int pos_env = pqn_opt(PQN_OPT_BWD_POS);
   const bool use_pos = use_pair && pos_env && nb >= 2 * QW_SLAB && (16 * sd.nseeds >= 256 || pos_env == 2);
   float *gposw = wpart + (size_t)QN_H1 * QN_HID;   // conv-block partials of the 16 position groups (second slab's place)
   if (use_pos) {
@@ -3683,7 +3685,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     }
   }
   // opt-in paired-dgrad backward of the pair kernel (PQN_T1_PD2=1; C = 4 only)
-  static const int pd2_env = getenv("PQN_T1_PD2") ? atoi(getenv("PQN_T1_PD2")) : 0;
+  const int pd2_env = pqn_opt(PQN_OPT_T1_PD2);
   const bool use_pd2 = use_pair && !use_pos && pd2_env && C == 4;
   if (use_pd2) {
     if constexpr (C == 4) {
@@ -3695,6 +3697,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       }
     }
   }
+  pqn_note_kernel_form(0, use_pos ? PQN_FORM_PAIR_POS : (use_pd2 ? PQN_FORM_PAIR_PD2 : (use_pair ? PQN_FORM_PAIR : PQN_FORM_SINGLE)));
   const int gs_max = pqn_cnn_seed_group(L.matmul_f16, sd.nseeds);
   for (int s0 = 0; s0 < sd.nseeds; s0 += gs_max) {
     const int gs = min(gs_max, sd.nseeds - s0);
@@ -3768,12 +3771,39 @@ extern "C" int pqn_qnet_cnn_grad(const pqn_cnn_layout_t *L, int32_t nb, const in
               "pqn_qnet_cnn_grad: NULL argument");
   PQN_REQUIRE(nb > 0 && nb % QN_TILE == 0, "pqn_qnet_cnn_grad: minibatch size %d must be a positive multiple of %d", nb,
               QN_TILE);
-  return pqn_qnet_cnn_grad_seeds(*L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out,
+  return pqn_qnet_cnn_grad_seeds_dyn(*L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out,
                                  pqn_one_seed(), (hipStream_t)stream);
 }
 
+extern "C" int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t *L, int32_t num_seeds, int32_t nb, const int64_t *idx,
+                                       int64_t idx_stride, int32_t n_env, int32_t n_env_total, const uint32_t *obs_bits,
+                                       const int32_t *action, const float *target, const float *theta,
+                                       int64_t theta_stride, const float *w1b, float *grad, const int32_t *count,
+                                       float *workspace, int64_t ws_stride, float *loss_out, float *qv_out, void *stream) {
+  PQN_REQUIRE(L && idx && obs_bits && action && target && theta && w1b && grad && count && workspace,
+              "pqn_qnet_cnn_grad_seeds: NULL argument");
+  PQN_REQUIRE(nb > 0 && nb % QN_TILE == 0, "pqn_qnet_cnn_grad_seeds: minibatch size %d must be a positive multiple of %d", nb,
+              QN_TILE);
+  PQN_REQUIRE(num_seeds >= 1 && num_seeds <= 128 && n_env > 0 && n_env_total >= n_env && idx_stride >= nb &&
+                  theta_stride >= L->alloc && ws_stride >= pqn_qnet_cnn_workspace_floats(L, nb),
+              "pqn_qnet_cnn_grad_seeds: bad seed batch (seeds=%d n_env=%d/%d strides idx=%lld theta=%lld ws=%lld)", num_seeds,
+              n_env, n_env_total, (long long)idx_stride, (long long)theta_stride, (long long)ws_stride);
+  pqn_seeds_t sd = pqn_one_seed();
+  sd.nseeds = num_seeds;
+  sd.n_env = n_env;
+  sd.n_env_total = n_env_total;
+  sd.idx_stride = idx_stride;
+  sd.theta_stride = theta_stride;
+  sd.w1b_stride = QN_H1 * QN_HID;
+  sd.ws_stride = ws_stride;
+  sd.lq_stride = 1;
+  sd.idx_mask = 0x7FFFFFFFll;
+  return pqn_qnet_cnn_grad_seeds_dyn(*L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out,
+                                     sd, (hipStream_t)stream);
+}
+
 // internal (pqn_update.hip): S seeds per launch, buffers = slices of stacked allocations (pqn_seeds_t)
-int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
+int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
                             hipStream_t st, bool with_reduce) {

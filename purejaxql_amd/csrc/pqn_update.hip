@@ -249,7 +249,7 @@ static int upd_shuffle(const pqn_update_args_t *a, const UpdCtx &c, int ep, hipS
 static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool with_reduce, hipStream_t st) {
   const int mb = i_mb % c.MB;
   // low bits of a sorted shuffle key = the transition index inside the seed (kernels mask with sd.idx_mask)
-  return pqn_qnet_cnn_grad_seeds(a->layout, c.B, a->sort_keys_out + (size_t)mb * c.B, a->bits, a->action, a->target, a->theta,
+  return pqn_qnet_cnn_grad_seeds_dyn(a->layout, c.B, a->sort_keys_out + (size_t)mb * c.B, a->bits, a->action, a->target, a->theta,
                                  a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, c.sd, st,
                                  with_reduce);
 }

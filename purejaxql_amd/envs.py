@@ -61,6 +61,10 @@ class Environment:
     def __init__(self, name: str, device: Optional[torch.device] = None):
         lib = _lib.load()
         env_id = lib.pqn_env_id(name.encode())
+        if env_id < 0 and name.startswith("Craftax") and name != "Craftax-Classic-Symbolic-v1":
+            # config/alg/pqn_craftax.yaml's default (full Craftax) is kept as the reference states it but is not built
+            raise ValueError(f"make({name!r}): only the Craftax-Classic symbolic env is implemented -- pass "
+                             "alg.ENV_NAME=Craftax-Classic-Symbolic-v1 (BASELINE.json configs[4])")
         _lib.check(min(env_id, 0), f"make({name!r})")
         self.name = name
         self.env_id = env_id
@@ -251,7 +255,7 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
         self.num_envs, self.reset_ratio = int(num_envs), int(reset_ratio)
         assert self.num_envs % self.reset_ratio == 0, "Reset ratio must perfectly divide num envs."   # (:96-98)
         self.num_resets = self.num_envs // self.reset_ratio
-        self._scratch = None
+        self._scratch = {}   # sort-key scratch per HIP stream: seeds running as concurrent streams share this wrapper
 
     def reset(self, rng, params=None, **kw):
         return self._env.reset(rng, params, self.num_envs, **kw)
@@ -270,8 +274,10 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
             raise ValueError(f"state holds {n} envs, the wrapper was built for {self.num_envs}")
         if action.dtype != torch.int32:
             action = action.to(torch.int32)
-        if self._scratch is None or self._scratch.device != state.words.device:
-            self._scratch = torch.empty(n, dtype=torch.int64, device=dev)
+        sid = _lib.stream_ptr()
+        scratch = self._scratch.get(sid)
+        if scratch is None or scratch.device != state.words.device:
+            scratch = self._scratch[sid] = torch.empty(n, dtype=torch.int64, device=dev)
         src_words = state.words
         if base.in_place_only:
             new_words = state.words if inplace else state.words.clone()
@@ -293,7 +299,7 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
         slots = torch.empty(n, dtype=torch.int32, device=dev) if want_slots else None
         _lib.check(lib.pqn_env_step_optimistic(base.env_id, n, rng, self.reset_ratio, _lib.ptr(src_words),
                                                _lib.ptr(new_words), _lib.ptr(action), C.byref(out),
-                                               _lib.ptr(self._scratch), _lib.ptr(slots), _lib.stream_ptr()),
+                                               _lib.ptr(scratch), _lib.ptr(slots), sid),
                    "pqn_env_step_optimistic")
         done_b = done.view(torch.bool)
         if log_info:

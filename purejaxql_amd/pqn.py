@@ -63,25 +63,33 @@ class TrainState:
         self.opt_state = {k: rs[k] for k in ("opt_count", "opt_mu", "opt_nu") if k in rs}
 
 
-class RunnerState(dict):
-    """train()'s `runner_state`.  A dict of named entries (this build's form) that ALSO answers the reference's tuple
-    protocol (pqn_minatar.py:420-424: `(train_state, (obs, env_state), test_metrics, rng)`), so that code written
-    against the reference -- `runner_state[0].params`, `train_state, expl_state, test_metrics, rng = runner_state` --
-    keeps working."""
+class RunnerState(tuple):
+    """train()'s `runner_state`: the reference's 4-tuple (pqn_minatar.py:420-424,
+    `(train_state, (obs, env_state), test_metrics, rng)`) -- a real tuple, so `runner_state[0].params`,
+    `train_state, expl_state, test_metrics, rng = runner_state`, len() and iteration behave exactly as they do on the
+    reference's value -- that additionally answers this build's named entries by STRING key (`rs["theta"]`,
+    `"driver" in rs`, `rs.get(...)`, `rs.entries` = the dict itself)."""
 
-    def _tuple(self):
-        return (TrainState(self), (self["last_obs"], self["env_state"]), self.get("test_metrics"), self.get("rng"))
+    def __new__(cls, entries):
+        entries = dict(entries)
+        self = super().__new__(cls, (TrainState(entries), (entries["last_obs"], entries["env_state"]),
+                                     entries.get("test_metrics"), entries.get("rng")))
+        self.entries = entries
+        return self
 
     def __getitem__(self, k):
-        if isinstance(k, int):
-            return self._tuple()[k]
-        return dict.__getitem__(self, k)
+        if isinstance(k, str):
+            return self.entries[k]
+        return tuple.__getitem__(self, k)
 
-    def __iter__(self):
-        return iter(self._tuple())
+    def __contains__(self, k):
+        return k in self.entries if isinstance(k, str) else tuple.__contains__(self, k)
 
-    def __len__(self):
-        return 4
+    def get(self, k, default=None):
+        return self.entries.get(k, default)
+
+    def as_tuple(self):
+        return tuple(self)
 
 
 class _Rollout:

@@ -67,6 +67,10 @@ def env_step_hbm_roofline(num_envs: int, device, env_name: str = "Breakout-MinAt
     end.synchronize()
     us = start.elapsed_time(end) * 1e3 / (reps * steps)
     gbs = 1926.0 * num_envs / (us * 1e-6) / 1e9
+    ws_mb = 1926.0 * num_envs / 2 ** 20   # bytes one launch touches (the obs buffer is re-used by every captured launch)
+    in_mall = ws_mb < 256.0
     return {"kernel": "minatar_kernel<Breakout> (gymnax surface: f32 obs + LogWrapper info)", "num_envs": num_envs,
             "avg_launch_us": us, "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-            "env_steps_per_s": num_envs / (us * 1e-6)}
+            "env_steps_per_s": num_envs / (us * 1e-6), "working_set_mib": ws_mb,
+            "level": ("Infinity Cache (the launch's working set fits the 256 MiB MALL and is re-written every launch): an "
+                      "on-chip rate, NOT an HBM figure") if in_mall else "HBM (working set > 256 MiB Infinity Cache)"}

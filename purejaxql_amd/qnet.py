@@ -175,6 +175,35 @@ class CnnTrainer:
         return self.layout.to_flax(self.theta)
 
 
+def cnn_grad_seeds(layout: CnnKernelLayout, theta_k: torch.Tensor, idx: torch.Tensor, obs_bits: torch.Tensor,
+                   action: torch.Tensor, target: torch.Tensor, n_env: int, n_env_total: Optional[int] = None):
+    """jax.vmap(value_and_grad(_loss_fn)) over seeds (pqn_minatar.py:271-291 under :459-461) in ONE set of launches
+    (pqn_qnet_cnn_grad_seeds): theta_k [S, stride] kernel-layout parameters (operand copies in step, see
+    CnnKernelLayout.to_kernel), idx int64 [S, nb] transition indices per seed into the stacked [T][S*N] record (or a
+    shared pool when n_env_total == n_env).  Returns (grad [S, stride], loss [S], mean q_a [S])."""
+    lib = _lib.load()
+    s, nb = int(idx.shape[0]), int(idx.shape[1])
+    dev = theta_k.device
+    n_env_total = int(n_env if n_env_total is None else n_env_total)
+    assert theta_k.dim() == 2 and theta_k.shape[0] == s and theta_k.is_contiguous() and idx.is_contiguous()
+    assert idx.dtype == torch.int64 and action.dtype == torch.int32 and target.dtype == torch.float32
+    ws_stride = (int(lib.pqn_qnet_cnn_workspace_floats(C.byref(layout.struct), nb)) + 3) // 4 * 4
+    ws = torch.empty((s, ws_stride), dtype=torch.float32, device=dev)
+    w1b = torch.empty((s, 1024 * 128), dtype=torch.float32, device=dev)
+    for k in range(s):
+        layout.refresh_copies(theta_k[k], w1b[k])
+    grad = torch.zeros_like(theta_k)
+    count = torch.zeros(s, dtype=torch.int32, device=dev)
+    loss = torch.zeros(s, dtype=torch.float32, device=dev)
+    qv = torch.zeros(s, dtype=torch.float32, device=dev)
+    _lib.check(lib.pqn_qnet_cnn_grad_seeds(C.byref(layout.struct), s, nb, _lib.ptr(idx), int(idx.stride(0)), int(n_env),
+                                           n_env_total, _lib.ptr(obs_bits), _lib.ptr(action), _lib.ptr(target),
+                                           _lib.ptr(theta_k), int(theta_k.stride(0)), _lib.ptr(w1b), _lib.ptr(grad),
+                                           _lib.ptr(count), _lib.ptr(ws), ws_stride, _lib.ptr(loss), _lib.ptr(qv),
+                                           _lib.stream_ptr()), "pqn_qnet_cnn_grad_seeds")
+    return grad, loss, qv
+
+
 class UpdateArgs(C.Structure):
     """pqn_update_args_t (include/pqn_hotpath.h)"""
     _fields_ = ([(n, C.c_int32) for n in ("env_id", "num_envs", "num_steps", "num_minibatches", "num_epochs",

@@ -45,7 +45,7 @@ def test_craftax_reset_world_and_observation(gpu, oracle):
         _check_state(env, oenv, state, ost)
 
 
-@pytest.mark.parametrize("n,steps", [(256, 600), (33, 300)])
+@pytest.mark.parametrize("n,steps", [(256, 600), (33, 300), (1024, 150)])   # 1024 = C5's NUM_ENVS (pqn_craftax.yaml:4)
 def test_craftax_step_autoreset_bit_exact_vs_oracle(gpu, oracle, n, steps):
     from purejaxql_amd.envs import LogWrapper, make
     env, params = make(NAME, device=gpu)
@@ -79,9 +79,10 @@ def test_craftax_step_autoreset_bit_exact_vs_oracle(gpu, oracle, n, steps):
     assert bin(int(ach)).count("1") >= 4       # several different achievements were unlocked along the way
 
 
-def test_craftax_optimistic_resets_bit_exact_vs_oracle(gpu, oracle):
+@pytest.mark.parametrize("n", [64, 1024])   # 1024 envs / ratio 16 = the C5 shape (pqn_craftax.yaml:4,25-26)
+def test_craftax_optimistic_resets_bit_exact_vs_oracle(gpu, oracle, n):
     from purejaxql_amd.envs import LogWrapper, OptimisticResetVecEnvWrapper, make
-    n, ratio = 64, 16
+    ratio = 16
     base, params = make(NAME, device=gpu)
     inner = LogWrapper(base)
     env = OptimisticResetVecEnvWrapper(inner, num_envs=n, reset_ratio=ratio)

@@ -83,6 +83,82 @@ def test_craftax_script_loop_vs_oracle(gpu, oracle, env_name, over, n_upd):
             assert np.abs(_np(bs[k]) - v).max() <= 1e-3 * max(np.abs(v).max(), 1e-3), k
 
 
+def test_c5_yaml_shape_loop_vs_oracle_on_craftax_classic(gpu, oracle):
+    """BASELINE.json configs[4] at its own shape: `+alg=pqn_craftax` exactly as config/alg/pqn_craftax.yaml states it
+    (1024 envs, 1 step x 1 minibatch x 1 epoch, BatchRenorm input + 4 x 1024 LayerNorm MLP, 1-step loss on
+    concat(obs, next_obs), optimistic resets ratio 16, clip 1.0) on Craftax-Classic-Symbolic-v1, whole loop vs
+    oracle.make_train(script="craftax") from shared initial parameters for 4 updates (pqn_craftax.py:96-114,277-304)."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.pqn import make_train, seed_keys
+    n_upd = 4
+    cfg = flatten(load_config(["+alg=pqn_craftax", "alg.ENV_NAME=Craftax-Classic-Symbolic-v1"]))
+    assert (cfg["NUM_ENVS"], cfg["NUM_STEPS"], cfg["HIDDEN_SIZE"], cfg["NUM_LAYERS"]) == (1024, 1, 1024, 4)
+    assert cfg["NORM_INPUT"] is True and cfg["NORM_TYPE"] == "layer_norm" and cfg["USE_OPTIMISTIC_RESETS"] is True
+    cfg.update({"TOTAL_TIMESTEPS": n_upd * 1024, "TOTAL_TIMESTEPS_DECAY": 30 * 1024, "TEST_DURING_TRAINING": False})
+    ocfg = dict(cfg)
+    key = seed_keys(5, 1)[0]
+    otrain = oracle.make_train(ocfg, script="craftax")
+    net = QNetwork("mlp", (1345,), 17, norm_type="layer_norm", norm_input=True, hidden_size=1024, num_layers=4, device=gpu,
+                   renorm=True)
+    assert list(net.shapes) == list(otrain.shapes) and net.num_params == 4555411
+    theta0 = net.init(21)
+    cfg["_INIT_PARAMS"] = theta0
+    train = make_train(cfg, device="cuda:0", script="craftax")
+    out = train(key)
+    oout = otrain(key, _np(theta0))
+    assert cfg["NUM_UPDATES"] == n_upd == len(oout["metrics"])
+    for u in range(n_upd):
+        om = oout["metrics"][u]
+        assert float(out["metrics"]["env_step"][u]) == om["env_step"] and float(out["metrics"]["grad_steps"][u]) == om["grad_steps"]
+        for k in ("td_loss", "qvals"):
+            assert abs(float(out["metrics"][k][u]) - om[k]) <= 1e-3 * max(1.0, abs(om[k])), (u, k, float(out["metrics"][k][u]), om[k])
+        for k in ("returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode"):
+            a, b = float(out["metrics"][k][u]), om[k]
+            assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= 1e-3 * max(1.0, abs(b)), (u, k, a, b)
+    th, oth, th0 = _np(out["runner_state"]["theta"]), oout["theta"], _np(theta0)
+    d = np.abs(th - oth)
+    bad = d > (2e-5 + 2e-3 * np.abs(oth))
+    upd, oupd = th - th0, oth - th0
+    cos = float(np.dot(upd, oupd) / (np.linalg.norm(upd) * np.linalg.norm(oupd)))
+    # 4.5 M parameters, RAdam's first steps are sign-like (m_hat only): entries whose gradient is rounding noise move by
+    # +-lr in either implementation; the criterion is therefore on the update vector plus a cap on the worst entry
+    assert cos > 0.99 and bad.mean() < 2e-2 and d.max() < 2 * n_upd * cfg["LR"], (cos, float(bad.mean()), float(d.max()))
+    bs = out["runner_state"]["batch_stats"]
+    for k, v in oout["batch_stats"].items():
+        if k.endswith("/steps"):
+            assert int(bs[k]) == int(v) == n_upd
+        else:
+            assert np.abs(_np(bs[k]) - v).max() <= 1e-3 * max(np.abs(v).max(), 1e-3), k
+
+
+@pytest.mark.parametrize("env_name,n,t,upd", [("Breakout-MinAtar", 64, 4, 40), ("Craftax-Classic-Symbolic-v1", 128, 1, 30)])
+def test_craftax_script_seeds_as_concurrent_streams_equal_solo_runs(gpu, env_name, n, t, upd):
+    """NUM_SEEDS > 1 on the Craftax script runs the seeds as concurrent HIP streams (the torch-op network has no
+    seed-batched kernels): every seed must be bit-identical to its solo run although all seeds share one env / wrapper
+    object -- the optimistic-reset sort keys and Craftax's reset-slot scratch are per stream (round-2 advisor finding:
+    they were shared, so one seed's reset kernels could overwrite another's between its step and world kernels)."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys, vmap_train
+    cfg = flatten(load_config(["+alg=pqn_craftax"]))
+    cfg.update({"ENV_NAME": env_name, "NUM_ENVS": n, "NUM_STEPS": t, "HIDDEN_SIZE": 64, "NUM_LAYERS": 2, "OPTIMISTIC_RESET_RATIO": 8,
+                "TOTAL_TIMESTEPS": upd * n * t, "TOTAL_TIMESTEPS_DECAY": upd * n * t, "EPS_START": 1.0, "TEST_DURING_TRAINING": False})
+    keys = seed_keys(11, 3)
+    train = make_train(dict(cfg), device="cuda:0", script="craftax")
+    assert not train.can_batch_seeds
+    both = vmap_train(train, keys, concurrent="streams")
+    torch.cuda.synchronize()
+    for s, k in enumerate(keys):
+        solo = make_train(dict(cfg), device="cuda:0", script="craftax")(k)
+        for name in ("td_loss", "qvals", "returned_episode", "returned_episode_returns"):
+            a, b = both["metrics"][name][s], solo["metrics"][name]
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (s, name)
+        assert torch.equal(both["runner_state"][s]["theta"], solo["runner_state"]["theta"]), s
+        assert torch.equal(both["runner_state"][s]["env_state"], solo["runner_state"]["env_state"]), s
+    if env_name.startswith("Breakout"):
+        assert float(torch.nan_to_num(both["metrics"]["returned_episode"]).sum()) > 0   # episodes ended: resets were handed out
+
+
 def test_craftax_config_group_and_entry_point(gpu):
     """`+alg=pqn_craftax` carries the values of config/alg/pqn_craftax.yaml:1-35; the entry module runs a tiny job
     end to end (wrapper-batched env, optimistic resets, 1-step loss, per-seed checkpoint in the reference's format)."""

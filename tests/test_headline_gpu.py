@@ -1,0 +1,235 @@
+"""The configuration bench.py times, under the oracle: MATMUL_DTYPE=bf16x3, 16 seeds x 4096 envs per GPU (BASELINE.json
+configs[3]'s per-GPU share) -- i.e. the PAIR forms of the training and rollout kernels with the XCD-aware (seed, pair)
+mapping (csrc/pqn_qnet.hip: qnet_cnn_train_pair_kernel, qnet_cnn_rollout_pair_kernel, qnet_fc1_wgrad_x3_kernel).
+Every test asserts in-process (pqn_cnn_last_kernel_form) that those are the kernels that ran.
+Reference lines: value_and_grad(_loss_fn) pqn_minatar.py:271-297 under the seeds vmap :459-461; _update_step :176-369."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+S, N, T, MB, EP = 16, 4096, 32, 32, 2
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _pack_bits(obs):
+    n, c = obs.shape[0], obs.shape[-1]
+    ow = (((100 * c + 31) // 32) + 3) // 4 * 4
+    padded = np.zeros((n, ow * 32), np.uint64)
+    padded[:, :100 * c] = obs.reshape(n, -1)
+    return (padded.reshape(n, ow, 32) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+
+
+def _cfg(n_upd, **extra):
+    from purejaxql_amd.config_loader import flatten, load_config
+    cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", f"alg.NUM_ENVS={N}",
+                               "alg.TEST_DURING_TRAINING=False", "alg.MATMUL_DTYPE=bf16x3"]))
+    assert (cfg["NUM_STEPS"], cfg["NUM_MINIBATCHES"], cfg["NUM_EPOCHS"]) == (T, MB, EP)
+    cfg["TOTAL_TIMESTEPS"] = n_upd * N * T
+    cfg["TOTAL_TIMESTEPS_DECAY"] = 30 * N * T
+    cfg.update(extra)
+    return cfg
+
+
+@pytest.mark.parametrize("stacked", [False, True])
+def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked):
+    """vmap(value_and_grad(_loss_fn)) at the bench's launch shape -- 16 seeds x 4096-sample minibatches in one launch,
+    bf16x3: 2048 workgroups of the pair kernel, seeds remapped over the XCDs -- against the oracle's numpy backward,
+    seed by seed (own parameters, own minibatch), with the tolerances of test_cnn_grad_vs_oracle.  stacked=True reads the
+    samples out of a stacked [T][S*N] record (the layout pqn_cnn_update_seeds trains from), False from a shared pool."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_grad_seeds, matmul_mode
+    rng = np.random.default_rng(2026 + stacked)
+    torch.manual_seed(7)
+    nb, c, a = 4096, 4, 3
+    n_env, t_len = (512, 12) if stacked else (20000, 1)
+    rows = n_env * t_len * (S if stacked else 1)
+    obs = (rng.random((rows, 10, 10, c)) < 0.12).astype(np.float32)
+    bits = torch.from_numpy(_pack_bits(obs).view(np.int32)).to(gpu)
+    action = rng.integers(0, a, rows).astype(np.int32)
+    target = rng.standard_normal(rows).astype(np.float32)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode("bf16x3"))
+    stride = (lay.alloc + 3) // 4 * 4
+    thetas = [net.init(100 + s) + 0.05 * torch.randn(net.num_params, device=gpu) for s in range(S)]
+    theta_k = torch.zeros((S, stride), dtype=torch.float32, device=gpu)
+    for s in range(S):
+        theta_k[s, :lay.alloc] = lay.to_kernel(thetas[s])
+    idx = np.stack([rng.permutation(n_env * t_len)[:nb] for _ in range(S)]).astype(np.int64)   # per-seed transition indices
+    grad, loss, qv = cnn_grad_seeds(lay, theta_k, torch.from_numpy(idx).to(gpu), bits, torch.from_numpy(action).to(gpu),
+                                    torch.from_numpy(target).to(gpu), n_env, n_env * S if stacked else n_env)
+    assert _lib.last_kernel_form()[0] == "pair"
+    shapes = oracle.cnn_shapes((10, 10, c), a)
+    for s in range(S):
+        j = idx[s]
+        row = (j // n_env) * (n_env * S) + s * n_env + j % n_env if stacked else j    # pqn_hotpath.h: pqn_qnet_cnn_grad_seeds
+        p = oracle.unflatten(_np(thetas[s]), shapes)
+        lo, chosen, g_ref = oracle.net_loss_grad("cnn", p, shapes, obs[row], action[row], target[row])
+        assert abs(float(loss[s]) - lo) <= 1e-4 * max(1.0, abs(lo)), s
+        assert abs(float(qv[s]) - chosen.mean()) <= 1e-4, s
+        g = _np(lay.to_flax(grad[s]))
+        np.testing.assert_allclose(g, g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9, err_msg=f"seed {s}")
+    if not stacked:   # the same seed alone (128 pairs: the single-tile kernel) gives the same bits
+        g1, l1, _ = cnn_grad_seeds(lay, theta_k[5:6].contiguous(), torch.from_numpy(idx[5:6]).to(gpu), bits,
+                                   torch.from_numpy(action).to(gpu), torch.from_numpy(target).to(gpu), n_env, n_env)
+        assert _lib.last_kernel_form()[0] == "single"
+        assert torch.equal(g1[0, :lay.total], grad[5, :lay.total]) and float(l1[0]) == float(loss[5])
+
+
+def test_single_seed_8192_sample_minibatch_takes_the_pair_kernel(gpu, oracle):
+    """One seed with 256 pairs per launch (nb = 8192) selects the pair kernel by itself; against the oracle."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer, matmul_mode
+    rng = np.random.default_rng(8192)
+    torch.manual_seed(3)
+    pool, nb = 30000, 8192
+    obs = (rng.random((pool, 10, 10, 4)) < 0.12).astype(np.float32)
+    bits = torch.from_numpy(_pack_bits(obs).view(np.int32)).to(gpu)
+    action = rng.integers(0, 3, pool).astype(np.int32)
+    target = rng.standard_normal(pool).astype(np.float32)
+    idx = rng.permutation(pool)[:nb].astype(np.int64)
+    net = QNetwork("cnn", (10, 10, 4), 3, device=gpu)
+    lay = CnnKernelLayout(4, 3, matmul_f16=matmul_mode("bf16x3"))
+    theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
+    tr = CnnTrainer(lay, theta, 5e-4, 10.0, max_minibatch=nb)
+    lo_t = torch.zeros(1, device=gpu)
+    g = tr.compute_grad(torch.from_numpy(idx).to(gpu), bits, torch.from_numpy(action).to(gpu), torch.from_numpy(target).to(gpu), lo_t)
+    assert _lib.last_kernel_form()[0] == "pair"
+    shapes = oracle.cnn_shapes((10, 10, 4), 3)
+    lo, _chosen, g_ref = oracle.net_loss_grad("cnn", oracle.unflatten(_np(theta), shapes), shapes, obs[idx], action[idx], target[idx])
+    assert abs(float(lo_t) - lo) <= 1e-4 * max(1.0, abs(lo))
+    np.testing.assert_allclose(_np(lay.to_flax(g)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
+
+
+def test_headline_16_seeds_bf16x3_bit_identical_to_solo_runs(gpu):
+    """The bench configuration (16 seeds x 4096 envs, bf16x3, hipGraph replay) for 2 updates: pair kernels in the batched
+    run, single-tile kernels in the solo runs (128 pairs would leave half the CUs idle) -- and still seeds 0 / 7 / 15 are
+    bit-identical to their solo runs (both forms sum in the same order by construction, phase2_fc1_x3)."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.pqn import make_train, seed_keys, vmap_train
+    cfg = _cfg(2)
+    keys = seed_keys(0, S)
+    outs = vmap_train(make_train(dict(cfg), device="cuda:0"), keys)
+    assert _lib.last_kernel_form() == ("pair", "pair")
+    rs = outs["runner_state"]
+    assert len(rs) == S and rs[0]["seed_batch"] == S and rs[0]["driver"] == "graph", rs[0]["driver_graph_error"]
+    for s in (0, 7, 15):
+        solo = make_train(dict(cfg), device="cuda:0")(keys[s])
+        assert _lib.last_kernel_form() == ("single", "single")
+        for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "returned_episode", "timestep"):
+            assert torch.equal(outs["metrics"][k][s], solo["metrics"][k]), (s, k)
+        assert torch.equal(rs[s]["theta"], solo["runner_state"]["theta"]), s
+        assert torch.equal(rs[s]["opt_mu"], solo["runner_state"]["opt_mu"][:rs[s]["opt_mu"].numel()]), s
+        assert torch.equal(rs[s]["env_state"], solo["runner_state"]["env_state"]), s
+    assert not torch.equal(outs["metrics"]["td_loss"][0], outs["metrics"]["td_loss"][1])
+
+
+def test_headline_whole_update_vs_oracle(gpu, oracle):
+    """ONE whole update of the bench workload -- 16 seeds batched into the launches, bf16x3, pair rollout + pair training
+    kernels -- against oracle.make_train, for seeds 0 / 7 / 15 (first, middle and last XCD group), from shared initial
+    parameters: metrics to 1e-3, the update vector by the size-aware criterion of test_make_train_end_to_end_vs_oracle
+    (cosine > 0.998, relative L2 < 6e-2, < 1 % of entries outside rtol 2e-3, worst entry < 4 lr)."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.pqn import make_train, seed_keys
+    cfg = _cfg(1)
+    ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+    net = QNetwork("cnn", (10, 10, 4), 3, device=gpu)
+    theta0 = net.init(123)
+    cfg["_INIT_PARAMS"] = theta0
+    keys = seed_keys(0, S)
+    train = make_train(cfg, device="cuda:0")
+    update, finish = train.make_batch_runner(keys)
+    update(0)
+    outs = finish()
+    assert _lib.last_kernel_form() == ("pair", "pair") and cfg["NUM_UPDATES"] == 1
+    otrain = oracle.make_train(ocfg)
+    th0 = _np(theta0)
+    for s in (0, 7, 15):
+        oout = otrain(keys[s], th0)
+        om = oout["metrics"][0]
+        m = outs[s]["metrics"]
+        for k in ("env_step", "update_steps", "grad_steps"):
+            assert float(m[k][0]) == om[k], (s, k)
+        for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode",
+                  "discount"):
+            assert abs(float(m[k][0]) - om[k]) <= 1e-3 * max(1.0, abs(om[k])), (s, k, float(m[k][0]), om[k])
+        th, oth = _np(outs[s]["runner_state"]["theta"]), oout["theta"]
+        d = np.abs(th - oth)
+        bad = d > (2e-5 + 2e-3 * np.abs(oth))
+        upd, oupd = th - th0, oth - th0
+        cos = float(np.dot(upd, oupd) / (np.linalg.norm(upd) * np.linalg.norm(oupd)))
+        rel = float(np.linalg.norm(upd - oupd) / np.linalg.norm(oupd))
+        assert cos > 0.998 and rel < 6e-2 and bad.mean() < 1e-2 and d.max() < 4 * cfg["LR"], (s, cos, rel, float(bad.mean()), float(d.max()))
+
+
+def test_forced_pair_forms_at_small_sizes_in_process(gpu):
+    """The pair forms forced at sizes where they are not selected by default (pqn_set_option, in-process): the training
+    kernel at 2, 8 and 256 pairs (C = 4) and 32 pairs (C = 6) -- repeats bit-identical, equal to the single-tile bf16x3
+    kernel bit for bit and to the f32-MFMA mode to f32 rounding; the rollout kernel bit-identical in every output."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
+    for c, a, nb, pool in ((4, 3, 64, 256), (4, 3, 256, 1000), (4, 3, 8192, 20000), (6, 4, 1024, 2000)):
+        rng = np.random.default_rng(nb + c)
+        torch.manual_seed(1234)
+        net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+        theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
+        obs = (rng.random((pool, 10, 10, c)) < 0.12).astype(np.float32)
+        bits = torch.from_numpy(_pack_bits(obs).view(np.int32)).to(gpu)
+        action = torch.from_numpy(rng.integers(0, a, pool).astype(np.int32)).to(gpu)
+        target = torch.from_numpy(rng.standard_normal(pool).astype(np.float32)).to(gpu)
+        idx = torch.from_numpy(rng.permutation(pool)[:nb].astype(np.int64)).to(gpu)
+        res = {}
+        for name, mode, pair in (("f32", 0, 0), ("single", 2, 0), ("pair", 2, 2)):
+            with _lib.options(t1_pair=pair):
+                lay = CnnKernelLayout(c, a, matmul_f16=mode)
+                tr = CnnTrainer(lay, theta, 5e-4, 10.0, max_minibatch=nb)
+                reps = [tr.compute_grad(idx, bits, action, target)[:lay.total].clone() for _ in range(3)]
+                assert _lib.last_kernel_form()[0] == ("pair" if pair else "single"), (name, c, nb)
+                assert torch.equal(reps[0], reps[1]) and torch.equal(reps[0], reps[2]), (name, c, nb)
+                res[name] = reps[0]
+        assert torch.equal(res["single"], res["pair"]), (c, nb)
+        scale = float(res["f32"].abs().max())
+        assert float((res["f32"] - res["pair"]).abs().max()) <= 2e-5 * scale, (c, nb)
+
+
+def test_forced_rollout_pair_form_is_bit_identical_in_process(gpu):
+    from purejaxql_amd import _lib
+    from purejaxql_amd.envs import LogWrapper, make
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_rollout, matmul_mode
+    lib = _lib.load()
+    for name, c, a, n, t in (("Breakout-MinAtar", 4, 3, 64, 40), ("Asterix-MinAtar", 4, 5, 96, 30), ("SpaceInvaders-MinAtar", 6, 4, 32, 20)):
+        env, params = make(name, device=gpu)
+        env = LogWrapper(env)
+        net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+        lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode("bf16x3"))
+        torch.manual_seed(0)
+        theta_k = lay.to_kernel(net.init(3) + 0.05 * torch.randn(net.num_params, device=gpu))
+        (_o, bits0), state = env.reset(11, params, n, want_obs=False, want_bits=True)
+        for i in range(30):
+            (_o, bits0), state, *_ = env.step(500 + i, state, torch.randint(0, a, (n,), dtype=torch.int32, device=gpu), params,
+                                              want_obs=False, want_bits=True)
+        keys = torch.empty(t, dtype=torch.int64, device=gpu)
+        _lib.check(lib.pqn_fold_in_range(0x77, 7, t, _lib.ptr(keys), _lib.stream_ptr()), "pqn_fold_in_range")
+        eps = torch.full((1,), 0.3, dtype=torch.float32, device=gpu)
+        outs = []
+        for pair in (0, 2):
+            with _lib.options(rollout_pair=pair):
+                words = state.words.clone()
+                ob = torch.zeros((t + 1, n, bits0.shape[1]), dtype=bits0.dtype, device=gpu)
+                ob[0] = bits0
+                rec = cnn_rollout(lay, env._env.env_id, words, ob, theta_k, keys, eps)
+                assert _lib.last_kernel_form()[1] == ("pair" if pair else "single")
+                outs.append((rec, words, ob))
+        for k in outs[0][0]:
+            assert torch.equal(outs[0][0][k], outs[1][0][k]), (name, k)
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), name
+        assert int(outs[0][0]["done"].sum()) > 0, name

@@ -85,6 +85,29 @@ def test_unknown_env_is_an_error():
     assert spec.state_words == 7 and spec.obs_words == 16 and spec.canon_si == 109
 
 
+def test_craftax_entry_point_default_env_name_fails_with_a_pointer_to_the_classic_env():
+    """`python -m purejaxql_amd.pqn_craftax` without overrides keeps the reference yaml's ENV_NAME (full Craftax,
+    config/alg/pqn_craftax.yaml:23), which this build does not implement: the failure must say what to pass instead."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.envs import make
+    assert flatten(load_config(["+alg=pqn_craftax"]))["ENV_NAME"] == "Craftax-Symbolic-v1"
+    with pytest.raises(ValueError, match="Craftax-Classic-Symbolic-v1"):
+        make("Craftax-Symbolic-v1", device="cpu")
+
+
+def test_run_time_options_and_kernel_form_query():
+    """pqn_set_option / pqn_get_option / pqn_cnn_last_kernel_form (host-only calls): unknown names are errors, the
+    context manager restores values, nothing has run yet in this process."""
+    from purejaxql_amd import _lib
+    assert _lib.get_option("t1_pair") == 1 and _lib.get_option("bwd_pos") == 0
+    with _lib.options(t1_pair=2, rollout_pair=0):
+        assert (_lib.get_option("t1_pair"), _lib.get_option("rollout_pair")) == (2, 0)
+    assert (_lib.get_option("t1_pair"), _lib.get_option("rollout_pair")) == (1, 1)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        _lib.set_option("no_such_switch", 1)
+    assert _lib.last_kernel_form() == ("none", "none")
+
+
 def test_header_is_plain_c(tmp_path):
     """include/pqn_hotpath.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch / HIP types) and a
     C translation unit must be able to reference every declared entry point."""

@@ -327,85 +327,48 @@ def test_bf16x3_is_deterministic_and_matches_f32_mode(gpu, c, a, nb, pool):
     assert float((out[0][2] - out[2][2]).abs().max()) <= 2e-5 * scale
 
 
-def test_pair_form_of_the_training_kernel_at_small_sizes(gpu):
-    """qnet_cnn_train_pair_kernel (two tiles per workgroup, bf16x3, C = 4 and 6) is normally chosen only when its grid
-    fills the chip (16 seeds x 4096 samples: tests/test_fullsize_gpu.py); PQN_T1_PAIR=2 forces it, so that 2-, 8- and
-    256-pair minibatches (C = 4) and a 32-pair one (C = 6) are checked too: bit-identical repeats, and the f32-MFMA mode of the single-tile kernel to f32 rounding.
-    The switch is read when the library loads, hence the subprocess."""
-    import os
-    import re
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PQN_T1_PAIR="2", BRIEF="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_x3_conv.py")], env=env, capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rows = [l for l in out.stdout.splitlines() if l.startswith("C 4 ") or l.startswith("C 6 ")]   # the channel counts whose LDS plan fits
-    assert len(rows) == 4, out.stdout
-    for l in rows:
-        rep = float(re.search(r"rep-to-rep max\|dg\| ([0-9.e+-]+)", l).group(1))
-        dif = float(re.search(r"max\|g_x3 - g_f32\| ([0-9.e+-]+)", l).group(1))
-        assert rep == 0.0 and dif < 2e-5, l
-
-
-def test_pair_form_of_the_rollout_kernel_is_bit_identical(gpu):
-    """qnet_cnn_rollout_pair_kernel (32 envs per workgroup sharing the fc1 weight stream, bf16x3) is chosen when its grid
-    fills the chip; PQN_ROLLOUT_PAIR=2 forces it at every size it supports, =0 disables it.  tools/rollout_digest.py
-    hashes every output of pqn_cnn_rollout (record, final env words, packed observations) for five cases over four
-    games: both forms must print the same digests.  The switch is read when the library loads, hence subprocesses."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for v in ("0", "2"):
-        env = dict(os.environ, PQN_ROLLOUT_PAIR=v, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "rollout_digest.py")], env=env,
-                             capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        outs.append([l for l in out.stdout.splitlines() if "MinAtar" in l])
-    assert len(outs[0]) == 5 and outs[0] == outs[1], (outs[0], outs[1])
-    assert all(int(l.split()[-1]) > 0 for l in outs[0][:3])   # episode ends (auto-reset) inside the windows
+def _grads_under_options(gpu, c, a, nb, pool, mode, reps=3, **opts):
+    """gradient of one fixed minibatch under run-time kernel-selection switches (pqn_set_option); returns
+    (gradient, kernel form that ran).  Repeats must be bit-identical."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
+    rng = np.random.default_rng(nb + c)
+    torch.manual_seed(1234)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
+    _obs, words = _random_bits(rng, pool, c, density=0.12)
+    bits = torch.from_numpy(words.view(np.int32)).to(gpu)
+    action = torch.from_numpy(rng.integers(0, a, pool).astype(np.int32)).to(gpu)
+    target = torch.from_numpy(rng.standard_normal(pool).astype(np.float32)).to(gpu)
+    idx = torch.from_numpy(rng.permutation(pool)[:nb].astype(np.int64)).to(gpu)
+    with _lib.options(**opts):
+        lay = CnnKernelLayout(c, a, matmul_f16=mode)
+        tr = CnnTrainer(lay, theta, 5e-4, 10.0, max_minibatch=nb)
+        out = [tr.compute_grad(idx, bits, action, target)[:lay.total].clone() for _ in range(reps)]
+        form = _lib.last_kernel_form()[0]
+    for g in out[1:]:
+        assert torch.equal(g, out[0]), (opts, c, nb)
+    return out[0], form
 
 
 def test_paired_dgrad_opt_in_path(gpu):
-    """PQN_T1_PD2=1 (with the pair kernel forced): the dgrad of both tiles against one pass over the weight planes
+    """t1_pd2=1 (with the pair kernel forced): the dgrad of both tiles against one pass over the weight planes
     (t1_dgrad_pair2_x3), LN0 backward without its staging buffer, two-round conv-wgrad fold.
-    Repeats bit-identical, gradient equal to the f32-MFMA mode of the default kernels to f32 rounding at 1, 8 and 256
-    pairs.  Opt-in path (not faster under full load yet), kept tested."""
-    import os
-    import re
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PQN_T1_PAIR="2", PQN_T1_PD2="1", BRIEF="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_x3_conv.py")], env=env, capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rows = [l for l in out.stdout.splitlines() if l.startswith("C 4 ")]
-    assert len(rows) == 3, out.stdout
-    for l in rows:
-        rep = float(re.search(r"rep-to-rep max\|dg\| ([0-9.e+-]+)", l).group(1))
-        dif = float(re.search(r"max\|g_x3 - g_f32\| ([0-9.e+-]+)", l).group(1))
-        assert rep == 0.0 and dif < 2e-5, l
+    Repeats bit-identical, gradient equal to the f32-MFMA mode of the default kernels to f32 rounding at 2, 8 and 256
+    pairs.  Opt-in path (not faster under full load), kept tested -- in-process through pqn_set_option."""
+    for nb, pool in ((64, 256), (256, 1000), (8192, 20000)):
+        g_f32, f0 = _grads_under_options(gpu, 4, 3, nb, pool, 0, t1_pair=0)
+        g_pd2, f1 = _grads_under_options(gpu, 4, 3, nb, pool, 2, t1_pair=2, t1_pd2=1)
+        assert (f0, f1) == ("single", "pair+pd2")
+        assert float((g_f32 - g_pd2).abs().max()) <= 2e-5 * float(g_f32.abs().max()), nb
 
 
 def test_position_parallel_backward_opt_in_path(gpu):
-    """PQN_BWD_POS=2 (with the pair kernel forced) routes the 4096-sample case through the forward-only pair kernel +
+    """bwd_pos=2 (with the pair kernel forced) routes a 4096-sample minibatch through the forward-only pair kernel +
     qnet_cnn_bwd_pos_kernel + the reduction without split-K slabs: repeats bit-identical, gradient
-    equal to the f32-MFMA mode of the default kernels to f32 rounding.  Opt-in path (it is not faster yet), kept tested."""
-    import os
-    import re
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PQN_T1_PAIR="2", PQN_BWD_POS="2", BRIEF="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_x3_conv.py")], env=env, capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rows = [l for l in out.stdout.splitlines() if l.startswith("C 4 nb 4096")]
-    assert len(rows) == 1, out.stdout
-    rep = float(re.search(r"rep-to-rep max\|dg\| ([0-9.e+-]+)", rows[0]).group(1))
-    dif = float(re.search(r"max\|g_x3 - g_f32\| ([0-9.e+-]+)", rows[0]).group(1))
-    assert rep == 0.0 and dif < 2e-5, rows[0]
+    equal to the f32-MFMA mode of the default kernels to f32 rounding."""
+    g_f32, f0 = _grads_under_options(gpu, 4, 3, 4096, 20000, 0, t1_pair=0)
+    g_pos, f1 = _grads_under_options(gpu, 4, 3, 4096, 20000, 2, t1_pair=2, bwd_pos=2)
+    assert (f0, f1) == ("single", "pair+pos")
+    assert float((g_f32 - g_pos).abs().max()) <= 2e-5 * float(g_f32.abs().max())
