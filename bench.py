@@ -316,7 +316,7 @@ def main():
                        "env_steps_per_step": env_steps_per_update, "matmul_dtype": matmul,
                        "backend": train.backend, "driver": driver_mode, "parallelism": f"{args.mode}x{world}",
                        "kernel_forms": dict(zip(("train", "rollout"), _lib.last_kernel_form())),
-                       "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                       "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if world > 1 else 1,
                        "dist_backend": dist.get_backend() if world > 1 else None,
                        "gpus_visible": torch.cuda.device_count(),
                        "loop_tflops": sps * LOOP_FLOP / 1e12, "loop_frac_f32_peak": sps * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS},

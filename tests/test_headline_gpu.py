@@ -171,7 +171,7 @@ def test_headline_whole_update_vs_oracle(gpu, oracle):
 
 def test_forced_pair_forms_at_small_sizes_in_process(gpu):
     """The pair forms forced at sizes where they are not selected by default (pqn_set_option, in-process): the training
-    kernel at 2, 8 and 256 pairs (C = 4) and 32 pairs (C = 6) -- repeats bit-identical, equal to the single-tile bf16x3
+    kernel at 2, 8 and 256 pairs (C = 4; at C = 6 its LDS plan does not fit and the single-tile kernel must be what runs) -- repeats bit-identical, equal to the single-tile bf16x3
     kernel bit for bit and to the f32-MFMA mode to f32 rounding; the rollout kernel bit-identical in every output."""
     from purejaxql_amd import _lib
     from purejaxql_amd.networks import QNetwork
@@ -192,7 +192,8 @@ def test_forced_pair_forms_at_small_sizes_in_process(gpu):
                 lay = CnnKernelLayout(c, a, matmul_f16=mode)
                 tr = CnnTrainer(lay, theta, 5e-4, 10.0, max_minibatch=nb)
                 reps = [tr.compute_grad(idx, bits, action, target)[:lay.total].clone() for _ in range(3)]
-                assert _lib.last_kernel_form()[0] == ("pair" if pair else "single"), (name, c, nb)
+                # C = 6: the pair kernel's LDS plan (164,864 B) exceeds the 160 KB of a CU, so the switch cannot select it
+                assert _lib.last_kernel_form()[0] == ("pair" if (pair and c == 4) else "single"), (name, c, nb)
                 assert torch.equal(reps[0], reps[1]) and torch.equal(reps[0], reps[2]), (name, c, nb)
                 res[name] = reps[0]
         assert torch.equal(res["single"], res["pair"]), (c, nb)
