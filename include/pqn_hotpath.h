@@ -420,6 +420,58 @@ int pqn_mlp_update_seeds(const pqn_mlp_update_args_t *args /* host */, int32_t n
                          const uint64_t *key_shuf_dev, int64_t theta_stride, int64_t workspace_stride, int64_t wt_stride,
                          void *stream);
 
+/* ---- wide MLP Q-network of the Craftax script (QNetwork, pqn_craftax.py:33-62, NORM_TYPE = layer_norm) ---------- */
+/* [BatchRenorm | BatchNorm | nothing](x) -> `layers` x (Dense(h) -> LayerNorm -> relu) -> Dense(a): the shape of
+ * config/alg/pqn_craftax.yaml (1345 -> 4 x 1024 -> 17, NORM_INPUT with BatchRenorm).  Every Dense layer -- forward, input
+ * gradient, weight gradient -- is a tiled bf16x3 MFMA GEMM (csrc/pqn_bigmlp.hip).  Parameter buffer: flax order
+ * ({BatchRenorm,BatchNorm}_0 scale, bias | per layer Dense kernel (in,out) row-major, Dense bias, LayerNorm scale,
+ * LayerNorm bias | output Dense kernel, bias), every segment start padded to 16 B; the gradient and the RAdam moments
+ * share the layout, so the optimizer is pqn_radam_clip_step on the flat buffer. */
+#define PQN_BIGMLP_MAX_LAYERS 8
+typedef struct {
+  int32_t d, h, layers, a;
+  int32_t norm_input;                 /* 0: none (the dummy input normalisation never trains), 1: nn.BatchNorm, 2: BatchRenorm */
+  int32_t off_in_scale, off_in_bias;
+  int32_t off_w[PQN_BIGMLP_MAX_LAYERS + 1], off_b[PQN_BIGMLP_MAX_LAYERS + 1]; /* index `layers` = the output layer */
+  int32_t off_lns[PQN_BIGMLP_MAX_LAYERS], off_lnb[PQN_BIGMLP_MAX_LAYERS];
+  int32_t total;
+} pqn_bigmlp_layout_t;
+int pqn_bigmlp_layout(int32_t d, int32_t h, int32_t layers, int32_t a, int32_t norm_input,
+                      pqn_bigmlp_layout_t *layout /* host */);
+/* workspace floats for `rows` forward rows of which the first `nb` carry gradient (pqn_bigmlp_forward: rows = nb = n;
+ * pqn_bigmlp_grad: rows = 2 nb with the 1-step loss, nb with the Q(lambda) loss) */
+int64_t pqn_bigmlp_workspace_floats(const pqn_bigmlp_layout_t *layout /* host */, int32_t rows, int32_t nb);
+/* network.apply(params, obs, train=False) (pqn_craftax.py:184-197,226-237,403-413) + the eps-greedy draw: obs [n][d]
+ * contiguous; in_mean / in_var [d] = the running moments of the input normalisation (batch_stats; NULL if norm_input = 0).
+ * Outputs (each nullable): q [n][a], action [n] (element e draws threefry(key, (e, 0)) as pqn_eps_greedy), qmax [n].
+ * eps_dev / key_dev (nullable): take eps / key from device memory instead (hipGraph-capturable callers). */
+int pqn_bigmlp_forward(const pqn_bigmlp_layout_t *layout /* host */, int32_t n, const float *obs, const float *theta,
+                       float *in_mean, float *in_var, float *workspace, float *q, int32_t *action, float *qmax, float eps,
+                       uint64_t key, const float *eps_dev, const uint64_t *key_dev, void *stream);
+/* value_and_grad(_loss_fn) of pqn_craftax.py:277-312, train = True with mutable batch_stats.  Minibatch row r reads
+ * transition idx[r] of the flat record: obs row idx[r], action / target / reward / done [idx[r]].
+ *   next_offset > 0: the `Q_LAMBDA: False` branch -- next_obs of transition j is obs row j + next_offset; obs and
+ *       next_obs go through the network as ONE batch of 2 nb rows (batch statistics over both halves), q_next carries no
+ *       gradient, target = reward + (1 - done) gamma max_a q_next (:296-306).  `target` unused.
+ *   next_offset = 0: the Q(lambda) branch, `target` given (:280-286); reward / done unused.
+ * in_mean / in_var / in_steps: running statistics of the input normalisation, updated in place (BatchRenorm:
+ * utils/batch_renorm.py:95-116, in_steps = its train-call counter).  Writes the flat gradient, loss and mean(q_a). */
+int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *layout /* host */, int32_t nb, const int64_t *idx, const float *obs,
+                    int64_t next_offset, const int32_t *action, const float *target, const float *reward,
+                    const uint8_t *done, float gamma, const float *theta, float *in_mean, float *in_var,
+                    int32_t *in_steps, float *grad, float *workspace, float *loss_out, float *qv_out, void *stream);
+
+/* Where a forward intermediate of the last pqn_bigmlp_forward / pqn_bigmlp_grad call lives inside `workspace` (float
+ * offset + leading dimension): what 0 = normalised input [rows][ld], 1 = z_layer, 2 = h_layer = relu(LN(z_layer)),
+ * 3 = (mean, rstd) of z_layer, 4 = q.  For tests (e.g. to compare relu decisions with a reference forward). */
+int pqn_bigmlp_workspace_view(const pqn_bigmlp_layout_t *layout /* host */, int32_t rows, int32_t nb, int32_t what,
+                              int32_t layer, int64_t *offset /* host */, int64_t *ld /* host */);
+/* The GEMM behind every Dense layer of the wide MLP, exposed for tests: C[m][n] = op(A) op(B) (+ bias[n]) with f32-grade
+ * bf16x3 products.  trans_a: A stored [k][m] (else [m][k]); trans_b: B stored [k][n] (else [n][k]); row-major with
+ * leading dimensions lda / ldb / ldc. */
+int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, int64_t lda, int32_t trans_a, const float *b,
+                    int64_t ldb, int32_t trans_b, const float *bias, float *c, int64_t ldc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

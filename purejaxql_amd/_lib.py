@@ -88,6 +88,16 @@ SIGNATURES = {
     "pqn_mlp_grad": (c_int, [c_void_p, c_int32] + [c_void_p] * 11 + [c_void_p]),
     "pqn_mlp_apply": (c_int, [c_void_p] * 7 + [c_float, c_float, C.c_double, c_float] + [c_void_p, c_void_p, c_int32, c_void_p]),
     "pqn_mlp_refresh_transposed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pqn_bigmlp_layout": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pqn_bigmlp_workspace_floats": (c_int64, [c_void_p, c_int32, c_int32]),
+    "pqn_bigmlp_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "pqn_bigmlp_workspace_view": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "pqn_bigmlp_gemm": (c_int, [c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p,
+                                c_void_p, c_int64, c_void_p]),
+    "pqn_bigmlp_grad": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
 }
 
 _lib = None

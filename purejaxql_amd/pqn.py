@@ -262,6 +262,63 @@ class _FusedMlpPolicy:
         return {"opt_count": self.tr.count, "opt_mu": self.tr.m, "opt_nu": self.tr.v, "kernel_layout": self.layout}
 
 
+class _FusedBigMlpPolicy:
+    """The wide LayerNorm MLP of the Craftax script (pqn_craftax.py:33-62 with NORM_TYPE = layer_norm; C5 = 1345 ->
+    4 x 1024 -> 17, BatchRenorm on the input) through the tiled bf16x3 MFMA GEMM kernels of csrc/pqn_bigmlp.hip: forward
+    (+ eps-greedy), value_and_grad of both branches of _loss_fn (:277-312), clip + RAdam on the flat buffer."""
+    packed = False
+
+    def __init__(self, network, theta, config, lr_steps, grad_hook):
+        from .qnet import BigMlpKernelLayout, BigMlpTrainer
+        self.net = network
+        norm_input = (2 if network.renorm else 1) if network.norm_input else 0
+        self.layout = BigMlpKernelLayout(network.obs_shape[0], network.hidden, network.layers, network.action_dim, norm_input)
+        self.tr = BigMlpTrainer(self.layout, theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps)
+        self.grad_hook = grad_hook
+        if norm_input and grad_hook is not None:
+            raise NotImplementedError("input BatchNorm / BatchRenorm with the envs of one seed sharded over ranks would need "
+                                      "the batch moments all-reduced as well; use seed sharding (dist.partition_seeds)")
+
+    def q_values(self, obs):
+        return self.tr.forward(obs)[0]
+
+    def act(self, obs, eps, key, action, qmax):
+        self.tr.forward(obs, want_q=False, eps=eps, key=key, action=action, qmax=qmax)
+
+    def max_q(self, obs, out):
+        self.tr.forward(obs, want_q=False, qmax=out)
+
+    def _step(self):
+        if self.grad_hook is not None:
+            self.grad_hook(self.tr.grad)
+        self.tr.apply()
+
+    def sgd_step(self, idx, obs_flat, act_flat, tgt_flat, loss_out, qv_out):
+        self.tr.compute_grad(idx, obs_flat, act_flat, target=tgt_flat, loss_out=loss_out, qv_out=qv_out)
+        self._step()
+
+    def sgd_step_1step(self, idx, obs_all_flat, n_env, act_flat, rew_flat, done_flat, gamma, loss_out, qv_out):
+        """`Q_LAMBDA: False` (pqn_craftax.py:287-304): next_obs of transition j is row j + n_env of the flattened [T+1][N]
+        observation record; obs and next_obs form ONE batch inside pqn_bigmlp_grad."""
+        self.tr.compute_grad(idx, obs_all_flat, act_flat, reward=rew_flat, done=done_flat, gamma=gamma, next_offset=n_env,
+                             loss_out=loss_out, qv_out=qv_out)
+        self._step()
+
+    def theta_flax(self):
+        return self.tr.theta_flax()
+
+    def opt_state(self):
+        from .networks import bn_module
+        stats = {}
+        if self.layout.norm_input:
+            name = bn_module(self.net.renorm) + "_0"
+            stats = {name + "/mean": self.tr.in_mean, name + "/var": self.tr.in_var}
+            if self.net.renorm:
+                stats[name + "/steps"] = self.tr.in_steps[0]
+        return {"opt_count": self.tr.count, "opt_mu": self.tr.m, "opt_nu": self.tr.v, "kernel_layout": self.layout,
+                "batch_stats": stats}
+
+
 def _mlp_fits_fused(obs_dim: int, hidden: int, layers: int) -> bool:
     """LDS footprint of mlp_train_kernel (csrc/pqn_mlp.hip) must stay under 160 KB."""
     if hidden % 16 or hidden < 16 or hidden > 1024 or layers < 1 or layers > 4:
@@ -328,17 +385,25 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
     sp = _lib.stream_ptr
     q_lambda_loss = bool(config.get("Q_LAMBDA", False)) if craftax else True     # pqn_craftax.py:277
     backend = config.get("_BACKEND")
-    if craftax:          # BatchRenorm network + wrapper-batched env: torch-op network over the HIP env / RAdam kernels
-        if backend not in (None, "torch"):
-            raise ValueError("the Craftax script variant runs the torch-op network (BatchRenorm, 1-step loss)")
-        backend = "torch"
+    from .qnet import bigmlp_supported
+    # wide LayerNorm MLPs (the Craftax yaml: 4 x 1024, input BatchRenorm): tiled MFMA GEMM kernels, csrc/pqn_bigmlp.hip
+    big_ok = (kind == "mlp" and config["NORM_TYPE"] == "layer_norm" and
+              bigmlp_supported(obs_shape[0], int(config.get("HIDDEN_SIZE", 128)), int(config.get("NUM_LAYERS", 2)), A) and
+              not (grad_hook is not None and config.get("NORM_INPUT", False)))
+    if craftax:          # wrapper-batched env, 1-step loss: the wide-MLP kernels, else the torch-op network (hidden BatchRenorm,
+        if backend not in (None, "torch", "fused_big"):   # narrow layers) -- over the HIP env / eps-greedy / RAdam kernels either way
+            raise ValueError("the Craftax script variant runs the wide-MLP kernels or the torch-op network")
+        if backend == "fused_big" and not big_ok:
+            raise ValueError("_BACKEND=fused_big needs NORM_TYPE=layer_norm and a shape csrc/pqn_bigmlp.hip tiles")
+        backend = backend or ("fused_big" if big_ok else "torch")
     if backend is None:  # fused kernels: LayerNorm networks; the CNN also needs 16 | minibatch
         plain_ln = config["NORM_TYPE"] == "layer_norm" and not config.get("NORM_INPUT", False)
         if kind == "cnn":
             backend = "fused" if (plain_ln and B % 16 == 0) else "torch"
+        elif plain_ln and _mlp_fits_fused(obs_shape[0], int(config.get("HIDDEN_SIZE", 128)), int(config.get("NUM_LAYERS", 2))):
+            backend = "fused"
         else:
-            backend = "fused" if (plain_ln and _mlp_fits_fused(obs_shape[0], int(config.get("HIDDEN_SIZE", 128)),
-                                                               int(config.get("NUM_LAYERS", 2)))) else "torch"
+            backend = "fused_big" if big_ok else "torch"
     packed = backend == "fused" and kind == "cnn"
     # shape limits of the whole-update C++ enqueue (pqn_cnn_update / pqn_mlp_update: the schedule kernel derives the
     # T + EPOCHS keys of an update with one 1024-thread block) and of seed batching (25 index bits in the shuffle
@@ -451,6 +516,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             policy = _FusedCnnPolicy(network, theta, config, lr_steps, grad_hook, B)
         elif backend == "fused":
             policy = _FusedMlpPolicy(network, theta, config, lr_steps, grad_hook, B)
+        elif backend == "fused_big":
+            policy = _FusedBigMlpPolicy(network, theta, config, lr_steps, grad_hook)
         else:
             policy = _TorchPolicy(network, theta, config, lr_steps, grad_hook)
         counters = {"timesteps": 0, "n_updates": 0, "grad_steps": 0}

@@ -584,3 +584,151 @@ class MlpTrainer:
 
     def theta_flax(self) -> torch.Tensor:
         return self.layout.to_flax(self.theta)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# wide MLP Q-network of the Craftax script (csrc/pqn_bigmlp.hip)
+# ---------------------------------------------------------------------------------------------------------
+BIGMLP_MAX_LAYERS = 8
+
+
+class BigMlpLayoutStruct(C.Structure):
+    """pqn_bigmlp_layout_t"""
+    _fields_ = [("d", C.c_int32), ("h", C.c_int32), ("layers", C.c_int32), ("a", C.c_int32), ("norm_input", C.c_int32),
+                ("off_in_scale", C.c_int32), ("off_in_bias", C.c_int32),
+                ("off_w", C.c_int32 * (BIGMLP_MAX_LAYERS + 1)), ("off_b", C.c_int32 * (BIGMLP_MAX_LAYERS + 1)),
+                ("off_lns", C.c_int32 * BIGMLP_MAX_LAYERS), ("off_lnb", C.c_int32 * BIGMLP_MAX_LAYERS), ("total", C.c_int32)]
+
+
+def bigmlp_supported(obs_dim: int, hidden: int, layers: int, num_actions: int) -> bool:
+    """Shapes csrc/pqn_bigmlp.hip tiles (pqn_bigmlp_layout rejects the rest)."""
+    return obs_dim >= 8 and 256 <= hidden <= 4096 and hidden % 256 == 0 and 1 <= layers <= BIGMLP_MAX_LAYERS and \
+        1 <= num_actions <= 64
+
+
+class BigMlpKernelLayout:
+    """pqn_bigmlp_layout_t + the flax-flat (networks.mlp_param_shapes order, layer_norm) <-> kernel-layout map: the same
+    order with every segment start padded to 16 B.  norm_input: 0 none / 1 nn.BatchNorm / 2 BatchRenorm on the input."""
+
+    def __init__(self, obs_dim: int, hidden: int, layers: int, num_actions: int, norm_input: int):
+        lib = _lib.load()
+        self.struct = BigMlpLayoutStruct()
+        _lib.check(lib.pqn_bigmlp_layout(obs_dim, hidden, layers, num_actions, int(norm_input), C.byref(self.struct)),
+                   "pqn_bigmlp_layout")
+        s = self.struct
+        self.d, self.h, self.layers, self.a, self.total = int(s.d), int(s.h), int(s.layers), int(s.a), int(s.total)
+        self.norm_input = int(s.norm_input)
+        segs = [(int(s.off_in_scale), self.d), (int(s.off_in_bias), self.d)]
+        kin = self.d
+        for l in range(self.layers):
+            segs += [(int(s.off_w[l]), kin * self.h), (int(s.off_b[l]), self.h), (int(s.off_lns[l]), self.h),
+                     (int(s.off_lnb[l]), self.h)]
+            kin = self.h
+        segs += [(int(s.off_w[self.layers]), self.h * self.a), (int(s.off_b[self.layers]), self.a)]
+        self.segments = []          # (flax offset, kernel offset, length)
+        off = 0
+        for koff, n in segs:
+            self.segments.append((off, koff, n))
+            off += n
+        self.num_flax = off
+
+    def to_kernel(self, theta_flax: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros(self.total, dtype=torch.float32, device=theta_flax.device)
+        for foff, koff, n in self.segments:
+            out[koff:koff + n] = theta_flax[foff:foff + n]
+        return out
+
+    def to_flax(self, theta_k: torch.Tensor) -> torch.Tensor:
+        return torch.cat([theta_k[koff:koff + n] for _f, koff, n in self.segments])
+
+
+class BigMlpTrainer:
+    """Parameters, RAdam state, running input statistics and workspace of one seed for the wide MLP;
+    value_and_grad(_loss_fn) of pqn_craftax.py:277-312 = pqn_bigmlp_grad, apply_gradients = pqn_radam_clip_step."""
+
+    def __init__(self, layout: BigMlpKernelLayout, theta_flax: torch.Tensor, lr: float, max_grad_norm: float,
+                 lr_decay_steps: float = 0.0, lr_end: float = 1e-20):
+        dev = theta_flax.device
+        self.layout = layout
+        self.theta = layout.to_kernel(theta_flax)
+        self.grad = torch.zeros_like(self.theta)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.lr, self.lr_end, self.lr_steps, self.max_norm = float(lr), float(lr_end), float(lr_decay_steps), float(max_grad_norm)
+        # batch_stats of the input normalisation: running mean 0 / var 1, BatchRenorm's step counter
+        self.in_mean = torch.zeros(layout.d, dtype=torch.float32, device=dev)
+        self.in_var = torch.ones(layout.d, dtype=torch.float32, device=dev)
+        self.in_steps = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ws = {}
+
+    def _workspace(self, rows: int, nb: int) -> torch.Tensor:
+        sid = _lib.stream_ptr()   # one workspace per stream: seeds may run as concurrent streams
+        n = int(_lib.load().pqn_bigmlp_workspace_floats(C.byref(self.layout.struct), rows, nb))
+        if n < 0:
+            raise RuntimeError("pqn_bigmlp_workspace_floats failed")
+        ws = self._ws.get(sid)
+        if ws is None or ws.numel() < n:
+            ws = self._ws[sid] = torch.empty(n, dtype=torch.float32, device=self.theta.device)
+        return ws
+
+    def intermediate(self, rows: int, nb: int, what: str, layer: int = 0) -> torch.Tensor:
+        """A forward intermediate of the last forward / compute_grad call on this stream (pqn_bigmlp_workspace_view):
+        what = "xn" | "z" | "h" | "stat" | "q"."""
+        off, ld = C.c_int64(0), C.c_int64(0)
+        code = {"xn": 0, "z": 1, "h": 2, "stat": 3, "q": 4}[what]
+        _lib.check(_lib.load().pqn_bigmlp_workspace_view(C.byref(self.layout.struct), rows, nb, code, layer, C.addressof(off),
+                                                         C.addressof(ld)), "pqn_bigmlp_workspace_view")
+        ws = self._ws[_lib.stream_ptr()]
+        return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)
+
+    def forward(self, obs: torch.Tensor, *, want_q: bool = True, eps: Optional[float] = None, key: int = 0, q=None,
+                action=None, qmax=None):
+        lib = _lib.load()
+        n = int(obs.shape[0])
+        dev = obs.device
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.layout.d
+        if want_q and q is None:
+            q = torch.empty((n, self.layout.a), dtype=torch.float32, device=dev)
+        if eps is not None and action is None:
+            action = torch.empty(n, dtype=torch.int32, device=dev)
+        if (eps is not None or not want_q) and qmax is None:
+            qmax = torch.empty(n, dtype=torch.float32, device=dev)
+        ws = self._workspace(n, n)
+        use_stats = self.layout.norm_input != 0
+        _lib.check(lib.pqn_bigmlp_forward(C.byref(self.layout.struct), n, _lib.ptr(obs), _lib.ptr(self.theta),
+                                          _lib.ptr(self.in_mean) if use_stats else None,
+                                          _lib.ptr(self.in_var) if use_stats else None, _lib.ptr(ws), _lib.ptr(q),
+                                          _lib.ptr(action) if eps is not None else None, _lib.ptr(qmax), float(eps or 0.0), key,
+                                          None, None, _lib.stream_ptr()), "pqn_bigmlp_forward")
+        return q, action, qmax
+
+    def compute_grad(self, idx: torch.Tensor, obs_flat: torch.Tensor, action: torch.Tensor, *, target=None, reward=None,
+                     done=None, gamma: float = 0.0, next_offset: int = 0, loss_out=None, qv_out=None):
+        lib = _lib.load()
+        nb = int(idx.numel())
+        assert idx.dtype == torch.int64 and action.dtype == torch.int32 and obs_flat.dtype == torch.float32
+        assert obs_flat.is_contiguous() and obs_flat.shape[1] == self.layout.d
+        if done is not None and done.dtype == torch.bool:
+            done = done.view(torch.uint8)
+        ws = self._workspace(2 * nb if next_offset > 0 else nb, nb)
+        use_stats = self.layout.norm_input != 0
+        _lib.check(lib.pqn_bigmlp_grad(C.byref(self.layout.struct), nb, _lib.ptr(idx), _lib.ptr(obs_flat), int(next_offset),
+                                       _lib.ptr(action), _lib.ptr(target), _lib.ptr(reward), _lib.ptr(done), float(gamma),
+                                       _lib.ptr(self.theta), _lib.ptr(self.in_mean) if use_stats else None,
+                                       _lib.ptr(self.in_var) if use_stats else None,
+                                       _lib.ptr(self.in_steps) if use_stats else None, _lib.ptr(self.grad), _lib.ptr(ws),
+                                       _lib.ptr(loss_out), _lib.ptr(qv_out), _lib.stream_ptr()), "pqn_bigmlp_grad")
+        return self.grad
+
+    def apply(self):
+        lib = _lib.load()
+        _lib.check(lib.pqn_radam_clip_step(_lib.ptr(self.theta), _lib.ptr(self.grad), _lib.ptr(self.m), _lib.ptr(self.v),
+                                           self.theta.numel(), _lib.ptr(self.count), self.lr, self.lr_end, self.lr_steps,
+                                           self.max_norm, _lib.ptr(self.scratch), _lib.ptr(self.gnorm), _lib.stream_ptr()),
+                   "pqn_radam_clip_step")
+
+    def theta_flax(self) -> torch.Tensor:
+        return self.layout.to_flax(self.theta)
