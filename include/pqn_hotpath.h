@@ -342,7 +342,7 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
 /* Run-time switches of the kernel selection (profiling, A/B runs, tests; no reference counterpart -- XLA picks its
  * fusions itself).  Names: "t1_pair", "rollout_pair" (pair form of the bf16x3 training / rollout kernel: 0 never,
  * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
- * variants), "seed_group", "ablate_train", "ablate", "fused_tail".  Each starts from its PQN_<NAME> environment
+ * variants), "seed_group", "ablate_train", "ablate", "fused_tail", "bm_tile", "bm_split" (wide-MLP GEMM tile height / K splits).  Each starts from its PQN_<NAME> environment
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);
@@ -468,9 +468,11 @@ int pqn_bigmlp_workspace_view(const pqn_bigmlp_layout_t *layout /* host */, int3
                               int32_t layer, int64_t *offset /* host */, int64_t *ld /* host */);
 /* The GEMM behind every Dense layer of the wide MLP, exposed for tests: C[m][n] = op(A) op(B) (+ bias[n]) with f32-grade
  * bf16x3 products.  trans_a: A stored [k][m] (else [m][k]); trans_b: B stored [k][n] (else [n][k]); row-major with
- * leading dimensions lda / ldb / ldc. */
+ * leading dimensions lda / ldb / ldc.  nsplit (1..4) K splits leave nsplit partial outputs split_stride floats apart (the
+ * caller sums them; no bias then); tile_rows = 64 | 128. */
 int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, int64_t lda, int32_t trans_a, const float *b,
-                    int64_t ldb, int32_t trans_b, const float *bias, float *c, int64_t ldc, void *stream);
+                    int64_t ldb, int32_t trans_b, const float *bias, float *c, int64_t ldc, int32_t nsplit,
+                    int64_t split_stride, int32_t tile_rows, void *stream);
 
 #ifdef __cplusplus
 }

@@ -94,7 +94,7 @@ SIGNATURES = {
                                    c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),
     "pqn_bigmlp_workspace_view": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "pqn_bigmlp_gemm": (c_int, [c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p,
-                                c_void_p, c_int64, c_void_p]),
+                                c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p]),
     "pqn_bigmlp_grad": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),

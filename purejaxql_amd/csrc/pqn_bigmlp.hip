@@ -69,41 +69,14 @@ struct BmOperand {
 };
 
 struct BmEpilogue {
-  float *out;                // BM_EPI_STORE: C, row-major, leading dimension ldc;  BM_EPI_INNORM: partials [m tile][2][N]
+  float *out;                // BM_EPI_STORE: C, row-major, leading dimension ldc;  BM_EPI_INNORM: partials [K split][m tile][2][N]
   long long ldc;
-  const float *bias;         // BM_EPI_STORE: optional per-column bias
+  const float *bias;         // BM_EPI_STORE: optional per-column bias (only without split-K)
+  long long split_stride;    // BM_EPI_STORE: elements between the partial outputs of consecutive K splits
   // BM_EPI_INNORM (input-normalisation parameter gradients): d scale_c = sum_r C[r][c] xhat[r][c], d bias_c = sum_r C[r][c]
   const float *xhat;         // [M][ldx]: (x - m_c) k_c of the gradient rows
   long long ldx;
 };
-
-// one pack: tile row t (global index), K indices k .. k + 7, zero outside the matrix.  Addresses are clamped into the
-// matrix and the loads stay unconditional (compiler finding 1); validity is applied to the values.
-template <bool TRANS, bool VEC>
-PQN_D void bm_load_pack(const BmOperand &o, int t, int k, float (&v)[8]) {
-  if (!TRANS) {
-    const float *row = o.p + (long long)min(t, o.rows - 1) * o.ld;
-    if (VEC) {   // rows 16-B aligned (ld % 4 == 0): two aligned quads, clamped to the row's last quad -- a clamped quad lies
-                 // wholly beyond the valid columns (k % 8 == 0, ld % 4 == 0), so the validity mask below zeroes it
-      const int lim4 = (int)o.ld - 4;
-      const f32x4 a = *reinterpret_cast<const f32x4 *>(row + min(k, lim4)), b = *reinterpret_cast<const f32x4 *>(row + min(k + 4, lim4));
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = row[min(k + j, o.cols - 1)];
-    }
-    const bool tok = t < o.rows;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (tok && k + j < o.cols) ? v[j] : 0.0f;
-  } else {
-    const int c = min(t, o.cols - 1);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = o.p[(long long)min(k + j, o.rows - 1) * o.ld + c];
-    const bool tok = t < o.cols;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (tok && k + j < o.rows) ? v[j] : 0.0f;
-  }
-}
 
 // split a pack into three planes and write the 16-B fragment slots: slot (block = t >> 4, lane = kb * 16 + (t & 15))
 PQN_D void bm_store_pack(u32x4 *planes, int nblk, int t_local, int kb, const float (&v)[8]) {
@@ -116,13 +89,98 @@ PQN_D void bm_store_pack(u32x4 *planes, int nblk, int t_local, int kb, const flo
   planes[2 * nblk * 64 + slot] = u32x4{l[0], l[1], l[2], l[3]};
 }
 
+// Operand loaders.  A "pack" = the 8 K-values k .. k + 7 of one tile row = one lane's share of an MFMA fragment.  Values
+// outside the matrix read as zero; addresses are clamped into the matrix so that every load stays unconditional
+// (compiler finding 1) and validity is applied to the values.
+//   BM_LM_ROWVEC  untransposed source, rows 16-B aligned: two aligned quads per pack
+//   BM_LM_ROWSCL  untransposed source, any alignment: eight dword loads per pack
+//   BM_LM_COLVEC  transposed source (K runs down the source rows), rows 16-B aligned: a unit = 8 K-rows x 4 adjacent tile
+//                 rows = eight quad loads that yield FOUR packs; a BT-row tile has BT units, served by BT threads
+//   BM_LM_COLSCL  transposed source, any alignment: eight dword loads per pack (adjacent lanes = adjacent tile rows)
+enum { BM_LM_ROWVEC = 0, BM_LM_ROWSCL = 1, BM_LM_COLVEC = 2, BM_LM_COLSCL = 3 };
+
+template <int LM, int BT, int TBASE>
+struct BmLoader {
+  static constexpr bool COL = LM >= BM_LM_COLVEC;
+  static constexpr int NP = LM == BM_LM_COLVEC ? 4 : BT * 4 / BM_THREADS;   // packs per thread and K step
+  float r[NP][8];
+  int t[NP], kb[NP];
+  bool active;
+  PQN_D void init(int tid) {
+    if (LM == BM_LM_COLVEC) {
+      const int u = tid - TBASE;            // TBASE and BT are multiples of 64: whole waves are active or not
+      active = u >= 0 && u < BT;
+      const int uu = active ? u : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { t[i] = 4 * (uu % (BT / 4)) + i; kb[i] = uu / (BT / 4); }
+    } else {
+      active = true;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int p = tid + BM_THREADS * q;
+        t[q] = COL ? p % BT : p >> 2;
+        kb[q] = COL ? p / BT : p & 3;
+      }
+    }
+  }
+  PQN_D void load(const BmOperand &o, int t0, int k0) {
+    if (LM == BM_LM_COLVEC) {
+      if (!active) return;
+      const int k = k0 + 8 * kb[0], c = t0 + t[0];
+      const int cc = min(c, (int)o.ld - 4);          // quads are aligned; a clamped quad lies wholly beyond the valid columns
+      f32x4 u[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const f32x4 *>(o.p + (long long)min(k + j, o.rows - 1) * o.ld + cc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool kok = k + j < o.rows;
+        r[0][j] = (kok && c < o.cols) ? u[j].x : 0.0f;
+        r[1][j] = (kok && c + 1 < o.cols) ? u[j].y : 0.0f;
+        r[2][j] = (kok && c + 2 < o.cols) ? u[j].z : 0.0f;
+        r[3][j] = (kok && c + 3 < o.cols) ? u[j].w : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int tt = t0 + t[q], k = k0 + 8 * kb[q];
+        float (&v)[8] = r[q];
+        if (!COL) {
+          const float *row = o.p + (long long)min(tt, o.rows - 1) * o.ld;
+          if (LM == BM_LM_ROWVEC) {   // a clamped quad lies wholly beyond the valid columns (k % 8 == 0, ld % 4 == 0)
+            const int lim4 = (int)o.ld - 4;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(row + min(k, lim4)), b = *reinterpret_cast<const f32x4 *>(row + min(k + 4, lim4));
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = row[min(k + j, o.cols - 1)];
+          }
+          const bool tok = tt < o.rows;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (tok && k + j < o.cols) ? v[j] : 0.0f;
+        } else {
+          const int c = min(tt, o.cols - 1);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = o.p[(long long)min(k + j, o.rows - 1) * o.ld + c];
+          const bool tok = tt < o.cols;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (tok && k + j < o.rows) ? v[j] : 0.0f;
+        }
+      }
+    }
+  }
+  PQN_D void store(u32x4 *planes) const {
+    if (LM == BM_LM_COLVEC && !active) return;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) bm_store_pack(planes, BT / 16, t[q], kb[q], r[q]);
+  }
+};
+
 template <int BM>
 constexpr int bm_lds_bytes() { return 2 * 3 * (BM / 16 + BM_BN / 16) * 64 * 16; }
 
-template <int BM, bool TA, bool VA, bool TB, bool VB, int EPI>
-__global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K, BmOperand A, BmOperand B, BmEpilogue E) {
+template <int BM, int LMA, int LMB, int EPI>
+__global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K, int klen, BmOperand A, BmOperand B, BmEpilogue E) {
   constexpr int NBA = BM / 16, NBB = BM_BN / 16;
-  constexpr int PA = BM * 4 / BM_THREADS, PB = BM_BN * 4 / BM_THREADS;   // packs per thread and K step
   constexpr int MI = BM / 32;                                           // 16-row blocks per wave (2 x 2 waves)
   extern __shared__ __attribute__((aligned(16))) char bm_smem[];
   u32x4 *sA = reinterpret_cast<u32x4 *>(bm_smem);                         // [2][3][NBA][64]
@@ -130,47 +188,27 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BM_BN;
-  // pack -> (tile row, kb): k-contiguous sources put the 4 kb of a row on adjacent lanes (128 B runs), transposed
-  // sources put consecutive tile rows (= consecutive source columns) on adjacent lanes
-  int ta[PA], ka[PA], tb[PB], kbb[PB];
-#pragma unroll
-  for (int q = 0; q < PA; ++q) {
-    const int p = tid + BM_THREADS * q;
-    ta[q] = TA ? p % BM : p >> 2;
-    ka[q] = TA ? p / BM : p & 3;
-  }
-#pragma unroll
-  for (int q = 0; q < PB; ++q) {
-    const int p = tid + BM_THREADS * q;
-    tb[q] = TB ? p % BM_BN : p >> 2;
-    kbb[q] = TB ? p / BM_BN : p & 3;
-  }
-  float ra[PA][8], rb[PB][8];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int q = 0; q < PA; ++q) bm_load_pack<TA, VA>(A, m0 + ta[q], k0 + 8 * ka[q], ra[q]);
-#pragma unroll
-    for (int q = 0; q < PB; ++q) bm_load_pack<TB, VB>(B, n0 + tb[q], k0 + 8 * kbb[q], rb[q]);
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < PA; ++q) bm_store_pack(sA + buf * 3 * NBA * 64, NBA, ta[q], ka[q], ra[q]);
-#pragma unroll
-    for (int q = 0; q < PB; ++q) bm_store_pack(sB + buf * 3 * NBB * 64, NBB, tb[q], kbb[q], rb[q]);
-  };
+  // split-K: workgroup z owns K indices [z klen, (z + 1) klen) (klen % 32 == 0) and writes its own partial output
+  const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
+  BmLoader<LMA, BM, 0> la;                         // transposed-vector units of A: threads 0 .. BM - 1
+  BmLoader<LMB, BM_BN, BM_THREADS - BM_BN> lb;     // ... of B: the last wave
+  la.init(tid);
+  lb.init(tid);
+  auto gload = [&](int k0) { la.load(A, m0, k0); lb.load(B, n0, k0); };
+  auto lstore = [&](int buf) { la.store(sA + buf * 3 * NBA * 64); lb.store(sB + buf * 3 * NBB * 64); };
   f32x4 accb[MI][2], accs[MI][2];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) { accb[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; accs[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const int nk = (K + BM_KS - 1) / BM_KS;
-  gload(0);
+  const int nk = (kend - kbeg + BM_KS - 1) / BM_KS;
+  gload(kbeg);
 #pragma unroll 1
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
     lstore(buf);
     __syncthreads();
-    if (ks + 1 < nk) gload((ks + 1) * BM_KS);   // in flight during the MFMAs below
+    if (ks + 1 < nk) gload(kbeg + (ks + 1) * BM_KS);   // in flight during the MFMAs below
     const u32x4 *pa = sA + buf * 3 * NBA * 64 + (wm * MI) * 64 + lane;
     const u32x4 *pb = sB + buf * 3 * NBB * 64 + (wn * 2) * 64 + lane;
     u32x4 a[MI][3], b[2][3];
@@ -196,6 +234,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
   // ---- epilogue ----
   const int col_l = lane & 15, rq = lane >> 4;
   if (EPI == BM_EPI_STORE) {
+    float *outp = E.out + (long long)blockIdx.z * E.split_stride;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -208,7 +247,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + (wm * MI + mi) * 16 + 4 * rq + r;
-          if (row < M && col < N) E.out[(long long)row * E.ldc + col] = tv[r] + bias;
+          if (row < M && col < N) outp[(long long)row * E.ldc + col] = tv[r] + bias;
         }
       }
   } else {
@@ -244,7 +283,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
     }
     __syncthreads();
     if (tid < 64 && n0 + tid < N) {
-      float *po = E.out + (long long)blockIdx.y * 2 * N;
+      float *po = E.out + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * 2 * N;
       po[n0 + tid] = red[tid * 2] + red[(64 + tid) * 2];
       po[N + n0 + tid] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
     }
@@ -258,22 +297,26 @@ PQN_D float bm_wave_sum(float v) {
   return v;
 }
 
-// h = relu(LayerNorm(z)) row by row (one wave per row), stat[r] = (mean, rstd) kept for the backward pass.
-// n % 256 == 0, n <= 4096.
+// z = sum of the K-split partials of the layer's GEMM + bias;  h = relu(LayerNorm(z)) row by row (one wave per row);
+// z and stat[r] = (mean, rstd) are kept for the backward pass.  n % 256 == 0, n <= 4096.
 #define BM_MAXQ 4
-__global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict__ z, int m, int n,
-                                                         const float *__restrict__ g, const float *__restrict__ beta,
+__global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict__ zpart, int nsplit, long long pstride, int m,
+                                                         int n, const float *__restrict__ bias, const float *__restrict__ g,
+                                                         const float *__restrict__ beta, float *__restrict__ z,
                                                          float *__restrict__ h, float *__restrict__ stat) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
-  const float *zr = z + (long long)row * n;
   const int nq = n / 256;
   f32x4 v[BM_MAXQ];
   float s = 0.f, q = 0.f;
 #pragma unroll
   for (int k = 0; k < BM_MAXQ; ++k)
     if (k < nq) {
-      v[k] = *reinterpret_cast<const f32x4 *>(zr + lane * 4 + 256 * k);
+      const int c = lane * 4 + 256 * k;
+      v[k] = *reinterpret_cast<const f32x4 *>(zpart + (long long)row * n + c);
+      for (int sp = 1; sp < nsplit; ++sp) v[k] += *reinterpret_cast<const f32x4 *>(zpart + sp * pstride + (long long)row * n + c);
+      v[k] += *reinterpret_cast<const f32x4 *>(bias + c);
+      *reinterpret_cast<f32x4 *>(z + (long long)row * n + c) = v[k];
       s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
       q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
     }
@@ -399,11 +442,10 @@ __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__
                                                        const uint8_t *__restrict__ done, float gamma, int next_rows,
                                                        float *__restrict__ dq, float *__restrict__ dbias,
                                                        float *__restrict__ loss_out, float *__restrict__ qv_out) {
-  __shared__ float s_g[1024];
-  __shared__ int s_a[1024];
+  __shared__ float s_b[16][64];    // per-wave partial column sums of dQ (a <= 64)
   __shared__ float s_l[16], s_q[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float lsum = 0.f, qsum = 0.f, bacc = 0.f;
+  float lsum = 0.f, qsum = 0.f, bacc = 0.f;   // bacc: lane j of a wave accumulates that wave's sum for action j
   const float inv_b = 1.0f / (float)b;
   for (int r0 = 0; r0 < b; r0 += 1024) {
     const int r = r0 + tid;
@@ -428,20 +470,21 @@ __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__
       qsum += qa;
       for (int k = 0; k < ldq; ++k) dq[(long long)r * ldq + k] = (k == act) ? g : 0.0f;
     }
-    s_g[tid] = g;
-    s_a[tid] = act;
-    __syncthreads();
-    if (tid < a) {
-      const int lim = min(1024, b - r0);
-      for (int i = 0; i < lim; ++i) bacc += (s_a[i] == tid) ? s_g[i] : 0.0f;
+    for (int k = 0; k < a; ++k) {   // fixed-order butterfly per action; every lane gets the wave total
+      const float t = bm_wave_sum(act == k ? g : 0.0f);
+      bacc += (lane == k) ? t : 0.0f;
     }
-    __syncthreads();
   }
-  if (tid < a) dbias[tid] = bacc;
+  s_b[wave][lane] = bacc;
   lsum = bm_wave_sum(lsum);
   qsum = bm_wave_sum(qsum);
   if (lane == 0) { s_l[wave] = lsum; s_q[wave] = qsum; }
   __syncthreads();
+  if (tid < a) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += s_b[w][tid];
+    dbias[tid] = t;
+  }
   if (tid == 0) {
     float l = 0.f, qq = 0.f;
     for (int w = 0; w < 16; ++w) { l += s_l[w]; qq += s_q[w]; }
@@ -450,11 +493,12 @@ __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__
   }
 }
 
-// relu mask + LayerNorm backward, in place on d (rows x n), one wave per row, BM_LB_ROWS rows per workgroup.
+// relu mask + LayerNorm backward: d (rows x n) <- f(sum of dpart), one wave per row, BM_LB_ROWS rows per workgroup.
 //   y = xhat g + beta;  dy = d [y > 0];  dxh = dy g;  dz = rstd (dxh - mean(dxh) - xhat mean(dxh xhat))
 // part[wg][0] = sum_rows dy xhat (d scale), [1] = sum_rows dy (d LN bias), [2] = sum_rows dz (d dense bias).  n <= 4096, n % 256 == 0.
 #define BM_LB_ROWS 8
-__global__ __launch_bounds__(256) void bm_ln_bwd_kernel(float *__restrict__ d, const float *__restrict__ z,
+__global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict__ dpart, int nsplit, long long pstride,
+                                                        float *__restrict__ d, const float *__restrict__ z,
                                                         const float *__restrict__ stat, const float *__restrict__ g,
                                                         const float *__restrict__ beta, int rows, int n,
                                                         float *__restrict__ part) {
@@ -476,7 +520,9 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(float *__restrict__ d, c
     for (int q = 0; q < BM_MAXQ; ++q) {
       if (q < nq) {
         const int c = lane * 4 + 256 * q;
-        const f32x4 zv = *reinterpret_cast<const f32x4 *>(zr + c), dv = *reinterpret_cast<const f32x4 *>(dr + c);
+        const f32x4 zv = *reinterpret_cast<const f32x4 *>(zr + c);
+        f32x4 dv = *reinterpret_cast<const f32x4 *>(dpart + (long long)row * n + c);   // d loss / d h: sum of the K-split partials
+        for (int sp = 1; sp < nsplit; ++sp) dv += *reinterpret_cast<const f32x4 *>(dpart + sp * pstride + (long long)row * n + c);
         const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c), bv = *reinterpret_cast<const f32x4 *>(beta + c);
         xh[q] = (zv - mean) * rstd;
         const f32x4 y = xh[q] * gv + bv;
@@ -523,17 +569,40 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(float *__restrict__ d, c
   }
 }
 
-// out_k[c] = sum_p part[(p * nseg + k) * n + c], k < nseg, fixed order over p; thread per (k, c)
-__global__ __launch_bounds__(256) void bm_colreduce_kernel(const float *__restrict__ part, int nparts, int nseg, int n,
-                                                           float *__restrict__ out0, float *__restrict__ out1,
-                                                           float *__restrict__ out2) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= nseg * n) return;
-  const int k = e / n, c = e - k * n;
+// out_k[c] = sum_p part[(p * nseg + k) * n + c], k < nseg.  Workgroup = 64 (k, c) elements x 16 partial groups: group j
+// sums partials j, j + 16, ... (fixed order), the 16 group sums are folded in a fixed tree through LDS.
+__global__ __launch_bounds__(1024) void bm_colreduce_kernel(const float *__restrict__ part, int nparts, int nseg, int n,
+                                                            float *__restrict__ out0, float *__restrict__ out1,
+                                                            float *__restrict__ out2) {
+  __shared__ float s_r[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const bool ok = e < nseg * n;
+  const int ee = ok ? e : 0;
+  const int k = ee / n, c = ee - k * n;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[((long long)p * nseg + k) * n + c];
-  float *o = k == 0 ? out0 : (k == 1 ? out1 : out2);
-  if (o) o[c] = s;
+  for (int p = grp; p < nparts; p += 16) s += part[((long long)p * nseg + k) * n + c];
+  s_r[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    float t[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t[j] = s_r[j][lane];
+    const float r = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                    (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+    float *o = k == 0 ? out0 : (k == 1 ? out1 : out2);
+    if (o) o[c] = r;
+  }
+}
+
+// out[i] = sum of the nsplit K-split partials of a weight-gradient GEMM (i < n, n % 4 == 0, everything 16-B aligned)
+__global__ __launch_bounds__(256) void bm_sum_partials_kernel(const float *__restrict__ part, int nsplit, long long pstride,
+                                                              long long n, float *__restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 v = *reinterpret_cast<const f32x4 *>(part + i);
+  for (int sp = 1; sp < nsplit; ++sp) v += *reinterpret_cast<const f32x4 *>(part + sp * pstride + i);
+  *reinterpret_cast<f32x4 *>(out + i) = v;
 }
 
 // eps-greedy over q rows with stride ldq (first-max argmax; element e draws threefry(key, (e, PQN_STREAM_ACT)))
@@ -569,36 +638,61 @@ __global__ __launch_bounds__(256) void bm_epsgreedy_kernel(const float *__restri
 // ---------------------------------------------------------------------------------------------------------------------
 bool bm_vec_ok(const BmOperand &o) { return (o.ld % 4) == 0 && o.ld >= 4 && (reinterpret_cast<uintptr_t>(o.p) & 15) == 0; }
 
+#define BM_MAX_SPLIT 4
+
+// One GEMM launch.  nsplit K splits write nsplit partial outputs E.split_stride apart (STORE) / nsplit x m-tile partial
+// records (INNORM); the consumer folds them.  Loader modes are picked from the operands' alignment.
 template <int BM, bool TA, bool TB, int EPI>
-int bm_launch3(int M, int N, int K, const BmOperand &A, const BmOperand &B, const BmEpilogue &E, hipStream_t st) {
-  const dim3 grid((N + BM_BN - 1) / BM_BN, (M + BM - 1) / BM);
+int bm_launch(int M, int N, int K, int nsplit, const BmOperand &A, const BmOperand &B, const BmEpilogue &E, hipStream_t st) {
+  const int klen = ((K + nsplit - 1) / nsplit + BM_KS - 1) / BM_KS * BM_KS;
+  const int nz = (K + klen - 1) / klen;
+  const dim3 grid((N + BM_BN - 1) / BM_BN, (M + BM - 1) / BM, nz);
   const int lds = bm_lds_bytes<BM>();
-  // vector (16-B) loads only for untransposed operands whose rows are 16-B aligned
-  const bool va = !TA && bm_vec_ok(A), vb = !TB && bm_vec_ok(B);
-#define BM_GO(VA_, VB_)                                                                                                  \
+  const bool va = bm_vec_ok(A), vb = bm_vec_ok(B);
+  constexpr int A_V = TA ? BM_LM_COLVEC : BM_LM_ROWVEC, A_S = TA ? BM_LM_COLSCL : BM_LM_ROWSCL;
+  constexpr int B_V = TB ? BM_LM_COLVEC : BM_LM_ROWVEC, B_S = TB ? BM_LM_COLSCL : BM_LM_ROWSCL;
+#define BM_GO(LA_, LB_)                                                                                                  \
   do {                                                                                                                   \
-    auto kern = &bm_gemm_kernel<BM, TA, VA_, TB, VB_, EPI>;                                                               \
+    auto kern = &bm_gemm_kernel<BM, LA_, LB_, EPI>;                                                                      \
     static bool attr = false;                                                                                            \
     if (!attr) {                                                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
       attr = true;                                                                                                       \
     }                                                                                                                    \
-    hipLaunchKernelGGL(kern, grid, dim3(BM_THREADS), lds, st, M, N, K, A, B, E);                                         \
+    hipLaunchKernelGGL(kern, grid, dim3(BM_THREADS), lds, st, M, N, K, klen, A, B, E);                                   \
   } while (0)
-  if (TA && TB) BM_GO(false, false);
-  else if (TA) { if (vb) BM_GO(false, true); else BM_GO(false, false); }
-  else if (TB) { if (va) BM_GO(true, false); else BM_GO(false, false); }
-  else { if (va && vb) BM_GO(true, true); else if (va) BM_GO(true, false); else if (vb) BM_GO(false, true); else BM_GO(false, false); }
+  if (va && vb) BM_GO(A_V, B_V);
+  else if (va) BM_GO(A_V, B_S);
+  else if (vb) BM_GO(A_S, B_V);
+  else BM_GO(A_S, B_S);
 #undef BM_GO
   return pqn_check_launch("pqn_bigmlp gemm");
 }
 
-// tile height: 128 rows when that still gives every CU a workgroup, else 64
+// Tile height and K split of a GEMM: 128-row tiles when they still give every second CU a workgroup, and as many K splits
+// (<= max_split, each >= 128 long) as it takes to put ~3 workgroups on every CU -- the kernel hides its global-load
+// latency behind OTHER workgroups' MFMAs.  Run-time switches "bm_tile" (64 / 128) and "bm_split" override (A/B runs).
+struct BmPlan { int bm, nsplit; };
+BmPlan bm_plan(int M, int N, int K, int max_split) {
+  const long long t128 = (long long)((M + 127) / 128) * ((N + BM_BN - 1) / BM_BN);
+  BmPlan p;
+  p.bm = t128 >= 128 ? 128 : 64;
+  if (pqn_opt(PQN_OPT_BM_TILE) == 64 || pqn_opt(PQN_OPT_BM_TILE) == 128) p.bm = pqn_opt(PQN_OPT_BM_TILE);
+  const long long tiles = (long long)((M + p.bm - 1) / p.bm) * ((N + BM_BN - 1) / BM_BN);
+  int s = (int)((768 + tiles - 1) / tiles);
+  if (pqn_opt(PQN_OPT_BM_SPLIT) > 0) s = pqn_opt(PQN_OPT_BM_SPLIT);
+  s = min(s, min(max_split, max(1, K / 128)));
+  p.nsplit = max(1, s);
+  return p;
+}
+
 template <bool TA, bool TB>
-int bm_gemm(int M, int N, int K, const BmOperand &A, const BmOperand &B, const BmEpilogue &E, hipStream_t st) {
-  const long long wg128 = (long long)((M + 127) / 128) * ((N + BM_BN - 1) / BM_BN);
-  if (wg128 >= 256) return bm_launch3<128, TA, TB, BM_EPI_STORE>(M, N, K, A, B, E, st);
-  return bm_launch3<64, TA, TB, BM_EPI_STORE>(M, N, K, A, B, E, st);
+int bm_gemm(int M, int N, int K, const BmOperand &A, const BmOperand &B, BmEpilogue E, int max_split, int *nsplit_out, hipStream_t st) {
+  const BmPlan p = bm_plan(M, N, K, max_split);
+  const int klen = ((K + p.nsplit - 1) / p.nsplit + BM_KS - 1) / BM_KS * BM_KS;
+  if (nsplit_out) *nsplit_out = (K + klen - 1) / klen;
+  if (p.bm == 128) return bm_launch<128, TA, TB, BM_EPI_STORE>(M, N, K, p.nsplit, A, B, E, st);
+  return bm_launch<64, TA, TB, BM_EPI_STORE>(M, N, K, p.nsplit, A, B, E, st);
 }
 
 BmOperand bm_op(const float *p, long long ld, int rows, int cols) {
@@ -606,9 +700,9 @@ BmOperand bm_op(const float *p, long long ld, int rows, int cols) {
   o.p = p; o.ld = ld; o.rows = rows; o.cols = cols;
   return o;
 }
-BmEpilogue bm_store(float *out, long long ldc, const float *bias = nullptr) {
+BmEpilogue bm_store(float *out, long long ldc, const float *bias = nullptr, long long split_stride = 0) {
   BmEpilogue e = {};
-  e.out = out; e.ldc = ldc; e.bias = bias;
+  e.out = out; e.ldc = ldc; e.bias = bias; e.split_stride = split_stride;
   return e;
 }
 
@@ -616,8 +710,9 @@ int align4(int x) { return (x + 3) & ~3; }
 
 // workspace carve-up (floats); rows = forward rows (2 nb with next_obs, else nb), nb = rows that carry gradient
 struct BmWs {
-  long long coef, cspart, xn, xhat, z[PQN_BIGMLP_MAX_LAYERS], h[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, dq, d0, d1,
-      lnpart, inpart, total;
+  long long coef, cspart, xn, xhat, z[PQN_BIGMLP_MAX_LAYERS], h[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, dq, dz,
+      zpart, dpart, wpart, lnpart, inpart, total;
+  long long zstride, dstride, wstride;   // elements between K-split partials
   int ldq, ldx, n_cs, n_ln, n_in;
 };
 BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
@@ -640,10 +735,15 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
   }
   w.q = take((long long)rows * w.ldq);
   w.dq = take((long long)nb * w.ldq);
-  w.d0 = take((long long)nb * L.h);
-  w.d1 = take((long long)nb * L.h);
+  w.dz = take((long long)nb * L.h);
+  w.zstride = (long long)rows * L.h;
+  w.zpart = take(BM_MAX_SPLIT * w.zstride);
+  w.dstride = (long long)nb * L.h;
+  w.dpart = take(BM_MAX_SPLIT * w.dstride);
+  w.wstride = (long long)align4(max(L.d, L.h)) * L.h;
+  w.wpart = take(BM_MAX_SPLIT * w.wstride);
   w.lnpart = take(3ll * w.n_ln * L.h);
-  w.inpart = take(2ll * w.n_in * L.d);
+  w.inpart = take(2ll * BM_MAX_SPLIT * w.n_in * L.d);
   w.total = off;
   return w;
 }
@@ -654,14 +754,15 @@ int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, float
     const int kin = l ? L.h : L.d;
     const BmOperand A = l ? bm_op(ws + w.h[l - 1], L.h, rows, L.h) : bm_op(ws + w.xn, w.ldx, rows, L.d);
     const BmOperand B = bm_op(theta + L.off_w[l], L.h, kin, L.h);
-    const int rc = bm_gemm<false, true>(rows, L.h, kin, A, B, bm_store(ws + w.z[l], L.h, theta + L.off_b[l]), st);
+    int ns = 1;
+    const int rc = bm_gemm<false, true>(rows, L.h, kin, A, B, bm_store(ws + w.zpart, L.h, nullptr, w.zstride), BM_MAX_SPLIT, &ns, st);
     if (rc != PQN_OK) return rc;
-    hipLaunchKernelGGL(bm_ln_relu_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ws + w.z[l], rows, L.h,
-                       theta + L.off_lns[l], theta + L.off_lnb[l], ws + w.h[l], ws + w.stat[l]);
+    hipLaunchKernelGGL(bm_ln_relu_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ws + w.zpart, ns, w.zstride, rows, L.h,
+                       theta + L.off_b[l], theta + L.off_lns[l], theta + L.off_lnb[l], ws + w.z[l], ws + w.h[l], ws + w.stat[l]);
   }
-  const int lo = L.layers;   // output layer: Q = h_last W_out + b_out
+  const int lo = L.layers;   // output layer: Q = h_last W_out + b_out (narrow: no K split)
   return bm_gemm<false, true>(rows, L.a, L.h, bm_op(ws + w.h[lo - 1], L.h, rows, L.h), bm_op(theta + L.off_w[lo], L.a, L.h, L.a),
-                              bm_store(ws + w.q, w.ldq, theta + L.off_b[lo]), st);
+                              bm_store(ws + w.q, w.ldq, theta + L.off_b[lo]), 1, nullptr, st);
 }
 
 }  // namespace
@@ -743,9 +844,10 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
     const bool renorm = L->norm_input == 2;
     hipLaunchKernelGGL(bm_colstats_kernel, dim3((L->d + 255) / 256, w.n_cs), dim3(256), 0, st, obs, (long long)L->d, idx, nb,
                        (long long)next_offset, rows, L->d, reinterpret_cast<double *>(ws + w.cspart));
-    hipLaunchKernelGGL(bm_instat_finish_kernel, dim3((L->d + 255) / 256), dim3(256), 0, st, reinterpret_cast<const double *>(ws + w.cspart), w.n_cs, rows, L->d,
-                       theta + L->off_in_scale, theta + L->off_in_bias, in_mean, in_var, (const int32_t *)in_steps, 1,
-                       renorm ? 1 : 0, renorm ? 1e-3f : 1e-5f, renorm ? 0.999f : 0.99f, ws + w.coef);
+    hipLaunchKernelGGL(bm_instat_finish_kernel, dim3((L->d + 255) / 256), dim3(256), 0, st,
+                       reinterpret_cast<const double *>(ws + w.cspart), w.n_cs, rows, L->d, theta + L->off_in_scale,
+                       theta + L->off_in_bias, in_mean, in_var, (const int32_t *)in_steps, 1, renorm ? 1 : 0,
+                       renorm ? 1e-3f : 1e-5f, renorm ? 0.999f : 0.99f, ws + w.coef);
     if (renorm) hipLaunchKernelGGL(bm_steps_inc_kernel, dim3(1), dim3(1), 0, st, in_steps);
     coef = ws + w.coef;
   } else {   // the dummy input normalisation never receives gradient (pqn_craftax.py:47-49)
@@ -763,37 +865,51 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
   hipLaunchKernelGGL(bm_loss_kernel, dim3(1), dim3(1024), 0, st, ws + w.q, w.ldq, nb, L->a, idx, action, target, reward, done,
                      gamma, next_offset > 0 ? 1 : 0, ws + w.dq, grad + L->off_b[lo], loss_out, qv_out);
   // backward over the first nb rows (the next_obs half carries no gradient: stop_gradient, pqn_craftax.py:301)
-  float *dcur = ws + w.d0, *dnext = ws + w.d1;
+  float *dz = ws + w.dz;
   const BmOperand dQ = bm_op(ws + w.dq, w.ldq, nb, L->a);
-  // d W_out = h_last^T dQ;   d h_last = dQ W_out^T
-  rc = bm_gemm<true, true>(L->h, L->a, nb, bm_op(ws + w.h[lo - 1], L->h, nb, L->h), dQ, bm_store(grad + L->off_w[lo], L->a), st);
+  auto wgrad = [&](int kin, const BmOperand &Hin, const BmOperand &dZ, int n_out, float *gout) -> int {   // d W = Hin^T dZ
+    int ns = 1;
+    const long long cnt = (long long)kin * n_out;
+    const bool direct = n_out < BM_BN || (cnt & 3);     // narrow output layer: one split, straight into the gradient
+    const int r = bm_gemm<true, true>(kin, n_out, nb, Hin, dZ, direct ? bm_store(gout, n_out) : bm_store(ws + w.wpart, n_out, nullptr, w.wstride),
+                                      direct ? 1 : BM_MAX_SPLIT, &ns, st);
+    if (r != PQN_OK || direct) return r;
+    hipLaunchKernelGGL(bm_sum_partials_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, st, ws + w.wpart, ns, w.wstride,
+                       cnt, gout);
+    return PQN_OK;
+  };
+  // d W_out = h_last^T dQ;   d h_last = dQ W_out^T (K = a: one split)
+  rc = wgrad(L->h, bm_op(ws + w.h[lo - 1], L->h, nb, L->h), dQ, L->a, grad + L->off_w[lo]);
   if (rc != PQN_OK) return rc;
-  rc = bm_gemm<false, false>(nb, L->h, L->a, dQ, bm_op(theta + L->off_w[lo], L->a, L->h, L->a), bm_store(dcur, L->h), st);
+  int nsd = 1;
+  rc = bm_gemm<false, false>(nb, L->h, L->a, dQ, bm_op(theta + L->off_w[lo], L->a, L->h, L->a), bm_store(ws + w.dpart, L->h, nullptr, w.dstride),
+                             1, &nsd, st);
   if (rc != PQN_OK) return rc;
   for (int l = lo - 1; l >= 0; --l) {
-    // dcur = d loss / d h_l  ->  relu mask + LayerNorm backward in place: dcur = d loss / d z_l
-    hipLaunchKernelGGL(bm_ln_bwd_kernel, dim3(w.n_ln), dim3(256), 0, st, dcur, ws + w.z[l], ws + w.stat[l],
-                       theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart);
-    hipLaunchKernelGGL(bm_colreduce_kernel, dim3((3 * L->h + 255) / 256), dim3(256), 0, st, ws + w.lnpart, w.n_ln, 3, L->h,
+    // dpart (nsd K-split partials) = d loss / d h_l  ->  relu mask + LayerNorm backward: dz = d loss / d z_l
+    hipLaunchKernelGGL(bm_ln_bwd_kernel, dim3(w.n_ln), dim3(256), 0, st, ws + w.dpart, nsd, w.dstride, dz, ws + w.z[l],
+                       ws + w.stat[l], theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart);
+    hipLaunchKernelGGL(bm_colreduce_kernel, dim3((3 * L->h + 63) / 64), dim3(1024), 0, st, ws + w.lnpart, w.n_ln, 3, L->h,
                        grad + L->off_lns[l], grad + L->off_lnb[l], grad + L->off_b[l]);
     const int kin = l ? L->h : L->d;
-    const BmOperand dZ = bm_op(dcur, L->h, nb, L->h);
+    const BmOperand dZ = bm_op(dz, L->h, nb, L->h);
     const BmOperand Hin = l ? bm_op(ws + w.h[l - 1], L->h, nb, L->h) : bm_op(ws + w.xn, w.ldx, nb, L->d);
-    // d W_l = h_{l-1}^T dZ_l
-    rc = bm_gemm<true, true>(kin, L->h, nb, Hin, dZ, bm_store(grad + L->off_w[l], L->h), st);
+    rc = wgrad(kin, Hin, dZ, L->h, grad + L->off_w[l]);   // d W_l = h_{l-1}^T dZ_l
     if (rc != PQN_OK) return rc;
     const BmOperand W = bm_op(theta + L->off_w[l], L->h, kin, L->h);
     if (l > 0) {   // d h_{l-1} = dZ_l W_l^T
-      rc = bm_gemm<false, false>(nb, kin, L->h, dZ, W, bm_store(dnext, L->h), st);
+      rc = bm_gemm<false, false>(nb, kin, L->h, dZ, W, bm_store(ws + w.dpart, L->h, nullptr, w.dstride), BM_MAX_SPLIT, &nsd, st);
       if (rc != PQN_OK) return rc;
-      float *t = dcur; dcur = dnext; dnext = t;
     } else if (coef) {
       // d (input-normalisation scale, bias): column sums of (dZ_0 W_0^T) xhat and of dZ_0 W_0^T over the nb rows
       BmEpilogue E = {};
       E.out = ws + w.inpart; E.xhat = ws + w.xhat; E.ldx = w.ldx;
-      rc = bm_launch3<64, false, false, BM_EPI_INNORM>(nb, kin, L->h, dZ, W, E, st);
+      const BmPlan p = bm_plan(nb, kin, L->h, BM_MAX_SPLIT);
+      const int klen = ((L->h + p.nsplit - 1) / p.nsplit + BM_KS - 1) / BM_KS * BM_KS;
+      const int nz = (L->h + klen - 1) / klen;
+      rc = bm_launch<64, false, false, BM_EPI_INNORM>(nb, kin, L->h, p.nsplit, dZ, W, E, st);
       if (rc != PQN_OK) return rc;
-      hipLaunchKernelGGL(bm_colreduce_kernel, dim3((2 * L->d + 255) / 256), dim3(256), 0, st, ws + w.inpart, w.n_in, 2, L->d,
+      hipLaunchKernelGGL(bm_colreduce_kernel, dim3((2 * L->d + 63) / 64), dim3(1024), 0, st, ws + w.inpart, nz * w.n_in, 2, L->d,
                          grad + L->off_in_scale, grad + L->off_in_bias, (float *)nullptr);
     }
   }
@@ -817,15 +933,22 @@ extern "C" int pqn_bigmlp_workspace_view(const pqn_bigmlp_layout_t *L, int32_t r
   return PQN_OK;
 }
 
-// C[M][N] = op(A) op(B) (+ bias[N]) with f32-grade bf16x3 products -- the GEMM every Dense layer above runs, exposed for
-// tests against a plain f32 / f64 matmul.  trans_a: A is stored [K][M] (else [M][K]); trans_b: B is stored [K][N] (else [N][K]).
+// C[M][N] = op(A) op(B) (+ bias[N]) with f32-grade bf16x3 products -- the GEMM every Dense layer above runs (one K split),
+// exposed for tests against a plain f32 / f64 matmul.  trans_a: A is stored [K][M] (else [M][K]); trans_b: B is stored
+// [K][N] (else [N][K]).  nsplit > 1: K-split partial outputs, `c` then holds nsplit x [M][ldc] partials split_stride apart.
 extern "C" int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, int64_t lda, int32_t trans_a, const float *b,
-                               int64_t ldb, int32_t trans_b, const float *bias, float *c, int64_t ldc, void *stream) {
-  PQN_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0, "pqn_bigmlp_gemm: bad arguments");
+                               int64_t ldb, int32_t trans_b, const float *bias, float *c, int64_t ldc, int32_t nsplit,
+                               int64_t split_stride, int32_t tile_rows, void *stream) {
+  PQN_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0 && nsplit >= 1 && nsplit <= BM_MAX_SPLIT && (tile_rows == 64 || tile_rows == 128),
+              "pqn_bigmlp_gemm: bad arguments");
+  PQN_REQUIRE(nsplit == 1 || !bias, "pqn_bigmlp_gemm: the bias belongs to the consumer of K-split partials");
   hipStream_t st = (hipStream_t)stream;
   const BmOperand A = trans_a ? bm_op(a, lda, k, m) : bm_op(a, lda, m, k);
   const BmOperand B = trans_b ? bm_op(b, ldb, k, n) : bm_op(b, ldb, n, k);
-  const BmEpilogue E = bm_store(c, ldc, bias);
-  if (trans_a) return trans_b ? bm_gemm<true, true>(m, n, k, A, B, E, st) : bm_gemm<true, false>(m, n, k, A, B, E, st);
-  return trans_b ? bm_gemm<false, true>(m, n, k, A, B, E, st) : bm_gemm<false, false>(m, n, k, A, B, E, st);
+  const BmEpilogue E = bm_store(c, ldc, bias, split_stride);
+#define BM_T(TA_, TB_) (tile_rows == 128 ? bm_launch<128, TA_, TB_, BM_EPI_STORE>(m, n, k, nsplit, A, B, E, st) \
+                                         : bm_launch<64, TA_, TB_, BM_EPI_STORE>(m, n, k, nsplit, A, B, E, st))
+  if (trans_a) return trans_b ? BM_T(true, true) : BM_T(true, false);
+  return trans_b ? BM_T(false, true) : BM_T(false, false);
+#undef BM_T
 }

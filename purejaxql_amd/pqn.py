@@ -656,9 +656,12 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             if rew_scale != 1.0:
                 ro.reward.mul_(rew_scale)      # REW_SCALE*reward (:205); LogWrapper saw the raw reward
 
-            # Q(lambda) TARGETS (pqn_minatar.py:227-260)
-            policy.max_q(obuf[T], ro.last_q)
-            ops.q_lambda(ro.reward, ro.done, ro.qmax, ro.last_q, gamma, lam, quirk=True, target=ro.target)
+            # Q(lambda) TARGETS (pqn_minatar.py:227-260).  The Craftax script traces them with `Q_LAMBDA: False` too
+            # (pqn_craftax.py:231-261) but nothing consumes them there, so XLA removes the bootstrap forward and the scan
+            # as dead code; they are skipped here for the same reason (no random draw, no state involved).
+            if q_lambda_loss:
+                policy.max_q(obuf[T], ro.last_q)
+                ops.q_lambda(ro.reward, ro.done, ro.qmax, ro.last_q, gamma, lam, quirk=True, target=ro.target)
 
             # NETWORKS UPDATE (pqn_minatar.py:263-327): one shared permutation per epoch (:299-315),
             # consumed as a gather index -- the shuffled copies are never materialised

@@ -33,31 +33,38 @@ def _setup(gpu, oracle, d, h, layers, a, norm_input, renorm, seed):
 @pytest.mark.parametrize("m,n,k", [(64, 64, 32), (2048, 1024, 1345), (1345, 1024, 1024), (1024, 1345, 1024), (1024, 17, 1024),
                                    (1000, 1024, 17), (130, 70, 45), (1, 1, 1)])
 @pytest.mark.parametrize("ta,tb", [(0, 1), (1, 1), (0, 0), (1, 0)])
-def test_bigmlp_gemm_vs_float64_matmul(gpu, m, n, k, ta, tb):
-    """pqn_bigmlp_gemm (bf16x3 products, f32 accumulate) in all four operand orientations, with ragged tiles, odd leading
-    dimensions and unaligned bases, against a float64 matmul: error <= 4e-7 * (|A| |B|) elementwise -- f32 grade."""
+@pytest.mark.parametrize("tile,nsplit", [(64, 1), (128, 3)])
+def test_bigmlp_gemm_vs_float64_matmul(gpu, m, n, k, ta, tb, tile, nsplit):
+    """pqn_bigmlp_gemm (bf16x3 products, f32 accumulate) in all four operand orientations, both tile heights, with and
+    without K splits, ragged tiles, odd leading dimensions and unaligned bases (scalar loaders) as well as aligned ones
+    (vector loaders), against a float64 matmul: error <= 4e-7 * (|A| |B|) elementwise -- f32 grade."""
     from purejaxql_amd import _lib
     lib = _lib.load()
     g = torch.Generator(device=gpu)
     g.manual_seed(m * 7 + n * 3 + k + ta * 2 + tb)
     pad = 4 if (m + n + k) % 2 else 3          # even / odd leading dimensions: vector and scalar loaders
     a_shape, b_shape = ((k, m) if ta else (m, k)), ((k, n) if tb else (n, k))
-    a_buf = torch.randn(a_shape[0] * (a_shape[1] + pad) + 1, device=gpu, generator=g)
-    b_buf = torch.randn(b_shape[0] * (b_shape[1] + pad) + 1, device=gpu, generator=g)
+    lda, ldb = (a_shape[1] + 3) // 4 * 4 + (0 if pad == 4 else 3), (b_shape[1] + 3) // 4 * 4 + (0 if pad == 4 else 3)
+    a_buf = torch.randn(a_shape[0] * lda + 1, device=gpu, generator=g)
+    b_buf = torch.randn(b_shape[0] * ldb + 1, device=gpu, generator=g)
     off = 1 if pad == 3 else 0                  # unaligned base pointer in the scalar case
-    a_v = a_buf[off:off + a_shape[0] * (a_shape[1] + pad)].view(a_shape[0], a_shape[1] + pad)[:, :a_shape[1]]
-    b_v = b_buf[off:off + b_shape[0] * (b_shape[1] + pad)].view(b_shape[0], b_shape[1] + pad)[:, :b_shape[1]]
-    bias = torch.randn(n, device=gpu, generator=g)
-    c = torch.full((m, n + 2), 7.0, device=gpu)
-    _lib.check(lib.pqn_bigmlp_gemm(m, n, k, a_v.data_ptr(), a_shape[1] + pad, ta, b_v.data_ptr(), b_shape[1] + pad, tb,
-                                   bias.data_ptr(), c.data_ptr(), n + 2, _lib.stream_ptr()), "pqn_bigmlp_gemm")
+    a_v = a_buf[off:off + a_shape[0] * lda].view(a_shape[0], lda)[:, :a_shape[1]]
+    b_v = b_buf[off:off + b_shape[0] * ldb].view(b_shape[0], ldb)[:, :b_shape[1]]
+    bias = torch.randn(n, device=gpu, generator=g) if nsplit == 1 else None
+    c = torch.full((nsplit, m, n + 2), 7.0, device=gpu)
+    _lib.check(lib.pqn_bigmlp_gemm(m, n, k, a_v.data_ptr(), lda, ta, b_v.data_ptr(), ldb, tb,
+                                   bias.data_ptr() if bias is not None else None, c.data_ptr(), n + 2, nsplit, m * (n + 2), tile,
+                                   _lib.stream_ptr()), "pqn_bigmlp_gemm")
     a64 = (a_v.T if ta else a_v).double()
     b64 = (b_v if tb else b_v.T).double()
-    ref = a64 @ b64 + bias.double()
-    bound = 4e-7 * (a64.abs() @ b64.abs() + bias.abs().double()) + 1e-30
-    err = (c[:, :n].double() - ref).abs()
+    ref = a64 @ b64 + (bias.double() if bias is not None else 0.0)
+    bound = 4e-7 * (a64.abs() @ b64.abs() + (bias.abs().double() if bias is not None else 0.0)) + 1e-30
+    klen = -(-(-(-k // nsplit)) // 32) * 32      # ceil(ceil(k / nsplit) / 32) * 32: the split the library takes
+    used = -(-k // klen)
+    err = (c[:used, :, :n].double().sum(0) - ref).abs()
     assert bool((err <= bound).all()), float((err / bound).max())
-    assert bool((c[:, n:] == 7.0).all())        # nothing written beyond the n valid columns
+    assert bool((c[:, :, n:] == 7.0).all())      # nothing written beyond the n valid columns
+    assert bool((c[used:] == 7.0).all())         # nor into partials the split did not need
 
 
 @pytest.mark.parametrize("d,h,layers,a,n,norm_input,renorm", [

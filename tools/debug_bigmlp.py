@@ -42,26 +42,13 @@ for k, s in shapes.items():
     print(f"{k:24s} max|ref| {np.abs(r).max():.3e} max err {e.max():.3e} rel-L2 {np.linalg.norm(x - r) / max(np.linalg.norm(r), 1e-30):.2e} bad {int(bad.sum())}{msg}")
     off += n
 
-# relu-mask agreement between the kernel's forward (h buffers in the workspace) and the oracle's forward
-def take_offsets(rows, nb):
-    off = [0]
-    def take(n):
-        o = off[0]; off[0] += (n + 3) // 4 * 4; return o
-    ldq, ldx = (a + 3) // 4 * 4, (d + 3) // 4 * 4
-    n_cs, n_ln, n_in = (rows + 63) // 64, (nb + 7) // 8, (nb + 63) // 64
-    w = {"coef": take(4 * d), "cspart": take(2 * n_cs * d), "xn": take(rows * ldx), "xhat": take(nb * ldx), "z": [], "h": [], "stat": []}
-    for l in range(layers):
-        w["z"].append(take(rows * h)); w["h"].append(take(rows * h)); w["stat"].append(take(2 * rows))
-    return w, ldx
-w, ldx = take_offsets(2 * nb, nb)
-ws = list(tr._ws.values())[0].cpu().numpy()
+# relu-mask agreement between the kernel's forward (activations in the workspace) and the oracle's forward
 xx = np.concatenate((obs_all[idx], obs_all[idx + n_env]))
 q_all, cache = O.net_forward("mlp", p, xx, layers=layers, want_cache=True, norm_type="layer_norm", norm_input=True, train=True,
                              stats=stats, new_stats={}, renorm=True)
-xn_k = ws[w["xn"]:w["xn"] + 2 * nb * ldx].reshape(2 * nb, ldx)[:, :d]
-print("xn max|diff|", np.abs(xn_k - cache["hs"][0]).max())
+print("xn max|diff|", np.abs(tr.intermediate(2 * nb, nb, "xn").cpu().numpy()[:, :d] - cache["hs"][0]).max())
 for l in range(layers):
-    hk = ws[w["h"][l]:w["h"][l] + 2 * nb * h].reshape(2 * nb, h)
+    hk = tr.intermediate(2 * nb, nb, "h", l).cpu().numpy()
     ho = cache["hs"][l + 1]
     mism = (hk > 0) != (ho > 0)
     print(f"layer {l}: max|h diff| {np.abs(hk - ho).max():.3e}  relu-mask mismatches {int(mism.sum())} (gradient rows: {int(mism[:nb].sum())}) "
