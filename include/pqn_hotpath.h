@@ -441,38 +441,52 @@ int pqn_bigmlp_layout(int32_t d, int32_t h, int32_t layers, int32_t a, int32_t n
 /* workspace floats for `rows` forward rows of which the first `nb` carry gradient (pqn_bigmlp_forward: rows = nb = n;
  * pqn_bigmlp_grad: rows = 2 nb with the 1-step loss, nb with the Q(lambda) loss) */
 int64_t pqn_bigmlp_workspace_floats(const pqn_bigmlp_layout_t *layout /* host */, int32_t rows, int32_t nb);
+/* The GEMM operands of the Dense kernels: every kernel split exactly into three bf16 planes (x = hi + mid + lo), once in
+ * (in, out) order (input gradient) and once transposed (forward).  `wplanes`: pqn_bigmlp_weight_plane_floats floats,
+ * caller-owned; call pqn_bigmlp_refresh_planes whenever theta has changed (after every optimizer step). */
+int64_t pqn_bigmlp_weight_plane_floats(const pqn_bigmlp_layout_t *layout /* host */);
+int pqn_bigmlp_refresh_planes(const pqn_bigmlp_layout_t *layout /* host */, const float *theta, float *wplanes, void *stream);
 /* network.apply(params, obs, train=False) (pqn_craftax.py:184-197,226-237,403-413) + the eps-greedy draw: obs [n][d]
  * contiguous; in_mean / in_var [d] = the running moments of the input normalisation (batch_stats; NULL if norm_input = 0).
  * Outputs (each nullable): q [n][a], action [n] (element e draws threefry(key, (e, 0)) as pqn_eps_greedy), qmax [n].
  * eps_dev / key_dev (nullable): take eps / key from device memory instead (hipGraph-capturable callers). */
 int pqn_bigmlp_forward(const pqn_bigmlp_layout_t *layout /* host */, int32_t n, const float *obs, const float *theta,
-                       float *in_mean, float *in_var, float *workspace, float *q, int32_t *action, float *qmax, float eps,
-                       uint64_t key, const float *eps_dev, const uint64_t *key_dev, void *stream);
+                       const float *wplanes, float *in_mean, float *in_var, float *workspace, float *q, int32_t *action,
+                       float *qmax, float eps, uint64_t key, const float *eps_dev, const uint64_t *key_dev, void *stream);
 /* value_and_grad(_loss_fn) of pqn_craftax.py:277-312, train = True with mutable batch_stats.  Minibatch row r reads
  * transition idx[r] of the flat record: obs row idx[r], action / target / reward / done [idx[r]].
  *   next_offset > 0: the `Q_LAMBDA: False` branch -- next_obs of transition j is obs row j + next_offset; obs and
  *       next_obs go through the network as ONE batch of 2 nb rows (batch statistics over both halves), q_next carries no
  *       gradient, target = reward + (1 - done) gamma max_a q_next (:296-306).  `target` unused.
  *   next_offset = 0: the Q(lambda) branch, `target` given (:280-286); reward / done unused.
- * in_mean / in_var / in_steps: running statistics of the input normalisation, updated in place (BatchRenorm:
- * utils/batch_renorm.py:95-116, in_steps = its train-call counter).  Writes the flat gradient, loss and mean(q_a). */
+ * in_mean / in_var [d], in_steps int32[2]: running statistics of the input normalisation, updated in place (BatchRenorm:
+ * utils/batch_renorm.py:95-116; in_steps[0] = its train-call counter, in_steps[1] = scratch, zero between calls).
+ * Writes the flat gradient, loss and mean(q_a). */
 int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *layout /* host */, int32_t nb, const int64_t *idx, const float *obs,
                     int64_t next_offset, const int32_t *action, const float *target, const float *reward,
-                    const uint8_t *done, float gamma, const float *theta, float *in_mean, float *in_var,
-                    int32_t *in_steps, float *grad, float *workspace, float *loss_out, float *qv_out, void *stream);
-
-/* Where a forward intermediate of the last pqn_bigmlp_forward / pqn_bigmlp_grad call lives inside `workspace` (float
- * offset + leading dimension): what 0 = normalised input [rows][ld], 1 = z_layer, 2 = h_layer = relu(LN(z_layer)),
- * 3 = (mean, rstd) of z_layer, 4 = q.  For tests (e.g. to compare relu decisions with a reference forward). */
+                    const uint8_t *done, float gamma, const float *theta, const float *wplanes, float *in_mean,
+                    float *in_var, int32_t *in_steps, float *grad, float *workspace, float *loss_out, float *qv_out,
+                    void *stream);
+/* Where a forward intermediate of the last pqn_bigmlp_forward / pqn_bigmlp_grad call lives inside `workspace`, for
+ * tests (e.g. to compare relu decisions with a reference forward).  f32 tensors -- what 1 = z_layer [rows][h], 3 = (mean,
+ * rstd) of z_layer, 4 = q: *offset in floats.  bf16 plane triples -- what 0 = the normalised input, 2 = h_layer =
+ * relu(LN(z_layer)): *offset in bf16 elements from the start of the workspace, planes rows * ld elements apart,
+ * value = hi + mid + lo. */
 int pqn_bigmlp_workspace_view(const pqn_bigmlp_layout_t *layout /* host */, int32_t rows, int32_t nb, int32_t what,
                               int32_t layer, int64_t *offset /* host */, int64_t *ld /* host */);
 /* The GEMM behind every Dense layer of the wide MLP, exposed for tests: C[m][n] = op(A) op(B) (+ bias[n]) with f32-grade
- * bf16x3 products.  trans_a: A stored [k][m] (else [m][k]); trans_b: B stored [k][n] (else [n][k]); row-major with
- * leading dimensions lda / ldb / ldc.  nsplit (1..4) K splits leave nsplit partial outputs split_stride floats apart (the
- * caller sums them; no bias then); tile_rows = 64 | 128. */
+ * bf16x3 products, from f32 matrices (split into planes first, transposed where K is not the contiguous dimension).
+ * trans_a: A stored [k][m] (else [m][k]); trans_b: B stored [k][n] (else [n][k]); row-major with leading dimensions
+ * lda / ldb / ldc.  nsplit (1..4) K splits leave nsplit partial outputs split_stride floats apart (the caller sums them; no
+ * bias then); tile_rows = 64 | 128; scratch: pqn_bigmlp_gemm_scratch_floats(m, n, k) floats. */
+/* Profiling aid (PQN_BM_STAMPS=1): cycle stamps of workgroup 0 / wave 0 of the last pqn_bigmlp_gemm launch -- [0] start,
+ * [1] first loads issued, [2] K loop done, [8 + 8 s ..]: K step s at LDS stores / stores issued / barrier passed / next
+ * loads issued / fragments in registers / MFMAs issued. */
+int pqn_debug_bm_stamps(unsigned long long *out /* host, 128 entries */);
+int64_t pqn_bigmlp_gemm_scratch_floats(int32_t m, int32_t n, int32_t k);
 int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, int64_t lda, int32_t trans_a, const float *b,
                     int64_t ldb, int32_t trans_b, const float *bias, float *c, int64_t ldc, int32_t nsplit,
-                    int64_t split_stride, int32_t tile_rows, void *stream);
+                    int64_t split_stride, int32_t tile_rows, float *scratch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -90,14 +90,18 @@ SIGNATURES = {
     "pqn_mlp_refresh_transposed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_bigmlp_layout": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pqn_bigmlp_workspace_floats": (c_int64, [c_void_p, c_int32, c_int32]),
+    "pqn_bigmlp_weight_plane_floats": (c_int64, [c_void_p]),
+    "pqn_bigmlp_refresh_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_bigmlp_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),
-    "pqn_bigmlp_workspace_view": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
-    "pqn_bigmlp_gemm": (c_int, [c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p,
-                                c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p]),
+                                   c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),
     "pqn_bigmlp_grad": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_void_p]),
+                                c_void_p, c_void_p]),
+    "pqn_bigmlp_workspace_view": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "pqn_debug_bm_stamps": (c_int, [c_void_p]),
+    "pqn_bigmlp_gemm_scratch_floats": (c_int64, [c_int32, c_int32, c_int32]),
+    "pqn_bigmlp_gemm": (c_int, [c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p,
+                                c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -7,22 +7,29 @@
 // activations live in LDS: here every Dense layer -- forward, input gradient, weight gradient -- is ONE tiled MFMA GEMM
 // kernel, and everything elementwise sits in a handful of row / column kernels around it.
 //
-//   bm_gemm_kernel   C[M,N] = op(A)[M,K] x op(B)[K,N] on the bf16 matrix core with f32-grade "bf16x3" products (see
-//                    pqn_qnet.hip: x = hi + mid + lo exactly, 6 x v_mfma_f32_16x16x32_bf16 per 32-wide K step, f32
-//                    accumulate).  Operands come straight from f32 global memory: a loader thread fetches 8 K-values of
-//                    one tile row, splits them into the three bf16 planes and writes one 16-B MFMA fragment slot per
-//                    plane into LDS (double-buffered, one barrier per K step; the next step's global loads are in flight
-//                    during the MFMAs).  Either operand may be read transposed (source rows = K), so forward (H W),
-//                    input gradient (dZ W^T) and weight gradient (H^T dZ) are the same kernel.  Tile BM x 64
-//                    (BM = 64 | 128), 4 waves as 2 x 2; epilogue = bias + store, or the column sums that are the
-//                    input-normalisation parameter gradients.
-//   bm_innorm_apply  gathers the minibatch rows out of the rollout record and applies the input normalisation
-//   bm_colstats*     batch moments of the gathered input rows + BatchRenorm / BatchNorm bookkeeping
-//                    (utils/batch_renorm.py:95-116) -> the coefficient vectors bm_innorm_apply uses
-//   bm_ln_relu       LayerNorm (flax: var = E[x^2] - E[x]^2 clamped, eps 1e-6) + relu of a pre-activation matrix
-//   bm_loss          TD loss of both branches of _loss_fn (pqn_craftax.py:277-312), dQ, d b_out, metrics
-//   bm_ln_bwd        relu mask + LayerNorm backward in place, column partial sums for d scale / d bias / d dense-bias
-//   bm_colreduce     fixed-order fold of per-workgroup column partials
+// Operand format ("planes").  The GEMMs evaluate f32 products on the bf16 matrix core as bf16x3 (pqn_qnet.hip: x = hi +
+// mid + lo exactly, 6 x v_mfma_f32_16x16x32_bf16 per 32-wide K step, f32 accumulate).  Splitting inside the GEMM would
+// repeat the ~5 VALU ops per element once per output tile that touches the element (16x for these shapes) and, measured,
+// cost as much issue time as the MFMAs themselves; so every tensor that feeds a GEMM is split ONCE, by the kernel that
+// produces it, into three bf16 planes stored K-contiguously: planes[p][row][k], k padded with zeros to a multiple of 32.
+// A GEMM operand is then "row r, K-values k .. k + 7 = 16 bytes per plane", and the GEMM's loaders are plain 16-B copies
+// global -> LDS with no arithmetic and no bounds masks (rows are clamped: a clamped row only feeds outputs that are never
+// stored).  Tensors needed with the other dimension as K (weights for the forward pass, activations and output
+// gradients for the weight gradients) get a transposed plane copy from an LDS-tiled 2-byte transpose kernel.
+//
+//   bm_gemm_kernel          C[M,N] (+)= A[M,K] B[N,K]^T from planes; tile BM x 64 (BM = 64 | 128), 4 waves as 2 x 2, LDS
+//                           double-buffered, one barrier per K step, the next step's global loads in flight during the
+//                           MFMAs; split-K over blockIdx.z (partial outputs, folded by the consumer) so that ~3
+//                           workgroups sit on every CU and hide each other's load latency; epilogue = (bias +) store, or
+//                           the column sums that are the input-normalisation parameter gradients
+//   bm_split_kernel         f32 matrix -> planes (weights; test entry);   bm_transpose_kernel  planes -> transposed planes
+//   bm_colstats* / bm_innorm_apply   batch moments of the gathered input rows, BatchRenorm / BatchNorm bookkeeping
+//                           (utils/batch_renorm.py:95-116), normalised input as planes (+ xhat for the parameter gradients)
+//   bm_ln_relu              z = sum of K-split partials + bias; LayerNorm (flax: var = E[x^2] - E[x]^2 clamped, eps 1e-6) +
+//                           relu -> activation planes; z and (mean, rstd) kept for the backward pass
+//   bm_loss                 TD loss of both branches of _loss_fn (pqn_craftax.py:277-312), dQ planes, d b_out, metrics
+//   bm_ln_bwd               relu mask + LayerNorm backward -> dz planes, column partial sums for d scale / d bias / d dense-bias
+//   bm_colreduce / bm_sum_partials   fixed-order folds of per-workgroup column partials / K-split weight-gradient partials
 // Everything is deterministic (fixed summation orders, no atomics).
 #include <stdlib.h>
 
@@ -34,11 +41,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short bf16_t;   // raw bf16 bits
 
 #define BM_THREADS 256
-#define BM_BN 64
 #define BM_KS 32
 #define BM_LN_EPS 1e-6f
+#define BM_MAX_SPLIT 4
+
+PQN_HD int bm_pad32(int x) { return (x + 31) & ~31; }
 
 // exact 3-way bf16 split of two f32 values (same arithmetic as x3_split2 in pqn_qnet.hip)
 PQN_D void bm_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
@@ -51,23 +61,41 @@ PQN_D void bm_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) 
   const f32x2 r2 = r1 - mf;
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
+// eight consecutive K-values -> one 16-B slot per plane
+PQN_D void bm_split8(const float (&v)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
+  unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bm_split2(v[2 * q], v[2 * q + 1], hh[q], mm[q], ll[q]);
+  h = u32x4{hh[0], hh[1], hh[2], hh[3]};
+  m = u32x4{mm[0], mm[1], mm[2], mm[3]};
+  l = u32x4{ll[0], ll[1], ll[2], ll[3]};
+}
 // tied-accumulator MFMA as volatile inline asm (see x3_mfma_tied in pqn_qnet.hip for why not the builtin)
 PQN_D f32x4 bm_mfma(const u32x4 &a, const u32x4 &b, f32x4 c) {
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
   return c;
 }
-PQN_D void bm_drain(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b)); }
+PQN_D void bm_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a)); }
+
+// planes of a logical matrix X[rows][k]: plane p at p + pl * pstride, row-major with leading dimension ld (bf16 elements,
+// ld % 32 == 0, columns [k, ld) zero), 16-B aligned
+struct BmPlanes {
+  const bf16_t *p;
+  long long ld, pstride;
+  int rows;
+};
+struct BmPlanesOut {
+  bf16_t *p;
+  long long ld, pstride;
+};
+PQN_D void bm_put(const BmPlanesOut &o, long long row, int k, const u32x4 &h, const u32x4 &m, const u32x4 &l) {
+  bf16_t *q = o.p + row * o.ld + k;
+  *reinterpret_cast<u32x4 *>(q) = h;
+  *reinterpret_cast<u32x4 *>(q + o.pstride) = m;
+  *reinterpret_cast<u32x4 *>(q + 2 * o.pstride) = l;
+}
 
 enum { BM_EPI_STORE = 0, BM_EPI_INNORM = 1 };
-
-// One GEMM operand: a row-major f32 source matrix S[rows][cols] with leading dimension ld.
-//   not TRANS: tile row t <-> S row, K index <-> S column;   TRANS: tile row t <-> S column, K index <-> S row.
-struct BmOperand {
-  const float *p;
-  long long ld;
-  int rows, cols;            // valid extent of S
-};
-
 struct BmEpilogue {
   float *out;                // BM_EPI_STORE: C, row-major, leading dimension ldc;  BM_EPI_INNORM: partials [K split][m tile][2][N]
   long long ldc;
@@ -76,173 +104,157 @@ struct BmEpilogue {
   // BM_EPI_INNORM (input-normalisation parameter gradients): d scale_c = sum_r C[r][c] xhat[r][c], d bias_c = sum_r C[r][c]
   const float *xhat;         // [M][ldx]: (x - m_c) k_c of the gradient rows
   long long ldx;
+  unsigned long long *stamps;   // profiling (pqn_bigmlp_gemm only): cycle stamps of workgroup 0 / wave 0, 8 per K step
 };
+#define BM_STAMP(i) do { if (E.stamps && blockIdx.x + blockIdx.y + blockIdx.z == 0 && tid == 0 && (i) < 120) E.stamps[i] = __builtin_readcyclecounter(); } while (0)
 
-// split a pack into three planes and write the 16-B fragment slots: slot (block = t >> 4, lane = kb * 16 + (t & 15))
-PQN_D void bm_store_pack(u32x4 *planes, int nblk, int t_local, int kb, const float (&v)[8]) {
-  unsigned h[4], m[4], l[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) bm_split2(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
-  const int slot = (t_local >> 4) * 64 + kb * 16 + (t_local & 15);
-  planes[slot] = u32x4{h[0], h[1], h[2], h[3]};
-  planes[nblk * 64 + slot] = u32x4{m[0], m[1], m[2], m[3]};
-  planes[2 * nblk * 64 + slot] = u32x4{l[0], l[1], l[2], l[3]};
-}
+template <int BM, int BN>
+constexpr int bm_lds_bytes() { return 2 * 3 * (BM / 16 + BN / 16) * 64 * 16; }
 
-// Operand loaders.  A "pack" = the 8 K-values k .. k + 7 of one tile row = one lane's share of an MFMA fragment.  Values
-// outside the matrix read as zero; addresses are clamped into the matrix so that every load stays unconditional
-// (compiler finding 1) and validity is applied to the values.
-//   BM_LM_ROWVEC  untransposed source, rows 16-B aligned: two aligned quads per pack
-//   BM_LM_ROWSCL  untransposed source, any alignment: eight dword loads per pack
-//   BM_LM_COLVEC  transposed source (K runs down the source rows), rows 16-B aligned: a unit = 8 K-rows x 4 adjacent tile
-//                 rows = eight quad loads that yield FOUR packs; a BT-row tile has BT units, served by BT threads
-//   BM_LM_COLSCL  transposed source, any alignment: eight dword loads per pack (adjacent lanes = adjacent tile rows)
-enum { BM_LM_ROWVEC = 0, BM_LM_ROWSCL = 1, BM_LM_COLVEC = 2, BM_LM_COLSCL = 3 };
-
-template <int LM, int BT, int TBASE>
-struct BmLoader {
-  static constexpr bool COL = LM >= BM_LM_COLVEC;
-  static constexpr int NP = LM == BM_LM_COLVEC ? 4 : BT * 4 / BM_THREADS;   // packs per thread and K step
-  float r[NP][8];
-  int t[NP], kb[NP];
-  bool active;
-  PQN_D void init(int tid) {
-    if (LM == BM_LM_COLVEC) {
-      const int u = tid - TBASE;            // TBASE and BT are multiples of 64: whole waves are active or not
-      active = u >= 0 && u < BT;
-      const int uu = active ? u : 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { t[i] = 4 * (uu % (BT / 4)) + i; kb[i] = uu / (BT / 4); }
-    } else {
-      active = true;
-#pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const int p = tid + BM_THREADS * q;
-        t[q] = COL ? p % BT : p >> 2;
-        kb[q] = COL ? p / BT : p & 3;
-      }
-    }
-  }
-  PQN_D void load(const BmOperand &o, int t0, int k0) {
-    if (LM == BM_LM_COLVEC) {
-      if (!active) return;
-      const int k = k0 + 8 * kb[0], c = t0 + t[0];
-      const int cc = min(c, (int)o.ld - 4);          // quads are aligned; a clamped quad lies wholly beyond the valid columns
-      f32x4 u[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const f32x4 *>(o.p + (long long)min(k + j, o.rows - 1) * o.ld + cc);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bool kok = k + j < o.rows;
-        r[0][j] = (kok && c < o.cols) ? u[j].x : 0.0f;
-        r[1][j] = (kok && c + 1 < o.cols) ? u[j].y : 0.0f;
-        r[2][j] = (kok && c + 2 < o.cols) ? u[j].z : 0.0f;
-        r[3][j] = (kok && c + 3 < o.cols) ? u[j].w : 0.0f;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const int tt = t0 + t[q], k = k0 + 8 * kb[q];
-        float (&v)[8] = r[q];
-        if (!COL) {
-          const float *row = o.p + (long long)min(tt, o.rows - 1) * o.ld;
-          if (LM == BM_LM_ROWVEC) {   // a clamped quad lies wholly beyond the valid columns (k % 8 == 0, ld % 4 == 0)
-            const int lim4 = (int)o.ld - 4;
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(row + min(k, lim4)), b = *reinterpret_cast<const f32x4 *>(row + min(k + 4, lim4));
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = row[min(k + j, o.cols - 1)];
-          }
-          const bool tok = tt < o.rows;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (tok && k + j < o.cols) ? v[j] : 0.0f;
-        } else {
-          const int c = min(tt, o.cols - 1);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = o.p[(long long)min(k + j, o.rows - 1) * o.ld + c];
-          const bool tok = tt < o.cols;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (tok && k + j < o.rows) ? v[j] : 0.0f;
-        }
-      }
-    }
-  }
-  PQN_D void store(u32x4 *planes) const {
-    if (LM == BM_LM_COLVEC && !active) return;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) bm_store_pack(planes, BT / 16, t[q], kb[q], r[q]);
-  }
-};
-
-template <int BM>
-constexpr int bm_lds_bytes() { return 2 * 3 * (BM / 16 + BM_BN / 16) * 64 * 16; }
-
-template <int BM, int LMA, int LMB, int EPI>
-__global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K, int klen, BmOperand A, BmOperand B, BmEpilogue E) {
-  constexpr int NBA = BM / 16, NBB = BM_BN / 16;
-  constexpr int MI = BM / 32;                                           // 16-row blocks per wave (2 x 2 waves)
+// C[m][n] = sum_k A[m][k] B[n][k]; K padded (the planes hold zeros there), klen % 32 == 0.
+// Workgroup tile BM x BN (128 x 64 | 64 x 64; 128 x 128 builds too and measured slower at one workgroup per CU), four
+// waves as 2 x 2, wave tile (BM/2) x (BN/2) = MI x NI MFMA tiles; two (three) workgroups per CU.
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int Kp, int klen, BmPlanes A, BmPlanes B, BmEpilogue E) {
+  constexpr int NBA = BM / 16, NBB = BN / 16;
+  constexpr int PA = BM * 4 / BM_THREADS, PB = BN * 4 / BM_THREADS;      // 16-B slots per thread, plane and K step
+  constexpr int MI = BM / 32, NI = BN / 32;                             // 16 x 16 MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) char bm_smem[];
   u32x4 *sA = reinterpret_cast<u32x4 *>(bm_smem);                         // [2][3][NBA][64]
   u32x4 *sB = sA + 2 * 3 * NBA * 64;                                      // [2][3][NBB][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BM_BN;
-  // split-K: workgroup z owns K indices [z klen, (z + 1) klen) (klen % 32 == 0) and writes its own partial output
-  const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
-  BmLoader<LMA, BM, 0> la;                         // transposed-vector units of A: threads 0 .. BM - 1
-  BmLoader<LMB, BM_BN, BM_THREADS - BM_BN> lb;     // ... of B: the last wave
-  la.init(tid);
-  lb.init(tid);
-  auto gload = [&](int k0) { la.load(A, m0, k0); lb.load(B, n0, k0); };
-  auto lstore = [&](int buf) { la.store(sA + buf * 3 * NBA * 64); lb.store(sB + buf * 3 * NBB * 64); };
-  f32x4 accb[MI][2], accs[MI][2];
+  // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB L2: with
+  // the plain (x, y, z) order the workgroups an XCD runs at a time touch many different A panels a few times each and
+  // every panel is fetched by every XCD.  Here XCD k owns a contiguous eighth of the (split, m tile, n tile) sequence, n
+  // fastest: its concurrent workgroups cover a few m tiles x all n tiles of one K split -- a panel set that fits its L2
+  // (measured L2 hit rate of the kernel: 89 %).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned tx = gridDim.x, ty = gridDim.y, total = tx * ty * gridDim.z;
+    if ((total & 7u) == 0u) {
+      const unsigned lin = blockIdx.x + tx * (blockIdx.y + ty * blockIdx.z);
+      const unsigned q = (lin & 7u) * (total >> 3) + (lin >> 3);
+      bz = q / (tx * ty);
+      const unsigned r = q - bz * (tx * ty);
+      by = r / tx;
+      bx = r - by * tx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * klen, kend = min(Kp, kbeg + klen);
+  // Staging through registers.  Global side: thread p fetches slot (tile row t = p >> 2, kb = p & 3) = K-values 8 kb ..
+  // + 7 of row t with one 16-B load per plane -- four adjacent lanes read 64 contiguous bytes of a row.  (The
+  // fragment-shaped assignment, lane = row + 16 kq, costs 4x the issue time in the vector-memory path: measured 2,400-3,400
+  // against 500-900 cycles for the nine loads of a step; the LDS-DMA form global_load_lds_dwordx4 needs exactly that
+  // assignment and was no faster.)  LDS side: slot (t, kb) lives at block (t >> 4) + 16 B x (16 kb + ((t & 15) ^ 2 kb)).
+  // The XOR makes both accesses conflict-free on this chip (MI355X_MICROARCH.md, LDS lane groups): a ds_write_b128 is
+  // served in groups of 8 adjacent lanes = 2 rows x 4 kb against 32 banks, a fragment's ds_read_b128 in the four
+  // non-contiguous 16-lane groups against 64 banks.  Rows beyond the matrix are clamped: they only feed outputs that are
+  // never stored.
+  const bf16_t *ga[PA], *gb[PB];
+  int sa[PA], sb[PB];
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int p = tid + BM_THREADS * q, t = p >> 2, kb = p & 3;
+    ga[q] = A.p + (long long)min(m0 + t, A.rows - 1) * A.ld + 8 * kb;
+    sa[q] = (t >> 4) * 64 + kb * 16 + ((t & 15) ^ (2 * kb));
+  }
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int p = tid + BM_THREADS * q, t = p >> 2, kb = p & 3;
+    gb[q] = B.p + (long long)min(n0 + t, B.rows - 1) * B.ld + 8 * kb;
+    sb[q] = (t >> 4) * 64 + kb * 16 + ((t & 15) ^ (2 * kb));
+  }
+  u32x4 ra[PA][3], rb[PB][3];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) ra[q][pl] = *reinterpret_cast<const u32x4 *>(ga[q] + pl * A.pstride + k0);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) rb[q][pl] = *reinterpret_cast<const u32x4 *>(gb[q] + pl * B.pstride + k0);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) sA[(buf * 3 + pl) * NBA * 64 + sa[q]] = ra[q][pl];
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) sB[(buf * 3 + pl) * NBB * 64 + sb[q]] = rb[q][pl];
+  };
+  // ONE accumulator per tile: the six products of a step meet in f32 in the order (l,h) (m,h) (h,l) (h,m) (m,m) (h,h)
+  f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) { accb[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; accs[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const int nk = (kend - kbeg + BM_KS - 1) / BM_KS;
-  gload(kbeg);
-#pragma unroll 1
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    lstore(buf);
-    __syncthreads();
-    if (ks + 1 < nk) gload(kbeg + (ks + 1) * BM_KS);   // in flight during the MFMAs below
-    const u32x4 *pa = sA + buf * 3 * NBA * 64 + (wm * MI) * 64 + lane;
-    const u32x4 *pb = sB + buf * 3 * NBB * 64 + (wn * 2) * 64 + lane;
-    u32x4 a[MI][3], b[2][3];
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // K loop, software-pipelined inside the wave.  At the top of iteration ks the MFMA fragments of step ks are (arriving)
+  // in registers, the global data of step ks + 1 is (arriving) in ra / rb; the iteration stores that data to the other LDS
+  // buffer, issues the global loads of step ks + 2, issues the MFMAs of step ks, passes the one barrier of the step and
+  // issues the fragment reads of step ks + 1.  So a global load has two MFMA phases to land and a fragment read has the
+  // next iteration's stores and loads.  Overwriting a / b right behind the MFMAs is safe: an LDS read takes longer to
+  // return than the last MFMA takes to read its operands (tools/ubench/mfma_war.hip).
+  const int nk = (kend - kbeg) / BM_KS;
+  u32x4 a[MI][3], b[NI][3];
+  auto fragload = [&](int buf) {
+    const int fl = (lane & 48) + ((lane & 15) ^ (2 * (lane >> 4)));   // fragment lane (row i, kq) -> its swizzled slot
+    const u32x4 *pa = sA + buf * 3 * NBA * 64 + (wm * MI) * 64 + fl;
+    const u32x4 *pb = sB + buf * 3 * NBB * 64 + (wn * NI) * 64 + fl;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) a[mi][pl] = pa[(pl * NBA + mi) * 64];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) b[ni][pl] = pb[(pl * NBB + ni) * 64];
+      for (int ni = 0; ni < NI; ++ni) b[ni][pl] = pb[(pl * NBB + ni) * 64];
     }
-    // products (l,h) (m,h) (h,l) (h,m) (m,m) (h,h): the three small terms meet in accs, the three leading ones in accb
-#define BM_PROD(PA_, PB_, ACC)                                                     \
+  };
+  BM_STAMP(0);
+  gload(kbeg);
+  BM_STAMP(1);
+  lstore(0);
+  __syncthreads();
+  if (nk > 1) gload(kbeg + BM_KS);
+  fragload(0);
+#pragma unroll 1
+  for (int ks = 0; ks < nk; ++ks) {
+    BM_STAMP(8 + 8 * ks);
+    if (ks + 1 < nk) lstore((ks + 1) & 1);
+    BM_STAMP(9 + 8 * ks);
+    if (ks + 2 < nk) gload(kbeg + (ks + 2) * BM_KS);
+    BM_STAMP(10 + 8 * ks);
+#define BM_PROD(PA_, PB_)                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                \
-      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) ACC[mi][ni] = bm_mfma(a[mi][PA_], b[ni][PB_], ACC[mi][ni]);
-    BM_PROD(2, 0, accs)
-    BM_PROD(1, 0, accb)
-    BM_PROD(0, 2, accs)
-    BM_PROD(0, 1, accb)
-    BM_PROD(1, 1, accs)
-    BM_PROD(0, 0, accb)
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = bm_mfma(a[mi][PA_], b[ni][PB_], acc[mi][ni]);
+    BM_PROD(2, 0)
+    BM_PROD(1, 0)
+    BM_PROD(0, 2)
+    BM_PROD(0, 1)
+    BM_PROD(1, 1)
+    BM_PROD(0, 0)
 #undef BM_PROD
+    BM_STAMP(11 + 8 * ks);
+    __syncthreads();
+    BM_STAMP(12 + 8 * ks);
+    if (ks + 1 < nk) fragload((ks + 1) & 1);
+    BM_STAMP(13 + 8 * ks);
   }
+  BM_STAMP(2);
   // ---- epilogue ----
   const int col_l = lane & 15, rq = lane >> 4;
   if (EPI == BM_EPI_STORE) {
-    float *outp = E.out + (long long)blockIdx.z * E.split_stride;
+    float *outp = E.out + (long long)bz * E.split_stride;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        bm_drain(accb[mi][ni], accs[mi][ni]);
-        const f32x4 t = accb[mi][ni] + accs[mi][ni];
-        const float tv[4] = {t.x, t.y, t.z, t.w};
-        const int col = n0 + wn * 32 + ni * 16 + col_l;
+      for (int ni = 0; ni < NI; ++ni) {
+        bm_drain(acc[mi][ni]);
+        const float tv[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+        const int col = n0 + (wn * NI + ni) * 16 + col_l;
         const float bias = E.bias ? E.bias[min(col, N - 1)] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -252,40 +264,39 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
       }
   } else {
     // input-normalisation parameter gradients: column sums over this tile's rows, folded lane -> row groups -> the two
-    // wave rows through LDS in a fixed order; one partial record per m tile
+    // wave rows through LDS in a fixed order; one partial record per (K split, m tile)
     __syncthreads();   // the operand buffers are dead: reuse them
-    float *red = reinterpret_cast<float *>(bm_smem);   // [2 wm][64 cols][2]
+    float *red = reinterpret_cast<float *>(bm_smem);   // [2 wm][BN cols][2]
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 32 + ni * 16 + col_l;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int cl = (wn * NI + ni) * 16 + col_l, col = n0 + cl;
       const int cc = min(col, N - 1);
-      float ss = 0.f, sb = 0.f;
+      float ss = 0.f, sb_ = 0.f;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        bm_drain(accb[mi][ni], accs[mi][ni]);
-        const f32x4 t = accb[mi][ni] + accs[mi][ni];
-        const float tv[4] = {t.x, t.y, t.z, t.w};
+        bm_drain(acc[mi][ni]);
+        const float tv[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + (wm * MI + mi) * 16 + 4 * rq + r;
           const float xh = E.xhat[(long long)min(row, M - 1) * E.ldx + cc];
           const float g = (row < M && col < N) ? tv[r] : 0.0f;
           ss += g * xh;
-          sb += g;
+          sb_ += g;
         }
       }
       ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      sb_ += __shfl_xor(sb_, 16, 64); sb_ += __shfl_xor(sb_, 32, 64);
       if (rq == 0) {
-        red[(wm * 64 + wn * 32 + ni * 16 + col_l) * 2] = ss;
-        red[(wm * 64 + wn * 32 + ni * 16 + col_l) * 2 + 1] = sb;
+        red[(wm * BN + cl) * 2] = ss;
+        red[(wm * BN + cl) * 2 + 1] = sb_;
       }
     }
     __syncthreads();
-    if (tid < 64 && n0 + tid < N) {
-      float *po = E.out + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * 2 * N;
-      po[n0 + tid] = red[tid * 2] + red[(64 + tid) * 2];
-      po[N + n0 + tid] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+    if (tid < BN && n0 + tid < N) {
+      float *po = E.out + ((long long)bz * gridDim.y + by) * 2 * N;
+      po[n0 + tid] = red[tid * 2] + red[(BN + tid) * 2];
+      po[N + n0 + tid] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
     }
   }
 }
@@ -297,45 +308,112 @@ PQN_D float bm_wave_sum(float v) {
   return v;
 }
 
-// z = sum of the K-split partials of the layer's GEMM + bias;  h = relu(LayerNorm(z)) row by row (one wave per row);
-// z and stat[r] = (mean, rstd) are kept for the backward pass.  n % 256 == 0, n <= 4096.
-#define BM_MAXQ 4
+// f32 matrix src[rows][cols] (leading dimension lds, any alignment) -> planes [rows][ld]; one thread per 8 columns,
+// columns >= cols are written as zeros up to ld
+__global__ __launch_bounds__(256) void bm_split_kernel(const float *__restrict__ src, long long lds, int rows, int cols,
+                                                       BmPlanesOut out) {
+  const int ppr = (int)(out.ld / 8);
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)rows * ppr) return;
+  const int r = (int)(e / ppr), k = (int)(e % ppr) * 8;
+  const float *sr = src + (long long)r * lds;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = sr[min(k + j, cols - 1)];
+    v[j] = (k + j < cols) ? x : 0.0f;
+  }
+  u32x4 h, m, l;
+  bm_split8(v, h, m, l);
+  bm_put(out, r, k, h, m, l);
+}
+
+// planes src[rows][ld_s] (logical columns `cols`) -> planes dst[cols][ld_d] (logical columns `rows`, zero beyond);
+// 64 x 64 element tiles through LDS, 16-B global accesses both ways; grid (ceil(ld_d / 64), ceil(cols / 64), 3 planes)
+__global__ __launch_bounds__(256) void bm_transpose_kernel(BmPlanes src, int cols, BmPlanesOut dst) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];   // row stride 144 B: the 2-B column gathers below spread over the banks
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;   // source rows r0.., source columns c0..
+  const bf16_t *sp = src.p + (long long)blockIdx.z * src.pstride;
+  bf16_t *dp = dst.p + (long long)blockIdx.z * dst.pstride;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {   // load: 64 rows x 8 chunks of 8 columns (columns >= cols hold the source's zero padding)
+    const int e = tid + 256 * q, r = e >> 3, ch = e & 7;
+    const int rr = r0 + r, cc = c0 + 8 * ch;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (rr < src.rows && cc < src.ld) v = *reinterpret_cast<const u32x4 *>(sp + (long long)rr * src.ld + cc);
+    *reinterpret_cast<u32x4 *>(&tile[r][8 * ch]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {   // store: 64 destination rows (source columns) x 8 chunks of 8 source rows
+    const int e = tid + 256 * q, c = e >> 3, ch = e & 7;
+    const int cc = c0 + c, rr = r0 + 8 * ch;
+    if (cc < cols && rr < dst.ld) {
+      unsigned v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[8 * ch + j][c];   // rows >= src.rows were loaded as zeros
+      u32x4 o;
+      o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
+      *reinterpret_cast<u32x4 *>(dp + (long long)cc * dst.ld + rr) = o;
+    }
+  }
+}
+
+// z = sum of the K-split partials of the layer's GEMM + bias;  h = relu(LayerNorm(z)) row by row (one wave per row) written
+// as planes; z and stat[r] = (mean, rstd) are kept for the backward pass.  n % 256 == 0, n <= 2048: lane owns the
+// 8-column packs lane, lane + 64, ... of the row.
+#define BM_MAXP 4
 __global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict__ zpart, int nsplit, long long pstride, int m,
                                                          int n, const float *__restrict__ bias, const float *__restrict__ g,
                                                          const float *__restrict__ beta, float *__restrict__ z,
-                                                         float *__restrict__ h, float *__restrict__ stat) {
+                                                         BmPlanesOut h, float *__restrict__ stat) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
-  const int nq = n / 256;
-  f32x4 v[BM_MAXQ];
+  const int np = n / 8;   // packs per row
+  f32x4 v[BM_MAXP][2];
   float s = 0.f, q = 0.f;
 #pragma unroll
-  for (int k = 0; k < BM_MAXQ; ++k)
-    if (k < nq) {
-      const int c = lane * 4 + 256 * k;
-      v[k] = *reinterpret_cast<const f32x4 *>(zpart + (long long)row * n + c);
-      for (int sp = 1; sp < nsplit; ++sp) v[k] += *reinterpret_cast<const f32x4 *>(zpart + sp * pstride + (long long)row * n + c);
-      v[k] += *reinterpret_cast<const f32x4 *>(bias + c);
-      *reinterpret_cast<f32x4 *>(z + (long long)row * n + c) = v[k];
-      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-      q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+  for (int k = 0; k < BM_MAXP; ++k) {
+    const int pk = lane + 64 * k;
+    if (pk < np) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int c = 8 * pk + 4 * hh;
+        f32x4 t = *reinterpret_cast<const f32x4 *>(zpart + (long long)row * n + c);
+        for (int sp = 1; sp < nsplit; ++sp) t += *reinterpret_cast<const f32x4 *>(zpart + sp * pstride + (long long)row * n + c);
+        t += *reinterpret_cast<const f32x4 *>(bias + c);
+        *reinterpret_cast<f32x4 *>(z + (long long)row * n + c) = t;
+        s += (t.x + t.y) + (t.z + t.w);
+        q += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        v[k][hh] = t;
+      }
     }
+  }
   s = bm_wave_sum(s);
   q = bm_wave_sum(q);
   const float mean = s / (float)n;
   const float var = fmaxf(q / (float)n - mean * mean, 0.0f);
   const float rstd = 1.0f / sqrtf(var + BM_LN_EPS);
   if (lane == 0) { stat[2 * row] = mean; stat[2 * row + 1] = rstd; }
-  float *hr = h + (long long)row * n;
 #pragma unroll
-  for (int k = 0; k < BM_MAXQ; ++k)
-    if (k < nq) {
-      const int c = lane * 4 + 256 * k;
-      const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c), bv = *reinterpret_cast<const f32x4 *>(beta + c);
-      const f32x4 xh = (v[k] - mean) * rstd;
-      const f32x4 y = xh * gv + bv;
-      *reinterpret_cast<f32x4 *>(hr + c) = f32x4{fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f)};
+  for (int k = 0; k < BM_MAXP; ++k) {
+    const int pk = lane + 64 * k;
+    if (pk < np) {
+      float y[8];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int c = 8 * pk + 4 * hh;
+        const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c), bv = *reinterpret_cast<const f32x4 *>(beta + c);
+        const f32x4 xh = (v[k][hh] - mean) * rstd;
+        const f32x4 yy = xh * gv + bv;
+        y[4 * hh] = fmaxf(yy.x, 0.f); y[4 * hh + 1] = fmaxf(yy.y, 0.f); y[4 * hh + 2] = fmaxf(yy.z, 0.f); y[4 * hh + 3] = fmaxf(yy.w, 0.f);
+      }
+      u32x4 ph, pm, pl;
+      bm_split8(y, ph, pm, pl);
+      bm_put(h, row, 8 * pk, ph, pm, pl);
     }
+  }
 }
 
 // source row of minibatch row r: idx == NULL: r itself;  else idx[r mod nb] (+ next_off for the next_obs half r >= nb)
@@ -367,57 +445,69 @@ __global__ __launch_bounds__(256) void bm_colstats_kernel(const float *__restric
 
 // stage 2 + the bookkeeping of utils/batch_renorm.py:95-116 (renorm = 1) / flax nn.BatchNorm (renorm = 0), thread per
 // column.  coef = [4][d]: m_c (mean used), a_c = k_c * scale_c, b_c = bias_c, k_c = 1 / sqrt(var used + eps).
-// train = 0: coefficients from the running moments only (use_running_average).
+// train = 0: coefficients from the running moments only (use_running_average).  steps[0] = BatchRenorm's train-call
+// counter, steps[1] = a ticket word (zero between launches): the last workgroup to finish advances the counter, once
+// every thread of the launch has read it.
 __global__ __launch_bounds__(256) void bm_instat_finish_kernel(const double *__restrict__ part, int nparts, int m, int d,
                                                                const float *__restrict__ scale, const float *__restrict__ bias,
                                                                float *__restrict__ ra_mean, float *__restrict__ ra_var,
-                                                               const int32_t *__restrict__ steps, int train, int renorm, float eps,
+                                                               int32_t *__restrict__ steps, int train, int renorm, float eps,
                                                                float momentum, float *__restrict__ coef) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= d) return;
-  float mean = ra_mean[c], var = ra_var[c];
-  if (train) {
-    double s = 0.0, q = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-      s += part[((long long)p * 2) * d + c];
-      q += part[((long long)p * 2 + 1) * d + c];
+  if (c < d) {
+    float mean = ra_mean[c], var = ra_var[c];
+    if (train) {
+      double s = 0.0, q = 0.0;
+      for (int p = 0; p < nparts; ++p) {
+        s += part[((long long)p * 2) * d + c];
+        q += part[((long long)p * 2 + 1) * d + c];
+      }
+      const float bmean = (float)(s / (double)m);
+      const float bvar = fmaxf((float)(q / (double)m) - bmean * bmean, 0.0f);
+      mean = bmean;
+      var = bvar;
+      if (renorm && steps[0] >= 1000) {
+        const float ra_std = sqrtf(ra_var[c] + eps);
+        const float r = fminf(fmaxf(sqrtf(bvar + eps) / ra_std, 1.0f / 3.0f), 3.0f);
+        const float dd = fminf(fmaxf((bmean - ra_mean[c]) / ra_std, -5.0f), 5.0f);
+        var = bvar / (r * r);
+        mean = bmean - dd * sqrtf(bvar) / r;
+      }
+      ra_mean[c] = momentum * ra_mean[c] + (1.0f - momentum) * bmean;
+      ra_var[c] = momentum * ra_var[c] + (1.0f - momentum) * bvar;
     }
-    const float bmean = (float)(s / (double)m);
-    const float bvar = fmaxf((float)(q / (double)m) - bmean * bmean, 0.0f);
-    mean = bmean;
-    var = bvar;
-    if (renorm && *steps >= 1000) {
-      const float ra_std = sqrtf(ra_var[c] + eps);
-      const float r = fminf(fmaxf(sqrtf(bvar + eps) / ra_std, 1.0f / 3.0f), 3.0f);
-      const float dd = fminf(fmaxf((bmean - ra_mean[c]) / ra_std, -5.0f), 5.0f);
-      var = bvar / (r * r);
-      mean = bmean - dd * sqrtf(bvar) / r;
-    }
-    ra_mean[c] = momentum * ra_mean[c] + (1.0f - momentum) * bmean;
-    ra_var[c] = momentum * ra_var[c] + (1.0f - momentum) * bvar;
+    const float k = 1.0f / sqrtf(var + eps);
+    coef[c] = mean;
+    coef[d + c] = k * scale[c];
+    coef[2 * d + c] = bias[c];
+    coef[3 * d + c] = k;
   }
-  const float k = 1.0f / sqrtf(var + eps);
-  coef[c] = mean;
-  coef[d + c] = k * scale[c];
-  coef[2 * d + c] = bias[c];
-  coef[3 * d + c] = k;
+  if (train && renorm) {
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_last = atomicAdd(steps + 1, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) { steps[0] += 1; steps[1] = 0; }
+  }
 }
-__global__ void bm_steps_inc_kernel(int32_t *steps) { *steps += 1; }
 
-// xn[r][c] = (x[src(r)][c] - m_c) a_c + b_c (coef != NULL) or the gathered x itself; xhat[r][c] = (x - m_c) k_c for the
-// gradient rows r < nb (xhat != NULL).  Columns [d, ldo) are zeroed.  One thread per (row, 4 columns).
+// xn[r][c] = (x[src(r)][c] - m_c) a_c + b_c (coef != NULL) or the gathered x itself, as planes [m][ld]; xhat[r][c] =
+// (x - m_c) k_c in f32 for the gradient rows r < nb (xhat != NULL).  One thread per (row, 8 columns); columns >= d zero.
 __global__ __launch_bounds__(256) void bm_innorm_apply_kernel(const float *__restrict__ x, long long ldx, const int64_t *idx,
-                                                              int nb, long long next_off, int m, int d, int ldo,
-                                                              const float *__restrict__ coef, float *__restrict__ xn,
-                                                              float *__restrict__ xhat) {
-  const int qpr = ldo / 4;   // quads per row
+                                                              int nb, long long next_off, int m, int d,
+                                                              const float *__restrict__ coef, BmPlanesOut xn,
+                                                              float *__restrict__ xhat, long long ldh) {
+  const int ppr = (int)(xn.ld / 8);
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long long)m * qpr) return;
-  const int r = (int)(e / qpr), c0 = (int)(e % qpr) * 4;
+  if (e >= (long long)m * ppr) return;
+  const int r = (int)(e / ppr), c0 = (int)(e % ppr) * 8;
   const float *xr = x + bm_src_row(idx, nb, next_off, r) * ldx;
-  float o[4], oh[4];
+  float o[8], oh[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 8; ++j) {
     const int c = c0 + j, cc = min(c, d - 1);
     const float v = xr[cc];
     float y = v, yh = 0.0f;
@@ -429,20 +519,27 @@ __global__ __launch_bounds__(256) void bm_innorm_apply_kernel(const float *__res
     o[j] = c < d ? y : 0.0f;
     oh[j] = c < d ? yh : 0.0f;
   }
-  *reinterpret_cast<f32x4 *>(xn + (long long)r * ldo + c0) = f32x4{o[0], o[1], o[2], o[3]};
-  if (xhat && r < nb) *reinterpret_cast<f32x4 *>(xhat + (long long)r * ldo + c0) = f32x4{oh[0], oh[1], oh[2], oh[3]};
+  u32x4 h, mm, l;
+  bm_split8(o, h, mm, l);
+  bm_put(xn, r, c0, h, mm, l);
+  if (xhat && r < nb) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c0 + j < ldh) xhat[(long long)r * ldh + c0 + j] = oh[j];
+  }
 }
 
 // TD loss (single workgroup: fixed-order sums).  Rows r < b of Q are the q-values of transition idx[r]; with
 // next_rows the rows b + r hold Q(next_obs) and target = reward + (1 - done) gamma max_a Q_next (pqn_craftax.py:300-306),
-// otherwise `target` is the given Q(lambda) target.  dQ[r][a] = [a == action] (q_a - target) / b; d b_out = column sums.
+// otherwise `target` is the given Q(lambda) target.  dQ[r][a] = [a == action] (q_a - target) / b as planes [b][32];
+// d b_out = column sums.  a <= 32.
 __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__ q, int ldq, int b, int a,
                                                        const int64_t *__restrict__ idx, const int32_t *__restrict__ action,
                                                        const float *__restrict__ target, const float *__restrict__ reward,
                                                        const uint8_t *__restrict__ done, float gamma, int next_rows,
-                                                       float *__restrict__ dq, float *__restrict__ dbias,
+                                                       BmPlanesOut dq, float *__restrict__ dbias,
                                                        float *__restrict__ loss_out, float *__restrict__ qv_out) {
-  __shared__ float s_b[16][64];    // per-wave partial column sums of dQ (a <= 64)
+  __shared__ float s_b[16][64];    // per-wave partial column sums of dQ
   __shared__ float s_l[16], s_q[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float lsum = 0.f, qsum = 0.f, bacc = 0.f;   // bacc: lane j of a wave accumulates that wave's sum for action j
@@ -468,7 +565,15 @@ __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__
       g = diff * inv_b;
       lsum += 0.5f * diff * diff;
       qsum += qa;
-      for (int k = 0; k < ldq; ++k) dq[(long long)r * ldq + k] = (k == act) ? g : 0.0f;
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8) {   // the row of dQ: one non-zero among 32 padded columns
+        float v[8];
+#pragma unroll
+        for (int j8 = 0; j8 < 8; ++j8) v[j8] = (8 * k8 + j8 == act) ? g : 0.0f;
+        u32x4 h, m, l;
+        bm_split8(v, h, m, l);
+        bm_put(dq, r, 8 * k8, h, m, l);
+      }
     }
     for (int k = 0; k < a; ++k) {   // fixed-order butterfly per action; every lane gets the wave total
       const float t = bm_wave_sum(act == k ? g : 0.0f);
@@ -493,57 +598,70 @@ __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__
   }
 }
 
-// relu mask + LayerNorm backward: d (rows x n) <- f(sum of dpart), one wave per row, BM_LB_ROWS rows per workgroup.
+// relu mask + LayerNorm backward: dz (planes, rows x n) <- f(sum of the dpart K-split partials), one wave per row,
+// BM_LB_ROWS rows per workgroup.
 //   y = xhat g + beta;  dy = d [y > 0];  dxh = dy g;  dz = rstd (dxh - mean(dxh) - xhat mean(dxh xhat))
-// part[wg][0] = sum_rows dy xhat (d scale), [1] = sum_rows dy (d LN bias), [2] = sum_rows dz (d dense bias).  n <= 4096, n % 256 == 0.
+// part[wg][0] = sum_rows dy xhat (d scale), [1] = sum_rows dy (d LN bias), [2] = sum_rows dz (d dense bias).  n <= 2048, n % 256 == 0.
 #define BM_LB_ROWS 8
 __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict__ dpart, int nsplit, long long pstride,
-                                                        float *__restrict__ d, const float *__restrict__ z,
+                                                        BmPlanesOut dzp, const float *__restrict__ z,
                                                         const float *__restrict__ stat, const float *__restrict__ g,
                                                         const float *__restrict__ beta, int rows, int n,
                                                         float *__restrict__ part) {
   __shared__ float s_red[4][3 * 1024];   // 1024 columns per pass of the cross-wave fold
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nq = n / 256;                // float4 per lane and row
-  f32x4 a0[BM_MAXQ], a1[BM_MAXQ], a2[BM_MAXQ];
+  const int np = n / 8;                  // packs per row: lane owns packs lane, lane + 64, ...
+  f32x4 a0[BM_MAXP][2], a1[BM_MAXP][2], a2[BM_MAXP][2];
 #pragma unroll
-  for (int q = 0; q < BM_MAXQ; ++q) { a0[q] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[q] = a0[q]; a2[q] = a0[q]; }
+  for (int k = 0; k < BM_MAXP; ++k)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) { a0[k][hh] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[k][hh] = a0[k][hh]; a2[k][hh] = a0[k][hh]; }
   for (int rr = wave; rr < BM_LB_ROWS; rr += 4) {
     const int row = blockIdx.x * BM_LB_ROWS + rr;
     if (row >= rows) break;
     const float mean = stat[2 * row], rstd = stat[2 * row + 1];
-    float *dr = d + (long long)row * n;
     const float *zr = z + (long long)row * n;
-    f32x4 xh[BM_MAXQ], dxh[BM_MAXQ], dy[BM_MAXQ];
+    f32x4 xh[BM_MAXP][2], dxh[BM_MAXP][2], dy[BM_MAXP][2];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < BM_MAXQ; ++q) {
-      if (q < nq) {
-        const int c = lane * 4 + 256 * q;
-        const f32x4 zv = *reinterpret_cast<const f32x4 *>(zr + c);
-        f32x4 dv = *reinterpret_cast<const f32x4 *>(dpart + (long long)row * n + c);   // d loss / d h: sum of the K-split partials
-        for (int sp = 1; sp < nsplit; ++sp) dv += *reinterpret_cast<const f32x4 *>(dpart + sp * pstride + (long long)row * n + c);
-        const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c), bv = *reinterpret_cast<const f32x4 *>(beta + c);
-        xh[q] = (zv - mean) * rstd;
-        const f32x4 y = xh[q] * gv + bv;
-        dy[q] = f32x4{y.x > 0.f ? dv.x : 0.f, y.y > 0.f ? dv.y : 0.f, y.z > 0.f ? dv.z : 0.f, y.w > 0.f ? dv.w : 0.f};
-        dxh[q] = dy[q] * gv;
-        s1 += (dxh[q].x + dxh[q].y) + (dxh[q].z + dxh[q].w);
-        const f32x4 t = dxh[q] * xh[q];
-        s2 += (t.x + t.y) + (t.z + t.w);
+    for (int k = 0; k < BM_MAXP; ++k) {
+      const int pk = lane + 64 * k;
+      if (pk < np) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int c = 8 * pk + 4 * hh;
+          const f32x4 zv = *reinterpret_cast<const f32x4 *>(zr + c);
+          f32x4 dv = *reinterpret_cast<const f32x4 *>(dpart + (long long)row * n + c);   // d loss / d h: sum of the K-split partials
+          for (int sp = 1; sp < nsplit; ++sp) dv += *reinterpret_cast<const f32x4 *>(dpart + sp * pstride + (long long)row * n + c);
+          const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c), bv = *reinterpret_cast<const f32x4 *>(beta + c);
+          xh[k][hh] = (zv - mean) * rstd;
+          const f32x4 y = xh[k][hh] * gv + bv;
+          dy[k][hh] = f32x4{y.x > 0.f ? dv.x : 0.f, y.y > 0.f ? dv.y : 0.f, y.z > 0.f ? dv.z : 0.f, y.w > 0.f ? dv.w : 0.f};
+          dxh[k][hh] = dy[k][hh] * gv;
+          s1 += (dxh[k][hh].x + dxh[k][hh].y) + (dxh[k][hh].z + dxh[k][hh].w);
+          const f32x4 t = dxh[k][hh] * xh[k][hh];
+          s2 += (t.x + t.y) + (t.z + t.w);
+        }
       }
     }
     s1 = bm_wave_sum(s1) / (float)n;
     s2 = bm_wave_sum(s2) / (float)n;
 #pragma unroll
-    for (int q = 0; q < BM_MAXQ; ++q) {
-      if (q < nq) {
-        const int c = lane * 4 + 256 * q;
-        const f32x4 dz = (dxh[q] - s1 - xh[q] * s2) * rstd;
-        *reinterpret_cast<f32x4 *>(dr + c) = dz;
-        a0[q] += dy[q] * xh[q];
-        a1[q] += dy[q];
-        a2[q] += dz;
+    for (int k = 0; k < BM_MAXP; ++k) {
+      const int pk = lane + 64 * k;
+      if (pk < np) {
+        float dzv[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x4 dz = (dxh[k][hh] - s1 - xh[k][hh] * s2) * rstd;
+          dzv[4 * hh] = dz.x; dzv[4 * hh + 1] = dz.y; dzv[4 * hh + 2] = dz.z; dzv[4 * hh + 3] = dz.w;
+          a0[k][hh] += dy[k][hh] * xh[k][hh];
+          a1[k][hh] += dy[k][hh];
+          a2[k][hh] += dz;
+        }
+        u32x4 ph, pm, pl;
+        bm_split8(dzv, ph, pm, pl);
+        bm_put(dzp, row, 8 * pk, ph, pm, pl);
       }
     }
   }
@@ -551,12 +669,16 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
   for (int base = 0; base < n; base += 1024) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < BM_MAXQ; ++q) {
-      const int c = lane * 4 + 256 * q;
-      if (q < nq && c >= base && c < base + 1024) {
-        *reinterpret_cast<f32x4 *>(&s_red[wave][c - base]) = a0[q];
-        *reinterpret_cast<f32x4 *>(&s_red[wave][1024 + c - base]) = a1[q];
-        *reinterpret_cast<f32x4 *>(&s_red[wave][2048 + c - base]) = a2[q];
+    for (int k = 0; k < BM_MAXP; ++k) {
+      const int pk = lane + 64 * k;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int c = 8 * pk + 4 * hh;
+        if (pk < np && c >= base && c < base + 1024) {
+          *reinterpret_cast<f32x4 *>(&s_red[wave][c - base]) = a0[k][hh];
+          *reinterpret_cast<f32x4 *>(&s_red[wave][1024 + c - base]) = a1[k][hh];
+          *reinterpret_cast<f32x4 *>(&s_red[wave][2048 + c - base]) = a2[k][hh];
+        }
       }
     }
     __syncthreads();
@@ -636,84 +758,98 @@ __global__ __launch_bounds__(256) void bm_epsgreedy_kernel(const float *__restri
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-bool bm_vec_ok(const BmOperand &o) { return (o.ld % 4) == 0 && o.ld >= 4 && (reinterpret_cast<uintptr_t>(o.p) & 15) == 0; }
+int align4(int x) { return (x + 3) & ~3; }
 
-#define BM_MAX_SPLIT 4
-
-// One GEMM launch.  nsplit K splits write nsplit partial outputs E.split_stride apart (STORE) / nsplit x m-tile partial
-// records (INNORM); the consumer folds them.  Loader modes are picked from the operands' alignment.
-template <int BM, bool TA, bool TB, int EPI>
-int bm_launch(int M, int N, int K, int nsplit, const BmOperand &A, const BmOperand &B, const BmEpilogue &E, hipStream_t st) {
-  const int klen = ((K + nsplit - 1) / nsplit + BM_KS - 1) / BM_KS * BM_KS;
-  const int nz = (K + klen - 1) / klen;
-  const dim3 grid((N + BM_BN - 1) / BM_BN, (M + BM - 1) / BM, nz);
-  const int lds = bm_lds_bytes<BM>();
-  const bool va = bm_vec_ok(A), vb = bm_vec_ok(B);
-  constexpr int A_V = TA ? BM_LM_COLVEC : BM_LM_ROWVEC, A_S = TA ? BM_LM_COLSCL : BM_LM_ROWSCL;
-  constexpr int B_V = TB ? BM_LM_COLVEC : BM_LM_ROWVEC, B_S = TB ? BM_LM_COLSCL : BM_LM_ROWSCL;
-#define BM_GO(LA_, LB_)                                                                                                  \
-  do {                                                                                                                   \
-    auto kern = &bm_gemm_kernel<BM, LA_, LB_, EPI>;                                                                      \
-    static bool attr = false;                                                                                            \
-    if (!attr) {                                                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
-      attr = true;                                                                                                       \
-    }                                                                                                                    \
-    hipLaunchKernelGGL(kern, grid, dim3(BM_THREADS), lds, st, M, N, K, klen, A, B, E);                                   \
-  } while (0)
-  if (va && vb) BM_GO(A_V, B_V);
-  else if (va) BM_GO(A_V, B_S);
-  else if (vb) BM_GO(A_S, B_V);
-  else BM_GO(A_S, B_S);
-#undef BM_GO
-  return pqn_check_launch("pqn_bigmlp gemm");
-}
-
-// Tile height and K split of a GEMM: 128-row tiles when they still give every second CU a workgroup, and as many K splits
-// (<= max_split, each >= 128 long) as it takes to put ~3 workgroups on every CU -- the kernel hides its global-load
-// latency behind OTHER workgroups' MFMAs.  Run-time switches "bm_tile" (64 / 128) and "bm_split" override (A/B runs).
-struct BmPlan { int bm, nsplit; };
-BmPlan bm_plan(int M, int N, int K, int max_split) {
-  const long long t128 = (long long)((M + 127) / 128) * ((N + BM_BN - 1) / BM_BN);
-  BmPlan p;
-  p.bm = t128 >= 128 ? 128 : 64;
-  if (pqn_opt(PQN_OPT_BM_TILE) == 64 || pqn_opt(PQN_OPT_BM_TILE) == 128) p.bm = pqn_opt(PQN_OPT_BM_TILE);
-  const long long tiles = (long long)((M + p.bm - 1) / p.bm) * ((N + BM_BN - 1) / BM_BN);
-  int s = (int)((768 + tiles - 1) / tiles);
-  if (pqn_opt(PQN_OPT_BM_SPLIT) > 0) s = pqn_opt(PQN_OPT_BM_SPLIT);
-  s = min(s, min(max_split, max(1, K / 128)));
-  p.nsplit = max(1, s);
+// a plane triple inside a bf16 arena: rows x ld elements per plane
+BmPlanes bm_pl(const bf16_t *base, int rows, int ld) {
+  BmPlanes p = {};
+  p.p = base; p.ld = ld; p.pstride = (long long)rows * ld; p.rows = rows;
   return p;
 }
-
-template <bool TA, bool TB>
-int bm_gemm(int M, int N, int K, const BmOperand &A, const BmOperand &B, BmEpilogue E, int max_split, int *nsplit_out, hipStream_t st) {
-  const BmPlan p = bm_plan(M, N, K, max_split);
-  const int klen = ((K + p.nsplit - 1) / p.nsplit + BM_KS - 1) / BM_KS * BM_KS;
-  if (nsplit_out) *nsplit_out = (K + klen - 1) / klen;
-  if (p.bm == 128) return bm_launch<128, TA, TB, BM_EPI_STORE>(M, N, K, p.nsplit, A, B, E, st);
-  return bm_launch<64, TA, TB, BM_EPI_STORE>(M, N, K, p.nsplit, A, B, E, st);
+BmPlanesOut bm_plo(bf16_t *base, int rows, int ld) {
+  BmPlanesOut p = {};
+  p.p = base; p.ld = ld; p.pstride = (long long)rows * ld;
+  return p;
 }
+long long bm_pl_elems(int rows, int ld) { return 3ll * rows * ld; }
 
-BmOperand bm_op(const float *p, long long ld, int rows, int cols) {
-  BmOperand o = {};
-  o.p = p; o.ld = ld; o.rows = rows; o.cols = cols;
-  return o;
-}
 BmEpilogue bm_store(float *out, long long ldc, const float *bias = nullptr, long long split_stride = 0) {
   BmEpilogue e = {};
   e.out = out; e.ldc = ldc; e.bias = bias; e.split_stride = split_stride;
   return e;
 }
 
-int align4(int x) { return (x + 3) & ~3; }
+// Tile and K split of a GEMM: 128 x 64 tiles when they still give every second CU a workgroup (else 64 x 64), and the K
+// split (<= max_split, each part >= 128 long) that fills whole "rounds" best -- a round = every CU holding as many
+// workgroups as its LDS takes (two 128 x 64, three 64 x 64).  Run-time switches "bm_tile" (64 / 128) and "bm_split"
+// override (A/B runs).
+struct BmPlan { int bm, nsplit, klen; };
+BmPlan bm_plan(int M, int N, int Kp, int max_split) {
+  const long long t128 = (long long)((M + 127) / 128) * ((N + 63) / 64);
+  BmPlan p;
+  p.bm = t128 >= 128 ? 128 : 64;
+  if (pqn_opt(PQN_OPT_BM_TILE) == 64 || pqn_opt(PQN_OPT_BM_TILE) == 128) p.bm = pqn_opt(PQN_OPT_BM_TILE);
+  const long long tiles = (long long)((M + p.bm - 1) / p.bm) * ((N + 63) / 64);
+  const long long round = 256ll * (p.bm == 128 ? 2 : 3);
+  int s = 1;
+  double best = 0.0;
+  for (int c = 1; c <= max_split; ++c) {
+    const double r = (double)(tiles * c) / (double)round, eff = r / (double)(long long)(r + 0.999999);
+    if (eff > best + 0.02) { best = eff; s = c; }
+  }
+  if (pqn_opt(PQN_OPT_BM_SPLIT) > 0) s = pqn_opt(PQN_OPT_BM_SPLIT);
+  s = max(1, min(s, min(max_split, max(1, Kp / 128))));
+  p.klen = ((Kp + s - 1) / s + BM_KS - 1) / BM_KS * BM_KS;
+  p.nsplit = (Kp + p.klen - 1) / p.klen;
+  return p;
+}
 
-// workspace carve-up (floats); rows = forward rows (2 nb with next_obs, else nb), nb = rows that carry gradient
+template <int EPI>
+int bm_launch(int M, int N, int Kp, const BmPlan &p, const BmPlanes &A, const BmPlanes &B, const BmEpilogue &E, hipStream_t st) {
+  const dim3 grid((N + 63) / 64, (M + p.bm - 1) / p.bm, p.nsplit);
+#define BM_GO(BM_)                                                                                                      \
+  do {                                                                                                                   \
+    auto kern = &bm_gemm_kernel<BM_, 64, EPI>;                                                                           \
+    constexpr int lds = bm_lds_bytes<BM_, 64>();                                                                        \
+    static bool attr = false;                                                                                            \
+    if (!attr) {                                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
+      attr = true;                                                                                                       \
+    }                                                                                                                    \
+    hipLaunchKernelGGL(kern, grid, dim3(BM_THREADS), lds, st, M, N, Kp, p.klen, A, B, E);                                \
+  } while (0)
+  if (p.bm == 128) BM_GO(128);
+  else BM_GO(64);
+#undef BM_GO
+  return pqn_check_launch("pqn_bigmlp gemm");
+}
+
+// C = A B^T from planes with K padded to Kp; returns the number of K-split partials written through *nsplit_out
+int bm_gemm(int M, int N, int Kp, const BmPlanes &A, const BmPlanes &B, const BmEpilogue &E, int max_split, int *nsplit_out,
+            hipStream_t st) {
+  const BmPlan p = bm_plan(M, N, Kp, max_split);
+  if (nsplit_out) *nsplit_out = p.nsplit;
+  return bm_launch<BM_EPI_STORE>(M, N, Kp, p, A, B, E, st);
+}
+
+void bm_split(const float *src, long long lds, int rows, int cols, const BmPlanesOut &out, hipStream_t st) {
+  const long long n = (long long)rows * (out.ld / 8);
+  hipLaunchKernelGGL(bm_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, rows, cols, out);
+}
+// dst[cols][ld_d] <- transpose of src[rows][.] (logical columns `cols`); ld_d = pad32(rows)
+void bm_transpose(const BmPlanes &src, int cols, const BmPlanesOut &dst, hipStream_t st) {
+  hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)((dst.ld + 63) / 64), (unsigned)((cols + 63) / 64), 3), dim3(256), 0, st, src, cols,
+                     dst);
+}
+
+// ---- workspace carve-up: a float region followed by a bf16 region (offsets in floats / in bf16 elements) ----
 struct BmWs {
-  long long coef, cspart, xn, xhat, z[PQN_BIGMLP_MAX_LAYERS], h[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, dq, dz,
-      zpart, dpart, wpart, lnpart, inpart, total;
-  long long zstride, dstride, wstride;   // elements between K-split partials
-  int ldq, ldx, n_cs, n_ln, n_in;
+  // f32
+  long long coef, cspart, xhat, z[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, zpart, dpart, wpart, lnpart, inpart, f_total;
+  long long zstride, dstride, wstride;
+  // bf16 planes (element offsets from the start of the bf16 region)
+  long long xn, xnT, h[PQN_BIGMLP_MAX_LAYERS], hT[PQN_BIGMLP_MAX_LAYERS], dz, dzT, dq, dqT, b_total;
+  int ldq, ldx, dp, nbp, n_cs, n_ln, n_in;
 };
 BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
   BmWs w = {};
@@ -721,21 +857,19 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
   auto take = [&](long long n) { const long long o = off; off += (n + 3) & ~3ll; return o; };
   w.ldq = align4(L.a);
   w.ldx = align4(L.d);
+  w.dp = bm_pad32(L.d);
+  w.nbp = bm_pad32(nb);
   w.n_cs = (rows + BM_CS_ROWS - 1) / BM_CS_ROWS;
   w.n_ln = (nb + BM_LB_ROWS - 1) / BM_LB_ROWS;
   w.n_in = (nb + 63) / 64;
   w.coef = take(4ll * L.d);
   w.cspart = take(4ll * w.n_cs * L.d);   // f64 partials
-  w.xn = take((long long)rows * w.ldx);
   w.xhat = take((long long)nb * w.ldx);
   for (int l = 0; l < L.layers; ++l) {
     w.z[l] = take((long long)rows * L.h);
-    w.h[l] = take((long long)rows * L.h);
     w.stat[l] = take(2ll * rows);
   }
   w.q = take((long long)rows * w.ldq);
-  w.dq = take((long long)nb * w.ldq);
-  w.dz = take((long long)nb * L.h);
   w.zstride = (long long)rows * L.h;
   w.zpart = take(BM_MAX_SPLIT * w.zstride);
   w.dstride = (long long)nb * L.h;
@@ -744,25 +878,58 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
   w.wpart = take(BM_MAX_SPLIT * w.wstride);
   w.lnpart = take(3ll * w.n_ln * L.h);
   w.inpart = take(2ll * BM_MAX_SPLIT * w.n_in * L.d);
-  w.total = off;
+  w.f_total = off;
+  long long bo = 0;
+  auto takeb = [&](long long n) { const long long o = bo; bo += (n + 7) & ~7ll; return o; };
+  w.xn = takeb(bm_pl_elems(rows, w.dp));
+  w.xnT = takeb(bm_pl_elems(L.d, w.nbp));
+  for (int l = 0; l < L.layers; ++l) {
+    w.h[l] = takeb(bm_pl_elems(rows, L.h));
+    w.hT[l] = takeb(bm_pl_elems(L.h, w.nbp));
+  }
+  w.dz = takeb(bm_pl_elems(nb, L.h));
+  w.dzT = takeb(bm_pl_elems(L.h, w.nbp));
+  w.dq = takeb(bm_pl_elems(nb, 32));
+  w.dqT = takeb(bm_pl_elems(L.a, w.nbp));
+  w.b_total = bo;
+  return w;
+}
+long long bm_ws_floats(const BmWs &w) { return w.f_total + (w.b_total + 1) / 2; }
+
+// weight planes (bf16 element offsets inside the arena): per layer the natural copy Wn[kin][pad32(out)] (input gradient:
+// K = out) and the transposed copy WT[out][pad32(kin)] (forward: K = kin)
+struct BmWp { long long wn[PQN_BIGMLP_MAX_LAYERS + 1], wt[PQN_BIGMLP_MAX_LAYERS + 1], total; };
+BmWp bm_wp(const pqn_bigmlp_layout_t &L) {
+  BmWp w = {};
+  long long bo = 0;
+  auto takeb = [&](long long n) { const long long o = bo; bo += (n + 7) & ~7ll; return o; };
+  for (int l = 0; l <= L.layers; ++l) {
+    const int kin = l ? L.h : L.d, out = l < L.layers ? L.h : L.a;
+    w.wn[l] = takeb(bm_pl_elems(kin, bm_pad32(out)));
+    w.wt[l] = takeb(bm_pl_elems(out, bm_pad32(kin)));
+  }
+  w.total = bo;
   return w;
 }
 
-// forward from the (normalised, gathered) input xn through the hidden layers (z_l, h_l, stat_l kept) to Q[rows][ldq]
-int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, float *ws, const BmWs &w, hipStream_t st) {
+// forward from the (normalised, gathered) input planes through the hidden layers (z_l, h_l planes, stat_l kept) to Q
+int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, const bf16_t *wpl, float *ws, bf16_t *wb, const BmWs &w,
+               hipStream_t st) {
+  const BmWp wp = bm_wp(L);
   for (int l = 0; l < L.layers; ++l) {
-    const int kin = l ? L.h : L.d;
-    const BmOperand A = l ? bm_op(ws + w.h[l - 1], L.h, rows, L.h) : bm_op(ws + w.xn, w.ldx, rows, L.d);
-    const BmOperand B = bm_op(theta + L.off_w[l], L.h, kin, L.h);
+    const int kin = l ? L.h : L.d, kp = bm_pad32(kin);
+    const BmPlanes A = l ? bm_pl(wb + w.h[l - 1], rows, L.h) : bm_pl(wb + w.xn, rows, w.dp);
+    const BmPlanes B = bm_pl(wpl + wp.wt[l], L.h, kp);
     int ns = 1;
-    const int rc = bm_gemm<false, true>(rows, L.h, kin, A, B, bm_store(ws + w.zpart, L.h, nullptr, w.zstride), BM_MAX_SPLIT, &ns, st);
+    const int rc = bm_gemm(rows, L.h, kp, A, B, bm_store(ws + w.zpart, L.h, nullptr, w.zstride), BM_MAX_SPLIT, &ns, st);
     if (rc != PQN_OK) return rc;
     hipLaunchKernelGGL(bm_ln_relu_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ws + w.zpart, ns, w.zstride, rows, L.h,
-                       theta + L.off_b[l], theta + L.off_lns[l], theta + L.off_lnb[l], ws + w.z[l], ws + w.h[l], ws + w.stat[l]);
+                       theta + L.off_b[l], theta + L.off_lns[l], theta + L.off_lnb[l], ws + w.z[l], bm_plo(wb + w.h[l], rows, L.h),
+                       ws + w.stat[l]);
   }
   const int lo = L.layers;   // output layer: Q = h_last W_out + b_out (narrow: no K split)
-  return bm_gemm<false, true>(rows, L.a, L.h, bm_op(ws + w.h[lo - 1], L.h, rows, L.h), bm_op(theta + L.off_w[lo], L.a, L.h, L.a),
-                              bm_store(ws + w.q, w.ldq, theta + L.off_b[lo]), 1, nullptr, st);
+  return bm_gemm(rows, L.a, L.h, bm_pl(wb + w.h[lo - 1], rows, L.h), bm_pl(wpl + wp.wt[lo], L.a, L.h),
+                 bm_store(ws + w.q, w.ldq, theta + L.off_b[lo]), 1, nullptr, st);
 }
 
 }  // namespace
@@ -770,10 +937,10 @@ int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, float
 extern "C" int pqn_bigmlp_layout(int32_t d, int32_t h, int32_t layers, int32_t a, int32_t norm_input,
                                  pqn_bigmlp_layout_t *L) {
   PQN_REQUIRE(L, "pqn_bigmlp_layout: NULL layout");
-  PQN_REQUIRE(d >= 8 && h >= 256 && h <= 4096 && h % 256 == 0 && layers >= 1 && layers <= PQN_BIGMLP_MAX_LAYERS && a >= 1 &&
-                  a <= 64 && norm_input >= 0 && norm_input <= 2,
+  PQN_REQUIRE(d >= 8 && h >= 256 && h <= 2048 && h % 256 == 0 && layers >= 1 && layers <= PQN_BIGMLP_MAX_LAYERS && a >= 1 &&
+                  a <= 32 && norm_input >= 0 && norm_input <= 2,
               "pqn_bigmlp_layout: unsupported shape d=%d h=%d layers=%d a=%d norm_input=%d (d >= 8; h: multiple of 256 in "
-              "[256, 4096]; layers <= %d; a <= 64)", d, h, layers, a, norm_input, PQN_BIGMLP_MAX_LAYERS);
+              "[256, 2048]; layers <= %d; a <= 32)", d, h, layers, a, norm_input, PQN_BIGMLP_MAX_LAYERS);
   *L = pqn_bigmlp_layout_t{};
   L->d = d; L->h = h; L->layers = layers; L->a = a; L->norm_input = norm_input;
   int off = 0;
@@ -796,28 +963,50 @@ extern "C" int pqn_bigmlp_layout(int32_t d, int32_t h, int32_t layers, int32_t a
 
 extern "C" int64_t pqn_bigmlp_workspace_floats(const pqn_bigmlp_layout_t *L, int32_t rows, int32_t nb) {
   if (!L || rows <= 0 || nb <= 0 || nb > rows) return -1;
-  return bm_ws(*L, rows, nb).total;
+  return bm_ws_floats(bm_ws(*L, rows, nb));
+}
+
+extern "C" int64_t pqn_bigmlp_weight_plane_floats(const pqn_bigmlp_layout_t *L) {
+  if (!L) return -1;
+  return (bm_wp(*L).total + 1) / 2;
+}
+
+extern "C" int pqn_bigmlp_refresh_planes(const pqn_bigmlp_layout_t *L, const float *theta, float *wplanes, void *stream) {
+  PQN_REQUIRE(L && theta && wplanes, "pqn_bigmlp_refresh_planes: NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  const BmWp wp = bm_wp(*L);
+  bf16_t *base = reinterpret_cast<bf16_t *>(wplanes);
+  for (int l = 0; l <= L->layers; ++l) {
+    const int kin = l ? L->h : L->d, out = l < L->layers ? L->h : L->a;
+    bm_split(theta + L->off_w[l], out, kin, out, bm_plo(base + wp.wn[l], kin, bm_pad32(out)), st);
+    bm_transpose(bm_pl(base + wp.wn[l], kin, bm_pad32(out)), out, bm_plo(base + wp.wt[l], out, bm_pad32(kin)), st);
+  }
+  return pqn_check_launch("pqn_bigmlp_refresh_planes");
 }
 
 extern "C" int pqn_bigmlp_forward(const pqn_bigmlp_layout_t *L, int32_t n, const float *obs, const float *theta,
-                                  float *in_mean, float *in_var, float *workspace, float *q, int32_t *action, float *qmax,
-                                  float eps, uint64_t key, const float *eps_dev, const uint64_t *key_dev, void *stream) {
-  PQN_REQUIRE(L && obs && theta && workspace, "pqn_bigmlp_forward: NULL argument");
+                                  const float *wplanes, float *in_mean, float *in_var, float *workspace, float *q,
+                                  int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
+                                  const uint64_t *key_dev, void *stream) {
+  PQN_REQUIRE(L && obs && theta && wplanes && workspace, "pqn_bigmlp_forward: NULL argument");
   PQN_REQUIRE(n > 0 && (q || action || qmax), "pqn_bigmlp_forward: nothing to do (n=%d)", n);
   PQN_REQUIRE(L->norm_input == 0 || (in_mean && in_var), "pqn_bigmlp_forward: the input normalisation needs its running moments");
   hipStream_t st = (hipStream_t)stream;
   const BmWs w = bm_ws(*L, n, n);
   float *ws = workspace;
+  bf16_t *wb = reinterpret_cast<bf16_t *>(workspace + w.f_total);
+  const bf16_t *wpl = reinterpret_cast<const bf16_t *>(wplanes);
   const float *coef = nullptr;
   if (L->norm_input) {   // use_running_average: coefficients from the running moments
     hipLaunchKernelGGL(bm_instat_finish_kernel, dim3((L->d + 255) / 256), dim3(256), 0, st, (const double *)nullptr, 0, n, L->d,
-                       theta + L->off_in_scale, theta + L->off_in_bias, in_mean, in_var, (const int32_t *)nullptr, 0,
+                       theta + L->off_in_scale, theta + L->off_in_bias, in_mean, in_var, (int32_t *)nullptr, 0,
                        L->norm_input == 2 ? 1 : 0, L->norm_input == 2 ? 1e-3f : 1e-5f, 0.0f, ws + w.coef);
     coef = ws + w.coef;
   }
-  hipLaunchKernelGGL(bm_innorm_apply_kernel, dim3((unsigned)(((long long)n * (w.ldx / 4) + 255) / 256)), dim3(256), 0, st, obs,
-                     (long long)L->d, (const int64_t *)nullptr, n, 0ll, n, L->d, w.ldx, coef, ws + w.xn, (float *)nullptr);
-  const int rc = bm_forward(*L, n, theta, ws, w, st);
+  hipLaunchKernelGGL(bm_innorm_apply_kernel, dim3((unsigned)(((long long)n * (w.dp / 8) + 255) / 256)), dim3(256), 0, st, obs,
+                     (long long)L->d, (const int64_t *)nullptr, n, 0ll, n, L->d, coef, bm_plo(wb + w.xn, n, w.dp), (float *)nullptr,
+                     (long long)w.ldx);
+  const int rc = bm_forward(*L, n, theta, wpl, ws, wb, w, st);
   if (rc != PQN_OK) return rc;
   hipLaunchKernelGGL(bm_epsgreedy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws + w.q, w.ldq, n, L->a, eps, key, eps_dev,
                      key_dev, action, qmax, q);
@@ -826,10 +1015,10 @@ extern "C" int pqn_bigmlp_forward(const pqn_bigmlp_layout_t *L, int32_t n, const
 
 extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const int64_t *idx, const float *obs,
                                int64_t next_offset, const int32_t *action, const float *target, const float *reward,
-                               const uint8_t *done, float gamma, const float *theta, float *in_mean, float *in_var,
-                               int32_t *in_steps, float *grad, float *workspace, float *loss_out, float *qv_out,
-                               void *stream) {
-  PQN_REQUIRE(L && idx && obs && action && theta && grad && workspace, "pqn_bigmlp_grad: NULL argument");
+                               const uint8_t *done, float gamma, const float *theta, const float *wplanes, float *in_mean,
+                               float *in_var, int32_t *in_steps, float *grad, float *workspace, float *loss_out,
+                               float *qv_out, void *stream) {
+  PQN_REQUIRE(L && idx && obs && action && theta && wplanes && grad && workspace, "pqn_bigmlp_grad: NULL argument");
   PQN_REQUIRE(nb > 0 && next_offset >= 0, "pqn_bigmlp_grad: bad shape nb=%d next_offset=%lld", nb, (long long)next_offset);
   PQN_REQUIRE(next_offset > 0 ? (reward && done) : (target != nullptr),
               "pqn_bigmlp_grad: the 1-step loss needs reward + done, the Q(lambda) loss needs target");
@@ -838,7 +1027,10 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
   hipStream_t st = (hipStream_t)stream;
   const int rows = next_offset > 0 ? 2 * nb : nb;
   const BmWs w = bm_ws(*L, rows, nb);
+  const BmWp wp = bm_wp(*L);
   float *ws = workspace;
+  bf16_t *wb = reinterpret_cast<bf16_t *>(workspace + w.f_total);
+  const bf16_t *wpl = reinterpret_cast<const bf16_t *>(wplanes);
   const float *coef = nullptr;
   if (L->norm_input) {
     const bool renorm = L->norm_input == 2;
@@ -846,9 +1038,8 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
                        (long long)next_offset, rows, L->d, reinterpret_cast<double *>(ws + w.cspart));
     hipLaunchKernelGGL(bm_instat_finish_kernel, dim3((L->d + 255) / 256), dim3(256), 0, st,
                        reinterpret_cast<const double *>(ws + w.cspart), w.n_cs, rows, L->d, theta + L->off_in_scale,
-                       theta + L->off_in_bias, in_mean, in_var, (const int32_t *)in_steps, 1, renorm ? 1 : 0,
-                       renorm ? 1e-3f : 1e-5f, renorm ? 0.999f : 0.99f, ws + w.coef);
-    if (renorm) hipLaunchKernelGGL(bm_steps_inc_kernel, dim3(1), dim3(1), 0, st, in_steps);
+                       theta + L->off_in_bias, in_mean, in_var, in_steps, 1, renorm ? 1 : 0, renorm ? 1e-3f : 1e-5f,
+                       renorm ? 0.999f : 0.99f, ws + w.coef);
     coef = ws + w.coef;
   } else {   // the dummy input normalisation never receives gradient (pqn_craftax.py:47-49)
     if (hipMemsetAsync(grad + L->off_in_scale, 0, sizeof(float) * (size_t)(L->off_w[0] - L->off_in_scale), st) != hipSuccess) {
@@ -856,99 +1047,140 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
       return PQN_E_HIP;
     }
   }
-  hipLaunchKernelGGL(bm_innorm_apply_kernel, dim3((unsigned)(((long long)rows * (w.ldx / 4) + 255) / 256)), dim3(256), 0, st, obs,
-                     (long long)L->d, idx, nb, (long long)next_offset, rows, L->d, w.ldx, coef, ws + w.xn,
-                     coef ? ws + w.xhat : (float *)nullptr);
-  int rc = bm_forward(*L, rows, theta, ws, w, st);
+  hipLaunchKernelGGL(bm_innorm_apply_kernel, dim3((unsigned)(((long long)rows * (w.dp / 8) + 255) / 256)), dim3(256), 0, st, obs,
+                     (long long)L->d, idx, nb, (long long)next_offset, rows, L->d, coef, bm_plo(wb + w.xn, rows, w.dp),
+                     coef ? ws + w.xhat : (float *)nullptr, (long long)w.ldx);
+  int rc = bm_forward(*L, rows, theta, wpl, ws, wb, w, st);
   if (rc != PQN_OK) return rc;
   const int lo = L->layers;
   hipLaunchKernelGGL(bm_loss_kernel, dim3(1), dim3(1024), 0, st, ws + w.q, w.ldq, nb, L->a, idx, action, target, reward, done,
-                     gamma, next_offset > 0 ? 1 : 0, ws + w.dq, grad + L->off_b[lo], loss_out, qv_out);
-  // backward over the first nb rows (the next_obs half carries no gradient: stop_gradient, pqn_craftax.py:301)
-  float *dz = ws + w.dz;
-  const BmOperand dQ = bm_op(ws + w.dq, w.ldq, nb, L->a);
-  auto wgrad = [&](int kin, const BmOperand &Hin, const BmOperand &dZ, int n_out, float *gout) -> int {   // d W = Hin^T dZ
+                     gamma, next_offset > 0 ? 1 : 0, bm_plo(wb + w.dq, nb, 32), grad + L->off_b[lo], loss_out, qv_out);
+  // backward over the first nb rows (the next_obs half carries no gradient: stop_gradient, pqn_craftax.py:301).
+  // Weight gradient d W = Hin^T dZ: both operands with the samples as K = the transposed plane copies [feature][sample].
+  auto wgrad = [&](int kin, const BmPlanes &HinT, const BmPlanes &dZT, int n_out, float *gout) -> int {
     int ns = 1;
     const long long cnt = (long long)kin * n_out;
-    const bool direct = n_out < BM_BN || (cnt & 3);     // narrow output layer: one split, straight into the gradient
-    const int r = bm_gemm<true, true>(kin, n_out, nb, Hin, dZ, direct ? bm_store(gout, n_out) : bm_store(ws + w.wpart, n_out, nullptr, w.wstride),
-                                      direct ? 1 : BM_MAX_SPLIT, &ns, st);
+    const bool direct = n_out < 64 || (cnt & 3);        // narrow output layer: one split, straight into the gradient
+    const int r = bm_gemm(kin, n_out, w.nbp, HinT, dZT, direct ? bm_store(gout, n_out) : bm_store(ws + w.wpart, n_out, nullptr, w.wstride),
+                          direct ? 1 : BM_MAX_SPLIT, &ns, st);
     if (r != PQN_OK || direct) return r;
     hipLaunchKernelGGL(bm_sum_partials_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, st, ws + w.wpart, ns, w.wstride,
                        cnt, gout);
     return PQN_OK;
   };
-  // d W_out = h_last^T dQ;   d h_last = dQ W_out^T (K = a: one split)
-  rc = wgrad(L->h, bm_op(ws + w.h[lo - 1], L->h, nb, L->h), dQ, L->a, grad + L->off_w[lo]);
+  auto hT = [&](int l) -> BmPlanes {   // transposed copy of the gradient rows of h_l (l = -1: the normalised input)
+    if (l < 0) {
+      BmPlanes src = bm_pl(wb + w.xn, nb, w.dp);
+      src.pstride = (long long)rows * w.dp;   // the planes hold all forward rows; only the first nb are transposed
+      bm_transpose(src, L->d, bm_plo(wb + w.xnT, L->d, w.nbp), st);
+      return bm_pl(wb + w.xnT, L->d, w.nbp);
+    }
+    BmPlanes src = bm_pl(wb + w.h[l], nb, L->h);
+    src.pstride = (long long)rows * L->h;
+    bm_transpose(src, L->h, bm_plo(wb + w.hT[l], L->h, w.nbp), st);
+    return bm_pl(wb + w.hT[l], L->h, w.nbp);
+  };
+  // output layer: d W_out = h_last^T dQ;   d h_last = dQ W_out^T (K = a padded to 32: one split)
+  bm_transpose(bm_pl(wb + w.dq, nb, 32), L->a, bm_plo(wb + w.dqT, L->a, w.nbp), st);
+  rc = wgrad(L->h, hT(lo - 1), bm_pl(wb + w.dqT, L->a, w.nbp), L->a, grad + L->off_w[lo]);
   if (rc != PQN_OK) return rc;
   int nsd = 1;
-  rc = bm_gemm<false, false>(nb, L->h, L->a, dQ, bm_op(theta + L->off_w[lo], L->a, L->h, L->a), bm_store(ws + w.dpart, L->h, nullptr, w.dstride),
-                             1, &nsd, st);
+  rc = bm_gemm(nb, L->h, 32, bm_pl(wb + w.dq, nb, 32), bm_pl(wpl + wp.wn[lo], L->h, 32), bm_store(ws + w.dpart, L->h, nullptr, w.dstride), 1,
+               &nsd, st);
   if (rc != PQN_OK) return rc;
   for (int l = lo - 1; l >= 0; --l) {
-    // dpart (nsd K-split partials) = d loss / d h_l  ->  relu mask + LayerNorm backward: dz = d loss / d z_l
-    hipLaunchKernelGGL(bm_ln_bwd_kernel, dim3(w.n_ln), dim3(256), 0, st, ws + w.dpart, nsd, w.dstride, dz, ws + w.z[l],
-                       ws + w.stat[l], theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart);
+    // dpart (nsd K-split partials) = d loss / d h_l  ->  relu mask + LayerNorm backward: dz planes = d loss / d z_l
+    hipLaunchKernelGGL(bm_ln_bwd_kernel, dim3(w.n_ln), dim3(256), 0, st, ws + w.dpart, nsd, w.dstride, bm_plo(wb + w.dz, nb, L->h),
+                       ws + w.z[l], ws + w.stat[l], theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart);
     hipLaunchKernelGGL(bm_colreduce_kernel, dim3((3 * L->h + 63) / 64), dim3(1024), 0, st, ws + w.lnpart, w.n_ln, 3, L->h,
                        grad + L->off_lns[l], grad + L->off_lnb[l], grad + L->off_b[l]);
     const int kin = l ? L->h : L->d;
-    const BmOperand dZ = bm_op(dz, L->h, nb, L->h);
-    const BmOperand Hin = l ? bm_op(ws + w.h[l - 1], L->h, nb, L->h) : bm_op(ws + w.xn, w.ldx, nb, L->d);
-    rc = wgrad(kin, Hin, dZ, L->h, grad + L->off_w[l]);   // d W_l = h_{l-1}^T dZ_l
+    const BmPlanes dZ = bm_pl(wb + w.dz, nb, L->h);
+    bm_transpose(dZ, L->h, bm_plo(wb + w.dzT, L->h, w.nbp), st);
+    rc = wgrad(kin, hT(l - 1), bm_pl(wb + w.dzT, L->h, w.nbp), L->h, grad + L->off_w[l]);   // d W_l = h_{l-1}^T dZ_l
     if (rc != PQN_OK) return rc;
-    const BmOperand W = bm_op(theta + L->off_w[l], L->h, kin, L->h);
+    const BmPlanes Wn = bm_pl(wpl + wp.wn[l], kin, L->h);   // rows = input feature, K = output feature
     if (l > 0) {   // d h_{l-1} = dZ_l W_l^T
-      rc = bm_gemm<false, false>(nb, kin, L->h, dZ, W, bm_store(ws + w.dpart, L->h, nullptr, w.dstride), BM_MAX_SPLIT, &nsd, st);
+      rc = bm_gemm(nb, kin, L->h, dZ, Wn, bm_store(ws + w.dpart, L->h, nullptr, w.dstride), BM_MAX_SPLIT, &nsd, st);
       if (rc != PQN_OK) return rc;
     } else if (coef) {
       // d (input-normalisation scale, bias): column sums of (dZ_0 W_0^T) xhat and of dZ_0 W_0^T over the nb rows
       BmEpilogue E = {};
       E.out = ws + w.inpart; E.xhat = ws + w.xhat; E.ldx = w.ldx;
       const BmPlan p = bm_plan(nb, kin, L->h, BM_MAX_SPLIT);
-      const int klen = ((L->h + p.nsplit - 1) / p.nsplit + BM_KS - 1) / BM_KS * BM_KS;
-      const int nz = (L->h + klen - 1) / klen;
-      rc = bm_launch<64, false, false, BM_EPI_INNORM>(nb, kin, L->h, p.nsplit, dZ, W, E, st);
+      rc = bm_launch<BM_EPI_INNORM>(nb, kin, L->h, p, dZ, Wn, E, st);
       if (rc != PQN_OK) return rc;
-      hipLaunchKernelGGL(bm_colreduce_kernel, dim3((2 * L->d + 63) / 64), dim3(1024), 0, st, ws + w.inpart, nz * w.n_in, 2, L->d,
+      hipLaunchKernelGGL(bm_colreduce_kernel, dim3((2 * L->d + 63) / 64), dim3(1024), 0, st, ws + w.inpart, p.nsplit * ((nb + p.bm - 1) / p.bm), 2, L->d,
                          grad + L->off_in_scale, grad + L->off_in_bias, (float *)nullptr);
     }
   }
   return pqn_check_launch("pqn_bigmlp_grad");
 }
 
-// where a forward intermediate lives in the workspace (tests / debugging): what 0 = normalised input xn [rows][ld],
-// 1 = pre-activation z_l [rows][h], 2 = activation h_l = relu(LN(z_l)) [rows][h], 3 = (mean, rstd) of z_l [rows][2], 4 = q [rows][ld]
+// where a forward intermediate lives in the workspace (tests / debugging).  f32 tensors (what 1 = pre-activation z_l
+// [rows][h], 3 = (mean, rstd) of z_l [rows][2], 4 = q [rows][ld]): *offset in floats.  bf16 plane triples (what 0 = the
+// normalised input [rows][ld], 2 = h_l = relu(LN(z_l)) [rows][h]): *offset in bf16 elements from the start of the
+// workspace, the three planes rows * ld elements apart; value = hi + mid + lo.
 extern "C" int pqn_bigmlp_workspace_view(const pqn_bigmlp_layout_t *L, int32_t rows, int32_t nb, int32_t what, int32_t layer,
                                          int64_t *offset, int64_t *ld) {
   PQN_REQUIRE(L && offset && ld && rows > 0 && nb > 0 && nb <= rows && layer >= 0 && layer < L->layers && what >= 0 && what <= 4,
               "pqn_bigmlp_workspace_view: bad arguments");
   const BmWs w = bm_ws(*L, rows, nb);
   switch (what) {
-    case 0: *offset = w.xn; *ld = w.ldx; break;
+    case 0: *offset = 2 * w.f_total + w.xn; *ld = w.dp; break;
     case 1: *offset = w.z[layer]; *ld = L->h; break;
-    case 2: *offset = w.h[layer]; *ld = L->h; break;
+    case 2: *offset = 2 * w.f_total + w.h[layer]; *ld = L->h; break;
     case 3: *offset = w.stat[layer]; *ld = 2; break;
     default: *offset = w.q; *ld = w.ldq; break;
   }
   return PQN_OK;
 }
 
-// C[M][N] = op(A) op(B) (+ bias[N]) with f32-grade bf16x3 products -- the GEMM every Dense layer above runs (one K split),
-// exposed for tests against a plain f32 / f64 matmul.  trans_a: A is stored [K][M] (else [M][K]); trans_b: B is stored
-// [K][N] (else [N][K]).  nsplit > 1: K-split partial outputs, `c` then holds nsplit x [M][ldc] partials split_stride apart.
+static unsigned long long *g_bm_stamps = nullptr;   // profiling: PQN_BM_STAMPS=1
+extern "C" int pqn_debug_bm_stamps(unsigned long long *out /* host, 128 entries */) {
+  if (!g_bm_stamps) return PQN_E_INVALID;
+  if (hipMemcpy(out, g_bm_stamps, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return PQN_E_HIP;
+  return PQN_OK;
+}
+
+extern "C" int64_t pqn_bigmlp_gemm_scratch_floats(int32_t m, int32_t n, int32_t k) {
+  if (m <= 0 || n <= 0 || k <= 0) return -1;
+  const long long kp = bm_pad32(k);
+  const long long tmp = 3ll * k * max(bm_pad32(m), bm_pad32(n));
+  return (3 * ((long long)m * kp + (long long)n * kp) + tmp) / 2 + 64;
+}
+
 extern "C" int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, int64_t lda, int32_t trans_a, const float *b,
                                int64_t ldb, int32_t trans_b, const float *bias, float *c, int64_t ldc, int32_t nsplit,
-                               int64_t split_stride, int32_t tile_rows, void *stream) {
-  PQN_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0 && nsplit >= 1 && nsplit <= BM_MAX_SPLIT && (tile_rows == 64 || tile_rows == 128),
-              "pqn_bigmlp_gemm: bad arguments");
+                               int64_t split_stride, int32_t tile_rows, float *scratch, void *stream) {
+  PQN_REQUIRE(a && b && c && scratch && m > 0 && n > 0 && k > 0 && nsplit >= 1 && nsplit <= BM_MAX_SPLIT &&
+                  (tile_rows == 64 || tile_rows == 128), "pqn_bigmlp_gemm: bad arguments");
   PQN_REQUIRE(nsplit == 1 || !bias, "pqn_bigmlp_gemm: the bias belongs to the consumer of K-split partials");
   hipStream_t st = (hipStream_t)stream;
-  const BmOperand A = trans_a ? bm_op(a, lda, k, m) : bm_op(a, lda, m, k);
-  const BmOperand B = trans_b ? bm_op(b, ldb, k, n) : bm_op(b, ldb, n, k);
-  const BmEpilogue E = bm_store(c, ldc, bias, split_stride);
-#define BM_T(TA_, TB_) (tile_rows == 128 ? bm_launch<128, TA_, TB_, BM_EPI_STORE>(m, n, k, nsplit, A, B, E, st) \
-                                         : bm_launch<64, TA_, TB_, BM_EPI_STORE>(m, n, k, nsplit, A, B, E, st))
-  if (trans_a) return trans_b ? BM_T(true, true) : BM_T(true, false);
-  return trans_b ? BM_T(false, true) : BM_T(false, false);
-#undef BM_T
+  const int kp = bm_pad32(k);
+  bf16_t *pa = reinterpret_cast<bf16_t *>(scratch);
+  bf16_t *pb = pa + bm_pl_elems(m, kp), *tmp = pb + bm_pl_elems(n, kp);
+  // -> planes [rows_out][kp] with K contiguous; a source stored [k][rows_out] is split as it lies, then transposed
+  auto prep = [&](const float *src, long long ld, bool k_major, int rows_out, bf16_t *dst) {
+    if (!k_major) {
+      bm_split(src, ld, rows_out, k, bm_plo(dst, rows_out, kp), st);
+    } else {
+      const int rp = bm_pad32(rows_out);
+      bm_split(src, ld, k, rows_out, bm_plo(tmp, k, rp), st);
+      bm_transpose(bm_pl(tmp, k, rp), rows_out, bm_plo(dst, rows_out, kp), st);
+    }
+  };
+  prep(a, lda, trans_a != 0, m, pa);
+  prep(b, ldb, trans_b != 0, n, pb);
+  BmPlan p;
+  p.bm = tile_rows;
+  p.klen = ((kp + nsplit - 1) / nsplit + BM_KS - 1) / BM_KS * BM_KS;
+  p.nsplit = (kp + p.klen - 1) / p.klen;
+  BmEpilogue E = bm_store(c, ldc, bias, split_stride);
+  if (getenv("PQN_BM_STAMPS")) {
+    if (!g_bm_stamps && (hipMalloc(&g_bm_stamps, 128 * sizeof(unsigned long long)) != hipSuccess ||
+                         hipMemset(g_bm_stamps, 0, 128 * sizeof(unsigned long long)) != hipSuccess)) g_bm_stamps = nullptr;
+    E.stamps = g_bm_stamps;
+  }
+  return bm_launch<BM_EPI_STORE>(m, n, kp, p, bm_pl(pa, m, kp), bm_pl(pb, n, kp), E, st);
 }

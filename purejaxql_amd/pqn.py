@@ -314,7 +314,7 @@ class _FusedBigMlpPolicy:
             name = bn_module(self.net.renorm) + "_0"
             stats = {name + "/mean": self.tr.in_mean, name + "/var": self.tr.in_var}
             if self.net.renorm:
-                stats[name + "/steps"] = self.tr.in_steps[0]
+                stats[name + "/steps"] = self.tr.in_steps[0]     # [1] is kernel scratch
         return {"opt_count": self.tr.count, "opt_mu": self.tr.m, "opt_nu": self.tr.v, "kernel_layout": self.layout,
                 "batch_stats": stats}
 

@@ -602,8 +602,8 @@ class BigMlpLayoutStruct(C.Structure):
 
 def bigmlp_supported(obs_dim: int, hidden: int, layers: int, num_actions: int) -> bool:
     """Shapes csrc/pqn_bigmlp.hip tiles (pqn_bigmlp_layout rejects the rest)."""
-    return obs_dim >= 8 and 256 <= hidden <= 4096 and hidden % 256 == 0 and 1 <= layers <= BIGMLP_MAX_LAYERS and \
-        1 <= num_actions <= 64
+    return obs_dim >= 8 and 256 <= hidden <= 2048 and hidden % 256 == 0 and 1 <= layers <= BIGMLP_MAX_LAYERS and \
+        1 <= num_actions <= 32
 
 
 class BigMlpKernelLayout:
@@ -661,8 +661,16 @@ class BigMlpTrainer:
         # batch_stats of the input normalisation: running mean 0 / var 1, BatchRenorm's step counter
         self.in_mean = torch.zeros(layout.d, dtype=torch.float32, device=dev)
         self.in_var = torch.ones(layout.d, dtype=torch.float32, device=dev)
-        self.in_steps = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.in_steps = torch.zeros(2, dtype=torch.int32, device=dev)   # [train-call counter, kernel scratch]
         self._ws = {}
+        # bf16 operand planes of the Dense kernels (hi / mid / lo, natural + transposed), refreshed after every step
+        n_wp = int(_lib.load().pqn_bigmlp_weight_plane_floats(C.byref(layout.struct)))
+        self.wplanes = torch.zeros(n_wp, dtype=torch.float32, device=dev)
+        self.refresh_planes()
+
+    def refresh_planes(self):
+        _lib.check(_lib.load().pqn_bigmlp_refresh_planes(C.byref(self.layout.struct), _lib.ptr(self.theta), _lib.ptr(self.wplanes),
+                                                         _lib.stream_ptr()), "pqn_bigmlp_refresh_planes")
 
     def _workspace(self, rows: int, nb: int) -> torch.Tensor:
         sid = _lib.stream_ptr()   # one workspace per stream: seeds may run as concurrent streams
@@ -675,13 +683,16 @@ class BigMlpTrainer:
         return ws
 
     def intermediate(self, rows: int, nb: int, what: str, layer: int = 0) -> torch.Tensor:
-        """A forward intermediate of the last forward / compute_grad call on this stream (pqn_bigmlp_workspace_view):
-        what = "xn" | "z" | "h" | "stat" | "q"."""
+        """A forward intermediate of the last forward / compute_grad call on this stream (pqn_bigmlp_workspace_view), as an
+        f32 tensor: what = "xn" | "z" | "h" | "stat" | "q" (plane triples are summed back: hi + mid + lo is exact)."""
         off, ld = C.c_int64(0), C.c_int64(0)
         code = {"xn": 0, "z": 1, "h": 2, "stat": 3, "q": 4}[what]
         _lib.check(_lib.load().pqn_bigmlp_workspace_view(C.byref(self.layout.struct), rows, nb, code, layer, C.addressof(off),
                                                          C.addressof(ld)), "pqn_bigmlp_workspace_view")
         ws = self._ws[_lib.stream_ptr()]
+        if code in (0, 2):
+            planes = ws.view(torch.bfloat16)[off.value:off.value + 3 * rows * ld.value].view(3, rows, ld.value)
+            return planes[0].float() + planes[1].float() + planes[2].float()
         return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)
 
     def forward(self, obs: torch.Tensor, *, want_q: bool = True, eps: Optional[float] = None, key: int = 0, q=None,
@@ -698,7 +709,7 @@ class BigMlpTrainer:
             qmax = torch.empty(n, dtype=torch.float32, device=dev)
         ws = self._workspace(n, n)
         use_stats = self.layout.norm_input != 0
-        _lib.check(lib.pqn_bigmlp_forward(C.byref(self.layout.struct), n, _lib.ptr(obs), _lib.ptr(self.theta),
+        _lib.check(lib.pqn_bigmlp_forward(C.byref(self.layout.struct), n, _lib.ptr(obs), _lib.ptr(self.theta), _lib.ptr(self.wplanes),
                                           _lib.ptr(self.in_mean) if use_stats else None,
                                           _lib.ptr(self.in_var) if use_stats else None, _lib.ptr(ws), _lib.ptr(q),
                                           _lib.ptr(action) if eps is not None else None, _lib.ptr(qmax), float(eps or 0.0), key,
@@ -717,7 +728,7 @@ class BigMlpTrainer:
         use_stats = self.layout.norm_input != 0
         _lib.check(lib.pqn_bigmlp_grad(C.byref(self.layout.struct), nb, _lib.ptr(idx), _lib.ptr(obs_flat), int(next_offset),
                                        _lib.ptr(action), _lib.ptr(target), _lib.ptr(reward), _lib.ptr(done), float(gamma),
-                                       _lib.ptr(self.theta), _lib.ptr(self.in_mean) if use_stats else None,
+                                       _lib.ptr(self.theta), _lib.ptr(self.wplanes), _lib.ptr(self.in_mean) if use_stats else None,
                                        _lib.ptr(self.in_var) if use_stats else None,
                                        _lib.ptr(self.in_steps) if use_stats else None, _lib.ptr(self.grad), _lib.ptr(ws),
                                        _lib.ptr(loss_out), _lib.ptr(qv_out), _lib.stream_ptr()), "pqn_bigmlp_grad")
@@ -729,6 +740,7 @@ class BigMlpTrainer:
                                            self.theta.numel(), _lib.ptr(self.count), self.lr, self.lr_end, self.lr_steps,
                                            self.max_norm, _lib.ptr(self.scratch), _lib.ptr(self.gnorm), _lib.stream_ptr()),
                    "pqn_radam_clip_step")
+        self.refresh_planes()
 
     def theta_flax(self) -> torch.Tensor:
         return self.layout.to_flax(self.theta)

@@ -52,15 +52,17 @@ def test_bigmlp_gemm_vs_float64_matmul(gpu, m, n, k, ta, tb, tile, nsplit):
     b_v = b_buf[off:off + b_shape[0] * ldb].view(b_shape[0], ldb)[:, :b_shape[1]]
     bias = torch.randn(n, device=gpu, generator=g) if nsplit == 1 else None
     c = torch.full((nsplit, m, n + 2), 7.0, device=gpu)
+    scratch = torch.empty(int(lib.pqn_bigmlp_gemm_scratch_floats(m, n, k)), device=gpu)
     _lib.check(lib.pqn_bigmlp_gemm(m, n, k, a_v.data_ptr(), lda, ta, b_v.data_ptr(), ldb, tb,
                                    bias.data_ptr() if bias is not None else None, c.data_ptr(), n + 2, nsplit, m * (n + 2), tile,
-                                   _lib.stream_ptr()), "pqn_bigmlp_gemm")
+                                   scratch.data_ptr(), _lib.stream_ptr()), "pqn_bigmlp_gemm")
     a64 = (a_v.T if ta else a_v).double()
     b64 = (b_v if tb else b_v.T).double()
     ref = a64 @ b64 + (bias.double() if bias is not None else 0.0)
     bound = 4e-7 * (a64.abs() @ b64.abs() + (bias.abs().double() if bias is not None else 0.0)) + 1e-30
-    klen = -(-(-(-k // nsplit)) // 32) * 32      # ceil(ceil(k / nsplit) / 32) * 32: the split the library takes
-    used = -(-k // klen)
+    kp = -(-k // 32) * 32                        # K padded to the 32-wide MFMA step
+    klen = -(-(-(-kp // nsplit)) // 32) * 32     # ceil(ceil(kp / nsplit) / 32) * 32: the split the library takes
+    used = -(-kp // klen)
     err = (c[:used, :, :n].double().sum(0) - ref).abs()
     assert bool((err <= bound).all()), float((err / bound).max())
     assert bool((c[:, :, n:] == 7.0).all())      # nothing written beyond the n valid columns
@@ -124,7 +126,7 @@ def test_bigmlp_one_step_loss_grad_vs_oracle(gpu, oracle, d, h, layers, a, nb, n
         steps = 1500 if warm else 3
         tr.in_mean.copy_(torch.from_numpy(rm))
         tr.in_var.copy_(torch.from_numpy(rv))
-        tr.in_steps.fill_(steps)
+        tr.in_steps[0] = steps
         stats = {bn0 + "/mean": rm.copy(), bn0 + "/var": rv.copy()}
         if renorm:
             stats[bn0 + "/steps"] = steps
@@ -173,7 +175,7 @@ def test_bigmlp_one_step_loss_grad_vs_oracle(gpu, oracle, d, h, layers, a, nb, n
             assert int(tr.in_steps[0]) == new_stats[bn0 + "/steps"]
     # repeat: bit-identical gradient (fixed summation orders); then clip + RAdam == oracle step on the flax-flat vector
     if norm_input:
-        tr.in_mean.copy_(torch.from_numpy(rm)); tr.in_var.copy_(torch.from_numpy(rv)); tr.in_steps.fill_(steps)
+        tr.in_mean.copy_(torch.from_numpy(rm)); tr.in_var.copy_(torch.from_numpy(rv)); tr.in_steps[0] = steps
     g2 = tr.compute_grad(torch.from_numpy(idx).to(gpu), torch.from_numpy(obs_all).to(gpu), torch.from_numpy(action).to(gpu),
                          reward=torch.from_numpy(reward).to(gpu), done=torch.from_numpy(done).to(gpu), gamma=0.99,
                          next_offset=n_env)

@@ -23,7 +23,7 @@ obs_all = (rng.standard_normal((rows, d)) * (rng.random(d) * 1.5) + 0.3 * rng.st
 action = rng.integers(0, a, nb).astype(np.int32); reward = rng.standard_normal(nb).astype(np.float32); done = rng.random(nb) < 0.2
 idx = rng.permutation(nb).astype(np.int64)
 stats = {"BatchRenorm_0/mean": np.zeros(d, np.float32), "BatchRenorm_0/var": np.ones(d, np.float32), "BatchRenorm_0/steps": 3}
-tr.in_steps.fill_(3)
+tr.in_steps[0] = 3
 g = tr.compute_grad(torch.from_numpy(idx).to(gpu), torch.from_numpy(obs_all).to(gpu), torch.from_numpy(action).to(gpu),
                     reward=torch.from_numpy(reward).to(gpu), done=torch.from_numpy(done).to(gpu), gamma=0.99, next_offset=n_env)
 lo, chosen, g_ref = O.net_loss_grad_1step("mlp", p, shapes, obs_all[idx], obs_all[idx + n_env], action[idx], reward[idx], done[idx], 0.99,
