@@ -534,6 +534,16 @@ PQN_D void phase2_fc1(const CnnSmem &s, const float *__restrict__ w1p, int tid, 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 PQN_D f16x4 to_f16x4(const f32x4 v) { return f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
+// v_mfma_f32_16x16x16_f16 with the accumulator TIED, as volatile inline asm -- the same discipline as x3_mfma_tied (the
+// builtin let the compiler give this instruction a destination tuple partially overlapping its accumulator input in the
+// 7- and 10-channel kernels, tools/check_mfma_overlap.py; the bf16 form of that pattern produced run-to-run different
+// results).  `s_nop 1` covers a VALU-written operand; the result is read only by the next tied MFMA or after f16_drain.
+PQN_D f32x4 f16_mfma_tied(const f16x4 &a, const f16x4 &b, f32x4 c) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+}
+PQN_D void f16_drain(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b)); }
+PQN_D void f16_drain(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 
 template <int PF = 16>
 PQN_D void phase2_fc1_f16(const CnnSmem &s, const _Float16 *__restrict__ w1h, int tid, int tile = -1) {
@@ -556,8 +566,8 @@ PQN_D void phase2_fc1_f16(const CnnSmem &s, const _Float16 *__restrict__ w1h, in
       const f32x4 a1 = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 1 + rot) & 63));
       a_next = *reinterpret_cast<const f32x4 *>(arow + 16 * ((g + i + 2 + rot) & 63));
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x16f16(to_f16x4(a0), b[i], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x16f16(to_f16x4(a1), b[i + 1], acc2, 0, 0, 0);
+      acc = f16_mfma_tied(to_f16x4(a0), b[i], acc);
+      acc2 = f16_mfma_tied(to_f16x4(a1), b[i + 1], acc2);
       if (more) {
         b[i] = wp[(((g + i + PF + rot) & 63) * 8 + wave) * 64 + lane];
         b[i + 1] = wp[(((g + i + 1 + PF + rot) & 63) * 8 + wave) * 64 + lane];
@@ -568,6 +578,7 @@ PQN_D void phase2_fc1_f16(const CnnSmem &s, const _Float16 *__restrict__ w1h, in
 #pragma unroll 1
   for (int g = 0; g < QN_H1 / 16 - PF; g += PF) group_block(g, std::true_type{});
   group_block(QN_H1 / 16 - PF, std::false_type{});
+  f16_drain(acc, acc2);
   acc += acc2;
   const int col = lane & 15, r0 = 4 * (lane >> 4);
   float *zp = s.z + r0 * QN_ZS + 16 * wave + col;
@@ -2121,14 +2132,15 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 8; g += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(afr[g], ring[8 * h + g], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(afr[g + 1], ring[8 * h + g + 1], acc1, 0, 0, 0);
+          acc0 = f16_mfma_tied(afr[g], ring[8 * h + g], acc0);
+          acc1 = f16_mfma_tied(afr[g + 1], ring[8 * h + g + 1], acc1);
           if (more) {
             ring[8 * h + g] = frag(16 * (ip + 1) + 8 * h + g);
             ring[8 * h + g + 1] = frag(16 * (ip + 1) + 8 * h + g + 1);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        f16_drain(acc0, acc1);
         acc0 = (acc0 + acc1) * isc;
         p0[0] = m0 > 0.0f ? acc0.x : 0.0f;
         p0[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
@@ -3258,9 +3270,10 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_f16_kernel(int nb, 
 #pragma unroll
       for (int a = 0; a < 4; ++a) a4[a] = *reinterpret_cast<const f16x4 *>(t + (16 * a + o) * RS + 16 * g + kq);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[a], b, acc[a], 0, 0, 0);
+      for (int a = 0; a < 4; ++a) acc[a] = f16_mfma_tied(a4[a], b, acc[a]);
     }
   }
+  f16_drain(acc[0], acc[1], acc[2], acc[3]);
   f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
 #pragma unroll
   for (int a = 0; a < 4; ++a) out[((4 * it + a) * 8 + cb) * 64 + lane] = acc[a] * inv_scale;

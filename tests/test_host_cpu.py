@@ -108,6 +108,18 @@ def test_run_time_options_and_kernel_form_query():
     assert _lib.last_kernel_form() == ("none", "none")
 
 
+def test_no_mfma_with_partially_overlapping_accumulator_in_any_kernel():
+    """Compiler finding 2 of DESIGN.md: a v_mfma whose destination tuple partially overlaps its accumulator input gave
+    run-to-run different results on MI355X.  Every MFMA of the bf16x3 / fp16 / wide-MLP paths is therefore issued as tied
+    inline asm; tools/check_mfma_overlap.py compiles every csrc/*.hip to gfx950 assembly and scans for the pattern."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_overlap.py")], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert out.stdout.count(" 0 partially overlapping") >= 7, out.stdout
+
+
 def test_header_is_plain_c(tmp_path):
     """include/pqn_hotpath.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch / HIP types) and a
     C translation unit must be able to reference every declared entry point."""
