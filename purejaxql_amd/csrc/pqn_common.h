@@ -82,7 +82,6 @@ enum {
   PQN_OPT_SEED_GROUP,     // PQN_SEED_GROUP: seeds per T1 -> T2 launch pair (0 = all)
   PQN_OPT_ABLATE_TRAIN,   // PQN_ABLATE_TRAIN: phase ablation mask of the training kernels (profiling)
   PQN_OPT_ABLATE,         // PQN_ABLATE: phase ablation of the forward kernel (profiling)
-  PQN_OPT_FUSED_TAIL,     // PQN_FUSED_TAIL: optimizer tail 0 = reduce + RAdam kernels / 1 = one ticketed kernel
   PQN_OPT_BM_TILE,        // PQN_BM_TILE: tile height of the wide-MLP GEMMs (0 auto, 64, 128)
   PQN_OPT_BM_SPLIT,       // PQN_BM_SPLIT: K splits of the wide-MLP GEMMs (0 auto, 1 .. 4)
   PQN_OPT_COUNT
