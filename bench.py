@@ -349,6 +349,57 @@ def main():
         if extras:
             from purejaxql_amd.profiling import env_step_hbm_roofline
             guarded("roofline_env_step", lambda: [env_step_hbm_roofline(n, dev) for n in (4096, 65536, 262144)])
+        if extras:
+            def craftax_c5():
+                """BASELINE.json configs[4]: Craftax-Classic at the yaml shape, whole loop through pqn_bigmlp_update."""
+                import ctypes
+                from purejaxql_amd.config_loader import flatten, load_config
+                c5 = flatten(load_config(["+alg=pqn_craftax", "alg.ENV_NAME=Craftax-Classic-Symbolic-v1"]))
+                n5, warm5, steps5 = c5["NUM_ENVS"], 40, 400
+                c5["TOTAL_TIMESTEPS"] = (warm5 + steps5 + 8) * n5 * c5["NUM_STEPS"]
+                c5["TOTAL_TIMESTEPS_DECAY"] = c5["TOTAL_TIMESTEPS"]
+                c5["TEST_DURING_TRAINING"] = False
+                tr5 = make_train(c5, device=str(dev), script="craftax")
+                upd5, _fin5 = tr5.make_runner(seed_keys(0, 1)[0])
+                d5 = timed_updates(upd5, steps5, warm5)
+                drv5 = getattr(upd5, "driver", None)
+                mode5 = None if drv5 is None else ("hipGraph replay" if drv5.graph is not None else "C++ enqueue (eager)")
+                # the GEMM kernel under HIP events: 4 more updates through the eager enqueue (events cannot be captured)
+                if drv5 is not None:
+                    drv5.graph, drv5.use_graph = None, False
+                _lib.check(lib.pqn_prof_enable(2), "pqn_prof_enable")
+                for u in range(warm5 + steps5, warm5 + steps5 + 4):
+                    upd5(u)
+                torch.cuda.synchronize()
+                cnt, tot = ctypes.c_int32(0), ctypes.c_float(0.0)
+                _lib.check(lib.pqn_prof_read(ctypes.byref(cnt), ctypes.byref(tot)), "pqn_prof_read")
+                lib.pqn_prof_enable(0)
+                d_in, h5, l5, a5 = 1345, c5["HIDDEN_SIZE"], c5["NUM_LAYERS"], 17
+                per_row = 2.0 * (d_in * h5 + (l5 - 1) * h5 * h5 + h5 * a5)            # forward = weight gradient FLOP per row
+                # input gradients: below the first layer only when the input normalisation trains (its scale / bias gradient)
+                dgrad_row = per_row if c5.get("NORM_INPUT") else 2.0 * ((l5 - 1) * h5 * h5 + h5 * a5)
+                nb5 = n5 * c5["NUM_STEPS"] // c5["NUM_MINIBATCHES"]
+                flop_upd = per_row * n5 * c5["NUM_STEPS"] + c5["NUM_MINIBATCHES"] * c5["NUM_EPOCHS"] * (
+                    per_row * 2 * nb5 + dgrad_row * nb5 + per_row * nb5)
+                gemm_s = tot.value * 1e-3 / 4
+                ach = flop_upd / gemm_s / 1e12
+                return {"workload": f"Craftax-Classic-Symbolic-v1 PQN at config/alg/pqn_craftax.yaml's shape: {n5} envs, "
+                                    f"{c5['NUM_STEPS']} step x {c5['NUM_MINIBATCHES']} minibatch x {c5['NUM_EPOCHS']} epoch, 1345 -> "
+                                    f"{l5} x {h5} -> 17 LayerNorm MLP with BatchRenorm input, 1-step loss, optimistic resets",
+                        "value": n5 * c5["NUM_STEPS"] * steps5 / d5, "unit": "env-steps/s", "ms_per_update": d5 / steps5 * 1e3,
+                        "backend": tr5.backend, "driver": mode5, "updates_timed": steps5,
+                        "roofline": {"kernel": "bm_gemm_kernel<128|64, 64> (every Dense product of the update: forward of the "
+                                               "rollout batch and of concat(obs, next_obs), input and weight gradients)",
+                                     "bound": "mfma", "achieved": ach, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": ach / F32_PEAK_TFLOPS, "traffic": None,
+                                     "flop_per_update": flop_upd, "gemm_us_per_update": gemm_s * 1e6,
+                                     "gemm_launches_per_update": cnt.value / 4,
+                                     "bf16_pipe": {"issued_tflops": ach * 6.0, "peak": BF16_PEAK_TFLOPS,
+                                                   "frac": ach * 6.0 / BF16_PEAK_TFLOPS},
+                                     "peak_note": "algorithmic f32 FLOPs (2 M N K on the unpadded shapes) against the f32 MFMA / "
+                                                  "vector peak; bf16_pipe prices the 6 bf16 products per f32 product against "
+                                                  "the dense bf16 peak"}}
+            guarded("craftax_c5", craftax_c5)
         if extras and fused:
             def other_modes():
                 res = {}

@@ -222,9 +222,11 @@ int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *layout /* host */, float *theta, 
  * for a matmul_f16 layout, the two fp16 copies in theta's own tail.  Call after writing parameters by hand. */
 int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *layout /* host */, float *theta, float *w1b, void *stream);
 
-/* Kernel timer for bench.py's roofline line: when enabled, pqn_qnet_cnn_grad brackets its dominant
- * kernel (qnet_cnn_train_kernel) with HIP events on the launch stream; pqn_prof_read synchronises
- * on them and returns the number of timed launches and their summed duration, then resets. */
+/* Kernel timer for bench.py's roofline lines: on = 1, pqn_qnet_cnn_grad brackets its dominant kernel
+ * (qnet_cnn_train_kernel) with HIP events on the launch stream; on = 2, every launch of the wide-MLP GEMM
+ * kernel (pqn_bigmlp_forward / _grad / _gemm) is bracketed instead; 0 = off.  pqn_prof_read synchronises on the
+ * events and returns the number of timed launches and their summed duration, then resets.  Not capturable in a
+ * hipGraph: time eager enqueues. */
 int pqn_prof_enable(int32_t on);
 int pqn_prof_read(int32_t *count /* host */, float *total_ms /* host */);
 
@@ -467,6 +469,51 @@ int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *layout /* host */, int32_t nb, co
                     const uint8_t *done, float gamma, const float *theta, const float *wplanes, float *in_mean,
                     float *in_var, int32_t *in_steps, float *grad, float *workspace, float *loss_out, float *qv_out,
                     void *stream);
+/* ONE whole update of the Craftax script's loop (`_update_step`, pqn_craftax.py:176-399) enqueued from C++ -- the wide-MLP
+ * twin of pqn_mlp_update: same device-side clock / key schedule / metrics row, hipGraph-capturable.  What differs from the
+ * gymnax script: the env is batched by a wrapper (reset_ratio > 0: OptimisticResetVecEnvWrapper(LogWrapper(env)), :99-108;
+ * 0: BatchEnvWrapper = auto-reset, :109-114); `q_lambda` = 0 selects the 1-step loss on concat(obs, next_obs) (:287-304,
+ * no bootstrap forward, no Q(lambda) scan: nothing consumes them); `done_weighted_info` = 1 writes the info columns of the
+ * metrics row as (x * returned_episode).sum() / returned_episode.sum() (:364-369; NaN when no episode finished).
+ * obs f32 [T+1][N][d], slot 0 = current observation on entry and exit. */
+typedef struct {
+  int32_t env_id, num_envs, num_steps, num_minibatches, num_epochs, metrics_capacity;
+  int32_t reset_ratio, q_lambda, done_weighted_info;
+  float gamma, lambda, rew_scale;
+  float eps_start, eps_finish;
+  float lr_init, lr_end, max_grad_norm;
+  double eps_decay_steps, lr_steps;
+  uint64_t key_roll, key_shuf;
+  uint64_t sort_temp_bytes;
+  pqn_bigmlp_layout_t layout;
+  int32_t *clock;        /* [4] */
+  uint64_t *sched_keys;  /* [num_steps + num_epochs] scratch */
+  float *sched_eps;      /* [1] scratch */
+  uint32_t *state;       /* [state_words][N], stepped in place */
+  float *obs;            /* [T+1][N][d] */
+  int32_t *action;       /* [T][N] */
+  float *reward;         /* [T][N] (scaled by rew_scale) */
+  uint8_t *done;         /* [T][N] */
+  float *qmax;           /* [T][N] */
+  float *discount, *rer; /* [T][N] */
+  int32_t *rel, *ts;     /* [T][N] */
+  float *target;         /* [T][N] (q_lambda = 1) */
+  float *last_q;         /* [N]    (q_lambda = 1) */
+  int64_t *sort_keys_in, *sort_keys_out; /* [T*N]; sort_keys_out ends up as the epoch's permutation */
+  void *sort_temp;       /* pqn_update_sort_temp_bytes(T*N) bytes */
+  uint64_t *opt_scratch; /* [N] sort keys of the optimistic resets (reset_ratio > 0) */
+  float *theta, *wplanes, *grad, *m, *v; /* pqn_bigmlp_layout buffers; wplanes as for pqn_bigmlp_forward */
+  int32_t *count;        /* [1] optimizer step counter */
+  float *in_mean, *in_var; /* [d] running statistics of the input normalisation (norm_input != 0) */
+  int32_t *in_steps;     /* [2] */
+  float *workspace;      /* max over pqn_bigmlp_workspace_floats(layout, N, N) and (layout, rows, B): B = T*N/num_minibatches,
+                            rows = 2 B for the 1-step loss, B for Q(lambda) */
+  float *radam_scratch;  /* [1024] */
+  float *loss_buf, *qv_buf; /* [num_minibatches*num_epochs] */
+  double *metrics;       /* [metrics_capacity][PQN_NUM_METRICS] (env_frame is written as env_step) */
+} pqn_bigmlp_update_args_t;
+int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *args /* host */, void *stream);
+
 /* Where a forward intermediate of the last pqn_bigmlp_forward / pqn_bigmlp_grad call lives inside `workspace`, for
  * tests (e.g. to compare relu decisions with a reference forward).  f32 tensors -- what 1 = z_layer [rows][h], 3 = (mean,
  * rstd) of z_layer, 4 = q: *offset in floats.  bf16 plane triples -- what 0 = the normalised input, 2 = h_layer =

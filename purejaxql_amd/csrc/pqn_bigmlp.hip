@@ -818,8 +818,10 @@ int bm_launch(int M, int N, int Kp, const BmPlan &p, const BmPlanes &A, const Bm
     }                                                                                                                    \
     hipLaunchKernelGGL(kern, grid, dim3(BM_THREADS), lds, st, M, N, Kp, p.klen, A, B, E);                                \
   } while (0)
+  const bool timed = pqn_prof_begin(2, st);
   if (p.bm == 128) BM_GO(128);
   else BM_GO(64);
+  if (timed) pqn_prof_end(st);
 #undef BM_GO
   return pqn_check_launch("pqn_bigmlp gemm");
 }

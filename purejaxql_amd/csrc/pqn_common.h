@@ -164,6 +164,10 @@ int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, in
 // half_off: float offset of the operand-copy region behind the parameters (pqn_cnn_layout_t.off_w1h; 0 = none);
 // copy_mode: 1 = two fp16 copies of the fc1 kernel (matmul_f16), 2 = six bf16 planes (bf16x3)
 
+// kernel timer of pqn_prof_enable(mode) for kernels outside pqn_qnet.hip (mode 2 = the wide-MLP GEMM kernel)
+bool pqn_prof_begin(int mode, hipStream_t st);
+void pqn_prof_end(hipStream_t st);
+
 // Craftax-Classic (pqn_craftax.hip); reset_ratio 0 = gymnax auto-reset, > 0 = optimistic resets (scratch u64[n])
 void pqn_craftax_spec(pqn_env_spec_t *s);
 int pqn_craftax_reset(int n, uint64_t key, uint32_t *state, float *obs, hipStream_t st);
@@ -174,6 +178,9 @@ int pqn_craftax_canon(int n, int do_export, uint32_t *state, int32_t *si, float 
 // internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
                      const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0, int key_stride = 0);
+// OptimisticResetVecEnvWrapper.step (pqn_env_step_optimistic) with the step key in device memory, stepped in place
+int pqn_env_step_optimistic_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, int reset_ratio, uint32_t *state,
+                                const int32_t *action, const pqn_step_out_t &out, uint64_t *scratch, hipStream_t st);
 // shuffle keys of the whole-update driver: keys[i] = rand31(i; *key_dev) << ib | i with ib = pqn_index_bits(n) --
 // the same order as the public pqn_shuffle_keys (rand31 << 32 | i), packed so the sort visits 31 + ib bits only
 int pqn_index_bits(int n);

@@ -499,19 +499,25 @@ __global__ __launch_bounds__(256) void cc_step_kernel(int n, uint64_t key, const
 __global__ __launch_bounds__(256) void cc_reset_kernel(int n, int mode, int reset_ratio, const uint8_t *__restrict__ done,
                                                        const uint64_t *__restrict__ opt_keys, uint32_t *state,
                                                        int32_t *__restrict__ slots) {
+  __shared__ uint64_t s_keys[2048];
   const int e = blockIdx.x * 256 + threadIdx.x;
+  const bool mine_done = e < n && mode != 0 && done[e];
+  int rank = 0;
+  if (mode == 2) {   // rank of a finished env = finished envs with a smaller sort key; the keys go through LDS in chunks
+    const uint64_t mine = mine_done ? opt_keys[e] : 0ull;
+    for (int base = 0; base < n; base += 2048) {
+      const int cnt = min(2048, n - base);
+      __syncthreads();
+      for (int j = threadIdx.x; j < cnt; j += 256) s_keys[j] = opt_keys[base + j];
+      __syncthreads();
+      if (mine_done)
+        for (int j = 0; j < cnt; ++j) rank += s_keys[j] < mine;   // uniform index: an LDS broadcast per iteration
+    }
+  }
   if (e >= n) return;
   int slot = -1;
   if (mode == 0) slot = e;
-  else if (done[e]) {
-    slot = e;
-    if (mode == 2) {
-      const uint64_t mine = opt_keys[e];
-      int rank = 0;
-      for (int j = 0; j < n; ++j) rank += opt_keys[j] < mine;
-      slot = rank < n / reset_ratio ? rank : e / reset_ratio;
-    }
-  }
+  else if (mine_done) slot = mode == 2 ? (rank < n / reset_ratio ? rank : e / reset_ratio) : e;
   slots[e] = slot;
   if (slot < 0) return;
   cc::Scalars s;
@@ -524,19 +530,19 @@ __global__ __launch_bounds__(256) void cc_reset_kernel(int n, int mode, int rese
   }
 }
 
-// thread per (env, map word): the world of every restarting env, 4 cells per thread; e is the fast index => coalesced
+// workgroup per env: the world of a restarting env, 4 map words (16 cells) per thread.  Few envs restart per step, so the
+// parallelism has to come from the cells of one world (a lane-per-env form left one lane of a wave generating 64 cells
+// in sequence: 121 us per step at 1024 envs); the other workgroups leave at once.
 __global__ __launch_bounds__(256) void cc_world_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev, int fold_reset,
                                                        const int32_t *__restrict__ slots, uint32_t *__restrict__ state) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int mw0 = blockIdx.y * 16;            // 16 map words per thread
-  if (e >= n) return;
+  const int e = blockIdx.x;
   const int slot = slots[e];
   if (slot < 0) return;
   if (key_dev) key = *key_dev;
   if (fold_reset) key = pqn_fold(key, 1u);   // optimistic resets draw their worlds from fold_in(key, 1)
   uint32_t o0, o1;
   pqn_bits(key, (uint32_t)slot, cc::ST_WORLD, o0, o1);
-  for (int mw = mw0; mw < mw0 + 16; ++mw) {
+  for (int mw = threadIdx.x; mw < cc::MAP_WORDS; mw += 256) {
     uint32_t w = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -682,7 +688,7 @@ int pqn_craftax_reset(int n, uint64_t key, uint32_t *state, float *obs, hipStrea
   PQN_REQUIRE(slots, "Craftax-Classic: cannot allocate the reset-slot scratch");
   const dim3 g((n + 255) / 256), b(256);
   hipLaunchKernelGGL(cc_reset_kernel, g, b, 0, st, n, 0, 1, (const uint8_t *)nullptr, (const uint64_t *)nullptr, state, slots);
-  hipLaunchKernelGGL(cc_world_kernel, dim3((n + 255) / 256, cc::MAP_WORDS / 16), b, 0, st, n, key, (const uint64_t *)nullptr, 0, slots, state);
+  hipLaunchKernelGGL(cc_world_kernel, dim3(n), b, 0, st, n, key, (const uint64_t *)nullptr, 0, slots, state);
   if (obs) hipLaunchKernelGGL(cc_obs_kernel, dim3(n), b, 0, st, n, state, obs);
   return pqn_check_launch("pqn_env_reset(Craftax-Classic)");
 }
@@ -693,11 +699,10 @@ int pqn_craftax_step(int n, uint64_t key, const uint64_t *key_dev, float rscale,
   int32_t *slots = slot_out ? slot_out : cc_slots(n, st);
   PQN_REQUIRE(slots, "Craftax-Classic: cannot allocate the reset-slot scratch");
   PQN_REQUIRE(out.obs_bits == nullptr, "Craftax-Classic has no packed observation");
-  PQN_REQUIRE(!(reset_ratio > 0 && key_dev), "Craftax-Classic: optimistic resets take the step key by value");
   const dim3 g((n + 255) / 256), b(256);
   hipLaunchKernelGGL(cc_step_kernel, g, b, 0, st, n, key, key_dev, rscale, state, action, out, reset_ratio > 0 ? scratch : (uint64_t *)nullptr);
   hipLaunchKernelGGL(cc_reset_kernel, g, b, 0, st, n, reset_ratio > 0 ? 2 : 1, reset_ratio > 0 ? reset_ratio : 1, out.done, scratch, state, slots);
-  hipLaunchKernelGGL(cc_world_kernel, dim3((n + 255) / 256, cc::MAP_WORDS / 16), b, 0, st, n, key, key_dev, reset_ratio > 0 ? 1 : 0, slots, state);
+  hipLaunchKernelGGL(cc_world_kernel, dim3(n), b, 0, st, n, key, key_dev, reset_ratio > 0 ? 1 : 0, slots, state);
   if (out.obs) hipLaunchKernelGGL(cc_obs_kernel, dim3(n), b, 0, st, n, state, out.obs);
   return pqn_check_launch("pqn_env_step(Craftax-Classic)");
 }

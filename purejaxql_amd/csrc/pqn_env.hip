@@ -34,11 +34,12 @@ PQN_D uint64_t opt_choice_key(uint64_t key, uint32_t e, int done) {
 }
 
 template <class Env, bool MINATAR>
-__global__ __launch_bounds__(256) void opt_reset_kernel(int n, uint64_t key, int reset_ratio,
+__global__ __launch_bounds__(256) void opt_reset_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev, int reset_ratio,
                                                         const uint64_t *__restrict__ opt_keys, uint32_t *state,
                                                         pqn_step_out_t out, int32_t *__restrict__ slot_out) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  if (key_dev) key = *key_dev;
   const uint64_t mine = opt_keys[e];
   int slot = -1;
   if (mine != ~(uint64_t)0) {
@@ -330,6 +331,30 @@ extern "C" int pqn_env_step(int env_id, int32_t n, uint64_t key, const uint32_t 
   return dispatch<false>(env_id, n, key, nullptr, 1.0f, state_in, state_out, action, *out, (hipStream_t)stream);
 }
 
+static int step_optimistic(int env_id, int n, uint64_t key, const uint64_t *key_dev, float rscale, int reset_ratio,
+                           const uint32_t *state_in, uint32_t *state_out, const int32_t *action, const pqn_step_out_t &out,
+                           uint64_t *scratch, int32_t *slot_out, hipStream_t st) {
+  if (env_id == PQN_ENV_CRAFTAX_CLASSIC) {
+    PQN_REQUIRE(state_in == state_out, "Craftax-Classic steps its state in place: state_in must equal state_out");
+    return pqn_craftax_step(n, key, key_dev, rscale, state_out, action, out, reset_ratio, scratch, slot_out, st);
+  }
+  const int rc = dispatch<false>(env_id, n, key, key_dev, rscale, state_in, state_out, action, out, st, 0, 0, scratch);
+  if (rc != PQN_OK) return rc;
+  const dim3 g((n + 255) / 256), b(256);
+#define OPT_RESET(ENV, MIN) hipLaunchKernelGGL((opt_reset_kernel<ENV, MIN>), g, b, 0, st, n, key, key_dev, reset_ratio, scratch, state_out, out, slot_out)
+  switch (env_id) {
+    case PQN_ENV_BREAKOUT: OPT_RESET(Breakout, true); break;
+    case PQN_ENV_ASTERIX: OPT_RESET(Asterix, true); break;
+    case PQN_ENV_FREEWAY: OPT_RESET(Freeway, true); break;
+    case PQN_ENV_SPACEINVADERS: OPT_RESET(SpaceInvaders, true); break;
+    case PQN_ENV_CARTPOLE: OPT_RESET(CartPole, false); break;
+    case PQN_ENV_ACROBOT: OPT_RESET(Acrobot, false); break;
+    default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
+  }
+#undef OPT_RESET
+  return pqn_check_launch("pqn_env_step_optimistic");
+}
+
 extern "C" int pqn_env_step_optimistic(int env_id, int32_t n, uint64_t key, int32_t reset_ratio, const uint32_t *state_in,
                                        uint32_t *state_out, const int32_t *action, const pqn_step_out_t *out,
                                        uint64_t *scratch, int32_t *slot_out, void *stream) {
@@ -338,24 +363,14 @@ extern "C" int pqn_env_step_optimistic(int env_id, int32_t n, uint64_t key, int3
   PQN_REQUIRE(out->reward && out->done, "pqn_env_step_optimistic: out->reward and out->done are required");
   PQN_REQUIRE(reset_ratio > 0 && n % reset_ratio == 0,
               "pqn_env_step_optimistic: reset ratio %d must perfectly divide num envs %d", reset_ratio, n);   // :96-98
-  hipStream_t st = (hipStream_t)stream;
-  if (env_id == PQN_ENV_CRAFTAX_CLASSIC) {
-    PQN_REQUIRE(state_in == state_out, "Craftax-Classic steps its state in place: state_in must equal state_out");
-    return pqn_craftax_step(n, key, nullptr, 1.0f, state_out, action, *out, reset_ratio, scratch, slot_out, st);
-  }
-  const int rc = dispatch<false>(env_id, n, key, nullptr, 1.0f, state_in, state_out, action, *out, st, 0, 0, scratch);
-  if (rc != PQN_OK) return rc;
-  const dim3 g((n + 255) / 256), b(256);
-  switch (env_id) {
-    case PQN_ENV_BREAKOUT: hipLaunchKernelGGL((opt_reset_kernel<Breakout, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
-    case PQN_ENV_ASTERIX: hipLaunchKernelGGL((opt_reset_kernel<Asterix, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
-    case PQN_ENV_FREEWAY: hipLaunchKernelGGL((opt_reset_kernel<Freeway, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
-    case PQN_ENV_SPACEINVADERS: hipLaunchKernelGGL((opt_reset_kernel<SpaceInvaders, true>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
-    case PQN_ENV_CARTPOLE: hipLaunchKernelGGL((opt_reset_kernel<CartPole, false>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
-    case PQN_ENV_ACROBOT: hipLaunchKernelGGL((opt_reset_kernel<Acrobot, false>), g, b, 0, st, n, key, reset_ratio, scratch, state_out, *out, slot_out); break;
-    default: pqn_set_error("unsupported env id %d", env_id); return PQN_E_UNSUPPORTED;
-  }
-  return pqn_check_launch("pqn_env_step_optimistic");
+  return step_optimistic(env_id, n, key, nullptr, 1.0f, reset_ratio, state_in, state_out, action, *out, scratch, slot_out,
+                         (hipStream_t)stream);
+}
+
+// internal (pqn_update.hip): the same with the step key read from device memory, stepped in place, reward scaled at the source
+int pqn_env_step_optimistic_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, int reset_ratio, uint32_t *state,
+                                const int32_t *action, const pqn_step_out_t &out, uint64_t *scratch, hipStream_t st) {
+  return step_optimistic(env_id, n, 0, key_dev, rscale, reset_ratio, state, state, action, out, scratch, nullptr, st);
 }
 
 // internal (pqn_update.hip): step key read from device memory, reward scaled at the source

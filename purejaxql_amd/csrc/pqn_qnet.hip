@@ -3574,9 +3574,17 @@ extern "C" int pqn_cnn_rollout_seeds(int env_id, const pqn_cnn_layout_t *layout,
 #define PQN_PROF_MAX 4096
 static struct {
   bool on = false, created = false;
+  int mode = 0;   // pqn_prof_enable(mode): 1 = the CNN training kernel (T1), 2 = the wide-MLP GEMM kernel
   int n = 0;
   hipEvent_t s[PQN_PROF_MAX], e[PQN_PROF_MAX];
 } g_prof;
+// other translation units (pqn_bigmlp.hip) bracket their kernel with these; begin returns false when this launch is not timed
+bool pqn_prof_begin(int mode, hipStream_t st) {
+  if (!g_prof.on || g_prof.mode != mode || g_prof.n >= PQN_PROF_MAX) return false;
+  (void)hipEventRecord(g_prof.s[g_prof.n], st);
+  return true;
+}
+void pqn_prof_end(hipStream_t st) { (void)hipEventRecord(g_prof.e[g_prof.n++], st); }
 
 extern "C" int pqn_prof_enable(int32_t on) {
   if (on && !g_prof.created) {
@@ -3589,6 +3597,7 @@ extern "C" int pqn_prof_enable(int32_t on) {
     g_prof.created = true;
   }
   g_prof.on = on != 0;
+  g_prof.mode = on;
   g_prof.n = 0;
   return PQN_OK;
 }
@@ -3717,7 +3726,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     pqn_seeds_t sg = sd;
     sg.seed_base = s0;
     const long long wo = (long long)s0 * sd.ws_stride;
-    const bool timed = g_prof.on && g_prof.n < PQN_PROF_MAX;
+    const bool timed = g_prof.on && g_prof.mode == 1 && g_prof.n < PQN_PROF_MAX;
     if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
     if (use_pos) {
       if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {

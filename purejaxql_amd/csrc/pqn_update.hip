@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void update_means_kernel(int count, int n_env,
                                                            const float *__restrict__ rer, const int32_t *__restrict__ rel,
                                                            const int32_t *__restrict__ ts,
                                                            const uint8_t *__restrict__ done, double *__restrict__ partial,
-                                                           long long partial_stride) {
+                                                           long long partial_stride, int weighted = 0) {
   __shared__ double s_part[4];
   const int which = blockIdx.x, chunk = blockIdx.y, seed = blockIdx.z;
   partial += seed * partial_stride;
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void update_means_kernel(int count, int n_env,
       case 3: v = (float)ts[i]; break;
       default: v = (float)done[i]; break;
     }
-    acc += (double)v;
+    // weighted: (x * returned_episode).sum() of pqn_craftax.py:364-369 (column 4 then holds returned_episode.sum())
+    acc += (weighted && !done[i]) ? 0.0 : (double)v;
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void update_means_kernel(int count, int n_env,
 __global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n, int channels, int n_mb_total,
                                    const float *__restrict__ loss_buf, const float *__restrict__ qv_buf,
                                    const double *__restrict__ partial, double *__restrict__ metrics, int capacity,
-                                   long long partial_stride) {
+                                   long long partial_stride, int weighted = 0) {
   const int u = clock[1];
   loss_buf += (size_t)blockIdx.x * n_mb_total;
   qv_buf += (size_t)blockIdx.x * n_mb_total;
@@ -101,7 +102,12 @@ __global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n
     if (threadIdx.x < 5) {
       double s = 0.0;
       for (int c = 0; c < MEANS_CHUNKS; ++c) s += partial[threadIdx.x * MEANS_CHUNKS + c];
-      row[M_DISCOUNT + threadIdx.x] = s / ((double)t_len * (double)n);
+      double den = (double)t_len * (double)n;
+      if (weighted) {   // / returned_episode.sum(): 0 / 0 = NaN when no episode finished, as in the reference
+        den = 0.0;
+        for (int c = 0; c < MEANS_CHUNKS; ++c) den += partial[4 * MEANS_CHUNKS + c];
+      }
+      row[M_DISCOUNT + threadIdx.x] = s / den;
     }
     if (threadIdx.x == 5) {
       double l = 0.0, qv = 0.0;
@@ -430,4 +436,90 @@ extern "C" int pqn_mlp_update_seeds(const pqn_mlp_update_args_t *a, int32_t num_
               "pqn_mlp_update_seeds: strides must be positive multiples of 4 floats");
   return mlp_update_impl(a, num_seeds, key_roll_dev, key_shuf_dev, theta_stride, workspace_stride, wt_stride,
                          (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The Craftax script's twin (pqn_craftax.py:176-399): wrapper-batched env (optimistic resets or auto-reset), the wide
+// LayerNorm MLP through the tiled GEMM kernels of pqn_bigmlp.hip, Q(lambda) or 1-step loss, done-weighted info means.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void keys_to_index_kernel(int64_t *__restrict__ keys, int n, long long mask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keys[i] &= mask;
+}
+
+extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PQN_REQUIRE(a, "pqn_bigmlp_update: args is NULL");
+  PQN_REQUIRE(a->clock && a->sched_keys && a->sched_eps && a->state && a->obs && a->action && a->reward && a->done &&
+                  a->qmax && a->discount && a->rer && a->rel && a->ts && a->sort_keys_in && a->sort_keys_out && a->sort_temp &&
+                  a->theta && a->wplanes && a->grad && a->m && a->v && a->count && a->workspace && a->radam_scratch &&
+                  a->loss_buf && a->qv_buf && a->metrics,
+              "pqn_bigmlp_update: NULL buffer in args");
+  const int N = a->num_envs, T = a->num_steps, MB = a->num_minibatches, EP = a->num_epochs;
+  PQN_REQUIRE(N > 0 && T > 0 && MB > 0 && EP > 0 && T + EP <= 1024, "pqn_bigmlp_update: bad shape N=%d T=%d MB=%d EP=%d", N, T,
+              MB, EP);
+  PQN_REQUIRE(((int64_t)N * T) % MB == 0, "NUM_MINIBATCHES must divide NUM_STEPS*NUM_ENVS");
+  PQN_REQUIRE(a->reset_ratio == 0 || (a->reset_ratio > 0 && N % a->reset_ratio == 0 && a->opt_scratch),
+              "pqn_bigmlp_update: reset ratio %d must perfectly divide num envs %d (and opt_scratch be given)", a->reset_ratio, N);
+  PQN_REQUIRE(!a->q_lambda || (a->target && a->last_q), "pqn_bigmlp_update: the Q(lambda) branch needs target and last_q");
+  const pqn_bigmlp_layout_t &L = a->layout;
+  PQN_REQUIRE(L.norm_input == 0 || (a->in_mean && a->in_var && (L.norm_input == 1 || a->in_steps)),
+              "pqn_bigmlp_update: the input normalisation needs its running statistics");
+  const int B = (int)(((int64_t)N * T) / MB), TN = T * N;
+  const size_t ostride = (size_t)N * L.d;
+
+  hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, (const uint64_t *)nullptr,
+                     (const uint64_t *)nullptr, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps,
+                     (float *)nullptr, 0ll);
+  // SAMPLE PHASE (_step_env scan, pqn_craftax.py:181-224)
+  for (int t = 0; t < T; ++t) {
+    const size_t o = (size_t)t * N;
+    UPD_CHECK(pqn_bigmlp_forward(&L, N, a->obs + t * ostride, a->theta, a->wplanes, a->in_mean, a->in_var, a->workspace, nullptr,
+                                 a->action + o, a->qmax + o, 0.0f, 0, a->sched_eps, a->sched_keys + t, stream));
+    pqn_step_out_t out = {};
+    out.obs = a->obs + (t + 1) * ostride;
+    out.reward = a->reward + o;
+    out.done = a->done + o;
+    out.discount = a->discount + o;
+    out.returned_episode_returns = a->rer + o;
+    out.returned_episode_lengths = a->rel + o;
+    out.timestep = a->ts + o;
+    if (a->reset_ratio > 0) {
+      UPD_CHECK(pqn_env_step_optimistic_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->reset_ratio, a->state, a->action + o,
+                                            out, a->opt_scratch, st));
+    } else {
+      UPD_CHECK(pqn_env_step_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->state, a->action + o, out, st));
+    }
+  }
+  if (a->q_lambda) {   // bootstrap value + Q(lambda) targets (:226-261); dead code of the reference's graph with Q_LAMBDA: False
+    UPD_CHECK(pqn_bigmlp_forward(&L, N, a->obs + T * ostride, a->theta, a->wplanes, a->in_mean, a->in_var, a->workspace, nullptr,
+                                 nullptr, a->last_q, 0.0f, 0, nullptr, nullptr, stream));
+    UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, N, 1, a->target, st));
+  }
+  // NETWORKS UPDATE (:263-357)
+  const long long mask = (1ll << pqn_index_bits(TN)) - 1;
+  int i_mb = 0;
+  for (int ep = 0; ep < EP; ++ep) {
+    UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, TN, a->sort_keys_in, st));
+    UPD_CHECK(pqn_sort_keys(a->sort_temp, (size_t)a->sort_temp_bytes, a->sort_keys_in, a->sort_keys_out, TN, 1, TN, st));
+    hipLaunchKernelGGL(keys_to_index_kernel, dim3((TN + 255) / 256), dim3(256), 0, st, a->sort_keys_out, TN, mask);
+    for (int mb = 0; mb < MB; ++mb, ++i_mb) {
+      UPD_CHECK(pqn_bigmlp_grad(&L, B, a->sort_keys_out + (size_t)mb * B, a->obs, a->q_lambda ? 0 : N, a->action,
+                                a->q_lambda ? a->target : nullptr, a->reward, a->done, a->gamma, a->theta, a->wplanes, a->in_mean,
+                                a->in_var, a->in_steps, a->grad, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, stream));
+      UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
+                                 a->max_grad_norm, a->radam_scratch, nullptr, 0, nullptr, 1, 0, st));
+      UPD_CHECK(pqn_bigmlp_refresh_planes(&L, a->theta, a->wplanes, stream));
+    }
+  }
+  if (hipMemcpyAsync(a->obs, a->obs + (size_t)T * ostride, ostride * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    pqn_set_error("pqn_bigmlp_update: hipMemcpyAsync failed");
+    return PQN_E_HIP;
+  }
+  double *partial = reinterpret_cast<double *>(a->workspace);   // idle between the last optimizer step and the next forward
+  hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS, 1), dim3(256), 0, st, TN, N, N, a->discount, a->rer, a->rel, a->ts,
+                     a->done, partial, 0ll, a->done_weighted_info);
+  hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, 1, MB * EP, a->loss_buf, a->qv_buf, partial,
+                     a->metrics, a->metrics_capacity, 0ll, a->done_weighted_info);
+  return pqn_check_launch("pqn_bigmlp_update");
 }

@@ -575,6 +575,15 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             driver = UpdateDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
                                   policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
                                   fused_opt=config.get("_FUSED_OPT", False))
+        elif backend == "fused_big" and grad_hook is None and config.get("_DRIVER", True) and driver_shape_ok:
+            # the Craftax script's loop (wrapper-batched env, wide MLP) from one C call, replayed as a hipGraph
+            from .qnet import BigMlpUpdateDriver
+            dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
+                    "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}
+            ratio = int(env.reset_ratio) if isinstance(env, OptimisticResetVecEnvWrapper) else 0
+            driver = BigMlpUpdateDriver(base_env.env_id, N, T, MB, EPOCHS, dcfg, (K_roll, K_shuf), policy.tr, ro, words,
+                                        NUM_UPDATES, reset_ratio=ratio, q_lambda=q_lambda_loss, done_weighted_info=craftax,
+                                        use_graph=config.get("_GRAPH", True))
         elif packed and grad_hook is not None and config.get("_DRIVER", True) and driver_shape_ok:
             # envs of one seed sharded over ranks: the same C++ enqueue, split at the gradient / optimizer boundary
             from .qnet import EnvShardDriver
@@ -609,7 +618,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                     tm_box[0] = get_test_metrics()
                 test_rows[u] = torch.stack([tm_box[0][k] for k in INFO_KEYS])
             cb = config.get("_CALLBACK")
-            if cb is not None:
+            # the Craftax script logs every WANDB_LOG_INTERVAL-th update only (pqn_craftax.py:394-397)
+            if cb is not None and (not craftax or counters["n_updates"] % int(config.get("WANDB_LOG_INTERVAL", 128)) == 0):
                 row = driver.metrics[u].tolist()   # synchronises: logging is opt-in
                 from .qnet import METRIC_NAMES
                 m = dict(zip(METRIC_NAMES, row))

@@ -744,3 +744,87 @@ class BigMlpTrainer:
 
     def theta_flax(self) -> torch.Tensor:
         return self.layout.to_flax(self.theta)
+
+
+class BigMlpUpdateArgs(C.Structure):
+    """pqn_bigmlp_update_args_t (include/pqn_hotpath.h)"""
+    _fields_ = ([(n, C.c_int32) for n in ("env_id", "num_envs", "num_steps", "num_minibatches", "num_epochs",
+                                           "metrics_capacity", "reset_ratio", "q_lambda", "done_weighted_info")] +
+                [(n, C.c_float) for n in ("gamma", "lam", "rew_scale", "eps_start", "eps_finish",
+                                          "lr_init", "lr_end", "max_grad_norm")] +
+                [(n, C.c_double) for n in ("eps_decay_steps", "lr_steps")] +
+                [(n, C.c_uint64) for n in ("key_roll", "key_shuf", "sort_temp_bytes")] +
+                [("layout", BigMlpLayoutStruct)] +
+                [(n, C.c_void_p) for n in ("clock", "sched_keys", "sched_eps", "state", "obs", "action", "reward",
+                                           "done", "qmax", "discount", "rer", "rel", "ts", "target", "last_q",
+                                           "sort_keys_in", "sort_keys_out", "sort_temp", "opt_scratch", "theta", "wplanes",
+                                           "grad", "m", "v", "count", "in_mean", "in_var", "in_steps", "workspace",
+                                           "radam_scratch", "loss_buf", "qv_buf", "metrics")])
+
+
+class BigMlpUpdateDriver:
+    """Whole-update enqueue of the Craftax script's loop (pqn_bigmlp_update) with hipGraph replay: the wide-MLP twin of
+    UpdateDriver.  `reset_ratio` > 0 = OptimisticResetVecEnvWrapper, 0 = BatchEnvWrapper; `q_lambda` False = the 1-step
+    loss on concat(obs, next_obs); `done_weighted_info` = the Craftax script's info means (pqn_craftax.py:364-369)."""
+
+    def __init__(self, env_id, n, t, mb, epochs, cfg, keys, trainer: "BigMlpTrainer", ro, words, num_updates, *,
+                 reset_ratio: int, q_lambda: bool, done_weighted_info: bool, use_graph: bool = True):
+        lib = _lib.load()
+        dev = trainer.theta.device
+        self.dev = dev
+        tn = n * t
+        b = tn // mb
+        self.clock = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.sched_keys = torch.zeros(t + epochs, dtype=torch.int64, device=dev)
+        self.sched_eps = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sk_in = torch.empty(tn, dtype=torch.int64, device=dev)
+        self.sk_out = torch.empty(tn, dtype=torch.int64, device=dev)
+        tb = int(lib.pqn_update_sort_temp_bytes(tn))
+        if tb < 0:
+            raise RuntimeError("pqn_update_sort_temp_bytes failed")
+        self.sort_temp = torch.empty(max(tb, 16), dtype=torch.uint8, device=dev)
+        self.opt_scratch = torch.empty(n, dtype=torch.int64, device=dev)
+        self.loss_buf = torch.zeros(mb * epochs, dtype=torch.float32, device=dev)
+        self.qv_buf = torch.zeros(mb * epochs, dtype=torch.float32, device=dev)
+        self.metrics = torch.zeros((max(num_updates, 1), len(METRIC_NAMES)), dtype=torch.float64, device=dev)
+        ls = C.byref(trainer.layout.struct)
+        rows = b if q_lambda else 2 * b
+        n_ws = max(int(lib.pqn_bigmlp_workspace_floats(ls, n, n)), int(lib.pqn_bigmlp_workspace_floats(ls, rows, b)))
+        if n_ws <= 0:
+            raise RuntimeError("pqn_bigmlp_workspace_floats failed")
+        self.ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        a = BigMlpUpdateArgs()
+        a.env_id, a.num_envs, a.num_steps, a.num_minibatches, a.num_epochs = env_id, n, t, mb, epochs
+        a.metrics_capacity = self.metrics.shape[0]
+        a.reset_ratio, a.q_lambda, a.done_weighted_info = int(reset_ratio), int(bool(q_lambda)), int(bool(done_weighted_info))
+        a.gamma, a.lam, a.rew_scale = cfg["gamma"], cfg["lam"], cfg["rew_scale"]
+        a.eps_start, a.eps_finish, a.eps_decay_steps = cfg["eps_start"], cfg["eps_finish"], cfg["eps_decay_steps"]
+        a.lr_init, a.lr_end, a.lr_steps, a.max_grad_norm = trainer.lr, trainer.lr_end, trainer.lr_steps, trainer.max_norm
+        a.key_roll, a.key_shuf = keys
+        a.sort_temp_bytes = tb
+        a.layout = trainer.layout.struct
+        p = _lib.ptr
+        a.clock, a.sched_keys, a.sched_eps = p(self.clock), p(self.sched_keys), p(self.sched_eps)
+        a.state, a.obs = p(words), p(ro.obs)
+        a.action, a.reward, a.done, a.qmax = p(ro.action), p(ro.reward), p(ro.done), p(ro.qmax)
+        a.discount, a.rer, a.rel, a.ts = p(ro.discount), p(ro.rer), p(ro.rel), p(ro.ts)
+        a.target, a.last_q = p(ro.target), p(ro.last_q)
+        a.sort_keys_in, a.sort_keys_out, a.sort_temp = p(self.sk_in), p(self.sk_out), p(self.sort_temp)
+        a.opt_scratch = p(self.opt_scratch)
+        a.theta, a.wplanes, a.grad, a.m, a.v = p(trainer.theta), p(trainer.wplanes), p(trainer.grad), p(trainer.m), p(trainer.v)
+        a.count = p(trainer.count)
+        if trainer.layout.norm_input:
+            a.in_mean, a.in_var, a.in_steps = p(trainer.in_mean), p(trainer.in_var), p(trainer.in_steps)
+        a.workspace, a.radam_scratch = p(self.ws), p(trainer.scratch)
+        a.loss_buf, a.qv_buf, a.metrics = p(self.loss_buf), p(self.qv_buf), p(self.metrics)
+        self.args = a
+        self._keep = (trainer, ro, words)
+        self.use_graph = use_graph
+        self.graph = None
+        self.graph_error = None
+        self.calls = 0
+
+    def _enqueue(self):
+        _lib.check(_lib.load().pqn_bigmlp_update(C.byref(self.args), _lib.stream_ptr()), "pqn_bigmlp_update")
+
+    update = UpdateDriver.update

@@ -219,3 +219,21 @@ def test_runner_state_answers_the_reference_tuple_protocol():
     assert rs[0].params == {"Dense_0/kernel": 1} and train_state.grad_steps == 128 and train_state.n_updates == 2
     assert (obs, env_state) == ("O", "S") and test_metrics == {"a": 1} and rng == 7 and len(rs) == 4
     assert rs["theta"] == 2 and "driver" not in rs and rs[1] == ("O", "S")
+
+
+def test_update_argument_structs_match_the_header(tmp_path):
+    """The ctypes mirrors of the three whole-update argument blocks have the size and the field offsets gcc gives the
+    structs of include/pqn_hotpath.h (a silent mismatch would hand the C side shifted pointers)."""
+    import ctypes as C
+    import subprocess
+    from purejaxql_amd import qnet
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pqn_hotpath.h"\n'
+                   '#define P(T) printf("%zu %zu %zu %zu\\n", sizeof(T), offsetof(T, layout), offsetof(T, clock), offsetof(T, metrics))\n'
+                   'int main(void) { P(pqn_update_args_t); P(pqn_mlp_update_args_t); P(pqn_bigmlp_update_args_t); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    rows = [tuple(int(x) for x in ln.split()) for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n") if ln]
+    for row, cls in zip(rows, (qnet.UpdateArgs, qnet.MlpUpdateArgs, qnet.BigMlpUpdateArgs)):
+        assert row == (C.sizeof(cls), cls.layout.offset, cls.clock.offset, cls.metrics.offset), (cls.__name__, row)
