@@ -502,6 +502,7 @@ typedef struct {
   int64_t *sort_keys_in, *sort_keys_out; /* [T*N]; sort_keys_out ends up as the epoch's permutation */
   void *sort_temp;       /* pqn_update_sort_temp_bytes(T*N) bytes */
   uint64_t *opt_scratch; /* [N] sort keys of the optimistic resets (reset_ratio > 0) */
+  int32_t *slot_scratch; /* [N] reset-slot table of the env kernels */
   float *theta, *wplanes, *grad, *m, *v; /* pqn_bigmlp_layout buffers; wplanes as for pqn_bigmlp_forward */
   int32_t *count;        /* [1] optimizer step counter */
   float *in_mean, *in_var; /* [d] running statistics of the input normalisation (norm_input != 0) */

@@ -177,10 +177,14 @@ int pqn_craftax_canon(int n, int do_export, uint32_t *state, int32_t *si, float 
 
 // internal launchers with device-resident keys / eps (used by the whole-update driver, pqn_update.hip)
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
-                     const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0, int key_stride = 0);
-// OptimisticResetVecEnvWrapper.step (pqn_env_step_optimistic) with the step key in device memory, stepped in place
+                     const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0, int key_stride = 0,
+                     int32_t *slot_scratch = nullptr);
+// OptimisticResetVecEnvWrapper.step (pqn_env_step_optimistic) with the step key in device memory, stepped in place.
+// slot_scratch i32[n] (both): Craftax-Classic's reset-slot table; without it the env allocates one per stream on first
+// use, which a hipGraph capture does not allow
 int pqn_env_step_optimistic_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, int reset_ratio, uint32_t *state,
-                                const int32_t *action, const pqn_step_out_t &out, uint64_t *scratch, hipStream_t st);
+                                const int32_t *action, const pqn_step_out_t &out, uint64_t *scratch, int32_t *slot_scratch,
+                                hipStream_t st);
 // shuffle keys of the whole-update driver: keys[i] = rand31(i; *key_dev) << ib | i with ib = pqn_index_bits(n) --
 // the same order as the public pqn_shuffle_keys (rand31 << 32 | i), packed so the sort visits 31 + ib bits only
 int pqn_index_bits(int n);

@@ -279,7 +279,7 @@ static void launch_minatar(int n, uint64_t key, const uint64_t *key_dev, float r
 template <bool IS_RESET>
 static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, float rscale, const uint32_t *si,
                     uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0,
-                    int key_stride = 0, uint64_t *opt_keys = nullptr) {
+                    int key_stride = 0, uint64_t *opt_keys = nullptr, int32_t *cc_slots = nullptr) {
   if (n_per_seed > 0 && env_id != PQN_ENV_CARTPOLE && env_id != PQN_ENV_ACROBOT) {
     pqn_set_error("seed-batched env.step is implemented for the flat-observation envs (the MinAtar path batches seeds "
                   "inside pqn_cnn_rollout_seeds)");
@@ -289,7 +289,7 @@ static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, fl
     PQN_REQUIRE(IS_RESET || si == so, "Craftax-Classic steps its state in place: state_in must equal state_out");
     PQN_REQUIRE(!opt_keys, "Craftax-Classic: use pqn_env_step_optimistic");
     if (IS_RESET) return pqn_craftax_reset(n, key, so, out.obs, st);
-    return pqn_craftax_step(n, key, key_dev, rscale, so, action, out, 0, nullptr, nullptr, st);
+    return pqn_craftax_step(n, key, key_dev, rscale, so, action, out, 0, nullptr, cc_slots, st);
   }
   switch (env_id) {
     case PQN_ENV_BREAKOUT: launch_minatar<Breakout, IS_RESET>(n, key, key_dev, rscale, si, so, action, out, st, opt_keys); break;
@@ -369,14 +369,15 @@ extern "C" int pqn_env_step_optimistic(int env_id, int32_t n, uint64_t key, int3
 
 // internal (pqn_update.hip): the same with the step key read from device memory, stepped in place, reward scaled at the source
 int pqn_env_step_optimistic_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, int reset_ratio, uint32_t *state,
-                                const int32_t *action, const pqn_step_out_t &out, uint64_t *scratch, hipStream_t st) {
-  return step_optimistic(env_id, n, 0, key_dev, rscale, reset_ratio, state, state, action, out, scratch, nullptr, st);
+                                const int32_t *action, const pqn_step_out_t &out, uint64_t *scratch, int32_t *slot_scratch,
+                                hipStream_t st) {
+  return step_optimistic(env_id, n, 0, key_dev, rscale, reset_ratio, state, state, action, out, scratch, slot_scratch, st);
 }
 
 // internal (pqn_update.hip): step key read from device memory, reward scaled at the source
 int pqn_env_step_dyn(int env_id, int n, const uint64_t *key_dev, float rscale, uint32_t *state, const int32_t *action,
-                     const pqn_step_out_t &out, hipStream_t st, int n_per_seed, int key_stride) {
-  return dispatch<false>(env_id, n, 0, key_dev, rscale, state, state, action, out, st, n_per_seed, key_stride);
+                     const pqn_step_out_t &out, hipStream_t st, int n_per_seed, int key_stride, int32_t *slot_scratch) {
+  return dispatch<false>(env_id, n, 0, key_dev, rscale, state, state, action, out, st, n_per_seed, key_stride, nullptr, slot_scratch);
 }
 
 template <bool EXPORT>

@@ -452,7 +452,7 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
   PQN_REQUIRE(a, "pqn_bigmlp_update: args is NULL");
   PQN_REQUIRE(a->clock && a->sched_keys && a->sched_eps && a->state && a->obs && a->action && a->reward && a->done &&
                   a->qmax && a->discount && a->rer && a->rel && a->ts && a->sort_keys_in && a->sort_keys_out && a->sort_temp &&
-                  a->theta && a->wplanes && a->grad && a->m && a->v && a->count && a->workspace && a->radam_scratch &&
+                  a->theta && a->wplanes && a->grad && a->m && a->v && a->count && a->workspace && a->radam_scratch && a->slot_scratch &&
                   a->loss_buf && a->qv_buf && a->metrics,
               "pqn_bigmlp_update: NULL buffer in args");
   const int N = a->num_envs, T = a->num_steps, MB = a->num_minibatches, EP = a->num_epochs;
@@ -486,9 +486,10 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
     out.timestep = a->ts + o;
     if (a->reset_ratio > 0) {
       UPD_CHECK(pqn_env_step_optimistic_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->reset_ratio, a->state, a->action + o,
-                                            out, a->opt_scratch, st));
+                                            out, a->opt_scratch, a->slot_scratch, st));
     } else {
-      UPD_CHECK(pqn_env_step_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->state, a->action + o, out, st));
+      UPD_CHECK(pqn_env_step_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->state, a->action + o, out, st, 0, 0,
+                                 a->slot_scratch));
     }
   }
   if (a->q_lambda) {   // bootstrap value + Q(lambda) targets (:226-261); dead code of the reference's graph with Q_LAMBDA: False

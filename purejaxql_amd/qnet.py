@@ -757,7 +757,8 @@ class BigMlpUpdateArgs(C.Structure):
                 [("layout", BigMlpLayoutStruct)] +
                 [(n, C.c_void_p) for n in ("clock", "sched_keys", "sched_eps", "state", "obs", "action", "reward",
                                            "done", "qmax", "discount", "rer", "rel", "ts", "target", "last_q",
-                                           "sort_keys_in", "sort_keys_out", "sort_temp", "opt_scratch", "theta", "wplanes",
+                                           "sort_keys_in", "sort_keys_out", "sort_temp", "opt_scratch", "slot_scratch", "theta",
+                                           "wplanes",
                                            "grad", "m", "v", "count", "in_mean", "in_var", "in_steps", "workspace",
                                            "radam_scratch", "loss_buf", "qv_buf", "metrics")])
 
@@ -784,6 +785,7 @@ class BigMlpUpdateDriver:
             raise RuntimeError("pqn_update_sort_temp_bytes failed")
         self.sort_temp = torch.empty(max(tb, 16), dtype=torch.uint8, device=dev)
         self.opt_scratch = torch.empty(n, dtype=torch.int64, device=dev)
+        self.slot_scratch = torch.empty(n, dtype=torch.int32, device=dev)
         self.loss_buf = torch.zeros(mb * epochs, dtype=torch.float32, device=dev)
         self.qv_buf = torch.zeros(mb * epochs, dtype=torch.float32, device=dev)
         self.metrics = torch.zeros((max(num_updates, 1), len(METRIC_NAMES)), dtype=torch.float64, device=dev)
@@ -810,7 +812,7 @@ class BigMlpUpdateDriver:
         a.discount, a.rer, a.rel, a.ts = p(ro.discount), p(ro.rer), p(ro.rel), p(ro.ts)
         a.target, a.last_q = p(ro.target), p(ro.last_q)
         a.sort_keys_in, a.sort_keys_out, a.sort_temp = p(self.sk_in), p(self.sk_out), p(self.sort_temp)
-        a.opt_scratch = p(self.opt_scratch)
+        a.opt_scratch, a.slot_scratch = p(self.opt_scratch), p(self.slot_scratch)
         a.theta, a.wplanes, a.grad, a.m, a.v = p(trainer.theta), p(trainer.wplanes), p(trainer.grad), p(trainer.m), p(trainer.v)
         a.count = p(trainer.count)
         if trainer.layout.norm_input:
