@@ -344,7 +344,8 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
 /* Run-time switches of the kernel selection (profiling, A/B runs, tests; no reference counterpart -- XLA picks its
  * fusions itself).  Names: "t1_pair", "rollout_pair" (pair form of the bf16x3 training / rollout kernel: 0 never,
  * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
- * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height / K splits).  Each starts from its PQN_<NAME> environment
+ * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP
+ * backward on a second stream; default 1).  Each starts from its PQN_<NAME> environment
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);

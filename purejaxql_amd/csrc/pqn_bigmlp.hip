@@ -310,10 +310,9 @@ PQN_D float bm_wave_sum(float v) {
 
 // f32 matrix src[rows][cols] (leading dimension lds, any alignment) -> planes [rows][ld]; one thread per 8 columns,
 // columns >= cols are written as zeros up to ld
-__global__ __launch_bounds__(256) void bm_split_kernel(const float *__restrict__ src, long long lds, int rows, int cols,
-                                                       BmPlanesOut out) {
+PQN_D void bm_split_body(const float *__restrict__ src, long long lds, int rows, int cols, const BmPlanesOut &out, long long block) {
   const int ppr = (int)(out.ld / 8);
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long e = block * 256 + threadIdx.x;
   if (e >= (long long)rows * ppr) return;
   const int r = (int)(e / ppr), k = (int)(e % ppr) * 8;
   const float *sr = src + (long long)r * lds;
@@ -327,15 +326,34 @@ __global__ __launch_bounds__(256) void bm_split_kernel(const float *__restrict__
   bm_split8(v, h, m, l);
   bm_put(out, r, k, h, m, l);
 }
+__global__ __launch_bounds__(256) void bm_split_kernel(const float *__restrict__ src, long long lds, int rows, int cols,
+                                                       BmPlanesOut out) {
+  bm_split_body(src, lds, rows, cols, out, blockIdx.x);
+}
+// several matrices in one launch (the Dense kernels of every layer after an optimizer step): job j owns blocks
+// [first[j], first[j + 1])
+#define BM_MAX_JOBS (PQN_BIGMLP_MAX_LAYERS + 1)
+struct BmSplitJobs {
+  int n;
+  const float *src[BM_MAX_JOBS];
+  long long lds[BM_MAX_JOBS];
+  int rows[BM_MAX_JOBS], cols[BM_MAX_JOBS];
+  BmPlanesOut out[BM_MAX_JOBS];
+  long long first[BM_MAX_JOBS + 1];
+};
+__global__ __launch_bounds__(256) void bm_split_multi_kernel(BmSplitJobs J) {
+  int j = 0;
+  while (j + 1 < J.n && (long long)blockIdx.x >= J.first[j + 1]) ++j;
+  bm_split_body(J.src[j], J.lds[j], J.rows[j], J.cols[j], J.out[j], (long long)blockIdx.x - J.first[j]);
+}
 
 // planes src[rows][ld_s] (logical columns `cols`) -> planes dst[cols][ld_d] (logical columns `rows`, zero beyond);
 // 64 x 64 element tiles through LDS, 16-B global accesses both ways; grid (ceil(ld_d / 64), ceil(cols / 64), 3 planes)
-__global__ __launch_bounds__(256) void bm_transpose_kernel(BmPlanes src, int cols, BmPlanesOut dst) {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];   // row stride 144 B: the 2-B column gathers below spread over the banks
+PQN_D void bm_transpose_body(const BmPlanes &src, int cols, const BmPlanesOut &dst, int bx, int by, int bz, bf16_t (*tile)[72]) {
   const int tid = threadIdx.x;
-  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;   // source rows r0.., source columns c0..
-  const bf16_t *sp = src.p + (long long)blockIdx.z * src.pstride;
-  bf16_t *dp = dst.p + (long long)blockIdx.z * dst.pstride;
+  const int r0 = bx * 64, c0 = by * 64;   // source rows r0.., source columns c0..
+  const bf16_t *sp = src.p + (long long)bz * src.pstride;
+  bf16_t *dp = dst.p + (long long)bz * dst.pstride;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {   // load: 64 rows x 8 chunks of 8 columns (columns >= cols hold the source's zero padding)
     const int e = tid + 256 * q, r = e >> 3, ch = e & 7;
@@ -358,6 +376,25 @@ __global__ __launch_bounds__(256) void bm_transpose_kernel(BmPlanes src, int col
       *reinterpret_cast<u32x4 *>(dp + (long long)cc * dst.ld + rr) = o;
     }
   }
+}
+__global__ __launch_bounds__(256) void bm_transpose_kernel(BmPlanes src, int cols, BmPlanesOut dst) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];   // row stride 144 B: the 2-B column gathers below spread over the banks
+  bm_transpose_body(src, cols, dst, blockIdx.x, blockIdx.y, blockIdx.z, tile);
+}
+// several plane sets in one launch; job j owns the linear blocks [first[j], first[j + 1]) = its (bx, by) grid, row-major in by
+struct BmTransposeJobs {
+  int n;
+  BmPlanes src[BM_MAX_JOBS];
+  int cols[BM_MAX_JOBS], nbx[BM_MAX_JOBS];
+  BmPlanesOut dst[BM_MAX_JOBS];
+  int first[BM_MAX_JOBS + 1];
+};
+__global__ __launch_bounds__(256) void bm_transpose_multi_kernel(BmTransposeJobs J) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
+  int j = 0;
+  while (j + 1 < J.n && (int)blockIdx.x >= J.first[j + 1]) ++j;
+  const int b = (int)blockIdx.x - J.first[j];
+  bm_transpose_body(J.src[j], J.cols[j], J.dst[j], b % J.nbx[j], b / J.nbx[j], blockIdx.z, tile);
 }
 
 // z = sum of the K-split partials of the layer's GEMM + bias;  h = relu(LayerNorm(z)) row by row (one wave per row) written
@@ -844,13 +881,27 @@ void bm_transpose(const BmPlanes &src, int cols, const BmPlanesOut &dst, hipStre
                      dst);
 }
 
+struct BmTransposeBatch {
+  BmTransposeJobs J = {};
+  void add(const BmPlanes &src, int cols, const BmPlanesOut &dst) {
+    const int j = J.n++;
+    J.src[j] = src; J.cols[j] = cols; J.dst[j] = dst;
+    J.nbx[j] = (int)((dst.ld + 63) / 64);
+    J.first[j + 1] = J.first[j] + J.nbx[j] * ((cols + 63) / 64);
+  }
+  void launch(hipStream_t st) {
+    if (J.n) hipLaunchKernelGGL(bm_transpose_multi_kernel, dim3((unsigned)J.first[J.n], 1, 3), dim3(256), 0, st, J);
+  }
+};
+
 // ---- workspace carve-up: a float region followed by a bf16 region (offsets in floats / in bf16 elements) ----
 struct BmWs {
   // f32
-  long long coef, cspart, xhat, z[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, zpart, dpart, wpart, lnpart, inpart, f_total;
+  long long coef, cspart, xhat, z[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, zpart, dpart, wpart[PQN_BIGMLP_MAX_LAYERS],
+      lnpart[PQN_BIGMLP_MAX_LAYERS], inpart, f_total;
   long long zstride, dstride, wstride;
   // bf16 planes (element offsets from the start of the bf16 region)
-  long long xn, xnT, h[PQN_BIGMLP_MAX_LAYERS], hT[PQN_BIGMLP_MAX_LAYERS], dz, dzT, dq, dqT, b_total;
+  long long xn, xnT, h[PQN_BIGMLP_MAX_LAYERS], hT[PQN_BIGMLP_MAX_LAYERS], dz[PQN_BIGMLP_MAX_LAYERS], dzT[PQN_BIGMLP_MAX_LAYERS], dq, dqT, b_total;
   int ldq, ldx, dp, nbp, n_cs, n_ln, n_in;
 };
 BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
@@ -877,8 +928,12 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
   w.dstride = (long long)nb * L.h;
   w.dpart = take(BM_MAX_SPLIT * w.dstride);
   w.wstride = (long long)align4(max(L.d, L.h)) * L.h;
-  w.wpart = take(BM_MAX_SPLIT * w.wstride);
-  w.lnpart = take(3ll * w.n_ln * L.h);
+  // per layer: the weight-gradient side of layer l (column sums, transposes, d W GEMM, fold) runs on a second stream
+  // beside the input-gradient chain of the layers below it, so none of its buffers may be reused by them
+  for (int l = 0; l < L.layers; ++l) {
+    w.wpart[l] = take(BM_MAX_SPLIT * w.wstride);
+    w.lnpart[l] = take(3ll * w.n_ln * L.h);
+  }
   w.inpart = take(2ll * BM_MAX_SPLIT * w.n_in * L.d);
   w.f_total = off;
   long long bo = 0;
@@ -889,8 +944,10 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
     w.h[l] = takeb(bm_pl_elems(rows, L.h));
     w.hT[l] = takeb(bm_pl_elems(L.h, w.nbp));
   }
-  w.dz = takeb(bm_pl_elems(nb, L.h));
-  w.dzT = takeb(bm_pl_elems(L.h, w.nbp));
+  for (int l = 0; l < L.layers; ++l) {
+    w.dz[l] = takeb(bm_pl_elems(nb, L.h));
+    w.dzT[l] = takeb(bm_pl_elems(L.h, w.nbp));
+  }
   w.dq = takeb(bm_pl_elems(nb, 32));
   w.dqT = takeb(bm_pl_elems(L.a, w.nbp));
   w.b_total = bo;
@@ -932,6 +989,45 @@ int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, const
   const int lo = L.layers;   // output layer: Q = h_last W_out + b_out (narrow: no K split)
   return bm_gemm(rows, L.a, L.h, bm_pl(wb + w.h[lo - 1], rows, L.h), bm_pl(wpl + wp.wt[lo], L.a, L.h),
                  bm_store(ws + w.q, w.ldq, theta + L.off_b[lo]), 1, nullptr, st);
+}
+
+// ---- second stream of the backward pass ----------------------------------------------------------------------------------
+// The input-gradient chain (LayerNorm backward_l -> d h_{l-1} GEMM -> LayerNorm backward_{l-1} ...) is the critical path of
+// the backward pass; everything that ends in a parameter gradient (column sums, plane transposes, the d W GEMMs, their
+// K-split folds) hangs off it.  Those launches go to ONE process-wide side stream, ordered against the caller's stream by
+// events (fork after the producer, one join at the end), so they fill the CUs the 1024-row GEMMs of the chain leave idle.
+// Event record / wait pairs are capturable: inside a hipGraph capture the side stream joins the capture at the first wait
+// and leaves it at the join.  Stream and events are created on first use (the first, eager update); if that fails, or with
+// the option bm_overlap = 0, everything stays on the caller's stream.
+struct BmFork {
+  hipStream_t side = nullptr;
+  hipEvent_t ev[PQN_BIGMLP_MAX_LAYERS + 4];
+  bool ok = false, tried = false;
+};
+BmFork g_bm_fork;
+BmFork *bm_fork() {
+  if (pqn_opt(PQN_OPT_BM_OVERLAP) == 0) return nullptr;
+  BmFork &f = g_bm_fork;
+  if (!f.tried) {
+    f.tried = true;
+    bool ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < PQN_BIGMLP_MAX_LAYERS + 4; ++i) ok = hipEventCreateWithFlags(&f.ev[i], hipEventDisableTiming) == hipSuccess;
+    f.ok = ok;
+    if (!ok) (void)hipGetLastError();
+  }
+  return f.ok ? &f : nullptr;
+}
+// the side stream, ordered behind everything enqueued on `st` so far (event slot i); `st` itself when there is no side stream
+hipStream_t bm_fork_at(BmFork *f, int i, hipStream_t st) {
+  if (!f) return st;
+  (void)hipEventRecord(f->ev[i], st);
+  (void)hipStreamWaitEvent(f->side, f->ev[i], 0);
+  return f->side;
+}
+void bm_join(BmFork *f, int i, hipStream_t st) {
+  if (!f) return;
+  (void)hipEventRecord(f->ev[i], f->side);
+  (void)hipStreamWaitEvent(st, f->ev[i], 0);
 }
 
 }  // namespace
@@ -978,11 +1074,18 @@ extern "C" int pqn_bigmlp_refresh_planes(const pqn_bigmlp_layout_t *L, const flo
   hipStream_t st = (hipStream_t)stream;
   const BmWp wp = bm_wp(*L);
   bf16_t *base = reinterpret_cast<bf16_t *>(wplanes);
+  BmSplitJobs S = {};   // two launches for all layers: every kernel split into planes, then every transposed copy
+  BmTransposeBatch T;
   for (int l = 0; l <= L->layers; ++l) {
     const int kin = l ? L->h : L->d, out = l < L->layers ? L->h : L->a;
-    bm_split(theta + L->off_w[l], out, kin, out, bm_plo(base + wp.wn[l], kin, bm_pad32(out)), st);
-    bm_transpose(bm_pl(base + wp.wn[l], kin, bm_pad32(out)), out, bm_plo(base + wp.wt[l], out, bm_pad32(kin)), st);
+    const BmPlanesOut wn = bm_plo(base + wp.wn[l], kin, bm_pad32(out));
+    S.src[l] = theta + L->off_w[l]; S.lds[l] = out; S.rows[l] = kin; S.cols[l] = out; S.out[l] = wn;
+    S.first[l + 1] = S.first[l] + ((long long)kin * (wn.ld / 8) + 255) / 256;
+    T.add(bm_pl(base + wp.wn[l], kin, bm_pad32(out)), out, bm_plo(base + wp.wt[l], out, bm_pad32(kin)));
   }
+  S.n = L->layers + 1;
+  hipLaunchKernelGGL(bm_split_multi_kernel, dim3((unsigned)S.first[S.n]), dim3(256), 0, st, S);
+  T.launch(st);
   return pqn_check_launch("pqn_bigmlp_refresh_planes");
 }
 
@@ -1054,52 +1157,61 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
                      coef ? ws + w.xhat : (float *)nullptr, (long long)w.ldx);
   int rc = bm_forward(*L, rows, theta, wpl, ws, wb, w, st);
   if (rc != PQN_OK) return rc;
-  const int lo = L->layers;
-  hipLaunchKernelGGL(bm_loss_kernel, dim3(1), dim3(1024), 0, st, ws + w.q, w.ldq, nb, L->a, idx, action, target, reward, done,
-                     gamma, next_offset > 0 ? 1 : 0, bm_plo(wb + w.dq, nb, 32), grad + L->off_b[lo], loss_out, qv_out);
   // backward over the first nb rows (the next_obs half carries no gradient: stop_gradient, pqn_craftax.py:301).
   // Weight gradient d W = Hin^T dZ: both operands with the samples as K = the transposed plane copies [feature][sample].
-  auto wgrad = [&](int kin, const BmPlanes &HinT, const BmPlanes &dZT, int n_out, float *gout) -> int {
+  // `sd` = the side stream of bm_fork (the caller's stream without it): see there for what runs where.
+  BmFork *fk = bm_fork();
+  auto wgrad = [&](int l, int kin, const BmPlanes &HinT, const BmPlanes &dZT, int n_out, float *gout, hipStream_t sd) -> int {
     int ns = 1;
     const long long cnt = (long long)kin * n_out;
     const bool direct = n_out < 64 || (cnt & 3);        // narrow output layer: one split, straight into the gradient
-    const int r = bm_gemm(kin, n_out, w.nbp, HinT, dZT, direct ? bm_store(gout, n_out) : bm_store(ws + w.wpart, n_out, nullptr, w.wstride),
-                          direct ? 1 : BM_MAX_SPLIT, &ns, st);
+    float *part = ws + w.wpart[l < L->layers ? l : 0];
+    const int r = bm_gemm(kin, n_out, w.nbp, HinT, dZT, direct ? bm_store(gout, n_out) : bm_store(part, n_out, nullptr, w.wstride),
+                          direct ? 1 : BM_MAX_SPLIT, &ns, sd);
     if (r != PQN_OK || direct) return r;
-    hipLaunchKernelGGL(bm_sum_partials_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, st, ws + w.wpart, ns, w.wstride,
-                       cnt, gout);
+    hipLaunchKernelGGL(bm_sum_partials_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, sd, part, ns, w.wstride, cnt, gout);
     return PQN_OK;
   };
-  auto hT = [&](int l) -> BmPlanes {   // transposed copy of the gradient rows of h_l (l = -1: the normalised input)
-    if (l < 0) {
-      BmPlanes src = bm_pl(wb + w.xn, nb, w.dp);
-      src.pstride = (long long)rows * w.dp;   // the planes hold all forward rows; only the first nb are transposed
-      bm_transpose(src, L->d, bm_plo(wb + w.xnT, L->d, w.nbp), st);
-      return bm_pl(wb + w.xnT, L->d, w.nbp);
+  // transposed copies of the gradient rows of every layer input (the normalised input, h_0 .. h_{L-1}): they depend on the
+  // forward pass only, so all of them go out at once, beside the loss kernel
+  hipStream_t sd = bm_fork_at(fk, 0, st);
+  {
+    BmTransposeBatch T;
+    BmPlanes src = bm_pl(wb + w.xn, nb, w.dp);
+    src.pstride = (long long)rows * w.dp;   // the planes hold all forward rows; only the first nb are transposed
+    T.add(src, L->d, bm_plo(wb + w.xnT, L->d, w.nbp));
+    for (int l = 0; l < L->layers; ++l) {
+      BmPlanes sh = bm_pl(wb + w.h[l], nb, L->h);
+      sh.pstride = (long long)rows * L->h;
+      T.add(sh, L->h, bm_plo(wb + w.hT[l], L->h, w.nbp));
     }
-    BmPlanes src = bm_pl(wb + w.h[l], nb, L->h);
-    src.pstride = (long long)rows * L->h;
-    bm_transpose(src, L->h, bm_plo(wb + w.hT[l], L->h, w.nbp), st);
-    return bm_pl(wb + w.hT[l], L->h, w.nbp);
-  };
-  // output layer: d W_out = h_last^T dQ;   d h_last = dQ W_out^T (K = a padded to 32: one split)
-  bm_transpose(bm_pl(wb + w.dq, nb, 32), L->a, bm_plo(wb + w.dqT, L->a, w.nbp), st);
-  rc = wgrad(L->h, hT(lo - 1), bm_pl(wb + w.dqT, L->a, w.nbp), L->a, grad + L->off_w[lo]);
-  if (rc != PQN_OK) return rc;
+    T.launch(sd);
+  }
+  auto hT = [&](int l) -> BmPlanes { return l < 0 ? bm_pl(wb + w.xnT, L->d, w.nbp) : bm_pl(wb + w.hT[l], L->h, w.nbp); };
+  const int lo = L->layers;
+  hipLaunchKernelGGL(bm_loss_kernel, dim3(1), dim3(1024), 0, st, ws + w.q, w.ldq, nb, L->a, idx, action, target, reward, done,
+                     gamma, next_offset > 0 ? 1 : 0, bm_plo(wb + w.dq, nb, 32), grad + L->off_b[lo], loss_out, qv_out);
+  // output layer: d W_out = h_last^T dQ (side);   d h_last = dQ W_out^T (K = a padded to 32: one split)
+  sd = bm_fork_at(fk, 1, st);
+  bm_transpose(bm_pl(wb + w.dq, nb, 32), L->a, bm_plo(wb + w.dqT, L->a, w.nbp), sd);
+  int rc2 = wgrad(lo, L->h, hT(lo - 1), bm_pl(wb + w.dqT, L->a, w.nbp), L->a, grad + L->off_w[lo], sd);
+  if (rc2 != PQN_OK) return rc2;
   int nsd = 1;
   rc = bm_gemm(nb, L->h, 32, bm_pl(wb + w.dq, nb, 32), bm_pl(wpl + wp.wn[lo], L->h, 32), bm_store(ws + w.dpart, L->h, nullptr, w.dstride), 1,
                &nsd, st);
   if (rc != PQN_OK) return rc;
   for (int l = lo - 1; l >= 0; --l) {
     // dpart (nsd K-split partials) = d loss / d h_l  ->  relu mask + LayerNorm backward: dz planes = d loss / d z_l
-    hipLaunchKernelGGL(bm_ln_bwd_kernel, dim3(w.n_ln), dim3(256), 0, st, ws + w.dpart, nsd, w.dstride, bm_plo(wb + w.dz, nb, L->h),
-                       ws + w.z[l], ws + w.stat[l], theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart);
-    hipLaunchKernelGGL(bm_colreduce_kernel, dim3((3 * L->h + 63) / 64), dim3(1024), 0, st, ws + w.lnpart, w.n_ln, 3, L->h,
-                       grad + L->off_lns[l], grad + L->off_lnb[l], grad + L->off_b[l]);
+    hipLaunchKernelGGL(bm_ln_bwd_kernel, dim3(w.n_ln), dim3(256), 0, st, ws + w.dpart, nsd, w.dstride, bm_plo(wb + w.dz[l], nb, L->h),
+                       ws + w.z[l], ws + w.stat[l], theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart[l]);
     const int kin = l ? L->h : L->d;
-    const BmPlanes dZ = bm_pl(wb + w.dz, nb, L->h);
-    bm_transpose(dZ, L->h, bm_plo(wb + w.dzT, L->h, w.nbp), st);
-    rc = wgrad(kin, hT(l - 1), bm_pl(wb + w.dzT, L->h, w.nbp), L->h, grad + L->off_w[l]);   // d W_l = h_{l-1}^T dZ_l
+    const BmPlanes dZ = bm_pl(wb + w.dz[l], nb, L->h);
+    // side: LayerNorm / bias gradients, d W_l = h_{l-1}^T dZ_l
+    sd = bm_fork_at(fk, 2 + l, st);
+    hipLaunchKernelGGL(bm_colreduce_kernel, dim3((3 * L->h + 63) / 64), dim3(1024), 0, sd, ws + w.lnpart[l], w.n_ln, 3, L->h,
+                       grad + L->off_lns[l], grad + L->off_lnb[l], grad + L->off_b[l]);
+    bm_transpose(dZ, L->h, bm_plo(wb + w.dzT[l], L->h, w.nbp), sd);
+    rc = wgrad(l, kin, hT(l - 1), bm_pl(wb + w.dzT[l], L->h, w.nbp), L->h, grad + L->off_w[l], sd);
     if (rc != PQN_OK) return rc;
     const BmPlanes Wn = bm_pl(wpl + wp.wn[l], kin, L->h);   // rows = input feature, K = output feature
     if (l > 0) {   // d h_{l-1} = dZ_l W_l^T
@@ -1116,6 +1228,7 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
                          grad + L->off_in_scale, grad + L->off_in_bias, (float *)nullptr);
     }
   }
+  bm_join(fk, PQN_BIGMLP_MAX_LAYERS + 3, st);
   return pqn_check_launch("pqn_bigmlp_grad");
 }
 

@@ -209,6 +209,44 @@ def test_bigmlp_q_lambda_loss_grad_vs_oracle(gpu, oracle):
     np.testing.assert_allclose(_np(tr.in_mean), new_stats[bn0 + "/mean"], rtol=1e-5, atol=1e-6)
 
 
+def test_bigmlp_backward_side_stream_is_bit_identical_to_one_stream(gpu, oracle):
+    """The parameter-gradient side of the backward pass runs on a second stream beside the input-gradient chain (option
+    bm_overlap, default 1).  Same kernels, same buffers, same summation orders: the gradient, the loss and the updated
+    input statistics must be bit-identical with the option off, over repeated calls (a missing event dependency would show
+    as run-to-run differences) and for both branches of the loss."""
+    from purejaxql_amd import _lib
+    d, h, layers, a, nb = 77, 512, 3, 7, 384
+    rng = np.random.default_rng(4)
+    pool = 2 * nb
+    obs = torch.from_numpy(rng.standard_normal((pool, d)).astype(np.float32)).to(gpu)
+    action = torch.from_numpy(rng.integers(0, a, pool).astype(np.int32)).to(gpu)
+    target = torch.from_numpy(rng.standard_normal(pool).astype(np.float32)).to(gpu)
+    reward = torch.from_numpy(rng.standard_normal(pool).astype(np.float32)).to(gpu)
+    done = torch.from_numpy((rng.random(pool) < 0.1).astype(np.uint8)).to(gpu)
+    idx = torch.from_numpy(rng.permutation(nb).astype(np.int64)).to(gpu)
+    results = {}
+    prev = _lib.get_option("bm_overlap")
+    try:
+        for ov in (1, 0):
+            _lib.set_option("bm_overlap", ov)
+            net, lay, tr, theta, shapes, p, bn0 = _setup(gpu, oracle, d, h, layers, a, True, True, 3)
+            outs = []
+            for rep in range(3):
+                lo_t, qv_t = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+                g1 = tr.compute_grad(idx, obs, action, reward=reward, done=done, gamma=0.99, next_offset=nb, loss_out=lo_t, qv_out=qv_t).clone()
+                g2 = tr.compute_grad(idx, obs, action, target=target, loss_out=lo_t, qv_out=qv_t).clone()
+                tr.apply()
+                outs.append((g1, g2, lo_t.clone(), tr.theta.clone(), tr.in_mean.clone(), tr.in_var.clone()))
+            torch.cuda.synchronize()
+            results[ov] = outs
+    finally:
+        _lib.set_option("bm_overlap", prev)
+    for ra, rb in zip(results[1], results[0]):
+        for ta, tb in zip(ra, rb):
+            assert torch.equal(ta, tb)
+    assert float(results[1][0][0].abs().sum()) > 0 and not torch.equal(results[1][0][3], results[1][2][3])
+
+
 def test_c5_runs_on_the_wide_mlp_kernels(gpu):
     """`+alg=pqn_craftax alg.ENV_NAME=Craftax-Classic-Symbolic-v1` selects the wide-MLP kernels by itself (the whole-loop
     oracle comparison at this shape is tests/test_craftax_gpu.py::test_c5_yaml_shape_loop_vs_oracle_on_craftax_classic)."""
