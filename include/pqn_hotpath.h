@@ -345,7 +345,7 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * fusions itself).  Names: "t1_pair", "rollout_pair" (pair form of the bf16x3 training / rollout kernel: 0 never,
  * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
  * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP
- * backward on a second stream; default 1).  Each starts from its PQN_<NAME> environment
+ * backward on a second stream; default 0).  Each starts from its PQN_<NAME> environment
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);
@@ -422,6 +422,29 @@ int pqn_mlp_update(const pqn_mlp_update_args_t *args /* host */, void *stream);
 int pqn_mlp_update_seeds(const pqn_mlp_update_args_t *args /* host */, int32_t num_seeds, const uint64_t *key_roll_dev,
                          const uint64_t *key_shuf_dev, int64_t theta_stride, int64_t workspace_stride, int64_t wt_stride,
                          void *stream);
+
+/* ---- env-sharded mode: one-shot all-reduce of the flat gradient over peer-mapped buffers (csrc/pqn_peer.hip) ------- */
+/* The collective `clip_by_global_norm` / `radam` need when the envs of ONE seed are sharded over the GPUs of a node
+ * (pqn_minatar.py:159-162,285-292: the gradient of the GLOBAL minibatch), without the host between the gradient and the
+ * optimizer kernels: every rank allocates a staging region (pqn_peer_alloc: fine-grained device memory + a 64-byte hipIpc
+ * handle), the ranks exchange the handles out of band (torch.distributed all_gather in purejaxql_amd/dist.py), map each
+ * other's regions (pqn_peer_open) and fill a pqn_peers_t; pqn_peer_allreduce_mean then only enqueues two small kernels
+ * (publish / wait + sum in rank order + scale by 1 / world), so it can sit inside a captured update.  All ranks obtain
+ * bit-identical results.  A peer that never arrives ends in an error word (pqn_peer_status), not in a hung device. */
+#define PQN_PEER_MAX 8
+typedef struct {
+  int32_t rank, world;
+  int64_t n;                    /* floats in the bucket */
+  void *region[PQN_PEER_MAX];   /* region[r]: rank r's staging region as mapped into THIS process (own: the allocation itself) */
+  uint32_t *local_state;        /* device u32[4], zero-initialised, private to this rank */
+} pqn_peers_t;
+int64_t pqn_peer_region_bytes(int64_t n);
+int pqn_peer_alloc(int64_t bytes, void **ptr /* host out */, uint8_t *handle64 /* host out [64] */);
+int pqn_peer_open(const uint8_t *handle64 /* host */, void **ptr /* host out */);
+int pqn_peer_close(void *ptr);
+int pqn_peer_free(void *ptr);
+int pqn_peer_allreduce_mean(const pqn_peers_t *peers /* host */, float *grad /* device, 16-B aligned, in place */, void *stream);
+int pqn_peer_status(const pqn_peers_t *peers /* host */, int32_t *error_out /* host; synchronises */);
 
 /* ---- wide MLP Q-network of the Craftax script (QNetwork, pqn_craftax.py:33-62, NORM_TYPE = layer_norm) ---------- */
 /* [BatchRenorm | BatchNorm | nothing](x) -> `layers` x (Dense(h) -> LayerNorm -> relu) -> Dense(a): the shape of

@@ -69,6 +69,13 @@ SIGNATURES = {
     "pqn_cnn_update_phase": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "pqn_mlp_update": (c_int, [c_void_p, c_void_p]),
     "pqn_bigmlp_update": (c_int, [c_void_p, c_void_p]),
+    "pqn_peer_region_bytes": (c_int64, [c_int64]),
+    "pqn_peer_alloc": (c_int, [c_int64, c_void_p, c_void_p]),
+    "pqn_peer_open": (c_int, [c_void_p, c_void_p]),
+    "pqn_peer_close": (c_int, [c_void_p]),
+    "pqn_peer_free": (c_int, [c_void_p]),
+    "pqn_peer_allreduce_mean": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "pqn_peer_status": (c_int, [c_void_p, c_void_p]),
     "pqn_mlp_update_seeds": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "pqn_cnn_rollout_seeds": (c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float,

@@ -998,7 +998,10 @@ int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, const
 // events (fork after the producer, one join at the end), so they fill the CUs the 1024-row GEMMs of the chain leave idle.
 // Event record / wait pairs are capturable: inside a hipGraph capture the side stream joins the capture at the first wait
 // and leaves it at the join.  Stream and events are created on first use (the first, eager update); if that fails, or with
-// the option bm_overlap = 0, everything stays on the caller's stream.
+// the option bm_overlap = 0 -- the DEFAULT -- everything stays on the caller's stream.  Measured on C5 (profiles/
+// r03_v2_c5_overlap_ab.txt): 1.149 ms per update with the side stream, 1.137 ms without; the overlapped kernels only slow
+// each other down (GEMM 29 -> 34 us, LayerNorm backward 16 -> 22 us on average): the update is throughput-bound on the
+// L2 -> LDS path, not latency-bound with idle CUs.  Kept as an option (bit-identical results, tested) for other shapes.
 struct BmFork {
   hipStream_t side = nullptr;
   hipEvent_t ev[PQN_BIGMLP_MAX_LAYERS + 4];
@@ -1006,7 +1009,7 @@ struct BmFork {
 };
 BmFork g_bm_fork;
 BmFork *bm_fork() {
-  if (pqn_opt(PQN_OPT_BM_OVERLAP) == 0) return nullptr;
+  if (pqn_opt(PQN_OPT_BM_OVERLAP) <= 0) return nullptr;
   BmFork &f = g_bm_fork;
   if (!f.tried) {
     f.tried = true;

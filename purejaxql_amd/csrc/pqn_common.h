@@ -84,7 +84,7 @@ enum {
   PQN_OPT_ABLATE,         // PQN_ABLATE: phase ablation of the forward kernel (profiling)
   PQN_OPT_BM_TILE,        // PQN_BM_TILE: tile height of the wide-MLP GEMMs (0 auto, 64, 128)
   PQN_OPT_BM_SPLIT,       // PQN_BM_SPLIT: K splits of the wide-MLP GEMMs (0 auto, 1 .. 4)
-  PQN_OPT_BM_OVERLAP,     // PQN_BM_OVERLAP: parameter-gradient side of the wide-MLP backward on a second stream (default 1)
+  PQN_OPT_BM_OVERLAP,     // PQN_BM_OVERLAP: parameter-gradient side of the wide-MLP backward on a second stream (default 0: measured no gain)
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);

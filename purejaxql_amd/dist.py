@@ -11,6 +11,7 @@ The reference has no multi-device code.  Its two vmap axes shard as
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
@@ -54,15 +55,121 @@ def partition_seeds(num_seeds: int, world_size: int, rank: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def make_grad_allreduce_hook(group: Optional[dist.ProcessGroup] = None) -> Callable[[torch.Tensor], None]:
-    """grad_hook for make_train (env-sharded mode): sum the flat gradient bucket over
-    ranks, divide by world size (mean over the global minibatch of B*G samples)."""
+class PeersStruct(C.Structure):
+    """pqn_peers_t (include/pqn_hotpath.h)"""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("n", C.c_int64), ("region", C.c_void_p * 8),
+                ("local_state", C.c_void_p)]
+
+
+class PeerAllReduce:
+    """One-shot all-reduce (mean) of a flat f32 bucket over hipIpc-mapped peer buffers (csrc/pqn_peer.hip): two small
+    kernels on the current stream, no host in the loop, capturable in a hipGraph.  Ranks of ONE node, world <= 8.
+    setup() is collective (handle exchange over the process group) and returns False on EVERY rank when any rank could not
+    allocate or map a region -- the caller then keeps the torch.distributed collective."""
+
+    def __init__(self, n: int, device: torch.device, group: Optional[dist.ProcessGroup] = None):
+        self.n, self.device, self.group = int(n), device, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.struct: Optional[PeersStruct] = None
+        self._own = None
+        self._opened: List[int] = []
+
+    def setup(self) -> bool:
+        from . import _lib
+        lib = _lib.load()
+        ok = self.world <= 8 and self.device.type == "cuda"
+        own, handle = C.c_void_p(0), (C.c_uint8 * 64)()
+        if ok:
+            nbytes = int(lib.pqn_peer_region_bytes(self.n))
+            ok = nbytes > 0 and lib.pqn_peer_alloc(nbytes, C.addressof(own), C.addressof(handle)) == 0
+        gathered: List[Any] = [None] * self.world
+        dist.all_gather_object(gathered, (bool(ok), bytes(handle), os.getpid()), group=self.group)
+        ok = all(g[0] for g in gathered)
+        st = PeersStruct()
+        st.rank, st.world, st.n = self.rank, self.world, self.n
+        if ok:
+            for r, (_ok, h, pid) in enumerate(gathered):
+                if r == self.rank:
+                    st.region[r] = own.value
+                    continue
+                ptr = C.c_void_p(0)
+                buf = (C.c_uint8 * 64).from_buffer_copy(h)
+                if pid == os.getpid() or lib.pqn_peer_open(C.addressof(buf), C.addressof(ptr)) != 0:
+                    ok = False
+                    break
+                self._opened.append(ptr.value)
+                st.region[r] = ptr.value
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bool(ok), group=self.group)   # everyone mapped everyone, or nobody uses the path
+        ok = all(flags)
+        self._own = own.value
+        if not ok:
+            self.close()
+            return False
+        self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        st.local_state = self.state.data_ptr()
+        self.struct = st
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)   # every region is zeroed and mapped before the first publish
+        return True
+
+    def __call__(self, flat_grad: torch.Tensor) -> None:
+        from . import _lib
+        assert flat_grad.numel() == self.n and flat_grad.dtype == torch.float32 and flat_grad.is_contiguous()
+        _lib.check(_lib.load().pqn_peer_allreduce_mean(C.byref(self.struct), _lib.ptr(flat_grad), _lib.stream_ptr()),
+                   "pqn_peer_allreduce_mean")
+
+    def check(self) -> None:
+        """Synchronises; raises if a peer never arrived inside a collective (the kernels give up instead of hanging)."""
+        from . import _lib
+        err = C.c_int32(0)
+        _lib.check(_lib.load().pqn_peer_status(C.byref(self.struct), C.addressof(err)), "pqn_peer_status")
+        if err.value:
+            raise RuntimeError("peer all-reduce: a rank did not publish its gradient in time (results are invalid)")
+
+    def close(self) -> None:
+        from . import _lib
+        lib = _lib.load()
+        for p in self._opened:
+            lib.pqn_peer_close(p)
+        self._opened = []
+        if self._own:
+            lib.pqn_peer_free(self._own)
+            self._own = None
+        self.struct = None
+
+
+def make_grad_allreduce_hook(group: Optional[dist.ProcessGroup] = None, peer: Optional[bool] = None) -> Callable[[torch.Tensor], None]:
+    """grad_hook for make_train (env-sharded mode): average the flat gradient bucket over ranks (mean over the global
+    minibatch of B*G samples).  peer (default: PQN_PEER_ALLREDUCE, on): try the one-shot all-reduce over hipIpc-mapped
+    peer buffers first (PeerAllReduce, set up on the first call, which is collective); `hook.capturable` then turns True and
+    the update drivers capture the whole update, collectives included, as ONE hipGraph.  Otherwise, or when the setup
+    fails on any rank (CPU tensors, ranks on different nodes, IPC unavailable), the torch.distributed all-reduce (RCCL)
+    issued from the host between graph segments."""
     world = dist.get_world_size(group)
+    if peer is None:
+        peer = os.environ.get("PQN_PEER_ALLREDUCE", "1") != "0"
+    box: Dict[str, Any] = {"peer": None, "tried": not peer}
 
     def hook(flat_grad: torch.Tensor) -> None:
+        if not box["tried"]:
+            box["tried"] = True
+            if flat_grad.is_cuda:
+                par = PeerAllReduce(flat_grad.numel(), flat_grad.device, group)
+                if par.setup():
+                    box["peer"] = par
+                    hook.capturable = True
+                    hook.mode = "peer"
+                    hook.check = par.check
+        if box["peer"] is not None:
+            box["peer"](flat_grad)
+            return
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
         flat_grad.div_(world)
 
+    hook.capturable = False
+    hook.mode = "host"
+    hook.check = lambda: None
     return hook
 
 

@@ -721,6 +721,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                    if craftax else m)
 
         def finish():
+            if grad_hook is not None and hasattr(grad_hook, "check"):
+                grad_hook.check()      # a peer that never arrived inside an in-graph collective: raise, do not return garbage
             if driver is not None:
                 from .qnet import METRIC_NAMES
                 for j, name in enumerate(METRIC_NAMES):
@@ -734,6 +736,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                             "last_obs": obuf[0], "test_metrics": tm_box[0], "network": network, "backend": backend,
                             "driver": None if driver is None else ("graph" if driver.graph is not None else "eager"),
                             "driver_graph_error": None if driver is None else driver.graph_error, "rng": K,
+                            "driver_graphs": None if driver is None else (1 if getattr(driver, "whole", None) is not None else
+                                                                          len(getattr(driver, "graphs", None) or [1])),
+                            "allreduce": getattr(grad_hook, "mode", None) if grad_hook is not None else None,
                             **policy.opt_state(), **counters})
             return {"runner_state": runner_state, "metrics": metrics}
 

@@ -334,14 +334,39 @@ class EnvShardDriver(UpdateDriver):
         segs.append([(PHASE_APPLY, n - 1), (PHASE_END, 0)])
         self.segments = segs
         self.graphs = None
+        self.whole = None    # the single graph of the whole update (capturable collective only)
 
     def _enqueue_segment(self, seg):
         lib = _lib.load()
         for phase, index in seg:
             _lib.check(lib.pqn_cnn_update_phase(C.byref(self.args), phase, index, _lib.stream_ptr()), "pqn_cnn_update_phase")
 
+    def _enqueue_all(self):
+        trainer = self._keep[0]
+        for k, seg in enumerate(self.segments):
+            self._enqueue_segment(seg)
+            if k + 1 < len(self.segments):
+                self.grad_hook(trainer.grad)
+
     def update(self):
         trainer = self._keep[0]
+        # a capturable collective (dist.PeerAllReduce: kernels on the training stream) lets the WHOLE update, its
+        # NUM_MINIBATCHES*NUM_EPOCHS all-reduces included, be one hipGraph per rank: update 0 runs eagerly (the hook sets
+        # itself up there), update 1 is captured and replayed, later ones replay
+        if getattr(self.grad_hook, "capturable", False) and self.use_graph and self.graph_error is None and self.graphs is None:
+            if self.whole is None and self.calls >= 1:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._enqueue_all()
+                    self.whole = self.graph = g
+                except Exception as exc:  # stay on the per-segment path below (still the HIP path)
+                    self.graph_error = repr(exc)
+                    torch.cuda.synchronize()
+            if self.whole is not None:
+                self.whole.replay()
+                self.calls += 1
+                return
         capture = self.use_graph and self.calls == 1 and self.graphs is None and self.graph_error is None
         new_graphs = []
         for k, seg in enumerate(self.segments):

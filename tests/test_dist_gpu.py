@@ -30,9 +30,9 @@ def _cfg(num_envs_global, n_upd):
     return cfg
 
 
-def _rank_main(rank, world, port, q, num_envs_global, n_upd, theta0, use_driver):
+def _rank_main(rank, world, port, q, num_envs_global, n_upd, theta0, use_driver, peer):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1")
+                      LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from purejaxql_amd import dist as pdist
     from purejaxql_amd.pqn import make_train, seed_keys
@@ -40,24 +40,26 @@ def _rank_main(rank, world, port, q, num_envs_global, n_upd, theta0, use_driver)
     cfg = pdist.shard_env_config(_cfg(num_envs_global, n_upd), rank, world)
     cfg["_INIT_PARAMS"] = torch.from_numpy(theta0).to("cuda:0")
     cfg["_DRIVER"] = use_driver
-    train = make_train(cfg, device="cuda:0", grad_hook=pdist.make_grad_allreduce_hook(),
+    train = make_train(cfg, device="cuda:0", grad_hook=pdist.make_grad_allreduce_hook(peer=peer),
                        metrics_hook=pdist.allreduce_mean_scalars)
     out = train(seed_keys(0, 1)[0])
     torch.cuda.synchronize()
     rs = out["runner_state"]
     q.put((rank, rs["theta"].cpu().numpy(), {k: v.cpu().numpy() for k, v in out["metrics"].items()}, rs["driver"],
-           rs["driver_graph_error"]))
+           (rs["driver_graph_error"], rs["allreduce"], rs["driver_graphs"])))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_driver", [True, False])
-def test_two_rank_env_sharded_training_matches_oracle_with_averaged_gradients(gpu, oracle, use_driver):
+@pytest.mark.parametrize("use_driver,peer", [(True, True), (True, False), (False, True), (False, False)])
+def test_two_rank_env_sharded_training_matches_oracle_with_averaged_gradients(gpu, oracle, use_driver, peer):
     """3 updates of make_train(grad_hook = all-reduce mean) on 2 ranks x 32 envs: theta identical on both ranks and
     equal (bulk rtol 2e-3, worst element < lr: the criterion of test_make_train_end_to_end_vs_oracle) to the oracle loop
     that averages the two shards' gradients per optimizer step; metric means are means over both shards.
-    use_driver: the phase-split C++ enqueue with per-segment hipGraphs (update 0 eager, 1 captured, 2 replayed) /
-    the per-kernel Python loop."""
+    use_driver: the phase-split C++ enqueue with hipGraphs (update 0 eager, 1 captured, 2 replayed) / the per-kernel
+    Python loop.  peer: the one-shot all-reduce over hipIpc-mapped peer buffers (csrc/pqn_peer.hip; two processes mapping
+    each other's staging regions on the one GPU) -- the whole update, its 8 collectives included, is then ONE graph per
+    rank -- / the torch.distributed collective issued from the host between 9 per-segment graphs."""
     from purejaxql_amd.dist import shard_env_config
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.pqn import seed_keys
@@ -66,7 +68,7 @@ def test_two_rank_env_sharded_training_matches_oracle_with_averaged_gradients(gp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, n_glob, n_upd, theta0, use_driver)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, n_glob, n_upd, theta0, use_driver, peer)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda x: x[0])
@@ -74,8 +76,11 @@ def test_two_rank_env_sharded_training_matches_oracle_with_averaged_gradients(gp
         p.join(timeout=120)
         assert p.exitcode == 0
     (_, th0, m0, drv0, err0), (_, th1, m1, _drv1, _err1) = res
+    gerr, mode, n_graphs = err0
+    assert mode == ("peer" if peer else "host"), (mode, gerr)
     if use_driver:
-        assert drv0 == "graph", err0
+        assert drv0 == "graph", gerr
+        assert n_graphs == (1 if peer else 9), (n_graphs, gerr)
     else:
         assert drv0 is None
     np.testing.assert_array_equal(th0, th1)                   # both ranks applied the same averaged gradients
@@ -94,3 +99,69 @@ def test_two_rank_env_sharded_training_matches_oracle_with_averaged_gradients(gp
     d = np.abs(th0 - oout["theta"])
     bad = d > (2e-5 + 2e-3 * np.abs(oout["theta"]))
     assert bad.mean() < 1e-3 and d.max() < 5e-4, (int(bad.sum()), float(d.max()))
+
+
+def _peer_main(rank, world, port, q, n, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from purejaxql_amd import dist as pdist
+    pdist.init_from_env()
+    dev = torch.device("cuda:0")
+    par = pdist.PeerAllReduce(n, dev)
+    ok = par.setup()
+    outs, refs = [], []
+    if ok:
+        g = torch.Generator(device="cpu")
+        side = torch.cuda.Stream()
+        for s in range(steps):
+            # every rank can rebuild every rank's bucket: the expected mean needs no second collective
+            vs = []
+            for r in range(world):
+                g.manual_seed(1000 * s + r)
+                vs.append(torch.randn(n, generator=g))
+            mine = vs[rank].to(dev)
+            if s == steps // 2:
+                time_skew = torch.randn(4096, 4096, device=dev)      # one rank arrives late at this step
+                for _ in range(20 if rank == 0 else 0):
+                    time_skew = time_skew @ time_skew * 1e-3
+            if s % 3 == 2:
+                with torch.cuda.stream(side):                        # the collective follows the caller's current stream
+                    side.wait_stream(torch.cuda.current_stream())
+                    par(mine)
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                par(mine)
+            acc = torch.zeros(n)
+            for r in range(world):
+                acc += vs[r]
+            outs.append(mine.cpu())
+            refs.append(acc * (1.0 / world))
+        par.check()
+    q.put((rank, ok, [o.numpy() for o in outs], [r.numpy() for r in refs]))
+    dist.barrier()
+    par.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [132475, 7])
+def test_peer_allreduce_two_processes_on_one_gpu(gpu, n):
+    """dist.PeerAllReduce by itself: two processes map each other's staging regions through hipIpc and average a bucket of
+    the CNN's size (odd length: the scalar tail) over 24 consecutive steps (double-buffer reuse, one rank arriving late,
+    calls from a side stream): bit-identical on both ranks and equal to the sum in rank order times 1 / world."""
+    world, steps = 2, 24
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_main, args=(r, world, port, q, n, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, ok0, o0, r0), (_, ok1, o1, _r1) = res
+    assert ok0 and ok1, "hipIpc peer mapping is unavailable on this box"
+    for s in range(steps):
+        np.testing.assert_array_equal(o0[s], o1[s], err_msg=f"step {s}")
+        np.testing.assert_array_equal(o0[s], r0[s], err_msg=f"step {s}")
