@@ -249,12 +249,14 @@ def main():
         # the envs of ONE seed split over the ranks, gradient all-reduce per optimizer step
         spg = 1
         scfg = pdist.shard_env_config(cfg, rank, world) if world > 1 else dict(cfg)
-        train = make_train(scfg, device=str(dev), grad_hook=pdist.make_grad_allreduce_hook() if world > 1 else None,
+        ghook = pdist.make_grad_allreduce_hook() if world > 1 else None   # one-shot peer all-reduce when hipIpc maps the ranks
+        train = make_train(scfg, device=str(dev), grad_hook=ghook,
                            metrics_hook=pdist.allreduce_mean_scalars if world > 1 else None)
         update, finish = train.make_runner(seed_keys(0, 1)[0])
         env_steps_per_update = cfg["NUM_ENVS"] * cfg["NUM_STEPS"]          # the global env count, all ranks together
         scaling = "strong"
     else:
+        ghook = None
         # seeds are independent runs: rank r trains seeds [r*spg, (r+1)*spg) of seed_keys(0, world*spg), no collective
         train = make_train(dict(cfg), device=str(dev))
         keys = seed_keys(0, world * spg)[rank * spg:(rank + 1) * spg]
@@ -318,6 +320,7 @@ def main():
                        "kernel_forms": dict(zip(("train", "rollout"), _lib.last_kernel_form())),
                        "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if world > 1 else 1,
                        "dist_backend": dist.get_backend() if world > 1 else None,
+                       "grad_allreduce": (getattr(ghook, "mode", None) if args.mode == "envs" and world > 1 else None),
                        "gpus_visible": torch.cuda.device_count(),
                        "loop_tflops": sps * LOOP_FLOP / 1e12, "loop_frac_f32_peak": sps * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS},
             "roofline": roof,
