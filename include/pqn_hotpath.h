@@ -81,6 +81,10 @@ typedef struct {
   float *returned_episode_returns;   /* [n] */
   int32_t *returned_episode_lengths; /* [n] */
   int32_t *timestep;                 /* [n] */
+  uint32_t *achievements;            /* [n] Craftax only (other envs ignore it): bit k = achievement k unlocked in the episode
+                                        that ENDED with this step, 0 for envs that did not finish -- the source of the
+                                        info["Achievements/<name>"] = done * unlocked * 100 keys the Craftax script logs
+                                        (pqn_craftax.py:364-369,384-387 with LOG_ACHIEVEMENTS) */
 } pqn_step_out_t;
 
 const char *pqn_last_error(void);

@@ -27,7 +27,7 @@ class StepOut(C.Structure):
     """pqn_step_out_t"""
     _fields_ = [("obs", c_void_p), ("obs_bits", c_void_p), ("reward", c_void_p), ("done", c_void_p),
                 ("discount", c_void_p), ("returned_episode_returns", c_void_p),
-                ("returned_episode_lengths", c_void_p), ("timestep", c_void_p)]
+                ("returned_episode_lengths", c_void_p), ("timestep", c_void_p), ("achievements", c_void_p)]
 
 
 # name -> (restype, argtypes).  Every symbol include/pqn_hotpath.h declares.

@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) void cc_step_kernel(int n, uint64_t key, const
   if (out.returned_episode_returns) out.returned_episode_returns[e] = log.ret_ret;
   if (out.returned_episode_lengths) out.returned_episode_lengths[e] = log.ret_len;
   if (out.timestep) out.timestep[e] = log.timestep;
+  if (out.achievements) out.achievements[e] = done ? (uint32_t)s.ach : 0u;
   if (opt_keys) {   // optimistic resets: the sort key that ranks the finished envs (see pqn_env.hip opt_choice_key)
     uint64_t k = ~(uint64_t)0;
     if (done) {

@@ -55,6 +55,13 @@ class EnvState:
         return self.words.shape[1]
 
 
+CRAFTAX_CLASSIC_ACHIEVEMENTS = (
+    "collect_coal", "collect_diamond", "collect_drink", "collect_iron", "collect_sapling", "collect_stone", "collect_wood",
+    "defeat_skeleton", "defeat_zombie", "eat_cow", "eat_plant", "make_iron_pickaxe", "make_iron_sword", "make_stone_pickaxe",
+    "make_stone_sword", "make_wood_pickaxe", "make_wood_sword", "place_furnace", "place_plant", "place_stone", "place_table",
+    "wake_up")
+
+
 class Environment:
     """Batched functional environment backed by pqn_env_reset / pqn_env_step."""
 
@@ -79,6 +86,8 @@ class Environment:
         self.num_actions = int(spec.num_actions)
         self.default_params = EnvParams(max_steps_in_episode=int(spec.max_steps))
         self.in_place_only = name.startswith("Craftax")
+        # Craftax-Classic's Achievement enum order (bit k of the mask pqn_step_out_t.achievements carries)
+        self.achievement_names = CRAFTAX_CLASSIC_ACHIEVEMENTS if name == "Craftax-Classic-Symbolic-v1" else ()
         self.device = torch.device(device) if device is not None else torch.device("cuda")
 
     # -- spaces ----------------------------------------------------------------
@@ -149,6 +158,10 @@ class Environment:
             out.returned_episode_returns = _lib.ptr(rer)
             out.returned_episode_lengths = _lib.ptr(rel)
             out.timestep = _lib.ptr(ts)
+        ach = None
+        if self.achievement_names:      # Craftax: the achievement mask of the episodes that end with this step
+            ach = torch.empty(n, dtype=torch.int32, device=dev)
+            out.achievements = _lib.ptr(ach)
         _lib.check(lib.pqn_env_step(self.env_id, n, key, _lib.ptr(src_words), _lib.ptr(new_words),
                                     _lib.ptr(action), C.byref(out), _lib.stream_ptr()), "pqn_env_step")
         done_b = done.view(torch.bool)
@@ -157,6 +170,8 @@ class Environment:
             info["returned_episode_lengths"] = rel
             info["timestep"] = ts
             info["returned_episode"] = done_b
+        if ach is not None:
+            info["achievements"] = ach
         new_state = EnvState(new_words)
         if want_bits:
             return (obs, bits), new_state, reward, done_b, info
@@ -297,6 +312,9 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
             ts = torch.empty(n, dtype=torch.int32, device=dev)
             out.returned_episode_returns, out.returned_episode_lengths, out.timestep = _lib.ptr(rer), _lib.ptr(rel), _lib.ptr(ts)
         slots = torch.empty(n, dtype=torch.int32, device=dev) if want_slots else None
+        if base.achievement_names:
+            info["achievements"] = torch.empty(n, dtype=torch.int32, device=dev)
+            out.achievements = _lib.ptr(info["achievements"])
         _lib.check(lib.pqn_env_step_optimistic(base.env_id, n, rng, self.reset_ratio, _lib.ptr(src_words),
                                                _lib.ptr(new_words), _lib.ptr(action), C.byref(out),
                                                _lib.ptr(scratch), _lib.ptr(slots), sid),

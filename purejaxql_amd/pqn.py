@@ -557,6 +557,11 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         names = ["env_step", "update_steps", "grad_steps", "td_loss", "qvals"] + list(INFO_KEYS)
         if kind == "cnn":
             names.insert(2, "env_frame")
+        # info["Achievements/<name>"] = done * unlocked * 100 of the Craftax envs (pqn_craftax.py:364-369,384-387): logged only
+        # with LOG_ACHIEVEMENTS, from the achievement mask the step kernel emits for the episodes that end
+        ach_names = list(base_env.achievement_names) if (craftax and config.get("LOG_ACHIEVEMENTS", False)) else []
+        ach_buf = torch.zeros((T, N), dtype=torch.int32, device=dev) if ach_names else None
+        names += [f"Achievements/{a}" for a in ach_names]
         if test_on:
             names += [f"test/{k}" for k in INFO_KEYS]
         metrics = {k: torch.zeros(NUM_UPDATES, dtype=torch.float32, device=dev) for k in names}
@@ -575,7 +580,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             driver = UpdateDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
                                   policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
                                   fused_opt=config.get("_FUSED_OPT", False))
-        elif backend == "fused_big" and grad_hook is None and config.get("_DRIVER", True) and driver_shape_ok:
+        elif backend == "fused_big" and grad_hook is None and config.get("_DRIVER", True) and driver_shape_ok and not ach_names:
             # the Craftax script's loop (wrapper-batched env, wide MLP) from one C call, replayed as a hipGraph
             from .qnet import BigMlpUpdateDriver
             dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
@@ -646,6 +651,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                     ro.rer[t].copy_(info_n["returned_episode_returns"])
                     ro.rel[t].copy_(info_n["returned_episode_lengths"])
                     ro.ts[t].copy_(info_n["timestep"])
+                    if ach_names:
+                        ach_buf[t].copy_(info_n["achievements"])
                 else:
                     env_step_into(sk, words, ro.action[t], None if packed else ro.obs[t + 1],
                                   ro.bits[t + 1] if packed else None, ro.reward[t], ro.done[t], ro.discount[t],
@@ -657,6 +664,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 info_means = {kk: ((vv.to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk, vv in
                               (("discount", ro.discount), ("returned_episode_returns", ro.rer),
                                ("returned_episode_lengths", ro.rel), ("timestep", ro.ts), ("returned_episode", ro.done))}
+                for k_a, a_name in enumerate(ach_names):   # x = done * unlocked * 100, then the same done-weighted mean
+                    x = ((ach_buf >> k_a) & 1).to(torch.float64) * 100.0 * dm
+                    info_means[f"Achievements/{a_name}"] = ((x * dm).sum() / cnt).to(torch.float32)
             else:
                 info_means = {
                     "discount": ro.discount.mean(), "returned_episode_returns": ro.rer.mean(),

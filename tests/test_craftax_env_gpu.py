@@ -54,7 +54,7 @@ def test_craftax_step_autoreset_bit_exact_vs_oracle(gpu, oracle, n, steps):
     obs, state = env.reset(5, params, n)
     oobs, ost = oenv.reset(5, n)
     rng = np.random.default_rng(n)
-    dones = 0
+    dones, ach_seen = 0, 0
     for t in range(steps):
         a = _policy(rng, n, t)
         if t == 100:   # hand out tools and materials once so that mining / crafting / placing / fighting rules fire
@@ -65,6 +65,12 @@ def test_craftax_step_autoreset_bit_exact_vs_oracle(gpu, oracle, n, steps):
             ost["si"][:] = si
         key = 7000 + t
         obs, state, r, d, info = env.step(key, state, torch.from_numpy(a).to(gpu), params)
+        # the achievement mask of the episodes that end with this step: the stepped state BEFORE the reset, from a copy
+        ost2 = {k: v.copy() for k, v in ost.items()}
+        _o2, ost2, _r2, od2, _i2 = oenv.step(key, ost2, a, autoreset=False)
+        exp_ach = np.where(od2, ost2["si"][:, S + 109], 0).astype(np.int32)
+        np.testing.assert_array_equal(_np(info["achievements"]), exp_ach, err_msg=f"achievements t={t}")
+        ach_seen |= int(np.bitwise_or.reduce(exp_ach))
         oobs, ost, orr, od, oinfo = oenv.step(key, ost, a)
         np.testing.assert_array_equal(_np(d), od, err_msg=f"done t={t}")
         np.testing.assert_array_equal(_np(r), orr, err_msg=f"reward t={t}")
@@ -75,6 +81,7 @@ def test_craftax_step_autoreset_bit_exact_vs_oracle(gpu, oracle, n, steps):
                 np.testing.assert_array_equal(_np(info[k]), oinfo[k], err_msg=k)
             _check_state(env, oenv, state, ost)
     assert dones > 0 and ost["ret_len"].max() > 0
+    assert n < 100 or ach_seen != 0            # finished episodes carried achievements in their info mask
     ach = np.bitwise_or.reduce(ost["si"][:, S + 109])
     assert bin(int(ach)).count("1") >= 4       # several different achievements were unlocked along the way
 
