@@ -349,13 +349,14 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * fusions itself).  Names: "t1_pair", "rollout_pair" (pair form of the bf16x3 training / rollout kernel: 0 never,
  * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
  * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP
- * backward on a second stream; default 0).  Each starts from its PQN_<NAME> environment
+ * backward on a second stream; default 0), "t1_ksplit" (K-split form of the f32-mode training kernel for minibatches of
+ * at most 256 samples: a tile's work cut along the conv positions over 8 workgroups; default 1).  Each starts from its PQN_<NAME> environment
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);
 /* Which form the LAST enqueued training (pqn_qnet_cnn_grad / pqn_cnn_update*) and rollout (pqn_cnn_rollout*) launch
  * used: 0 none yet, 1 single-tile kernels, 2 pair kernels, 3 pair + paired dgrad, 4 pair forward + position-parallel
- * backward.  Lets a test assert in-process that the configuration it means to cover is the one that ran. */
+ * backward, 5 K-split kernels (small minibatches, f32 mode).  Lets a test assert in-process that the configuration it means to cover is the one that ran. */
 int pqn_cnn_last_kernel_form(int32_t *train_form /* host, nullable */, int32_t *rollout_form /* host, nullable */);
 
 /* ---- fused MLP Q-network (QNetwork of pqn_gymnax.py:29-58, layer_norm, NORM_INPUT=False) ----------- */

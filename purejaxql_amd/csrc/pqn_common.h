@@ -84,12 +84,13 @@ enum {
   PQN_OPT_ABLATE,         // PQN_ABLATE: phase ablation of the forward kernel (profiling)
   PQN_OPT_BM_TILE,        // PQN_BM_TILE: tile height of the wide-MLP GEMMs (0 auto, 64, 128)
   PQN_OPT_BM_SPLIT,       // PQN_BM_SPLIT: K splits of the wide-MLP GEMMs (0 auto, 1 .. 4)
+  PQN_OPT_T1_KSPLIT,      // PQN_T1_KSPLIT: K-split form of the f32-mode training kernel for minibatches <= 256 samples (default 1)
   PQN_OPT_BM_OVERLAP,     // PQN_BM_OVERLAP: parameter-gradient side of the wide-MLP backward on a second stream (default 0: measured no gain)
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);
 // which form of the training / rollout kernels the last launch used (pqn_cnn_last_kernel_form)
-enum { PQN_FORM_NONE = 0, PQN_FORM_SINGLE = 1, PQN_FORM_PAIR = 2, PQN_FORM_PAIR_PD2 = 3, PQN_FORM_PAIR_POS = 4 };
+enum { PQN_FORM_NONE = 0, PQN_FORM_SINGLE = 1, PQN_FORM_PAIR = 2, PQN_FORM_PAIR_PD2 = 3, PQN_FORM_PAIR_POS = 4, PQN_FORM_KSPLIT = 5 };
 void pqn_note_kernel_form(int which /* 0 = training, 1 = rollout */, int form);
 
 // bf16x3 weight planes (pqn_qnet.hip): x = hi + mid + lo exactly, each a bf16 (round to nearest even); element (i, o)

@@ -2213,6 +2213,340 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// T1 for SMALL minibatches (f32 operand mode, nb <= KS_MAX_NB): the K-split form.  A 128-sample minibatch is 8 tiles:
+// the single-tile kernel above then runs on 8 of 256 CUs and one optimizer step costs the latency of a whole tile pass
+// (36 us: the yaml-default MinAtar run, 128 envs, spends 56 % of its time there).  Here a tile is cut along the conv
+// POSITIONS -- the K dimension of fc1, the N dimension of its input gradient, the M dimension of its weight gradient --
+// into NG = 64 / PG groups of PG positions, one 256-thread workgroup each, so that 8 tiles are 64 (PG = 8) workgroups:
+//   ks_fwd   (group, tile): conv + LayerNorm_0 + relu of its PG positions x 16 samples, fc1 partial over its 16 PG features
+//            against its 1/NG of W1 -> zpart[tile][group][16][128]
+//   ks_head  (tile): z = sum of the NG partials, then the unchanged head of the training kernel (train_head): loss, head
+//            parameter gradients, dz[16][128]
+//   ks_bwd   (group, tile): conv + LayerNorm_0 again (cheaper than a round trip through memory), input gradient of ITS
+//            features from dz and its 1/NG of W1 (dgrad fragment order), relu mask, LayerNorm_0 backward, conv weight
+//            gradient partial, and its rows of the fc1 weight gradient for the tile -- straight in the layout of the
+//            split-K slabs of T2, one slab per tile -- so there is no h1 hand-over and no T2.
+// Everything stays in MFMA accumulator layout: ks_fwd runs the conv TRANSPOSED (rows = channels, columns = samples), which
+// makes a lane's four conv outputs exactly its A fragment of the fc1 product; ks_bwd runs it the usual way (rows =
+// samples, columns = channels), which is the layout the input gradient comes out in, the B fragment of the conv weight
+// gradient and the A fragment of the fc1 weight gradient.  No LDS transposes, no staging.
+// gfx950's f32-input MFMA (v_mfma_f32_16x16x4_f32) throughout: exact f32 products, as the large-batch f32 mode.
+// ---------------------------------------------------------------------------
+#define KS_MAX_NB 256
+#define KS_PG 8                 // conv positions per workgroup
+#define KS_NG (64 / KS_PG)      // position groups (workgroups) per tile
+#define KS_THREADS 256
+#define KS_DZS 132   // LDS row stride of the dz tile
+
+// window masks of ONE point (sample's packed row, position): word ky = the 3C bits of window row ky
+template <int C>
+PQN_D void window_masks_point(const uint32_t *row_bits, int pos, uint32_t (&m)[3]) {
+  const int py = pos >> 3, px = pos & 7;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int b = ((py + ky) * 10 + px) * C;
+    const uint64_t v = ((((uint64_t)row_bits[(b >> 5) + 1]) << 32) | row_bits[b >> 5]) >> (b & 31);
+    m[ky] = (uint32_t)v & ((1u << (3 * C)) - 1u);
+  }
+}
+
+// gather of the tile's packed observations + the window masks of (position pl of the group, sample) into LDS
+template <int C, int PG>
+PQN_D void ks_gather(int nb, int b0, int grp, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits,
+                     const pqn_seeds_t &sd, int seed, uint32_t *s_bits, uint32_t *s_wm, int tid) {
+  using Cfg = CnnCfg<C>;
+  auto row_of = [&](int64_t key) -> int64_t {
+    const uint32_t j = (uint32_t)(key & sd.idx_mask);
+    if (sd.n_env_total == sd.n_env) return (int64_t)j;
+    const uint32_t t = j / (uint32_t)sd.n_env;
+    return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
+  };
+  for (int i = tid; i < QN_TILE * Cfg::OW; i += KS_THREADS) {
+    const int le = i / Cfg::OW;
+    s_bits[i] = (b0 + le < nb) ? obs_bits[(size_t)row_of(idx[b0 + le]) * Cfg::OW + (i % Cfg::OW)] : 0u;
+  }
+  if (tid < 4) s_bits[QN_TILE * Cfg::OW + tid] = 0u;
+  __syncthreads();
+  for (int t = tid; t < 16 * PG; t += KS_THREADS) {
+    uint32_t m[3];
+    window_masks_point<C>(s_bits + (t & 15) * Cfg::OW, grp * PG + (t >> 4), m);
+    s_wm[t * 3] = m[0]; s_wm[t * 3 + 1] = m[1]; s_wm[t * 3 + 2] = m[2];
+  }
+  __syncthreads();
+}
+
+template <int C, int PG>
+__global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_fwd_kernel(int nb, const int64_t *__restrict__ idx,
+                                                                     const uint32_t *__restrict__ obs_bits,
+                                                                     const float *__restrict__ theta, pqn_cnn_layout_t L,
+                                                                     float *__restrict__ zpart, pqn_seeds_t sd) {
+  using Cfg = CnnCfg<C>;
+  constexpr int NG = 64 / PG, PW = PG / 4;   // groups per tile, positions per wave
+  static_assert(PG == 4 || PG == 8 || PG == 16, "positions per workgroup");
+  __shared__ __attribute__((aligned(16))) uint32_t s_bits[QN_TILE * Cfg::OW + 4];
+  __shared__ uint32_t s_wm[16 * PG * 3];
+  __shared__ __attribute__((aligned(16))) float s_wc[Cfg::KW * 16 + 48];
+  __shared__ __attribute__((aligned(16))) float s_z[4][QN_TILE][QN_HID + 4];
+  const int seed = blockIdx.z + sd.seed_base;
+  idx += seed * sd.idx_stride;
+  theta += seed * sd.theta_stride;
+  zpart += seed * sd.ws_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x, tile = blockIdx.y, b0 = tile * QN_TILE;
+  for (int i = tid; i < Cfg::KW * 16 + 48; i += KS_THREADS) s_wc[i] = theta[L.off_wc + i];
+  ks_gather<C, PG>(nb, b0, grp, idx, obs_bits, sd, seed, s_bits, s_wm, tid);
+  ConvMfma<C> cv;
+  cv.init(s_wc, lane);                       // wk[s] = Wc[4 s + (lane >> 4)][lane & 15]: here the A operand (row = channel)
+  const float *bc = s_wc + Cfg::KW * 16;
+  const int smp = lane & 15, cq = 4 * (lane >> 4);   // this lane: sample column, channels cq .. cq + 3
+  const f32x4 *wp = reinterpret_cast<const f32x4 *>(theta + L.off_w1);
+  f32x4 acc[8];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < PW; ++q) {
+    const int pl = wave * PW + q, pos = grp * PG + pl;
+    f32x4 wfr[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) wfr[cb] = wp[(pos * 8 + cb) * 64 + lane];   // this position's 16 rows of W1: 8 KB per wave
+    const uint32_t m[3] = {s_wm[(pl * 16 + smp) * 3], s_wm[(pl * 16 + smp) * 3 + 1], s_wm[(pl * 16 + smp) * 3 + 2]};
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < ConvMfma<C>::NS; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(cv.wk[st], cv.a_of(m, st), d, 0, 0, 0);
+    float v[4] = {d.x + bc[cq], d.y + bc[cq + 1], d.z + bc[cq + 2], d.w + bc[cq + 3]};
+    float sum = (v[0] + v[1]) + (v[2] + v[3]);
+    float sq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+    sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);   // the 16 channels of (sample, position): 4 lanes x 4
+    sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+    const float mean = sum * (1.0f / 16.0f);
+    const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
+    const float rstd = rsqrt_exact(var + QN_LN_EPS);
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf((v[r] - mean) * rstd, bc[16 + cq + r], bc[32 + cq + r]), 0.0f);
+    // fc1 partial: A[i = sample][K slot = lane >> 4] of sub-step x is feature 16 pos + 4 (lane >> 4) + x = y[x]
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[0], wfr[cb].x, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[1], wfr[cb].y, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2], wfr[cb].z, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[3], wfr[cb].w, acc[cb], 0, 0, 0);
+    }
+  }
+  // D: column = output 16 cb + (lane & 15), rows = samples 4 (lane >> 4) + r.  Fold the four waves in fixed order.
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) {
+    float *zp = &s_z[wave][cq][16 * cb + smp];
+    zp[0] = acc[cb].x; zp[QN_HID + 4] = acc[cb].y; zp[2 * (QN_HID + 4)] = acc[cb].z; zp[3 * (QN_HID + 4)] = acc[cb].w;
+  }
+  __syncthreads();
+  float *dst = zpart + ((size_t)tile * NG + grp) * (QN_TILE * QN_HID);
+  for (int e = tid; e < QN_TILE * QN_HID / 4; e += KS_THREADS) {
+    const int mrow = e >> 5, c4 = (e & 31) * 4;
+    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&s_z[0][mrow][c4]), a1 = *reinterpret_cast<const f32x4 *>(&s_z[1][mrow][c4]);
+    const f32x4 a2 = *reinterpret_cast<const f32x4 *>(&s_z[2][mrow][c4]), a3 = *reinterpret_cast<const f32x4 *>(&s_z[3][mrow][c4]);
+    reinterpret_cast<f32x4 *>(dst)[e] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+// head of the K-split form: one 512-thread workgroup per tile, the head code of the training kernel unchanged
+template <int C, int NG>
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_ks_head_kernel(
+    int nb, const int64_t *__restrict__ idx, const int32_t *__restrict__ action, const float *__restrict__ target,
+    const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b, const float *__restrict__ zpart, float *__restrict__ dzbuf,
+    float *__restrict__ dzT, float *__restrict__ gpart, pqn_seeds_t sd, float dz_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int seed = blockIdx.y + sd.seed_base;
+  idx += seed * sd.idx_stride;
+  theta += seed * sd.theta_stride;
+  zpart += seed * sd.ws_stride;
+  dzbuf += seed * sd.ws_stride;
+  dzT += seed * sd.ws_stride;
+  gpart += seed * sd.ws_stride;
+  auto row_of = [&](int64_t key) -> int64_t {
+    const uint32_t j = (uint32_t)(key & sd.idx_mask);
+    if (sd.n_env_total == sd.n_env) return (int64_t)j;
+    const uint32_t t = j / (uint32_t)sd.n_env;
+    return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
+  };
+  const TrainSmem ts = carve_train_smem<C>(smem_raw);
+  const CnnSmem &s = ts.n;
+  const int tid = threadIdx.x, tile = blockIdx.x, b0 = tile * QN_TILE;
+  const int rec = small_record_floats(C, L.a);
+  float *gp = gpart + (size_t)tile * NG * rec;          // the record of group 0 carries the tile's head block
+  const int64_t src16 = (tid < QN_TILE && b0 + tid < nb) ? row_of(idx[b0 + tid]) : -1;
+  TileParams<C> tp;
+  tp.load(theta, L, tid);
+  if (src16 >= 0) {
+    ts.act[tid] = action[src16];
+    ts.tgt[tid] = target[src16];
+  } else if (tid < QN_TILE) {
+    ts.act[tid] = 0;
+    ts.tgt[tid] = 0.0f;
+  }
+  tp.store(s, L, tid);
+  const float *zp = zpart + (size_t)tile * NG * (QN_TILE * QN_HID);
+  for (int e = tid; e < QN_TILE * QN_HID / 4; e += QN_THREADS) {
+    f32x4 a = reinterpret_cast<const f32x4 *>(zp)[e];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) a += reinterpret_cast<const f32x4 *>(zp + (size_t)g * (QN_TILE * QN_HID))[e];   // fixed order
+    *reinterpret_cast<f32x4 *>(s.z + (e >> 5) * QN_ZS + (e & 31) * 4) = a;
+  }
+  __syncthreads();
+  switch (L.a) {
+    case 3: train_head<C, 3>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+    case 4: train_head<C, 4>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+    case 5: train_head<C, 5>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+    case 6: train_head<C, 6>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+    default: train_head<C, 0>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, dz_scale); break;
+  }
+  float *dz = dzbuf + (size_t)tile * (QN_TILE * QN_HID);   // train_head left dz in the z tile (and ended with a barrier)
+  for (int e = tid; e < QN_TILE * QN_HID / 4; e += QN_THREADS)
+    reinterpret_cast<f32x4 *>(dz)[e] = *reinterpret_cast<const f32x4 *>(s.z + (e >> 5) * QN_ZS + (e & 31) * 4);
+}
+
+template <int C, int PG>
+__global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_bwd_kernel(int nb, const int64_t *__restrict__ idx,
+                                                                     const uint32_t *__restrict__ obs_bits,
+                                                                     const float *__restrict__ theta, const float *__restrict__ w1b,
+                                                                     pqn_cnn_layout_t L, const float *__restrict__ dzbuf,
+                                                                     float *__restrict__ gpart, float *__restrict__ wpart,
+                                                                     pqn_seeds_t sd) {
+  using Cfg = CnnCfg<C>;
+  constexpr int NG = 64 / PG, PW = PG / 4;
+  constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C;   // 16-row blocks of the conv kernel's k index
+  __shared__ __attribute__((aligned(16))) uint32_t s_bits[QN_TILE * Cfg::OW + 4];
+  __shared__ uint32_t s_wm[16 * PG * 3];
+  __shared__ __attribute__((aligned(16))) float s_wc[Cfg::KW * 16 + 48];
+  __shared__ __attribute__((aligned(16))) float s_dz[QN_TILE * KS_DZS];
+  __shared__ float s_red[4][48];
+  __shared__ float s_cw[4][NRB * 256];
+  const int seed = blockIdx.z + sd.seed_base;
+  idx += seed * sd.idx_stride;
+  theta += seed * sd.theta_stride;
+  w1b += seed * sd.w1b_stride;
+  dzbuf += seed * sd.ws_stride;
+  gpart += seed * sd.ws_stride;
+  wpart += seed * sd.ws_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x, tile = blockIdx.y, b0 = tile * QN_TILE;
+  const int rec = small_record_floats(C, L.a);
+  float *gp = gpart + ((size_t)tile * NG + grp) * rec;
+  for (int i = tid; i < Cfg::KW * 16 + 48; i += KS_THREADS) s_wc[i] = theta[L.off_wc + i];
+  {
+    const float *dz = dzbuf + (size_t)tile * (QN_TILE * QN_HID);
+    for (int e = tid; e < QN_TILE * QN_HID / 4; e += KS_THREADS)
+      *reinterpret_cast<f32x4 *>(s_dz + (e >> 5) * KS_DZS + (e & 31) * 4) = reinterpret_cast<const f32x4 *>(dz)[e];
+  }
+  ks_gather<C, PG>(nb, b0, grp, idx, obs_bits, sd, seed, s_bits, s_wm, tid);
+  ConvMfma<C> cv;
+  cv.init(s_wc, lane);                       // B operand: wk[s] = Wc[4 s + (lane >> 4)][channel = lane & 15]
+  const float *bc = s_wc + Cfg::KW * 16;
+  const int ch = lane & 15, kk = lane >> 4;  // this lane: channel column, samples 4 kk .. 4 kk + 3 (D rows)
+  const float bias = bc[ch], ln_s = bc[16 + ch], ln_b = bc[32 + ch];
+  // A fragments of the input-gradient product: dz[sample = lane & 15][16 cb + 4 kk + x]
+  f32x4 dzf[8];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) dzf[cb] = *reinterpret_cast<const f32x4 *>(s_dz + (lane & 15) * KS_DZS + 16 * cb + 4 * kk);
+  int kyL[NRB], shL[NRB];                    // conv weight gradient: this lane's row k = 16 rb + (lane & 15)
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) {
+    const int k = 16 * j + ch;
+    kyL[j] = (k < 9 * C) ? k / RB : 0;
+    shL[j] = (k < 9 * C) ? k % RB : 31;      // padding rows test bit 31, which no window mask has
+  }
+  f32x4 accw[NRB];
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) accw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gsc = 0.f, gbi = 0.f, gbc = 0.f;
+  const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
+  f32x4 *slab = reinterpret_cast<f32x4 *>(wpart + (size_t)tile * QN_H1 * QN_HID);
+#pragma unroll
+  for (int q = 0; q < PW; ++q) {
+    const int pl = wave * PW + q, pos = grp * PG + pl;
+    f32x4 wfr[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) wfr[cb] = wb[(cb * 64 + pos) * 64 + lane];   // W1[16 pos + ch][16 cb + 4 kk + x]
+    // conv + LayerNorm_0 of (samples, this position): rows = samples (A = window bits of sample lane & 15), columns = channels
+    const uint32_t mA[3] = {s_wm[(pl * 16 + (lane & 15)) * 3], s_wm[(pl * 16 + (lane & 15)) * 3 + 1], s_wm[(pl * 16 + (lane & 15)) * 3 + 2]};
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < ConvMfma<C>::NS; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(cv.a_of(mA, st), cv.wk[st], d, 0, 0, 0);
+    const float v[4] = {d.x + bias, d.y + bias, d.z + bias, d.w + bias};
+    float xh[4], rstd[4], y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {            // sample 4 kk + r: its 16 channels sit in the 16 lanes of this DPP row
+      const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
+      const float mean = sum * (1.0f / 16.0f);
+      const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
+      rstd[r] = rsqrt_exact(var + QN_LN_EPS);
+      xh[r] = (v[r] - mean) * rstd[r];
+      y[r] = fmaxf(fmaf(xh[r], ln_s, ln_b), 0.0f);
+    }
+    // input gradient of this position's 16 features: D rows = samples, columns = channels -- the layout of v / xh / y
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].x, wfr[cb].x, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].y, wfr[cb].y, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].z, wfr[cb].z, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].w, wfr[cb].w, a1, 0, 0, 0);
+    }
+    a0 += a1;
+    const float dh[4] = {a0.x, a0.y, a0.z, a0.w};
+    float dx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float g = y[r] > 0.0f ? dh[r] : 0.0f;       // relu mask
+      gbi += g;
+      gsc = fmaf(g, xh[r], gsc);
+      const float dxh = g * ln_s;
+      const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[r]) * (1.0f / 16.0f);
+      dx[r] = rstd[r] * (dxh - s1 - xh[r] * s2);
+      gbc += dx[r];
+    }
+    // conv weight gradient: dWc[k][ch] += sum over samples of bit(sample, pos, k) / 255 * dx[sample][ch]; K slot kk of
+    // sub-step r stands for sample 4 kk + r, which is register r of the lanes of row kk (B) -- A is built to match
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t *wmp = s_wm + (pl * 16 + 4 * kk + r) * 3;
+#pragma unroll
+      for (int j = 0; j < NRB; ++j)
+        accw[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bit_times_inv255(wmp[kyL[j]], shL[j]), dx[r], accw[j], 0, 0, 0);
+    }
+    // fc1 weight gradient rows 16 pos .. 16 pos + 15 of this tile: D rows = features (A: y[r] of lane (ch, kk) = h1[sample
+    // 4 kk + r][ch]), columns = outputs (B: dz[sample 4 kk + r][16 cb + (lane & 15)]); stored as the fragment the
+    // reduction kernel folds (the layout of the fc1 kernel itself)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_mfma_f32_16x16x4f32(y[r], s_dz[(4 * kk + r) * KS_DZS + 16 * cb + ch], w, 0, 0, 0);
+      slab[(pos * 8 + cb) * 64 + lane] = w;
+    }
+  }
+  // channel sums: the 4 sample rows of the wave (lanes ch, ch + 16, ch + 32, ch + 48), then the 4 waves in fixed order
+  gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
+  gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
+  gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
+  if (lane < 16) {
+    s_red[wave][lane] = gbc;
+    s_red[wave][16 + lane] = gsc;
+    s_red[wave][32 + lane] = gbi;
+  }
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) {            // D: row k = 16 j + 4 kk + reg, column ch
+    float *pp = &s_cw[wave][(j * 16 + 4 * kk) * 16 + ch];
+    pp[0] = accw[j].x; pp[16] = accw[j].y; pp[32] = accw[j].z; pp[48] = accw[j].w;
+  }
+  __syncthreads();
+  for (int e = tid; e < Cfg::KW * 16; e += KS_THREADS) gp[e] = (s_cw[0][e] + s_cw[1][e]) + (s_cw[2][e] + s_cw[3][e]);
+  if (tid < 48) gp[Cfg::KW * 16 + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+  if (grp != 0)                              // the head block and the loss live in group 0's record (ks_head)
+    for (int e = Cfg::KW * 16 + 48 + tid; e < rec; e += KS_THREADS) gp[e] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------
 // T1, pair form (bf16x3 mode): one workgroup runs TWO 16-sample tiles and shares the fc1 weight stream between them
 // (phase2_fc1_x3<.., 2>): the forward fc1 of a tile is bounded by the CU's 64 B/clk vector-memory path moving 768 KB of
 // weight planes, whichever tile they are for.  Everything else is the single-tile code, run once per tile, with the
@@ -3652,8 +3986,34 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   float *dzT = ws + 1024;
   float *h1T = dzT + (size_t)QN_HID * qw_ld(nb);
   float *gpart = h1T + (size_t)QN_H1 * qw_h1_cols(nb);
-  float *wpart = gpart + (size_t)ntiles * rec;
+  // K-split form for small minibatches in the f32 operand mode (a function of nb and the mode only: a seed gets the same
+  // bits alone and inside a batch of seeds); PQN_T1_KSPLIT=0 keeps the single-tile kernel
+  // (with_reduce == false is the experimental one-kernel optimizer, which folds the standard partial layout itself)
+  const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && pqn_opt(PQN_OPT_T1_KSPLIT) != 0;
+  float *wpart = gpart + (size_t)ntiles * (use_ks ? KS_NG : 1) * rec;
   const size_t smem1 = train_smem_bytes<C>();
+  if (use_ks) {
+    static bool ks_attr = false;
+    if (!ks_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_ks_head_kernel<C, KS_NG>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
+      ks_attr = true;
+    }
+    // zpart [tile][group][16][128] and dz [tile][16][128] live in the (unused) h1^T region: nb * 1152 <= 1024 * qw_h1_cols(nb)
+    float *zpart = h1T, *dzbuf = h1T + (size_t)ntiles * KS_NG * QN_TILE * QN_HID;
+    const float inv_b_ks = 1.0f / (float)nb;
+    pqn_note_kernel_form(0, PQN_FORM_KSPLIT);
+    hipLaunchKernelGGL((qnet_cnn_ks_fwd_kernel<C, KS_PG>), dim3(KS_NG, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits, theta, L,
+                       zpart, sd);
+    hipLaunchKernelGGL((qnet_cnn_ks_head_kernel<C, KS_NG>), dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, action, target,
+                       theta, L, inv_b_ks, zpart, dzbuf, dzT, gpart, sd, 1.0f);
+    hipLaunchKernelGGL((qnet_cnn_ks_bwd_kernel<C, KS_PG>), dim3(KS_NG, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits, theta, w1b,
+                       L, dzbuf, gpart, wpart, sd);
+    if (with_reduce)
+      hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles * KS_NG, ntiles,
+                         rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b_ks, sd, (const float *)nullptr, 0);
+    return pqn_check_launch("pqn_qnet_cnn_grad");
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C, 0>),
@@ -3780,9 +4140,16 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
 
 extern "C" int64_t pqn_qnet_cnn_workspace_floats(const pqn_cnn_layout_t *L, int32_t nb) {
   if (!L || nb <= 0) return -1;
+  const int64_t rec = small_record_floats(L->c, L->a);
   const int64_t ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB;
-  return 1024 + (int64_t)QN_HID * qw_ld(nb) + (int64_t)QN_H1 * qw_h1_cols(nb) + ntiles * small_record_floats(L->c, L->a) +
-         nks * (int64_t)QN_H1 * QN_HID;
+  const int64_t std_layout = 1024 + (int64_t)QN_HID * qw_ld(nb) + (int64_t)QN_H1 * qw_h1_cols(nb) + ntiles * rec + nks * (int64_t)QN_H1 * QN_HID;
+  // small minibatches (K-split form of T1): a record per (tile, position group) and a weight-gradient slab per tile.
+  // Callers size the workspace once for their LARGEST minibatch and may pass smaller ones, so the result is monotonic:
+  // the K-split layout of min(nb, KS_MAX_NB) is covered at every nb.
+  const int nbk = min(nb, KS_MAX_NB) / QN_TILE * QN_TILE;
+  const int64_t kt = nbk / QN_TILE;
+  const int64_t ks_layout = nbk ? 1024 + (int64_t)QN_HID * qw_ld(nbk) + (int64_t)QN_H1 * qw_h1_cols(nbk) + kt * KS_NG * rec + kt * (int64_t)QN_H1 * QN_HID : 0;
+  return max(std_layout, ks_layout);
 }
 
 extern "C" int pqn_qnet_cnn_grad(const pqn_cnn_layout_t *L, int32_t nb, const int64_t *idx, const uint32_t *obs_bits,

@@ -372,3 +372,33 @@ def test_position_parallel_backward_opt_in_path(gpu):
     g_pos, f1 = _grads_under_options(gpu, 4, 3, 4096, 20000, 2, t1_pair=2, bwd_pos=2)
     assert (f0, f1) == ("single", "pair+pos")
     assert float((g_f32 - g_pos).abs().max()) <= 2e-5 * float(g_f32.abs().max())
+
+
+@pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 128, 1000), (4, 3, 16, 64), (6, 4, 256, 600), (7, 3, 96, 300), (10, 6, 48, 100)])
+def test_ksplit_form_of_the_training_kernel_for_small_minibatches(gpu, oracle, c, a, nb, pool):
+    """f32 operand mode, minibatches of at most 256 samples (the yaml-default MinAtar run has 128): the K-split kernels
+    (a tile's work cut along the conv positions over 8 workgroups, fc1 weight gradient without the h1 hand-over) are what
+    runs (`pqn_cnn_last_kernel_form`), repeats are bit-identical, and the gradient agrees (a) with the oracle's numpy
+    backward at the tolerance of test_cnn_grad_vs_oracle and (b) with the single-tile kernel of the same library
+    (option t1_ksplit = 0) to f32 summation-order noise."""
+    g_ks, form = _grads_under_options(gpu, c, a, nb, pool, 0, t1_ksplit=1)
+    assert form == "ksplit"
+    g_single, form1 = _grads_under_options(gpu, c, a, nb, pool, 0, t1_ksplit=0)
+    assert form1 == "single"
+    scale = float(g_single.abs().max())
+    assert float((g_ks - g_single).abs().max()) <= 3e-6 * scale, float((g_ks - g_single).abs().max()) / scale
+    # the oracle on the same inputs (regenerated exactly as _grads_under_options draws them)
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout
+    rng = np.random.default_rng(nb + c)
+    torch.manual_seed(1234)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
+    obs, _words = _random_bits(rng, pool, c, density=0.12)
+    action = rng.integers(0, a, pool).astype(np.int32)
+    target = rng.standard_normal(pool).astype(np.float32)
+    idx = rng.permutation(pool)[:nb]
+    shapes = oracle.cnn_shapes((10, 10, c), a)
+    _lo, _chosen, g_ref = oracle.net_loss_grad("cnn", oracle.unflatten(_np(theta), shapes), shapes, obs[idx], action[idx], target[idx])
+    lay = CnnKernelLayout(c, a, matmul_f16=0)
+    np.testing.assert_allclose(_np(lay.to_flax(g_ks)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
