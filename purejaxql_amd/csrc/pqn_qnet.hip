@@ -2233,8 +2233,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 // gfx950's f32-input MFMA (v_mfma_f32_16x16x4_f32) throughout: exact f32 products, as the large-batch f32 mode.
 // ---------------------------------------------------------------------------
 #define KS_MAX_NB 256
-#define KS_PG 8                 // conv positions per workgroup
-#define KS_NG (64 / KS_PG)      // position groups (workgroups) per tile
+#define KS_NG_MAX 16             // position groups (workgroups) per tile at the finest cut (4 positions each)
 #define KS_THREADS 256
 #define KS_DZS 132   // LDS row stride of the dz tile
 
@@ -3989,29 +3988,41 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // K-split form for small minibatches in the f32 operand mode (a function of nb and the mode only: a seed gets the same
   // bits alone and inside a batch of seeds); PQN_T1_KSPLIT=0 keeps the single-tile kernel
   // (with_reduce == false is the experimental one-kernel optimizer, which folds the standard partial layout itself)
-  const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && pqn_opt(PQN_OPT_T1_KSPLIT) != 0;
-  float *wpart = gpart + (size_t)ntiles * (use_ks ? KS_NG : 1) * rec;
+  const int ks_opt = pqn_opt(PQN_OPT_T1_KSPLIT);   // 0 off, 1 = 8 positions per workgroup (default), 2 = 4, 3 = 16
+  const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && ks_opt != 0;
+  const int ks_ng = ks_opt == 2 ? 16 : (ks_opt == 3 ? 4 : 8);
+  float *wpart = gpart + (size_t)ntiles * rec;
   const size_t smem1 = train_smem_bytes<C>();
   if (use_ks) {
-    static bool ks_attr = false;
-    if (!ks_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_ks_head_kernel<C, KS_NG>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
-      ks_attr = true;
-    }
-    // zpart [tile][group][16][128] and dz [tile][16][128] live in the (unused) h1^T region: nb * 1152 <= 1024 * qw_h1_cols(nb)
-    float *zpart = h1T, *dzbuf = h1T + (size_t)ntiles * KS_NG * QN_TILE * QN_HID;
+    // the K-split carve-up (pqn_qnet_cnn_workspace_floats covers it at every nb): behind the dz^T region (which the
+    // shared head code still writes) zpart [tile][group][16][128], dz [tile][16][128], a record per (tile, group), a
+    // weight-gradient slab per tile
+    float *zpart = h1T, *dzbuf = zpart + (size_t)ntiles * ks_ng * QN_TILE * QN_HID;
+    gpart = dzbuf + (size_t)ntiles * QN_TILE * QN_HID;
+    wpart = gpart + (size_t)ntiles * ks_ng * rec;
     const float inv_b_ks = 1.0f / (float)nb;
     pqn_note_kernel_form(0, PQN_FORM_KSPLIT);
-    hipLaunchKernelGGL((qnet_cnn_ks_fwd_kernel<C, KS_PG>), dim3(KS_NG, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits, theta, L,
-                       zpart, sd);
-    hipLaunchKernelGGL((qnet_cnn_ks_head_kernel<C, KS_NG>), dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, action, target,
-                       theta, L, inv_b_ks, zpart, dzbuf, dzT, gpart, sd, 1.0f);
-    hipLaunchKernelGGL((qnet_cnn_ks_bwd_kernel<C, KS_PG>), dim3(KS_NG, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits, theta, w1b,
-                       L, dzbuf, gpart, wpart, sd);
-    if (with_reduce)
-      hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles * KS_NG, ntiles,
-                         rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b_ks, sd, (const float *)nullptr, 0);
+#define KS_LAUNCH(PG_)                                                                                                               \
+    do {                                                                                                                               \
+      static bool ks_attr = false;                                                                                                     \
+      if (!ks_attr) {                                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_ks_head_kernel<C, 64 / PG_>),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);                                             \
+        ks_attr = true;                                                                                                                \
+      }                                                                                                                                \
+      hipLaunchKernelGGL((qnet_cnn_ks_fwd_kernel<C, PG_>), dim3(64 / PG_, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits,  \
+                         theta, L, zpart, sd);                                                                                         \
+      hipLaunchKernelGGL((qnet_cnn_ks_head_kernel<C, 64 / PG_>), dim3(ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, action, \
+                         target, theta, L, inv_b_ks, zpart, dzbuf, dzT, gpart, sd, 1.0f);                                              \
+      hipLaunchKernelGGL((qnet_cnn_ks_bwd_kernel<C, PG_>), dim3(64 / PG_, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits,  \
+                         theta, w1b, L, dzbuf, gpart, wpart, sd);                                                                      \
+    } while (0)
+    if (ks_ng == 16) KS_LAUNCH(4);
+    else if (ks_ng == 4) KS_LAUNCH(16);
+    else KS_LAUNCH(8);
+#undef KS_LAUNCH
+    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles * ks_ng, ntiles,
+                       rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b_ks, sd, (const float *)nullptr, 0);
     return pqn_check_launch("pqn_qnet_cnn_grad");
   }
   static bool attr_set = false;
@@ -4148,7 +4159,7 @@ extern "C" int64_t pqn_qnet_cnn_workspace_floats(const pqn_cnn_layout_t *L, int3
   // the K-split layout of min(nb, KS_MAX_NB) is covered at every nb.
   const int nbk = min(nb, KS_MAX_NB) / QN_TILE * QN_TILE;
   const int64_t kt = nbk / QN_TILE;
-  const int64_t ks_layout = nbk ? 1024 + (int64_t)QN_HID * qw_ld(nbk) + (int64_t)QN_H1 * qw_h1_cols(nbk) + kt * KS_NG * rec + kt * (int64_t)QN_H1 * QN_HID : 0;
+  const int64_t ks_layout = nbk ? 1024 + (int64_t)QN_HID * qw_ld(nbk) + kt * (KS_NG_MAX + 1) * (QN_TILE * QN_HID) + kt * KS_NG_MAX * rec + kt * (int64_t)QN_H1 * QN_HID : 0;
   return max(std_layout, ks_layout);
 }
 
