@@ -2293,21 +2293,25 @@ __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_fwd_kernel(int nb, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x, tile = blockIdx.y, b0 = tile * QN_TILE;
   for (int i = tid; i < Cfg::KW * 16 + 48; i += KS_THREADS) s_wc[i] = theta[L.off_wc + i];
+  // the wave's rows of W1 (8 KB per position) go out FIRST: they do not depend on the gather, whose two dependent loads
+  // and two barriers then run in their shadow
+  const f32x4 *wp = reinterpret_cast<const f32x4 *>(theta + L.off_w1);
+  f32x4 wfr[PW][8];
+#pragma unroll
+  for (int q = 0; q < PW; ++q)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) wfr[q][cb] = wp[((grp * PG + wave * PW + q) * 8 + cb) * 64 + lane];
   ks_gather<C, PG>(nb, b0, grp, idx, obs_bits, sd, seed, s_bits, s_wm, tid);
   ConvMfma<C> cv;
   cv.init(s_wc, lane);                       // wk[s] = Wc[4 s + (lane >> 4)][lane & 15]: here the A operand (row = channel)
   const float *bc = s_wc + Cfg::KW * 16;
   const int smp = lane & 15, cq = 4 * (lane >> 4);   // this lane: sample column, channels cq .. cq + 3
-  const f32x4 *wp = reinterpret_cast<const f32x4 *>(theta + L.off_w1);
   f32x4 acc[8];
 #pragma unroll
   for (int cb = 0; cb < 8; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < PW; ++q) {
-    const int pl = wave * PW + q, pos = grp * PG + pl;
-    f32x4 wfr[8];
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) wfr[cb] = wp[(pos * 8 + cb) * 64 + lane];   // this position's 16 rows of W1: 8 KB per wave
+    const int pl = wave * PW + q;
     const uint32_t m[3] = {s_wm[(pl * 16 + smp) * 3], s_wm[(pl * 16 + smp) * 3 + 1], s_wm[(pl * 16 + smp) * 3 + 2]};
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2326,10 +2330,10 @@ __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_fwd_kernel(int nb, con
     // fc1 partial: A[i = sample][K slot = lane >> 4] of sub-step x is feature 16 pos + 4 (lane >> 4) + x = y[x]
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[0], wfr[cb].x, acc[cb], 0, 0, 0);
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[1], wfr[cb].y, acc[cb], 0, 0, 0);
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2], wfr[cb].z, acc[cb], 0, 0, 0);
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[3], wfr[cb].w, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[0], wfr[q][cb].x, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[1], wfr[q][cb].y, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2], wfr[q][cb].z, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[3], wfr[q][cb].w, acc[cb], 0, 0, 0);
     }
   }
   // D: column = output 16 cb + (lane & 15), rows = samples 4 (lane >> 4) + r.  Fold the four waves in fixed order.
@@ -2432,6 +2436,12 @@ __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_bwd_kernel(int nb, con
   const int rec = small_record_floats(C, L.a);
   float *gp = gpart + ((size_t)tile * NG + grp) * rec;
   for (int i = tid; i < Cfg::KW * 16 + 48; i += KS_THREADS) s_wc[i] = theta[L.off_wc + i];
+  const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
+  f32x4 wfr[PW][8];                          // W1[16 pos + ch][16 cb + 4 kk + x]: out before the gather (see ks_fwd)
+#pragma unroll
+  for (int q = 0; q < PW; ++q)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) wfr[q][cb] = wb[(cb * 64 + grp * PG + (threadIdx.x >> 6) * PW + q) * 64 + (threadIdx.x & 63)];
   {
     const float *dz = dzbuf + (size_t)tile * (QN_TILE * QN_HID);
     for (int e = tid; e < QN_TILE * QN_HID / 4; e += KS_THREADS)
@@ -2458,14 +2468,10 @@ __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_bwd_kernel(int nb, con
 #pragma unroll
   for (int j = 0; j < NRB; ++j) accw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float gsc = 0.f, gbi = 0.f, gbc = 0.f;
-  const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
   f32x4 *slab = reinterpret_cast<f32x4 *>(wpart + (size_t)tile * QN_H1 * QN_HID);
 #pragma unroll
   for (int q = 0; q < PW; ++q) {
     const int pl = wave * PW + q, pos = grp * PG + pl;
-    f32x4 wfr[8];
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) wfr[cb] = wb[(cb * 64 + pos) * 64 + lane];   // W1[16 pos + ch][16 cb + 4 kk + x]
     // conv + LayerNorm_0 of (samples, this position): rows = samples (A = window bits of sample lane & 15), columns = channels
     const uint32_t mA[3] = {s_wm[(pl * 16 + (lane & 15)) * 3], s_wm[(pl * 16 + (lane & 15)) * 3 + 1], s_wm[(pl * 16 + (lane & 15)) * 3 + 2]};
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -2486,10 +2492,10 @@ __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_bwd_kernel(int nb, con
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].x, wfr[cb].x, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].y, wfr[cb].y, a1, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].z, wfr[cb].z, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].w, wfr[cb].w, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].x, wfr[q][cb].x, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].y, wfr[q][cb].y, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].z, wfr[q][cb].z, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].w, wfr[q][cb].w, a1, 0, 0, 0);
     }
     a0 += a1;
     const float dh[4] = {a0.x, a0.y, a0.z, a0.w};
@@ -3988,9 +3994,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // K-split form for small minibatches in the f32 operand mode (a function of nb and the mode only: a seed gets the same
   // bits alone and inside a batch of seeds); PQN_T1_KSPLIT=0 keeps the single-tile kernel
   // (with_reduce == false is the experimental one-kernel optimizer, which folds the standard partial layout itself)
-  const int ks_opt = pqn_opt(PQN_OPT_T1_KSPLIT);   // 0 off, 1 = 8 positions per workgroup (default), 2 = 4, 3 = 16
+  const int ks_opt = pqn_opt(PQN_OPT_T1_KSPLIT);   // 0 off, 1 = 4 positions per workgroup (default: measured best), 2 = 8, 3 = 16
   const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && ks_opt != 0;
-  const int ks_ng = ks_opt == 2 ? 16 : (ks_opt == 3 ? 4 : 8);
+  const int ks_ng = ks_opt == 2 ? 8 : (ks_opt == 3 ? 4 : 16);
   float *wpart = gpart + (size_t)ntiles * rec;
   const size_t smem1 = train_smem_bytes<C>();
   if (use_ks) {
