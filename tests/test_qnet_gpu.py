@@ -377,12 +377,15 @@ def test_position_parallel_backward_opt_in_path(gpu):
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 128, 1000), (4, 3, 16, 64), (6, 4, 256, 600), (7, 3, 96, 300), (10, 6, 48, 100)])
 def test_ksplit_form_of_the_training_kernel_for_small_minibatches(gpu, oracle, c, a, nb, pool):
     """f32 operand mode, minibatches of at most 256 samples (the yaml-default MinAtar run has 128): the K-split kernels
-    (a tile's work cut along the conv positions over 8 workgroups, fc1 weight gradient without the h1 hand-over) are what
+    (a tile's work cut along the conv positions over 16 workgroups, fc1 weight gradient without the h1 hand-over) are what
     runs (`pqn_cnn_last_kernel_form`), repeats are bit-identical, and the gradient agrees (a) with the oracle's numpy
     backward at the tolerance of test_cnn_grad_vs_oracle and (b) with the single-tile kernel of the same library
     (option t1_ksplit = 0) to f32 summation-order noise."""
     g_ks, form = _grads_under_options(gpu, c, a, nb, pool, 0, t1_ksplit=1)
     assert form == "ksplit"
+    for other in (2, 3):   # 8 and 16 positions per workgroup: same arithmetic per position, other fold orders
+        g_o, form_o = _grads_under_options(gpu, c, a, nb, pool, 0, t1_ksplit=other)
+        assert form_o == "ksplit" and float((g_o - g_ks).abs().max()) <= 3e-6 * float(g_ks.abs().max())
     g_single, form1 = _grads_under_options(gpu, c, a, nb, pool, 0, t1_ksplit=0)
     assert form1 == "single"
     scale = float(g_single.abs().max())
