@@ -2,7 +2,7 @@
 # Round 3, call j: the whole -m gpu suite, smoke(), and the default bench line.
 mkdir -p gpurun_out/r3j
 cd "$GRAFT_REPO_ROOT"
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=15 > gpurun_out/r3j/pytest.txt 2>&1
+timeout 1500 python -m pytest tests -q -m gpu --durations=15 > gpurun_out/r3j/pytest.txt 2>&1
 echo "pytest exit $?" >> gpurun_out/r3j/pytest.txt
 tail -30 gpurun_out/r3j/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r3j/smoke.txt 2>&1
