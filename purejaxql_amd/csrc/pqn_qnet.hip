@@ -2408,6 +2408,108 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_ks_head_kernel(
     reinterpret_cast<f32x4 *>(dz)[e] = *reinterpret_cast<const f32x4 *>(s.z + (e >> 5) * QN_ZS + (e & 31) * 4);
 }
 
+// backward of ONE conv position x 16 samples by one wave (see the header above): recomputed conv + LayerNorm_0, input
+// gradient of the position's 16 features, relu mask, LayerNorm_0 backward, conv weight-gradient and channel-sum
+// accumulation, and the position's 16 rows of the tile's fc1 weight gradient (stored to `slab`).
+//   wm_pl  window masks of (this position, sample) : wm_pl[sample * 3 + ky];  dz  the tile's dz in LDS, row stride dzs
+template <int C>
+struct KsBwdLane {
+  static constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C;
+  int kyL[NRB], shL[NRB];     // conv weight gradient: this lane's row k = 16 rb + (lane & 15)
+  f32x4 accw[NRB];
+  float gsc, gbi, gbc, bias, ln_s, ln_b;
+  PQN_D void init(const float *bc, int lane) {
+    const int ch = lane & 15;
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {
+      const int k = 16 * j + ch;
+      kyL[j] = (k < 9 * C) ? k / RB : 0;
+      shL[j] = (k < 9 * C) ? k % RB : 31;      // padding rows test bit 31, which no window mask has
+      accw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    gsc = gbi = gbc = 0.f;
+    bias = bc[ch]; ln_s = bc[16 + ch]; ln_b = bc[32 + ch];
+  }
+  PQN_D void position(const ConvMfma<C> &cv, const uint32_t *wm_pl, const f32x4 (&dzf)[8], const f32x4 (&wfr)[8], const float *dz,
+                      int dzs, f32x4 *slab_pos, int lane) {
+    const int ch = lane & 15, kk = lane >> 4;  // this lane: channel column, samples 4 kk .. 4 kk + 3 (D rows)
+    // conv + LayerNorm_0 of (samples, this position): rows = samples (A = window bits of sample lane & 15), columns = channels
+    const uint32_t mA[3] = {wm_pl[(lane & 15) * 3], wm_pl[(lane & 15) * 3 + 1], wm_pl[(lane & 15) * 3 + 2]};
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < ConvMfma<C>::NS; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(cv.a_of(mA, st), cv.wk[st], d, 0, 0, 0);
+    const float v[4] = {d.x + bias, d.y + bias, d.z + bias, d.w + bias};
+    float xh[4], rstd[4], y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {            // sample 4 kk + r: its 16 channels sit in the 16 lanes of this DPP row
+      const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
+      const float mean = sum * (1.0f / 16.0f);
+      const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
+      rstd[r] = rsqrt_exact(var + QN_LN_EPS);
+      xh[r] = (v[r] - mean) * rstd[r];
+      y[r] = fmaxf(fmaf(xh[r], ln_s, ln_b), 0.0f);
+    }
+    // input gradient of this position's 16 features: D rows = samples, columns = channels -- the layout of v / xh / y
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].x, wfr[cb].x, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].y, wfr[cb].y, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].z, wfr[cb].z, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].w, wfr[cb].w, a1, 0, 0, 0);
+    }
+    a0 += a1;
+    const float dh[4] = {a0.x, a0.y, a0.z, a0.w};
+    float dx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float g = y[r] > 0.0f ? dh[r] : 0.0f;       // relu mask
+      gbi += g;
+      gsc = fmaf(g, xh[r], gsc);
+      const float dxh = g * ln_s;
+      const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[r]) * (1.0f / 16.0f);
+      dx[r] = rstd[r] * (dxh - s1 - xh[r] * s2);
+      gbc += dx[r];
+    }
+    // conv weight gradient: dWc[k][ch] += sum over samples of bit(sample, pos, k) / 255 * dx[sample][ch]; K slot kk of
+    // sub-step r stands for sample 4 kk + r, which is register r of the lanes of row kk (B) -- A is built to match
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t *wmp = wm_pl + (4 * kk + r) * 3;
+#pragma unroll
+      for (int j = 0; j < NRB; ++j)
+        accw[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bit_times_inv255(wmp[kyL[j]], shL[j]), dx[r], accw[j], 0, 0, 0);
+    }
+    // fc1 weight gradient rows 16 pos .. 16 pos + 15 of this tile: D rows = features (A: y[r] of lane (ch, kk) = h1[sample
+    // 4 kk + r][ch]), columns = outputs (B: dz[sample 4 kk + r][16 cb + (lane & 15)]); stored as the fragment the
+    // reduction kernel folds (the layout of the fc1 kernel itself)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_mfma_f32_16x16x4f32(y[r], dz[(4 * kk + r) * dzs + 16 * cb + ch], w, 0, 0, 0);
+      slab_pos[cb * 64 + lane] = w;
+    }
+  }
+  // channel sums of the wave -> red[48] (conv bias | ln0 scale | ln0 bias); conv weight-gradient tile -> cw[NRB * 256]
+  PQN_D void finish(float *red, float *cw, int lane) {
+    const int ch = lane & 15, kk = lane >> 4;
+    gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);   // the 4 sample rows: lanes ch, ch + 16, ch + 32, ch + 48
+    gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
+    gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
+    if (lane < 16) {
+      red[lane] = gbc;
+      red[16 + lane] = gsc;
+      red[32 + lane] = gbi;
+    }
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {            // D: row k = 16 j + 4 kk + reg, column ch
+      float *pp = cw + (j * 16 + 4 * kk) * 16 + ch;
+      pp[0] = accw[j].x; pp[16] = accw[j].y; pp[32] = accw[j].z; pp[48] = accw[j].w;
+    }
+  }
+};
+
 template <int C, int PG>
 __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_bwd_kernel(int nb, const int64_t *__restrict__ idx,
                                                                      const uint32_t *__restrict__ obs_bits,
@@ -2417,7 +2519,7 @@ __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_bwd_kernel(int nb, con
                                                                      pqn_seeds_t sd) {
   using Cfg = CnnCfg<C>;
   constexpr int NG = 64 / PG, PW = PG / 4;
-  constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C;   // 16-row blocks of the conv kernel's k index
+  constexpr int NRB = (9 * C + 15) / 16;   // 16-row blocks of the conv kernel's k index
   __shared__ __attribute__((aligned(16))) uint32_t s_bits[QN_TILE * Cfg::OW + 4];
   __shared__ uint32_t s_wm[16 * PG * 3];
   __shared__ __attribute__((aligned(16))) float s_wc[Cfg::KW * 16 + 48];
@@ -2441,7 +2543,7 @@ __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_bwd_kernel(int nb, con
 #pragma unroll
   for (int q = 0; q < PW; ++q)
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) wfr[q][cb] = wb[(cb * 64 + grp * PG + (threadIdx.x >> 6) * PW + q) * 64 + (threadIdx.x & 63)];
+    for (int cb = 0; cb < 8; ++cb) wfr[q][cb] = wb[(cb * 64 + grp * PG + wave * PW + q) * 64 + lane];
   {
     const float *dz = dzbuf + (size_t)tile * (QN_TILE * QN_HID);
     for (int e = tid; e < QN_TILE * QN_HID / 4; e += KS_THREADS)
@@ -2450,105 +2552,130 @@ __global__ __launch_bounds__(KS_THREADS) void qnet_cnn_ks_bwd_kernel(int nb, con
   ks_gather<C, PG>(nb, b0, grp, idx, obs_bits, sd, seed, s_bits, s_wm, tid);
   ConvMfma<C> cv;
   cv.init(s_wc, lane);                       // B operand: wk[s] = Wc[4 s + (lane >> 4)][channel = lane & 15]
-  const float *bc = s_wc + Cfg::KW * 16;
-  const int ch = lane & 15, kk = lane >> 4;  // this lane: channel column, samples 4 kk .. 4 kk + 3 (D rows)
-  const float bias = bc[ch], ln_s = bc[16 + ch], ln_b = bc[32 + ch];
+  KsBwdLane<C> bl;
+  bl.init(s_wc + Cfg::KW * 16, lane);
   // A fragments of the input-gradient product: dz[sample = lane & 15][16 cb + 4 kk + x]
   f32x4 dzf[8];
 #pragma unroll
-  for (int cb = 0; cb < 8; ++cb) dzf[cb] = *reinterpret_cast<const f32x4 *>(s_dz + (lane & 15) * KS_DZS + 16 * cb + 4 * kk);
-  int kyL[NRB], shL[NRB];                    // conv weight gradient: this lane's row k = 16 rb + (lane & 15)
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) {
-    const int k = 16 * j + ch;
-    kyL[j] = (k < 9 * C) ? k / RB : 0;
-    shL[j] = (k < 9 * C) ? k % RB : 31;      // padding rows test bit 31, which no window mask has
-  }
-  f32x4 accw[NRB];
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) accw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float gsc = 0.f, gbi = 0.f, gbc = 0.f;
+  for (int cb = 0; cb < 8; ++cb) dzf[cb] = *reinterpret_cast<const f32x4 *>(s_dz + (lane & 15) * KS_DZS + 16 * cb + 4 * (lane >> 4));
   f32x4 *slab = reinterpret_cast<f32x4 *>(wpart + (size_t)tile * QN_H1 * QN_HID);
 #pragma unroll
   for (int q = 0; q < PW; ++q) {
     const int pl = wave * PW + q, pos = grp * PG + pl;
-    // conv + LayerNorm_0 of (samples, this position): rows = samples (A = window bits of sample lane & 15), columns = channels
-    const uint32_t mA[3] = {s_wm[(pl * 16 + (lane & 15)) * 3], s_wm[(pl * 16 + (lane & 15)) * 3 + 1], s_wm[(pl * 16 + (lane & 15)) * 3 + 2]};
-    f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int st = 0; st < ConvMfma<C>::NS; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(cv.a_of(mA, st), cv.wk[st], d, 0, 0, 0);
-    const float v[4] = {d.x + bias, d.y + bias, d.z + bias, d.w + bias};
-    float xh[4], rstd[4], y[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {            // sample 4 kk + r: its 16 channels sit in the 16 lanes of this DPP row
-      const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
-      const float mean = sum * (1.0f / 16.0f);
-      const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
-      rstd[r] = rsqrt_exact(var + QN_LN_EPS);
-      xh[r] = (v[r] - mean) * rstd[r];
-      y[r] = fmaxf(fmaf(xh[r], ln_s, ln_b), 0.0f);
-    }
-    // input gradient of this position's 16 features: D rows = samples, columns = channels -- the layout of v / xh / y
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].x, wfr[q][cb].x, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].y, wfr[q][cb].y, a1, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].z, wfr[q][cb].z, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[cb].w, wfr[q][cb].w, a1, 0, 0, 0);
-    }
-    a0 += a1;
-    const float dh[4] = {a0.x, a0.y, a0.z, a0.w};
-    float dx[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float g = y[r] > 0.0f ? dh[r] : 0.0f;       // relu mask
-      gbi += g;
-      gsc = fmaf(g, xh[r], gsc);
-      const float dxh = g * ln_s;
-      const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[r]) * (1.0f / 16.0f);
-      dx[r] = rstd[r] * (dxh - s1 - xh[r] * s2);
-      gbc += dx[r];
-    }
-    // conv weight gradient: dWc[k][ch] += sum over samples of bit(sample, pos, k) / 255 * dx[sample][ch]; K slot kk of
-    // sub-step r stands for sample 4 kk + r, which is register r of the lanes of row kk (B) -- A is built to match
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t *wmp = s_wm + (pl * 16 + 4 * kk + r) * 3;
-#pragma unroll
-      for (int j = 0; j < NRB; ++j)
-        accw[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bit_times_inv255(wmp[kyL[j]], shL[j]), dx[r], accw[j], 0, 0, 0);
-    }
-    // fc1 weight gradient rows 16 pos .. 16 pos + 15 of this tile: D rows = features (A: y[r] of lane (ch, kk) = h1[sample
-    // 4 kk + r][ch]), columns = outputs (B: dz[sample 4 kk + r][16 cb + (lane & 15)]); stored as the fragment the
-    // reduction kernel folds (the layout of the fc1 kernel itself)
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_mfma_f32_16x16x4f32(y[r], s_dz[(4 * kk + r) * KS_DZS + 16 * cb + ch], w, 0, 0, 0);
-      slab[(pos * 8 + cb) * 64 + lane] = w;
-    }
+    bl.position(cv, s_wm + pl * 16 * 3, dzf, wfr[q], s_dz, KS_DZS, slab + (size_t)pos * 8 * 64, lane);
   }
-  // channel sums: the 4 sample rows of the wave (lanes ch, ch + 16, ch + 32, ch + 48), then the 4 waves in fixed order
-  gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
-  gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
-  gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
-  if (lane < 16) {
-    s_red[wave][lane] = gbc;
-    s_red[wave][16 + lane] = gsc;
-    s_red[wave][32 + lane] = gbi;
-  }
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) {            // D: row k = 16 j + 4 kk + reg, column ch
-    float *pp = &s_cw[wave][(j * 16 + 4 * kk) * 16 + ch];
-    pp[0] = accw[j].x; pp[16] = accw[j].y; pp[32] = accw[j].z; pp[48] = accw[j].w;
-  }
+  bl.finish(s_red[wave], s_cw[wave], lane);   // then the 4 waves in fixed order
   __syncthreads();
   for (int e = tid; e < Cfg::KW * 16; e += KS_THREADS) gp[e] = (s_cw[0][e] + s_cw[1][e]) + (s_cw[2][e] + s_cw[3][e]);
   if (tid < 48) gp[Cfg::KW * 16 + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
   if (grp != 0)                              // the head block and the loss live in group 0's record (ks_head)
     for (int e = Cfg::KW * 16 + 48 + tid; e < rec; e += KS_THREADS) gp[e] = 0.0f;
+}
+
+// head + backward in ONE launch: a 512-thread workgroup per (group of 8 positions, tile) first runs the tile's head --
+// every one of the 8 groups of a tile recomputes it (16 samples x 128 features: cheap) instead of waiting for a launch
+// of its own, which costs as much as the whole kernel at these sizes -- then each of its 8 waves takes one position.
+// Only group 0's record keeps the head block.
+template <int C, int NGF>   // NGF: position groups of the forward launch (partials to sum)
+__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_ks_hb_kernel(
+    int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
+    const float *__restrict__ target, const float *__restrict__ theta, const float *__restrict__ w1b, pqn_cnn_layout_t L,
+    float inv_b, const float *__restrict__ zpart, float *__restrict__ dzT, float *__restrict__ gpart, float *__restrict__ wpart,
+    pqn_seeds_t sd) {
+  using Cfg = CnnCfg<C>;
+  constexpr int PG = 8, NG = 8;
+  constexpr int NRB = (9 * C + 15) / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int seed = blockIdx.z + sd.seed_base;
+  idx += seed * sd.idx_stride;
+  theta += seed * sd.theta_stride;
+  w1b += seed * sd.w1b_stride;
+  zpart += seed * sd.ws_stride;
+  dzT += seed * sd.ws_stride;
+  gpart += seed * sd.ws_stride;
+  wpart += seed * sd.ws_stride;
+  auto row_of = [&](int64_t key) -> int64_t {
+    const uint32_t j = (uint32_t)(key & sd.idx_mask);
+    if (sd.n_env_total == sd.n_env) return (int64_t)j;
+    const uint32_t t = j / (uint32_t)sd.n_env;
+    return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
+  };
+  const TrainSmem ts = carve_train_smem<C>(smem_raw);
+  const CnnSmem &s = ts.n;
+  // the h1 tile of the training kernel's LDS plan is not used here: window masks and the cross-wave folds live in it
+  uint32_t *s_wm = reinterpret_cast<uint32_t *>(s.h1);            // [16 * PG * 3]
+  float (*s_red)[48] = reinterpret_cast<float (*)[48]>(s.h1 + 512);       // [8][48]
+  float (*s_cw)[NRB * 256] = reinterpret_cast<float (*)[NRB * 256]>(s.h1 + 1024);   // [8][NRB * 256]
+  static_assert(1024 + 8 * NRB * 256 <= QN_TILE * QN_H1S, "scratch must fit the h1 tile");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x, tile = blockIdx.y, b0 = tile * QN_TILE;
+  const int rec = small_record_floats(C, L.a);
+  float *gp = gpart + ((size_t)tile * NG + grp) * rec;
+  const int pos = grp * PG + wave;
+  const f32x4 *wb = reinterpret_cast<const f32x4 *>(w1b);
+  f32x4 wfr[8];                              // out first: nothing below depends on them until the backward
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) wfr[cb] = wb[(cb * 64 + pos) * 64 + lane];
+  // gather: indices -> observation rows, action, target; parameters; the forward partials
+  constexpr int NBI = (QN_TILE * Cfg::OW + QN_THREADS - 1) / QN_THREADS;
+  uint32_t gb[NBI];
+#pragma unroll
+  for (int k = 0; k < NBI; ++k) {
+    const int i = tid + k * QN_THREADS, le = i / Cfg::OW;
+    gb[k] = (i < QN_TILE * Cfg::OW && b0 + le < nb) ? obs_bits[(size_t)row_of(idx[b0 + le]) * Cfg::OW + (i % Cfg::OW)] : 0u;
+  }
+  const int64_t src16 = (tid < QN_TILE && b0 + tid < nb) ? row_of(idx[b0 + tid]) : -1;
+  TileParams<C> tp;
+  tp.load(theta, L, tid);
+  if (tid < QN_TILE) {
+    ts.act[tid] = src16 >= 0 ? action[src16] : 0;
+    ts.tgt[tid] = src16 >= 0 ? target[src16] : 0.0f;
+  }
+  tp.store(s, L, tid);
+#pragma unroll
+  for (int k = 0; k < NBI; ++k) {
+    const int i = tid + k * QN_THREADS;
+    if (i < QN_TILE * Cfg::OW) s.bits[i] = gb[k];
+  }
+  if (tid < 4) s.bits[QN_TILE * Cfg::OW + tid] = 0u;
+  const float *zp = zpart + (size_t)tile * NGF * (QN_TILE * QN_HID);
+  for (int e = tid; e < QN_TILE * QN_HID / 4; e += QN_THREADS) {
+    f32x4 a = reinterpret_cast<const f32x4 *>(zp)[e];
+#pragma unroll
+    for (int g = 1; g < NGF; ++g) a += reinterpret_cast<const f32x4 *>(zp + (size_t)g * (QN_TILE * QN_HID))[e];   // fixed order
+    *reinterpret_cast<f32x4 *>(s.z + (e >> 5) * QN_ZS + (e & 31) * 4) = a;
+  }
+  __syncthreads();
+  if (tid < 16 * PG) {
+    uint32_t m[3];
+    window_masks_point<C>(s.bits + (tid & 15) * Cfg::OW, grp * PG + (tid >> 4), m);
+    s_wm[tid * 3] = m[0]; s_wm[tid * 3 + 1] = m[1]; s_wm[tid * 3 + 2] = m[2];
+  }
+  switch (L.a) {   // ends with a barrier; leaves dz in the z tile
+    case 3: train_head<C, 3>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, 1.0f); break;
+    case 4: train_head<C, 4>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, 1.0f); break;
+    case 5: train_head<C, 5>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, 1.0f); break;
+    case 6: train_head<C, 6>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, 1.0f); break;
+    default: train_head<C, 0>(s, ts, L, tid, nb, b0, inv_b, gp, dzT, 1.0f); break;
+  }
+  ConvMfma<C> cv;
+  cv.init(s.wc, lane);
+  KsBwdLane<C> bl;
+  bl.init(s.wc + Cfg::KW * 16, lane);
+  f32x4 dzf[8];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) dzf[cb] = *reinterpret_cast<const f32x4 *>(s.z + (lane & 15) * QN_ZS + 16 * cb + 4 * (lane >> 4));
+  f32x4 *slab = reinterpret_cast<f32x4 *>(wpart + (size_t)tile * QN_H1 * QN_HID);
+  bl.position(cv, s_wm + wave * 16 * 3, dzf, wfr, s.z, QN_ZS, slab + (size_t)pos * 8 * 64, lane);
+  bl.finish(s_red[wave], s_cw[wave], lane);   // then the 8 waves in fixed order
+  __syncthreads();
+  for (int e = tid; e < Cfg::KW * 16; e += QN_THREADS)
+    gp[e] = ((s_cw[0][e] + s_cw[1][e]) + (s_cw[2][e] + s_cw[3][e])) + ((s_cw[4][e] + s_cw[5][e]) + (s_cw[6][e] + s_cw[7][e]));
+  if (tid < 48)
+    gp[Cfg::KW * 16 + tid] = ((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) +
+                             ((s_red[4][tid] + s_red[5][tid]) + (s_red[6][tid] + s_red[7][tid]));
+  if (grp != 0)                              // only group 0's record keeps the head block and the loss
+    for (int e = Cfg::KW * 16 + 48 + tid; e < rec; e += QN_THREADS) gp[e] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------
@@ -3994,9 +4121,12 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // K-split form for small minibatches in the f32 operand mode (a function of nb and the mode only: a seed gets the same
   // bits alone and inside a batch of seeds); PQN_T1_KSPLIT=0 keeps the single-tile kernel
   // (with_reduce == false is the experimental one-kernel optimizer, which folds the standard partial layout itself)
-  const int ks_opt = pqn_opt(PQN_OPT_T1_KSPLIT);   // 0 off, 1 = 4 positions per workgroup (default: measured best), 2 = 8, 3 = 16
+  // 0 off; three launches (forward partial, head, backward) with 4 (1), 8 (2) or 16 (3) positions per workgroup; 4 = two
+  // launches: forward partial with 4 positions per workgroup, then head + backward in one (8 positions per workgroup)
+  const int ks_opt = pqn_opt(PQN_OPT_T1_KSPLIT);
   const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && ks_opt != 0;
-  const int ks_ng = ks_opt == 2 ? 8 : (ks_opt == 3 ? 4 : 16);
+  const bool ks_hb = ks_opt == 4;
+  const int ks_ng = ks_hb ? 8 : (ks_opt == 2 ? 8 : (ks_opt == 3 ? 4 : 16));   // records (and backward groups) per tile
   float *wpart = gpart + (size_t)ntiles * rec;
   const size_t smem1 = train_smem_bytes<C>();
   if (use_ks) {
@@ -4023,7 +4153,23 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       hipLaunchKernelGGL((qnet_cnn_ks_bwd_kernel<C, PG_>), dim3(64 / PG_, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits,  \
                          theta, w1b, L, dzbuf, gpart, wpart, sd);                                                                      \
     } while (0)
-    if (ks_ng == 16) KS_LAUNCH(4);
+    if (ks_hb) {
+      static bool hb_attr = false;
+      if (!hb_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_ks_hb_kernel<C, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem1);
+        hb_attr = true;
+      }
+      // the forward partials use 16 groups per tile: zpart needs ntiles * 16 tiles of [16][128], which is what the carve-up
+      // reserves at the finest cut (dzbuf / gpart / wpart were placed for ks_ng = 8: move them behind the 16-group zpart)
+      dzbuf = zpart + (size_t)ntiles * 16 * QN_TILE * QN_HID;
+      gpart = dzbuf + (size_t)ntiles * QN_TILE * QN_HID;
+      wpart = gpart + (size_t)ntiles * ks_ng * rec;
+      hipLaunchKernelGGL((qnet_cnn_ks_fwd_kernel<C, 4>), dim3(16, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits, theta, L, zpart,
+                         sd);
+      hipLaunchKernelGGL((qnet_cnn_ks_hb_kernel<C, 16>), dim3(8, ntiles, sd.nseeds), dim3(QN_THREADS), smem1, st, nb, idx, bits, action, target,
+                         theta, w1b, L, inv_b_ks, zpart, dzT, gpart, wpart, sd);
+    } else if (ks_ng == 16) KS_LAUNCH(4);
     else if (ks_ng == 4) KS_LAUNCH(16);
     else KS_LAUNCH(8);
 #undef KS_LAUNCH
