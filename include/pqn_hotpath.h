@@ -350,8 +350,9 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
  * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP
  * backward on a second stream; default 0), "t1_ksplit" (K-split form of the f32-mode training kernel for minibatches of
- * at most 256 samples: a tile's work cut along the conv positions over 16 workgroups of 4 positions (1, default), 8 x 8
- * (2) or 4 x 16 (3); 0 = the single-tile kernel).  Each starts from its PQN_<NAME> environment
+ * at most 256 samples: a tile's work cut along the conv positions over many workgroups; 1 (default) = forward partial +
+ * head-and-backward as two launches, 2 / 3 / 4 = three launches with 4 / 8 / 16 positions per workgroup, 0 = the
+ * single-tile kernel).  Each starts from its PQN_<NAME> environment
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);

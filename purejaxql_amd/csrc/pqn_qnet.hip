@@ -2222,6 +2222,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 //            against its 1/NG of W1 -> zpart[tile][group][16][128]
 //   ks_head  (tile): z = sum of the NG partials, then the unchanged head of the training kernel (train_head): loss, head
 //            parameter gradients, dz[16][128]
+//   (default: ks_head and ks_bwd are ONE launch, qnet_cnn_ks_hb_kernel -- every group of a tile recomputes the head)
 //   ks_bwd   (group, tile): conv + LayerNorm_0 again (cheaper than a round trip through memory), input gradient of ITS
 //            features from dz and its 1/NG of W1 (dgrad fragment order), relu mask, LayerNorm_0 backward, conv weight
 //            gradient partial, and its rows of the fc1 weight gradient for the tile -- straight in the layout of the
@@ -4121,12 +4122,13 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // K-split form for small minibatches in the f32 operand mode (a function of nb and the mode only: a seed gets the same
   // bits alone and inside a batch of seeds); PQN_T1_KSPLIT=0 keeps the single-tile kernel
   // (with_reduce == false is the experimental one-kernel optimizer, which folds the standard partial layout itself)
-  // 0 off; three launches (forward partial, head, backward) with 4 (1), 8 (2) or 16 (3) positions per workgroup; 4 = two
-  // launches: forward partial with 4 positions per workgroup, then head + backward in one (8 positions per workgroup)
+  // 0 off; 1 (default, measured best) = two launches: forward partial with 4 positions per workgroup, then head + backward
+  // in one (8 positions per workgroup); three launches (forward partial, head, backward) with 4 (2), 8 (3) or 16 (4)
+  // positions per workgroup
   const int ks_opt = pqn_opt(PQN_OPT_T1_KSPLIT);
   const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && ks_opt != 0;
-  const bool ks_hb = ks_opt == 4;
-  const int ks_ng = ks_hb ? 8 : (ks_opt == 2 ? 8 : (ks_opt == 3 ? 4 : 16));   // records (and backward groups) per tile
+  const bool ks_hb = ks_opt == 1 || ks_opt > 4;
+  const int ks_ng = ks_hb ? 8 : (ks_opt == 3 ? 8 : (ks_opt == 4 ? 4 : 16));   // records (and backward groups) per tile
   float *wpart = gpart + (size_t)ntiles * rec;
   const size_t smem1 = train_smem_bytes<C>();
   if (use_ks) {

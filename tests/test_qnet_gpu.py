@@ -383,7 +383,7 @@ def test_ksplit_form_of_the_training_kernel_for_small_minibatches(gpu, oracle, c
     (option t1_ksplit = 0) to f32 summation-order noise."""
     g_ks, form = _grads_under_options(gpu, c, a, nb, pool, 0, t1_ksplit=1)
     assert form == "ksplit"
-    for other in (2, 3, 4):   # 8 / 16 positions per workgroup, head + backward in one launch: same arithmetic per position, other fold orders
+    for other in (2, 3, 4):   # the three-launch forms with 4 / 8 / 16 positions per workgroup: same arithmetic per position, other fold orders
         g_o, form_o = _grads_under_options(gpu, c, a, nb, pool, 0, t1_ksplit=other)
         assert form_o == "ksplit" and float((g_o - g_ks).abs().max()) <= 3e-6 * float(g_ks.abs().max())
     g_single, form1 = _grads_under_options(gpu, c, a, nb, pool, 0, t1_ksplit=0)
