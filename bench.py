@@ -403,6 +403,25 @@ def main():
                                                   "vector peak; bf16_pipe prices the 6 bf16 products per f32 product against "
                                                   "the dense bf16 peak"}}
             guarded("craftax_c5", craftax_c5)
+
+            def yaml_default():
+                """The reference's own default (config/alg/pqn_minatar.yaml: 128 envs x 32 steps, 32 x 2 minibatches of 128
+                samples, f32 operand mode): the small-minibatch regime, K-split training kernels."""
+                from purejaxql_amd.config_loader import flatten, load_config
+                cd = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar"]))
+                cd["TEST_DURING_TRAINING"] = False
+                warm_d, steps_d = 30, 300
+                cd["TOTAL_TIMESTEPS_DECAY"] = cd["TOTAL_TIMESTEPS"]
+                trd = make_train(cd, device=str(dev))
+                updd, _find = trd.make_runner(seed_keys(0, 1)[0])
+                dd = timed_updates(updd, steps_d, warm_d)
+                per_upd = cd["NUM_ENVS"] * cd["NUM_STEPS"]
+                return {"workload": f"Breakout-MinAtar PQN at the yaml defaults: NUM_ENVS={cd['NUM_ENVS']} NUM_STEPS={cd['NUM_STEPS']} "
+                                    f"NUM_MINIBATCHES={cd['NUM_MINIBATCHES']} NUM_EPOCHS={cd['NUM_EPOCHS']}, one seed, f32 operands",
+                        "value": per_upd * steps_d / dd, "unit": "env-steps/s", "ms_per_update": dd / steps_d * 1e3,
+                        "updates_timed": steps_d, "kernel_forms": dict(zip(("train", "rollout"), _lib.last_kernel_form())),
+                        "seconds_for_1e7_steps": 1e7 / (per_upd * steps_d / dd)}
+            guarded("yaml_default", yaml_default)
         if extras and fused:
             def other_modes():
                 res = {}

@@ -1,5 +1,5 @@
-"""The bench line contract (driver-facing): the committed round artefact profiles/r02_v4_bench.json -- the JSON line
-bench.py printed on an MI355X at the end of round 2 -- carries every field the contract names, with consistent
+"""The bench line contract (driver-facing): the committed round artefact profiles/r03_bench.json -- the JSON line
+bench.py printed on an MI355X at the end of round 3 -- carries every field the contract names, with consistent
 arithmetic."""
 import json
 import os
@@ -8,12 +8,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_v4_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"].split(",")[0] == base["metric"].split(",")[0] and "4096 envs" in d["metric"]
+    # what changed against the plain reading of the metric is IN the label: seeds batched per GPU and the operand mode
+    assert "16 seeds/GPU" in d["metric"] and "bf16x3" in d["metric"]
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     # the arithmetic type is f32 throughout; the label says how the f32 products are evaluated
     assert d["dtype"].startswith("f32") and "bf16x3" in d["dtype"] and "f32 accumulate" in d["dtype"]
@@ -30,7 +32,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["flop_per_launch"] == 674048 * 4096 * 16
     assert r["traffic"] is None or (r["traffic"] > 0 and "from file" in r["traffic_source"])
     # the headline's traffic comes from PMC passes of the 16-seed launch shape itself, not from a scaled single-seed pass
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_train_kernel_bf16x3_seeds16.json")))
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_train_kernel_bf16x3_seeds16.json")))
+    assert "r03_pmc" in r["traffic_source"] and abs(r["l2_to_cu_bytes"] - pmc["l2_to_cu_bytes_per_launch"]) <= 1e-6 * r["l2_to_cu_bytes"]
     assert pmc["seeds_per_launch"] == 16 and "seeds16" in r["traffic_source"]
     assert abs(r["traffic"] - pmc["hbm_bytes_per_launch"]) <= 1e-6 * r["traffic"]
     assert abs(pmc["hbm_bytes_per_launch"] - (2 * pmc["FETCH_SIZE_KB_avg"] + pmc["WRITE_SIZE_KB_avg"]) * 1024.0) < 1.0
@@ -39,6 +42,20 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert "NUM_ENVS=4096" in cb["sample"]                      # the CPU leg runs the bench shape itself
+    # which kernels ran is asked of the library, the timed region is backed by a longer one, the env-step roofline says
+    # which level of the memory system it measures
+    assert d["config"]["kernel_forms"] == {"train": "pair", "rollout": "pair"} and d["config"]["driver"] == "hipGraph replay"
+    assert d["sustained"]["seconds"] >= 5.0 and abs(d["sustained"]["value"] / d["value"] - 1.0) < 0.1
+    levels = [e["level"].split(" ")[0] for e in d["roofline_env_step"]]
+    assert levels == ["Infinity", "Infinity", "HBM"] and d["roofline_env_step"][-1]["frac"] < 0.9
+    # BASELINE.json configs[4] beside the headline: Craftax-Classic at the yaml shape through the wide-MLP kernels
+    c5 = d["craftax_c5"]
+    assert c5["backend"] == "fused_big" and c5["driver"] == "hipGraph replay" and c5["value"] > 5e5
+    assert abs(c5["roofline"]["frac"] - c5["roofline"]["achieved"] / c5["roofline"]["peak"]) < 1e-9
+    # the reference's yaml defaults (128 envs): the small-minibatch regime runs the K-split training kernels
+    yd = d["yaml_default"]
+    assert yd["kernel_forms"]["train"] == "ksplit" and yd["value"] > 1.2e6 and yd["seconds_for_1e7_steps"] < 8.0
     # the extras report the other operand modes and the single-seed run beside the headline, never instead of it
     assert d["matmul_modes"]["f32"]["value"] < d["value"] < d["matmul_modes"]["f16"]["value"]
     assert d["single_seed"]["seeds_per_gpu"] == 1 and d["single_seed"]["value"] < d["value"]
