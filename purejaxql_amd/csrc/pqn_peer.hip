@@ -20,7 +20,9 @@
 
 #include "pqn_common.h"
 
-#define PEER_FLAG_OFFSET_BYTES(n) ((((size_t)(n) * 2 * sizeof(float)) + 255) & ~(size_t)255)
+// each of the two staging buffers holds PEER_STRIDE(n) floats: a multiple of 4, so both start 16-byte aligned
+#define PEER_STRIDE(n) (((size_t)(n) + 3) & ~(size_t)3)
+#define PEER_FLAG_OFFSET_BYTES(n) (((PEER_STRIDE(n) * 2 * sizeof(float)) + 255) & ~(size_t)255)
 #define PEER_SPIN_LIMIT (1u << 21)   // ~ 5 s of polling: a missing peer ends in an error word, not in a hung GPU
 
 extern "C" int64_t pqn_peer_region_bytes(int64_t n) { return n > 0 ? (int64_t)PEER_FLAG_OFFSET_BYTES(n) + 256 : -1; }
@@ -72,7 +74,7 @@ struct PeerPtrs {
 __global__ __launch_bounds__(256) void peer_publish_kernel(const float *__restrict__ grad, long long n, float *send_mine,
                                                            unsigned *flag_mine, unsigned *local_state) {
   const unsigned seq = local_state[0];   // every block reads it before the last block (below) advances it
-  float *dst = send_mine + (size_t)(seq & 1u) * n;
+  float *dst = send_mine + (size_t)(seq & 1u) * PEER_STRIDE(n);
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void peer_reduce_kernel(float *__restrict__ gr
     }
   }
   __syncthreads();
-  const size_t off = (size_t)((target - 1u) & 1u) * n;
+  const size_t off = (size_t)((target - 1u) & 1u) * PEER_STRIDE(n);
   const float scale = 1.0f / (float)world;
   const long long n2 = n >> 1;
   const long long stride = (long long)gridDim.x * 256;
