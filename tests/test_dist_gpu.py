@@ -165,3 +165,32 @@ def test_peer_allreduce_two_processes_on_one_gpu(gpu, n):
     for s in range(steps):
         np.testing.assert_array_equal(o0[s], o1[s], err_msg=f"step {s}")
         np.testing.assert_array_equal(o0[s], r0[s], err_msg=f"step {s}")
+
+
+@pytest.mark.parametrize("mode", ["seeds", "envs"])
+def test_bench_gpus_2_launches_its_own_ranks(gpu, mode):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command line) re-executes itself
+    under torch.distributed.run with two ranks -- both on the one GPU of the box here (PQN_BENCH_ONE_GPU=1, gloo) -- and
+    rank 0 prints ONE JSON line with n_gpus = 2, the whole-job rate, max-over-ranks timing; --mode envs also reports
+    which gradient all-reduce ran (the in-graph peer kernels)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PQN_BENCH_ONE_GPU="1", PQN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras",
+           "--no-cpu-baseline", "--seeds-per-gpu", "2", "--mode", mode]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    c = d["config"]
+    assert c["dist_backend"] == "gloo" and c["rccl_ranks"] == 0 and c["gpus_visible"] == 1
+    if mode == "seeds":
+        assert d["scaling"] == "weak" and c["seeds_total"] == 4 and c["env_steps_per_step"] == 4 * 4096 * 32
+        assert abs(d["value"] - c["env_steps_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    else:
+        assert d["scaling"] == "strong" and c["grad_allreduce"] == "peer" and c["driver"] == "hipGraph replay"
