@@ -352,7 +352,8 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * backward on a second stream; default 0), "t1_ksplit" (K-split form of the f32-mode training kernel for minibatches of
  * at most 256 samples: a tile's work cut along the conv positions over many workgroups; 1 (default) = forward partial +
  * head-and-backward as two launches, 2 / 3 / 4 = three launches with 4 / 8 / 16 positions per workgroup, 0 = the
- * single-tile kernel).  Each starts from its PQN_<NAME> environment
+ * single-tile kernel), "t1_ksplit_tiles" (the K-split form is taken while tiles x seeds of a launch stay at or below
+ * this; default 48).  Each starts from its PQN_<NAME> environment
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);

@@ -85,6 +85,7 @@ enum {
   PQN_OPT_BM_TILE,        // PQN_BM_TILE: tile height of the wide-MLP GEMMs (0 auto, 64, 128)
   PQN_OPT_BM_SPLIT,       // PQN_BM_SPLIT: K splits of the wide-MLP GEMMs (0 auto, 1 .. 4)
   PQN_OPT_T1_KSPLIT,      // PQN_T1_KSPLIT: K-split form of the f32-mode training kernel for minibatches <= 256 samples (default 1)
+  PQN_OPT_T1_KSPLIT_TILES, // PQN_T1_KSPLIT_TILES: the K-split form is taken while tiles x seeds of the launch stay at or below this (default 48)
   PQN_OPT_BM_OVERLAP,     // PQN_BM_OVERLAP: parameter-gradient side of the wide-MLP backward on a second stream (default 0: measured no gain)
   PQN_OPT_COUNT
 };

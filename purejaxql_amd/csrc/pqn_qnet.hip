@@ -4119,14 +4119,19 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   float *dzT = ws + 1024;
   float *h1T = dzT + (size_t)QN_HID * qw_ld(nb);
   float *gpart = h1T + (size_t)QN_H1 * qw_h1_cols(nb);
-  // K-split form for small minibatches in the f32 operand mode (a function of nb and the mode only: a seed gets the same
-  // bits alone and inside a batch of seeds); PQN_T1_KSPLIT=0 keeps the single-tile kernel
+  // K-split form for small minibatches in the f32 operand mode; PQN_T1_KSPLIT=0 keeps the single-tile kernel
   // (with_reduce == false is the experimental one-kernel optimizer, which folds the standard partial layout itself)
   // 0 off; 1 (default, measured best) = two launches: forward partial with 4 positions per workgroup, then head + backward
   // in one (8 positions per workgroup); three launches (forward partial, head, backward) with 4 (2), 8 (3) or 16 (4)
   // positions per workgroup
   const int ks_opt = pqn_opt(PQN_OPT_T1_KSPLIT);
-  const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && ks_opt != 0;
+  // ... and only while the launch is small: with many tiles in flight (seeds batched into the launch) the chip is filled
+  // by whole tiles and the K-split form's recomputation costs more than the latency it hides (yaml-default run, S seeds x 8
+  // tiles per launch, K-split vs single-tile: S = 1: 5.9 vs 9.9 s, 2: 6.9 vs 10.3, 4: 7.8 vs 11.1, 6: 10.2 vs 11.6, 10: 14.1
+  // vs 12.4).  A seed therefore gets the same bits alone and inside a batch only as long
+  // as both launches fall on the same side of this threshold (option t1_ksplit_tiles).
+  const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && ks_opt != 0 &&
+                      ntiles * sd.nseeds <= pqn_opt(PQN_OPT_T1_KSPLIT_TILES);
   const bool ks_hb = ks_opt == 1 || ks_opt > 4;
   const int ks_ng = ks_hb ? 8 : (ks_opt == 3 ? 8 : (ks_opt == 4 ? 4 : 16));   // records (and backward groups) per tile
   float *wpart = gpart + (size_t)ntiles * rec;
