@@ -305,7 +305,9 @@ int pqn_cnn_update_phase(const pqn_update_args_t *args /* host */, int32_t phase
  *   sched_keys u64[S][T+EP]; sort_keys_in/out i64[S*T*N]; sort_temp: pqn_update_sort_temp_bytes(S*T*N)
  *   metrics f64[S][metrics_capacity][PQN_NUM_METRICS]; clock, sched_eps shared (same update index and eps)
  * key_roll_dev / key_shuf_dev: device u64[S] (args->key_roll / key_shuf are ignored when num_seeds > 1).
- * Results per seed are bit-identical to num_seeds single-seed pqn_cnn_update calls.  Needs NUM_ENVS % 16 == 0,
+ * Results per seed are bit-identical to num_seeds single-seed pqn_cnn_update calls whenever both take the same form of the
+ * training kernel (the f32-mode K-split form for minibatches <= 256 samples is chosen by tiles x seeds of the launch, option
+ * t1_ksplit_tiles; across that threshold the results agree to f32 summation order).  Needs NUM_ENVS % 16 == 0,
  * T*N <= 2^25, num_seeds <= 128; strides in floats, multiples of 4. */
 int pqn_cnn_update_seeds(const pqn_update_args_t *args /* host */, int32_t num_seeds, const uint64_t *key_roll_dev,
                          const uint64_t *key_shuf_dev, int64_t theta_stride, int64_t workspace_stride, void *stream);

@@ -758,7 +758,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
     def make_batch_runner(rngs: List[int]):
         """jax.vmap(train)(rngs) inside the launches: all seeds advance in the same kernels (grid.y = seed,
         pqn_cnn_update_seeds), one hipGraph replay per update for all of them.  Same key schedule, same
-        kernels and summation orders as make_runner, so every seed's result is bit-identical to its solo run.
+        kernels and summation orders as make_runner, so every seed's result is bit-identical to its solo run (one exception:
+        f32 mode, minibatches <= 256 samples, when only one of the two launches is small enough for the K-split training
+        kernels -- option t1_ksplit_tiles; they then agree to f32 summation order).
         Returns (update, finish); finish() -> list of per-seed result dicts."""
         from .qnet import METRIC_NAMES, CnnKernelLayout, MlpKernelLayout, SeedsUpdateDriver, matmul_mode, mlp_forward
         S = len(rngs)
