@@ -276,6 +276,20 @@ static void launch_minatar(int n, uint64_t key, const uint64_t *key_dev, float r
   }
 }
 
+// Craftax-Classic keeps its 64 x 64 map in the state (4.2 KB per env) and its kernels step it where it lies; a functional
+// call (state_out != state_in) copies the state across first and steps the copy -- same results, one extra pass over the
+// state, state_in left untouched.  The training loops step in place.
+static int craftax_functional_copy(int n, const uint32_t *si, uint32_t *so, hipStream_t st) {
+  if (si == so) return PQN_OK;
+  pqn_env_spec_t sp = {};
+  pqn_craftax_spec(&sp);
+  if (hipMemcpyAsync(so, si, sizeof(uint32_t) * (size_t)sp.state_words * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    pqn_set_error("Craftax-Classic: copying the state for a functional step failed");
+    return PQN_E_HIP;
+  }
+  return PQN_OK;
+}
+
 template <bool IS_RESET>
 static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, float rscale, const uint32_t *si,
                     uint32_t *so, const int32_t *action, const pqn_step_out_t &out, hipStream_t st, int n_per_seed = 0,
@@ -286,8 +300,8 @@ static int dispatch(int env_id, int n, uint64_t key, const uint64_t *key_dev, fl
     return PQN_E_UNSUPPORTED;
   }
   if (env_id == PQN_ENV_CRAFTAX_CLASSIC) {   // map-in-memory env: its own kernels, stepped in place
-    PQN_REQUIRE(IS_RESET || si == so, "Craftax-Classic steps its state in place: state_in must equal state_out");
     PQN_REQUIRE(!opt_keys, "Craftax-Classic: use pqn_env_step_optimistic");
+    if (!IS_RESET) { const int rc = craftax_functional_copy(n, si, so, st); if (rc != PQN_OK) return rc; }
     if (IS_RESET) return pqn_craftax_reset(n, key, so, out.obs, st);
     return pqn_craftax_step(n, key, key_dev, rscale, so, action, out, 0, nullptr, cc_slots, st);
   }
@@ -335,7 +349,8 @@ static int step_optimistic(int env_id, int n, uint64_t key, const uint64_t *key_
                            const uint32_t *state_in, uint32_t *state_out, const int32_t *action, const pqn_step_out_t &out,
                            uint64_t *scratch, int32_t *slot_out, hipStream_t st) {
   if (env_id == PQN_ENV_CRAFTAX_CLASSIC) {
-    PQN_REQUIRE(state_in == state_out, "Craftax-Classic steps its state in place: state_in must equal state_out");
+    const int rc = craftax_functional_copy(n, state_in, state_out, st);
+    if (rc != PQN_OK) return rc;
     return pqn_craftax_step(n, key, key_dev, rscale, state_out, action, out, reset_ratio, scratch, slot_out, st);
   }
   const int rc = dispatch<false>(env_id, n, key, key_dev, rscale, state_in, state_out, action, out, st, 0, 0, scratch);

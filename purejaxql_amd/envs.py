@@ -85,7 +85,6 @@ class Environment:
         self.state_words = int(spec.state_words)
         self.num_actions = int(spec.num_actions)
         self.default_params = EnvParams(max_steps_in_episode=int(spec.max_steps))
-        self.in_place_only = name.startswith("Craftax")
         # Craftax-Classic's Achievement enum order (bit k of the mask pqn_step_out_t.achievements carries)
         self.achievement_names = CRAFTAX_CLASSIC_ACHIEVEMENTS if name == "Craftax-Classic-Symbolic-v1" else ()
         self.device = torch.device(device) if device is not None else torch.device("cuda")
@@ -139,11 +138,7 @@ class Environment:
             raise ValueError(f"action must be a contiguous [{n}] tensor")
         dev = self.device
         src_words = state.words
-        if self.in_place_only:      # map-in-memory envs (Craftax) step their state in place: functional calls copy first
-            new_words = state.words if inplace else state.words.clone()
-            src_words = new_words
-        else:
-            new_words = state.words if inplace else torch.empty_like(state.words)
+        new_words = state.words if inplace else torch.empty_like(state.words)   # functional by default, like gymnax
         obs, bits = self._alloc_obs(n, want_obs, want_bits)
         reward = torch.empty(n, dtype=torch.float32, device=dev)
         done = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -294,11 +289,7 @@ class OptimisticResetVecEnvWrapper(GymnaxWrapper):
         if scratch is None or scratch.device != state.words.device:
             scratch = self._scratch[sid] = torch.empty(n, dtype=torch.int64, device=dev)
         src_words = state.words
-        if base.in_place_only:
-            new_words = state.words if inplace else state.words.clone()
-            src_words = new_words
-        else:
-            new_words = state.words if inplace else torch.empty_like(state.words)
+        new_words = state.words if inplace else torch.empty_like(state.words)
         obs, bits = base._alloc_obs(n, want_obs, want_bits)
         reward = torch.empty(n, dtype=torch.float32, device=dev)
         done = torch.empty(n, dtype=torch.uint8, device=dev)

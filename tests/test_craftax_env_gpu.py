@@ -132,3 +132,27 @@ def test_craftax_script_runs_on_craftax_classic(gpu):
                  "alg.TOTAL_TIMESTEPS=12800", "alg.TOTAL_TIMESTEPS_DECAY=12800", "SAVE_PATH=null"], "pqn_craftax", script="craftax")
     m = outs["metrics"]
     assert m["td_loss"].shape == (1, 100) and torch.isfinite(m["td_loss"]).all() and float(m["env_step"][0, -1]) == 12800
+
+
+def test_craftax_functional_step_equals_in_place(gpu):
+    """env.step is functional like gymnax's (a new state comes back, the old one is untouched) unless `inplace=True`; the
+    map-in-memory env does it by copying its 4.2 KB per env across before stepping the copy.  Same outputs either way, plain
+    and under optimistic resets."""
+    from purejaxql_amd.envs import LogWrapper, OptimisticResetVecEnvWrapper, make
+    n = 64
+    base, params = make(NAME, device=gpu)
+    for env in (LogWrapper(base), OptimisticResetVecEnvWrapper(LogWrapper(base), num_envs=n, reset_ratio=16)):
+        obs, state = env.reset(3, params, n) if isinstance(env, LogWrapper) else env.reset(3, params)
+        rng = np.random.default_rng(0)
+        for t in range(30):
+            a = torch.from_numpy(rng.integers(0, 17, n).astype(np.int32)).to(gpu)
+            before = state.words.clone()
+            o1, s1, r1, d1, i1 = env.step(100 + t, state, a, params)
+            assert torch.equal(state.words, before) and s1.words.data_ptr() != state.words.data_ptr()
+            twin = type(state)(before.clone())
+            o2, s2, r2, d2, i2 = env.step(100 + t, twin, a, params, inplace=True)
+            assert s2.words.data_ptr() == twin.words.data_ptr()
+            assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(s1.words, s2.words)
+            for k in i1:
+                assert torch.equal(i1[k], i2[k]), k
+            state = s1
