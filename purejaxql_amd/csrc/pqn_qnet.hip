@@ -2205,7 +2205,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
   __syncthreads();
   T1_STAMP(5);
   // ---- P5: LN0 backward (t1_ln0_bwd; contains the barrier that ends the phase) ----
-  t1_ln0_bwd<C>(s.h1, s.stg, ts.red, theta, L, xkeep, rkeep, gp, tid, ablate);
+  if constexpr (MODE == 2) t1_ln0_bwd_ns<C>(s.h1, ts.red, theta, L, xkeep, rkeep, gp, tid);   // as the pair kernel: same bits
+  else t1_ln0_bwd<C>(s.h1, s.stg, ts.red, theta, L, xkeep, rkeep, gp, tid, ablate);
   T1_STAMP(6);
   // ---- P6: conv weight gradient (t1_conv_wgrad) ----
   t1_conv_wgrad<C, MODE>(s.h1, s.bits, reinterpret_cast<uint32_t *>(s.stg), ts.scr, gp, tid, ablate);
@@ -2891,14 +2892,17 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   t1_dgrad_x3<false>(zA, h1A, nullptr, theta, L, lane, wave, prot);
   __syncthreads();
   T1_STAMP(7);
-  t1_ln0_bwd<C>(h1A, h1B, red, theta, L, xkA, rkA, gpT[0], tid, ablate);
+  // LayerNorm_0 backward without the staging buffer (channel sums in registers + permlane swaps): -2.7 % per launch
+  // against the staged form in an in-call A/B (profiles/r03_v4_ln0ns_ab.txt); the single-tile bf16x3 kernel uses the same
+  // function, so a tile gets the same bits from both forms
+  t1_ln0_bwd_ns<C>(h1A, red, theta, L, xkA, rkA, gpT[0], tid);
   t1_conv_wgrad<C, 2>(h1A, bitsA, wmS, scr, gpT[0], tid, ablate);
   __syncthreads();   // dx of A and the scratch fully consumed
   T1_STAMP(8);
   t1_dgrad_x3<true>(zB, h1A, maskB, theta, L, lane, wave, prot);
   __syncthreads();
   T1_STAMP(9);
-  t1_ln0_bwd<C>(h1A, h1B, red, theta, L, xkB, rkB, gpT[1], tid, ablate);
+  t1_ln0_bwd_ns<C>(h1A, red, theta, L, xkB, rkB, gpT[1], tid);
   t1_conv_wgrad<C, 2>(h1A, bitsB, wmS, scr, gpT[1], tid, ablate);
   T1_STAMP(10);
 }

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/ab
 L=purejaxql_amd/csrc/libpqn_hip.so
 cp $L /tmp/libpqn_default.so
 run() {
-  timeout 600 python bench.py --steps 10 --warmup 3 --no-extras > gpurun_out/ab/bench_$1.json 2> gpurun_out/ab/bench_$1.err
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline > gpurun_out/ab/bench_$1.json 2> gpurun_out/ab/bench_$1.err
   python - <<PY
 import json
 d = json.loads(open("gpurun_out/ab/bench_$1.json").read().strip().splitlines()[-1])
