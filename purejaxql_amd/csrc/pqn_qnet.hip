@@ -2970,11 +2970,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_pair_kernel(
     phase1_conv<C, false, true, true>(sA, tid);
     phase1_conv<C, false, true, true>(sB, tid);
     __syncthreads();
-#ifdef ROLL_PF3   // A/B hook: 3-deep weight ring in the rollout pair kernel
-    phase2_fc1_x3<3, 2>(sA, theta + L.off_w1h, tid, tile_in_seed >> 1, &sB);
-#else
-    phase2_fc1_x3<2, 2>(sA, theta + L.off_w1h, tid, tile_in_seed >> 1, &sB);
-#endif
+    phase2_fc1_x3<2, 2>(sA, theta + L.off_w1h, tid, tile_in_seed >> 1, &sB);   // (a 3-deep ring spills 38 VGPRs here)
     __syncthreads();
     {
       float q[QN_MAXA], h2[8], xh[8], rstd;
@@ -3567,11 +3563,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, c
   // a load under a condition, or a select right behind it, makes the compiler drain the whole queue
   // (s_waitcnt vmcnt(0)) at every step, which serialises the HBM round trips.
   auto fetch = [&](int itn, int u) -> f32x4 {   // h1 slab-major (h1s_index): step tile = 8 KB contiguous, 16 B per thread
-#ifdef T2_NT_LOAD   // A/B hook: streaming (read-once) loads of the h1 slab
-    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(h1T + ((((size_t)ks * 16 + it0 + min(itn, G - 1)) * 8 + u) * 2048 + 4 * tid)));
-#else
+    // (streaming loads measured: T2 itself unchanged, the reduction behind it 30.2 -> 28.9 us -- profiles/r03_v4_ln0ns_ab.txt)
     return *reinterpret_cast<const f32x4 *>(h1T + ((((size_t)ks * 16 + it0 + min(itn, G - 1)) * 8 + u) * 2048 + 4 * tid));
-#endif
   };
   auto masked = [&](const f32x4 &v, int u) -> f32x4 { return (a_col + QY_KS * u < nb) ? v : zero4; };
   f32x4 pre[NST];
