@@ -1,8 +1,10 @@
 #!/bin/bash
-# Round 3, call t: K-split forms at many tiles (10 seeds x 8 tiles per launch), threshold lifted
+# Round 3, call t: three-launch K-split form (4 positions per workgroup) against the single-tile kernel at 16 seeds x 8 tiles
 mkdir -p gpurun_out/r3t
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-for ks in 0 2 3 4; do
-  echo "== S=10 PQN_T1_KSPLIT=$ks"; PQN_T1_KSPLIT_TILES=100000 PQN_T1_KSPLIT=$ks timeout 600 python tools/time_default_run.py 10 1 0 2>&1 | tail -1 | cut -c1-90 | tee -a gpurun_out/r3t/default_10seeds_forms.txt
+for S in 16; do
+  for ks in 0 2; do
+    echo "== S=$S PQN_T1_KSPLIT=$ks"; PQN_T1_KSPLIT_TILES=100000 PQN_T1_KSPLIT=$ks timeout 600 python tools/time_default_run.py $S 1 0 2>&1 | tail -1 | cut -c1-90 | tee -a gpurun_out/r3t/default_16seeds_forms.txt
+  done
 done
