@@ -192,3 +192,66 @@ def test_observation_layout(oracle):
     np.testing.assert_allclose(t[:12], (np.arange(12) % 10) / 10.0, rtol=0, atol=1e-7)
     np.testing.assert_allclose(t[12:16], 0.9, atol=1e-7)
     assert list(t[16:20]) == [0, 0, 0, 1] and t[21] == 0.0 and 0.0 <= t[20] <= 1.0
+
+
+def test_sword_damage_table_and_eat_cow(oracle):
+    """Crafter's damage table (1 bare-handed, 2 wood, 3 stone, 5 iron sword: the best sword held counts) on a cow of 3
+    health, and what eating it pays: food + 6 capped at 9, hunger clock cleared, EAT_COW once."""
+    for sword_slot, hits in ((None, 3), (9, 2), (10, 1), (11, 1)):          # inventory slots 9 / 10 / 11 = wood / stone / iron sword
+        env, st = fresh(oracle)
+        st["si"][0, S + 20:S + 35] = 0                                       # no zombies
+        st["si"][0, S + 35:S + 47] = 0
+        st["si"][0, S + 35:S + 39] = [33, 32, 3, 1]                          # a cow right below (r, c, health, mask) ...
+        for rr, cc in ((34, 32), (33, 31), (33, 33)):
+            put(st, rr, cc, STONE)                                           # ... walled in: it cannot wander off
+        st["si"][0, S + 4] = 2                                               # food 2
+        if sword_slot is not None:
+            st["si"][0, S + 8 + sword_slot] = 1
+        n = 0
+        while sc(st, 38) and n < 6:
+            assert (sc(st, 35), sc(st, 36)) == (33, 32)
+            act(env, st, DO, key=40 + n)
+            n += 1
+        assert n == hits, (sword_slot, n)
+        assert sc(st, 4) == 8 and sc(st, 109) & (1 << 9)                     # food 2 + 6, EAT_COW
+        assert float(st["sf"][0, 1]) <= 1.0                                  # hunger clock restarted (at most this step's tick)
+
+
+def test_stone_bridges_water_and_lava_and_mobs_block_the_way(oracle):
+    """PLACE_STONE is allowed onto water and lava (Crafter data.yaml place.stone.where = grass, sand, path, water, lava);
+    a cell occupied by a mob can neither be entered nor built on; the facing direction follows the action regardless."""
+    env, st = fresh(oracle)
+    st["si"][0, S + 20:S + 69] = 0
+    st["si"][0, S + 8 + 1] = 3                                               # 3 stones
+    put(st, 33, 32, WATER)
+    _, r, _ = act(env, st, P_STONE)
+    assert cell(st, 33, 32) == STONE and sc(st, 9) == 2 and r == 1.0         # PLACE_STONE achievement
+    act(env, st, RIGHT)                                                      # now at (32, 33), facing right
+    assert (sc(st, 0), sc(st, 1), sc(st, 2)) == (32, 33, RIGHT)
+    put(st, 32, 34, LAVA)
+    act(env, st, P_STONE)
+    assert cell(st, 32, 34) == STONE and sc(st, 9) == 1
+    # a cow in the way: no move, no placement, but the player turns
+    st["si"][0, S + 35:S + 39] = [31, 33, 3, 1]
+    act(env, st, UP, key=77)
+    if (sc(st, 35), sc(st, 36)) == (31, 33):                                 # (unless this draw moved the cow away)
+        assert (sc(st, 0), sc(st, 1), sc(st, 2)) == (32, 33, UP)
+        before = cell(st, 31, 33)
+        act(env, st, P_STONE, key=78)
+        if (sc(st, 35), sc(st, 36)) == (31, 33):
+            assert cell(st, 31, 33) == before and sc(st, 9) == 1
+
+
+def test_sleeping_player_ignores_actions(oracle):
+    """While is_sleeping the chosen action is replaced by noop (Crafter Player.update: `if self.sleeping: action = noop`):
+    no move, no interaction, until energy is back."""
+    env, st = fresh(oracle)
+    st["si"][0, S + 20:S + 69] = 0
+    st["si"][0, S + 6] = 3                                                   # energy 3
+    put(st, 33, 32, TREE)
+    act(env, st, SLEEP)
+    assert sc(st, 7) == 1
+    pos = (sc(st, 0), sc(st, 1))
+    act(env, st, LEFT, key=5)
+    act(env, st, DO, key=6)
+    assert sc(st, 7) == 1 and (sc(st, 0), sc(st, 1)) == pos and sc(st, 8) == 0     # still asleep, not moved, no wood collected
