@@ -184,6 +184,13 @@ def main():
     ap.add_argument("--mode", default="seeds", choices=["seeds", "envs"],
                     help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
                          "(RCCL gradient all-reduce per optimizer step)")
+    ap.add_argument("--seed-groups", type=int, default=0,
+                    help="seed groups per GPU (0 = the package's automatic choice: 2 for the 16-seed workload).  With G > 1 the "
+                         "HBM-bound optimizer tail of one group runs on a second stream under the training kernel of the next "
+                         "(pqn_cnn_update_seed_groups); 1 = all seeds in one chain of launches (rounds 1-3)")
+    ap.add_argument("--groups-tail", default="graph",
+                    help="graph (default: one two-branch hipGraph per update) | eager (C++ enqueue, high-priority tail stream) "
+                         "| masked:<lo>:<hi> (eager, tail stream on CUs [lo, hi), training kernels on the rest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only")
     ap.add_argument("--matmul-dtype", default="bf16x3", choices=["f32", "bf16x3", "f16"],
@@ -240,6 +247,8 @@ def main():
     if args.matmul_dtype:
         cfg["MATMUL_DTYPE"] = args.matmul_dtype
     matmul = str(cfg.get("MATMUL_DTYPE", "f32")).lower()
+    cfg["SEED_GROUPS"] = args.seed_groups
+    cfg["_SEED_GROUPS_TAIL"] = args.groups_tail
     SUSTAIN_MAX = 400
     n_total = args.steps + args.warmup + 3 + SUSTAIN_MAX
     cfg["TOTAL_TIMESTEPS"] = n_total * cfg["NUM_ENVS"] * cfg["NUM_STEPS"]
@@ -290,9 +299,14 @@ def main():
     mb = train.config["NUM_ENVS"] * cfg["NUM_STEPS"] // cfg["NUM_MINIBATCHES"]   # minibatch per rank and seed
     drv0 = getattr(update, "driver", None)
     driver_mode = None if drv0 is None else ("hipGraph replay" if drv0.graph is not None else "C++ enqueue (eager)")
+    groups = len(getattr(drv0, "drivers", [None]))          # seed groups of the headline runner (SeedGroupsDriver)
+    spl = spg // groups                                      # seeds per training-kernel launch
     if fused and (rank == 0 or (world > 1 and args.mode == "envs")):
-        avg_s, launches = kernel_timer_pass(lib, update, n_done, mb, spg)
-        roof = t1_roofline(avg_s, launches, mb, spg, matmul, _lib.last_kernel_form()[0])
+        avg_s, launches = kernel_timer_pass(lib, update, n_done, mb, spl)
+        roof = t1_roofline(avg_s, launches, mb, spl, matmul, _lib.last_kernel_form()[0])
+        if groups > 1:
+            roof["note"] = (f"{groups} seed groups of {spl} seeds: each timed launch covers one group and runs while the "
+                            "previous group's fc1 weight gradient / fold / RAdam kernels share the GPU on a second stream")
 
     if rank == 0:
         if roof is None:
@@ -315,6 +329,7 @@ def main():
                                       f"(BASELINE.json configs[3] = 128 seeds x 4096 envs over 8 GPUs is 16 per GPU)"
                                       if args.mode == "seeds" else f"ONE seed, its envs sharded over {world} rank(s)"),
                        "seeds_per_gpu": spg, "seeds_total": spg * world if args.mode == "seeds" else 1,
+                       "seed_groups": groups, "seed_groups_tail": args.groups_tail if groups > 1 else None,
                        "env_steps_per_step": env_steps_per_update, "matmul_dtype": matmul,
                        "backend": train.backend, "driver": driver_mode, "parallelism": f"{args.mode}x{world}",
                        "kernel_forms": dict(zip(("train", "rollout"), _lib.last_kernel_form())),

@@ -312,6 +312,25 @@ int pqn_cnn_update_phase(const pqn_update_args_t *args /* host */, int32_t phase
 int pqn_cnn_update_seeds(const pqn_update_args_t *args /* host */, int32_t num_seeds, const uint64_t *key_roll_dev,
                          const uint64_t *key_shuf_dev, int64_t theta_stride, int64_t workspace_stride, void *stream);
 
+/* The same update for num_groups GROUPS of seeds (each group = its own pqn_cnn_update_seeds argument set: own stacked
+ * buffers, clock, workspace), software-pipelined over two streams: one optimizer step of a group is a compute-bound
+ * training kernel followed by an HBM-bound tail (fc1 weight gradient, fold of the partials, clip + RAdam); the seeds of
+ * jax.vmap(make_train) (pqn_minatar.py:459-461) are independent, so every group's tail is enqueued on `tail_stream` and
+ * runs UNDER the next group's training kernel on `stream` (edges training kernel(g,i) -> tail(g,i) -> training
+ * kernel(g,i+1) as events).  tail_stream is forked from and joined back into `stream` inside the call: capturing `stream`
+ * yields one hipGraph with two branches.  Per seed bit-identical to pqn_cnn_update_seeds on the same group.  All groups
+ * must share NUM_MINIBATCHES / NUM_EPOCHS; array arguments are host arrays of num_groups entries. */
+int pqn_cnn_update_seed_groups(int32_t num_groups, const pqn_update_args_t *const *args /* host */,
+                               const int32_t *num_seeds /* host */, const uint64_t *const *key_roll_dev,
+                               const uint64_t *const *key_shuf_dev, const int64_t *theta_stride /* host */,
+                               const int64_t *workspace_stride /* host */, void *stream, void *tail_stream);
+/* A HIP stream restricted to the compute units whose bit is set in cu_mask (mask_words 32-bit words; 0 words = no mask,
+ * then high_priority != 0 asks for the device's highest stream priority).  Measurement aid for the eager form of
+ * pqn_cnn_update_seed_groups (a replayed hipGraph does not carry stream attributes); no reference counterpart. */
+int pqn_stream_create_masked(const uint32_t *cu_mask /* host */, int32_t mask_words, int32_t high_priority,
+                             void **stream_out /* host */);
+int pqn_stream_destroy(void *stream);
+
 /* The rollout scan alone, as ONE persistent launch: num_steps x (Q-network forward, eps-greedy, env.step with
  * auto-reset + LogWrapper) for every env, then the bootstrap forward of the last observation.  Replaces
  * jax.lax.scan(_step_env) + the last_q forward (pqn_minatar.py:181-235) and, with eps = EPS_TEST and

@@ -81,6 +81,9 @@ SIGNATURES = {
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float,
                                       c_void_p]),
     "pqn_cnn_update_seeds": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "pqn_cnn_update_seed_groups": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pqn_stream_create_masked": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    "pqn_stream_destroy": (c_int, [c_void_p]),
     "pqn_cnn_rollout": (c_int, [c_int, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "pqn_debug_t1_stamps": (c_int, [c_void_p]),

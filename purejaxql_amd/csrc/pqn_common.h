@@ -199,7 +199,8 @@ int pqn_cnn_grad_reduce_blocks(int total);   // number of sum-of-squares partial
 int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out,
-                            const pqn_seeds_t &sd, hipStream_t st, bool with_reduce = true);
+                            const pqn_seeds_t &sd, hipStream_t st, bool with_reduce = true, int part = 0);
+// part: 0 = whole gradient, 1 = the training kernel(s) only, 2 = fc1 weight gradient + fold of the partials only
 // fold + clip + RAdam in one launch with a grid-wide barrier (see qnet_reduce_apply_kernel); scratch word 1022 of
 // the workspace is its ticket counter and must be zero before the first launch of an update
 int pqn_qnet_cnn_reduce_apply_seeds(const pqn_cnn_layout_t &L, int nb, float *theta, float *w1b, float *m, float *v,

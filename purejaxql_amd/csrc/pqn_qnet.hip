@@ -4117,7 +4117,10 @@ template <int C>
 static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits,
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                         const int32_t *count, float *ws, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
-                        hipStream_t st, bool with_reduce) {
+                        hipStream_t st, bool with_reduce, int part) {
+  // part: 0 = the whole gradient; 1 = the compute-bound training kernel(s) only; 2 = the HBM-bound rest (fc1 weight
+  // gradient + fold of the partials) only -- pqn_cnn_update_seed_groups runs the two parts of a seed group on different
+  // streams so that one group's tail overlaps the other group's training kernel
   const int ntiles = nb / QN_TILE, rec = small_record_floats(C, L.a);
   const int nks = (nb + QW_SLAB - 1) / QW_SLAB;
   float *scratch = ws;
@@ -4149,6 +4152,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     gpart = dzbuf + (size_t)ntiles * QN_TILE * QN_HID;
     wpart = gpart + (size_t)ntiles * ks_ng * rec;
     const float inv_b_ks = 1.0f / (float)nb;
+    if (part == 2) return PQN_OK;   // the K-split form has no separate tail: part 1 ran everything
     pqn_note_kernel_form(0, PQN_FORM_KSPLIT);
 #define KS_LAUNCH(PG_)                                                                                                               \
     do {                                                                                                                               \
@@ -4261,9 +4265,11 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     pqn_seeds_t sg = sd;
     sg.seed_base = s0;
     const long long wo = (long long)s0 * sd.ws_stride;
-    const bool timed = g_prof.on && g_prof.mode == 1 && g_prof.n < PQN_PROF_MAX;
+    const bool timed = part != 2 && g_prof.on && g_prof.mode == 1 && g_prof.n < PQN_PROF_MAX;
     if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
-    if (use_pos) {
+    if (part == 2) {
+      if (use_pos) continue;
+    } else if (use_pos) {
       if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
         if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;
       }
@@ -4284,6 +4290,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     hipLaunchKernelGGL(t1, dim3(ntiles, gs), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
                        target, theta, w1b, L, inv_b, dzT, h1T, gpart, ablate, g_t1_stamps, sg, dz_scale);
     if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
+    if (part == 1) continue;
     if (L.matmul_f16 == 1)
       hipLaunchKernelGGL(qnet_fc1_wgrad_f16_kernel, dim3(16, nks, gs), dim3(QN_THREADS), 0, st, nb, h1T + wo, dzT + wo, wpart + wo,
                          sd.ws_stride, 1.0f / dz_scale);
@@ -4306,7 +4313,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, gs), dim3(QN_THREADS), 0, st, nb, h1T + wo, dzT + wo, wpart + wo,
                          sd.ws_stride);
   }
-  if (with_reduce)
+  if (with_reduce && part != 1)
     hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles,
                        use_pos ? 1 : nks, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd,
                        use_pos ? gposw : nullptr, use_pos ? 16 : 0);
@@ -4370,12 +4377,12 @@ extern "C" int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t *L, int32_t num_se
 int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
-                            hipStream_t st, bool with_reduce) {
+                            hipStream_t st, bool with_reduce, int part) {
   switch (L.c) {
-    case 4: return launch_train<4>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce);
-    case 6: return launch_train<6>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce);
-    case 7: return launch_train<7>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce);
-    case 10: return launch_train<10>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce);
+    case 4: return launch_train<4>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
+    case 6: return launch_train<6>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
+    case 7: return launch_train<7>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
+    case 10: return launch_train<10>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
     default: pqn_set_error("pqn_qnet_cnn_grad: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
   }
 }

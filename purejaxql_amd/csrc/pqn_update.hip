@@ -252,12 +252,12 @@ static int upd_shuffle(const pqn_update_args_t *a, const UpdCtx &c, int ep, hipS
   return pqn_sort_keys(a->sort_temp, tb, a->sort_keys_in, a->sort_keys_out, c.S * c.TN, c.S, c.TN, st);
 }
 
-static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool with_reduce, hipStream_t st) {
+static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool with_reduce, hipStream_t st, int part = 0) {
   const int mb = i_mb % c.MB;
   // low bits of a sorted shuffle key = the transition index inside the seed (kernels mask with sd.idx_mask)
   return pqn_qnet_cnn_grad_seeds_dyn(a->layout, c.B, a->sort_keys_out + (size_t)mb * c.B, a->bits, a->action, a->target, a->theta,
                                  a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, c.sd, st,
-                                 with_reduce);
+                                 with_reduce, part);
 }
 
 static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool norm_pass, hipStream_t st) {
@@ -334,6 +334,124 @@ extern "C" int pqn_cnn_update_seeds(const pqn_update_args_t *a, int32_t num_seed
   PQN_REQUIRE(num_seeds == 1 || (theta_stride > 0 && workspace_stride > 0 && theta_stride % 4 == 0 && workspace_stride % 4 == 0),
               "pqn_cnn_update_seeds: strides must be positive multiples of 4 floats");
   return cnn_update_impl(a, num_seeds, key_roll_dev, key_shuf_dev, theta_stride, workspace_stride, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// G groups of seeds, software-pipelined over TWO streams (round 4).  One optimizer step of a seed group is a
+// compute-bound training kernel (T1: ~75 % of the step, ~1 TB/s of HBM traffic, every CU's LDS and registers) followed by
+// an HBM-bound tail (fc1 weight gradient, fold of the partials, clip + RAdam: ~25 % of the step at 4.5-5.4 TB/s with the
+// matrix cores nearly idle).  Seeds are independent (jax.vmap axis, pqn_minatar.py:459-461), so the launches of group g+1
+// do not depend on group g: the training kernels of all groups run back to back on `stream`, and every group's tail runs
+// on `tail_stream` UNDER the next group's training kernel:
+//     stream       T1(g0,i)  T1(g1,i)  T1(g0,i+1)  T1(g1,i+1) ...
+//     tail_stream            tail(g0,i) tail(g1,i)  tail(g0,i+1) ...
+// with the edges T1(g,i) -> tail(g,i) -> T1(g,i+1) as events.  Only enqueues; capturable (the second stream is forked
+// from and joined back into `stream`, so a capture of `stream` records one graph with two branches).  Each group's
+// buffers are its own pqn_cnn_update_seeds arguments; results per seed are bit-identical to pqn_cnn_update_seeds (same
+// kernels, same launch shapes per group, only their order in time changes).
+// ---------------------------------------------------------------------------------------------------------
+#define PQN_MAX_SEED_GROUPS 8
+static struct {
+  bool created = false;
+  hipEvent_t fork, join, t1[PQN_MAX_SEED_GROUPS], tail[PQN_MAX_SEED_GROUPS];
+} g_sg_ev;
+
+#define HIP_OK(call, what)                                             \
+  do {                                                                 \
+    if ((call) != hipSuccess) {                                        \
+      pqn_set_error("pqn_cnn_update_seed_groups: %s failed", what);    \
+      return PQN_E_HIP;                                                \
+    }                                                                  \
+  } while (0)
+
+extern "C" int pqn_cnn_update_seed_groups(int32_t num_groups, const pqn_update_args_t *const *args, const int32_t *num_seeds,
+                                          const uint64_t *const *key_roll_dev, const uint64_t *const *key_shuf_dev,
+                                          const int64_t *theta_stride, const int64_t *workspace_stride, void *stream,
+                                          void *tail_stream) {
+  PQN_REQUIRE(num_groups >= 1 && num_groups <= PQN_MAX_SEED_GROUPS && args && num_seeds && key_roll_dev && key_shuf_dev &&
+                  theta_stride && workspace_stride,
+              "pqn_cnn_update_seed_groups: 1 <= num_groups <= %d and non-NULL argument arrays", PQN_MAX_SEED_GROUPS);
+  PQN_REQUIRE(tail_stream && tail_stream != stream, "pqn_cnn_update_seed_groups: tail_stream must be a second, non-NULL stream");
+  hipStream_t sc = (hipStream_t)stream, sm = (hipStream_t)tail_stream;
+  const int G = num_groups;
+  UpdCtx c[PQN_MAX_SEED_GROUPS];
+  for (int g = 0; g < G; ++g) {
+    PQN_REQUIRE(num_seeds[g] == 1 || (theta_stride[g] > 0 && workspace_stride[g] > 0 && theta_stride[g] % 4 == 0 && workspace_stride[g] % 4 == 0),
+                "pqn_cnn_update_seed_groups: strides must be positive multiples of 4 floats");
+    UPD_CHECK(upd_ctx(args[g], num_seeds[g], key_roll_dev[g], key_shuf_dev[g], theta_stride[g], workspace_stride[g], c[g]));
+    PQN_REQUIRE(c[g].MB == c[0].MB && c[g].EP == c[0].EP, "pqn_cnn_update_seed_groups: every group must have the same NUM_MINIBATCHES / NUM_EPOCHS");
+    PQN_REQUIRE(!c[g].fused_opt, "pqn_cnn_update_seed_groups: the experimental one-kernel optimizer cannot run with several updates in flight");
+    for (int h = 0; h < g; ++h)
+      PQN_REQUIRE(args[h]->workspace != args[g]->workspace && args[h]->theta != args[g]->theta && args[h]->clock != args[g]->clock,
+                  "pqn_cnn_update_seed_groups: groups %d and %d share buffers", h, g);
+  }
+  if (!g_sg_ev.created) {   // events are plain dependency markers: no timing, reusable across steps and captures
+    HIP_OK(hipEventCreateWithFlags(&g_sg_ev.fork, hipEventDisableTiming), "hipEventCreate");
+    HIP_OK(hipEventCreateWithFlags(&g_sg_ev.join, hipEventDisableTiming), "hipEventCreate");
+    for (int g = 0; g < PQN_MAX_SEED_GROUPS; ++g) {
+      HIP_OK(hipEventCreateWithFlags(&g_sg_ev.t1[g], hipEventDisableTiming), "hipEventCreate");
+      HIP_OK(hipEventCreateWithFlags(&g_sg_ev.tail[g], hipEventDisableTiming), "hipEventCreate");
+    }
+    g_sg_ev.created = true;
+  }
+  HIP_OK(hipEventRecord(g_sg_ev.fork, sc), "hipEventRecord");
+  HIP_OK(hipStreamWaitEvent(sm, g_sg_ev.fork, 0), "hipStreamWaitEvent");
+  // rollouts + targets: compute-bound persistent kernels, one group after the other on the compute stream
+  for (int g = 0; g < G; ++g) UPD_CHECK(upd_begin(args[g], c[g], key_roll_dev[g], key_shuf_dev[g], sc));
+  int i_mb = 0;
+  for (int ep = 0; ep < c[0].EP; ++ep) {
+    // the epoch's permutation is read by the training kernels only (all on `sc`, in order): no extra edge needed
+    for (int g = 0; g < G; ++g) UPD_CHECK(upd_shuffle(args[g], c[g], ep, sc));
+    for (int mb = 0; mb < c[0].MB; ++mb, ++i_mb) {
+      for (int g = 0; g < G; ++g) {
+        if (i_mb > 0) HIP_OK(hipStreamWaitEvent(sc, g_sg_ev.tail[g], 0), "hipStreamWaitEvent");   // parameters of step i_mb - 1
+        UPD_CHECK(upd_grad(args[g], c[g], i_mb, true, sc, 1));
+        HIP_OK(hipEventRecord(g_sg_ev.t1[g], sc), "hipEventRecord");
+        HIP_OK(hipStreamWaitEvent(sm, g_sg_ev.t1[g], 0), "hipStreamWaitEvent");
+        UPD_CHECK(upd_grad(args[g], c[g], i_mb, true, sm, 2));
+        UPD_CHECK(upd_apply(args[g], c[g], i_mb, false, sm));
+        HIP_OK(hipEventRecord(g_sg_ev.tail[g], sm), "hipEventRecord");
+      }
+    }
+  }
+  for (int g = 0; g < G; ++g) {
+    HIP_OK(hipStreamWaitEvent(sc, g_sg_ev.tail[g], 0), "hipStreamWaitEvent");
+    UPD_CHECK(upd_end(args[g], c[g], sc));
+  }
+  HIP_OK(hipEventRecord(g_sg_ev.join, sm), "hipEventRecord");
+  HIP_OK(hipStreamWaitEvent(sc, g_sg_ev.join, 0), "hipStreamWaitEvent");
+  return PQN_OK;
+}
+
+// A stream restricted to a subset of the compute units (bit i of cu_mask = CU i may run its workgroups), optionally with
+// the highest priority the device offers: lets a caller give the HBM-bound tail stream of pqn_cnn_update_seed_groups its
+// own CUs in the EAGER enqueue (a hipGraph replay does not carry stream attributes).  Measurement aid; the default
+// path does not need it.
+extern "C" int pqn_stream_create_masked(const uint32_t *cu_mask /* host */, int32_t mask_words, int32_t high_priority,
+                                        void **stream_out) {
+  PQN_REQUIRE(stream_out && (mask_words == 0 || cu_mask) && mask_words >= 0 && mask_words <= 32,
+              "pqn_stream_create_masked: bad arguments");
+  hipStream_t s = nullptr;
+  hipError_t e;
+  if (mask_words > 0) e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask);
+  else {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : lo);
+  }
+  if (e != hipSuccess) {
+    pqn_set_error("pqn_stream_create_masked: %s", hipGetErrorString(e));
+    return PQN_E_HIP;
+  }
+  *stream_out = (void *)s;
+  return PQN_OK;
+}
+extern "C" int pqn_stream_destroy(void *stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+    pqn_set_error("pqn_stream_destroy failed");
+    return PQN_E_HIP;
+  }
+  return PQN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------

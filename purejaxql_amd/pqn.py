@@ -21,6 +21,7 @@ Key schedule (this build's own; jax streams cannot be reproduced):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
@@ -755,7 +756,48 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         update.driver = driver   # bench.py switches graph replay off for its HIP-event timing pass
         return update, finish
 
-    def make_batch_runner(rngs: List[int]):
+    def seed_groups_for(S: int) -> int:
+        """How many seed groups a batch of S seeds is cut into (config SEED_GROUPS; 0 / absent = automatic).  Two groups
+        let one group's HBM-bound optimizer tail run under the other group's compute-bound training kernel
+        (qnet.SeedGroupsDriver); taken automatically when both halves still fill the chip with pair-form workgroups."""
+        g = int(config.get("SEED_GROUPS", 0) or 0)
+        if g <= 0:
+            g = int(os.environ.get("PQN_SEED_GROUPS", "0") or 0)
+        if g <= 0:
+            mbs = (T * N) // MB
+            g = 2 if (packed and S % 2 == 0 and (mbs // 32) * (S // 2) >= 256 and config.get("_GRAPH", True)) else 1
+        if not packed or g < 1 or S % g != 0 or g > 8:
+            g = 1
+        return g
+
+    def make_grouped_runner(rngs: List[int], G: int):
+        """make_batch_runner over G seed groups advanced together (pqn_cnn_update_seed_groups): group g holds the seeds
+        rngs[g*S/G : (g+1)*S/G] in its own stacked buffers; update / finish behave as make_batch_runner's."""
+        from .qnet import SeedGroupsDriver
+        per = len(rngs) // G
+        subs = [make_batch_runner(rngs[g * per:(g + 1) * per], groups=1) for g in range(G)]
+        gd = SeedGroupsDriver([u.driver for u, _f in subs], tail=str(config.get("_SEED_GROUPS_TAIL", os.environ.get("PQN_SEED_GROUPS_TAIL", "graph"))))
+
+        def update(u: int):
+            if u != gd.calls:
+                raise RuntimeError(f"update({u}) out of order: the device clock is at {gd.calls}")
+            gd.update()
+            for upd, _f in subs:
+                upd(u, enqueue=False)
+
+        def finish():
+            outs = []
+            for _u, fin in subs:
+                outs.extend(fin())
+            for o in outs:
+                o["runner_state"].entries["seed_batch"] = len(rngs)
+                o["runner_state"].entries["seed_groups"] = G
+            return outs
+
+        update.driver = gd
+        return update, finish
+
+    def make_batch_runner(rngs: List[int], groups: Optional[int] = None):
         """jax.vmap(train)(rngs) inside the launches: all seeds advance in the same kernels (grid.y = seed,
         pqn_cnn_update_seeds), one hipGraph replay per update for all of them.  Same key schedule, same
         kernels and summation orders as make_runner, so every seed's result is bit-identical to its solo run (one exception:
@@ -766,6 +808,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         S = len(rngs)
         if not (backend == "fused" and grad_hook is None and seeds_shape_ok and 1 <= S <= 128):
             raise RuntimeError("seed batching needs a fused path, no gradient hook, NUM_ENVS % 16 == 0, <= 128 seeds")
+        G = seed_groups_for(S) if groups is None else int(groups)
+        if G > 1:
+            return make_grouped_runner(rngs, G)
         if packed:
             layout = CnnKernelLayout(obs_shape[-1], A,
                                      matmul_f16=matmul_mode(config.get("MATMUL_DTYPE", "f32")))
@@ -856,10 +901,11 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         test_rows = torch.zeros((S, NUM_UPDATES, len(INFO_KEYS)), dtype=torch.float32, device=dev) if test_on else None
         counters = {"timesteps": 0, "n_updates": 0, "grad_steps": 0}
 
-        def update(u: int):
-            if u != drv.calls:
-                raise RuntimeError(f"update({u}) out of order: the device clock is at {drv.calls}")
-            drv.update()
+        def update(u: int, enqueue: bool = True):
+            if enqueue:     # (False: a SeedGroupsDriver already advanced this group's driver)
+                if u != drv.calls:
+                    raise RuntimeError(f"update({u}) out of order: the device clock is at {drv.calls}")
+                drv.update()
             counters["timesteps"] += T * N
             counters["n_updates"] += 1
             counters["grad_steps"] += MB * EPOCHS

@@ -491,6 +491,94 @@ class SeedsUpdateDriver:
     update = UpdateDriver.update
 
 
+class SeedGroupsDriver:
+    """G seed groups (one SeedsUpdateDriver each, CNN path) advanced together by pqn_cnn_update_seed_groups: the training
+    kernels of all groups back to back on the current stream, every group's HBM-bound tail (fc1 weight gradient, fold,
+    clip + RAdam) on a second stream under the NEXT group's training kernel.  The seeds of jax.vmap(make_train)
+    (pqn_minatar.py:459-461) are independent, so only the order in time changes: every seed keeps the bits of its
+    group's own pqn_cnn_update_seeds.  One hipGraph (two branches) per update by default.
+
+    tail: "graph" (default: capture + replay), "eager" (C++ enqueue on a high-priority tail stream), "masked:<lo>:<hi>" or
+    "maskmod:<m>:<r>" (eager, tail stream restricted to CUs [lo, hi) / to CUs with index % m == r, the compute stream to
+    the others -- measurement aid)."""
+
+    def __init__(self, drivers, tail: str = "graph"):
+        if any(d.mlp for d in drivers):
+            raise RuntimeError("SeedGroupsDriver: CNN path only")
+        self.drivers = list(drivers)
+        self.tail = tail
+        g = len(self.drivers)
+        self._args = (C.c_void_p * g)(*[C.addressof(d.args) for d in self.drivers])
+        self._seeds = (C.c_int32 * g)(*[d.s for d in self.drivers])
+        self._kr = (C.c_void_p * g)(*[_lib.ptr(d.key_roll) for d in self.drivers])
+        self._ks = (C.c_void_p * g)(*[_lib.ptr(d.key_shuf) for d in self.drivers])
+        self._ts = (C.c_int64 * g)(*[d.stride for d in self.drivers])
+        self._ws = (C.c_int64 * g)(*[d.ws_stride for d in self.drivers])
+        self.use_graph = tail == "graph" and all(d.use_graph for d in self.drivers)
+        self.graph, self.graph_error, self.calls = None, None, 0
+        self._raw = []          # raw hipStream_t handles made by pqn_stream_create_masked
+        self._compute_stream = None
+        lib = _lib.load()
+        if tail.startswith("mask"):
+            kind, lo, hi = tail.split(":")      # masked:<lo>:<hi> = CUs [lo, hi); maskmod:<m>:<r> = CUs with i % m == r
+            lo, hi = int(lo), int(hi)
+            ncu = torch.cuda.get_device_properties(self.drivers[0].theta.device).multi_processor_count
+            words = (ncu + 31) // 32
+            tm, cm = [0] * words, [0] * words
+            for i in range(ncu):
+                on_tail = (i % lo == hi) if kind == "maskmod" else (lo <= i < hi)
+                (tm if on_tail else cm)[i // 32] |= 1 << (i % 32)
+            self._compute_stream = self._make_raw((C.c_uint32 * words)(*cm), words, 0)
+            self._tail_ptr = self._make_raw((C.c_uint32 * words)(*tm), words, 0)
+            self._fork = torch.cuda.Event()
+        elif tail == "eager":
+            self._tail_ptr = self._make_raw(None, 0, 1)
+        else:
+            self._tail_stream = torch.cuda.Stream(priority=-1)
+            self._tail_ptr = self._tail_stream.cuda_stream
+
+    def _make_raw(self, mask, words, prio):
+        out = C.c_void_p(0)
+        _lib.check(_lib.load().pqn_stream_create_masked(mask, words, prio, C.byref(out)), "pqn_stream_create_masked")
+        self._raw.append(out.value)
+        return out.value
+
+    def close(self):
+        for h in self._raw:
+            _lib.load().pqn_stream_destroy(h)
+        self._raw = []
+
+    def _enqueue(self):
+        lib = _lib.load()
+        sc = _lib.stream_ptr()
+        if self._compute_stream is not None:
+            # the masked compute stream is a raw HIP stream torch does not know: order it behind / ahead of torch's current
+            # stream with a device-wide dependency through the legacy default stream semantics is not available, so fence
+            # with events recorded by torch and waited on in C++ is overkill for a measurement aid -- synchronise instead
+            torch.cuda.current_stream().synchronize()
+            sc = self._compute_stream
+        _lib.check(lib.pqn_cnn_update_seed_groups(len(self.drivers), self._args, self._seeds, self._kr, self._ks, self._ts,
+                                                  self._ws, sc, self._tail_ptr), "pqn_cnn_update_seed_groups")
+
+    def update(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+            if self.use_graph and self.calls == 0 and self.graph_error is None:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._enqueue()
+                    self.graph = g
+                except Exception as exc:  # stay on the eager C++ enqueue (still the HIP path)
+                    self.graph_error = repr(exc)
+                    torch.cuda.synchronize()
+        self.calls += 1
+        for d in self.drivers:
+            d.calls, d.graph, d.graph_error = self.calls, self.graph, self.graph_error
+
+
 # ---------------------------------------------------------------------------------------------------------
 # fused MLP Q-network (csrc/pqn_mlp.hip)
 # ---------------------------------------------------------------------------------------------------------

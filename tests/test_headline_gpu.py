@@ -130,6 +130,41 @@ def test_headline_16_seeds_bf16x3_bit_identical_to_solo_runs(gpu):
     assert not torch.equal(outs["metrics"]["td_loss"][0], outs["metrics"]["td_loss"][1])
 
 
+@pytest.mark.parametrize("tail", ["graph", "eager"])
+def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
+    """pqn_cnn_update_seed_groups (two groups of 8 seeds, the tails of one group on a second stream under the training
+    kernel of the other -- the default of the bench configuration) against ONE 16-seed batch through
+    pqn_cnn_update_seeds: every seed, every metric, parameters, optimizer state and env state bit for bit, as a replayed
+    two-branch hipGraph and as the eager two-stream enqueue.  (vmap over seeds, pqn_minatar.py:459-461.)"""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.pqn import make_train, seed_keys
+    keys = seed_keys(3, S)
+
+    def run(groups):
+        cfg = _cfg(3, SEED_GROUPS=groups, _SEED_GROUPS_TAIL=tail)
+        update, finish = make_train(cfg, device="cuda:0").make_batch_runner(keys)
+        for u in range(3):
+            update(u)
+        torch.cuda.synchronize()
+        return finish(), update.driver
+
+    one, d1 = run(1)
+    two, d2 = run(2)
+    assert _lib.last_kernel_form() == ("pair", "pair")
+    assert type(d2).__name__ == "SeedGroupsDriver" and len(d2.drivers) == 2 and type(d1).__name__ == "SeedsUpdateDriver"
+    assert two[0]["runner_state"]["seed_groups"] == 2 and two[0]["runner_state"]["seed_batch"] == S
+    if tail == "graph":
+        assert d2.graph is not None, d2.graph_error
+    else:
+        assert d2.graph is None
+    for s in range(S):
+        a, b = one[s], two[s]
+        for k in a["metrics"]:
+            assert torch.equal(a["metrics"][k], b["metrics"][k]), (s, k)
+        for k in ("theta", "opt_mu", "opt_nu", "env_state", "opt_count"):
+            assert torch.equal(a["runner_state"][k], b["runner_state"][k]), (s, k)
+
+
 def test_headline_whole_update_vs_oracle(gpu, oracle):
     """ONE whole update of the bench workload -- 16 seeds batched into the launches, bf16x3, pair rollout + pair training
     kernels -- against oracle.make_train, for seeds 0 / 7 / 15 (first, middle and last XCD group), from shared initial
