@@ -185,9 +185,9 @@ def main():
                     help="multi-GPU sharding: independent seeds per rank (no collective) or envs of one seed "
                          "(RCCL gradient all-reduce per optimizer step)")
     ap.add_argument("--seed-groups", type=int, default=0,
-                    help="seed groups per GPU (0 = the package's automatic choice: 2 for the 16-seed workload).  With G > 1 the "
+                    help="seed groups per GPU (0 / 1 = all seeds in one chain of launches, the default).  With G > 1 the "
                          "HBM-bound optimizer tail of one group runs on a second stream under the training kernel of the next "
-                         "(pqn_cnn_update_seed_groups); 1 = all seeds in one chain of launches (rounds 1-3)")
+                         "(pqn_cnn_update_seed_groups): measured slower, profiles/r04_v0_seed_groups_ab.txt")
     ap.add_argument("--groups-tail", default="graph",
                     help="graph (default: one two-branch hipGraph per update) | eager (C++ enqueue, high-priority tail stream) "
                          "| masked:<lo>:<hi> (eager, tail stream on CUs [lo, hi), training kernels on the rest)")

@@ -757,15 +757,16 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         return update, finish
 
     def seed_groups_for(S: int) -> int:
-        """How many seed groups a batch of S seeds is cut into (config SEED_GROUPS; 0 / absent = automatic).  Two groups
-        let one group's HBM-bound optimizer tail run under the other group's compute-bound training kernel
-        (qnet.SeedGroupsDriver); taken automatically when both halves still fill the chip with pair-form workgroups."""
+        """How many seed groups a batch of S seeds is cut into (config SEED_GROUPS, else PQN_SEED_GROUPS; default 1).
+        With G > 1 one group's HBM-bound optimizer tail runs on a second stream under the next group's compute-bound
+        training kernel (qnet.SeedGroupsDriver).  Opt-in: measured SLOWER on the bench workload (2 x 8 seeds: 51.3 ms per
+        update as one two-branch hipGraph, 48.1 ms as eager streams, against 44.1 ms for one 16-seed chain of launches;
+        profiles/r04_v0_seed_groups_ab.txt) -- the training kernel's workgroups hold every CU's LDS and registers for
+        ~54 us each, so the tail kernels wait for CUs instead of running beside it, and their traffic evicts the weight
+        planes from the L2s."""
         g = int(config.get("SEED_GROUPS", 0) or 0)
         if g <= 0:
             g = int(os.environ.get("PQN_SEED_GROUPS", "0") or 0)
-        if g <= 0:
-            mbs = (T * N) // MB
-            g = 2 if (packed and S % 2 == 0 and (mbs // 32) * (S // 2) >= 256 and config.get("_GRAPH", True)) else 1
         if not packed or g < 1 or S % g != 0 or g > 8:
             g = 1
         return g

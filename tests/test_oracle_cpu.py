@@ -265,6 +265,87 @@ def test_oracle_radam_matches_formula(oracle):
     assert ro_inf - 2 * 5 * b2 ** 5 / (1 - b2 ** 5) < 5.0 <= ro_inf - 2 * 6 * b2 ** 6 / (1 - b2 ** 6)
 
 
+def _torch_radam_reference(p0, grads, lr, max_norm=None):
+    """torch.optim.RAdam (an independent implementation of Liu et al. 2020, the algorithm optax.radam implements) fed the
+    same gradients; optax.clip_by_global_norm restated as its two lines (g if norm < max else g / norm * max)."""
+    pt = torch.nn.Parameter(torch.from_numpy(p0.astype(np.float64)))
+    opt = torch.optim.RAdam([pt], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    out = []
+    for g in grads:
+        g64 = torch.from_numpy(g.astype(np.float64))
+        if max_norm is not None:
+            norm = g64.norm()
+            if not norm < max_norm:
+                g64 = g64 / norm * max_norm
+        pt.grad = g64
+        opt.step()
+        out.append(pt.detach().numpy().copy())
+    return out
+
+
+def test_oracle_radam_vs_torch_optim_radam(oracle):
+    """pqn_oracle_radam_clip_step (optax.chain(clip_by_global_norm, radam), pqn_minatar.py:159-162) against
+    torch.optim.RAdam over 200 steps, through the rho <= 5 warm-up (SGD-with-momentum steps 1-5) into the rectified
+    branch.  The two libraries differ only in where eps enters -- optax: r m_hat / (sqrt(v_hat) + eps); torch:
+    r m_hat sqrt(bc2) / (sqrt(v) + eps) = r m_hat / (sqrt(v_hat) + eps / sqrt(bc2)) -- i.e. by <= eps / sqrt(v_hat)
+    relative (1e-5 for |g| ~ 1e-2 at step 6, shrinking with bc2 -> 1), and torch rectifies for rho > 5 where optax
+    takes rho >= 5 (rho_5 = 4.99, rho_6 = 5.98: the same steps).  An independent witness of the published algorithm,
+    not a reference golden."""
+    rng = np.random.default_rng(11)
+    n, steps, lr = 4096, 200, 5e-4
+    p0 = rng.standard_normal(n).astype(np.float32)
+    grads = [(rng.standard_normal(n) * (0.3 if t % 7 else 3.0) * np.exp(-t / 120.0)).astype(np.float32) for t in range(steps)]
+    for max_norm in (1e9, 10.0):           # never clipped / clipped on the large-gradient steps
+        p, m, v = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        ref = _torch_radam_reference(p0, grads, lr, max_norm)
+        clipped = 0
+        for t, g in enumerate(grads):
+            gn = oracle.radam_clip_step(p, g, m, v, t, np.float32(lr), max_norm)
+            clipped += int(not gn < max_norm)
+            # one step moves an element by <= ~lr; the eps placement shifts that by <= 1e-5 relative: atol = a few % of
+            # ONE f32 rounding of p plus the accumulated step difference
+            np.testing.assert_allclose(p, ref[t], rtol=0, atol=2e-7 + 2e-5 * lr * (t + 1), err_msg=f"step {t}")
+        assert (clipped > 20) == (max_norm == 10.0)
+    # warm-up really is the unrectified branch in both: after 5 steps p moved by lr * sum of bias-corrected momenta
+    m64, acc = np.zeros(n), np.zeros(n)
+    for t in range(5):
+        m64 = 0.9 * m64 + 0.1 * grads[t].astype(np.float64)
+        acc += m64 / (1 - 0.9 ** (t + 1))
+    np.testing.assert_allclose(_torch_radam_reference(p0, grads[:5], lr)[-1], p0 - lr * acc, rtol=0, atol=1e-9)
+
+
+def test_oracle_layernorm_and_conv_vs_torch_functional(oracle):
+    """The oracle's LayerNorm (flax: eps 1e-6 inside the rsqrt, fast variance) and its 3x3 VALID NHWC convolution with an
+    HWIO kernel (nn.Conv(16, (3, 3), padding="VALID"), pqn_minatar.py:28-36) against torch.nn.functional.layer_norm /
+    conv2d, forward and input / parameter gradients -- library implementations this build did not write."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((64, 8, 8, 16)).astype(np.float32) * 3 + 1
+    sc, bi = rng.standard_normal(16).astype(np.float32), rng.standard_normal(16).astype(np.float32)
+    y, cache = oracle._ln_fwd(x, sc, bi)
+    xt, st, bt = (torch.from_numpy(a.copy()).requires_grad_(True) for a in (x, sc, bi))
+    yt = F.layer_norm(xt, (16,), st, bt, 1e-6)
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-5, atol=2e-6)
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    yt.backward(torch.from_numpy(dy))
+    dx, dsc, dbi = oracle._ln_bwd(dy, sc, cache)
+    np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dsc, st.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(dbi, bt.grad.numpy(), rtol=2e-4, atol=2e-4)
+    for c in (4, 6, 7, 10):
+        obs = (rng.random((32, 10, 10, c)) < 0.2).astype(np.float32)
+        k = (rng.standard_normal((3, 3, c, 16)) * 0.2).astype(np.float32)          # flax HWIO
+        b = rng.standard_normal(16).astype(np.float32)
+        out = oracle._patches(np.ascontiguousarray(obs)) @ k.reshape(-1, 16) + b    # the oracle's conv (net_forward)
+        kt = torch.from_numpy(k.copy()).requires_grad_(True)
+        ot = F.conv2d(torch.from_numpy(obs).permute(0, 3, 1, 2), kt.permute(3, 2, 0, 1), torch.from_numpy(b)).permute(0, 2, 3, 1)
+        np.testing.assert_allclose(out, ot.detach().numpy(), rtol=1e-5, atol=1e-5)
+        d = rng.standard_normal(out.shape).astype(np.float32)
+        ot.backward(torch.from_numpy(d))
+        dk = oracle._patches(np.ascontiguousarray(obs)).reshape(-1, 9 * c).T @ d.reshape(-1, 16)   # _net_backward's wgrad
+        np.testing.assert_allclose(dk.reshape(3, 3, c, 16), kt.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
 def test_oracle_regression_pins():
     """The oracle's outputs on seeded inputs still hash to the committed digests (tests/golden/regression_pins.json):
     env rules + RNG streams of all five envs, eps-greedy, shuffle, Q(lambda) both forms, fold_in.  Self-regression
