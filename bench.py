@@ -43,49 +43,46 @@ def workload_config(num_envs: int, mode: str):
 
 
 def cpu_baseline(cfg, theta0):
-    """The CPU oracle (numpy/C restatement, kind="port") on a bounded sample of the SAME workload shape: ONE whole
-    update (rollout + Q(lambda) + NUM_EPOCHS x NUM_MINIBATCHES optimizer steps) of one seed at NUM_ENVS = the bench's
-    own NUM_ENVS (4096: ~30 s on the GPU box's host cores), after a tiny untimed run that loads the libraries and
-    spins up the BLAS / OpenMP pools."""
+    """The CPU path beside the GPU number (kind = "port"): the oracle loop -- C/OpenMP env step + LogWrapper
+    + eps-greedy + Q(lambda) + shuffle + optax-exact clip/RAdam -- with the Q-network on torch-CPU over EVERY host core
+    (oracle/pqn_cpu_torch.py; held to the numpy oracle loop by tests/test_oracle_cpu.py), at the bench's own shape
+    (NUM_ENVS = 4096, one seed): one untimed update (library load, thread pools, first-touch of the full-size buffers), then
+    whole updates until >= 3 are timed and ~20 s have passed (at most 8).  The reference's JAX-CPU path cannot run here
+    (no jax in the image): this is the same algorithm, not the same library."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import pqn_oracle as oracle
+    import pqn_cpu_torch as cpu_loop
     ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
-    t = int(ocfg["NUM_STEPS"])
-    sample_envs, timed = int(cfg["NUM_ENVS"]), 1
-    # threads actually used: numpy's BLAS pool (the network, most of the time) and OpenMP (C env step)
+    t, n_envs = int(ocfg["NUM_STEPS"]), int(cfg["NUM_ENVS"])
+    ocfg["TOTAL_TIMESTEPS"] = ocfg["TOTAL_TIMESTEPS_DECAY"] = 1e7
+    threads = os.cpu_count() or 1
+    train = cpu_loop.make_train(ocfg, threads=threads)
+    out = train(12345, theta0, max_updates=9, time_budget=20.0, min_updates=4)
+    secs = out["seconds_per_update"][1:]                    # the first update is the warm-up
+    dt = float(sum(secs))
     try:
         from threadpoolctl import threadpool_info
-        pools = threadpool_info()
-        cores = max([p.get("num_threads", 1) for p in pools] + [1])
-        pool_desc = ", ".join(f"{p.get('internal_api')}:{p.get('num_threads')}" for p in pools)
+        pool_desc = ", ".join(f"{p.get('internal_api')}:{p.get('num_threads')}" for p in threadpool_info())
     except Exception:
-        cores, pool_desc = os.cpu_count() or 1, "unknown"
-    ocfg["TOTAL_TIMESTEPS"] = ocfg["TOTAL_TIMESTEPS_DECAY"] = 1e7
-    wcfg = dict(ocfg, NUM_ENVS=64, NUM_MINIBATCHES=4)
-    oracle.make_train(wcfg)(1, theta0, max_updates=1)            # untimed: library load, thread pools
-    ocfg["NUM_ENVS"] = sample_envs
-    train = oracle.make_train(ocfg)
-    t0 = time.perf_counter()
-    train(12345, theta0, max_updates=timed)
-    dt = time.perf_counter() - t0
+        pool_desc = "unknown"
     # env-only rate (uniform-random actions, no network): the C oracle's OpenMP env.step + auto-reset + LogWrapper
     env = oracle.OracleEnv(ocfg["ENV_NAME"])
-    n_env_only = int(cfg["NUM_ENVS"])
-    _obs, st = env.reset(1, n_env_only)
+    _obs, st = env.reset(1, n_envs)
     rng = np.random.default_rng(0)
-    acts = rng.integers(0, env.num_actions, size=(50, n_env_only)).astype(np.int32)
+    acts = rng.integers(0, env.num_actions, size=(50, n_envs)).astype(np.int32)
     env.step(2, st, acts[0])
     t1 = time.perf_counter()
     for i in range(50):
         _o, st, _r, _d, _info = env.step(100 + i, st, acts[i])
-    env_only = 50 * n_env_only / (time.perf_counter() - t1)
-    return {"value": timed * sample_envs * t / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "env_only_env_steps_per_s": env_only,
-            "sample": f"{timed} timed full PQN update (rollout+Q(lambda)+{ocfg['NUM_EPOCHS']}x{ocfg['NUM_MINIBATCHES']} SGD steps) of ONE "
-                      f"seed at NUM_ENVS={sample_envs}, NUM_STEPS={t} (the bench shape): {timed * sample_envs * t} env-steps in {dt:.1f}s, "
-                      "after an untimed 64-env update; oracle/pqn_oracle.py (C env/eps-greedy/Q(lambda)/RAdam + numpy-BLAS "
-                      f"network), not JAX; host has {os.cpu_count()} logical cores, thread pools: {pool_desc}"}
+    env_only = 50 * n_envs / (time.perf_counter() - t1)
+    return {"value": len(secs) * n_envs * t / dt, "unit": "env-steps/s", "cores": out["threads"], "kind": "port",
+            "env_only_env_steps_per_s": env_only, "updates_timed": len(secs), "seconds_per_update": [round(x, 3) for x in secs],
+            "sample": f"{len(secs)} timed full PQN updates (rollout+Q(lambda)+{ocfg['NUM_EPOCHS']}x{ocfg['NUM_MINIBATCHES']} SGD steps) of ONE "
+                      f"seed at NUM_ENVS={n_envs}, NUM_STEPS={t} (the bench shape): {len(secs) * n_envs * t} env-steps in {dt:.1f}s, after one "
+                      "untimed update of the same shape; oracle/pqn_cpu_torch.py = C/OpenMP env + eps-greedy + Q(lambda) + RAdam of the "
+                      f"oracle, Q-network forward/backward on torch-CPU with torch.set_num_threads({out['threads']}) = os.cpu_count(); "
+                      f"not JAX; thread pools: {pool_desc}"}
 
 
 def timed_updates(update, steps, warmup, first=0, barrier=None):

@@ -87,6 +87,7 @@ enum {
   PQN_OPT_T1_KSPLIT,      // PQN_T1_KSPLIT: K-split form of the f32-mode training kernel for minibatches <= 256 samples (default 1)
   PQN_OPT_T1_KSPLIT_TILES, // PQN_T1_KSPLIT_TILES: the K-split form is taken while tiles x seeds of the launch stay at or below this (default 48)
   PQN_OPT_BM_OVERLAP,     // PQN_BM_OVERLAP: parameter-gradient side of the wide-MLP backward on a second stream (default 0: measured no gain)
+  PQN_OPT_T2_ACC,         // PQN_T2_ACC: bf16x3 fc1 weight gradient without split-K partials 0 never / 1 when row blocks x seeds fill the chip / 2 always
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);

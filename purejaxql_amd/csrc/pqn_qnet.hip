@@ -166,6 +166,70 @@ PQN_D f32x4 x3_mfma_tied(const u32x4 &a, const u32x4 &b, f32x4 c) {
   return c;
 }
 #define X3_MFMA(A, B, C) x3_mfma_tied(A, B, C)
+// GROUPS of independent MFMAs (different accumulators) as ONE asm statement with ONE leading `s_nop 1` (round 4).  The pad
+// in front of a single MFMA covers a VALU write of one of its operands in the preceding issue slots -- the compiler cannot
+// see inside the asm string and schedules its own VALU instructions between the statements -- but inside a run of MFMAs
+// it is pure cost: MI355X_MICROARCH.md prices one extra issue state between MFMAs at ~6 cycles (different accumulators)
+// against the ~16 cycles the MFMA itself occupies the pipe.  Inside a group nothing can be scheduled between the MFMAs, so
+// only the first needs the pad; instruction order, operands and therefore results are unchanged.
+#ifdef X3_NO_GROUP   // A/B hook: one statement (and one pad) per MFMA, as in rounds 2-3
+PQN_D void x3_grp2(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
+  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1);
+}
+PQN_D void x3_grp4(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
+  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1); c2 = x3_mfma_tied(a2, b2, c2); c3 = x3_mfma_tied(a3, b3, c3);
+}
+PQN_D void x3_grp6(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3, f32x4 &c4, const u32x4 &a4,
+                   const u32x4 &b4, f32x4 &c5, const u32x4 &a5, const u32x4 &b5) {
+  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1); c2 = x3_mfma_tied(a2, b2, c2); c3 = x3_mfma_tied(a3, b3, c3);
+  c4 = x3_mfma_tied(a4, b4, c4); c5 = x3_mfma_tied(a5, b5, c5);
+}
+#else
+PQN_D void x3_grp2(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\t"
+               "v_mfma_f32_16x16x32_bf16 %1, %4, %5, %1"
+               : "+v"(c0), "+v"(c1)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+PQN_D void x3_grp4(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n\t"
+               "v_mfma_f32_16x16x32_bf16 %1, %6, %7, %1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %2, %8, %9, %2\n\t"
+               "v_mfma_f32_16x16x32_bf16 %3, %10, %11, %3"
+               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+}
+PQN_D void x3_grp6(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3, f32x4 &c4, const u32x4 &a4,
+                   const u32x4 &b4, f32x4 &c5, const u32x4 &a5, const u32x4 &b5) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %0, %6, %7, %0\n\t"
+               "v_mfma_f32_16x16x32_bf16 %1, %8, %9, %1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %2, %10, %11, %2\n\t"
+               "v_mfma_f32_16x16x32_bf16 %3, %12, %13, %3\n\t"
+               "v_mfma_f32_16x16x32_bf16 %4, %14, %15, %4\n\t"
+               "v_mfma_f32_16x16x32_bf16 %5, %16, %17, %5"
+               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
+}
+#endif
+// N MFMAs sharing the B operand (N row blocks against one fragment): grouped for the N the kernels use
+template <int N>
+PQN_D void x3_grp_sameb(f32x4 (&c)[N], const u32x4 (&a)[N], const u32x4 &b) {
+  if constexpr (N == 2) x3_grp2(c[0], a[0], b, c[1], a[1], b);
+  else if constexpr (N == 3) { x3_grp2(c[0], a[0], b, c[1], a[1], b); c[2] = x3_mfma_tied(a[2], b, c[2]); }
+  else if constexpr (N == 4) x3_grp4(c[0], a[0], b, c[1], a[1], b, c[2], a[2], b, c[3], a[3], b);
+  else if constexpr (N == 6) x3_grp6(c[0], a[0], b, c[1], a[1], b, c[2], a[2], b, c[3], a[3], b, c[4], a[4], b, c[5], a[5], b);
+  else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) c[j] = x3_mfma_tied(a[j], b, c[j]);
+  }
+}
 // end of an accumulation chain: 16 wait states (an MFMA result may not be read by anything but a tied MFMA earlier)
 PQN_D void x3_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a)); }
 PQN_D void x3_drain(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b)); }
@@ -313,12 +377,9 @@ struct ConvX3 {
     for (int t = 0; t < 4; ++t) { ab[t] = f32x4{0.f, 0.f, 0.f, 0.f}; as[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) as[t] = X3_MFMA(fa[t][s], w[s].l, as[t]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) ab[t] = X3_MFMA(fa[t][s], w[s].h, ab[t]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) as[t] = X3_MFMA(fa[t][s], w[s].m, as[t]);
+      x3_grp4(as[0], fa[0][s], w[s].l, as[1], fa[1][s], w[s].l, as[2], fa[2][s], w[s].l, as[3], fa[3][s], w[s].l);
+      x3_grp4(ab[0], fa[0][s], w[s].h, ab[1], fa[1][s], w[s].h, ab[2], fa[2][s], w[s].h, ab[3], fa[3][s], w[s].h);
+      x3_grp4(as[0], fa[0][s], w[s].m, as[1], fa[1][s], w[s].m, as[2], fa[2][s], w[s].m, as[3], fa[3][s], w[s].m);
     }
     x3_drain(ab[0], ab[1], ab[2], ab[3]);
     x3_drain(as[0], as[1], as[2], as[3]);
@@ -659,9 +720,12 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
       for (int k = 0; k < NK; ++k) { acc_b[t][c][k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_s[t][c][k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   auto step_mfma = [&](const X3Frag (&af)[NT], const X3Frag (&bq)[2]) {
     // products in the order (l,h) (m,h) (h,l) (h,m) (m,m) (h,h): small and leading terms alternate
-#define FC1_PROD(AP, BP, ACC, K)                                                          \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                         \
-      _Pragma("unroll") for (int c = 0; c < 2; ++c) ACC[t][c][K] = X3_MFMA(af[t].AP, bq[c].BP, ACC[t][c][K]);
+#define FC1_PROD(AP, BP, ACC, K)                                                                                           \
+    if constexpr (NT == 2)                                                                                                  \
+      x3_grp4(ACC[0][0][K], af[0].AP, bq[0].BP, ACC[0][1][K], af[0].AP, bq[1].BP, ACC[NT - 1][0][K], af[NT - 1].AP, bq[0].BP, \
+              ACC[NT - 1][1][K], af[NT - 1].AP, bq[1].BP);                                                                  \
+    else                                                                                                                    \
+      x3_grp2(ACC[0][0][K], af[0].AP, bq[0].BP, ACC[0][1][K], af[0].AP, bq[1].BP);
     FC1_PROD(l, h, acc_s, 0)
     FC1_PROD(m, h, acc_b, 0)
     FC1_PROD(h, l, acc_s, NK - 1)
@@ -1089,14 +1153,29 @@ __host__ __device__ inline size_t h1s_index(int i, int b) {
   return ((((size_t)(b >> 8) * 16 + (i >> 6)) * 8 + ((b >> 5) & 7)) * 64 + (i & 63)) * 32 + (b & 31);
 }
 
+__host__ __device__ inline int small_record_floats(int c, int a) { return 9 * c * 16 + 48 + 384 + 128 * a + a + 2; }
+// bf16x3 mode: dz is handed from T1 to T2 as three bf16 planes, already split, in the B-fragment order T2's MFMAs read:
+//   dzw[plane][slab ks][column block cb][step u][lane = kg * 16 + (o & 15)][8]  -- slot j of the 8 = sample
+//   256 ks + 32 u + 16 (j >> 2) + 4 kg + (j & 3), output o = 16 cb + (o & 15); one dwordx4 per lane = one operand.
+// Plane stride = slabs * 256 * 128 elements.  The region sits behind the split-K slabs of the workspace; every kernel
+// derives it from the dz^T pointer (workspace carve-up of launch_train).
+__host__ __device__ inline int qw_slabs(int nb) { return (nb + 255) / 256; }
+__host__ __device__ inline size_t qw_dzw_offset(int nb, int c, int a) {   // floats from dzT to the planes
+  return (size_t)QN_HID * qw_ld(nb) + (size_t)QN_H1 * qw_h1_cols(nb) + (size_t)(nb / QN_TILE) * small_record_floats(c, a) +
+         (size_t)qw_slabs(nb) * QN_H1 * QN_HID;
+}
+__host__ __device__ inline size_t qw_dzw_floats(int nb) { return (size_t)qw_slabs(nb) * 256 * QN_HID * 3 / 2; }
+PQN_HD size_t dzw_index(int b, int o) {   // element offset of (sample b, output o) inside one plane
+  const int ks = b >> 8, u = (b >> 5) & 7, hf = (b >> 4) & 1, kg = (b >> 2) & 3;
+  return (((((size_t)ks * 8 + (o >> 4)) * 8 + u) * 64 + kg * 16 + (o & 15)) << 3) + 4 * hf + (b & 3);
+}
+
 template <int C>
 struct TrainCfg {
   using Cfg = CnnCfg<C>;
   static constexpr int CONVBLK = Cfg::KW * 16 + 48;
   static constexpr int SCR = (3 * QN_TILE * QN_ZS > Cfg::KW * 64) ? 3 * QN_TILE * QN_ZS : Cfg::KW * 64;
 };
-
-__host__ __device__ inline int small_record_floats(int c, int a) { return 9 * c * 16 + 48 + 384 + 128 * a + a + 2; }
 
 struct TrainSmem {
   CnnSmem n;
@@ -1339,6 +1418,21 @@ PQN_D void train_head_nt(const CnnSmem (&sv)[NT], const TrainSmem (&tv)[NT], con
         *reinterpret_cast<u2 *>(pb + 512) = u2{mm[0], mm[1]};
         *reinterpret_cast<u2 *>(pb + 1024) = u2{ll[0], ll[1]};
       }
+    } else if (L.matmul_f16 == 2) {
+      // bf16x3: dz leaves already split, in T2's operand order (dzw_index): T2 loads its B fragments with no arithmetic
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      unsigned short *dzw = reinterpret_cast<unsigned short *>(dzT + qw_dzw_offset(nb, C, L.a));
+      const size_t ps = (size_t)qw_slabs(nb) * 256 * QN_HID;
+      for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
+        const int o = i >> 2, mq = i & 3;
+        unsigned hh[2], mm[2], ll[2];
+        x3_split2(s.z[(4 * mq + 0) * QN_ZS + o], s.z[(4 * mq + 1) * QN_ZS + o], hh[0], mm[0], ll[0]);
+        x3_split2(s.z[(4 * mq + 2) * QN_ZS + o], s.z[(4 * mq + 3) * QN_ZS + o], hh[1], mm[1], ll[1]);
+        unsigned short *pw = dzw + dzw_index(b0 + 4 * mq, o);
+        __builtin_nontemporal_store(u2{hh[0], hh[1]}, reinterpret_cast<u2 *>(pw));
+        __builtin_nontemporal_store(u2{mm[0], mm[1]}, reinterpret_cast<u2 *>(pw + ps));
+        __builtin_nontemporal_store(u2{ll[0], ll[1]}, reinterpret_cast<u2 *>(pw + 2 * ps));
+      }
     } else
     for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
       const int o = i >> 2, mq = i & 3;
@@ -1429,12 +1523,7 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
         X3Frag bf;
         bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
         const X3Frag &a = afr[sK];
-        acc_s[0] = X3_MFMA(a.l, bf.h, acc_s[0]);
-        acc_b[0] = X3_MFMA(a.m, bf.h, acc_b[0]);
-        acc_s[1] = X3_MFMA(a.h, bf.l, acc_s[1]);
-        acc_b[1] = X3_MFMA(a.h, bf.m, acc_b[1]);
-        acc_c[0] = X3_MFMA(a.m, bf.m, acc_c[0]);
-        acc_c[1] = X3_MFMA(a.h, bf.h, acc_c[1]);
+        x3_grp6(acc_s[0], a.l, bf.h, acc_b[0], a.m, bf.h, acc_s[1], a.h, bf.l, acc_b[1], a.h, bf.m, acc_c[0], a.m, bf.m, acc_c[1], a.h, bf.h);
         if (more) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, ibk + 1, sK);
@@ -1600,12 +1689,9 @@ PQN_D void t1_conv_wgrad_2r(const float *dx, const uint32_t *bits, uint32_t *wm_
         }
         af[j] = u32x4{d[0], d[1], d[2], d[3]};
       }
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) accs[j] = X3_MFMA(af[j], bf.l, accs[j]);
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) acc[j] = X3_MFMA(af[j], bf.h, acc[j]);
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) accs[j] = X3_MFMA(af[j], bf.m, accs[j]);
+      x3_grp_sameb<NRB>(accs, af, bf.l);
+      x3_grp_sameb<NRB>(acc, af, bf.h);
+      x3_grp_sameb<NRB>(accs, af, bf.m);
     }
   }
 #pragma unroll
@@ -1728,12 +1814,7 @@ PQN_D void t1_dgrad_pair2_x3(const float *ztA, float *outA, const u32x4 *planesB
         X3Frag bf;
         bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
         const X3Frag &a = afr[sK];
-        acc_s[0] = X3_MFMA(a.l, bf.h, acc_s[0]);
-        acc_b[0] = X3_MFMA(a.m, bf.h, acc_b[0]);
-        acc_s[1] = X3_MFMA(a.h, bf.l, acc_s[1]);
-        acc_b[1] = X3_MFMA(a.h, bf.m, acc_b[1]);
-        acc_c[0] = X3_MFMA(a.m, bf.m, acc_c[0]);
-        acc_c[1] = X3_MFMA(a.h, bf.h, acc_c[1]);
+        x3_grp6(acc_s[0], a.l, bf.h, acc_b[0], a.m, bf.h, acc_s[1], a.h, bf.l, acc_b[1], a.h, bf.m, acc_c[0], a.m, bf.m, acc_c[1], a.h, bf.h);
         __builtin_amdgcn_sched_barrier(0);
       }
       x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
@@ -1754,12 +1835,7 @@ PQN_D void t1_dgrad_pair2_x3(const float *ztA, float *outA, const u32x4 *planesB
         const X3Frag a = bq;
         if (sK + 1 < 4) bq = bfrag(sK + 1);
         __builtin_amdgcn_sched_barrier(0);
-        acc_s[0] = X3_MFMA(a.l, bf.h, acc_s[0]);
-        acc_b[0] = X3_MFMA(a.m, bf.h, acc_b[0]);
-        acc_s[1] = X3_MFMA(a.h, bf.l, acc_s[1]);
-        acc_b[1] = X3_MFMA(a.h, bf.m, acc_b[1]);
-        acc_c[0] = X3_MFMA(a.m, bf.m, acc_c[0]);
-        acc_c[1] = X3_MFMA(a.h, bf.h, acc_c[1]);
+        x3_grp6(acc_s[0], a.l, bf.h, acc_b[0], a.m, bf.h, acc_s[1], a.h, bf.l, acc_b[1], a.h, bf.m, acc_c[0], a.m, bf.m, acc_c[1], a.h, bf.h);
         if (more) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, ibk + 1, sK);
@@ -1926,12 +2002,9 @@ PQN_D void t1_conv_wgrad(const float *dx, const uint32_t *bits, uint32_t *wm_bas
             af[j] = u32x4{d[0], d[1], d[2], d[3]};
           }
           // {h plane} and {m + l planes} accumulate separately: 2 RBW independent chains (see phase2_fc1_x3)
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) accs[j] = X3_MFMA(af[j], bf.l, accs[j]);
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) acc[j] = X3_MFMA(af[j], bf.h, acc[j]);
-#pragma unroll
-          for (int j = 0; j < RBW; ++j) accs[j] = X3_MFMA(af[j], bf.m, accs[j]);
+          x3_grp_sameb<RBW>(accs, af, bf.l);
+          x3_grp_sameb<RBW>(acc, af, bf.h);
+          x3_grp_sameb<RBW>(accs, af, bf.m);
         }
       }
 #pragma unroll
@@ -3535,58 +3608,84 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_kernel(int nb, cons
 #define QY_APL (64 * 64)                     // one A plane: 64 rows x 32 bf16
 #define QY_ABUF (3 * QY_APL)                 // 12,288 B
 #define QY_LDS (8 * QY_ABUF)                  // 98,304 B (dynamic LDS)
+#define QY_LDS_ACC (QY_LDS + 4 * 16 * QN_THREADS)   // + the running sums of the ACC form
 static_assert(QY_SLAB == 256, "8 steps of 32 samples");
 PQN_D int qy_swz(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
+// Round 4: dz arrives as bf16 planes in B-fragment order (dzw_index; split once by T1's head), so the fragments are
+// plain dwordx4 loads.  Two forms of one body:
+//   ACC = false  workgroup = (group of G row blocks, slab ks, seed): dz of ONE slab resident, walks over G row blocks and
+//                writes a partial tile per row block into split-K slab ks (folded in slab order by qnet_grad_reduce_kernel);
+//   ACC = true   workgroup = (row block it, seed), walks over ALL slabs: per slab a partial tile P_ks from zero, then
+//                tot += P_ks in slab order -- the very sum the reduction forms from the partial slabs, bit for bit -- and
+//                writes tot into slab 0 ONCE: no split-K partials in HBM at all (16 seeds x 4096 samples: 134 MB written
+//                + 134 MB re-read per optimizer step before).  The dz fragments of step u are re-loaded IN PLACE for the
+//                next slab right behind the step's last MFMA (8 steps of latency cover).  Taken when row blocks x seeds
+//                fill the chip (launch_train).
+#ifndef T2_ABL
+#define T2_ABL 0   // profiling builds only (-DT2_ABL=mask): 1 no MFMAs, 2 no operand split in stage_a, 4 no dz reload, 8 no LDS fragment reads, 16 no barrier
+#endif
+template <bool ACC>
 __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, const float *__restrict__ h1T,
-                                                                       const float *__restrict__ dzT,
+                                                                       const unsigned short *__restrict__ dzw,
                                                                        float *__restrict__ wpart, long long ws_stride,
                                                                        int G, unsigned long long *__restrict__ stamps) {
 #define T2_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) stamps[k] = __builtin_readcyclecounter(); } while (0)
   static_assert(QN_WAVES == 8, "one column block per wave");
   extern __shared__ __attribute__((aligned(16))) char abuf[];   // QY_LDS: two groups x four step tiles
   T2_STAMP(0);
-  h1T += blockIdx.z * ws_stride;   // seed slice
-  dzT += blockIdx.z * ws_stride;
-  wpart += blockIdx.z * ws_stride;
+  // ACC: XCD-aware (seed, row block).  Workgroups go to the 8 XCDs round-robin in dispatch order; when the seeds divide
+  // over the XCDs, XCD k runs all 16 row blocks of seeds [k S/8, (k+1) S/8): a seed's dz planes (3 MB, read by each of its
+  // 16 workgroups) then cross ONE L2 instead of eight.
+  int seed = blockIdx.z, it0 = blockIdx.x * G, ks0 = blockIdx.y;
+  if (ACC) {
+    it0 = blockIdx.x;
+    ks0 = 0;
+    if ((gridDim.z & 7) == 0) {
+      const unsigned lin = blockIdx.z * gridDim.x + blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
+      seed = xcd * (gridDim.z >> 3) + slot / gridDim.x;
+      it0 = slot % gridDim.x;
+    }
+  }
+  h1T += seed * ws_stride;   // seed slice
+  dzw += 2 * seed * ws_stride;
+  wpart += seed * ws_stride;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int it0 = blockIdx.x * G, ks = blockIdx.y;
   const int r = lane & 15, kg = lane >> 4;
-  const int c0 = ks * QY_SLAB;
-  const int ld = qw_ld(nb);
+  const int nks = qw_slabs(nb);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  constexpr int NST = QY_SLAB / QY_KS;   // 8 steps per row block = the prefetch distance
+  constexpr int NST = QY_SLAB / QY_KS;   // 8 steps per (row block, slab) = the prefetch distance
+  const int NQ = ACC ? nks : G;          // outer iterations: slabs (ACC) or row blocks
   // h1T loader: thread -> (row, 4 consecutive samples) of the 64 x 32 step tile
   const int arow = tid >> 3, q8 = tid & 7;
-  const int a_col = c0 + 4 * q8;
   const int a_dst = arow * 64 + (((q8 & 3) ^ qy_swz(arow)) << 4) + ((q8 >> 2) << 3);
-  // Every prefetch is UNCONDITIONAL (row block and column clamped into range, the value masked when it is consumed):
+  // Every prefetch is UNCONDITIONAL (row block / slab clamped into range, the value masked when it is consumed):
   // a load under a condition, or a select right behind it, makes the compiler drain the whole queue
   // (s_waitcnt vmcnt(0)) at every step, which serialises the HBM round trips.
-  auto fetch = [&](int itn, int u) -> f32x4 {   // h1 slab-major (h1s_index): step tile = 8 KB contiguous, 16 B per thread
-    // (streaming loads measured: T2 itself unchanged, the reduction behind it 30.2 -> 28.9 us -- profiles/r03_v4_ln0ns_ab.txt)
-    return *reinterpret_cast<const f32x4 *>(h1T + ((((size_t)ks * 16 + it0 + min(itn, G - 1)) * 8 + u) * 2048 + 4 * tid));
+  auto fetch = [&](int qn, int u) -> f32x4 {   // h1 slab-major (h1s_index): step tile = 8 KB contiguous, 16 B per thread
+    const int qc = min(qn, NQ - 1);
+    const size_t ks = ACC ? qc : ks0, it = ACC ? it0 : it0 + qc;
+    return *reinterpret_cast<const f32x4 *>(h1T + (((ks * 16 + it) * 8 + u) * 2048 + 4 * tid));
   };
-  auto masked = [&](const f32x4 &v, int u) -> f32x4 { return (a_col + QY_KS * u < nb) ? v : zero4; };
+  // samples past nb (ragged last slab): h1 masked to zero here; the dz planes of that range are zeroed by the host
+  auto masked = [&](const f32x4 &v, int qn, int u) -> f32x4 {
+    const int ks = ACC ? min(qn, NQ - 1) : ks0;
+    return (ks * QY_SLAB + 4 * q8 + QY_KS * u < nb) ? v : zero4;
+  };
   f32x4 pre[NST];
 #pragma unroll
   for (int u = 0; u < NST; ++u) pre[u] = fetch(0, u);
-  // the wave's dz fragments for the whole slab: row o = 16 wave + r, samples c0 + 32 u + {4 kg .. +3, 16 + 4 kg .. +3}
+  // the wave's dz fragments of one slab: column block `wave`, 8 steps x 3 planes x one dwordx4 (96 VGPRs)
+  const u32x4 *dzq = reinterpret_cast<const u32x4 *>(dzw);
+  const size_t psq = (size_t)nks * (QY_SLAB * QN_HID / 8);   // plane stride in dwordx4
+  auto dz_frag = [&](int ks, int u) -> X3Frag {
+    const size_t e = (((size_t)ks * 8 + wave) * 8 + u) * 64 + lane;
+    X3Frag f;
+    f.h = dzq[e]; f.m = dzq[psq + e]; f.l = dzq[2 * psq + e];
+    return f;
+  };
   X3Frag bp[NST];
-  {
-    const float *drow = dzT + (size_t)(16 * wave + r) * ld;
-    f32x4 lo[NST], hi[NST];
 #pragma unroll
-    for (int u = 0; u < NST; ++u) {
-      const int cl = c0 + QY_KS * u + 4 * kg, ch = cl + 16;
-      lo[u] = *reinterpret_cast<const f32x4 *>(drow + min(cl, nb - 4));
-      hi[u] = *reinterpret_cast<const f32x4 *>(drow + min(ch, nb - 4));
-    }
-#pragma unroll
-    for (int u = 0; u < NST; ++u) {
-      const int cl = c0 + QY_KS * u + 4 * kg, ch = cl + 16;
-      bp[u] = x3_split8(cl < nb ? lo[u] : zero4, ch < nb ? hi[u] : zero4);
-    }
-  }
+  for (int u = 0; u < NST; ++u) bp[u] = dz_frag(ks0, u);
   int a_off[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -3596,14 +3695,19 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, c
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   auto stage_a = [&](char *t, const f32x4 &v) {
     unsigned h0, m0, l0, h1, m1, l1;
-    x3_split2(v.x, v.y, h0, m0, l0);
-    x3_split2(v.z, v.w, h1, m1, l1);
+    if (T2_ABL & 2) {
+      h0 = __float_as_uint(v.x); m0 = __float_as_uint(v.y); l0 = h0 ^ m0; h1 = __float_as_uint(v.z); m1 = __float_as_uint(v.w); l1 = h1 ^ m1;
+    } else {
+      x3_split2(v.x, v.y, h0, m0, l0);
+      x3_split2(v.z, v.w, h1, m1, l1);
+    }
     *reinterpret_cast<u32x2 *>(t + a_dst) = u32x2{h0, h1};
     *reinterpret_cast<u32x2 *>(t + QY_APL + a_dst) = u32x2{m0, m1};
     *reinterpret_cast<u32x2 *>(t + 2 * QY_APL + a_dst) = u32x2{l0, l1};
   };
   u32x4 ah[4], am[4], al[4];
   auto load_plane = [&](const char *t, int plane, u32x4 (&dst)[4]) {
+    if ((T2_ABL & 8) && t != abuf) return;
 #pragma unroll
     for (int a = 0; a < 4; ++a) dst[a] = *reinterpret_cast<const u32x4 *>(t + plane * QY_APL + a_off[a]);
   };
@@ -3613,10 +3717,10 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, c
   // of an 8-tile LDS ring; within a group a wave runs free: it reloads each fragment plane from the NEXT step's tile
   // as soon as the current step's MFMAs on that plane have issued.
   auto tile = [&](int half, int slot) -> char * { return abuf + (half * 4 + slot) * QY_ABUF; };
-  // prologue: group 0 of the first row block
+  // prologue: group 0 of the first iteration
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    stage_a(tile(0, u), masked(pre[u], u));
+    stage_a(tile(0, u), masked(pre[u], 0, u));
     pre[u] = fetch(1, u);
   }
   __syncthreads();
@@ -3624,24 +3728,27 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, c
   load_plane(tile(0, 0), 1, am);
   load_plane(tile(0, 0), 0, ah);
   T2_STAMP(1);
+  // ACC: the running sum over the slabs lives in LDS (4 x 16 B per thread behind the staging ring, touched once per slab):
+  // 16 more live registers would spill (the kernel sits at 239 of 256 with the dz fragments resident)
+  f32x4 *totl = reinterpret_cast<f32x4 *>(abuf + QY_LDS) + tid;
   f32x4 acc_b[4], acc_s[4];
-  for (int itl = 0; itl < G; ++itl) {
-    const int it = it0 + itl;
+  if (ACC) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) totl[a * QN_THREADS] = zero4;
+  }
+  for (int q = 0; q < NQ; ++q) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) { acc_b[a] = zero4; acc_s[a] = zero4; }
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
-      // All NST steps always run (samples past nb are zeros in both operands) and the last group of the last row
-      // block stages / reads harmless extra tiles: no data-dependent control flow inside the pipeline.
+      // All NST steps always run (samples past nb are zeros in both operands) and the last group of the last iteration
+      // stages / reads harmless extra tiles: no data-dependent control flow inside the pipeline.
       const int half = (u >> 2) & 1, slot = u & 3;
       const bool last = (slot == 3);                          // last step of its group: the next tile is behind the barrier
       const char *tnext = last ? tile(half ^ 1, 0) : tile(half, slot + 1);
-      const int us = (u + 4) % NST, its = itl + (u + 4) / NST;   // step staged now: same slot of the next group
-#define QX_ROW(AP, BP, ACC)                           \
-      ACC[0] = X3_MFMA(AP[0], bp[u].BP, ACC[0]);      \
-      ACC[1] = X3_MFMA(AP[1], bp[u].BP, ACC[1]);      \
-      ACC[2] = X3_MFMA(AP[2], bp[u].BP, ACC[2]);      \
-      ACC[3] = X3_MFMA(AP[3], bp[u].BP, ACC[3]);
+      const int us = (u + 4) % NST, qs = q + (u + 4) / NST;   // step staged now: same slot of the next group
+#define QX_ROW(AP, BP, ACC_)                           \
+      if (!(T2_ABL & 1)) x3_grp4(ACC_[0], AP[0], bp[u].BP, ACC_[1], AP[1], bp[u].BP, ACC_[2], AP[2], bp[u].BP, ACC_[3], AP[3], bp[u].BP);
       QX_ROW(al, h, acc_s)
       __builtin_amdgcn_sched_barrier(0);
       if (!last) load_plane(tnext, 2, al);
@@ -3657,22 +3764,33 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, c
 #undef QX_ROW
       __builtin_amdgcn_sched_barrier(0);
       if (!last) load_plane(tnext, 0, ah);
-      stage_a(tile(half ^ 1, slot), masked(pre[us], us));   // split once, stored as planes
-      pre[us] = fetch(its + 1, us);                          // refill the slot: the same step one row block further down
+      if (ACC && !(T2_ABL & 4)) bp[u] = dz_frag(min(q + 1, NQ - 1), u);   // next slab's fragments of this step, in place (unconditional)
+      stage_a(tile(half ^ 1, slot), masked(pre[us], qs, us));   // split once, stored as planes
+      pre[us] = fetch(qs + 1, us);                               // refill the slot: the same step one iteration further on
       if (last) {
-        __syncthreads();   // the next group's planes complete; this group's half may be overwritten from now on
+        if (!(T2_ABL & 16)) __syncthreads();   // the next group's planes complete; this group's half may be overwritten from now on
         load_plane(tnext, 2, al);
         load_plane(tnext, 1, am);
         load_plane(tnext, 0, ah);
       }
-      if (itl == 0) T2_STAMP(2 + u);
+      if (q == 0) T2_STAMP(2 + u);
     }
     x3_drain(acc_b[0], acc_b[1], acc_b[2], acc_b[3]);
     x3_drain(acc_s[0], acc_s[1], acc_s[2], acc_s[3]);
-    f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks * QN_H1 * QN_HID);
+    if (ACC) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) out[((4 * it + a) * 8 + wave) * 64 + lane] = acc_b[a] + acc_s[a];
-    T2_STAMP(10 + itl);
+      for (int a = 0; a < 4; ++a) totl[a * QN_THREADS] += acc_b[a] + acc_s[a];   // 0 + P_0 + P_1 + ...: the reduction's own order
+    } else {
+      f32x4 *out = reinterpret_cast<f32x4 *>(wpart + (size_t)ks0 * QN_H1 * QN_HID);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) out[((4 * (it0 + q) + a) * 8 + wave) * 64 + lane] = acc_b[a] + acc_s[a];
+    }
+    T2_STAMP(10 + min(q, 15));
+  }
+  if (ACC) {
+    f32x4 *out = reinterpret_cast<f32x4 *>(wpart);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) out[((4 * it0 + a) * 8 + wave) * 64 + lane] = totl[a * QN_THREADS];
   }
 }
 
@@ -4260,6 +4378,22 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   pqn_note_kernel_form(0, use_pos ? PQN_FORM_PAIR_POS : (use_pd2 ? PQN_FORM_PAIR_PD2 : (use_pair ? PQN_FORM_PAIR : PQN_FORM_SINGLE)));
   const int gs_max = pqn_cnn_seed_group(L.matmul_f16, sd.nseeds);
+  // bf16x3 fc1 weight gradient without split-K partials (qnet_fc1_wgrad_x3_kernel<true>): option t2_acc = 0 never, 1 (default)
+  // when row blocks x seeds of a launch give every CU a workgroup, 2 always.  Both forms sum the slabs in the same order, so
+  // a seed's bits do not depend on which one its launch took.
+  const int acc_opt = pqn_opt(PQN_OPT_T2_ACC);
+  const bool t2_acc = L.matmul_f16 == 2 && !use_pos && (acc_opt == 2 || (acc_opt == 1 && 16 * min(gs_max, sd.nseeds) >= 256));
+  if (L.matmul_f16 == 2 && !use_pos && part != 2 && (nb % QW_SLAB) != 0) {
+    // ragged last slab: T1 writes the dz planes of existing samples only; the rest of the slab must read as zero in T2
+    unsigned short *dzw = reinterpret_cast<unsigned short *>(dzT + qw_dzw_offset(nb, C, L.a));
+    const size_t ps = (size_t)nks * QW_SLAB * QN_HID, slab = (size_t)QW_SLAB * QN_HID;
+    for (int pl = 0; pl < 3; ++pl)
+      if (hipMemset2DAsync(dzw + pl * ps + (size_t)(nks - 1) * slab, sd.nseeds > 1 ? (size_t)sd.ws_stride * sizeof(float) : slab * sizeof(unsigned short), 0, slab * sizeof(unsigned short),
+                           (size_t)sd.nseeds, st) != hipSuccess) {
+        pqn_set_error("pqn_qnet_cnn_grad: hipMemset2DAsync failed");
+        return PQN_E_HIP;
+      }
+  }
   for (int s0 = 0; s0 < sd.nseeds; s0 += gs_max) {
     const int gs = min(gs_max, sd.nseeds - s0);
     pqn_seeds_t sg = sd;
@@ -4297,25 +4431,33 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     else if (L.matmul_f16 == 2) {
       static bool x3_attr = false;
       if (!x3_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, QY_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, QY_LDS_ACC);
         x3_attr = true;
       }
-      // row blocks per workgroup: as many as still leave one workgroup per CU (16 = the dz slab is read once)
-      int G = 16;
-      while (G > 1 && (16 / G) * nks * gs < 256) G >>= 1;
       if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
         if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;
       }
-      hipLaunchKernelGGL(qnet_fc1_wgrad_x3_kernel, dim3(16 / G, nks, gs), dim3(QN_THREADS), QY_LDS, st, nb, h1T + wo, dzT + wo,
-                         wpart + wo, sd.ws_stride, G, g_t2_stamps);
+      const unsigned short *dzw = reinterpret_cast<const unsigned short *>(dzT + qw_dzw_offset(nb, C, L.a) + wo);
+      if (t2_acc) {   // one workgroup per (row block, seed) walks over every slab: no split-K partials (see the kernel)
+        hipLaunchKernelGGL(qnet_fc1_wgrad_x3_kernel<true>, dim3(16, 1, gs), dim3(QN_THREADS), QY_LDS_ACC, st, nb, h1T + wo, dzw, wpart + wo,
+                           sd.ws_stride, 1, g_t2_stamps);
+      } else {
+        // row blocks per workgroup: as many as still leave one workgroup per CU (16 = the dz slab is read once)
+        int G = 16;
+        while (G > 1 && (16 / G) * nks * gs < 256) G >>= 1;
+        hipLaunchKernelGGL(qnet_fc1_wgrad_x3_kernel<false>, dim3(16 / G, nks, gs), dim3(QN_THREADS), QY_LDS, st, nb, h1T + wo, dzw,
+                           wpart + wo, sd.ws_stride, G, g_t2_stamps);
+      }
     } else
       hipLaunchKernelGGL(qnet_fc1_wgrad_kernel, dim3(16, nks, gs), dim3(QN_THREADS), 0, st, nb, h1T + wo, dzT + wo, wpart + wo,
                          sd.ws_stride);
   }
   if (with_reduce && part != 1)
     hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles,
-                       use_pos ? 1 : nks, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd,
+                       (use_pos || t2_acc) ? 1 : nks, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd,
                        use_pos ? gposw : nullptr, use_pos ? 16 : 0);
   return pqn_check_launch("pqn_qnet_cnn_grad");
 }
@@ -4324,7 +4466,9 @@ extern "C" int64_t pqn_qnet_cnn_workspace_floats(const pqn_cnn_layout_t *L, int3
   if (!L || nb <= 0) return -1;
   const int64_t rec = small_record_floats(L->c, L->a);
   const int64_t ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB;
-  const int64_t std_layout = 1024 + (int64_t)QN_HID * qw_ld(nb) + (int64_t)QN_H1 * qw_h1_cols(nb) + ntiles * rec + nks * (int64_t)QN_H1 * QN_HID;
+  // (the dz planes of the bf16x3 mode sit behind the split-K slabs: qw_dzw_offset)
+  const int64_t std_layout = 1024 + (int64_t)QN_HID * qw_ld(nb) + (int64_t)QN_H1 * qw_h1_cols(nb) + ntiles * rec +
+                             nks * (int64_t)QN_H1 * QN_HID + (int64_t)qw_dzw_floats(nb);
   // small minibatches (K-split form of T1): a record per (tile, position group) and a weight-gradient slab per tile.
   // Callers size the workspace once for their LARGEST minibatch and may pass smaller ones, so the result is monotonic:
   // the K-split layout of min(nb, KS_MAX_NB) is covered at every nb.

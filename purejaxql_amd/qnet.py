@@ -176,7 +176,8 @@ class CnnTrainer:
 
 
 def cnn_grad_seeds(layout: CnnKernelLayout, theta_k: torch.Tensor, idx: torch.Tensor, obs_bits: torch.Tensor,
-                   action: torch.Tensor, target: torch.Tensor, n_env: int, n_env_total: Optional[int] = None):
+                   action: torch.Tensor, target: torch.Tensor, n_env: int, n_env_total: Optional[int] = None,
+                   _ws_fill: Optional[float] = None):
     """jax.vmap(value_and_grad(_loss_fn)) over seeds (pqn_minatar.py:271-291 under :459-461) in ONE set of launches
     (pqn_qnet_cnn_grad_seeds): theta_k [S, stride] kernel-layout parameters (operand copies in step, see
     CnnKernelLayout.to_kernel), idx int64 [S, nb] transition indices per seed into the stacked [T][S*N] record (or a
@@ -189,6 +190,8 @@ def cnn_grad_seeds(layout: CnnKernelLayout, theta_k: torch.Tensor, idx: torch.Te
     assert idx.dtype == torch.int64 and action.dtype == torch.int32 and target.dtype == torch.float32
     ws_stride = (int(lib.pqn_qnet_cnn_workspace_floats(C.byref(layout.struct), nb)) + 3) // 4 * 4
     ws = torch.empty((s, ws_stride), dtype=torch.float32, device=dev)
+    if _ws_fill is not None:      # tests: poison the workspace (every byte the kernels read must have been written by them)
+        ws.fill_(_ws_fill)
     w1b = torch.empty((s, 1024 * 128), dtype=torch.float32, device=dev)
     for k in range(s):
         layout.refresh_copies(theta_k[k], w1b[k])

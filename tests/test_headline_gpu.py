@@ -204,6 +204,43 @@ def test_headline_whole_update_vs_oracle(gpu, oracle):
         assert cos > 0.998 and rel < 6e-2 and bad.mean() < 1e-2 and d.max() < 4 * cfg["LR"], (s, cos, rel, float(bad.mean()), float(d.max()))
 
 
+@pytest.mark.parametrize("nb,seeds", [(4096, 16), (512, 2), (272, 3), (16, 1)])
+def test_fc1_weight_gradient_without_split_k_partials_is_bit_identical(gpu, nb, seeds):
+    """qnet_fc1_wgrad_x3_kernel<true> (round 4: one workgroup per (row block, seed) walks over every 256-sample slab and
+    adds the per-slab tiles in slab order -- no split-K partials in HBM) against the partial-slab form + the reduction's
+    fold: the whole flat gradient bit for bit, at the bench's launch shape (16 seeds x 4096 samples, where it is the
+    default), at a ragged minibatch (272 = one slab + one tile: the zeroed tail of the dz planes) and at one tile, from a
+    NaN-poisoned workspace.  fc1 part of value_and_grad(_loss_fn), pqn_minatar.py:271-291."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_grad_seeds, matmul_mode
+    rng = np.random.default_rng(nb + seeds)
+    c, a, rows = 4, 3, 6000
+    obs = (rng.random((rows, 10, 10, c)) < 0.12).astype(np.float32)
+    bits = torch.from_numpy(_pack_bits(obs).view(np.int32)).to(gpu)
+    action = torch.from_numpy(rng.integers(0, a, rows).astype(np.int32)).to(gpu)
+    target = torch.from_numpy(rng.standard_normal(rows).astype(np.float32)).to(gpu)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode("bf16x3"))
+    stride = (lay.alloc + 3) // 4 * 4
+    theta_k = torch.zeros((seeds, stride), dtype=torch.float32, device=gpu)
+    for s in range(seeds):
+        th = lay.to_kernel(net.init(40 + s) + 0.05 * torch.randn(net.num_params, device=gpu))
+        theta_k[s, :th.numel()] = th
+    idx = torch.from_numpy(np.stack([rng.permutation(rows)[:nb] for _ in range(seeds)]).astype(np.int64)).to(gpu).contiguous()
+    out = {}
+    for acc in (0, 2, 1):
+        with _lib.options(t2_acc=acc):
+            g, lo, qv = cnn_grad_seeds(lay, theta_k, idx, bits, action, target, rows, _ws_fill=float("nan"))
+        torch.cuda.synchronize()
+        out[acc] = (g.clone(), lo.clone(), qv.clone())
+        assert torch.isfinite(g).all() and torch.isfinite(lo).all()
+    for acc in (2, 1):
+        for x, y in zip(out[0], out[acc]):
+            assert torch.equal(x, y), (nb, seeds, acc)
+    assert float(out[0][0][:, lay.struct.off_w1:lay.struct.off_w1 + 1024 * 128].abs().max()) > 0
+
+
 def test_forced_pair_forms_at_small_sizes_in_process(gpu):
     """The pair forms forced at sizes where they are not selected by default (pqn_set_option, in-process): the training
     kernel at 2, 8 and 256 pairs (C = 4; at C = 6 its LDS plan does not fit and the single-tile kernel must be what runs) -- repeats bit-identical, equal to the single-tile bf16x3

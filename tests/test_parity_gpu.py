@@ -295,6 +295,31 @@ def test_radam_clip_vs_oracle(gpu, oracle):
         assert int(opt.count[0]) == 10
 
 
+def test_radam_kernel_vs_torch_optim_radam(gpu):
+    """radam_apply_kernel (pqn_radam_clip_step: optax.chain(clip_by_global_norm, radam), pqn_minatar.py:159-162) against
+    torch.optim.RAdam in f64 -- an independent implementation of the published algorithm -- over 200 steps, through the
+    rho <= 5 warm-up into the rectified branch, clipped and unclipped.  The libraries differ only by where eps enters
+    (<= eps / sqrt(v_hat) relative per step; see tests/test_oracle_cpu.py::test_oracle_radam_vs_torch_optim_radam)."""
+    from purejaxql_amd import ops
+    from tests.test_oracle_cpu import _torch_radam_reference
+    rng = np.random.default_rng(11)
+    n, steps, lr = 132475, 200, 5e-4
+    p0 = rng.standard_normal(n).astype(np.float32)
+    grads = [(rng.standard_normal(n) * (0.03 if t % 7 else 0.3) * np.exp(-t / 120.0)).astype(np.float32) for t in range(steps)]
+    for max_norm in (1e9, 10.0):
+        ref = _torch_radam_reference(p0, grads, lr, max_norm)
+        pt = torch.from_numpy(p0.copy()).to(gpu)
+        opt = ops.FlatRAdam(pt, lr, max_norm)
+        clipped = 0
+        for t, g in enumerate(grads):
+            opt.step(torch.from_numpy(g).to(gpu))
+            if t in (0, 4, 5, 6, 20, 199):
+                clipped += int(not float(opt.gnorm[0]) < max_norm)
+                np.testing.assert_allclose(_np(pt), ref[t], rtol=2e-7 * np.sqrt(t + 1.0), atol=1e-7 + 2e-5 * lr * (t + 1),
+                                           err_msg=f"step {t} max_norm {max_norm}")
+        assert int(opt.count[0]) == steps and (clipped > 0) == (max_norm == 10.0)
+
+
 def test_product_network_vs_oracle_network(gpu, oracle):
     """torch-on-GPU fp32 network vs the oracle's numpy network (same theta)."""
     from purejaxql_amd.networks import QNetwork
