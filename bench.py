@@ -35,6 +35,12 @@ BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 T1_FLOP_PER_SAMPLE = 674048.0
 
 
+def t1_flop_per_sample(channels: int, actions: int) -> float:
+    """The same count for any MinAtar game: conv 3x3xC -> 16 on 8x8 positions (forward + weight gradient), fc1 1024 -> 128
+    (forward + input gradient), fc2 128 -> A (forward, input and weight gradient); Breakout (C = 4, A = 3): 674,048."""
+    return 2.0 * 18432.0 * channels + 2.0 * 262144.0 + 3.0 * 256.0 * actions
+
+
 def workload_config(num_envs: int, mode: str):
     from purejaxql_amd.config_loader import flatten, load_config
     cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", f"alg.NUM_ENVS={num_envs}",
@@ -127,8 +133,8 @@ def kernel_timer_pass(lib, update, first, mb_samples, seeds):
     return tot.value * 1e-3 / cnt.value, cnt.value
 
 
-def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form):
-    achieved = T1_FLOP_PER_SAMPLE * mb_samples * seeds / avg_s / 1e12
+def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sample=T1_FLOP_PER_SAMPLE):
+    achieved = flop_per_sample * mb_samples * seeds / avg_s / 1e12
     traffic, tsrc, l2cu = None, None, None
     for name in (f"r03_pmc_train_kernel_{matmul}_seeds{seeds}.json", f"r02_pmc_train_kernel_{matmul}_seeds{seeds}.json",
                  f"r02_pmc_train_kernel_{matmul}.json", "r01_pmc_train_kernel.json"):
@@ -151,7 +157,7 @@ def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form):
            "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "l2_to_cu_bytes": l2cu,
            "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
-           "flop_per_launch": T1_FLOP_PER_SAMPLE * mb_samples * seeds,
+           "flop_per_launch": flop_per_sample * mb_samples * seeds,
            "peak_note": "f32 MFMA / vector peak of MI355X (157.3 TFLOP/s); algorithmic f32 FLOPs of the kernel"}
     if matmul == "bf16x3":
         # the same f32 products, evaluated as 6 bf16 MFMA products each (3 for the conv phases, whose bit operand is
@@ -273,6 +279,13 @@ def main():
         env_steps_per_update = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * spg * world
         scaling = "weak"
     fused = train.backend == "fused"
+    # one tiny collective on a DEVICE tensor before the timed region: proof that the process group (RCCL under the nccl
+    # backend) really spans `world` ranks -- in seeds mode the data path itself has no collective
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.float32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(round(float(one.item())))
     dt = timed_updates(update, args.steps, args.warmup, 0, barrier)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -330,7 +343,8 @@ def main():
                        "env_steps_per_step": env_steps_per_update, "matmul_dtype": matmul,
                        "backend": train.backend, "driver": driver_mode, "parallelism": f"{args.mode}x{world}",
                        "kernel_forms": dict(zip(("train", "rollout"), _lib.last_kernel_form())),
-                       "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if world > 1 else 1,
+                       "rccl_ranks": (ranks_seen if dist.get_backend() == "nccl" else 0) if world > 1 else 1,
+                       "ranks_in_allreduce": ranks_seen,
                        "dist_backend": dist.get_backend() if world > 1 else None,
                        "grad_allreduce": (getattr(ghook, "mode", None) if args.mode == "envs" and world > 1 else None),
                        "gpus_visible": torch.cuda.device_count(),
@@ -361,6 +375,43 @@ def main():
                         "roofline": t1_roofline(a1, l1, mb, 1, matmul, _lib.last_kernel_form()[0]),
                         "note": "ONE seed of 4096 envs alone on the GPU (round 1's headline configuration)"}
             guarded("single_seed", single_seed)
+        if extras and fused:
+            def minatar_suite():
+                """BASELINE.json configs[2] (the MinAtar suite at 4096 envs: gymnax 0.0.6 has four games) and configs[1]
+                (Breakout at 1024 envs), each as the headline workload: 16 seeds per GPU batched into the launches, the
+                yaml's 32 steps x 32 minibatches x 2 epochs, same operand mode.  Per line: whole-loop env-steps/s, the kernel
+                forms the library took, the training kernel's HIP-event duration and its fraction of the f32 peak."""
+                from purejaxql_amd.config_loader import flatten, load_config
+                from purejaxql_amd.envs import make
+                res = []
+                for env_name, n_envs in (("Asterix-MinAtar", 4096), ("Freeway-MinAtar", 4096), ("SpaceInvaders-MinAtar", 4096),
+                                         ("Breakout-MinAtar", 4096), ("Breakout-MinAtar", 1024)):
+                    try:
+                        cg = flatten(load_config(["+alg=pqn_minatar", f"alg.ENV_NAME={env_name}", f"alg.NUM_ENVS={n_envs}",
+                                                  "alg.TEST_DURING_TRAINING=False"]))
+                        cg["MATMUL_DTYPE"] = matmul
+                        w_g, s_g = 3, 12
+                        cg["TOTAL_TIMESTEPS"] = (w_g + s_g + 3) * n_envs * cg["NUM_STEPS"]
+                        trg = make_train(cg, device=str(dev))
+                        updg, _fg = trg.make_batch_runner(seed_keys(0, spg)) if spg > 1 else trg.make_runner(seed_keys(0, 1)[0])
+                        dg = timed_updates(updg, s_g, w_g)
+                        forms = dict(zip(("train", "rollout"), _lib.last_kernel_form()))
+                        mbg = n_envs * cg["NUM_STEPS"] // cg["NUM_MINIBATCHES"]
+                        ag, lg = kernel_timer_pass(lib, updg, w_g + s_g, mbg, spg)
+                        env_g, _pg = make(env_name, device=dev)
+                        ch, na = int(env_g.obs_shape[-1]), int(env_g.num_actions)
+                        rg = t1_roofline(ag, lg, mbg, spg, matmul, forms["train"], t1_flop_per_sample(ch, na))
+                        res.append({"env": env_name, "num_envs": n_envs, "seeds_per_gpu": spg, "channels": ch, "actions": na,
+                                    "value": n_envs * cg["NUM_STEPS"] * spg * s_g / dg, "unit": "env-steps/s",
+                                    "ms_per_update": dg / s_g * 1e3, "kernel_forms": forms,
+                                    "t1_avg_launch_us": rg["avg_launch_us"], "t1_frac_f32_peak": rg["frac"],
+                                    "t1_flop_per_sample": t1_flop_per_sample(ch, na), "minibatch": mbg})
+                        del updg, trg
+                    except Exception as exc:  # noqa: BLE001
+                        res.append({"env": env_name, "num_envs": n_envs, "error": repr(exc)[:300]})
+                        torch.cuda.synchronize()
+                return res
+            guarded("minatar_suite", minatar_suite)
         if extras:
             from purejaxql_amd.profiling import env_step_hbm_roofline
             guarded("roofline_env_step", lambda: [env_step_hbm_roofline(n, dev) for n in (4096, 65536, 262144)])
@@ -460,6 +511,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        if ghook is not None:
+            ghook.close()
         dist.destroy_process_group()
 
 

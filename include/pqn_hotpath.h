@@ -248,7 +248,12 @@ typedef struct {
   int32_t reserved; /* flags.  bit 0 (experimental, leave 0): run the fold of the gradient partials, the global-norm
                        clip and RAdam as ONE kernel with a grid-wide barrier instead of two kernels.  Measured slower
                        in round 1 and unsafe when several updates are in flight on different streams of one GPU; same
-                       results up to the summation grouping of the global norm. */
+                       results up to the summation grouping of the global norm.
+                       bit 1: choose the form of the training kernel from the minibatch size alone, never from the number
+                       of seeds batched into the launch (pqn_cnn_update_seeds): every seed then takes the kernels of its
+                       solo run and is bit-identical to it in the one regime where the default is not -- f32 operand mode,
+                       minibatches <= 256 samples, more than t1_ksplit_tiles tiles x seeds per launch -- at the cost of the
+                       slower K-split form there. */
   float gamma, lambda, rew_scale;                 /* GAMMA, LAMBDA, REW_SCALE */
   float eps_start, eps_finish;                    /* linear_schedule over updates (:134-138) */
   float lr_init, lr_end, max_grad_norm;           /* :140-147,159-162 */
@@ -370,7 +375,8 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * fusions itself).  Names: "t1_pair", "rollout_pair" (pair form of the bf16x3 training / rollout kernel: 0 never,
  * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
  * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP
- * backward on a second stream; default 0), "t1_ksplit" (K-split form of the f32-mode training kernel for minibatches of
+ * backward on a second stream; default 0), "peer_timeout_s" (seconds pqn_peer_allreduce_mean waits for a peer; default 60), "t2_acc" (bf16x3 fc1 weight
+ * gradient without split-K partials: 0 never, 1 (default) when row blocks x seeds of a launch fill the chip, 2 always), "t1_ksplit" (K-split form of the f32-mode training kernel for minibatches of
  * at most 256 samples: a tile's work cut along the conv positions over many workgroups; 1 (default) = forward partial +
  * head-and-backward as two launches, 2 / 3 / 4 = three launches with 4 / 8 / 16 positions per workgroup, 0 = the
  * single-tile kernel), "t1_ksplit_tiles" (the K-split form is taken while tiles x seeds of a launch stay at or below
@@ -459,7 +465,10 @@ int pqn_mlp_update_seeds(const pqn_mlp_update_args_t *args /* host */, int32_t n
  * handle), the ranks exchange the handles out of band (torch.distributed all_gather in purejaxql_amd/dist.py), map each
  * other's regions (pqn_peer_open) and fill a pqn_peers_t; pqn_peer_allreduce_mean then only enqueues two small kernels
  * (publish / wait + sum in rank order + scale by 1 / world), so it can sit inside a captured update.  All ranks obtain
- * bit-identical results.  A peer that never arrives ends in an error word (pqn_peer_status), not in a hung device. */
+ * bit-identical results.  A peer that never arrives within the WALL-CLOCK time-out (option "peer_timeout_s", default 60 s;
+ * the device's constant 100 MHz clock) ends in a sticky error word (pqn_peer_status: 0 = fine, r + 1 = rank r never
+ * published), not in a hung device; every later collective then fails fast.  Callers poll the word once per update
+ * (purejaxql_amd/dist.py) and stop: gradients behind a time-out are not synchronised. */
 #define PQN_PEER_MAX 8
 typedef struct {
   int32_t rank, world;

@@ -87,6 +87,7 @@ enum {
   PQN_OPT_T1_KSPLIT,      // PQN_T1_KSPLIT: K-split form of the f32-mode training kernel for minibatches <= 256 samples (default 1)
   PQN_OPT_T1_KSPLIT_TILES, // PQN_T1_KSPLIT_TILES: the K-split form is taken while tiles x seeds of the launch stay at or below this (default 48)
   PQN_OPT_BM_OVERLAP,     // PQN_BM_OVERLAP: parameter-gradient side of the wide-MLP backward on a second stream (default 0: measured no gain)
+  PQN_OPT_PEER_TIMEOUT_S, // PQN_PEER_TIMEOUT_S: wall-clock seconds the in-graph peer all-reduce waits for a peer's gradient (default 60)
   PQN_OPT_T2_ACC,         // PQN_T2_ACC: bf16x3 fc1 weight gradient without split-K partials 0 never / 1 when row blocks x seeds fill the chip / 2 always
   PQN_OPT_COUNT
 };
@@ -153,6 +154,8 @@ struct pqn_seeds_t {
   long long lq_stride;           // loss_buf / qv_buf
   long long idx_mask;            // low bits of a sorted key that hold the local transition index
   int seed_base;                 // first seed of this launch (seed = blockIdx.y + seed_base): launches over seed groups
+  int pin_form;                  // != 0: choose the training-kernel form from the minibatch size alone (never from how many
+                                 // seeds share the launch), so a seed inside a batch takes the form of its solo run
 };
 inline pqn_seeds_t pqn_one_seed() {
   pqn_seeds_t s = {};

@@ -23,7 +23,11 @@
 // each of the two staging buffers holds PEER_STRIDE(n) floats: a multiple of 4, so both start 16-byte aligned
 #define PEER_STRIDE(n) (((size_t)(n) + 3) & ~(size_t)3)
 #define PEER_FLAG_OFFSET_BYTES(n) (((PEER_STRIDE(n) * 2 * sizeof(float)) + 255) & ~(size_t)255)
-#define PEER_SPIN_LIMIT (1u << 21)   // ~ 5 s of polling: a missing peer ends in an error word, not in a hung GPU
+// A missing peer ends in an error word, not in a hung GPU -- but only after a WALL-CLOCK time-out (round 4; rounds 1-3
+// counted polls, ~1-5 s depending on the xGMI load latency): s_memrealtime ticks of the constant 100 MHz clock, option
+// "peer_timeout_s" / PQN_PEER_TIMEOUT_S, default 60 s -- rank skew of a few seconds (a slow graph instantiate, a host
+// stall, logging on one rank) is normal and must not turn into silently unsynchronised gradients.
+#define PEER_TICKS_PER_S 100000000ull
 
 extern "C" int64_t pqn_peer_region_bytes(int64_t n) { return n > 0 ? (int64_t)PEER_FLAG_OFFSET_BYTES(n) + 256 : -1; }
 
@@ -94,13 +98,17 @@ __global__ __launch_bounds__(256) void peer_publish_kernel(const float *__restri
 }
 
 __global__ __launch_bounds__(256) void peer_reduce_kernel(float *__restrict__ grad, long long n, PeerPtrs P, int rank, int world,
-                                                          unsigned *local_state) {
+                                                          unsigned *local_state, unsigned long long timeout_ticks) {
   const unsigned target = local_state[0];   // the publish kernel of this step ran before us on the stream
   if (threadIdx.x < world && (int)threadIdx.x != rank && local_state[2] == 0u) {   // after one time-out: fail fast
-    unsigned spins = 0;
+    const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(P.flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
-      if (++spins > PEER_SPIN_LIMIT) { local_state[2] = 1u; break; }
-      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > timeout_ticks) {
+        local_state[2] = 1u;                       // sticky error word: pqn_peer_status / PeerAllReduce.check()
+        local_state[3] = threadIdx.x + 1u;         // which peer never arrived (1-based)
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
     }
   }
   __syncthreads();
@@ -145,7 +153,10 @@ extern "C" int pqn_peer_allreduce_mean(const pqn_peers_t *P, float *grad, void *
   const int blocks = (int)min((long long)64, (P->n / 4 + 255) / 256 + 1);   // small grids: always co-resident, never in the way
   hipLaunchKernelGGL(peer_publish_kernel, dim3(blocks), dim3(256), 0, st, grad, (long long)P->n, pp.send[P->rank], pp.flag[P->rank],
                      P->local_state);
-  hipLaunchKernelGGL(peer_reduce_kernel, dim3(blocks), dim3(256), 0, st, grad, (long long)P->n, pp, P->rank, P->world, P->local_state);
+  const int tsec = pqn_opt(PQN_OPT_PEER_TIMEOUT_S);
+  const unsigned long long ticks = (unsigned long long)(tsec > 0 ? tsec : 60) * PEER_TICKS_PER_S;
+  hipLaunchKernelGGL(peer_reduce_kernel, dim3(blocks), dim3(256), 0, st, grad, (long long)P->n, pp, P->rank, P->world, P->local_state,
+                     ticks);
   return pqn_check_launch("pqn_peer_allreduce_mean");
 }
 
@@ -157,6 +168,6 @@ extern "C" int pqn_peer_status(const pqn_peers_t *P, int32_t *error_out) {
     pqn_set_error("pqn_peer_status: hipMemcpy failed");
     return PQN_E_HIP;
   }
-  *error_out = (int32_t)st[2];
+  *error_out = st[2] ? (int32_t)(st[3] ? st[3] : 1u) : 0;   // 0 = fine, r + 1 = rank r never published in time
   return PQN_OK;
 }

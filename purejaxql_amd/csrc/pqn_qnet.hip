@@ -2769,8 +2769,15 @@ struct PairSmem {
   using Cfg = CnnCfg<C>;
   static constexpr int WCN = (Cfg::KW * 16 + 48 + 3) & ~3;
   static constexpr int BITN = QN_TILE * Cfg::OW + 4;
-  static constexpr size_t BYTES = sizeof(float) * (2 * QN_TILE * QN_H1S + 2 * QN_TILE * QN_ZS + WCN + QN_HP_FLOATS) +
-                                  sizeof(uint32_t) * (2 * BITN + QN_TILE * 32) + sizeof(float) * (6 * QN_TILE + QN_WAVES * 48);
+  // the head-parameter block is sized by the ACTUAL action count (round 4): with the 8-action block of the single-tile
+  // kernels the plan of C = 6 missed the 160 KB by 1,024 B and that of C = 7 by 2,112 B; SpaceInvaders (C = 6, A = 4) and
+  // Freeway (C = 7, A = 3) now take the pair form too
+  static constexpr int hp_floats(int a) { return (384 + 128 * a + a + 3) & ~3; }
+  static constexpr int HP_MIN = hp_floats(1);
+  static constexpr size_t bytes(int a) {
+    return sizeof(float) * (2 * QN_TILE * QN_H1S + 2 * QN_TILE * QN_ZS + WCN + hp_floats(a)) +
+           sizeof(uint32_t) * (2 * BITN + QN_TILE * 32) + sizeof(float) * (6 * QN_TILE + QN_WAVES * 48);
+  }
   // the freed h1 B region must hold the head / conv-wgrad scratch followed by the window masks, and the LN0-bwd staging
   static_assert(TrainCfg<C>::SCR + QN_WAVES * 192 <= QN_TILE * QN_H1S && QN_WAVES * 64 * QN_STG <= QN_TILE * QN_H1S, "scratch must fit h1 B");
   static_assert(2 * 3 * QN_TILE * QN_ZS <= QN_TILE * QN_H1S, "the staged tiles of both heads (train_head_nt<.., 2>) must fit h1 B");
@@ -2816,7 +2823,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   float *h1A = reinterpret_cast<float *>(smem_raw), *h1B = h1A + QN_TILE * QN_H1S;
   float *zA = h1B + QN_TILE * QN_H1S, *zB = zA + QN_TILE * QN_ZS;
   float *wc = zB + QN_TILE * QN_ZS, *hp = wc + PS::WCN;
-  uint32_t *bitsA = reinterpret_cast<uint32_t *>(hp + QN_HP_FLOATS), *bitsB = bitsA + PS::BITN, *maskB = bitsB + PS::BITN;
+  uint32_t *bitsA = reinterpret_cast<uint32_t *>(hp + PS::hp_floats(L.a)), *bitsB = bitsA + PS::BITN, *maskB = bitsB + PS::BITN;
   float *small = reinterpret_cast<float *>(maskB + QN_TILE * 32);   // gs[2][16] | tgt[2][16] | act[2][16] | red[8][48]
   float *red = small + 6 * QN_TILE;
   float *scr = h1B;                                                 // once h1 B has been packed to maskB
@@ -2943,8 +2950,8 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
     float *scr2 = zA + QN_WAVES * 192;                                // ... and 12 KB of wave partials, all inside z A .. hp
     float *redB = reinterpret_cast<float *>(maskB);                   // tile B's cross-wave sums (the mask bits are dead by then)
     static_assert(sizeof(float) * (QN_WAVES * 192 + 4 * ((9 * C + 15) / 16) * 256) <=
-                      sizeof(float) * (2 * QN_TILE * QN_ZS + PS::WCN + QN_HP_FLOATS), "conv-wgrad scratch must fit z A .. hp");
-    static_assert(12288 <= sizeof(float) * (QN_TILE * QN_ZS + PS::WCN + QN_HP_FLOATS), "dz planes of tile B must fit z B .. hp");
+                      sizeof(float) * (2 * QN_TILE * QN_ZS + PS::WCN + PS::HP_MIN), "conv-wgrad scratch must fit z A .. hp");
+    static_assert(12288 <= sizeof(float) * (QN_TILE * QN_ZS + PS::WCN + PS::HP_MIN), "dz planes of tile B must fit z B .. hp");
     static_assert(QN_WAVES * 48 * sizeof(float) <= QN_TILE * 32 * sizeof(uint32_t), "tile B's sums must fit the mask bits");
     pd2_dz_planes(zB, planesB, lane, wave);
     t1_dgrad_pair2_x3(zA, h1A, planesB, h1B, maskB, theta, L, lane, wave, prot);
@@ -4256,8 +4263,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // tiles per launch, K-split vs single-tile: S = 1: 5.9 vs 9.9 s, 2: 6.9 vs 10.3, 4: 7.8 vs 11.1, 6: 10.2 vs 11.6, 10: 14.1
   // vs 12.4).  A seed therefore gets the same bits alone and inside a batch only as long
   // as both launches fall on the same side of this threshold (option t1_ksplit_tiles).
+  // (sd.pin_form: the caller asked for a batch that is bit-identical to its solo runs -- the form then follows the solo rule)
   const bool use_ks = L.matmul_f16 == 0 && nb <= KS_MAX_NB && with_reduce && ks_opt != 0 &&
-                      ntiles * sd.nseeds <= pqn_opt(PQN_OPT_T1_KSPLIT_TILES);
+                      ntiles * (sd.pin_form ? 1 : sd.nseeds) <= pqn_opt(PQN_OPT_T1_KSPLIT_TILES);
   const bool ks_hb = ks_opt == 1 || ks_opt > 4;
   const int ks_ng = ks_hb ? 8 : (ks_opt == 3 ? 8 : (ks_opt == 4 ? 4 : 16));   // records (and backward groups) per tile
   float *wpart = gpart + (size_t)ntiles * rec;
@@ -4337,13 +4345,14 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // minibatch has an even number of tiles; PQN_T1_PAIR=0 keeps the single-tile kernel (profiling / A-B runs)
   const int pair_env = pqn_opt(PQN_OPT_T1_PAIR);
   // (and the launch still has a workgroup for every CU: a single 4096-sample seed is 128 pairs, half a chip)
-  const bool use_pair = pair_env && L.matmul_f16 == 2 && PairSmem<C>::BYTES <= 160 * 1024 && ntiles >= 2 && (ntiles % 2) == 0 &&
+  const size_t pair_bytes = PairSmem<C>::bytes(L.a);
+  const bool use_pair = pair_env && L.matmul_f16 == 2 && pair_bytes <= 160 * 1024 && ntiles >= 2 && (ntiles % 2) == 0 &&
                         ((ntiles / 2) * sd.nseeds >= 256 || pair_env == 2);   // PQN_T1_PAIR=2: pair form at any size (tests)
   if (use_pair) {
     static bool pair_attr = false;
     if (!pair_attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem<C>::BYTES);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       pair_attr = true;
     }
   }
@@ -4359,7 +4368,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_bwd_pos_kernel<C>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_pos_lds_bytes<C>());
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem<C>::BYTES);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       fwd_attr = true;
     }
   }
@@ -4371,7 +4380,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       static bool pd2_attr = false;
       if (!pd2_attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem<C>::BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         pd2_attr = true;
       }
     }
@@ -4407,7 +4416,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
         if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;
       }
-      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
+      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), pair_bytes, st, nb, idx, bits,
                          action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
       hipLaunchKernelGGL(qnet_cnn_bwd_pos_kernel<C>, dim3(16, gs), dim3(QN_THREADS), bwd_pos_lds_bytes<C>(), st, nb, idx, bits, theta, L,
                          reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg, g_t2_stamps);
@@ -4415,10 +4424,10 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       continue;   // no T2: dW1 was accumulated in registers
     } else if (use_pair && use_pd2) {
       if constexpr (C == 4)
-        hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb,
+        hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), pair_bytes, st, nb,
                            idx, bits, action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps, wpart);
     } else if (use_pair)
-      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false>), dim3(ntiles / 2, gs), dim3(QN_THREADS), PairSmem<C>::BYTES, st, nb, idx, bits,
+      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false>), dim3(ntiles / 2, gs), dim3(QN_THREADS), pair_bytes, st, nb, idx, bits,
                          action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
     else
     hipLaunchKernelGGL(t1, dim3(ntiles, gs), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,

@@ -216,6 +216,8 @@ static int upd_ctx(const pqn_update_args_t *a, int S, const uint64_t *key_roll_d
   // barrier costs more than the launch it saves) and unsafe when several updates are in flight on different
   // streams (two partially resident barrier grids could dead-lock), so the two-kernel version is the default.
   c.fused_opt = (a->reserved & 1) != 0;
+  // reserved bit 1: kernel form of the training launches from the minibatch size alone (pqn_seeds_t.pin_form)
+  c.sd.pin_form = (a->reserved & 2) != 0;
   PQN_REQUIRE(!(c.fused_opt && a->layout.matmul_f16 == 2), "pqn_cnn_update: the experimental one-kernel optimizer does not maintain the bf16x3 planes");
   return PQN_OK;
 }

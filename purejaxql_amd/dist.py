@@ -109,9 +109,47 @@ class PeerAllReduce:
         self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
         st.local_state = self.state.data_ptr()
         self.struct = st
+        self._host_state = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._poll_ev = None
         torch.cuda.synchronize(self.device)
         dist.barrier(group=self.group)   # every region is zeroed and mapped before the first publish
+        if not self._self_test():
+            self.close()
+            return False
         return True
+
+    def _self_test(self) -> bool:
+        """Collective.  Three all-reduces of a known bucket through the REAL kernels and mappings before the path is trusted
+        with gradients: rank r contributes (r + 1) * x, every rank must obtain exactly sum_r (r + 1) * x / W summed in rank
+        order.  This is where a node whose cross-device visibility differs from what the kernels assume (fine-grained
+        staging regions, system-scope flags and loads over hipIpc mappings) is caught -- at setup, with a 10-s time-out, and
+        answered by falling back to the torch.distributed collective on EVERY rank (the verdict is all-gathered)."""
+        from . import _lib
+        old = _lib.get_option("peer_timeout_s")
+        _lib.set_option("peer_timeout_s", 10)
+        ok = True
+        try:
+            g = torch.Generator(device="cpu")
+            for step in range(3):
+                g.manual_seed(424242 + step)
+                x = torch.randn(self.n, generator=g)
+                want = torch.zeros(self.n)
+                for r in range(self.world):
+                    want += x * float(r + 1)
+                want *= 1.0 / self.world
+                mine = (x * float(self.rank + 1)).to(self.device)
+                self(mine)
+                torch.cuda.synchronize(self.device)
+                ok = ok and bool(torch.equal(mine.cpu(), want))
+            err = C.c_int32(0)
+            ok = ok and _lib.load().pqn_peer_status(C.byref(self.struct), C.addressof(err)) == 0 and err.value == 0
+        except Exception:   # noqa: BLE001 -- any failure here means "do not use the path"
+            ok = False
+        finally:
+            _lib.set_option("peer_timeout_s", old)
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, bool(ok), group=self.group)
+        return all(verdicts)
 
     def __call__(self, flat_grad: torch.Tensor) -> None:
         from . import _lib
@@ -122,10 +160,31 @@ class PeerAllReduce:
     def check(self) -> None:
         """Synchronises; raises if a peer never arrived inside a collective (the kernels give up instead of hanging)."""
         from . import _lib
+        if self.struct is None:
+            return
         err = C.c_int32(0)
         _lib.check(_lib.load().pqn_peer_status(C.byref(self.struct), C.addressof(err)), "pqn_peer_status")
         if err.value:
-            raise RuntimeError("peer all-reduce: a rank did not publish its gradient in time (results are invalid)")
+            raise RuntimeError(f"peer all-reduce on rank {self.rank}: rank {err.value - 1} did not publish its gradient within "
+                               "the time-out (option peer_timeout_s); every optimizer step since then used unsynchronised "
+                               "gradients -- the run is invalid from that update on")
+
+    def poll(self) -> None:
+        """check() without stalling the stream: looks at the error word an EARLIER call copied to pinned host memory (raises
+        if it is set) and queues a fresh asynchronous copy.  Called once per update by the env-sharded training loop, so a
+        time-out is reported an update or two after it happened instead of at finish()."""
+        if self.struct is None:
+            return
+        if self._poll_ev is not None and self._poll_ev.query():
+            self._poll_ev = None
+            if int(self._host_state[2]):
+                bad = int(self._host_state[3]) - 1
+                raise RuntimeError(f"peer all-reduce on rank {self.rank}: rank {bad} did not publish its gradient within the "
+                                   "time-out (option peer_timeout_s); gradients are no longer synchronised -- stopping")
+        if self._poll_ev is None:
+            self._host_state.copy_(self.state, non_blocking=True)
+            self._poll_ev = torch.cuda.Event()
+            self._poll_ev.record()
 
     def close(self) -> None:
         from . import _lib
@@ -161,6 +220,10 @@ def make_grad_allreduce_hook(group: Optional[dist.ProcessGroup] = None, peer: Op
                     hook.capturable = True
                     hook.mode = "peer"
                     hook.check = par.check
+                    hook.poll = par.poll
+                    hook.close = par.close
+                else:
+                    hook.mode = "host (peer path unavailable or failed its self-test)"
         if box["peer"] is not None:
             box["peer"](flat_grad)
             return
@@ -170,6 +233,9 @@ def make_grad_allreduce_hook(group: Optional[dist.ProcessGroup] = None, peer: Op
     hook.capturable = False
     hook.mode = "host"
     hook.check = lambda: None
+    hook.poll = lambda: None
+    hook.close = lambda: None
+    hook.barrier = lambda: dist.barrier(group=group)   # host barrier of the ranks (after graph capture, before the first replay)
     return hook
 
 

@@ -610,10 +610,16 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             for name in ("env_step", "env_frame"):
                 row[METRIC_NAMES.index(name)] *= shard_world
 
+        forms = {}    # kernel forms of this run's launches (asked of the library after the first, eager, enqueue)
+
         def driver_update(u: int):
             if u != driver.calls:
                 raise RuntimeError(f"update({u}) out of order: the device clock is at {driver.calls}")
             driver.update()
+            if not forms and packed:
+                forms.update(zip(("train", "rollout"), _lib.last_kernel_form()))
+            if grad_hook is not None and hasattr(grad_hook, "poll"):
+                grad_hook.poll()       # in-graph peer all-reduce: a time-out surfaces within an update or two, not at finish()
             if shard_world > 1 or metrics_hook is not None:
                 share_metrics_row(driver.metrics[u])
             counters["timesteps"] += T * N
@@ -750,7 +756,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                             "driver_graphs": None if driver is None else (1 if getattr(driver, "whole", None) is not None else
                                                                           len(getattr(driver, "graphs", None) or [1])),
                             "allreduce": getattr(grad_hook, "mode", None) if grad_hook is not None else None,
-                            **policy.opt_state(), **counters})
+                            "kernel_forms": dict(forms), **policy.opt_state(), **counters})
             return {"runner_state": runner_state, "metrics": metrics}
 
         update.driver = driver   # bench.py switches graph replay off for its HIP-event timing pass
@@ -837,7 +843,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 drv = SeedsUpdateDriver(layout, base_env.env_id, S, N, T, MB, EPOCHS, base_env.obs_words, dcfg,
                                         [k[3] for k in Ks], [k[4] for k in Ks], config["LR"], 1e-20, lr_steps,
                                         config["MAX_GRAD_NORM"], ro, words, NUM_UPDATES, dev,
-                                        use_graph=config.get("_GRAPH", True))
+                                        use_graph=config.get("_GRAPH", True),
+                                        pin_form=bool(config.get("SEED_BATCH_BIT_IDENTICAL", False)))
             words[:, s * N:(s + 1) * N] = st.words
             (ro.bits if packed else ro.obs)[0, s * N:(s + 1) * N] = o0[1] if packed else o0
             th = network.init(K_init) if theta_init is None else theta_init.to(dev, torch.float32)   # (:150-173)
@@ -901,12 +908,15 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         test_period = int(NUM_UPDATES * config["TEST_INTERVAL"]) if test_on else 0
         test_rows = torch.zeros((S, NUM_UPDATES, len(INFO_KEYS)), dtype=torch.float32, device=dev) if test_on else None
         counters = {"timesteps": 0, "n_updates": 0, "grad_steps": 0}
+        forms = {}    # which kernel forms the library took for this batch (asked after the first, eager, enqueue)
 
         def update(u: int, enqueue: bool = True):
             if enqueue:     # (False: a SeedGroupsDriver already advanced this group's driver)
                 if u != drv.calls:
                     raise RuntimeError(f"update({u}) out of order: the device clock is at {drv.calls}")
                 drv.update()
+            if not forms:
+                forms.update(zip(("train", "rollout"), _lib.last_kernel_form()))
             counters["timesteps"] += T * N
             counters["n_updates"] += 1
             counters["grad_steps"] += MB * EPOCHS
@@ -933,7 +943,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                                 "backend": backend, "driver": "graph" if drv.graph is not None else "eager",
                                 "driver_graph_error": drv.graph_error, "opt_count": drv.count[s:s + 1],
                                 "opt_mu": drv.m[s, :layout.total], "opt_nu": drv.v[s, :layout.total],
-                                "kernel_layout": layout, "seed_batch": S, **counters})
+                                "kernel_layout": layout, "seed_batch": S, "kernel_forms": dict(forms), **counters})
                 outs.append({"runner_state": runner_state, "metrics": metrics})
             return outs
 

@@ -366,6 +366,12 @@ class EnvShardDriver(UpdateDriver):
                 except Exception as exc:  # stay on the per-segment path below (still the HIP path)
                     self.graph_error = repr(exc)
                     torch.cuda.synchronize()
+                # capture + instantiate take a rank-dependent time (hundreds of ms): meet on the host before the first
+                # replayed collective so that no rank's in-graph wait starts long before its peers can publish
+                barrier = getattr(self.grad_hook, "barrier", None)
+                if barrier is not None:
+                    torch.cuda.synchronize()
+                    barrier()
             if self.whole is not None:
                 self.whole.replay()
                 self.calls += 1
@@ -404,7 +410,8 @@ class SeedsUpdateDriver:
     and env state."""
 
     def __init__(self, layout, env_id, s, n, t, mb, epochs, obs_words, cfg, keys_roll, keys_shuf,
-                 lr, lr_end, lr_steps, max_norm, ro, words, num_updates, device, use_graph: bool = True):
+                 lr, lr_end, lr_steps, max_norm, ro, words, num_updates, device, use_graph: bool = True,
+                 pin_form: bool = False):
         lib = _lib.load()
         dev = torch.device(device)
         self.layout, self.s, self.n = layout, int(s), int(n)
@@ -457,6 +464,7 @@ class SeedsUpdateDriver:
             a.obs, a.wt = p(ro.obs), p(self.wt)
         else:
             a.obs_words, a.bits, a.w1b = obs_words, p(ro.bits), p(self.w1b)
+            a.reserved = 2 if pin_form else 0    # pqn_update_args_t.reserved bit 1: kernel form from the minibatch size alone
         a.action, a.reward, a.done, a.qmax = p(ro.action), p(ro.reward), p(ro.done), p(ro.qmax)
         a.discount, a.rer, a.rel, a.ts = p(ro.discount), p(ro.rer), p(ro.rel), p(ro.ts)
         a.target, a.last_q = p(ro.target), p(ro.last_q)

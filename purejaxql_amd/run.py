@@ -50,10 +50,13 @@ def single_run(config: Dict[str, Any], device: Optional[str] = None, make_train_
     if world > 1 and shard_mode == "envs":
         # every rank runs ALL seeds on its share of the envs; gradients are averaged over ranks per optimizer step
         cfg = pdist.shard_env_config(config, rank, world)
-        train = make_train_fn(cfg, device=device, grad_hook=pdist.make_grad_allreduce_hook(),
-                              metrics_hook=pdist.allreduce_mean_scalars)
+        ghook = pdist.make_grad_allreduce_hook()
+        train = make_train_fn(cfg, device=device, grad_hook=ghook, metrics_hook=pdist.allreduce_mean_scalars)
         mine = list(range(num_seeds))
-        outs = vmap_fn(train, keys, concurrent=False)
+        try:
+            outs = vmap_fn(train, keys, concurrent=False)
+        finally:
+            ghook.close()      # unmap the peers' staging regions of the in-graph all-reduce, free our own
         metrics = outs["metrics"]
         saver = rank == 0
     else:
@@ -68,6 +71,15 @@ def single_run(config: Dict[str, Any], device: Optional[str] = None, make_train_
         torch.distributed.barrier()
     if rank == 0:
         print(f"Took {time.time() - t0} seconds to complete.")      # (:462)
+        rs0 = outs["runner_state"][0] if outs["runner_state"] else None
+        forms = rs0.get("kernel_forms") if rs0 is not None and hasattr(rs0, "get") else None
+        if forms:
+            # which form of the training / rollout kernels these launches took.  A seed batch normally takes the kernels its
+            # seeds would take alone and is bit-identical to the solo runs; the one exception (f32 operands, minibatches <=
+            # 256 samples, more than t1_ksplit_tiles tiles x seeds per launch: "single" here, "ksplit" alone) agrees with
+            # the solo runs to f32 summation order only -- SEED_BATCH_BIT_IDENTICAL=True pins the solo form
+            print(f"kernel forms: training={forms.get('train')} rollout={forms.get('rollout')} "
+                  f"(seed batch of {rs0.get('seed_batch', 1)}, SEED_BATCH_BIT_IDENTICAL={bool(config.get('SEED_BATCH_BIT_IDENTICAL', False))})")
     if config.get("SAVE_PATH", None) is not None:
         save_dir = os.path.join(config["SAVE_PATH"], env_name)
         os.makedirs(save_dir, exist_ok=True)

@@ -167,6 +167,76 @@ def test_peer_allreduce_two_processes_on_one_gpu(gpu, n):
         np.testing.assert_array_equal(o0[s], r0[s], err_msg=f"step {s}")
 
 
+def _peer_timeout_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import time
+    import torch.distributed as dist
+    from purejaxql_amd import _lib
+    from purejaxql_amd import dist as pdist
+    pdist.init_from_env()
+    dev = torch.device("cuda:0")
+    n = 4099
+    par = pdist.PeerAllReduce(n, dev)
+    ok = par.setup()            # includes the 3-step self-test through the real kernels
+    res = {"ok": ok}
+    if ok:
+        _lib.set_option("peer_timeout_s", 2)
+        x = torch.full((n,), float(rank + 1), device=dev)
+        par(x)                  # step 4: both ranks take part
+        torch.cuda.synchronize()
+        res["step_ok"] = bool(torch.equal(x.cpu(), torch.full((n,), 1.5)))
+        if rank == 0:           # rank 1 never publishes step 5: rank 0's wait must end after ~2 s of WALL CLOCK with the error word set
+            t0 = time.time()
+            par(x)
+            torch.cuda.synchronize()
+            res["waited_s"] = time.time() - t0
+            par.poll()          # queues the asynchronous copy of the error word ...
+            torch.cuda.synchronize()
+            try:
+                par.poll()      # ... and the next call sees it
+                res["poll_raised"] = False
+            except RuntimeError as exc:
+                res["poll_raised"] = "rank 1" in str(exc)
+            try:
+                par.check()
+                res["check_raised"] = False
+            except RuntimeError as exc:
+                res["check_raised"] = "rank 1" in str(exc)
+            t1 = time.time()
+            par(x)              # after a time-out every later collective fails fast
+            torch.cuda.synchronize()
+            res["fail_fast_s"] = time.time() - t1
+    q.put((rank, res))
+    dist.barrier()
+    par.close()
+    dist.destroy_process_group()
+
+
+def test_peer_allreduce_time_out_is_wall_clock_and_reported(gpu):
+    """The in-graph peer all-reduce with a rank that never publishes (round 4 hardening): the waiting rank gives up after the
+    configured WALL-CLOCK time (option peer_timeout_s = 2 here; rounds 1-3 counted polls), leaves a sticky error word that
+    names the missing rank, PeerAllReduce.poll() -- the training loop's once-per-update, non-blocking look at it -- and
+    check() raise, and later collectives fail fast instead of waiting again.  setup() has by then passed its self-test
+    (three all-reduces of a known bucket through the real kernels, verdict all-gathered)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_timeout_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0]["ok"] and res[1]["ok"], "hipIpc peer mapping is unavailable on this box"
+    assert res[0]["step_ok"] and res[1]["step_ok"]
+    assert 1.5 <= res[0]["waited_s"] <= 6.0, res[0]
+    assert res[0]["poll_raised"] is True and res[0]["check_raised"] is True, res[0]
+    assert res[0]["fail_fast_s"] < 1.0, res[0]
+
+
 @pytest.mark.parametrize("mode", ["seeds", "envs"])
 def test_bench_gpus_2_launches_its_own_ranks(gpu, mode):
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command line) re-executes itself

@@ -243,12 +243,15 @@ def test_fc1_weight_gradient_without_split_k_partials_is_bit_identical(gpu, nb, 
 
 def test_forced_pair_forms_at_small_sizes_in_process(gpu):
     """The pair forms forced at sizes where they are not selected by default (pqn_set_option, in-process): the training
-    kernel at 2, 8 and 256 pairs (C = 4; at C = 6 its LDS plan does not fit and the single-tile kernel must be what runs) -- repeats bit-identical, equal to the single-tile bf16x3
-    kernel bit for bit and to the f32-MFMA mode to f32 rounding; the rollout kernel bit-identical in every output."""
+    kernel at 2, 8 and 256 pairs (C = 4), and -- round 4, head-parameter block of the LDS plan sized by the action count --
+    at C = 6 (SpaceInvaders' shape) and C = 7 (Freeway's); C = 10 with 6 actions still exceeds the 160 KB and must run the
+    single-tile kernel.  Repeats bit-identical, equal to the single-tile bf16x3 kernel bit for bit and to the f32-MFMA mode
+    to f32 rounding."""
     from purejaxql_amd import _lib
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
-    for c, a, nb, pool in ((4, 3, 64, 256), (4, 3, 256, 1000), (4, 3, 8192, 20000), (6, 4, 1024, 2000)):
+    for c, a, nb, pool in ((4, 3, 64, 256), (4, 3, 256, 1000), (4, 3, 8192, 20000), (6, 4, 1024, 2000), (7, 3, 512, 1000),
+                           (4, 5, 512, 1000), (10, 6, 512, 1000)):
         rng = np.random.default_rng(nb + c)
         torch.manual_seed(1234)
         net = QNetwork("cnn", (10, 10, c), a, device=gpu)
@@ -264,9 +267,9 @@ def test_forced_pair_forms_at_small_sizes_in_process(gpu):
                 lay = CnnKernelLayout(c, a, matmul_f16=mode)
                 tr = CnnTrainer(lay, theta, 5e-4, 10.0, max_minibatch=nb)
                 reps = [tr.compute_grad(idx, bits, action, target)[:lay.total].clone() for _ in range(3)]
-                # C = 6: the pair kernel's LDS plan (164,864 B) exceeds the 160 KB of a CU, so the switch cannot select it
+                # C = 10: the pair kernel's LDS plan exceeds the 160 KB of a CU, so the switch cannot select it
                 # (and the f32 operand mode takes its K-split form at minibatches of at most 256 samples)
-                want = "pair" if (pair and c == 4) else ("ksplit" if (mode == 0 and nb <= 256) else "single")
+                want = "pair" if (pair and c != 10) else ("ksplit" if (mode == 0 and nb <= 256) else "single")
                 assert _lib.last_kernel_form()[0] == want, (name, c, nb)
                 assert torch.equal(reps[0], reps[1]) and torch.equal(reps[0], reps[2]), (name, c, nb)
                 res[name] = reps[0]

@@ -75,6 +75,48 @@ def test_vmap_train_seeds_are_independent_and_stacked(gpu):
             torch.testing.assert_close(a["theta"], b["theta"], rtol=0, atol=0)
 
 
+def test_ten_seed_yaml_default_batch_against_its_solo_runs(gpu):
+    """The one regime where a seed batch does NOT take the kernels of its solo runs: the yaml default
+    (f32 operands, 128 envs -> 128-sample minibatches = 8 tiles) with 10 seeds in the launch is 80 tiles > t1_ksplit_tiles =
+    48, so the batch runs the single-tile training kernel while a solo run takes the K-split form.  The forms are recorded
+    in runner_state["kernel_forms"] (run.py prints them); the two agree to f32 summation order -- stated here as a bound:
+    after 3 updates (192 optimizer steps) every metric to 1e-4 relative and theta to 2 lr per element (RAdam's sign-like
+    steps turn a rounding-level gradient difference into at most one step of either sign per optimizer step, and the
+    differing elements are rare).  SEED_BATCH_BIT_IDENTICAL=True pins the solo form: bit-identical, K-split in both.
+    (jax.vmap over seeds, pqn_minatar.py:459-461.)"""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys, vmap_train
+    S, n_upd = 10, 3
+    keys = seed_keys(5, S)
+
+    def cfg(**kw):
+        c = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", "alg.TEST_DURING_TRAINING=False"]))
+        c["TOTAL_TIMESTEPS"] = n_upd * c["NUM_ENVS"] * c["NUM_STEPS"]
+        c.update(kw)
+        return c
+
+    assert cfg()["NUM_ENVS"] == 128 and str(cfg().get("MATMUL_DTYPE", "f32")) == "f32"
+    batch = vmap_train(make_train(cfg(), device="cuda:0"), keys)
+    pinned = vmap_train(make_train(cfg(SEED_BATCH_BIT_IDENTICAL=True), device="cuda:0"), keys)
+    assert batch["runner_state"][0]["kernel_forms"]["train"] == "single"
+    assert pinned["runner_state"][0]["kernel_forms"]["train"] == "ksplit"
+    lr = float(cfg()["LR"])
+    worst = 0.0
+    for s in (0, 4, 9):
+        solo = make_train(cfg(), device="cuda:0")(keys[s])
+        assert solo["runner_state"]["kernel_forms"]["train"] == "ksplit"
+        for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "timestep"):
+            assert torch.equal(pinned["metrics"][k][s], solo["metrics"][k]), (s, k)
+            torch.testing.assert_close(batch["metrics"][k][s], solo["metrics"][k], rtol=1e-4, atol=1e-5)
+        assert torch.equal(pinned["runner_state"][s]["theta"], solo["runner_state"]["theta"]), s
+        assert torch.equal(pinned["runner_state"][s]["env_state"], solo["runner_state"]["env_state"]), s
+        d = (batch["runner_state"][s]["theta"] - solo["runner_state"]["theta"]).abs()
+        worst = max(worst, float(d.max()))
+        assert float(d.max()) <= 2.0 * lr and float((d > 1e-5).float().mean()) < 0.02, (s, float(d.max()))
+        assert torch.equal(batch["runner_state"][s]["env_state"], solo["runner_state"]["env_state"]), s   # same actions so far
+    assert worst > 0.0     # the default batch really is not bit-identical here: that is what the switch is for
+
+
 def test_single_run_saves_reference_format_checkpoints(gpu, tmp_path):
     from purejaxql_amd.config_loader import load_config
     from purejaxql_amd.networks import QNetwork
