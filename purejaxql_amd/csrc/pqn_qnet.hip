@@ -166,6 +166,27 @@ PQN_D f32x4 x3_mfma_tied(const u32x4 &a, const u32x4 &b, f32x4 c) {
   return c;
 }
 #define X3_MFMA(A, B, C) x3_mfma_tied(A, B, C)
+// De-phasing the two waves of a SIMD (round 4).  Waves w and w + 4 of a 512-thread workgroup share a SIMD; released by the
+// same barrier they run the same loop in lockstep -- both in their MFMA burst, then both in their VALU / LDS / load part --
+// and the two instruction classes add up instead of overlapping (T2: 51 us of data movement + 47 us of matrix pipe = 101 us,
+// profiles/r04_v1_t2_ablate.txt; fc1: 1.8k cycles per K step against ~1.0k issue slots).  A one-off s_sleep of about half a
+// loop period on waves 4..7 in front of a barrier-free loop puts one wave's MFMA burst beside the other's VALU part for the
+// whole loop.  Timing only: no effect on results.  (-DX3_SKEW_* = s_sleep argument, units of 64 clocks; 0 = off.)
+#ifndef X3_SKEW_FC1
+#define X3_SKEW_FC1 0
+#endif
+#ifndef X3_SKEW_DGRAD
+#define X3_SKEW_DGRAD 0
+#endif
+#ifndef X3_SKEW_T2
+#define X3_SKEW_T2 0
+#endif
+template <int N>
+PQN_D void x3_skew(int wave) {
+  if constexpr (N > 0) {
+    if (wave >= 4) __builtin_amdgcn_s_sleep(N);
+  }
+}
 // GROUPS of independent MFMAs (different accumulators) as ONE asm statement with ONE leading `s_nop 1` (round 4).  The pad
 // in front of a single MFMA covers a VALU write of one of its operands in the preceding issue slots -- the compiler cannot
 // see inside the asm string and schedules its own VALU instructions between the statements -- but inside a run of MFMAs
@@ -774,6 +795,7 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
     side(g + i, i);
     __builtin_amdgcn_sched_barrier(0);
   };
+  x3_skew<X3_SKEW_FC1>(wave);
   int g = 0;
 #pragma unroll 1
   for (; g + 2 * PF <= NS; g += PF) {
@@ -1538,6 +1560,7 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
       p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
       p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
     };
+    x3_skew<X3_SKEW_DGRAD>(wave);
 #pragma unroll 1
     for (int ibk = 0; ibk < IBW - 1; ++ibk) ib_step(ibk, std::true_type{});
     ib_step(IBW - 1, std::false_type{});
@@ -3776,6 +3799,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, c
       pre[us] = fetch(qs + 1, us);                               // refill the slot: the same step one iteration further on
       if (last) {
         if (!(T2_ABL & 16)) __syncthreads();   // the next group's planes complete; this group's half may be overwritten from now on
+        x3_skew<X3_SKEW_T2>(wave);
         load_plane(tnext, 2, al);
         load_plane(tnext, 1, am);
         load_plane(tnext, 0, ah);

@@ -132,6 +132,93 @@ def test_c5_yaml_shape_loop_vs_oracle_on_craftax_classic(gpu, oracle):
             assert np.abs(_np(bs[k]) - v).max() <= 1e-3 * max(np.abs(v).max(), 1e-3), k
 
 
+def test_c5_trajectory_gradients_match_oracle_at_same_theta(gpu, oracle):
+    """The same-theta counterpart of test_c5_yaml_shape_loop_vs_oracle_on_craftax_classic (whose whole-loop criterion is a
+    cosine: RAdam's sign-like first steps amplify rounding-level gradient entries): the oracle walks 6 updates of the
+    yaml's C5 loop on Craftax-Classic (1024 envs, 1 step, optimistic resets ratio 16, BatchRenorm input, 1-step loss on
+    concat(obs, next_obs), clip 1.0 + RAdam) and at EVERY update the wide-MLP kernels (pqn_bigmlp_grad) are evaluated AT THE
+    ORACLE'S parameters and running statistics on the oracle's own transition batch: loss to 1e-4, every gradient entry
+    to rtol 2e-3 (given the kernel's relu decisions, which may differ from the oracle's only at |h| <= 1e-4), updated
+    BatchRenorm statistics to 1e-5.  Reference lines: pqn_craftax.py:181-224,277-312; utils/batch_renorm.py:95-116."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.networks import QNetwork, bn_module
+    from purejaxql_amd.qnet import BigMlpKernelLayout, BigMlpTrainer
+    O = oracle
+    cfg = flatten(load_config(["+alg=pqn_craftax", "alg.ENV_NAME=Craftax-Classic-Symbolic-v1"]))
+    N, d, h, layers, a = int(cfg["NUM_ENVS"]), 1345, int(cfg["HIDDEN_SIZE"]), int(cfg["NUM_LAYERS"]), 17
+    assert (N, cfg["NUM_STEPS"], cfg["NUM_MINIBATCHES"], cfg["NUM_EPOCHS"], h, layers) == (1024, 1, 1, 1, 1024, 4)
+    ratio, gamma, lr, clip = int(cfg["OPTIMISTIC_RESET_RATIO"]), float(cfg["GAMMA"]), float(cfg["LR"]), float(cfg["MAX_GRAD_NORM"])
+    n_upd = 6
+    env = O.OracleEnv("Craftax-Classic-Symbolic-v1")
+    net = QNetwork("mlp", (d,), a, norm_type="layer_norm", norm_input=True, hidden_size=h, num_layers=layers, device=gpu, renorm=True)
+    lay = BigMlpKernelLayout(d, h, layers, a, 2)
+    theta0 = net.init(21)
+    tr = BigMlpTrainer(lay, theta0, lr, clip)
+    shapes = O.mlp_shapes(d, a, h, layers, "layer_norm", True)
+    bn0 = bn_module(True) + "_0"
+    th = _np(theta0).copy()
+    p = O.unflatten(th, shapes)
+    m, v = np.zeros_like(th), np.zeros_like(th)
+    stats = O.init_batch_stats("mlp", (d,), h, layers, "layer_norm", True, True)
+    nkw = dict(layers=layers, norm_type="layer_norm", norm_input=True, renorm=True)
+    obs, st = env.reset(77, N)
+    obs = obs.reshape(N, -1)
+    worst = 0.0
+    for u in range(n_upd):
+        eps = O.linear_schedule(cfg["EPS_START"], cfg["EPS_FINISH"], 10.0, u)
+        q = O.net_forward("mlp", p, obs, stats=stats, **nkw)
+        act, _qm = O.eps_greedy(q, np.float32(eps), 1000 + u)
+        o_next, st, rew, done, _info = env.step_optimistic(1000 + u, st, act, ratio)
+        o_next = o_next.reshape(N, -1)
+        obs_all = np.concatenate((obs, o_next)).astype(np.float32)            # the [T+1][N] record with T = 1
+        idx = O.permutation(O.fold_in(55, u), N).astype(np.int64)
+        # --- the kernels at the oracle's theta / statistics
+        tr.theta.copy_(lay.to_kernel(torch.from_numpy(th).to(gpu)))
+        tr.refresh_planes()
+        tr.in_mean.copy_(torch.from_numpy(np.asarray(stats[bn0 + "/mean"], np.float32)))
+        tr.in_var.copy_(torch.from_numpy(np.asarray(stats[bn0 + "/var"], np.float32)))
+        tr.in_steps[0] = int(stats[bn0 + "/steps"])
+        lo_t, qv_t = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+        g = tr.compute_grad(torch.from_numpy(idx).to(gpu), torch.from_numpy(obs_all).to(gpu), torch.from_numpy(act).to(gpu),
+                            reward=torch.from_numpy(rew).to(gpu), done=torch.from_numpy(done.astype(np.uint8)).to(gpu), gamma=gamma,
+                            next_offset=N, loss_out=lo_t, qv_out=qv_t).clone()
+        # --- the oracle's value_and_grad, spelled out so that its backward takes the kernel's relu decisions
+        new_stats = {}
+        xx = np.concatenate((obs_all[idx], obs_all[idx + N])).astype(np.float32)
+        q_all, cache = O.net_forward("mlp", p, xx, want_cache=True, train=True, stats=stats, new_stats=new_stats, **nkw)
+        flips = 0
+        for l in range(layers):
+            hk, ho = _np(tr.intermediate(2 * N, N, "h", l)), cache["hs"][l + 1]
+            np.testing.assert_allclose(hk, ho, rtol=1e-4, atol=1e-4, err_msg=f"update {u} h_{l}")
+            mism = (hk > 0) != (ho > 0)
+            flips += int(mism.sum())
+            assert not mism.any() or float(np.maximum(hk, ho)[mism].max()) <= 1e-4, (u, l)
+            cache["hs"][l + 1] = hk.copy()
+        assert flips <= 64, (u, flips)
+        qo, q_next = q_all[:N], q_all[N:]
+        tgt = (rew[idx] + (np.float32(1) - done[idx].astype(np.float32)) * np.float32(gamma) * q_next.max(-1)).astype(np.float32)
+        chosen = qo[np.arange(N), act[idx]]
+        diff = (chosen - tgt).astype(np.float32)
+        lo = np.float32(0.5) * np.mean(diff * diff, dtype=np.float32)
+        dq = np.zeros_like(q_all)
+        dq[np.arange(N), act[idx]] = diff / np.float32(N)
+        g_ref = O._net_backward("mlp", p, shapes, xx, cache, dq, layers, True)
+        assert abs(float(lo_t) - lo) <= 1e-4 * max(1.0, abs(lo)), (u, float(lo_t), lo)
+        g_flax = _np(lay.to_flax(g))
+        np.testing.assert_allclose(g_flax, g_ref, rtol=2e-3, atol=1e-5 * np.abs(g_ref).max() + 1e-9, err_msg=f"update {u}")
+        worst = max(worst, float(np.abs(g_flax - g_ref).max() / np.abs(g_ref).max()))
+        np.testing.assert_allclose(_np(tr.in_mean), new_stats[bn0 + "/mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(_np(tr.in_var), new_stats[bn0 + "/var"], rtol=1e-5, atol=1e-6)
+        assert int(tr.in_steps[0]) == int(new_stats[bn0 + "/steps"]) == u + 1
+        # --- the oracle moves on (its own gradient: the trajectory is the oracle's)
+        _lo2, _ch2, g_or = O.net_loss_grad_1step("mlp", p, shapes, obs_all[idx], obs_all[idx + N], act[idx], rew[idx], done[idx],
+                                                 gamma, stats=stats, new_stats={}, **nkw)
+        O.radam_clip_step(th, g_or, m, v, u, np.float32(lr), np.float32(clip))
+        stats.update(new_stats)
+        obs = o_next
+    assert worst < 2e-3, worst
+
+
 @pytest.mark.parametrize("env_name,n,t,upd", [("Breakout-MinAtar", 64, 4, 40), ("Craftax-Classic-Symbolic-v1", 128, 1, 30)])
 def test_craftax_script_seeds_as_concurrent_streams_equal_solo_runs(gpu, env_name, n, t, upd):
     """NUM_SEEDS > 1 on the Craftax script runs the seeds as concurrent HIP streams (the torch-op network has no
