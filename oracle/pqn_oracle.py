@@ -363,6 +363,9 @@ def _bn_bwd(dy, scale, cache):
 BRN_EPS, BRN_MOMENTUM, BRN_R_MAX, BRN_D_MAX, BRN_WARMUP = np.float32(1e-3), np.float32(0.999), np.float32(3.0), np.float32(5.0), 1000
 
 
+MOMENTS_DTYPE = np.float32   # batch moments of brn_fwd: f32 = the flax restatement (default); see the note inside
+
+
 def brn_fwd(x, scale, bias, stats, train, new_stats=None):
     f = x.shape[-1]
     x2 = x.reshape(-1, f).astype(np.float32)
@@ -370,8 +373,13 @@ def brn_fwd(x, scale, bias, stats, train, new_stats=None):
         mean, var = stats["mean"], stats["var"]
         cache = None
     else:
-        bmean = x2.mean(0, dtype=np.float32)
-        bvar = np.maximum((x2 * x2).mean(0, dtype=np.float32) - bmean * bmean, np.float32(0))
+        # flax's fast variance E[x^2] - E[x]^2 in f32 (MOMENTS_DTYPE).  For near-constant columns (a symbolic observation has
+        # many) it cancels catastrophically: two correct f32 implementations then differ at the 1e-3 level.  Tests that need
+        # to tell such conditioning apart from an error set MOMENTS_DTYPE = np.float64 -- the value both approximate.
+        md = MOMENTS_DTYPE
+        bmean64 = x2.mean(0, dtype=md)
+        bvar = np.maximum((x2.astype(md) * x2.astype(md)).mean(0, dtype=md) - bmean64 * bmean64, 0).astype(np.float32)
+        bmean = bmean64.astype(np.float32)
         mean, var = bmean, bvar
         r = d = None
         if int(stats["steps"]) >= BRN_WARMUP:

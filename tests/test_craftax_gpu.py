@@ -164,6 +164,21 @@ def test_c5_trajectory_gradients_match_oracle_at_same_theta(gpu, oracle):
     obs, st = env.reset(77, N)
     obs = obs.reshape(N, -1)
     worst = 0.0
+    # Batch moments of the BatchRenorm input layer in f64 on the oracle's side: a Craftax observation is full of
+    # near-constant columns, for which flax's f32 fast variance E[x^2] - E[x]^2 cancels -- the oracle's own f32 restatement
+    # and the kernels (which accumulate these moments in f64) then differ by up to 2.5e-3 in h_0 with
+    # neither being wrong.  With exact moments the comparison isolates everything else at the usual tolerances.
+    O.MOMENTS_DTYPE = np.float64
+    try:
+        worst = _c5_trajectory(O, env, tr, lay, shapes, p, th, m, v, stats, nkw, obs, st, cfg, N, layers, ratio, gamma, lr, clip, bn0,
+                               n_upd, gpu)
+    finally:
+        O.MOMENTS_DTYPE = np.float32
+    assert worst < 2e-3, worst
+
+
+def _c5_trajectory(O, env, tr, lay, shapes, p, th, m, v, stats, nkw, obs, st, cfg, N, layers, ratio, gamma, lr, clip, bn0, n_upd, gpu):
+    worst = 0.0
     for u in range(n_upd):
         eps = O.linear_schedule(cfg["EPS_START"], cfg["EPS_FINISH"], 10.0, u)
         q = O.net_forward("mlp", p, obs, stats=stats, **nkw)
@@ -216,7 +231,7 @@ def test_c5_trajectory_gradients_match_oracle_at_same_theta(gpu, oracle):
         O.radam_clip_step(th, g_or, m, v, u, np.float32(lr), np.float32(clip))
         stats.update(new_stats)
         obs = o_next
-    assert worst < 2e-3, worst
+    return worst
 
 
 @pytest.mark.parametrize("env_name,n,t,upd", [("Breakout-MinAtar", 64, 4, 40), ("Craftax-Classic-Symbolic-v1", 128, 1, 30)])
