@@ -47,6 +47,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define QN_MAXA 8
 #define QN_HP_FLOATS (384 + 128 * QN_MAXA + QN_MAXA)   // head parameters staged in LDS
 #define QN_STG 20        // floats per staged point (16 + pad: conflict-free ds_read_b128 across lanes)
+// bf16x3 kernels (in-place conv staging): the h1 tile keeps the quad swizzle of its staging slots -- feature i of a row
+// lives at slot i ^ (((i >> 6) & 3) << 2), i.e. the four 16-B quads of position p are XORed with (p >> 2) & 3 (round 4).
+// The conv phase's final ds_write_b128 of a lane's 64 B (lane = position, lane stride 64 B) was a 4-way bank conflict
+// with the plain layout; swizzled it goes to the very slots the lane just read its staged values from, conflict-free.
+// Readers (fc1 A fragments, the h1^T slices, the relu mask of the in-place dgrad) apply the same map.
+#ifndef QN_H1_SWIZZLE
+#define QN_H1_SWIZZLE 1
+#endif
+__device__ __forceinline__ int h1_slot(int i) { return QN_H1_SWIZZLE ? (i ^ (((i >> 6) & 3) << 2)) : i; }
 
 template <int C>
 struct CnnCfg {
@@ -517,6 +526,7 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, 
       rkeep[mm] = rstd;
     }
     f32x4 *dst = reinterpret_cast<f32x4 *>(s.h1 + m * QN_H1S + lane * 16);
+    const int sw = (INPLACE && QN_H1_SWIZZLE) ? ((lane >> 2) & 3) : 0;   // h1_slot: the quads of position `lane`
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       f32x4 y;
@@ -524,7 +534,7 @@ PQN_D void phase1_conv(const CnnSmem &s, int tid, float (*xkeep)[16] = nullptr, 
       y.y = fmaxf(fmaf(xhat[4 * qd + 1], bc[16 + 4 * qd + 1], bc[32 + 4 * qd + 1]), 0.0f);
       y.z = fmaxf(fmaf(xhat[4 * qd + 2], bc[16 + 4 * qd + 2], bc[32 + 4 * qd + 2]), 0.0f);
       y.w = fmaxf(fmaf(xhat[4 * qd + 3], bc[16 + 4 * qd + 3], bc[32 + 4 * qd + 3]), 0.0f);
-      dst[qd] = y;
+      dst[qd ^ sw] = y;
     }
   }
 }
@@ -718,9 +728,10 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(planes);
   const float *arow[NT];
   float *zt[NT];
-  arow[0] = s.h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4);
+  arow[0] = s.h1 + (lane & 15) * QN_H1S;     // + h1_slot(32 st + kq4) (+ 16): the lane's two quads of K step st
   zt[0] = s.z;
-  if (NT == 2) { arow[NT - 1] = s2->h1 + (lane & 15) * QN_H1S + 4 * (lane >> 4); zt[NT - 1] = s2->z; }
+  if (NT == 2) { arow[NT - 1] = s2->h1 + (lane & 15) * QN_H1S; zt[NT - 1] = s2->z; }
+  const int kq4 = 4 * (lane >> 4);
   auto wfrag = [&](int p, int st, int c) {   // plane p, K step st (global), column block 2cp + c
 #ifdef T1_NO_WLOAD
     return wf[(size_t)p * (X3_PLANE / 8) + ((0 * 8 + 2 * cp + c) * 64 + lane)];
@@ -766,17 +777,18 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
   f32x4 a0n[NT], a1n[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    a0n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + 32 * st0);
-    a1n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + 32 * st0 + 16);
+    a0n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + h1_slot(32 * st0 + kq4));
+    a1n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + h1_slot(32 * st0 + kq4) + 16);
   }
   auto one_step = [&](int g, int i, bool reload) {
     f32x4 a0[NT], a1[NT];
     const int stn = NS * kh + ((g + i + 1 + rot) & (NS - 1));   // next step's A fragments (wraps harmlessly at the end)
+    const int sln = h1_slot(32 * stn + kq4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       a0[t] = a0n[t]; a1[t] = a1n[t];
-      a0n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + 32 * stn);
-      a1n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + 32 * stn + 16);
+      a0n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + sln);
+      a1n[t] = *reinterpret_cast<const f32x4 *>(arow[t] + sln + 16);
     }
     __builtin_amdgcn_sched_barrier(0);
     X3Frag af[NT], bq[2];
@@ -1535,7 +1547,8 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
         m2 = (float)((mw[2] >> bsel) & 1ull);
         m3 = (float)((mw[3] >> bsel) & 1ull);
       } else {
-        m0 = p0[0]; m1 = p0[QN_H1S]; m2 = p0[2 * QN_H1S]; m3 = p0[3 * QN_H1S];
+        const float *pm = out + r0 * QN_H1S + h1_slot(16 * ib + col);   // the forward h1 tile is quad-swizzled (h1_slot)
+        m0 = pm[0]; m1 = pm[QN_H1S]; m2 = pm[2 * QN_H1S]; m3 = pm[3 * QN_H1S];
       }
       // four accumulators per K parity ({small, leading} x 2): reuse distance 6 in issue order (see phase2_fc1_x3)
       f32x4 acc_b[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -1825,7 +1838,8 @@ PQN_D void t1_dgrad_pair2_x3(const float *ztA, float *outA, const u32x4 *planesB
     const int ib = ib_first + ((ibk + prot) & (IBW - 1));
     const int off = r0 * QN_H1S + 16 * ib + col;
     float *pA = outA + off, *pB = outB + off;
-    const float m0 = pA[0], m1 = pA[QN_H1S], m2 = pA[2 * QN_H1S], m3 = pA[3 * QN_H1S];   // tile A: relu mask = its h1, in place
+    const float *pmA = outA + r0 * QN_H1S + h1_slot(16 * ib + col);
+    const float m0 = pmA[0], m1 = pmA[QN_H1S], m2 = pmA[2 * QN_H1S], m3 = pmA[3 * QN_H1S];   // tile A: relu mask = its h1 (quad-swizzled), in place
     const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(maskB) + ib * 4;   // tile B: packed bits
     const int bsel = col * 4 + (lane >> 4);
     const unsigned long long w0 = mw[0], w1 = mw[1], w2 = mw[2], w3 = mw[3];
@@ -2152,7 +2166,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
 #ifndef T1_NO_H1T
       if (!(j & 1)) {
         const int e = tid + (j >> 1) * QN_THREADS, i = e >> 2, mq = e & 3;
-        const float *src = s.h1 + (4 * mq) * QN_H1S + i;
+        const float *src = s.h1 + (4 * mq) * QN_H1S + h1_slot(i);
         const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
         ws_store(reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0 + 4 * mq)), v);
       }
@@ -2923,7 +2937,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
     auto h1t_slice = [&](int j, int jc) {   // jc = j % 2 at compile time (PF = 2)
       const int t = jc & 1, e = tid + (j >> 1) * QN_THREADS;
       const int i = e >> 2, mq = e & 3;
-      const float *src = (t ? h1B : h1A) + (4 * mq) * QN_H1S + i;
+      const float *src = (t ? h1B : h1A) + (4 * mq) * QN_H1S + h1_slot(i);
       const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
       ws_store(reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0T[0] + QN_TILE * t + 4 * mq)), v);
       if (t == 1) {
@@ -3969,13 +3983,15 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
     const float *src = (from_pos ? gpos : gpart) + (r >= 0 ? r : 0);
     const int stride = from_pos ? convblk : rec, n = r < 0 ? 0 : (from_pos ? npos : ntiles);
     const int n_all = (gpos && npos > ntiles) ? npos : ntiles;   // uniform loop bound
+    // 16 loads in flight per lane (round 4; 8 before: the fold of 256 records per seed was 8 dependent HBM round trips per
+    // wave); the order of the additions -- records wave, wave + 4, wave + 8, ... -- is unchanged
     float g = 0.0f;
-    for (int t0 = wave; t0 < n_all; t0 += 32) {
-      float v[8];
+    for (int t0 = wave; t0 < n_all; t0 += 64) {
+      float v[16];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = src[(size_t)max(min(t0 + 4 * q, n - 1), 0) * stride];
+      for (int q = 0; q < 16; ++q) v[q] = src[(size_t)max(min(t0 + 4 * q, n - 1), 0) * stride];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) g += v[q] * ((t0 + 4 * q < n) ? 1.0f : 0.0f);
+      for (int q = 0; q < 16; ++q) g += v[q] * ((t0 + 4 * q < n) ? 1.0f : 0.0f);
     }
     s_red[wave][lane] = g;
     __syncthreads();
