@@ -143,7 +143,8 @@ def kernel_timer_pass(lib, update, first, mb_samples, seeds):
 def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sample=T1_FLOP_PER_SAMPLE):
     achieved = flop_per_sample * mb_samples * seeds / avg_s / 1e12
     traffic, tsrc, l2cu = None, None, None
-    for name in (f"r03_pmc_train_kernel_{matmul}_seeds{seeds}.json", f"r02_pmc_train_kernel_{matmul}_seeds{seeds}.json",
+    for name in (f"r04_pmc_train_kernel_{matmul}_seeds{seeds}.json", f"r03_pmc_train_kernel_{matmul}_seeds{seeds}.json",
+                 f"r02_pmc_train_kernel_{matmul}_seeds{seeds}.json",
                  f"r02_pmc_train_kernel_{matmul}.json", "r01_pmc_train_kernel.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
