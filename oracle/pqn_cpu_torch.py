@@ -102,7 +102,7 @@ def make_train(config, threads=None):
                     oracle.radam_clip_step(theta, g, m, v, grad_steps, np.float32(lr), np.float32(config["MAX_GRAD_NORM"]))
                     grad_steps += 1
                     losses.append(float(loss.detach()))
-                    qvs.append(float(chosen.mean()))
+                    qvs.append(float(chosen.detach().mean()))
             n_updates += 1
             metrics.append({"env_step": n_updates * T * N, "update_steps": n_updates, "grad_steps": grad_steps,
                             "td_loss": float(np.mean(losses)), "qvals": float(np.mean(qvs))})

@@ -18,6 +18,15 @@ Q-network module, and writes small .npz fixtures next to this file:
     ref_qnet.npz            QNetwork.apply + value_and_grad(_loss_fn) (pqn_minatar.py:24-69,271-291) on a fixed batch
     ref_radam.npz           5 steps of optax.chain(clip_by_global_norm, radam(linear_schedule)) (:140-147,159-162)
     ref_qlambda.npz         the Q(lambda) scan (:237-260) on the KA1 inputs of SURVEY 8(c) and on a random [32, 64] case
+    ref_craftax_qnet.npz    the Craftax script's QNetwork (pqn_craftax.py:33-62: BatchRenorm input, LayerNorm MLP) --
+                            value_and_grad of the `Q_LAMBDA: False` loss (:287-304) on concat(obs, next_obs), cold and
+                            warm BatchRenorm statistics (utils/batch_renorm.py:95-116), updated batch_stats, eval forward
+    ref_optimistic.npz      OptimisticResetVecEnvWrapper(LogWrapper(CartPole-v1), 16, 4).step (utils/craftax_wrappers.py:
+                            83-148) over 300 steps: which envs finished, which reset slot each took (its deterministic
+                            part: the choice of reset index per done env follows jax.random.choice on the done mask and
+                            is compared as "a done env receives ONE of the num_resets fresh states"), obs / reward / done /
+                            LogWrapper info
+    (ref_env_Acrobot-v1.npz is written by the env loop like the other envs.)
 
 tests/test_reference_fixtures_cpu.py (oracle) and tests/test_reference_fixtures_gpu.py (HIP path) pick the files up and
 skip while they are absent.  Commit the .npz files (data: inputs and expected outputs), not anything of the reference.
@@ -53,7 +62,7 @@ def env_fixtures(out_dir):
     import jax.numpy as jnp
     assert gymnax.__version__.startswith("0.0.6"), f"the reference pins gymnax==0.0.6, found {gymnax.__version__}"
     n_envs, n_steps = 8, 400
-    for name in ("Breakout-MinAtar", "Asterix-MinAtar", "Freeway-MinAtar", "SpaceInvaders-MinAtar", "CartPole-v1"):
+    for name in ("Breakout-MinAtar", "Asterix-MinAtar", "Freeway-MinAtar", "SpaceInvaders-MinAtar", "CartPole-v1", "Acrobot-v1"):
         env, params = gymnax.make(name)                                      # pqn_minatar.py:103
         n_act = env.action_space(params).n
         rng = np.random.default_rng(hash(name) % (2 ** 31))
@@ -179,6 +188,93 @@ def qlambda_fixtures(out_dir):
     print("wrote ref_qlambda.npz")
 
 
+def craftax_qnet_fixtures(reference_root, out_dir):
+    """pqn_craftax.py's QNetwork + BatchRenorm: the pieces rows a18 / f4 restate (oracle brn_fwd / brn_bwd, net_loss_grad_1step)."""
+    import jax
+    import jax.numpy as jnp
+    from flax.traverse_util import flatten_dict
+    spec = importlib.util.spec_from_file_location("ref_pqn_craftax", os.path.join(reference_root, "purejaxql", "pqn_craftax.py"))
+    refc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(refc)           # imports craftax as well: fails loudly where it is missing
+    rng = np.random.default_rng(3)
+    nb, d, a, h, layers, gamma = 64, 40, 5, 64, 2, 0.99
+    obs = (rng.standard_normal((nb, d)) * (0.3 + rng.random(d)) + 0.3 * rng.standard_normal(d)).astype(np.float32)
+    nxt = (obs + 0.1 * rng.standard_normal((nb, d))).astype(np.float32)
+    action = rng.integers(0, a, nb).astype(np.int32)
+    reward = rng.standard_normal(nb).astype(np.float32)
+    done = (rng.random(nb) < 0.2)
+    rec = {"obs": obs, "next_obs": nxt, "action": action, "reward": reward, "done": done, "gamma": np.float32(gamma)}
+    network = refc.QNetwork(action_dim=a, hidden_size=h, num_layers=layers, norm_type="layer_norm", norm_input=True)   # :33-62
+    variables = network.init(jax.random.PRNGKey(2), jnp.zeros((1, d)), train=False)
+    params = variables["params"]
+    for tag, steps in (("cold", 0), ("warm", 2000)):
+        bs = jax.tree_util.tree_map(lambda x: x, variables["batch_stats"])
+        flat_bs = flatten_dict(bs, sep="/")
+        # warm: running statistics away from their init and the step counter past the warm-up, so that r / d act (:100-105)
+        flat_bs = {k: (jnp.asarray(steps, v.dtype) if k.endswith("steps") else
+                       (v + 0.1 * jnp.asarray(rng.standard_normal(v.shape), v.dtype) if k.endswith("mean") else
+                        v * jnp.asarray(0.6 + rng.random(v.shape), v.dtype))) if steps else v for k, v in flat_bs.items()}
+        from flax.traverse_util import unflatten_dict
+        bs = unflatten_dict(flat_bs, sep="/")
+
+        def loss_fn(p):   # the body of _loss_fn with Q_LAMBDA False, pqn_craftax.py:287-304
+            all_q, updates = network.apply({"params": p, "batch_stats": bs}, jnp.concatenate((jnp.asarray(obs), jnp.asarray(nxt))),
+                                           train=True, mutable=["batch_stats"])
+            q_vals, q_next = jnp.split(all_q, 2)
+            q_next = jnp.max(jax.lax.stop_gradient(q_next), axis=-1)
+            target = jnp.asarray(reward) + (1 - jnp.asarray(done)) * gamma * q_next
+            chosen = jnp.take_along_axis(q_vals, jnp.expand_dims(jnp.asarray(action), axis=-1), axis=-1).squeeze(axis=-1)
+            return 0.5 * jnp.square(chosen - target).mean(), (updates, chosen, all_q)
+
+        (loss, (updates, chosen, all_q)), grads = jax.value_and_grad(loss_fn, has_aux=True)(params)
+        q_eval = network.apply({"params": params, "batch_stats": bs}, jnp.asarray(obs), train=False)
+        for k, v in flatten_dict(params, sep="/").items():
+            rec[f"{tag}/params/{k}"] = np.asarray(v)
+        for k, v in flatten_dict(grads, sep="/").items():
+            rec[f"{tag}/grads/{k}"] = np.asarray(v)
+        for k, v in flat_bs.items():
+            rec[f"{tag}/batch_stats/{k}"] = np.asarray(v)
+        for k, v in flatten_dict(updates["batch_stats"], sep="/").items():
+            rec[f"{tag}/new_batch_stats/{k}"] = np.asarray(v)
+        rec[f"{tag}/loss"], rec[f"{tag}/chosen"], rec[f"{tag}/all_q"], rec[f"{tag}/q_eval"] = (np.asarray(loss), np.asarray(chosen),
+                                                                                             np.asarray(all_q), np.asarray(q_eval))
+    np.savez_compressed(os.path.join(out_dir, "ref_craftax_qnet.npz"), **rec)
+    print("wrote ref_craftax_qnet.npz")
+
+
+def optimistic_fixtures(reference_root, out_dir):
+    """OptimisticResetVecEnvWrapper(LogWrapper(env)) on CartPole-v1 (utils/craftax_wrappers.py:83-148,151-200)."""
+    import gymnax
+    import jax
+    import jax.numpy as jnp
+    sys.path.insert(0, reference_root)
+    from purejaxql.utils.craftax_wrappers import LogWrapper, OptimisticResetVecEnvWrapper
+    n_envs, ratio, n_steps = 16, 4, 300
+    env, params = gymnax.make("CartPole-v1")
+    wenv = OptimisticResetVecEnvWrapper(LogWrapper(env), num_envs=n_envs, reset_ratio=ratio)
+    rng = np.random.default_rng(4)
+    actions = rng.integers(0, 2, size=(n_steps, n_envs)).astype(np.int32)
+    obs, state = wenv.reset(jax.random.PRNGKey(0), params)
+    step = jax.jit(wenv.step)
+    rec = {"actions": actions, "obs0": np.asarray(obs), "num_envs": np.int32(n_envs), "reset_ratio": np.int32(ratio)}
+    ob, rw, dn, info_rer, info_rel, info_ts = [], [], [], [], [], []
+    before, after = [], []
+    for t in range(n_steps):
+        before.append(_flat(state))
+        obs, state, r, d, info = step(jax.random.PRNGKey(5000 + t), state, jnp.asarray(actions[t]), params)
+        after.append(_flat(state))
+        ob.append(np.asarray(obs)); rw.append(np.asarray(r)); dn.append(np.asarray(d))
+        info_rer.append(np.asarray(info["returned_episode_returns"])); info_rel.append(np.asarray(info["returned_episode_lengths"]))
+        info_ts.append(np.asarray(info["timestep"]))
+    for k in before[0]:
+        rec[f"before/{k}"] = np.stack([b[k] for b in before])
+        rec[f"after/{k}"] = np.stack([a[k] for a in after])
+    rec.update(obs=np.stack(ob), reward=np.stack(rw), done=np.stack(dn), returned_episode_returns=np.stack(info_rer),
+               returned_episode_lengths=np.stack(info_rel), timestep=np.stack(info_ts))
+    np.savez_compressed(os.path.join(out_dir, "ref_optimistic.npz"), **rec)
+    print("wrote ref_optimistic.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("PUREJAXQL_REFERENCE", "/root/reference"))
@@ -192,6 +288,11 @@ def main():
     qnet_fixtures(ref, args.out)
     radam_fixtures(args.out)
     qlambda_fixtures(args.out)
+    for fn in (craftax_qnet_fixtures, optimistic_fixtures):   # need the craftax package besides gymnax: keep the rest if absent
+        try:
+            fn(args.reference, args.out)
+        except ImportError as exc:
+            print(f"skipped {fn.__name__}: {exc}")
 
 
 if __name__ == "__main__":

@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 4, final artefacts: the bench line, the rocprofv3 kernel-trace summary of the same command, PMC traffic of the headline
 # launch shape (tools/pmc_bench.sh), the C5 kernel table.  Copy gpurun_out/r4final/* to profiles/r04_*.
-O=gpurun_out/r4final; mkdir -p $O
 R=$PWD
+O=$R/gpurun_out/r4final; mkdir -p $O
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
 (cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pk; timeout 600 rocprofv3 --kernel-trace -d /tmp/pk -o x -- python $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > /dev/null 2>&1; python $R/tools/rocprof_summary.py /tmp/pk/x_results.db 20 | cut -c1-200) > $O/kernel_stats_seeds16_bf16x3.txt 2>&1
 head -12 $O/kernel_stats_seeds16_bf16x3.txt | cut -c1-150
