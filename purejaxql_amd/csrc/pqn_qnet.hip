@@ -1467,6 +1467,19 @@ PQN_D void train_head_nt(const CnnSmem (&sv)[NT], const TrainSmem (&tv)[NT], con
         __builtin_nontemporal_store(u2{mm[0], mm[1]}, reinterpret_cast<u2 *>(pw + ps));
         __builtin_nontemporal_store(u2{ll[0], ll[1]}, reinterpret_cast<u2 *>(pw + 2 * ps));
       }
+      if ((nb & (QW_SLAB - 1)) != 0) {
+        // ragged last slab: T2 multiplies whole 256-sample slabs, so the planes of the samples nb .. slabs * 256 - 1 must read
+        // as zero.  The tail's 16-sample "virtual tiles" are shared out over the real tiles (tile t zeroes the virtual tiles
+        // t + ntiles, t + 2 ntiles, ...): no extra launch, no host memset
+        const int ntl = nb / QN_TILE, nvt = qw_slabs(nb) * (QW_SLAB / QN_TILE);
+        for (int v = ntl + b0 / QN_TILE; v < nvt; v += ntl)
+          for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
+            unsigned short *pw = dzw + dzw_index(QN_TILE * v + 4 * (i & 3), i >> 2);
+            __builtin_nontemporal_store(u2{0u, 0u}, reinterpret_cast<u2 *>(pw));
+            __builtin_nontemporal_store(u2{0u, 0u}, reinterpret_cast<u2 *>(pw + ps));
+            __builtin_nontemporal_store(u2{0u, 0u}, reinterpret_cast<u2 *>(pw + 2 * ps));
+          }
+      }
     } else
     for (int i = tid; i < QN_HID * 4; i += QN_THREADS) {
       const int o = i >> 2, mq = i & 3;
@@ -4432,17 +4445,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // a seed's bits do not depend on which one its launch took.
   const int acc_opt = pqn_opt(PQN_OPT_T2_ACC);
   const bool t2_acc = L.matmul_f16 == 2 && !use_pos && (acc_opt == 2 || (acc_opt == 1 && 16 * min(gs_max, sd.nseeds) >= 256));
-  if (L.matmul_f16 == 2 && !use_pos && part != 2 && (nb % QW_SLAB) != 0) {
-    // ragged last slab: T1 writes the dz planes of existing samples only; the rest of the slab must read as zero in T2
-    unsigned short *dzw = reinterpret_cast<unsigned short *>(dzT + qw_dzw_offset(nb, C, L.a));
-    const size_t ps = (size_t)nks * QW_SLAB * QN_HID, slab = (size_t)QW_SLAB * QN_HID;
-    for (int pl = 0; pl < 3; ++pl)
-      if (hipMemset2DAsync(dzw + pl * ps + (size_t)(nks - 1) * slab, sd.nseeds > 1 ? (size_t)sd.ws_stride * sizeof(float) : slab * sizeof(unsigned short), 0, slab * sizeof(unsigned short),
-                           (size_t)sd.nseeds, st) != hipSuccess) {
-        pqn_set_error("pqn_qnet_cnn_grad: hipMemset2DAsync failed");
-        return PQN_E_HIP;
-      }
-  }
+  // (ragged minibatches: the tail of the last slab of the dz planes is zeroed by T1's head itself, see train_head_nt)
   for (int s0 = 0; s0 < sd.nseeds; s0 += gs_max) {
     const int gs = min(gs_max, sd.nseeds - s0);
     pqn_seeds_t sg = sd;
