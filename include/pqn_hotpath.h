@@ -384,6 +384,10 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);
+/* Options are read when a launch is ENQUEUED: a captured hipGraph keeps replaying the kernels chosen at capture time.  The
+ * epoch counts the pqn_set_option calls that changed a value; a caller that replays captured updates compares it with the
+ * epoch at capture and re-captures when it moved (purejaxql_amd/qnet.py drivers do). */
+int pqn_options_epoch(void);
 /* Which form the LAST enqueued training (pqn_qnet_cnn_grad / pqn_cnn_update*) and rollout (pqn_cnn_rollout*) launch
  * used: 0 none yet, 1 single-tile kernels, 2 pair kernels, 3 pair + paired dgrad, 4 pair forward + position-parallel
  * backward, 5 K-split kernels (small minibatches, f32 mode).  Lets a test assert in-process that the configuration it means to cover is the one that ran. */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "pqn_cnn_seed_group": (c_int, [c_int, c_int]),
     "pqn_set_option": (c_int, [C.c_char_p, c_int32]),
     "pqn_get_option": (c_int, [C.c_char_p, c_void_p]),
+    "pqn_options_epoch": (c_int, []),
     "pqn_cnn_last_kernel_form": (c_int, [c_void_p, c_void_p]),
     "pqn_mlp_layout": (c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pqn_mlp_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64,

@@ -66,13 +66,16 @@ static int opt_index(const char *name) {
     if (!strcmp(name, g_opts[i].name)) return i;
   return -1;
 }
+static int g_opts_epoch = 0;   // bumped by every pqn_set_option that changes a value: see pqn_options_epoch
 extern "C" int pqn_set_option(const char *name, int32_t value) {
   const int i = opt_index(name);
   PQN_REQUIRE(i >= 0, "pqn_set_option: unknown option '%s'", name ? name : "(null)");
+  if (pqn_opt(i) != value) ++g_opts_epoch;
   g_opts[i].value = value;
   g_opts[i].init = true;
   return PQN_OK;
 }
+extern "C" int pqn_options_epoch(void) { return g_opts_epoch; }
 extern "C" int pqn_get_option(const char *name, int32_t *value) {
   const int i = opt_index(name);
   PQN_REQUIRE(i >= 0 && value, "pqn_get_option: unknown option '%s' or NULL output", name ? name : "(null)");

@@ -1300,5 +1300,12 @@ extern "C" int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, 
                          hipMemset(g_bm_stamps, 0, 128 * sizeof(unsigned long long)) != hipSuccess)) g_bm_stamps = nullptr;
     E.stamps = g_bm_stamps;
   }
+  // the K range may need fewer splits than asked for (k = 45: two 32-wide ranges for nsplit = 3): the remaining partial outputs
+  // are zero-filled, so that "nsplit partials, the caller sums them" holds for every shape
+  for (int sp = p.nsplit; sp < nsplit; ++sp)
+    if (hipMemset2DAsync(c + (long long)sp * split_stride, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), (size_t)m, st) != hipSuccess) {
+      pqn_set_error("pqn_bigmlp_gemm: hipMemset2DAsync failed");
+      return PQN_E_HIP;
+    }
   return bm_launch<BM_EPI_STORE>(m, n, kp, p, bm_pl(pa, m, kp), bm_pl(pb, n, kp), E, st);
 }

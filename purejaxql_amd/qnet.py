@@ -290,18 +290,25 @@ class UpdateDriver:
             _lib.check(lib.pqn_cnn_update(C.byref(self.args), _lib.stream_ptr()), "pqn_cnn_update")
 
     def update(self):
-        """Enqueue (or replay) one update; the update index lives on the device (self.clock[0])."""
+        """Enqueue (or replay) one update; the update index lives on the device (self.clock[0]).  A captured graph replays the
+        kernels chosen at capture time: when a kernel-selection option changed since (pqn_options_epoch) it is dropped and
+        the update is captured again, so that pqn_set_option / _lib.options(...) take effect on running drivers too."""
+        lib = _lib.load()
+        epoch = int(lib.pqn_options_epoch())
+        if self.graph is not None and getattr(self, "_graph_epoch", epoch) != epoch:
+            self.graph = None
         if self.graph is not None:
             self.graph.replay()
         else:
             self._enqueue()
-            if self.use_graph and self.calls == 0 and self.graph_error is None:
+            if self.use_graph and (self.calls == 0 or getattr(self, "_graph_epoch", None) is not None) and self.graph_error is None:
                 # first update ran eagerly (kernel attributes set, caches warm); capture the next one
                 try:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._enqueue()
                     self.graph = g
+                    self._graph_epoch = epoch
                 except Exception as exc:  # stay on the eager C++ enqueue (still the HIP path)
                     self.graph_error = repr(exc)
                     torch.cuda.synchronize()

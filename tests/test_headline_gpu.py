@@ -241,6 +241,51 @@ def test_fc1_weight_gradient_without_split_k_partials_is_bit_identical(gpu, nb, 
     assert float(out[0][0][:, lay.struct.off_w1:lay.struct.off_w1 + 1024 * 128].abs().max()) > 0
 
 
+def test_kernel_selection_options_reach_a_running_graph_driver(gpu):
+    """A captured hipGraph replays the kernels chosen at capture time; the update drivers therefore watch pqn_options_epoch and
+    re-capture when a kernel-selection option changed (an option set after the capture used to be ignored while
+    pqn_cnn_last_kernel_form kept reporting the last ENQUEUE).  Small Breakout run, bf16x3: pair form forced, two updates (the
+    second captured), then the option flips to the single-tile form mid-run -- the very next update is enqueued and captured
+    again in that form -- and back; the metrics equal an undisturbed run bit for bit (the two forms sum in the same order)."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys
+
+    def cfg():
+        c = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", "alg.NUM_ENVS=64", "alg.TEST_DURING_TRAINING=False",
+                                 "alg.MATMUL_DTYPE=bf16x3"]))
+        c["TOTAL_TIMESTEPS"] = 5 * 64 * c["NUM_STEPS"]
+        return c
+
+    key = seed_keys(9, 1)[0]
+    prev = _lib.get_option("t1_pair")
+    try:
+        _lib.set_option("t1_pair", 2)
+        ref_update, ref_finish = make_train(cfg(), device="cuda:0").make_runner(key)
+        for u in range(5):
+            ref_update(u)
+        ref = ref_finish()
+        update, finish = make_train(cfg(), device="cuda:0").make_runner(key)
+        update(0); update(1)
+        assert update.driver.graph is not None and _lib.last_kernel_form()[0] == "pair"
+        g1 = update.driver.graph
+        _lib.set_option("t1_pair", 0)
+        update(2)
+        assert _lib.last_kernel_form()[0] == "single" and update.driver.graph is not None and update.driver.graph is not g1
+        g2 = update.driver.graph
+        update(3)
+        assert update.driver.graph is g2          # no option changed: plain replay
+        _lib.set_option("t1_pair", 2)
+        update(4)
+        assert _lib.last_kernel_form()[0] == "pair" and update.driver.graph is not g2
+        out = finish()
+    finally:
+        _lib.set_option("t1_pair", prev)
+    for k in ("td_loss", "qvals", "returned_episode_returns"):
+        assert torch.equal(out["metrics"][k], ref["metrics"][k]), k
+    assert torch.equal(out["runner_state"]["theta"], ref["runner_state"]["theta"])
+
+
 def test_forced_pair_forms_at_small_sizes_in_process(gpu):
     """The pair forms forced at sizes where they are not selected by default (pqn_set_option, in-process): the training
     kernel at 2, 8 and 256 pairs (C = 4), and -- round 4, head-parameter block of the LDS plan sized by the action count --
