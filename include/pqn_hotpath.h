@@ -578,6 +578,12 @@ typedef struct {
   float *radam_scratch;  /* [1024] */
   float *loss_buf, *qv_buf; /* [num_minibatches*num_epochs] */
   double *metrics;       /* [metrics_capacity][PQN_NUM_METRICS] (env_frame is written as env_step) */
+  /* LOG_ACHIEVEMENTS (pqn_craftax.py:364-369,384-387), both nullable together: achievements u32[T][N] = scratch for the
+   * achievement mask of the episodes that end with each step (pqn_step_out_t.achievements); ach_metrics
+   * f64[metrics_capacity][32]: column k of row u = (100 * unlocked_k * returned_episode).sum() / returned_episode.sum() over
+   * update u's [T][N] steps (NaN when no episode finished), k = bit k of the mask */
+  uint32_t *achievements;
+  double *ach_metrics;
 } pqn_bigmlp_update_args_t;
 int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *args /* host */, void *stream);
 

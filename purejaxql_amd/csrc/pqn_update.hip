@@ -558,6 +558,26 @@ extern "C" int pqn_mlp_update_seeds(const pqn_mlp_update_args_t *a, int32_t num_
                          (hipStream_t)stream);
 }
 
+// LOG_ACHIEVEMENTS (pqn_craftax.py:364-369,384-387): block k = achievement k: (100 * unlocked_k * done).sum() / done.sum() over the
+// update's [T][N] steps, in fixed order (f64), into row clock[1] of ach_metrics
+__global__ __launch_bounds__(256) void update_ach_means_kernel(const int32_t *__restrict__ clock, int count,
+                                                               const uint32_t *__restrict__ ach, const uint8_t *__restrict__ done,
+                                                               double *__restrict__ ach_metrics, int capacity) {
+  __shared__ double s_num[4], s_den[4];
+  const int k = blockIdx.x, u = clock[1];
+  double num = 0.0, den = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) {
+    const double d = done[i] ? 1.0 : 0.0;
+    den += d;
+    num += d * (double)((ach[i] >> k) & 1u) * 100.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) { num += __shfl_down(num, off, 64); den += __shfl_down(den, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_num[threadIdx.x >> 6] = num; s_den[threadIdx.x >> 6] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0 && u < capacity)
+    ach_metrics[(size_t)u * 32 + k] = ((s_num[0] + s_num[1]) + (s_num[2] + s_num[3])) / ((s_den[0] + s_den[1]) + (s_den[2] + s_den[3]));
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The Craftax script's twin (pqn_craftax.py:176-399): wrapper-batched env (optimistic resets or auto-reset), the wide
 // LayerNorm MLP through the tiled GEMM kernels of pqn_bigmlp.hip, Q(lambda) or 1-step loss, done-weighted info means.
@@ -582,6 +602,7 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
   PQN_REQUIRE(a->reset_ratio == 0 || (a->reset_ratio > 0 && N % a->reset_ratio == 0 && a->opt_scratch),
               "pqn_bigmlp_update: reset ratio %d must perfectly divide num envs %d (and opt_scratch be given)", a->reset_ratio, N);
   PQN_REQUIRE(!a->q_lambda || (a->target && a->last_q), "pqn_bigmlp_update: the Q(lambda) branch needs target and last_q");
+  PQN_REQUIRE((a->achievements == nullptr) == (a->ach_metrics == nullptr), "pqn_bigmlp_update: achievements and ach_metrics go together");
   const pqn_bigmlp_layout_t &L = a->layout;
   PQN_REQUIRE(L.norm_input == 0 || (a->in_mean && a->in_var && (L.norm_input == 1 || a->in_steps)),
               "pqn_bigmlp_update: the input normalisation needs its running statistics");
@@ -604,6 +625,7 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
     out.returned_episode_returns = a->rer + o;
     out.returned_episode_lengths = a->rel + o;
     out.timestep = a->ts + o;
+    if (a->achievements) out.achievements = a->achievements + o;
     if (a->reset_ratio > 0) {
       UPD_CHECK(pqn_env_step_optimistic_dyn(a->env_id, N, a->sched_keys + t, a->rew_scale, a->reset_ratio, a->state, a->action + o,
                                             out, a->opt_scratch, a->slot_scratch, st));
@@ -640,6 +662,9 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
   double *partial = reinterpret_cast<double *>(a->workspace);   // idle between the last optimizer step and the next forward
   hipLaunchKernelGGL(update_means_kernel, dim3(5, MEANS_CHUNKS, 1), dim3(256), 0, st, TN, N, N, a->discount, a->rer, a->rel, a->ts,
                      a->done, partial, 0ll, a->done_weighted_info);
+  if (a->achievements)   // before the tick: it reads the update index the sched kernel latched into clock[1]
+    hipLaunchKernelGGL(update_ach_means_kernel, dim3(32), dim3(256), 0, st, a->clock, TN, a->achievements, a->done, a->ach_metrics,
+                       a->metrics_capacity);
   hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, 1, MB * EP, a->loss_buf, a->qv_buf, partial,
                      a->metrics, a->metrics_capacity, 0ll, a->done_weighted_info);
   return pqn_check_launch("pqn_bigmlp_update");

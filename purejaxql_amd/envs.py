@@ -85,7 +85,9 @@ class Environment:
         self.state_words = int(spec.state_words)
         self.num_actions = int(spec.num_actions)
         self.default_params = EnvParams(max_steps_in_episode=int(spec.max_steps))
-        # Craftax-Classic's Achievement enum order (bit k of the mask pqn_step_out_t.achievements carries)
+        # bit k of the mask pqn_step_out_t.achievements = achievement k of this tuple: ALPHABETICAL order (this build's own
+        # numbering, shared by the kernel, the oracle and the metric names -- NOT the package's Achievement enum values, which
+        # this build never exchanges with anything)
         self.achievement_names = CRAFTAX_CLASSIC_ACHIEVEMENTS if name == "Craftax-Classic-Symbolic-v1" else ()
         self.device = torch.device(device) if device is not None else torch.device("cuda")
 

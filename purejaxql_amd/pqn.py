@@ -581,7 +581,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             driver = UpdateDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
                                   policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
                                   fused_opt=config.get("_FUSED_OPT", False))
-        elif backend == "fused_big" and grad_hook is None and config.get("_DRIVER", True) and driver_shape_ok and not ach_names:
+        elif backend == "fused_big" and grad_hook is None and config.get("_DRIVER", True) and driver_shape_ok:
             # the Craftax script's loop (wrapper-batched env, wide MLP) from one C call, replayed as a hipGraph
             from .qnet import BigMlpUpdateDriver
             dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
@@ -589,7 +589,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             ratio = int(env.reset_ratio) if isinstance(env, OptimisticResetVecEnvWrapper) else 0
             driver = BigMlpUpdateDriver(base_env.env_id, N, T, MB, EPOCHS, dcfg, (K_roll, K_shuf), policy.tr, ro, words,
                                         NUM_UPDATES, reset_ratio=ratio, q_lambda=q_lambda_loss, done_weighted_info=craftax,
-                                        use_graph=config.get("_GRAPH", True))
+                                        use_graph=config.get("_GRAPH", True), log_achievements=bool(ach_names))
         elif packed and grad_hook is not None and config.get("_DRIVER", True) and driver_shape_ok:
             # envs of one seed sharded over ranks: the same C++ enqueue, split at the gradient / optimizer boundary
             from .qnet import EnvShardDriver
@@ -745,6 +745,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 for j, name in enumerate(METRIC_NAMES):
                     if name in metrics:
                         metrics[name] = driver.metrics[:NUM_UPDATES, j].to(torch.float32)
+                if ach_names and getattr(driver, "ach_metrics", None) is not None:   # LOG_ACHIEVEMENTS columns of the whole-update enqueue
+                    for k_a, a_name in enumerate(ach_names):
+                        metrics[f"Achievements/{a_name}"] = driver.ach_metrics[:NUM_UPDATES, k_a].to(torch.float32)
                 if test_on:
                     for j, k in enumerate(INFO_KEYS):
                         metrics[f"test/{k}"] = test_rows[:, j]

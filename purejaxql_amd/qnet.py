@@ -275,6 +275,11 @@ class UpdateDriver:
         a.theta, a.grad, a.m, a.v = p(trainer.theta), p(trainer.grad), p(trainer.m), p(trainer.v)
         a.count, a.workspace = p(trainer.count), p(trainer.ws)
         a.loss_buf, a.qv_buf, a.metrics = p(self.loss_buf), p(self.qv_buf), p(self.metrics)
+        self.ach_buf = self.ach_metrics = None
+        if log_achievements:   # LOG_ACHIEVEMENTS: the 22 done-weighted Achievements/<name> columns, reduced on the device
+            self.ach_buf = torch.zeros((t, n), dtype=torch.int32, device=dev)
+            self.ach_metrics = torch.zeros((max(num_updates, 1), 32), dtype=torch.float64, device=dev)
+            a.achievements, a.ach_metrics = p(self.ach_buf), p(self.ach_metrics)
         self.args = a
         self._keep = (trainer, ro, words)
         self.use_graph = use_graph
@@ -891,7 +896,7 @@ class BigMlpUpdateArgs(C.Structure):
                                            "sort_keys_in", "sort_keys_out", "sort_temp", "opt_scratch", "slot_scratch", "theta",
                                            "wplanes",
                                            "grad", "m", "v", "count", "in_mean", "in_var", "in_steps", "workspace",
-                                           "radam_scratch", "loss_buf", "qv_buf", "metrics")])
+                                           "radam_scratch", "loss_buf", "qv_buf", "metrics", "achievements", "ach_metrics")])
 
 
 class BigMlpUpdateDriver:
@@ -900,7 +905,8 @@ class BigMlpUpdateDriver:
     loss on concat(obs, next_obs); `done_weighted_info` = the Craftax script's info means (pqn_craftax.py:364-369)."""
 
     def __init__(self, env_id, n, t, mb, epochs, cfg, keys, trainer: "BigMlpTrainer", ro, words, num_updates, *,
-                 reset_ratio: int, q_lambda: bool, done_weighted_info: bool, use_graph: bool = True):
+                 reset_ratio: int, q_lambda: bool, done_weighted_info: bool, use_graph: bool = True,
+                 log_achievements: bool = False):
         lib = _lib.load()
         dev = trainer.theta.device
         self.dev = dev

@@ -345,20 +345,23 @@ def test_wide_mlp_whole_update_enqueue_equals_the_stepwise_loop(gpu, script, env
     assert saw_done or "Craftax" in env_name, "no finished episode inside the run: the reset paths were not exercised"
 
 
-def test_log_achievements_adds_the_done_weighted_achievement_means(gpu):
+@pytest.mark.parametrize("driver", [True, False])
+def test_log_achievements_adds_the_done_weighted_achievement_means(gpu, driver):
     """`LOG_ACHIEVEMENTS: True` (pqn_craftax.py:384-387 keeps the info["Achievements/<name>"] keys in the metrics): 22
     columns `Achievements/<name>` = (done * unlocked * 100 * returned_episode).sum() / returned_episode.sum(), NaN exactly
     where no episode finished, within [0, 100] otherwise; the per-step masks themselves are checked against the oracle in
-    tests/test_craftax_env_gpu.py.  The run takes the stepwise loop (the whole-update enqueue has the 11 fixed columns)."""
+    tests/test_craftax_env_gpu.py.  Round 4: the whole-update enqueue (pqn_bigmlp_update, one hipGraph per update) reduces
+    the columns on the device (update_ach_means_kernel) instead of dropping to the stepwise loop; both paths must give the
+    same columns bit for bit (same f64 sums of 0 / 100 values over the same masks)."""
     from purejaxql_amd.config_loader import flatten, load_config
     from purejaxql_amd.envs import CRAFTAX_CLASSIC_ACHIEVEMENTS
     from purejaxql_amd.pqn import make_train, seed_keys
     cfg = flatten(load_config(["+alg=pqn_craftax", "alg.ENV_NAME=Craftax-Classic-Symbolic-v1"]))
     n_upd = 500
     cfg.update({"NUM_ENVS": 128, "HIDDEN_SIZE": 256, "NUM_LAYERS": 2, "TOTAL_TIMESTEPS": n_upd * 128, "TOTAL_TIMESTEPS_DECAY": n_upd * 128,
-                "LOG_ACHIEVEMENTS": True, "EPS_START": 1.0, "EPS_FINISH": 1.0})
+                "LOG_ACHIEVEMENTS": True, "EPS_START": 1.0, "EPS_FINISH": 1.0, "_DRIVER": driver})
     out = make_train(cfg, device="cuda:0", script="craftax")(seed_keys(2, 1)[0])
-    assert out["runner_state"]["driver"] is None and len(CRAFTAX_CLASSIC_ACHIEVEMENTS) == 22
+    assert (out["runner_state"]["driver"] == "graph") == driver and len(CRAFTAX_CLASSIC_ACHIEVEMENTS) == 22
     m = out["metrics"]
     nan_ref = torch.isnan(m["returned_episode_returns"])
     for name in CRAFTAX_CLASSIC_ACHIEVEMENTS:
@@ -366,5 +369,10 @@ def test_log_achievements_adds_the_done_weighted_achievement_means(gpu):
         assert v.shape == (n_upd,) and torch.equal(torch.isnan(v), nan_ref), name
         ok = v[~nan_ref]
         assert bool(((ok >= 0) & (ok <= 100)).all()), name
-    print("updates with finished episodes:", int((~nan_ref).sum()), "max collect_wood %:",
-          float(torch.nan_to_num(m["Achievements/collect_wood"], nan=0.0).max()))
+    assert int((~nan_ref).sum()) > 0 and float(torch.nan_to_num(m["Achievements/collect_wood"], nan=0.0).max()) > 0
+    key = ("ach", tuple(float(x) for x in torch.nan_to_num(m["Achievements/collect_wood"], nan=-1.0)[:200]))
+    _ACH_RUNS.setdefault("ref", key)
+    assert _ACH_RUNS["ref"] == key, "the graph driver and the stepwise loop disagree on Achievements/collect_wood"
+
+
+_ACH_RUNS = {}
