@@ -275,11 +275,6 @@ class UpdateDriver:
         a.theta, a.grad, a.m, a.v = p(trainer.theta), p(trainer.grad), p(trainer.m), p(trainer.v)
         a.count, a.workspace = p(trainer.count), p(trainer.ws)
         a.loss_buf, a.qv_buf, a.metrics = p(self.loss_buf), p(self.qv_buf), p(self.metrics)
-        self.ach_buf = self.ach_metrics = None
-        if log_achievements:   # LOG_ACHIEVEMENTS: the 22 done-weighted Achievements/<name> columns, reduced on the device
-            self.ach_buf = torch.zeros((t, n), dtype=torch.int32, device=dev)
-            self.ach_metrics = torch.zeros((max(num_updates, 1), 32), dtype=torch.float64, device=dev)
-            a.achievements, a.ach_metrics = p(self.ach_buf), p(self.ach_metrics)
         self.args = a
         self._keep = (trainer, ro, words)
         self.use_graph = use_graph
@@ -956,6 +951,11 @@ class BigMlpUpdateDriver:
             a.in_mean, a.in_var, a.in_steps = p(trainer.in_mean), p(trainer.in_var), p(trainer.in_steps)
         a.workspace, a.radam_scratch = p(self.ws), p(trainer.scratch)
         a.loss_buf, a.qv_buf, a.metrics = p(self.loss_buf), p(self.qv_buf), p(self.metrics)
+        self.ach_buf = self.ach_metrics = None
+        if log_achievements:   # LOG_ACHIEVEMENTS: the 22 done-weighted Achievements/<name> columns, reduced on the device
+            self.ach_buf = torch.zeros((t, n), dtype=torch.int32, device=dev)
+            self.ach_metrics = torch.zeros((max(num_updates, 1), 32), dtype=torch.float64, device=dev)
+            a.achievements, a.ach_metrics = p(self.ach_buf), p(self.ach_metrics)
         self.args = a
         self._keep = (trainer, ro, words)
         self.use_graph = use_graph
