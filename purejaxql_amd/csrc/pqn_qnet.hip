@@ -1549,7 +1549,9 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
     auto ib_step = [&](int ibk, auto more_t) {
       constexpr bool more = decltype(more_t)::value;
       const int ib = ib_first + ((ibk + prot) & (IBW - 1));
-      float *p0 = out + r0 * QN_H1S + 16 * ib + col;
+      // the dh1 / dx tile keeps the quad swizzle of the forward h1 tile (h1_slot): LayerNorm_0's backward reads and writes it
+      // one position per lane with ds_read/write_b128 at a lane stride of 64 B -- conflict-free only in the swizzled layout
+      float *p0 = out + r0 * QN_H1S + h1_slot(16 * ib + col);
       float m0, m1, m2, m3;   // relu mask (h1 > 0), read ahead of the MFMAs
       if (MASKBITS) {         // packed by the pair kernel's h1^T loop: 64-bit word [16-feature block ib][sample & 3],
                               // bit (feature & 15) * 4 + (sample >> 2)
@@ -1560,8 +1562,7 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
         m2 = (float)((mw[2] >> bsel) & 1ull);
         m3 = (float)((mw[3] >> bsel) & 1ull);
       } else {
-        const float *pm = out + r0 * QN_H1S + h1_slot(16 * ib + col);   // the forward h1 tile is quad-swizzled (h1_slot)
-        m0 = pm[0]; m1 = pm[QN_H1S]; m2 = pm[2 * QN_H1S]; m3 = pm[3 * QN_H1S];
+        m0 = p0[0]; m1 = p0[QN_H1S]; m2 = p0[2 * QN_H1S]; m3 = p0[3 * QN_H1S];   // the forward tile, in place (same slot map)
       }
       // four accumulators per K parity ({small, leading} x 2): reuse distance 6 in issue order (see phase2_fc1_x3)
       f32x4 acc_b[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -1635,11 +1636,12 @@ PQN_D void t1_ln0_bwd_ns(float *dh1, float *red, const float *__restrict__ theta
   for (int mm = 0; mm < QN_SPW; ++mm) {
     const int msamp = QN_SPW * wave + mm;
     f32x4 *gptr = reinterpret_cast<f32x4 *>(dh1 + msamp * QN_H1S + lane * 16);   // d relu-input (masked) -> dx in place
+    const int sw = QN_H1_SWIZZLE ? ((lane >> 2) & 3) : 0;                          // quad swizzle of position `lane` (h1_slot)
     const float rstd = rkeep[mm];
     float g[16];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      const f32x4 v = gptr[qd];
+      const f32x4 v = gptr[qd ^ sw];
       g[4 * qd] = v.x; g[4 * qd + 1] = v.y; g[4 * qd + 2] = v.z; g[4 * qd + 3] = v.w;
     }
     float s1 = 0.f, s2 = 0.f, dxh[16];
@@ -1662,7 +1664,7 @@ PQN_D void t1_ln0_bwd_ns(float *dh1, float *red, const float *__restrict__ theta
         GX[c] += g[c] * xkeep[mm][c];
         DX[c] += d4[e];
       }
-      gptr[qd] = f32x4{d4[0], d4[1], d4[2], d4[3]};
+      gptr[qd ^ sw] = f32x4{d4[0], d4[1], d4[2], d4[3]};
     }
   }
   float tb[4], ts[4], ti[4];
@@ -1718,7 +1720,7 @@ PQN_D void t1_conv_wgrad_2r(const float *dx, const uint32_t *bits, uint32_t *wm_
     uint32_t wv[16][NRB];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      bv[q] = dxm[64 * q];
+      bv[q] = dx[msamp * QN_H1S + h1_slot(lane + 64 * q)];   // (dx keeps the quad swizzle of the h1 tile)
 #pragma unroll
       for (int j = 0; j < NRB; ++j) wv[q][j] = wm[(4 * q + kk) * 3 + kyL[j]];
     }
@@ -1849,10 +1851,9 @@ PQN_D void t1_dgrad_pair2_x3(const float *ztA, float *outA, const u32x4 *planesB
   auto ib_step = [&](int ibk, auto more_t) {
     constexpr bool more = decltype(more_t)::value;
     const int ib = ib_first + ((ibk + prot) & (IBW - 1));
-    const int off = r0 * QN_H1S + 16 * ib + col;
+    const int off = r0 * QN_H1S + h1_slot(16 * ib + col);   // forward h1 and dh1 / dx tiles share the quad swizzle
     float *pA = outA + off, *pB = outB + off;
-    const float *pmA = outA + r0 * QN_H1S + h1_slot(16 * ib + col);
-    const float m0 = pmA[0], m1 = pmA[QN_H1S], m2 = pmA[2 * QN_H1S], m3 = pmA[3 * QN_H1S];   // tile A: relu mask = its h1 (quad-swizzled), in place
+    const float m0 = pA[0], m1 = pA[QN_H1S], m2 = pA[2 * QN_H1S], m3 = pA[3 * QN_H1S];   // tile A: relu mask = its h1, in place
     const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(maskB) + ib * 4;   // tile B: packed bits
     const int bsel = col * 4 + (lane >> 4);
     const unsigned long long w0 = mw[0], w1 = mw[1], w2 = mw[2], w3 = mw[3];
@@ -2031,7 +2032,7 @@ PQN_D void t1_conv_wgrad(const float *dx, const uint32_t *bits, uint32_t *wm_bas
         uint32_t wv[16][RBW];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {           // q = 8 st + j: all LDS reads of the sample in flight at once
-          bv[q] = dxm[64 * q];
+          bv[q] = dx[msamp * QN_H1S + h1_slot(lane + 64 * q)];   // (dx keeps the quad swizzle of the h1 tile)
 #pragma unroll
           for (int j = 0; j < RBW; ++j) wv[q][j] = wm[(4 * q + kk) * 3 + kyL[j]];
         }
