@@ -1,5 +1,5 @@
-"""The bench line contract (driver-facing): the committed round artefact profiles/r03_bench.json -- the JSON line
-bench.py printed on an MI355X at the end of round 3 -- carries every field the contract names, with consistent
+"""The bench line contract (driver-facing): the committed round artefact profiles/r04_bench.json -- the JSON line
+bench.py printed on an MI355X at the end of round 4 -- carries every field the contract names, with consistent
 arithmetic."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -32,8 +32,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["flop_per_launch"] == 674048 * 4096 * 16
     assert r["traffic"] is None or (r["traffic"] > 0 and "from file" in r["traffic_source"])
     # the headline's traffic comes from PMC passes of the 16-seed launch shape itself, not from a scaled single-seed pass
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_train_kernel_bf16x3_seeds16.json")))
-    assert "r03_pmc" in r["traffic_source"] and abs(r["l2_to_cu_bytes"] - pmc["l2_to_cu_bytes_per_launch"]) <= 1e-6 * r["l2_to_cu_bytes"]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_train_kernel_bf16x3_seeds16.json")))
+    assert "r04_pmc" in r["traffic_source"] and abs(r["l2_to_cu_bytes"] - pmc["l2_to_cu_bytes_per_launch"]) <= 1e-6 * r["l2_to_cu_bytes"]
     assert pmc["seeds_per_launch"] == 16 and "seeds16" in r["traffic_source"]
     assert abs(r["traffic"] - pmc["hbm_bytes_per_launch"]) <= 1e-6 * r["traffic"]
     assert abs(pmc["hbm_bytes_per_launch"] - (2 * pmc["FETCH_SIZE_KB_avg"] + pmc["WRITE_SIZE_KB_avg"]) * 1024.0) < 1.0
@@ -43,6 +43,9 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert "NUM_ENVS=4096" in cb["sample"]                      # the CPU leg runs the bench shape itself
+    # round 4: >= 3 timed whole updates, thread count calibrated (more torch threads are slower) and reported as `cores`
+    assert cb["updates_timed"] >= 3 and str(cb["cores"]) in cb["seconds_per_update_by_threads"] and cb["host_logical_cores"] >= cb["cores"]
+    assert cb["seconds_per_update_by_threads"][str(cb["cores"])] == min(cb["seconds_per_update_by_threads"].values())
     # which kernels ran is asked of the library, the timed region is backed by a longer one, the env-step roofline says
     # which level of the memory system it measures
     assert d["config"]["kernel_forms"] == {"train": "pair", "rollout": "pair"} and d["config"]["driver"] == "hipGraph replay"
@@ -56,6 +59,14 @@ def test_committed_bench_line_has_the_contract_fields():
     # the reference's yaml defaults (128 envs): the small-minibatch regime runs the K-split training kernels
     yd = d["yaml_default"]
     assert yd["kernel_forms"]["train"] == "ksplit" and yd["value"] > 1.2e6 and yd["seconds_for_1e7_steps"] < 8.0
+    # BASELINE.json configs[2] / configs[1] beside the headline: the suite at 4096 envs and Breakout at 1024, all on the pair kernels
+    suite = {(g["env"], g["num_envs"]): g for g in d["minatar_suite"]}
+    assert set(suite) == {("Asterix-MinAtar", 4096), ("Freeway-MinAtar", 4096), ("SpaceInvaders-MinAtar", 4096),
+                          ("Breakout-MinAtar", 4096), ("Breakout-MinAtar", 1024)}
+    for g in suite.values():
+        assert g["kernel_forms"] == {"train": "pair", "rollout": "pair"} and g["seeds_per_gpu"] == 16 and g["value"] > 3e7, g
+        assert g["t1_flop_per_sample"] == 36864 * g["channels"] + 524288 + 768 * g["actions"] and 0.4 < g["t1_frac_f32_peak"] < 0.9
+    assert d["config"]["seed_groups"] == 1
     # the extras report the other operand modes and the single-seed run beside the headline, never instead of it
     assert d["matmul_modes"]["f32"]["value"] < d["value"] < d["matmul_modes"]["f16"]["value"]
     assert d["single_seed"]["seeds_per_gpu"] == 1 and d["single_seed"]["value"] < d["value"]
