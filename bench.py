@@ -386,14 +386,14 @@ def main():
         if extras and fused:
             def minatar_suite():
                 """BASELINE.json configs[2] (the MinAtar suite at 4096 envs: gymnax 0.0.6 has four games) and configs[1]
-                (Breakout at 1024 envs), each as the headline workload: 16 seeds per GPU batched into the launches, the
+                (Breakout at 1024 envs: with 16 seeds per GPU and as ONE seed alone), each as the headline workload: seeds batched into the launches, the
                 yaml's 32 steps x 32 minibatches x 2 epochs, same operand mode.  Per line: whole-loop env-steps/s, the kernel
                 forms the library took, the training kernel's HIP-event duration and its fraction of the f32 peak."""
                 from purejaxql_amd.config_loader import flatten, load_config
                 from purejaxql_amd.envs import make
                 res = []
-                for env_name, n_envs in (("Asterix-MinAtar", 4096), ("Freeway-MinAtar", 4096), ("SpaceInvaders-MinAtar", 4096),
-                                         ("Breakout-MinAtar", 4096), ("Breakout-MinAtar", 1024)):
+                for env_name, n_envs, spg_g in (("Asterix-MinAtar", 4096, spg), ("Freeway-MinAtar", 4096, spg), ("SpaceInvaders-MinAtar", 4096, spg),
+                                                ("Breakout-MinAtar", 4096, spg), ("Breakout-MinAtar", 1024, spg), ("Breakout-MinAtar", 1024, 1)):
                     try:
                         cg = flatten(load_config(["+alg=pqn_minatar", f"alg.ENV_NAME={env_name}", f"alg.NUM_ENVS={n_envs}",
                                                   "alg.TEST_DURING_TRAINING=False"]))
@@ -401,16 +401,16 @@ def main():
                         w_g, s_g = 3, 12
                         cg["TOTAL_TIMESTEPS"] = (w_g + s_g + 3) * n_envs * cg["NUM_STEPS"]
                         trg = make_train(cg, device=str(dev))
-                        updg, _fg = trg.make_batch_runner(seed_keys(0, spg)) if spg > 1 else trg.make_runner(seed_keys(0, 1)[0])
+                        updg, _fg = trg.make_batch_runner(seed_keys(0, spg_g)) if spg_g > 1 else trg.make_runner(seed_keys(0, 1)[0])
                         dg = timed_updates(updg, s_g, w_g)
                         forms = dict(zip(("train", "rollout"), _lib.last_kernel_form()))
                         mbg = n_envs * cg["NUM_STEPS"] // cg["NUM_MINIBATCHES"]
-                        ag, lg = kernel_timer_pass(lib, updg, w_g + s_g, mbg, spg)
+                        ag, lg = kernel_timer_pass(lib, updg, w_g + s_g, mbg, spg_g)
                         env_g, _pg = make(env_name, device=dev)
                         ch, na = int(env_g.obs_shape[-1]), int(env_g.num_actions)
-                        rg = t1_roofline(ag, lg, mbg, spg, matmul, forms["train"], t1_flop_per_sample(ch, na))
-                        res.append({"env": env_name, "num_envs": n_envs, "seeds_per_gpu": spg, "channels": ch, "actions": na,
-                                    "value": n_envs * cg["NUM_STEPS"] * spg * s_g / dg, "unit": "env-steps/s",
+                        rg = t1_roofline(ag, lg, mbg, spg_g, matmul, forms["train"], t1_flop_per_sample(ch, na))
+                        res.append({"env": env_name, "num_envs": n_envs, "seeds_per_gpu": spg_g, "channels": ch, "actions": na,
+                                    "value": n_envs * cg["NUM_STEPS"] * spg_g * s_g / dg, "unit": "env-steps/s",
                                     "ms_per_update": dg / s_g * 1e3, "kernel_forms": forms,
                                     "t1_avg_launch_us": rg["avg_launch_us"], "t1_frac_f32_peak": rg["frac"],
                                     "t1_flop_per_sample": t1_flop_per_sample(ch, na), "minibatch": mbg})
