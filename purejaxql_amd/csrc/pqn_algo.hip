@@ -239,7 +239,16 @@ __global__ __launch_bounds__(256) void radam_norm_kernel(const float *__restrict
                                                          float *__restrict__ scratch) {
   __shared__ float s_part[4];
   float acc = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * stride < n; i += 8 * stride) {   // 8 loads in flight, the additions in the order of the plain loop
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = g[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(t[u], t[u], acc);
+  }
+  for (; i < n; i += stride) {
     const float v = g[i];
     acc = fmaf(v, v, acc);
   }

@@ -302,6 +302,16 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
 }
 
 // all-reduce over the 64 lanes of a wave, fixed butterfly order
+// row of Q (ldq % 4 == 0, 16-B aligned, ldq <= 32) into registers: 8 unconditional vector loads, packs beyond the row
+// re-read its last pack (those entries are never used: k >= ldq >= a)
+PQN_D void bm_load_qrow(const float *__restrict__ row, int ldq, float (&out)[32]) {
+#pragma unroll
+  for (int k4 = 0; k4 < 8; ++k4) {
+    const f32x4 t = *reinterpret_cast<const f32x4 *>(row + min(4 * k4, ldq - 4));
+    out[4 * k4] = t.x; out[4 * k4 + 1] = t.y; out[4 * k4 + 2] = t.z; out[4 * k4 + 3] = t.w;
+  }
+}
+
 PQN_D float bm_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256) void bm_split_kernel(const float *__restrict__
 }
 // several matrices in one launch (the Dense kernels of every layer after an optimizer step): job j owns blocks
 // [first[j], first[j + 1])
-#define BM_MAX_JOBS (PQN_BIGMLP_MAX_LAYERS + 1)
+#define BM_MAX_JOBS (2 * PQN_BIGMLP_MAX_LAYERS + 2)   // backward: the input, every h_l, dQ and every dz_l in one transpose launch
 struct BmSplitJobs {
   int n;
   const float *src[BM_MAX_JOBS];
@@ -401,29 +411,43 @@ __global__ __launch_bounds__(256) void bm_transpose_multi_kernel(BmTransposeJobs
 // as planes; z and stat[r] = (mean, rstd) are kept for the backward pass.  n % 256 == 0, n <= 2048: lane owns the
 // 8-column packs lane, lane + 64, ... of the row.
 #define BM_MAXP 4
-__global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict__ zpart, int nsplit, long long pstride, int m,
+// Straight-line loads: NS (the K-split count) is a template parameter and the packs beyond the row are clamped to its
+// last pack instead of branched around, so every load of a lane (partials, bias, LayerNorm scale / bias) is in flight at
+// once.  With a run-time split loop inside per-pack branches each (pack, half, split) was its own round trip: 10 us per
+// launch at 1024 x 1024 where the traffic needs 4.
+template <int NS>
+__global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict__ zpart, long long pstride, int m,
                                                          int n, const float *__restrict__ bias, const float *__restrict__ g,
                                                          const float *__restrict__ beta, float *__restrict__ z,
                                                          BmPlanesOut h, float *__restrict__ stat) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
   const int np = n / 8;   // packs per row
-  f32x4 v[BM_MAXP][2];
+  f32x4 v[BM_MAXP][2], gv[BM_MAXP][2], bv[BM_MAXP][2];
+#pragma unroll
+  for (int k = 0; k < BM_MAXP; ++k) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = 8 * min(lane + 64 * k, np - 1) + 4 * hh;
+      f32x4 t = *reinterpret_cast<const f32x4 *>(zpart + (long long)row * n + c);
+#pragma unroll
+      for (int sp = 1; sp < NS; ++sp) t += *reinterpret_cast<const f32x4 *>(zpart + sp * pstride + (long long)row * n + c);
+      t += *reinterpret_cast<const f32x4 *>(bias + c);
+      v[k][hh] = t;
+      gv[k][hh] = *reinterpret_cast<const f32x4 *>(g + c);
+      bv[k][hh] = *reinterpret_cast<const f32x4 *>(beta + c);
+    }
+  }
   float s = 0.f, q = 0.f;
 #pragma unroll
   for (int k = 0; k < BM_MAXP; ++k) {
-    const int pk = lane + 64 * k;
-    if (pk < np) {
+    if (lane + 64 * k < np) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const int c = 8 * pk + 4 * hh;
-        f32x4 t = *reinterpret_cast<const f32x4 *>(zpart + (long long)row * n + c);
-        for (int sp = 1; sp < nsplit; ++sp) t += *reinterpret_cast<const f32x4 *>(zpart + sp * pstride + (long long)row * n + c);
-        t += *reinterpret_cast<const f32x4 *>(bias + c);
-        *reinterpret_cast<f32x4 *>(z + (long long)row * n + c) = t;
+        const f32x4 t = v[k][hh];
+        *reinterpret_cast<f32x4 *>(z + (long long)row * n + 8 * (lane + 64 * k) + 4 * hh) = t;
         s += (t.x + t.y) + (t.z + t.w);
         q += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
-        v[k][hh] = t;
       }
     }
   }
@@ -440,10 +464,8 @@ __global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict
       float y[8];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const int c = 8 * pk + 4 * hh;
-        const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c), bv = *reinterpret_cast<const f32x4 *>(beta + c);
         const f32x4 xh = (v[k][hh] - mean) * rstd;
-        const f32x4 yy = xh * gv + bv;
+        const f32x4 yy = xh * gv[k][hh] + bv[k][hh];
         y[4 * hh] = fmaxf(yy.x, 0.f); y[4 * hh + 1] = fmaxf(yy.y, 0.f); y[4 * hh + 2] = fmaxf(yy.z, 0.f); y[4 * hh + 3] = fmaxf(yy.w, 0.f);
       }
       u32x4 ph, pm, pl;
@@ -463,25 +485,43 @@ PQN_D long long bm_src_row(const int64_t *idx, int nb, long long next_off, int r
 // Accumulated in f64: flax's fast variance E[x^2] - E[x]^2 cancels catastrophically for columns whose spread is small
 // against their mean, and an f32 running sum would put its own rounding (~1e-5 relative) straight into that difference.
 #define BM_CS_ROWS 64
+// workgroup = 64 columns x 4 waves; wave w sums rows r0 + w, r0 + w + 4, ... of the chunk (16 loads in flight per lane instead
+// of one lane walking 64 rows), the four wave sums are folded in a fixed order through LDS.  grid (ceil(d / 64), chunks).
 __global__ __launch_bounds__(256) void bm_colstats_kernel(const float *__restrict__ x, long long ldx, const int64_t *idx, int nb,
                                                           long long next_off, int m, int d, double *__restrict__ part) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double s_s[4][64], s_q[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   const int r0 = blockIdx.y * BM_CS_ROWS, r1 = min(r0 + BM_CS_ROWS, m);
   const int cc = min(c, d - 1);
+  // lane i < 16 fetches the source row of the wave's i-th row, then the 16 column loads go out together (a loop of
+  // "row index, wait, element, wait" was 2 x 16 dependent round trips)
+  const int myr = r0 + wave + 4 * (lane & 15);
+  const long long mysrc = myr < r1 ? bm_src_row(idx, nb, next_off, myr) : 0ll;
+  float v[BM_CS_ROWS / 4];
+#pragma unroll
+  for (int i = 0; i < BM_CS_ROWS / 4; ++i) v[i] = x[__shfl(mysrc, i) * ldx + cc];   // rows >= r1: row 0, not added
   double s = 0.0, q = 0.0;
-  for (int r = r0; r < r1; ++r) {
-    const double v = (double)x[bm_src_row(idx, nb, next_off, r) * ldx + cc];
-    s += v;
-    q += v * v;
+#pragma unroll
+  for (int i = 0; i < BM_CS_ROWS / 4; ++i) {
+    if (r0 + wave + 4 * i < r1) {
+      const double d = (double)v[i];
+      s += d;
+      q += d * d;
+    }
   }
-  if (c < d) {
-    part[((long long)blockIdx.y * 2) * d + c] = s;
-    part[((long long)blockIdx.y * 2 + 1) * d + c] = q;
+  s_s[wave][lane] = s;
+  s_q[wave][lane] = q;
+  __syncthreads();
+  if (wave == 0 && c < d) {
+    part[((long long)blockIdx.y * 2) * d + c] = (s_s[0][lane] + s_s[1][lane]) + (s_s[2][lane] + s_s[3][lane]);
+    part[((long long)blockIdx.y * 2 + 1) * d + c] = (s_q[0][lane] + s_q[1][lane]) + (s_q[2][lane] + s_q[3][lane]);
   }
 }
 
 // stage 2 + the bookkeeping of utils/batch_renorm.py:95-116 (renorm = 1) / flax nn.BatchNorm (renorm = 0), thread per
-// column.  coef = [4][d]: m_c (mean used), a_c = k_c * scale_c, b_c = bias_c, k_c = 1 / sqrt(var used + eps).
+// column.  coef = [4][ldc] (ldc >= d, a multiple of 8; zero beyond d): m_c (mean used), a_c = k_c * scale_c, b_c = bias_c,
+// k_c = 1 / sqrt(var used + eps).
 // train = 0: coefficients from the running moments only (use_running_average).  steps[0] = BatchRenorm's train-call
 // counter, steps[1] = a ticket word (zero between launches): the last workgroup to finish advances the counter, once
 // every thread of the launch has read it.
@@ -489,15 +529,23 @@ __global__ __launch_bounds__(256) void bm_instat_finish_kernel(const double *__r
                                                                const float *__restrict__ scale, const float *__restrict__ bias,
                                                                float *__restrict__ ra_mean, float *__restrict__ ra_var,
                                                                int32_t *__restrict__ steps, int train, int renorm, float eps,
-                                                               float momentum, float *__restrict__ coef) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+                                                               float momentum, float *__restrict__ coef, int ldc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;   // 64-thread workgroups: d / 64 CUs share the partial loads
   if (c < d) {
     float mean = ra_mean[c], var = ra_var[c];
     if (train) {
       double s = 0.0, q = 0.0;
-      for (int p = 0; p < nparts; ++p) {
-        s += part[((long long)p * 2) * d + c];
-        q += part[((long long)p * 2 + 1) * d + c];
+      for (int p0 = 0; p0 < nparts; p0 += 8) {   // 16 loads in flight; same order of additions
+        double ts[8], tq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int p = min(p0 + u, nparts - 1);
+          ts[u] = part[((long long)p * 2) * d + c];
+          tq[u] = part[((long long)p * 2 + 1) * d + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (p0 + u < nparts) { s += ts[u]; q += tq[u]; }
       }
       const float bmean = (float)(s / (double)m);
       const float bvar = fmaxf((float)(q / (double)m) - bmean * bmean, 0.0f);
@@ -515,9 +563,11 @@ __global__ __launch_bounds__(256) void bm_instat_finish_kernel(const double *__r
     }
     const float k = 1.0f / sqrtf(var + eps);
     coef[c] = mean;
-    coef[d + c] = k * scale[c];
-    coef[2 * d + c] = bias[c];
-    coef[3 * d + c] = k;
+    coef[ldc + c] = k * scale[c];
+    coef[2 * ldc + c] = bias[c];
+    coef[3 * ldc + c] = k;
+  } else if (c < ldc) {
+    coef[c] = 0.0f; coef[ldc + c] = 0.0f; coef[2 * ldc + c] = 0.0f; coef[3 * ldc + c] = 0.0f;
   }
   if (train && renorm) {
     __shared__ int s_last;
@@ -531,38 +581,55 @@ __global__ __launch_bounds__(256) void bm_instat_finish_kernel(const double *__r
   }
 }
 
-// xn[r][c] = (x[src(r)][c] - m_c) a_c + b_c (coef != NULL) or the gathered x itself, as planes [m][ld]; xhat[r][c] =
-// (x - m_c) k_c in f32 for the gradient rows r < nb (xhat != NULL).  One thread per (row, 8 columns); columns >= d zero.
+// xn[r][c] = (x[src(r)][c] - m_c) a_c + b_c (NORM; coef = [4][xn.ld] of bm_instat_finish_kernel) or the gathered x itself, as
+// planes [m][ld]; xhat[r][c] = (x - m_c) k_c in f32 for the gradient rows r < nb (xhat != NULL).  One thread per (row, 8
+// columns); columns >= d zero.  All loads of a thread are independent (8 scalar x -- rows of odd length are not 16-B
+// aligned -- and 8 vector coefficient loads): one memory round trip.  The first version branched on `coef` per element
+// and the compiler serialised the eight (x, 4 coefficients) groups: 16 / 35 us at 1024 / 2048 rows of 1345.
+template <bool NORM>
 __global__ __launch_bounds__(256) void bm_innorm_apply_kernel(const float *__restrict__ x, long long ldx, const int64_t *idx,
                                                               int nb, long long next_off, int m, int d,
                                                               const float *__restrict__ coef, BmPlanesOut xn,
                                                               float *__restrict__ xhat, long long ldh) {
-  const int ppr = (int)(xn.ld / 8);
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long long)m * ppr) return;
-  const int r = (int)(e / ppr), c0 = (int)(e % ppr) * 8;
+  const unsigned ppr = (unsigned)(xn.ld / 8);
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= (unsigned)m * ppr) return;
+  const unsigned ru = e / ppr;
+  const int r = (int)ru, c0 = (int)(e - ru * ppr) * 8;
   const float *xr = x + bm_src_row(idx, nb, next_off, r) * ldx;
-  float o[8], oh[8];
+  float v[8], o[8], oh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = c0 + j, cc = min(c, d - 1);
-    const float v = xr[cc];
-    float y = v, yh = 0.0f;
-    if (coef) {
-      const float xc = v - coef[cc];
-      y = xc * coef[d + cc] + coef[2 * d + cc];
-      yh = xc * coef[3 * d + cc];
+  for (int j = 0; j < 8; ++j) v[j] = xr[min(c0 + j, d - 1)];
+  if (NORM) {
+    const long long ldc = xn.ld;
+    f32x4 cm[2], ca[2], cb[2], ck[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      cm[hh] = *reinterpret_cast<const f32x4 *>(coef + c0 + 4 * hh);
+      ca[hh] = *reinterpret_cast<const f32x4 *>(coef + ldc + c0 + 4 * hh);
+      cb[hh] = *reinterpret_cast<const f32x4 *>(coef + 2 * ldc + c0 + 4 * hh);
+      ck[hh] = *reinterpret_cast<const f32x4 *>(coef + 3 * ldc + c0 + 4 * hh);
     }
-    o[j] = c < d ? y : 0.0f;
-    oh[j] = c < d ? yh : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xc = v[j] - cm[j >> 2][j & 3];
+      const float y = xc * ca[j >> 2][j & 3] + cb[j >> 2][j & 3];
+      const float yh = xc * ck[j >> 2][j & 3];
+      o[j] = c0 + j < d ? y : 0.0f;
+      oh[j] = c0 + j < d ? yh : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = c0 + j < d ? v[j] : 0.0f; oh[j] = 0.0f; }
   }
   u32x4 h, mm, l;
   bm_split8(o, h, mm, l);
   bm_put(xn, r, c0, h, mm, l);
-  if (xhat && r < nb) {
+  if (NORM && xhat && r < nb) {   // ldh % 4 == 0: whole 16-B stores
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (c0 + j < ldh) xhat[(long long)r * ldh + c0 + j] = oh[j];
+    for (int hh = 0; hh < 2; ++hh)
+      if (c0 + 4 * hh < ldh)
+        *reinterpret_cast<f32x4 *>(xhat + (long long)r * ldh + c0 + 4 * hh) = f32x4{oh[4 * hh], oh[4 * hh + 1], oh[4 * hh + 2], oh[4 * hh + 3]};
   }
 }
 
@@ -586,14 +653,21 @@ __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__
     float g = 0.f;
     int act = -1;
     if (r < b) {
+      // the Q rows are loaded whole, as vectors, before anything that depends on idx / action arrives: a run-time loop over
+      // the a actions compiled to a actions x (load, wait), 16 dependent round trips on the single workgroup of the chain
+      float qr[32], qx[32];
+      bm_load_qrow(q + (long long)r * ldq, ldq, qr);
+      if (next_rows) bm_load_qrow(q + (long long)(b + r) * ldq, ldq, qx);
       const long long j = idx ? idx[r] : r;
       act = action[j];
-      const float qa = q[(long long)r * ldq + act];
+      float qa = qr[0];
+#pragma unroll
+      for (int k = 1; k < 32; ++k) qa = k == act ? qr[k] : qa;
       float tgt;
       if (next_rows) {
-        const float *qn = q + (long long)(b + r) * ldq;
-        float mx = qn[0];
-        for (int k = 1; k < a; ++k) mx = fmaxf(mx, qn[k]);
+        float mx = qx[0];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) mx = k < a ? fmaxf(mx, qx[k]) : mx;
         tgt = reward[j] + (1.0f - (float)done[j]) * gamma * mx;
       } else {
         tgt = target[j];
@@ -639,8 +713,9 @@ __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__
 // BM_LB_ROWS rows per workgroup.
 //   y = xhat g + beta;  dy = d [y > 0];  dxh = dy g;  dz = rstd (dxh - mean(dxh) - xhat mean(dxh xhat))
 // part[wg][0] = sum_rows dy xhat (d scale), [1] = sum_rows dy (d LN bias), [2] = sum_rows dz (d dense bias).  n <= 2048, n % 256 == 0.
-#define BM_LB_ROWS 8
-__global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict__ dpart, int nsplit, long long pstride,
+#define BM_LB_ROWS 4   // one row per wave: 256 workgroups at 1024 gradient rows
+template <int NS>   // the K-split count of dpart: straight-line loads, see bm_ln_relu_kernel
+__global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict__ dpart, long long pstride,
                                                         BmPlanesOut dzp, const float *__restrict__ z,
                                                         const float *__restrict__ stat, const float *__restrict__ g,
                                                         const float *__restrict__ beta, int rows, int n,
@@ -659,6 +734,21 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
     const float mean = stat[2 * row], rstd = stat[2 * row + 1];
     const float *zr = z + (long long)row * n;
     f32x4 xh[BM_MAXP][2], dxh[BM_MAXP][2], dy[BM_MAXP][2];
+    f32x4 zv[BM_MAXP][2], dv[BM_MAXP][2], gv[BM_MAXP][2], bv[BM_MAXP][2];
+#pragma unroll
+    for (int k = 0; k < BM_MAXP; ++k) {   // every load of the row in flight at once (packs beyond the row: its last pack again)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int c = 8 * min(lane + 64 * k, np - 1) + 4 * hh;
+        zv[k][hh] = *reinterpret_cast<const f32x4 *>(zr + c);
+        f32x4 d = *reinterpret_cast<const f32x4 *>(dpart + (long long)row * n + c);   // d loss / d h: sum of the K-split partials
+#pragma unroll
+        for (int sp = 1; sp < NS; ++sp) d += *reinterpret_cast<const f32x4 *>(dpart + sp * pstride + (long long)row * n + c);
+        dv[k][hh] = d;
+        gv[k][hh] = *reinterpret_cast<const f32x4 *>(g + c);
+        bv[k][hh] = *reinterpret_cast<const f32x4 *>(beta + c);
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < BM_MAXP; ++k) {
@@ -666,15 +756,11 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
       if (pk < np) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const int c = 8 * pk + 4 * hh;
-          const f32x4 zv = *reinterpret_cast<const f32x4 *>(zr + c);
-          f32x4 dv = *reinterpret_cast<const f32x4 *>(dpart + (long long)row * n + c);   // d loss / d h: sum of the K-split partials
-          for (int sp = 1; sp < nsplit; ++sp) dv += *reinterpret_cast<const f32x4 *>(dpart + sp * pstride + (long long)row * n + c);
-          const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c), bv = *reinterpret_cast<const f32x4 *>(beta + c);
-          xh[k][hh] = (zv - mean) * rstd;
-          const f32x4 y = xh[k][hh] * gv + bv;
-          dy[k][hh] = f32x4{y.x > 0.f ? dv.x : 0.f, y.y > 0.f ? dv.y : 0.f, y.z > 0.f ? dv.z : 0.f, y.w > 0.f ? dv.w : 0.f};
-          dxh[k][hh] = dy[k][hh] * gv;
+          xh[k][hh] = (zv[k][hh] - mean) * rstd;
+          const f32x4 y = xh[k][hh] * gv[k][hh] + bv[k][hh];
+          const f32x4 d = dv[k][hh];
+          dy[k][hh] = f32x4{y.x > 0.f ? d.x : 0.f, y.y > 0.f ? d.y : 0.f, y.z > 0.f ? d.z : 0.f, y.w > 0.f ? d.w : 0.f};
+          dxh[k][hh] = dy[k][hh] * gv[k][hh];
           s1 += (dxh[k][hh].x + dxh[k][hh].y) + (dxh[k][hh].z + dxh[k][hh].w);
           const f32x4 t = dxh[k][hh] * xh[k][hh];
           s2 += (t.x + t.y) + (t.z + t.w);
@@ -730,17 +816,22 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
 
 // out_k[c] = sum_p part[(p * nseg + k) * n + c], k < nseg.  Workgroup = 64 (k, c) elements x 16 partial groups: group j
 // sums partials j, j + 16, ... (fixed order), the 16 group sums are folded in a fixed tree through LDS.
-__global__ __launch_bounds__(1024) void bm_colreduce_kernel(const float *__restrict__ part, int nparts, int nseg, int n,
-                                                            float *__restrict__ out0, float *__restrict__ out1,
-                                                            float *__restrict__ out2) {
-  __shared__ float s_r[16][64];
+PQN_D void bm_colreduce_body(const float *__restrict__ part, int nparts, int nseg, int n, float *__restrict__ out0,
+                             float *__restrict__ out1, float *__restrict__ out2, int block, float (*s_r)[64]) {
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;
+  const int e = block * 64 + lane;
   const bool ok = e < nseg * n;
   const int ee = ok ? e : 0;
   const int k = ee / n, c = ee - k * n;
   float s = 0.f;
-  for (int p = grp; p < nparts; p += 16) s += part[((long long)p * nseg + k) * n + c];
+  for (int p0 = grp; p0 < nparts; p0 += 16 * 8) {   // 8 loads in flight; same order of additions
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = part[((long long)min(p0 + 16 * u, nparts - 1) * nseg + k) * n + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + 16 * u < nparts) s += t[u];
+  }
   s_r[grp][lane] = s;
   __syncthreads();
   if (grp == 0 && ok) {
@@ -753,15 +844,52 @@ __global__ __launch_bounds__(1024) void bm_colreduce_kernel(const float *__restr
     if (o) o[c] = r;
   }
 }
+__global__ __launch_bounds__(1024) void bm_colreduce_kernel(const float *__restrict__ part, int nparts, int nseg, int n,
+                                                            float *__restrict__ out0, float *__restrict__ out1,
+                                                            float *__restrict__ out2) {
+  __shared__ float s_r[16][64];
+  bm_colreduce_body(part, nparts, nseg, n, out0, out1, out2, blockIdx.x, s_r);
+}
+// the column sums of every layer in one launch (job j owns blocks [first[j], first[j + 1])): same body, same sums
+struct BmColreduceJobs {
+  int n;
+  const float *part[BM_MAX_JOBS];
+  int nparts[BM_MAX_JOBS], nseg[BM_MAX_JOBS], ncol[BM_MAX_JOBS];
+  float *out[BM_MAX_JOBS][3];
+  int first[BM_MAX_JOBS + 1];
+};
+__global__ __launch_bounds__(1024) void bm_colreduce_multi_kernel(BmColreduceJobs J) {
+  __shared__ float s_r[16][64];
+  int j = 0;
+  while (j + 1 < J.n && (int)blockIdx.x >= J.first[j + 1]) ++j;
+  bm_colreduce_body(J.part[j], J.nparts[j], J.nseg[j], J.ncol[j], J.out[j][0], J.out[j][1], J.out[j][2], (int)blockIdx.x - J.first[j], s_r);
+}
 
 // out[i] = sum of the nsplit K-split partials of a weight-gradient GEMM (i < n, n % 4 == 0, everything 16-B aligned)
-__global__ __launch_bounds__(256) void bm_sum_partials_kernel(const float *__restrict__ part, int nsplit, long long pstride,
-                                                              long long n, float *__restrict__ out) {
-  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+PQN_D void bm_sum_partials_body(const float *__restrict__ part, int nsplit, long long pstride, long long n, float *__restrict__ out,
+                                long long block) {
+  const long long i = (block * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   f32x4 v = *reinterpret_cast<const f32x4 *>(part + i);
   for (int sp = 1; sp < nsplit; ++sp) v += *reinterpret_cast<const f32x4 *>(part + sp * pstride + i);
   *reinterpret_cast<f32x4 *>(out + i) = v;
+}
+__global__ __launch_bounds__(256) void bm_sum_partials_kernel(const float *__restrict__ part, int nsplit, long long pstride,
+                                                              long long n, float *__restrict__ out) {
+  bm_sum_partials_body(part, nsplit, pstride, n, out, blockIdx.x);
+}
+struct BmSumJobs {
+  int n;
+  const float *part[BM_MAX_JOBS];
+  int nsplit[BM_MAX_JOBS];
+  long long pstride[BM_MAX_JOBS], cnt[BM_MAX_JOBS];
+  float *out[BM_MAX_JOBS];
+  long long first[BM_MAX_JOBS + 1];
+};
+__global__ __launch_bounds__(256) void bm_sum_partials_multi_kernel(BmSumJobs J) {
+  int j = 0;
+  while (j + 1 < J.n && (long long)blockIdx.x >= J.first[j + 1]) ++j;
+  bm_sum_partials_body(J.part[j], J.nsplit[j], J.pstride[j], J.cnt[j], J.out[j], (long long)blockIdx.x - J.first[j]);
 }
 
 // eps-greedy over q rows with stride ldq (first-max argmax; element e draws threefry(key, (e, PQN_STREAM_ACT)))
@@ -773,15 +901,21 @@ __global__ __launch_bounds__(256) void bm_epsgreedy_kernel(const float *__restri
   if (i >= m) return;
   if (eps_dev) eps = *eps_dev;
   if (key_dev) key = *key_dev;
-  const float *qi = q + (long long)i * ldq;
+  float qi[32];
+  bm_load_qrow(q + (long long)i * ldq, ldq, qi);   // ldq % 4 == 0: the whole row in 8 vector loads
   int best = 0;
   float bv = qi[0];
-  for (int j = 1; j < a; ++j) {
-    const float v = qi[j];
-    if (v > bv) { bv = v; best = j; }
+#pragma unroll
+  for (int j = 1; j < 32; ++j) {
+    const bool up = j < a && qi[j] > bv;
+    bv = up ? qi[j] : bv;
+    best = up ? j : best;
   }
-  if (q_out)
-    for (int j = 0; j < a; ++j) q_out[(long long)i * a + j] = qi[j];
+  if (q_out) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < a) q_out[(long long)i * a + j] = qi[j];
+  }
   if (action) {
     uint32_t o0, o1;
     pqn_bits(key, (uint32_t)i, PQN_STREAM_ACT, o0, o1);
@@ -915,7 +1049,7 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
   w.n_cs = (rows + BM_CS_ROWS - 1) / BM_CS_ROWS;
   w.n_ln = (nb + BM_LB_ROWS - 1) / BM_LB_ROWS;
   w.n_in = (nb + 63) / 64;
-  w.coef = take(4ll * L.d);
+  w.coef = take(4ll * w.dp);   // [4][dp], zero beyond d
   w.cspart = take(4ll * w.n_cs * L.d);   // f64 partials
   w.xhat = take((long long)nb * w.ldx);
   for (int l = 0; l < L.layers; ++l) {
@@ -971,6 +1105,31 @@ BmWp bm_wp(const pqn_bigmlp_layout_t &L) {
   return w;
 }
 
+// K-split count -> template instance
+template <typename... Args>
+void bm_ln_relu(int ns, int blocks, hipStream_t st, Args... args) {
+  switch (ns) {
+    case 1: hipLaunchKernelGGL(bm_ln_relu_kernel<1>, dim3(blocks), dim3(256), 0, st, args...); break;
+    case 2: hipLaunchKernelGGL(bm_ln_relu_kernel<2>, dim3(blocks), dim3(256), 0, st, args...); break;
+    case 3: hipLaunchKernelGGL(bm_ln_relu_kernel<3>, dim3(blocks), dim3(256), 0, st, args...); break;
+    default: hipLaunchKernelGGL(bm_ln_relu_kernel<4>, dim3(blocks), dim3(256), 0, st, args...); break;
+  }
+}
+template <typename... Args>
+void bm_ln_bwd(int ns, int blocks, hipStream_t st, Args... args) {
+  switch (ns) {
+    case 1: hipLaunchKernelGGL(bm_ln_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, args...); break;
+    case 2: hipLaunchKernelGGL(bm_ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, args...); break;
+    case 3: hipLaunchKernelGGL(bm_ln_bwd_kernel<3>, dim3(blocks), dim3(256), 0, st, args...); break;
+    default: hipLaunchKernelGGL(bm_ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, st, args...); break;
+  }
+}
+template <typename... Args>
+void bm_innorm_apply(bool norm, unsigned blocks, hipStream_t st, Args... args) {
+  if (norm) hipLaunchKernelGGL(bm_innorm_apply_kernel<true>, dim3(blocks), dim3(256), 0, st, args...);
+  else hipLaunchKernelGGL(bm_innorm_apply_kernel<false>, dim3(blocks), dim3(256), 0, st, args...);
+}
+
 // forward from the (normalised, gathered) input planes through the hidden layers (z_l, h_l planes, stat_l kept) to Q
 int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, const bf16_t *wpl, float *ws, bf16_t *wb, const BmWs &w,
                hipStream_t st) {
@@ -982,9 +1141,8 @@ int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, const
     int ns = 1;
     const int rc = bm_gemm(rows, L.h, kp, A, B, bm_store(ws + w.zpart, L.h, nullptr, w.zstride), BM_MAX_SPLIT, &ns, st);
     if (rc != PQN_OK) return rc;
-    hipLaunchKernelGGL(bm_ln_relu_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ws + w.zpart, ns, w.zstride, rows, L.h,
-                       theta + L.off_b[l], theta + L.off_lns[l], theta + L.off_lnb[l], ws + w.z[l], bm_plo(wb + w.h[l], rows, L.h),
-                       ws + w.stat[l]);
+    bm_ln_relu(ns, (rows + 3) / 4, st, (const float *)(ws + w.zpart), w.zstride, rows, L.h, theta + L.off_b[l], theta + L.off_lns[l],
+               theta + L.off_lnb[l], ws + w.z[l], bm_plo(wb + w.h[l], rows, L.h), ws + w.stat[l]);
   }
   const int lo = L.layers;   // output layer: Q = h_last W_out + b_out (narrow: no K split)
   return bm_gemm(rows, L.a, L.h, bm_pl(wb + w.h[lo - 1], rows, L.h), bm_pl(wpl + wp.wt[lo], L.a, L.h),
@@ -1106,14 +1264,13 @@ extern "C" int pqn_bigmlp_forward(const pqn_bigmlp_layout_t *L, int32_t n, const
   const bf16_t *wpl = reinterpret_cast<const bf16_t *>(wplanes);
   const float *coef = nullptr;
   if (L->norm_input) {   // use_running_average: coefficients from the running moments
-    hipLaunchKernelGGL(bm_instat_finish_kernel, dim3((L->d + 255) / 256), dim3(256), 0, st, (const double *)nullptr, 0, n, L->d,
+    hipLaunchKernelGGL(bm_instat_finish_kernel, dim3((w.dp + 63) / 64), dim3(64), 0, st, (const double *)nullptr, 0, n, L->d,
                        theta + L->off_in_scale, theta + L->off_in_bias, in_mean, in_var, (int32_t *)nullptr, 0,
-                       L->norm_input == 2 ? 1 : 0, L->norm_input == 2 ? 1e-3f : 1e-5f, 0.0f, ws + w.coef);
+                       L->norm_input == 2 ? 1 : 0, L->norm_input == 2 ? 1e-3f : 1e-5f, 0.0f, ws + w.coef, w.dp);
     coef = ws + w.coef;
   }
-  hipLaunchKernelGGL(bm_innorm_apply_kernel, dim3((unsigned)(((long long)n * (w.dp / 8) + 255) / 256)), dim3(256), 0, st, obs,
-                     (long long)L->d, (const int64_t *)nullptr, n, 0ll, n, L->d, coef, bm_plo(wb + w.xn, n, w.dp), (float *)nullptr,
-                     (long long)w.ldx);
+  bm_innorm_apply(coef != nullptr, (unsigned)(((long long)n * (w.dp / 8) + 255) / 256), st, obs, (long long)L->d, (const int64_t *)nullptr,
+                  n, 0ll, n, L->d, coef, bm_plo(wb + w.xn, n, w.dp), (float *)nullptr, (long long)w.ldx);
   const int rc = bm_forward(*L, n, theta, wpl, ws, wb, w, st);
   if (rc != PQN_OK) return rc;
   hipLaunchKernelGGL(bm_epsgreedy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws + w.q, w.ldq, n, L->a, eps, key, eps_dev,
@@ -1142,12 +1299,12 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
   const float *coef = nullptr;
   if (L->norm_input) {
     const bool renorm = L->norm_input == 2;
-    hipLaunchKernelGGL(bm_colstats_kernel, dim3((L->d + 255) / 256, w.n_cs), dim3(256), 0, st, obs, (long long)L->d, idx, nb,
+    hipLaunchKernelGGL(bm_colstats_kernel, dim3((L->d + 63) / 64, w.n_cs), dim3(256), 0, st, obs, (long long)L->d, idx, nb,
                        (long long)next_offset, rows, L->d, reinterpret_cast<double *>(ws + w.cspart));
-    hipLaunchKernelGGL(bm_instat_finish_kernel, dim3((L->d + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(bm_instat_finish_kernel, dim3((w.dp + 63) / 64), dim3(64), 0, st,
                        reinterpret_cast<const double *>(ws + w.cspart), w.n_cs, rows, L->d, theta + L->off_in_scale,
                        theta + L->off_in_bias, in_mean, in_var, in_steps, 1, renorm ? 1 : 0, renorm ? 1e-3f : 1e-5f,
-                       renorm ? 0.999f : 0.99f, ws + w.coef);
+                       renorm ? 0.999f : 0.99f, ws + w.coef, w.dp);
     coef = ws + w.coef;
   } else {   // the dummy input normalisation never receives gradient (pqn_craftax.py:47-49)
     if (hipMemsetAsync(grad + L->off_in_scale, 0, sizeof(float) * (size_t)(L->off_w[0] - L->off_in_scale), st) != hipSuccess) {
@@ -1155,16 +1312,36 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
       return PQN_E_HIP;
     }
   }
-  hipLaunchKernelGGL(bm_innorm_apply_kernel, dim3((unsigned)(((long long)rows * (w.dp / 8) + 255) / 256)), dim3(256), 0, st, obs,
-                     (long long)L->d, idx, nb, (long long)next_offset, rows, L->d, coef, bm_plo(wb + w.xn, rows, w.dp),
-                     coef ? ws + w.xhat : (float *)nullptr, (long long)w.ldx);
+  bm_innorm_apply(coef != nullptr, (unsigned)(((long long)rows * (w.dp / 8) + 255) / 256), st, obs, (long long)L->d, idx, nb,
+                  (long long)next_offset, rows, L->d, coef, bm_plo(wb + w.xn, rows, w.dp), coef ? ws + w.xhat : (float *)nullptr,
+                  (long long)w.ldx);
   int rc = bm_forward(*L, rows, theta, wpl, ws, wb, w, st);
   if (rc != PQN_OK) return rc;
   // backward over the first nb rows (the next_obs half carries no gradient: stop_gradient, pqn_craftax.py:301).
   // Weight gradient d W = Hin^T dZ: both operands with the samples as K = the transposed plane copies [feature][sample].
-  // `sd` = the side stream of bm_fork (the caller's stream without it): see there for what runs where.
+  // Two launch orders, same kernels / buffers / sums (bit-identical results, tested):
+  //  * default: the input-gradient chain first (loss -> d h_last -> LayerNorm backward_l -> d h_{l-1} ...), then everything
+  //    that ends in a parameter gradient in FOUR batched steps: one transpose launch (input, h_l, dQ, dz_l), one column-sum
+  //    launch (LayerNorm / bias gradients of every layer, the input-normalisation gradient), the d W GEMMs, one fold launch
+  //    of their K-split partials -- 3 small launches instead of 15 (profiles/r04_v7_c5_batched_backward.txt);
+  //  * option bm_overlap = 1: layer by layer on the side stream of bm_fork beside the chain (see there).
   BmFork *fk = bm_fork();
-  auto wgrad = [&](int l, int kin, const BmPlanes &HinT, const BmPlanes &dZT, int n_out, float *gout, hipStream_t sd) -> int {
+  const bool deferred = fk == nullptr;
+  BmTransposeBatch TB;
+  BmColreduceJobs CJ = {};
+  BmSumJobs SJ = {};
+  struct PendingWgrad { int l, kin, n_out; BmPlanes HinT, dZT; float *gout; } pend[PQN_BIGMLP_MAX_LAYERS + 1];
+  int npend = 0;
+  auto fold = [&](const float *part, int ns, long long cnt, float *gout, hipStream_t sd) {
+    if (deferred) {
+      const int j = SJ.n++;
+      SJ.part[j] = part; SJ.nsplit[j] = ns; SJ.pstride[j] = w.wstride; SJ.cnt[j] = cnt; SJ.out[j] = gout;
+      SJ.first[j + 1] = SJ.first[j] + (cnt / 4 + 255) / 256;
+    } else {
+      hipLaunchKernelGGL(bm_sum_partials_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, sd, part, ns, w.wstride, cnt, gout);
+    }
+  };
+  auto wgrad_now = [&](int l, int kin, const BmPlanes &HinT, const BmPlanes &dZT, int n_out, float *gout, hipStream_t sd) -> int {
     int ns = 1;
     const long long cnt = (long long)kin * n_out;
     const bool direct = n_out < 64 || (cnt & 3);        // narrow output layer: one split, straight into the gradient
@@ -1172,21 +1349,41 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
     const int r = bm_gemm(kin, n_out, w.nbp, HinT, dZT, direct ? bm_store(gout, n_out) : bm_store(part, n_out, nullptr, w.wstride),
                           direct ? 1 : BM_MAX_SPLIT, &ns, sd);
     if (r != PQN_OK || direct) return r;
-    hipLaunchKernelGGL(bm_sum_partials_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, sd, part, ns, w.wstride, cnt, gout);
+    fold(part, ns, cnt, gout, sd);
     return PQN_OK;
   };
+  auto wgrad = [&](int l, int kin, const BmPlanes &HinT, const BmPlanes &dZT, int n_out, float *gout, hipStream_t sd) -> int {
+    if (!deferred) return wgrad_now(l, kin, HinT, dZT, n_out, gout, sd);
+    pend[npend++] = PendingWgrad{l, kin, n_out, HinT, dZT, gout};
+    return PQN_OK;
+  };
+  auto transpose = [&](const BmPlanes &src, int cols, const BmPlanesOut &dst, hipStream_t sd) {
+    if (deferred) TB.add(src, cols, dst);
+    else bm_transpose(src, cols, dst, sd);
+  };
+  auto colreduce = [&](const float *part, int nparts, int nseg, int ncol, float *o0, float *o1, float *o2, hipStream_t sd) {
+    if (deferred) {
+      const int j = CJ.n++;
+      CJ.part[j] = part; CJ.nparts[j] = nparts; CJ.nseg[j] = nseg; CJ.ncol[j] = ncol;
+      CJ.out[j][0] = o0; CJ.out[j][1] = o1; CJ.out[j][2] = o2;
+      CJ.first[j + 1] = CJ.first[j] + (nseg * ncol + 63) / 64;
+    } else {
+      hipLaunchKernelGGL(bm_colreduce_kernel, dim3((nseg * ncol + 63) / 64), dim3(1024), 0, sd, part, nparts, nseg, ncol, o0, o1, o2);
+    }
+  };
   // transposed copies of the gradient rows of every layer input (the normalised input, h_0 .. h_{L-1}): they depend on the
-  // forward pass only, so all of them go out at once, beside the loss kernel
+  // forward pass only (side stream: all of them at once, beside the loss kernel)
   hipStream_t sd = bm_fork_at(fk, 0, st);
   {
     BmTransposeBatch T;
+    BmTransposeBatch &TT = deferred ? TB : T;
     BmPlanes src = bm_pl(wb + w.xn, nb, w.dp);
     src.pstride = (long long)rows * w.dp;   // the planes hold all forward rows; only the first nb are transposed
-    T.add(src, L->d, bm_plo(wb + w.xnT, L->d, w.nbp));
+    TT.add(src, L->d, bm_plo(wb + w.xnT, L->d, w.nbp));
     for (int l = 0; l < L->layers; ++l) {
       BmPlanes sh = bm_pl(wb + w.h[l], nb, L->h);
       sh.pstride = (long long)rows * L->h;
-      T.add(sh, L->h, bm_plo(wb + w.hT[l], L->h, w.nbp));
+      TT.add(sh, L->h, bm_plo(wb + w.hT[l], L->h, w.nbp));
     }
     T.launch(sd);
   }
@@ -1196,7 +1393,7 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
                      gamma, next_offset > 0 ? 1 : 0, bm_plo(wb + w.dq, nb, 32), grad + L->off_b[lo], loss_out, qv_out);
   // output layer: d W_out = h_last^T dQ (side);   d h_last = dQ W_out^T (K = a padded to 32: one split)
   sd = bm_fork_at(fk, 1, st);
-  bm_transpose(bm_pl(wb + w.dq, nb, 32), L->a, bm_plo(wb + w.dqT, L->a, w.nbp), sd);
+  transpose(bm_pl(wb + w.dq, nb, 32), L->a, bm_plo(wb + w.dqT, L->a, w.nbp), sd);
   int rc2 = wgrad(lo, L->h, hT(lo - 1), bm_pl(wb + w.dqT, L->a, w.nbp), L->a, grad + L->off_w[lo], sd);
   if (rc2 != PQN_OK) return rc2;
   int nsd = 1;
@@ -1205,15 +1402,14 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
   if (rc != PQN_OK) return rc;
   for (int l = lo - 1; l >= 0; --l) {
     // dpart (nsd K-split partials) = d loss / d h_l  ->  relu mask + LayerNorm backward: dz planes = d loss / d z_l
-    hipLaunchKernelGGL(bm_ln_bwd_kernel, dim3(w.n_ln), dim3(256), 0, st, ws + w.dpart, nsd, w.dstride, bm_plo(wb + w.dz[l], nb, L->h),
-                       ws + w.z[l], ws + w.stat[l], theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart[l]);
+    bm_ln_bwd(nsd, w.n_ln, st, (const float *)(ws + w.dpart), w.dstride, bm_plo(wb + w.dz[l], nb, L->h), (const float *)(ws + w.z[l]),
+              (const float *)(ws + w.stat[l]), theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart[l]);
     const int kin = l ? L->h : L->d;
     const BmPlanes dZ = bm_pl(wb + w.dz[l], nb, L->h);
     // side: LayerNorm / bias gradients, d W_l = h_{l-1}^T dZ_l
     sd = bm_fork_at(fk, 2 + l, st);
-    hipLaunchKernelGGL(bm_colreduce_kernel, dim3((3 * L->h + 63) / 64), dim3(1024), 0, sd, ws + w.lnpart[l], w.n_ln, 3, L->h,
-                       grad + L->off_lns[l], grad + L->off_lnb[l], grad + L->off_b[l]);
-    bm_transpose(dZ, L->h, bm_plo(wb + w.dzT[l], L->h, w.nbp), sd);
+    colreduce(ws + w.lnpart[l], w.n_ln, 3, L->h, grad + L->off_lns[l], grad + L->off_lnb[l], grad + L->off_b[l], sd);
+    transpose(dZ, L->h, bm_plo(wb + w.dzT[l], L->h, w.nbp), sd);
     rc = wgrad(l, kin, hT(l - 1), bm_pl(wb + w.dzT[l], L->h, w.nbp), L->h, grad + L->off_w[l], sd);
     if (rc != PQN_OK) return rc;
     const BmPlanes Wn = bm_pl(wpl + wp.wn[l], kin, L->h);   // rows = input feature, K = output feature
@@ -1227,9 +1423,19 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
       const BmPlan p = bm_plan(nb, kin, L->h, BM_MAX_SPLIT);
       rc = bm_launch<BM_EPI_INNORM>(nb, kin, L->h, p, dZ, Wn, E, st);
       if (rc != PQN_OK) return rc;
-      hipLaunchKernelGGL(bm_colreduce_kernel, dim3((2 * L->d + 63) / 64), dim3(1024), 0, st, ws + w.inpart, p.nsplit * ((nb + p.bm - 1) / p.bm), 2, L->d,
-                         grad + L->off_in_scale, grad + L->off_in_bias, (float *)nullptr);
+      colreduce(ws + w.inpart, p.nsplit * ((nb + p.bm - 1) / p.bm), 2, L->d, grad + L->off_in_scale, grad + L->off_in_bias,
+                (float *)nullptr, st);
     }
+  }
+  if (deferred) {
+    TB.launch(st);
+    if (CJ.n) hipLaunchKernelGGL(bm_colreduce_multi_kernel, dim3((unsigned)CJ.first[CJ.n]), dim3(1024), 0, st, CJ);
+    for (int i = 0; i < npend; ++i) {
+      const PendingWgrad &g = pend[i];
+      rc = wgrad_now(g.l, g.kin, g.HinT, g.dZT, g.n_out, g.gout, st);
+      if (rc != PQN_OK) return rc;
+    }
+    if (SJ.n) hipLaunchKernelGGL(bm_sum_partials_multi_kernel, dim3((unsigned)SJ.first[SJ.n]), dim3(256), 0, st, SJ);
   }
   bm_join(fk, PQN_BIGMLP_MAX_LAYERS + 3, st);
   return pqn_check_launch("pqn_bigmlp_grad");

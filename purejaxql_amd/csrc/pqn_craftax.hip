@@ -14,7 +14,7 @@
 //                     SoA words (<= ~150 cell reads, a handful of byte writes per step)
 //   cc_reset_kernel   lane per env: which finished envs restart from which reset slot (auto-reset: its own; optimistic
 //                     resets: the wrapper's rank rule), scalars of the fresh episode
-//   cc_world_kernel   thread per (env, map word): procedural world of the restarting envs -- a pure function of
+//   cc_world_kernel   thread per (env, map cell): procedural world of the restarting envs -- a pure function of
 //                     (key, slot, cell): fixed-point value noise, so the 4 KB map is regenerated in parallel
 //   cc_obs_kernel     workgroup per env: 7 x 9 view -> 1345 f32 (21 one-hot channels per cell + 22 scalars), coalesced
 #include <string.h>
@@ -139,7 +139,10 @@ struct Scalars {
     return m;
   }
   PQN_D void load(const uint32_t *st, int n, int e) {
-    auto W = [&](int i) { return st[(size_t)(MAP_WORDS + i) * n + e]; };
+    load_from([&](int i) { return st[(size_t)(MAP_WORDS + i) * n + e]; });
+  }
+  template <class F>
+  PQN_D void load_from(F W) {   // W(i) = scalar word i (SCALAR_WORDS of them)
     const uint32_t w0 = W(0), w2 = W(2);
     pr = w0 & 255; pc = (w0 >> 8) & 255; dir = (w0 >> 16) & 255; sleeping = (w0 >> 24) & 1;
     health = (int)W(1);
@@ -511,8 +514,17 @@ __global__ __launch_bounds__(256) void cc_reset_kernel(int n, int mode, int rese
       __syncthreads();
       for (int j = threadIdx.x; j < cnt; j += 256) s_keys[j] = opt_keys[base + j];
       __syncthreads();
-      if (mine_done)
-        for (int j = 0; j < cnt; ++j) rank += s_keys[j] < mine;   // uniform index: an LDS broadcast per iteration
+      if (mine_done) {   // uniform index: an LDS broadcast per key, 16 reads in flight
+        int j = 0;
+        for (; j + 16 <= cnt; j += 16) {
+          uint64_t k[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) k[u] = s_keys[j + u];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) rank += k[u] < mine;
+        }
+        for (; j < cnt; ++j) rank += s_keys[j] < mine;
+      }
     }
   }
   if (e >= n) return;
@@ -531,9 +543,10 @@ __global__ __launch_bounds__(256) void cc_reset_kernel(int n, int mode, int rese
   }
 }
 
-// workgroup per env: the world of a restarting env, 4 map words (16 cells) per thread.  Few envs restart per step, so the
-// parallelism has to come from the cells of one world (a lane-per-env form left one lane of a wave generating 64 cells
-// in sequence: 121 us per step at 1024 envs); the other workgroups leave at once.
+// the world of a restarting env: thread per CELL, grid (env, 16 blocks of 256 cells); the four lanes of a map word pack
+// their bytes with two lane exchanges.  Few envs restart per step, so the parallelism has to come from the cells of one
+// world: a lane-per-env form left one lane of a wave generating 4096 cells in sequence (121 us per step at 1024 envs), 16
+// cells per thread still 38 us on average (world_cell is ~1000 integer instructions); the other workgroups leave at once.
 __global__ __launch_bounds__(256) void cc_world_kernel(int n, uint64_t key, const uint64_t *__restrict__ key_dev, int fold_reset,
                                                        const int32_t *__restrict__ slots, uint32_t *__restrict__ state) {
   const int e = blockIdx.x;
@@ -543,15 +556,11 @@ __global__ __launch_bounds__(256) void cc_world_kernel(int n, uint64_t key, cons
   if (fold_reset) key = pqn_fold(key, 1u);   // optimistic resets draw their worlds from fold_in(key, 1)
   uint32_t o0, o1;
   pqn_bits(key, (uint32_t)slot, cc::ST_WORLD, o0, o1);
-  for (int mw = threadIdx.x; mw < cc::MAP_WORDS; mw += 256) {
-    uint32_t w = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int cell = 4 * mw + k;
-      w |= (uint32_t)cc::world_cell(o0, cell >> 6, cell & 63) << (8 * k);
-    }
-    state[(size_t)mw * n + e] = w;
-  }
+  const int cell = blockIdx.y * 256 + threadIdx.x;
+  uint32_t w = (uint32_t)cc::world_cell(o0, cell >> 6, cell & 63) << (8 * (cell & 3));
+  w |= __shfl_xor(w, 1);
+  w |= __shfl_xor(w, 2);
+  if ((cell & 3) == 0) state[(size_t)(cell >> 2) * n + e] = w;
 }
 
 // workgroup per env: the symbolic observation
@@ -559,9 +568,14 @@ __global__ __launch_bounds__(256) void cc_obs_kernel(int n, const uint32_t *__re
   __shared__ int s_cell[64];      // block id | mob channel bits << 8
   __shared__ float s_tail[22];
   const int e = blockIdx.x, tid = threadIdx.x;
-  __shared__ int s_p[2];
+  // the scalar words of env e sit in SCALAR_WORDS different cache lines ([word][env] layout): ONE vector load (lane =
+  // word), then every lane unpacks from LDS.  A uniform-address load per word compiles to a chain of scalar loads, each
+  // waited for before the next (28 round trips: 25 us per launch at 1024 envs).
+  __shared__ uint32_t s_w[cc::SCALAR_WORDS];
+  if (tid < cc::SCALAR_WORDS) s_w[tid] = state[(size_t)(cc::MAP_WORDS + tid) * n + e];
+  __syncthreads();
   cc::Scalars s;
-  s.load(state, n, e);            // every lane loads the same words (broadcast)
+  s.load_from([&](int i) { return s_w[i]; });
   if (tid < 63) {
     const int vr = tid / 9, vc = tid % 9;
     const int r = s.pr + vr - 3, c = s.pc + vc - 4;
@@ -588,7 +602,6 @@ __global__ __launch_bounds__(256) void cc_obs_kernel(int n, const uint32_t *__re
     else t = (float)s.sleeping;
     s_tail[tid] = t;
   }
-  (void)s_p;
   __syncthreads();
   float *dst = obs + (size_t)e * cc::OBS;
   for (int i = tid; i < cc::OBS; i += 256) {
@@ -689,7 +702,7 @@ int pqn_craftax_reset(int n, uint64_t key, uint32_t *state, float *obs, hipStrea
   PQN_REQUIRE(slots, "Craftax-Classic: cannot allocate the reset-slot scratch");
   const dim3 g((n + 255) / 256), b(256);
   hipLaunchKernelGGL(cc_reset_kernel, g, b, 0, st, n, 0, 1, (const uint8_t *)nullptr, (const uint64_t *)nullptr, state, slots);
-  hipLaunchKernelGGL(cc_world_kernel, dim3(n), b, 0, st, n, key, (const uint64_t *)nullptr, 0, slots, state);
+  hipLaunchKernelGGL(cc_world_kernel, dim3(n, cc::MAP * cc::MAP / 256), b, 0, st, n, key, (const uint64_t *)nullptr, 0, slots, state);
   if (obs) hipLaunchKernelGGL(cc_obs_kernel, dim3(n), b, 0, st, n, state, obs);
   return pqn_check_launch("pqn_env_reset(Craftax-Classic)");
 }
@@ -703,7 +716,7 @@ int pqn_craftax_step(int n, uint64_t key, const uint64_t *key_dev, float rscale,
   const dim3 g((n + 255) / 256), b(256);
   hipLaunchKernelGGL(cc_step_kernel, g, b, 0, st, n, key, key_dev, rscale, state, action, out, reset_ratio > 0 ? scratch : (uint64_t *)nullptr);
   hipLaunchKernelGGL(cc_reset_kernel, g, b, 0, st, n, reset_ratio > 0 ? 2 : 1, reset_ratio > 0 ? reset_ratio : 1, out.done, scratch, state, slots);
-  hipLaunchKernelGGL(cc_world_kernel, dim3(n), b, 0, st, n, key, key_dev, reset_ratio > 0 ? 1 : 0, slots, state);
+  hipLaunchKernelGGL(cc_world_kernel, dim3(n, cc::MAP * cc::MAP / 256), b, 0, st, n, key, key_dev, reset_ratio > 0 ? 1 : 0, slots, state);
   if (out.obs) hipLaunchKernelGGL(cc_obs_kernel, dim3(n), b, 0, st, n, state, out.obs);
   return pqn_check_launch("pqn_env_step(Craftax-Classic)");
 }
