@@ -892,6 +892,31 @@ __global__ __launch_bounds__(256) void bm_sum_partials_multi_kernel(BmSumJobs J)
   bm_sum_partials_body(J.part[j], J.nsplit[j], J.pstride[j], J.cnt[j], J.out[j], (long long)blockIdx.x - J.first[j]);
 }
 
+// Q = sum of the K-split partials of the output layer's GEMM + bias, [rows][ldq] (ldq % 4 == 0; columns >= a stay as the
+// GEMM left them).  The output layer is 17 columns wide: unsplit it is 16 (32) workgroups walking all of K (24 us for
+// 0.07 GFLOP), split 8 ways it is a 6-us launch plus this fold.  All loads of a thread in flight at once.
+#define BM_HEAD_SPLIT 8
+__global__ __launch_bounds__(256) void bm_qfold_kernel(const float *__restrict__ part, int nsplit, long long pstride, long long n4,
+                                                       int ldq, const float *__restrict__ bias, int a, float *__restrict__ q) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 t[BM_HEAD_SPLIT];
+#pragma unroll
+  for (int sp = 0; sp < BM_HEAD_SPLIT; ++sp) t[sp] = *reinterpret_cast<const f32x4 *>(part + min(sp, nsplit - 1) * pstride + 4 * i);
+  f32x4 v = t[0];
+#pragma unroll
+  for (int sp = 1; sp < BM_HEAD_SPLIT; ++sp)
+    if (sp < nsplit) v += t[sp];
+  const int c = (int)((4 * i) % ldq);
+  float bb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bb[j] = bias[min(c + j, a - 1)];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (c + j < a) v[j] += bb[j];
+  *reinterpret_cast<f32x4 *>(q + 4 * i) = v;
+}
+
 // eps-greedy over q rows with stride ldq (first-max argmax; element e draws threefry(key, (e, PQN_STREAM_ACT)))
 __global__ __launch_bounds__(256) void bm_epsgreedy_kernel(const float *__restrict__ q, int ldq, int m, int a, float eps,
                                                            uint64_t key, const float *__restrict__ eps_dev,
@@ -966,7 +991,7 @@ BmPlan bm_plan(int M, int N, int Kp, int max_split) {
   double best = 0.0;
   for (int c = 1; c <= max_split; ++c) {
     const double r = (double)(tiles * c) / (double)round, eff = r / (double)(long long)(r + 0.999999);
-    if (eff > best + 0.02) { best = eff; s = c; }
+    if (eff > best + 0.02 || (r <= 1.0 && eff > best)) { best = eff; s = c; }   // below one round every extra split helps
   }
   if (pqn_opt(PQN_OPT_BM_SPLIT) > 0) s = pqn_opt(PQN_OPT_BM_SPLIT);
   s = max(1, min(s, min(max_split, max(1, Kp / 128))));
@@ -1031,9 +1056,9 @@ struct BmTransposeBatch {
 // ---- workspace carve-up: a float region followed by a bf16 region (offsets in floats / in bf16 elements) ----
 struct BmWs {
   // f32
-  long long coef, cspart, xhat, z[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, zpart, dpart, wpart[PQN_BIGMLP_MAX_LAYERS],
-      lnpart[PQN_BIGMLP_MAX_LAYERS], inpart, f_total;
-  long long zstride, dstride, wstride;
+  long long coef, cspart, xhat, z[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, qpart, zpart, dpart, wpart[PQN_BIGMLP_MAX_LAYERS],
+      wpart_out, lnpart[PQN_BIGMLP_MAX_LAYERS], inpart, f_total;
+  long long zstride, dstride, wstride, qstride, wostride;
   // bf16 planes (element offsets from the start of the bf16 region)
   long long xn, xnT, h[PQN_BIGMLP_MAX_LAYERS], hT[PQN_BIGMLP_MAX_LAYERS], dz[PQN_BIGMLP_MAX_LAYERS], dzT[PQN_BIGMLP_MAX_LAYERS], dq, dqT, b_total;
   int ldq, ldx, dp, nbp, n_cs, n_ln, n_in;
@@ -1057,6 +1082,8 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
     w.stat[l] = take(2ll * rows);
   }
   w.q = take((long long)rows * w.ldq);
+  w.qstride = (long long)rows * w.ldq;
+  w.qpart = take(BM_HEAD_SPLIT * w.qstride);   // K-split partials of the output layer
   w.zstride = (long long)rows * L.h;
   w.zpart = take(BM_MAX_SPLIT * w.zstride);
   w.dstride = (long long)nb * L.h;
@@ -1068,6 +1095,8 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
     w.wpart[l] = take(BM_MAX_SPLIT * w.wstride);
     w.lnpart[l] = take(3ll * w.n_ln * L.h);
   }
+  w.wostride = (long long)align4(L.h * L.a);
+  w.wpart_out = take(BM_HEAD_SPLIT * w.wostride);   // K-split partials of the output layer's weight gradient
   w.inpart = take(2ll * BM_MAX_SPLIT * w.n_in * L.d);
   w.f_total = off;
   long long bo = 0;
@@ -1144,9 +1173,15 @@ int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, const
     bm_ln_relu(ns, (rows + 3) / 4, st, (const float *)(ws + w.zpart), w.zstride, rows, L.h, theta + L.off_b[l], theta + L.off_lns[l],
                theta + L.off_lnb[l], ws + w.z[l], bm_plo(wb + w.h[l], rows, L.h), ws + w.stat[l]);
   }
-  const int lo = L.layers;   // output layer: Q = h_last W_out + b_out (narrow: no K split)
-  return bm_gemm(rows, L.a, L.h, bm_pl(wb + w.h[lo - 1], rows, L.h), bm_pl(wpl + wp.wt[lo], L.a, L.h),
-                 bm_store(ws + w.q, w.ldq, theta + L.off_b[lo]), 1, nullptr, st);
+  const int lo = L.layers;   // output layer: Q = h_last W_out + b_out, K split + fold (see bm_qfold_kernel)
+  int nsq = 1;
+  const int rc = bm_gemm(rows, L.a, L.h, bm_pl(wb + w.h[lo - 1], rows, L.h), bm_pl(wpl + wp.wt[lo], L.a, L.h),
+                         bm_store(ws + w.qpart, w.ldq, nullptr, w.qstride), BM_HEAD_SPLIT, &nsq, st);
+  if (rc != PQN_OK) return rc;
+  const long long n4 = w.qstride / 4;
+  hipLaunchKernelGGL(bm_qfold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float *)(ws + w.qpart), nsq, w.qstride, n4,
+                     w.ldq, theta + L.off_b[lo], L.a, ws + w.q);
+  return pqn_check_launch("pqn_bigmlp forward");
 }
 
 // ---- second stream of the backward pass ----------------------------------------------------------------------------------
@@ -1332,24 +1367,26 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
   BmSumJobs SJ = {};
   struct PendingWgrad { int l, kin, n_out; BmPlanes HinT, dZT; float *gout; } pend[PQN_BIGMLP_MAX_LAYERS + 1];
   int npend = 0;
-  auto fold = [&](const float *part, int ns, long long cnt, float *gout, hipStream_t sd) {
+  auto fold = [&](const float *part, int ns, long long pstride, long long cnt, float *gout, hipStream_t sd) {
     if (deferred) {
       const int j = SJ.n++;
-      SJ.part[j] = part; SJ.nsplit[j] = ns; SJ.pstride[j] = w.wstride; SJ.cnt[j] = cnt; SJ.out[j] = gout;
+      SJ.part[j] = part; SJ.nsplit[j] = ns; SJ.pstride[j] = pstride; SJ.cnt[j] = cnt; SJ.out[j] = gout;
       SJ.first[j + 1] = SJ.first[j] + (cnt / 4 + 255) / 256;
     } else {
-      hipLaunchKernelGGL(bm_sum_partials_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, sd, part, ns, w.wstride, cnt, gout);
+      hipLaunchKernelGGL(bm_sum_partials_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, sd, part, ns, pstride, cnt, gout);
     }
   };
   auto wgrad_now = [&](int l, int kin, const BmPlanes &HinT, const BmPlanes &dZT, int n_out, float *gout, hipStream_t sd) -> int {
     int ns = 1;
     const long long cnt = (long long)kin * n_out;
-    const bool direct = n_out < 64 || (cnt & 3);        // narrow output layer: one split, straight into the gradient
-    float *part = ws + w.wpart[l < L->layers ? l : 0];
-    const int r = bm_gemm(kin, n_out, w.nbp, HinT, dZT, direct ? bm_store(gout, n_out) : bm_store(part, n_out, nullptr, w.wstride),
-                          direct ? 1 : BM_MAX_SPLIT, &ns, sd);
+    const bool direct = (cnt & 3) != 0;                  // (odd element count: one split, straight into the gradient)
+    const bool head = l == L->layers;                    // 17 columns: few tiles, so up to 8 K splits (see bm_qfold_kernel)
+    float *part = ws + (head ? w.wpart_out : w.wpart[l]);
+    const long long pstride = head ? w.wostride : w.wstride;
+    const int r = bm_gemm(kin, n_out, w.nbp, HinT, dZT, direct ? bm_store(gout, n_out) : bm_store(part, n_out, nullptr, pstride),
+                          direct ? 1 : (head ? BM_HEAD_SPLIT : BM_MAX_SPLIT), &ns, sd);
     if (r != PQN_OK || direct) return r;
-    fold(part, ns, cnt, gout, sd);
+    fold(part, ns, pstride, cnt, gout, sd);
     return PQN_OK;
   };
   auto wgrad = [&](int l, int kin, const BmPlanes &HinT, const BmPlanes &dZT, int n_out, float *gout, hipStream_t sd) -> int {
