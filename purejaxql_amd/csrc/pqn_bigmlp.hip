@@ -633,28 +633,33 @@ __global__ __launch_bounds__(256) void bm_innorm_apply_kernel(const float *__res
   }
 }
 
-// TD loss (single workgroup: fixed-order sums).  Rows r < b of Q are the q-values of transition idx[r]; with
-// next_rows the rows b + r hold Q(next_obs) and target = reward + (1 - done) gamma max_a Q_next (pqn_craftax.py:300-306),
-// otherwise `target` is the given Q(lambda) target.  dQ[r][a] = [a == action] (q_a - target) / b as planes [b][32];
-// d b_out = column sums.  a <= 32.
-__global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__ q, int ldq, int b, int a,
-                                                       const int64_t *__restrict__ idx, const int32_t *__restrict__ action,
-                                                       const float *__restrict__ target, const float *__restrict__ reward,
-                                                       const uint8_t *__restrict__ done, float gamma, int next_rows,
-                                                       BmPlanesOut dq, float *__restrict__ dbias,
-                                                       float *__restrict__ loss_out, float *__restrict__ qv_out) {
-  __shared__ float s_b[16][64];    // per-wave partial column sums of dQ
-  __shared__ float s_l[16], s_q[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float lsum = 0.f, qsum = 0.f, bacc = 0.f;   // bacc: lane j of a wave accumulates that wave's sum for action j
+// TD loss.  Rows r < b of Q are the q-values of transition idx[r]; with next_rows the rows b + r hold Q(next_obs) and
+// target = reward + (1 - done) gamma max_a Q_next (pqn_craftax.py:300-306), otherwise `target` is the given Q(lambda)
+// target.  dQ[r][a] = [a == action] (q_a - target) / b as planes [b][32].  a <= 32.
+// BM_LOSS_WG one-wave workgroups, workgroup w = rows 64 w + lane (+ 1024 per pass); each leaves a record in `part`:
+//   part[w * a + k]            sum over its rows of dQ[.][k]           -> d b_out        (folded by bm_colreduce, fixed order)
+//   part[BM_LOSS_WG * 32 + w]  sum of 0.5 (q_a - target)^2 / b         -> the loss
+//   part[BM_LOSS_WG * 33 + w]  sum of q_a / b                          -> mean chosen Q
+// (A single 1024-thread workgroup did all of it in round 3: 16 us on the critical chain of the backward pass -- 196 KB of
+// plane stores from one CU and 17 six-step lane butterflies per wave for the column sums.)
+#define BM_LOSS_WG 16
+__global__ __launch_bounds__(64) void bm_loss_kernel(const float *__restrict__ q, int ldq, int b, int a,
+                                                     const int64_t *__restrict__ idx, const int32_t *__restrict__ action,
+                                                     const float *__restrict__ target, const float *__restrict__ reward,
+                                                     const uint8_t *__restrict__ done, float gamma, int next_rows,
+                                                     BmPlanesOut dq, float *__restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float s_g[64];
+  __shared__ __attribute__((aligned(16))) int s_a[64];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x, w = blockIdx.x;
+  float lsum = 0.f, qsum = 0.f, bacc = 0.f;   // bacc: lane k accumulates this workgroup's column sum for action k
   const float inv_b = 1.0f / (float)b;
-  for (int r0 = 0; r0 < b; r0 += 1024) {
-    const int r = r0 + tid;
+  for (int r0 = 0; r0 < b; r0 += 64 * BM_LOSS_WG) {
+    const int r = r0 + 64 * w + lane;
     float g = 0.f;
     int act = -1;
     if (r < b) {
-      // the Q rows are loaded whole, as vectors, before anything that depends on idx / action arrives: a run-time loop over
-      // the a actions compiled to a actions x (load, wait), 16 dependent round trips on the single workgroup of the chain
+      // the Q rows are loaded whole, as vectors, before anything that depends on idx / action arrives
       float qr[32], qx[32];
       bm_load_qrow(q + (long long)r * ldq, ldq, qr);
       if (next_rows) bm_load_qrow(q + (long long)(b + r) * ldq, ldq, qx);
@@ -686,27 +691,28 @@ __global__ __launch_bounds__(1024) void bm_loss_kernel(const float *__restrict__
         bm_put(dq, r, 8 * k8, h, m, l);
       }
     }
-    for (int k = 0; k < a; ++k) {   // fixed-order butterfly per action; every lane gets the wave total
-      const float t = bm_wave_sum(act == k ? g : 0.0f);
-      bacc += (lane == k) ? t : 0.0f;
+    s_g[lane] = g;
+    s_a[lane] = act;
+    __syncthreads();
+    if (lane < a) {   // column sum of action `lane` over the 64 rows, in row order
+      float t = 0.f;
+#pragma unroll
+      for (int j4 = 0; j4 < 16; ++j4) {
+        const f32x4 gv = *reinterpret_cast<const f32x4 *>(&s_g[4 * j4]);
+        const i32x4 av = *reinterpret_cast<const i32x4 *>(&s_a[4 * j4]);
+        t += av.x == lane ? gv.x : 0.f;
+        t += av.y == lane ? gv.y : 0.f;
+        t += av.z == lane ? gv.z : 0.f;
+        t += av.w == lane ? gv.w : 0.f;
+      }
+      bacc += t;
     }
+    __syncthreads();
   }
-  s_b[wave][lane] = bacc;
   lsum = bm_wave_sum(lsum);
   qsum = bm_wave_sum(qsum);
-  if (lane == 0) { s_l[wave] = lsum; s_q[wave] = qsum; }
-  __syncthreads();
-  if (tid < a) {
-    float t = 0.f;
-    for (int w = 0; w < 16; ++w) t += s_b[w][tid];
-    dbias[tid] = t;
-  }
-  if (tid == 0) {
-    float l = 0.f, qq = 0.f;
-    for (int w = 0; w < 16; ++w) { l += s_l[w]; qq += s_q[w]; }
-    if (loss_out) *loss_out = l * inv_b;
-    if (qv_out) *qv_out = qq * inv_b;
-  }
+  if (lane < a) part[w * a + lane] = bacc;
+  if (lane == 0) { part[BM_LOSS_WG * 32 + w] = lsum * inv_b; part[BM_LOSS_WG * 33 + w] = qsum * inv_b; }
 }
 
 // relu mask + LayerNorm backward: dz (planes, rows x n) <- f(sum of the dpart K-split partials), one wave per row,
@@ -1056,7 +1062,7 @@ struct BmTransposeBatch {
 // ---- workspace carve-up: a float region followed by a bf16 region (offsets in floats / in bf16 elements) ----
 struct BmWs {
   // f32
-  long long coef, cspart, xhat, z[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, qpart, zpart, dpart, wpart[PQN_BIGMLP_MAX_LAYERS],
+  long long coef, cspart, xhat, z[PQN_BIGMLP_MAX_LAYERS], stat[PQN_BIGMLP_MAX_LAYERS], q, qpart, losspart, zpart, dpart, wpart[PQN_BIGMLP_MAX_LAYERS],
       wpart_out, lnpart[PQN_BIGMLP_MAX_LAYERS], inpart, f_total;
   long long zstride, dstride, wstride, qstride, wostride;
   // bf16 planes (element offsets from the start of the bf16 region)
@@ -1084,6 +1090,7 @@ BmWs bm_ws(const pqn_bigmlp_layout_t &L, int rows, int nb) {
   w.q = take((long long)rows * w.ldq);
   w.qstride = (long long)rows * w.ldq;
   w.qpart = take(BM_HEAD_SPLIT * w.qstride);   // K-split partials of the output layer
+  w.losspart = take(BM_LOSS_WG * 34);          // records of bm_loss_kernel
   w.zstride = (long long)rows * L.h;
   w.zpart = take(BM_MAX_SPLIT * w.zstride);
   w.dstride = (long long)nb * L.h;
@@ -1426,10 +1433,14 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
   }
   auto hT = [&](int l) -> BmPlanes { return l < 0 ? bm_pl(wb + w.xnT, L->d, w.nbp) : bm_pl(wb + w.hT[l], L->h, w.nbp); };
   const int lo = L->layers;
-  hipLaunchKernelGGL(bm_loss_kernel, dim3(1), dim3(1024), 0, st, ws + w.q, w.ldq, nb, L->a, idx, action, target, reward, done,
-                     gamma, next_offset > 0 ? 1 : 0, bm_plo(wb + w.dq, nb, 32), grad + L->off_b[lo], loss_out, qv_out);
+  hipLaunchKernelGGL(bm_loss_kernel, dim3(BM_LOSS_WG), dim3(64), 0, st, ws + w.q, w.ldq, nb, L->a, idx, action, target, reward, done,
+                     gamma, next_offset > 0 ? 1 : 0, bm_plo(wb + w.dq, nb, 32), ws + w.losspart);
   // output layer: d W_out = h_last^T dQ (side);   d h_last = dQ W_out^T (K = a padded to 32: one split)
   sd = bm_fork_at(fk, 1, st);
+  // d b_out, the loss and the mean chosen Q: folds of the loss kernel's records
+  colreduce(ws + w.losspart, BM_LOSS_WG, 1, L->a, grad + L->off_b[lo], (float *)nullptr, (float *)nullptr, sd);
+  if (loss_out) colreduce(ws + w.losspart + BM_LOSS_WG * 32, BM_LOSS_WG, 1, 1, loss_out, (float *)nullptr, (float *)nullptr, sd);
+  if (qv_out) colreduce(ws + w.losspart + BM_LOSS_WG * 33, BM_LOSS_WG, 1, 1, qv_out, (float *)nullptr, (float *)nullptr, sd);
   transpose(bm_pl(wb + w.dq, nb, 32), L->a, bm_plo(wb + w.dqT, L->a, w.nbp), sd);
   int rc2 = wgrad(lo, L->h, hT(lo - 1), bm_pl(wb + w.dqT, L->a, w.nbp), L->a, grad + L->off_w[lo], sd);
   if (rc2 != PQN_OK) return rc2;
