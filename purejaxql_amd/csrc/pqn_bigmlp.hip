@@ -981,7 +981,7 @@ BmEpilogue bm_store(float *out, long long ldc, const float *bias = nullptr, long
   return e;
 }
 
-// Tile and K split of a GEMM: 128 x 64 tiles when they still give every second CU a workgroup (else 64 x 64), and the K
+// Tile and K split of a GEMM: 128 x 64 tiles when they give more than every second CU a workgroup (else 64 x 64), and the K
 // split (<= max_split, each part >= 128 long) that fills whole "rounds" best -- a round = every CU holding as many
 // workgroups as its LDS takes (two 128 x 64, three 64 x 64).  Run-time switches "bm_tile" (64 / 128) and "bm_split"
 // override (A/B runs).
@@ -989,8 +989,12 @@ struct BmPlan { int bm, nsplit, klen; };
 BmPlan bm_plan(int M, int N, int Kp, int max_split) {
   const long long t128 = (long long)((M + 127) / 128) * ((N + 63) / 64);
   BmPlan p;
-  p.bm = t128 >= 128 ? 128 : 64;
-  if (pqn_opt(PQN_OPT_BM_TILE) == 64 || pqn_opt(PQN_OPT_BM_TILE) == 128) p.bm = pqn_opt(PQN_OPT_BM_TILE);
+  // 128 x 64 tiles only when they give MORE than 128 workgroups: at exactly 128 (1024 x 1024 outputs, C5's rollout forward,
+  // input gradients and weight gradients) the 64 x 64 tile with 3 K splits = one round of 768 workgroups measured faster
+  // inside the update than 128 x 64 with 4 splits (0.777 vs 0.809 ms per C5 update, profiles/r04_v7_c5_batched_backward.txt).
+  const int topt = pqn_opt(PQN_OPT_BM_TILE);   // 64 / 128: forced tile height; > 128: the 128-row tile from that many tiles up
+  p.bm = t128 >= (topt > 128 ? topt : 129) ? 128 : 64;
+  if (topt == 64 || topt == 128) p.bm = topt;
   const long long tiles = (long long)((M + p.bm - 1) / p.bm) * ((N + 63) / 64);
   const long long round = 256ll * (p.bm == 128 ? 2 : 3);
   int s = 1;
