@@ -514,6 +514,12 @@ int64_t pqn_bigmlp_workspace_floats(const pqn_bigmlp_layout_t *layout /* host */
  * caller-owned; call pqn_bigmlp_refresh_planes whenever theta has changed (after every optimizer step). */
 int64_t pqn_bigmlp_weight_plane_floats(const pqn_bigmlp_layout_t *layout /* host */);
 int pqn_bigmlp_refresh_planes(const pqn_bigmlp_layout_t *layout /* host */, const float *theta, float *wplanes, void *stream);
+/* The same with the two copies on two streams: the transposed copy (what the next forward pass reads) on `stream`, the
+ * (in, out)-order copy (what the next backward pass reads) on `gradient_stream`; the caller orders gradient_stream against
+ * theta's producer and the next pqn_bigmlp_grad (events).  pqn_bigmlp_update uses it after the last optimizer step of an
+ * update so that the second copy runs beside the update's closing bookkeeping kernels. */
+int pqn_bigmlp_refresh_planes_streams(const pqn_bigmlp_layout_t *layout /* host */, const float *theta, float *wplanes, void *stream,
+                                      void *gradient_stream);
 /* network.apply(params, obs, train=False) (pqn_craftax.py:184-197,226-237,403-413) + the eps-greedy draw: obs [n][d]
  * contiguous; in_mean / in_var [d] = the running moments of the input normalisation (batch_stats; NULL if norm_input = 0).
  * Outputs (each nullable): q [n][a], action [n] (element e draws threefry(key, (e, 0)) as pqn_eps_greedy), qmax [n].

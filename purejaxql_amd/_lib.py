@@ -104,6 +104,7 @@ SIGNATURES = {
     "pqn_bigmlp_workspace_floats": (c_int64, [c_void_p, c_int32, c_int32]),
     "pqn_bigmlp_weight_plane_floats": (c_int64, [c_void_p]),
     "pqn_bigmlp_refresh_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pqn_bigmlp_refresh_planes_streams": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pqn_bigmlp_forward": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),
     "pqn_bigmlp_grad": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

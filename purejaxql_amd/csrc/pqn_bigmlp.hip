@@ -407,6 +407,55 @@ __global__ __launch_bounds__(256) void bm_transpose_multi_kernel(BmTransposeJobs
   bm_transpose_body(J.src[j], J.cols[j], J.dst[j], b % J.nbx[j], b / J.nbx[j], blockIdx.z, tile);
 }
 
+// f32 matrix src[rows][cols] (leading dimension lds, any alignment) -> planes dst[cols][ld_d] of its TRANSPOSE (logical
+// columns `rows`, zero beyond): split + transpose in one pass, 64 x 64 element tiles through LDS.  Job j owns the linear
+// blocks [first[j], first[j + 1]) = its (bx over source rows, by over source columns) grid, row-major in by.
+struct BmSplitTJobs {
+  int n;
+  const float *src[BM_MAX_JOBS];
+  long long lds[BM_MAX_JOBS];
+  int rows[BM_MAX_JOBS], cols[BM_MAX_JOBS], nbx[BM_MAX_JOBS];
+  BmPlanesOut dst[BM_MAX_JOBS];
+  int first[BM_MAX_JOBS + 1];
+};
+__global__ __launch_bounds__(256) void bm_split_transpose_multi_kernel(BmSplitTJobs J) {
+  __shared__ float tile[64][65];
+  int j = 0;
+  while (j + 1 < J.n && (int)blockIdx.x >= J.first[j + 1]) ++j;
+  const int b = (int)blockIdx.x - J.first[j];
+  const int r0 = (b % J.nbx[j]) * 64, c0 = (b / J.nbx[j]) * 64;   // source rows r0.., source columns c0..
+  const float *__restrict__ src = J.src[j];
+  const long long lds = J.lds[j];
+  const int rows = J.rows[j], cols = J.cols[j];
+  const BmPlanesOut dst = J.dst[j];
+  const int tid = threadIdx.x;
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {   // 16 coalesced 4-B loads per thread in flight
+    const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+    v[q] = (r0 + r < rows && c0 + c < cols) ? src[(long long)(r0 + r) * lds + c0 + c] : 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = tid + 256 * q;
+    tile[e >> 6][e & 63] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {    // destination row = source column c, 8 source rows = 8 K-values per 16-B pack
+    const int e = tid + 256 * q, c = e >> 3, ch = e & 7;
+    const int cc = c0 + c, rr = r0 + 8 * ch;
+    if (cc < cols && rr < dst.ld) {
+      float y[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y[k] = tile[8 * ch + k][c];   // rows >= `rows` were loaded as zeros
+      u32x4 ph, pm, pl;
+      bm_split8(y, ph, pm, pl);
+      bm_put(dst, cc, rr, ph, pm, pl);
+    }
+  }
+}
+
 // z = sum of the K-split partials of the layer's GEMM + bias;  h = relu(LayerNorm(z)) row by row (one wave per row) written
 // as planes; z and stat[r] = (mean, rstd) are kept for the backward pass.  n % 256 == 0, n <= 2048: lane owns the
 // 8-column packs lane, lane + 64, ... of the row.
@@ -1276,24 +1325,38 @@ extern "C" int64_t pqn_bigmlp_weight_plane_floats(const pqn_bigmlp_layout_t *L) 
   return (bm_wp(*L).total + 1) / 2;
 }
 
-extern "C" int pqn_bigmlp_refresh_planes(const pqn_bigmlp_layout_t *L, const float *theta, float *wplanes, void *stream) {
-  PQN_REQUIRE(L && theta && wplanes, "pqn_bigmlp_refresh_planes: NULL argument");
-  hipStream_t st = (hipStream_t)stream;
+// the two plane sets of every Dense kernel straight from theta: the transposed copy (forward operand) on `st`, the natural
+// copy (input-gradient operand) on `st_nat` -- the same stream, or a second one the caller orders itself
+static int bm_refresh(const pqn_bigmlp_layout_t *L, const float *theta, float *wplanes, hipStream_t st, hipStream_t st_nat) {
   const BmWp wp = bm_wp(*L);
   bf16_t *base = reinterpret_cast<bf16_t *>(wplanes);
-  BmSplitJobs S = {};   // two launches for all layers: every kernel split into planes, then every transposed copy
-  BmTransposeBatch T;
+  BmSplitJobs S = {};   // one launch per orientation for all layers
+  BmSplitTJobs T = {};
   for (int l = 0; l <= L->layers; ++l) {
     const int kin = l ? L->h : L->d, out = l < L->layers ? L->h : L->a;
     const BmPlanesOut wn = bm_plo(base + wp.wn[l], kin, bm_pad32(out));
     S.src[l] = theta + L->off_w[l]; S.lds[l] = out; S.rows[l] = kin; S.cols[l] = out; S.out[l] = wn;
     S.first[l + 1] = S.first[l] + ((long long)kin * (wn.ld / 8) + 255) / 256;
-    T.add(bm_pl(base + wp.wn[l], kin, bm_pad32(out)), out, bm_plo(base + wp.wt[l], out, bm_pad32(kin)));
+    const BmPlanesOut wt = bm_plo(base + wp.wt[l], out, bm_pad32(kin));
+    T.src[l] = theta + L->off_w[l]; T.lds[l] = out; T.rows[l] = kin; T.cols[l] = out; T.dst[l] = wt;
+    T.nbx[l] = (int)((wt.ld + 63) / 64);
+    T.first[l + 1] = T.first[l] + T.nbx[l] * ((out + 63) / 64);
   }
-  S.n = L->layers + 1;
-  hipLaunchKernelGGL(bm_split_multi_kernel, dim3((unsigned)S.first[S.n]), dim3(256), 0, st, S);
-  T.launch(st);
+  S.n = T.n = L->layers + 1;
+  hipLaunchKernelGGL(bm_split_transpose_multi_kernel, dim3((unsigned)T.first[T.n]), dim3(256), 0, st, T);
+  hipLaunchKernelGGL(bm_split_multi_kernel, dim3((unsigned)S.first[S.n]), dim3(256), 0, st_nat, S);
   return pqn_check_launch("pqn_bigmlp_refresh_planes");
+}
+
+extern "C" int pqn_bigmlp_refresh_planes(const pqn_bigmlp_layout_t *L, const float *theta, float *wplanes, void *stream) {
+  PQN_REQUIRE(L && theta && wplanes, "pqn_bigmlp_refresh_planes: NULL argument");
+  return bm_refresh(L, theta, wplanes, (hipStream_t)stream, (hipStream_t)stream);
+}
+
+extern "C" int pqn_bigmlp_refresh_planes_streams(const pqn_bigmlp_layout_t *L, const float *theta, float *wplanes, void *stream,
+                                                 void *gradient_stream) {
+  PQN_REQUIRE(L && theta && wplanes, "pqn_bigmlp_refresh_planes_streams: NULL argument");
+  return bm_refresh(L, theta, wplanes, (hipStream_t)stream, (hipStream_t)gradient_stream);
 }
 
 extern "C" int pqn_bigmlp_forward(const pqn_bigmlp_layout_t *L, int32_t n, const float *obs, const float *theta,

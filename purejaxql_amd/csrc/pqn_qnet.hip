@@ -1715,7 +1715,6 @@ PQN_D void t1_conv_wgrad_2r(const float *dx, const uint32_t *bits, uint32_t *wm_
   for (int mm = 0; mm < 2; ++mm) {
     const int msamp = 2 * sg + mm;
     window_masks<C>(bits + msamp * Cfg::OW, wm, lane);
-    const float *dxm = dx + msamp * QN_H1S + lane;
     float bv[16];
     uint32_t wv[16][NRB];
 #pragma unroll
@@ -2027,7 +2026,6 @@ PQN_D void t1_conv_wgrad(const float *dx, const uint32_t *bits, uint32_t *wm_bas
       for (int mm = 0; mm < SPW6; ++mm) {
         const int msamp = SPW6 * sg + mm;
         window_masks<C>(bits + msamp * Cfg::OW, wm, lane);
-        const float *dxm = dx + msamp * QN_H1S + lane;
         float bv[16];
         uint32_t wv[16][RBW];
 #pragma unroll

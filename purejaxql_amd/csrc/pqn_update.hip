@@ -587,6 +587,27 @@ __global__ void keys_to_index_kernel(int64_t *__restrict__ keys, int n, long lon
   if (i < n) keys[i] &= mask;
 }
 
+// side stream + fork / join events of pqn_bigmlp_update (process-wide, created on first use; NULL = run everything on the
+// caller's stream: option upd_overlap = 0, or the stream / events could not be created)
+struct UpdSide {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool tried = false, ok = false;
+};
+static UpdSide g_upd_side;
+static UpdSide *upd_side() {
+  if (pqn_opt(PQN_OPT_UPD_OVERLAP) <= 0) return nullptr;
+  UpdSide &u = g_upd_side;
+  if (!u.tried) {
+    u.tried = true;
+    u.ok = hipStreamCreateWithFlags(&u.s, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&u.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&u.join, hipEventDisableTiming) == hipSuccess;
+    if (!u.ok) (void)hipGetLastError();
+  }
+  return u.ok ? &u : nullptr;
+}
+
 extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   PQN_REQUIRE(a, "pqn_bigmlp_update: args is NULL");
@@ -612,6 +633,30 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
   hipLaunchKernelGGL(update_sched_kernel, dim3(1), dim3(1024), 0, st, a->clock, a->key_roll, a->key_shuf, (const uint64_t *)nullptr,
                      (const uint64_t *)nullptr, T, EP, a->eps_start, a->eps_finish, a->eps_decay_steps, a->sched_keys, a->sched_eps,
                      (float *)nullptr, 0ll);
+  // Option upd_overlap = 1 (default 0): the first epoch's permutation (shuffle keys -> rocPRIM sort -> index mask: three
+  // launch-bound kernels, 20 us at C5's 1024 transitions) depends on the key schedule only and goes to a side stream beside
+  // the rollout, joining before the first minibatch; the input-gradient plane copy of the last optimizer step runs beside
+  // the closing bookkeeping kernels.  Event record / wait pairs are capturable (the side stream joins a capture at its
+  // first wait).  Measured on C5 inside one call (profiles/r04_v7_c5_batched_backward.txt): 0.816 ms per update with the
+  // side stream, 0.784 without -- the update is a chain of back-to-back kernels with no idle CUs to fill, and every fork /
+  // join is one more dependency for the graph to resolve.  Same results either way.
+  const long long mask = (1ll << pqn_index_bits(TN)) - 1;
+  auto permutation = [&](int ep, hipStream_t s) -> int {
+    UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, TN, a->sort_keys_in, s));
+    UPD_CHECK(pqn_sort_keys(a->sort_temp, (size_t)a->sort_temp_bytes, a->sort_keys_in, a->sort_keys_out, TN, 1, TN, s));
+    hipLaunchKernelGGL(keys_to_index_kernel, dim3((TN + 255) / 256), dim3(256), 0, s, a->sort_keys_out, TN, mask);
+    return PQN_OK;
+  };
+  UpdSide *side = upd_side();
+  if (side) {
+    if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      side = nullptr;
+    } else {
+      UPD_CHECK(permutation(0, side->s));
+      HIP_OK(hipEventRecord(side->join, side->s), "hipEventRecord");
+    }
+  }
   // SAMPLE PHASE (_step_env scan, pqn_craftax.py:181-224)
   for (int t = 0; t < T; ++t) {
     const size_t o = (size_t)t * N;
@@ -640,19 +685,26 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
     UPD_CHECK(pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, T, N, 1, a->target, st));
   }
   // NETWORKS UPDATE (:263-357)
-  const long long mask = (1ll << pqn_index_bits(TN)) - 1;
   int i_mb = 0;
+  bool side_open = false;
   for (int ep = 0; ep < EP; ++ep) {
-    UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, TN, a->sort_keys_in, st));
-    UPD_CHECK(pqn_sort_keys(a->sort_temp, (size_t)a->sort_temp_bytes, a->sort_keys_in, a->sort_keys_out, TN, 1, TN, st));
-    hipLaunchKernelGGL(keys_to_index_kernel, dim3((TN + 255) / 256), dim3(256), 0, st, a->sort_keys_out, TN, mask);
+    if (ep == 0 && side) HIP_OK(hipStreamWaitEvent(st, side->join, 0), "hipStreamWaitEvent");
+    else UPD_CHECK(permutation(ep, st));
     for (int mb = 0; mb < MB; ++mb, ++i_mb) {
       UPD_CHECK(pqn_bigmlp_grad(&L, B, a->sort_keys_out + (size_t)mb * B, a->obs, a->q_lambda ? 0 : N, a->action,
                                 a->q_lambda ? a->target : nullptr, a->reward, a->done, a->gamma, a->theta, a->wplanes, a->in_mean,
                                 a->in_var, a->in_steps, a->grad, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, stream));
       UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
                                  a->max_grad_norm, a->radam_scratch, nullptr, 0, nullptr, 1, 0, st));
-      UPD_CHECK(pqn_bigmlp_refresh_planes(&L, a->theta, a->wplanes, stream));
+      if (side && i_mb + 1 == MB * EP) {   // last optimizer step: the input-gradient copy beside the closing bookkeeping below
+        HIP_OK(hipEventRecord(side->fork, st), "hipEventRecord");
+        HIP_OK(hipStreamWaitEvent(side->s, side->fork, 0), "hipStreamWaitEvent");
+        UPD_CHECK(pqn_bigmlp_refresh_planes_streams(&L, a->theta, a->wplanes, stream, side->s));
+        HIP_OK(hipEventRecord(side->join, side->s), "hipEventRecord");
+        side_open = true;
+      } else {
+        UPD_CHECK(pqn_bigmlp_refresh_planes(&L, a->theta, a->wplanes, stream));
+      }
     }
   }
   if (hipMemcpyAsync(a->obs, a->obs + (size_t)T * ostride, ostride * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
@@ -667,5 +719,6 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
                        a->metrics_capacity);
   hipLaunchKernelGGL(update_tick_kernel, dim3(1), dim3(64), 0, st, a->clock, T, N, 1, MB * EP, a->loss_buf, a->qv_buf, partial,
                      a->metrics, a->metrics_capacity, 0ll, a->done_weighted_info);
+  if (side_open) HIP_OK(hipStreamWaitEvent(st, side->join, 0), "hipStreamWaitEvent");
   return pqn_check_launch("pqn_bigmlp_update");
 }
