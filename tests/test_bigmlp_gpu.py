@@ -210,10 +210,11 @@ def test_bigmlp_q_lambda_loss_grad_vs_oracle(gpu, oracle):
 
 
 def test_bigmlp_backward_side_stream_is_bit_identical_to_one_stream(gpu, oracle):
-    """The parameter-gradient side of the backward pass runs on a second stream beside the input-gradient chain (option
-    bm_overlap, default 1).  Same kernels, same buffers, same summation orders: the gradient, the loss and the updated
-    input statistics must be bit-identical with the option off, over repeated calls (a missing event dependency would show
-    as run-to-run differences) and for both branches of the loss."""
+    """Two launch orders of the backward pass: the default runs the input-gradient chain first and then the
+    parameter-gradient side in batched launches (one transpose, one column-sum, the dW GEMMs, one fold); option
+    bm_overlap = 1 runs that side layer by layer on a second stream beside the chain.  Same kernel bodies, same buffers, same
+    summation orders: the gradient, the loss and the updated input statistics must be bit-identical between the two, over
+    repeated calls (a missing event dependency would show as run-to-run differences) and for both branches of the loss."""
     from purejaxql_amd import _lib
     d, h, layers, a, nb = 77, 512, 3, 7, 384
     rng = np.random.default_rng(4)
