@@ -374,8 +374,10 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
 /* Run-time switches of the kernel selection (profiling, A/B runs, tests; no reference counterpart -- XLA picks its
  * fusions itself).  Names: "t1_pair", "rollout_pair" (pair form of the bf16x3 training / rollout kernel: 0 never,
  * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
- * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP
- * backward on a second stream; default 0), "peer_timeout_s" (seconds pqn_peer_allreduce_mean waits for a peer; default 60), "t2_acc" (bf16x3 fc1 weight
+ * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height 64 / 128 -- a value above 128 = "128-row tiles from that many tiles
+ * up" -- / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP backward layer by layer on a second stream instead of batched behind
+ * the input-gradient chain; default 0), "upd_overlap" (pqn_bigmlp_update: first permutation and last gradient-copy plane refresh on a side stream;
+ * default 0, measured slower), "peer_timeout_s" (seconds pqn_peer_allreduce_mean waits for a peer; default 60), "t2_acc" (bf16x3 fc1 weight
  * gradient without split-K partials: 0 never, 1 (default) when row blocks x seeds of a launch fill the chip, 2 always), "t1_ksplit" (K-split form of the f32-mode training kernel for minibatches of
  * at most 256 samples: a tile's work cut along the conv positions over many workgroups; 1 (default) = forward partial +
  * head-and-backward as two launches, 2 / 3 / 4 = three launches with 4 / 8 / 16 positions per workgroup, 0 = the

@@ -82,7 +82,7 @@ enum {
   PQN_OPT_SEED_GROUP,     // PQN_SEED_GROUP: seeds per T1 -> T2 launch pair (0 = all)
   PQN_OPT_ABLATE_TRAIN,   // PQN_ABLATE_TRAIN: phase ablation mask of the training kernels (profiling)
   PQN_OPT_ABLATE,         // PQN_ABLATE: phase ablation of the forward kernel (profiling)
-  PQN_OPT_BM_TILE,        // PQN_BM_TILE: tile height of the wide-MLP GEMMs (0 auto, 64, 128)
+  PQN_OPT_BM_TILE,        // PQN_BM_TILE: tile height of the wide-MLP GEMMs (0 auto, 64, 128; > 128: 128-row tiles from that many tiles up)
   PQN_OPT_BM_SPLIT,       // PQN_BM_SPLIT: K splits of the wide-MLP GEMMs (0 auto, 1 .. 4)
   PQN_OPT_T1_KSPLIT,      // PQN_T1_KSPLIT: K-split form of the f32-mode training kernel for minibatches <= 256 samples (default 1)
   PQN_OPT_T1_KSPLIT_TILES, // PQN_T1_KSPLIT_TILES: the K-split form is taken while tiles x seeds of the launch stay at or below this (default 48)
