@@ -717,7 +717,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 m["env_frame"] = counters["timesteps"] * obs_shape[-1]
             m.update(info_means)
             if metrics_hook is not None or shard_world > 1:   # env-sharded mode: means over all shards, counts over all envs
-                mean_keys = ["td_loss", "qvals"] + list(INFO_KEYS)
+                mean_keys = ["td_loss", "qvals"] + list(INFO_KEYS) + [k for k in m if k.startswith("Achievements/")]
                 vals = torch.stack([torch.as_tensor(m[k], dtype=torch.float32, device=dev) for k in mean_keys])
                 if metrics_hook is not None:
                     vals = metrics_hook(vals)
