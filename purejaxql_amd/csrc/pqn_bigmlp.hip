@@ -22,14 +22,20 @@
 //                           MFMAs; split-K over blockIdx.z (partial outputs, folded by the consumer) so that ~3
 //                           workgroups sit on every CU and hide each other's load latency; epilogue = (bias +) store, or
 //                           the column sums that are the input-normalisation parameter gradients
-//   bm_split_kernel         f32 matrix -> planes (weights; test entry);   bm_transpose_kernel  planes -> transposed planes
+//   bm_split_kernel         f32 matrix -> planes (weights; test entry);   bm_transpose_kernel  planes -> transposed planes;
+//                           bm_split_transpose_multi: theta -> transposed weight planes in one pass (after an optimizer step)
 //   bm_colstats* / bm_innorm_apply   batch moments of the gathered input rows, BatchRenorm / BatchNorm bookkeeping
 //                           (utils/batch_renorm.py:95-116), normalised input as planes (+ xhat for the parameter gradients)
 //   bm_ln_relu              z = sum of K-split partials + bias; LayerNorm (flax: var = E[x^2] - E[x]^2 clamped, eps 1e-6) +
 //                           relu -> activation planes; z and (mean, rstd) kept for the backward pass
-//   bm_loss                 TD loss of both branches of _loss_fn (pqn_craftax.py:277-312), dQ planes, d b_out, metrics
+//   bm_qfold                Q = sum of the output layer's K-split partials + bias (the 17-column layer runs 8 K splits)
+//   bm_loss                 TD loss of both branches of _loss_fn (pqn_craftax.py:277-312), dQ planes; per-workgroup records of
+//                           d b_out / loss / mean chosen Q for bm_colreduce
 //   bm_ln_bwd               relu mask + LayerNorm backward -> dz planes, column partial sums for d scale / d bias / d dense-bias
 //   bm_colreduce / bm_sum_partials   fixed-order folds of per-workgroup column partials / K-split weight-gradient partials
+//                           (_multi: every layer's fold in one launch)
+// The row / column kernels issue all loads of a thread before the first use (straight-line code: K-split counts as template
+// parameters, clamped indices instead of bounds branches) -- they move a few MB each and are latency-, not bandwidth-bound.
 // Everything is deterministic (fixed summation orders, no atomics).
 #include <stdlib.h>
 
