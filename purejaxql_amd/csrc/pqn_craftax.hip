@@ -244,6 +244,53 @@ struct MapRef {
   }
 };
 
+// The 3 x 3 cells around the player's position at the start of a step, loaded as ONE batch of nine independent reads and
+// kept coherent with the step's writes: every cell the player's own action reads or writes lies in it.  (The rule used to
+// walk them one dependent load at a time -- near(table), near(furnace), the faced cell, near(table) again, the cell moved
+// to: up to ~30 L2 round trips at the head of a step whose whole kernel is latency.)
+struct Hood {
+  int r0, c0;
+  int v[9];   // -1 = out of bounds
+  PQN_D void load(const MapRef &m, int pr, int pc) {
+    r0 = pr; c0 = pc;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int r = pr + k / 3 - 1, c = pc + k % 3 - 1;
+      const int b = m.get(min(max(r, 0), MAP - 1), min(max(c, 0), MAP - 1));   // unconditional: all nine in flight
+      v[k] = in_bounds(r, c) ? b : -1;
+    }
+  }
+  PQN_D bool has(int r, int c) const { return iabs_(r - r0) <= 1 && iabs_(c - c0) <= 1; }
+  PQN_D int at(int r, int c) const {
+    const int k = (r - r0 + 1) * 3 + (c - c0 + 1);
+    int b = v[0];
+#pragma unroll
+    for (int j = 1; j < 9; ++j) b = k == j ? v[j] : b;
+    return b;
+  }
+  PQN_D void put(int r, int c, int b) {
+    const int k = (r - r0 + 1) * 3 + (c - c0 + 1);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v[j] = k == j ? b : v[j];
+  }
+  PQN_D bool near(int block) const {
+    bool f = false;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) f = f || v[j] == block;
+    return f;
+  }
+};
+// the map as the rule sees it: the neighbourhood from registers, everything else from memory; writes go to both
+struct MapView {
+  const MapRef &m;
+  Hood &h;
+  PQN_D int get(int r, int c) const { return h.has(r, c) ? h.at(r, c) : m.get(r, c); }
+  PQN_D void set(int r, int c, int b) const {
+    m.set(r, c, b);
+    if (h.has(r, c)) h.put(r, c, b);
+  }
+};
+
 PQN_D int toward(int r, int c, int tr, int tc, bool long_axis) {
   const int dr = tr - r, dc = tc - c;
   const bool vertical_longer = iabs_(dr) > iabs_(dc);
@@ -255,14 +302,17 @@ PQN_D int toward(int r, int c, int tr, int tc, bool long_axis) {
 }
 
 // the transition rule (oracle/craftax_classic.c cc_step_one, rule for rule)
-PQN_D float step(Scalars &s, const MapRef &map, int action, uint64_t key, uint32_t e, int &done) {
+PQN_D float step(Scalars &s, const MapRef &mref, int action, uint64_t key, uint32_t e, int &done) {
   const int a = s.sleeping ? (int)A_NOOP : action;
   const int ach0 = s.ach, health0 = s.health;
   uint32_t o0, o1;
   auto give = [&](int k) { s.ach |= (1 << k); };
   int *inv = s.inv;
+  Hood hood;
+  hood.load(mref, s.pr, s.pc);
+  const MapView map{mref, hood};
   {  // 1. crafting
-    const bool table = map.near(s.pr, s.pc, B_TABLE), furnace = map.near(s.pr, s.pc, B_FURNACE);
+    const bool table = hood.near(B_TABLE), furnace = hood.near(B_FURNACE);
     if (a == A_MAKE_WOOD_PICKAXE && table && inv[I_WOOD] >= 1) { inv[I_WOOD]--; inv[I_WOOD_PICKAXE]++; give(ACH_MAKE_WOOD_PICKAXE); }
     if (a == A_MAKE_STONE_PICKAXE && table && inv[I_WOOD] >= 1 && inv[I_STONE] >= 1) { inv[I_WOOD]--; inv[I_STONE]--; inv[I_STONE_PICKAXE]++; give(ACH_MAKE_STONE_PICKAXE); }
     if (a == A_MAKE_IRON_PICKAXE && table && furnace && inv[I_WOOD] >= 1 && inv[I_COAL] >= 1 && inv[I_IRON] >= 1) { inv[I_WOOD]--; inv[I_COAL]--; inv[I_IRON]--; inv[I_IRON_PICKAXE]++; give(ACH_MAKE_IRON_PICKAXE); }
@@ -307,7 +357,7 @@ PQN_D float step(Scalars &s, const MapRef &map, int action, uint64_t key, uint32
     const int b = map.get(tr, tc);
     if (a == A_PLACE_STONE && inv[I_STONE] >= 1 && (walkable(b) || b == B_WATER || b == B_LAVA)) { map.set(tr, tc, B_STONE); inv[I_STONE]--; give(ACH_PLACE_STONE); }
     if (a == A_PLACE_TABLE && inv[I_WOOD] >= 1 && walkable(b)) { map.set(tr, tc, B_TABLE); inv[I_WOOD]--; give(ACH_PLACE_TABLE); }
-    if (a == A_PLACE_FURNACE && inv[I_STONE] >= 1 && walkable(b) && map.near(s.pr, s.pc, B_TABLE)) { map.set(tr, tc, B_FURNACE); inv[I_STONE]--; give(ACH_PLACE_FURNACE); }
+    if (a == A_PLACE_FURNACE && inv[I_STONE] >= 1 && walkable(b) && hood.near(B_TABLE)) { map.set(tr, tc, B_FURNACE); inv[I_STONE]--; give(ACH_PLACE_FURNACE); }
     if (a == A_PLACE_PLANT && inv[I_SAPLING] >= 1 && b == B_GRASS) {
       bool placed = false;
 #pragma unroll
@@ -324,38 +374,40 @@ PQN_D float step(Scalars &s, const MapRef &map, int action, uint64_t key, uint32
       if ((walkable(b) || b == B_LAVA) && !s.mob_at(nr, nc)) { s.pr = nr; s.pc = nc; }
     }
   }
-  // 5. mobs
+  // 5. mobs.  What a mob wants (direction, target cell) depends on its own position, the player's and its own random draws
+  // only, and no mob writes the map: every wish is decided first, the target cells are fetched as one batch, then the
+  // moves are applied in the oracle's order (zombies, cows, skeletons; mob_at sees the earlier moves).
+  int zr[NZ], zc[NZ], zb[NZ], cr[NC], cc_[NC], cb[NC], kr[NS], kc[NS], kb[NS], kdir[NS];
+  bool kshoot[NS];
 #pragma unroll
   for (int i = 0; i < NZ; ++i) {
-    Mob &z = s.z[i];
+    const Mob &z = s.z[i];
+    zr[i] = zc[i] = 0; zb[i] = -1;
     if (!z.mask) continue;
     pqn_bits(key, e, ST_ZOMBIE + (uint32_t)i, o0, o1);
-    int dist = max(iabs_(z.r - s.pr), iabs_(z.c - s.pc));
+    const int dist = max(iabs_(z.r - s.pr), iabs_(z.c - s.pc));
     int d;
     if (dist <= 8 && pqn_uniform(o0) < 0.9f) d = toward(z.r, z.c, s.pr, s.pc, (o1 >> 8) % 10u < 8u);
     else d = 1 + (int)pqn_randint(o1, 4u);
-    const int nr = z.r + dr_of(d), nc = z.c + dc_of(d);
-    if (in_bounds(nr, nc) && walkable(map.get(nr, nc)) && !s.mob_at(nr, nc) && !(nr == s.pr && nc == s.pc)) { z.r = nr; z.c = nc; }
-    dist = max(iabs_(z.r - s.pr), iabs_(z.c - s.pc));
-    if (dist <= 1) {
-      if (z.cd > 0) z.cd--;
-      else { s.health -= s.sleeping ? 7 : 2; z.cd = 5; }
-    }
+    zr[i] = z.r + dr_of(d); zc[i] = z.c + dc_of(d);
+    if (in_bounds(zr[i], zc[i])) zb[i] = map.get(zr[i], zc[i]);
   }
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
-    Mob &w = s.cow[i];
+    const Mob &w = s.cow[i];
+    cr[i] = cc_[i] = 0; cb[i] = -1;
     if (!w.mask) continue;
     pqn_bits(key, e, ST_COW + (uint32_t)i, o0, o1);
     if (pqn_uniform(o0) > 0.5f) {
       const int d = 1 + (int)pqn_randint(o1, 4u);
-      const int nr = w.r + dr_of(d), nc = w.c + dc_of(d);
-      if (in_bounds(nr, nc) && walkable(map.get(nr, nc)) && !s.mob_at(nr, nc) && !(nr == s.pr && nc == s.pc)) { w.r = nr; w.c = nc; }
+      cr[i] = w.r + dr_of(d); cc_[i] = w.c + dc_of(d);
+      if (in_bounds(cr[i], cc_[i])) cb[i] = map.get(cr[i], cc_[i]);
     }
   }
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     Mob &k = s.sk[i];
+    kr[i] = kc[i] = 0; kb[i] = -1; kdir[i] = 0; kshoot[i] = false;
     if (!k.mask) continue;
     uint32_t p0, p1;
     pqn_bits(key, e, ST_SKEL_A + (uint32_t)i, o0, o1);
@@ -365,21 +417,50 @@ PQN_D float step(Scalars &s, const MapRef &map, int action, uint64_t key, uint32
     int d = 0;
     if (dist <= 3 && pqn_uniform(o0) < 0.4f) d = toward(k.r, k.c, s.pr, s.pc, pqn_uniform(o1) < 0.6f);
     else if (dist <= 5 && k.cd == 0 && pqn_uniform(p0) < 0.5f) {
-      const int ad = toward(k.r, k.c, s.pr, s.pc, true);
-      const int ar = k.r + dr_of(ad), ac = k.c + dc_of(ad);
+      kdir[i] = toward(k.r, k.c, s.pr, s.pc, true);   // the arrow's direction
+      kshoot[i] = true;
       k.cd = 2;
-      if (in_bounds(ar, ac) && map.get(ar, ac) == B_PATH && !s.mob_at(ar, ac)) {
+    } else if (dist <= 8 && pqn_uniform(p0) < 0.3f) d = toward(k.r, k.c, s.pr, s.pc, pqn_uniform(o1) < 0.6f);
+    else if (pqn_uniform(p1) < 0.2f) d = 1 + (int)pqn_randint(o1, 4u);
+    if (kshoot[i]) d = kdir[i];
+    else kdir[i] = d;
+    if (d) {   // the cell the arrow would start in / the skeleton would step to
+      kr[i] = k.r + dr_of(d); kc[i] = k.c + dc_of(d);
+      if (in_bounds(kr[i], kc[i])) kb[i] = map.get(kr[i], kc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NZ; ++i) {
+    Mob &z = s.z[i];
+    if (!z.mask) continue;
+    const int nr = zr[i], nc = zc[i];
+    if (in_bounds(nr, nc) && walkable(zb[i]) && !s.mob_at(nr, nc) && !(nr == s.pr && nc == s.pc)) { z.r = nr; z.c = nc; }
+    const int dist = max(iabs_(z.r - s.pr), iabs_(z.c - s.pc));
+    if (dist <= 1) {
+      if (z.cd > 0) z.cd--;
+      else { s.health -= s.sleeping ? 7 : 2; z.cd = 5; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    Mob &w = s.cow[i];
+    if (!w.mask || cb[i] < 0) continue;   // no wish this step, or out of bounds
+    const int nr = cr[i], nc = cc_[i];
+    if (walkable(cb[i]) && !s.mob_at(nr, nc) && !(nr == s.pr && nc == s.pc)) { w.r = nr; w.c = nc; }
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    Mob &k = s.sk[i];
+    if (!k.mask || kdir[i] == 0) continue;
+    const int nr = kr[i], nc = kc[i];
+    if (kshoot[i]) {
+      if (in_bounds(nr, nc) && kb[i] == B_PATH && !s.mob_at(nr, nc)) {
         bool shot = false;
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-          if (!shot && !s.ar[j].mask) { s.ar[j] = Mob{ar, ac, 0, ad, 1}; shot = true; }
+          if (!shot && !s.ar[j].mask) { s.ar[j] = Mob{nr, nc, 0, kdir[i], 1}; shot = true; }
       }
-    } else if (dist <= 8 && pqn_uniform(p0) < 0.3f) d = toward(k.r, k.c, s.pr, s.pc, pqn_uniform(o1) < 0.6f);
-    else if (pqn_uniform(p1) < 0.2f) d = 1 + (int)pqn_randint(o1, 4u);
-    if (d) {
-      const int nr = k.r + dr_of(d), nc = k.c + dc_of(d);
-      if (in_bounds(nr, nc) && map.get(nr, nc) == B_PATH && !s.mob_at(nr, nc) && !(nr == s.pr && nc == s.pc)) { k.r = nr; k.c = nc; }
-    }
+    } else if (in_bounds(nr, nc) && kb[i] == B_PATH && !s.mob_at(nr, nc) && !(nr == s.pr && nc == s.pc)) { k.r = nr; k.c = nc; }
   }
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
@@ -402,14 +483,21 @@ PQN_D float step(Scalars &s, const MapRef &map, int action, uint64_t key, uint32
   {
     const float light = light_level(s.timestep);
     const float zchance = 0.02f + 0.1f * ((1.0f - light) * (1.0f - light));
+    int sr[3], sc[3], sb[3];   // candidate cell of each kind and its block (-1: no spawn attempt / out of bounds), one batch
 #pragma unroll
     for (int kind = 0; kind < 3; ++kind) {
       pqn_bits(key, e, ST_SPAWN_COW + (uint32_t)kind, o0, o1);
       const float chance = kind == 0 ? 0.1f : (kind == 1 ? zchance : 0.1f);
-      if (!(pqn_uniform(o0) < chance)) continue;
-      const int r = s.pr + (int)(((o1 & 0xFFFFu) * 19u) >> 16) - 9, c = s.pc + (int)(((o1 >> 16) * 19u) >> 16) - 9;
-      if (!in_bounds(r, c) || s.mob_at(r, c)) continue;
-      const int dist = max(iabs_(r - s.pr), iabs_(c - s.pc)), b = map.get(r, c);
+      sr[kind] = s.pr + (int)(((o1 & 0xFFFFu) * 19u) >> 16) - 9;
+      sc[kind] = s.pc + (int)(((o1 >> 16) * 19u) >> 16) - 9;
+      sb[kind] = -1;
+      if (pqn_uniform(o0) < chance && in_bounds(sr[kind], sc[kind])) sb[kind] = map.get(sr[kind], sc[kind]);
+    }
+#pragma unroll
+    for (int kind = 0; kind < 3; ++kind) {
+      const int r = sr[kind], c = sc[kind], b = sb[kind];
+      if (b < 0 || s.mob_at(r, c)) continue;   // mob_at sees the mobs the earlier kinds just spawned
+      const int dist = max(iabs_(r - s.pr), iabs_(c - s.pc));
       bool placed = false;
       if (kind == 0 && b == B_GRASS && dist >= 4) {
 #pragma unroll
@@ -424,11 +512,14 @@ PQN_D float step(Scalars &s, const MapRef &map, int action, uint64_t key, uint32
     }
   }
   // 7. plants
+  int pb[NP];   // one batch (a plant's own write below touches its own cell only)
+#pragma unroll
+  for (int i = 0; i < NP; ++i) pb[i] = s.pl[i].mask ? map.get(s.pl[i].r, s.pl[i].c) : -1;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     Plant &p = s.pl[i];
     if (!p.mask) continue;
-    const int b = map.get(p.r, p.c);
+    const int b = pb[i];
     if (b != B_PLANT && b != B_RIPE) { p.mask = 0; continue; }
     p.age++;
     if (p.age > 300) map.set(p.r, p.c, B_RIPE);
