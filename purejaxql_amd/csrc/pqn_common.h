@@ -89,7 +89,7 @@ enum {
   PQN_OPT_BM_OVERLAP,     // PQN_BM_OVERLAP: parameter-gradient side of the wide-MLP backward on a second stream (default 0: measured no gain)
   PQN_OPT_PEER_TIMEOUT_S, // PQN_PEER_TIMEOUT_S: wall-clock seconds the in-graph peer all-reduce waits for a peer's gradient (default 60)
   PQN_OPT_T2_ACC,         // PQN_T2_ACC: bf16x3 fc1 weight gradient without split-K partials 0 never / 1 when row blocks x seeds fill the chip / 2 always
-  PQN_OPT_UPD_OVERLAP,    // PQN_UPD_OVERLAP: pqn_bigmlp_update puts the first epoch's permutation and the last gradient-copy plane refresh on a side stream (default 0: measured slower)
+  PQN_OPT_UPD_OVERLAP,    // PQN_UPD_OVERLAP: pqn_bigmlp_update puts the first epoch's permutation and the last gradient-copy plane refresh on a side stream (bit 0 / bit 1; default 0: a fork / join pair in the graph costs ~30 us)
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);

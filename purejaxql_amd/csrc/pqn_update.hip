@@ -637,9 +637,10 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
   // launch-bound kernels, 20 us at C5's 1024 transitions) depends on the key schedule only and goes to a side stream beside
   // the rollout, joining before the first minibatch; the input-gradient plane copy of the last optimizer step runs beside
   // the closing bookkeeping kernels.  Event record / wait pairs are capturable (the side stream joins a capture at its
-  // first wait).  Measured on C5 inside one call (profiles/r04_v7_c5_batched_backward.txt): 0.816 ms per update with the
-  // side stream, 0.784 without -- the update is a chain of back-to-back kernels with no idle CUs to fill, and every fork /
-  // join is one more dependency for the graph to resolve.  Same results either way.
+  // first wait).  Bit 0 of the option = the permutation, bit 1 = the plane copy.  Measured on C5 inside one call
+  // (profiles/r04_v7_c5_batched_backward.txt), ms per update: 0.781 without, 0.809 permutation only, 0.819 plane copy only,
+  // 0.816 both -- ONE fork / join pair in the replayed graph costs ~30 us, more than the 20 us of kernels it hides (the
+  // branches of a hipGraph run on separate queues and meet through barrier packets).  Same results either way.
   const long long mask = (1ll << pqn_index_bits(TN)) - 1;
   auto permutation = [&](int ep, hipStream_t s) -> int {
     UPD_CHECK(pqn_shuffle_keys_dyn(a->sched_keys + T + ep, TN, a->sort_keys_in, s));
@@ -648,13 +649,16 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
     return PQN_OK;
   };
   UpdSide *side = upd_side();
-  if (side) {
+  const int side_mask = pqn_opt(PQN_OPT_UPD_OVERLAP);   // bit 0: the permutation, bit 1: the plane copy
+  bool side_perm = false;
+  if (side && (side_mask & 1)) {
     if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) {
       (void)hipGetLastError();
       side = nullptr;
     } else {
       UPD_CHECK(permutation(0, side->s));
       HIP_OK(hipEventRecord(side->join, side->s), "hipEventRecord");
+      side_perm = true;
     }
   }
   // SAMPLE PHASE (_step_env scan, pqn_craftax.py:181-224)
@@ -688,7 +692,7 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
   int i_mb = 0;
   bool side_open = false;
   for (int ep = 0; ep < EP; ++ep) {
-    if (ep == 0 && side) HIP_OK(hipStreamWaitEvent(st, side->join, 0), "hipStreamWaitEvent");
+    if (ep == 0 && side_perm) HIP_OK(hipStreamWaitEvent(st, side->join, 0), "hipStreamWaitEvent");
     else UPD_CHECK(permutation(ep, st));
     for (int mb = 0; mb < MB; ++mb, ++i_mb) {
       UPD_CHECK(pqn_bigmlp_grad(&L, B, a->sort_keys_out + (size_t)mb * B, a->obs, a->q_lambda ? 0 : N, a->action,
@@ -696,7 +700,7 @@ extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream
                                 a->in_var, a->in_steps, a->grad, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, stream));
       UPD_CHECK(pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
                                  a->max_grad_norm, a->radam_scratch, nullptr, 0, nullptr, 1, 0, st));
-      if (side && i_mb + 1 == MB * EP) {   // last optimizer step: the input-gradient copy beside the closing bookkeeping below
+      if (side && (side_mask & 2) && i_mb + 1 == MB * EP) {   // last optimizer step: the input-gradient copy beside the closing bookkeeping below
         HIP_OK(hipEventRecord(side->fork, st), "hipEventRecord");
         HIP_OK(hipStreamWaitEvent(side->s, side->fork, 0), "hipStreamWaitEvent");
         UPD_CHECK(pqn_bigmlp_refresh_planes_streams(&L, a->theta, a->wplanes, stream, side->s));
