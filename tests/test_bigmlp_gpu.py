@@ -101,6 +101,7 @@ def test_bigmlp_forward_vs_oracle(gpu, oracle, d, h, layers, a, n, norm_input, r
     (1345, 1024, 4, 17, 1024, True, True, True),     # the same after 1000 steps: r / d renormalisation active
     (37, 256, 2, 5, 96, False, True, False),
     (20, 512, 1, 3, 200, True, False, False),
+    (37, 256, 2, 5, 1300, True, True, False),        # more than 1024 gradient rows: second pass of the loss kernel's workgroups, ragged tiles
 ])
 def test_bigmlp_one_step_loss_grad_vs_oracle(gpu, oracle, d, h, layers, a, nb, norm_input, renorm, warm):
     """value_and_grad of the `Q_LAMBDA: False` branch (pqn_craftax.py:287-304): obs and next_obs as one batch of 2 nb rows

@@ -345,6 +345,42 @@ def test_wide_mlp_whole_update_enqueue_equals_the_stepwise_loop(gpu, script, env
     assert saw_done or "Craftax" in env_name, "no finished episode inside the run: the reset paths were not exercised"
 
 
+def test_wide_mlp_update_side_stream_option_is_bit_identical(gpu):
+    """Option upd_overlap (bit 0: the first epoch's permutation on a side stream beside the rollout, bit 1: the
+    input-gradient plane copy of the last optimizer step beside the closing bookkeeping; pqn_bigmlp_refresh_planes_streams)
+    only moves launches between streams: parameters, optimizer state, statistics, env state and metrics of a run must not
+    change by a bit, with several minibatches and epochs per update (the later permutations stay on the main stream)."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys
+    cfg = flatten(load_config(["+alg=pqn_craftax"]))
+    cfg.update(dict(NUM_ENVS=64, NUM_STEPS=4, NUM_MINIBATCHES=2, NUM_EPOCHS=2, Q_LAMBDA=True, USE_OPTIMISTIC_RESETS=True,
+                    OPTIMISTIC_RESET_RATIO=8))
+    n, t, n_upd = cfg["NUM_ENVS"], cfg["NUM_STEPS"], 40
+    cfg.update({"ENV_NAME": "Craftax-Classic-Symbolic-v1", "HIDDEN_SIZE": 256, "NUM_LAYERS": 2, "NORM_TYPE": "layer_norm",
+                "TOTAL_TIMESTEPS": n_upd * n * t, "TOTAL_TIMESTEPS_DECAY": 30 * n * t, "TEST_DURING_TRAINING": False, "EPS_START": 0.5})
+    key = seed_keys(5, 1)[0]
+    prev = _lib.get_option("upd_overlap")
+    outs = []
+    try:
+        for ov in (0, 3, 1):
+            _lib.set_option("upd_overlap", ov)
+            out = make_train(dict(cfg), device="cuda:0", script="craftax")(key)
+            assert out["runner_state"]["driver"] == "graph", out["runner_state"]["driver_graph_error"]
+            outs.append(out)
+    finally:
+        _lib.set_option("upd_overlap", prev)
+    ref = outs[0]["runner_state"]
+    for o in outs[1:]:
+        rs = o["runner_state"]
+        for k in ("theta", "opt_mu", "opt_nu", "env_state", "last_obs"):
+            assert torch.equal(rs[k], ref[k]), k
+        for k, v in ref["batch_stats"].items():
+            assert torch.equal(rs["batch_stats"][k], v), k
+        for k, v in outs[0]["metrics"].items():
+            assert torch.equal(torch.nan_to_num(o["metrics"][k]), torch.nan_to_num(v)), k
+
+
 @pytest.mark.parametrize("driver", [True, False])
 def test_log_achievements_adds_the_done_weighted_achievement_means(gpu, driver):
     """`LOG_ACHIEVEMENTS: True` (pqn_craftax.py:384-387 keeps the info["Achievements/<name>"] keys in the metrics): 22
