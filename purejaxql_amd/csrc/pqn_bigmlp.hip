@@ -465,12 +465,12 @@ __global__ __launch_bounds__(256) void bm_split_transpose_multi_kernel(BmSplitTJ
 // z = sum of the K-split partials of the layer's GEMM + bias;  h = relu(LayerNorm(z)) row by row (one wave per row) written
 // as planes; z and stat[r] = (mean, rstd) are kept for the backward pass.  n % 256 == 0, n <= 2048: lane owns the
 // 8-column packs lane, lane + 64, ... of the row.
-#define BM_MAXP 4
+#define BM_MAXP 4   // packs per lane at the widest row (n <= 2048); the LayerNorm kernels are instantiated per count (KP)
 // Straight-line loads: NS (the K-split count) is a template parameter and the packs beyond the row are clamped to its
 // last pack instead of branched around, so every load of a lane (partials, bias, LayerNorm scale / bias) is in flight at
 // once.  With a run-time split loop inside per-pack branches each (pack, half, split) was its own round trip: 10 us per
 // launch at 1024 x 1024 where the traffic needs 4.
-template <int NS>
+template <int NS, int KP>   // KP = 8-column packs per lane = ceil(n / 512): no loads or arithmetic for packs the row does not have
 __global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict__ zpart, long long pstride, int m,
                                                          int n, const float *__restrict__ bias, const float *__restrict__ g,
                                                          const float *__restrict__ beta, float *__restrict__ z,
@@ -478,9 +478,9 @@ __global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
   const int np = n / 8;   // packs per row
-  f32x4 v[BM_MAXP][2], gv[BM_MAXP][2], bv[BM_MAXP][2];
+  f32x4 v[KP][2], gv[KP][2], bv[KP][2];
 #pragma unroll
-  for (int k = 0; k < BM_MAXP; ++k) {
+  for (int k = 0; k < KP; ++k) {
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int c = 8 * min(lane + 64 * k, np - 1) + 4 * hh;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict
   }
   float s = 0.f, q = 0.f;
 #pragma unroll
-  for (int k = 0; k < BM_MAXP; ++k) {
+  for (int k = 0; k < KP; ++k) {
     if (lane + 64 * k < np) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void bm_ln_relu_kernel(const float *__restrict
   const float rstd = 1.0f / sqrtf(var + BM_LN_EPS);
   if (lane == 0) { stat[2 * row] = mean; stat[2 * row + 1] = rstd; }
 #pragma unroll
-  for (int k = 0; k < BM_MAXP; ++k) {
+  for (int k = 0; k < KP; ++k) {
     const int pk = lane + 64 * k;
     if (pk < np) {
       float y[8];
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64) void bm_loss_kernel(const float *__restrict__ q
 //   y = xhat g + beta;  dy = d [y > 0];  dxh = dy g;  dz = rstd (dxh - mean(dxh) - xhat mean(dxh xhat))
 // part[wg][0] = sum_rows dy xhat (d scale), [1] = sum_rows dy (d LN bias), [2] = sum_rows dz (d dense bias).  n <= 2048, n % 256 == 0.
 #define BM_LB_ROWS 4   // one row per wave: 256 workgroups at 1024 gradient rows
-template <int NS>   // the K-split count of dpart: straight-line loads, see bm_ln_relu_kernel
+template <int NS, int KP>   // the K-split count of dpart and the packs per lane: straight-line loads, see bm_ln_relu_kernel
 __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict__ dpart, long long pstride,
                                                         BmPlanesOut dzp, const float *__restrict__ z,
                                                         const float *__restrict__ stat, const float *__restrict__ g,
@@ -784,9 +784,9 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
   __shared__ float s_red[4][3 * 1024];   // 1024 columns per pass of the cross-wave fold
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int np = n / 8;                  // packs per row: lane owns packs lane, lane + 64, ...
-  f32x4 a0[BM_MAXP][2], a1[BM_MAXP][2], a2[BM_MAXP][2];
+  f32x4 a0[KP][2], a1[KP][2], a2[KP][2];
 #pragma unroll
-  for (int k = 0; k < BM_MAXP; ++k)
+  for (int k = 0; k < KP; ++k)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) { a0[k][hh] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[k][hh] = a0[k][hh]; a2[k][hh] = a0[k][hh]; }
   for (int rr = wave; rr < BM_LB_ROWS; rr += 4) {
@@ -794,10 +794,10 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
     if (row >= rows) break;
     const float mean = stat[2 * row], rstd = stat[2 * row + 1];
     const float *zr = z + (long long)row * n;
-    f32x4 xh[BM_MAXP][2], dxh[BM_MAXP][2], dy[BM_MAXP][2];
-    f32x4 zv[BM_MAXP][2], dv[BM_MAXP][2], gv[BM_MAXP][2], bv[BM_MAXP][2];
+    f32x4 xh[KP][2], dxh[KP][2], dy[KP][2];
+    f32x4 zv[KP][2], dv[KP][2], gv[KP][2], bv[KP][2];
 #pragma unroll
-    for (int k = 0; k < BM_MAXP; ++k) {   // every load of the row in flight at once (packs beyond the row: its last pack again)
+    for (int k = 0; k < KP; ++k) {   // every load of the row in flight at once (packs beyond the row: its last pack again)
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int c = 8 * min(lane + 64 * k, np - 1) + 4 * hh;
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < BM_MAXP; ++k) {
+    for (int k = 0; k < KP; ++k) {
       const int pk = lane + 64 * k;
       if (pk < np) {
 #pragma unroll
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
     s1 = bm_wave_sum(s1) / (float)n;
     s2 = bm_wave_sum(s2) / (float)n;
 #pragma unroll
-    for (int k = 0; k < BM_MAXP; ++k) {
+    for (int k = 0; k < KP; ++k) {
       const int pk = lane + 64 * k;
       if (pk < np) {
         float dzv[8];
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256) void bm_ln_bwd_kernel(const float *__restrict_
   for (int base = 0; base < n; base += 1024) {
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < BM_MAXP; ++k) {
+    for (int k = 0; k < KP; ++k) {
       const int pk = lane + 64 * k;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -1200,25 +1200,35 @@ BmWp bm_wp(const pqn_bigmlp_layout_t &L) {
   return w;
 }
 
-// K-split count -> template instance
+// (K-split count, packs per lane) -> template instance
+#define BM_LN_CASES(KERN, NS_)                                                                              \
+  switch (kp) {                                                                                             \
+    case 1: hipLaunchKernelGGL((KERN<NS_, 1>), dim3(blocks), dim3(256), 0, st, args...); break;             \
+    case 2: hipLaunchKernelGGL((KERN<NS_, 2>), dim3(blocks), dim3(256), 0, st, args...); break;             \
+    case 3: hipLaunchKernelGGL((KERN<NS_, 3>), dim3(blocks), dim3(256), 0, st, args...); break;             \
+    default: hipLaunchKernelGGL((KERN<NS_, 4>), dim3(blocks), dim3(256), 0, st, args...); break;            \
+  }
 template <typename... Args>
-void bm_ln_relu(int ns, int blocks, hipStream_t st, Args... args) {
+void bm_ln_relu(int ns, int n, int blocks, hipStream_t st, Args... args) {
+  const int kp = (n / 8 + 63) / 64;
   switch (ns) {
-    case 1: hipLaunchKernelGGL(bm_ln_relu_kernel<1>, dim3(blocks), dim3(256), 0, st, args...); break;
-    case 2: hipLaunchKernelGGL(bm_ln_relu_kernel<2>, dim3(blocks), dim3(256), 0, st, args...); break;
-    case 3: hipLaunchKernelGGL(bm_ln_relu_kernel<3>, dim3(blocks), dim3(256), 0, st, args...); break;
-    default: hipLaunchKernelGGL(bm_ln_relu_kernel<4>, dim3(blocks), dim3(256), 0, st, args...); break;
+    case 1: BM_LN_CASES(bm_ln_relu_kernel, 1) break;
+    case 2: BM_LN_CASES(bm_ln_relu_kernel, 2) break;
+    case 3: BM_LN_CASES(bm_ln_relu_kernel, 3) break;
+    default: BM_LN_CASES(bm_ln_relu_kernel, 4) break;
   }
 }
 template <typename... Args>
-void bm_ln_bwd(int ns, int blocks, hipStream_t st, Args... args) {
+void bm_ln_bwd(int ns, int n, int blocks, hipStream_t st, Args... args) {
+  const int kp = (n / 8 + 63) / 64;
   switch (ns) {
-    case 1: hipLaunchKernelGGL(bm_ln_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, args...); break;
-    case 2: hipLaunchKernelGGL(bm_ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, args...); break;
-    case 3: hipLaunchKernelGGL(bm_ln_bwd_kernel<3>, dim3(blocks), dim3(256), 0, st, args...); break;
-    default: hipLaunchKernelGGL(bm_ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, st, args...); break;
+    case 1: BM_LN_CASES(bm_ln_bwd_kernel, 1) break;
+    case 2: BM_LN_CASES(bm_ln_bwd_kernel, 2) break;
+    case 3: BM_LN_CASES(bm_ln_bwd_kernel, 3) break;
+    default: BM_LN_CASES(bm_ln_bwd_kernel, 4) break;
   }
 }
+#undef BM_LN_CASES
 template <typename... Args>
 void bm_innorm_apply(bool norm, unsigned blocks, hipStream_t st, Args... args) {
   if (norm) hipLaunchKernelGGL(bm_innorm_apply_kernel<true>, dim3(blocks), dim3(256), 0, st, args...);
@@ -1236,7 +1246,7 @@ int bm_forward(const pqn_bigmlp_layout_t &L, int rows, const float *theta, const
     int ns = 1;
     const int rc = bm_gemm(rows, L.h, kp, A, B, bm_store(ws + w.zpart, L.h, nullptr, w.zstride), BM_MAX_SPLIT, &ns, st);
     if (rc != PQN_OK) return rc;
-    bm_ln_relu(ns, (rows + 3) / 4, st, (const float *)(ws + w.zpart), w.zstride, rows, L.h, theta + L.off_b[l], theta + L.off_lns[l],
+    bm_ln_relu(ns, L.h, (rows + 3) / 4, st, (const float *)(ws + w.zpart), w.zstride, rows, L.h, theta + L.off_b[l], theta + L.off_lns[l],
                theta + L.off_lnb[l], ws + w.z[l], bm_plo(wb + w.h[l], rows, L.h), ws + w.stat[l]);
   }
   const int lo = L.layers;   // output layer: Q = h_last W_out + b_out, K split + fold (see bm_qfold_kernel)
@@ -1523,7 +1533,7 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
   if (rc != PQN_OK) return rc;
   for (int l = lo - 1; l >= 0; --l) {
     // dpart (nsd K-split partials) = d loss / d h_l  ->  relu mask + LayerNorm backward: dz planes = d loss / d z_l
-    bm_ln_bwd(nsd, w.n_ln, st, (const float *)(ws + w.dpart), w.dstride, bm_plo(wb + w.dz[l], nb, L->h), (const float *)(ws + w.z[l]),
+    bm_ln_bwd(nsd, L->h, w.n_ln, st, (const float *)(ws + w.dpart), w.dstride, bm_plo(wb + w.dz[l], nb, L->h), (const float *)(ws + w.z[l]),
               (const float *)(ws + w.stat[l]), theta + L->off_lns[l], theta + L->off_lnb[l], nb, L->h, ws + w.lnpart[l]);
     const int kin = l ? L->h : L->d;
     const BmPlanes dZ = bm_pl(wb + w.dz[l], nb, L->h);
