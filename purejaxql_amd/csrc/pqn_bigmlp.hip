@@ -370,13 +370,18 @@ PQN_D void bm_transpose_body(const BmPlanes &src, int cols, const BmPlanesOut &d
   const int r0 = bx * 64, c0 = by * 64;   // source rows r0.., source columns c0..
   const bf16_t *sp = src.p + (long long)bz * src.pstride;
   bf16_t *dp = dst.p + (long long)bz * dst.pstride;
+  u32x4 lv[2];   // load: 64 rows x 8 chunks of 8 columns (columns >= cols hold the source's zero padding); both loads in flight
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {   // load: 64 rows x 8 chunks of 8 columns (columns >= cols hold the source's zero padding)
+  for (int q = 0; q < 2; ++q) {
     const int e = tid + 256 * q, r = e >> 3, ch = e & 7;
-    const int rr = r0 + r, cc = c0 + 8 * ch;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (rr < src.rows && cc < src.ld) v = *reinterpret_cast<const u32x4 *>(sp + (long long)rr * src.ld + cc);
-    *reinterpret_cast<u32x4 *>(&tile[r][8 * ch]) = v;
+    const int rr = min(r0 + r, src.rows - 1), cc = min((long long)(c0 + 8 * ch), src.ld - 8);   // clamped: masked below
+    lv[q] = *reinterpret_cast<const u32x4 *>(sp + (long long)rr * src.ld + cc);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = tid + 256 * q, r = e >> 3, ch = e & 7;
+    const bool ok = r0 + r < src.rows && c0 + 8 * ch < src.ld;
+    *reinterpret_cast<u32x4 *>(&tile[r][8 * ch]) = ok ? lv[q] : u32x4{0u, 0u, 0u, 0u};
   }
   __syncthreads();
 #pragma unroll
