@@ -174,7 +174,7 @@ def prng_key(seed: int) -> int:
     return int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
-KERNEL_FORMS = {0: "none", 1: "single", 2: "pair", 3: "pair+pd2", 4: "pair+pos", 5: "ksplit"}
+KERNEL_FORMS = {0: "none", 1: "single", 2: "pair", 3: "pair+pd2", 4: "pair+pos", 5: "ksplit", 6: "pos"}
 
 
 def set_option(name: str, value: int):

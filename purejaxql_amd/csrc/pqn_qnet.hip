@@ -32,37 +32,8 @@
 
 #include "pqn_common.h"
 #include "pqn_env_rules.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define QN_TILE 16        // samples per workgroup (= one MFMA M-tile)
-#define QN_WAVES 8        // 512-thread workgroups: 2 waves per SIMD so MFMA / VALU / loads of different waves overlap
-#define QN_THREADS (64 * QN_WAVES)
-#define QN_SPW (QN_TILE / QN_WAVES)   // samples owned by one wave in the per-sample phases
-#define QN_H1 1024        // conv features (8*8*16)
-#define QN_H1S 1032       // LDS row stride of the h1 tile (floats): conflict-free ds_read_b128
-#define QN_HID 128
-#define QN_ZS 132         // LDS row stride of the z tile
-#define QN_LN_EPS 1e-6f   // flax nn.LayerNorm default
-#define QN_MAXA 8
-#define QN_HP_FLOATS (384 + 128 * QN_MAXA + QN_MAXA)   // head parameters staged in LDS
-#define QN_STG 20        // floats per staged point (16 + pad: conflict-free ds_read_b128 across lanes)
-// bf16x3 kernels (in-place conv staging): the h1 tile keeps the quad swizzle of its staging slots -- feature i of a row
-// lives at slot i ^ (((i >> 6) & 3) << 2), i.e. the four 16-B quads of position p are XORed with (p >> 2) & 3 (round 4).
-// The conv phase's final ds_write_b128 of a lane's 64 B (lane = position, lane stride 64 B) was a 4-way bank conflict
-// with the plain layout; swizzled it goes to the very slots the lane just read its staged values from, conflict-free.
-// Readers (fc1 A fragments, the h1^T slices, the relu mask of the in-place dgrad) apply the same map.
-#ifndef QN_H1_SWIZZLE
-#define QN_H1_SWIZZLE 1
-#endif
-__device__ __forceinline__ int h1_slot(int i) { return QN_H1_SWIZZLE ? (i ^ (((i >> 6) & 3) << 2)) : i; }
-
-template <int C>
-struct CnnCfg {
-  static constexpr int OW = (((100 * C + 31) / 32) + 3) / 4 * 4;  // packed obs words (16-B multiple)
-  static constexpr int ROWBITS = 3 * C;                           // bits of one window row
-  static constexpr int KW = 9 * C;                                // conv reduction length
-};
+#include "pqn_qnet_x3.h"
+#include "pqn_qnet_pos.h"
 
 struct CnnSmem {
   float *h1;      // [QN_TILE][QN_H1S]
@@ -72,211 +43,6 @@ struct CnnSmem {
   float *hp;      // head parameters: b1[128] | ln1 scale[128] | ln1 bias[128] | w2[128][A] | b2[A]
   uint32_t *bits; // [QN_TILE][OW]
 };
-
-// v_rsq_f32 (1 ulp) + one Newton step: ~1e-7 relative, a handful of VALU ops instead of the
-// ~25-instruction IEEE sqrt+divide expansion.
-PQN_D float rsqrt_exact(float x) {
-  float y = __builtin_amdgcn_rsqf(x);
-  const float h = 0.5f * x * y;
-  return fmaf(y, fmaf(-h, y, 0.5f), y);
-}
-
-// all-reduce sum over each 16-lane row with DPP row rotates (VALU speed, no LDS crossbar).
-// Rotating by half the remaining period is a butterfly: every lane ends with bit-identical sums.
-template <int N>
-PQN_D float row_ror(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
-}
-PQN_D float group16_sum(float v) {
-  v += row_ror<8>(v);
-  v += row_ror<4>(v);
-  v += row_ror<2>(v);
-  v += row_ror<1>(v);
-  return v;
-}
-
-// ---------------------------------------------------------------------------
-// bf16x3 split-operand products (pqn_cnn_layout_t.matmul_f16 == 2, config MATMUL_DTYPE: bf16x3).
-// gfx950 has no tf32/xf32 path and its f32-input MFMA runs at the vector rate (1/16 of the bf16 rate), so an
-// f32 x f32 product is evaluated on the bf16 matrix core from EXACT three-way splits: x = hi + mid + lo with
-// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (8 + 8 + 8 significand bits; both subtractions are
-// exact in f32), and a*b ~= ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh -- the three dropped terms are
-// <= 2^-23 |a b|, i.e. f32 rounding level; every partial product is exact in the f32 accumulator's input and
-// the accumulation is f32.  6 x v_mfma_f32_16x16x32_bf16 (K = 32) replace 8 x v_mfma_f32_16x16x4_f32: ~5x
-// fewer matrix-pipe cycles.  Measured error vs an f64 dot product (K = 1024, tools/ubench/bf16x3.hip):
-// 1.7e-7 * sum|a b|, against 0.9e-7 for the f32 fma chain.
-// The split is 9 VALU ops per pair of values (v_cvt_pk_bf16_f32, shift / mask back to f32, v_pk_add_f32).
-// ---------------------------------------------------------------------------
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-PQN_D void x3_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-  const f32x2 x = {x0, x1};
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
-  const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xFFFF0000u)};
-  const f32x2 r1 = x - hf;
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
-  const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xFFFF0000u)};
-  const f32x2 r2 = r1 - mf;
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
-}
-
-// the same split in three stages (4 + 4 + 1 VALU ops), for kernels that interleave it with MFMAs by hand
-struct X3Split {
-  f32x2 x, r;
-  unsigned h, m, l;
-};
-PQN_D void x3_stage1(X3Split &s) {
-  s.h = __builtin_bit_cast(unsigned, __builtin_convertvector(s.x, bf16x2_t));
-  const f32x2 hf = {__uint_as_float(s.h << 16), __uint_as_float(s.h & 0xFFFF0000u)};
-  s.r = s.x - hf;
-}
-PQN_D void x3_stage2(X3Split &s) {
-  s.m = __builtin_bit_cast(unsigned, __builtin_convertvector(s.r, bf16x2_t));
-  const f32x2 mf = {__uint_as_float(s.m << 16), __uint_as_float(s.m & 0xFFFF0000u)};
-  s.r = s.r - mf;
-}
-PQN_D void x3_stage3(X3Split &s) { s.l = __builtin_bit_cast(unsigned, __builtin_convertvector(s.r, bf16x2_t)); }
-
-// one MFMA operand fragment (8 k-values per lane) as three bf16 planes
-struct X3Frag {
-  u32x4 h, m, l;
-};
-// k-values 0..3 = a, 4..7 = b (the two float4 halves a lane holds of a 32-wide K step)
-PQN_D X3Frag x3_split8(const f32x4 a, const f32x4 b) {
-  unsigned h[4], m[4], l[4];
-  x3_split2(a.x, a.y, h[0], m[0], l[0]);
-  x3_split2(a.z, a.w, h[1], m[1], l[1]);
-  x3_split2(b.x, b.y, h[2], m[2], l[2]);
-  x3_split2(b.z, b.w, h[3], m[3], l[3]);
-  X3Frag f;
-  f.h = u32x4{h[0], h[1], h[2], h[3]};
-  f.m = u32x4{m[0], m[1], m[2], m[3]};
-  f.l = u32x4{l[0], l[1], l[2], l[3]};
-  return f;
-}
-// v_mfma_f32_16x16x32_bf16 with the accumulator TIED (D and C the same register tuple), as VOLATILE inline asm.
-// Why not the builtin, and why volatile: with ROCm 7.2 the builtin form of this instruction produced run-to-run
-// DIFFERENT results in the conv phase of the training kernel (only in builds whose assembly gave the MFMA a destination
-// tuple partially overlapping its accumulator input -- tools/check_mfma_overlap.py scans for that), and so did the
-// tied but NON-volatile asm once the compiler was free to re-order it (10-channel / 7-channel / 6-channel kernels,
-// conv phase only; the 4-channel kernel never showed it).  The hardware hazards one might suspect were measured and
-// ruled out (tools/ubench/mfma_war.hip: overwriting A / B right behind the MFMA is safe, a VALU-written operand needs
-// ONE wait state, dependent chains at any distance are exact), so the root cause is left as "compiler scheduling of
-// this new instruction"; what is relied on is what was verified: source-order issue (volatile), tied accumulators,
-// the pads below, and tests/test_qnet_gpu.py::test_bf16x3_is_deterministic_and_matches_f32_mode over all channel counts.
-// Inline asm carries its own wait states (the compiler pads nothing inside the string):
-//   - `s_nop 1` ahead of the MFMA covers a VALU write of an operand in the preceding issue slots (1 state needed);
-//   - the result is consumed only by the next tied MFMA of the chain (no wait states needed) or after x3_drain*.
-PQN_D f32x4 x3_mfma_tied(const u32x4 &a, const u32x4 &b, f32x4 c) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-  return c;
-}
-#define X3_MFMA(A, B, C) x3_mfma_tied(A, B, C)
-// De-phasing the two waves of a SIMD (round 4).  Waves w and w + 4 of a 512-thread workgroup share a SIMD; released by the
-// same barrier they run the same loop in lockstep -- both in their MFMA burst, then both in their VALU / LDS / load part --
-// and the two instruction classes add up instead of overlapping (T2: 51 us of data movement + 47 us of matrix pipe = 101 us,
-// profiles/r04_v1_t2_ablate.txt; fc1: 1.8k cycles per K step against ~1.0k issue slots).  A one-off s_sleep of about half a
-// loop period on waves 4..7 in front of a barrier-free loop puts one wave's MFMA burst beside the other's VALU part for the
-// whole loop.  Timing only: no effect on results.  (-DX3_SKEW_* = s_sleep argument, units of 64 clocks; 0 = off.)
-#ifndef X3_SKEW_FC1
-#define X3_SKEW_FC1 0
-#endif
-#ifndef X3_SKEW_DGRAD
-#define X3_SKEW_DGRAD 0
-#endif
-#ifndef X3_SKEW_T2
-#define X3_SKEW_T2 0
-#endif
-template <int N>
-PQN_D void x3_skew(int wave) {
-  if constexpr (N > 0) {
-    if (wave >= 4) __builtin_amdgcn_s_sleep(N);
-  }
-}
-// GROUPS of independent MFMAs (different accumulators) as ONE asm statement with ONE leading `s_nop 1` (round 4).  The pad
-// in front of a single MFMA covers a VALU write of one of its operands in the preceding issue slots -- the compiler cannot
-// see inside the asm string and schedules its own VALU instructions between the statements -- but inside a run of MFMAs
-// it is pure cost: MI355X_MICROARCH.md prices one extra issue state between MFMAs at ~6 cycles (different accumulators)
-// against the ~16 cycles the MFMA itself occupies the pipe.  Inside a group nothing can be scheduled between the MFMAs, so
-// only the first needs the pad; instruction order, operands and therefore results are unchanged.
-#ifdef X3_NO_GROUP   // A/B hook: one statement (and one pad) per MFMA, as in rounds 2-3
-PQN_D void x3_grp2(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
-  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1);
-}
-PQN_D void x3_grp4(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
-                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
-  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1); c2 = x3_mfma_tied(a2, b2, c2); c3 = x3_mfma_tied(a3, b3, c3);
-}
-PQN_D void x3_grp6(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
-                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3, f32x4 &c4, const u32x4 &a4,
-                   const u32x4 &b4, f32x4 &c5, const u32x4 &a5, const u32x4 &b5) {
-  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1); c2 = x3_mfma_tied(a2, b2, c2); c3 = x3_mfma_tied(a3, b3, c3);
-  c4 = x3_mfma_tied(a4, b4, c4); c5 = x3_mfma_tied(a5, b5, c5);
-}
-#else
-PQN_D void x3_grp2(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
-  asm volatile("s_nop 1\n\t"
-               "v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\t"
-               "v_mfma_f32_16x16x32_bf16 %1, %4, %5, %1"
-               : "+v"(c0), "+v"(c1)
-               : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
-}
-PQN_D void x3_grp4(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
-                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
-  asm volatile("s_nop 1\n\t"
-               "v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n\t"
-               "v_mfma_f32_16x16x32_bf16 %1, %6, %7, %1\n\t"
-               "v_mfma_f32_16x16x32_bf16 %2, %8, %9, %2\n\t"
-               "v_mfma_f32_16x16x32_bf16 %3, %10, %11, %3"
-               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
-               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
-}
-PQN_D void x3_grp6(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
-                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3, f32x4 &c4, const u32x4 &a4,
-                   const u32x4 &b4, f32x4 &c5, const u32x4 &a5, const u32x4 &b5) {
-  asm volatile("s_nop 1\n\t"
-               "v_mfma_f32_16x16x32_bf16 %0, %6, %7, %0\n\t"
-               "v_mfma_f32_16x16x32_bf16 %1, %8, %9, %1\n\t"
-               "v_mfma_f32_16x16x32_bf16 %2, %10, %11, %2\n\t"
-               "v_mfma_f32_16x16x32_bf16 %3, %12, %13, %3\n\t"
-               "v_mfma_f32_16x16x32_bf16 %4, %14, %15, %4\n\t"
-               "v_mfma_f32_16x16x32_bf16 %5, %16, %17, %5"
-               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5)
-               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
-}
-#endif
-// N MFMAs sharing the B operand (N row blocks against one fragment): grouped for the N the kernels use
-template <int N>
-PQN_D void x3_grp_sameb(f32x4 (&c)[N], const u32x4 (&a)[N], const u32x4 &b) {
-  if constexpr (N == 2) x3_grp2(c[0], a[0], b, c[1], a[1], b);
-  else if constexpr (N == 3) { x3_grp2(c[0], a[0], b, c[1], a[1], b); c[2] = x3_mfma_tied(a[2], b, c[2]); }
-  else if constexpr (N == 4) x3_grp4(c[0], a[0], b, c[1], a[1], b, c[2], a[2], b, c[3], a[3], b);
-  else if constexpr (N == 6) x3_grp6(c[0], a[0], b, c[1], a[1], b, c[2], a[2], b, c[3], a[3], b, c[4], a[4], b, c[5], a[5], b);
-  else {
-#pragma unroll
-    for (int j = 0; j < N; ++j) c[j] = x3_mfma_tied(a[j], b, c[j]);
-  }
-}
-// end of an accumulation chain: 16 wait states (an MFMA result may not be read by anything but a tied MFMA earlier)
-PQN_D void x3_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a)); }
-PQN_D void x3_drain(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b)); }
-PQN_D void x3_drain(f32x4 &a, f32x4 &b, f32x4 &c) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c)); }
-PQN_D void x3_drain(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) {
-  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-}
-// acc_s takes the three small cross terms, acc_b the three leading ones: two independent dependency chains, and the
-// small terms are summed among themselves before they meet the large ones
-PQN_D void x3_mfma6(const X3Frag &a, const X3Frag &b, f32x4 &acc_b, f32x4 &acc_s) {
-  acc_s = X3_MFMA(a.l, b.h, acc_s);
-  acc_b = X3_MFMA(a.m, b.h, acc_b);
-  acc_s = X3_MFMA(a.h, b.l, acc_s);
-  acc_b = X3_MFMA(a.h, b.m, acc_b);
-  acc_s = X3_MFMA(a.m, b.m, acc_s);
-  acc_b = X3_MFMA(a.h, b.h, acc_b);
-}
 
 // ---------------------------------------------------------------------------
 // conv 3x3xC -> 16 as MFMA.  A 16x16 output tile = 16 "points" (rows) x 16 channels; the
@@ -347,74 +113,6 @@ struct ConvMfma {
     }
     dA = a0;
     dB = a1;
-  }
-};
-
-// The same conv on the bf16 matrix core (operand mode 2).  The observation bits are exact in bf16, so the A operand is
-// ONE plane; the kernel Wc is split exactly into three bf16 planes (x3_split2) when the workgroup starts, and
-//   out = sum_k bit_k * (Wh + Wm + Wl)[k]   -- 3 x v_mfma_f32_16x16x32_bf16 per 32 window bits, f32 accumulate
-// has no rounding beyond the f32 accumulation itself (the f32-operand path rounds bit/255 * w per product instead).
-// K slot (kq = lane>>4, j) of step s stands for window element k = 32 s + 8 kq + j.  A "set" bit is written as the
-// bf16 value 2.0 (0x4000: a single bit, so a pair of slots is two shifts and two masks); the 1/255 input scale and
-// the 1/2 are applied once to the accumulator.
-template <int C>
-struct ConvX3 {
-  static constexpr int NK = 9 * C, NS = (NK + 31) / 32, RB = 3 * C;
-  static constexpr float OUT_SCALE = 0.5f / 255.0f;
-  X3Frag w[NS];
-  PQN_D void init(const float *wc, int lane) {
-    const int kq = lane >> 4, o = lane & 15;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = 32 * s + 8 * kq + j;
-        v[j] = (k < NK) ? wc[k * 16 + o] : 0.0f;
-      }
-      w[s] = x3_split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
-    }
-  }
-  // bits [32 s, 32 s + 32) of the 9C-bit window string m0 | m1 << RB | m2 << 2 RB (compile-time shifts)
-  static PQN_D uint32_t word(const uint32_t (&m)[3], int s) {
-    uint32_t wv = 0u;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int off = r * RB - 32 * s;
-      if (off >= 0 && off < 32) wv |= m[r] << off;
-      else if (off < 0 && off > -32) wv |= m[r] >> (-off);
-    }
-    return wv;
-  }
-  // 8 bits -> 8 bf16 slots (2.0 or 0): y carries bit 2jj at 2jj and bit 2jj+1 at 2jj+16; one shift + mask per pair
-  static PQN_D u32x4 expand8(uint32_t byte) {
-    const uint32_t y = (byte << 15) | byte;
-    return u32x4{(y << 14) & 0x40004000u, (y << 12) & 0x40004000u, (y << 10) & 0x40004000u, (y << 8) & 0x40004000u};
-  }
-  // the four 16-point tiles of one sample at once: eight independent accumulators ({h plane, m + l planes} per tile),
-  // reuse distance >= 4 in issue order (a dependent MFMA issues ~90 counter ticks after its producer)
-  PQN_D void tile4(const uint32_t *wm, int i, int kq, f32x4 (&d)[4]) const {
-    u32x4 fa[4][NS];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int p = 16 * t + i;
-      const uint32_t m[3] = {wm[p * 3], wm[p * 3 + 1], wm[p * 3 + 2]};
-#pragma unroll
-      for (int s = 0; s < NS; ++s) fa[t][s] = expand8(__builtin_amdgcn_ubfe(word(m, s), 8u * kq, 8u));
-    }
-    f32x4 ab[4], as[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { ab[t] = f32x4{0.f, 0.f, 0.f, 0.f}; as[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      x3_grp4(as[0], fa[0][s], w[s].l, as[1], fa[1][s], w[s].l, as[2], fa[2][s], w[s].l, as[3], fa[3][s], w[s].l);
-      x3_grp4(ab[0], fa[0][s], w[s].h, ab[1], fa[1][s], w[s].h, ab[2], fa[2][s], w[s].h, ab[3], fa[3][s], w[s].h);
-      x3_grp4(as[0], fa[0][s], w[s].m, as[1], fa[1][s], w[s].m, as[2], fa[2][s], w[s].m, as[3], fa[3][s], w[s].m);
-    }
-    x3_drain(ab[0], ab[1], ab[2], ab[3]);
-    x3_drain(as[0], as[1], as[2], as[3]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) d[t] = (ab[t] + as[t]) * OUT_SCALE;
   }
 };
 
@@ -678,23 +376,6 @@ PQN_D void phase2_fc1_f16(const CnnSmem &s, const _Float16 *__restrict__ w1h, in
   zp[QN_ZS] = acc.y;
   zp[2 * QN_ZS] = acc.z;
   zp[3 * QN_ZS] = acc.w;
-}
-
-// Weight operands of the bf16x3 mode: the fc1 kernel's three bf16 planes, kept in the tail of the parameter buffer
-// (pqn_cnn_layout_t.off_w1h, 6 x 131072 bf16 = 393216 floats) by the optimizer kernel, in the two fragment orders the
-// kernels stream:
-//   forward  Wf[p][s][cb][lane][8]    lane = kk*16 + o%16, slot j: i = 32 s + 16 (j>>2) + 4 kk + (j&3), o = 16 cb + o%16
-//   dgrad    Wd[p][ib][sK][lane][8]   lane = kd*16 + i%16, slot j: o = 32 sK + 16 (j>>2) + 4 kd + (j&3), i = 16 ib + i%16
-// (one dwordx4 per lane = the 8 k-values of a 32-wide MFMA step; 1 KB per wave-instruction).  Splitting the weights
-// once per optimizer step instead of once per use leaves the kernels with the A-operand split only.
-#define X3_PLANE (QN_H1 * QN_HID)                 // bf16 elements per plane
-PQN_HD int x3_fwd_index(int i, int o) {           // element offset inside one forward plane
-  const int s = i >> 5, h = (i >> 4) & 1, kk = (i >> 2) & 3, sx = i & 3;
-  return ((((s * 8 + (o >> 4)) * 64) + kk * 16 + (o & 15)) << 3) + 4 * h + sx;
-}
-PQN_HD int x3_dgrad_index(int i, int o) {         // element offset inside one dgrad plane
-  const int sK = o >> 5, h = (o >> 4) & 1, kd = (o >> 2) & 3, sx = o & 3;
-  return (((((i >> 4) * 4 + sK) * 64) + kd * 16 + (i & 15)) << 3) + 4 * h + sx;
 }
 
 // phase 2, bf16x3: z[16][128] = h1 x W1 on the bf16 matrix core.  Wave w = (K half kh = w&1, column-block pair
@@ -1173,37 +854,6 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_kernel(
 // "Small" partial record per tile (floats): [conv kernel KW*16 | conv bias 16 | ln0 scale 16 |
 // ln0 bias 16 | b1 128 | ln1 scale 128 | ln1 bias 128 | w2 128*A | b2 A | loss | sum q_a].
 // ===========================================================================
-#define QW_SLAB 256
-// leading dimension of the transposed operands: nb + 32 floats, so consecutive rows (16 KB apart at
-// nb = 4096) do not all land on the same L2 channel
-__host__ __device__ inline int qw_ld(int nb) { return nb + 32; }
-// columns reserved per h1 feature row in the workspace: the sample-major layout needs nb + 32, the slab-major layout
-// of the bf16x3 mode (h1s_index) whole 256-sample slabs
-__host__ __device__ inline int qw_h1_cols(int nb) { return max(nb + 32, (nb + QW_SLAB - 1) / QW_SLAB * QW_SLAB); }
-// bf16x3 mode: h1 is handed from T1 to T2 slab-major, [slab ks][row block it][step u][64 rows][32 samples] -- the tile
-// a T2 workgroup consumes per step is 8 KB contiguous, a workgroup's whole stream 64 KB x G contiguous (the sample-major
-// layout made every 128-B line of that stream a different DRAM page: ~3.6 TB/s with no compute at all)
-__host__ __device__ inline size_t h1s_index(int i, int b) {
-  return ((((size_t)(b >> 8) * 16 + (i >> 6)) * 8 + ((b >> 5) & 7)) * 64 + (i & 63)) * 32 + (b & 31);
-}
-
-__host__ __device__ inline int small_record_floats(int c, int a) { return 9 * c * 16 + 48 + 384 + 128 * a + a + 2; }
-// bf16x3 mode: dz is handed from T1 to T2 as three bf16 planes, already split, in the B-fragment order T2's MFMAs read:
-//   dzw[plane][slab ks][column block cb][step u][lane = kg * 16 + (o & 15)][8]  -- slot j of the 8 = sample
-//   256 ks + 32 u + 16 (j >> 2) + 4 kg + (j & 3), output o = 16 cb + (o & 15); one dwordx4 per lane = one operand.
-// Plane stride = slabs * 256 * 128 elements.  The region sits behind the split-K slabs of the workspace; every kernel
-// derives it from the dz^T pointer (workspace carve-up of launch_train).
-__host__ __device__ inline int qw_slabs(int nb) { return (nb + 255) / 256; }
-__host__ __device__ inline size_t qw_dzw_offset(int nb, int c, int a) {   // floats from dzT to the planes
-  return (size_t)QN_HID * qw_ld(nb) + (size_t)QN_H1 * qw_h1_cols(nb) + (size_t)(nb / QN_TILE) * small_record_floats(c, a) +
-         (size_t)qw_slabs(nb) * QN_H1 * QN_HID;
-}
-__host__ __device__ inline size_t qw_dzw_floats(int nb) { return (size_t)qw_slabs(nb) * 256 * QN_HID * 3 / 2; }
-PQN_HD size_t dzw_index(int b, int o) {   // element offset of (sample b, output o) inside one plane
-  const int ks = b >> 8, u = (b >> 5) & 7, hf = (b >> 4) & 1, kg = (b >> 2) & 3;
-  return (((((size_t)ks * 8 + (o >> 4)) * 8 + u) * 64 + kg * 16 + (o & 15)) << 3) + 4 * hf + (b & 3);
-}
-
 template <int C>
 struct TrainCfg {
   using Cfg = CnnCfg<C>;
@@ -1237,18 +887,6 @@ PQN_D TrainSmem carve_train_smem(char *base) {
 template <int C>
 constexpr size_t train_smem_bytes() {
   return cnn_smem_bytes<C>() + sizeof(float) * (TrainCfg<C>::SCR + 3 * QN_TILE + QN_WAVES * 48 + 4);
-}
-
-// dz as bf16 planes for the position-parallel backward (element offsets in bf16 units inside one plane set):
-//   dzA[plane][sample][sK][kq][8]: the 8 values are outputs 32 sK + 16 (j >> 2) + 4 kq + (j & 3) -- one dwordx4 per lane is
-//       the A fragment (row = sample) of a K = 32 dgrad step, in the K-slot order of the optimizer's dgrad planes;
-//   dzB[super-tile of 32 samples][cb][plane][lane][tile 0/1][4], lane = kq * 16 + (o & 15): samples 4 kq .. 4 kq + 3 of
-//       each of the two tiles for output 16 cb + (o & 15) -- one dwordx4 per lane is the B fragment (column = output) of
-//       a K = 32 step of dW1 = h1^T dz whose K slot j stands for sample 16 (j >> 2) + 4 kq + (j & 3) of the super-tile.
-// Plane stride: nb * 128 (dzA), 512 inside a (super-tile, cb) block (dzB).  dzA occupies 3 nb 128 elements, dzB follows it.
-PQN_HD size_t dz_planes_a(int nb, int sample, int sK, int kq) { (void)nb; return ((size_t)sample * 16 + sK * 4 + kq) * 8; }
-PQN_HD size_t dz_planes_b(int tile, int cb, int lane) {
-  return (((((size_t)(tile >> 1) * 8 + cb) * 3) * 64 + lane) * 2 + (tile & 1)) * 4;
 }
 
 // all-reduce sum over each aligned group of 32 lanes: DPP butterfly inside the 16-lane rows, then one
@@ -4383,6 +4021,35 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   const float inv_b = 1.0f / (float)nb;
   const int ablate = pqn_opt(PQN_OPT_ABLATE_TRAIN);  // profiling only
+  // ---- the position-parallel form (pqn_qnet_pos.hip; round 5): gather -> forward (wave = 32 samples, z in registers, W1
+  // planes shared through LDS) -> backward (wave = conv position, its W1 / dW1 rows resident) -> fold.  Option bwd_pos:
+  // 0 never, 1 when the launch fills the chip, 2 whenever the shape allows (tests), 3 / 4 = the pair kernel forward-only in
+  // front of round 2's / this round's backward (A/B).  One workgroup per 256 samples (forward) and per (8 positions, chunk)
+  // (backward): 16 seeds x 4096 samples give 256 + 256.  The summation orders depend on the minibatch size only, never on the
+  // number of seeds in the launch; sd.pin_form takes the form from the minibatch size alone (a solo run then equals its batch).
+  {
+    const int pos_opt = pqn_opt(PQN_OPT_BWD_POS);
+    const bool pos_shape = L.matmul_f16 == 2 && with_reduce && nb % 256 == 0 && pos_shape_ok(nb) && pqn_cnn_pos_forward_supported(C, L.a);
+    const bool pos_full = pos_shape && (pos_opt == 2 || (pos_opt == 1 && (sd.pin_form ? nb >= 2048 : (nb / 256) * sd.nseeds >= 160)));
+    if (pos_full) {
+      const int nch = pos_chunks(nb);
+      const pos_ws_t PW = pos_ws_layout(nb, C, L.a);
+      pqn_note_kernel_form(0, PQN_FORM_POS);
+      if (part != 2) {
+        const bool timed = g_prof.on && g_prof.mode == 1 && g_prof.n < PQN_PROF_MAX;
+        if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
+        int rc = pqn_cnn_pos_gather(L, nb, idx, bits, action, target, h1T, PW, sd, sd.nseeds, st);
+        if (rc == PQN_OK) rc = pqn_cnn_pos_forward(L, nb, theta, inv_b, h1T, PW, sd, sd.nseeds, st);
+        if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, nch, theta, h1T, wpart, PW, sd, sd.nseeds, 1, st);
+        if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
+        if (rc != PQN_OK) return rc;
+      }
+      if (part != 1)
+        hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, nb / 256, nch, rec,
+                           h1T + PW.recs, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd, h1T + PW.gpos, 8 * nch);
+      return pqn_check_launch("pqn_qnet_cnn_grad");
+    }
+  }
   if (!g_t1_stamps && getenv("PQN_T1_STAMPS")) {
     if (hipMalloc(&g_t1_stamps, 64 * sizeof(unsigned long long)) != hipSuccess) g_t1_stamps = nullptr;
   }
@@ -4412,7 +4079,10 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // planes; one workgroup per (seed, 4 positions) then needs >= 16 seeds to fill the chip.  PQN_BWD_POS: 0 off, 1 auto,
   // 2 at any size (tests)
   const int pos_env = pqn_opt(PQN_OPT_BWD_POS);
-  const bool use_pos = use_pair && pos_env && nb >= 2 * QW_SLAB && (16 * sd.nseeds >= 256 || pos_env == 2);
+  const bool use_pos = use_pair && pos_env >= 3 && nb >= 2 * QW_SLAB && (pos_env == 3 || pos_shape_ok(nb));
+  const bool pos_old = use_pos && pos_env == 3;      // round 2's producer / consumer kernel (kept for the A/B of round 5)
+  const int pos_nch = pos_chunks(nb);                // sample chunks (= partial dW1 slabs) of the round-5 backward
+  const pos_ws_t posW = pos_ws_layout(nb, C, L.a);   // its carve-up of the h1^T region (dz planes first, as the forward kernel writes them)
   float *gposw = wpart + (size_t)QN_H1 * QN_HID;   // conv-block partials of the 16 position groups (second slab's place)
   if (use_pos) {
     static bool fwd_attr = false;
@@ -4460,8 +4130,14 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       }
       hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), pair_bytes, st, nb, idx, bits,
                          action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
-      hipLaunchKernelGGL(qnet_cnn_bwd_pos_kernel<C>, dim3(16, gs), dim3(QN_THREADS), bwd_pos_lds_bytes<C>(), st, nb, idx, bits, theta, L,
-                         reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg, g_t2_stamps);
+      if (pos_old)
+        hipLaunchKernelGGL(qnet_cnn_bwd_pos_kernel<C>, dim3(16, gs), dim3(QN_THREADS), bwd_pos_lds_bytes<C>(), st, nb, idx, bits, theta, L,
+                           reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg, g_t2_stamps);
+      else {
+        int rc = pqn_cnn_pos_gather(L, nb, idx, bits, action, target, h1T, posW, sg, gs, st);
+        if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, pos_nch, theta, h1T, wpart, posW, sg, gs, 0, st);
+        if (rc != PQN_OK) return rc;
+      }
       if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
       continue;   // no T2: dW1 was accumulated in registers
     } else if (use_pair && use_pd2) {
@@ -4508,8 +4184,8 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   if (with_reduce && part != 1)
     hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles,
-                       (use_pos || t2_acc) ? 1 : nks, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd,
-                       use_pos ? gposw : nullptr, use_pos ? 16 : 0);
+                       use_pos ? (pos_old ? 1 : pos_nch) : (t2_acc ? 1 : nks), rec, gpart, wpart, grad, count, scratch, loss_out, qv_out,
+                       inv_b, sd, use_pos ? (pos_old ? gposw : h1T + posW.gpos) : nullptr, use_pos ? (pos_old ? 16 : 8 * pos_nch) : 0);
   return pqn_check_launch("pqn_qnet_cnn_grad");
 }
 

@@ -1,0 +1,58 @@
+// pqn_qnet_pos.h -- interface between pqn_qnet.hip (kernel selection, workspace, reduction) and pqn_qnet_pos.hip (the
+// position-parallel training kernels).  Internal to libpqn_hip.so.
+#pragma once
+#include "pqn_common.h"
+
+// words of the bit-transposed observation table of one 32-sample super-tile: 100 C bit words + the zero word the padding
+// rows of the conv weight gradient read, rounded up to whole 1-KB LDS-DMA instructions
+__host__ __device__ constexpr int pos_t32_words(int c) { return (100 * c + 1 + 255) / 256 * 256; }
+
+// carve-up of the h1^T region of a seed's training workspace in the position-parallel form (float offsets from the region's
+// start; every offset a multiple of 4 floats = 16 B).  dz comes first: the DMA plan addresses everything relative to it.
+struct pos_ws_t {
+  long long dz;        // dzA [3][nb][128] bf16 | dzB [nb / 32][8][3][64][8] bf16 (dz_planes_a / dz_planes_b)
+  long long mb_bits;   // [nb][OW] packed observation rows in minibatch order
+  long long t32;       // [nb / 32][pos_t32_words] bit-transposed rows
+  long long stats;     // [nb / 32][64 positions][32 samples][2]: LayerNorm_0 mean, 1/std (forward kernel)
+  long long gpos;      // [8 nch][9C*16 + 48] conv-block records of the backward workgroups
+  long long act;       // [nb] i32 (minibatch order)
+  long long tgt;       // [nb] f32
+  long long recs;      // [nb / 256][record] head-block records of the forward workgroups
+  long long end;       // floats used
+};
+inline pos_ws_t pos_ws_layout(int nb, int c, int a) {
+  auto al = [](long long x) { return (x + 3) & ~3ll; };
+  const int ow = ((((100 * c + 31) / 32) + 3) / 4) * 4;
+  const long long rec = 9 * c * 16 + 48 + 384 + 128 * a + a + 2;
+  pos_ws_t w;
+  w.dz = 0;
+  w.mb_bits = al((long long)nb * 384);
+  w.t32 = al(w.mb_bits + (long long)nb * ow);
+  w.stats = al(w.t32 + (long long)(nb / 32) * pos_t32_words(c));
+  w.gpos = al(w.stats + (long long)nb * 128);
+  w.act = al(w.gpos + 16ll * (9 * c * 16 + 48));
+  w.tgt = al(w.act + nb);
+  w.recs = al(w.tgt + nb);
+  w.end = al(w.recs + (long long)((nb + 255) / 256) * rec);
+  return w;
+}
+
+// number of sample chunks of the backward (one partial dW1 slab each): a function of the minibatch size alone, so that a
+// seed's summation order does not depend on how many seeds share the launch
+inline int pos_chunks(int nb) { return nb >= 1024 ? 2 : 1; }
+inline bool pos_shape_ok(int nb) { return nb % (64 * pos_chunks(nb)) == 0; }
+
+// The three launches of the position-parallel form.  wsx = seed 0's h1^T region (carved up by pos_ws_layout), w1out = seed 0's
+// split-K slab region (nch slabs are written); sg.seed_base / nseeds select the seeds of this launch.
+//   gather    minibatch rows, actions, targets in minibatch order + the bit-transpose per super-tile
+//   forward   conv .. loss and the head's backward: dz planes, LayerNorm_0 statistics, one head record per 256 samples
+//             (nb % 256 == 0; (channels, actions) as pqn_cnn_pos_forward_supported says)
+//   backward  dgrad, LayerNorm_0 / conv backward, dW1 rows in registers; stats = 1: LayerNorm_0 statistics of `forward`,
+//             0: recomputed (dz planes then come from qnet_cnn_train_pair_kernel<C, true>)
+int pqn_cnn_pos_gather(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits, const int32_t *action,
+                       const float *target, float *wsx, const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st);
+bool pqn_cnn_pos_forward_supported(int c, int a);
+int pqn_cnn_pos_forward(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
+                        const pqn_seeds_t &sg, int nseeds, hipStream_t st);
+int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out, const pos_ws_t &W,
+                         const pqn_seeds_t &sg, int nseeds, int stats, hipStream_t st);

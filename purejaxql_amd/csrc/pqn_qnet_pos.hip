@@ -1,0 +1,920 @@
+// pqn_qnet_pos.hip -- the position-parallel form of the MinAtar CNN training step (bf16x3 operand mode, gfx950).
+//
+// One optimizer step of _learn_phase (purejaxql/pqn_minatar.py:266-297) on a seed's minibatch of nb samples.  Everything
+// below fc1 is local to a conv position: h1[m][16 pos + ch] depends only on sample m's 3x3 window at pos, LayerNorm_0
+// (pqn_minatar.py:31-36, flax LayerNorm over the 16 channels) is per point, and the dgrad columns / dW1 rows of a position
+// need only that position's 16 rows of the fc1 kernel W1.  The backward therefore gives every WAVE one conv position and
+// keeps that position's slice of W1 (48 VGPRs of bf16 planes) and of dW1 (32 accumulator VGPRs) resident while the
+// workgroup walks over the samples: no weight-plane stream, no h1 hand-over, no separate fc1 weight-gradient GEMM.
+//
+//   pos_gather_kernel    (super-tile of 32 samples, seed): the minibatch's packed observation rows in minibatch order +
+//                        their bit-transpose T32[bit] = one word over the 32 samples (the conv weight gradient's operand)
+//   cnn_pos_bwd_kernel   (8 positions, chunk of samples, seed), wave = position: per super-tile the conv + LayerNorm_0 are
+//                        recomputed in MFMA accumulator layout (lane = channel, 4 samples per lane and tile), then dgrad
+//                        against the resident planes, relu mask, LayerNorm_0 backward, and -- with h1 / dx split ONCE, in
+//                        registers -- the position's rows of dW1 and its conv weight-gradient tile.  dz (both operand
+//                        orders), the packed rows and T32 arrive per super-tile through LDS-DMA (global_load_lds) into a
+//                        two-slot ring: one barrier per super-tile, no staging registers, no ds_write.
+//
+// The forward half (conv, fc1, head, loss, dz planes) is qnet_cnn_train_pair_kernel<C, true> of pqn_qnet.hip.
+#include <stdlib.h>
+
+#include "pqn_qnet_x3.h"
+#include "pqn_qnet_pos.h"
+
+#define POS_THREADS 512
+#define POS_ST 32              // samples per super-tile (two 16-sample MFMA tiles)
+
+template <int C>
+struct PosCfg {
+  using Cfg = CnnCfg<C>;
+  static constexpr int OW = Cfg::OW;                 // packed observation words per sample (multiple of 4)
+  static constexpr int ROWCH = OW / 4;               // 16-B chunks per packed row
+  static constexpr int ROWSTRIDE = ROWCH + 1;        // LDS row stride in chunks (one pad chunk: spreads the rows over the banks)
+  static constexpr int NBITS = 100 * C;              // observation bits per sample
+  static constexpr int TW = pos_t32_words(C);        // words of T32 per super-tile (zero word at NBITS, padded to 1 KB)
+  static constexpr int KW = 9 * C, RB = 3 * C, NRB = (KW + 15) / 16;
+  static constexpr int CONVBLK = KW * 16 + 48;
+  // ring slot, in 16-B chunks: dzA | dzB | rows | T32 | LN0 statistics
+  static constexpr int N_DZ = 1536;                  // 3 planes x 32 samples x 16 quads
+  static constexpr int N_ROWS = (POS_ST * ROWSTRIDE + 63) / 64 * 64;
+  static constexpr int N_T32 = TW / 4;
+  static constexpr int N_STAT = 128;                 // 8 positions x 32 samples x {mean, rstd}
+  static constexpr int O_DZB = N_DZ, O_ROWS = 2 * N_DZ, O_T32 = O_ROWS + N_ROWS, O_STAT = O_T32 + N_T32;
+  static constexpr int SLOT = O_STAT + N_STAT;       // chunks per slot (a multiple of 64: whole DMA instructions)
+  static constexpr int NI = SLOT / 64;               // 1-KB DMA instructions per slot
+  static constexpr int NTAIL = NI - 48;              // instructions behind the 48 of the dz planes
+  static_assert(NTAIL >= 1 && NTAIL <= 16, "at most two tail instructions per wave");
+  static constexpr int NCS = (KW + 31) / 32;          // K steps of the conv product
+  static constexpr size_t lds_bytes() { return (size_t)2 * SLOT * 16 + sizeof(float) * ((CONVBLK + 3) & ~3) + (size_t)NCS * 3 * 64 * 16; }
+};
+
+// sorted shuffle key -> row of the stacked [T][S * N] rollout record (see pqn_seeds_t)
+PQN_D int64_t pos_row_of(int64_t key, const pqn_seeds_t &sd, int seed) {
+  const uint32_t j = (uint32_t)(key & sd.idx_mask);
+  if (sd.n_env_total == sd.n_env) return (int64_t)j;
+  const uint32_t t = j / (uint32_t)sd.n_env;
+  return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
+}
+
+// ---------------------------------------------------------------------------
+// minibatch gather: rows in minibatch order + the bit-transpose per super-tile
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void pos_gather_kernel(int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits,
+                                                         const int32_t *__restrict__ action, const float *__restrict__ target,
+                                                         float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd) {
+  using P = PosCfg<C>;
+  __shared__ uint32_t rows[POS_ST * P::OW];
+  const int seed = blockIdx.y + sd.seed_base;
+  idx += seed * sd.idx_stride;
+  wsx += seed * sd.ws_stride;
+  uint32_t *mb_bits = reinterpret_cast<uint32_t *>(wsx + W.mb_bits);
+  uint32_t *t32 = reinterpret_cast<uint32_t *>(wsx + W.t32);
+  const int st = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < POS_ST * P::OW; i += 256) {
+    const int smp = i / P::OW, w = i - smp * P::OW;
+    const int64_t src = pos_row_of(idx[st * POS_ST + smp], sd, seed);
+    const uint32_t v = obs_bits[(size_t)src * P::OW + w];
+    rows[i] = v;
+    mb_bits[(size_t)st * POS_ST * P::OW + i] = v;
+  }
+  if (tid < POS_ST) {
+    const int64_t src = pos_row_of(idx[st * POS_ST + tid], sd, seed);
+    reinterpret_cast<int32_t *>(wsx + W.act)[st * POS_ST + tid] = action[src];
+    (wsx + W.tgt)[st * POS_ST + tid] = target[src];
+  }
+  __syncthreads();
+  for (int b = tid; b < P::TW; b += 256) {
+    uint32_t word = 0u;
+    if (b < P::NBITS) {
+#pragma unroll
+      for (int s = 0; s < POS_ST; ++s) word |= ((rows[s * P::OW + (b >> 5)] >> (b & 31)) & 1u) << s;
+    }
+    t32[(size_t)st * P::TW + b] = word;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LDS-DMA: one wave-instruction (global_load_lds_dwordx4) moves 64 x 16 B from per-lane global addresses (uniform 64-bit
+// base + per-lane 32-bit byte offset) to LDS at a wave-uniform byte address + 16 lane.  Issued as inline asm: through the
+// builtin, hipcc orders every later LDS read behind `s_waitcnt vmcnt(0)` (it cannot tell which LDS bytes the DMA writes),
+// which serialises the ring -- the transfer of super-tile j + 1 would have to land before super-tile j is even read.
+// The asm form is invisible to the compiler's wait-count bookkeeping, so the kernel drains it itself (pos_dma_wait) in
+// front of the barrier that publishes the slot.  M0 (the LDS destination) is saved and restored inside the statement.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char lds_char_t;
+PQN_D uint32_t pos_lds_addr(const void *p) { return (uint32_t)(uintptr_t)(lds_char_t *)p; }
+PQN_D void pos_dma16(uint32_t voff, const void *sbase, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+PQN_D void pos_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#ifdef POS_STAMPS   // variant builds only: the stamp stores are VMEM operations the compiler counts, and its vmcnt waits would drain the DMA
+#define POSB_STAMP(k) do { if (stamps && j == 4 && lane == 0 && blockIdx.x == 0 && wave == 0) stamps[(k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define POSB_STAMP(k) do { } while (0)
+#endif
+
+// STATS: 0 = LayerNorm_0 statistics recomputed here (DPP row sums over the 16 channel lanes); 1 = read from the forward
+// kernel's record (mean, 1/std per (sample, position)) -- then xhat and the relu mask are the forward's own, bit for bit
+template <int C, int STATS>
+__global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nch, const float *__restrict__ theta, pqn_cnn_layout_t L,
+                                                                  float *__restrict__ wsx, float *__restrict__ w1out,
+                                                                  pos_ws_t W, pqn_seeds_t sd, unsigned long long *__restrict__ stamps) {
+  using P = PosCfg<C>;
+  using Cfg = CnnCfg<C>;
+  constexpr int NRB = P::NRB, RB = P::RB, CONVBLK = P::CONVBLK;
+  extern __shared__ __attribute__((aligned(16))) char pos_smem[];
+  u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);
+  float *s_wc = reinterpret_cast<float *>(ring + 2 * P::SLOT);
+  u32x4 *s_cvw = reinterpret_cast<u32x4 *>(s_wc + ((CONVBLK + 3) & ~3));   // conv kernel as bf16-plane B fragments [K step][plane][lane]: one copy for all waves
+  // (seed, position group, chunk) of this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id; the 8 nch
+  // workgroups of a seed all read that seed's dz planes, so they are placed on ONE XCD's L2 when the seeds divide over the XCDs.
+  const int wps = 8 * nch, nsl = gridDim.x / wps;
+  int seed_l, within;
+  {
+    const int lin = blockIdx.x;
+    if ((nsl & 7) == 0) {
+      const int xcd = lin & 7, k = lin >> 3;
+      seed_l = xcd * (nsl >> 3) + k / wps;
+      within = k % wps;
+    } else {
+      seed_l = lin / wps;
+      within = lin % wps;
+    }
+  }
+  const int pg = within & 7, chunk = within >> 3;
+  const int seed = seed_l + sd.seed_base;
+  theta += seed * sd.theta_stride;
+  wsx += seed * sd.ws_stride;
+  w1out += seed * sd.ws_stride + (size_t)chunk * QN_H1 * QN_HID;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = lane & 15, kq = lane >> 4;
+  const int nst = nb / (POS_ST * nch), st0 = chunk * nst;   // super-tiles of this chunk, first super-tile
+  const int p = 8 * pg + wave, py = p >> 3, px = p & 7;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- DMA plan of this wave: instruction i = wave + 8 k fills chunks [64 i, 64 i + 64) of the slot ----
+  const u32x4 *g_dza = reinterpret_cast<const u32x4 *>(wsx + W.dz);                      // [3][nb][16 quads]
+  const u32x4 *g_dzb = g_dza + (size_t)3 * nb * 16;                                      // [super-tile][8 cb][3][64]
+  const u32x4 *g_rows = reinterpret_cast<const u32x4 *>(wsx + W.mb_bits);                // [nb][ROWCH]
+  const u32x4 *g_t32 = reinterpret_cast<const u32x4 *>(wsx + W.t32);                     // [super-tile][N_T32]
+  const u32x4 *g_stat = reinterpret_cast<const u32x4 *>(wsx + W.stats);                  // [super-tile][64 pos][16]
+  const size_t pa = (size_t)nb * 16;                                                     // dzA plane stride in chunks
+  // per-lane byte offsets; plane / instruction index and the super-tile advance the UNIFORM base.  dzA: instruction
+  // wave + 8 k covers plane k, samples 4 wave .. 4 wave + 3: chunk (sample, slot) holds quad = slot ^ (sample & 15)
+  uint32_t offT[2];
+  int strT[2], tailq[2];         // wave-uniform: chunks per super-tile of a tail instruction's source, its slot chunk (-1: none)
+  const uint32_t offA = (uint32_t)(((4 * wave + (lane >> 4)) * 16 + ((lane & 15) ^ ((4 * wave + (lane >> 4)) & 15))) * 16);
+  const uint32_t offB = (uint32_t)(lane * 16);            // dzB: lane-linear
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int ti = wave + 8 * k;                          // tail instruction index (wave-uniform)
+    const int q0 = (48 + ti) * 64, q = q0 + lane;         // the instruction's 64 chunks are all of one kind
+    tailq[k] = ti < P::NTAIL ? q0 : -1;
+    uint32_t off = 0u;
+    int str = 0;
+    if (ti < P::NTAIL) {
+      if (q0 < P::O_T32) {                                // packed rows, padded row stride
+        const int r = q - P::O_ROWS, row = r / P::ROWSTRIDE, cc = r - row * P::ROWSTRIDE;
+        const bool real = row < POS_ST && cc < P::ROWCH;
+        off = (uint32_t)((const char *)(g_rows + (real ? row * P::ROWCH + cc : 0)) - (const char *)g_dza);
+        str = POS_ST * P::ROWCH;
+      } else if (q0 < P::O_STAT) {
+        off = (uint32_t)((const char *)(g_t32 + (q - P::O_T32)) - (const char *)g_dza);
+        str = P::N_T32;
+      } else {
+        off = (uint32_t)((const char *)(g_stat + (size_t)pg * 128 + (q - P::O_STAT)) - (const char *)g_dza);
+        str = 1024;
+      }
+    }
+    offT[k] = off;
+    strT[k] = str;
+  }
+  const uint32_t ring_lds = pos_lds_addr(ring);
+  auto dma_slot = [&](int j) {   // super-tile st0 + min(j, nst - 1) -> slot j & 1
+    const int g = st0 + min(j, nst - 1);
+    const uint32_t slot = ring_lds + (uint32_t)((j & 1) * P::SLOT * 16);
+    const u32x4 *bA = g_dza + (size_t)g * (POS_ST * 16), *bB = g_dzb + (size_t)g * 1536;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tailq[k] >= 0) pos_dma16(offT[k], g_dza + (size_t)g * strT[k], slot + (uint32_t)(tailq[k] * 16));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pos_dma16(offA, bA + (size_t)k * pa, slot + (uint32_t)((wave + 8 * k) * 1024));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pos_dma16(offB, bB + (wave + 8 * k) * 64, slot + (uint32_t)((P::O_DZB + (wave + 8 * k) * 64) * 16));
+  };
+  dma_slot(0);
+
+  // ---- per-wave constants ----
+  for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
+  u32x4 wfr[4][3];               // the position's 16 rows of W1 as dgrad-order bf16 planes: B fragments of dh1 = dz W1p^T
+  {
+    const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
+#pragma unroll
+    for (int sK = 0; sK < 4; ++sK)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wfr[sK][pl] = wd[(size_t)pl * (X3_PLANE / 8) + ((p * 4 + sK) * 64 + lane)];
+  }
+  int bw[3], bs[3];              // window row ky of this position: word and bit offset inside a packed row (wave-uniform)
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int bp = ((py + ky) * 10 + px) * C;
+    bw[ky] = bp >> 5;
+    bs[ky] = bp & 31;
+  }
+  int tb[NRB];                   // conv weight gradient: T32 word of this lane's row k = 16 rb + ch (padding rows: the zero word)
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    const int k = 16 * rb + ch;
+    tb[rb] = k < P::KW ? ((py + k / RB) * 10 + px) * C + (k % RB) : P::NBITS;
+  }
+  pos_dma_wait();
+  __syncthreads();               // s_wc complete, slot 0 landed
+  if (wave == 0) {               // the conv kernel's planes are the same for every position: split once, shared through LDS
+    ConvX3<C> cv;
+    cv.init(s_wc, lane);
+#pragma unroll
+    for (int sx = 0; sx < P::NCS; ++sx) {
+      s_cvw[(sx * 3 + 0) * 64 + lane] = cv.w[sx].h;
+      s_cvw[(sx * 3 + 1) * 64 + lane] = cv.w[sx].m;
+      s_cvw[(sx * 3 + 2) * 64 + lane] = cv.w[sx].l;
+    }
+  }
+  __syncthreads();
+  const float bias = s_wc[Cfg::KW * 16 + ch], g0 = s_wc[Cfg::KW * 16 + 16 + ch], be0 = s_wc[Cfg::KW * 16 + 32 + ch];
+  f32x4 dw[8], cw[NRB];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) dw[c] = zero4;
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) cw[rb] = zero4;
+  float gbi = 0.f, gsc = 0.f, gbc = 0.f;
+  // the plane fragments must have ARRIVED before the loop: a compiler-counted load still pending at the loop's first use
+  // would put `s_waitcnt vmcnt(N)` inside the loop, and with the (uncounted) DMA in flight that wait drains the DMA
+#pragma unroll
+  for (int sK = 0; sK < 4; ++sK)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(wfr[sK][pl]));
+
+#pragma unroll 1
+  for (int j = 0; j < nst; ++j) {
+    dma_slot(j + 1);             // the other slot was last read an iteration ago, before that iteration's barrier
+    POSB_STAMP(0);
+    const u32x4 *slot = ring + (j & 1) * P::SLOT;
+    const u32x4 *ldA = slot, *ldB = slot + P::O_DZB + lane;
+    const uint32_t *rowsL = reinterpret_cast<const uint32_t *>(slot + P::O_ROWS);
+    const uint32_t *t32L = reinterpret_cast<const uint32_t *>(slot + P::O_T32);
+    // ---- window masks of (sample lane & 15 of each tile, this position) ----
+    uint32_t mk[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t *row = rowsL + (16 * t + ch) * (P::ROWSTRIDE * 4);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const uint32_t lo = row[bw[ky]], hi = row[bw[ky] + 1];
+        mk[t][ky] = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> bs[ky]) & ((1u << RB) - 1u);
+      }
+    }
+    // ---- conv: rows = samples, columns = channels; the two tiles interleaved ----
+    f32x4 cb_[2] = {zero4, zero4}, cs_[2] = {zero4, zero4};
+#pragma unroll
+    for (int sx = 0; sx < ConvX3<C>::NS; ++sx) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fa[t] = ConvX3<C>::expand8(__builtin_amdgcn_ubfe(ConvX3<C>::word(mk[t], sx), 8u * kq, 8u));
+      const u32x4 wh = s_cvw[(sx * 3 + 0) * 64 + lane], wm = s_cvw[(sx * 3 + 1) * 64 + lane], wl = s_cvw[(sx * 3 + 2) * 64 + lane];
+      x3_grp2(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
+      x3_grp2(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
+      x3_grp2(cs_[0], fa[0], wm, cs_[1], fa[1], wm);
+    }
+    // dgrad operands of both tiles from LDS while the conv drains; ONE register set, each plane re-read for the next K step
+    // right behind the last MFMA group that uses it (l after the first group, m after the fifth, h after the sixth)
+    u32x4 az[2][3];
+    auto load_az = [&](int sK, int pl) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) az[t][pl] = ldA[(pl * 32 + 16 * t + ch) * 16 + ((sK * 4 + kq) ^ ch)];
+    };
+    load_az(0, 0); load_az(0, 1); load_az(0, 2);
+    POSB_STAMP(1);
+    x3_drain(cb_[0], cs_[0], cb_[1], cs_[1]);
+    float xh[2][4], rs[2][4], dxv[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 cvo = (cb_[t] + cs_[t]) * ConvX3<C>::OUT_SCALE;
+      const float v[4] = {cvo.x + bias, cvo.y + bias, cvo.z + bias, cvo.w + bias};
+      float mean[4];
+      if constexpr (STATS == 1) {
+        const f32x4 *sp = reinterpret_cast<const f32x4 *>(slot + P::O_STAT) + ((wave * POS_ST + 16 * t + 4 * kq) >> 1);
+        const f32x4 s0 = sp[0], s1 = sp[1];
+        mean[0] = s0.x; rs[t][0] = s0.y; mean[1] = s0.z; rs[t][1] = s0.w;
+        mean[2] = s1.x; rs[t][2] = s1.y; mean[3] = s1.z; rs[t][3] = s1.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
+          mean[r] = sum * (1.0f / 16.0f);
+          const float var = fmaxf(sq * (1.0f / 16.0f) - mean[r] * mean[r], 0.0f);
+          rs[t][r] = rsqrt_exact(var + QN_LN_EPS);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xh[t][r] = (v[r] - mean[r]) * rs[t][r];
+      }
+    }
+    POSB_STAMP(2);
+    // ---- dgrad: dh1[sample][feature of this position], eight independent accumulators ----
+    f32x4 gb[2] = {zero4, zero4}, gs[2] = {zero4, zero4};   // {leading, small} terms per tile: four independent chains
+#pragma unroll
+    for (int sK = 0; sK < 4; ++sK) {
+      x3_grp2(gs[0], az[0][2], wfr[sK][0], gs[1], az[1][2], wfr[sK][0]);
+      if (sK + 1 < 4) load_az(sK + 1, 2);
+      x3_grp2(gb[0], az[0][1], wfr[sK][0], gb[1], az[1][1], wfr[sK][0]);
+      x3_grp4(gs[0], az[0][0], wfr[sK][2], gs[1], az[1][0], wfr[sK][2], gb[0], az[0][0], wfr[sK][1], gb[1], az[1][0], wfr[sK][1]);
+      x3_grp2(gs[0], az[0][1], wfr[sK][1], gs[1], az[1][1], wfr[sK][1]);
+      if (sK + 1 < 4) load_az(sK + 1, 1);
+      x3_grp2(gb[0], az[0][0], wfr[sK][0], gb[1], az[1][0], wfr[sK][0]);
+      if (sK + 1 < 4) load_az(sK + 1, 0);
+    }
+    POSB_STAMP(3);
+    x3_drain(gb[0], gs[0], gb[1], gs[1]);
+    // ---- relu mask + LayerNorm_0 backward (per point = per (kq, r); sums over the 16 channel lanes) ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 dh4 = gb[t] + gs[t];
+      const float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float g = fmaf(xh[t][r], g0, be0) > 0.0f ? dh[r] : 0.0f;
+        gbi += g;
+        gsc = fmaf(g, xh[t][r], gsc);
+        const float dxh = g * g0;
+        const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[t][r]) * (1.0f / 16.0f);
+        dxv[t][r] = rs[t][r] * (dxh - s1 - xh[t][r] * s2);
+        gbc += dxv[t][r];
+      }
+    }
+    POSB_STAMP(4);
+    // h1 and dx of the 32 samples as bf16 planes, split ONCE: K slot j = sample 16 (j >> 2) + 4 kq + (j & 3), i.e. exactly
+    // this lane's eight values -- already the A fragment of dW1p = h1^T dz and the B fragment of dWc = bits^T dx
+    float h1v[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1v[t][r] = fmaxf(fmaf(xh[t][r], g0, be0), 0.0f);
+    const X3Frag fh = x3_split8(f32x4{h1v[0][0], h1v[0][1], h1v[0][2], h1v[0][3]}, f32x4{h1v[1][0], h1v[1][1], h1v[1][2], h1v[1][3]});
+    const X3Frag fd = x3_split8(f32x4{dxv[0][0], dxv[0][1], dxv[0][2], dxv[0][3]}, f32x4{dxv[1][0], dxv[1][1], dxv[1][2], dxv[1][3]});
+    // ---- dW1p[feature][o] += sum over the 32 samples of h1[sample][feature] dz[sample][o] ----
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      u32x4 bh[4], bm[4], bl[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const u32x4 *bq = ldB + ((4 * hf + c) * 3) * 64;
+        bh[c] = bq[0]; bm[c] = bq[64]; bl[c] = bq[128];
+      }
+      f32x4 *d = dw + 4 * hf;
+      x3_grp4(d[0], fh.l, bh[0], d[1], fh.l, bh[1], d[2], fh.l, bh[2], d[3], fh.l, bh[3]);
+      x3_grp4(d[0], fh.h, bl[0], d[1], fh.h, bl[1], d[2], fh.h, bl[2], d[3], fh.h, bl[3]);
+      x3_grp4(d[0], fh.m, bm[0], d[1], fh.m, bm[1], d[2], fh.m, bm[2], d[3], fh.m, bm[3]);
+      x3_grp4(d[0], fh.m, bh[0], d[1], fh.m, bh[1], d[2], fh.m, bh[2], d[3], fh.m, bh[3]);
+      x3_grp4(d[0], fh.h, bm[0], d[1], fh.h, bm[1], d[2], fh.h, bm[2], d[3], fh.h, bm[3]);
+      x3_grp4(d[0], fh.h, bh[0], d[1], fh.h, bh[1], d[2], fh.h, bh[2], d[3], fh.h, bh[3]);
+    }
+    POSB_STAMP(5);
+    // ---- conv weight gradient: dWc[k][ch] += sum over samples of bit(sample, k) dx[sample][ch]; the bits of window
+    // element k over the 32 samples are ONE word of T32: nibble kq of each half = this lane's eight K slots ----
+    u32x4 fa[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const uint32_t wv = t32L[tb[rb]];
+      const uint32_t byte = __builtin_amdgcn_ubfe(wv, 4u * kq, 4u) | (__builtin_amdgcn_ubfe(wv, 16u + 4u * kq, 4u) << 4);
+      fa[rb] = ConvX3<C>::expand8(byte);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) cw[rb] = X3_MFMA(fa[rb], fd.l, cw[rb]);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) cw[rb] = X3_MFMA(fa[rb], fd.m, cw[rb]);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) cw[rb] = X3_MFMA(fa[rb], fd.h, cw[rb]);
+    POSB_STAMP(6);
+    pos_dma_wait();              // this wave's share of the next slot has landed ...
+    __syncthreads();             // ... and after the barrier everyone's has; every wave is done reading this slot
+    POSB_STAMP(7);
+  }
+
+  // ---- epilogue: the position's rows of dW1 (kernel / fragment layout) and the conv-block record of the workgroup ----
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) x3_drain(dw[4 * hf], dw[4 * hf + 1], dw[4 * hf + 2], dw[4 * hf + 3]);
+  {
+    f32x4 *out = reinterpret_cast<f32x4 *>(w1out);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[(p * 8 + c) * 64 + lane] = dw[c];
+  }
+  float *part = reinterpret_cast<float *>(pos_smem);   // [8 waves][CONVBLK]: the ring is dead (last barrier passed)
+  static_assert((size_t)8 * CONVBLK * sizeof(float) <= (size_t)2 * P::SLOT * 16, "conv partials must fit the ring");
+  {
+    float *pr = part + wave * CONVBLK;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      x3_drain(cw[rb]);
+      const f32x4 a = cw[rb] * (0.5f / 255.0f);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * rb + 4 * kq + r;
+        if (k < Cfg::KW) pr[k * 16 + ch] = av[r];
+      }
+    }
+    gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
+    gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
+    gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
+    if (lane < 16) {
+      pr[Cfg::KW * 16 + lane] = gbc; pr[Cfg::KW * 16 + 16 + lane] = gsc; pr[Cfg::KW * 16 + 32 + lane] = gbi;
+    }
+  }
+  __syncthreads();
+  float *gpos = wsx + W.gpos + (size_t)(chunk * 8 + pg) * CONVBLK;
+  for (int e = tid; e < CONVBLK; e += POS_THREADS)
+    gpos[e] = ((part[e] + part[CONVBLK + e]) + (part[2 * CONVBLK + e] + part[3 * CONVBLK + e])) +
+              ((part[4 * CONVBLK + e] + part[5 * CONVBLK + e]) + (part[6 * CONVBLK + e] + part[7 * CONVBLK + e]));
+}
+
+// ---------------------------------------------------------------------------
+// Forward half: conv -> LayerNorm_0 -> relu -> fc1 -> LayerNorm_1 -> relu -> head -> loss, and the head's backward down to
+// dz (pqn_minatar.py:24-69, 271-285).  Workgroup = 256 samples of one seed's minibatch, wave = 32 samples (two MFMA tiles)
+// for ALL 64 conv positions.  Per K step of fc1 (= two conv positions) a wave
+//   - runs the conv TRANSPOSED (rows = channels, columns = samples), so that a lane's four conv outputs of a position are
+//     four K slots of its fc1 A fragment: LayerNorm_0 is three in-lane adds and two lane swaps per sum, the activations
+//     are split into bf16 planes ONCE, in registers, and no h1 tile exists anywhere;
+//   - multiplies them against the K step's 24 KB of W1 planes, which ONE LDS-DMA per workgroup brings in for all eight
+//     waves (two-slot ring): the plane stream per sample is 1/8 of what a 32-sample workgroup pulls through its CU;
+//   - accumulates z[32][128] in 64 VGPRs over all 32 K steps: no split-K partials, no z tile in LDS.
+// The head then works on the accumulator layout directly (lane = 8 output columns x 8 sample rows; row sums are DPP
+// butterflies over the 16 column lanes), leaves its parameter-gradient sums as ONE record per workgroup, and writes dz as
+// pre-split bf16 planes in both operand orders of the backward (dz_planes_a / dz_planes_b) plus LayerNorm_0's (mean, 1/std).
+// Inputs in minibatch order (pos_gather_kernel): packed rows, action, target.
+// ---------------------------------------------------------------------------
+// all-reduce of TWO per-lane values over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} with three lane swaps:
+// fixed order ((l&15) + (l&15)+32) + ((l&15)+16 + (l&15)+48), the same bits in all four lanes
+PQN_D void pos_quad_sum2(float &a, float &b) {
+  const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const float w = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);        // lanes < 32: a over the halves, lanes >= 32: b
+  const auto r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+  const float u = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);        // ... and over the row pairs
+  const auto r3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+  a = __uint_as_float(r3[0]);                                             // the lower half's total, everywhere
+  b = __uint_as_float(r3[1]);
+}
+PQN_D float pos_quad_sum1(float a) {
+  const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+  const float w = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);
+  const auto r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+  return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+
+template <int C>
+struct PosFwdCfg {
+  using P = PosCfg<C>;
+  static constexpr int N_W = 1536;                                  // chunks of one K step's planes: [3][8 cb][64]
+  static constexpr int ROWW = POS_ST * P::ROWSTRIDE * 4;            // words of a wave's packed rows
+  static constexpr int DZS = 132;                                   // LDS row stride of the dz transposition tile
+  static constexpr size_t ring_bytes = (size_t)2 * N_W * 16;
+  static constexpr size_t rows_bytes = (size_t)8 * ROWW * 4;
+  static constexpr size_t misc_floats(int a) { return ((P::CONVBLK + 3) & ~3) + ((384 + 128 * a + a + 3) & ~3) + 8 * 64; }
+  static constexpr size_t loop_bytes(int a) { return ring_bytes + rows_bytes + (size_t)P::NCS * 3 * 64 * 16 + sizeof(float) * misc_floats(a); }
+  static constexpr size_t tail_bytes = (size_t)8 * POS_ST * DZS * 4;   // dz tiles of the eight waves (over ring + rows)
+  static constexpr size_t lds_bytes(int a) {
+    const size_t fixed = (size_t)P::NCS * 3 * 64 * 16 + sizeof(float) * misc_floats(a);
+    const size_t front = ring_bytes + rows_bytes > tail_bytes ? ring_bytes + rows_bytes : tail_bytes;
+    return front + fixed;
+  }
+};
+
+template <int C, int NA>
+__global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
+                                                                  float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd) {
+  using P = PosCfg<C>;
+  using F = PosFwdCfg<C>;
+  using Cfg = CnnCfg<C>;
+  constexpr int RB = P::RB, CONVBLK = P::CONVBLK, NCS = P::NCS;
+  constexpr int REC = CONVBLK + 384 + 128 * NA + NA + 2;
+  extern __shared__ __attribute__((aligned(16))) char pos_smem[];
+  constexpr size_t FRONT = F::ring_bytes + F::rows_bytes > F::tail_bytes ? F::ring_bytes + F::rows_bytes : F::tail_bytes;
+  u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);                               // [2][3][8][64]
+  uint32_t *s_rows = reinterpret_cast<uint32_t *>(pos_smem + F::ring_bytes);       // [8 waves][32][ROWSTRIDE * 4]
+  u32x4 *s_cvw = reinterpret_cast<u32x4 *>(pos_smem + FRONT);                       // conv kernel planes [K step][plane][lane]
+  float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * 3 * 64);                    // conv kernel | bias | ln0 scale | ln0 bias
+  float *s_hp = s_wc + ((CONVBLK + 3) & ~3);                                        // b1 | ln1 scale | ln1 bias | w2[128][A] | b2
+  float *s_at = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                            // [8 waves][32 act (as int) | 32 tgt]
+  // XCD-aware (seed, block): the blocks of a seed stream the same 768 KB of planes -- one XCD's L2 per seed when possible
+  const int nblk = nb / 256, nsl = gridDim.x / nblk;
+  int seed_l, blk;
+  {
+    const int lin = blockIdx.x;
+    if ((nsl & 7) == 0) {
+      const int xcd = lin & 7, k = lin >> 3;
+      seed_l = xcd * (nsl >> 3) + k / nblk;
+      blk = k % nblk;
+    } else {
+      seed_l = lin / nblk;
+      blk = lin % nblk;
+    }
+  }
+  const int seed = seed_l + sd.seed_base;
+  theta += seed * sd.theta_stride;
+  wsx += seed * sd.ws_stride;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g = lane >> 4;          // conv phase: sample column, channels 4 g .. 4 g + 3; head: output column, rows 4 g ..
+  const int st = blk * 8 + wave;                     // this wave's super-tile
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const u32x4 *wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h);   // forward-order planes [3][32 steps][8 cb][64]
+  const uint32_t ring_lds = pos_lds_addr(ring);
+  const uint32_t offW = (uint32_t)(lane * 16);
+  auto dma_step = [&](int s) {                        // K step min(s, 31) -> slot s & 1; wave w moves column block w of each plane
+    const int sc = min(s, 31);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      pos_dma16(offW, wf + (size_t)pl * (X3_PLANE / 8) + (sc * 8 + wave) * 64, ring_lds + (uint32_t)(((s & 1) * F::N_W + (pl * 8 + wave) * 64) * 16));
+  };
+  dma_step(0);
+  // ---- prologue: parameters, this wave's packed rows / actions / targets ----
+  for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
+  for (int i = tid; i < 384; i += POS_THREADS) s_hp[i] = theta[L.off_b1 + i];
+  for (int i = tid; i < 128 * NA; i += POS_THREADS) s_hp[384 + i] = theta[L.off_w2 + i];
+  if (tid < NA) s_hp[384 + 128 * NA + tid] = theta[L.off_b2 + tid];
+  {
+    const u32x4 *g_rows = reinterpret_cast<const u32x4 *>(wsx + W.mb_bits) + (size_t)st * POS_ST * P::ROWCH;
+    u32x4 *rw = reinterpret_cast<u32x4 *>(s_rows + wave * F::ROWW);
+    for (int c = lane; c < POS_ST * P::ROWCH; c += 64) {
+      const int row = c / P::ROWCH, cc = c - row * P::ROWCH;
+      rw[row * P::ROWSTRIDE + cc] = g_rows[c];
+    }
+    if (lane < POS_ST) {
+      s_at[wave * 64 + lane] = __int_as_float(reinterpret_cast<const int32_t *>(wsx + W.act)[st * POS_ST + lane]);
+      s_at[wave * 64 + 32 + lane] = (wsx + W.tgt)[st * POS_ST + lane];
+    }
+  }
+  pos_dma_wait();
+  __syncthreads();
+  if (wave == 0) {
+    ConvX3<C> cv;
+    cv.init(s_wc, lane);
+#pragma unroll
+    for (int sx = 0; sx < NCS; ++sx) {
+      s_cvw[(sx * 3 + 0) * 64 + lane] = cv.w[sx].h;
+      s_cvw[(sx * 3 + 1) * 64 + lane] = cv.w[sx].m;
+      s_cvw[(sx * 3 + 2) * 64 + lane] = cv.w[sx].l;
+    }
+  }
+  __syncthreads();
+  // lane constants of the transposed conv: channels 4 g .. 4 g + 3
+  float cbias[4], cg0[4], cbe0[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    cbias[r] = s_wc[Cfg::KW * 16 + 4 * g + r];
+    cg0[r] = s_wc[Cfg::KW * 16 + 16 + 4 * g + r];
+    cbe0[r] = s_wc[Cfg::KW * 16 + 32 + 4 * g + r];
+  }
+  const uint32_t *rowsW = s_rows + wave * F::ROWW;
+  float *g_stat = wsx + W.stats + (size_t)st * (64 * POS_ST * 2);
+  f32x4 zacc[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) zacc[t][c] = zero4;
+
+#pragma unroll 1
+  for (int s = 0; s < 32; ++s) {
+    dma_step(s + 1);
+    const u32x4 *slot = ring + (s & 1) * F::N_W + lane;
+    const int py = s >> 2, pxb = 2 * (s & 3);          // positions p0 = 8 py + pxb, p1 = p0 + 1 (same window rows, one column apart)
+    // ---- window masks of sample (16 t + lane & 15) at both positions ----
+    uint32_t mk[2][2][3];                               // [position][tile][window row]
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int bp = ((py + ky) * 10 + pxb) * C, bwd = bp >> 5, bsh = bp & 31;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t *row = rowsW + (16 * t + i16) * (P::ROWSTRIDE * 4);
+        const uint32_t lo = row[bwd], hi = row[bwd + 1];
+        const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> bsh);
+        mk[0][t][ky] = v & ((1u << RB) - 1u);
+        mk[1][t][ky] = (v >> C) & ((1u << RB) - 1u);
+      }
+    }
+    // ---- conv (transposed) + LayerNorm_0 + relu of the two positions x two tiles; y[q][t] = the lane's 4 channels ----
+    float y[2][2][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 cb_[2] = {zero4, zero4}, cs_[2] = {zero4, zero4};
+#pragma unroll
+      for (int sx = 0; sx < NCS; ++sx) {
+        u32x4 fa[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[t] = ConvX3<C>::expand8(__builtin_amdgcn_ubfe(ConvX3<C>::word(mk[q][t], sx), 8u * g, 8u));
+        const u32x4 wh = s_cvw[(sx * 3 + 0) * 64 + lane], wm = s_cvw[(sx * 3 + 1) * 64 + lane], wl = s_cvw[(sx * 3 + 2) * 64 + lane];
+        x3_grp2(cs_[0], wl, fa[0], cs_[1], wl, fa[1]);
+        x3_grp2(cb_[0], wh, fa[0], cb_[1], wh, fa[1]);
+        x3_grp2(cs_[0], wm, fa[0], cs_[1], wm, fa[1]);
+      }
+      x3_drain(cb_[0], cs_[0], cb_[1], cs_[1]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 cvo = (cb_[t] + cs_[t]) * ConvX3<C>::OUT_SCALE;
+        const float v[4] = {cvo.x + cbias[0], cvo.y + cbias[1], cvo.z + cbias[2], cvo.w + cbias[3]};
+        float sum = (v[0] + v[1]) + (v[2] + v[3]);
+        float sq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+        pos_quad_sum2(sum, sq);                          // the 16 channels of (sample, position): 4 lanes x 4
+        const float mean = sum * (1.0f / 16.0f);
+        const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
+        const float rstd = rsqrt_exact(var + QN_LN_EPS);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[q][t][r] = fmaxf(fmaf((v[r] - mean) * rstd, cg0[r], cbe0[r]), 0.0f);
+        if (g == 0) {                                    // LayerNorm_0 statistics for the backward: [position][sample][2]
+          f32x2 ms = {mean, rstd};
+          *reinterpret_cast<f32x2 *>(g_stat + ((size_t)(2 * s + q) * POS_ST + 16 * t + i16) * 2) = ms;
+        }
+      }
+    }
+    // ---- fc1: K slots 0..3 = position p0's channels 4 g .., 4..7 = p1's (x3_fwd_index) ----
+    X3Frag af[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      af[t] = x3_split8(f32x4{y[0][t][0], y[0][t][1], y[0][t][2], y[0][t][3]}, f32x4{y[1][t][0], y[1][t][1], y[1][t][2], y[1][t][3]});
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+      const u32x4 bh0 = slot[(0 * 8 + c) * 64], bm0 = slot[(1 * 8 + c) * 64], bl0 = slot[(2 * 8 + c) * 64];
+      const u32x4 bh1 = slot[(0 * 8 + c + 1) * 64], bm1 = slot[(1 * 8 + c + 1) * 64], bl1 = slot[(2 * 8 + c + 1) * 64];
+      f32x4 &z00 = zacc[0][c], &z10 = zacc[1][c], &z01 = zacc[0][c + 1], &z11 = zacc[1][c + 1];
+      x3_grp4(z00, af[0].l, bh0, z10, af[1].l, bh0, z01, af[0].l, bh1, z11, af[1].l, bh1);
+      x3_grp4(z00, af[0].h, bl0, z10, af[1].h, bl0, z01, af[0].h, bl1, z11, af[1].h, bl1);
+      x3_grp4(z00, af[0].m, bm0, z10, af[1].m, bm0, z01, af[0].m, bm1, z11, af[1].m, bm1);
+      x3_grp4(z00, af[0].m, bh0, z10, af[1].m, bh0, z01, af[0].m, bh1, z11, af[1].m, bh1);
+      x3_grp4(z00, af[0].h, bm0, z10, af[1].h, bm0, z01, af[0].h, bm1, z11, af[1].h, bm1);
+      x3_grp4(z00, af[0].h, bh0, z10, af[1].h, bh0, z01, af[0].h, bh1, z11, af[1].h, bh1);
+    }
+    pos_dma_wait();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; c += 4) x3_drain(zacc[t][c], zacc[t][c + 1], zacc[t][c + 2], zacc[t][c + 3]);
+
+  // ================= head, on the accumulator layout: lane = columns o = 16 c + i16, rows = samples 16 t + 4 g + r =================
+  float *dzt = reinterpret_cast<float *>(pos_smem) + (size_t)wave * POS_ST * F::DZS;   // this wave's dz tile (ring / rows are dead)
+  float hb1[8], hs1[8], hbe1[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    hb1[c] = s_hp[16 * c + i16];
+    hs1[c] = s_hp[128 + 16 * c + i16];
+    hbe1[c] = s_hp[256 + 16 * c + i16];
+  }
+  float a_b1[8], a_sc[8], a_bi[8], a_w2[8][NA], a_b2[NA], a_loss = 0.f, a_cq = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    a_b1[c] = 0.f; a_sc[c] = 0.f; a_bi[c] = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) a_w2[c][a] = 0.f;
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) a_b2[a] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float zz[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      zz[c][0] = zacc[t][c].x + hb1[c]; zz[c][1] = zacc[t][c].y + hb1[c]; zz[c][2] = zacc[t][c].z + hb1[c]; zz[c][3] = zacc[t][c].w + hb1[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __builtin_amdgcn_sched_barrier(0);                 // one row at a time: interleaved rows multiply the live registers (spills)
+      const int smp = 16 * t + 4 * g + r;
+      float sum = 0.f, sq = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { sum += zz[c][r]; sq = fmaf(zz[c][r], zz[c][r], sq); }
+      sum = group16_sum(sum);
+      sq = group16_sum(sq);
+      const float mean = sum * (1.0f / QN_HID);
+      const float var = fmaxf(sq * (1.0f / QN_HID) - mean * mean, 0.0f);
+      const float rstd = rsqrt_exact(var + QN_LN_EPS);
+      float xh[8], h2[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        xh[c] = (zz[c][r] - mean) * rstd;
+        h2[c] = fmaxf(fmaf(xh[c], hs1[c], hbe1[c]), 0.0f);
+      }
+      float qv[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) part = fmaf(h2[c], s_hp[384 + (16 * c + i16) * NA + a], part);
+        qv[a] = group16_sum(part) + s_hp[384 + 128 * NA + a];
+      }
+      const int act = __float_as_int(s_at[wave * 64 + smp]);
+      const float tgt = s_at[wave * 64 + 32 + smp];
+      float chosen = qv[0];
+#pragma unroll
+      for (int a = 1; a < NA; ++a)
+        if (a == act) chosen = qv[a];
+      const float diff = chosen - tgt;
+      const float gm = diff * inv_b;                     // d loss / d q_a, loss = 0.5 * mean(diff^2)  (pqn_minatar.py:285)
+      a_loss = fmaf(0.5f * diff, diff, a_loss);
+      a_cq += chosen;
+      float dxh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float w2a = s_hp[384 + (16 * c + i16) * NA];
+#pragma unroll
+        for (int a = 1; a < NA; ++a)
+          if (a == act) w2a = s_hp[384 + (16 * c + i16) * NA + a];
+        const float dy = h2[c] > 0.0f ? gm * w2a : 0.0f;
+        a_sc[c] = fmaf(dy, xh[c], a_sc[c]);
+        a_bi[c] += dy;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) a_w2[c][a] = fmaf(h2[c], a == act ? gm : 0.0f, a_w2[c][a]);
+        dxh[c] = dy * hs1[c];
+        s1 += dxh[c];
+        s2 = fmaf(dxh[c], xh[c], s2);
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a) a_b2[a] += (a == act ? gm : 0.0f);
+      s1 = group16_sum(s1) * (1.0f / QN_HID);
+      s2 = group16_sum(s2) * (1.0f / QN_HID);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float dz = rstd * (dxh[c] - s1 - xh[c] * s2);
+        a_b1[c] += dz;
+        zz[c][r] = dz;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float *dp = dzt + (16 * t + 4 * g) * F::DZS + 16 * c + i16;
+      dp[0] = zz[c][0]; dp[F::DZS] = zz[c][1]; dp[2 * F::DZS] = zz[c][2]; dp[3 * F::DZS] = zz[c][3];
+    }
+  }
+  // ---- dz as bf16 planes: dzB straight from the accumulator layout (K slots = samples), dzA through the wave's LDS tile ----
+  {
+    u32x4 *g_dza = reinterpret_cast<u32x4 *>(wsx + W.dz);
+    u32x4 *g_dzb = g_dza + (size_t)3 * nb * 16 + (size_t)st * 1536;
+    const size_t pa = (size_t)nb * 16;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float *d0 = dzt + (4 * g) * F::DZS + 16 * c + i16, *d1 = d0 + 16 * F::DZS;   // this lane's own eight values again
+      const X3Frag f = x3_split8(f32x4{d0[0], d0[F::DZS], d0[2 * F::DZS], d0[3 * F::DZS]}, f32x4{d1[0], d1[F::DZS], d1[2 * F::DZS], d1[3 * F::DZS]});
+      g_dzb[(c * 3 + 0) * 64 + lane] = f.h;
+      g_dzb[(c * 3 + 1) * 64 + lane] = f.m;
+      g_dzb[(c * 3 + 2) * 64 + lane] = f.l;
+    }
+    // (the tile was written by this wave only: no barrier, the compiler orders the LDS reads behind the writes)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int sK = 0; sK < 4; ++sK) {
+        const float *zr = dzt + (16 * t + i16) * F::DZS + 32 * sK + 4 * g;
+        const X3Frag f = x3_split8(*reinterpret_cast<const f32x4 *>(zr), *reinterpret_cast<const f32x4 *>(zr + 16));
+        const size_t e = ((size_t)st * POS_ST + 16 * t + i16) * 16 + sK * 4 + g;
+        g_dza[e] = f.h;
+        g_dza[pa + e] = f.m;
+        g_dza[2 * pa + e] = f.l;
+      }
+  }
+  // ---- the workgroup's record of head-parameter gradient sums: rows of the lane -> the 4 row groups -> the 8 waves ----
+  __syncthreads();                                       // every wave is done with its dz tile: the front of the LDS becomes the record scratch
+  float *recw = reinterpret_cast<float *>(pos_smem) + (size_t)wave * REC;
+  static_assert((size_t)8 * REC * sizeof(float) <= FRONT, "records must fit the front region");
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    pos_quad_sum2(a_b1[c], a_sc[c]);
+    a_bi[c] = pos_quad_sum1(a_bi[c]);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) a_w2[c][a] = pos_quad_sum1(a_w2[c][a]);
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) a_b2[a] = pos_quad_sum1(a_b2[a]);
+  pos_quad_sum2(a_loss, a_cq);
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int o = 16 * c + lane;
+      recw[CONVBLK + o] = a_b1[c];
+      recw[CONVBLK + 128 + o] = a_sc[c];
+      recw[CONVBLK + 256 + o] = a_bi[c];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) recw[CONVBLK + 384 + o * NA + a] = a_w2[c][a];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a) recw[CONVBLK + 384 + 128 * NA + a] = a_b2[a];
+      recw[REC - 2] = a_loss;
+      recw[REC - 1] = a_cq;
+    }
+  }
+  __syncthreads();
+  float *rec = wsx + W.recs + (size_t)blk * REC;
+  const float *r0 = reinterpret_cast<const float *>(pos_smem);
+  for (int e = tid; e < REC; e += POS_THREADS) {
+    float v = 0.0f;
+    if (e >= CONVBLK)
+      v = ((r0[e] + r0[REC + e]) + (r0[2 * REC + e] + r0[3 * REC + e])) + ((r0[4 * REC + e] + r0[5 * REC + e]) + (r0[6 * REC + e] + r0[7 * REC + e]));
+    rec[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static unsigned long long *g_pos_stamps = nullptr;   // profiling only (PQN_T1_STAMPS=1)
+extern "C" int pqn_debug_pos_stamps(unsigned long long *out /* host, 32 entries */) {
+  if (!g_pos_stamps) return PQN_E_INVALID;
+  if (hipMemcpy(out, g_pos_stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return PQN_E_HIP;
+  return PQN_OK;
+}
+
+template <int C, int NA>
+static int pos_forward_launch(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
+                              const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
+  using F = PosFwdCfg<C>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_fwd_kernel<C, NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)F::lds_bytes(NA));
+    attr = true;
+  }
+  hipLaunchKernelGGL((cnn_pos_fwd_kernel<C, NA>), dim3((nb / 256) * nseeds), dim3(POS_THREADS), F::lds_bytes(NA), st, nb, theta, L, inv_b,
+                     wsx, W, sg);
+  return pqn_check_launch("pqn_cnn_pos_forward");
+}
+
+// the (channels, actions) pairs of the MinAtar games gymnax implements
+bool pqn_cnn_pos_forward_supported(int c, int a) { return (c == 4 && (a == 3 || a == 5)) || (c == 6 && a == 4) || (c == 7 && a == 3); }
+
+int pqn_cnn_pos_forward(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
+                        const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
+  if (L.c == 4 && L.a == 3) return pos_forward_launch<4, 3>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+  if (L.c == 4 && L.a == 5) return pos_forward_launch<4, 5>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+  if (L.c == 6 && L.a == 4) return pos_forward_launch<6, 4>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+  if (L.c == 7 && L.a == 3) return pos_forward_launch<7, 3>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+  pqn_set_error("pqn_cnn_pos_forward: unsupported (channels, actions) = (%d, %d)", L.c, L.a);
+  return PQN_E_UNSUPPORTED;
+}
+
+template <int C>
+static int pos_gather_launch(int nb, const int64_t *idx, const uint32_t *bits, const int32_t *action, const float *target, float *wsx,
+                             const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
+  hipLaunchKernelGGL(pos_gather_kernel<C>, dim3(nb / POS_ST, nseeds), dim3(256), 0, st, nb, idx, bits, action, target, wsx, W, sg);
+  return pqn_check_launch("pqn_cnn_pos_gather");
+}
+int pqn_cnn_pos_gather(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits, const int32_t *action,
+                       const float *target, float *wsx, const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
+  switch (L.c) {
+    case 4: return pos_gather_launch<4>(nb, idx, bits, action, target, wsx, W, sg, nseeds, st);
+    case 6: return pos_gather_launch<6>(nb, idx, bits, action, target, wsx, W, sg, nseeds, st);
+    case 7: return pos_gather_launch<7>(nb, idx, bits, action, target, wsx, W, sg, nseeds, st);
+    default: pqn_set_error("pqn_cnn_pos_gather: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
+  }
+}
+
+template <int C>
+static int pos_backward_launch(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out,
+                               const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, int stats, hipStream_t st) {
+  using P = PosCfg<C>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_bwd_kernel<C, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)P::lds_bytes());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_bwd_kernel<C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)P::lds_bytes());
+    attr = true;
+  }
+  if (!g_pos_stamps && getenv("PQN_T1_STAMPS")) {
+    if (hipMalloc(&g_pos_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_pos_stamps = nullptr;
+  }
+  if (stats)
+    hipLaunchKernelGGL((cnn_pos_bwd_kernel<C, 1>), dim3(8 * nch * nseeds), dim3(POS_THREADS), P::lds_bytes(), st, nb, nch, theta, L, wsx,
+                       w1out, W, sg, g_pos_stamps);
+  else
+    hipLaunchKernelGGL((cnn_pos_bwd_kernel<C, 0>), dim3(8 * nch * nseeds), dim3(POS_THREADS), P::lds_bytes(), st, nb, nch, theta, L, wsx,
+                       w1out, W, sg, g_pos_stamps);
+  return pqn_check_launch("pqn_cnn_pos_backward");
+}
+
+int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out, const pos_ws_t &W,
+                         const pqn_seeds_t &sg, int nseeds, int stats, hipStream_t st) {
+  switch (L.c) {
+    case 4: return pos_backward_launch<4>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, stats, st);
+    case 6: return pos_backward_launch<6>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, stats, st);
+    case 7: return pos_backward_launch<7>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, stats, st);
+    default: pqn_set_error("pqn_cnn_pos_backward: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
+  }
+}

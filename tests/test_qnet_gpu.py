@@ -342,13 +342,20 @@ def _grads_under_options(gpu, c, a, nb, pool, mode, reps=3, **opts):
     action = torch.from_numpy(rng.integers(0, a, pool).astype(np.int32)).to(gpu)
     target = torch.from_numpy(rng.standard_normal(pool).astype(np.float32)).to(gpu)
     idx = torch.from_numpy(rng.permutation(pool)[:nb].astype(np.int64)).to(gpu)
+    want_lq = opts.pop("want_loss", False)
     with _lib.options(**opts):
         lay = CnnKernelLayout(c, a, matmul_f16=mode)
         tr = CnnTrainer(lay, theta, 5e-4, 10.0, max_minibatch=nb)
-        out = [tr.compute_grad(idx, bits, action, target)[:lay.total].clone() for _ in range(reps)]
+        out, lq = [], []
+        for _ in range(reps):
+            lo, qv = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+            out.append(tr.compute_grad(idx, bits, action, target, lo, qv)[:lay.total].clone())
+            lq.append((float(lo), float(qv)))
         form = _lib.last_kernel_form()[0]
-    for g in out[1:]:
-        assert torch.equal(g, out[0]), (opts, c, nb)
+    for g, v in zip(out[1:], lq[1:]):
+        assert torch.equal(g, out[0]) and v == lq[0], (opts, c, nb)
+    if want_lq:
+        return out[0], form, lq[0]
     return out[0], form
 
 
@@ -364,12 +371,44 @@ def test_paired_dgrad_opt_in_path(gpu):
         assert float((g_f32 - g_pd2).abs().max()) <= 2e-5 * float(g_f32.abs().max()), nb
 
 
-def test_position_parallel_backward_opt_in_path(gpu):
-    """bwd_pos=2 (with the pair kernel forced) routes a 4096-sample minibatch through the forward-only pair kernel +
-    qnet_cnn_bwd_pos_kernel + the reduction without split-K slabs: repeats bit-identical, gradient
-    equal to the f32-MFMA mode of the default kernels to f32 rounding."""
+@pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 4096, 20000), (4, 3, 512, 3000), (4, 5, 1024, 4000), (6, 4, 2048, 6000), (7, 3, 1024, 3000)])
+def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool):
+    """bwd_pos=2 routes a minibatch through the position-parallel kernels of pqn_qnet_pos.hip -- minibatch gather +
+    bit-transpose, cnn_pos_fwd_kernel (wave = 32 samples, conv on the fly, z in registers, head on the accumulator layout),
+    cnn_pos_bwd_kernel (wave = conv position, its dW1 rows in registers, one partial slab per sample chunk) -- and the
+    reduction: the form is reported, repeats are bit-identical (gradient, loss, mean chosen q), loss
+    and chosen q equal the f32-MFMA mode of the default kernels, the gradient equals it to f32 rounding and the oracle's numpy
+    backward at the tolerance of test_cnn_grad_vs_oracle.  bwd_pos=4 (this round's backward behind the forward-only pair
+    kernel, LayerNorm_0 statistics recomputed) is held to the same.  pqn_minatar.py:271-291."""
+    g_f32, f0, lq0 = _grads_under_options(gpu, c, a, nb, pool, 0, t1_pair=0, t1_ksplit=0, want_loss=True)
+    g_pos, f1, lq1 = _grads_under_options(gpu, c, a, nb, pool, 2, bwd_pos=2, want_loss=True)
+    g_mix, f2, lq2 = _grads_under_options(gpu, c, a, nb, pool, 2, t1_pair=2, bwd_pos=4, want_loss=True)
+    assert (f0, f1, f2) == ("single", "pos", "pair+pos")
+    scale = float(g_f32.abs().max())
+    for g, lq in ((g_pos, lq1), (g_mix, lq2)):
+        assert abs(lq[0] - lq0[0]) <= 2e-6 * max(1.0, abs(lq0[0])) and abs(lq[1] - lq0[1]) <= 2e-6 * max(1.0, abs(lq0[1])), (lq, lq0)
+        assert float((g_f32 - g).abs().max()) <= 2e-5 * scale, float((g_f32 - g).abs().max()) / scale
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout
+    rng = np.random.default_rng(nb + c)
+    torch.manual_seed(1234)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
+    obs, _words = _random_bits(rng, pool, c, density=0.12)
+    action = rng.integers(0, a, pool).astype(np.int32)
+    target = rng.standard_normal(pool).astype(np.float32)
+    idx = rng.permutation(pool)[:nb]
+    shapes = oracle.cnn_shapes((10, 10, c), a)
+    _lo, _chosen, g_ref = oracle.net_loss_grad("cnn", oracle.unflatten(_np(theta), shapes), shapes, obs[idx], action[idx], target[idx])
+    lay = CnnKernelLayout(c, a, matmul_f16=2)
+    for g in (g_pos, g_mix):
+        np.testing.assert_allclose(_np(lay.to_flax(g)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
+
+
+def test_position_parallel_backward_round2_kernel(gpu):
+    """bwd_pos=3: round 2's producer / consumer kernel (qnet_cnn_bwd_pos_kernel), kept as the A/B partner of the round-5 one."""
     g_f32, f0 = _grads_under_options(gpu, 4, 3, 4096, 20000, 0, t1_pair=0)
-    g_pos, f1 = _grads_under_options(gpu, 4, 3, 4096, 20000, 2, t1_pair=2, bwd_pos=2)
+    g_pos, f1 = _grads_under_options(gpu, 4, 3, 4096, 20000, 2, t1_pair=2, bwd_pos=3)
     assert (f0, f1) == ("single", "pair+pos")
     assert float((g_f32 - g_pos).abs().max()) <= 2e-5 * float(g_f32.abs().max())
 
