@@ -35,6 +35,15 @@ BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 T1_FLOP_PER_SAMPLE = 674048.0
 
 
+# position-parallel form (round 5): the backward kernel is the dominant one.  Algorithmic FLOP per sample of the backward
+# (cnn_pos_bwd_kernel): fc1 dgrad 262,144 + fc1 wgrad 262,144 + conv wgrad 73,728 = 598,016 (its recomputed conv is not
+# algorithmic work); of the forward (cnn_pos_fwd_kernel): conv 73,728 + fc1 262,144 + fc2 forward / dgrad / wgrad 2,304 = 338,176.
+def pos_flop_per_sample(channels: int, actions: int):
+    bwd = 2.0 * 262144.0 + 18432.0 * channels
+    fwd = 18432.0 * channels + 262144.0 + 3.0 * 256.0 * actions
+    return bwd, fwd
+
+
 def t1_flop_per_sample(channels: int, actions: int) -> float:
     """The same count for any MinAtar game: conv 3x3xC -> 16 on 8x8 positions (forward + weight gradient), fc1 1024 -> 128
     (forward + input gradient), fc2 128 -> A (forward, input and weight gradient); Breakout (C = 4, A = 3): 674,048."""
@@ -115,7 +124,7 @@ def timed_updates(update, steps, warmup, first=0, barrier=None):
     return time.perf_counter() - t0
 
 
-def kernel_timer_pass(lib, update, first, mb_samples, seeds):
+def kernel_timer_pass(lib, update, first, mb_samples, seeds, mode=1):
     """HIP-event timing of the dominant kernel on its launch stream.  Events recorded while a hipGraph is being
     captured cannot be read back on ROCm 7, so the timed region runs the graph and this pass re-runs 2 more
     updates of the same workload through the eager C++ enqueue with the kernel timer on (same kernels, shapes,
@@ -128,7 +137,7 @@ def kernel_timer_pass(lib, update, first, mb_samples, seeds):
         drv.graph, drv.use_graph = None, False
         if hasattr(drv, "graphs"):
             drv.graphs = None
-    _lib.check(lib.pqn_prof_enable(1), "pqn_prof_enable")
+    _lib.check(lib.pqn_prof_enable(mode), "pqn_prof_enable")
     for u in range(first, first + 2):
         update(u)
     torch.cuda.synchronize()
@@ -140,12 +149,15 @@ def kernel_timer_pass(lib, update, first, mb_samples, seeds):
     return tot.value * 1e-3 / cnt.value, cnt.value
 
 
-def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sample=T1_FLOP_PER_SAMPLE):
+def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sample=T1_FLOP_PER_SAMPLE, channels=4, actions=3):
+    if form == "pos":     # the timed kernel is the backward of the position-parallel form
+        flop_per_sample = pos_flop_per_sample(channels, actions)[0]
     achieved = flop_per_sample * mb_samples * seeds / avg_s / 1e12
     traffic, tsrc, l2cu = None, None, None
-    for name in (f"r04_pmc_train_kernel_{matmul}_seeds{seeds}.json", f"r03_pmc_train_kernel_{matmul}_seeds{seeds}.json",
+    for name in ((f"r05_pmc_pos_bwd_kernel_{matmul}_seeds{seeds}.json",) if form == "pos" else
+                 (f"r04_pmc_train_kernel_{matmul}_seeds{seeds}.json", f"r03_pmc_train_kernel_{matmul}_seeds{seeds}.json",
                  f"r02_pmc_train_kernel_{matmul}_seeds{seeds}.json",
-                 f"r02_pmc_train_kernel_{matmul}.json", "r01_pmc_train_kernel.json"):
+                 f"r02_pmc_train_kernel_{matmul}.json", "r01_pmc_train_kernel.json")):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             pj = json.load(open(pmc))
@@ -161,7 +173,10 @@ def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sampl
                 break
     # which form ran is asked of the library (pqn_cnn_last_kernel_form), not re-derived here
     kname = {"pair": "qnet_cnn_train_pair_kernel<4>", "single": "qnet_cnn_train_kernel<4>"}.get(form, form)
-    out = {"kernel": f"{kname} (fwd + bwd of one {mb_samples}-sample minibatch of each of {seeds} seed(s) per launch)",
+    what = (f"cnn_pos_bwd_kernel (position-parallel form: fc1 input + weight gradient, LayerNorm_0 / conv backward of one "
+            f"{mb_samples}-sample minibatch of each of {seeds} seed(s) per launch)") if form == "pos" else \
+        f"{kname} (fwd + bwd of one {mb_samples}-sample minibatch of each of {seeds} seed(s) per launch)"
+    out = {"kernel": what,
            "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "l2_to_cu_bytes": l2cu,
            "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
@@ -172,9 +187,9 @@ def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sampl
         # exact in bf16): also priced against the pipe they actually run on
         out["bf16_pipe"] = {"issued_tflops": achieved * 6.0, "peak": BF16_PEAK_TFLOPS, "frac": achieved * 6.0 / BF16_PEAK_TFLOPS,
                             "note": "upper bound on the bf16 MFMA FLOPs issued (6 per algorithmic f32 FLOP) against the dense "
-                                    "bf16 peak: the kernel is NOT matrix-pipe bound in this mode -- what bounds fc1 / dgrad is the "
-                                    "64 B/clk/CU vector-memory path streaming the 1.5 MB of weight planes per 16-sample tile "
-                                    "(DESIGN.md section 5)"}
+                                    "bf16 peak: the kernel is NOT matrix-pipe bound in this mode -- it is bound by instruction "
+                                    "issue on the SIMDs (the exact 3-way operand split, LayerNorm, the conv operand build: "
+                                    "4-7 VALU instructions per MFMA, which the matrix pipe does not hide; DESIGN.md sections 3.6, 9)"}
     return out
 
 
@@ -321,7 +336,19 @@ def main():
     spl = spg // groups                                      # seeds per training-kernel launch
     if fused and (rank == 0 or (world > 1 and args.mode == "envs")):
         avg_s, launches = kernel_timer_pass(lib, update, n_done, mb, spl)
-        roof = t1_roofline(avg_s, launches, mb, spl, matmul, _lib.last_kernel_form()[0])
+        form0 = _lib.last_kernel_form()[0]
+        roof = t1_roofline(avg_s, launches, mb, spl, matmul, form0)
+        if form0 == "pos":   # the other two launches of the training step, timed the same way (2 more updates each)
+            f_s, _ = kernel_timer_pass(lib, update, n_done + 2, mb, spl, mode=3)
+            a_s, _ = kernel_timer_pass(lib, update, n_done + 4, mb, spl, mode=4)
+            bwd_f, fwd_f = pos_flop_per_sample(4, 3)
+            roof["training_step"] = {
+                "forward_kernel_us": f_s * 1e6, "forward_frac_f32_peak": fwd_f * mb * spl / f_s / 1e12 / F32_PEAK_TFLOPS,
+                "gather_forward_backward_us": a_s * 1e6,
+                "value_and_grad_frac_f32_peak": (bwd_f + fwd_f) * mb * spl / a_s / 1e12 / F32_PEAK_TFLOPS,
+                "note": "cnn_pos_fwd_kernel alone, and pos_gather + cnn_pos_fwd + cnn_pos_bwd together = the whole "
+                        "value_and_grad(_loss_fn) of an optimizer step incl. the fc1 weight gradient (936,192 algorithmic "
+                        "FLOP per sample for Breakout); HIP events on the launch stream, 2 eager updates each"}
         if groups > 1:
             roof["note"] = (f"{groups} seed groups of {spl} seeds: each timed launch covers one group and runs while the "
                             "previous group's fc1 weight gradient / fold / RAdam kernels share the GPU on a second stream")
@@ -408,12 +435,13 @@ def main():
                         ag, lg = kernel_timer_pass(lib, updg, w_g + s_g, mbg, spg_g)
                         env_g, _pg = make(env_name, device=dev)
                         ch, na = int(env_g.obs_shape[-1]), int(env_g.num_actions)
-                        rg = t1_roofline(ag, lg, mbg, spg_g, matmul, forms["train"], t1_flop_per_sample(ch, na))
+                        rg = t1_roofline(ag, lg, mbg, spg_g, matmul, forms["train"], t1_flop_per_sample(ch, na), ch, na)
                         res.append({"env": env_name, "num_envs": n_envs, "seeds_per_gpu": spg_g, "channels": ch, "actions": na,
                                     "value": n_envs * cg["NUM_STEPS"] * spg_g * s_g / dg, "unit": "env-steps/s",
                                     "ms_per_update": dg / s_g * 1e3, "kernel_forms": forms,
                                     "t1_avg_launch_us": rg["avg_launch_us"], "t1_frac_f32_peak": rg["frac"],
-                                    "t1_flop_per_sample": t1_flop_per_sample(ch, na), "minibatch": mbg})
+                                    "t1_flop_per_sample": rg["flop_per_launch"] / (mbg * spg_g), "t1_kernel": rg["kernel"].split(" ")[0],
+                                    "minibatch": mbg})
                         del updg, trg
                     except Exception as exc:  # noqa: BLE001
                         res.append({"env": env_name, "num_envs": n_envs, "error": repr(exc)[:300]})

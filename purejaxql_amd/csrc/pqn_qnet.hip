@@ -4036,12 +4036,18 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       const pos_ws_t PW = pos_ws_layout(nb, C, L.a);
       pqn_note_kernel_form(0, PQN_FORM_POS);
       if (part != 2) {
-        const bool timed = g_prof.on && g_prof.mode == 1 && g_prof.n < PQN_PROF_MAX;
-        if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
+        // kernel timer (pqn_prof_enable): mode 1 = the dominant kernel (the backward), 3 = the forward kernel, 4 = gather +
+        // forward + backward together (the whole value_and_grad of the step)
+        const bool prof = g_prof.on && g_prof.n < PQN_PROF_MAX;
+        const bool t_all = prof && g_prof.mode == 4, t_fwd = prof && g_prof.mode == 3, t_bwd = prof && g_prof.mode == 1;
+        if (t_all) (void)hipEventRecord(g_prof.s[g_prof.n], st);
         int rc = pqn_cnn_pos_gather(L, nb, idx, bits, action, target, h1T, PW, sd, sd.nseeds, st);
+        if (t_fwd) (void)hipEventRecord(g_prof.s[g_prof.n], st);
         if (rc == PQN_OK) rc = pqn_cnn_pos_forward(L, nb, theta, inv_b, h1T, PW, sd, sd.nseeds, st);
+        if (t_fwd) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
+        if (t_bwd) (void)hipEventRecord(g_prof.s[g_prof.n], st);
         if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, nch, theta, h1T, wpart, PW, sd, sd.nseeds, 1, st);
-        if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
+        if (t_bwd || t_all) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
         if (rc != PQN_OK) return rc;
       }
       if (part != 1)

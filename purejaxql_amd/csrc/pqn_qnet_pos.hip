@@ -497,9 +497,15 @@ struct PosFwdCfg {
   }
 };
 
+#ifdef POS_STAMPS
+#define POSF_STAMP(k) do { if (stamps && (s == 5 || (k) >= 8) && lane == 0 && blockIdx.x == 0 && wave == 0) stamps[16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define POSF_STAMP(k) do { } while (0)
+#endif
 template <int C, int NA>
 __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
-                                                                  float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd) {
+                                                                  float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd,
+                                                                  unsigned long long *__restrict__ stamps) {
   using P = PosCfg<C>;
   using F = PosFwdCfg<C>;
   using Cfg = CnnCfg<C>;
@@ -594,6 +600,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
 #pragma unroll 1
   for (int s = 0; s < 32; ++s) {
     dma_step(s + 1);
+    POSF_STAMP(0);
     const u32x4 *slot = ring + (s & 1) * F::N_W + lane;
     const int py = s >> 2, pxb = 2 * (s & 3);          // positions p0 = 8 py + pxb, p1 = p0 + 1 (same window rows, one column apart)
     // ---- window masks of sample (16 t + lane & 15) at both positions ----
@@ -610,6 +617,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
         mk[1][t][ky] = (v >> C) & ((1u << RB) - 1u);
       }
     }
+    POSF_STAMP(1);
     // ---- conv (transposed) + LayerNorm_0 + relu of the two positions x two tiles; y[q][t] = the lane's 4 channels ----
     float y[2][2][4];
 #pragma unroll
@@ -644,11 +652,13 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
         }
       }
     }
+    POSF_STAMP(2);
     // ---- fc1: K slots 0..3 = position p0's channels 4 g .., 4..7 = p1's (x3_fwd_index) ----
     X3Frag af[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       af[t] = x3_split8(f32x4{y[0][t][0], y[0][t][1], y[0][t][2], y[0][t][3]}, f32x4{y[1][t][0], y[1][t][1], y[1][t][2], y[1][t][3]});
+    POSF_STAMP(3);
 #pragma unroll
     for (int c = 0; c < 8; c += 2) {
       const u32x4 bh0 = slot[(0 * 8 + c) * 64], bm0 = slot[(1 * 8 + c) * 64], bl0 = slot[(2 * 8 + c) * 64];
@@ -661,9 +671,12 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
       x3_grp4(z00, af[0].h, bm0, z10, af[1].h, bm0, z01, af[0].h, bm1, z11, af[1].h, bm1);
       x3_grp4(z00, af[0].h, bh0, z10, af[1].h, bh0, z01, af[0].h, bh1, z11, af[1].h, bh1);
     }
+    POSF_STAMP(4);
     pos_dma_wait();
     __syncthreads();
+    POSF_STAMP(5);
   }
+  { const int s = 0; (void)s; POSF_STAMP(8); }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -763,6 +776,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
       dp[0] = zz[c][0]; dp[F::DZS] = zz[c][1]; dp[2 * F::DZS] = zz[c][2]; dp[3 * F::DZS] = zz[c][3];
     }
   }
+  { const int s = 0; (void)s; POSF_STAMP(9); }
   // ---- dz as bf16 planes: dzB straight from the accumulator layout (K slots = samples), dzA through the wave's LDS tile ----
   {
     u32x4 *g_dza = reinterpret_cast<u32x4 *>(wsx + W.dz);
@@ -789,6 +803,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
         g_dza[2 * pa + e] = f.l;
       }
   }
+  { const int s = 0; (void)s; POSF_STAMP(10); }
   // ---- the workgroup's record of head-parameter gradient sums: rows of the lane -> the 4 row groups -> the 8 waves ----
   __syncthreads();                                       // every wave is done with its dz tile: the front of the LDS becomes the record scratch
   float *recw = reinterpret_cast<float *>(pos_smem) + (size_t)wave * REC;
@@ -829,11 +844,13 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
       v = ((r0[e] + r0[REC + e]) + (r0[2 * REC + e] + r0[3 * REC + e])) + ((r0[4 * REC + e] + r0[5 * REC + e]) + (r0[6 * REC + e] + r0[7 * REC + e]));
     rec[e] = v;
   }
+  { const int s = 0; (void)s; POSF_STAMP(11); }
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+
 static unsigned long long *g_pos_stamps = nullptr;   // profiling only (PQN_T1_STAMPS=1)
 extern "C" int pqn_debug_pos_stamps(unsigned long long *out /* host, 32 entries */) {
   if (!g_pos_stamps) return PQN_E_INVALID;
@@ -851,8 +868,11 @@ static int pos_forward_launch(const pqn_cnn_layout_t &L, int nb, const float *th
                               (int)F::lds_bytes(NA));
     attr = true;
   }
+  if (!g_pos_stamps && getenv("PQN_T1_STAMPS")) {
+    if (hipMalloc(&g_pos_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_pos_stamps = nullptr;
+  }
   hipLaunchKernelGGL((cnn_pos_fwd_kernel<C, NA>), dim3((nb / 256) * nseeds), dim3(POS_THREADS), F::lds_bytes(NA), st, nb, theta, L, inv_b,
-                     wsx, W, sg);
+                     wsx, W, sg, g_pos_stamps);
   return pqn_check_launch("pqn_cnn_pos_forward");
 }
 

@@ -166,15 +166,20 @@ def test_c4_per_gpu_share_16_seeds_x_4096_envs_equals_solo_runs(gpu):
     assert not torch.equal(outs["metrics"]["td_loss"][0], outs["metrics"]["td_loss"][1])
 
 
-def test_full_size_sgd_trajectory_gradients_match_oracle_at_same_theta(gpu, oracle):
-    """The headline shape's optimizer loop (Breakout 4096 envs x 32 steps, 32 minibatches of 4096, 2 epochs), oracle and
+@pytest.mark.parametrize("mode,opts,form", [("f32", {}, "single"), ("bf16x3", {"bwd_pos": 0}, "single"), ("bf16x3", {"bwd_pos": 2}, "pos")])
+def test_full_size_sgd_trajectory_gradients_match_oracle_at_same_theta(gpu, oracle, mode, opts, form):
+    """(mode / kernel form: the package default f32-MFMA mode; the bf16x3 mode bench.py reports, through the single-tile
+    kernels a solo run takes and -- option bwd_pos = 2 -- through the position-parallel kernels the benched 16-seed launches
+    take: the same 64-step same-theta proof in the benched operand mode AND kernel form.)
+    The headline shape's optimizer loop (Breakout 4096 envs x 32 steps, 32 minibatches of 4096, 2 epochs), oracle and
     fused HIP kernels side by side on the SAME rollout data and permutations: at every optimizer step the HIP gradient
     evaluated AT THE ORACLE'S parameters equals the oracle's (<= 2e-4 of the largest entry, every one of the 64 steps,
     both epochs), and the free-running HIP trajectory stays within 6e-2 of the oracle's update (cosine > 0.998) --
     the residual is RAdam's amplification of f32 rounding noise in cancelling gradient entries, see
     test_make_train_end_to_end_vs_oracle."""
+    from purejaxql_amd import _lib
     from purejaxql_amd.networks import QNetwork
-    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer, matmul_mode
     O = oracle
     N, T, MB, EP = 4096, 32, 32, 2
     env = O.OracleEnv("Breakout-MinAtar")
@@ -198,11 +203,29 @@ def test_full_size_sgd_trajectory_gradients_match_oracle_at_same_theta(gpu, orac
     words = (padded.reshape(-1, 16, 32) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
     bits = torch.from_numpy(words.view(np.int32)).to(gpu)
     act_t, tgt_t = torch.from_numpy(af).to(gpu), torch.from_numpy(tf).to(gpu)
-    lay = CnnKernelLayout(4, 3)
+    lay = CnnKernelLayout(4, 3, matmul_f16=matmul_mode(mode))
     B, lr_steps = T * N // MB, 30 * MB * EP
     free = CnnTrainer(lay, theta0, 5e-4, 10.0, lr_decay_steps=float(lr_steps), max_minibatch=B)
     sync = CnnTrainer(lay, theta0, 5e-4, 10.0, lr_decay_steps=float(lr_steps), max_minibatch=B)
     m, v = np.zeros_like(th), np.zeros_like(th)
+    step, worst = 0, 0.0
+    prev = {k: _lib.get_option(k) for k in opts}
+    for k, val in opts.items():
+        _lib.set_option(k, val)
+    try:
+        worst = _trajectory(O, lay, free, sync, of, af, tf, bits, act_t, tgt_t, th, p, shapes, m, v, T, N, MB, EP, B, lr_steps, form)
+    finally:
+        for k, val in prev.items():
+            _lib.set_option(k, val)
+    upd, oupd = _np(free.theta_flax()) - _np(theta0), th - _np(theta0)
+    cos = float(np.dot(upd, oupd) / (np.linalg.norm(upd) * np.linalg.norm(oupd)))
+    rel = float(np.linalg.norm(upd - oupd) / np.linalg.norm(oupd))
+    assert cos > 0.998 and rel < 6e-2, (cos, rel, worst)
+
+
+def _trajectory(O, lay, free, sync, of, af, tf, bits, act_t, tgt_t, th, p, shapes, m, v, T, N, MB, EP, B, lr_steps, form):
+    from purejaxql_amd import _lib
+    gpu = bits.device
     step, worst = 0, 0.0
     for ep in range(EP):
         perm = O.permutation(O.fold_in(99, ep), T * N)
@@ -213,6 +236,7 @@ def test_full_size_sgd_trajectory_gradients_match_oracle_at_same_theta(gpu, orac
             sync.theta.copy_(lay.to_kernel(torch.from_numpy(th).to(gpu)))
             lay.refresh_copies(sync.theta, sync.w1b)
             g_gpu = _np(lay.to_flax(sync.compute_grad(idx_t, bits, act_t, tgt_t)))
+            assert _lib.last_kernel_form()[0] == form
             err = float(np.abs(g_gpu - g).max() / np.abs(g).max())
             worst = max(worst, err)
             assert err <= 2e-4, (ep, mb, err)
@@ -220,7 +244,4 @@ def test_full_size_sgd_trajectory_gradients_match_oracle_at_same_theta(gpu, orac
             free.apply()
             O.radam_clip_step(th, g, m, v, step, np.float32(O.linear_schedule(5e-4, 1e-20, lr_steps, step)), 10.0)
             step += 1
-    upd, oupd = _np(free.theta_flax()) - _np(theta0), th - _np(theta0)
-    cos = float(np.dot(upd, oupd) / (np.linalg.norm(upd) * np.linalg.norm(oupd)))
-    rel = float(np.linalg.norm(upd - oupd) / np.linalg.norm(oupd))
-    assert cos > 0.998 and rel < 6e-2, (cos, rel, worst)
+    return worst

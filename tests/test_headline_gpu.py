@@ -1,6 +1,8 @@
 """The configuration bench.py times, under the oracle: MATMUL_DTYPE=bf16x3, 16 seeds x 4096 envs per GPU (BASELINE.json
-configs[3]'s per-GPU share) -- i.e. the PAIR forms of the training and rollout kernels with the XCD-aware (seed, pair)
-mapping (csrc/pqn_qnet.hip: qnet_cnn_train_pair_kernel, qnet_cnn_rollout_pair_kernel, qnet_fc1_wgrad_x3_kernel).
+configs[3]'s per-GPU share) -- i.e. the POSITION-PARALLEL form of the training step (csrc/pqn_qnet_pos.hip: pos_gather_kernel,
+cnn_pos_fwd_kernel, cnn_pos_bwd_kernel; round 5) and the pair form of the rollout kernel (csrc/pqn_qnet.hip:
+qnet_cnn_rollout_pair_kernel), plus -- option bwd_pos = 0 -- the pair form of the training kernel that launches of 2 .. 9
+seeds still take (qnet_cnn_train_pair_kernel, qnet_fc1_wgrad_x3_kernel).
 Every test asserts in-process (pqn_cnn_last_kernel_form) that those are the kernels that ran.
 Reference lines: value_and_grad(_loss_fn) pqn_minatar.py:271-297 under the seeds vmap :459-461; _update_step :176-369."""
 import numpy as np
@@ -24,9 +26,12 @@ def _pack_bits(obs):
     return (padded.reshape(n, ow, 32) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
 
 
-def _cfg(n_upd, **extra):
+GAMES = {"Breakout-MinAtar": (4, 3), "Asterix-MinAtar": (4, 5), "SpaceInvaders-MinAtar": (6, 4), "Freeway-MinAtar": (7, 3)}
+
+
+def _cfg(n_upd, env="Breakout-MinAtar", **extra):
     from purejaxql_amd.config_loader import flatten, load_config
-    cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", f"alg.NUM_ENVS={N}",
+    cfg = flatten(load_config(["+alg=pqn_minatar", f"alg.ENV_NAME={env}", f"alg.NUM_ENVS={N}",
                                "alg.TEST_DURING_TRAINING=False", "alg.MATMUL_DTYPE=bf16x3"]))
     assert (cfg["NUM_STEPS"], cfg["NUM_MINIBATCHES"], cfg["NUM_EPOCHS"]) == (T, MB, EP)
     cfg["TOTAL_TIMESTEPS"] = n_upd * N * T
@@ -35,18 +40,46 @@ def _cfg(n_upd, **extra):
     return cfg
 
 
-@pytest.mark.parametrize("stacked", [False, True])
-def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked):
+def _assert_grad_close(g, g_ref, shapes, what):
+    """The tolerance of test_cnn_grad_vs_oracle (rtol 2e-3, atol 3e-6 max|g|) -- except for relu decisions AT the threshold:
+    a launch of 16 seeds x 4096 samples evaluates 8.4e6 hidden units of Dense_0, and a unit whose LayerNorm_1 output is zero
+    to f32 rounding is "on" in one implementation and "off" in the other.  Each such flip moves ONE output column of the
+    Dense_0 kernel gradient (and that unit's bias / LayerNorm_1 entries, and through dz a trace in the conv block) by one
+    sample's contribution out of 4096.  So: either the plain tolerance holds, or the violating Dense_0 entries are confined
+    to at most two output columns, the worst entry is within 2e-3 of max|g| and the whole gradient within 1e-3 in L2."""
+    atol = 3e-6 * np.abs(g_ref).max() + 1e-9
+    d = np.abs(g - g_ref)
+    bad = d > atol + 2e-3 * np.abs(g_ref)
+    if not bad.any():
+        return
+    off = 0
+    for k, shp in shapes.items():
+        n = int(np.prod(shp))
+        if k.endswith("Dense_0/kernel") and tuple(shp) == (1024, 128):
+            cols = np.unique(np.nonzero(bad[off:off + n].reshape(1024, 128))[1])
+            assert len(cols) <= 2, (what, "Dense_0 kernel gradient off in columns", cols[:10])
+        off += n
+    assert d.max() <= 2e-3 * np.abs(g_ref).max() and np.linalg.norm(g - g_ref) <= 1e-3 * np.linalg.norm(g_ref), \
+        (what, float(d.max()), float(np.abs(g_ref).max()), int(bad.sum()))
+
+
+@pytest.mark.parametrize("stacked,c,a,form", [(False, 4, 3, "pos"), (True, 4, 3, "pos"), (False, 6, 4, "pos"), (False, 7, 3, "pos"),
+                                              (False, 4, 3, "pair"), (True, 4, 3, "pair"), (False, 6, 4, "pair"), (False, 7, 3, "pair")])
+def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked, c, a, form):
     """vmap(value_and_grad(_loss_fn)) at the bench's launch shape -- 16 seeds x 4096-sample minibatches in one launch,
-    bf16x3: 2048 workgroups of the pair kernel, seeds remapped over the XCDs -- against the oracle's numpy backward,
-    seed by seed (own parameters, own minibatch), with the tolerances of test_cnn_grad_vs_oracle.  stacked=True reads the
-    samples out of a stacked [T][S*N] record (the layout pqn_cnn_update_seeds trains from), False from a shared pool."""
+    bf16x3, seeds remapped over the XCDs -- against the oracle's numpy backward, seed by seed (own parameters, own
+    minibatch), with the tolerances of test_cnn_grad_vs_oracle; for Breakout (C = 4, 3 actions), SpaceInvaders (C = 6, 4)
+    and Freeway (C = 7, 3) -- the shapes bench.py's minatar_suite times.  form = "pos": the default of such a launch, the
+    position-parallel kernels (256 forward + 256 backward workgroups); form = "pair" (option bwd_pos = 0): 2048 workgroups
+    of the pair kernel + the fc1 weight-gradient kernel, what launches of fewer than 10 seeds take.  stacked=True reads the
+    samples out of a stacked [T][S*N] record (the layout pqn_cnn_update_seeds trains from), False from a shared pool.
+    The same seed launched ALONE in the same form gives the same bits (the summation orders do not depend on the launch)."""
     from purejaxql_amd import _lib
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import CnnKernelLayout, cnn_grad_seeds, matmul_mode
-    rng = np.random.default_rng(2026 + stacked)
+    rng = np.random.default_rng(2026 + stacked + 10 * c)
     torch.manual_seed(7)
-    nb, c, a = 4096, 4, 3
+    nb = 4096
     n_env, t_len = (512, 12) if stacked else (20000, 1)
     rows = n_env * t_len * (S if stacked else 1)
     obs = (rng.random((rows, 10, 10, c)) < 0.12).astype(np.float32)
@@ -61,9 +94,10 @@ def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked):
     for s in range(S):
         theta_k[s, :lay.alloc] = lay.to_kernel(thetas[s])
     idx = np.stack([rng.permutation(n_env * t_len)[:nb] for _ in range(S)]).astype(np.int64)   # per-seed transition indices
-    grad, loss, qv = cnn_grad_seeds(lay, theta_k, torch.from_numpy(idx).to(gpu), bits, torch.from_numpy(action).to(gpu),
-                                    torch.from_numpy(target).to(gpu), n_env, n_env * S if stacked else n_env)
-    assert _lib.last_kernel_form()[0] == "pair"
+    with _lib.options(bwd_pos=1 if form == "pos" else 0):
+        grad, loss, qv = cnn_grad_seeds(lay, theta_k, torch.from_numpy(idx).to(gpu), bits, torch.from_numpy(action).to(gpu),
+                                        torch.from_numpy(target).to(gpu), n_env, n_env * S if stacked else n_env)
+        assert _lib.last_kernel_form()[0] == form
     shapes = oracle.cnn_shapes((10, 10, c), a)
     for s in range(S):
         j = idx[s]
@@ -73,11 +107,12 @@ def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked):
         assert abs(float(loss[s]) - lo) <= 1e-4 * max(1.0, abs(lo)), s
         assert abs(float(qv[s]) - chosen.mean()) <= 1e-4, s
         g = _np(lay.to_flax(grad[s]))
-        np.testing.assert_allclose(g, g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9, err_msg=f"seed {s}")
-    if not stacked:   # the same seed alone (128 pairs: the single-tile kernel) gives the same bits
-        g1, l1, _ = cnn_grad_seeds(lay, theta_k[5:6].contiguous(), torch.from_numpy(idx[5:6]).to(gpu), bits,
-                                   torch.from_numpy(action).to(gpu), torch.from_numpy(target).to(gpu), n_env, n_env)
-        assert _lib.last_kernel_form()[0] == "single"
+        _assert_grad_close(g, g_ref, shapes, f"seed {s}")
+    if not stacked:   # the same seed alone: the same form forced ("pos"), or the single-tile kernel whose sums run in the pair kernel's order
+        with _lib.options(bwd_pos=2 if form == "pos" else 0):
+            g1, l1, _ = cnn_grad_seeds(lay, theta_k[5:6].contiguous(), torch.from_numpy(idx[5:6]).to(gpu), bits,
+                                       torch.from_numpy(action).to(gpu), torch.from_numpy(target).to(gpu), n_env, n_env)
+            assert _lib.last_kernel_form()[0] == ("pos" if form == "pos" else "single")
         assert torch.equal(g1[0, :lay.total], grad[5, :lay.total]) and float(l1[0]) == float(loss[5])
 
 
@@ -107,26 +142,40 @@ def test_single_seed_8192_sample_minibatch_takes_the_pair_kernel(gpu, oracle):
     np.testing.assert_allclose(_np(lay.to_flax(g)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
 
 
-def test_headline_16_seeds_bf16x3_bit_identical_to_solo_runs(gpu):
-    """The bench configuration (16 seeds x 4096 envs, bf16x3, hipGraph replay) for 2 updates: pair kernels in the batched
-    run, single-tile kernels in the solo runs (128 pairs would leave half the CUs idle) -- and still seeds 0 / 7 / 15 are
-    bit-identical to their solo runs (both forms sum in the same order by construction, phase2_fc1_x3)."""
+@pytest.mark.parametrize("pinned", [True, False])
+def test_headline_16_seeds_bf16x3_against_solo_runs(gpu, pinned):
+    """The bench configuration (16 seeds x 4096 envs, bf16x3, hipGraph replay) for 2 updates against the solo runs of seeds
+    0 / 7 / 15.  The batch trains through the position-parallel kernels (one workgroup per 256 samples / per 8 conv
+    positions: they need >= 10 seeds to fill the chip); a solo run by default takes the single-tile kernels (256 workgroups of
+    16 samples) -- other summation orders, so the two agree to f32 rounding amplified by RAdam, stated here as a bound.
+    SEED_BATCH_BIT_IDENTICAL=True takes the form from the minibatch size alone in BOTH runs (the solo run is then slow:
+    32 workgroups) and they are bit-identical: metrics, parameters, optimizer state, env state.  pqn_minatar.py:459-461."""
     from purejaxql_amd import _lib
     from purejaxql_amd.pqn import make_train, seed_keys, vmap_train
-    cfg = _cfg(2)
+    cfg = _cfg(2, SEED_BATCH_BIT_IDENTICAL=pinned)
     keys = seed_keys(0, S)
     outs = vmap_train(make_train(dict(cfg), device="cuda:0"), keys)
-    assert _lib.last_kernel_form() == ("pair", "pair")
+    assert _lib.last_kernel_form() == ("pos", "pair")
     rs = outs["runner_state"]
     assert len(rs) == S and rs[0]["seed_batch"] == S and rs[0]["driver"] == "graph", rs[0]["driver_graph_error"]
     for s in (0, 7, 15):
         solo = make_train(dict(cfg), device="cuda:0")(keys[s])
-        assert _lib.last_kernel_form() == ("single", "single")
-        for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "returned_episode", "timestep"):
-            assert torch.equal(outs["metrics"][k][s], solo["metrics"][k]), (s, k)
-        assert torch.equal(rs[s]["theta"], solo["runner_state"]["theta"]), s
-        assert torch.equal(rs[s]["opt_mu"], solo["runner_state"]["opt_mu"][:rs[s]["opt_mu"].numel()]), s
-        assert torch.equal(rs[s]["env_state"], solo["runner_state"]["env_state"]), s
+        assert _lib.last_kernel_form() == (("pos", "single") if pinned else ("single", "single"))
+        if pinned:
+            for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "returned_episode", "timestep"):
+                assert torch.equal(outs["metrics"][k][s], solo["metrics"][k]), (s, k)
+            assert torch.equal(rs[s]["theta"], solo["runner_state"]["theta"]), s
+            assert torch.equal(rs[s]["opt_mu"], solo["runner_state"]["opt_mu"][:rs[s]["opt_mu"].numel()]), s
+            assert torch.equal(rs[s]["env_state"], solo["runner_state"]["env_state"]), s
+        else:
+            # first update: same parameters, same rollout -- identical data, td_loss / qvals to f32 rounding; after two
+            # updates the parameters sit within a few learning-rate steps of each other (RAdam is scale-free: an entry whose
+            # gradient is rounding noise moves by +-lr in either run; 128 optimizer steps)
+            for k in ("td_loss", "qvals"):
+                a0, b0 = float(outs["metrics"][k][s][0]), float(solo["metrics"][k][0])
+                assert abs(a0 - b0) <= 1e-4 * max(1.0, abs(b0)), (s, k, a0, b0)
+            d = (rs[s]["theta"] - solo["runner_state"]["theta"]).abs()
+            assert float(d.max()) <= 16 * cfg["LR"] and float(d.mean()) <= 0.2 * cfg["LR"], (s, float(d.max()), float(d.mean()))
     assert not torch.equal(outs["metrics"]["td_loss"][0], outs["metrics"]["td_loss"][1])
 
 
@@ -141,7 +190,8 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
     keys = seed_keys(3, S)
 
     def run(groups):
-        cfg = _cfg(3, SEED_GROUPS=groups, _SEED_GROUPS_TAIL=tail)
+        # (pinned form: a group of 8 seeds would otherwise fall back to the pair kernels and no longer equal the 16-seed batch)
+        cfg = _cfg(3, SEED_GROUPS=groups, _SEED_GROUPS_TAIL=tail, SEED_BATCH_BIT_IDENTICAL=True)
         update, finish = make_train(cfg, device="cuda:0").make_batch_runner(keys)
         for u in range(3):
             update(u)
@@ -150,7 +200,7 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
 
     one, d1 = run(1)
     two, d2 = run(2)
-    assert _lib.last_kernel_form() == ("pair", "pair")
+    assert _lib.last_kernel_form() == ("pos", "pair")
     assert type(d2).__name__ == "SeedGroupsDriver" and len(d2.drivers) == 2 and type(d1).__name__ == "SeedsUpdateDriver"
     assert two[0]["runner_state"]["seed_groups"] == 2 and two[0]["runner_state"]["seed_batch"] == S
     if tail == "graph":
@@ -165,17 +215,23 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
             assert torch.equal(a["runner_state"][k], b["runner_state"][k]), (s, k)
 
 
-def test_headline_whole_update_vs_oracle(gpu, oracle):
-    """ONE whole update of the bench workload -- 16 seeds batched into the launches, bf16x3, pair rollout + pair training
-    kernels -- against oracle.make_train, for seeds 0 / 7 / 15 (first, middle and last XCD group), from shared initial
-    parameters: metrics to 1e-3, the update vector by the size-aware criterion of test_make_train_end_to_end_vs_oracle
-    (cosine > 0.998, relative L2 < 6e-2, < 1 % of entries outside rtol 2e-3, worst entry < 4 lr)."""
+@pytest.mark.parametrize("env_name,seeds_checked", [("Breakout-MinAtar", (0, 7, 15)), ("SpaceInvaders-MinAtar", (7,)),
+                                                   ("Freeway-MinAtar", (7,)), ("Asterix-MinAtar", (7,))])
+def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked):
+    """ONE whole update of the bench workload -- 16 seeds batched into the launches, bf16x3, pair rollout + position-parallel
+    training kernels -- against oracle.make_train, for seeds 0 / 7 / 15 of Breakout (first, middle and last XCD group) and
+    seed 7 of the other three games of bench.py's minatar_suite (C = 6 / 7 channels, 4 / 3 / 5 actions), from shared
+    initial parameters: metrics to 1e-3, the update vector by the size-aware criterion of
+    test_make_train_end_to_end_vs_oracle (cosine > 0.998, relative L2 < 6e-2, < 1 % of entries outside rtol 2e-3, worst
+    entry < 4 lr; backed in the benched operand mode and kernel form by the same-theta trajectory test of
+    tests/test_fullsize_gpu.py)."""
     from purejaxql_amd import _lib
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.pqn import make_train, seed_keys
-    cfg = _cfg(1)
+    cfg = _cfg(1, env=env_name)
     ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
-    net = QNetwork("cnn", (10, 10, 4), 3, device=gpu)
+    c, a = GAMES[env_name]
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
     theta0 = net.init(123)
     cfg["_INIT_PARAMS"] = theta0
     keys = seed_keys(0, S)
@@ -183,10 +239,10 @@ def test_headline_whole_update_vs_oracle(gpu, oracle):
     update, finish = train.make_batch_runner(keys)
     update(0)
     outs = finish()
-    assert _lib.last_kernel_form() == ("pair", "pair") and cfg["NUM_UPDATES"] == 1
+    assert _lib.last_kernel_form() == ("pos", "pair") and cfg["NUM_UPDATES"] == 1
     otrain = oracle.make_train(ocfg)
     th0 = _np(theta0)
-    for s in (0, 7, 15):
+    for s in seeds_checked:
         oout = otrain(keys[s], th0)
         om = oout["metrics"][0]
         m = outs[s]["metrics"]

@@ -99,7 +99,7 @@ def test_run_time_options_and_kernel_form_query():
     """pqn_set_option / pqn_get_option / pqn_cnn_last_kernel_form (host-only calls): unknown names are errors, the
     context manager restores values, nothing has run yet in this process."""
     from purejaxql_amd import _lib
-    assert _lib.get_option("t1_pair") == 1 and _lib.get_option("bwd_pos") == 0
+    assert _lib.get_option("t1_pair") == 1 and _lib.get_option("bwd_pos") == 1
     with _lib.options(t1_pair=2, rollout_pair=0):
         assert (_lib.get_option("t1_pair"), _lib.get_option("rollout_pair")) == (2, 0)
     assert (_lib.get_option("t1_pair"), _lib.get_option("rollout_pair")) == (1, 1)

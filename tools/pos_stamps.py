@@ -27,7 +27,11 @@ def main():
     _lib.check(lib.pqn_debug_pos_stamps(buf), "stamps")
     names = ["start", "masks+conv", "conv drain+LN", "dgrad", "drain+LN bwd", "split+dW1", "conv wgrad", "barrier"]
     s = [buf[k] for k in range(len(names))]
-    print("pos bwd:", " ".join("%s=%d" % (names[k + 1], s[k + 1] - s[k]) for k in range(len(names) - 1)), "total=%d" % (s[-1] - s[0]))
+    print("pos bwd (one super-tile):", " ".join("%s=%d" % (names[k + 1], s[k + 1] - s[k]) for k in range(len(names) - 1)), "total=%d" % (s[-1] - s[0]))
+    f = [buf[16 + k] for k in range(12)]
+    fn = ["start", "masks", "conv+LN x4", "split", "fc1", "barrier"]
+    print("pos fwd (K step 5):", " ".join("%s=%d" % (fn[k + 1], f[k + 1] - f[k]) for k in range(5)), "step total=%d" % (f[5] - f[0]))
+    print("pos fwd tail: head=%d dz planes=%d record=%d" % (f[9] - f[8], f[10] - f[9], f[11] - f[10]))
 
 
 if __name__ == "__main__":
