@@ -12,9 +12,10 @@
 //   cnn_pos_bwd_kernel   (8 positions, chunk of samples, seed), wave = position: per super-tile the conv + LayerNorm_0 are
 //                        recomputed in MFMA accumulator layout (lane = channel, 4 samples per lane and tile), then dgrad
 //                        against the resident planes, relu mask, LayerNorm_0 backward, and -- with h1 / dx split ONCE, in
-//                        registers -- the position's rows of dW1 and its conv weight-gradient tile.  dz (both operand
-//                        orders), the packed rows and T32 arrive per super-tile through LDS-DMA (global_load_lds) into a
-//                        two-slot ring: one barrier per super-tile, no staging registers, no ds_write.
+//                        registers -- the position's rows of dW1 and its conv weight-gradient tile.  dz (bf16 planes, ONE
+//                        image for both operand orders: ds_read_b128 / ds_read_b64_tr_b16), the packed rows and T32 arrive
+//                        per super-tile through LDS-DMA (global_load_lds) into a two-slot ring: one barrier per super-tile,
+//                        no staging registers, no ds_write.
 //
 // The forward half (conv, fc1, head, loss, dz planes) is qnet_cnn_train_pair_kernel<C, true> of pqn_qnet.hip.
 #include <stdlib.h>
@@ -23,7 +24,35 @@
 #include "pqn_qnet_pos.h"
 
 #define POS_THREADS 512
+// Wave priority inside an iteration (A/B hook, -DPOS_PRIO=1): the two waves of a SIMD (w and w + 4) are released by the same
+// barrier; the older one wins the issue arbitration and reaches the next barrier ~25 % of an iteration early, after which
+// the SIMD runs a single wave.  With POS_PRIO the younger half is raised to priority 1 for the second half of every iteration.
+#ifndef POS_PRIO
+#define POS_PRIO 0
+#endif
+template <int P>
+__device__ __forceinline__ void pos_prio(int wave) {
+  if constexpr (POS_PRIO != 0) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(P);
+  }
+}
 #define POS_ST 32              // samples per super-tile (two 16-sample MFMA tiles)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// LDS image of a super-tile's dz planes: [plane][32 samples][16 slots of 16 B], slot = quad ^ pos_sigma(sample & 15), where
+// quad = 4 sK + kq names the 8 outputs 32 sK + 16 (j >> 2) + 4 kq + (j & 3) (dz_planes_a).  ONE image serves both products
+// of the backward: the dgrad's A fragment (row = sample, 8 K slots = one quad) is a ds_read_b128, the weight gradient's
+// B fragment (column = output, K slots = samples) is two ds_read_b64_tr_b16 (the transposing LDS read of gfx950: lane i of a
+// 16-lane group fetches 8 B of row i >> 2, the result in lane n, element j is row j / column n of the 4 x 16 block).
+// pos_sigma is the GF(2)-linear map (found by search over all 20,160) under which the ds_read_b128 pattern is conflict-free in
+// the instruction's real lane groups AND the transposing reads hit every 16-B slot at most twice per 32-lane pass (the
+// minimum: they use one 8-B half of every slot).
+PQN_HD int pos_sigma(int v) { return v ^ ((v & 1) * 12) ^ ((v & 2) << 2); }
+typedef short pos_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pos_s16x4 pos_lds_s16x4;
+PQN_D u32x2_t pos_tr_read(uint32_t lds_byte_addr) {   // ds_read_b64_tr_b16 (builtin: the compiler counts it in lgkmcnt)
+  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((pos_lds_s16x4 *)(uintptr_t)lds_byte_addr));
+}
 
 template <int C>
 struct PosCfg {
@@ -35,15 +64,15 @@ struct PosCfg {
   static constexpr int TW = pos_t32_words(C);        // words of T32 per super-tile (zero word at NBITS, padded to 1 KB)
   static constexpr int KW = 9 * C, RB = 3 * C, NRB = (KW + 15) / 16;
   static constexpr int CONVBLK = KW * 16 + 48;
-  // ring slot, in 16-B chunks: dzA | dzB | rows | T32 | LN0 statistics
+  // ring slot, in 16-B chunks: dz planes | rows | T32 | LN0 statistics
   static constexpr int N_DZ = 1536;                  // 3 planes x 32 samples x 16 quads
   static constexpr int N_ROWS = (POS_ST * ROWSTRIDE + 63) / 64 * 64;
   static constexpr int N_T32 = TW / 4;
   static constexpr int N_STAT = 128;                 // 8 positions x 32 samples x {mean, rstd}
-  static constexpr int O_DZB = N_DZ, O_ROWS = 2 * N_DZ, O_T32 = O_ROWS + N_ROWS, O_STAT = O_T32 + N_T32;
+  static constexpr int O_ROWS = N_DZ, O_T32 = O_ROWS + N_ROWS, O_STAT = O_T32 + N_T32;
   static constexpr int SLOT = O_STAT + N_STAT;       // chunks per slot (a multiple of 64: whole DMA instructions)
   static constexpr int NI = SLOT / 64;               // 1-KB DMA instructions per slot
-  static constexpr int NTAIL = NI - 48;              // instructions behind the 48 of the dz planes
+  static constexpr int NTAIL = NI - 24;              // instructions behind the 24 of the dz planes
   static_assert(NTAIL >= 1 && NTAIL <= 16, "at most two tail instructions per wave");
   static constexpr int NCS = (KW + 31) / 32;          // K steps of the conv product
   static constexpr size_t lds_bytes() { return (size_t)2 * SLOT * 16 + sizeof(float) * ((CONVBLK + 3) & ~3) + (size_t)NCS * 3 * 64 * 16; }
@@ -162,21 +191,19 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 
   // ---- DMA plan of this wave: instruction i = wave + 8 k fills chunks [64 i, 64 i + 64) of the slot ----
   const u32x4 *g_dza = reinterpret_cast<const u32x4 *>(wsx + W.dz);                      // [3][nb][16 quads]
-  const u32x4 *g_dzb = g_dza + (size_t)3 * nb * 16;                                      // [super-tile][8 cb][3][64]
   const u32x4 *g_rows = reinterpret_cast<const u32x4 *>(wsx + W.mb_bits);                // [nb][ROWCH]
   const u32x4 *g_t32 = reinterpret_cast<const u32x4 *>(wsx + W.t32);                     // [super-tile][N_T32]
   const u32x4 *g_stat = reinterpret_cast<const u32x4 *>(wsx + W.stats);                  // [super-tile][64 pos][16]
   const size_t pa = (size_t)nb * 16;                                                     // dzA plane stride in chunks
   // per-lane byte offsets; plane / instruction index and the super-tile advance the UNIFORM base.  dzA: instruction
-  // wave + 8 k covers plane k, samples 4 wave .. 4 wave + 3: chunk (sample, slot) holds quad = slot ^ (sample & 15)
+  // wave + 8 k covers plane k, samples 4 wave .. 4 wave + 3: chunk (sample, slot) holds quad = slot ^ pos_sigma(sample & 15)
   uint32_t offT[2];
   int strT[2], tailq[2];         // wave-uniform: chunks per super-tile of a tail instruction's source, its slot chunk (-1: none)
-  const uint32_t offA = (uint32_t)(((4 * wave + (lane >> 4)) * 16 + ((lane & 15) ^ ((4 * wave + (lane >> 4)) & 15))) * 16);
-  const uint32_t offB = (uint32_t)(lane * 16);            // dzB: lane-linear
+  const uint32_t offA = (uint32_t)(((4 * wave + (lane >> 4)) * 16 + ((lane & 15) ^ pos_sigma((4 * wave + (lane >> 4)) & 15))) * 16);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int ti = wave + 8 * k;                          // tail instruction index (wave-uniform)
-    const int q0 = (48 + ti) * 64, q = q0 + lane;         // the instruction's 64 chunks are all of one kind
+    const int q0 = (24 + ti) * 64, q = q0 + lane;         // the instruction's 64 chunks are all of one kind
     tailq[k] = ti < P::NTAIL ? q0 : -1;
     uint32_t off = 0u;
     int str = 0;
@@ -201,14 +228,12 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
   auto dma_slot = [&](int j) {   // super-tile st0 + min(j, nst - 1) -> slot j & 1
     const int g = st0 + min(j, nst - 1);
     const uint32_t slot = ring_lds + (uint32_t)((j & 1) * P::SLOT * 16);
-    const u32x4 *bA = g_dza + (size_t)g * (POS_ST * 16), *bB = g_dzb + (size_t)g * 1536;
+    const u32x4 *bA = g_dza + (size_t)g * (POS_ST * 16);
 #pragma unroll
     for (int k = 0; k < 2; ++k)
       if (tailq[k] >= 0) pos_dma16(offT[k], g_dza + (size_t)g * strT[k], slot + (uint32_t)(tailq[k] * 16));
 #pragma unroll
     for (int k = 0; k < 3; ++k) pos_dma16(offA, bA + (size_t)k * pa, slot + (uint32_t)((wave + 8 * k) * 1024));
-#pragma unroll
-    for (int k = 0; k < 3; ++k) pos_dma16(offB, bB + (wave + 8 * k) * 64, slot + (uint32_t)((P::O_DZB + (wave + 8 * k) * 64) * 16));
   };
   dma_slot(0);
 
@@ -228,6 +253,15 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     const int bp = ((py + ky) * 10 + px) * C;
     bw[ky] = bp >> 5;
     bs[ky] = bp & 31;
+  }
+  const int sig_ch = pos_sigma(ch);
+  // transposing reads: lane (i = ch, g = kq) fetches 8 B of sample row 4 g + (i >> 2), quad 4 sK + (i & 3); per sK the swizzled
+  // slot differs by more than a constant, so four lane offsets; plane (+8192 B), tile (+4096 B), half (+8 B) are immediates
+  uint32_t tr_sk[4];
+  {
+    const int row = 4 * kq + (ch >> 2), sg = pos_sigma(row);
+#pragma unroll
+    for (int sK = 0; sK < 4; ++sK) tr_sk[sK] = (uint32_t)((row * 16 + ((4 * sK + (ch & 3)) ^ sg)) * 16);
   }
   int tb[NRB];                   // conv weight gradient: T32 word of this lane's row k = 16 rb + ch (padding rows: the zero word)
 #pragma unroll
@@ -265,9 +299,11 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 #pragma unroll 1
   for (int j = 0; j < nst; ++j) {
     dma_slot(j + 1);             // the other slot was last read an iteration ago, before that iteration's barrier
+    pos_prio<0>(wave);
     POSB_STAMP(0);
     const u32x4 *slot = ring + (j & 1) * P::SLOT;
-    const u32x4 *ldA = slot, *ldB = slot + P::O_DZB + lane;
+    const u32x4 *ldA = slot;
+    const uint32_t trb = ring_lds + (uint32_t)((j & 1) * P::SLOT * 16);   // transposing reads of the same planes
     const uint32_t *rowsL = reinterpret_cast<const uint32_t *>(slot + P::O_ROWS);
     const uint32_t *t32L = reinterpret_cast<const uint32_t *>(slot + P::O_T32);
     // ---- window masks of (sample lane & 15 of each tile, this position) ----
@@ -298,7 +334,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     u32x4 az[2][3];
     auto load_az = [&](int sK, int pl) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) az[t][pl] = ldA[(pl * 32 + 16 * t + ch) * 16 + ((sK * 4 + kq) ^ ch)];
+      for (int t = 0; t < 2; ++t) az[t][pl] = ldA[(pl * 32 + 16 * t + ch) * 16 + ((sK * 4 + kq) ^ sig_ch)];
     };
     load_az(0, 0); load_az(0, 1); load_az(0, 2);
     POSB_STAMP(1);
@@ -361,6 +397,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
       }
     }
     POSB_STAMP(4);
+    pos_prio<1>(wave);
     // h1 and dx of the 32 samples as bf16 planes, split ONCE: K slot j = sample 16 (j >> 2) + 4 kq + (j & 3), i.e. exactly
     // this lane's eight values -- already the A fragment of dW1p = h1^T dz and the B fragment of dWc = bits^T dx
     float h1v[2][4];
@@ -373,11 +410,19 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     // ---- dW1p[feature][o] += sum over the 32 samples of h1[sample][feature] dz[sample][o] ----
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      // B fragments of column blocks 4 hf .. 4 hf + 3 (sK = cb >> 1, half h = cb & 1 of each quad): K slots 0..3 = the lane group's
+      // four samples of tile 0, 4..7 = of tile 1 -- two transposing reads per (column block, plane)
       u32x4 bh[4], bm[4], bl[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const u32x4 *bq = ldB + ((4 * hf + c) * 3) * 64;
-        bh[c] = bq[0]; bm[c] = bq[64]; bl[c] = bq[128];
+        const int cb = 4 * hf + c;
+        const uint32_t a0 = trb + tr_sk[cb >> 1] + 8u * (cb & 1);
+        const u32x2_t h0 = pos_tr_read(a0), h1 = pos_tr_read(a0 + 4096u);
+        const u32x2_t m0 = pos_tr_read(a0 + 8192u), m1 = pos_tr_read(a0 + 8192u + 4096u);
+        const u32x2_t l0 = pos_tr_read(a0 + 16384u), l1 = pos_tr_read(a0 + 16384u + 4096u);
+        bh[c] = u32x4{h0.x, h0.y, h1.x, h1.y};
+        bm[c] = u32x4{m0.x, m0.y, m1.x, m1.y};
+        bl[c] = u32x4{l0.x, l0.y, l1.x, l1.y};
       }
       f32x4 *d = dw + 4 * hf;
       x3_grp4(d[0], fh.l, bh[0], d[1], fh.l, bh[1], d[2], fh.l, bh[2], d[3], fh.l, bh[3]);
@@ -600,6 +645,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
 #pragma unroll 1
   for (int s = 0; s < 32; ++s) {
     dma_step(s + 1);
+    pos_prio<0>(wave);
     POSF_STAMP(0);
     const u32x4 *slot = ring + (s & 1) * F::N_W + lane;
     const int py = s >> 2, pxb = 2 * (s & 3);          // positions p0 = 8 py + pxb, p1 = p0 + 1 (same window rows, one column apart)
@@ -653,6 +699,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
       }
     }
     POSF_STAMP(2);
+    pos_prio<1>(wave);
     // ---- fc1: K slots 0..3 = position p0's channels 4 g .., 4..7 = p1's (x3_fwd_index) ----
     X3Frag af[2];
 #pragma unroll
@@ -777,19 +824,11 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
     }
   }
   { const int s = 0; (void)s; POSF_STAMP(9); }
-  // ---- dz as bf16 planes: dzB straight from the accumulator layout (K slots = samples), dzA through the wave's LDS tile ----
+  // ---- dz as bf16 planes in the dgrad's operand order (dz_planes_a; the backward derives the weight gradient's operand from
+  // the same image with transposing LDS reads): through the wave's LDS tile, rows = samples ----
   {
     u32x4 *g_dza = reinterpret_cast<u32x4 *>(wsx + W.dz);
-    u32x4 *g_dzb = g_dza + (size_t)3 * nb * 16 + (size_t)st * 1536;
     const size_t pa = (size_t)nb * 16;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float *d0 = dzt + (4 * g) * F::DZS + 16 * c + i16, *d1 = d0 + 16 * F::DZS;   // this lane's own eight values again
-      const X3Frag f = x3_split8(f32x4{d0[0], d0[F::DZS], d0[2 * F::DZS], d0[3 * F::DZS]}, f32x4{d1[0], d1[F::DZS], d1[2 * F::DZS], d1[3 * F::DZS]});
-      g_dzb[(c * 3 + 0) * 64 + lane] = f.h;
-      g_dzb[(c * 3 + 1) * 64 + lane] = f.m;
-      g_dzb[(c * 3 + 2) * 64 + lane] = f.l;
-    }
     // (the tile was written by this wave only: no barrier, the compiler orders the LDS reads behind the writes)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -803,7 +842,6 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
         g_dza[2 * pa + e] = f.l;
       }
   }
-  { const int s = 0; (void)s; POSF_STAMP(10); }
   // ---- the workgroup's record of head-parameter gradient sums: rows of the lane -> the 4 row groups -> the 8 waves ----
   __syncthreads();                                       // every wave is done with its dz tile: the front of the LDS becomes the record scratch
   float *recw = reinterpret_cast<float *>(pos_smem) + (size_t)wave * REC;
