@@ -30,6 +30,15 @@
 #ifndef POS_PRIO
 #define POS_PRIO 0
 #endif
+// Barrier period of the backward: ONE barrier per TWO super-tiles over a four-slot ring, the favoured half of the waves
+// (s_setprio 1) alternating between the two super-tiles of a period -- the older wave of a SIMD then leads in one and trails in
+// the other, and both reach the barrier together instead of one of them idling a quarter of every iteration (stamps: 2.3k of
+// 8.5k cycles).  In-call A/B (profiles/r05_v2_pair_sync_ab.txt): backward 264 -> 248 us; the same period WITHOUT the
+// priority alternation gains nothing, and so does the alternation with a barrier per super-tile.  -DPOS_PAIR_SYNC=0 = one
+// barrier per super-tile, two slots.
+#ifndef POS_PAIR_SYNC
+#define POS_PAIR_SYNC 1
+#endif
 template <int P>
 __device__ __forceinline__ void pos_prio(int wave) {
   if constexpr (POS_PRIO != 0) {
@@ -75,7 +84,8 @@ struct PosCfg {
   static constexpr int NTAIL = NI - 24;              // instructions behind the 24 of the dz planes
   static_assert(NTAIL >= 1 && NTAIL <= 16, "at most two tail instructions per wave");
   static constexpr int NCS = (KW + 31) / 32;          // K steps of the conv product
-  static constexpr size_t lds_bytes() { return (size_t)2 * SLOT * 16 + sizeof(float) * ((CONVBLK + 3) & ~3) + (size_t)NCS * 3 * 64 * 16; }
+  static constexpr int RS = POS_PAIR_SYNC ? 4 : 2;    // ring slots
+  static constexpr size_t lds_bytes() { return (size_t)RS * SLOT * 16 + sizeof(float) * ((CONVBLK + 3) & ~3) + (size_t)NCS * 3 * 64 * 16; }
 };
 
 // sorted shuffle key -> row of the stacked [T][S * N] rollout record (see pqn_seeds_t)
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
   constexpr int NRB = P::NRB, RB = P::RB, CONVBLK = P::CONVBLK;
   extern __shared__ __attribute__((aligned(16))) char pos_smem[];
   u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);
-  float *s_wc = reinterpret_cast<float *>(ring + 2 * P::SLOT);
+  float *s_wc = reinterpret_cast<float *>(ring + P::RS * P::SLOT);
   u32x4 *s_cvw = reinterpret_cast<u32x4 *>(s_wc + ((CONVBLK + 3) & ~3));   // conv kernel as bf16-plane B fragments [K step][plane][lane]: one copy for all waves
   // (seed, position group, chunk) of this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id; the 8 nch
   // workgroups of a seed all read that seed's dz planes, so they are placed on ONE XCD's L2 when the seeds divide over the XCDs.
@@ -225,9 +235,9 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     strT[k] = str;
   }
   const uint32_t ring_lds = pos_lds_addr(ring);
-  auto dma_slot = [&](int j) {   // super-tile st0 + min(j, nst - 1) -> slot j & 1
+  auto dma_slot = [&](int j) {   // super-tile st0 + min(j, nst - 1) -> slot j % RS
     const int g = st0 + min(j, nst - 1);
-    const uint32_t slot = ring_lds + (uint32_t)((j & 1) * P::SLOT * 16);
+    const uint32_t slot = ring_lds + (uint32_t)((j & (P::RS - 1)) * P::SLOT * 16);
     const u32x4 *bA = g_dza + (size_t)g * (POS_ST * 16);
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -236,6 +246,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     for (int k = 0; k < 3; ++k) pos_dma16(offA, bA + (size_t)k * pa, slot + (uint32_t)((wave + 8 * k) * 1024));
   };
   dma_slot(0);
+  if constexpr (POS_PAIR_SYNC != 0) dma_slot(1);
 
   // ---- per-wave constants ----
   for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
@@ -298,12 +309,20 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 
 #pragma unroll 1
   for (int j = 0; j < nst; ++j) {
-    dma_slot(j + 1);             // the other slot was last read an iteration ago, before that iteration's barrier
-    pos_prio<0>(wave);
+    if constexpr (POS_PAIR_SYNC != 0) {
+      if ((j & 1) == 0) { dma_slot(j + 2); dma_slot(j + 3); }   // the slots of the previous period: every wave passed its barrier
+#ifndef POS_PAIR_NOPRIO
+      if ((wave >= 4) == ((j & 1) != 0)) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+#endif
+    } else {
+      dma_slot(j + 1);           // the other slot was last read an iteration ago, before that iteration's barrier
+      pos_prio<0>(wave);
+    }
     POSB_STAMP(0);
-    const u32x4 *slot = ring + (j & 1) * P::SLOT;
+    const u32x4 *slot = ring + (j & (P::RS - 1)) * P::SLOT;
     const u32x4 *ldA = slot;
-    const uint32_t trb = ring_lds + (uint32_t)((j & 1) * P::SLOT * 16);   // transposing reads of the same planes
+    const uint32_t trb = ring_lds + (uint32_t)((j & (P::RS - 1)) * P::SLOT * 16);   // transposing reads of the same planes
     const uint32_t *rowsL = reinterpret_cast<const uint32_t *>(slot + P::O_ROWS);
     const uint32_t *t32L = reinterpret_cast<const uint32_t *>(slot + P::O_T32);
     // ---- window masks of (sample lane & 15 of each tile, this position) ----
@@ -449,8 +468,10 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) cw[rb] = X3_MFMA(fa[rb], fd.h, cw[rb]);
     POSB_STAMP(6);
-    pos_dma_wait();              // this wave's share of the next slot has landed ...
-    __syncthreads();             // ... and after the barrier everyone's has; every wave is done reading this slot
+    if (POS_PAIR_SYNC == 0 || (j & 1) != 0) {
+      pos_dma_wait();            // this wave's share of the next slot(s) has landed ...
+      __syncthreads();           // ... and after the barrier everyone's has; every wave is done reading this period's slot(s)
+    }
     POSB_STAMP(7);
   }
 
@@ -463,7 +484,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     for (int c = 0; c < 8; ++c) out[(p * 8 + c) * 64 + lane] = dw[c];
   }
   float *part = reinterpret_cast<float *>(pos_smem);   // [8 waves][CONVBLK]: the ring is dead (last barrier passed)
-  static_assert((size_t)8 * CONVBLK * sizeof(float) <= (size_t)2 * P::SLOT * 16, "conv partials must fit the ring");
+  static_assert((size_t)8 * CONVBLK * sizeof(float) <= (size_t)P::RS * P::SLOT * 16, "conv partials must fit the ring");
   {
     float *pr = part + wave * CONVBLK;
 #pragma unroll
@@ -524,13 +545,17 @@ PQN_D float pos_quad_sum1(float a) {
   return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
 }
 
+#ifndef POS_PAIR_SYNC_FWD
+#define POS_PAIR_SYNC_FWD 1     // forward kernel: one barrier per two K steps over a four-slot ring (see POS_PAIR_SYNC)
+#endif
 template <int C>
 struct PosFwdCfg {
   using P = PosCfg<C>;
   static constexpr int N_W = 1536;                                  // chunks of one K step's planes: [3][8 cb][64]
   static constexpr int ROWW = POS_ST * P::ROWSTRIDE * 4;            // words of a wave's packed rows
   static constexpr int DZS = 132;                                   // LDS row stride of the dz transposition tile
-  static constexpr size_t ring_bytes = (size_t)2 * N_W * 16;
+  static constexpr int RS = POS_PAIR_SYNC_FWD ? 4 : 2;              // ring slots
+  static constexpr size_t ring_bytes = (size_t)RS * N_W * 16;
   static constexpr size_t rows_bytes = (size_t)8 * ROWW * 4;
   static constexpr size_t misc_floats(int a) { return ((P::CONVBLK + 3) & ~3) + ((384 + 128 * a + a + 3) & ~3) + 8 * 64; }
   static constexpr size_t loop_bytes(int a) { return ring_bytes + rows_bytes + (size_t)P::NCS * 3 * 64 * 16 + sizeof(float) * misc_floats(a); }
@@ -589,13 +614,15 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h);   // forward-order planes [3][32 steps][8 cb][64]
   const uint32_t ring_lds = pos_lds_addr(ring);
   const uint32_t offW = (uint32_t)(lane * 16);
-  auto dma_step = [&](int s) {                        // K step min(s, 31) -> slot s & 1; wave w moves column block w of each plane
+  auto dma_step = [&](int s) {                        // K step min(s, 31) -> slot s % RS; wave w moves column block w of each plane
     const int sc = min(s, 31);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
-      pos_dma16(offW, wf + (size_t)pl * (X3_PLANE / 8) + (sc * 8 + wave) * 64, ring_lds + (uint32_t)(((s & 1) * F::N_W + (pl * 8 + wave) * 64) * 16));
+      pos_dma16(offW, wf + (size_t)pl * (X3_PLANE / 8) + (sc * 8 + wave) * 64,
+                ring_lds + (uint32_t)(((s & (F::RS - 1)) * F::N_W + (pl * 8 + wave) * 64) * 16));
   };
   dma_step(0);
+  if constexpr (POS_PAIR_SYNC_FWD != 0) dma_step(1);
   // ---- prologue: parameters, this wave's packed rows / actions / targets ----
   for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
   for (int i = tid; i < 384; i += POS_THREADS) s_hp[i] = theta[L.off_b1 + i];
@@ -644,10 +671,16 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
 
 #pragma unroll 1
   for (int s = 0; s < 32; ++s) {
-    dma_step(s + 1);
-    pos_prio<0>(wave);
+    if constexpr (POS_PAIR_SYNC_FWD != 0) {
+      if ((s & 1) == 0) { dma_step(s + 2); dma_step(s + 3); }
+      if ((wave >= 4) == ((s & 1) != 0)) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    } else {
+      dma_step(s + 1);
+      pos_prio<0>(wave);
+    }
     POSF_STAMP(0);
-    const u32x4 *slot = ring + (s & 1) * F::N_W + lane;
+    const u32x4 *slot = ring + (s & (F::RS - 1)) * F::N_W + lane;
     const int py = s >> 2, pxb = 2 * (s & 3);          // positions p0 = 8 py + pxb, p1 = p0 + 1 (same window rows, one column apart)
     // ---- window masks of sample (16 t + lane & 15) at both positions ----
     uint32_t mk[2][2][3];                               // [position][tile][window row]
@@ -719,8 +752,10 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
       x3_grp4(z00, af[0].h, bh0, z10, af[1].h, bh0, z01, af[0].h, bh1, z11, af[1].h, bh1);
     }
     POSF_STAMP(4);
-    pos_dma_wait();
-    __syncthreads();
+    if (POS_PAIR_SYNC_FWD == 0 || (s & 1) != 0) {
+      pos_dma_wait();
+      __syncthreads();
+    }
     POSF_STAMP(5);
   }
   { const int s = 0; (void)s; POSF_STAMP(8); }
