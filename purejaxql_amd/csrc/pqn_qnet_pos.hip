@@ -63,6 +63,24 @@ PQN_D u32x2_t pos_tr_read(uint32_t lds_byte_addr) {   // ds_read_b64_tr_b16 (bui
   return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((pos_lds_s16x4 *)(uintptr_t)lds_byte_addr));
 }
 
+// 8 observation bits -> the 8 bf16 slots of an MFMA operand (2.0 = 0x4000 per set bit, ConvX3::expand8) as ONE 16-B LDS
+// read from a 256-entry table instead of nine VALU instructions: both kernels are bound by instruction issue, and the
+// operand build was 12-18 % of their vector instructions.  The table is filled once per workgroup (4 KB).
+#ifndef POS_LUT
+#define POS_LUT 1
+#endif
+PQN_D void pos_lut_fill(u32x4 *lut, int tid, int nthreads) {
+  for (int b = tid; b < 256; b += nthreads) {
+    const uint32_t y = ((uint32_t)b << 15) | (uint32_t)b;
+    lut[b] = u32x4{(y << 14) & 0x40004000u, (y << 12) & 0x40004000u, (y << 10) & 0x40004000u, (y << 8) & 0x40004000u};
+  }
+}
+template <int C>
+PQN_D u32x4 pos_expand8(const u32x4 *lut, uint32_t byte) {
+  if constexpr (POS_LUT != 0) return lut[byte];
+  else return ConvX3<C>::expand8(byte);
+}
+
 template <int C>
 struct PosCfg {
   using Cfg = CnnCfg<C>;
@@ -85,7 +103,7 @@ struct PosCfg {
   static_assert(NTAIL >= 1 && NTAIL <= 16, "at most two tail instructions per wave");
   static constexpr int NCS = (KW + 31) / 32;          // K steps of the conv product
   static constexpr int RS = POS_PAIR_SYNC ? 4 : 2;    // ring slots
-  static constexpr size_t lds_bytes() { return (size_t)RS * SLOT * 16 + sizeof(float) * ((CONVBLK + 3) & ~3) + (size_t)NCS * 3 * 64 * 16; }
+  static constexpr size_t lds_bytes() { return (size_t)RS * SLOT * 16 + sizeof(float) * ((CONVBLK + 3) & ~3) + (size_t)NCS * 3 * 64 * 16 + 4096; }
 };
 
 // sorted shuffle key -> row of the stacked [T][S * N] rollout record (see pqn_seeds_t)
@@ -172,6 +190,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
   u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);
   float *s_wc = reinterpret_cast<float *>(ring + P::RS * P::SLOT);
   u32x4 *s_cvw = reinterpret_cast<u32x4 *>(s_wc + ((CONVBLK + 3) & ~3));   // conv kernel as bf16-plane B fragments [K step][plane][lane]: one copy for all waves
+  u32x4 *s_lut = s_cvw + P::NCS * 3 * 64;                                   // pos_expand8 table
   // (seed, position group, chunk) of this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id; the 8 nch
   // workgroups of a seed all read that seed's dz planes, so they are placed on ONE XCD's L2 when the seeds divide over the XCDs.
   const int wps = 8 * nch, nsl = gridDim.x / wps;
@@ -250,6 +269,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 
   // ---- per-wave constants ----
   for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
+  pos_lut_fill(s_lut, tid, POS_THREADS);
   u32x4 wfr[4][3];               // the position's 16 rows of W1 as dgrad-order bf16 planes: B fragments of dh1 = dz W1p^T
   {
     const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     for (int sx = 0; sx < ConvX3<C>::NS; ++sx) {
       u32x4 fa[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) fa[t] = ConvX3<C>::expand8(__builtin_amdgcn_ubfe(ConvX3<C>::word(mk[t], sx), 8u * kq, 8u));
+      for (int t = 0; t < 2; ++t) fa[t] = pos_expand8<C>(s_lut, __builtin_amdgcn_ubfe(ConvX3<C>::word(mk[t], sx), 8u * kq, 8u));
       const u32x4 wh = s_cvw[(sx * 3 + 0) * 64 + lane], wm = s_cvw[(sx * 3 + 1) * 64 + lane], wl = s_cvw[(sx * 3 + 2) * 64 + lane];
       x3_grp2(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
       x3_grp2(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
@@ -459,7 +479,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     for (int rb = 0; rb < NRB; ++rb) {
       const uint32_t wv = t32L[tb[rb]];
       const uint32_t byte = __builtin_amdgcn_ubfe(wv, 4u * kq, 4u) | (__builtin_amdgcn_ubfe(wv, 16u + 4u * kq, 4u) << 4);
-      fa[rb] = ConvX3<C>::expand8(byte);
+      fa[rb] = pos_expand8<C>(s_lut, byte);
     }
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) cw[rb] = X3_MFMA(fa[rb], fd.l, cw[rb]);
@@ -557,7 +577,7 @@ struct PosFwdCfg {
   static constexpr int RS = POS_PAIR_SYNC_FWD ? 4 : 2;              // ring slots
   static constexpr size_t ring_bytes = (size_t)RS * N_W * 16;
   static constexpr size_t rows_bytes = (size_t)8 * ROWW * 4;
-  static constexpr size_t misc_floats(int a) { return ((P::CONVBLK + 3) & ~3) + ((384 + 128 * a + a + 3) & ~3) + 8 * 64; }
+  static constexpr size_t misc_floats(int a) { return ((P::CONVBLK + 3) & ~3) + ((384 + 128 * a + a + 3) & ~3) + 8 * 64 + 1024; }   // + the pos_expand8 table
   static constexpr size_t loop_bytes(int a) { return ring_bytes + rows_bytes + (size_t)P::NCS * 3 * 64 * 16 + sizeof(float) * misc_floats(a); }
   static constexpr size_t tail_bytes = (size_t)8 * POS_ST * DZS * 4;   // dz tiles of the eight waves (over ring + rows)
   static constexpr size_t lds_bytes(int a) {
@@ -589,6 +609,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * 3 * 64);                    // conv kernel | bias | ln0 scale | ln0 bias
   float *s_hp = s_wc + ((CONVBLK + 3) & ~3);                                        // b1 | ln1 scale | ln1 bias | w2[128][A] | b2
   float *s_at = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                            // [8 waves][32 act (as int) | 32 tgt]
+  u32x4 *s_lut = reinterpret_cast<u32x4 *>(s_at + 8 * 64);                          // pos_expand8 table
   // XCD-aware (seed, block): the blocks of a seed stream the same 768 KB of planes -- one XCD's L2 per seed when possible
   const int nblk = nb / 256, nsl = gridDim.x / nblk;
   int seed_l, blk;
@@ -628,6 +649,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   for (int i = tid; i < 384; i += POS_THREADS) s_hp[i] = theta[L.off_b1 + i];
   for (int i = tid; i < 128 * NA; i += POS_THREADS) s_hp[384 + i] = theta[L.off_w2 + i];
   if (tid < NA) s_hp[384 + 128 * NA + tid] = theta[L.off_b2 + tid];
+  pos_lut_fill(s_lut, tid, POS_THREADS);
   {
     const u32x4 *g_rows = reinterpret_cast<const u32x4 *>(wsx + W.mb_bits) + (size_t)st * POS_ST * P::ROWCH;
     u32x4 *rw = reinterpret_cast<u32x4 *>(s_rows + wave * F::ROWW);
@@ -668,6 +690,42 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int c = 0; c < 8; ++c) zacc[t][c] = zero4;
+  // window masks of sample (16 t + lane & 15) at the two positions of K step sn: p0 = 8 py + pxb, p1 = p0 + 1 (same window
+  // rows, one column apart) -- in two halves: the LDS reads, and (once they have arrived) the shifts
+  auto mask_words = [&](int sn, uint32_t (&lo)[3][2], uint32_t (&hi)[3][2]) {
+    sn = min(sn, 31);
+    const int py = sn >> 2, pxb = 2 * (sn & 3);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int bwd = (((py + ky) * 10 + pxb) * C) >> 5;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t *row = rowsW + (16 * t + i16) * (P::ROWSTRIDE * 4);
+        lo[ky][t] = row[bwd];
+        hi[ky][t] = row[bwd + 1];
+      }
+    }
+  };
+  auto mask_finish = [&](int sn, const uint32_t (&lo)[3][2], const uint32_t (&hi)[3][2], uint32_t (&m)[2][2][3]) {
+    sn = min(sn, 31);
+    const int py = sn >> 2, pxb = 2 * (sn & 3);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int bsh = (((py + ky) * 10 + pxb) * C) & 31;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t v = (uint32_t)(((((uint64_t)hi[ky][t]) << 32) | lo[ky][t]) >> bsh);
+        m[0][t][ky] = v & ((1u << RB) - 1u);
+        m[1][t][ky] = (v >> C) & ((1u << RB) - 1u);
+      }
+    }
+  };
+  uint32_t mk[2][2][3];                                 // [position][tile][window row] of the CURRENT K step
+  {
+    uint32_t lo0[3][2], hi0[3][2];
+    mask_words(0, lo0, hi0);
+    mask_finish(0, lo0, hi0, mk);
+  }
 
 #pragma unroll 1
   for (int s = 0; s < 32; ++s) {
@@ -681,41 +739,33 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
     }
     POSF_STAMP(0);
     const u32x4 *slot = ring + (s & (F::RS - 1)) * F::N_W + lane;
-    const int py = s >> 2, pxb = 2 * (s & 3);          // positions p0 = 8 py + pxb, p1 = p0 + 1 (same window rows, one column apart)
-    // ---- window masks of sample (16 t + lane & 15) at both positions ----
-    uint32_t mk[2][2][3];                               // [position][tile][window row]
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int bp = ((py + ky) * 10 + pxb) * C, bwd = bp >> 5, bsh = bp & 31;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const uint32_t *row = rowsW + (16 * t + i16) * (P::ROWSTRIDE * 4);
-        const uint32_t lo = row[bwd], hi = row[bwd + 1];
-        const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> bsh);
-        mk[0][t][ky] = v & ((1u << RB) - 1u);
-        mk[1][t][ky] = (v >> C) & ((1u << RB) - 1u);
-      }
-    }
     POSF_STAMP(1);
-    // ---- conv (transposed) + LayerNorm_0 + relu of the two positions x two tiles; y[q][t] = the lane's 4 channels ----
+    // ---- conv (transposed) of the two positions x two tiles at once: eight independent accumulator chains ----
+    f32x4 cb_[2][2] = {{zero4, zero4}, {zero4, zero4}}, cs_[2][2] = {{zero4, zero4}, {zero4, zero4}};
+#pragma unroll
+    for (int sx = 0; sx < NCS; ++sx) {
+      u32x4 fa[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[q][t] = pos_expand8<C>(s_lut, __builtin_amdgcn_ubfe(ConvX3<C>::word(mk[q][t], sx), 8u * g, 8u));
+      const u32x4 wh = s_cvw[(sx * 3 + 0) * 64 + lane], wm = s_cvw[(sx * 3 + 1) * 64 + lane], wl = s_cvw[(sx * 3 + 2) * 64 + lane];
+      x3_grp4(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
+      x3_grp4(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
+      x3_grp4(cs_[0][0], wm, fa[0][0], cs_[0][1], wm, fa[0][1], cs_[1][0], wm, fa[1][0], cs_[1][1], wm, fa[1][1]);
+    }
+    // the next K step's window words (the rows are this wave's own: always resident) go out now, in the conv's shadow
+    uint32_t nlo[3][2], nhi[3][2];
+    mask_words(s + 1, nlo, nhi);
+    x3_drain(cb_[0][0], cs_[0][0], cb_[0][1], cs_[0][1]);
+    x3_drain(cb_[1][0], cs_[1][0], cb_[1][1], cs_[1][1]);
+    // ---- LayerNorm_0 + relu of the four (position, tile) combinations: independent chains, interleaved by the scheduler ----
     float y[2][2][4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      f32x4 cb_[2] = {zero4, zero4}, cs_[2] = {zero4, zero4};
-#pragma unroll
-      for (int sx = 0; sx < NCS; ++sx) {
-        u32x4 fa[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) fa[t] = ConvX3<C>::expand8(__builtin_amdgcn_ubfe(ConvX3<C>::word(mk[q][t], sx), 8u * g, 8u));
-        const u32x4 wh = s_cvw[(sx * 3 + 0) * 64 + lane], wm = s_cvw[(sx * 3 + 1) * 64 + lane], wl = s_cvw[(sx * 3 + 2) * 64 + lane];
-        x3_grp2(cs_[0], wl, fa[0], cs_[1], wl, fa[1]);
-        x3_grp2(cb_[0], wh, fa[0], cb_[1], wh, fa[1]);
-        x3_grp2(cs_[0], wm, fa[0], cs_[1], wm, fa[1]);
-      }
-      x3_drain(cb_[0], cs_[0], cb_[1], cs_[1]);
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const f32x4 cvo = (cb_[t] + cs_[t]) * ConvX3<C>::OUT_SCALE;
+        const f32x4 cvo = (cb_[q][t] + cs_[q][t]) * ConvX3<C>::OUT_SCALE;
         const float v[4] = {cvo.x + cbias[0], cvo.y + cbias[1], cvo.z + cbias[2], cvo.w + cbias[3]};
         float sum = (v[0] + v[1]) + (v[2] + v[3]);
         float sq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
@@ -730,26 +780,32 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
           *reinterpret_cast<f32x2 *>(g_stat + ((size_t)(2 * s + q) * POS_ST + 16 * t + i16) * 2) = ms;
         }
       }
-    }
+    mask_finish(s + 1, nlo, nhi, mk);
     POSF_STAMP(2);
-    pos_prio<1>(wave);
-    // ---- fc1: K slots 0..3 = position p0's channels 4 g .., 4..7 = p1's (x3_fwd_index) ----
+    // ---- fc1: K slots 0..3 = position p0's channels 4 g .., 4..7 = p1's (x3_fwd_index); the fragments of column-block pair
+    // c + 1 are read while the 24 MFMAs of pair c issue (two register sets) ----
     X3Frag af[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       af[t] = x3_split8(f32x4{y[0][t][0], y[0][t][1], y[0][t][2], y[0][t][3]}, f32x4{y[1][t][0], y[1][t][1], y[1][t][2], y[1][t][3]});
     POSF_STAMP(3);
+    u32x4 bf[2][6];                                      // [set][h0 m0 l0 h1 m1 l1]
+    auto load_b = [&](int c, u32x4 (&d)[6]) {
+      d[0] = slot[(0 * 8 + c) * 64]; d[1] = slot[(1 * 8 + c) * 64]; d[2] = slot[(2 * 8 + c) * 64];
+      d[3] = slot[(0 * 8 + c + 1) * 64]; d[4] = slot[(1 * 8 + c + 1) * 64]; d[5] = slot[(2 * 8 + c + 1) * 64];
+    };
+    load_b(0, bf[0]);
 #pragma unroll
     for (int c = 0; c < 8; c += 2) {
-      const u32x4 bh0 = slot[(0 * 8 + c) * 64], bm0 = slot[(1 * 8 + c) * 64], bl0 = slot[(2 * 8 + c) * 64];
-      const u32x4 bh1 = slot[(0 * 8 + c + 1) * 64], bm1 = slot[(1 * 8 + c + 1) * 64], bl1 = slot[(2 * 8 + c + 1) * 64];
+      if (c + 2 < 8) load_b(c + 2, bf[((c >> 1) + 1) & 1]);
+      const u32x4 (&b)[6] = bf[(c >> 1) & 1];
       f32x4 &z00 = zacc[0][c], &z10 = zacc[1][c], &z01 = zacc[0][c + 1], &z11 = zacc[1][c + 1];
-      x3_grp4(z00, af[0].l, bh0, z10, af[1].l, bh0, z01, af[0].l, bh1, z11, af[1].l, bh1);
-      x3_grp4(z00, af[0].h, bl0, z10, af[1].h, bl0, z01, af[0].h, bl1, z11, af[1].h, bl1);
-      x3_grp4(z00, af[0].m, bm0, z10, af[1].m, bm0, z01, af[0].m, bm1, z11, af[1].m, bm1);
-      x3_grp4(z00, af[0].m, bh0, z10, af[1].m, bh0, z01, af[0].m, bh1, z11, af[1].m, bh1);
-      x3_grp4(z00, af[0].h, bm0, z10, af[1].h, bm0, z01, af[0].h, bm1, z11, af[1].h, bm1);
-      x3_grp4(z00, af[0].h, bh0, z10, af[1].h, bh0, z01, af[0].h, bh1, z11, af[1].h, bh1);
+      x3_grp4(z00, af[0].l, b[0], z10, af[1].l, b[0], z01, af[0].l, b[3], z11, af[1].l, b[3]);
+      x3_grp4(z00, af[0].h, b[2], z10, af[1].h, b[2], z01, af[0].h, b[5], z11, af[1].h, b[5]);
+      x3_grp4(z00, af[0].m, b[1], z10, af[1].m, b[1], z01, af[0].m, b[4], z11, af[1].m, b[4]);
+      x3_grp4(z00, af[0].m, b[0], z10, af[1].m, b[0], z01, af[0].m, b[3], z11, af[1].m, b[3]);
+      x3_grp4(z00, af[0].h, b[1], z10, af[1].h, b[1], z01, af[0].h, b[4], z11, af[1].h, b[4]);
+      x3_grp4(z00, af[0].h, b[0], z10, af[1].h, b[0], z01, af[0].h, b[3], z11, af[1].h, b[3]);
     }
     POSF_STAMP(4);
     if (POS_PAIR_SYNC_FWD == 0 || (s & 1) != 0) {
