@@ -90,6 +90,7 @@ enum {
   PQN_OPT_PEER_TIMEOUT_S, // PQN_PEER_TIMEOUT_S: wall-clock seconds the in-graph peer all-reduce waits for a peer's gradient (default 60)
   PQN_OPT_T2_ACC,         // PQN_T2_ACC: bf16x3 fc1 weight gradient without split-K partials 0 never / 1 when row blocks x seeds fill the chip / 2 always
   PQN_OPT_UPD_OVERLAP,    // PQN_UPD_OVERLAP: pqn_bigmlp_update puts the first epoch's permutation and the last gradient-copy plane refresh on a side stream (bit 0 / bit 1; default 0: a fork / join pair in the graph costs ~30 us)
+  PQN_OPT_ROLLOUT_POS,    // PQN_ROLLOUT_POS: position-structure rollout kernel (256 envs per workgroup, pqn_qnet_pos.hip) 0 never / 1 when the launch fills the chip (default) / 2 whenever the shape allows
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);
@@ -226,4 +227,4 @@ int pqn_mlp_refresh_transposed_seeds(const pqn_mlp_layout_t &L, const float *the
 int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
                          const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
                          const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st,
-                         int n_per_seed = 0, long long theta_stride = 0, int keys_stride = 0);
+                         int n_per_seed = 0, long long theta_stride = 0, int keys_stride = 0, int pin_form = 0);

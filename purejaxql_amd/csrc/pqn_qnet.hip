@@ -3748,10 +3748,22 @@ extern "C" int pqn_qnet_cnn_forward(const pqn_cnn_layout_t *L, int32_t n, const 
 
 
 template <int C, class Env>
-static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
+static int launch_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
                           const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
                           const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed,
-                          long long theta_stride, int keys_stride) {
+                          long long theta_stride, int keys_stride, int pin_form) {
+  // position-structure form (pqn_qnet_pos.hip, round 5): one workgroup per 256 envs -- taken when the launch gives most CUs a
+  // workgroup (option rollout_pos: 0 never, 1 auto, 2 whenever the shape allows; pin_form: from the envs per seed alone)
+  {
+    const int rp = pqn_opt(PQN_OPT_ROLLOUT_POS);
+    const int nps = n_per_seed > 0 ? n_per_seed : n;
+    if (rp && L.matmul_f16 == 2 && pqn_cnn_pos_rollout_supported(env_id, C, L.a, n, n_per_seed) &&
+        (rp == 2 || (pin_form ? nps >= 2048 : n / 256 >= 160))) {
+      pqn_note_kernel_form(1, PQN_FORM_POS);
+      return pqn_cnn_pos_rollout(env_id, L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st,
+                                 n_per_seed, theta_stride, keys_stride);
+    }
+  }
   const size_t smem = cnn_smem_bytes<C>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -3800,23 +3812,23 @@ static int launch_rollout(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t 
 int pqn_qnet_cnn_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits,
                          const float *theta, const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q,
                          const float *eps_dev, const uint64_t *keys, float rscale, int store_obs, hipStream_t st,
-                         int n_per_seed, long long theta_stride, int keys_stride) {
+                         int n_per_seed, long long theta_stride, int keys_stride, int pin_form) {
   if (n_per_seed > 0 && n_per_seed % QN_TILE != 0) {
     pqn_set_error("pqn_qnet_cnn_rollout: seed batching needs NUM_ENVS %% %d == 0 (got %d)", QN_TILE, n_per_seed);
     return PQN_E_INVALID;
   }
   switch (env_id) {
     case PQN_ENV_BREAKOUT:
-      if (L.c == 4) return launch_rollout<4, Breakout>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride);
+      if (L.c == 4) return launch_rollout<4, Breakout>(env_id, L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride, pin_form);
       break;
     case PQN_ENV_ASTERIX:
-      if (L.c == 4) return launch_rollout<4, Asterix>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride);
+      if (L.c == 4) return launch_rollout<4, Asterix>(env_id, L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride, pin_form);
       break;
     case PQN_ENV_FREEWAY:
-      if (L.c == 7) return launch_rollout<7, Freeway>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride);
+      if (L.c == 7) return launch_rollout<7, Freeway>(env_id, L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride, pin_form);
       break;
     case PQN_ENV_SPACEINVADERS:
-      if (L.c == 6) return launch_rollout<6, SpaceInvaders>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride);
+      if (L.c == 6) return launch_rollout<6, SpaceInvaders>(env_id, L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, n_per_seed, theta_stride, keys_stride, pin_form);
       break;
     default: break;
   }

@@ -56,3 +56,11 @@ int pqn_cnn_pos_forward(const pqn_cnn_layout_t &L, int nb, const float *theta, f
                         const pqn_seeds_t &sg, int nseeds, hipStream_t st);
 int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out, const pos_ws_t &W,
                          const pqn_seeds_t &sg, int nseeds, int stats, hipStream_t st);
+
+// persistent rollout in the structure of the forward kernel (one workgroup per 256 envs, wave = 32 envs): the scan of
+// pqn_qnet_cnn_rollout for launches whose envs (per seed) come in multiples of 256; same arguments
+bool pqn_cnn_pos_rollout_supported(int env_id, int c, int a, int n, int n_per_seed);
+int pqn_cnn_pos_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
+                        const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
+                        const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed, long long theta_stride,
+                        int keys_stride);

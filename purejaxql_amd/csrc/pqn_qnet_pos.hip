@@ -20,6 +20,7 @@
 // The forward half (conv, fc1, head, loss, dz planes) is qnet_cnn_train_pair_kernel<C, true> of pqn_qnet.hip.
 #include <stdlib.h>
 
+#include "pqn_env_rules.h"
 #include "pqn_qnet_x3.h"
 #include "pqn_qnet_pos.h"
 
@@ -592,6 +593,167 @@ struct PosFwdCfg {
 #else
 #define POSF_STAMP(k) do { } while (0)
 #endif
+// The K loop of fc1 for one wave's 32 samples: 32 K steps (two conv positions each), z accumulated in `zacc`.  Shared by the
+// training forward kernel and the persistent rollout kernel (which runs it once per env step; kk0 = the number of K steps the
+// workgroup has run before, so that the weight ring and the barrier period continue across env steps).  On entry the ring
+// holds K steps kk0 and kk0 + 1 (visible to every wave); on exit it holds kk0 + 32 and kk0 + 33, i.e. steps 0 and 1 again.
+template <int C>
+struct PosFwdCtx {
+  const u32x4 *wf;            // forward-order W1 planes of this seed [3][32 steps][8 cb][64]
+  const u32x4 *ring;          // LDS ring of K-step plane sets [RS][3][8][64]
+  uint32_t ring_lds;
+  const u32x4 *s_cvw, *s_lut; // conv kernel planes [K step][plane][lane]; pos_expand8 table
+  const uint32_t *rowsW;      // this wave's packed rows [32][ROWSTRIDE * 4]
+  float *g_stat;              // LayerNorm_0 statistics of this wave's super-tile [64 pos][32][2] (STATS only)
+  int lane, wave, i16, g;
+  float cbias[4], cg0[4], cbe0[4];   // conv bias / LayerNorm_0 scale, bias of channels 4 g .. 4 g + 3
+  unsigned long long *stamps;
+};
+template <int C>
+PQN_D void pos_fwd_dma_step(const PosFwdCtx<C> &cx, int kk) {   // K step kk & 31 -> slot kk % RS; wave w moves column block w of each plane
+  using F = PosFwdCfg<C>;
+  const uint32_t offW = (uint32_t)(cx.lane * 16);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl)
+    pos_dma16(offW, cx.wf + (size_t)pl * (X3_PLANE / 8) + ((kk & 31) * 8 + cx.wave) * 64,
+              cx.ring_lds + (uint32_t)(((kk & (F::RS - 1)) * F::N_W + (pl * 8 + cx.wave) * 64) * 16));
+}
+template <int C, bool STATS>
+PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
+  using P = PosCfg<C>;
+  using F = PosFwdCfg<C>;
+  constexpr int RB = P::RB, NCS = P::NCS;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned long long *stamps = cx.stamps;
+  const int lane = cx.lane, wave = cx.wave;
+  (void)stamps; (void)lane; (void)wave;
+  auto dma_step = [&](int kk) { pos_fwd_dma_step<C>(cx, kk); };
+  // window masks of sample (16 t + lane & 15) at the two positions of K step sn: p0 = 8 py + pxb, p1 = p0 + 1 (same window
+  // rows, one column apart) -- in two halves: the LDS reads, and (once they have arrived) the shifts
+  auto mask_words = [&](int sn, uint32_t (&lo)[3][2], uint32_t (&hi)[3][2]) {
+    sn = min(sn, 31);
+    const int py = sn >> 2, pxb = 2 * (sn & 3);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int bwd = (((py + ky) * 10 + pxb) * C) >> 5;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t *row = cx.rowsW + (16 * t + cx.i16) * (P::ROWSTRIDE * 4);
+        lo[ky][t] = row[bwd];
+        hi[ky][t] = row[bwd + 1];
+      }
+    }
+  };
+  auto mask_finish = [&](int sn, const uint32_t (&lo)[3][2], const uint32_t (&hi)[3][2], uint32_t (&m)[2][2][3]) {
+    sn = min(sn, 31);
+    const int py = sn >> 2, pxb = 2 * (sn & 3);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int bsh = (((py + ky) * 10 + pxb) * C) & 31;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t v = (uint32_t)(((((uint64_t)hi[ky][t]) << 32) | lo[ky][t]) >> bsh);
+        m[0][t][ky] = v & ((1u << RB) - 1u);
+        m[1][t][ky] = (v >> C) & ((1u << RB) - 1u);
+      }
+    }
+  };
+  uint32_t mk[2][2][3];                                 // [position][tile][window row] of the CURRENT K step
+  {
+    uint32_t lo0[3][2], hi0[3][2];
+    mask_words(0, lo0, hi0);
+    mask_finish(0, lo0, hi0, mk);
+  }
+
+#pragma unroll 1
+  for (int s = 0; s < 32; ++s) {
+    if constexpr (POS_PAIR_SYNC_FWD != 0) {
+      if ((s & 1) == 0) { dma_step(kk0 + s + 2); dma_step(kk0 + s + 3); }
+      if ((cx.wave >= 4) == ((s & 1) != 0)) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    } else {
+      dma_step(kk0 + s + 1);
+      pos_prio<0>(cx.wave);
+    }
+    POSF_STAMP(0);
+    const u32x4 *slot = cx.ring + ((kk0 + s) & (F::RS - 1)) * F::N_W + cx.lane;
+    POSF_STAMP(1);
+    // ---- conv (transposed) of the two positions x two tiles at once: eight independent accumulator chains ----
+    f32x4 cb_[2][2] = {{zero4, zero4}, {zero4, zero4}}, cs_[2][2] = {{zero4, zero4}, {zero4, zero4}};
+#pragma unroll
+    for (int sx = 0; sx < NCS; ++sx) {
+      u32x4 fa[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[q][t] = pos_expand8<C>(cx.s_lut, __builtin_amdgcn_ubfe(ConvX3<C>::word(mk[q][t], sx), 8u * cx.g, 8u));
+      const u32x4 wh = cx.s_cvw[(sx * 3 + 0) * 64 + cx.lane], wm = cx.s_cvw[(sx * 3 + 1) * 64 + cx.lane], wl = cx.s_cvw[(sx * 3 + 2) * 64 + cx.lane];
+      x3_grp4(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
+      x3_grp4(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
+      x3_grp4(cs_[0][0], wm, fa[0][0], cs_[0][1], wm, fa[0][1], cs_[1][0], wm, fa[1][0], cs_[1][1], wm, fa[1][1]);
+    }
+    // the next K step's window words (the rows are this wave's own: always resident) go out now, in the conv's shadow
+    uint32_t nlo[3][2], nhi[3][2];
+    mask_words(s + 1, nlo, nhi);
+    x3_drain(cb_[0][0], cs_[0][0], cb_[0][1], cs_[0][1]);
+    x3_drain(cb_[1][0], cs_[1][0], cb_[1][1], cs_[1][1]);
+    // ---- LayerNorm_0 + relu of the four (position, tile) combinations: independent chains, interleaved by the scheduler ----
+    float y[2][2][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 cvo = (cb_[q][t] + cs_[q][t]) * ConvX3<C>::OUT_SCALE;
+        const float v[4] = {cvo.x + cx.cbias[0], cvo.y + cx.cbias[1], cvo.z + cx.cbias[2], cvo.w + cx.cbias[3]};
+        float sum = (v[0] + v[1]) + (v[2] + v[3]);
+        float sq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+        pos_quad_sum2(sum, sq);                          // the 16 channels of (sample, position): 4 lanes x 4
+        const float mean = sum * (1.0f / 16.0f);
+        const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
+        const float rstd = rsqrt_exact(var + QN_LN_EPS);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[q][t][r] = fmaxf(fmaf((v[r] - mean) * rstd, cx.cg0[r], cx.cbe0[r]), 0.0f);
+        if (STATS && cx.g == 0) {                                    // LayerNorm_0 statistics for the backward: [position][sample][2]
+          f32x2 ms = {mean, rstd};
+          *reinterpret_cast<f32x2 *>(cx.g_stat + ((size_t)(2 * s + q) * POS_ST + 16 * t + cx.i16) * 2) = ms;
+        }
+      }
+    mask_finish(s + 1, nlo, nhi, mk);
+    POSF_STAMP(2);
+    // ---- fc1: K slots 0..3 = position p0's channels 4 g .., 4..7 = p1's (x3_fwd_index); the fragments of column-block pair
+    // c + 1 are read while the 24 MFMAs of pair c issue (two register sets) ----
+    X3Frag af[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      af[t] = x3_split8(f32x4{y[0][t][0], y[0][t][1], y[0][t][2], y[0][t][3]}, f32x4{y[1][t][0], y[1][t][1], y[1][t][2], y[1][t][3]});
+    POSF_STAMP(3);
+    u32x4 bf[2][6];                                      // [set][h0 m0 l0 h1 m1 l1]
+    auto load_b = [&](int c, u32x4 (&d)[6]) {
+      d[0] = slot[(0 * 8 + c) * 64]; d[1] = slot[(1 * 8 + c) * 64]; d[2] = slot[(2 * 8 + c) * 64];
+      d[3] = slot[(0 * 8 + c + 1) * 64]; d[4] = slot[(1 * 8 + c + 1) * 64]; d[5] = slot[(2 * 8 + c + 1) * 64];
+    };
+    load_b(0, bf[0]);
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+      if (c + 2 < 8) load_b(c + 2, bf[((c >> 1) + 1) & 1]);
+      const u32x4 (&b)[6] = bf[(c >> 1) & 1];
+      f32x4 &z00 = zacc[0][c], &z10 = zacc[1][c], &z01 = zacc[0][c + 1], &z11 = zacc[1][c + 1];
+      x3_grp4(z00, af[0].l, b[0], z10, af[1].l, b[0], z01, af[0].l, b[3], z11, af[1].l, b[3]);
+      x3_grp4(z00, af[0].h, b[2], z10, af[1].h, b[2], z01, af[0].h, b[5], z11, af[1].h, b[5]);
+      x3_grp4(z00, af[0].m, b[1], z10, af[1].m, b[1], z01, af[0].m, b[4], z11, af[1].m, b[4]);
+      x3_grp4(z00, af[0].m, b[0], z10, af[1].m, b[0], z01, af[0].m, b[3], z11, af[1].m, b[3]);
+      x3_grp4(z00, af[0].h, b[1], z10, af[1].h, b[1], z01, af[0].h, b[4], z11, af[1].h, b[4]);
+      x3_grp4(z00, af[0].h, b[0], z10, af[1].h, b[0], z01, af[0].h, b[3], z11, af[1].h, b[3]);
+    }
+    POSF_STAMP(4);
+    if (POS_PAIR_SYNC_FWD == 0 || (s & 1) != 0) {
+      pos_dma_wait();
+      __syncthreads();
+    }
+    POSF_STAMP(5);
+  }
+}
+
 template <int C, int NA>
 __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
                                                                   float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd,
@@ -599,7 +761,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   using P = PosCfg<C>;
   using F = PosFwdCfg<C>;
   using Cfg = CnnCfg<C>;
-  constexpr int RB = P::RB, CONVBLK = P::CONVBLK, NCS = P::NCS;
+  constexpr int CONVBLK = P::CONVBLK, NCS = P::NCS;
   constexpr int REC = CONVBLK + 384 + 128 * NA + NA + 2;
   extern __shared__ __attribute__((aligned(16))) char pos_smem[];
   constexpr size_t FRONT = F::ring_bytes + F::rows_bytes > F::tail_bytes ? F::ring_bytes + F::rows_bytes : F::tail_bytes;
@@ -634,16 +796,12 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h);   // forward-order planes [3][32 steps][8 cb][64]
   const uint32_t ring_lds = pos_lds_addr(ring);
-  const uint32_t offW = (uint32_t)(lane * 16);
-  auto dma_step = [&](int s) {                        // K step min(s, 31) -> slot s % RS; wave w moves column block w of each plane
-    const int sc = min(s, 31);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      pos_dma16(offW, wf + (size_t)pl * (X3_PLANE / 8) + (sc * 8 + wave) * 64,
-                ring_lds + (uint32_t)(((s & (F::RS - 1)) * F::N_W + (pl * 8 + wave) * 64) * 16));
-  };
-  dma_step(0);
-  if constexpr (POS_PAIR_SYNC_FWD != 0) dma_step(1);
+  {   // the first two K steps' planes go out before anything else
+    PosFwdCtx<C> c0;
+    c0.wf = wf; c0.ring_lds = ring_lds; c0.lane = lane; c0.wave = wave;
+    pos_fwd_dma_step<C>(c0, 0);
+    if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C>(c0, 1);
+  }
   // ---- prologue: parameters, this wave's packed rows / actions / targets ----
   for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
   for (int i = tid; i < 384; i += POS_THREADS) s_hp[i] = theta[L.off_b1 + i];
@@ -690,130 +848,12 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int c = 0; c < 8; ++c) zacc[t][c] = zero4;
-  // window masks of sample (16 t + lane & 15) at the two positions of K step sn: p0 = 8 py + pxb, p1 = p0 + 1 (same window
-  // rows, one column apart) -- in two halves: the LDS reads, and (once they have arrived) the shifts
-  auto mask_words = [&](int sn, uint32_t (&lo)[3][2], uint32_t (&hi)[3][2]) {
-    sn = min(sn, 31);
-    const int py = sn >> 2, pxb = 2 * (sn & 3);
+  PosFwdCtx<C> cx;
+  cx.wf = wf; cx.ring = ring; cx.ring_lds = ring_lds; cx.s_cvw = s_cvw; cx.s_lut = s_lut; cx.rowsW = rowsW; cx.g_stat = g_stat;
+  cx.lane = lane; cx.wave = wave; cx.i16 = i16; cx.g = g; cx.stamps = stamps;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int bwd = (((py + ky) * 10 + pxb) * C) >> 5;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const uint32_t *row = rowsW + (16 * t + i16) * (P::ROWSTRIDE * 4);
-        lo[ky][t] = row[bwd];
-        hi[ky][t] = row[bwd + 1];
-      }
-    }
-  };
-  auto mask_finish = [&](int sn, const uint32_t (&lo)[3][2], const uint32_t (&hi)[3][2], uint32_t (&m)[2][2][3]) {
-    sn = min(sn, 31);
-    const int py = sn >> 2, pxb = 2 * (sn & 3);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int bsh = (((py + ky) * 10 + pxb) * C) & 31;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const uint32_t v = (uint32_t)(((((uint64_t)hi[ky][t]) << 32) | lo[ky][t]) >> bsh);
-        m[0][t][ky] = v & ((1u << RB) - 1u);
-        m[1][t][ky] = (v >> C) & ((1u << RB) - 1u);
-      }
-    }
-  };
-  uint32_t mk[2][2][3];                                 // [position][tile][window row] of the CURRENT K step
-  {
-    uint32_t lo0[3][2], hi0[3][2];
-    mask_words(0, lo0, hi0);
-    mask_finish(0, lo0, hi0, mk);
-  }
-
-#pragma unroll 1
-  for (int s = 0; s < 32; ++s) {
-    if constexpr (POS_PAIR_SYNC_FWD != 0) {
-      if ((s & 1) == 0) { dma_step(s + 2); dma_step(s + 3); }
-      if ((wave >= 4) == ((s & 1) != 0)) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
-    } else {
-      dma_step(s + 1);
-      pos_prio<0>(wave);
-    }
-    POSF_STAMP(0);
-    const u32x4 *slot = ring + (s & (F::RS - 1)) * F::N_W + lane;
-    POSF_STAMP(1);
-    // ---- conv (transposed) of the two positions x two tiles at once: eight independent accumulator chains ----
-    f32x4 cb_[2][2] = {{zero4, zero4}, {zero4, zero4}}, cs_[2][2] = {{zero4, zero4}, {zero4, zero4}};
-#pragma unroll
-    for (int sx = 0; sx < NCS; ++sx) {
-      u32x4 fa[2][2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) fa[q][t] = pos_expand8<C>(s_lut, __builtin_amdgcn_ubfe(ConvX3<C>::word(mk[q][t], sx), 8u * g, 8u));
-      const u32x4 wh = s_cvw[(sx * 3 + 0) * 64 + lane], wm = s_cvw[(sx * 3 + 1) * 64 + lane], wl = s_cvw[(sx * 3 + 2) * 64 + lane];
-      x3_grp4(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
-      x3_grp4(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
-      x3_grp4(cs_[0][0], wm, fa[0][0], cs_[0][1], wm, fa[0][1], cs_[1][0], wm, fa[1][0], cs_[1][1], wm, fa[1][1]);
-    }
-    // the next K step's window words (the rows are this wave's own: always resident) go out now, in the conv's shadow
-    uint32_t nlo[3][2], nhi[3][2];
-    mask_words(s + 1, nlo, nhi);
-    x3_drain(cb_[0][0], cs_[0][0], cb_[0][1], cs_[0][1]);
-    x3_drain(cb_[1][0], cs_[1][0], cb_[1][1], cs_[1][1]);
-    // ---- LayerNorm_0 + relu of the four (position, tile) combinations: independent chains, interleaved by the scheduler ----
-    float y[2][2][4];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f32x4 cvo = (cb_[q][t] + cs_[q][t]) * ConvX3<C>::OUT_SCALE;
-        const float v[4] = {cvo.x + cbias[0], cvo.y + cbias[1], cvo.z + cbias[2], cvo.w + cbias[3]};
-        float sum = (v[0] + v[1]) + (v[2] + v[3]);
-        float sq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-        pos_quad_sum2(sum, sq);                          // the 16 channels of (sample, position): 4 lanes x 4
-        const float mean = sum * (1.0f / 16.0f);
-        const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
-        const float rstd = rsqrt_exact(var + QN_LN_EPS);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[q][t][r] = fmaxf(fmaf((v[r] - mean) * rstd, cg0[r], cbe0[r]), 0.0f);
-        if (g == 0) {                                    // LayerNorm_0 statistics for the backward: [position][sample][2]
-          f32x2 ms = {mean, rstd};
-          *reinterpret_cast<f32x2 *>(g_stat + ((size_t)(2 * s + q) * POS_ST + 16 * t + i16) * 2) = ms;
-        }
-      }
-    mask_finish(s + 1, nlo, nhi, mk);
-    POSF_STAMP(2);
-    // ---- fc1: K slots 0..3 = position p0's channels 4 g .., 4..7 = p1's (x3_fwd_index); the fragments of column-block pair
-    // c + 1 are read while the 24 MFMAs of pair c issue (two register sets) ----
-    X3Frag af[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      af[t] = x3_split8(f32x4{y[0][t][0], y[0][t][1], y[0][t][2], y[0][t][3]}, f32x4{y[1][t][0], y[1][t][1], y[1][t][2], y[1][t][3]});
-    POSF_STAMP(3);
-    u32x4 bf[2][6];                                      // [set][h0 m0 l0 h1 m1 l1]
-    auto load_b = [&](int c, u32x4 (&d)[6]) {
-      d[0] = slot[(0 * 8 + c) * 64]; d[1] = slot[(1 * 8 + c) * 64]; d[2] = slot[(2 * 8 + c) * 64];
-      d[3] = slot[(0 * 8 + c + 1) * 64]; d[4] = slot[(1 * 8 + c + 1) * 64]; d[5] = slot[(2 * 8 + c + 1) * 64];
-    };
-    load_b(0, bf[0]);
-#pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-      if (c + 2 < 8) load_b(c + 2, bf[((c >> 1) + 1) & 1]);
-      const u32x4 (&b)[6] = bf[(c >> 1) & 1];
-      f32x4 &z00 = zacc[0][c], &z10 = zacc[1][c], &z01 = zacc[0][c + 1], &z11 = zacc[1][c + 1];
-      x3_grp4(z00, af[0].l, b[0], z10, af[1].l, b[0], z01, af[0].l, b[3], z11, af[1].l, b[3]);
-      x3_grp4(z00, af[0].h, b[2], z10, af[1].h, b[2], z01, af[0].h, b[5], z11, af[1].h, b[5]);
-      x3_grp4(z00, af[0].m, b[1], z10, af[1].m, b[1], z01, af[0].m, b[4], z11, af[1].m, b[4]);
-      x3_grp4(z00, af[0].m, b[0], z10, af[1].m, b[0], z01, af[0].m, b[3], z11, af[1].m, b[3]);
-      x3_grp4(z00, af[0].h, b[1], z10, af[1].h, b[1], z01, af[0].h, b[4], z11, af[1].h, b[4]);
-      x3_grp4(z00, af[0].h, b[0], z10, af[1].h, b[0], z01, af[0].h, b[3], z11, af[1].h, b[3]);
-    }
-    POSF_STAMP(4);
-    if (POS_PAIR_SYNC_FWD == 0 || (s & 1) != 0) {
-      pos_dma_wait();
-      __syncthreads();
-    }
-    POSF_STAMP(5);
-  }
+  for (int r = 0; r < 4; ++r) { cx.cbias[r] = cbias[r]; cx.cg0[r] = cg0[r]; cx.cbe0[r] = cbe0[r]; }
+  pos_fwd_kloop<C, true>(cx, 0, zacc);
   { const int s = 0; (void)s; POSF_STAMP(8); }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -977,6 +1017,218 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
 }
 
 // ---------------------------------------------------------------------------
+// Persistent rollout in the same structure (the `_step_env` scan + bootstrap forward, pqn_minatar.py:181-235; with
+// eps = EPS_TEST and store_obs = 0 the evaluation scan :380-401): one workgroup owns 256 envs for all T steps, wave = 32 envs.
+// Per env step a wave runs the K loop of the training forward (pos_fwd_kloop: conv on the fly from its own packed rows in
+// LDS, W1 planes through the workgroup's LDS ring, z in registers), the head's forward on the accumulator layout, and -- lane
+// = env, the lower half of the wave -- the eps-greedy draw, the transition rule, LogWrapper and the record, exactly as
+// qnet_cnn_rollout_kernel does; the new observation bits go straight back into the wave's rows.  Nothing but the K loop's
+// barriers synchronises the waves.  q is summed in the K order of the training forward kernel (one chain over the 32 K steps),
+// not in the order of the 16-env kernels of pqn_qnet.hip: the two agree to f32 rounding, not bit for bit.
+// ---------------------------------------------------------------------------
+template <int C, int NA>
+struct PosRollCfg {
+  using P = PosCfg<C>;
+  using F = PosFwdCfg<C>;
+  static constexpr size_t fixed_floats = ((P::CONVBLK + 3) & ~3) + ((384 + 128 * NA + NA + 3) & ~3) + 8 * POS_ST * 8 + 1024;
+  static constexpr size_t lds_bytes = F::ring_bytes + F::rows_bytes + (size_t)P::NCS * 3 * 64 * 16 + sizeof(float) * fixed_floats;
+};
+
+template <int C, class Env, int NA>
+__global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
+    int n, int t_len, uint32_t *__restrict__ state, uint32_t *__restrict__ bits_all, const float *__restrict__ theta,
+    pqn_cnn_layout_t L, int32_t *__restrict__ action, float *__restrict__ qmax, float *__restrict__ reward,
+    uint8_t *__restrict__ done, float *__restrict__ discount, float *__restrict__ rer, int32_t *__restrict__ rel,
+    int32_t *__restrict__ ts, float *__restrict__ last_q, const float *__restrict__ eps_dev,
+    const uint64_t *__restrict__ keys, float rscale, int store_obs, int n_per_seed, long long theta_stride, int keys_stride) {
+  using P = PosCfg<C>;
+  using F = PosFwdCfg<C>;
+  using Cfg = CnnCfg<C>;
+  static_assert(Cfg::OW == Env::OBS_WORDS, "packed observation width");
+  static_assert(NA <= 8, "q exchange buffer");
+  constexpr int CONVBLK = P::CONVBLK, NCS = P::NCS;
+  extern __shared__ __attribute__((aligned(16))) char pos_smem[];
+  u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);
+  uint32_t *s_rows = reinterpret_cast<uint32_t *>(pos_smem + F::ring_bytes);
+  u32x4 *s_cvw = reinterpret_cast<u32x4 *>(pos_smem + F::ring_bytes + F::rows_bytes);
+  float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * 3 * 64);
+  float *s_hp = s_wc + ((CONVBLK + 3) & ~3);
+  float *s_q = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                              // [8 waves][32 envs][8]
+  u32x4 *s_lut = reinterpret_cast<u32x4 *>(s_q + 8 * POS_ST * 8);
+  // (seed, block) of this workgroup, XCD-aware as in the training forward: the blocks of a seed share its W1 planes
+  const int nps = n_per_seed > 0 ? n_per_seed : n, nblk = nps / 256, nsl = gridDim.x / nblk;
+  int seed_l, blk;
+  {
+    const int lin = blockIdx.x;
+    if ((nsl & 7) == 0) {
+      const int xcd = lin & 7, k = lin >> 3;
+      seed_l = xcd * (nsl >> 3) + k / nblk;
+      blk = k % nblk;
+    } else {
+      seed_l = lin / nblk;
+      blk = lin % nblk;
+    }
+  }
+  int e_off = 0;           // first env of this seed: the RNG counters use the env index inside the seed
+  if (n_per_seed > 0) {
+    theta += seed_l * theta_stride;
+    keys += (size_t)seed_l * keys_stride;
+    e_off = seed_l * n_per_seed;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+  const int e0 = e_off + blk * 256 + POS_ST * wave;   // first env of this wave
+  const int e = e0 + (lane & 31), e_rng = e - e_off;
+  const bool owner = lane < POS_ST;
+  const size_t bstride = (size_t)n * Cfg::OW;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  PosFwdCtx<C> cx;
+  cx.wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h);
+  cx.ring = ring; cx.ring_lds = pos_lds_addr(ring); cx.s_cvw = s_cvw; cx.s_lut = s_lut;
+  cx.rowsW = s_rows + wave * F::ROWW; cx.g_stat = nullptr;
+  cx.lane = lane; cx.wave = wave; cx.i16 = i16; cx.g = g; cx.stamps = nullptr;
+  pos_fwd_dma_step<C>(cx, 0);
+  if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C>(cx, 1);
+  for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
+  for (int i = tid; i < 384; i += POS_THREADS) s_hp[i] = theta[L.off_b1 + i];
+  for (int i = tid; i < 128 * NA; i += POS_THREADS) s_hp[384 + i] = theta[L.off_w2 + i];
+  if (tid < NA) s_hp[384 + 128 * NA + tid] = theta[L.off_b2 + tid];
+  pos_lut_fill(s_lut, tid, POS_THREADS);
+  uint32_t *rowsM = s_rows + wave * F::ROWW;         // (mutable view of cx.rowsW)
+  {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(bits_all) + (size_t)e0 * P::ROWCH;   // slot 0 = the current observation
+    u32x4 *rw = reinterpret_cast<u32x4 *>(rowsM);
+    for (int c = lane; c < POS_ST * P::ROWCH; c += 64) {
+      const int row = c / P::ROWCH, cc = c - row * P::ROWCH;
+      rw[row * P::ROWSTRIDE + cc] = src[c];
+    }
+  }
+  Env env;
+  LogRec log;
+  if (owner) {
+    uint32_t w[Env::ENV_WORDS];
+#pragma unroll
+    for (int i = 0; i < Env::ENV_WORDS; ++i) w[i] = state[(size_t)i * n + e];
+    env.unpack(w);
+    log.load(state, n, e, Env::ENV_WORDS);
+  }
+  const float eps = *eps_dev;
+  pos_dma_wait();
+  __syncthreads();
+  if (wave == 0) {
+    ConvX3<C> cv;
+    cv.init(s_wc, lane);
+#pragma unroll
+    for (int sx = 0; sx < NCS; ++sx) {
+      s_cvw[(sx * 3 + 0) * 64 + lane] = cv.w[sx].h;
+      s_cvw[(sx * 3 + 1) * 64 + lane] = cv.w[sx].m;
+      s_cvw[(sx * 3 + 2) * 64 + lane] = cv.w[sx].l;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    cx.cbias[r] = s_wc[Cfg::KW * 16 + 4 * g + r];
+    cx.cg0[r] = s_wc[Cfg::KW * 16 + 16 + 4 * g + r];
+    cx.cbe0[r] = s_wc[Cfg::KW * 16 + 32 + 4 * g + r];
+  }
+  float *qx = s_q + wave * (POS_ST * 8);
+#pragma unroll 1
+  for (int t = 0; t <= t_len; ++t) {
+    f32x4 zacc[2][8];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) zacc[tt][c] = zero4;
+    pos_fwd_kloop<C, false>(cx, 32 * t, zacc);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int c = 0; c < 8; c += 4) x3_drain(zacc[tt][c], zacc[tt][c + 1], zacc[tt][c + 2], zacc[tt][c + 3]);
+    // ---- head forward on the accumulator layout: lane = columns o = 16 c + i16, rows = envs 16 tt + 4 g + r ----
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float zz[8], sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          zz[c] = zacc[tt][c][r] + s_hp[16 * c + i16];
+          sum += zz[c];
+          sq = fmaf(zz[c], zz[c], sq);
+        }
+        sum = group16_sum(sum);
+        sq = group16_sum(sq);
+        const float mean = sum * (1.0f / QN_HID);
+        const float var = fmaxf(sq * (1.0f / QN_HID) - mean * mean, 0.0f);
+        const float rstd = rsqrt_exact(var + QN_LN_EPS);
+        float h2[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) h2[c] = fmaxf(fmaf((zz[c] - mean) * rstd, s_hp[128 + 16 * c + i16], s_hp[256 + 16 * c + i16]), 0.0f);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          float part = 0.f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) part = fmaf(h2[c], s_hp[384 + (16 * c + i16) * NA + a], part);
+          const float qa = group16_sum(part) + s_hp[384 + 128 * NA + a];
+          if (i16 == 0) qx[(16 * tt + 4 * g + r) * 8 + a] = qa;
+        }
+      }
+    // ---- lane = env: eps-greedy (pqn_minatar.py:184-196), env.step + auto-reset + LogWrapper, the transition record ----
+    if (owner) {
+      int best = 0;
+      float bv = qx[lane * 8];
+#pragma unroll
+      for (int a = 1; a < NA; ++a) {
+        const float qa = qx[lane * 8 + a];
+        if (qa > bv) { bv = qa; best = a; }
+      }
+      if (t == t_len) {
+        if (last_q) last_q[e] = bv;                        // bootstrap value of obs_T
+      } else {
+        const uint64_t key = keys[t];
+        uint32_t o0, o1;
+        pqn_bits(key, (uint32_t)e_rng, PQN_STREAM_ACT, o0, o1);
+        const int act = (pqn_uniform(o0) < eps) ? (int)pqn_randint(o1, (uint32_t)NA) : best;
+        int dn = 0;
+        const float rw = env.step(act, key, (uint32_t)e_rng, dn);
+        log.step(rw, dn);
+        if (dn) env.reset(key, (uint32_t)e_rng);           // gymnax auto-reset
+        const size_t o = (size_t)t * n + e;
+        if (action) action[o] = act;
+        if (qmax) qmax[o] = bv;
+        if (reward) reward[o] = rw * rscale;
+        if (done) done[o] = (uint8_t)dn;
+        if (discount) discount[o] = dn ? 0.0f : 1.0f;
+        if (rer) rer[o] = log.ret_ret;
+        if (rel) rel[o] = log.ret_len;
+        if (ts) ts[o] = log.timestep;
+        env.obs_bits(&rowsM[lane * (P::ROWSTRIDE * 4)]);   // obs_{t+1} straight into the wave's rows
+      }
+    }
+    if (t == t_len) break;
+    // transition record: packed obs_{t+1} of the wave's envs (the training kernels gather from it); an evaluation rollout
+    // (store_obs = 0) keeps only the running observation, in slot 0
+    if (store_obs || t + 1 == t_len) {
+      u32x4 *dst = reinterpret_cast<u32x4 *>(bits_all + (store_obs ? (size_t)(t + 1) * bstride : (size_t)0)) + (size_t)e0 * P::ROWCH;
+      const u32x4 *rw = reinterpret_cast<const u32x4 *>(rowsM);
+      for (int c = lane; c < POS_ST * P::ROWCH; c += 64) {
+        const int row = c / P::ROWCH, cc = c - row * P::ROWCH;
+        dst[c] = rw[row * P::ROWSTRIDE + cc];
+      }
+    }
+  }
+  if (owner) {
+    uint32_t w[Env::ENV_WORDS];
+    env.pack(w);
+#pragma unroll
+    for (int i = 0; i < Env::ENV_WORDS; ++i) state[(size_t)i * n + e] = w[i];
+    log.store(state, n, e, Env::ENV_WORDS);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 
@@ -1066,4 +1318,46 @@ int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float
     case 7: return pos_backward_launch<7>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, stats, st);
     default: pqn_set_error("pqn_cnn_pos_backward: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
   }
+}
+
+template <int C, class Env, int NA>
+static int pos_rollout_launch(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
+                              const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
+                              const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed,
+                              long long theta_stride, int keys_stride) {
+  using R = PosRollCfg<C, NA>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_rollout_kernel<C, Env, NA>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::lds_bytes);
+    attr = true;
+  }
+  hipLaunchKernelGGL((cnn_pos_rollout_kernel<C, Env, NA>), dim3(n / 256), dim3(POS_THREADS), R::lds_bytes, st, n, t_len, state, bits, theta,
+                     L, action, qmax, rec.reward, rec.done, rec.discount, rec.returned_episode_returns,
+                     rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys, rscale, store_obs, n_per_seed, theta_stride,
+                     keys_stride);
+  return pqn_check_launch("pqn_cnn_pos_rollout");
+}
+
+bool pqn_cnn_pos_rollout_supported(int env_id, int c, int a, int n, int n_per_seed) {
+  const int nps = n_per_seed > 0 ? n_per_seed : n;
+  if (nps <= 0 || nps % 256 != 0 || n % nps != 0) return false;
+  return (env_id == PQN_ENV_BREAKOUT && c == 4 && a == 3) || (env_id == PQN_ENV_ASTERIX && c == 4 && a == 5) ||
+         (env_id == PQN_ENV_FREEWAY && c == 7 && a == 3) || (env_id == PQN_ENV_SPACEINVADERS && c == 6 && a == 4);
+}
+
+int pqn_cnn_pos_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
+                        const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
+                        const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed, long long theta_stride,
+                        int keys_stride) {
+#define POS_ROLL(CH, ENV, NACT) \
+  return pos_rollout_launch<CH, ENV, NACT>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, \
+                                           n_per_seed, theta_stride, keys_stride)
+  if (env_id == PQN_ENV_BREAKOUT && L.c == 4 && L.a == 3) POS_ROLL(4, Breakout, 3);
+  if (env_id == PQN_ENV_ASTERIX && L.c == 4 && L.a == 5) POS_ROLL(4, Asterix, 5);
+  if (env_id == PQN_ENV_FREEWAY && L.c == 7 && L.a == 3) POS_ROLL(7, Freeway, 3);
+  if (env_id == PQN_ENV_SPACEINVADERS && L.c == 6 && L.a == 4) POS_ROLL(6, SpaceInvaders, 4);
+#undef POS_ROLL
+  pqn_set_error("pqn_cnn_pos_rollout: env %d / %d channels / %d actions has no position-parallel rollout", env_id, L.c, L.a);
+  return PQN_E_UNSUPPORTED;
 }

@@ -238,7 +238,7 @@ static int upd_begin(const pqn_update_args_t *a, const UpdCtx &c, const uint64_t
   rec.timestep = a->ts;
   UPD_CHECK(pqn_qnet_cnn_rollout(a->env_id, L, c.SN, c.T, a->state, a->bits, a->theta, rec, a->action, a->qmax, a->last_q,
                                  a->sched_eps, a->sched_keys, a->rew_scale, 1, st, c.S > 1 ? c.N : 0, c.sd.theta_stride,
-                                 c.T + c.EP));
+                                 c.T + c.EP, c.sd.pin_form));
   // Q(lambda) TARGETS (:237-260): lane per env over the stacked [T][S*N] record
   return pqn_q_lambda(a->reward, a->done, a->qmax, a->last_q, a->gamma, a->lambda, c.T, c.SN, 1, a->target, st);
 }

@@ -666,15 +666,21 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                                   ro.bits[t + 1] if packed else None, ro.reward[t], ro.done[t], ro.discount[t],
                                   ro.rer[t], ro.rel[t], ro.ts[t])
             counters["timesteps"] += T * N
+            info_sums = None
             if craftax:   # (x * returned_episode).sum() / returned_episode.sum()  (pqn_craftax.py:364-369)
                 dm = ro.done.to(torch.float64)
                 cnt = dm.sum()
-                info_means = {kk: ((vv.to(torch.float64) * dm).sum() / cnt).to(torch.float32) for kk, vv in
-                              (("discount", ro.discount), ("returned_episode_returns", ro.rer),
-                               ("returned_episode_lengths", ro.rel), ("timestep", ro.ts), ("returned_episode", ro.done))}
+                # numerators and the common denominator separately: with the envs sharded over ranks the reference's ratio is
+                # sum-over-all-envs / count-over-all-envs, not the mean of the shards' ratios (a shard without a finished
+                # episode would contribute 0 / 0)
+                info_sums = {kk: (vv.to(torch.float64) * dm).sum() for kk, vv in
+                             (("discount", ro.discount), ("returned_episode_returns", ro.rer),
+                              ("returned_episode_lengths", ro.rel), ("timestep", ro.ts), ("returned_episode", ro.done))}
                 for k_a, a_name in enumerate(ach_names):   # x = done * unlocked * 100, then the same done-weighted mean
                     x = ((ach_buf >> k_a) & 1).to(torch.float64) * 100.0 * dm
-                    info_means[f"Achievements/{a_name}"] = ((x * dm).sum() / cnt).to(torch.float32)
+                    info_sums[f"Achievements/{a_name}"] = (x * dm).sum()
+                info_means = {kk: (vv / cnt).to(torch.float32) for kk, vv in info_sums.items()}
+                info_sums["_count"] = cnt
             else:
                 info_means = {
                     "discount": ro.discount.mean(), "returned_episode_returns": ro.rer.mean(),
@@ -718,11 +724,21 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 m["env_frame"] = counters["timesteps"] * obs_shape[-1]
             m.update(info_means)
             if metrics_hook is not None or shard_world > 1:   # env-sharded mode: means over all shards, counts over all envs
-                mean_keys = ["td_loss", "qvals"] + list(INFO_KEYS) + [k for k in m if k.startswith("Achievements/")]
-                vals = torch.stack([torch.as_tensor(m[k], dtype=torch.float32, device=dev) for k in mean_keys])
-                if metrics_hook is not None:
-                    vals = metrics_hook(vals)
-                m.update({k: vals[i] for i, k in enumerate(mean_keys)})
+                if info_sums is not None:   # done-weighted means (Craftax script): all-reduce numerators and the denominator
+                    sum_keys = [k for k in info_sums if k != "_count"]
+                    mean_keys = ["td_loss", "qvals"]
+                    vals = torch.stack([torch.as_tensor(m[k], dtype=torch.float32, device=dev) for k in mean_keys] +
+                                       [info_sums[k].to(torch.float32) for k in sum_keys] + [info_sums["_count"].to(torch.float32)])
+                    if metrics_hook is not None:
+                        vals = metrics_hook(vals)       # mean over the shards of every entry: the common factor 1 / world cancels
+                    m.update({k: vals[i] for i, k in enumerate(mean_keys)})
+                    m.update({k: vals[len(mean_keys) + i] / vals[-1] for i, k in enumerate(sum_keys)})
+                else:
+                    mean_keys = ["td_loss", "qvals"] + list(INFO_KEYS)
+                    vals = torch.stack([torch.as_tensor(m[k], dtype=torch.float32, device=dev) for k in mean_keys])
+                    if metrics_hook is not None:
+                        vals = metrics_hook(vals)
+                    m.update({k: vals[i] for i, k in enumerate(mean_keys)})
                 for k in ("env_step", "env_frame"):
                     if k in m:
                         m[k] = m[k] * shard_world

@@ -1,7 +1,6 @@
 """The configuration bench.py times, under the oracle: MATMUL_DTYPE=bf16x3, 16 seeds x 4096 envs per GPU (BASELINE.json
 configs[3]'s per-GPU share) -- i.e. the POSITION-PARALLEL form of the training step (csrc/pqn_qnet_pos.hip: pos_gather_kernel,
-cnn_pos_fwd_kernel, cnn_pos_bwd_kernel; round 5) and the pair form of the rollout kernel (csrc/pqn_qnet.hip:
-qnet_cnn_rollout_pair_kernel), plus -- option bwd_pos = 0 -- the pair form of the training kernel that launches of 2 .. 9
+cnn_pos_fwd_kernel, cnn_pos_bwd_kernel; round 5) and the same structure's rollout kernel (cnn_pos_rollout_kernel), plus -- option bwd_pos = 0 -- the pair form of the training kernel that launches of 2 .. 9
 seeds still take (qnet_cnn_train_pair_kernel, qnet_fc1_wgrad_x3_kernel).
 Every test asserts in-process (pqn_cnn_last_kernel_form) that those are the kernels that ran.
 Reference lines: value_and_grad(_loss_fn) pqn_minatar.py:271-297 under the seeds vmap :459-461; _update_step :176-369."""
@@ -155,12 +154,12 @@ def test_headline_16_seeds_bf16x3_against_solo_runs(gpu, pinned):
     cfg = _cfg(2, SEED_BATCH_BIT_IDENTICAL=pinned)
     keys = seed_keys(0, S)
     outs = vmap_train(make_train(dict(cfg), device="cuda:0"), keys)
-    assert _lib.last_kernel_form() == ("pos", "pair")
+    assert _lib.last_kernel_form() == ("pos", "pos")
     rs = outs["runner_state"]
     assert len(rs) == S and rs[0]["seed_batch"] == S and rs[0]["driver"] == "graph", rs[0]["driver_graph_error"]
     for s in (0, 7, 15):
         solo = make_train(dict(cfg), device="cuda:0")(keys[s])
-        assert _lib.last_kernel_form() == (("pos", "single") if pinned else ("single", "single"))
+        assert _lib.last_kernel_form() == (("pos", "pos") if pinned else ("single", "single"))
         if pinned:
             for k in ("td_loss", "qvals", "returned_episode_returns", "returned_episode_lengths", "returned_episode", "timestep"):
                 assert torch.equal(outs["metrics"][k][s], solo["metrics"][k]), (s, k)
@@ -200,7 +199,7 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
 
     one, d1 = run(1)
     two, d2 = run(2)
-    assert _lib.last_kernel_form() == ("pos", "pair")
+    assert _lib.last_kernel_form() == ("pos", "pos")
     assert type(d2).__name__ == "SeedGroupsDriver" and len(d2.drivers) == 2 and type(d1).__name__ == "SeedsUpdateDriver"
     assert two[0]["runner_state"]["seed_groups"] == 2 and two[0]["runner_state"]["seed_batch"] == S
     if tail == "graph":
@@ -239,7 +238,7 @@ def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked):
     update, finish = train.make_batch_runner(keys)
     update(0)
     outs = finish()
-    assert _lib.last_kernel_form() == ("pos", "pair") and cfg["NUM_UPDATES"] == 1
+    assert _lib.last_kernel_form() == ("pos", "pos") and cfg["NUM_UPDATES"] == 1
     otrain = oracle.make_train(ocfg)
     th0 = _np(theta0)
     for s in seeds_checked:

@@ -242,6 +242,75 @@ def test_cnn_rollout_equals_step_by_step(gpu, name, c, a, n, t, mode):
     assert torch.equal(words_b, st.words) and torch.equal(bits_b[0], bits) and torch.equal(rec_b["done"], rec["done"])
 
 
+@pytest.mark.parametrize("name,c,a,n,t", [("Breakout-MinAtar", 4, 3, 512, 40), ("Asterix-MinAtar", 4, 5, 256, 24),
+                                          ("Freeway-MinAtar", 7, 3, 256, 16), ("SpaceInvaders-MinAtar", 6, 4, 512, 24)])
+def test_position_structure_rollout_is_consistent_step_by_step(gpu, name, c, a, n, t):
+    """cnn_pos_rollout_kernel (pqn_qnet_pos.hip: one workgroup per 256 envs, the K loop of the training forward kernel per env
+    step; option rollout_pos = 2 forces it at these sizes) against the step-by-step pieces of the product: its q values are
+    summed in another order than the 16-env kernels', so actions may differ where the two best q values tie to f32 rounding
+    -- and nowhere else.  At every step, on the RECORDED observations: max_a Q equals pqn_qnet_cnn_forward's to 1e-5; the
+    recorded action equals the eps-greedy action of that kernel (same key, same draws) unless the top-two gap of q is below
+    1e-5 max|q|; and pqn_env_step from the recorded state with the RECORDED action reproduces reward, done, LogWrapper info and
+    the next packed observation bit for bit, as well as the final env state.  Also the evaluation mode (store_obs = 0) and
+    the bootstrap value.  _step_env scan, pqn_minatar.py:181-235."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.envs import LogWrapper, make
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, cnn_forward, cnn_rollout, matmul_mode
+    lib = _lib.load()
+    env, params = make(name, device=gpu)
+    env = LogWrapper(env)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode("bf16x3"))
+    torch.manual_seed(0)
+    theta_k = lay.to_kernel(net.init(3) + 0.05 * torch.randn(net.num_params, device=gpu))
+    (_o, bits0), state = env.reset(11, params, n, want_obs=False, want_bits=True)
+    for i in range(30):
+        (_o, bits0), state, *_ = env.step(500 + i, state, torch.randint(0, a, (n,), dtype=torch.int32, device=gpu), params,
+                                          want_obs=False, want_bits=True)
+    K = 0x7654321
+    keys = torch.empty(t, dtype=torch.int64, device=gpu)
+    _lib.check(lib.pqn_fold_in_range(K, 3, t, _lib.ptr(keys), _lib.stream_ptr()), "pqn_fold_in_range")
+    eps = torch.full((1,), 0.3, dtype=torch.float32, device=gpu)
+    env_id = env.env_id if hasattr(env, "env_id") else env._env.env_id
+    words_a = state.words.clone()
+    bits_a = torch.zeros((t + 1, n, bits0.shape[1]), dtype=bits0.dtype, device=gpu)
+    bits_a[0] = bits0
+    with _lib.options(rollout_pos=2):
+        rec = cnn_rollout(lay, env_id, words_a, bits_a, theta_k, keys, eps)
+        assert _lib.last_kernel_form()[1] == "pos"
+        rec2 = cnn_rollout(lay, env_id, state.words.clone(), bits_a.clone()[:1].repeat(t + 1, 1, 1).contiguous(), theta_k, keys, eps)
+    for k_ in rec:
+        assert torch.equal(rec[k_], rec2[k_]), k_          # repeats are bit-identical
+    st, ties = state, 0
+    for i in range(t):
+        k = _lib.fold_in(K, 3 + i)
+        q, act_ref, qmax_ref = cnn_forward(lay, bits_a[i].contiguous(), theta_k, eps=0.3, key=k)
+        torch.testing.assert_close(rec["qmax"][i], qmax_ref, rtol=1e-5, atol=1e-6)
+        top2 = torch.topk(q, 2, dim=1).values
+        tie = (top2[:, 0] - top2[:, 1]).abs() <= 1e-5 * q.abs().max()
+        diff = rec["action"][i] != act_ref
+        assert not bool((diff & ~tie).any()), (i, int((diff & ~tie).sum()))
+        ties += int(diff.sum())
+        (_o, nbits), st, r, d, info = env.step(k, st, rec["action"][i].contiguous(), params, want_obs=False, want_bits=True)
+        assert torch.equal(rec["reward"][i], r) and torch.equal(rec["done"][i].bool(), d.bool()), i
+        assert torch.equal(rec["returned_episode_returns"][i], info["returned_episode_returns"])
+        assert torch.equal(rec["returned_episode_lengths"][i], info["returned_episode_lengths"].to(torch.int32))
+        assert torch.equal(rec["timestep"][i], info["timestep"].to(torch.int32))
+        assert torch.equal(rec["discount"][i], info["discount"])
+        assert torch.equal(bits_a[i + 1], nbits), i
+    assert torch.equal(words_a, st.words) and ties <= max(2, n * t // 2000)
+    _q, _a, last = cnn_forward(lay, bits_a[t].contiguous(), theta_k, want_q=False)
+    torch.testing.assert_close(rec["last_q"], last, rtol=1e-5, atol=1e-6)
+    assert rec["done"].sum() > 0 or name == "Freeway-MinAtar"     # episode ends (auto-reset) inside the window; Freeway's episodes last 2500 steps
+    # evaluation mode: nothing recorded but the running observation
+    words_b = state.words.clone()
+    bits_b = bits0.clone().unsqueeze(0)
+    with _lib.options(rollout_pos=2):
+        rec_b = cnn_rollout(lay, env_id, words_b, bits_b, theta_k, keys, eps, store_obs=False, want_last_q=False)
+    assert torch.equal(words_b, words_a) and torch.equal(bits_b[0], bits_a[t]) and torch.equal(rec_b["done"], rec["done"])
+
+
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 64, 256), (4, 3, 4096, 20000), (7, 3, 256, 1024)])
 def test_cnn_f16_matmul_mode_vs_oracle(gpu, oracle, c, a, nb, pool):
     """MATMUL_DTYPE=f16 (pqn_cnn_layout_t.matmul_f16): fc1 forward / input gradient with fp16 operands and f32
