@@ -420,21 +420,39 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     }
     POSB_STAMP(3);
     x3_drain(gb[0], gs[0], gb[1], gs[1]);
-    // ---- relu mask + LayerNorm_0 backward (per point = per (kq, r); sums over the 16 channel lanes) ----
+    // ---- relu mask + LayerNorm_0 backward (per point = per (kq, r); sums over the 16 channel lanes, four at a time) ----
+    {
+      float dxh[2][4], dxx[2][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const f32x4 dh4 = gb[t] + gs[t];
-      const float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 dh4 = gb[t] + gs[t];
+        const float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float g = fmaf(xh[t][r], g0, be0) > 0.0f ? dh[r] : 0.0f;
-        gbi += g;
-        gsc = fmaf(g, xh[t][r], gsc);
-        const float dxh = g * g0;
-        const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[t][r]) * (1.0f / 16.0f);
-        dxv[t][r] = rs[t][r] * (dxh - s1 - xh[t][r] * s2);
-        gbc += dxv[t][r];
+        for (int r = 0; r < 4; ++r) {
+          const float g = fmaf(xh[t][r], g0, be0) > 0.0f ? dh[r] : 0.0f;
+          gbi += g;
+          gsc = fmaf(g, xh[t][r], gsc);
+          dxh[t][r] = g * g0;
+          dxx[t][r] = dxh[t][r] * xh[t][r];
+        }
       }
+      float s1[2][4], s2[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[t][r] = dxh[t][r]; s2[t][r] = dxx[t][r]; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        group16_sum4(s1[t][0], s1[t][1], s1[t][2], s1[t][3]);
+        group16_sum4(s2[t][0], s2[t][1], s2[t][2], s2[t][3]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dxv[t][r] = rs[t][r] * (dxh[t][r] - s1[t][r] * (1.0f / 16.0f) - xh[t][r] * (s2[t][r] * (1.0f / 16.0f)));
+          gbc += dxv[t][r];
+        }
     }
     POSB_STAMP(4);
     pos_prio<1>(wave);

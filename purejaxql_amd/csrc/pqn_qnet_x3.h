@@ -52,6 +52,32 @@ template <int N>
 PQN_D float row_ror(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
 }
+// four such sums at once, as ONE asm block of 16 v_add_f32_dpp (the DPP rotate fused into the add).  Through
+// __builtin_amdgcn_update_dpp the compiler emits v_mov_b32 0 / v_mov_b32_dpp / v_pk_add_f32 per step -- 2.5 instructions
+// where one does the work -- plus the wait states between a VALU write and a DPP read of the same register; here the four
+// independent chains are interleaved, so every DPP read sits three instructions behind the write it depends on (two wait
+// states are required) and only the block's first instruction needs padding.  Same butterfly, same bits as group16_sum.
+PQN_D void group16_sum4(float &a, float &b, float &c, float &d) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 PQN_D float group16_sum(float v) {
   v += row_ror<8>(v);
   v += row_ror<4>(v);
