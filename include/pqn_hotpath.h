@@ -368,14 +368,19 @@ int pqn_debug_t1_stamps(unsigned long long *out /* host, 64 entries */);
 /* The same for the bf16x3 fc1 weight-gradient kernel (workgroup 0): [0] start, [1] operands resident, [2..9] the eight
  * steps of the first row block, [10..25] the row blocks. */
 int pqn_debug_t2_stamps(unsigned long long *out /* host, 32 entries */);
+/* The same for the position-parallel kernels of a library built with -DPOS_STAMPS (tools/build_pos_variant.sh; the default
+ * build compiles the stamp stores out, because vector-memory stores inside the loops would drain the LDS-DMA ring):
+ * [0..7] one super-tile of the backward's loop, [16..27] one K step of the forward's loop and its tail phases. */
+int pqn_debug_pos_stamps(unsigned long long *out /* host, 32 entries */);
 /* Seeds covered by ONE launch of the training kernel (and therefore by one pqn_prof_read sample) when `nseeds` seeds
  * are batched: nseeds unless the profiling override PQN_SEED_GROUP cuts the launches into T1 -> T2 pairs per group. */
 int pqn_cnn_seed_group(int matmul_mode, int nseeds);
 
 /* Run-time switches of the kernel selection (profiling, A/B runs, tests; no reference counterpart -- XLA picks its
  * fusions itself).  Names: "t1_pair", "rollout_pair" (pair form of the bf16x3 training / rollout kernel: 0 never,
- * 1 when its grid fills the chip (default), 2 whenever the shape allows), "t1_pd2", "bwd_pos" (opt-in backward
- * variants), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height 64 / 128 -- a value above 128 = "128-row tiles from that many tiles
+ * 1 when its grid fills the chip (default), 2 whenever the shape allows), "bwd_pos", "rollout_pos" (position-parallel form of
+ * the bf16x3 training step / rollout, pqn_qnet_pos.hip: 0 never, 1 (default) when the launch fills the chip -- minibatch tiles of 256 x seeds >= 160 --
+ * or, under SEED_BATCH_BIT_IDENTICAL, from the per-seed size alone; 2 whenever the shape allows), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height 64 / 128 -- a value above 128 = "128-row tiles from that many tiles
  * up" -- / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP backward layer by layer on a second stream instead of batched behind
  * the input-gradient chain; default 0), "upd_overlap" (pqn_bigmlp_update: first permutation and last gradient-copy plane refresh on a side stream;
  * default 0, measured slower), "peer_timeout_s" (seconds pqn_peer_allreduce_mean waits for a peer; default 60), "t2_acc" (bf16x3 fc1 weight
@@ -392,8 +397,8 @@ int pqn_get_option(const char *name, int32_t *value /* host */);
  * epoch at capture and re-captures when it moved (purejaxql_amd/qnet.py drivers do). */
 int pqn_options_epoch(void);
 /* Which form the LAST enqueued training (pqn_qnet_cnn_grad / pqn_cnn_update*) and rollout (pqn_cnn_rollout*) launch
- * used: 0 none yet, 1 single-tile kernels, 2 pair kernels, 3 pair + paired dgrad, 4 pair forward + position-parallel
- * backward, 5 K-split kernels (small minibatches, f32 mode).  Lets a test assert in-process that the configuration it means to cover is the one that ran. */
+ * used: 0 none yet, 1 single-tile kernels, 2 pair kernels, 5 K-split kernels (small minibatches, f32 mode), 6 the position-parallel
+ * kernels of pqn_qnet_pos.hip (3 and 4 were round-2 variants, retired).  Lets a test assert in-process that the configuration it means to cover is the one that ran. */
 int pqn_cnn_last_kernel_form(int32_t *train_form /* host, nullable */, int32_t *rollout_form /* host, nullable */);
 
 /* ---- fused MLP Q-network (QNetwork of pqn_gymnax.py:29-58, layer_norm, NORM_INPUT=False) ----------- */

@@ -88,6 +88,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "pqn_debug_t1_stamps": (c_int, [c_void_p]),
     "pqn_debug_t2_stamps": (c_int, [c_void_p]),
+    "pqn_debug_pos_stamps": (c_int, [c_void_p]),
     "pqn_cnn_seed_group": (c_int, [c_int, c_int]),
     "pqn_set_option": (c_int, [C.c_char_p, c_int32]),
     "pqn_get_option": (c_int, [C.c_char_p, c_void_p]),
@@ -174,7 +175,7 @@ def prng_key(seed: int) -> int:
     return int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
-KERNEL_FORMS = {0: "none", 1: "single", 2: "pair", 3: "pair+pd2", 4: "pair+pos", 5: "ksplit", 6: "pos"}
+KERNEL_FORMS = {0: "none", 1: "single", 2: "pair", 5: "ksplit", 6: "pos"}
 
 
 def set_option(name: str, value: int):

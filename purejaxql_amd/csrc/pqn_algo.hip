@@ -40,9 +40,8 @@ static struct {
   bool init;
 } g_opts[PQN_OPT_COUNT] = {
     {"t1_pair", "PQN_T1_PAIR", 1, 0, false},       {"rollout_pair", "PQN_ROLLOUT_PAIR", 1, 0, false},
-    {"t1_pd2", "PQN_T1_PD2", 0, 0, false},         {"bwd_pos", "PQN_BWD_POS", 1, 0, false},
-    {"seed_group", "PQN_SEED_GROUP", 0, 0, false}, {"ablate_train", "PQN_ABLATE_TRAIN", 0, 0, false},
-    {"ablate", "PQN_ABLATE", 0, 0, false},
+    {"bwd_pos", "PQN_BWD_POS", 1, 0, false},       {"seed_group", "PQN_SEED_GROUP", 0, 0, false},
+    {"ablate_train", "PQN_ABLATE_TRAIN", 0, 0, false}, {"ablate", "PQN_ABLATE", 0, 0, false},
     {"bm_tile", "PQN_BM_TILE", 0, 0, false},       {"bm_split", "PQN_BM_SPLIT", 0, 0, false},
     {"t1_ksplit", "PQN_T1_KSPLIT", 1, 0, false},   {"t1_ksplit_tiles", "PQN_T1_KSPLIT_TILES", 48, 0, false},
     {"bm_overlap", "PQN_BM_OVERLAP", 0, 0, false}, {"peer_timeout_s", "PQN_PEER_TIMEOUT_S", 60, 0, false},

@@ -77,8 +77,7 @@ int pqn_check_launch(const char *what);
 enum {
   PQN_OPT_T1_PAIR = 0,    // PQN_T1_PAIR: pair form of the bf16x3 training kernel 0 never / 1 when its grid fills the chip / 2 always
   PQN_OPT_ROLLOUT_PAIR,   // PQN_ROLLOUT_PAIR: pair form of the bf16x3 rollout kernel, same meaning
-  PQN_OPT_T1_PD2,         // PQN_T1_PD2: opt-in paired-dgrad backward of the pair kernel
-  PQN_OPT_BWD_POS,        // PQN_BWD_POS: position-parallel form of the bf16x3 training step 0 off / 1 when the launch fills the chip / 2 whenever the shape allows / 3, 4: A/B forms (pqn_qnet.hip launch_train)
+  PQN_OPT_BWD_POS,        // PQN_BWD_POS: position-parallel form of the bf16x3 training step 0 off / 1 when the launch fills the chip (default) / 2 whenever the shape allows (pqn_qnet.hip launch_train)
   PQN_OPT_SEED_GROUP,     // PQN_SEED_GROUP: seeds per T1 -> T2 launch pair (0 = all)
   PQN_OPT_ABLATE_TRAIN,   // PQN_ABLATE_TRAIN: phase ablation mask of the training kernels (profiling)
   PQN_OPT_ABLATE,         // PQN_ABLATE: phase ablation of the forward kernel (profiling)
@@ -95,7 +94,8 @@ enum {
 };
 int pqn_opt(int id);
 // which form of the training / rollout kernels the last launch used (pqn_cnn_last_kernel_form)
-enum { PQN_FORM_NONE = 0, PQN_FORM_SINGLE = 1, PQN_FORM_PAIR = 2, PQN_FORM_PAIR_PD2 = 3, PQN_FORM_PAIR_POS = 4, PQN_FORM_KSPLIT = 5, PQN_FORM_POS = 6 };
+// (3 and 4 named round-2 opt-in variants that are gone; the numbers stay retired so that old logs keep their meaning)
+enum { PQN_FORM_NONE = 0, PQN_FORM_SINGLE = 1, PQN_FORM_PAIR = 2, PQN_FORM_KSPLIT = 5, PQN_FORM_POS = 6 };
 void pqn_note_kernel_form(int which /* 0 = training, 1 = rollout */, int form);
 
 // bf16x3 weight planes (pqn_qnet.hip): x = hi + mid + lo exactly, each a bf16 (round to nearest even); element (i, o)

@@ -414,11 +414,7 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
   if (NT == 2) { arow[NT - 1] = s2->h1 + (lane & 15) * QN_H1S; zt[NT - 1] = s2->z; }
   const int kq4 = 4 * (lane >> 4);
   auto wfrag = [&](int p, int st, int c) {   // plane p, K step st (global), column block 2cp + c
-#ifdef T1_NO_WLOAD
-    return wf[(size_t)p * (X3_PLANE / 8) + ((0 * 8 + 2 * cp + c) * 64 + lane)];
-#else
     return wf[(size_t)p * (X3_PLANE / 8) + ((st * 8 + 2 * cp + c) * 64 + lane)];
-#endif
   };
   // Independent accumulators {small, leading terms} x column block x tile: a dependent v_mfma_f32_16x16x32_bf16 issues
   // ~90 counter ticks after its producer and the pipe takes one per ~10 (tools/ubench/mfma_issue.hip); the MFMAs of a
@@ -488,7 +484,6 @@ PQN_D void phase2_fc1_x3(const CnnSmem &s, const float *__restrict__ planes, int
     side(g + i, i);
     __builtin_amdgcn_sched_barrier(0);
   };
-  x3_skew<X3_SKEW_FC1>(wave);
   int g = 0;
 #pragma unroll 1
   for (; g + 2 * PF <= NS; g += PF) {
@@ -898,11 +893,7 @@ PQN_D float group32_sum(float v) {
 
 // stores of the T1 -> T2 hand-over operands (h1^T, dz^T: 18 MB per seed and launch, never read again by this kernel)
 PQN_D void ws_store(f32x4 *p, const f32x4 &v) {
-#ifdef T1_PLAIN_STORES   // A/B hook
-  *p = v;
-#else
   __builtin_nontemporal_store(v, p);   // streaming: keeps the weight planes in L2 (-1 % on the 16-seed launch)
-#endif
 }
 
 // Head of the training kernel.  Forward: z + b1 -> LN(128) -> relu -> fc2 -> q_a -> loss
@@ -917,8 +908,7 @@ PQN_D void ws_store(f32x4 *p, const f32x4 &v) {
 // and its order are those of NT = 1, so a tile gets the same bits from both forms.
 template <int C, int NA, int NT>
 PQN_D void train_head_nt(const CnnSmem (&sv)[NT], const TrainSmem (&tv)[NT], const pqn_cnn_layout_t &L, int tid, int nb,
-                         const int (&b0v)[NT], float inv_b, float *const (&gpv)[NT], float *__restrict__ dzT, float dz_scale,
-                         unsigned short *__restrict__ dzp = nullptr) {
+                         const int (&b0v)[NT], float inv_b, float *const (&gpv)[NT], float *__restrict__ dzT, float dz_scale) {
   constexpr int NAQ = NA ? NA : QN_MAXA;
   const int na = NA ? NA : L.a;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1062,34 +1052,6 @@ PQN_D void train_head_nt(const CnnSmem (&sv)[NT], const TrainSmem (&tv)[NT], con
         for (int r = 0; r < 8; ++r) vv[r] = (_Float16)(s.z[(8 * hh + r) * QN_ZS + o] * dz_scale);
         *reinterpret_cast<f16x8 *>(dzP + (size_t)o * QN_TILE + 8 * hh) = vv;
       }
-    } else if (dzp) {
-      // position-parallel backward (qnet_cnn_bwd_pos_kernel): dz leaves as bf16 planes, already split, in the two MFMA
-      // operand orders that kernel reads -- dzA (A of the dgrad, sample rows) and dzB (B of the dW1 product, 4-sample
-      // K groups); see dz_planes_a / dz_planes_b
-      typedef unsigned u2 __attribute__((ext_vector_type(2)));
-      {
-        const int ms = tid >> 5, q = tid & 31;                // sample, (sK, kq, h) = 4 consecutive outputs
-        const int sK = q >> 3, kq = (q >> 1) & 3, h = q & 1;
-        const float *zr = s.z + ms * QN_ZS + 32 * sK + 16 * h + 4 * kq;
-        unsigned hh[2], mm[2], ll[2];
-        x3_split2(zr[0], zr[1], hh[0], mm[0], ll[0]);
-        x3_split2(zr[2], zr[3], hh[1], mm[1], ll[1]);
-        const size_t e = dz_planes_a(nb, b0 + ms, sK, kq) + 4 * h;
-        *reinterpret_cast<u2 *>(dzp + e) = u2{hh[0], hh[1]};
-        *reinterpret_cast<u2 *>(dzp + (size_t)nb * QN_HID + e) = u2{mm[0], mm[1]};
-        *reinterpret_cast<u2 *>(dzp + 2 * (size_t)nb * QN_HID + e) = u2{ll[0], ll[1]};
-      }
-      {
-        const int o = tid >> 2, kq = tid & 3;                 // output, samples 4 kq .. 4 kq + 3 of the tile
-        const float *zc = s.z + (4 * kq) * QN_ZS + o;
-        unsigned hh[2], mm[2], ll[2];
-        x3_split2(zc[0], zc[QN_ZS], hh[0], mm[0], ll[0]);
-        x3_split2(zc[2 * QN_ZS], zc[3 * QN_ZS], hh[1], mm[1], ll[1]);
-        unsigned short *pb = dzp + 3 * (size_t)nb * QN_HID + dz_planes_b(b0 / QN_TILE, o >> 4, kq * 16 + (o & 15));
-        *reinterpret_cast<u2 *>(pb) = u2{hh[0], hh[1]};
-        *reinterpret_cast<u2 *>(pb + 512) = u2{mm[0], mm[1]};
-        *reinterpret_cast<u2 *>(pb + 1024) = u2{ll[0], ll[1]};
-      }
     } else if (L.matmul_f16 == 2) {
       // bf16x3: dz leaves already split, in T2's operand order (dzw_index): T2 loads its B fragments with no arithmetic
       typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -1139,13 +1101,12 @@ PQN_D void train_head_nt(const CnnSmem (&sv)[NT], const TrainSmem (&tv)[NT], con
 
 template <int C, int NA>
 PQN_D void train_head(const CnnSmem &s, const TrainSmem &ts, const pqn_cnn_layout_t &L, int tid, int nb, int b0,
-                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT, float dz_scale,
-                      unsigned short *__restrict__ dzp = nullptr) {
+                      float inv_b, float *__restrict__ gp, float *__restrict__ dzT, float dz_scale) {
   const CnnSmem sv[1] = {s};
   const TrainSmem tv[1] = {ts};
   const int b0v[1] = {b0};
   float *const gpv[1] = {gp};
-  train_head_nt<C, NA, 1>(sv, tv, L, tid, nb, b0v, inv_b, gpv, dzT, dz_scale, dzp);
+  train_head_nt<C, NA, 1>(sv, tv, L, tid, nb, b0v, inv_b, gpv, dzT, dz_scale);
 }
 
 // profiling: per-phase s_memtime stamps of workgroup 0 / wave 0 (PQN_T1_STAMPS=1), read by tools/t1_stamps.py
@@ -1172,11 +1133,7 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
     constexpr int IBW = 64 / QN_WAVES;
     const int ib_first = IBW * wave;
     auto frag = [&](int pl, int ibk, int sK) {   // plane pl, the wave's ibk-th i-block (rotated), K step sK
-#ifdef T1_NO_WLOAD
-      const int ib = ib_first;
-#else
       const int ib = ib_first + ((ibk + prot) & (IBW - 1));
-#endif
       return wd[(size_t)pl * (X3_PLANE / 8) + ((ib * 4 + sK) * 64 + lane)];
     };
     u32x4 ring[4][3];
@@ -1225,20 +1182,11 @@ PQN_D void t1_dgrad_x3(const float *zt, float *out, const uint32_t *mask, const 
       p0[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
       p0[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
     };
-    x3_skew<X3_SKEW_DGRAD>(wave);
 #pragma unroll 1
     for (int ibk = 0; ibk < IBW - 1; ++ibk) ib_step(ibk, std::true_type{});
     ib_step(IBW - 1, std::false_type{});
 }
 
-// =====================================================================================================================
-// Opt-in "paired dgrad" form of the pair kernel's backward (PQN_T1_PD2=1).  Pieces:
-//   pd2_dz_planes       tile B's dz tile as pre-split dgrad A fragments in LDS (12 KB over z B + the parameter block)
-//   t1_dgrad_pair2_x3   rolled i-block loop, ONE pass over the dgrad-order planes for both tiles; results in place on
-//                       h1 A and into the h1 B region (which therefore stops being scratch)
-//   t1_ln0_bwd_ns       LN0 backward without the 40 KB staging buffer (channel sums by lane-swap reductions)
-//   t1_conv_wgrad_2r    conv weight gradient with its eight wave partials folded in two rounds of four (12 KB)
-// =====================================================================================================================
 // sum over the 64 lanes of each of 16 per-lane values; afterwards lane l holds, in out[r] (r = 0..3), the wave total of
 // value 8 (l >> 5) + 4 ((l >> 4) & 1) + r -- every lane of a 16-lane row holds the same four totals.  Halving by lane
 // swaps (v_permlane32_swap / v_permlane16_swap: 8 + 4 swaps), then a DPP row sum of the remaining four: fixed order.
@@ -1325,223 +1273,6 @@ PQN_D void t1_ln0_bwd_ns(float *dh1, float *red, const float *__restrict__ theta
     for (int w = 0; w < QN_WAVES; ++w) acc += red[w * 48 + tid];
     gp[Cfg::KW * 16 + tid] = acc;
   }
-}
-
-// conv weight gradient of one tile (bf16x3 operands, the C = 4 shape: wave = sample pair, all three row blocks): the
-// MFMA part of t1_conv_wgrad<C, 2>, the eight wave partials folded through 12 KB in two rounds of four -- the same
-// sum ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).  wm_base: QN_WAVES x 192 words; scr: 4 x NRB x 256 floats.
-template <int C>
-PQN_D void t1_conv_wgrad_2r(const float *dx, const uint32_t *bits, uint32_t *wm_base, float *scr, float *__restrict__ gp, int tid) {
-  using Cfg = CnnCfg<C>;
-  const int lane = tid & 63, wave = tid >> 6;
-  constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C;
-  static_assert((NRB % 2) == 1 && QN_WAVES == 8, "wave = sample pair, all row blocks");
-  const int sg = wave;
-  const int i = lane & 15, kk = lane >> 4;
-  int kyL[NRB], shL[NRB];
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) {
-    const int k = 16 * j + i;
-    kyL[j] = (k < 9 * C) ? k / RB : 0;
-    shL[j] = (k < 9 * C) ? k % RB : 31;
-  }
-  f32x4 acc[NRB], accs[NRB];
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; accs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  uint32_t *wm = wm_base + wave * 192;
-#pragma unroll
-  for (int mm = 0; mm < 2; ++mm) {
-    const int msamp = 2 * sg + mm;
-    window_masks<C>(bits + msamp * Cfg::OW, wm, lane);
-    float bv[16];
-    uint32_t wv[16][NRB];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      bv[q] = dx[msamp * QN_H1S + h1_slot(lane + 64 * q)];   // (dx keeps the quad swizzle of the h1 tile)
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) wv[q][j] = wm[(4 * q + kk) * 3 + kyL[j]];
-    }
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      const float *b = bv + 8 * st;
-      const X3Frag bf = x3_split8(f32x4{b[0], b[1], b[2], b[3]}, f32x4{b[4], b[5], b[6], b[7]});
-      u32x4 af[NRB];
-#pragma unroll
-      for (int j = 0; j < NRB; ++j) {
-        uint32_t d[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const uint32_t b0 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj][j], (uint32_t)shL[j], 1u);
-          const uint32_t b1 = __builtin_amdgcn_ubfe(wv[8 * st + 2 * jj + 1][j], (uint32_t)shL[j], 1u);
-          d[jj] = ((b1 << 16) | b0) << 14;
-        }
-        af[j] = u32x4{d[0], d[1], d[2], d[3]};
-      }
-      x3_grp_sameb<NRB>(accs, af, bf.l);
-      x3_grp_sameb<NRB>(acc, af, bf.h);
-      x3_grp_sameb<NRB>(accs, af, bf.m);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) {
-    x3_drain(acc[j], accs[j]);
-    acc[j] = (acc[j] + accs[j]) * (0.5f / 255.0f);
-  }
-  auto put = [&](int slot) {
-#pragma unroll
-    for (int j = 0; j < NRB; ++j) {
-      float *pp = scr + ((slot * NRB + j) * 16 + 4 * kk) * 16 + i;
-      pp[0] = acc[j].x; pp[16] = acc[j].y; pp[32] = acc[j].z; pp[48] = acc[j].w;
-    }
-  };
-  constexpr int NE = Cfg::KW * 16, NEI = (NE + QN_THREADS - 1) / QN_THREADS;
-  float half0[NEI];
-  if (sg < 4) put(sg);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NEI; ++q) {
-    const int e = tid + q * QN_THREADS;
-    const float *pp = scr + min(e, NE - 1);
-    half0[q] = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
-  }
-  __syncthreads();
-  if (sg >= 4) put(sg - 4);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NEI; ++q) {
-    const int e = tid + q * QN_THREADS;
-    const float *pp = scr + min(e, NE - 1);
-    const float half1 = (pp[0] + pp[NRB * 256]) + (pp[2 * NRB * 256] + pp[3 * NRB * 256]);
-    if (e < NE) gp[e] = half0[q] + half1;
-  }
-}
-
-// xhat[sample][position][16 channels] of a tile parked in global memory between the conv and the LN0 backward (lane =
-// position: 64 contiguous bytes per lane and sample, 4 KB per wave; written and read back by the same lane).  The slot is the tile's share of the split-K slab
-// region of the workspace, which T2 only writes after this kernel: nb x 2 KB per seed on both sides.
-PQN_D void xk_park(float *__restrict__ slot, const float (*xk)[16], int lane, int wave) {
-#pragma unroll
-  for (int mm = 0; mm < QN_SPW; ++mm) {
-    f32x4 *dst = reinterpret_cast<f32x4 *>(slot + ((size_t)(QN_SPW * wave + mm) * 64 + lane) * 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      dst[q] = f32x4{xk[mm][4 * q], xk[mm][4 * q + 1], xk[mm][4 * q + 2], xk[mm][4 * q + 3]};   // L2-resident: streaming stores / loads measured slower
-  }
-}
-PQN_D void xk_fetch(const float *__restrict__ slot, float (*xk)[16], int lane, int wave) {
-#pragma unroll
-  for (int mm = 0; mm < QN_SPW; ++mm) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(slot + ((size_t)(QN_SPW * wave + mm) * 64 + lane) * 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = src[q];
-      xk[mm][4 * q] = v.x; xk[mm][4 * q + 1] = v.y; xk[mm][4 * q + 2] = v.z; xk[mm][4 * q + 3] = v.w;
-    }
-  }
-}
-
-PQN_D void pd2_dz_planes(const float *zt, u32x4 *planes, int lane, int wave) {   // planes may overlap zt: two barriers inside
-  X3Frag f;
-  if (wave < 4) {
-    const int sK = wave;
-    const f32x4 lo = *reinterpret_cast<const f32x4 *>(zt + (lane & 15) * QN_ZS + 32 * sK + 4 * (lane >> 4));
-    const f32x4 hi = *reinterpret_cast<const f32x4 *>(zt + (lane & 15) * QN_ZS + 32 * sK + 16 + 4 * (lane >> 4));
-    f = x3_split8(lo, hi);
-  }
-  __syncthreads();
-  if (wave < 4) {
-    const int sK = wave;
-    planes[(sK * 3 + 0) * 64 + lane] = f.h; planes[(sK * 3 + 1) * 64 + lane] = f.m; planes[(sK * 3 + 2) * 64 + lane] = f.l;
-  }
-  __syncthreads();
-}
-
-// the dgrad of both tiles against one pass over the planes (see the block comment above).  Per tile and accumulator the
-// MFMA sequence is that of t1_dgrad_x3: same bits.
-PQN_D void t1_dgrad_pair2_x3(const float *ztA, float *outA, const u32x4 *planesB, float *outB, const uint32_t *maskB,
-                             const float *__restrict__ theta, const pqn_cnn_layout_t &L, int lane, int wave, int prot) {
-  const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
-  X3Frag afr[4];
-#pragma unroll
-  for (int sK = 0; sK < 4; ++sK) {
-    const f32x4 lo = *reinterpret_cast<const f32x4 *>(ztA + (lane & 15) * QN_ZS + 32 * sK + 4 * (lane >> 4));
-    const f32x4 hi = *reinterpret_cast<const f32x4 *>(ztA + (lane & 15) * QN_ZS + 32 * sK + 16 + 4 * (lane >> 4));
-    afr[sK] = x3_split8(lo, hi);
-  }
-  const int col = lane & 15, r0 = 4 * (lane >> 4);
-  constexpr int IBW = 64 / QN_WAVES;
-  const int ib_first = IBW * wave;
-  auto frag = [&](int pl, int ibk, int sK) {
-    const int ib = ib_first + ((ibk + prot) & (IBW - 1));
-    return wd[(size_t)pl * (X3_PLANE / 8) + ((ib * 4 + sK) * 64 + lane)];
-  };
-  auto bfrag = [&](int sK) {
-    X3Frag b;
-    b.h = planesB[(sK * 3 + 0) * 64 + lane]; b.m = planesB[(sK * 3 + 1) * 64 + lane]; b.l = planesB[(sK * 3 + 2) * 64 + lane];
-    return b;
-  };
-  u32x4 ring[4][3];
-#pragma unroll
-  for (int sK = 0; sK < 4; ++sK)
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, 0, sK);
-  auto ib_step = [&](int ibk, auto more_t) {
-    constexpr bool more = decltype(more_t)::value;
-    const int ib = ib_first + ((ibk + prot) & (IBW - 1));
-    const int off = r0 * QN_H1S + h1_slot(16 * ib + col);   // forward h1 and dh1 / dx tiles share the quad swizzle
-    float *pA = outA + off, *pB = outB + off;
-    const float m0 = pA[0], m1 = pA[QN_H1S], m2 = pA[2 * QN_H1S], m3 = pA[3 * QN_H1S];   // tile A: relu mask = its h1, in place
-    const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(maskB) + ib * 4;   // tile B: packed bits
-    const int bsel = col * 4 + (lane >> 4);
-    const unsigned long long w0 = mw[0], w1 = mw[1], w2 = mw[2], w3 = mw[3];
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    {   // tile A
-      f32x4 acc_b[2] = {z4, z4}, acc_s[2] = {z4, z4}, acc_c[2] = {z4, z4};
-#pragma unroll
-      for (int sK = 0; sK < 4; ++sK) {
-        X3Frag bf;
-        bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
-        const X3Frag &a = afr[sK];
-        x3_grp6(acc_s[0], a.l, bf.h, acc_b[0], a.m, bf.h, acc_s[1], a.h, bf.l, acc_b[1], a.h, bf.m, acc_c[0], a.m, bf.m, acc_c[1], a.h, bf.h);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
-      x3_drain(acc_c[0], acc_c[1]);
-      const f32x4 acc0 = ((acc_b[0] + acc_b[1]) + acc_c[1]) + ((acc_s[0] + acc_s[1]) + acc_c[0]);
-      pA[0] = m0 > 0.0f ? acc0.x : 0.0f;
-      pA[QN_H1S] = m1 > 0.0f ? acc0.y : 0.0f;
-      pA[2 * QN_H1S] = m2 > 0.0f ? acc0.z : 0.0f;
-      pA[3 * QN_H1S] = m3 > 0.0f ? acc0.w : 0.0f;
-    }
-    {   // tile B: the same plane fragments once more, its own dz fragments from LDS one K step ahead
-      f32x4 acc_b[2] = {z4, z4}, acc_s[2] = {z4, z4}, acc_c[2] = {z4, z4};
-      X3Frag bq = bfrag(0);
-#pragma unroll
-      for (int sK = 0; sK < 4; ++sK) {
-        X3Frag bf;
-        bf.h = ring[sK][0]; bf.m = ring[sK][1]; bf.l = ring[sK][2];
-        const X3Frag a = bq;
-        if (sK + 1 < 4) bq = bfrag(sK + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        x3_grp6(acc_s[0], a.l, bf.h, acc_b[0], a.m, bf.h, acc_s[1], a.h, bf.l, acc_b[1], a.h, bf.m, acc_c[0], a.m, bf.m, acc_c[1], a.h, bf.h);
-        if (more) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) ring[sK][pl] = frag(pl, ibk + 1, sK);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      x3_drain(acc_b[0], acc_s[0], acc_b[1], acc_s[1]);
-      x3_drain(acc_c[0], acc_c[1]);
-      const f32x4 acc0 = ((acc_b[0] + acc_b[1]) + acc_c[1]) + ((acc_s[0] + acc_s[1]) + acc_c[0]);
-      pB[0] = ((w0 >> bsel) & 1ull) ? acc0.x : 0.0f;
-      pB[QN_H1S] = ((w1 >> bsel) & 1ull) ? acc0.y : 0.0f;
-      pB[2 * QN_H1S] = ((w2 >> bsel) & 1ull) ? acc0.z : 0.0f;
-      pB[3 * QN_H1S] = ((w3 >> bsel) & 1ull) ? acc0.w : 0.0f;
-    }
-  };
-#pragma unroll 1
-  for (int ibk = 0; ibk < IBW - 1; ++ibk) ib_step(ibk, std::true_type{});
-  ib_step(IBW - 1, std::false_type{});
 }
 
 // ---- P5: LN0 backward of one 16-sample tile, in place on dh1 (d relu-input -> dx); ends with the workgroup barrier
@@ -1813,14 +1544,12 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
     // h1^T for T2 (slab-major, h1s_index) leaves during fc1, one 512-thread slice at every second K step, in the
     // shadow of the weight stream (see the pair kernel)
     auto h1t_slice = [&](int j, int) {
-#ifndef T1_NO_H1T
       if (!(j & 1)) {
         const int e = tid + (j >> 1) * QN_THREADS, i = e >> 2, mq = e & 3;
         const float *src = s.h1 + (4 * mq) * QN_H1S + h1_slot(i);
         const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
         ws_store(reinterpret_cast<f32x4 *>(h1T + h1s_index(i, b0 + 4 * mq)), v);
       }
-#endif
     };
     phase2_fc1_x3<3>(s, theta + L.off_w1h, tid, -1, nullptr, h1t_slice);
   } else phase2_fc1<0>(s, theta + L.off_w1, tid);
@@ -1838,14 +1567,12 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_kernel(
       *reinterpret_cast<f16x8 *>(h1P + (size_t)i * QN_TILE + 8 * hh) = v;
     }
   } else if (MODE == 0) {
-#ifndef T1_NO_H1T
     for (int e = tid; e < QN_H1 * 4; e += QN_THREADS) {
       const int i = e >> 2, mq = e & 3;
       const float *src = s.h1 + (4 * mq) * QN_H1S + i;
       const f32x4 v = {src[0], src[QN_H1S], src[2 * QN_H1S], src[3 * QN_H1S]};
       ws_store(reinterpret_cast<f32x4 *>(h1T + (size_t)i * qw_ld(nb) + b0 + 4 * mq), v);
     }
-#endif
   }
   if (tid < QN_TILE) {
     ts.act[tid] = act_g;
@@ -2470,16 +2197,12 @@ struct PairSmem {
   static_assert(2 * 3 * QN_TILE * QN_ZS <= QN_TILE * QN_H1S, "the staged tiles of both heads (train_head_nt<.., 2>) must fit h1 B");
 };
 
-// FWD_ONLY: the forward half for the position-parallel backward -- conv, fc1, heads; dz leaves as bf16 planes in the
-// (then unused) h1^T region; no h1^T, no relu masks, no LN0 state kept, no backward below the heads.
-// PD2: the opt-in paired-dgrad backward (see t1_dgrad_pair2_x3); xkws = the seed's split-K slab region of the workspace
-template <int C, bool FWD_ONLY, bool PD2 = false>
+template <int C>
 __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
     int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const int32_t *__restrict__ action,
     const float *__restrict__ target, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
     float *__restrict__ dzT, float *__restrict__ h1T, float *__restrict__ gpart, int ablate, pqn_seeds_t sd, float dz_scale,
-    unsigned long long *__restrict__ stamps, float *__restrict__ xkws = nullptr) {
-  static_assert(!(FWD_ONLY && PD2), "the paired dgrad belongs to the full kernel");
+    unsigned long long *__restrict__ stamps) {
   using Cfg = CnnCfg<C>;
   using PS = PairSmem<C>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2499,7 +2222,6 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   dzT += seed * sd.ws_stride;
   h1T += seed * sd.ws_stride;
   gpart += seed * sd.ws_stride;
-  if (PD2) xkws += seed * sd.ws_stride;
   auto row_of = [&](int64_t key) -> int64_t {
     const uint32_t j = (uint32_t)(key & sd.idx_mask);
     if (sd.n_env_total == sd.n_env) return (int64_t)j;
@@ -2572,15 +2294,12 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   T1_STAMP(1);
   // ---- forward: conv of both tiles, then fc1 of both against one pass over the weight planes ----
   float xkA[QN_SPW][16], rkA[QN_SPW], xkB[QN_SPW][16], rkB[QN_SPW];
-  phase1_conv<C, !FWD_ONLY, true, true>(sT[0], tid, xkA, rkA);
+  phase1_conv<C, true, true, true>(sT[0], tid, xkA, rkA);
   T1_STAMP(2);
-  phase1_conv<C, !FWD_ONLY, true, true>(sT[1], tid, xkB, rkB);
-  float *slotB = PD2 ? xkws + (size_t)pair_id * (QN_TILE * 64 * 16) : nullptr;
-  if (PD2) xk_park(slotB, xkB, lane, wave);   // tile B's xhat leaves the register file until its LN0 backward
+  phase1_conv<C, true, true, true>(sT[1], tid, xkB, rkB);
   __syncthreads();
   T1_STAMP(3);
-  if (FWD_ONLY) phase2_fc1_x3<3, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1]);   // no LN0 state alive: room for a 3-deep ring
-  else {
+  {
     // h1^T for T2 (slab-major, h1s_index) leaves DURING fc1: K step j of every wave also stores one 512-thread slice
     // (tile j & 1, slice j >> 1) of the two h1 tiles, and tile B leaves its relu mask as bits on the way.  h1 is only
     // read in this phase, so the order against the MFMA operand reads does not matter.
@@ -2599,13 +2318,7 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
         }
       }
     };
-#ifdef T1_H1T_AFTER   // A/B hook: the stores as a phase of their own behind fc1
-    phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1]);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) h1t_slice(j, j & 1);
-#else
     phase2_fc1_x3<2, 2>(sT[0], theta + L.off_w1h, tid, pair_id, &sT[1], h1t_slice);
-#endif
   }
   T1_STAMP(4);
   if (tid < 2 * QN_TILE) {
@@ -2617,44 +2330,15 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_train_pair_kernel(
   // ---- heads (both tiles together) ----
   {
     float *const gpv[2] = {gpT[0], gpT[1]};
-    unsigned short *dzpl = FWD_ONLY ? reinterpret_cast<unsigned short *>(h1T) : nullptr;
     switch (L.a) {
-      case 3: train_head_nt<C, 3, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale, dzpl); break;
-      case 4: train_head_nt<C, 4, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale, dzpl); break;
-      case 6: train_head_nt<C, 6, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale, dzpl); break;
-      default: train_head_nt<C, 0, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale, dzpl); break;
+      case 3: train_head_nt<C, 3, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale); break;
+      case 4: train_head_nt<C, 4, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale); break;
+      case 6: train_head_nt<C, 6, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale); break;
+      default: train_head_nt<C, 0, 2>(sT, tsT, L, tid, nb, b0T, inv_b, gpv, dzT, dz_scale); break;
     }
   }
   T1_STAMP(6);
-  if (FWD_ONLY) return;
   const int prot = pair_id & (64 / QN_WAVES - 1);
-  if constexpr (PD2) {
-    // ---- backward, paired-dgrad form: dgrad of both tiles in one pass over the planes (A in place on h1 A, B into
-    // the h1 B region), LN0 backward of both without staging, conv weight gradients with their scratch in the dead
-    // z / parameter tiles ----
-    u32x4 *planesB = reinterpret_cast<u32x4 *>(zB);                   // 12 KB over z B | conv parameters | head parameters
-    uint32_t *wm2 = reinterpret_cast<uint32_t *>(zA);                 // 6 KB of window masks ...
-    float *scr2 = zA + QN_WAVES * 192;                                // ... and 12 KB of wave partials, all inside z A .. hp
-    float *redB = reinterpret_cast<float *>(maskB);                   // tile B's cross-wave sums (the mask bits are dead by then)
-    static_assert(sizeof(float) * (QN_WAVES * 192 + 4 * ((9 * C + 15) / 16) * 256) <=
-                      sizeof(float) * (2 * QN_TILE * QN_ZS + PS::WCN + PS::HP_MIN), "conv-wgrad scratch must fit z A .. hp");
-    static_assert(12288 <= sizeof(float) * (QN_TILE * QN_ZS + PS::WCN + PS::HP_MIN), "dz planes of tile B must fit z B .. hp");
-    static_assert(QN_WAVES * 48 * sizeof(float) <= QN_TILE * 32 * sizeof(uint32_t), "tile B's sums must fit the mask bits");
-    pd2_dz_planes(zB, planesB, lane, wave);
-    t1_dgrad_pair2_x3(zA, h1A, planesB, h1B, maskB, theta, L, lane, wave, prot);
-    __syncthreads();
-    T1_STAMP(7);
-    xk_fetch(slotB, xkB, lane, wave);   // back from L2 while tile A's LN0 backward runs
-    t1_ln0_bwd_ns<C>(h1A, red, theta, L, xkA, rkA, gpT[0], tid);
-    t1_ln0_bwd_ns<C>(h1B, redB, theta, L, xkB, rkB, gpT[1], tid);
-    T1_STAMP(8);
-    t1_conv_wgrad_2r<C>(h1A, bitsA, wm2, scr2, gpT[0], tid);
-    __syncthreads();   // tile A's partials fully read
-    T1_STAMP(9);
-    t1_conv_wgrad_2r<C>(h1B, bitsB, wm2, scr2, gpT[1], tid);
-    T1_STAMP(10);
-    return;
-  }
   // ---- backward of A in place on h1 A, then of B into the same region ----
   t1_dgrad_x3<false>(zA, h1A, nullptr, theta, L, lane, wave, prot);
   __syncthreads();
@@ -2789,419 +2473,6 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_cnn_rollout_pair_kernel(
     for (int i = 0; i < Env::ENV_WORDS; ++i) state[(size_t)i * n + e] = w[i];
     log.store(state, n, e, Env::ENV_WORDS);
   }
-}
-
-// ---------------------------------------------------------------------------
-// Position-parallel backward (bf16x3 mode, many seeds per launch).  Everything below fc1 is local to a conv position:
-// h1[m][16 pos + ch] depends only on sample m's 3x3 window at pos, LayerNorm_0 is per point, and the dgrad columns /
-// dW1 rows of a position need only that position's 16 rows of W1.  Workgroup = (seed, group of 4 positions) for ALL
-// samples of the minibatch; wave w = (position 4 pg + (w & 3), sample-tile parity w >> 2).  Per 16-sample tile a wave
-//   a. rebuilds the window masks of its position for the 16 samples (gathered observation bits),
-//   b. recomputes conv + LN0 (D layout: lane = channel, 4 samples per lane; channel sums are DPP row reductions),
-//   c. dgrad  dh1 = dz W1p^T  (A = dz planes from the forward kernel, B = the position's 48 resident plane fragments),
-//   d. relu mask, LN0 backward, running channel sums,
-//   e. conv weight gradient  dWc += bits^T dx   (K = 16 samples, v_mfma_f32_16x16x16_bf16; dx is already in B layout),
-//   f. dW1p += h1^T dz  (h1 is already in A layout; B = dz planes in 4-sample K groups), accumulated in registers over
-//      the whole minibatch: no split-K partial tiles, no h1^T hand-over, no weight-plane stream.
-// The two parities of a position are folded through LDS at the end; conv / LN0 partials of the 8 waves in fixed order.
-// ---------------------------------------------------------------------------
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-PQN_D f32x4 x3_mfma16_tied(const u32x2 &a, const u32x2 &b, f32x4 c) {   // K = 16 form, same rules as x3_mfma_tied
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-  return c;
-}
-struct X3Frag16 {
-  u32x2 h, m, l;
-};
-PQN_D X3Frag16 x3_split4(float x0, float x1, float x2, float x3) {
-  unsigned h0, m0, l0, h1, m1, l1;
-  x3_split2(x0, x1, h0, m0, l0);
-  x3_split2(x2, x3, h1, m1, l1);
-  X3Frag16 f;
-  f.h = u32x2{h0, h1}; f.m = u32x2{m0, m1}; f.l = u32x2{l0, l1};
-  return f;
-}
-
-// LDS plan of qnet_cnn_bwd_pos_kernel (16-B units unless noted): dzA[2][1536] | dzB[2][1536] | exchange[2][4 pos][6][64]
-// | window masks u32 [2][4][32][4] | conv parameters
-template <int C>
-constexpr size_t bwd_pos_lds_bytes() {
-  return 16 * (2 * 1536 + 2 * 1536 + 2 * 4 * 6 * 64) + 4 * (2 * 4 * 32 * 4) + 4 * (((9 * C * 16 + 48) + 3) & ~3);
-}
-template <int C>
-__global__ __launch_bounds__(QN_THREADS) void qnet_cnn_bwd_pos_kernel(
-    int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits, const float *__restrict__ theta,
-    pqn_cnn_layout_t L, const unsigned short *__restrict__ dzp, float *__restrict__ w1out, float *__restrict__ gpos,
-    pqn_seeds_t sd, unsigned long long *__restrict__ stamps) {
-#define BP_STAMP(k) do { if (stamps && js == 8 && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == 4)) stamps[(wave ? 16 : 0) + (k)] = __builtin_readcyclecounter(); } while (0)
-  using Cfg = CnnCfg<C>;
-  constexpr int NRB = (9 * C + 15) / 16, RB = 3 * C, CONVBLK = Cfg::KW * 16 + 48;
-  constexpr int RBH = (NRB + 1) / 2;     // conv-wgrad row blocks per back wave
-  extern __shared__ __attribute__((aligned(16))) char bp_smem[];
-  u32x4 *s_dza = reinterpret_cast<u32x4 *>(bp_smem);          // [2][3 pl][32 samples][16 quads], quads XOR-swizzled with the sample
-  u32x4 *s_dzb = s_dza + 2 * 1536;                             // [2][8 cb][3 pl][64 lanes]
-  u32x4 *s_ex = s_dzb + 2 * 1536;                              // [2][4 pos][h1 h,m,l | dx h,m,l][64 lanes]
-  uint32_t *s_mk = reinterpret_cast<uint32_t *>(s_ex + 2 * 4 * 6 * 64);   // [2][4 pos][32 samples][4]
-  float *s_wc = reinterpret_cast<float *>(s_mk + 2 * 4 * 32 * 4);
-  // XCD-aware placement (speed only): every position group re-reads its seed's dz planes (6 MB per seed), so the 16
-  // workgroups of a seed should share one XCD's L2.  Workgroups are dealt to the 8 XCDs round-robin by linear id, hence
-  // seed and position group are derived from the linear id such that id % 8 determines the seed's XCD.
-  int pg_, sl_;
-  {
-    const int nsl = gridDim.y, lin = blockIdx.x + 16 * blockIdx.y;
-    if ((nsl & 7) == 0) {
-      const int xcd = lin & 7, k = lin >> 3;          // k in [0, 2 nsl)
-      sl_ = xcd * (nsl >> 3) + (k >> 4);
-      pg_ = k & 15;
-    } else {
-      sl_ = blockIdx.y;
-      pg_ = blockIdx.x;
-    }
-  }
-  const int seed = sl_ + sd.seed_base;
-  idx += seed * sd.idx_stride;
-  theta += seed * sd.theta_stride;
-  dzp += 2 * seed * sd.ws_stride;     // bf16 units inside a float workspace
-  w1out += seed * sd.ws_stride;
-  gpos += seed * sd.ws_stride;
-  auto row_of = [&](int64_t key) -> int64_t {
-    const uint32_t j = (uint32_t)(key & sd.idx_mask);
-    if (sd.n_env_total == sd.n_env) return (int64_t)j;
-    const uint32_t t = j / (uint32_t)sd.n_env;
-    return (int64_t)t * sd.n_env_total + (int64_t)seed * sd.n_env + (int64_t)(j - t * (uint32_t)sd.n_env);
-  };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pg = pg_;
-  const int ch = lane & 15, kq = lane >> 4;
-  const bool front = wave < 4;          // waves w and w + 4 share a SIMD: one producer and one consumer each
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const int nsuper = nb / (2 * QN_TILE);
-  const u32x4 *dza = reinterpret_cast<const u32x4 *>(dzp);                              // 16-B units
-  const u32x4 *dzbg = reinterpret_cast<const u32x4 *>(dzp + 3 * (size_t)nb * QN_HID);   // dzB, 16-B units
-  const size_t pa = (size_t)nb * QN_HID / 8;                                           // dzA plane stride (16-B units)
-  for (int i = tid; i < CONVBLK; i += QN_THREADS) s_wc[i] = theta[L.off_wc + i];
-  __syncthreads();
-
-  // The two roles are separate code paths with their own loops (same number of barriers on both sides): registers are
-  // allocated for the larger role, not for the union of the two.
-  float gbi = 0.f, gsc = 0.f, gbc = 0.f;                 // producer results needed by the epilogue
-  f32x4 dw[2][4], cw[2][(((9 * C + 15) / 16) + 1) / 2];   // consumer results needed by the epilogue
-  const int bwv = wave & 3, pp = bwv >> 1, ohalf = bwv & 1;
-  if (front) {
-    // =========================== producer state (waves 0..3: one position each) ===========================
-    const int p = 4 * pg + (wave & 3), py = p >> 3, px = p & 7;
-    ConvX3<C> cv;
-    u32x4 wfr[4][3];
-    float bias = 0.f, g0 = 0.f, be0 = 0.f;
-    int bw[3], bs[3];
-    uint32_t lo[2][3], hi[2][3];
-    // Two-stage gather: the permutation indices of super-tile js + 2 are loaded while the window words of js + 1 (whose
-    // indices arrived an iteration ago) go out -- a dependent idx -> obs load chain inside one iteration stalled the
-    // producer for a full memory round trip (4.5k of its 8.7k ticks per super-tile).
-    int64_t key[2];
-    auto load_keys = [&](int js) {
-      js = min(js, nsuper - 1);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) key[t] = idx[(2 * js + t) * QN_TILE + ch];
-    };
-    auto gather = [&]() {   // window words of both tiles of the super-tile whose keys are in `key` (lane & 15 = sample)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int64_t src = row_of(key[t]);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          lo[t][ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky]];
-          hi[t][ky] = obs_bits[(size_t)src * Cfg::OW + bw[ky] + 1];
-        }
-      }
-    };
-    {
-      cv.init(s_wc, lane);
-      bias = s_wc[Cfg::KW * 16 + ch]; g0 = s_wc[Cfg::KW * 16 + 16 + ch]; be0 = s_wc[Cfg::KW * 16 + 32 + ch];
-      const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
-  #pragma unroll
-      for (int sK = 0; sK < 4; ++sK)
-  #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) wfr[sK][pl] = wd[(size_t)pl * (X3_PLANE / 8) + ((p * 4 + sK) * 64 + lane)];
-  #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int bp = ((py + ky) * 10 + px) * C;
-        bw[ky] = bp >> 5;
-        bs[ky] = bp & 31;
-      }
-      load_keys(0);
-      gather();
-      load_keys(1);
-    }
-
-    __syncthreads();   // consumers' prologue: dzA of super-tile 0 staged
-#pragma unroll 1
-    for (int js = 0; js <= nsuper; ++js) {
-      if (js < nsuper) {
-
-          BP_STAMP(0);
-          const u32x4 *ldA = s_dza + (js & 1) * 1536;
-          float h1v[2][4], dxv[2][4];
-          uint32_t mk[2][3];
-  #pragma unroll
-          for (int t = 0; t < 2; ++t)
-  #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-              mk[t][ky] = (uint32_t)(((((uint64_t)hi[t][ky]) << 32) | lo[t][ky]) >> bs[ky]) & ((1u << RB) - 1u);
-          gather();            // super-tile js + 1 (keys loaded last iteration; clamped at the end)
-          load_keys(js + 2);
-          if (kq == 0) {
-            uint32_t *mw = s_mk + (((js & 1) * 4 + (wave & 3)) * 32) * 4;
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) { mw[(16 * t + ch) * 4 + 0] = mk[t][0]; mw[(16 * t + ch) * 4 + 1] = mk[t][1]; mw[(16 * t + ch) * 4 + 2] = mk[t][2]; }
-          }
-          // The two tiles of the super-tile go through every phase TOGETHER: a producer is alone on its SIMD for this
-          // work, and a single tile's chain (conv MFMAs -> drain -> LayerNorm -> dgrad MFMAs -> drain -> LayerNorm
-          // backward) is latency-bound; two independent chains interleaved halve that.
-          // ---- conv: rows = samples, columns = channels ----
-          f32x4 cb_[2] = {zero4, zero4}, cs_[2] = {zero4, zero4};
-  #pragma unroll
-          for (int sx = 0; sx < ConvX3<C>::NS; ++sx) {
-            u32x4 fa[2];
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) fa[t] = ConvX3<C>::expand8(__builtin_amdgcn_ubfe(ConvX3<C>::word(mk[t], sx), 8u * kq, 8u));
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) cs_[t] = X3_MFMA(fa[t], cv.w[sx].l, cs_[t]);
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) cb_[t] = X3_MFMA(fa[t], cv.w[sx].h, cb_[t]);
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) cs_[t] = X3_MFMA(fa[t], cv.w[sx].m, cs_[t]);
-          }
-          // dgrad operands of both tiles from LDS while the conv drains (one K step ahead of its use)
-          u32x4 az[2][2][3];
-          auto load_az = [&](int sK, u32x4 (&dst)[2][3]) {
-  #pragma unroll
-            for (int t = 0; t < 2; ++t)
-  #pragma unroll
-              for (int pl = 0; pl < 3; ++pl) dst[t][pl] = ldA[(pl * 32 + 16 * t + ch) * 16 + ((sK * 4 + kq) ^ ch)];
-          };
-          load_az(0, az[0]);
-          BP_STAMP(1);
-          x3_drain(cb_[0], cs_[0], cb_[1], cs_[1]);
-          float xh[2][4], rs[2][4];
-  #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const f32x4 cvo = (cb_[t] + cs_[t]) * ConvX3<C>::OUT_SCALE;
-            const float v[4] = {cvo.x + bias, cvo.y + bias, cvo.z + bias, cvo.w + bias};
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
-              const float mean = sum * (1.0f / 16.0f);
-              const float var = fmaxf(sq * (1.0f / 16.0f) - mean * mean, 0.0f);
-              rs[t][r] = rsqrt_exact(var + QN_LN_EPS);
-              xh[t][r] = (v[r] - mean) * rs[t][r];
-              h1v[t][r] = fmaxf(fmaf(xh[t][r], g0, be0), 0.0f);
-            }
-          }
-          BP_STAMP(2);
-          // ---- dgrad: dh1[sample][feature], eight independent accumulators ----
-          f32x4 gb[2][2] = {{zero4, zero4}, {zero4, zero4}}, gs[2][2] = {{zero4, zero4}, {zero4, zero4}};
-  #pragma unroll
-          for (int sK = 0; sK < 4; ++sK) {
-            const u32x4 (&a)[2][3] = az[sK & 1];
-            if (sK + 1 < 4) load_az(sK + 1, az[(sK + 1) & 1]);
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) gs[t][0] = X3_MFMA(a[t][2], wfr[sK][0], gs[t][0]);
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) gb[t][0] = X3_MFMA(a[t][1], wfr[sK][0], gb[t][0]);
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) gs[t][1] = X3_MFMA(a[t][0], wfr[sK][2], gs[t][1]);
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) gb[t][1] = X3_MFMA(a[t][0], wfr[sK][1], gb[t][1]);
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) gs[t][0] = X3_MFMA(a[t][1], wfr[sK][1], gs[t][0]);
-  #pragma unroll
-            for (int t = 0; t < 2; ++t) gb[t][0] = X3_MFMA(a[t][0], wfr[sK][0], gb[t][0]);
-          }
-          BP_STAMP(3);
-          x3_drain(gb[0][0], gs[0][0], gb[0][1], gs[0][1]);
-          x3_drain(gb[1][0], gs[1][0], gb[1][1], gs[1][1]);
-          // ---- relu mask + LN0 backward (per point = per (kq, r); sums over the 16 channel lanes) ----
-  #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const f32x4 dh4 = (gb[t][0] + gb[t][1]) + (gs[t][0] + gs[t][1]);
-            const float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float g = h1v[t][r] > 0.0f ? dh[r] : 0.0f;
-              gbi += g;
-              gsc = fmaf(g, xh[t][r], gsc);
-              const float dxh = g * g0;
-              const float s1 = group16_sum(dxh) * (1.0f / 16.0f), s2 = group16_sum(dxh * xh[t][r]) * (1.0f / 16.0f);
-              dxv[t][r] = rs[t][r] * (dxh - s1 - xh[t][r] * s2);
-              gbc += dxv[t][r];
-            }
-          }
-          BP_STAMP(4);
-          // hand h1 and dx of the 32 samples to the consumers as bf16 planes: K slot j = sample 16 (j >> 2) + 4 kq + (j & 3),
-          // i.e. exactly this lane's eight values -- lane-contiguous 16-B stores, already in MFMA operand layout
-          const X3Frag fh = x3_split8(f32x4{h1v[0][0], h1v[0][1], h1v[0][2], h1v[0][3]}, f32x4{h1v[1][0], h1v[1][1], h1v[1][2], h1v[1][3]});
-          const X3Frag fd = x3_split8(f32x4{dxv[0][0], dxv[0][1], dxv[0][2], dxv[0][3]}, f32x4{dxv[1][0], dxv[1][1], dxv[1][2], dxv[1][3]});
-          u32x4 *ex = s_ex + (((js & 1) * 4 + (wave & 3)) * 6) * 64 + lane;
-          ex[0] = fh.h; ex[64] = fh.m; ex[128] = fh.l; ex[192] = fd.h; ex[256] = fd.m; ex[320] = fd.l;
-          BP_STAMP(5);
-
-      }
-      __syncthreads();
-      BP_STAMP(6);
-    }
-  } else {
-    // =========================== consumer state (waves 4..7: position pair x half of the outputs) ===========================
-    const int bt = tid - 4 * 64;   // bt: thread index among the 256 consumer threads
-  #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-  #pragma unroll
-      for (int c = 0; c < 4; ++c) dw[q][c] = zero4;
-  #pragma unroll
-      for (int j = 0; j < RBH; ++j) cw[q][j] = zero4;
-    }
-    int kyL[RBH], shL[RBH];
-  #pragma unroll
-    for (int j = 0; j < RBH; ++j) {
-      const int rb = ohalf * RBH + j, k = 16 * rb + ch;
-      kyL[j] = (rb < NRB && k < 9 * C) ? k / RB : 0;
-      shL[j] = (rb < NRB && k < 9 * C) ? k % RB : 31;
-    }
-    // the consumers also move the dz planes: per iteration dzA of the NEXT super-tile (for the producers) and dzB of the
-    // CURRENT one (for themselves, one iteration later); 3072 16-B chunks over 256 threads, unconditional (clamped)
-    u32x4 pf[12];
-    const u32x4 *pfa[6], *pfb[6];     // chunk addresses at super-tile 0; a super-tile advances dzA by 512 and dzB by 1536 chunks
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int c = bt + 256 * q;
-      pfa[q] = dza + (size_t)(c >> 9) * pa + (c & 511);
-      pfb[q] = dzbg + c;
-    }
-    auto pf_load = [&](int js) {
-      const int ja = min(js + 1, nsuper - 1), jb = min(js, nsuper - 1);
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        pf[q] = pfa[q][(size_t)ja * 512];
-        pf[6 + q] = pfb[q][(size_t)jb * 1536];
-      }
-    };
-    auto pf_store = [&](int js) {
-      u32x4 *da = s_dza + ((js + 1) & 1) * 1536, *db = s_dzb + (js & 1) * 1536;
-  #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int c = bt + 256 * q, r = c & 511, smp = r >> 4, quad = r & 15;
-        da[((c >> 9) * 32 + smp) * 16 + (quad ^ (smp & 15))] = pf[q];
-        db[c] = pf[6 + q];
-      }
-    };
-    {   // prologue: dzA of super-tile 0
-  #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int c = bt + 256 * q, r = c & 511, smp = r >> 4, quad = r & 15;
-        s_dza[((c >> 9) * 32 + smp) * 16 + (quad ^ (smp & 15))] = dza[(size_t)(c >> 9) * pa + r];
-      }
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int js = 0; js <= nsuper; ++js) {
-        BP_STAMP(0);
-        pf_load(js);
-        BP_STAMP(1);
-        if (js >= 1) {
-          const int jb = (js - 1) & 1;
-          const u32x4 *ldB = s_dzb + jb * 1536 + lane;                         // + (cb * 3 + pl) * 64
-  #pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int pos = 2 * pp + q;
-            const u32x4 *ex = s_ex + ((jb * 4 + pos) * 6) * 64 + lane;
-            // ---- dW1[feature][o] += sum over the 32 samples of h1[sample][feature] dz[sample][o] ----
-            const u32x4 ahh = ex[0], ahm = ex[64], ahl = ex[128];
-            u32x4 bh[4], bm[4], bl[4];
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const u32x4 *bq = ldB + ((4 * ohalf + c) * 3) * 64;
-              bh[c] = bq[0]; bm[c] = bq[64]; bl[c] = bq[128];
-            }
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahl, bh[c], dw[q][c]);
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahh, bl[c], dw[q][c]);
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahm, bm[c], dw[q][c]);
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahm, bh[c], dw[q][c]);
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahh, bm[c], dw[q][c]);
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) dw[q][c] = X3_MFMA(ahh, bh[c], dw[q][c]);
-            if (q == 1) BP_STAMP(2);
-            // ---- conv weight gradient: dWc[k][ch] += sum_samples bit(sample, k) dx[sample][ch] ----
-            const u32x4 dxh_ = ex[192], dxm_ = ex[256], dxl_ = ex[320];
-            const uint32_t *mw = s_mk + ((jb * 4 + pos) * 32) * 4;
-            u32x4 fa[RBH];
-  #pragma unroll
-            for (int j = 0; j < RBH; ++j) {
-              uint32_t d[4];
-  #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) {           // K slots 2 jj, 2 jj + 1: samples 16 (jj >> 1) + 4 kq + 2 (jj & 1) + {0, 1}
-                const int s0 = 16 * (jj >> 1) + 4 * kq + 2 * (jj & 1);
-                const uint32_t b0_ = __builtin_amdgcn_ubfe(mw[s0 * 4 + kyL[j]], (uint32_t)shL[j], 1u);
-                const uint32_t b1_ = __builtin_amdgcn_ubfe(mw[(s0 + 1) * 4 + kyL[j]], (uint32_t)shL[j], 1u);
-                d[jj] = ((b1_ << 16) | b0_) << 14;       // bit as bf16 2.0
-              }
-              fa[j] = u32x4{d[0], d[1], d[2], d[3]};
-            }
-  #pragma unroll
-            for (int j = 0; j < RBH; ++j) cw[q][j] = X3_MFMA(fa[j], dxl_, cw[q][j]);
-  #pragma unroll
-            for (int j = 0; j < RBH; ++j) cw[q][j] = X3_MFMA(fa[j], dxm_, cw[q][j]);
-  #pragma unroll
-            for (int j = 0; j < RBH; ++j) cw[q][j] = X3_MFMA(fa[j], dxh_, cw[q][j]);
-          }
-        }
-        BP_STAMP(3);
-        pf_store(js);
-        BP_STAMP(4);
-
-      __syncthreads();
-      BP_STAMP(5);
-    }
-  }
-  // ---- epilogue ----
-  float *part = reinterpret_cast<float *>(bp_smem);   // [4 pos][CONVBLK] conv / LN0 partials (the dz buffers are dead)
-  if (front) {
-    gbi += __shfl_xor(gbi, 16, 64); gbi += __shfl_xor(gbi, 32, 64);
-    gsc += __shfl_xor(gsc, 16, 64); gsc += __shfl_xor(gsc, 32, 64);
-    gbc += __shfl_xor(gbc, 16, 64); gbc += __shfl_xor(gbc, 32, 64);
-    if (lane < 16) {
-      float *pr = part + (wave & 3) * CONVBLK + Cfg::KW * 16;
-      pr[lane] = gbc; pr[16 + lane] = gsc; pr[32 + lane] = gbi;
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      x3_drain(dw[q][0], dw[q][1], dw[q][2], dw[q][3]);
-      const int pos = 4 * pg + 2 * pp + q;
-      f32x4 *out = reinterpret_cast<f32x4 *>(w1out);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) out[(pos * 8 + 4 * ohalf + c) * 64 + lane] = dw[q][c];   // fc1 block, kernel (fragment) layout
-#pragma unroll
-      for (int j = 0; j < RBH; ++j) {
-        x3_drain(cw[q][j]);
-        const int rb = ohalf * RBH + j;
-        const f32x4 a = cw[q][j] * (0.5f / 255.0f);
-        const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * rb + 4 * kq + r;
-          if (rb < NRB && k < Cfg::KW) part[(2 * pp + q) * CONVBLK + k * 16 + ch] = av[r];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < CONVBLK; e += QN_THREADS)
-    gpos[(size_t)pg * CONVBLK + e] = (part[e] + part[CONVBLK + e]) + (part[2 * CONVBLK + e] + part[3 * CONVBLK + e]);
 }
 
 // ---------------------------------------------------------------------------
@@ -3463,7 +2734,6 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_x3_kernel(int nb, c
       pre[us] = fetch(qs + 1, us);                               // refill the slot: the same step one iteration further on
       if (last) {
         if (!(T2_ABL & 16)) __syncthreads();   // the next group's planes complete; this group's half may be overwritten from now on
-        x3_skew<X3_SKEW_T2>(wave);
         load_plane(tnext, 2, al);
         load_plane(tnext, 1, am);
         load_plane(tnext, 0, ah);
@@ -4035,8 +3305,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   const int ablate = pqn_opt(PQN_OPT_ABLATE_TRAIN);  // profiling only
   // ---- the position-parallel form (pqn_qnet_pos.hip; round 5): gather -> forward (wave = 32 samples, z in registers, W1
   // planes shared through LDS) -> backward (wave = conv position, its W1 / dW1 rows resident) -> fold.  Option bwd_pos:
-  // 0 never, 1 when the launch fills the chip, 2 whenever the shape allows (tests), 3 / 4 = the pair kernel forward-only in
-  // front of round 2's / this round's backward (A/B).  One workgroup per 256 samples (forward) and per (8 positions, chunk)
+  // 0 never, 1 when the launch fills the chip, 2 whenever the shape allows (tests).  One workgroup per 256 samples (forward) and per (8 positions, chunk)
   // (backward): 16 seeds x 4096 samples give 256 + 256.  The summation orders depend on the minibatch size only, never on the
   // number of seeds in the launch; sd.pin_form takes the form from the minibatch size alone (a solo run then equals its batch).
   {
@@ -4058,7 +3327,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
         if (rc == PQN_OK) rc = pqn_cnn_pos_forward(L, nb, theta, inv_b, h1T, PW, sd, sd.nseeds, st);
         if (t_fwd) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
         if (t_bwd) (void)hipEventRecord(g_prof.s[g_prof.n], st);
-        if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, nch, theta, h1T, wpart, PW, sd, sd.nseeds, 1, st);
+        if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, nch, theta, h1T, wpart, PW, sd, sd.nseeds, st);
         if (t_bwd || t_all) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
         if (rc != PQN_OK) return rc;
       }
@@ -4088,50 +3357,18 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   if (use_pair) {
     static bool pair_attr = false;
     if (!pair_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, false>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       pair_attr = true;
     }
   }
-  // position-parallel backward (qnet_cnn_bwd_pos_kernel): the pair kernel runs forward-only and hands dz over as bf16
-  // planes; one workgroup per (seed, 4 positions) then needs >= 16 seeds to fill the chip.  PQN_BWD_POS: 0 off, 1 auto,
-  // 2 at any size (tests)
-  const int pos_env = pqn_opt(PQN_OPT_BWD_POS);
-  const bool use_pos = use_pair && pos_env >= 3 && nb >= 2 * QW_SLAB && (pos_env == 3 || pos_shape_ok(nb));
-  const bool pos_old = use_pos && pos_env == 3;      // round 2's producer / consumer kernel (kept for the A/B of round 5)
-  const int pos_nch = pos_chunks(nb);                // sample chunks (= partial dW1 slabs) of the round-5 backward
-  const pos_ws_t posW = pos_ws_layout(nb, C, L.a);   // its carve-up of the h1^T region (dz planes first, as the forward kernel writes them)
-  float *gposw = wpart + (size_t)QN_H1 * QN_HID;   // conv-block partials of the 16 position groups (second slab's place)
-  if (use_pos) {
-    static bool fwd_attr = false;
-    if (!fwd_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_bwd_pos_kernel<C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_pos_lds_bytes<C>());
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      fwd_attr = true;
-    }
-  }
-  // opt-in paired-dgrad backward of the pair kernel (PQN_T1_PD2=1; C = 4 only)
-  const int pd2_env = pqn_opt(PQN_OPT_T1_PD2);
-  const bool use_pd2 = use_pair && !use_pos && pd2_env && C == 4;
-  if (use_pd2) {
-    if constexpr (C == 4) {
-      static bool pd2_attr = false;
-      if (!pd2_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C, false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        pd2_attr = true;
-      }
-    }
-  }
-  pqn_note_kernel_form(0, use_pos ? PQN_FORM_PAIR_POS : (use_pd2 ? PQN_FORM_PAIR_PD2 : (use_pair ? PQN_FORM_PAIR : PQN_FORM_SINGLE)));
+  pqn_note_kernel_form(0, use_pair ? PQN_FORM_PAIR : PQN_FORM_SINGLE);
   const int gs_max = pqn_cnn_seed_group(L.matmul_f16, sd.nseeds);
   // bf16x3 fc1 weight gradient without split-K partials (qnet_fc1_wgrad_x3_kernel<true>): option t2_acc = 0 never, 1 (default)
   // when row blocks x seeds of a launch give every CU a workgroup, 2 always.  Both forms sum the slabs in the same order, so
   // a seed's bits do not depend on which one its launch took.
   const int acc_opt = pqn_opt(PQN_OPT_T2_ACC);
-  const bool t2_acc = L.matmul_f16 == 2 && !use_pos && (acc_opt == 2 || (acc_opt == 1 && 16 * min(gs_max, sd.nseeds) >= 256));
+  const bool t2_acc = L.matmul_f16 == 2 && (acc_opt == 2 || (acc_opt == 1 && 16 * min(gs_max, sd.nseeds) >= 256));
   // (ragged minibatches: the tail of the last slab of the dz planes is zeroed by T1's head itself, see train_head_nt)
   for (int s0 = 0; s0 < sd.nseeds; s0 += gs_max) {
     const int gs = min(gs_max, sd.nseeds - s0);
@@ -4141,29 +3378,8 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     const bool timed = part != 2 && g_prof.on && g_prof.mode == 1 && g_prof.n < PQN_PROF_MAX;
     if (timed) (void)hipEventRecord(g_prof.s[g_prof.n], st);
     if (part == 2) {
-      if (use_pos) continue;
-    } else if (use_pos) {
-      if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
-        if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;
-      }
-      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), pair_bytes, st, nb, idx, bits,
-                         action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
-      if (pos_old)
-        hipLaunchKernelGGL(qnet_cnn_bwd_pos_kernel<C>, dim3(16, gs), dim3(QN_THREADS), bwd_pos_lds_bytes<C>(), st, nb, idx, bits, theta, L,
-                           reinterpret_cast<const unsigned short *>(h1T), wpart, gposw, sg, g_t2_stamps);
-      else {
-        int rc = pqn_cnn_pos_gather(L, nb, idx, bits, action, target, h1T, posW, sg, gs, st);
-        if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, pos_nch, theta, h1T, wpart, posW, sg, gs, 0, st);
-        if (rc != PQN_OK) return rc;
-      }
-      if (timed) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
-      continue;   // no T2: dW1 was accumulated in registers
-    } else if (use_pair && use_pd2) {
-      if constexpr (C == 4)
-        hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false, true>), dim3(ntiles / 2, gs), dim3(QN_THREADS), pair_bytes, st, nb,
-                           idx, bits, action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps, wpart);
     } else if (use_pair)
-      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C, false>), dim3(ntiles / 2, gs), dim3(QN_THREADS), pair_bytes, st, nb, idx, bits,
+      hipLaunchKernelGGL((qnet_cnn_train_pair_kernel<C>), dim3(ntiles / 2, gs), dim3(QN_THREADS), pair_bytes, st, nb, idx, bits,
                          action, target, theta, L, inv_b, dzT, h1T, gpart, ablate, sg, dz_scale, g_t1_stamps);
     else
     hipLaunchKernelGGL(t1, dim3(ntiles, gs), dim3(QN_THREADS), smem1, st, nb, idx, bits, action,
@@ -4202,8 +3418,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   }
   if (with_reduce && part != 1)
     hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles,
-                       use_pos ? (pos_old ? 1 : pos_nch) : (t2_acc ? 1 : nks), rec, gpart, wpart, grad, count, scratch, loss_out, qv_out,
-                       inv_b, sd, use_pos ? (pos_old ? gposw : h1T + posW.gpos) : nullptr, use_pos ? (pos_old ? 16 : 8 * pos_nch) : 0);
+                       t2_acc ? 1 : nks, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd, (const float *)nullptr, 0);
   return pqn_check_launch("pqn_qnet_cnn_grad");
 }
 

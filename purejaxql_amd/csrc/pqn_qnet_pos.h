@@ -10,7 +10,7 @@ __host__ __device__ constexpr int pos_t32_words(int c) { return (100 * c + 1 + 2
 // carve-up of the h1^T region of a seed's training workspace in the position-parallel form (float offsets from the region's
 // start; every offset a multiple of 4 floats = 16 B).  dz comes first: the DMA plan addresses everything relative to it.
 struct pos_ws_t {
-  long long dz;        // dzA [3][nb][128] bf16 | dzB [nb / 32][8][3][64][8] bf16 (dz_planes_a / dz_planes_b)
+  long long dz;        // dz as three bf16 planes [3][nb][128] in the dgrad's operand order (dz_planes_a)
   long long mb_bits;   // [nb][OW] packed observation rows in minibatch order
   long long t32;       // [nb / 32][pos_t32_words] bit-transposed rows
   long long stats;     // [nb / 32][64 positions][32 samples][2]: LayerNorm_0 mean, 1/std (forward kernel)
@@ -26,7 +26,7 @@ inline pos_ws_t pos_ws_layout(int nb, int c, int a) {
   const long long rec = 9 * c * 16 + 48 + 384 + 128 * a + a + 2;
   pos_ws_t w;
   w.dz = 0;
-  w.mb_bits = al((long long)nb * 384);
+  w.mb_bits = al((long long)nb * 192);
   w.t32 = al(w.mb_bits + (long long)nb * ow);
   w.stats = al(w.t32 + (long long)(nb / 32) * pos_t32_words(c));
   w.gpos = al(w.stats + (long long)nb * 128);
@@ -47,15 +47,14 @@ inline bool pos_shape_ok(int nb) { return nb % (64 * pos_chunks(nb)) == 0; }
 //   gather    minibatch rows, actions, targets in minibatch order + the bit-transpose per super-tile
 //   forward   conv .. loss and the head's backward: dz planes, LayerNorm_0 statistics, one head record per 256 samples
 //             (nb % 256 == 0; (channels, actions) as pqn_cnn_pos_forward_supported says)
-//   backward  dgrad, LayerNorm_0 / conv backward, dW1 rows in registers; stats = 1: LayerNorm_0 statistics of `forward`,
-//             0: recomputed (dz planes then come from qnet_cnn_train_pair_kernel<C, true>)
+//   backward  dgrad, LayerNorm_0 / conv backward, dW1 rows in registers (dz planes and LayerNorm_0 statistics of `forward`)
 int pqn_cnn_pos_gather(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits, const int32_t *action,
                        const float *target, float *wsx, const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st);
 bool pqn_cnn_pos_forward_supported(int c, int a);
 int pqn_cnn_pos_forward(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
                         const pqn_seeds_t &sg, int nseeds, hipStream_t st);
 int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out, const pos_ws_t &W,
-                         const pqn_seeds_t &sg, int nseeds, int stats, hipStream_t st);
+                         const pqn_seeds_t &sg, int nseeds, hipStream_t st);
 
 // persistent rollout in the structure of the forward kernel (one workgroup per 256 envs, wave = 32 envs): the scan of
 // pqn_qnet_cnn_rollout for launches whose envs (per seed) come in multiples of 256; same arguments

@@ -17,7 +17,6 @@
 //                        per super-tile through LDS-DMA (global_load_lds) into a two-slot ring: one barrier per super-tile,
 //                        no staging registers, no ds_write.
 //
-// The forward half (conv, fc1, head, loss, dz planes) is qnet_cnn_train_pair_kernel<C, true> of pqn_qnet.hip.
 #include <stdlib.h>
 
 #include "pqn_env_rules.h"
@@ -25,12 +24,6 @@
 #include "pqn_qnet_pos.h"
 
 #define POS_THREADS 512
-// Wave priority inside an iteration (A/B hook, -DPOS_PRIO=1): the two waves of a SIMD (w and w + 4) are released by the same
-// barrier; the older one wins the issue arbitration and reaches the next barrier ~25 % of an iteration early, after which
-// the SIMD runs a single wave.  With POS_PRIO the younger half is raised to priority 1 for the second half of every iteration.
-#ifndef POS_PRIO
-#define POS_PRIO 0
-#endif
 // Barrier period of the backward: ONE barrier per TWO super-tiles over a four-slot ring, the favoured half of the waves
 // (s_setprio 1) alternating between the two super-tiles of a period -- the older wave of a SIMD then leads in one and trails in
 // the other, and both reach the barrier together instead of one of them idling a quarter of every iteration (stamps: 2.3k of
@@ -40,12 +33,6 @@
 #ifndef POS_PAIR_SYNC
 #define POS_PAIR_SYNC 1
 #endif
-template <int P>
-__device__ __forceinline__ void pos_prio(int wave) {
-  if constexpr (POS_PRIO != 0) {
-    if (wave >= 4) __builtin_amdgcn_s_setprio(P);
-  }
-}
 #define POS_ST 32              // samples per super-tile (two 16-sample MFMA tiles)
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
@@ -178,9 +165,9 @@ PQN_D void pos_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #define POSB_STAMP(k) do { } while (0)
 #endif
 
-// STATS: 0 = LayerNorm_0 statistics recomputed here (DPP row sums over the 16 channel lanes); 1 = read from the forward
-// kernel's record (mean, 1/std per (sample, position)) -- then xhat and the relu mask are the forward's own, bit for bit
-template <int C, int STATS>
+// LayerNorm_0 statistics (mean, 1/std per (sample, position)) are the forward kernel's record: xhat and the relu mask are then
+// the forward's own, bit for bit
+template <int C>
 __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nch, const float *__restrict__ theta, pqn_cnn_layout_t L,
                                                                   float *__restrict__ wsx, float *__restrict__ w1out,
                                                                   pos_ws_t W, pqn_seeds_t sd, unsigned long long *__restrict__ stamps) {
@@ -332,13 +319,10 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
   for (int j = 0; j < nst; ++j) {
     if constexpr (POS_PAIR_SYNC != 0) {
       if ((j & 1) == 0) { dma_slot(j + 2); dma_slot(j + 3); }   // the slots of the previous period: every wave passed its barrier
-#ifndef POS_PAIR_NOPRIO
       if ((wave >= 4) == ((j & 1) != 0)) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
-#endif
     } else {
       dma_slot(j + 1);           // the other slot was last read an iteration ago, before that iteration's barrier
-      pos_prio<0>(wave);
     }
     POSB_STAMP(0);
     const u32x4 *slot = ring + (j & (P::RS - 1)) * P::SLOT;
@@ -385,19 +369,11 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
       const f32x4 cvo = (cb_[t] + cs_[t]) * ConvX3<C>::OUT_SCALE;
       const float v[4] = {cvo.x + bias, cvo.y + bias, cvo.z + bias, cvo.w + bias};
       float mean[4];
-      if constexpr (STATS == 1) {
+      {
         const f32x4 *sp = reinterpret_cast<const f32x4 *>(slot + P::O_STAT) + ((wave * POS_ST + 16 * t + 4 * kq) >> 1);
         const f32x4 s0 = sp[0], s1 = sp[1];
         mean[0] = s0.x; rs[t][0] = s0.y; mean[1] = s0.z; rs[t][1] = s0.w;
         mean[2] = s1.x; rs[t][2] = s1.y; mean[3] = s1.z; rs[t][3] = s1.w;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sum = group16_sum(v[r]), sq = group16_sum(v[r] * v[r]);
-          mean[r] = sum * (1.0f / 16.0f);
-          const float var = fmaxf(sq * (1.0f / 16.0f) - mean[r] * mean[r], 0.0f);
-          rs[t][r] = rsqrt_exact(var + QN_LN_EPS);
-        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -455,7 +431,6 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
         }
     }
     POSB_STAMP(4);
-    pos_prio<1>(wave);
     // h1 and dx of the 32 samples as bf16 planes, split ONCE: K slot j = sample 16 (j >> 2) + 4 kq + (j & 3), i.e. exactly
     // this lane's eight values -- already the A fragment of dW1p = h1^T dz and the B fragment of dWc = bits^T dx
     float h1v[2][4];
@@ -691,7 +666,6 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
       else __builtin_amdgcn_s_setprio(0);
     } else {
       dma_step(kk0 + s + 1);
-      pos_prio<0>(cx.wave);
     }
     POSF_STAMP(0);
     const u32x4 *slot = cx.ring + ((kk0 + s) & (F::RS - 1)) * F::N_W + cx.lane;
@@ -1306,34 +1280,28 @@ int pqn_cnn_pos_gather(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, co
 
 template <int C>
 static int pos_backward_launch(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out,
-                               const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, int stats, hipStream_t st) {
+                               const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
   using P = PosCfg<C>;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_bwd_kernel<C, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)P::lds_bytes());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_bwd_kernel<C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)P::lds_bytes());
     attr = true;
   }
   if (!g_pos_stamps && getenv("PQN_T1_STAMPS")) {
     if (hipMalloc(&g_pos_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_pos_stamps = nullptr;
   }
-  if (stats)
-    hipLaunchKernelGGL((cnn_pos_bwd_kernel<C, 1>), dim3(8 * nch * nseeds), dim3(POS_THREADS), P::lds_bytes(), st, nb, nch, theta, L, wsx,
-                       w1out, W, sg, g_pos_stamps);
-  else
-    hipLaunchKernelGGL((cnn_pos_bwd_kernel<C, 0>), dim3(8 * nch * nseeds), dim3(POS_THREADS), P::lds_bytes(), st, nb, nch, theta, L, wsx,
-                       w1out, W, sg, g_pos_stamps);
+  hipLaunchKernelGGL((cnn_pos_bwd_kernel<C>), dim3(8 * nch * nseeds), dim3(POS_THREADS), P::lds_bytes(), st, nb, nch, theta, L, wsx, w1out,
+                     W, sg, g_pos_stamps);
   return pqn_check_launch("pqn_cnn_pos_backward");
 }
 
 int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out, const pos_ws_t &W,
-                         const pqn_seeds_t &sg, int nseeds, int stats, hipStream_t st) {
+                         const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
   switch (L.c) {
-    case 4: return pos_backward_launch<4>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, stats, st);
-    case 6: return pos_backward_launch<6>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, stats, st);
-    case 7: return pos_backward_launch<7>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, stats, st);
+    case 4: return pos_backward_launch<4>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, st);
+    case 6: return pos_backward_launch<6>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, st);
+    case 7: return pos_backward_launch<7>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, st);
     default: pqn_set_error("pqn_cnn_pos_backward: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
   }
 }

@@ -166,48 +166,12 @@ PQN_D f32x4 x3_mfma_tied(const u32x4 &a, const u32x4 &b, f32x4 c) {
   return c;
 }
 #define X3_MFMA(A, B, C) x3_mfma_tied(A, B, C)
-// De-phasing the two waves of a SIMD (round 4).  Waves w and w + 4 of a 512-thread workgroup share a SIMD; released by the
-// same barrier they run the same loop in lockstep -- both in their MFMA burst, then both in their VALU / LDS / load part --
-// and the two instruction classes add up instead of overlapping (T2: 51 us of data movement + 47 us of matrix pipe = 101 us,
-// profiles/r04_v1_t2_ablate.txt; fc1: 1.8k cycles per K step against ~1.0k issue slots).  A one-off s_sleep of about half a
-// loop period on waves 4..7 in front of a barrier-free loop puts one wave's MFMA burst beside the other's VALU part for the
-// whole loop.  Timing only: no effect on results.  (-DX3_SKEW_* = s_sleep argument, units of 64 clocks; 0 = off.)
-#ifndef X3_SKEW_FC1
-#define X3_SKEW_FC1 0
-#endif
-#ifndef X3_SKEW_DGRAD
-#define X3_SKEW_DGRAD 0
-#endif
-#ifndef X3_SKEW_T2
-#define X3_SKEW_T2 0
-#endif
-template <int N>
-PQN_D void x3_skew(int wave) {
-  if constexpr (N > 0) {
-    if (wave >= 4) __builtin_amdgcn_s_sleep(N);
-  }
-}
 // GROUPS of independent MFMAs (different accumulators) as ONE asm statement with ONE leading `s_nop 1` (round 4).  The pad
 // in front of a single MFMA covers a VALU write of one of its operands in the preceding issue slots -- the compiler cannot
 // see inside the asm string and schedules its own VALU instructions between the statements -- but inside a run of MFMAs
 // it is pure cost: MI355X_MICROARCH.md prices one extra issue state between MFMAs at ~6 cycles (different accumulators)
 // against the ~16 cycles the MFMA itself occupies the pipe.  Inside a group nothing can be scheduled between the MFMAs, so
 // only the first needs the pad; instruction order, operands and therefore results are unchanged.
-#ifdef X3_NO_GROUP   // A/B hook: one statement (and one pad) per MFMA, as in rounds 2-3
-PQN_D void x3_grp2(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
-  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1);
-}
-PQN_D void x3_grp4(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
-                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
-  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1); c2 = x3_mfma_tied(a2, b2, c2); c3 = x3_mfma_tied(a3, b3, c3);
-}
-PQN_D void x3_grp6(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
-                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3, f32x4 &c4, const u32x4 &a4,
-                   const u32x4 &b4, f32x4 &c5, const u32x4 &a5, const u32x4 &b5) {
-  c0 = x3_mfma_tied(a0, b0, c0); c1 = x3_mfma_tied(a1, b1, c1); c2 = x3_mfma_tied(a2, b2, c2); c3 = x3_mfma_tied(a3, b3, c3);
-  c4 = x3_mfma_tied(a4, b4, c4); c5 = x3_mfma_tied(a5, b5, c5);
-}
-#else
 PQN_D void x3_grp2(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
   asm volatile("s_nop 1\n\t"
                "v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\t"
@@ -238,7 +202,6 @@ PQN_D void x3_grp6(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const
                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5)
                : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
 }
-#endif
 // N MFMAs sharing the B operand (N row blocks against one fragment): grouped for the N the kernels use
 template <int N>
 PQN_D void x3_grp_sameb(f32x4 (&c)[N], const u32x4 (&a)[N], const u32x4 &b) {
@@ -388,12 +351,7 @@ PQN_HD size_t dzw_index(int b, int o) {   // element offset of (sample b, output
 // dz as bf16 planes for the position-parallel backward (element offsets in bf16 units inside one plane set):
 //   dzA[plane][sample][sK][kq][8]: the 8 values are outputs 32 sK + 16 (j >> 2) + 4 kq + (j & 3) -- one dwordx4 per lane is
 //       the A fragment (row = sample) of a K = 32 dgrad step, in the K-slot order of the optimizer's dgrad planes;
-//   dzB[super-tile of 32 samples][cb][plane][lane][tile 0/1][4], lane = kq * 16 + (o & 15): samples 4 kq .. 4 kq + 3 of
-//       each of the two tiles for output 16 cb + (o & 15) -- one dwordx4 per lane is the B fragment (column = output) of
-//       a K = 32 step of dW1 = h1^T dz whose K slot j stands for sample 16 (j >> 2) + 4 kq + (j & 3) of the super-tile.
-// Plane stride: nb * 128 (dzA), 512 inside a (super-tile, cb) block (dzB).  dzA occupies 3 nb 128 elements, dzB follows it.
+//   (the weight gradient's B fragment -- column = output, K slots = samples -- is read from the same image by the backward with
+//   transposing LDS reads, pqn_qnet_pos.hip.)  Plane stride: nb * 128 elements.
 PQN_HD size_t dz_planes_a(int nb, int sample, int sK, int kq) { (void)nb; return ((size_t)sample * 16 + sK * 4 + kq) * 8; }
-PQN_HD size_t dz_planes_b(int tile, int cb, int lane) {
-  return (((((size_t)(tile >> 1) * 8 + cb) * 3) * 64 + lane) * 2 + (tile & 1)) * 4;
-}
 

@@ -428,18 +428,6 @@ def _grads_under_options(gpu, c, a, nb, pool, mode, reps=3, **opts):
     return out[0], form
 
 
-def test_paired_dgrad_opt_in_path(gpu):
-    """t1_pd2=1 (with the pair kernel forced): the dgrad of both tiles against one pass over the weight planes
-    (t1_dgrad_pair2_x3), LN0 backward without its staging buffer, two-round conv-wgrad fold.
-    Repeats bit-identical, gradient equal to the f32-MFMA mode of the default kernels to f32 rounding at 2, 8 and 256
-    pairs.  Opt-in path (not faster under full load), kept tested -- in-process through pqn_set_option."""
-    for nb, pool in ((64, 256), (256, 1000), (8192, 20000)):
-        g_f32, f0 = _grads_under_options(gpu, 4, 3, nb, pool, 0, t1_pair=0)
-        g_pd2, f1 = _grads_under_options(gpu, 4, 3, nb, pool, 2, t1_pair=2, t1_pd2=1)
-        assert (f0, f1) == ("ksplit" if nb <= 256 else "single", "pair+pd2")   # the f32 mode's small-minibatch form
-        assert float((g_f32 - g_pd2).abs().max()) <= 2e-5 * float(g_f32.abs().max()), nb
-
-
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 4096, 20000), (4, 3, 512, 3000), (4, 5, 1024, 4000), (6, 4, 2048, 6000), (7, 3, 1024, 3000)])
 def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool):
     """bwd_pos=2 routes a minibatch through the position-parallel kernels of pqn_qnet_pos.hip -- minibatch gather +
@@ -447,16 +435,13 @@ def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool
     cnn_pos_bwd_kernel (wave = conv position, its dW1 rows in registers, one partial slab per sample chunk) -- and the
     reduction: the form is reported, repeats are bit-identical (gradient, loss, mean chosen q), loss
     and chosen q equal the f32-MFMA mode of the default kernels, the gradient equals it to f32 rounding and the oracle's numpy
-    backward at the tolerance of test_cnn_grad_vs_oracle.  bwd_pos=4 (this round's backward behind the forward-only pair
-    kernel, LayerNorm_0 statistics recomputed) is held to the same.  pqn_minatar.py:271-291."""
+    backward at the tolerance of test_cnn_grad_vs_oracle.  pqn_minatar.py:271-291."""
     g_f32, f0, lq0 = _grads_under_options(gpu, c, a, nb, pool, 0, t1_pair=0, t1_ksplit=0, want_loss=True)
     g_pos, f1, lq1 = _grads_under_options(gpu, c, a, nb, pool, 2, bwd_pos=2, want_loss=True)
-    g_mix, f2, lq2 = _grads_under_options(gpu, c, a, nb, pool, 2, t1_pair=2, bwd_pos=4, want_loss=True)
-    assert (f0, f1, f2) == ("single", "pos", "pair+pos")
+    assert (f0, f1) == ("single", "pos")
     scale = float(g_f32.abs().max())
-    for g, lq in ((g_pos, lq1), (g_mix, lq2)):
-        assert abs(lq[0] - lq0[0]) <= 2e-6 * max(1.0, abs(lq0[0])) and abs(lq[1] - lq0[1]) <= 2e-6 * max(1.0, abs(lq0[1])), (lq, lq0)
-        assert float((g_f32 - g).abs().max()) <= 2e-5 * scale, float((g_f32 - g).abs().max()) / scale
+    assert abs(lq1[0] - lq0[0]) <= 2e-6 * max(1.0, abs(lq0[0])) and abs(lq1[1] - lq0[1]) <= 2e-6 * max(1.0, abs(lq0[1])), (lq1, lq0)
+    assert float((g_f32 - g_pos).abs().max()) <= 2e-5 * scale, float((g_f32 - g_pos).abs().max()) / scale
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import CnnKernelLayout
     rng = np.random.default_rng(nb + c)
@@ -470,16 +455,7 @@ def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool
     shapes = oracle.cnn_shapes((10, 10, c), a)
     _lo, _chosen, g_ref = oracle.net_loss_grad("cnn", oracle.unflatten(_np(theta), shapes), shapes, obs[idx], action[idx], target[idx])
     lay = CnnKernelLayout(c, a, matmul_f16=2)
-    for g in (g_pos, g_mix):
-        np.testing.assert_allclose(_np(lay.to_flax(g)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
-
-
-def test_position_parallel_backward_round2_kernel(gpu):
-    """bwd_pos=3: round 2's producer / consumer kernel (qnet_cnn_bwd_pos_kernel), kept as the A/B partner of the round-5 one."""
-    g_f32, f0 = _grads_under_options(gpu, 4, 3, 4096, 20000, 0, t1_pair=0)
-    g_pos, f1 = _grads_under_options(gpu, 4, 3, 4096, 20000, 2, t1_pair=2, bwd_pos=3)
-    assert (f0, f1) == ("single", "pair+pos")
-    assert float((g_f32 - g_pos).abs().max()) <= 2e-5 * float(g_f32.abs().max())
+    np.testing.assert_allclose(_np(lay.to_flax(g_pos)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
 
 
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 128, 1000), (4, 3, 16, 64), (6, 4, 256, 600), (7, 3, 96, 300), (10, 6, 48, 100)])

@@ -1,5 +1,6 @@
 """Phase stamps of the T1 pair kernel under the HEADLINE launch shape (16 seeds x 4096-sample minibatches per launch):
-run with PQN_T1_STAMPS=1 (and PQN_T1_PD2=0/1).  The single-seed stamps of tools/ablate_train.py come from a half-empty
+run with PQN_T1_STAMPS=1 PQN_BWD_POS=0 (the position-parallel form that 16-seed launches take by default has its own
+stamps: tools/pos_stamps.py).  The single-seed stamps of tools/ablate_train.py come from a half-empty
 chip whose 128 workgroups all stream the same seed's planes; these are the phases as the bench sees them."""
 import ctypes
 import os
@@ -24,15 +25,10 @@ def main():
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
     _lib.check(_lib.load().pqn_debug_t1_stamps(buf), "stamps")
-    pd2 = os.environ.get("PQN_T1_PD2", "0") not in ("", "0")
-    if pd2:
-        names = ["start", "inputs", "conv A", "conv B + park", "fc1 pair + h1T", "act/tgt", "heads A,B", "planes + dgrad A+B",
-                 "LN0 bwd A,B", "conv wgrad A", "conv wgrad B"]
-    else:
-        names = ["start", "inputs", "conv A", "conv B", "fc1 pair + h1T", "act/tgt", "heads A,B", "dgrad A", "P5+P6 A", "dgrad B", "P5+P6 B"]
+    names = ["start", "inputs", "conv A", "conv B", "fc1 pair + h1T", "act/tgt", "heads A,B", "dgrad A", "P5+P6 A", "dgrad B", "P5+P6 B"]
     for wg in range(4):
         s = [buf[wg * 16 + k] for k in range(len(names))]
-        print("PD2=%d WG%d:" % (pd2, wg), " ".join("%s=%d" % (names[k + 1], s[k + 1] - s[k]) for k in range(len(names) - 1)),
+        print("WG%d:" % wg, " ".join("%s=%d" % (names[k + 1], s[k + 1] - s[k]) for k in range(len(names) - 1)),
               "total=%d" % (s[-1] - s[0]))
 
 
