@@ -479,8 +479,10 @@ int pqn_mlp_update_seeds(const pqn_mlp_update_args_t *args /* host */, int32_t n
  * (publish / wait + sum in rank order + scale by 1 / world), so it can sit inside a captured update.  All ranks obtain
  * bit-identical results.  A peer that never arrives within the WALL-CLOCK time-out (option "peer_timeout_s", default 60 s;
  * the device's constant 100 MHz clock) ends in a sticky error word (pqn_peer_status: 0 = fine, r + 1 = rank r never
- * published), not in a hung device; every later collective then fails fast.  Callers poll the word once per update
- * (purejaxql_amd/dist.py) and stop: gradients behind a time-out are not synchronised. */
+ * published), not in a hung device; the bucket of that call -- and of every later one, which fails fast -- is overwritten
+ * with NaN rather than with a mean of stale staging buffers, so that the optimizer state of the detecting rank (and, through
+ * the NaN bucket it publishes at the next step, of every rank still alive) cannot pass for a synchronised result.  Callers
+ * poll the word once per update (purejaxql_amd/dist.py) and stop. */
 #define PQN_PEER_MAX 8
 typedef struct {
   int32_t rank, world;

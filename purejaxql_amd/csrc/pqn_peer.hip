@@ -100,18 +100,30 @@ __global__ __launch_bounds__(256) void peer_publish_kernel(const float *__restri
 __global__ __launch_bounds__(256) void peer_reduce_kernel(float *__restrict__ grad, long long n, PeerPtrs P, int rank, int world,
                                                           unsigned *local_state, unsigned long long timeout_ticks) {
   const unsigned target = local_state[0];   // the publish kernel of this step ran before us on the stream
-  if (threadIdx.x < world && (int)threadIdx.x != rank && local_state[2] == 0u) {   // after one time-out: fail fast
+  __shared__ unsigned s_bad;                // this block saw a time-out (now or at an earlier step)
+  if (threadIdx.x == 0) s_bad = local_state[2];
+  __syncthreads();
+  if (threadIdx.x < world && (int)threadIdx.x != rank && s_bad == 0u) {   // after one time-out: fail fast
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(P.flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
       if (wall_clock64() - t0 > timeout_ticks) {
         local_state[2] = 1u;                       // sticky error word: pqn_peer_status / PeerAllReduce.check()
         local_state[3] = threadIdx.x + 1u;         // which peer never arrived (1-based)
+        s_bad = 1u;
         break;
       }
       __builtin_amdgcn_s_sleep(32);
     }
   }
   __syncthreads();
+  if (s_bad != 0u) {
+    // a peer never arrived: the staging buffers hold some older step.  The bucket is poisoned instead of averaged, so that
+    // nothing downstream (optimizer step, metrics row, checkpoint) can pass for a synchronised result before the host
+    // has read the error word
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) grad[i] = qnan;
+    return;
+  }
   const size_t off = (size_t)((target - 1u) & 1u) * PEER_STRIDE(n);
   const float scale = 1.0f / (float)world;
   const long long n2 = n >> 1;

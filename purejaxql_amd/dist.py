@@ -166,8 +166,8 @@ class PeerAllReduce:
         _lib.check(_lib.load().pqn_peer_status(C.byref(self.struct), C.addressof(err)), "pqn_peer_status")
         if err.value:
             raise RuntimeError(f"peer all-reduce on rank {self.rank}: rank {err.value - 1} did not publish its gradient within "
-                               "the time-out (option peer_timeout_s); every optimizer step since then used unsynchronised "
-                               "gradients -- the run is invalid from that update on")
+                               "the time-out (option peer_timeout_s); from that step on this rank's gradient bucket is NaN "
+                               "(and, one step later, every live rank's) -- the run is invalid from that update on")
 
     def poll(self) -> None:
         """check() without stalling the stream: looks at the error word an EARLIER call copied to pinned host memory (raises
@@ -180,7 +180,7 @@ class PeerAllReduce:
             if int(self._host_state[2]):
                 bad = int(self._host_state[3]) - 1
                 raise RuntimeError(f"peer all-reduce on rank {self.rank}: rank {bad} did not publish its gradient within the "
-                                   "time-out (option peer_timeout_s); gradients are no longer synchronised -- stopping")
+                                   "time-out (option peer_timeout_s); the gradient bucket is NaN from that step on -- stopping")
         if self._poll_ev is None:
             self._host_state.copy_(self.state, non_blocking=True)
             self._poll_ev = torch.cuda.Event()

@@ -640,7 +640,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                     m.pop("env_frame", None)
                 if test_on:
                     m.update({f"test/{k}": float(v) for k, v in tm_box[0].items()})
-                cb(u, m)
+                _log_row(config, K, u, m)
 
         def update(u: int):
             if driver is not None:
@@ -751,8 +751,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             cb = config.get("_CALLBACK")
             # the Craftax script logs every WANDB_LOG_INTERVAL-th update only (pqn_craftax.py:394-397)
             if cb is not None and (not craftax or counters["n_updates"] % int(config.get("WANDB_LOG_INTERVAL", 128)) == 0):
-                cb(u, {k: v for k, v in m.items() if config.get("LOG_ACHIEVEMENTS", False) or "achievement" not in k.lower()}
-                   if craftax else m)
+                _log_row(config, K, u, {k: v for k, v in m.items() if config.get("LOG_ACHIEVEMENTS", False) or "achievement" not in k.lower()}
+                         if craftax else m)
 
         def finish():
             if grad_hook is not None and hasattr(grad_hook, "check"):
@@ -983,6 +983,16 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
     train.config = config
     train.backend = backend
     return train
+
+
+def _log_row(config: Dict[str, Any], rng: int, u: int, m: Dict[str, Any]) -> None:
+    """The reporting callback of the scripts (pqn_minatar.py:353-365, pqn_gymnax.py:346-358, pqn_craftax.py:394-408):
+    one call per seed and update; WANDB_LOG_ALL_SEEDS adds every metric a second time under "rng<original_rng>/", where
+    original_rng = rng[0] (:132), the first word of the seed's key."""
+    if config.get("WANDB_LOG_ALL_SEEDS", False):
+        tag = (int(rng) >> 32) & 0xFFFFFFFF
+        m = {**m, **{f"rng{tag}/{k}": v for k, v in m.items()}}
+    config["_CALLBACK"](u, m)
 
 
 def vmap_train(train: Callable[[int], Dict[str, Any]], keys: List[int], concurrent: bool = True) -> Dict[str, Any]:

@@ -226,6 +226,15 @@ METRIC_NAMES = ("env_step", "update_steps", "env_frame", "grad_steps", "td_loss"
                 "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode")
 
 
+def _options_epoch_moved(drv) -> bool:
+    """Shared by every update driver: a captured hipGraph replays the kernels (and the by-value kernel arguments, e.g. the peer
+    time-out) chosen at capture time.  Returns True when a pqn_set_option changed a value since `drv` captured
+    (pqn_options_epoch, include/pqn_hotpath.h); the caller then drops its graph(s) and captures again.  Leaves the current
+    epoch in drv._epoch_now for the capture that follows."""
+    drv._epoch_now = int(_lib.load().pqn_options_epoch())
+    return getattr(drv, "_graph_epoch", None) is not None and drv._graph_epoch != drv._epoch_now
+
+
 class UpdateDriver:
     """Whole-update enqueue (pqn_cnn_update / pqn_mlp_update) with optional hipGraph replay.  Holds the scratch
     buffers the C side needs; all training buffers are the caller's (rollout record, Cnn/MlpTrainer)."""
@@ -295,10 +304,9 @@ class UpdateDriver:
         """Enqueue (or replay) one update; the update index lives on the device (self.clock[0]).  A captured graph replays the
         kernels chosen at capture time: when a kernel-selection option changed since (pqn_options_epoch) it is dropped and
         the update is captured again, so that pqn_set_option / _lib.options(...) take effect on running drivers too."""
-        lib = _lib.load()
-        epoch = int(lib.pqn_options_epoch())
-        if self.graph is not None and getattr(self, "_graph_epoch", epoch) != epoch:
+        if _options_epoch_moved(self):
             self.graph = None
+        epoch = self._epoch_now
         if self.graph is not None:
             self.graph.replay()
         else:
@@ -362,6 +370,10 @@ class EnvShardDriver(UpdateDriver):
 
     def update(self):
         trainer = self._keep[0]
+        if _options_epoch_moved(self):
+            # an option changed (on every rank, by the same code path: the re-capture below meets on the hook's barrier): drop
+            # the whole-update graph and the per-segment graphs; this update runs the segments eagerly or re-captures them
+            self.whole = self.graphs = self.graph = None
         # a capturable collective (dist.PeerAllReduce: kernels on the training stream) lets the WHOLE update, its
         # NUM_MINIBATCHES*NUM_EPOCHS all-reduces included, be one hipGraph per rank: update 0 runs eagerly (the hook sets
         # itself up there), update 1 is captured and replayed, later ones replay
@@ -372,6 +384,7 @@ class EnvShardDriver(UpdateDriver):
                     with torch.cuda.graph(g):
                         self._enqueue_all()
                     self.whole = self.graph = g
+                    self._graph_epoch = self._epoch_now
                 except Exception as exc:  # stay on the per-segment path below (still the HIP path)
                     self.graph_error = repr(exc)
                     torch.cuda.synchronize()
@@ -385,7 +398,7 @@ class EnvShardDriver(UpdateDriver):
                 self.whole.replay()
                 self.calls += 1
                 return
-        capture = self.use_graph and self.calls == 1 and self.graphs is None and self.graph_error is None
+        capture = self.use_graph and self.calls >= 1 and self.graphs is None and self.graph_error is None
         new_graphs = []
         for k, seg in enumerate(self.segments):
             if self.graphs is not None:
@@ -409,6 +422,7 @@ class EnvShardDriver(UpdateDriver):
         if capture and self.graph_error is None and len(new_graphs) == len(self.segments):
             self.graphs = new_graphs
             self.graph = new_graphs[0]   # "graph" in runner_state["driver"]
+            self._graph_epoch = self._epoch_now
         self.calls += 1
 
 
@@ -581,16 +595,19 @@ class SeedGroupsDriver:
                                                   self._ws, sc, self._tail_ptr), "pqn_cnn_update_seed_groups")
 
     def update(self):
+        if _options_epoch_moved(self):
+            self.graph = None
         if self.graph is not None:
             self.graph.replay()
         else:
             self._enqueue()
-            if self.use_graph and self.calls == 0 and self.graph_error is None:
+            if self.use_graph and (self.calls == 0 or getattr(self, "_graph_epoch", None) is not None) and self.graph_error is None:
                 try:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._enqueue()
                     self.graph = g
+                    self._graph_epoch = self._epoch_now
                 except Exception as exc:  # stay on the eager C++ enqueue (still the HIP path)
                     self.graph_error = repr(exc)
                     torch.cuda.synchronize()

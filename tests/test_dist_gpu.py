@@ -101,6 +101,68 @@ def test_two_rank_env_sharded_training_matches_oracle_with_averaged_gradients(gp
     assert bad.mean() < 1e-3 and d.max() < 5e-4, (int(bad.sum()), float(d.max()))
 
 
+def _recapture_main(rank, world, port, q, theta0, peer):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from purejaxql_amd import _lib
+    from purejaxql_amd import dist as pdist
+    from purejaxql_amd.pqn import make_train, seed_keys
+    pdist.init_from_env()
+    thetas, graphs = [], []
+    for flip in (False, True):
+        cfg = pdist.shard_env_config(_cfg(64, 5), rank, world)
+        cfg["_INIT_PARAMS"] = torch.from_numpy(theta0).to("cuda:0")
+        train = make_train(cfg, device="cuda:0", grad_hook=pdist.make_grad_allreduce_hook(peer=peer),
+                           metrics_hook=pdist.allreduce_mean_scalars)
+        update, finish = train.make_runner(seed_keys(0, 1)[0])
+        drv = update.driver
+        seen = []
+        prev = _lib.get_option("peer_timeout_s")
+        for u in range(5):
+            if flip and u == 3:
+                _lib.set_option("peer_timeout_s", prev + 1)    # every rank, same update: the re-capture is collective
+            update(u)
+            seen.append(id(drv.whole) if drv.whole is not None else (id(drv.graphs[0]) if drv.graphs else None))
+        _lib.set_option("peer_timeout_s", prev)
+        out = finish()
+        torch.cuda.synchronize()
+        thetas.append(out["runner_state"]["theta"].cpu().numpy())
+        graphs.append(seen)
+        dist.barrier()
+    q.put((rank, thetas, graphs, type(drv).__name__))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("peer", [True, False])
+def test_env_shard_driver_recaptures_its_graphs_when_an_option_changes(gpu, peer):
+    """EnvShardDriver watches pqn_options_epoch like UpdateDriver does.  Two ranks x 32 envs, 5 updates: update 1
+    captures (one whole-update graph with the in-graph peer all-reduce / nine per-segment graphs around the host collective),
+    update 2 replays, an option changes on both ranks before update 3 -- that update is enqueued and captured afresh -- and the
+    parameters equal the undisturbed run's bit for bit on both ranks."""
+    from purejaxql_amd.networks import QNetwork
+    world = 2
+    theta0 = QNetwork("cnn", (10, 10, 4), 3, device=gpu).init(17).cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_recapture_main, args=(r, world, port, q, theta0, peer)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _rank, thetas, graphs, name in res:
+        assert name == "EnvShardDriver"
+        plain, flipped = graphs
+        assert plain[1] is not None and plain[1] == plain[2] == plain[3] == plain[4], plain
+        assert flipped[1] == flipped[2] and flipped[3] is not None and flipped[3] != flipped[2] and flipped[4] == flipped[3], flipped
+        np.testing.assert_array_equal(thetas[0], thetas[1])
+    np.testing.assert_array_equal(res[0][1][0], res[1][1][0])
+
+
 def _peer_main(rank, world, port, q, n, steps):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -144,27 +206,29 @@ def _peer_main(rank, world, port, q, n, steps):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [132475, 7])
-def test_peer_allreduce_two_processes_on_one_gpu(gpu, n):
-    """dist.PeerAllReduce by itself: two processes map each other's staging regions through hipIpc and average a bucket of
-    the CNN's size (odd length: the scalar tail) over 24 consecutive steps (double-buffer reuse, one rank arriving late,
-    calls from a side stream): bit-identical on both ranks and equal to the sum in rank order times 1 / world."""
-    world, steps = 2, 24
+@pytest.mark.parametrize("world,n", [(2, 132475), (2, 7), (8, 132475)])
+def test_peer_allreduce_processes_on_one_gpu(gpu, world, n):
+    """dist.PeerAllReduce by itself: `world` processes map each other's staging regions through hipIpc and average a bucket
+    of the CNN's size (odd length: the scalar tail) over 24 consecutive steps (double-buffer reuse, one rank arriving late,
+    calls from a side stream): bit-identical on all ranks and equal to the sum in rank order times 1 / world.  world = 8 is
+    PQN_PEER_MAX, the node size of BASELINE.json's configs[3] (eight processes on the one GPU of the box here)."""
+    steps = 24
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_peer_main, args=(r, world, port, q, n, steps)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda x: x[0])
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda x: x[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, ok0, o0, r0), (_, ok1, o1, _r1) = res
-    assert ok0 and ok1, "hipIpc peer mapping is unavailable on this box"
+    assert all(ok for _, ok, _o, _r in res), "hipIpc peer mapping is unavailable on this box"
+    _, _, o0, r0 = res[0]
     for s in range(steps):
-        np.testing.assert_array_equal(o0[s], o1[s], err_msg=f"step {s}")
         np.testing.assert_array_equal(o0[s], r0[s], err_msg=f"step {s}")
+        for rk in range(1, world):
+            np.testing.assert_array_equal(o0[s], res[rk][2][s], err_msg=f"step {s} rank {rk}")
 
 
 def _peer_timeout_main(rank, world, port, q):
@@ -191,6 +255,7 @@ def _peer_timeout_main(rank, world, port, q):
             par(x)
             torch.cuda.synchronize()
             res["waited_s"] = time.time() - t0
+            res["poisoned"] = bool(torch.isnan(x).all())   # no plausible mean of stale buffers: the bucket is NaN
             par.poll()          # queues the asynchronous copy of the error word ...
             torch.cuda.synchronize()
             try:
@@ -215,8 +280,8 @@ def _peer_timeout_main(rank, world, port, q):
 
 def test_peer_allreduce_time_out_is_wall_clock_and_reported(gpu):
     """The in-graph peer all-reduce with a rank that never publishes (round 4 hardening): the waiting rank gives up after the
-    configured WALL-CLOCK time (option peer_timeout_s = 2 here; rounds 1-3 counted polls), leaves a sticky error word that
-    names the missing rank, PeerAllReduce.poll() -- the training loop's once-per-update, non-blocking look at it -- and
+    configured WALL-CLOCK time (option peer_timeout_s = 2 here; rounds 1-3 counted polls), writes NaN over its gradient bucket
+    instead of a mean of stale staging buffers (round 5), leaves a sticky error word that names the missing rank, PeerAllReduce.poll() -- the training loop's once-per-update, non-blocking look at it -- and
     check() raise, and later collectives fail fast instead of waiting again.  setup() has by then passed its self-test
     (three all-reduces of a known bucket through the real kernels, verdict all-gathered)."""
     world = 2
@@ -233,30 +298,32 @@ def test_peer_allreduce_time_out_is_wall_clock_and_reported(gpu):
     assert res[0]["ok"] and res[1]["ok"], "hipIpc peer mapping is unavailable on this box"
     assert res[0]["step_ok"] and res[1]["step_ok"]
     assert 1.5 <= res[0]["waited_s"] <= 6.0, res[0]
+    assert res[0]["poisoned"] is True, res[0]
     assert res[0]["poll_raised"] is True and res[0]["check_raised"] is True, res[0]
     assert res[0]["fail_fast_s"] < 1.0, res[0]
 
 
-@pytest.mark.parametrize("mode", ["seeds", "envs"])
-def test_bench_gpus_2_launches_its_own_ranks(gpu, mode):
-    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command line) re-executes itself
-    under torch.distributed.run with two ranks -- both on the one GPU of the box here (PQN_BENCH_ONE_GPU=1, gloo) -- and
-    rank 0 prints ONE JSON line with n_gpus = 2, the whole-job rate, max-over-ranks timing; --mode envs also reports
-    which gradient all-reduce ran (the in-graph peer kernels)."""
+@pytest.mark.parametrize("gpus,mode", [(2, "seeds"), (2, "envs"), (8, "envs")])
+def test_bench_gpus_n_launches_its_own_ranks(gpu, gpus, mode):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the driver's command line) re-executes itself
+    under torch.distributed.run with N ranks -- all on the one GPU of the box here (PQN_BENCH_ONE_GPU=1, gloo) -- and
+    rank 0 prints ONE JSON line with n_gpus = N, the whole-job rate, max-over-ranks timing; --mode envs also reports
+    which gradient all-reduce ran (the in-graph peer kernels) and how many ranks took part in it.  N = 8 is the node size of
+    BASELINE.json's configs[3]: control flow of the 8-rank launch, not a scaling measurement."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(PQN_BENCH_ONE_GPU="1", PQN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--no-extras",
            "--no-cpu-baseline", "--seeds-per-gpu", "2", "--mode", mode]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    assert d["n_gpus"] == gpus and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
     c = d["config"]
     assert c["dist_backend"] == "gloo" and c["rccl_ranks"] == 0 and c["gpus_visible"] == 1
     if mode == "seeds":
@@ -264,3 +331,4 @@ def test_bench_gpus_2_launches_its_own_ranks(gpu, mode):
         assert abs(d["value"] - c["env_steps_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     else:
         assert d["scaling"] == "strong" and c["grad_allreduce"] == "peer" and c["driver"] == "hipGraph replay"
+        assert c["ranks_in_allreduce"] == gpus

@@ -183,7 +183,8 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
     """pqn_cnn_update_seed_groups (two groups of 8 seeds, the tails of one group on a second stream under the training
     kernel of the other -- the default of the bench configuration) against ONE 16-seed batch through
     pqn_cnn_update_seeds: every seed, every metric, parameters, optimizer state and env state bit for bit, as a replayed
-    two-branch hipGraph and as the eager two-stream enqueue.  (vmap over seeds, pqn_minatar.py:459-461.)"""
+    two-branch hipGraph and as the eager two-stream enqueue; the graph is re-captured when pqn_options_epoch moves between two
+    updates.  (vmap over seeds, pqn_minatar.py:459-461.)"""
     from purejaxql_amd import _lib
     from purejaxql_amd.pqn import make_train, seed_keys
     keys = seed_keys(3, S)
@@ -192,9 +193,18 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
         # (pinned form: a group of 8 seeds would otherwise fall back to the pair kernels and no longer equal the 16-seed batch)
         cfg = _cfg(3, SEED_GROUPS=groups, _SEED_GROUPS_TAIL=tail, SEED_BATCH_BIT_IDENTICAL=True)
         update, finish = make_train(cfg, device="cuda:0").make_batch_runner(keys)
-        for u in range(3):
-            update(u)
+        update(0); update(1)
+        g1 = update.driver.graph
+        # an option changes mid-run (one that leaves the results alone): every driver -- SeedGroupsDriver included, ADVICE r4 --
+        # drops its graph and captures again, so that options held by value in the captured launches follow pqn_set_option
+        prev = _lib.get_option("peer_timeout_s")
+        try:
+            _lib.set_option("peer_timeout_s", prev + 1)
+            update(2)
+        finally:
+            _lib.set_option("peer_timeout_s", prev)
         torch.cuda.synchronize()
+        assert (g1 is None and update.driver.graph is None) or update.driver.graph is not g1
         return finish(), update.driver
 
     one, d1 = run(1)

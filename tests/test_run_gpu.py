@@ -141,6 +141,32 @@ def test_single_run_saves_reference_format_checkpoints(gpu, tmp_path):
     torch.testing.assert_close(theta, outs["runner_state"][1]["theta"].cpu(), rtol=0, atol=0)
 
 
+def test_single_run_logs_json_lines_per_seed_with_rng_prefixed_copies(gpu, capsys):
+    """WANDB_MODE != disabled: one JSON line per seed and update (wandb is not available offline; pqn_minatar.py:353-365 calls
+    wandb.log once per vmapped seed); WANDB_LOG_ALL_SEEDS adds every metric again under "rng<first word of the seed's key>/"
+    (:356-362, original_rng = rng[0] at :132).  The logged values are the returned metrics."""
+    import json
+    from purejaxql_amd import _lib
+    from purejaxql_amd.config_loader import load_config
+    from purejaxql_amd.pqn import seed_keys
+    from purejaxql_amd.run import single_run
+    cfg = load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", "alg.NUM_ENVS=32", "alg.NUM_STEPS=8",
+                       "alg.NUM_MINIBATCHES=4", "alg.TOTAL_TIMESTEPS=768", "alg.TEST_DURING_TRAINING=False",
+                       "NUM_SEEDS=2", "SEED=7", "WANDB_MODE=online", "alg.WANDB_LOG_ALL_SEEDS=True"])
+    outs = single_run(cfg)
+    rows = [json.loads(ln) for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(rows) == 2 * 3                     # seeds one after the other, three updates each
+    tags = [(k >> 32) & 0xFFFFFFFF for k in seed_keys(7, 2)]
+    assert tags[0] != tags[1]
+    for s in range(2):
+        for u in range(3):
+            r = rows[3 * s + u]
+            assert r["update_steps"] == u + 1 and r[f"rng{tags[s]}/update_steps"] == u + 1
+            plain = {k for k in r if not k.startswith("rng")}
+            assert {f"rng{tags[s]}/{k}" for k in plain} == {k for k in r if k.startswith("rng")}
+            assert r["td_loss"] == r[f"rng{tags[s]}/td_loss"] == float(outs["metrics"]["td_loss"][s][u])
+
+
 @pytest.mark.parametrize("backend", ["fused", "torch"])
 def test_eval_metrics_flat_obs_path_vs_oracle(gpu, oracle, backend):
     """get_test_metrics on the gymnax-classic path (pqn_gymnax.py:362-404): CartPole-v1, fused MLP kernels and
