@@ -325,7 +325,9 @@ int pqn_cnn_update_seeds(const pqn_update_args_t *args /* host */, int32_t num_s
  * runs UNDER the next group's training kernel on `stream` (edges training kernel(g,i) -> tail(g,i) -> training
  * kernel(g,i+1) as events).  tail_stream is forked from and joined back into `stream` inside the call: capturing `stream`
  * yields one hipGraph with two branches.  Per seed bit-identical to pqn_cnn_update_seeds on the same group.  All groups
- * must share NUM_MINIBATCHES / NUM_EPOCHS; array arguments are host arrays of num_groups entries. */
+ * must share NUM_MINIBATCHES / NUM_EPOCHS; array arguments are host arrays of num_groups entries.  The dependency events are
+ * kept per device (the device current at the call).  An error return can leave tail_stream forked but not joined: a caller
+ * that is capturing `stream` must end the capture and discard the graph (pqn_bigmlp_update with option upd_overlap: the same). */
 int pqn_cnn_update_seed_groups(int32_t num_groups, const pqn_update_args_t *const *args /* host */,
                                const int32_t *num_seeds /* host */, const uint64_t *const *key_roll_dev,
                                const uint64_t *const *key_shuf_dev, const int64_t *theta_stride /* host */,

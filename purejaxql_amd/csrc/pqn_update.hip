@@ -353,17 +353,25 @@ extern "C" int pqn_cnn_update_seeds(const pqn_update_args_t *a, int32_t num_seed
 // kernels, same launch shapes per group, only their order in time changes).
 // ---------------------------------------------------------------------------------------------------------
 #define PQN_MAX_SEED_GROUPS 8
-static struct {
+#define PQN_MAX_DEVICES 16
+// dependency markers, one set per DEVICE (an event belongs to the device that was current when it was created; a process
+// that drives several GPUs gets a set for each)
+struct SeedGroupEvents {
   bool created = false;
   hipEvent_t fork, join, t1[PQN_MAX_SEED_GROUPS], tail[PQN_MAX_SEED_GROUPS];
-} g_sg_ev;
+};
+static SeedGroupEvents g_sg_ev_dev[PQN_MAX_DEVICES];
 
-#define HIP_OK(call, what)                                             \
-  do {                                                                 \
-    if ((call) != hipSuccess) {                                        \
-      pqn_set_error("pqn_cnn_update_seed_groups: %s failed", what);    \
-      return PQN_E_HIP;                                                \
-    }                                                                  \
+// the enclosing function names itself in `pqn_fn_`.  An error return between a fork and its join leaves the side stream
+// un-joined: a caller that is capturing must end and discard the capture (the qnet.py drivers do -- torch.cuda.graph's exit
+// ends the capture, the exception drops the graph); include/pqn_hotpath.h says so at both entry points.
+#define HIP_OK(call, what)                                  \
+  do {                                                      \
+    if ((call) != hipSuccess) {                             \
+      (void)hipGetLastError();                              \
+      pqn_set_error("%s: %s failed", pqn_fn_, what);        \
+      return PQN_E_HIP;                                     \
+    }                                                       \
   } while (0)
 
 extern "C" int pqn_cnn_update_seed_groups(int32_t num_groups, const pqn_update_args_t *const *args, const int32_t *num_seeds,
@@ -374,8 +382,13 @@ extern "C" int pqn_cnn_update_seed_groups(int32_t num_groups, const pqn_update_a
                   theta_stride && workspace_stride,
               "pqn_cnn_update_seed_groups: 1 <= num_groups <= %d and non-NULL argument arrays", PQN_MAX_SEED_GROUPS);
   PQN_REQUIRE(tail_stream && tail_stream != stream, "pqn_cnn_update_seed_groups: tail_stream must be a second, non-NULL stream");
+  static const char *const pqn_fn_ = "pqn_cnn_update_seed_groups";
   hipStream_t sc = (hipStream_t)stream, sm = (hipStream_t)tail_stream;
   const int G = num_groups;
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev), "hipGetDevice");
+  PQN_REQUIRE(dev >= 0 && dev < PQN_MAX_DEVICES, "pqn_cnn_update_seed_groups: device ordinal %d out of range", dev);
+  SeedGroupEvents &g_sg_ev = g_sg_ev_dev[dev];
   UpdCtx c[PQN_MAX_SEED_GROUPS];
   for (int g = 0; g < G; ++g) {
     PQN_REQUIRE(num_seeds[g] == 1 || (theta_stride[g] > 0 && workspace_stride[g] > 0 && theta_stride[g] % 4 == 0 && workspace_stride[g] % 4 == 0),
@@ -587,17 +600,22 @@ __global__ void keys_to_index_kernel(int64_t *__restrict__ keys, int n, long lon
   if (i < n) keys[i] &= mask;
 }
 
-// side stream + fork / join events of pqn_bigmlp_update (process-wide, created on first use; NULL = run everything on the
-// caller's stream: option upd_overlap = 0, or the stream / events could not be created)
+// side stream + fork / join events of pqn_bigmlp_update (one set per device, created on first use there; NULL = run
+// everything on the caller's stream: option upd_overlap = 0, or the stream / events could not be created)
 struct UpdSide {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   bool tried = false, ok = false;
 };
-static UpdSide g_upd_side;
+static UpdSide g_upd_side[PQN_MAX_DEVICES];
 static UpdSide *upd_side() {
   if (pqn_opt(PQN_OPT_UPD_OVERLAP) <= 0) return nullptr;
-  UpdSide &u = g_upd_side;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PQN_MAX_DEVICES) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  UpdSide &u = g_upd_side[dev];
   if (!u.tried) {
     u.tried = true;
     u.ok = hipStreamCreateWithFlags(&u.s, hipStreamNonBlocking) == hipSuccess &&
@@ -609,6 +627,7 @@ static UpdSide *upd_side() {
 }
 
 extern "C" int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *a, void *stream) {
+  static const char *const pqn_fn_ = "pqn_bigmlp_update";
   hipStream_t st = (hipStream_t)stream;
   PQN_REQUIRE(a, "pqn_bigmlp_update: args is NULL");
   PQN_REQUIRE(a->clock && a->sched_keys && a->sched_eps && a->state && a->obs && a->action && a->reward && a->done &&
