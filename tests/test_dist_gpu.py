@@ -117,13 +117,16 @@ def _recapture_main(rank, world, port, q, theta0, peer):
                            metrics_hook=pdist.allreduce_mean_scalars)
         update, finish = train.make_runner(seed_keys(0, 1)[0])
         drv = update.driver
-        seen = []
+        seen, alive = [], []
         prev = _lib.get_option("peer_timeout_s")
         for u in range(5):
             if flip and u == 3:
                 _lib.set_option("peer_timeout_s", prev + 1)    # every rank, same update: the re-capture is collective
             update(u)
-            seen.append(id(drv.whole) if drv.whole is not None else (id(drv.graphs[0]) if drv.graphs else None))
+            g = drv.whole if drv.whole is not None else (drv.graphs[0] if drv.graphs else None)
+            if g is not None and not any(g is x for x in alive):
+                alive.append(g)            # kept alive: a dropped graph's address could be handed to its successor
+            seen.append(None if g is None else [i for i, x in enumerate(alive) if x is g][0])
         _lib.set_option("peer_timeout_s", prev)
         out = finish()
         torch.cuda.synchronize()
