@@ -9,13 +9,19 @@
 //
 //   pos_gather_kernel    (super-tile of 32 samples, seed): the minibatch's packed observation rows in minibatch order +
 //                        their bit-transpose T32[bit] = one word over the 32 samples (the conv weight gradient's operand)
-//   cnn_pos_bwd_kernel   (8 positions, chunk of samples, seed), wave = position: per super-tile the conv + LayerNorm_0 are
-//                        recomputed in MFMA accumulator layout (lane = channel, 4 samples per lane and tile), then dgrad
-//                        against the resident planes, relu mask, LayerNorm_0 backward, and -- with h1 / dx split ONCE, in
-//                        registers -- the position's rows of dW1 and its conv weight-gradient tile.  dz (bf16 planes, ONE
-//                        image for both operand orders: ds_read_b128 / ds_read_b64_tr_b16), the packed rows and T32 arrive
-//                        per super-tile through LDS-DMA (global_load_lds) into a two-slot ring: one barrier per super-tile,
-//                        no staging registers, no ds_write.
+//   cnn_pos_fwd_kernel   (256 samples, seed), wave = 32 samples for all 64 positions: conv on the fly (transposed, so that its
+//                        outputs are fc1's A fragments), z[32][128] in registers, the W1 planes of a K step through ONE
+//                        LDS-DMA per workgroup; head, loss and the head's backward on the accumulator layout; writes dz
+//                        as bf16 planes, LayerNorm_0's (mean, 1/std) and one head record per workgroup
+//   cnn_pos_bwd_kernel   (8 positions, chunk of samples, seed), wave = position: per super-tile the conv is recomputed in
+//                        MFMA accumulator layout (lane = channel, 4 samples per lane and tile) and normalised with the
+//                        forward's statistics, then dgrad against the resident planes, relu mask, LayerNorm_0 backward,
+//                        and -- with h1 / dx split ONCE, in registers -- the position's rows of dW1 and its conv
+//                        weight-gradient tile.  dz (bf16 planes, ONE image for both operand orders: ds_read_b128 /
+//                        ds_read_b64_tr_b16), the packed rows, T32 and the statistics arrive per super-tile through
+//                        LDS-DMA (global_load_lds) into a four-slot ring: one barrier per two super-tiles, no staging
+//                        registers, no ds_write.
+//   cnn_pos_rollout_kernel  the persistent rollout in the forward kernel's structure (256 envs per workgroup)
 //
 #include <stdlib.h>
 
@@ -538,7 +544,8 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 //   - accumulates z[32][128] in 64 VGPRs over all 32 K steps: no split-K partials, no z tile in LDS.
 // The head then works on the accumulator layout directly (lane = 8 output columns x 8 sample rows; row sums are DPP
 // butterflies over the 16 column lanes), leaves its parameter-gradient sums as ONE record per workgroup, and writes dz as
-// pre-split bf16 planes in both operand orders of the backward (dz_planes_a / dz_planes_b) plus LayerNorm_0's (mean, 1/std).
+// pre-split bf16 planes in the dgrad's operand order (dz_planes_a; the weight gradient reads the same image through the
+// transposing LDS read) plus LayerNorm_0's (mean, 1/std).
 // Inputs in minibatch order (pos_gather_kernel): packed rows, action, target.
 // ---------------------------------------------------------------------------
 // all-reduce of TWO per-lane values over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} with three lane swaps:
