@@ -34,6 +34,7 @@ def _rank_main(rank, world, port, q, num_envs_global, n_upd, theta0, use_driver,
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
+    torch.set_num_threads(2)      # the ranks share the host: one thread per core EACH (the default) thrashes
     from purejaxql_amd import dist as pdist
     from purejaxql_amd.pqn import make_train, seed_keys
     pdist.init_from_env()
@@ -105,6 +106,7 @@ def _recapture_main(rank, world, port, q, theta0, peer):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
+    torch.set_num_threads(2)      # the ranks share the host: one thread per core EACH (the default) thrashes
     from purejaxql_amd import _lib
     from purejaxql_amd import dist as pdist
     from purejaxql_amd.pqn import make_train, seed_keys
@@ -170,11 +172,15 @@ def _peer_main(rank, world, port, q, n, steps):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
+    torch.set_num_threads(2)      # the ranks share the host: one thread per core EACH (the default) thrashes
     from purejaxql_amd import dist as pdist
     pdist.init_from_env()
     dev = torch.device("cuda:0")
+    import time
+    t_start = time.time()
     par = pdist.PeerAllReduce(n, dev)
     ok = par.setup()
+    t_setup = time.time() - t_start
     outs, refs = [], []
     if ok:
         g = torch.Generator(device="cpu")
@@ -203,6 +209,8 @@ def _peer_main(rank, world, port, q, n, steps):
             outs.append(mine.cpu())
             refs.append(acc * (1.0 / world))
         par.check()
+    if rank == 0:
+        print(f"peer all-reduce, world {world}: setup {t_setup:.1f} s, {steps} steps {time.time() - t_start - t_setup:.1f} s", flush=True)
     q.put((rank, ok, [o.numpy() for o in outs], [r.numpy() for r in refs]))
     dist.barrier()
     par.close()
@@ -239,6 +247,7 @@ def _peer_timeout_main(rank, world, port, q):
                       LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import time
     import torch.distributed as dist
+    torch.set_num_threads(2)      # the ranks share the host: one thread per core EACH (the default) thrashes
     from purejaxql_amd import _lib
     from purejaxql_amd import dist as pdist
     pdist.init_from_env()
