@@ -114,20 +114,23 @@ struct BmEpilogue {
 };
 #define BM_STAMP(i) do { if (E.stamps && blockIdx.x + blockIdx.y + blockIdx.z == 0 && tid == 0 && (i) < 120) E.stamps[i] = __builtin_readcyclecounter(); } while (0)
 
-template <int BM, int BN>
-constexpr int bm_lds_bytes() { return 2 * 3 * (BM / 16 + BN / 16) * 64 * 16; }
+template <int BM, int BN, int STG = 2>
+constexpr int bm_lds_bytes() { return STG * 3 * (BM / 16 + BN / 16) * 64 * 16; }
 
 // C[m][n] = sum_k A[m][k] B[n][k]; K padded (the planes hold zeros there), klen % 32 == 0.
 // Workgroup tile BM x BN (128 x 64 | 64 x 64; 128 x 128 builds too and measured slower at one workgroup per CU), four
 // waves as 2 x 2, wave tile (BM/2) x (BN/2) = MI x NI MFMA tiles; two (three) workgroups per CU.
-template <int BM, int BN, int EPI>
+// STG = 2: two LDS stages, one barrier per K step.  STG = 1 (64 x 64 tiles, option bm_stages = 1): ONE stage of 24 KB and
+// two barriers per K step -- the buffer is rewritten as soon as every wave holds its fragments of the step in registers --
+// so that four workgroups (16 waves) share a CU instead of three.
+template <int BM, int BN, int EPI, int STG = 2>
 __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int Kp, int klen, BmPlanes A, BmPlanes B, BmEpilogue E) {
   constexpr int NBA = BM / 16, NBB = BN / 16;
   constexpr int PA = BM * 4 / BM_THREADS, PB = BN * 4 / BM_THREADS;      // 16-B slots per thread, plane and K step
   constexpr int MI = BM / 32, NI = BN / 32;                             // 16 x 16 MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) char bm_smem[];
-  u32x4 *sA = reinterpret_cast<u32x4 *>(bm_smem);                         // [2][3][NBA][64]
-  u32x4 *sB = sA + 2 * 3 * NBA * 64;                                      // [2][3][NBB][64]
+  u32x4 *sA = reinterpret_cast<u32x4 *>(bm_smem);                         // [STG][3][NBA][64]
+  u32x4 *sB = sA + STG * 3 * NBA * 64;                                    // [STG][3][NBB][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB L2: with
@@ -229,7 +232,14 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
 #pragma unroll 1
   for (int ks = 0; ks < nk; ++ks) {
     BM_STAMP(8 + 8 * ks);
-    if (ks + 1 < nk) lstore((ks + 1) & 1);
+    if constexpr (STG == 1) {
+      if (ks + 1 < nk) {
+        __syncthreads();          // every wave has its fragments of step ks out of the (only) buffer
+        lstore(0);
+      }
+    } else {
+      if (ks + 1 < nk) lstore((ks + 1) & 1);
+    }
     BM_STAMP(9 + 8 * ks);
     if (ks + 2 < nk) gload(kbeg + (ks + 2) * BM_KS);
     BM_STAMP(10 + 8 * ks);
@@ -244,9 +254,9 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
     BM_PROD(0, 0)
 #undef BM_PROD
     BM_STAMP(11 + 8 * ks);
-    __syncthreads();
+    if (STG == 2 || ks + 1 < nk) __syncthreads();
     BM_STAMP(12 + 8 * ks);
-    if (ks + 1 < nk) fragload((ks + 1) & 1);
+    if (ks + 1 < nk) fragload(STG == 1 ? 0 : (ks + 1) & 1);
     BM_STAMP(13 + 8 * ks);
   }
   BM_STAMP(2);
@@ -1045,7 +1055,7 @@ BmEpilogue bm_store(float *out, long long ldc, const float *bias = nullptr, long
 // split (<= max_split, each part >= 128 long) that fills whole "rounds" best -- a round = every CU holding as many
 // workgroups as its LDS takes (two 128 x 64, three 64 x 64).  Run-time switches "bm_tile" (64 / 128) and "bm_split"
 // override (A/B runs).
-struct BmPlan { int bm, nsplit, klen; };
+struct BmPlan { int bm, nsplit, klen, stages; };
 BmPlan bm_plan(int M, int N, int Kp, int max_split) {
   const long long t128 = (long long)((M + 127) / 128) * ((N + 63) / 64);
   BmPlan p;
@@ -1056,7 +1066,8 @@ BmPlan bm_plan(int M, int N, int Kp, int max_split) {
   p.bm = t128 >= (topt > 128 ? topt : 129) ? 128 : 64;
   if (topt == 64 || topt == 128) p.bm = topt;
   const long long tiles = (long long)((M + p.bm - 1) / p.bm) * ((N + 63) / 64);
-  const long long round = 256ll * (p.bm == 128 ? 2 : 3);
+  p.stages = (p.bm == 64 && pqn_opt(PQN_OPT_BM_STAGES) == 1) ? 1 : 2;
+  const long long round = 256ll * (p.bm == 128 ? 2 : (p.stages == 1 ? 4 : 3));
   int s = 1;
   double best = 0.0;
   for (int c = 1; c <= max_split; ++c) {
@@ -1073,10 +1084,10 @@ BmPlan bm_plan(int M, int N, int Kp, int max_split) {
 template <int EPI>
 int bm_launch(int M, int N, int Kp, const BmPlan &p, const BmPlanes &A, const BmPlanes &B, const BmEpilogue &E, hipStream_t st) {
   const dim3 grid((N + 63) / 64, (M + p.bm - 1) / p.bm, p.nsplit);
-#define BM_GO(BM_)                                                                                                      \
+#define BM_GO(BM_, STG_)                                                                                                \
   do {                                                                                                                   \
-    auto kern = &bm_gemm_kernel<BM_, 64, EPI>;                                                                           \
-    constexpr int lds = bm_lds_bytes<BM_, 64>();                                                                        \
+    auto kern = &bm_gemm_kernel<BM_, 64, EPI, STG_>;                                                                     \
+    constexpr int lds = bm_lds_bytes<BM_, 64, STG_>();                                                                  \
     static bool attr = false;                                                                                            \
     if (!attr) {                                                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
@@ -1085,8 +1096,9 @@ int bm_launch(int M, int N, int Kp, const BmPlan &p, const BmPlanes &A, const Bm
     hipLaunchKernelGGL(kern, grid, dim3(BM_THREADS), lds, st, M, N, Kp, p.klen, A, B, E);                                \
   } while (0)
   const bool timed = pqn_prof_begin(2, st);
-  if (p.bm == 128) BM_GO(128);
-  else BM_GO(64);
+  if (p.bm == 128) BM_GO(128, 2);
+  else if (p.stages == 1) BM_GO(64, 1);
+  else BM_GO(64, 2);
   if (timed) pqn_prof_end(st);
 #undef BM_GO
   return pqn_check_launch("pqn_bigmlp gemm");
@@ -1634,6 +1646,7 @@ extern "C" int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, 
   prep(b, ldb, trans_b != 0, n, pb);
   BmPlan p;
   p.bm = tile_rows;
+  p.stages = (tile_rows == 64 && pqn_opt(PQN_OPT_BM_STAGES) == 1) ? 1 : 2;
   p.klen = ((kp + nsplit - 1) / nsplit + BM_KS - 1) / BM_KS * BM_KS;
   p.nsplit = (kp + p.klen - 1) / p.klen;
   BmEpilogue E = bm_store(c, ldc, bias, split_stride);
