@@ -384,8 +384,7 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * the bf16x3 training step / rollout, pqn_qnet_pos.hip: 0 never, 1 (default) when the launch fills the chip -- minibatch tiles of 256 x seeds >= 160 --
  * or, under SEED_BATCH_BIT_IDENTICAL, from the per-seed size alone; 2 whenever the shape allows), "seed_group", "ablate_train", "ablate", "bm_tile", "bm_split" (wide-MLP GEMM tile height 64 / 128 -- a value above 128 = "128-row tiles from that many tiles
  * up" -- / K splits), "bm_overlap" (parameter-gradient side of the wide-MLP backward layer by layer on a second stream instead of batched behind
- * the input-gradient chain; default 0), "bm_stages" (LDS stages of the 64 x 64 GEMM tile: 2 (default), 1 = one stage, two barriers per K step,
- * four workgroups per CU: measured 1 % slower, profiles/r05_v4_c5_gemm_single_stage_ab.txt), "upd_overlap" (pqn_bigmlp_update: first permutation and last gradient-copy plane refresh on a side stream;
+ * the input-gradient chain; default 0), "upd_overlap" (pqn_bigmlp_update: first permutation and last gradient-copy plane refresh on a side stream;
  * default 0, measured slower), "peer_timeout_s" (seconds pqn_peer_allreduce_mean waits for a peer; default 60), "t2_acc" (bf16x3 fc1 weight
  * gradient without split-K partials: 0 never, 1 (default) when row blocks x seeds of a launch fill the chip, 2 always), "t1_ksplit" (K-split form of the f32-mode training kernel for minibatches of
  * at most 256 samples: a tile's work cut along the conv positions over many workgroups; 1 (default) = forward partial +
@@ -609,8 +608,10 @@ int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *args /* host */, void *str
 /* Where a forward intermediate of the last pqn_bigmlp_forward / pqn_bigmlp_grad call lives inside `workspace`, for
  * tests (e.g. to compare relu decisions with a reference forward).  f32 tensors -- what 1 = z_layer [rows][h], 3 = (mean,
  * rstd) of z_layer, 4 = q: *offset in floats.  bf16 plane triples -- what 0 = the normalised input, 2 = h_layer =
- * relu(LN(z_layer)): *offset in bf16 elements from the start of the workspace, planes rows * ld elements apart,
- * value = hi + mid + lo. */
+ * relu(LN(z_layer)): *offset in bf16 elements from the start of the workspace, planes pad16(rows) * ld elements apart,
+ * value = hi + mid + lo.  A plane is stored fragment-major (round 5): one 1 KB block per (16 rows, 32 columns), the blocks of
+ * a row block consecutive along the columns; inside a block the 16-B slot of (row r, columns 8 kb .. 8 kb + 7) is number
+ * 16 kb + (r ^ 2 kb) (purejaxql_amd/qnet.py BigMlpTrainer.intermediate undoes it). */
 int pqn_bigmlp_workspace_view(const pqn_bigmlp_layout_t *layout /* host */, int32_t rows, int32_t nb, int32_t what,
                               int32_t layer, int64_t *offset /* host */, int64_t *ld /* host */);
 /* The GEMM behind every Dense layer of the wide MLP, exposed for tests: C[m][n] = op(A) op(B) (+ bias[n]) with f32-grade

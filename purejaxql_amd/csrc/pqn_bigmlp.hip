@@ -82,9 +82,30 @@ PQN_D f32x4 bm_mfma(const u32x4 &a, const u32x4 &b, f32x4 c) {
   return c;
 }
 PQN_D void bm_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a)); }
+// LDS-DMA (see pqn_qnet_pos.hip): 64 lanes x 16 B from uniform base + per-lane byte offset to LDS at a uniform address + 16 lane
+typedef __attribute__((address_space(3))) char bm_lds_char_t;
+PQN_D uint32_t bm_lds_addr(const void *p) { return (uint32_t)(uintptr_t)(bm_lds_char_t *)p; }
+PQN_D void bm_dma16(uint32_t voff, const void *sbase, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+PQN_D void bm_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// planes of a logical matrix X[rows][k]: plane p at p + pl * pstride, row-major with leading dimension ld (bf16 elements,
-// ld % 32 == 0, columns [k, ld) zero), 16-B aligned
+// Planes of a logical matrix X[rows][k]: plane p at p + pl * pstride, leading dimension ld (bf16 elements, ld % 32 == 0,
+// columns [k, ld) zero), 16-B aligned.  Round 5: the planes are stored FRAGMENT-MAJOR -- one contiguous 1 KB block per (16
+// rows, 32 K-values), the blocks of a row block consecutive along K; inside a block the 16-B slot of (row r, K-values 8 kb ..
+// 8 kb + 7) is number 16 kb + (r ^ 2 kb), i.e. the block IS the LDS image a 16 x 32 MFMA operand fragment is read from
+// conflict-free (bm_gemm_kernel) -- so that the GEMM moves it global -> LDS by LDS-DMA with fully contiguous reads and no
+// register staging.  Every producer and the transposes address 16-B slots through bm_slot(); rows are allocated in whole
+// blocks (bm_pad16).
+PQN_HD int bm_pad16(int x) { return (x + 15) & ~15; }
+PQN_HD long long bm_slot(long long ld, long long row, int k) {   // element offset of the slot holding (row, k .. k + 7), k % 8 == 0
+  const int kb = (k >> 3) & 3, r = (int)row & 15;
+  return ((((row >> 4) * (ld >> 5) + (k >> 5)) << 6) + 16 * kb + (r ^ (2 * kb))) << 3;
+}
 struct BmPlanes {
   const bf16_t *p;
   long long ld, pstride;
@@ -95,7 +116,7 @@ struct BmPlanesOut {
   long long ld, pstride;
 };
 PQN_D void bm_put(const BmPlanesOut &o, long long row, int k, const u32x4 &h, const u32x4 &m, const u32x4 &l) {
-  bf16_t *q = o.p + row * o.ld + k;
+  bf16_t *q = o.p + bm_slot(o.ld, row, k);
   *reinterpret_cast<u32x4 *>(q) = h;
   *reinterpret_cast<u32x4 *>(q + o.pstride) = m;
   *reinterpret_cast<u32x4 *>(q + 2 * o.pstride) = l;
@@ -110,27 +131,24 @@ struct BmEpilogue {
   // BM_EPI_INNORM (input-normalisation parameter gradients): d scale_c = sum_r C[r][c] xhat[r][c], d bias_c = sum_r C[r][c]
   const float *xhat;         // [M][ldx]: (x - m_c) k_c of the gradient rows
   long long ldx;
-  unsigned long long *stamps;   // profiling (pqn_bigmlp_gemm only): cycle stamps of workgroup 0 / wave 0, 8 per K step
+  unsigned long long *stamps;   // (rounds 3-4: cycle stamps of the register-staged K loop; the LDS-DMA loop of round 5 carries no vector-memory stores and records none)
 };
-#define BM_STAMP(i) do { if (E.stamps && blockIdx.x + blockIdx.y + blockIdx.z == 0 && tid == 0 && (i) < 120) E.stamps[i] = __builtin_readcyclecounter(); } while (0)
 
-template <int BM, int BN, int STG = 2>
-constexpr int bm_lds_bytes() { return STG * 3 * (BM / 16 + BN / 16) * 64 * 16; }
+template <int BM, int BN>
+constexpr int bm_lds_bytes() { return 2 * 3 * (BM / 16 + BN / 16) * 64 * 16; }
 
 // C[m][n] = sum_k A[m][k] B[n][k]; K padded (the planes hold zeros there), klen % 32 == 0.
 // Workgroup tile BM x BN (128 x 64 | 64 x 64; 128 x 128 builds too and measured slower at one workgroup per CU), four
 // waves as 2 x 2, wave tile (BM/2) x (BN/2) = MI x NI MFMA tiles; two (three) workgroups per CU.
-// STG = 2: two LDS stages, one barrier per K step.  STG = 1 (64 x 64 tiles, option bm_stages = 1): ONE stage of 24 KB and
-// two barriers per K step -- the buffer is rewritten as soon as every wave holds its fragments of the step in registers --
-// so that four workgroups (16 waves) share a CU instead of three.
-template <int BM, int BN, int EPI, int STG = 2>
+// (A single-stage LDS plan with four 64 x 64 workgroups per CU was measured in round 5 and lost by 1 %:
+// profiles/r05_v4_c5_gemm_single_stage_ab.txt.)
+template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int Kp, int klen, BmPlanes A, BmPlanes B, BmEpilogue E) {
   constexpr int NBA = BM / 16, NBB = BN / 16;
-  constexpr int PA = BM * 4 / BM_THREADS, PB = BN * 4 / BM_THREADS;      // 16-B slots per thread, plane and K step
   constexpr int MI = BM / 32, NI = BN / 32;                             // 16 x 16 MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) char bm_smem[];
-  u32x4 *sA = reinterpret_cast<u32x4 *>(bm_smem);                         // [STG][3][NBA][64]
-  u32x4 *sB = sA + STG * 3 * NBA * 64;                                    // [STG][3][NBB][64]
+  u32x4 *sA = reinterpret_cast<u32x4 *>(bm_smem);                         // [2][3][NBA][64]
+  u32x4 *sB = sA + 2 * 3 * NBA * 64;                                      // [2][3][NBB][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB L2: with
@@ -152,49 +170,42 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
   }
   const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = bz * klen, kend = min(Kp, kbeg + klen);
-  // Staging through registers.  Global side: thread p fetches slot (tile row t = p >> 2, kb = p & 3) = K-values 8 kb ..
-  // + 7 of row t with one 16-B load per plane -- four adjacent lanes read 64 contiguous bytes of a row.  (The
-  // fragment-shaped assignment, lane = row + 16 kq, costs 4x the issue time in the vector-memory path: measured 2,400-3,400
-  // against 500-900 cycles for the nine loads of a step; the LDS-DMA form global_load_lds_dwordx4 needs exactly that
-  // assignment and was no faster.)  LDS side: slot (t, kb) lives at block (t >> 4) + 16 B x (16 kb + ((t & 15) ^ 2 kb)).
-  // The XOR makes both accesses conflict-free on this chip (MI355X_MICROARCH.md, LDS lane groups): a ds_write_b128 is
-  // served in groups of 8 adjacent lanes = 2 rows x 4 kb against 32 banks, a fragment's ds_read_b128 in the four
-  // non-contiguous 16-lane groups against 64 banks.  Rows beyond the matrix are clamped: they only feed outputs that are
-  // never stored.
-  const bf16_t *ga[PA], *gb[PB];
-  int sa[PA], sb[PB];
+  // Global -> LDS by LDS-DMA.  The planes are fragment-major (bm_slot): the 3 (NBA + NBB) blocks a K step needs are 1 KB
+  // runs of global memory, and one global_load_lds_dwordx4 per block (64 lanes x 16 B, lane-linear on both sides) drops each
+  // into its place of the stage -- no VGPR staging, no ds_write, no address arithmetic in the loop.  (Round 4 staged through
+  // registers from row-major planes: the LDS-DMA form needs lane = slot, which on row-major planes is a 16-B gather per lane
+  // and measured 4x the issue time.)  Issued as inline asm so that the compiler's wait-count bookkeeping does not see it (it
+  // would order every LDS read behind vmcnt(0), see pqn_qnet_pos.hip); the kernel drains it itself in front of the barrier
+  // that publishes a stage.  Row blocks beyond the matrix are clamped to the last one: they only feed outputs that are never
+  // stored.  tools/ubench/gemm_dma.hip is the measurement this rests on (1024^3, three K splits: 17.2 against 21.9 us).
+  constexpr int NBLK = 3 * (NBA + NBB), PER_WAVE = NBLK / 4;
+  static_assert(NBLK % 4 == 0, "blocks of a K step must divide over the four waves");
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int a_blocks = (A.rows + 15) >> 4, b_blocks = (B.rows + 15) >> 4;
+  const long long a_kb = A.ld >> 5, b_kb = B.ld >> 5;
+  const bf16_t *src[PER_WAVE];
+  uint32_t dst[PER_WAVE];      // LDS byte offset inside a stage
 #pragma unroll
-  for (int q = 0; q < PA; ++q) {
-    const int p = tid + BM_THREADS * q, t = p >> 2, kb = p & 3;
-    ga[q] = A.p + (long long)min(m0 + t, A.rows - 1) * A.ld + 8 * kb;
-    sa[q] = (t >> 4) * 64 + kb * 16 + ((t & 15) ^ (2 * kb));
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int q = PER_WAVE * wave_u + i;
+    if (q < 3 * NBA) {
+      const int pl = q / NBA, rb = q % NBA;
+      src[i] = A.p + pl * A.pstride + (((long long)min(m0 / 16 + rb, a_blocks - 1) * a_kb + (kbeg >> 5)) << 9);
+      dst[i] = (uint32_t)((pl * NBA + rb) * 1024);
+    } else {
+      const int qq = q - 3 * NBA, pl = qq / NBB, rb = qq % NBB;
+      src[i] = B.p + pl * B.pstride + (((long long)min(n0 / 16 + rb, b_blocks - 1) * b_kb + (kbeg >> 5)) << 9);
+      dst[i] = (uint32_t)((2 * 3 * NBA + pl * NBB + rb) * 1024);   // sB starts behind both stages of sA
+    }
   }
+  const uint32_t lds0 = bm_lds_addr(bm_smem);
+  auto dma_step = [&](int ks) {
+    const int buf = ks & 1;
 #pragma unroll
-  for (int q = 0; q < PB; ++q) {
-    const int p = tid + BM_THREADS * q, t = p >> 2, kb = p & 3;
-    gb[q] = B.p + (long long)min(n0 + t, B.rows - 1) * B.ld + 8 * kb;
-    sb[q] = (t >> 4) * 64 + kb * 16 + ((t & 15) ^ (2 * kb));
-  }
-  u32x4 ra[PA][3], rb[PB][3];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int q = 0; q < PA; ++q)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) ra[q][pl] = *reinterpret_cast<const u32x4 *>(ga[q] + pl * A.pstride + k0);
-#pragma unroll
-    for (int q = 0; q < PB; ++q)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) rb[q][pl] = *reinterpret_cast<const u32x4 *>(gb[q] + pl * B.pstride + k0);
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < PA; ++q)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) sA[(buf * 3 + pl) * NBA * 64 + sa[q]] = ra[q][pl];
-#pragma unroll
-    for (int q = 0; q < PB; ++q)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) sB[(buf * 3 + pl) * NBB * 64 + sb[q]] = rb[q][pl];
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const bool is_a = PER_WAVE * wave_u + i < 3 * NBA;
+      bm_dma16(lane * 16u, src[i] + ((long long)ks << 9), lds0 + dst[i] + (uint32_t)(buf * 3 * (is_a ? NBA : NBB) * 1024));
+    }
   };
   // ONE accumulator per tile: the six products of a step meet in f32 in the order (l,h) (m,h) (h,l) (h,m) (m,m) (h,h)
   f32x4 acc[MI][NI];
@@ -202,12 +213,9 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // K loop, software-pipelined inside the wave.  At the top of iteration ks the MFMA fragments of step ks are (arriving)
-  // in registers, the global data of step ks + 1 is (arriving) in ra / rb; the iteration stores that data to the other LDS
-  // buffer, issues the global loads of step ks + 2, issues the MFMAs of step ks, passes the one barrier of the step and
-  // issues the fragment reads of step ks + 1.  So a global load has two MFMA phases to land and a fragment read has the
-  // next iteration's stores and loads.  Overwriting a / b right behind the MFMAs is safe: an LDS read takes longer to
-  // return than the last MFMA takes to read its operands (tools/ubench/mfma_war.hip).
+  // K loop: at the top of iteration ks stage ks & 1 holds step ks (landed, published by the last barrier); the iteration starts
+  // the transfer of step ks + 1 into the other stage (every wave passed the barrier behind its last read of it), reads its
+  // fragments, issues the MFMAs, waits for its own share of the transfer and meets the others at the one barrier of the step.
   const int nk = (kend - kbeg) / BM_KS;
   u32x4 a[MI][3], b[NI][3];
   auto fragload = [&](int buf) {
@@ -222,27 +230,13 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
       for (int ni = 0; ni < NI; ++ni) b[ni][pl] = pb[(pl * NBB + ni) * 64];
     }
   };
-  BM_STAMP(0);
-  gload(kbeg);
-  BM_STAMP(1);
-  lstore(0);
+  if (nk > 0) dma_step(0);
+  bm_dma_wait();
   __syncthreads();
-  if (nk > 1) gload(kbeg + BM_KS);
-  fragload(0);
 #pragma unroll 1
   for (int ks = 0; ks < nk; ++ks) {
-    BM_STAMP(8 + 8 * ks);
-    if constexpr (STG == 1) {
-      if (ks + 1 < nk) {
-        __syncthreads();          // every wave has its fragments of step ks out of the (only) buffer
-        lstore(0);
-      }
-    } else {
-      if (ks + 1 < nk) lstore((ks + 1) & 1);
-    }
-    BM_STAMP(9 + 8 * ks);
-    if (ks + 2 < nk) gload(kbeg + (ks + 2) * BM_KS);
-    BM_STAMP(10 + 8 * ks);
+    if (ks + 1 < nk) dma_step(ks + 1);
+    fragload(ks & 1);
 #define BM_PROD(PA_, PB_)                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = bm_mfma(a[mi][PA_], b[ni][PB_], acc[mi][ni]);
@@ -253,13 +247,9 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
     BM_PROD(1, 1)
     BM_PROD(0, 0)
 #undef BM_PROD
-    BM_STAMP(11 + 8 * ks);
-    if (STG == 2 || ks + 1 < nk) __syncthreads();
-    BM_STAMP(12 + 8 * ks);
-    if (ks + 1 < nk) fragload(STG == 1 ? 0 : (ks + 1) & 1);
-    BM_STAMP(13 + 8 * ks);
+    bm_dma_wait();
+    __syncthreads();
   }
-  BM_STAMP(2);
   // ---- epilogue ----
   const int col_l = lane & 15, rq = lane >> 4;
   if (EPI == BM_EPI_STORE) {
@@ -385,7 +375,7 @@ PQN_D void bm_transpose_body(const BmPlanes &src, int cols, const BmPlanesOut &d
   for (int q = 0; q < 2; ++q) {
     const int e = tid + 256 * q, r = e >> 3, ch = e & 7;
     const int rr = min(r0 + r, src.rows - 1), cc = min((long long)(c0 + 8 * ch), src.ld - 8);   // clamped: masked below
-    lv[q] = *reinterpret_cast<const u32x4 *>(sp + (long long)rr * src.ld + cc);
+    lv[q] = *reinterpret_cast<const u32x4 *>(sp + bm_slot(src.ld, rr, (int)cc));
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -404,7 +394,7 @@ PQN_D void bm_transpose_body(const BmPlanes &src, int cols, const BmPlanesOut &d
       for (int j = 0; j < 8; ++j) v[j] = tile[8 * ch + j][c];   // rows >= src.rows were loaded as zeros
       u32x4 o;
       o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
-      *reinterpret_cast<u32x4 *>(dp + (long long)cc * dst.ld + rr) = o;
+      *reinterpret_cast<u32x4 *>(dp + bm_slot(dst.ld, cc, rr)) = o;
     }
   }
 }
@@ -1035,15 +1025,15 @@ int align4(int x) { return (x + 3) & ~3; }
 // a plane triple inside a bf16 arena: rows x ld elements per plane
 BmPlanes bm_pl(const bf16_t *base, int rows, int ld) {
   BmPlanes p = {};
-  p.p = base; p.ld = ld; p.pstride = (long long)rows * ld; p.rows = rows;
+  p.p = base; p.ld = ld; p.pstride = (long long)bm_pad16(rows) * ld; p.rows = rows;
   return p;
 }
 BmPlanesOut bm_plo(bf16_t *base, int rows, int ld) {
   BmPlanesOut p = {};
-  p.p = base; p.ld = ld; p.pstride = (long long)rows * ld;
+  p.p = base; p.ld = ld; p.pstride = (long long)bm_pad16(rows) * ld;
   return p;
 }
-long long bm_pl_elems(int rows, int ld) { return 3ll * rows * ld; }
+long long bm_pl_elems(int rows, int ld) { return 3ll * bm_pad16(rows) * ld; }
 
 BmEpilogue bm_store(float *out, long long ldc, const float *bias = nullptr, long long split_stride = 0) {
   BmEpilogue e = {};
@@ -1055,7 +1045,7 @@ BmEpilogue bm_store(float *out, long long ldc, const float *bias = nullptr, long
 // split (<= max_split, each part >= 128 long) that fills whole "rounds" best -- a round = every CU holding as many
 // workgroups as its LDS takes (two 128 x 64, three 64 x 64).  Run-time switches "bm_tile" (64 / 128) and "bm_split"
 // override (A/B runs).
-struct BmPlan { int bm, nsplit, klen, stages; };
+struct BmPlan { int bm, nsplit, klen; };
 BmPlan bm_plan(int M, int N, int Kp, int max_split) {
   const long long t128 = (long long)((M + 127) / 128) * ((N + 63) / 64);
   BmPlan p;
@@ -1066,8 +1056,7 @@ BmPlan bm_plan(int M, int N, int Kp, int max_split) {
   p.bm = t128 >= (topt > 128 ? topt : 129) ? 128 : 64;
   if (topt == 64 || topt == 128) p.bm = topt;
   const long long tiles = (long long)((M + p.bm - 1) / p.bm) * ((N + 63) / 64);
-  p.stages = (p.bm == 64 && pqn_opt(PQN_OPT_BM_STAGES) == 1) ? 1 : 2;
-  const long long round = 256ll * (p.bm == 128 ? 2 : (p.stages == 1 ? 4 : 3));
+  const long long round = 256ll * (p.bm == 128 ? 2 : 3);
   int s = 1;
   double best = 0.0;
   for (int c = 1; c <= max_split; ++c) {
@@ -1084,10 +1073,10 @@ BmPlan bm_plan(int M, int N, int Kp, int max_split) {
 template <int EPI>
 int bm_launch(int M, int N, int Kp, const BmPlan &p, const BmPlanes &A, const BmPlanes &B, const BmEpilogue &E, hipStream_t st) {
   const dim3 grid((N + 63) / 64, (M + p.bm - 1) / p.bm, p.nsplit);
-#define BM_GO(BM_, STG_)                                                                                                \
+#define BM_GO(BM_)                                                                                                      \
   do {                                                                                                                   \
-    auto kern = &bm_gemm_kernel<BM_, 64, EPI, STG_>;                                                                     \
-    constexpr int lds = bm_lds_bytes<BM_, 64, STG_>();                                                                  \
+    auto kern = &bm_gemm_kernel<BM_, 64, EPI>;                                                                           \
+    constexpr int lds = bm_lds_bytes<BM_, 64>();                                                                        \
     static bool attr = false;                                                                                            \
     if (!attr) {                                                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
@@ -1096,9 +1085,8 @@ int bm_launch(int M, int N, int Kp, const BmPlan &p, const BmPlanes &A, const Bm
     hipLaunchKernelGGL(kern, grid, dim3(BM_THREADS), lds, st, M, N, Kp, p.klen, A, B, E);                                \
   } while (0)
   const bool timed = pqn_prof_begin(2, st);
-  if (p.bm == 128) BM_GO(128, 2);
-  else if (p.stages == 1) BM_GO(64, 1);
-  else BM_GO(64, 2);
+  if (p.bm == 128) BM_GO(128);
+  else BM_GO(64);
   if (timed) pqn_prof_end(st);
 #undef BM_GO
   return pqn_check_launch("pqn_bigmlp gemm");
@@ -1522,11 +1510,11 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
     BmTransposeBatch T;
     BmTransposeBatch &TT = deferred ? TB : T;
     BmPlanes src = bm_pl(wb + w.xn, nb, w.dp);
-    src.pstride = (long long)rows * w.dp;   // the planes hold all forward rows; only the first nb are transposed
+    src.pstride = (long long)bm_pad16(rows) * w.dp;   // the planes hold all forward rows; only the first nb are transposed
     TT.add(src, L->d, bm_plo(wb + w.xnT, L->d, w.nbp));
     for (int l = 0; l < L->layers; ++l) {
       BmPlanes sh = bm_pl(wb + w.h[l], nb, L->h);
-      sh.pstride = (long long)rows * L->h;
+      sh.pstride = (long long)bm_pad16(rows) * L->h;
       TT.add(sh, L->h, bm_plo(wb + w.hT[l], L->h, w.nbp));
     }
     T.launch(sd);
@@ -1592,7 +1580,7 @@ extern "C" int pqn_bigmlp_grad(const pqn_bigmlp_layout_t *L, int32_t nb, const i
 // where a forward intermediate lives in the workspace (tests / debugging).  f32 tensors (what 1 = pre-activation z_l
 // [rows][h], 3 = (mean, rstd) of z_l [rows][2], 4 = q [rows][ld]): *offset in floats.  bf16 plane triples (what 0 = the
 // normalised input [rows][ld], 2 = h_l = relu(LN(z_l)) [rows][h]): *offset in bf16 elements from the start of the
-// workspace, the three planes rows * ld elements apart; value = hi + mid + lo.
+// workspace, the three planes pad16(rows) * ld elements apart, fragment-major (bm_slot); value = hi + mid + lo.
 extern "C" int pqn_bigmlp_workspace_view(const pqn_bigmlp_layout_t *L, int32_t rows, int32_t nb, int32_t what, int32_t layer,
                                          int64_t *offset, int64_t *ld) {
   PQN_REQUIRE(L && offset && ld && rows > 0 && nb > 0 && nb <= rows && layer >= 0 && layer < L->layers && what >= 0 && what <= 4,
@@ -1618,8 +1606,8 @@ extern "C" int pqn_debug_bm_stamps(unsigned long long *out /* host, 128 entries 
 extern "C" int64_t pqn_bigmlp_gemm_scratch_floats(int32_t m, int32_t n, int32_t k) {
   if (m <= 0 || n <= 0 || k <= 0) return -1;
   const long long kp = bm_pad32(k);
-  const long long tmp = 3ll * k * max(bm_pad32(m), bm_pad32(n));
-  return (3 * ((long long)m * kp + (long long)n * kp) + tmp) / 2 + 64;
+  const long long tmp = 3ll * bm_pad16(k) * max(bm_pad32(m), bm_pad32(n));
+  return (3 * ((long long)bm_pad16(m) * kp + (long long)bm_pad16(n) * kp) + tmp) / 2 + 64;
 }
 
 extern "C" int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, int64_t lda, int32_t trans_a, const float *b,
@@ -1646,7 +1634,6 @@ extern "C" int pqn_bigmlp_gemm(int32_t m, int32_t n, int32_t k, const float *a, 
   prep(b, ldb, trans_b != 0, n, pb);
   BmPlan p;
   p.bm = tile_rows;
-  p.stages = (tile_rows == 64 && pqn_opt(PQN_OPT_BM_STAGES) == 1) ? 1 : 2;
   p.klen = ((kp + nsplit - 1) / nsplit + BM_KS - 1) / BM_KS * BM_KS;
   p.nsplit = (kp + p.klen - 1) / p.klen;
   BmEpilogue E = bm_store(c, ldc, bias, split_stride);

@@ -90,7 +90,6 @@ enum {
   PQN_OPT_T2_ACC,         // PQN_T2_ACC: bf16x3 fc1 weight gradient without split-K partials 0 never / 1 when row blocks x seeds fill the chip / 2 always
   PQN_OPT_UPD_OVERLAP,    // PQN_UPD_OVERLAP: pqn_bigmlp_update puts the first epoch's permutation and the last gradient-copy plane refresh on a side stream (bit 0 / bit 1; default 0: a fork / join pair in the graph costs ~30 us)
   PQN_OPT_ROLLOUT_POS,    // PQN_ROLLOUT_POS: position-structure rollout kernel (256 envs per workgroup, pqn_qnet_pos.hip) 0 never / 1 when the launch fills the chip (default) / 2 whenever the shape allows
-  PQN_OPT_BM_STAGES,      // PQN_BM_STAGES: LDS stages of the 64 x 64 wide-MLP GEMM tile: 2 (default; three workgroups per CU) / 1 (four)
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);
