@@ -611,7 +611,7 @@ int pqn_bigmlp_update(const pqn_bigmlp_update_args_t *args /* host */, void *str
  * relu(LN(z_layer)): *offset in bf16 elements from the start of the workspace, planes pad16(rows) * ld elements apart,
  * value = hi + mid + lo.  A plane is stored fragment-major (round 5): one 1 KB block per (16 rows, 32 columns), the blocks of
  * a row block consecutive along the columns; inside a block the 16-B slot of (row r, columns 8 kb .. 8 kb + 7) is number
- * 16 kb + (r ^ 2 kb) (purejaxql_amd/qnet.py BigMlpTrainer.intermediate undoes it). */
+ * 4 r + (kb ^ (-(r >> 2) & 3)) (purejaxql_amd/qnet.py BigMlpTrainer.intermediate undoes it). */
 int pqn_bigmlp_workspace_view(const pqn_bigmlp_layout_t *layout /* host */, int32_t rows, int32_t nb, int32_t what,
                               int32_t layer, int64_t *offset /* host */, int64_t *ld /* host */);
 /* The GEMM behind every Dense layer of the wide MLP, exposed for tests: C[m][n] = op(A) op(B) (+ bias[n]) with f32-grade

@@ -97,14 +97,15 @@ PQN_D void bm_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // Planes of a logical matrix X[rows][k]: plane p at p + pl * pstride, leading dimension ld (bf16 elements, ld % 32 == 0,
 // columns [k, ld) zero), 16-B aligned.  Round 5: the planes are stored FRAGMENT-MAJOR -- one contiguous 1 KB block per (16
 // rows, 32 K-values), the blocks of a row block consecutive along K; inside a block the 16-B slot of (row r, K-values 8 kb ..
-// 8 kb + 7) is number 16 kb + (r ^ 2 kb), i.e. the block IS the LDS image a 16 x 32 MFMA operand fragment is read from
-// conflict-free (bm_gemm_kernel) -- so that the GEMM moves it global -> LDS by LDS-DMA with fully contiguous reads and no
-// register staging.  Every producer and the transposes address 16-B slots through bm_slot(); rows are allocated in whole
-// blocks (bm_pad16).
+// 8 kb + 7) is number 4 r + (kb ^ (-(r >> 2) & 3)): a row's four slots are one 64-B run (a producer that owns a row writes
+// whole 64-B pieces), and the block IS the LDS image a 16 x 32 MFMA operand fragment is read from conflict-free -- the XOR
+// puts the 16 lanes of every ds_read_b128 lane group (MI355X_MICROARCH.md, LDS) on 16 different slots mod 16 -- so that the
+// GEMM moves it global -> LDS by LDS-DMA with fully contiguous reads and no register staging.  Every producer and the
+// transposes address 16-B slots through bm_slot(); rows are allocated in whole blocks (bm_pad16).
 PQN_HD int bm_pad16(int x) { return (x + 15) & ~15; }
 PQN_HD long long bm_slot(long long ld, long long row, int k) {   // element offset of the slot holding (row, k .. k + 7), k % 8 == 0
   const int kb = (k >> 3) & 3, r = (int)row & 15;
-  return ((((row >> 4) * (ld >> 5) + (k >> 5)) << 6) + 16 * kb + (r ^ (2 * kb))) << 3;
+  return ((((row >> 4) * (ld >> 5) + (k >> 5)) << 6) + 4 * r + (kb ^ ((0 - (r >> 2)) & 3))) << 3;
 }
 struct BmPlanes {
   const bf16_t *p;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm_gemm_kernel(int M, int N, int K
   const int nk = (kend - kbeg) / BM_KS;
   u32x4 a[MI][3], b[NI][3];
   auto fragload = [&](int buf) {
-    const int fl = (lane & 48) + ((lane & 15) ^ (2 * (lane >> 4)));   // fragment lane (row i, kq) -> its swizzled slot
+    const int fl = 4 * (lane & 15) + ((lane >> 4) ^ ((0 - ((lane & 15) >> 2)) & 3));   // fragment lane (row i, kq) -> its slot (bm_slot)
     const u32x4 *pa = sA + buf * 3 * NBA * 64 + (wm * MI) * 64 + fl;
     const u32x4 *pb = sB + buf * 3 * NBB * 64 + (wn * NI) * 64 + fl;
 #pragma unroll

@@ -841,11 +841,11 @@ class BigMlpTrainer:
                                                          C.addressof(ld)), "pqn_bigmlp_workspace_view")
         ws = self._ws[_lib.stream_ptr()]
         if code in (0, 2):
-            # fragment-major planes (csrc/pqn_bigmlp.hip, bm_slot): [plane][row block of 16][K block of 32][slot 16 kb + (r ^ 2 kb)][8]
+            # fragment-major planes (csrc/pqn_bigmlp.hip, bm_slot): [plane][row block of 16][K block of 32][slot 4 r + (kb ^ (-(r >> 2) & 3))][8]
             rp, k = (rows + 15) // 16 * 16, int(ld.value)
-            blk = ws.view(torch.bfloat16)[off.value:off.value + 3 * rp * k].view(3, rp // 16, k // 32, 4, 16, 8)
+            blk = ws.view(torch.bfloat16)[off.value:off.value + 3 * rp * k].view(3, rp // 16, k // 32, 16, 4, 8)
             r = torch.arange(16, device=blk.device)
-            rows_of = torch.stack([blk[:, :, :, kb, r ^ (2 * kb), :] for kb in range(4)], dim=3)   # [3][rb][kblk][kb][r][8]
+            rows_of = torch.stack([blk[:, :, :, r, kb ^ ((-(r >> 2)) & 3), :] for kb in range(4)], dim=3)   # [3][rb][kblk][kb][r][8]
             planes = rows_of.permute(0, 1, 4, 2, 3, 5).reshape(3, rp, k)[:, :rows]
             return planes[0].float() + planes[1].float() + planes[2].float()
         return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)
