@@ -11,16 +11,18 @@
 // mid + lo exactly, 6 x v_mfma_f32_16x16x32_bf16 per 32-wide K step, f32 accumulate).  Splitting inside the GEMM would
 // repeat the ~5 VALU ops per element once per output tile that touches the element (16x for these shapes) and, measured,
 // cost as much issue time as the MFMAs themselves; so every tensor that feeds a GEMM is split ONCE, by the kernel that
-// produces it, into three bf16 planes stored K-contiguously: planes[p][row][k], k padded with zeros to a multiple of 32.
-// A GEMM operand is then "row r, K-values k .. k + 7 = 16 bytes per plane", and the GEMM's loaders are plain 16-B copies
-// global -> LDS with no arithmetic and no bounds masks (rows are clamped: a clamped row only feeds outputs that are never
-// stored).  Tensors needed with the other dimension as K (weights for the forward pass, activations and output
-// gradients for the weight gradients) get a transposed plane copy from an LDS-tiled 2-byte transpose kernel.
+// produces it, into three bf16 planes, k padded with zeros to a multiple of 32.  A GEMM operand is "row r, K-values k ..
+// k + 7 = 16 bytes per plane"; since round 5 those 16-B slots are stored FRAGMENT-MAJOR (bm_slot below: one contiguous 1 KB
+// block per 16 rows x 32 K-values, laid out as the LDS image the MFMA fragments are read from), so that the GEMM moves a K
+// step global -> LDS with one LDS-DMA instruction per block: no registers, no arithmetic, no bounds masks (row blocks are
+// clamped: a clamped block only feeds outputs that are never stored).  Tensors needed with the other dimension as K (weights
+// for the forward pass, activations and output gradients for the weight gradients) get a transposed plane copy from an
+// LDS-tiled 2-byte transpose kernel.
 //
-//   bm_gemm_kernel          C[M,N] (+)= A[M,K] B[N,K]^T from planes; tile BM x 64 (BM = 64 | 128), 4 waves as 2 x 2, LDS
-//                           double-buffered, one barrier per K step, the next step's global loads in flight during the
-//                           MFMAs; split-K over blockIdx.z (partial outputs, folded by the consumer) so that ~3
-//                           workgroups sit on every CU and hide each other's load latency; epilogue = (bias +) store, or
+//   bm_gemm_kernel          C[M,N] (+)= A[M,K] B[N,K]^T from planes; tile BM x 64 (BM = 64 | 128), 4 waves as 2 x 2, two LDS
+//                           stages filled by LDS-DMA (global_load_lds_dwordx4, 6 | 9 per wave and K step), one barrier per
+//                           K step; split-K over blockIdx.z (partial outputs, folded by the consumer) so that ~3
+//                           workgroups sit on every CU and hide each other's latency; epilogue = (bias +) store, or
 //                           the column sums that are the input-normalisation parameter gradients
 //   bm_split_kernel         f32 matrix -> planes (weights; test entry);   bm_transpose_kernel  planes -> transposed planes;
 //                           bm_split_transpose_multi: theta -> transposed weight planes in one pass (after an optimizer step)
