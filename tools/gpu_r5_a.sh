@@ -1,6 +1,8 @@
 #!/bin/bash
-# round 5, call A: the position-parallel backward (cnn_pos_bwd_kernel) -- parity tests, then the headline bench with the
-# default kernels (PQN_BWD_POS=0), the round-5 backward (1) and round 2's (3), each with its rocprofv3 kernel table.
+# round 5: the position-parallel form (gather + cnn_pos_fwd_kernel + cnn_pos_bwd_kernel) -- parity tests, then the headline bench with
+# the round-4 kernels (PQN_BWD_POS=0) and with the position form (1), each with its rocprofv3 kernel table.  (When the r05_v0 / r05_v1
+# profiles were taken the script also ran the values 3 and 4 = round 2's backward / this backward behind the forward-only pair
+# kernel; both paths were deleted later in the round.)
 O=gpurun_out/r5a; mkdir -p $O
 timeout 900 python -m pytest tests/test_qnet_gpu.py -x -q -m gpu -k "position_parallel" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 tail -15 $O/pytest.log
@@ -18,5 +20,4 @@ PY
 }
 run 0
 run 1
-run 3
 PQN_BWD_POS=1 PQN_T1_STAMPS=1 timeout 300 python tools/pos_stamps.py > $O/stamps.txt 2>&1; tail -5 $O/stamps.txt
