@@ -428,12 +428,14 @@ def _grads_under_options(gpu, c, a, nb, pool, mode, reps=3, **opts):
     return out[0], form
 
 
-@pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 4096, 20000), (4, 3, 512, 3000), (4, 5, 1024, 4000), (6, 4, 2048, 6000), (7, 3, 1024, 3000)])
+@pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 4096, 20000), (4, 3, 512, 3000), (4, 5, 1024, 4000), (6, 4, 2048, 6000), (7, 3, 1024, 3000),
+                                         (4, 3, 256, 1000), (4, 3, 8192, 20000), (6, 4, 768, 2000)])
 def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool):
     """bwd_pos=2 routes a minibatch through the position-parallel kernels of pqn_qnet_pos.hip -- minibatch gather +
     bit-transpose, cnn_pos_fwd_kernel (wave = 32 samples, conv on the fly, z in registers, head on the accumulator layout),
     cnn_pos_bwd_kernel (wave = conv position, its dW1 rows in registers, one partial slab per sample chunk) -- and the
-    reduction: the form is reported, repeats are bit-identical (gradient, loss, mean chosen q), loss
+    reduction, from ONE forward workgroup (256 samples) over one- and two-chunk backward shapes (512,
+    768 / 1024 .. 8192: up to 128 super-tiles per workgroup): the form is reported, repeats are bit-identical (gradient, loss, mean chosen q), loss
     and chosen q equal the f32-MFMA mode of the default kernels, the gradient equals it to f32 rounding and the oracle's numpy
     backward at the tolerance of test_cnn_grad_vs_oracle.  pqn_minatar.py:271-291."""
     g_f32, f0, lq0 = _grads_under_options(gpu, c, a, nb, pool, 0, t1_pair=0, t1_ksplit=0, want_loss=True)
