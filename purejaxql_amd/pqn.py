@@ -582,8 +582,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                                   policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
                                   fused_opt=config.get("_FUSED_OPT", False),
                                   pin_form=bool(config.get("SEED_BATCH_BIT_IDENTICAL", False)))
-        elif backend == "fused_big" and grad_hook is None and config.get("_DRIVER", True) and driver_shape_ok:
-            # the Craftax script's loop (wrapper-batched env, wide MLP) from one C call, replayed as a hipGraph
+        elif backend == "fused_big" and grad_hook is None and metrics_hook is None and config.get("_DRIVER", True) and driver_shape_ok:
+            # the Craftax script's loop (wrapper-batched env, wide MLP) from one C call, replayed as a hipGraph (not with a
+            # cross-shard metrics hook: the device computes the done-weighted RATIOS of this shard, the hook needs the sums)
             from .qnet import BigMlpUpdateDriver
             dcfg = {"gamma": gamma, "lam": lam, "rew_scale": rew_scale, "eps_start": config["EPS_START"],
                     "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}

@@ -412,3 +412,31 @@ def test_log_achievements_adds_the_done_weighted_achievement_means(gpu, driver):
 
 
 _ACH_RUNS = {}
+
+
+def test_done_weighted_means_are_global_ratios_under_a_metrics_hook(gpu):
+    """Env-sharded mode: the Craftax script's done-weighted metrics -- (x * returned_episode).sum() /
+    returned_episode.sum(), pqn_craftax.py:364-369, and the Achievements/* columns -- go to the cross-shard hook as
+    NUMERATORS and the finished-episode COUNT, and are divided afterwards, so that the result is the ratio over all envs
+    and a shard without a finished episode contributes 0 / 0 to nothing.  A hook that stands for "the other shard finished no
+    episode" (it halves every entry: the mean of this shard's sums and a shard of zeros) must leave every done-weighted
+    column exactly as the undisturbed run has it -- with the ratio taken per shard first it was (x + NaN) / 2 = NaN -- while
+    the plain means (td_loss, qvals) are halved."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.envs import CRAFTAX_CLASSIC_ACHIEVEMENTS
+    from purejaxql_amd.pqn import make_train, seed_keys
+    n_upd = 300
+
+    def run(hook):
+        cfg = flatten(load_config(["+alg=pqn_craftax", "alg.ENV_NAME=Craftax-Classic-Symbolic-v1"]))
+        cfg.update({"NUM_ENVS": 128, "HIDDEN_SIZE": 256, "NUM_LAYERS": 2, "TOTAL_TIMESTEPS": n_upd * 128, "TOTAL_TIMESTEPS_DECAY": n_upd * 128,
+                    "LOG_ACHIEVEMENTS": True, "EPS_START": 1.0, "EPS_FINISH": 1.0})
+        return make_train(cfg, device="cuda:0", script="craftax", metrics_hook=hook)(seed_keys(2, 1)[0])["metrics"]
+
+    plain, halved = run(None), run(lambda v: 0.5 * v)
+    fin = ~torch.isnan(plain["returned_episode_returns"])
+    assert int(fin.sum()) > 10
+    for k in ["returned_episode_returns", "returned_episode_lengths", "timestep", "discount"] + [f"Achievements/{a}" for a in CRAFTAX_CLASSIC_ACHIEVEMENTS]:
+        assert torch.equal(torch.isnan(halved[k]), ~fin), k
+        torch.testing.assert_close(halved[k][fin], plain[k][fin], rtol=1e-6, atol=0)
+    torch.testing.assert_close(halved["td_loss"], 0.5 * plain["td_loss"], rtol=1e-6, atol=0)
