@@ -3315,6 +3315,9 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     if (pos_full) {
       const int nch = pos_chunks(nb);
       const pos_ws_t PW = pos_ws_layout(nb, C, L.a);
+      // the form's buffers live in the region that holds h1^T in the other forms (pqn_qnet_cnn_workspace_floats sizes it)
+      PQN_REQUIRE(PW.end <= (long long)QN_H1 * qw_h1_cols(nb), "pqn_qnet_cnn_grad: position-parallel layout (%lld floats) exceeds the h1^T region",
+                  PW.end);
       pqn_note_kernel_form(0, PQN_FORM_POS);
       if (part != 2) {
         // kernel timer (pqn_prof_enable): mode 1 = the dominant kernel (the backward), 3 = the forward kernel, 4 = gather +
