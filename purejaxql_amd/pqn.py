@@ -93,6 +93,38 @@ class RunnerState(tuple):
         return tuple(self)
 
 
+class _TestRows:
+    """metrics["test/<k>"][u] = the result of the LATEST evaluation at update u (pqn_minatar.py:340-350: test_metrics is carried
+    through the scan and refreshed every NUM_UPDATES * TEST_INTERVAL updates).  Kept as (first update, values) spans and
+    written out once, in rows(): the update drivers replay one hipGraph per update, and NOTHING should be enqueued between
+    two replays that does not have to be -- a per-update torch.stack + slice assignment here (~100 small launches behind a 27 ms
+    graph at 16 seeds x 4096 envs) ended in a GPU memory access fault after ~16 updates on ROCm 7.2, while the same launches
+    behind a stream synchronisation, or the same update enqueued eagerly, ran clean (tools/learn_headline.py found it)."""
+
+    def __init__(self, num_updates: int):
+        self.num_updates, self.spans = int(num_updates), []
+
+    def note(self, u: int, values: torch.Tensor) -> None:
+        """`values` ([..., len(INFO_KEYS)]) holds from update u on (until the next note)."""
+        self.spans.append((int(u), values))
+
+    def rows(self) -> torch.Tensor:
+        """[..., NUM_UPDATES, len(INFO_KEYS)]"""
+        first = self.spans[0][1]
+        out = torch.zeros((*first.shape[:-1], self.num_updates, first.shape[-1]), dtype=torch.float32, device=first.device)
+        for i, (u0, v) in enumerate(self.spans):
+            u1 = self.spans[i + 1][0] if i + 1 < len(self.spans) else self.num_updates
+            if u1 > u0:
+                out[..., u0:u1, :] = v.to(torch.float32).unsqueeze(-2)
+        return out
+
+
+def _sync_behind_graph(drv) -> None:
+    """Host-side wait for the stream before eager work is enqueued behind a replayed update graph (see _TestRows)."""
+    if drv is not None and getattr(drv, "graph", None) is not None:
+        torch.cuda.current_stream().synchronize()
+
+
 class _Rollout:
     """Time-major rollout record of one update: the reference's `Transition`
     (pqn_minatar.py:72-79) with next_obs folded into slot T of the observation buffer and q_val
@@ -600,13 +632,16 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             driver = EnvShardDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
                                     policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
                                     grad_hook=grad_hook)
-        test_rows = torch.zeros((NUM_UPDATES, len(INFO_KEYS)), dtype=torch.float32, device=dev) if test_on else None
+        test_rows = _TestRows(NUM_UPDATES) if test_on else None
+        if test_on:
+            test_rows.note(0, torch.stack([tm_box[0][k] for k in INFO_KEYS]))
         shard_world = int(shard[1]) if shard is not None else 1
 
         def share_metrics_row(row):
             """Env-sharded mode: the means of an update are over ALL env shards, the step counts over all envs."""
             from .qnet import METRIC_NAMES
             i0 = METRIC_NAMES.index("td_loss")
+            _sync_behind_graph(driver)
             if metrics_hook is not None:
                 row[i0:] = metrics_hook(row[i0:].clone())
             for name in ("env_step", "env_frame"):
@@ -627,10 +662,10 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             counters["timesteps"] += T * N
             counters["n_updates"] += 1
             counters["grad_steps"] += MB * EPOCHS
-            if test_on:
-                if test_period > 0 and counters["n_updates"] % test_period == 0:
-                    tm_box[0] = get_test_metrics()
-                test_rows[u] = torch.stack([tm_box[0][k] for k in INFO_KEYS])
+            if test_on and test_period > 0 and counters["n_updates"] % test_period == 0:
+                _sync_behind_graph(driver)
+                tm_box[0] = get_test_metrics()
+                test_rows.note(u, torch.stack([tm_box[0][k] for k in INFO_KEYS]))
             cb = config.get("_CALLBACK")
             # the Craftax script logs every WANDB_LOG_INTERVAL-th update only (pqn_craftax.py:394-397)
             if cb is not None and (not craftax or counters["n_updates"] % int(config.get("WANDB_LOG_INTERVAL", 128)) == 0):
@@ -767,8 +802,9 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                     for k_a, a_name in enumerate(ach_names):
                         metrics[f"Achievements/{a_name}"] = driver.ach_metrics[:NUM_UPDATES, k_a].to(torch.float32)
                 if test_on:
+                    rows = test_rows.rows()
                     for j, k in enumerate(INFO_KEYS):
-                        metrics[f"test/{k}"] = test_rows[:, j]
+                        metrics[f"test/{k}"] = rows[:, j]
             theta_f = policy.theta_flax()
             runner_state = RunnerState({"params": network.views(theta_f), "theta": theta_f, "env_state": words,
                             "last_obs": obuf[0], "test_metrics": tm_box[0], "network": network, "backend": backend,
@@ -927,7 +963,10 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
 
         tm_box = [test_all()]
         test_period = int(NUM_UPDATES * config["TEST_INTERVAL"]) if test_on else 0
-        test_rows = torch.zeros((S, NUM_UPDATES, len(INFO_KEYS)), dtype=torch.float32, device=dev) if test_on else None
+        stack_tm = lambda tm: torch.stack([torch.stack([tm[s][k] for k in INFO_KEYS]) for s in range(S)])   # [S, len(INFO_KEYS)]
+        test_rows = _TestRows(NUM_UPDATES) if test_on else None
+        if test_on:
+            test_rows.note(0, stack_tm(tm_box[0]))
         counters = {"timesteps": 0, "n_updates": 0, "grad_steps": 0}
         forms = {}    # which kernel forms the library took for this batch (asked after the first, eager, enqueue)
 
@@ -941,21 +980,22 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             counters["timesteps"] += T * N
             counters["n_updates"] += 1
             counters["grad_steps"] += MB * EPOCHS
-            if test_on:
-                if test_period > 0 and counters["n_updates"] % test_period == 0:
-                    tm_box[0] = test_all()
-                test_rows[:, u] = torch.stack([torch.stack([tm_box[0][s][k] for k in INFO_KEYS]) for s in range(S)])
+            if test_on and test_period > 0 and counters["n_updates"] % test_period == 0:
+                _sync_behind_graph(drv)
+                tm_box[0] = test_all()
+                test_rows.note(u, stack_tm(tm_box[0]))
 
         def finish():
             names = ["env_step", "update_steps", "grad_steps", "td_loss", "qvals"] + list(INFO_KEYS)
             if kind == "cnn":
                 names.insert(2, "env_frame")
             outs = []
+            rows = test_rows.rows() if test_on else None     # [S, NUM_UPDATES, len(INFO_KEYS)]
             for s in range(S):
                 metrics = {name: drv.metrics[s, :NUM_UPDATES, METRIC_NAMES.index(name)].to(torch.float32) for name in names}
                 if test_on:
                     for j, k in enumerate(INFO_KEYS):
-                        metrics[f"test/{k}"] = test_rows[s, :, j]
+                        metrics[f"test/{k}"] = rows[s, :, j]
                 theta_f = layout.to_flax(drv.theta_k(s))
                 sl = slice(s * N, (s + 1) * N)
                 runner_state = RunnerState({"params": network.views(theta_f), "theta": theta_f, "env_state": words[:, sl].contiguous(),
