@@ -655,10 +655,10 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             driver.update()
             if not forms and packed:
                 forms.update(zip(("train", "rollout"), _lib.last_kernel_form()))
+            if shard_world > 1 or metrics_hook is not None:
+                share_metrics_row(driver.metrics[u])     # (waits for the stream first: nothing is enqueued behind a replay in flight)
             if grad_hook is not None and hasattr(grad_hook, "poll"):
                 grad_hook.poll()       # in-graph peer all-reduce: a time-out surfaces within an update or two, not at finish()
-            if shard_world > 1 or metrics_hook is not None:
-                share_metrics_row(driver.metrics[u])
             counters["timesteps"] += T * N
             counters["n_updates"] += 1
             counters["grad_steps"] += MB * EPOCHS
