@@ -237,3 +237,29 @@ def test_update_argument_structs_match_the_header(tmp_path):
     rows = [tuple(int(x) for x in ln.split()) for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n") if ln]
     for row, cls in zip(rows, (qnet.UpdateArgs, qnet.MlpUpdateArgs, qnet.BigMlpUpdateArgs)):
         assert row == (C.sizeof(cls), cls.layout.offset, cls.clock.offset, cls.metrics.offset), (cls.__name__, row)
+
+
+def test_test_rows_are_spans_of_the_latest_evaluation():
+    """pqn._TestRows: metrics["test/<k>"][u] is the result of the latest evaluation at update u (pqn_minatar.py:340-350), kept as
+    (first update, values) spans and written once -- for one seed ([5] values) and for a seed batch ([S, 5])."""
+    import torch
+    from purejaxql_amd.pqn import INFO_KEYS, _TestRows
+    k = len(INFO_KEYS)
+    tr = _TestRows(10)
+    tr.note(0, torch.arange(k, dtype=torch.float32))
+    tr.note(4, 10.0 + torch.arange(k, dtype=torch.float32))
+    tr.note(9, 20.0 + torch.arange(k, dtype=torch.float32))
+    rows = tr.rows()
+    assert rows.shape == (10, k)
+    for u in range(10):
+        base = 0.0 if u < 4 else (10.0 if u < 9 else 20.0)
+        assert torch.equal(rows[u], base + torch.arange(k, dtype=torch.float32)), u
+    tb = _TestRows(6)
+    tb.note(0, torch.zeros((3, k)))
+    tb.note(2, torch.ones((3, k)) * torch.tensor([[1.0], [2.0], [3.0]]))
+    rb = tb.rows()
+    assert rb.shape == (3, 6, k) and float(rb[:, :2].abs().max()) == 0.0
+    assert torch.equal(rb[:, 2:, 0], torch.tensor([[1.0] * 4, [2.0] * 4, [3.0] * 4]))
+    one = _TestRows(3)
+    one.note(0, torch.full((k,), float("nan")))          # an evaluation in which no episode finished
+    assert bool(torch.isnan(one.rows()).all())
