@@ -246,10 +246,8 @@ int pqn_prof_read(int32_t *count /* host */, float *total_ms /* host */);
                               returned_episode_returns, returned_episode_lengths, timestep, returned_episode */
 typedef struct {
   int32_t env_id, num_envs, num_steps, num_minibatches, num_epochs, obs_words, metrics_capacity;
-  int32_t reserved; /* flags.  bit 0 (experimental, leave 0): run the fold of the gradient partials, the global-norm
-                       clip and RAdam as ONE kernel with a grid-wide barrier instead of two kernels.  Measured slower
-                       in round 1 and unsafe when several updates are in flight on different streams of one GPU; same
-                       results up to the summation grouping of the global norm.
+  int32_t reserved; /* flags.  bit 0: ignored (rounds 1-4: a one-kernel fold + clip + RAdam with a grid-wide barrier,
+                       measured slower; removed in round 5).
                        bit 1: choose the form of the training kernel from the minibatch size alone, never from the number
                        of seeds batched into the launch (pqn_cnn_update_seeds): every seed then takes the kernels of its
                        solo run and is bit-identical to it in the one regime where the default is not -- f32 operand mode,

@@ -207,11 +207,6 @@ int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out,
                             const pqn_seeds_t &sd, hipStream_t st, bool with_reduce = true, int part = 0);
 // part: 0 = whole gradient, 1 = the training kernel(s) only, 2 = fc1 weight gradient + fold of the partials only
-// fold + clip + RAdam in one launch with a grid-wide barrier (see qnet_reduce_apply_kernel); scratch word 1022 of
-// the workspace is its ticket counter and must be zero before the first launch of an update
-int pqn_qnet_cnn_reduce_apply_seeds(const pqn_cnn_layout_t &L, int nb, float *theta, float *w1b, float *m, float *v,
-                                    int32_t *count, float *workspace, float *loss_out, float *qv_out, float lr_init,
-                                    float lr_end, double lr_steps, float max_norm, const pqn_seeds_t &sd, hipStream_t st);
 int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *obs_bits, const float *theta, float *q,
                              int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
                              const uint64_t *key_dev, hipStream_t st);

@@ -3225,7 +3225,6 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   float *h1T = dzT + (size_t)QN_HID * qw_ld(nb);
   float *gpart = h1T + (size_t)QN_H1 * qw_h1_cols(nb);
   // K-split form for small minibatches in the f32 operand mode; PQN_T1_KSPLIT=0 keeps the single-tile kernel
-  // (with_reduce == false is the experimental one-kernel optimizer, which folds the standard partial layout itself)
   // 0 off; 1 (default, measured best) = two launches: forward partial with 4 positions per workgroup, then head + backward
   // in one (8 positions per workgroup); three launches (forward partial, head, backward) with 4 (2), 8 (3) or 16 (4)
   // positions per workgroup
@@ -3495,199 +3494,6 @@ int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t
 }
 
 int pqn_cnn_grad_reduce_blocks(int total) { return grad_reduce_blocks(total); }
-
-// ---------------------------------------------------------------------------
-// T3 fused: fold of the partials + clip_by_global_norm + RAdam in ONE launch (pqn_cnn_update only).  The global
-// gradient norm needs every element before any element can be updated, so the kernel carries a grid-wide
-// barrier: QRA_G small workgroups per seed (128 x 512 threads: co-resident many times over on 256 CUs), a
-// ticket counter in the optimizer scratch (zeroed by the update driver), thread 0 of each workgroup spins with
-// s_sleep.  Every thread keeps the gradient elements it reduced in registers across the barrier, so the flat
-// gradient is never written or re-read.  Reduction orders are those of qnet_grad_reduce_kernel, the update
-// arithmetic that of radam_apply_kernel.  Seeds (grid.y) synchronise only among their own workgroups.
-// Not used when several updates may be in flight on different streams (partial residency of two spinning
-// grids could dead-lock): those paths keep the two-kernel version.
-// ---------------------------------------------------------------------------
-#define QRA_G 128
-#define QRA_CTR 1022   // scratch word holding the ticket counter
-#define QRA_NKQ 6      // small elements per wave of the four "small" waves: 128 x 4 x 6 = 3072 >= any layout's count
-
-__global__ __launch_bounds__(512) void qnet_reduce_apply_kernel(
-    pqn_cnn_layout_t L, int ntiles, int nks, int rec, const float *__restrict__ gpart, const float *__restrict__ wpart,
-    float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ count, float *scratch,
-    float *__restrict__ loss_out, float *__restrict__ qv_out, float inv_b, float lr_init, float lr_end, double lr_steps,
-    float max_norm, float *__restrict__ w1b, pqn_seeds_t sd) {
-  __shared__ float s_part[8];
-  __shared__ float s_np[QRA_G];
-  __shared__ float s_sc[8];
-  {  // seed slice
-    const long long s = blockIdx.y;
-    gpart += s * sd.ws_stride;
-    wpart += s * sd.ws_stride;
-    scratch += s * sd.ws_stride;
-    p += s * sd.theta_stride; m += s * sd.theta_stride; v += s * sd.theta_stride;
-    count += s;
-    if (loss_out) loss_out += s * sd.lq_stride;
-    if (qv_out) qv_out += s * sd.lq_stride;
-    w1b += s * sd.w1b_stride;
-  }
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int32_t c = *count;   // read before the barrier; workgroup 0 advances it after
-  // ---- phase A: reduce this thread's gradient elements (kept in registers) ----
-  float ss = 0.0f;
-  f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
-  const int j4 = blockIdx.x * 256 + tid;   // fc1 float4 owned by threads 0..255
-  float gs[QRA_NKQ];
-  int is[QRA_NKQ];                         // small elements owned by lane 0 of waves 4..7 (-1: none)
-#pragma unroll
-  for (int kq = 0; kq < QRA_NKQ; ++kq) { gs[kq] = 0.f; is[kq] = -1; }
-  if (tid < 256) {
-    for (int k = 0; k < nks; ++k) g4 += reinterpret_cast<const f32x4 *>(wpart + (size_t)k * QN_H1 * QN_HID)[j4];
-    ss = fmaf(g4.x, g4.x, fmaf(g4.y, g4.y, fmaf(g4.z, g4.z, g4.w * g4.w)));
-  } else {
-    const int convblk = 9 * L.c * 16 + 48;
-#pragma unroll
-    for (int kq = 0; kq < QRA_NKQ; ++kq) {
-      const int sidx = (blockIdx.x * 4 + (wave - 4)) + QRA_G * 4 * kq;   // index among the non-fc1 elements
-      const int i = sidx < L.off_w1 ? sidx : sidx + QN_H1 * QN_HID;
-      if (i >= L.total) continue;
-      int r = -1;  // index into the small record (-1: dummy BatchNorm / padding -> zero gradient, nothing to update)
-      if (i >= L.off_wc && i < L.off_wc + convblk) r = i - L.off_wc;
-      else if (i >= L.off_b1 && i < L.off_b1 + 384) r = convblk + (i - L.off_b1);
-      else if (i >= L.off_w2 && i < L.off_w2 + 128 * L.a) r = convblk + 384 + (i - L.off_w2);
-      else if (i >= L.off_b2 && i < L.off_b2 + L.a) r = convblk + 384 + 128 * L.a + (i - L.off_b2);
-      if (r < 0) continue;
-      float g = 0.0f;
-      for (int t = lane; t < ntiles; t += 64) g += gpart[(size_t)t * rec + r];
-      for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off, 64);
-      if (lane == 0) { gs[kq] = g; is[kq] = i; ss = fmaf(g, g, ss); }
-    }
-    if (blockIdx.x == 0 && wave == 4) {  // metrics td_loss / qvals (pqn_minatar.py:334-335)
-      float l = 0.f, qv = 0.f;
-      for (int t = lane; t < ntiles; t += 64) {
-        l += gpart[(size_t)t * rec + rec - 2];
-        qv += gpart[(size_t)t * rec + rec - 1];
-      }
-      for (int off = 32; off > 0; off >>= 1) { l += __shfl_down(l, off, 64); qv += __shfl_down(qv, off, 64); }
-      if (lane == 0) {
-        if (loss_out) *loss_out = l * inv_b;
-        if (qv_out) *qv_out = qv * inv_b;
-      }
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-  if (lane == 0) s_part[wave] = ss;
-  __syncthreads();
-  // ---- grid barrier (per seed) ----
-  if (tid == 0) {
-    const float part = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) + ((s_part[4] + s_part[5]) + (s_part[6] + s_part[7]));
-    __hip_atomic_store(scratch + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned *ctr = reinterpret_cast<unsigned *>(scratch) + QRA_CTR;
-    __threadfence();
-    const unsigned ticket = atomicAdd(ctr, 1u);
-    const unsigned target = (ticket / QRA_G + 1u) * QRA_G;   // every launch adds exactly QRA_G tickets
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-    __threadfence();
-  }
-  __syncthreads();
-  // ---- phase B: global norm (fixed order), step scalars, update of the owned elements ----
-  if (tid < QRA_G) s_np[tid] = __hip_atomic_load(scratch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (tid == 0) {
-    float acc = 0.0f;
-    for (int i = 0; i < QRA_G; ++i) acc += s_np[i];
-    const float gnorm = sqrtf(acc);
-    const double b1 = 0.9, b2 = 0.999, thr = 5.0;
-    const double t = (double)c + 1.0;
-    const double b1t = pqn_powi(b1, c + 1), b2t = pqn_powi(b2, c + 1);
-    const double ro_inf = 2.0 / (1.0 - b2) - 1.0;
-    const double ro = ro_inf - 2.0 * t * b2t / (1.0 - b2t);
-    const int rect = ro >= thr;
-    const float r = rect ? (float)sqrt((ro - 4.0) * (ro - 2.0) * ro_inf / ((ro_inf - 4.0) * (ro_inf - 2.0) * ro)) : 0.0f;
-    float lr = lr_init;
-    if (lr_steps > 0.0) {  // optax.linear_schedule evaluated at the pre-increment count
-      double cc = (double)c;
-      if (cc > lr_steps) cc = lr_steps;
-      lr = (float)(((double)lr_init - (double)lr_end) * (1.0 - cc / lr_steps) + (double)lr_end);
-    }
-    s_sc[0] = gnorm;
-    s_sc[1] = (gnorm < max_norm) ? 0.0f : 1.0f;
-    s_sc[2] = (float)(1.0 - b1t);
-    s_sc[3] = (float)(1.0 - b2t);
-    s_sc[4] = rect ? 1.0f : 0.0f;
-    s_sc[5] = r;
-    s_sc[6] = lr;
-    if (blockIdx.x == 0) *count = c + 1;
-  }
-  __syncthreads();
-  const float gnorm = s_sc[0];
-  const bool clip = s_sc[1] != 0.0f;
-  const float bc1 = s_sc[2], bc2 = s_sc[3];
-  const bool rect = s_sc[4] != 0.0f;
-  const float r = s_sc[5], lr = s_sc[6];
-  const float c1 = (float)(1.0 - 0.9), d1 = (float)0.9, c2 = (float)(1.0 - 0.999), d2 = (float)0.999;
-  auto step1 = [&](float gi, float &mi, float &vi, float pi) -> float {   // == radam_apply_kernel
-    if (clip) gi = (gi / gnorm) * max_norm;
-    mi = c1 * gi + d1 * mi;
-    vi = c2 * (gi * gi) + d2 * vi;
-    const float mh = mi / bc1;
-    const float vh = vi / bc2;
-    const float u = rect ? r * mh / (sqrtf(vh) + 1e-8f) : mh;
-    return pi - lr * u;
-  };
-  if (tid < 256) {
-    f32x4 *p4 = reinterpret_cast<f32x4 *>(p + L.off_w1) + j4, *m4 = reinterpret_cast<f32x4 *>(m + L.off_w1) + j4,
-          *v4 = reinterpret_cast<f32x4 *>(v + L.off_w1) + j4;
-    const f32x4 pm = *m4, pv = *v4, pp = *p4;
-    const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
-    float ma[4] = {pm.x, pm.y, pm.z, pm.w}, va[4] = {pv.x, pv.y, pv.z, pv.w}, pa[4] = {pp.x, pp.y, pp.z, pp.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pa[k] = step1(ga[k], ma[k], va[k], pa[k]);
-    *m4 = f32x4{ma[0], ma[1], ma[2], ma[3]};
-    *v4 = f32x4{va[0], va[1], va[2], va[3]};
-    *p4 = f32x4{pa[0], pa[1], pa[2], pa[3]};
-    _Float16 *w1h = L.matmul_f16 == 1 ? reinterpret_cast<_Float16 *>(p + L.off_w1h) : nullptr;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {   // keep the fragment-order copies of the fc1 kernel in step (as radam_apply_kernel)
-      const int j = 4 * j4 + k;
-      const int frag = j >> 8, ln = (j >> 2) & 63, sx = j & 3;
-      const int gi = frag >> 3, cb = frag & 7, kk = ln >> 4, jj = ln & 15;
-      const int jb = (((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3);
-      w1b[jb] = pa[k];
-      if (w1h) {
-        w1h[j] = (_Float16)pa[k];
-        w1h[QN_H1 * QN_HID + jb] = (_Float16)pa[k];
-      }
-    }
-  } else if (lane == 0) {
-#pragma unroll
-    for (int kq = 0; kq < QRA_NKQ; ++kq) {
-      if (is[kq] < 0) continue;
-      float mi = m[is[kq]], vi = v[is[kq]];
-      const float pn = step1(gs[kq], mi, vi, p[is[kq]]);
-      m[is[kq]] = mi;
-      v[is[kq]] = vi;
-      p[is[kq]] = pn;
-    }
-  }
-}
-
-int pqn_qnet_cnn_reduce_apply_seeds(const pqn_cnn_layout_t &L, int nb, float *theta, float *w1b, float *m, float *v,
-                                    int32_t *count, float *workspace, float *loss_out, float *qv_out, float lr_init,
-                                    float lr_end, double lr_steps, float max_norm, const pqn_seeds_t &sd, hipStream_t st) {
-  const int ntiles = nb / QN_TILE, nks = (nb + QW_SLAB - 1) / QW_SLAB, rec = small_record_floats(L.c, L.a);
-  PQN_REQUIRE(L.total - QN_H1 * QN_HID <= QRA_G * 4 * QRA_NKQ, "pqn_qnet_cnn_reduce_apply: %d small parameters exceed the kernel's plan",
-              L.total - QN_H1 * QN_HID);
-  float *scratch = workspace;
-  float *dzT = workspace + 1024;
-  float *h1T = dzT + (size_t)QN_HID * qw_ld(nb);
-  float *gpart = h1T + (size_t)QN_H1 * qw_h1_cols(nb);
-  float *wpart = gpart + (size_t)ntiles * rec;
-  hipLaunchKernelGGL(qnet_reduce_apply_kernel, dim3(QRA_G, sd.nseeds), dim3(512), 0, st, L, ntiles, nks, rec, gpart, wpart,
-                     theta, m, v, count, scratch, loss_out, qv_out, 1.0f / (float)nb, lr_init, lr_end, lr_steps, max_norm, w1b,
-                     sd);
-  return pqn_check_launch("pqn_qnet_cnn_reduce_apply");
-}
-
 
 extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float *w1b, const float *grad, float *m,
                                   float *v, int32_t *count, float lr_init, float lr_end, double lr_steps,

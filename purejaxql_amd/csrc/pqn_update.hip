@@ -175,7 +175,6 @@ static int pqn_sort_keys(void *temp, size_t temp_bytes, const int64_t *in, int64
 struct UpdCtx {
   int N, T, MB, EP, B, S, SN, TN, OW;
   pqn_seeds_t sd;
-  bool fused_opt;
 };
 
 static int upd_ctx(const pqn_update_args_t *a, int S, const uint64_t *key_roll_dev, const uint64_t *key_shuf_dev,
@@ -211,14 +210,11 @@ static int upd_ctx(const pqn_update_args_t *a, int S, const uint64_t *key_roll_d
     c.sd.lq_stride = (long long)c.MB * c.EP;
   }
   c.sd.idx_mask = (1ll << pqn_index_bits(c.TN)) - 1;   // low bits of a sorted shuffle key = the transition index
-  // reserved bit 0 (experimental, off by default): fold + clip + RAdam as ONE kernel with a grid-wide barrier
-  // instead of two kernels.  Measured slower in round 1 (5.47 vs 4.92 ms per update at the bench shape: the
-  // barrier costs more than the launch it saves) and unsafe when several updates are in flight on different
-  // streams (two partially resident barrier grids could dead-lock), so the two-kernel version is the default.
-  c.fused_opt = (a->reserved & 1) != 0;
+  // (reserved bit 0 selected a one-kernel fold + clip + RAdam with a grid-wide barrier in rounds 1-4: measured slower in round 1
+  // -- 5.47 vs 4.92 ms per update, the barrier costs more than the launch it saves -- and its summation order had drifted
+  // from qnet_grad_reduce_kernel's by round 5; removed, the bit is ignored)
   // reserved bit 1: kernel form of the training launches from the minibatch size alone (pqn_seeds_t.pin_form)
   c.sd.pin_form = (a->reserved & 2) != 0;
-  PQN_REQUIRE(!(c.fused_opt && a->layout.matmul_f16 == 2), "pqn_cnn_update: the experimental one-kernel optimizer does not maintain the bf16x3 planes");
   return PQN_OK;
 }
 
@@ -264,9 +260,6 @@ static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool 
 
 static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool norm_pass, hipStream_t st) {
   const pqn_cnn_layout_t &L = a->layout;
-  if (c.fused_opt && !norm_pass)   // fold + clip + RAdam in one launch (grid barrier); the flat gradient is never materialised
-    return pqn_qnet_cnn_reduce_apply_seeds(L, c.B, a->theta, a->w1b, a->m, a->v, a->count, a->workspace, a->loss_buf + i_mb,
-                                           a->qv_buf + i_mb, a->lr_init, a->lr_end, a->lr_steps, a->max_grad_norm, c.sd, st);
   return pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
                           a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, norm_pass ? 1 : 0,
                           pqn_cnn_grad_reduce_blocks(L.total), st, c.S, c.sd.theta_stride, c.sd.ws_stride, c.sd.w1b_stride,
@@ -299,7 +292,7 @@ static int cnn_update_impl(const pqn_update_args_t *a, int S, const uint64_t *ke
   for (int ep = 0; ep < c.EP; ++ep) {
     UPD_CHECK(upd_shuffle(a, c, ep, st));
     for (int mb = 0; mb < c.MB; ++mb, ++i_mb) {
-      UPD_CHECK(upd_grad(a, c, i_mb, !c.fused_opt, st));
+      UPD_CHECK(upd_grad(a, c, i_mb, true, st));
       UPD_CHECK(upd_apply(a, c, i_mb, false, st));
     }
   }
@@ -395,7 +388,6 @@ extern "C" int pqn_cnn_update_seed_groups(int32_t num_groups, const pqn_update_a
                 "pqn_cnn_update_seed_groups: strides must be positive multiples of 4 floats");
     UPD_CHECK(upd_ctx(args[g], num_seeds[g], key_roll_dev[g], key_shuf_dev[g], theta_stride[g], workspace_stride[g], c[g]));
     PQN_REQUIRE(c[g].MB == c[0].MB && c[g].EP == c[0].EP, "pqn_cnn_update_seed_groups: every group must have the same NUM_MINIBATCHES / NUM_EPOCHS");
-    PQN_REQUIRE(!c[g].fused_opt, "pqn_cnn_update_seed_groups: the experimental one-kernel optimizer cannot run with several updates in flight");
     for (int h = 0; h < g; ++h)
       PQN_REQUIRE(args[h]->workspace != args[g]->workspace && args[h]->theta != args[g]->theta && args[h]->clock != args[g]->clock,
                   "pqn_cnn_update_seed_groups: groups %d and %d share buffers", h, g);

@@ -612,7 +612,6 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                     "eps_finish": config["EPS_FINISH"], "eps_decay_steps": config["EPS_DECAY"] * config["NUM_UPDATES_DECAY"]}
             driver = UpdateDriver(base_env.env_id, N, T, MB, EPOCHS, base_env.obs_words, dcfg, (K_roll, K_shuf),
                                   policy.tr, ro, words, NUM_UPDATES, use_graph=config.get("_GRAPH", True),
-                                  fused_opt=config.get("_FUSED_OPT", False),
                                   pin_form=bool(config.get("SEED_BATCH_BIT_IDENTICAL", False)))
         elif backend == "fused_big" and grad_hook is None and metrics_hook is None and config.get("_DRIVER", True) and driver_shape_ok:
             # the Craftax script's loop (wrapper-batched env, wide MLP) from one C call, replayed as a hipGraph (not with a
@@ -1066,7 +1065,6 @@ def vmap_train(train: Callable[[int], Dict[str, Any]], keys: List[int], concurre
 
 def _vmap_streams(train, keys):
     """Seeds as concurrent HIP streams (paths without seed-batched kernels: torch-op networks)."""
-    train.config["_FUSED_OPT"] = False   # several updates in flight at once: no grid-barrier optimizer kernel
     num_updates = int(train.config["NUM_UPDATES"])
     main = torch.cuda.current_stream()
     streams = [torch.cuda.Stream() for _ in keys]

@@ -240,7 +240,7 @@ class UpdateDriver:
     buffers the C side needs; all training buffers are the caller's (rollout record, Cnn/MlpTrainer)."""
 
     def __init__(self, env_id, n, t, mb, epochs, obs_words, cfg, keys, trainer, ro, words, num_updates,
-                 use_graph: bool = True, fused_opt: bool = False, pin_form: bool = False):
+                 use_graph: bool = True, pin_form: bool = False):
         lib = _lib.load()
         dev = trainer.theta.device
         self.dev = dev
@@ -275,10 +275,9 @@ class UpdateDriver:
             a.obs, a.wt = p(ro.obs), p(trainer.wt)
         else:
             a.obs_words, a.bits, a.w1b = obs_words, p(ro.bits), p(trainer.w1b)
-            # experimental (config _FUSED_OPT, default off): fold + clip + RAdam as one kernel with a grid barrier
             # bit 1 (config SEED_BATCH_BIT_IDENTICAL): kernel form from the minibatch size alone -- a solo run then takes the
             # kernels a seed batch of the same shape takes and equals its seed of that batch bit for bit
-            a.reserved = (1 if fused_opt else 0) | (2 if pin_form else 0)
+            a.reserved = 2 if pin_form else 0
         a.action, a.reward, a.done, a.qmax = p(ro.action), p(ro.reward), p(ro.done), p(ro.qmax)
         a.discount, a.rer, a.rel, a.ts = p(ro.discount), p(ro.rer), p(ro.rel), p(ro.ts)
         a.target, a.last_q = p(ro.target), p(ro.last_q)
