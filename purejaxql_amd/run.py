@@ -1,7 +1,8 @@
 """single_run(config): the launcher half of the reference scripts (purejaxql/pqn_minatar.py:435-483,
 534-545) on top of make_train: seeds = independent runs (jax.vmap(make_train) at :459-461), wall-clock
 line (:462), per-seed .safetensors + resolved config yaml (:464-483).  wandb is not available offline:
-WANDB_MODE other than "disabled" logs metrics as JSON lines to stdout instead.
+WANDB_MODE other than "disabled" logs metrics as JSON lines to stdout instead, and tune() (HYP_TUNE, :484-531) runs the
+sweep's search space as a grid.
 
 Multi-GPU (one process per GPU, `python -m torch.distributed.run --nproc-per-node G -m purejaxql_amd.pqn_minatar ...`):
 the reference's seed axis is sharded over the ranks -- rank r trains partition_seeds(NUM_SEEDS, G, r), batched
@@ -95,6 +96,53 @@ def single_run(config: Dict[str, Any], device: Optional[str] = None, make_train_
             "rank": rank, "world_size": world}
 
 
+# the sweep the reference hands to wandb (pqn_minatar.py:509-527; the other scripts carry the same block): one parameter, four values,
+# metric returned_episode_returns, goal maximize
+SWEEP_PARAMETERS = {"LR": [0.001, 0.0005, 0.0001, 0.00005]}
+SWEEP_METRIC = "returned_episode_returns"
+
+
+def tune(default_config: Dict[str, Any], script: str = "gymnax", parameters: Optional[Dict[str, List[Any]]] = None,
+         run_fn: Optional[Callable] = None) -> Dict[str, Any]:
+    """tune(default_config) of the reference scripts (pqn_minatar.py:484-531) without the wandb service: the reference
+    registers a sweep (method "bayes", metric returned_episode_returns, goal maximize) over LR in {1e-3, 5e-4, 1e-4, 5e-5}
+    and lets wandb.agent call wrapped_make_train -- a copy of the default config with the drawn parameters written over
+    it, NUM_SEEDS vmapped seeds (:495-507) -- up to 1000 times.  Offline the sweep's search space is what can be honoured:
+    every combination of `parameters` (default: the reference's) is run once through single_run (same launcher path, seeds
+    batched into the launches, checkpoints off), the metric is the mean over seeds of its last-update value (NaN-safe), and
+    the ranking is printed and returned.  With WORLD_SIZE > 1 every rank runs every configuration on its share of the seeds;
+    rank 0 reports."""
+    import copy
+    import itertools
+    import math
+    space = dict(SWEEP_PARAMETERS if parameters is None else parameters)
+    names = sorted(space)
+    run_fn = single_run if run_fn is None else run_fn
+    trials = []
+    for values in itertools.product(*(space[n] for n in names)):
+        config = copy.deepcopy(default_config)
+        flat_alg = config.get("alg") if isinstance(config.get("alg"), dict) else None
+        for n, v in zip(names, values):       # wandb.config entries are written over the flattened config (:497-499)
+            config[n] = v
+            if flat_alg is not None and n in flat_alg:
+                flat_alg[n] = v
+        config["SAVE_PATH"] = None
+        outs = run_fn(config, script=script)
+        m = outs["metrics"].get(SWEEP_METRIC)
+        last = torch.as_tensor(m)[..., -1].to(torch.float64).reshape(-1) if m is not None else torch.empty(0, dtype=torch.float64)
+        ok = last[~torch.isnan(last)]
+        score = float(ok.mean()) if ok.numel() else float("nan")
+        trials.append({"parameters": dict(zip(names, values)), SWEEP_METRIC: score, "rank": outs.get("rank", 0)})
+        if outs.get("rank", 0) == 0:
+            print(f"sweep trial {len(trials)}: {dict(zip(names, values))} -> {SWEEP_METRIC} = {score:.4f}", flush=True)
+    ranked = sorted(trials, key=lambda t: (math.isnan(t[SWEEP_METRIC]), -t[SWEEP_METRIC] if not math.isnan(t[SWEEP_METRIC]) else 0.0))
+    if trials and trials[0]["rank"] == 0:
+        print("sweep ranking (metric: %s, goal: maximize):" % SWEEP_METRIC)
+        for t in ranked:
+            print("  ", json.dumps({**t["parameters"], SWEEP_METRIC: t[SWEEP_METRIC]}))
+    return {"trials": trials, "best": ranked[0] if ranked else None}
+
+
 def main(argv: List[str], default_alg: str, script: str = "gymnax") -> Dict[str, Any]:
     """`python -m purejaxql_amd.pqn_minatar +alg=pqn_minatar alg.KEY=V KEY=V` (README.md:170-187)."""
     overrides = list(argv)
@@ -104,8 +152,12 @@ def main(argv: List[str], default_alg: str, script: str = "gymnax") -> Dict[str,
     rank, _world, _lr = pdist.world_info()
     if rank == 0:
         print("Config:\n", yaml.safe_dump(config))
-    if config.get("HYP_TUNE", False):
-        raise SystemExit("HYP_TUNE (wandb sweep, pqn_minatar.py:486-531) needs the wandb service: out of scope offline")
+    if config.get("HYP_TUNE", False):      # (:537-540)
+        res = tune(config, script=script)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return res
     outs = single_run(config, script=script)
     if outs["rank"] == 0:
         m = outs["metrics"]

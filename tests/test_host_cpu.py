@@ -263,3 +263,38 @@ def test_test_rows_are_spans_of_the_latest_evaluation():
     one = _TestRows(3)
     one.note(0, torch.full((k,), float("nan")))          # an evaluation in which no episode finished
     assert bool(torch.isnan(one.rows()).all())
+
+
+def test_tune_runs_the_references_sweep_space_offline(capsys):
+    """run.tune (pqn_minatar.py:484-531 without the wandb service): every value of the reference's sweep space (LR in {1e-3, 5e-4,
+    1e-4, 5e-5}) is run once through the launcher path with the drawn value written over the config -- also inside the nested
+    `alg` group, which single_run's flatten would otherwise let win --, checkpoints off; the metric is the mean over seeds of
+    the last returned_episode_returns (NaN-safe), the goal maximize.  Driven with a stand-in run function (no GPU here)."""
+    import torch
+    from purejaxql_amd.config_loader import load_config
+    from purejaxql_amd.run import SWEEP_METRIC, SWEEP_PARAMETERS, tune
+    assert SWEEP_PARAMETERS == {"LR": [0.001, 0.0005, 0.0001, 0.00005]} and SWEEP_METRIC == "returned_episode_returns"
+    seen = []
+
+    def fake_run(config, script="gymnax"):
+        from purejaxql_amd.config_loader import flatten
+        flat = flatten(config)
+        seen.append((flat["LR"], flat.get("SAVE_PATH"), script, config["alg"]["LR"]))
+        lr = float(flat["LR"])
+        # two seeds, three updates; "returns" peak at 5e-4; the 5e-5 run finishes no episode in its last update (NaN)
+        last = float("nan") if lr == 0.00005 else 100.0 - abs(lr - 0.0005) * 1e5
+        m = torch.tensor([[1.0, 2.0, last], [1.0, 2.0, last + 2.0]])
+        return {"metrics": {SWEEP_METRIC: m}, "rank": 0, "world_size": 1}
+
+    cfg = load_config(["+alg=pqn_minatar", "HYP_TUNE=True", "SAVE_PATH=/tmp/should_not_be_used"])
+    res = tune(cfg, script="gymnax", run_fn=fake_run)
+    assert [s[0] for s in seen] == SWEEP_PARAMETERS["LR"] and all(s[1] is None and s[0] == s[3] for s in seen)
+    assert cfg["alg"]["LR"] == 0.0005 and cfg["SAVE_PATH"] == "/tmp/should_not_be_used"      # the default config is not modified
+    assert res["best"]["parameters"] == {"LR": 0.0005} and abs(res["best"][SWEEP_METRIC] - 101.0) < 1e-9
+    assert [t["parameters"]["LR"] for t in res["trials"]] == SWEEP_PARAMETERS["LR"]
+    import math
+    assert math.isnan(res["trials"][3][SWEEP_METRIC])
+    out = capsys.readouterr().out
+    assert out.count("sweep trial") == 4 and "sweep ranking" in out
+    two = tune(cfg, parameters={"LR": [1e-3], "LAMBDA": [0.5, 0.9]}, run_fn=fake_run)
+    assert len(two["trials"]) == 2 and {t["parameters"]["LAMBDA"] for t in two["trials"]} == {0.5, 0.9}

@@ -169,6 +169,23 @@ def test_single_run_logs_json_lines_per_seed_with_rng_prefixed_copies(gpu, capsy
             assert r["td_loss"] == r[f"rng{tags[s]}/td_loss"] and abs(r["td_loss"] - want) <= 1e-6 * abs(want)
 
 
+def test_hyp_tune_runs_the_sweep_space_through_the_launcher(gpu, capsys):
+    """`HYP_TUNE=True` (pqn_minatar.py:537-540 -> tune, :484-531): offline the reference's sweep space is run as a grid -- four LR
+    values, two seeds each, batched into the launches -- and the ranking by the last returned_episode_returns is reported;
+    every trial is a real training run (its loss is finite and the trials differ)."""
+    import math
+    from purejaxql_amd.run import SWEEP_PARAMETERS, main
+    res = main(["alg.ENV_NAME=Breakout-MinAtar", "alg.NUM_ENVS=32", "alg.NUM_STEPS=8", "alg.NUM_MINIBATCHES=4",
+                "alg.TOTAL_TIMESTEPS=10240", "alg.TOTAL_TIMESTEPS_DECAY=10240", "alg.TEST_DURING_TRAINING=False", "NUM_SEEDS=2",
+                "HYP_TUNE=True"], "pqn_minatar")
+    assert [t["parameters"]["LR"] for t in res["trials"]] == SWEEP_PARAMETERS["LR"]
+    scores = [t["returned_episode_returns"] for t in res["trials"]]
+    assert all(math.isfinite(x) and x > 0 for x in scores) and len(set(scores)) > 1
+    assert res["best"]["returned_episode_returns"] == max(scores)
+    out = capsys.readouterr().out
+    assert out.count("sweep trial") == 4 and "sweep ranking" in out
+
+
 @pytest.mark.parametrize("backend", ["fused", "torch"])
 def test_eval_metrics_flat_obs_path_vs_oracle(gpu, oracle, backend):
     """get_test_metrics on the gymnax-classic path (pqn_gymnax.py:362-404): CartPole-v1, fused MLP kernels and
