@@ -74,19 +74,27 @@ def cpu_baseline(cfg, theta0):
     t, n_envs = int(ocfg["NUM_STEPS"]), int(cfg["NUM_ENVS"])
     ocfg["TOTAL_TIMESTEPS"] = ocfg["TOTAL_TIMESTEPS_DECAY"] = 1e7
     ncpu = os.cpu_count() or 1
+    try:   # every native pool of the process (torch's OpenMP, numpy's OpenBLAS, the C oracle's OpenMP) at the SAME count: in round 5
+        from threadpoolctl import threadpool_info, threadpool_limits   # openblas sat at 64 threads beside torch's 16
+    except Exception:  # noqa: BLE001
+        threadpool_info = threadpool_limits = None
+
+    def run(thr, **kw):
+        if threadpool_limits is None:
+            return cpu_loop.make_train(ocfg, threads=thr)(12345, theta0, **kw), "unknown"
+        with threadpool_limits(limits=thr):
+            out = cpu_loop.make_train(ocfg, threads=thr)(12345, theta0, **kw)
+            desc = ", ".join(f"{p.get('internal_api')}:{p.get('num_threads')}" for p in threadpool_info())
+        return out, desc
+
     tried = {}
     for thr in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
-        out = cpu_loop.make_train(ocfg, threads=thr)(12345, theta0, max_updates=2, time_budget=8.0, min_updates=1)
+        out, _ = run(thr, max_updates=2, time_budget=8.0, min_updates=1)
         tried[thr] = out["seconds_per_update"][-1]              # the second (warm) update, or the only one if it was slow
     best = min(tried, key=tried.get)
-    out = cpu_loop.make_train(ocfg, threads=best)(12345, theta0, max_updates=7, time_budget=12.0, min_updates=4)
+    out, pool_desc = run(best, max_updates=7, time_budget=12.0, min_updates=4)
     secs = out["seconds_per_update"][1:]                    # the first update is the warm-up
     dt = float(sum(secs))
-    try:
-        from threadpoolctl import threadpool_info
-        pool_desc = ", ".join(f"{p.get('internal_api')}:{p.get('num_threads')}" for p in threadpool_info())
-    except Exception:
-        pool_desc = "unknown"
     # env-only rate (uniform-random actions, no network): the C oracle's OpenMP env.step + auto-reset + LogWrapper
     env = oracle.OracleEnv(ocfg["ENV_NAME"])
     _obs, st = env.reset(1, n_envs)
@@ -98,7 +106,7 @@ def cpu_baseline(cfg, theta0):
         _o, st, _r, _d, _info = env.step(100 + i, st, acts[i])
     env_only = 50 * n_envs / (time.perf_counter() - t1)
     return {"value": len(secs) * n_envs * t / dt, "unit": "env-steps/s", "cores": best, "kind": "port",
-            "host_logical_cores": ncpu, "seconds_per_update_by_threads": {str(k): round(v, 3) for k, v in tried.items()},
+            "host_logical_cores": ncpu, "cores_used_of_present": f"{best} of {ncpu}", "thread_pools": pool_desc, "seconds_per_update_by_threads": {str(k): round(v, 3) for k, v in tried.items()},
             "env_only_env_steps_per_s": env_only, "updates_timed": len(secs), "seconds_per_update": [round(x, 3) for x in secs],
             "sample": f"{len(secs)} timed full PQN updates (rollout+Q(lambda)+{ocfg['NUM_EPOCHS']}x{ocfg['NUM_MINIBATCHES']} SGD steps) of ONE "
                       f"seed at NUM_ENVS={n_envs}, NUM_STEPS={t} (the bench shape): {len(secs) * n_envs * t} env-steps in {dt:.1f}s, after one "
@@ -154,7 +162,7 @@ def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sampl
         flop_per_sample = pos_flop_per_sample(channels, actions)[0]
     achieved = flop_per_sample * mb_samples * seeds / avg_s / 1e12
     traffic, tsrc, l2cu = None, None, None
-    for name in ((f"r05_pmc_pos_bwd_kernel_{matmul}_seeds{seeds}.json",) if form == "pos" else
+    for name in ((f"r06_pmc_pos_bwd_kernel_{matmul}_seeds{seeds}.json", f"r05_pmc_pos_bwd_kernel_{matmul}_seeds{seeds}.json") if form == "pos" else
                  (f"r04_pmc_train_kernel_{matmul}_seeds{seeds}.json", f"r03_pmc_train_kernel_{matmul}_seeds{seeds}.json",
                  f"r02_pmc_train_kernel_{matmul}_seeds{seeds}.json",
                  f"r02_pmc_train_kernel_{matmul}.json", "r01_pmc_train_kernel.json")):
@@ -169,7 +177,8 @@ def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sampl
                 tsrc = (f"from file profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
                         f"{ps}-seed launch of this kernel, gfx950-corrected as MI355X_MICROARCH.md prescribes"
                         + (f", x{seeds // ps} for the {seeds} seeds of this launch" if seeds != ps else "")
-                        + "; not measured in this run")
+                        + f"; NOT measured in this run (counter passes need rocprofv3 around the process): file written {pj.get('date', 'in the round its name says')}"
+                        + (f" at commit {pj['commit']}" if pj.get('commit') else ""))
                 break
     # which form ran is asked of the library (pqn_cnn_last_kernel_form), not re-derived here
     kname = {"pair": "qnet_cnn_train_pair_kernel<4>", "single": "qnet_cnn_train_kernel<4>"}.get(form, form)
@@ -231,7 +240,7 @@ def main():
     ap.add_argument("--matmul-dtype", default="bf16x3", choices=["f32", "bf16x3", "f16"],
                     help="operand mode of the fc1 / conv products (config MATMUL_DTYPE).  bf16x3 (default here) evaluates "
                          "every f32 product exactly-split on the bf16 matrix core with f32 accumulation and is held to "
-                         "the same f32 tolerances as the f32-MFMA mode by the parity tests; the package default stays f32")
+                         "the same f32 tolerances as the f32-MFMA mode by the parity tests; the package default is auto = this mode from 512-sample minibatches on, f32 below")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -351,6 +360,10 @@ def main():
             f_s, _ = kernel_timer_pass(lib, update, n_done + 2, mb, spl, mode=3)
             a_s, _ = kernel_timer_pass(lib, update, n_done + 4, mb, spl, mode=4)
             bwd_f, fwd_f = pos_flop_per_sample(4, 3)
+            # flat scalars (a line parser that keeps scalars only still shows the whole training step)
+            roof["forward_kernel_us"] = f_s * 1e6
+            roof["gather_forward_backward_us"] = a_s * 1e6
+            roof["value_and_grad_frac"] = (bwd_f + fwd_f) * mb * spl / a_s / 1e12 / roof["peak"]
             roof["training_step"] = {
                 "forward_kernel_us": f_s * 1e6, "forward_frac": fwd_f * mb * spl / f_s / 1e12 / roof["peak"],
                 "forward_frac_f32_peak": fwd_f * mb * spl / f_s / 1e12 / F32_PEAK_TFLOPS,
@@ -505,15 +518,16 @@ def main():
                         "backend": tr5.backend, "driver": mode5, "updates_timed": steps5,
                         "roofline": {"kernel": "bm_gemm_kernel<128|64, 64> (every Dense product of the update: forward of the "
                                                "rollout batch and of concat(obs, next_obs), input and weight gradients)",
-                                     "bound": "mfma", "achieved": ach, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                     "frac": ach / F32_PEAK_TFLOPS, "traffic": None,
+                                     "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS / 6.0, "unit": "TFLOP/s",
+                                     "frac": ach / (BF16_PEAK_TFLOPS / 6.0), "frac_f32_mfma_peak": ach / F32_PEAK_TFLOPS, "traffic": None,
+                                     "gemm_share_of_update": gemm_s / (d5 / steps5),
                                      "flop_per_update": flop_upd, "gemm_us_per_update": gemm_s * 1e6,
                                      "gemm_launches_per_update": cnt.value / 4,
                                      "bf16_pipe": {"issued_tflops": ach * 6.0, "peak": BF16_PEAK_TFLOPS,
                                                    "frac": ach * 6.0 / BF16_PEAK_TFLOPS},
-                                     "peak_note": "algorithmic f32 FLOPs (2 M N K on the unpadded shapes) against the f32 MFMA / "
-                                                  "vector peak; bf16_pipe prices the 6 bf16 products per f32 product against "
-                                                  "the dense bf16 peak"}}
+                                     "peak_note": "the headline's basis: algorithmic f32 FLOPs (2 M N K on the unpadded shapes) against "
+                                                  "dense bf16 peak / 6 products per f32 product = 416.7 TFLOP/s (round 5 printed this "
+                                                  "line against the f32 MFMA peak: that fraction is kept as frac_f32_mfma_peak)"}}
             guarded("craftax_c5", craftax_c5)
 
             def yaml_default():
@@ -529,7 +543,7 @@ def main():
                 dd = timed_updates(updd, steps_d, warm_d)
                 per_upd = cd["NUM_ENVS"] * cd["NUM_STEPS"]
                 return {"workload": f"Breakout-MinAtar PQN at the yaml defaults: NUM_ENVS={cd['NUM_ENVS']} NUM_STEPS={cd['NUM_STEPS']} "
-                                    f"NUM_MINIBATCHES={cd['NUM_MINIBATCHES']} NUM_EPOCHS={cd['NUM_EPOCHS']}, one seed, f32 operands",
+                                    f"NUM_MINIBATCHES={cd['NUM_MINIBATCHES']} NUM_EPOCHS={cd['NUM_EPOCHS']}, one seed, MATMUL_DTYPE=auto -> f32 operands",
                         "value": per_upd * steps_d / dd, "unit": "env-steps/s", "ms_per_update": dd / steps_d * 1e3,
                         "updates_timed": steps_d, "kernel_forms": dict(zip(("train", "rollout"), _lib.last_kernel_form())),
                         "seconds_for_1e7_steps": 1e7 / (per_upd * steps_d / dd)}

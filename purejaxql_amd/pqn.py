@@ -231,7 +231,7 @@ class _FusedCnnPolicy:
         from .qnet import CnnKernelLayout, CnnTrainer, cnn_forward, matmul_mode
         self.net = network
         self.layout = CnnKernelLayout(network.obs_shape[-1], network.action_dim,
-                                      matmul_f16=matmul_mode(config.get("MATMUL_DTYPE", "f32")))
+                                      matmul_f16=matmul_mode(config.get("MATMUL_DTYPE", "auto"), max_mb))
         self.tr = CnnTrainer(self.layout, theta, config["LR"], config["MAX_GRAD_NORM"], lr_decay_steps=lr_steps,
                              max_minibatch=max_mb)
         self.fwd = cnn_forward
@@ -654,6 +654,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             driver.update()
             if not forms and packed:
                 forms.update(zip(("train", "rollout"), _lib.last_kernel_form()))
+                forms["matmul_dtype"] = ("f32", "f16", "bf16x3")[policy.layout.mode]   # what MATMUL_DTYPE (auto) resolved to
             if shard_world > 1 or metrics_hook is not None:
                 share_metrics_row(driver.metrics[u])     # (waits for the stream first: nothing is enqueued behind a replay in flight)
             if grad_hook is not None and hasattr(grad_hook, "poll"):
@@ -876,7 +877,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             return make_grouped_runner(rngs, G)
         if packed:
             layout = CnnKernelLayout(obs_shape[-1], A,
-                                     matmul_f16=matmul_mode(config.get("MATMUL_DTYPE", "f32")))
+                                     matmul_f16=matmul_mode(config.get("MATMUL_DTYPE", "auto"),
+                                                            config["NUM_ENVS"] * config["NUM_STEPS"] // config["NUM_MINIBATCHES"]))
         else:
             layout = MlpKernelLayout(obs_shape[0], int(config.get("HIDDEN_SIZE", 128)), int(config.get("NUM_LAYERS", 2)), A)
         Ks = []
@@ -976,6 +978,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 drv.update()
             if not forms:
                 forms.update(zip(("train", "rollout"), _lib.last_kernel_form()))
+                if packed:
+                    forms["matmul_dtype"] = ("f32", "f16", "bf16x3")[layout.mode]
             counters["timesteps"] += T * N
             counters["n_updates"] += 1
             counters["grad_steps"] += MB * EPOCHS

@@ -24,15 +24,29 @@ class CnnLayoutStruct(C.Structure):
 
 
 MATMUL_MODES = {"f32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "bf16x3": 2}
+# MATMUL_DTYPE: auto (the package default since round 6) picks between the two f32-grade modes by the minibatch size: bf16x3 from 512
+# samples on, f32 below.  Measured whole-loop rates of Breakout (tools/mode_sweep.py, profiles/r06_v1_mode_sweep.txt): minibatch 128 /
+# 256 -> f32 1.74e6 / 3.01e6 vs bf16x3 1.05e6 / 2.14e6 env-steps/s (only the f32 mode has the K-split kernels of the small
+# launches); 512 / 1024 / 2048 / 4096 -> f32 3.78e6 / 7.46e6 / 1.45e7 / 2.78e7 vs bf16x3 4.28e6 / 8.58e6 / 1.68e7 / 3.05e7 (one seed),
+# and 3.6e7 vs 7.55e7 with 16 seeds in the launches.  Both modes are held to the same tolerances against the oracle.
+AUTO_BF16X3_MIN_MINIBATCH = 512
 
 
-def matmul_mode(config_value) -> int:
-    """config MATMUL_DTYPE -> pqn_cnn_layout_t.matmul_f16: 0 = f32-input MFMA (exact f32 fma chains), 1 = fp16 operands
-    (opt-in, narrower than the reference's f32), 2 = bf16x3 split operands (f32-grade products on the bf16 matrix core)."""
-    key = str(config_value if config_value is not None else "f32").lower()
+def resolve_matmul_dtype(config_value, minibatch=None) -> str:
+    """config MATMUL_DTYPE -> the operand mode that runs: auto (or unset) = bf16x3 for minibatches of >= 512 samples, else f32."""
+    key = str(config_value if config_value is not None else "auto").lower()
+    if key == "auto":
+        return "bf16x3" if (minibatch is not None and int(minibatch) >= AUTO_BF16X3_MIN_MINIBATCH) else "f32"
     if key not in MATMUL_MODES:
-        raise ValueError(f"MATMUL_DTYPE={config_value!r}: expected one of {sorted(set(MATMUL_MODES))}")
-    return MATMUL_MODES[key]
+        raise ValueError(f"MATMUL_DTYPE={config_value!r}: expected auto or one of {sorted(set(MATMUL_MODES))}")
+    return key
+
+
+def matmul_mode(config_value, minibatch=None) -> int:
+    """config MATMUL_DTYPE -> pqn_cnn_layout_t.matmul_f16: 0 = f32-input MFMA (exact f32 fma chains), 1 = fp16 operands
+    (opt-in, narrower than the reference's f32), 2 = bf16x3 split operands (f32-grade products on the bf16 matrix core);
+    auto: see resolve_matmul_dtype."""
+    return MATMUL_MODES[resolve_matmul_dtype(config_value, minibatch)]
 
 
 class CnnKernelLayout:
