@@ -328,10 +328,15 @@ def main():
         dist.all_reduce(one)
         ranks_seen = int(round(float(one.item())))
     dt = timed_updates(update, args.steps, args.warmup, 0, barrier)
+    per_rank_ms = None
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        # every rank's own time for the same timed region (value uses the MAX): a slow GPU of the node shows up as spread
+        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        mine = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        dt = max(float(x.item()) for x in every)
     sps = env_steps_per_update * args.steps / dt
 
     # A second, longer timed region of the SAME runner (>= 6 s of back-to-back graph replays, N = 1 only): the rate once
@@ -408,6 +413,8 @@ def main():
                        "dist_backend": dist.get_backend() if world > 1 else None,
                        "grad_allreduce": (getattr(ghook, "mode", None) if args.mode == "envs" and world > 1 else None),
                        "gpus_visible": torch.cuda.device_count(),
+                       "per_rank_ms_per_step": per_rank_ms,
+                       "per_rank_spread": (None if not per_rank_ms else (max(per_rank_ms) - min(per_rank_ms)) / max(per_rank_ms)),
                        "loop_tflops": sps * LOOP_FLOP / 1e12, "loop_frac_f32_peak": sps * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS},
             "roofline": roof,
         }

@@ -355,7 +355,11 @@ int pqn_cnn_rollout(int env_id, const pqn_cnn_layout_t *layout, int32_t num_envs
                     float rew_scale, void *stream);
 /* The same scan for num_seeds independent seeds in one launch: env e of seed s is column s*envs_per_seed + e of
  * every array, draws its randomness as env e of a single-seed call with keys_dev[s*keys_stride + t], and is driven by
- * the parameters theta + s*theta_stride (envs_per_seed % 16 == 0).  Bit-identical to num_seeds pqn_cnn_rollout calls. */
+ * the parameters theta + s*theta_stride (envs_per_seed % 16 == 0).  Bit-identical to num_seeds pqn_cnn_rollout calls whenever
+ * both take the same rollout kernel; the kernel follows the LAUNCH size by default (bf16x3 mode: the position-structure
+ * kernel from 40,960 envs per launch on, option rollout_pos), so a seed batch that fills the chip and its solo runs can differ
+ * in the f32 summation order of q (near-tied actions may then differ).  Option pin_form = 1 (pqn_set_option; config
+ * SEED_BATCH_BIT_IDENTICAL sets it) takes the kernel from envs_per_seed alone in both calls: bit-identical again. */
 int pqn_cnn_rollout_seeds(int env_id, const pqn_cnn_layout_t *layout, int32_t num_seeds, int32_t envs_per_seed,
                           int32_t num_steps, uint32_t *state, uint32_t *obs_bits, int32_t store_obs, const float *theta,
                           int64_t theta_stride, const pqn_step_out_t *rec /* host */, int32_t *action, float *qmax,

@@ -398,8 +398,10 @@ def brn_fwd(x, scale, bias, stats, train, new_stats=None):
     return y.reshape(x.shape), cache
 
 
-def brn_bwd(dy, scale, cache):
-    """d/dx, d/dscale, d/dbias of the train-mode BatchRenorm (batch moments are functions of x; r, d are constants)."""
+def brn_bwd(dy, scale, cache, need_dx=True):
+    """d/dx, d/dscale, d/dbias of the train-mode BatchRenorm (batch moments are functions of x; r, d are constants).
+    need_dx=False (the INPUT normalisation: nothing consumes d/dx) returns None for it -- its d var / d x term divides by
+    sqrt(batch variance), which is 0 for a constant observation column: NaNs that nobody reads, but that np.testing treats as equal."""
     x2, bmean, bvar, cm, cv, r, d = cache
     n = x2.shape[0]
     dy2 = dy.reshape(x2.shape).astype(np.float32)
@@ -407,6 +409,8 @@ def brn_bwd(dy, scale, cache):
     xc = x2 - cm
     dscale = (dy2 * xc * k).sum(0)
     dbias = dy2.sum(0)
+    if not need_dx:
+        return None, dscale.astype(np.float32), dbias.astype(np.float32)
     dyh = dy2 * scale
     g_cm = -k * dyh.sum(0)
     g_cv = -0.5 * k ** 3 * (dyh * xc).sum(0)
@@ -435,12 +439,12 @@ def _batchnorm_fwd(x, scale, bias, name, train, stats, new_stats, renorm):
     return _bn_fwd(x, scale, bias, name, train, stats, new_stats)
 
 
-def _batchnorm_bwd(dy, scale, cache):
+def _batchnorm_bwd(dy, scale, cache, need_dx=True):
     if isinstance(cache, tuple) and len(cache) == 3 and isinstance(cache[0], str) and cache[0] == "brn":
         _tag, c, train = cache
         if not train:
             raise ValueError("backward through an eval-mode BatchRenorm is not used on this path")
-        return brn_bwd(dy, scale, c)
+        return brn_bwd(dy, scale, c, need_dx)
     return _bn_bwd(dy, scale, cache)
 
 
@@ -574,7 +578,7 @@ def _net_backward(kind, p, shapes, x, cache, dq, layers, norm_input):
             g[f"Dense_{l}/bias"] = d.sum(0)
             d = d @ p[f"Dense_{l}/kernel"].T
         if norm_input:
-            _dx, g[bn0 + "/scale"], g[bn0 + "/bias"] = _batchnorm_bwd(d, p[bn0 + "/scale"], cache["cin"])
+            _dx, g[bn0 + "/scale"], g[bn0 + "/bias"] = _batchnorm_bwd(d, p[bn0 + "/scale"], cache["cin"], need_dx=False)
     return np.concatenate([g[k].reshape(-1).astype(np.float32) for k in shapes])
 
 

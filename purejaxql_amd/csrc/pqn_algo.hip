@@ -46,7 +46,7 @@ static struct {
     {"t1_ksplit", "PQN_T1_KSPLIT", 1, 0, false},   {"t1_ksplit_tiles", "PQN_T1_KSPLIT_TILES", 48, 0, false},
     {"bm_overlap", "PQN_BM_OVERLAP", 0, 0, false}, {"peer_timeout_s", "PQN_PEER_TIMEOUT_S", 60, 0, false},
     {"t2_acc", "PQN_T2_ACC", 1, 0, false},        {"upd_overlap", "PQN_UPD_OVERLAP", 0, 0, false},
-    {"rollout_pos", "PQN_ROLLOUT_POS", 1, 0, false},
+    {"rollout_pos", "PQN_ROLLOUT_POS", 1, 0, false}, {"pin_form", "PQN_PIN_FORM", 0, 0, false},
 };
 static int g_forms[2] = {PQN_FORM_NONE, PQN_FORM_NONE};
 

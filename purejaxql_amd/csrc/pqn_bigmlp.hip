@@ -1080,10 +1080,9 @@ int bm_launch(int M, int N, int Kp, const BmPlan &p, const BmPlanes &A, const Bm
   do {                                                                                                                   \
     auto kern = &bm_gemm_kernel<BM_, 64, EPI>;                                                                           \
     constexpr int lds = bm_lds_bytes<BM_, 64>();                                                                        \
-    static bool attr = false;                                                                                            \
-    if (!attr) {                                                                                                         \
+    static pqn_once_per_device attr;                                                                                            \
+    if (attr.first()) {                                                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
-      attr = true;                                                                                                       \
     }                                                                                                                    \
     hipLaunchKernelGGL(kern, grid, dim3(BM_THREADS), lds, st, M, N, Kp, p.klen, A, B, E);                                \
   } while (0)

@@ -9,6 +9,24 @@
 #define PQN_HD __host__ __device__ __forceinline__
 #define PQN_D __device__ __forceinline__
 
+// "do this once per device" flag for hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute belongs to the (function, device)
+// pair, and a process may drive several devices (a process-wide bool skipped it on the second device)
+#define PQN_MAX_DEVICES 16
+inline bool pqn_not_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+}
+struct pqn_once_per_device {
+  bool done[PQN_MAX_DEVICES] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= PQN_MAX_DEVICES) return true;   // unknown device: set the attribute again (idempotent)
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // threefry2x32-20.  Counter-based: no RNG state in HBM, every lane evaluates
 // its own block function from (key, (index, stream)).
@@ -90,6 +108,7 @@ enum {
   PQN_OPT_T2_ACC,         // PQN_T2_ACC: bf16x3 fc1 weight gradient without split-K partials 0 never / 1 when row blocks x seeds fill the chip / 2 always
   PQN_OPT_UPD_OVERLAP,    // PQN_UPD_OVERLAP: pqn_bigmlp_update puts the first epoch's permutation and the last gradient-copy plane refresh on a side stream (bit 0 / bit 1; default 0: a fork / join pair in the graph costs ~30 us)
   PQN_OPT_ROLLOUT_POS,    // PQN_ROLLOUT_POS: position-structure rollout kernel (256 envs per workgroup, pqn_qnet_pos.hip) 0 never / 1 when the launch fills the chip (default) / 2 whenever the shape allows
+  PQN_OPT_PIN_FORM,       // PQN_PIN_FORM: pqn_cnn_rollout / pqn_cnn_rollout_seeds choose the rollout kernel from the envs PER SEED alone, never from the number of seeds in the launch (default 0)
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);

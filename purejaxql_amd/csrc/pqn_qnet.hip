@@ -2983,11 +2983,10 @@ static int launch_fwd(int n, const uint32_t *bits, const float *theta, const pqn
                       int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,
                       const uint64_t *key_dev, hipStream_t st) {
   const size_t smem = cnn_smem_bytes<C>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static pqn_once_per_device attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_fwd_kernel<C>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int ablate = pqn_opt(PQN_OPT_ABLATE);  // profiling only
   hipLaunchKernelGGL((qnet_cnn_fwd_kernel<C>), dim3((n + QN_TILE - 1) / QN_TILE), dim3(QN_THREADS), smem, st, n, bits, theta, L,
@@ -3035,15 +3034,14 @@ static int launch_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_le
     }
   }
   const size_t smem = cnn_smem_bytes<C>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static pqn_once_per_device attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_kernel<C, Env, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_kernel<C, Env, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_kernel<C, Env, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   // one instantiation per operand mode (as the training kernel): the env state lives in registers across the T-step
   // loop, and carrying all three fc1 / conv variants in one kernel cost 27 spilled VGPRs
@@ -3055,11 +3053,10 @@ static int launch_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_le
   const bool use_pair = rp_env && L.matmul_f16 == 2 && pair_smem <= 160 * 1024 && n % (2 * QN_TILE) == 0 &&
                         (n_per_seed <= 0 || n_per_seed % (2 * QN_TILE) == 0) && (n / (2 * QN_TILE) >= 256 || rp_env == 2);
   if (use_pair) {
-    static bool pattr = false;
-    if (!pattr) {
+    static pqn_once_per_device pattr;
+    if (pattr.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_rollout_pair_kernel<C, Env>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem);
-      pattr = true;
     }
     hipLaunchKernelGGL((qnet_cnn_rollout_pair_kernel<C, Env>), dim3(n / (2 * QN_TILE)), dim3(QN_THREADS), pair_smem, st, n,
                        t_len, state, bits, theta, L, action, qmax, rec.reward, rec.done, rec.discount,
@@ -3117,7 +3114,7 @@ extern "C" int pqn_cnn_rollout(int env_id, const pqn_cnn_layout_t *layout, int32
   PQN_REQUIRE(r.obs == nullptr && r.obs_bits == nullptr,
               "pqn_cnn_rollout: observations are recorded through obs_bits[T+1][n][OW], rec->obs / rec->obs_bits must be NULL");
   return pqn_qnet_cnn_rollout(env_id, *layout, num_envs, num_steps, state, obs_bits, theta, r, action, qmax, last_q, eps_dev,
-                              keys_dev, rew_scale, store_obs != 0, (hipStream_t)stream);
+                              keys_dev, rew_scale, store_obs != 0, (hipStream_t)stream, 0, 0, 0, pqn_opt(PQN_OPT_PIN_FORM));
 }
 
 extern "C" int pqn_cnn_rollout_seeds(int env_id, const pqn_cnn_layout_t *layout, int32_t num_seeds, int32_t envs_per_seed,
@@ -3133,7 +3130,7 @@ extern "C" int pqn_cnn_rollout_seeds(int env_id, const pqn_cnn_layout_t *layout,
   PQN_REQUIRE(r.obs == nullptr && r.obs_bits == nullptr, "pqn_cnn_rollout_seeds: rec->obs / rec->obs_bits must be NULL");
   return pqn_qnet_cnn_rollout(env_id, *layout, num_seeds * envs_per_seed, num_steps, state, obs_bits, theta, r, action, qmax,
                               last_q, eps_dev, keys_dev, rew_scale, store_obs != 0, (hipStream_t)stream, envs_per_seed,
-                              theta_stride, keys_stride);
+                              theta_stride, keys_stride, pqn_opt(PQN_OPT_PIN_FORM));
 }
 
 // ---------------------------------------------------------------------------
@@ -3253,11 +3250,10 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     pqn_note_kernel_form(0, PQN_FORM_KSPLIT);
 #define KS_LAUNCH(PG_)                                                                                                               \
     do {                                                                                                                               \
-      static bool ks_attr = false;                                                                                                     \
-      if (!ks_attr) {                                                                                                                  \
+      static pqn_once_per_device ks_attr;                                                                                                     \
+      if (ks_attr.first()) {                                                                                                                  \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_ks_head_kernel<C, 64 / PG_>),                              \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);                                             \
-        ks_attr = true;                                                                                                                \
       }                                                                                                                                \
       hipLaunchKernelGGL((qnet_cnn_ks_fwd_kernel<C, PG_>), dim3(64 / PG_, ntiles, sd.nseeds), dim3(KS_THREADS), 0, st, nb, idx, bits,  \
                          theta, L, zpart, sd);                                                                                         \
@@ -3267,11 +3263,10 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
                          theta, w1b, L, dzbuf, gpart, wpart, sd);                                                                      \
     } while (0)
     if (ks_hb) {
-      static bool hb_attr = false;
-      if (!hb_attr) {
+      static pqn_once_per_device hb_attr;
+      if (hb_attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_ks_hb_kernel<C, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem1);
-        hb_attr = true;
       }
       // the forward partials use 16 groups per tile: zpart needs ntiles * 16 tiles of [16][128], which is what the carve-up
       // reserves at the finest cut (dzbuf / gpart / wpart were placed for ks_ng = 8: move them behind the 16-group zpart)
@@ -3290,15 +3285,14 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
                        rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b_ks, sd, (const float *)nullptr, 0);
     return pqn_check_launch("pqn_qnet_cnn_grad");
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static pqn_once_per_device attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_kernel<C, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
-    attr_set = true;
   }
   const float inv_b = 1.0f / (float)nb;
   const int ablate = pqn_opt(PQN_OPT_ABLATE_TRAIN);  // profiling only
@@ -3339,7 +3333,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       return pqn_check_launch("pqn_qnet_cnn_grad");
     }
   }
-  if (!g_t1_stamps && getenv("PQN_T1_STAMPS")) {
+  if (!g_t1_stamps && getenv("PQN_T1_STAMPS") && pqn_not_capturing(st)) {   // (profiling only; an allocation is illegal under stream capture)
     if (hipMalloc(&g_t1_stamps, 64 * sizeof(unsigned long long)) != hipSuccess) g_t1_stamps = nullptr;
   }
   // matmul_f16: dz (O(1/nb)) is scaled by a power of two into fp16's normal range; products are scaled back in f32
@@ -3357,11 +3351,10 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   const bool use_pair = pair_env && L.matmul_f16 == 2 && pair_bytes <= 160 * 1024 && ntiles >= 2 && (ntiles % 2) == 0 &&
                         ((ntiles / 2) * sd.nseeds >= 256 || pair_env == 2);   // PQN_T1_PAIR=2: pair form at any size (tests)
   if (use_pair) {
-    static bool pair_attr = false;
-    if (!pair_attr) {
+    static pqn_once_per_device pair_attr;
+    if (pair_attr.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_cnn_train_pair_kernel<C>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      pair_attr = true;
     }
   }
   pqn_note_kernel_form(0, use_pair ? PQN_FORM_PAIR : PQN_FORM_SINGLE);
@@ -3392,13 +3385,12 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
       hipLaunchKernelGGL(qnet_fc1_wgrad_f16_kernel, dim3(16, nks, gs), dim3(QN_THREADS), 0, st, nb, h1T + wo, dzT + wo, wpart + wo,
                          sd.ws_stride, 1.0f / dz_scale);
     else if (L.matmul_f16 == 2) {
-      static bool x3_attr = false;
-      if (!x3_attr) {
+      static pqn_once_per_device x3_attr;
+      if (x3_attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, QY_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qnet_fc1_wgrad_x3_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, QY_LDS_ACC);
-        x3_attr = true;
       }
       if (!g_t2_stamps && getenv("PQN_T1_STAMPS")) {
         if (hipMalloc(&g_t2_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_t2_stamps = nullptr;

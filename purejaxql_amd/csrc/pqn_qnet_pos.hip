@@ -1242,13 +1242,12 @@ template <int C, int NA>
 static int pos_forward_launch(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
                               const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
   using F = PosFwdCfg<C>;
-  static bool attr = false;
-  if (!attr) {
+  static pqn_once_per_device attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_fwd_kernel<C, NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)F::lds_bytes(NA));
-    attr = true;
   }
-  if (!g_pos_stamps && getenv("PQN_T1_STAMPS")) {
+  if (!g_pos_stamps && getenv("PQN_T1_STAMPS") && pqn_not_capturing(st)) {   // (profiling only; an allocation is illegal under stream capture)
     if (hipMalloc(&g_pos_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_pos_stamps = nullptr;
   }
   hipLaunchKernelGGL((cnn_pos_fwd_kernel<C, NA>), dim3((nb / 256) * nseeds), dim3(POS_THREADS), F::lds_bytes(NA), st, nb, theta, L, inv_b,
@@ -1289,13 +1288,12 @@ template <int C>
 static int pos_backward_launch(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out,
                                const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
   using P = PosCfg<C>;
-  static bool attr = false;
-  if (!attr) {
+  static pqn_once_per_device attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)P::lds_bytes());
-    attr = true;
   }
-  if (!g_pos_stamps && getenv("PQN_T1_STAMPS")) {
+  if (!g_pos_stamps && getenv("PQN_T1_STAMPS") && pqn_not_capturing(st)) {   // (profiling only; an allocation is illegal under stream capture)
     if (hipMalloc(&g_pos_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_pos_stamps = nullptr;
   }
   hipLaunchKernelGGL((cnn_pos_bwd_kernel<C>), dim3(8 * nch * nseeds), dim3(POS_THREADS), P::lds_bytes(), st, nb, nch, theta, L, wsx, w1out,
@@ -1319,11 +1317,10 @@ static int pos_rollout_launch(const pqn_cnn_layout_t &L, int n, int t_len, uint3
                               const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed,
                               long long theta_stride, int keys_stride) {
   using R = PosRollCfg<C, NA>;
-  static bool attr = false;
-  if (!attr) {
+  static pqn_once_per_device attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_rollout_kernel<C, Env, NA>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::lds_bytes);
-    attr = true;
   }
   hipLaunchKernelGGL((cnn_pos_rollout_kernel<C, Env, NA>), dim3(n / 256), dim3(POS_THREADS), R::lds_bytes, st, n, t_len, state, bits, theta,
                      L, action, qmax, rec.reward, rec.done, rec.discount, rec.returned_episode_returns,

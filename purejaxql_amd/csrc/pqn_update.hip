@@ -346,7 +346,7 @@ extern "C" int pqn_cnn_update_seeds(const pqn_update_args_t *a, int32_t num_seed
 // kernels, same launch shapes per group, only their order in time changes).
 // ---------------------------------------------------------------------------------------------------------
 #define PQN_MAX_SEED_GROUPS 8
-#define PQN_MAX_DEVICES 16
+
 // dependency markers, one set per DEVICE (an event belongs to the device that was current when it was created; a process
 // that drives several GPUs gets a set for each)
 struct SeedGroupEvents {

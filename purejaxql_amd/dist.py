@@ -55,6 +55,12 @@ def partition_seeds(num_seeds: int, world_size: int, rank: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
+def _fault(kind: str, rank: int) -> bool:
+    """Fault injection for the peer path's setup (tests only): PQN_PEER_FAULT="open:1" / "selftest:0"."""
+    spec = os.environ.get("PQN_PEER_FAULT", "")
+    return spec == f"{kind}:{rank}"
+
+
 class PeersStruct(C.Structure):
     """pqn_peers_t (include/pqn_hotpath.h)"""
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("n", C.c_int64), ("region", C.c_void_p * 8),
@@ -94,7 +100,10 @@ class PeerAllReduce:
                     continue
                 ptr = C.c_void_p(0)
                 buf = (C.c_uint8 * 64).from_buffer_copy(h)
-                if pid == os.getpid() or lib.pqn_peer_open(C.addressof(buf), C.addressof(ptr)) != 0:
+                # PQN_PEER_FAULT="open:<rank>" (tests): this rank behaves as if hipIpcOpenMemHandle had failed -- what a node without
+                # cross-device IPC visibility would do at the driver's first 8-GPU run
+                if (pid == os.getpid() or _fault("open", self.rank)
+                        or lib.pqn_peer_open(C.addressof(buf), C.addressof(ptr)) != 0):
                     ok = False
                     break
                 self._opened.append(ptr.value)
@@ -147,6 +156,8 @@ class PeerAllReduce:
             ok = False
         finally:
             _lib.set_option("peer_timeout_s", old)
+        if _fault("selftest", self.rank):     # PQN_PEER_FAULT="selftest:<rank>" (tests): this rank's self-test verdict is "failed"
+            ok = False
         verdicts = [None] * self.world
         dist.all_gather_object(verdicts, bool(ok), group=self.group)
         return all(verdicts)

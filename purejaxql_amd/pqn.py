@@ -119,9 +119,47 @@ class _TestRows:
         return out
 
 
+def _streamed(stream, fn, join: bool):
+    """Runs fn with `stream` as PyTorch's current stream: the stream first waits for the caller's current stream (inputs prepared
+    there), and with join=True the caller's stream waits for `stream` afterwards (results are then ordered for the caller).
+    Attributes set on fn (update.driver) are kept."""
+    if stream is None:
+        return fn
+
+    def wrapped(*args, **kwargs):
+        cur = torch.cuda.current_stream(stream.device)
+        if cur == stream:
+            return fn(*args, **kwargs)
+        stream.wait_stream(cur)
+        with torch.cuda.stream(stream):
+            out = fn(*args, **kwargs)
+        if join:
+            cur.wait_stream(stream)
+        return out
+
+    wrapped.__dict__.update(fn.__dict__)
+    wrapped.__doc__ = fn.__doc__
+    return wrapped
+
+
+def _streamed_factory(stream, factory):
+    """A runner factory (make_runner / make_batch_runner) whose construction, update() and finish() all run on `stream`."""
+    if stream is None:
+        return factory
+
+    def build(*args, **kwargs):
+        update, finish = _streamed(stream, factory, join=True)(*args, **kwargs)
+        return _streamed(stream, update, join=False), _streamed(stream, finish, join=True)
+
+    build.__doc__ = factory.__doc__
+    return build
+
+
 def _sync_behind_graph(drv) -> None:
-    """Host-side wait for the stream before eager work is enqueued behind a replayed update graph (see _TestRows)."""
-    if drv is not None and getattr(drv, "graph", None) is not None:
+    """Host-side wait for the stream before eager work is enqueued behind a replayed update graph -- only when the run sits on the
+    legacy NULL stream (config _WORK_STREAM=False): that is the one combination that faults (see make_train); on the run's own
+    stream nothing waits."""
+    if drv is not None and getattr(drv, "graph", None) is not None and torch.cuda.current_stream().cuda_stream == 0:
         torch.cuda.current_stream().synchronize()
 
 
@@ -378,6 +416,17 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
     dev = torch.device(device or "cuda")
     if dev.type != "cuda":
         raise RuntimeError("purejaxql_amd runs on the GPU only (no CPU fallback); got device=%s" % dev)
+    # Everything a run enqueues goes to ONE created stream, never to the legacy NULL stream (PyTorch's default current stream).
+    # Round 6 root cause of the round-5 fault (16 seeds x 4096 envs with evaluations died after ~16 updates): the HIP runtime
+    # bundled in the PyTorch wheel (ROCm 7.0.51831 in torch/lib, the one a Python process loads) faults after ~25 replays of a
+    # long hipGraph launched on the NULL stream when eager launches are queued behind the replay; on a created stream, or
+    # with /opt/rocm's 7.2 runtime, the same program is clean (tools/repro/update_replay.cpp, profiles/r06_v2_null_stream_fault.txt).
+    # config _WORK_STREAM=False keeps the caller's current stream (the regression test's negative control).
+    work_stream = torch.cuda.Stream(dev) if config.get("_WORK_STREAM", True) else None
+    if config.get("SEED_BATCH_BIT_IDENTICAL", False):
+        # the evaluation rollouts (pqn_cnn_rollout / pqn_cnn_rollout_seeds) follow the same rule as the update's kernels: form from
+        # the per-seed shape alone (library option, process-wide; the update itself carries the flag in pqn_update_args_t.reserved)
+        _lib.set_option("pin_form", 1)
 
     env, env_params = make(config["ENV_NAME"], device=dev, **(config.get("ENV_KWARGS") or {}))
     kind = "cnn" if (len(env.obs_shape) == 3 and not craftax) else "mlp"
@@ -524,7 +573,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                 sums[kk] += (info[kk].to(torch.float64) * dm).sum()
         return {kk: (sums[kk] / cnt).to(torch.float32) for kk in INFO_KEYS}
 
-    def make_runner(rng: int):
+    def _make_runner(rng: int):
         """Builds the per-seed training state and returns (update, finish): update(u) runs ONE
         PQN update (rollout + targets + epochs); finish() returns train()'s result dict."""
         K = int(rng) & 0xFFFFFFFFFFFFFFFF
@@ -834,6 +883,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             g = 1
         return g
 
+    make_runner = _streamed_factory(work_stream, _make_runner)
+
     def make_grouped_runner(rngs: List[int], G: int):
         """make_batch_runner over G seed groups advanced together (pqn_cnn_update_seed_groups): group g holds the seeds
         rngs[g*S/G : (g+1)*S/G] in its own stacked buffers; update / finish behave as make_batch_runner's."""
@@ -861,7 +912,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         update.driver = gd
         return update, finish
 
-    def make_batch_runner(rngs: List[int], groups: Optional[int] = None):
+    def _make_batch_runner(rngs: List[int], groups: Optional[int] = None):
         """jax.vmap(train)(rngs) inside the launches: all seeds advance in the same kernels (grid.y = seed,
         pqn_cnn_update_seeds), one hipGraph replay per update for all of them.  Same key schedule, same
         kernels and summation orders as make_runner, so every seed's result is bit-identical to its solo run (one exception:
@@ -1014,6 +1065,8 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
         update.driver = drv
         return update, finish
 
+    make_batch_runner = _streamed_factory(work_stream, _make_batch_runner)
+
     def train(rng: int) -> Dict[str, Any]:
         update, finish = make_runner(rng)
         for u in range(NUM_UPDATES):
@@ -1026,6 +1079,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
                                  and config.get("_DRIVER", True) and config.get("_CALLBACK") is None)
     train.config = config
     train.backend = backend
+    train.stream = work_stream
     return train
 
 

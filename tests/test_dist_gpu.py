@@ -30,9 +30,10 @@ def _cfg(num_envs_global, n_upd):
     return cfg
 
 
-def _rank_main(rank, world, port, q, num_envs_global, n_upd, theta0, use_driver, peer):
+def _rank_main(rank, world, port, q, num_envs_global, n_upd, theta0, use_driver, peer, fault=""):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(rank), PQN_DIST_BACKEND="gloo", PQN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      PQN_PEER_FAULT=fault)
     import torch.distributed as dist
     torch.set_num_threads(2)      # the ranks share the host: one thread per core EACH (the default) thrashes
     from purejaxql_amd import dist as pdist
@@ -100,6 +101,34 @@ def test_two_rank_env_sharded_training_matches_oracle_with_averaged_gradients(gp
     d = np.abs(th0 - oout["theta"])
     bad = d > (2e-5 + 2e-3 * np.abs(oout["theta"]))
     assert bad.mean() < 1e-3 and d.max() < 5e-4, (int(bad.sum()), float(d.max()))
+
+
+@pytest.mark.parametrize("fault", ["open:1", "selftest:0"])
+def test_peer_path_setup_failure_on_one_rank_falls_back_to_the_host_collective_on_all(gpu, fault):
+    """First-contact readiness for an 8-GPU node: when ONE rank cannot map a peer region (as if
+    hipIpcOpenMemHandle failed across devices) or fails the path's self-test, EVERY rank must land on the torch.distributed
+    collective -- no hang, no rank left on the peer kernels -- and the ranks' parameters stay identical.  2 ranks x 32 envs, 3
+    updates, phase-split driver (9 segment graphs: the host collective sits between them)."""
+    from purejaxql_amd.networks import QNetwork
+    world, n_glob, n_upd = 2, 64, 3
+    theta0 = QNetwork("cnn", (10, 10, 4), 3, device=gpu).init(17).cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, n_glob, n_upd, theta0, True, True, fault)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, th0, m0, drv0, (gerr0, mode0, ng0)), (_, th1, m1, drv1, (gerr1, mode1, ng1)) = res
+    assert mode0.startswith("host") and mode1.startswith("host") and "self-test" in mode0, (mode0, mode1)
+    assert drv0 == drv1 == "graph" and ng0 == ng1 == 9, (gerr0, gerr1, ng0, ng1)
+    assert np.isfinite(th0).all()
+    np.testing.assert_array_equal(th0, th1)
+    for k in m0:
+        np.testing.assert_array_equal(m0[k], m1[k], err_msg=k)
 
 
 def _recapture_main(rank, world, port, q, theta0, peer):
@@ -338,6 +367,7 @@ def test_bench_gpus_n_launches_its_own_ranks(gpu, gpus, mode):
     assert d["n_gpus"] == gpus and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
     c = d["config"]
     assert c["dist_backend"] == "gloo" and c["rccl_ranks"] == 0 and c["gpus_visible"] == 1
+    assert len(c["per_rank_ms_per_step"]) == gpus and abs(max(c["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-6 and 0 <= c["per_rank_spread"] < 1
     if mode == "seeds":
         assert d["scaling"] == "weak" and c["seeds_total"] == 4 and c["env_steps_per_step"] == 4 * 4096 * 32
         assert abs(d["value"] - c["env_steps_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

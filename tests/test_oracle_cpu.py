@@ -531,3 +531,39 @@ def test_third_party_rule_known_answers_timers_waves_thresholds(oracle):
     np.testing.assert_array_equal(st2["sf"][:, 0], st["sf"][:, 0])
     np.testing.assert_array_equal(st2["sf"][:, 2], st["sf"][:, 2])
     assert (st2["sf"][[0, 1], 1] > 0).all()
+
+
+def test_float64_learn_phase_twin_tracks_the_f32_oracle(oracle):
+    """oracle/pqn_oracle_f64.py (the float64 learn phase the headline tests measure both sides against) on the f32 oracle's own
+    rollout record of one small update: gradient of the first minibatch to f32 rounding, parameters after the whole update within
+    a few lr of the f32 oracle's (RAdam turns rounding-level gradient differences of near-zero elements into lr-sized steps), the
+    update vectors aligned.  purejaxql/pqn_minatar.py:263-327."""
+    import pqn_oracle_f64 as o64
+    cfg = {"ENV_NAME": "Breakout-MinAtar", "NUM_ENVS": 64, "NUM_STEPS": 16, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2, "TOTAL_TIMESTEPS": 64 * 16,
+           "TOTAL_TIMESTEPS_DECAY": 64 * 16 * 10, "EPS_START": 1.0, "EPS_FINISH": 0.05, "EPS_DECAY": 0.1, "GAMMA": 0.99, "LAMBDA": 0.65,
+           "LR": 5e-4, "LR_LINEAR_DECAY": True, "MAX_GRAD_NORM": 10.0, "NORM_TYPE": "layer_norm", "NORM_INPUT": False, "REW_SCALE": 1.0,
+           "TEST_DURING_TRAINING": False}
+    train = oracle.make_train(cfg)
+    shapes = train.shapes
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    rng = np.random.default_rng(3)
+    theta0 = (rng.standard_normal(n) * 0.05).astype(np.float32)
+    p0 = oracle.unflatten(theta0, shapes)
+    for k in p0:
+        if k.endswith("/scale"):
+            p0[k][...] = 1.0
+    key = 0x1234567
+    out = train(key, theta0)
+    sh = out["shards"][0]
+    k_shuf = oracle.fold_in(key & 0xFFFFFFFFFFFFFFFF, 4)
+    # one gradient, same inputs
+    idx = oracle.permutation(oracle.fold_in(k_shuf, 0), 64 * 16)[:256]
+    _l32, _c32, g32 = oracle.net_loss_grad("cnn", p0, shapes, sh["of"][idx], sh["af"][idx], sh["tf"][idx])
+    p64 = oracle.unflatten(theta0.astype(np.float64), shapes)
+    _l64, _c64, g64 = o64.cnn_loss_grad(p64, shapes, sh["of"][idx], sh["af"][idx], sh["tf"][idx])
+    assert np.isfinite(g32).all() and np.isfinite(g64).all()
+    assert np.abs(g32 - g64).max() <= 2e-6 * np.abs(g64).max()
+    th64, _m, _v = o64.learn_phase(cfg, shapes, theta0, sh["of"], sh["af"], sh["tf"], k_shuf)
+    upd32, upd64 = out["theta"].astype(np.float64) - theta0, th64 - theta0
+    cos = float(np.dot(upd32, upd64) / (np.linalg.norm(upd32) * np.linalg.norm(upd64)))
+    assert cos > 0.999 and np.abs(out["theta"] - th64).max() < 4 * cfg["LR"], (cos, float(np.abs(out["theta"] - th64).max()))
