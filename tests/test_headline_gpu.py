@@ -279,7 +279,13 @@ def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked):
             rel_hip = float(np.linalg.norm(upd - u64) / np.linalg.norm(u64))
             rel_np = float(np.linalg.norm(oupd - u64) / np.linalg.norm(u64))
             print(f"\nupdate vector vs the float64 learn phase: HIP rel-L2 {rel_hip:.3e}, numpy-f32 oracle rel-L2 {rel_np:.3e}, HIP vs numpy-f32 {rel:.3e}")
-            assert np.isfinite(th64).all() and rel_hip < 6e-2 and rel_hip <= 1.5 * rel_np + 1e-3, (rel_hip, rel_np, rel)
+            # measured (round 6, profiles/r06_v4_f64_learn_phase.txt): HIP 2.1e-4, numpy-f32 oracle 3.9e-2 -- the numpy oracle is the
+            # outlier (its f32 matmuls sum 4096-sample columns in one f32 chain), not the kernels.  Against the float64 reference the
+            # criterion is 30x tighter than the 6e-2 the f32-vs-f32 comparison above has to allow.
+            cos64 = float(np.dot(upd, u64) / (np.linalg.norm(upd) * np.linalg.norm(u64)))
+            d64 = np.abs(th - th64)
+            assert np.isfinite(th64).all() and rel_hip < 2e-3 and cos64 > 0.999995 and rel_hip < rel_np, (rel_hip, rel_np, rel, cos64)
+            assert (d64 > 2e-5 + 2e-3 * np.abs(th64)).mean() < 1e-4 and d64.max() < cfg["LR"], (float(d64.max()),)
 
 
 @pytest.mark.parametrize("nb,seeds", [(4096, 16), (512, 2), (272, 3), (16, 1)])

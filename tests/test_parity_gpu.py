@@ -349,7 +349,8 @@ def test_product_network_vs_oracle_network(gpu, oracle):
     ("pqn_minatar", "Freeway-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
                                         "MATMUL_DTYPE": "bf16x3"}),
     # the headline shape itself (BASELINE.json metric; bench.py's workload): one whole update, fused + hipGraph
-    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 4096, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 4096, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),   # MATMUL_DTYPE auto -> bf16x3
+    ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 4096, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2, "MATMUL_DTYPE": "f32"}),
     ("pqn_minatar", "Asterix-MinAtar", {"NUM_ENVS": 4096, "NUM_STEPS": 32, "NUM_MINIBATCHES": 32, "NUM_EPOCHS": 2}),
     ("pqn_minatar", "Asterix-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
     ("pqn_minatar", "Freeway-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2}),
@@ -424,6 +425,15 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
         cos = float(np.dot(upd, oupd) / (np.linalg.norm(upd) * np.linalg.norm(oupd)))
         rel = float(np.linalg.norm(upd - oupd) / np.linalg.norm(oupd))
         assert cos > 0.998 and rel < 6e-2 and bad.mean() < 1e-2 and d.max() < 4 * cfg["LR"], (cos, rel, float(bad.mean()), float(d.max()))
+        if kind == "cnn" and cfg["NORM_TYPE"] == "layer_norm" and not cfg.get("NORM_INPUT", False) and n_upd == 1:
+            # round 6: the numpy-f32 oracle is the outlier of that comparison (profiles/r06_v4_f64_learn_phase.txt); against the float64
+            # learn phase on the oracle's own rollout record the kernels are held 30x tighter
+            import pqn_oracle_f64 as o64
+            sh = oout["shards"][0]
+            th64, _m, _v = o64.learn_phase(ocfg, otrain.shapes, th0, sh["of"], sh["af"], sh["tf"], oracle.fold_in(int(key) & 0xFFFFFFFFFFFFFFFF, 4))
+            u64 = th64 - th0
+            rel64, rel_np = float(np.linalg.norm(upd - u64) / np.linalg.norm(u64)), float(np.linalg.norm(oupd - u64) / np.linalg.norm(u64))
+            assert np.isfinite(th64).all() and rel64 < 2e-3 and rel64 < rel_np, (rel64, rel_np, rel)
 
 
 @pytest.mark.parametrize("alg,env_name,norm_type,norm_input", [
