@@ -284,6 +284,13 @@ typedef struct {
 } pqn_update_args_t;
 
 int64_t pqn_update_sort_temp_bytes(int32_t n);
+/* Workspace floats (per seed) of a whole update: pqn_qnet_cnn_workspace_floats(layout, T*N/num_minibatches) plus, in the bf16x3
+ * mode at minibatch sizes the position-parallel kernels take, the EPOCH region -- the gathered rows / bit-transposes / actions /
+ * targets of all num_minibatches minibatches of an epoch, written by one launch per epoch instead of one per optimizer step
+ * (the shuffled batch of pqn_minatar.py:299-315 cut into its minibatches, :316-320).  A caller whose workspace (stride) is only
+ * pqn_qnet_cnn_workspace_floats keeps the per-minibatch gather: same results, 64 small launches more per update. */
+int64_t pqn_cnn_update_workspace_floats(const pqn_cnn_layout_t *layout /* host */, int32_t num_envs, int32_t num_steps,
+                                        int32_t num_minibatches);
 int pqn_cnn_update(const pqn_update_args_t *args /* host */, void *stream);
 
 /* The same update enqueued one PHASE at a time, so that the caller can put a collective between the gradient

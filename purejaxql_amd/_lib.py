@@ -65,6 +65,7 @@ SIGNATURES = {
     "pqn_prof_enable": (c_int, [c_int32]),
     "pqn_prof_read": (c_int, [c_void_p, c_void_p]),
     "pqn_update_sort_temp_bytes": (c_int64, [c_int32]),
+    "pqn_cnn_update_workspace_floats": (c_int64, [c_void_p, c_int32, c_int32, c_int32]),
     "pqn_cnn_update": (c_int, [c_void_p, c_void_p]),
     "pqn_cnn_update_phase": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "pqn_mlp_update": (c_int, [c_void_p, c_void_p]),

@@ -224,7 +224,13 @@ int pqn_cnn_grad_reduce_blocks(int total);   // number of sum-of-squares partial
 int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out,
-                            const pqn_seeds_t &sd, hipStream_t st, bool with_reduce = true, int part = 0);
+                            const pqn_seeds_t &sd, hipStream_t st, bool with_reduce = true, int part = 0, int epoch_mb = -1,
+                            int epoch_nmb = 0);
+// the position-parallel form's gather once per epoch (pqn_qnet.hip); _applies: pure predicate of shape, options and workspace stride
+bool pqn_qnet_cnn_epoch_applies(const pqn_cnn_layout_t &L, int nb, int nmb, const pqn_seeds_t &sd);
+int pqn_qnet_cnn_epoch_gather(const pqn_cnn_layout_t &L, int nb, int nmb, const int64_t *idx_epoch, const uint32_t *obs_bits,
+                              const int32_t *action, const float *target, float *workspace, const pqn_seeds_t &sd, hipStream_t st);
+long long pqn_qnet_cnn_epoch_floats(const pqn_cnn_layout_t &L, int nb, int nmb);
 // part: 0 = whole gradient, 1 = the training kernel(s) only, 2 = fc1 weight gradient + fold of the partials only
 int pqn_qnet_cnn_forward_dyn(const pqn_cnn_layout_t &L, int n, const uint32_t *obs_bits, const float *theta, float *q,
                              int32_t *action, float *qmax, float eps, uint64_t key, const float *eps_dev,

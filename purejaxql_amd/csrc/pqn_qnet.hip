@@ -3211,7 +3211,9 @@ template <int C>
 static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits,
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                         const int32_t *count, float *ws, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
-                        hipStream_t st, bool with_reduce, int part) {
+                        hipStream_t st, bool with_reduce, int part, int epoch_mb = -1, int epoch_nmb = 0) {
+  // epoch_mb >= 0 (round 6): the rows / actions / targets of ALL epoch_nmb minibatches of this epoch were gathered once, by
+  // pqn_qnet_cnn_epoch_gather, into the epoch region behind the workspace; this is minibatch epoch_mb of them
   // part: 0 = the whole gradient; 1 = the compute-bound training kernel(s) only; 2 = the HBM-bound rest (fc1 weight
   // gradient + fold of the partials) only -- pqn_cnn_update_seed_groups runs the two parts of a seed group on different
   // streams so that one group's tail overlaps the other group's training kernel
@@ -3318,12 +3320,23 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
         const bool prof = g_prof.on && g_prof.n < PQN_PROF_MAX;
         const bool t_all = prof && g_prof.mode == 4, t_fwd = prof && g_prof.mode == 3, t_bwd = prof && g_prof.mode == 1;
         if (t_all) (void)hipEventRecord(g_prof.s[g_prof.n], st);
-        int rc = pqn_cnn_pos_gather(L, nb, idx, bits, action, target, h1T, PW, sd, sd.nseeds, st);
+        int rc = PQN_OK;
+        pos_ws_t PM = PW;        // the minibatch's view: its gathered rows either in the form's own region or inside the epoch region
+        if (epoch_mb >= 0) {
+          const pos_epoch_t E = pos_epoch_layout(nb, epoch_nmb, C);
+          const long long e0 = pqn_qnet_cnn_workspace_floats(&L, nb) - (long long)(h1T - ws);   // epoch region, relative to h1T
+          PM.mb_bits = e0 + E.bits + (long long)epoch_mb * nb * CnnCfg<C>::OW;
+          PM.t32 = e0 + E.t32 + (long long)epoch_mb * (nb / 32) * pos_t32_words(C);
+          PM.act = e0 + E.act + (long long)epoch_mb * nb;
+          PM.tgt = e0 + E.tgt + (long long)epoch_mb * nb;
+        } else {
+          rc = pqn_cnn_pos_gather(L, nb, idx, bits, action, target, h1T, PW, sd, sd.nseeds, st);
+        }
         if (t_fwd) (void)hipEventRecord(g_prof.s[g_prof.n], st);
-        if (rc == PQN_OK) rc = pqn_cnn_pos_forward(L, nb, theta, inv_b, h1T, PW, sd, sd.nseeds, st);
+        if (rc == PQN_OK) rc = pqn_cnn_pos_forward(L, nb, theta, inv_b, h1T, PM, sd, sd.nseeds, st);
         if (t_fwd) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
         if (t_bwd) (void)hipEventRecord(g_prof.s[g_prof.n], st);
-        if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, nch, theta, h1T, wpart, PW, sd, sd.nseeds, st);
+        if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, nch, theta, h1T, wpart, PM, sd, sd.nseeds, st);
         if (t_bwd || t_all) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
         if (rc != PQN_OK) return rc;
       }
@@ -3475,17 +3488,57 @@ extern "C" int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t *L, int32_t num_se
 int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
-                            hipStream_t st, bool with_reduce, int part) {
+                            hipStream_t st, bool with_reduce, int part, int epoch_mb, int epoch_nmb) {
   switch (L.c) {
-    case 4: return launch_train<4>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
-    case 6: return launch_train<6>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
-    case 7: return launch_train<7>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
+    case 4: return launch_train<4>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb);
+    case 6: return launch_train<6>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb);
+    case 7: return launch_train<7>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb);
     case 10: return launch_train<10>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
     default: pqn_set_error("pqn_qnet_cnn_grad: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
   }
 }
 
 int pqn_cnn_grad_reduce_blocks(int total) { return grad_reduce_blocks(total); }
+
+// ---- the minibatch gather of the position-parallel form, once per EPOCH (round 6) ----
+// pos_gather_kernel ran in front of every optimizer step (64 launches of ~9 us per update at the headline shape).  The rows of a whole
+// epoch are the shuffled batch cut into num_minibatches slices, so ONE launch over all T*N samples of the epoch produces every
+// minibatch's rows / bit-transposes / actions / targets; launch_train then points the forward / backward kernels at slice `mb` of
+// the epoch region (same bytes at other addresses: results are bit-identical).  The region sits behind the per-minibatch workspace
+// (pqn_qnet_cnn_workspace_floats); pqn_cnn_update_workspace_floats() sizes both.  Callers whose workspace stride is smaller keep
+// the per-minibatch gather.
+static bool pos_form_taken(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd) {
+  const int pos_opt = pqn_opt(PQN_OPT_BWD_POS);
+  const bool pos_shape = L.matmul_f16 == 2 && nb % 256 == 0 && pos_shape_ok(nb) && pqn_cnn_pos_forward_supported(L.c, L.a) && L.c != 10;
+  return pos_shape && (pos_opt == 2 || (pos_opt == 1 && (sd.pin_form ? nb >= 2048 : (nb / 256) * sd.nseeds >= 160)));
+}
+long long pqn_qnet_cnn_epoch_floats(const pqn_cnn_layout_t &L, int nb, int nmb) {
+  if (L.matmul_f16 != 2 || nb % 256 != 0 || !pos_shape_ok(nb) || !pqn_cnn_pos_forward_supported(L.c, L.a) || L.c == 10) return 0;
+  return pos_epoch_layout(nb, nmb, L.c).end;
+}
+// true when the update of this shape gathers per epoch: the launch takes the position-parallel form and the caller's workspace stride
+// has room for the epoch region (a pure function of its arguments and the options: pqn_cnn_update_phase callers decide the same
+// way in their SHUFFLE and GRAD phases)
+bool pqn_qnet_cnn_epoch_applies(const pqn_cnn_layout_t &L, int nb, int nmb, const pqn_seeds_t &sd) {
+  if (!pos_form_taken(L, nb, sd) || (long long)nmb * nb > (1ll << 25)) return false;
+  return sd.ws_stride >= pqn_qnet_cnn_workspace_floats(&L, nb) + pqn_qnet_cnn_epoch_floats(L, nb, nmb);
+}
+int pqn_qnet_cnn_epoch_gather(const pqn_cnn_layout_t &L, int nb, int nmb, const int64_t *idx_epoch, const uint32_t *obs_bits,
+                              const int32_t *action, const float *target, float *workspace, const pqn_seeds_t &sd, hipStream_t st) {
+  PQN_REQUIRE(pqn_qnet_cnn_epoch_applies(L, nb, nmb, sd), "pqn_qnet_cnn_epoch_gather: not applicable to this launch");
+  float *h1T = workspace + 1024 + (size_t)QN_HID * qw_ld(nb);
+  const pos_epoch_t E = pos_epoch_layout(nb, nmb, L.c);
+  const long long e0 = pqn_qnet_cnn_workspace_floats(&L, nb) - (long long)(h1T - workspace);
+  pos_ws_t W = pos_ws_layout(nb, L.c, L.a);
+  W.mb_bits = e0 + E.bits; W.t32 = e0 + E.t32; W.act = e0 + E.act; W.tgt = e0 + E.tgt;
+  return pqn_cnn_pos_gather(L, nmb * nb, idx_epoch, obs_bits, action, target, h1T, W, sd, sd.nseeds, st);
+}
+extern "C" int64_t pqn_cnn_update_workspace_floats(const pqn_cnn_layout_t *L, int32_t num_envs, int32_t num_steps, int32_t num_minibatches) {
+  if (!L || num_envs <= 0 || num_steps <= 0 || num_minibatches <= 0 || ((int64_t)num_envs * num_steps) % num_minibatches) return -1;
+  const int nb = (int)((int64_t)num_envs * num_steps / num_minibatches);
+  const int64_t base = pqn_qnet_cnn_workspace_floats(L, nb);
+  return base < 0 ? base : base + pqn_qnet_cnn_epoch_floats(*L, nb, num_minibatches);
+}
 
 extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float *w1b, const float *grad, float *m,
                                   float *v, int32_t *count, float lr_init, float lr_end, double lr_steps,

@@ -37,6 +37,23 @@ inline pos_ws_t pos_ws_layout(int nb, int c, int a) {
   return w;
 }
 
+// the epoch region (round 6): the gather outputs of ALL minibatches of an epoch, each array [num_minibatches][per minibatch] so that
+// minibatch mb's slice is contiguous (float offsets from the region's start, multiples of 4)
+struct pos_epoch_t {
+  long long bits, t32, act, tgt, end;
+};
+inline pos_epoch_t pos_epoch_layout(int nb, int nmb, int c) {
+  auto al = [](long long x) { return (x + 3) & ~3ll; };
+  const int ow = ((((100 * c + 31) / 32) + 3) / 4) * 4;
+  pos_epoch_t e;
+  e.bits = 0;
+  e.t32 = al(e.bits + (long long)nmb * nb * ow);
+  e.act = al(e.t32 + (long long)nmb * (nb / 32) * pos_t32_words(c));
+  e.tgt = al(e.act + (long long)nmb * nb);
+  e.end = al(e.tgt + (long long)nmb * nb);
+  return e;
+}
+
 // number of sample chunks of the backward (one partial dW1 slab each): a function of the minibatch size alone, so that a
 // seed's summation order does not depend on how many seeds share the launch
 inline int pos_chunks(int nb) { return nb >= 1024 ? 2 : 1; }

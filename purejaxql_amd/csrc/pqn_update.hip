@@ -247,15 +247,20 @@ static int upd_shuffle(const pqn_update_args_t *a, const UpdCtx &c, int ep, hipS
   } else {   // one global sort: the seed id in the top bits keeps every seed's segment in place
     UPD_CHECK(pqn_shuffle_keys_seeds(a->sched_keys + c.T + ep, c.T + c.EP, c.S, c.TN, a->sort_keys_in, st));
   }
-  return pqn_sort_keys(a->sort_temp, tb, a->sort_keys_in, a->sort_keys_out, c.S * c.TN, c.S, c.TN, st);
+  UPD_CHECK(pqn_sort_keys(a->sort_temp, tb, a->sort_keys_in, a->sort_keys_out, c.S * c.TN, c.S, c.TN, st));
+  // position-parallel form: the rows / bit-transposes / actions / targets of all MB minibatches of this epoch in one launch
+  if (pqn_qnet_cnn_epoch_applies(a->layout, c.B, c.MB, c.sd))
+    return pqn_qnet_cnn_epoch_gather(a->layout, c.B, c.MB, a->sort_keys_out, a->bits, a->action, a->target, a->workspace, c.sd, st);
+  return PQN_OK;
 }
 
 static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool with_reduce, hipStream_t st, int part = 0) {
   const int mb = i_mb % c.MB;
   // low bits of a sorted shuffle key = the transition index inside the seed (kernels mask with sd.idx_mask)
+  const bool epoch = with_reduce && pqn_qnet_cnn_epoch_applies(a->layout, c.B, c.MB, c.sd);   // gathered by upd_shuffle
   return pqn_qnet_cnn_grad_seeds_dyn(a->layout, c.B, a->sort_keys_out + (size_t)mb * c.B, a->bits, a->action, a->target, a->theta,
                                  a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, c.sd, st,
-                                 with_reduce, part);
+                                 with_reduce, part, epoch ? mb : -1, c.MB);
 }
 
 static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool norm_pass, hipStream_t st) {

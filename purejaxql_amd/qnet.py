@@ -456,8 +456,10 @@ class SeedsUpdateDriver:
         f32 = torch.float32
         alloc = layout.total if self.mlp else layout.alloc
         self.stride = (alloc + 3) // 4 * 4
-        wsf = lib.pqn_mlp_workspace_floats if self.mlp else lib.pqn_qnet_cnn_workspace_floats
-        ws = int(wsf(C.byref(layout.struct), tn // mb))
+        if self.mlp:
+            ws = int(lib.pqn_mlp_workspace_floats(C.byref(layout.struct), tn // mb))
+        else:   # per-minibatch workspace + the epoch region of the position-parallel form (one gather launch per epoch)
+            ws = int(lib.pqn_cnn_update_workspace_floats(C.byref(layout.struct), n, t, mb))
         if ws < 0:
             raise RuntimeError("workspace size query failed")
         self.ws_stride = (ws + 3) // 4 * 4
