@@ -229,7 +229,8 @@ int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *layout /* host */, float *thet
 /* Kernel timer for bench.py's roofline lines: on = 1, pqn_qnet_cnn_grad brackets its dominant kernel with HIP
  * events on the launch stream (the position-parallel form: cnn_pos_bwd_kernel; the other forms: qnet_cnn_train_kernel);
  * on = 2, every launch of the wide-MLP GEMM kernel (pqn_bigmlp_forward / _grad / _gemm) is bracketed instead;
- * on = 3 / 4 (position-parallel form only): cnn_pos_fwd_kernel / gather + forward + backward together; 0 = off.  pqn_prof_read synchronises on the
+ * on = 3 / 4 (position-parallel form only): cnn_pos_fwd_kernel / (per-minibatch gather +) forward + backward together; on = 5: the
+ * once-per-epoch gather of the position-parallel form (pqn_cnn_update*); 0 = off.  pqn_prof_read synchronises on the
  * events and returns the number of timed launches and their summed duration, then resets.  Not capturable in a
  * hipGraph: time eager enqueues. */
 int pqn_prof_enable(int32_t on);

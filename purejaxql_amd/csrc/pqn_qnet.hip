@@ -3531,7 +3531,10 @@ int pqn_qnet_cnn_epoch_gather(const pqn_cnn_layout_t &L, int nb, int nmb, const 
   const long long e0 = pqn_qnet_cnn_workspace_floats(&L, nb) - (long long)(h1T - workspace);
   pos_ws_t W = pos_ws_layout(nb, L.c, L.a);
   W.mb_bits = e0 + E.bits; W.t32 = e0 + E.t32; W.act = e0 + E.act; W.tgt = e0 + E.tgt;
-  return pqn_cnn_pos_gather(L, nmb * nb, idx_epoch, obs_bits, action, target, h1T, W, sd, sd.nseeds, st);
+  const bool timed = pqn_prof_begin(5, st);   // kernel timer mode 5: the epoch gather
+  const int rc = pqn_cnn_pos_gather(L, nmb * nb, idx_epoch, obs_bits, action, target, h1T, W, sd, sd.nseeds, st);
+  if (timed) pqn_prof_end(st);
+  return rc;
 }
 extern "C" int64_t pqn_cnn_update_workspace_floats(const pqn_cnn_layout_t *L, int32_t num_envs, int32_t num_steps, int32_t num_minibatches) {
   if (!L || num_envs <= 0 || num_steps <= 0 || num_minibatches <= 0 || ((int64_t)num_envs * num_steps) % num_minibatches) return -1;
