@@ -157,11 +157,10 @@ __global__ __launch_bounds__(256) void pos_gather_kernel(int nb, const int64_t *
 typedef __attribute__((address_space(3))) char lds_char_t;
 PQN_D uint32_t pos_lds_addr(const void *p) { return (uint32_t)(uintptr_t)(lds_char_t *)p; }
 PQN_D void pos_dma16(uint32_t voff, const void *sbase, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
+  // round 6: M0 is left holding the LDS destination.  Nothing else in these kernels reads M0 (gfx950 DS instructions do not; there is no
+  // s_movrel / sendmsg / GWS / LDS-DMA builtin in this file: tests/test_host_cpu.py scans the assembly), and the save / restore pair
+  // was two of the four scalar instructions of every transfer
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 PQN_D void pos_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -348,15 +347,20 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
       }
     }
     // ---- conv: rows = samples, columns = channels; the two tiles interleaved ----
-    f32x4 cb_[2] = {zero4, zero4}, cs_[2] = {zero4, zero4};
+    f32x4 cb_[2], cs_[2];       // (round 6) the first product of every chain runs on C = 0: no zeroed register tuples
 #pragma unroll
     for (int sx = 0; sx < ConvX3<C>::NS; ++sx) {
       u32x4 fa[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) fa[t] = pos_expand8<C>(s_lut, __builtin_amdgcn_ubfe(ConvX3<C>::word(mk[t], sx), 8u * kq, 8u));
       const u32x4 wh = s_cvw[(sx * 3 + 0) * 64 + lane], wm = s_cvw[(sx * 3 + 1) * 64 + lane], wl = s_cvw[(sx * 3 + 2) * 64 + lane];
-      x3_grp2(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
-      x3_grp2(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
+      if (sx == 0) {
+        x3_grp2_zero(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
+        x3_grp2_zero(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
+      } else {
+        x3_grp2(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
+        x3_grp2(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
+      }
       x3_grp2(cs_[0], fa[0], wm, cs_[1], fa[1], wm);
     }
     // dgrad operands of both tiles from LDS while the conv drains; ONE register set, each plane re-read for the next K step
@@ -388,12 +392,14 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     }
     POSB_STAMP(2);
     // ---- dgrad: dh1[sample][feature of this position], eight independent accumulators ----
-    f32x4 gb[2] = {zero4, zero4}, gs[2] = {zero4, zero4};   // {leading, small} terms per tile: four independent chains
+    f32x4 gb[2], gs[2];         // {leading, small} terms per tile: four independent chains, each started on C = 0
 #pragma unroll
     for (int sK = 0; sK < 4; ++sK) {
-      x3_grp2(gs[0], az[0][2], wfr[sK][0], gs[1], az[1][2], wfr[sK][0]);
+      if (sK == 0) x3_grp2_zero(gs[0], az[0][2], wfr[sK][0], gs[1], az[1][2], wfr[sK][0]);
+      else x3_grp2(gs[0], az[0][2], wfr[sK][0], gs[1], az[1][2], wfr[sK][0]);
       if (sK + 1 < 4) load_az(sK + 1, 2);
-      x3_grp2(gb[0], az[0][1], wfr[sK][0], gb[1], az[1][1], wfr[sK][0]);
+      if (sK == 0) x3_grp2_zero(gb[0], az[0][1], wfr[sK][0], gb[1], az[1][1], wfr[sK][0]);
+      else x3_grp2(gb[0], az[0][1], wfr[sK][0], gb[1], az[1][1], wfr[sK][0]);
       x3_grp4(gs[0], az[0][0], wfr[sK][2], gs[1], az[1][0], wfr[sK][2], gb[0], az[0][0], wfr[sK][1], gb[1], az[1][0], wfr[sK][1]);
       x3_grp2(gs[0], az[0][1], wfr[sK][1], gs[1], az[1][1], wfr[sK][1]);
       if (sK + 1 < 4) load_az(sK + 1, 1);
@@ -420,13 +426,9 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
       }
       float s1[2][4], s2[2][4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[t][r] = dxh[t][r]; s2[t][r] = dxx[t][r]; }
-#pragma unroll
       for (int t = 0; t < 2; ++t) {
-        group16_sum4(s1[t][0], s1[t][1], s1[t][2], s1[t][3]);
-        group16_sum4(s2[t][0], s2[t][1], s2[t][2], s2[t][3]);
+        group16_sum4_from(s1[t][0], s1[t][1], s1[t][2], s1[t][3], dxh[t][0], dxh[t][1], dxh[t][2], dxh[t][3]);
+        group16_sum4_from(s2[t][0], s2[t][1], s2[t][2], s2[t][3], dxx[t][0], dxx[t][1], dxx[t][2], dxx[t][3]);
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -481,12 +483,9 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
       const uint32_t byte = __builtin_amdgcn_ubfe(wv, 4u * kq, 4u) | (__builtin_amdgcn_ubfe(wv, 16u + 4u * kq, 4u) << 4);
       fa[rb] = pos_expand8<C>(s_lut, byte);
     }
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) cw[rb] = X3_MFMA(fa[rb], fd.l, cw[rb]);
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) cw[rb] = X3_MFMA(fa[rb], fd.m, cw[rb]);
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) cw[rb] = X3_MFMA(fa[rb], fd.h, cw[rb]);
+    x3_grp_sameb<NRB>(cw, fa, fd.l);   // NRB independent chains per plane: one asm group (one pad) each
+    x3_grp_sameb<NRB>(cw, fa, fd.m);
+    x3_grp_sameb<NRB>(cw, fa, fd.h);
     POSB_STAMP(6);
     if (POS_PAIR_SYNC == 0 || (j & 1) != 0) {
       pos_dma_wait();            // this wave's share of the next slot(s) has landed ...

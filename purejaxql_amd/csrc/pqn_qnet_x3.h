@@ -78,6 +78,29 @@ PQN_D void group16_sum4(float &a, float &b, float &c, float &d) {
                "s_nop 1"
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// the same four sums with the FIRST butterfly step out of place (o = a + ror8(a)): the inputs stay intact, no copies (round 6)
+PQN_D void group16_sum4_from(float &o0, float &o1, float &o2, float &o3, const float a, const float b, const float c, const float d) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+               : "v"(a), "v"(b), "v"(c), "v"(d));
+}
 PQN_D float group16_sum(float v) {
   v += row_ror<8>(v);
   v += row_ror<4>(v);
@@ -202,11 +225,39 @@ PQN_D void x3_grp6(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const
                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5)
                : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
 }
+// first MFMA of a chain: C = 0 as the inline constant instead of a zeroed register tuple (round 6: four v_mov per accumulator less;
+// 0 + a b is what the zeroed tuple gave, bit for bit)
+PQN_D void x3_grp4_zero(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                        const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %0, %4, %5, 0\n\t"
+               "v_mfma_f32_16x16x32_bf16 %1, %6, %7, 0\n\t"
+               "v_mfma_f32_16x16x32_bf16 %2, %8, %9, 0\n\t"
+               "v_mfma_f32_16x16x32_bf16 %3, %10, %11, 0"
+               : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+}
+PQN_D void x3_grp2_zero(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %0, %2, %3, 0\n\t"
+               "v_mfma_f32_16x16x32_bf16 %1, %4, %5, 0"
+               : "=&v"(c0), "=&v"(c1)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+PQN_D void x3_grp3(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2, const u32x4 &a2,
+                   const u32x4 &b2) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n\t"
+               "v_mfma_f32_16x16x32_bf16 %1, %5, %6, %1\n\t"
+               "v_mfma_f32_16x16x32_bf16 %2, %7, %8, %2"
+               : "+v"(c0), "+v"(c1), "+v"(c2)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2));
+}
 // N MFMAs sharing the B operand (N row blocks against one fragment): grouped for the N the kernels use
 template <int N>
 PQN_D void x3_grp_sameb(f32x4 (&c)[N], const u32x4 (&a)[N], const u32x4 &b) {
   if constexpr (N == 2) x3_grp2(c[0], a[0], b, c[1], a[1], b);
-  else if constexpr (N == 3) { x3_grp2(c[0], a[0], b, c[1], a[1], b); c[2] = x3_mfma_tied(a[2], b, c[2]); }
+  else if constexpr (N == 3) x3_grp3(c[0], a[0], b, c[1], a[1], b, c[2], a[2], b);
   else if constexpr (N == 4) x3_grp4(c[0], a[0], b, c[1], a[1], b, c[2], a[2], b, c[3], a[3], b);
   else if constexpr (N == 6) x3_grp6(c[0], a[0], b, c[1], a[1], b, c[2], a[2], b, c[3], a[3], b, c[4], a[4], b, c[5], a[5], b);
   else {

@@ -25,15 +25,32 @@ def scan(asm_path):
     return hits
 
 
+M0_OK = re.compile(r'^\s*s_mov_b32 m0, s\d+\s*$')
+
+
+def scan_m0(asm_path):
+    """pqn_qnet_pos.hip leaves M0 holding the LDS-DMA destination (pos_dma16 does not save / restore it since round 6): every
+    mention of m0 in its assembly must be one of those writes -- nothing may READ it (s_movrel, sendmsg, GWS, v_readlane m0 ...)."""
+    return [(ln, line.strip()) for ln, line in enumerate(open(asm_path), 1)
+            if re.search(r'\bm0\b', line.split(";")[0]) and not M0_OK.match(line.split(";")[0])]
+
+
 def main():
     files = [os.path.abspath(f) for f in sys.argv[1:]] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     bad = 0
     for f in files:
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "x.s")
-            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+            extra = ["-fno-slp-vectorize"] if os.path.basename(f) == "pqn_qnet_pos.hip" else []     # as the Makefile builds it
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", *extra,
                             "--cuda-device-only", "-S", f, "-o", out], check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
             hits = scan(out)
+            if os.path.basename(f) == "pqn_qnet_pos.hip":
+                m0 = scan_m0(out)
+                print("%-20s %d uses of M0 other than the LDS-DMA destination writes" % (os.path.basename(f), len(m0)))
+                for ln, l in m0[:8]:
+                    print("    line %d  %s" % (ln, l))
+                bad += len(m0)
         print("%-20s %d partially overlapping MFMA D/C" % (os.path.basename(f), len(hits)))
         for k, ln, l in hits[:12]:
             print("    %s:%d  %s" % (k[:50], ln, l))
