@@ -677,7 +677,7 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
     const u32x4 *slot = cx.ring + ((kk0 + s) & (F::RS - 1)) * F::N_W + cx.lane;
     POSF_STAMP(1);
     // ---- conv (transposed) of the two positions x two tiles at once: eight independent accumulator chains ----
-    f32x4 cb_[2][2] = {{zero4, zero4}, {zero4, zero4}}, cs_[2][2] = {{zero4, zero4}, {zero4, zero4}};
+    f32x4 cb_[2][2], cs_[2][2];   // (round 6) the first product of every chain runs on C = 0: no zeroed register tuples
 #pragma unroll
     for (int sx = 0; sx < NCS; ++sx) {
       u32x4 fa[2][2];
@@ -686,8 +686,13 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) fa[q][t] = pos_expand8<C>(cx.s_lut, __builtin_amdgcn_ubfe(ConvX3<C>::word(mk[q][t], sx), 8u * cx.g, 8u));
       const u32x4 wh = cx.s_cvw[(sx * 3 + 0) * 64 + cx.lane], wm = cx.s_cvw[(sx * 3 + 1) * 64 + cx.lane], wl = cx.s_cvw[(sx * 3 + 2) * 64 + cx.lane];
-      x3_grp4(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
-      x3_grp4(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
+      if (sx == 0) {
+        x3_grp4_zero(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
+        x3_grp4_zero(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
+      } else {
+        x3_grp4(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
+        x3_grp4(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
+      }
       x3_grp4(cs_[0][0], wm, fa[0][0], cs_[0][1], wm, fa[0][1], cs_[1][0], wm, fa[1][0], cs_[1][1], wm, fa[1][1]);
     }
     // the next K step's window words (the rows are this wave's own: always resident) go out now, in the conv's shadow
@@ -712,7 +717,7 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[q][t][r] = fmaxf(fmaf((v[r] - mean) * rstd, cx.cg0[r], cx.cbe0[r]), 0.0f);
         if (STATS && cx.g == 0) {                                    // LayerNorm_0 statistics for the backward: [position][sample][2]
-          f32x2 ms = {mean, rstd};
+          f32x2 ms = {mean, rstd};                                   // (all four g lanes hold the same bits; storing from all of them was measured SLOWER: 4x the store requests)
           *reinterpret_cast<f32x2 *>(cx.g_stat + ((size_t)(2 * s + q) * POS_ST + 16 * t + cx.i16) * 2) = ms;
         }
       }
