@@ -13,7 +13,7 @@ struct pos_ws_t {
   long long dz;        // dz as three bf16 planes [3][nb][128] in the dgrad's operand order (dz_planes_a)
   long long mb_bits;   // [nb][OW] packed observation rows in minibatch order
   long long t32;       // [nb / 32][pos_t32_words] bit-transposed rows
-  long long stats;     // [nb / 32][64 positions][32 samples][2]: LayerNorm_0 mean, 1/std (forward kernel)
+  long long stats;     // [nb / 32][64 positions][2][32 samples]: LayerNorm_0 mean | 1/std (forward kernel; round 5: [..][32][2])
   long long gpos;      // [8 nch][9C*16 + 48] conv-block records of the backward workgroups
   long long act;       // [nb] i32 (minibatch order)
   long long tgt;       // [nb] f32

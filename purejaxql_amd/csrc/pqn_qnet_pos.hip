@@ -40,6 +40,14 @@
 #define POS_PAIR_SYNC 1
 #endif
 #define POS_ST 32              // samples per super-tile (two 16-sample MFMA tiles)
+// Round 6: the elementwise arithmetic of the backward's two long vector stretches (LayerNorm_0 normalise, relu mask / LayerNorm_0
+// backward) written on EXPLICIT pairs (f32x2 -> v_pk_add / mul / fma_f32): inside a long VALU-only stretch a packed instruction costs
+// about one issue slot for two values, next to MFMAs it costs ~10 cycles per cluster (profiles/r06_ubench_issue_kinds.txt) -- so the
+// file is built without the compiler's SLP packing and packs by hand exactly where it pays.  Same operations per value, same order:
+// bit-identical results.  For the pairs the forward keeps LayerNorm_0's statistics as [position][mean | 1/std][32 samples].
+#ifndef POS_BWD_PK
+#define POS_BWD_PK 1
+#endif
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 // LDS image of a super-tile's dz planes: [plane][32 samples][16 slots of 16 B], slot = quad ^ pos_sigma(sample & 15), where
@@ -374,7 +382,27 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     POSB_STAMP(1);
     x3_drain(cb_[0], cs_[0], cb_[1], cs_[1]);
     float xh[2][4], rs[2][4], dxv[2][4];
+#if POS_BWD_PK
+    f32x2 xh2[2][2], rs2[2][2], y2[2][2];      // [tile][pair]: values r = 2 pair, 2 pair + 1 of the lane
+    const f32x2 bias2 = {bias, bias}, g02 = {g0, g0}, be02 = {be0, be0};
 #pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 *sp = reinterpret_cast<const f32x4 *>(slot + P::O_STAT) + ((wave * 2 * POS_ST + 16 * t + 4 * kq) >> 2);
+      const f32x4 mean4 = sp[0], rs4 = sp[POS_ST / 4];
+      const f32x2 cbl = {cb_[t].x, cb_[t].y}, cbh = {cb_[t].z, cb_[t].w}, csl = {cs_[t].x, cs_[t].y}, csh = {cs_[t].z, cs_[t].w};
+      const f32x2 sc2 = {ConvX3<C>::OUT_SCALE, ConvX3<C>::OUT_SCALE};
+      const f32x2 vl = (cbl + csl) * sc2 + bias2, vh = (cbh + csh) * sc2 + bias2;      // -ffp-contract=off: add, mul, add as in the forward
+      rs2[t][0] = f32x2{rs4.x, rs4.y}; rs2[t][1] = f32x2{rs4.z, rs4.w};
+      xh2[t][0] = (vl - f32x2{mean4.x, mean4.y}) * rs2[t][0];
+      xh2[t][1] = (vh - f32x2{mean4.z, mean4.w}) * rs2[t][1];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        y2[t][h] = __builtin_elementwise_fma(xh2[t][h], g02, be02);
+        xh[t][2 * h] = xh2[t][h].x; xh[t][2 * h + 1] = xh2[t][h].y;
+        rs[t][2 * h] = rs2[t][h].x; rs[t][2 * h + 1] = rs2[t][h].y;
+      }
+    }
+#else
     for (int t = 0; t < 2; ++t) {
       const f32x4 cvo = (cb_[t] + cs_[t]) * ConvX3<C>::OUT_SCALE;
       const float v[4] = {cvo.x + bias, cvo.y + bias, cvo.z + bias, cvo.w + bias};
@@ -390,6 +418,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
         xh[t][r] = (v[r] - mean[r]) * rs[t][r];
       }
     }
+#endif
     POSB_STAMP(2);
     // ---- dgrad: dh1[sample][feature of this position], eight independent accumulators ----
     f32x4 gb[2], gs[2];         // {leading, small} terms per tile: four independent chains, each started on C = 0
@@ -409,6 +438,40 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     POSB_STAMP(3);
     x3_drain(gb[0], gs[0], gb[1], gs[1]);
     // ---- relu mask + LayerNorm_0 backward (per point = per (kq, r); sums over the 16 channel lanes, four at a time) ----
+#if POS_BWD_PK
+    {
+      f32x2 dxh2[2][2], dxx2[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x2 dhl = f32x2{gb[t].x, gb[t].y} + f32x2{gs[t].x, gs[t].y}, dhh = f32x2{gb[t].z, gb[t].w} + f32x2{gs[t].z, gs[t].w};
+        const f32x2 dh2[2] = {dhl, dhh};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 g2 = {y2[t][h].x > 0.0f ? dh2[h].x : 0.0f, y2[t][h].y > 0.0f ? dh2[h].y : 0.0f};
+          gbi += g2.x; gbi += g2.y;                                  // (the three running sums keep their element order)
+          gsc = fmaf(g2.x, xh2[t][h].x, gsc); gsc = fmaf(g2.y, xh2[t][h].y, gsc);
+          dxh2[t][h] = g2 * g02;
+          dxx2[t][h] = dxh2[t][h] * xh2[t][h];
+        }
+      }
+      float s1[2][4], s2[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        group16_sum4_from(s1[t][0], s1[t][1], s1[t][2], s1[t][3], dxh2[t][0].x, dxh2[t][0].y, dxh2[t][1].x, dxh2[t][1].y);
+        group16_sum4_from(s2[t][0], s2[t][1], s2[t][2], s2[t][3], dxx2[t][0].x, dxx2[t][0].y, dxx2[t][1].x, dxx2[t][1].y);
+      }
+      const f32x2 k16 = {1.0f / 16.0f, 1.0f / 16.0f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 s1p = {s1[t][2 * h], s1[t][2 * h + 1]}, s2p = {s2[t][2 * h], s2[t][2 * h + 1]};
+          const f32x2 d2 = rs2[t][h] * ((dxh2[t][h] - s1p * k16) - xh2[t][h] * (s2p * k16));
+          dxv[t][2 * h] = d2.x; dxv[t][2 * h + 1] = d2.y;
+          gbc += d2.x; gbc += d2.y;
+        }
+    }
+#else
     {
       float dxh[2][4], dxx[2][4];
 #pragma unroll
@@ -438,6 +501,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
           gbc += dxv[t][r];
         }
     }
+#endif
     POSB_STAMP(4);
     // h1 and dx of the 32 samples as bf16 planes, split ONCE: K slot j = sample 16 (j >> 2) + 4 kq + (j & 3), i.e. exactly
     // this lane's eight values -- already the A fragment of dW1p = h1^T dz and the B fragment of dWc = bits^T dx
@@ -445,7 +509,13 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h1v[t][r] = fmaxf(fmaf(xh[t][r], g0, be0), 0.0f);
+      for (int r = 0; r < 4; ++r) {
+#if POS_BWD_PK
+        h1v[t][r] = fmaxf((r & 1) ? y2[t][r >> 1].y : y2[t][r >> 1].x, 0.0f);      // the same fma(xh, g0, be0) as the relu mask's
+#else
+        h1v[t][r] = fmaxf(fmaf(xh[t][r], g0, be0), 0.0f);
+#endif
+      }
     const X3Frag fh = x3_split8(f32x4{h1v[0][0], h1v[0][1], h1v[0][2], h1v[0][3]}, f32x4{h1v[1][0], h1v[1][1], h1v[1][2], h1v[1][3]});
     const X3Frag fd = x3_split8(f32x4{dxv[0][0], dxv[0][1], dxv[0][2], dxv[0][3]}, f32x4{dxv[1][0], dxv[1][1], dxv[1][2], dxv[1][3]});
     // ---- dW1p[feature][o] += sum over the 32 samples of h1[sample][feature] dz[sample][o] ----
@@ -716,10 +786,15 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
         const float rstd = rsqrt_exact(var + QN_LN_EPS);
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[q][t][r] = fmaxf(fmaf((v[r] - mean) * rstd, cx.cg0[r], cx.cbe0[r]), 0.0f);
+#if POS_BWD_PK
+        if (STATS && cx.g < 2)     // LayerNorm_0 statistics for the backward: [position][mean | 1/std][sample]; lanes g = 0 store the mean, g = 1 1/std
+          cx.g_stat[((size_t)(2 * s + q) * 2 + cx.g) * POS_ST + 16 * t + cx.i16] = cx.g == 0 ? mean : rstd;
+#else
         if (STATS && cx.g == 0) {                                    // LayerNorm_0 statistics for the backward: [position][sample][2]
           f32x2 ms = {mean, rstd};                                   // (all four g lanes hold the same bits; storing from all of them was measured SLOWER: 4x the store requests)
           *reinterpret_cast<f32x2 *>(cx.g_stat + ((size_t)(2 * s + q) * POS_ST + 16 * t + cx.i16) * 2) = ms;
         }
+#endif
       }
     mask_finish(s + 1, nlo, nhi, mk);
     POSF_STAMP(2);
