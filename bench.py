@@ -162,7 +162,7 @@ def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sampl
         flop_per_sample = pos_flop_per_sample(channels, actions)[0]
     achieved = flop_per_sample * mb_samples * seeds / avg_s / 1e12
     traffic, tsrc, l2cu = None, None, None
-    for name in ((f"r06_pmc_pos_bwd_kernel_{matmul}_seeds{seeds}.json", f"r05_pmc_pos_bwd_kernel_{matmul}_seeds{seeds}.json") if form == "pos" else
+    for name in ((f"r06_pmc_pos_bwd_kernel_{matmul}_seeds{seeds}.json",) + ((f"r05_pmc_pos_bwd_kernel_{matmul}_seeds{seeds}.json",) if matmul != "f16x2" else ()) if form == "pos" else
                  (f"r04_pmc_train_kernel_{matmul}_seeds{seeds}.json", f"r03_pmc_train_kernel_{matmul}_seeds{seeds}.json",
                  f"r02_pmc_train_kernel_{matmul}_seeds{seeds}.json",
                  f"r02_pmc_train_kernel_{matmul}.json", "r01_pmc_train_kernel.json")):
@@ -208,11 +208,22 @@ def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sampl
                                     "position-parallel kernels keep the matrix pipe 41-47 % busy; the rest is instruction issue on the "
                                     "SIMDs (4.1 VALU instructions per MFMA in the backward: operand split, LayerNorm_0 backward, bit "
                                     "expansion) and the latency of a two-wave-per-SIMD schedule (DESIGN.md section 3.6)"}
+    if matmul == "f16x2":
+        h2_peak = BF16_PEAK_TFLOPS / 3.0     # the fp16 MFMA peak equals the bf16 one
+        out.update({"peak": h2_peak, "frac": achieved / h2_peak, "frac_f32_mfma_peak": achieved / F32_PEAK_TFLOPS,
+                    "peak_note": "dense fp16 MFMA peak of MI355X (2500 TFLOP/s) / 3 fp16 products per f32 product of the two-way split "
+                                 "= 833.3 TFLOP/s of 22-bit products; `achieved` = algorithmic f32 FLOPs of the kernel per second.  "
+                                 "frac_f32_mfma_peak = the same rate against the f32 MFMA peak (157.3 TFLOP/s)"})
+        out["fp16_pipe"] = {"issued_tflops": achieved * 3.0, "peak": BF16_PEAK_TFLOPS, "frac": achieved * 3.0 / BF16_PEAK_TFLOPS,
+                            "note": "fp16 MFMA FLOPs issued (3 per algorithmic f32 FLOP; the conv weight gradient stays on 3 bf16 products) "
+                                    "against the dense peak"}
     return out
 
 
 DTYPE_LABEL = {"f32": "f32",
                "bf16x3": "f32 (bf16x3 split operands, 6 bf16 MFMA products per f32 product, f32 accumulate)",
+               "f16x2": "f32 (f16x2 split operands: two range-scaled fp16 pieces = 22 significand bits, 3 fp16 MFMA products per f32 "
+                        "product, f32 accumulate; bf16x3 outside the position-parallel kernels)",
                "f16": "f16 operands / f32 accumulate (fc1), f32 elsewhere"}
 
 
@@ -237,7 +248,7 @@ def main():
                          "| masked:<lo>:<hi> (eager, tail stream on CUs [lo, hi), training kernels on the rest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only")
-    ap.add_argument("--matmul-dtype", default="bf16x3", choices=["f32", "bf16x3", "f16"],
+    ap.add_argument("--matmul-dtype", default="bf16x3", choices=["f32", "bf16x3", "f16x2", "f16"],
                     help="operand mode of the fc1 / conv products (config MATMUL_DTYPE).  bf16x3 (default here) evaluates "
                          "every f32 product exactly-split on the bf16 matrix core with f32 accumulation and is held to "
                          "the same f32 tolerances as the f32-MFMA mode by the parity tests; the package default is auto = this mode from 512-sample minibatches on, f32 below")
@@ -566,7 +577,7 @@ def main():
         if extras and fused:
             def other_modes():
                 res = {}
-                for md in ("f32", "bf16x3", "f16"):
+                for md in ("f32", "bf16x3", "f16x2", "f16"):
                     if md == matmul:
                         continue
                     c2 = dict(cfg)

@@ -177,6 +177,11 @@ typedef struct {
   int32_t matmul_f16;
   int32_t off_w1h; /* float offset of the fp16 forward copy (131072 halves), the dgrad copy follows it */
   int32_t alloc;   /* floats to allocate for theta (== total when matmul_f16 == 0) */
+  /* pqn_cnn_layout_ex mode 3 ("f16x2"): matmul_f16 = 2 (every kernel form other than the position-parallel one runs bf16x3 as in mode
+   * 2) and pos_f16x2 = 1: the position-parallel kernels (forward, backward, rollout) take their fc1 / conv operands as TWO fp16
+   * pieces (22 significand bits, exact power-of-two range scaling, 3 matrix instructions per product instead of 6).  theta then
+   * also carries four fp16 planes of the fc1 kernel behind the six bf16 planes (alloc covers them). */
+  int32_t pos_f16x2;
 } pqn_cnn_layout_t;
 
 int pqn_cnn_layout(int32_t c, int32_t a, pqn_cnn_layout_t *layout /* host */);           /* matmul_f16 = 0 */

@@ -342,8 +342,9 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
       const int frag = (int)(j >> 8), ln = (int)(j >> 2) & 63, sx = (int)j & 3;
       const int gi = frag >> 3, cb = frag & 7, kk = ln >> 4, jj = ln & 15;
       const int jb = (((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3);
-      if (half_off && copy_mode == 2) {   // bf16x3 layout: the six bf16 planes in the tail of the parameter buffer
+      if (half_off && copy_mode >= 2) {   // bf16x3 layout: the six bf16 planes in the tail of the parameter buffer (3: + four f16x2 planes)
         pqn_x3_store_planes(reinterpret_cast<unsigned short *>(p + half_off), 16 * gi + 4 * kk + sx, 16 * cb + jj, pn);
+        if (copy_mode == 3) pqn_h2_store_planes(reinterpret_cast<_Float16 *>(p + half_off + H2_PLANES_OFF), 16 * gi + 4 * kk + sx, 16 * cb + jj, pn);
         return;
       }
       w1b[jb] = pn;
@@ -361,12 +362,13 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
   // planes, and after a 4 x 4 exchange inside each lane quad (through LDS) for the dgrad-order planes -- instead of
   // 24 two-byte stores per thread (measured: the optimizer kernel took 33 us per 16-seed launch against 18 without
   // the planes).  The generic loops below then skip that range.
-  const bool x3_w1 = w1b && half_off && copy_mode == 2 && n4 > 0 && (w1_off & 3) == 0;
+  const bool x3_w1 = w1b && half_off && copy_mode >= 2 && n4 > 0 && (w1_off & 3) == 0;
   if (x3_w1) {
     __shared__ float s_tr[4][256];
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned short *planes = reinterpret_cast<unsigned short *>(p + half_off);
+    unsigned short *hplanes = reinterpret_cast<unsigned short *>(p + half_off + H2_PLANES_OFF);   // copy_mode 3: f16x2 planes (hi, lo per order)
     constexpr int NQ = 1024 * 128 / 4, P = 1024 * 128;
     const int iters = (NQ + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256);
     for (int it = 0; it < iters; ++it) {
@@ -401,6 +403,18 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
         M = u2{(unsigned)mm[0] | ((unsigned)mm[1] << 16), (unsigned)mm[2] | ((unsigned)mm[3] << 16)};
         Lo = u2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
       };
+      auto split4h = [&](const float (&x)[4], u2 &H, u2 &Lo) {
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          _Float16 hh, ll;
+          pqn_h2_split1(x[c], hh, ll);
+          h[c] = __builtin_bit_cast(unsigned short, hh);
+          l[c] = __builtin_bit_cast(unsigned short, ll);
+        }
+        H = u2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+        Lo = u2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+      };
       if (on) {   // forward-order planes: the lane's four values are K-consecutive (same index math as pqn_x3_store_planes)
         const int i0 = 16 * gi + 4 * kk, o = 16 * cb + jj;
         const int jf = ((((i0 >> 5) * 8 + (o >> 4)) * 64 + ((i0 >> 2) & 3) * 16 + (o & 15)) << 3) + 4 * ((i0 >> 4) & 1);
@@ -409,6 +423,11 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
         *reinterpret_cast<u2 *>(planes + jf) = H;
         *reinterpret_cast<u2 *>(planes + P + jf) = M;
         *reinterpret_cast<u2 *>(planes + 2 * P + jf) = Lo;
+        if (copy_mode == 3) {
+          split4h(pa, H, Lo);
+          *reinterpret_cast<u2 *>(hplanes + jf) = H;
+          *reinterpret_cast<u2 *>(hplanes + P + jf) = Lo;
+        }
       }
       // dgrad-order planes want four consecutive o for one i: exchange inside the quad of lanes jj = 4a .. 4a+3
       __syncthreads();
@@ -426,6 +445,11 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
         *reinterpret_cast<u2 *>(planes + 3 * P + jd) = H;
         *reinterpret_cast<u2 *>(planes + 4 * P + jd) = M;
         *reinterpret_cast<u2 *>(planes + 5 * P + jd) = Lo;
+        if (copy_mode == 3) {
+          split4h(tv, H, Lo);
+          *reinterpret_cast<u2 *>(hplanes + 2 * P + jd) = H;
+          *reinterpret_cast<u2 *>(hplanes + 3 * P + jd) = Lo;
+        }
       }
     }
   }

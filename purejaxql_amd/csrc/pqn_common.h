@@ -145,6 +145,29 @@ PQN_HD void pqn_x3_store_planes(unsigned short *planes, int i, int o, float w) {
   planes[3 * P + jd] = h; planes[4 * P + jd] = m; planes[5 * P + jd] = l;
 }
 
+// f16x2 planes of the fc1 kernel (position-parallel kernels, pqn_cnn_layout_t.pos_f16x2; pqn_qnet_x3.h): four planes of 131072 halves
+// behind the six bf16 planes -- forward order hi, lo, then dgrad order hi, lo (the fragment orders of the bf16 planes), holding
+// 128 w = hi + lo with hi = f16(128 w), lo = f16(128 w - hi)
+#define H2_W_SCALE 128.0f
+#define H2_W_SHIFT 7
+#define H2_PLANES_OFF (3 * 1024 * 128)            // floats from off_w1h to the f16 planes
+PQN_HD void pqn_h2_split1(float w, _Float16 &h, _Float16 &l) {
+  const float x = w * H2_W_SCALE;
+  h = (_Float16)x;
+  l = (_Float16)(x - (float)h);
+}
+PQN_HD void pqn_h2_store_planes(_Float16 *planes, int i, int o, float w) {
+  _Float16 h, l;
+  pqn_h2_split1(w, h, l);
+  const int s = i >> 5, hh = (i >> 4) & 1, kk = (i >> 2) & 3, sx = i & 3;
+  const int jf = ((((s * 8 + (o >> 4)) * 64) + kk * 16 + (o & 15)) << 3) + 4 * hh + sx;
+  const int sK = o >> 5, hd = (o >> 4) & 1, kd = (o >> 2) & 3, sd = o & 3;
+  const int jd = (((((i >> 4) * 4 + sK) * 64) + kd * 16 + (i & 15)) << 3) + 4 * hd + sd;
+  const int P = 1024 * 128;
+  planes[jf] = h; planes[P + jf] = l;
+  planes[2 * P + jd] = h; planes[3 * P + jd] = l;
+}
+
 // b^t for integer t >= 1 in f64 (<= 2 ulp from pow(); only its f32 cast is used)
 PQN_HD double pqn_powi(double b, int t) {
   double r = 1.0;
@@ -190,7 +213,7 @@ int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, in
                      float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds = 1, long long pstride = 0,
                      long long sstride = 0, long long w1bstride = 0, int half_off = 0, int copy_mode = 1);
 // half_off: float offset of the operand-copy region behind the parameters (pqn_cnn_layout_t.off_w1h; 0 = none);
-// copy_mode: 1 = two fp16 copies of the fc1 kernel (matmul_f16), 2 = six bf16 planes (bf16x3)
+// copy_mode: 1 = two fp16 copies of the fc1 kernel (matmul_f16), 2 = six bf16 planes (bf16x3), 3 = those + the four f16x2 planes
 
 // kernel timer of pqn_prof_enable(mode) for kernels outside pqn_qnet.hip (mode 2 = the wide-MLP GEMM kernel)
 bool pqn_prof_begin(int mode, hipStream_t st);

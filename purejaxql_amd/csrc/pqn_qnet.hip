@@ -2970,11 +2970,14 @@ extern "C" int pqn_cnn_layout_ex(int32_t c, int32_t a, int32_t matmul_f16, pqn_c
   L->off_w2 = off; off = align4(off + QN_HID * a);
   L->off_b2 = off; off = align4(off + a);
   L->total = off;
-  PQN_REQUIRE(matmul_f16 >= 0 && matmul_f16 <= 2, "pqn_cnn_layout_ex: operand mode %d (0 f32, 1 f16, 2 bf16x3)", matmul_f16);
+  PQN_REQUIRE(matmul_f16 >= 0 && matmul_f16 <= 3, "pqn_cnn_layout_ex: operand mode %d (0 f32, 1 f16, 2 bf16x3, 3 f16x2)", matmul_f16);
+  L->pos_f16x2 = matmul_f16 == 3;                          // 3: bf16x3 everywhere but the position-parallel kernels, which run f16x2
+  if (matmul_f16 == 3) matmul_f16 = 2;
   L->matmul_f16 = matmul_f16;                              // 0: f32 MFMA; 1: fp16 operands; 2: bf16x3 split operands
   L->off_w1h = off;                                        // mode 1: 2 x 131072 halves = 131072 floats behind the parameters
   L->alloc = matmul_f16 == 1 ? off + QN_H1 * QN_HID            // two fp16 copies
                              : (matmul_f16 == 2 ? off + 3 * QN_H1 * QN_HID : off);   // mode 2: 6 bf16 planes (3 forward + 3 dgrad order)
+  if (L->pos_f16x2) L->alloc += 2 * QN_H1 * QN_HID;        // + 4 fp16 planes (H2_PLANES_OFF behind off_w1h)
   return PQN_OK;
 }
 
@@ -3550,13 +3553,13 @@ extern "C" int pqn_qnet_cnn_apply(const pqn_cnn_layout_t *L, float *theta, float
   PQN_REQUIRE(L && theta && w1b && grad && m && v && count && workspace, "pqn_qnet_cnn_apply: NULL argument");
   return pqn_launch_radam(theta, grad, m, v, L->total, count, lr_init, lr_end, lr_steps, max_norm, workspace, gnorm_out,
                           L->off_w1, w1b, recompute_norm, grad_reduce_blocks(L->total), (hipStream_t)stream, 1, 0, 0, 0,
-                          L->matmul_f16 != 0 ? L->off_w1h : 0, L->matmul_f16);
+                          L->matmul_f16 != 0 ? L->off_w1h : 0, L->matmul_f16 + L->pos_f16x2);
 }
 
 // w1b: f32 dgrad-fragment copy (nullable);  w1h: fp16 forward-fragment copy + fp16 dgrad-fragment copy (nullable);
 // x3: the six bf16 planes of the bf16x3 mode (nullable)
 __global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict__ w1b, _Float16 *__restrict__ w1h,
-                                unsigned short *__restrict__ x3) {
+                                unsigned short *__restrict__ x3, _Float16 *__restrict__ h2) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= QN_H1 * QN_HID) return;
   const int frag = j >> 8, ln = (j >> 2) & 63, sx = j & 3;
@@ -3569,6 +3572,7 @@ __global__ void pack_w1b_kernel(const float *__restrict__ w1p, float *__restrict
     w1h[QN_H1 * QN_HID + jb] = (_Float16)w;
   }
   if (x3) pqn_x3_store_planes(x3, 16 * gi + 4 * kk + sx, 16 * cb + jj, w);
+  if (h2) pqn_h2_store_planes(h2, 16 * gi + 4 * kk + sx, 16 * cb + jj, w);
 }
 
 // theta is written only in its tail (the fp16 copies of a matmul_f16 layout); pass w1b = NULL to refresh just those
@@ -3577,6 +3581,7 @@ extern "C" int pqn_qnet_cnn_pack_w1b(const pqn_cnn_layout_t *L, float *theta, fl
   PQN_REQUIRE(w1b || L->matmul_f16 != 0, "pqn_qnet_cnn_pack_w1b: nothing to do");
   hipLaunchKernelGGL(pack_w1b_kernel, dim3(QN_H1 * QN_HID / 256), dim3(256), 0, (hipStream_t)stream, theta + L->off_w1, w1b,
                      L->matmul_f16 == 1 ? reinterpret_cast<_Float16 *>(theta + L->off_w1h) : (_Float16 *)nullptr,
-                     L->matmul_f16 == 2 ? reinterpret_cast<unsigned short *>(theta + L->off_w1h) : (unsigned short *)nullptr);
+                     L->matmul_f16 == 2 ? reinterpret_cast<unsigned short *>(theta + L->off_w1h) : (unsigned short *)nullptr,
+                     L->pos_f16x2 ? reinterpret_cast<_Float16 *>(theta + L->off_w1h + H2_PLANES_OFF) : (_Float16 *)nullptr);
   return pqn_check_launch("pqn_qnet_cnn_pack_w1b");
 }

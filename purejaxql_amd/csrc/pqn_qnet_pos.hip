@@ -83,7 +83,7 @@ PQN_D u32x4 pos_expand8(const u32x4 *lut, uint32_t byte) {
   else return ConvX3<C>::expand8(byte);
 }
 
-template <int C>
+template <int C, int NPL = 3>      // NPL: planes per split operand -- 3 = bf16x3, 2 = f16x2 (pqn_qnet_x3.h)
 struct PosCfg {
   using Cfg = CnnCfg<C>;
   static constexpr int OW = Cfg::OW;                 // packed observation words per sample (multiple of 4)
@@ -94,18 +94,21 @@ struct PosCfg {
   static constexpr int KW = 9 * C, RB = 3 * C, NRB = (KW + 15) / 16;
   static constexpr int CONVBLK = KW * 16 + 48;
   // ring slot, in 16-B chunks: dz planes | rows | T32 | LN0 statistics
-  static constexpr int N_DZ = 1536;                  // 3 planes x 32 samples x 16 quads
+  static constexpr int N_DZ = NPL * 512;             // planes x 32 samples x 16 quads
   static constexpr int N_ROWS = (POS_ST * ROWSTRIDE + 63) / 64 * 64;
   static constexpr int N_T32 = TW / 4;
   static constexpr int N_STAT = 128;                 // 8 positions x 32 samples x {mean, rstd}
   static constexpr int O_ROWS = N_DZ, O_T32 = O_ROWS + N_ROWS, O_STAT = O_T32 + N_T32;
   static constexpr int SLOT = O_STAT + N_STAT;       // chunks per slot (a multiple of 64: whole DMA instructions)
   static constexpr int NI = SLOT / 64;               // 1-KB DMA instructions per slot
-  static constexpr int NTAIL = NI - 24;              // instructions behind the 24 of the dz planes
+  static constexpr int NTAIL = NI - 8 * NPL;         // instructions behind the 8 per plane of dz
+  // f16x2: the per-sample factors 2^-k / 128 of the dz rows (forward kernel) ride in the last 32 words of the super-tile's T32 block
+  static constexpr int F_OFF = TW - 32;
+  static_assert(NPL == 3 || TW - (NBITS + 1) >= 32, "no room for the dz row factors behind the bit words");
   static_assert(NTAIL >= 1 && NTAIL <= 16, "at most two tail instructions per wave");
   static constexpr int NCS = (KW + 31) / 32;          // K steps of the conv product
   static constexpr int RS = POS_PAIR_SYNC ? 4 : 2;    // ring slots
-  static constexpr size_t lds_bytes() { return (size_t)RS * SLOT * 16 + sizeof(float) * ((CONVBLK + 3) & ~3) + (size_t)NCS * 3 * 64 * 16 + 4096; }
+  static constexpr size_t lds_bytes() { return (size_t)RS * SLOT * 16 + sizeof(float) * ((CONVBLK + 3) & ~3) + (size_t)NCS * NPL * 64 * 16 + 4096; }
 };
 
 // sorted shuffle key -> row of the stacked [T][S * N] rollout record (see pqn_seeds_t)
@@ -172,6 +175,51 @@ PQN_D void pos_dma16(uint32_t voff, const void *sbase, uint32_t lds_dst) {
 }
 PQN_D void pos_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// wave max over all 64 lanes (prologue / epilogue use only)
+PQN_D float pos_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// f16x2: the conv kernel's scale (a power of two from max |w|; every wave derives the same value from the LDS copy) and
+// LayerNorm_0's output scale from 4 max|scale| + max|bias| (|xhat| <= sqrt(15))
+template <int C>
+PQN_D float pos_h2_conv_scale(const float *s_wc, int lane) {
+  float m = 0.0f;
+  for (int i = lane; i < CnnCfg<C>::KW * 16; i += 64) m = fmaxf(m, fabsf(s_wc[i]));
+  return h2_pow2_below(pos_wave_max(m));
+}
+template <int C>
+PQN_D float pos_h2_h1_scale(const float *s_wc, int lane) {
+  const float g = fabsf(s_wc[CnnCfg<C>::KW * 16 + 16 + (lane & 15)]), b = fabsf(s_wc[CnnCfg<C>::KW * 16 + 32 + (lane & 15)]);
+  return h2_pow2_below(4.0f * pos_wave_max(g) + pos_wave_max(b));
+}
+// the conv kernel as B-fragment planes [K step][plane][lane] in LDS, written by ONE wave (bf16x3: h, m, l; f16x2: h, l of scale * w)
+template <int C, int NPL>
+PQN_D void pos_conv_planes(const float *s_wc, u32x4 *s_cvw, int lane, float scale) {
+  constexpr int NK = 9 * C, NS = (NK + 31) / 32;
+  const int kq = lane >> 4, o = lane & 15;
+#pragma unroll
+  for (int sx = 0; sx < NS; ++sx) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * sx + 8 * kq + j;
+      v[j] = (k < NK) ? s_wc[k * 16 + o] : 0.0f;
+    }
+    if constexpr (NPL == 2) {
+      const H2Frag f = h2_split8(f32x4{v[0], v[1], v[2], v[3]} * scale, f32x4{v[4], v[5], v[6], v[7]} * scale);
+      s_cvw[(sx * 2 + 0) * 64 + lane] = f.h;
+      s_cvw[(sx * 2 + 1) * 64 + lane] = f.l;
+    } else {
+      const X3Frag f = x3_split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+      s_cvw[(sx * 3 + 0) * 64 + lane] = f.h;
+      s_cvw[(sx * 3 + 1) * 64 + lane] = f.m;
+      s_cvw[(sx * 3 + 2) * 64 + lane] = f.l;
+    }
+  }
+}
+
 #ifdef POS_STAMPS   // variant builds only: the stamp stores are VMEM operations the compiler counts, and its vmcnt waits would drain the DMA
 #define POSB_STAMP(k) do { if (stamps && j == 4 && lane == 0 && blockIdx.x == 0 && wave == 0) stamps[(k)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -180,18 +228,21 @@ PQN_D void pos_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // LayerNorm_0 statistics (mean, 1/std per (sample, position)) are the forward kernel's record: xhat and the relu mask are then
 // the forward's own, bit for bit
-template <int C>
+template <int C, int NPL>
 __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nch, const float *__restrict__ theta, pqn_cnn_layout_t L,
                                                                   float *__restrict__ wsx, float *__restrict__ w1out,
                                                                   pos_ws_t W, pqn_seeds_t sd, unsigned long long *__restrict__ stamps) {
-  using P = PosCfg<C>;
+  using P = PosCfg<C, NPL>;
   using Cfg = CnnCfg<C>;
+  using M = PosMM<NPL>;
+  constexpr bool H2 = NPL == 2;
+  static_assert(!H2 || POS_BWD_PK, "the f16x2 backward is written on the paired form");
   constexpr int NRB = P::NRB, RB = P::RB, CONVBLK = P::CONVBLK;
   extern __shared__ __attribute__((aligned(16))) char pos_smem[];
   u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);
   float *s_wc = reinterpret_cast<float *>(ring + P::RS * P::SLOT);
   u32x4 *s_cvw = reinterpret_cast<u32x4 *>(s_wc + ((CONVBLK + 3) & ~3));   // conv kernel as bf16-plane B fragments [K step][plane][lane]: one copy for all waves
-  u32x4 *s_lut = s_cvw + P::NCS * 3 * 64;                                   // pos_expand8 table
+  u32x4 *s_lut = s_cvw + P::NCS * NPL * 64;                                 // pos_expand8 table
   // (seed, position group, chunk) of this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id; the 8 nch
   // workgroups of a seed all read that seed's dz planes, so they are placed on ONE XCD's L2 when the seeds divide over the XCDs.
   const int wps = 8 * nch, nsl = gridDim.x / wps;
@@ -220,7 +271,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ---- DMA plan of this wave: instruction i = wave + 8 k fills chunks [64 i, 64 i + 64) of the slot ----
-  const u32x4 *g_dza = reinterpret_cast<const u32x4 *>(wsx + W.dz);                      // [3][nb][16 quads]
+  const u32x4 *g_dza = reinterpret_cast<const u32x4 *>(wsx + W.dz);                      // [NPL][nb][16 quads]
   const u32x4 *g_rows = reinterpret_cast<const u32x4 *>(wsx + W.mb_bits);                // [nb][ROWCH]
   const u32x4 *g_t32 = reinterpret_cast<const u32x4 *>(wsx + W.t32);                     // [super-tile][N_T32]
   const u32x4 *g_stat = reinterpret_cast<const u32x4 *>(wsx + W.stats);                  // [super-tile][64 pos][16]
@@ -233,7 +284,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int ti = wave + 8 * k;                          // tail instruction index (wave-uniform)
-    const int q0 = (24 + ti) * 64, q = q0 + lane;         // the instruction's 64 chunks are all of one kind
+    const int q0 = (8 * NPL + ti) * 64, q = q0 + lane;    // the instruction's 64 chunks are all of one kind
     tailq[k] = ti < P::NTAIL ? q0 : -1;
     uint32_t off = 0u;
     int str = 0;
@@ -263,7 +314,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     for (int k = 0; k < 2; ++k)
       if (tailq[k] >= 0) pos_dma16(offT[k], g_dza + (size_t)g * strT[k], slot + (uint32_t)(tailq[k] * 16));
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pos_dma16(offA, bA + (size_t)k * pa, slot + (uint32_t)((wave + 8 * k) * 1024));
+    for (int k = 0; k < NPL; ++k) pos_dma16(offA, bA + (size_t)k * pa, slot + (uint32_t)((wave + 8 * k) * 1024));
   };
   dma_slot(0);
   if constexpr (POS_PAIR_SYNC != 0) dma_slot(1);
@@ -271,13 +322,24 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
   // ---- per-wave constants ----
   for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
   pos_lut_fill(s_lut, tid, POS_THREADS);
-  u32x4 wfr[4][3];               // the position's 16 rows of W1 as dgrad-order bf16 planes: B fragments of dh1 = dz W1p^T
+  u32x4 wfr[4][NPL];             // the position's 16 rows of W1 as dgrad-order planes: B fragments of dh1 = dz W1p^T
   {
-    const u32x4 *wd = reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
+    const u32x4 *wd = H2 ? reinterpret_cast<const u32x4 *>(theta + L.off_w1h + H2_PLANES_OFF) + 2 * (X3_PLANE / 8)
+                         : reinterpret_cast<const u32x4 *>(theta + L.off_w1h) + 3 * (X3_PLANE / 8);
 #pragma unroll
     for (int sK = 0; sK < 4; ++sK)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wfr[sK][pl] = wd[(size_t)pl * (X3_PLANE / 8) + ((p * 4 + sK) * 64 + lane)];
+      for (int pl = 0; pl < NPL; ++pl) wfr[sK][pl] = wd[(size_t)pl * (X3_PLANE / 8) + ((p * 4 + sK) * 64 + lane)];
+  }
+  // f16x2: the largest dz row factor of this chunk (the forward left one per sample behind the bit words of T32): the weight
+  // gradient's h1 operand carries factor / largest <= 1 per sample, the epilogue puts the largest back
+  float *scr = reinterpret_cast<float *>(ring + (P::RS - 1) * P::SLOT);   // the last ring slot is idle until the loop
+  if constexpr (H2) {
+    const float *tf = wsx + W.t32 + (size_t)st0 * P::TW + P::F_OFF;
+    float fm = 0.0f;
+    for (int i = tid; i < nst * POS_ST; i += POS_THREADS) fm = fmaxf(fm, tf[(size_t)(i >> 5) * P::TW + (i & 31)]);
+    fm = pos_wave_max(fm);
+    if (lane == 0) scr[wave] = fm;
   }
   int bw[3], bs[3];              // window row ky of this position: word and bit offset inside a packed row (wave-uniform)
 #pragma unroll
@@ -303,15 +365,17 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
   }
   pos_dma_wait();
   __syncthreads();               // s_wc complete, slot 0 landed
-  if (wave == 0) {               // the conv kernel's planes are the same for every position: split once, shared through LDS
-    ConvX3<C> cv;
-    cv.init(s_wc, lane);
+  float oscale = ConvX3<C>::OUT_SCALE, kh1 = 1.0f;      // conv output scale; f16x2: the h1 operand's scale (LayerNorm_0 bound / largest row factor)
+  if constexpr (H2) {
+    const float sc = pos_h2_conv_scale<C>(s_wc, lane);
+    oscale = ConvX3<C>::OUT_SCALE / sc;
+    float fm = scr[0];
 #pragma unroll
-    for (int sx = 0; sx < P::NCS; ++sx) {
-      s_cvw[(sx * 3 + 0) * 64 + lane] = cv.w[sx].h;
-      s_cvw[(sx * 3 + 1) * 64 + lane] = cv.w[sx].m;
-      s_cvw[(sx * 3 + 2) * 64 + lane] = cv.w[sx].l;
-    }
+    for (int w = 1; w < 8; ++w) fm = fmaxf(fm, scr[w]);
+    kh1 = pos_h2_h1_scale<C>(s_wc, lane) / fmaxf(fm, 1e-30f);
+    if (wave == 0) pos_conv_planes<C, NPL>(s_wc, s_cvw, lane, sc);
+  } else {
+    if (wave == 0) pos_conv_planes<C, NPL>(s_wc, s_cvw, lane, 1.0f);   // the same for every position: split once, shared through LDS
   }
   __syncthreads();
   const float bias = s_wc[Cfg::KW * 16 + ch], g0 = s_wc[Cfg::KW * 16 + 16 + ch], be0 = s_wc[Cfg::KW * 16 + 32 + ch];
@@ -326,7 +390,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
 #pragma unroll
   for (int sK = 0; sK < 4; ++sK)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(wfr[sK][pl]));
+    for (int pl = 0; pl < NPL; ++pl) asm volatile("" : "+v"(wfr[sK][pl]));
 
 #pragma unroll 1
   for (int j = 0; j < nst; ++j) {
@@ -361,43 +425,51 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
       u32x4 fa[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) fa[t] = pos_expand8<C>(s_lut, __builtin_amdgcn_ubfe(ConvX3<C>::word(mk[t], sx), 8u * kq, 8u));
-      const u32x4 wh = s_cvw[(sx * 3 + 0) * 64 + lane], wm = s_cvw[(sx * 3 + 1) * 64 + lane], wl = s_cvw[(sx * 3 + 2) * 64 + lane];
+      const u32x4 wh = s_cvw[(sx * NPL + 0) * 64 + lane], wl = s_cvw[(sx * NPL + NPL - 1) * 64 + lane];
       if (sx == 0) {
-        x3_grp2_zero(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
-        x3_grp2_zero(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
+        M::grp2_zero(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
+        M::grp2_zero(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
       } else {
-        x3_grp2(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
-        x3_grp2(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
+        M::grp2(cs_[0], fa[0], wl, cs_[1], fa[1], wl);
+        M::grp2(cb_[0], fa[0], wh, cb_[1], fa[1], wh);
       }
-      x3_grp2(cs_[0], fa[0], wm, cs_[1], fa[1], wm);
+      if constexpr (!H2) {
+        const u32x4 wm = s_cvw[(sx * 3 + 1) * 64 + lane];
+        x3_grp2(cs_[0], fa[0], wm, cs_[1], fa[1], wm);
+      }
     }
     // dgrad operands of both tiles from LDS while the conv drains; ONE register set, each plane re-read for the next K step
     // right behind the last MFMA group that uses it (l after the first group, m after the fifth, h after the sixth)
-    u32x4 az[2][3];
+    u32x4 az[2][NPL];            // planes in storage order: bf16x3 h, m, l; f16x2 h, l
     auto load_az = [&](int sK, int pl) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) az[t][pl] = ldA[(pl * 32 + 16 * t + ch) * 16 + ((sK * 4 + kq) ^ sig_ch)];
     };
-    load_az(0, 0); load_az(0, 1); load_az(0, 2);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) load_az(0, pl);
     POSB_STAMP(1);
     x3_drain(cb_[0], cs_[0], cb_[1], cs_[1]);
     float xh[2][4], rs[2][4], dxv[2][4];
+    f32x4 fs4[2];               // f16x2: the dz row factors of this lane's eight samples
+    (void)fs4;
 #if POS_BWD_PK
     f32x2 xh2[2][2], rs2[2][2], y2[2][2];      // [tile][pair]: values r = 2 pair, 2 pair + 1 of the lane
-    const f32x2 bias2 = {bias, bias}, g02 = {g0, g0}, be02 = {be0, be0};
+    const f32x2 bias2 = {bias, bias}, g02 = {g0, g0};
+    // f16x2: relu's argument is formed with scale / bias times kh1 (a power of two: same sign, and max(.., 0) is the h1 operand's scaling)
+    const f32x2 gy2 = {g0 * kh1, g0 * kh1}, by2 = {be0 * kh1, be0 * kh1};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const f32x4 *sp = reinterpret_cast<const f32x4 *>(slot + P::O_STAT) + ((wave * 2 * POS_ST + 16 * t + 4 * kq) >> 2);
       const f32x4 mean4 = sp[0], rs4 = sp[POS_ST / 4];
       const f32x2 cbl = {cb_[t].x, cb_[t].y}, cbh = {cb_[t].z, cb_[t].w}, csl = {cs_[t].x, cs_[t].y}, csh = {cs_[t].z, cs_[t].w};
-      const f32x2 sc2 = {ConvX3<C>::OUT_SCALE, ConvX3<C>::OUT_SCALE};
+      const f32x2 sc2 = {oscale, oscale};
       const f32x2 vl = (cbl + csl) * sc2 + bias2, vh = (cbh + csh) * sc2 + bias2;      // -ffp-contract=off: add, mul, add as in the forward
       rs2[t][0] = f32x2{rs4.x, rs4.y}; rs2[t][1] = f32x2{rs4.z, rs4.w};
       xh2[t][0] = (vl - f32x2{mean4.x, mean4.y}) * rs2[t][0];
       xh2[t][1] = (vh - f32x2{mean4.z, mean4.w}) * rs2[t][1];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        y2[t][h] = __builtin_elementwise_fma(xh2[t][h], g02, be02);
+        y2[t][h] = __builtin_elementwise_fma(xh2[t][h], gy2, by2);
         xh[t][2 * h] = xh2[t][h].x; xh[t][2 * h + 1] = xh2[t][h].y;
         rs[t][2 * h] = rs2[t][h].x; rs[t][2 * h + 1] = rs2[t][h].y;
       }
@@ -424,16 +496,26 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     f32x4 gb[2], gs[2];         // {leading, small} terms per tile: four independent chains, each started on C = 0
 #pragma unroll
     for (int sK = 0; sK < 4; ++sK) {
-      if (sK == 0) x3_grp2_zero(gs[0], az[0][2], wfr[sK][0], gs[1], az[1][2], wfr[sK][0]);
-      else x3_grp2(gs[0], az[0][2], wfr[sK][0], gs[1], az[1][2], wfr[sK][0]);
-      if (sK + 1 < 4) load_az(sK + 1, 2);
-      if (sK == 0) x3_grp2_zero(gb[0], az[0][1], wfr[sK][0], gb[1], az[1][1], wfr[sK][0]);
-      else x3_grp2(gb[0], az[0][1], wfr[sK][0], gb[1], az[1][1], wfr[sK][0]);
-      x3_grp4(gs[0], az[0][0], wfr[sK][2], gs[1], az[1][0], wfr[sK][2], gb[0], az[0][0], wfr[sK][1], gb[1], az[1][0], wfr[sK][1]);
-      x3_grp2(gs[0], az[0][1], wfr[sK][1], gs[1], az[1][1], wfr[sK][1]);
-      if (sK + 1 < 4) load_az(sK + 1, 1);
-      x3_grp2(gb[0], az[0][0], wfr[sK][0], gb[1], az[1][0], wfr[sK][0]);
-      if (sK + 1 < 4) load_az(sK + 1, 0);
+      if constexpr (H2) {      // small terms l h + h l on gs, the leading h h on gb
+        if (sK == 0) h2_grp2_zero(gs[0], az[0][1], wfr[sK][0], gs[1], az[1][1], wfr[sK][0]);
+        else h2_grp2(gs[0], az[0][1], wfr[sK][0], gs[1], az[1][1], wfr[sK][0]);
+        if (sK + 1 < 4) load_az(sK + 1, 1);
+        if (sK == 0) h2_grp2_zero(gb[0], az[0][0], wfr[sK][0], gb[1], az[1][0], wfr[sK][0]);
+        else h2_grp2(gb[0], az[0][0], wfr[sK][0], gb[1], az[1][0], wfr[sK][0]);
+        h2_grp2(gs[0], az[0][0], wfr[sK][1], gs[1], az[1][0], wfr[sK][1]);
+        if (sK + 1 < 4) load_az(sK + 1, 0);
+      } else {
+        if (sK == 0) x3_grp2_zero(gs[0], az[0][2], wfr[sK][0], gs[1], az[1][2], wfr[sK][0]);
+        else x3_grp2(gs[0], az[0][2], wfr[sK][0], gs[1], az[1][2], wfr[sK][0]);
+        if (sK + 1 < 4) load_az(sK + 1, 2);
+        if (sK == 0) x3_grp2_zero(gb[0], az[0][1], wfr[sK][0], gb[1], az[1][1], wfr[sK][0]);
+        else x3_grp2(gb[0], az[0][1], wfr[sK][0], gb[1], az[1][1], wfr[sK][0]);
+        x3_grp4(gs[0], az[0][0], wfr[sK][NPL - 1], gs[1], az[1][0], wfr[sK][NPL - 1], gb[0], az[0][0], wfr[sK][1], gb[1], az[1][0], wfr[sK][1]);
+        x3_grp2(gs[0], az[0][1], wfr[sK][1], gs[1], az[1][1], wfr[sK][1]);
+        if (sK + 1 < 4) load_az(sK + 1, 1);
+        x3_grp2(gb[0], az[0][0], wfr[sK][0], gb[1], az[1][0], wfr[sK][0]);
+        if (sK + 1 < 4) load_az(sK + 1, 0);
+      }
     }
     POSB_STAMP(3);
     x3_drain(gb[0], gs[0], gb[1], gs[1]);
@@ -443,7 +525,12 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
       f32x2 dxh2[2][2], dxx2[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const f32x2 dhl = f32x2{gb[t].x, gb[t].y} + f32x2{gs[t].x, gs[t].y}, dhh = f32x2{gb[t].z, gb[t].w} + f32x2{gs[t].z, gs[t].w};
+        f32x2 dhl = f32x2{gb[t].x, gb[t].y} + f32x2{gs[t].x, gs[t].y}, dhh = f32x2{gb[t].z, gb[t].w} + f32x2{gs[t].z, gs[t].w};
+        if constexpr (H2) {      // undo the rows' dz scaling (and the fc1 planes' 2^7): factor = 2^-k / 128 per sample
+          fs4[t] = *reinterpret_cast<const f32x4 *>(t32L + P::F_OFF + 16 * t + 4 * kq);
+          dhl *= f32x2{fs4[t].x, fs4[t].y};
+          dhh *= f32x2{fs4[t].z, fs4[t].w};
+        }
         const f32x2 dh2[2] = {dhl, dhh};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -512,36 +599,47 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
       for (int r = 0; r < 4; ++r) {
 #if POS_BWD_PK
         h1v[t][r] = fmaxf((r & 1) ? y2[t][r >> 1].y : y2[t][r >> 1].x, 0.0f);      // the same fma(xh, g0, be0) as the relu mask's
+        if constexpr (H2) h1v[t][r] *= fs4[t][r];                                  // (scaled by kh1) x the row factor: <= 2^15
 #else
         h1v[t][r] = fmaxf(fmaf(xh[t][r], g0, be0), 0.0f);
 #endif
       }
-    const X3Frag fh = x3_split8(f32x4{h1v[0][0], h1v[0][1], h1v[0][2], h1v[0][3]}, f32x4{h1v[1][0], h1v[1][1], h1v[1][2], h1v[1][3]});
     const X3Frag fd = x3_split8(f32x4{dxv[0][0], dxv[0][1], dxv[0][2], dxv[0][3]}, f32x4{dxv[1][0], dxv[1][1], dxv[1][2], dxv[1][3]});
     // ---- dW1p[feature][o] += sum over the 32 samples of h1[sample][feature] dz[sample][o] ----
+    // B fragments of column blocks 4 hf .. 4 hf + 3 (sK = cb >> 1, half h = cb & 1 of each quad): K slots 0..3 = the lane group's
+    // four samples of tile 0, 4..7 = of tile 1 -- two transposing reads per (column block, plane)
+    auto tr_frag = [&](int cb, int pl) {
+      const uint32_t a0 = trb + tr_sk[cb >> 1] + 8u * (cb & 1) + 8192u * pl;
+      const u32x2_t v0 = pos_tr_read(a0), v1 = pos_tr_read(a0 + 4096u);
+      return u32x4{v0.x, v0.y, v1.x, v1.y};
+    };
+    if constexpr (H2) {
+      const H2Frag fh = h2_split8(f32x4{h1v[0][0], h1v[0][1], h1v[0][2], h1v[0][3]}, f32x4{h1v[1][0], h1v[1][1], h1v[1][2], h1v[1][3]});
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      // B fragments of column blocks 4 hf .. 4 hf + 3 (sK = cb >> 1, half h = cb & 1 of each quad): K slots 0..3 = the lane group's
-      // four samples of tile 0, 4..7 = of tile 1 -- two transposing reads per (column block, plane)
-      u32x4 bh[4], bm[4], bl[4];
+      for (int hf = 0; hf < 2; ++hf) {
+        u32x4 bh[4], bl[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int cb = 4 * hf + c;
-        const uint32_t a0 = trb + tr_sk[cb >> 1] + 8u * (cb & 1);
-        const u32x2_t h0 = pos_tr_read(a0), h1 = pos_tr_read(a0 + 4096u);
-        const u32x2_t m0 = pos_tr_read(a0 + 8192u), m1 = pos_tr_read(a0 + 8192u + 4096u);
-        const u32x2_t l0 = pos_tr_read(a0 + 16384u), l1 = pos_tr_read(a0 + 16384u + 4096u);
-        bh[c] = u32x4{h0.x, h0.y, h1.x, h1.y};
-        bm[c] = u32x4{m0.x, m0.y, m1.x, m1.y};
-        bl[c] = u32x4{l0.x, l0.y, l1.x, l1.y};
+        for (int c = 0; c < 4; ++c) { bh[c] = tr_frag(4 * hf + c, 0); bl[c] = tr_frag(4 * hf + c, 1); }
+        f32x4 *d = dw + 4 * hf;
+        h2_grp4(d[0], fh.l, bh[0], d[1], fh.l, bh[1], d[2], fh.l, bh[2], d[3], fh.l, bh[3]);
+        h2_grp4(d[0], fh.h, bl[0], d[1], fh.h, bl[1], d[2], fh.h, bl[2], d[3], fh.h, bl[3]);
+        h2_grp4(d[0], fh.h, bh[0], d[1], fh.h, bh[1], d[2], fh.h, bh[2], d[3], fh.h, bh[3]);
       }
-      f32x4 *d = dw + 4 * hf;
-      x3_grp4(d[0], fh.l, bh[0], d[1], fh.l, bh[1], d[2], fh.l, bh[2], d[3], fh.l, bh[3]);
-      x3_grp4(d[0], fh.h, bl[0], d[1], fh.h, bl[1], d[2], fh.h, bl[2], d[3], fh.h, bl[3]);
-      x3_grp4(d[0], fh.m, bm[0], d[1], fh.m, bm[1], d[2], fh.m, bm[2], d[3], fh.m, bm[3]);
-      x3_grp4(d[0], fh.m, bh[0], d[1], fh.m, bh[1], d[2], fh.m, bh[2], d[3], fh.m, bh[3]);
-      x3_grp4(d[0], fh.h, bm[0], d[1], fh.h, bm[1], d[2], fh.h, bm[2], d[3], fh.h, bm[3]);
-      x3_grp4(d[0], fh.h, bh[0], d[1], fh.h, bh[1], d[2], fh.h, bh[2], d[3], fh.h, bh[3]);
+    } else {
+      const X3Frag fh = x3_split8(f32x4{h1v[0][0], h1v[0][1], h1v[0][2], h1v[0][3]}, f32x4{h1v[1][0], h1v[1][1], h1v[1][2], h1v[1][3]});
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        u32x4 bh[4], bm[4], bl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bh[c] = tr_frag(4 * hf + c, 0); bm[c] = tr_frag(4 * hf + c, 1); bl[c] = tr_frag(4 * hf + c, NPL - 1); }
+        f32x4 *d = dw + 4 * hf;
+        x3_grp4(d[0], fh.l, bh[0], d[1], fh.l, bh[1], d[2], fh.l, bh[2], d[3], fh.l, bh[3]);
+        x3_grp4(d[0], fh.h, bl[0], d[1], fh.h, bl[1], d[2], fh.h, bl[2], d[3], fh.h, bl[3]);
+        x3_grp4(d[0], fh.m, bm[0], d[1], fh.m, bm[1], d[2], fh.m, bm[2], d[3], fh.m, bm[3]);
+        x3_grp4(d[0], fh.m, bh[0], d[1], fh.m, bh[1], d[2], fh.m, bh[2], d[3], fh.m, bh[3]);
+        x3_grp4(d[0], fh.h, bm[0], d[1], fh.h, bm[1], d[2], fh.h, bm[2], d[3], fh.h, bm[3]);
+        x3_grp4(d[0], fh.h, bh[0], d[1], fh.h, bh[1], d[2], fh.h, bh[2], d[3], fh.h, bh[3]);
+      }
     }
     POSB_STAMP(5);
     // ---- conv weight gradient: dWc[k][ch] += sum over samples of bit(sample, k) dx[sample][ch]; the bits of window
@@ -569,8 +667,10 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
   for (int hf = 0; hf < 2; ++hf) x3_drain(dw[4 * hf], dw[4 * hf + 1], dw[4 * hf + 2], dw[4 * hf + 3]);
   {
     f32x4 *out = reinterpret_cast<f32x4 *>(w1out);
+    // f16x2: the accumulators hold sum (kh1 h1 f) (dz / (128 f)) = (kh1 / 128) dW1 -- kh1 a power of two: the product is exact
+    const float wsc = H2 ? H2_W_SCALE / kh1 : 1.0f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) out[(p * 8 + c) * 64 + lane] = dw[c];
+    for (int c = 0; c < 8; ++c) out[(p * 8 + c) * 64 + lane] = H2 ? dw[c] * wsc : dw[c];
   }
   float *part = reinterpret_cast<float *>(pos_smem);   // [8 waves][CONVBLK]: the ring is dead (last barrier passed)
   static_assert((size_t)8 * CONVBLK * sizeof(float) <= (size_t)P::RS * P::SLOT * 16, "conv partials must fit the ring");
@@ -638,20 +738,20 @@ PQN_D float pos_quad_sum1(float a) {
 #ifndef POS_PAIR_SYNC_FWD
 #define POS_PAIR_SYNC_FWD 1     // forward kernel: one barrier per two K steps over a four-slot ring (see POS_PAIR_SYNC)
 #endif
-template <int C>
+template <int C, int NPL = 3>
 struct PosFwdCfg {
-  using P = PosCfg<C>;
-  static constexpr int N_W = 1536;                                  // chunks of one K step's planes: [3][8 cb][64]
+  using P = PosCfg<C, NPL>;
+  static constexpr int N_W = NPL * 512;                             // chunks of one K step's planes: [NPL][8 cb][64]
   static constexpr int ROWW = POS_ST * P::ROWSTRIDE * 4;            // words of a wave's packed rows
   static constexpr int DZS = 132;                                   // LDS row stride of the dz transposition tile
   static constexpr int RS = POS_PAIR_SYNC_FWD ? 4 : 2;              // ring slots
   static constexpr size_t ring_bytes = (size_t)RS * N_W * 16;
   static constexpr size_t rows_bytes = (size_t)8 * ROWW * 4;
   static constexpr size_t misc_floats(int a) { return ((P::CONVBLK + 3) & ~3) + ((384 + 128 * a + a + 3) & ~3) + 8 * 64 + 1024; }   // + the pos_expand8 table
-  static constexpr size_t loop_bytes(int a) { return ring_bytes + rows_bytes + (size_t)P::NCS * 3 * 64 * 16 + sizeof(float) * misc_floats(a); }
+  static constexpr size_t loop_bytes(int a) { return ring_bytes + rows_bytes + (size_t)P::NCS * NPL * 64 * 16 + sizeof(float) * misc_floats(a); }
   static constexpr size_t tail_bytes = (size_t)8 * POS_ST * DZS * 4;   // dz tiles of the eight waves (over ring + rows)
   static constexpr size_t lds_bytes(int a) {
-    const size_t fixed = (size_t)P::NCS * 3 * 64 * 16 + sizeof(float) * misc_floats(a);
+    const size_t fixed = (size_t)P::NCS * NPL * 64 * 16 + sizeof(float) * misc_floats(a);
     const size_t front = ring_bytes + rows_bytes > tail_bytes ? ring_bytes + rows_bytes : tail_bytes;
     return front + fixed;
   }
@@ -668,35 +768,60 @@ struct PosFwdCfg {
 // holds K steps kk0 and kk0 + 1 (visible to every wave); on exit it holds kk0 + 32 and kk0 + 33, i.e. steps 0 and 1 again.
 template <int C>
 struct PosFwdCtx {
-  const u32x4 *wf;            // forward-order W1 planes of this seed [3][32 steps][8 cb][64]
-  const u32x4 *ring;          // LDS ring of K-step plane sets [RS][3][8][64]
+  const u32x4 *wf;            // forward-order W1 planes of this seed [NPL][32 steps][8 cb][64]
+  const u32x4 *ring;          // LDS ring of K-step plane sets [RS][NPL][8][64]
   uint32_t ring_lds;
   const u32x4 *s_cvw, *s_lut; // conv kernel planes [K step][plane][lane]; pos_expand8 table
   const uint32_t *rowsW;      // this wave's packed rows [32][ROWSTRIDE * 4]
   float *g_stat;              // LayerNorm_0 statistics of this wave's super-tile [64 pos][32][2] (STATS only)
   int lane, wave, i16, g;
-  float cbias[4], cg0[4], cbe0[4];   // conv bias / LayerNorm_0 scale, bias of channels 4 g .. 4 g + 3
+  float cbias[4], cg0[4], cbe0[4];   // conv bias / LayerNorm_0 scale, bias of channels 4 g .. 4 g + 3 (f16x2: scale, bias times the h1 operand scale)
+  float oscale;                      // conv accumulator -> conv output (bf16x3: 0.5 / 255; f16x2: that over the conv kernel's scale)
+  float zscale;                      // f16x2: fc1 accumulator -> z (1 / (h1 scale * 128))
   unsigned long long *stamps;
 };
-template <int C>
+// per-wave constants of the K loop from the LDS copy of the conv block (after the barrier that completes it)
+template <int C, int NPL>
+PQN_D float pos_fwd_consts(PosFwdCtx<C> &cx, const float *s_wc) {   // returns the conv kernel's scale (the plane builder's argument)
+  using Cfg = CnnCfg<C>;
+  float sc = 1.0f, sh = 1.0f;
+  cx.oscale = ConvX3<C>::OUT_SCALE;
+  cx.zscale = 1.0f;
+  if constexpr (NPL == 2) {
+    sc = pos_h2_conv_scale<C>(s_wc, cx.lane);
+    sh = pos_h2_h1_scale<C>(s_wc, cx.lane);
+    cx.oscale = ConvX3<C>::OUT_SCALE / sc;
+    cx.zscale = 1.0f / (sh * H2_W_SCALE);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    cx.cbias[r] = s_wc[Cfg::KW * 16 + 4 * cx.g + r];
+    cx.cg0[r] = s_wc[Cfg::KW * 16 + 16 + 4 * cx.g + r] * sh;
+    cx.cbe0[r] = s_wc[Cfg::KW * 16 + 32 + 4 * cx.g + r] * sh;
+  }
+  return sc;
+}
+template <int C, int NPL>
 PQN_D void pos_fwd_dma_step(const PosFwdCtx<C> &cx, int kk) {   // K step kk & 31 -> slot kk % RS; wave w moves column block w of each plane
-  using F = PosFwdCfg<C>;
+  using F = PosFwdCfg<C, NPL>;
   const uint32_t offW = (uint32_t)(cx.lane * 16);
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl)
+  for (int pl = 0; pl < NPL; ++pl)
     pos_dma16(offW, cx.wf + (size_t)pl * (X3_PLANE / 8) + ((kk & 31) * 8 + cx.wave) * 64,
               cx.ring_lds + (uint32_t)(((kk & (F::RS - 1)) * F::N_W + (pl * 8 + cx.wave) * 64) * 16));
 }
-template <int C, bool STATS>
+template <int C, int NPL, bool STATS>
 PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
-  using P = PosCfg<C>;
-  using F = PosFwdCfg<C>;
+  using P = PosCfg<C, NPL>;
+  using F = PosFwdCfg<C, NPL>;
+  using M = PosMM<NPL>;
+  constexpr bool H2 = NPL == 2;
   constexpr int RB = P::RB, NCS = P::NCS;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   unsigned long long *stamps = cx.stamps;
   const int lane = cx.lane, wave = cx.wave;
   (void)stamps; (void)lane; (void)wave;
-  auto dma_step = [&](int kk) { pos_fwd_dma_step<C>(cx, kk); };
+  auto dma_step = [&](int kk) { pos_fwd_dma_step<C, NPL>(cx, kk); };
   // window masks of sample (16 t + lane & 15) at the two positions of K step sn: p0 = 8 py + pxb, p1 = p0 + 1 (same window
   // rows, one column apart) -- in two halves: the LDS reads, and (once they have arrived) the shifts
   auto mask_words = [&](int sn, uint32_t (&lo)[3][2], uint32_t (&hi)[3][2]) {
@@ -755,15 +880,18 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int t = 0; t < 2; ++t) fa[q][t] = pos_expand8<C>(cx.s_lut, __builtin_amdgcn_ubfe(ConvX3<C>::word(mk[q][t], sx), 8u * cx.g, 8u));
-      const u32x4 wh = cx.s_cvw[(sx * 3 + 0) * 64 + cx.lane], wm = cx.s_cvw[(sx * 3 + 1) * 64 + cx.lane], wl = cx.s_cvw[(sx * 3 + 2) * 64 + cx.lane];
+      const u32x4 wh = cx.s_cvw[(sx * NPL + 0) * 64 + cx.lane], wl = cx.s_cvw[(sx * NPL + NPL - 1) * 64 + cx.lane];
       if (sx == 0) {
-        x3_grp4_zero(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
-        x3_grp4_zero(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
+        M::grp4_zero(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
+        M::grp4_zero(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
       } else {
-        x3_grp4(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
-        x3_grp4(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
+        M::grp4(cs_[0][0], wl, fa[0][0], cs_[0][1], wl, fa[0][1], cs_[1][0], wl, fa[1][0], cs_[1][1], wl, fa[1][1]);
+        M::grp4(cb_[0][0], wh, fa[0][0], cb_[0][1], wh, fa[0][1], cb_[1][0], wh, fa[1][0], cb_[1][1], wh, fa[1][1]);
       }
-      x3_grp4(cs_[0][0], wm, fa[0][0], cs_[0][1], wm, fa[0][1], cs_[1][0], wm, fa[1][0], cs_[1][1], wm, fa[1][1]);
+      if constexpr (!H2) {
+        const u32x4 wm = cx.s_cvw[(sx * 3 + 1) * 64 + cx.lane];
+        x3_grp4(cs_[0][0], wm, fa[0][0], cs_[0][1], wm, fa[0][1], cs_[1][0], wm, fa[1][0], cs_[1][1], wm, fa[1][1]);
+      }
     }
     // the next K step's window words (the rows are this wave's own: always resident) go out now, in the conv's shadow
     uint32_t nlo[3][2], nhi[3][2];
@@ -776,7 +904,7 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const f32x4 cvo = (cb_[q][t] + cs_[q][t]) * ConvX3<C>::OUT_SCALE;
+        const f32x4 cvo = (cb_[q][t] + cs_[q][t]) * cx.oscale;
         const float v[4] = {cvo.x + cx.cbias[0], cvo.y + cx.cbias[1], cvo.z + cx.cbias[2], cvo.w + cx.cbias[3]};
         float sum = (v[0] + v[1]) + (v[2] + v[3]);
         float sq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
@@ -800,28 +928,44 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
     POSF_STAMP(2);
     // ---- fc1: K slots 0..3 = position p0's channels 4 g .., 4..7 = p1's (x3_fwd_index); the fragments of column-block pair
     // c + 1 are read while the 24 MFMAs of pair c issue (two register sets) ----
-    X3Frag af[2];
+    // (f16x2: y already carries the h1 operand scale through cg0 / cbe0)
+    u32x4 afh[2], afm[2], afl[2];
+    (void)afm;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-      af[t] = x3_split8(f32x4{y[0][t][0], y[0][t][1], y[0][t][2], y[0][t][3]}, f32x4{y[1][t][0], y[1][t][1], y[1][t][2], y[1][t][3]});
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 ya = {y[0][t][0], y[0][t][1], y[0][t][2], y[0][t][3]}, yb = {y[1][t][0], y[1][t][1], y[1][t][2], y[1][t][3]};
+      if constexpr (H2) {
+        const H2Frag f = h2_split8(ya, yb);
+        afh[t] = f.h; afl[t] = f.l;
+      } else {
+        const X3Frag f = x3_split8(ya, yb);
+        afh[t] = f.h; afm[t] = f.m; afl[t] = f.l;
+      }
+    }
     POSF_STAMP(3);
-    u32x4 bf[2][6];                                      // [set][h0 m0 l0 h1 m1 l1]
-    auto load_b = [&](int c, u32x4 (&d)[6]) {
-      d[0] = slot[(0 * 8 + c) * 64]; d[1] = slot[(1 * 8 + c) * 64]; d[2] = slot[(2 * 8 + c) * 64];
-      d[3] = slot[(0 * 8 + c + 1) * 64]; d[4] = slot[(1 * 8 + c + 1) * 64]; d[5] = slot[(2 * 8 + c + 1) * 64];
+    u32x4 bf[2][2 * NPL];                                // [set][planes of block c | planes of block c + 1], storage order (h, m, l / h, l)
+    auto load_b = [&](int c, u32x4 (&d)[2 * NPL]) {
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) { d[pl] = slot[(pl * 8 + c) * 64]; d[NPL + pl] = slot[(pl * 8 + c + 1) * 64]; }
     };
     load_b(0, bf[0]);
 #pragma unroll
     for (int c = 0; c < 8; c += 2) {
       if (c + 2 < 8) load_b(c + 2, bf[((c >> 1) + 1) & 1]);
-      const u32x4 (&b)[6] = bf[(c >> 1) & 1];
+      const u32x4 (&b)[2 * NPL] = bf[(c >> 1) & 1];
       f32x4 &z00 = zacc[0][c], &z10 = zacc[1][c], &z01 = zacc[0][c + 1], &z11 = zacc[1][c + 1];
-      x3_grp4(z00, af[0].l, b[0], z10, af[1].l, b[0], z01, af[0].l, b[3], z11, af[1].l, b[3]);
-      x3_grp4(z00, af[0].h, b[2], z10, af[1].h, b[2], z01, af[0].h, b[5], z11, af[1].h, b[5]);
-      x3_grp4(z00, af[0].m, b[1], z10, af[1].m, b[1], z01, af[0].m, b[4], z11, af[1].m, b[4]);
-      x3_grp4(z00, af[0].m, b[0], z10, af[1].m, b[0], z01, af[0].m, b[3], z11, af[1].m, b[3]);
-      x3_grp4(z00, af[0].h, b[1], z10, af[1].h, b[1], z01, af[0].h, b[4], z11, af[1].h, b[4]);
-      x3_grp4(z00, af[0].h, b[0], z10, af[1].h, b[0], z01, af[0].h, b[3], z11, af[1].h, b[3]);
+      if constexpr (H2) {
+        h2_grp4(z00, afl[0], b[0], z10, afl[1], b[0], z01, afl[0], b[2], z11, afl[1], b[2]);
+        h2_grp4(z00, afh[0], b[1], z10, afh[1], b[1], z01, afh[0], b[3], z11, afh[1], b[3]);
+        h2_grp4(z00, afh[0], b[0], z10, afh[1], b[0], z01, afh[0], b[2], z11, afh[1], b[2]);
+      } else {
+        x3_grp4(z00, afl[0], b[0], z10, afl[1], b[0], z01, afl[0], b[3], z11, afl[1], b[3]);
+        x3_grp4(z00, afh[0], b[2], z10, afh[1], b[2], z01, afh[0], b[5], z11, afh[1], b[5]);
+        x3_grp4(z00, afm[0], b[1], z10, afm[1], b[1], z01, afm[0], b[4], z11, afm[1], b[4]);
+        x3_grp4(z00, afm[0], b[0], z10, afm[1], b[0], z01, afm[0], b[3], z11, afm[1], b[3]);
+        x3_grp4(z00, afh[0], b[1], z10, afh[1], b[1], z01, afh[0], b[4], z11, afh[1], b[4]);
+        x3_grp4(z00, afh[0], b[0], z10, afh[1], b[0], z01, afh[0], b[3], z11, afh[1], b[3]);
+      }
     }
     POSF_STAMP(4);
     if (POS_PAIR_SYNC_FWD == 0 || (s & 1) != 0) {
@@ -832,21 +976,22 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
   }
 }
 
-template <int C, int NA>
+template <int C, int NA, int NPL>
 __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
                                                                   float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd,
                                                                   unsigned long long *__restrict__ stamps) {
-  using P = PosCfg<C>;
-  using F = PosFwdCfg<C>;
+  using P = PosCfg<C, NPL>;
+  using F = PosFwdCfg<C, NPL>;
   using Cfg = CnnCfg<C>;
+  constexpr bool H2 = NPL == 2;
   constexpr int CONVBLK = P::CONVBLK, NCS = P::NCS;
   constexpr int REC = CONVBLK + 384 + 128 * NA + NA + 2;
   extern __shared__ __attribute__((aligned(16))) char pos_smem[];
   constexpr size_t FRONT = F::ring_bytes + F::rows_bytes > F::tail_bytes ? F::ring_bytes + F::rows_bytes : F::tail_bytes;
-  u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);                               // [2][3][8][64]
+  u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);                               // [RS][NPL][8][64]
   uint32_t *s_rows = reinterpret_cast<uint32_t *>(pos_smem + F::ring_bytes);       // [8 waves][32][ROWSTRIDE * 4]
   u32x4 *s_cvw = reinterpret_cast<u32x4 *>(pos_smem + FRONT);                       // conv kernel planes [K step][plane][lane]
-  float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * 3 * 64);                    // conv kernel | bias | ln0 scale | ln0 bias
+  float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * NPL * 64);                  // conv kernel | bias | ln0 scale | ln0 bias
   float *s_hp = s_wc + ((CONVBLK + 3) & ~3);                                        // b1 | ln1 scale | ln1 bias | w2[128][A] | b2
   float *s_at = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                            // [8 waves][32 act (as int) | 32 tgt]
   u32x4 *s_lut = reinterpret_cast<u32x4 *>(s_at + 8 * 64);                          // pos_expand8 table
@@ -872,13 +1017,13 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   const int i16 = lane & 15, g = lane >> 4;          // conv phase: sample column, channels 4 g .. 4 g + 3; head: output column, rows 4 g ..
   const int st = blk * 8 + wave;                     // this wave's super-tile
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const u32x4 *wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h);   // forward-order planes [3][32 steps][8 cb][64]
+  const u32x4 *wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h + (H2 ? H2_PLANES_OFF : 0));   // forward-order planes [NPL][32 steps][8 cb][64]
   const uint32_t ring_lds = pos_lds_addr(ring);
   {   // the first two K steps' planes go out before anything else
     PosFwdCtx<C> c0;
     c0.wf = wf; c0.ring_lds = ring_lds; c0.lane = lane; c0.wave = wave;
-    pos_fwd_dma_step<C>(c0, 0);
-    if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C>(c0, 1);
+    pos_fwd_dma_step<C, NPL>(c0, 0);
+    if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C, NPL>(c0, 1);
   }
   // ---- prologue: parameters, this wave's packed rows / actions / targets ----
   for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
@@ -900,38 +1045,22 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   }
   pos_dma_wait();
   __syncthreads();
-  if (wave == 0) {
-    ConvX3<C> cv;
-    cv.init(s_wc, lane);
-#pragma unroll
-    for (int sx = 0; sx < NCS; ++sx) {
-      s_cvw[(sx * 3 + 0) * 64 + lane] = cv.w[sx].h;
-      s_cvw[(sx * 3 + 1) * 64 + lane] = cv.w[sx].m;
-      s_cvw[(sx * 3 + 2) * 64 + lane] = cv.w[sx].l;
-    }
-  }
-  __syncthreads();
-  // lane constants of the transposed conv: channels 4 g .. 4 g + 3
-  float cbias[4], cg0[4], cbe0[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    cbias[r] = s_wc[Cfg::KW * 16 + 4 * g + r];
-    cg0[r] = s_wc[Cfg::KW * 16 + 16 + 4 * g + r];
-    cbe0[r] = s_wc[Cfg::KW * 16 + 32 + 4 * g + r];
-  }
   const uint32_t *rowsW = s_rows + wave * F::ROWW;
   float *g_stat = wsx + W.stats + (size_t)st * (64 * POS_ST * 2);
+  PosFwdCtx<C> cx;
+  cx.wf = wf; cx.ring = ring; cx.ring_lds = ring_lds; cx.s_cvw = s_cvw; cx.s_lut = s_lut; cx.rowsW = rowsW; cx.g_stat = g_stat;
+  cx.lane = lane; cx.wave = wave; cx.i16 = i16; cx.g = g; cx.stamps = stamps;
+  {   // lane constants of the transposed conv (channels 4 g .. 4 g + 3), the operand scales, the conv kernel's planes
+    const float sc = pos_fwd_consts<C, NPL>(cx, s_wc);
+    if (wave == 0) pos_conv_planes<C, NPL>(s_wc, s_cvw, lane, sc);
+  }
+  __syncthreads();
   f32x4 zacc[2][8];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int c = 0; c < 8; ++c) zacc[t][c] = zero4;
-  PosFwdCtx<C> cx;
-  cx.wf = wf; cx.ring = ring; cx.ring_lds = ring_lds; cx.s_cvw = s_cvw; cx.s_lut = s_lut; cx.rowsW = rowsW; cx.g_stat = g_stat;
-  cx.lane = lane; cx.wave = wave; cx.i16 = i16; cx.g = g; cx.stamps = stamps;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { cx.cbias[r] = cbias[r]; cx.cg0[r] = cg0[r]; cx.cbe0[r] = cbe0[r]; }
-  pos_fwd_kloop<C, true>(cx, 0, zacc);
+  pos_fwd_kloop<C, NPL, true>(cx, 0, zacc);
   { const int s = 0; (void)s; POSF_STAMP(8); }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -961,7 +1090,12 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
     float zz[8][4];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      zz[c][0] = zacc[t][c].x + hb1[c]; zz[c][1] = zacc[t][c].y + hb1[c]; zz[c][2] = zacc[t][c].z + hb1[c]; zz[c][3] = zacc[t][c].w + hb1[c];
+      if constexpr (H2) {   // accumulator / (h1 scale * 128): a power of two, so the fma rounds once, like the add
+        zz[c][0] = fmaf(zacc[t][c].x, cx.zscale, hb1[c]); zz[c][1] = fmaf(zacc[t][c].y, cx.zscale, hb1[c]);
+        zz[c][2] = fmaf(zacc[t][c].z, cx.zscale, hb1[c]); zz[c][3] = fmaf(zacc[t][c].w, cx.zscale, hb1[c]);
+      } else {
+        zz[c][0] = zacc[t][c].x + hb1[c]; zz[c][1] = zacc[t][c].y + hb1[c]; zz[c][2] = zacc[t][c].z + hb1[c]; zz[c][3] = zacc[t][c].w + hb1[c];
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1040,16 +1174,46 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
     const size_t pa = (size_t)nb * 16;
     // (the tile was written by this wave only: no barrier, the compiler orders the LDS reads behind the writes)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      f32x4 va[4], vb[4];       // sample row 16 t + i16: this lane's 32 of its 128 values (lanes g = 0..3 hold the rest)
 #pragma unroll
       for (int sK = 0; sK < 4; ++sK) {
         const float *zr = dzt + (16 * t + i16) * F::DZS + 32 * sK + 4 * g;
-        const X3Frag f = x3_split8(*reinterpret_cast<const f32x4 *>(zr), *reinterpret_cast<const f32x4 *>(zr + 16));
-        const size_t e = ((size_t)st * POS_ST + 16 * t + i16) * 16 + sK * 4 + g;
-        g_dza[e] = f.h;
-        g_dza[pa + e] = f.m;
-        g_dza[2 * pa + e] = f.l;
+        va[sK] = *reinterpret_cast<const f32x4 *>(zr);
+        vb[sK] = *reinterpret_cast<const f32x4 *>(zr + 16);
       }
+      if constexpr (H2) {       // the row goes out scaled into [2^14, 2^15) by its own power of two; the backward gets 2^-k / 128
+        float am = 0.0f;
+#pragma unroll
+        for (int sK = 0; sK < 4; ++sK) {
+          am = fmaxf(fmaxf(am, fmaxf(fabsf(va[sK].x), fabsf(va[sK].y))), fmaxf(fabsf(va[sK].z), fabsf(va[sK].w)));
+          am = fmaxf(fmaxf(am, fmaxf(fabsf(vb[sK].x), fabsf(vb[sK].y))), fmaxf(fabsf(vb[sK].z), fabsf(vb[sK].w)));
+        }
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        int e = __builtin_amdgcn_frexp_expf(am);
+        e = e < -40 ? -40 : (e > 60 ? 60 : e);
+        const float inv = __int_as_float((127 + 15 - e) << 23);
+        // (stored by all four g lanes of the sample -- the same bits: a lane-masked store here is a branch, and with it the kernel spilled 85 VGPRs)
+        (wsx + W.t32 + (size_t)st * P::TW + P::F_OFF)[16 * t + i16] = __int_as_float((127 + e - 15 - H2_W_SHIFT) << 23);
+#pragma unroll
+        for (int sK = 0; sK < 4; ++sK) { va[sK] *= inv; vb[sK] *= inv; }
+      }
+#pragma unroll
+      for (int sK = 0; sK < 4; ++sK) {
+        const size_t e = ((size_t)st * POS_ST + 16 * t + i16) * 16 + sK * 4 + g;
+        if constexpr (H2) {
+          const H2Frag f = h2_split8(va[sK], vb[sK]);
+          g_dza[e] = f.h;
+          g_dza[pa + e] = f.l;
+        } else {
+          const X3Frag f = x3_split8(va[sK], vb[sK]);
+          g_dza[e] = f.h;
+          g_dza[pa + e] = f.m;
+          g_dza[2 * pa + e] = f.l;
+        }
+      }
+    }
   }
   // ---- the workgroup's record of head-parameter gradient sums: rows of the lane -> the 4 row groups -> the 8 waves ----
   __syncthreads();                                       // every wave is done with its dz tile: the front of the LDS becomes the record scratch
@@ -1104,24 +1268,25 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
 // barriers synchronises the waves.  q is summed in the K order of the training forward kernel (one chain over the 32 K steps),
 // not in the order of the 16-env kernels of pqn_qnet.hip: the two agree to f32 rounding, not bit for bit.
 // ---------------------------------------------------------------------------
-template <int C, int NA>
+template <int C, int NA, int NPL>
 struct PosRollCfg {
-  using P = PosCfg<C>;
-  using F = PosFwdCfg<C>;
+  using P = PosCfg<C, NPL>;
+  using F = PosFwdCfg<C, NPL>;
   static constexpr size_t fixed_floats = ((P::CONVBLK + 3) & ~3) + ((384 + 128 * NA + NA + 3) & ~3) + 8 * POS_ST * 8 + 1024;
-  static constexpr size_t lds_bytes = F::ring_bytes + F::rows_bytes + (size_t)P::NCS * 3 * 64 * 16 + sizeof(float) * fixed_floats;
+  static constexpr size_t lds_bytes = F::ring_bytes + F::rows_bytes + (size_t)P::NCS * NPL * 64 * 16 + sizeof(float) * fixed_floats;
 };
 
-template <int C, class Env, int NA>
+template <int C, class Env, int NA, int NPL>
 __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
     int n, int t_len, uint32_t *__restrict__ state, uint32_t *__restrict__ bits_all, const float *__restrict__ theta,
     pqn_cnn_layout_t L, int32_t *__restrict__ action, float *__restrict__ qmax, float *__restrict__ reward,
     uint8_t *__restrict__ done, float *__restrict__ discount, float *__restrict__ rer, int32_t *__restrict__ rel,
     int32_t *__restrict__ ts, float *__restrict__ last_q, const float *__restrict__ eps_dev,
     const uint64_t *__restrict__ keys, float rscale, int store_obs, int n_per_seed, long long theta_stride, int keys_stride) {
-  using P = PosCfg<C>;
-  using F = PosFwdCfg<C>;
+  using P = PosCfg<C, NPL>;
+  using F = PosFwdCfg<C, NPL>;
   using Cfg = CnnCfg<C>;
+  constexpr bool H2 = NPL == 2;
   static_assert(Cfg::OW == Env::OBS_WORDS, "packed observation width");
   static_assert(NA <= 8, "q exchange buffer");
   constexpr int CONVBLK = P::CONVBLK, NCS = P::NCS;
@@ -1129,7 +1294,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
   u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);
   uint32_t *s_rows = reinterpret_cast<uint32_t *>(pos_smem + F::ring_bytes);
   u32x4 *s_cvw = reinterpret_cast<u32x4 *>(pos_smem + F::ring_bytes + F::rows_bytes);
-  float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * 3 * 64);
+  float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * NPL * 64);
   float *s_hp = s_wc + ((CONVBLK + 3) & ~3);
   float *s_q = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                              // [8 waves][32 envs][8]
   u32x4 *s_lut = reinterpret_cast<u32x4 *>(s_q + 8 * POS_ST * 8);
@@ -1162,12 +1327,12 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
   const size_t bstride = (size_t)n * Cfg::OW;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   PosFwdCtx<C> cx;
-  cx.wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h);
+  cx.wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h + (H2 ? H2_PLANES_OFF : 0));
   cx.ring = ring; cx.ring_lds = pos_lds_addr(ring); cx.s_cvw = s_cvw; cx.s_lut = s_lut;
   cx.rowsW = s_rows + wave * F::ROWW; cx.g_stat = nullptr;
   cx.lane = lane; cx.wave = wave; cx.i16 = i16; cx.g = g; cx.stamps = nullptr;
-  pos_fwd_dma_step<C>(cx, 0);
-  if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C>(cx, 1);
+  pos_fwd_dma_step<C, NPL>(cx, 0);
+  if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C, NPL>(cx, 1);
   for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
   for (int i = tid; i < 384; i += POS_THREADS) s_hp[i] = theta[L.off_b1 + i];
   for (int i = tid; i < 128 * NA; i += POS_THREADS) s_hp[384 + i] = theta[L.off_w2 + i];
@@ -1194,23 +1359,11 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
   const float eps = *eps_dev;
   pos_dma_wait();
   __syncthreads();
-  if (wave == 0) {
-    ConvX3<C> cv;
-    cv.init(s_wc, lane);
-#pragma unroll
-    for (int sx = 0; sx < NCS; ++sx) {
-      s_cvw[(sx * 3 + 0) * 64 + lane] = cv.w[sx].h;
-      s_cvw[(sx * 3 + 1) * 64 + lane] = cv.w[sx].m;
-      s_cvw[(sx * 3 + 2) * 64 + lane] = cv.w[sx].l;
-    }
+  {
+    const float sc = pos_fwd_consts<C, NPL>(cx, s_wc);
+    if (wave == 0) pos_conv_planes<C, NPL>(s_wc, s_cvw, lane, sc);
   }
   __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    cx.cbias[r] = s_wc[Cfg::KW * 16 + 4 * g + r];
-    cx.cg0[r] = s_wc[Cfg::KW * 16 + 16 + 4 * g + r];
-    cx.cbe0[r] = s_wc[Cfg::KW * 16 + 32 + 4 * g + r];
-  }
   float *qx = s_q + wave * (POS_ST * 8);
 #pragma unroll 1
   for (int t = 0; t <= t_len; ++t) {
@@ -1219,7 +1372,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int c = 0; c < 8; ++c) zacc[tt][c] = zero4;
-    pos_fwd_kloop<C, false>(cx, 32 * t, zacc);
+    pos_fwd_kloop<C, NPL, false>(cx, 32 * t, zacc);
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -1232,7 +1385,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
         float zz[8], sum = 0.f, sq = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          zz[c] = zacc[tt][c][r] + s_hp[16 * c + i16];
+          zz[c] = H2 ? fmaf(zacc[tt][c][r], cx.zscale, s_hp[16 * c + i16]) : zacc[tt][c][r] + s_hp[16 * c + i16];
           sum += zz[c];
           sq = fmaf(zz[c], zz[c], sq);
         }
@@ -1317,21 +1470,27 @@ extern "C" int pqn_debug_pos_stamps(unsigned long long *out /* host, 32 entries 
   return PQN_OK;
 }
 
-template <int C, int NA>
-static int pos_forward_launch(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
-                              const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
-  using F = PosFwdCfg<C>;
+template <int C, int NA, int NPL>
+static int pos_forward_launch_m(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
+                                const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
+  using F = PosFwdCfg<C, NPL>;
   static pqn_once_per_device attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_fwd_kernel<C, NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_fwd_kernel<C, NA, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)F::lds_bytes(NA));
   }
   if (!g_pos_stamps && getenv("PQN_T1_STAMPS") && pqn_not_capturing(st)) {   // (profiling only; an allocation is illegal under stream capture)
     if (hipMalloc(&g_pos_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_pos_stamps = nullptr;
   }
-  hipLaunchKernelGGL((cnn_pos_fwd_kernel<C, NA>), dim3((nb / 256) * nseeds), dim3(POS_THREADS), F::lds_bytes(NA), st, nb, theta, L, inv_b,
+  hipLaunchKernelGGL((cnn_pos_fwd_kernel<C, NA, NPL>), dim3((nb / 256) * nseeds), dim3(POS_THREADS), F::lds_bytes(NA), st, nb, theta, L, inv_b,
                      wsx, W, sg, g_pos_stamps);
   return pqn_check_launch("pqn_cnn_pos_forward");
+}
+template <int C, int NA>
+static int pos_forward_launch(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
+                              const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
+  return L.pos_f16x2 ? pos_forward_launch_m<C, NA, 2>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st)
+                     : pos_forward_launch_m<C, NA, 3>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
 }
 
 // the (channels, actions) pairs of the MinAtar games gymnax implements
@@ -1363,21 +1522,27 @@ int pqn_cnn_pos_gather(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, co
   }
 }
 
-template <int C>
-static int pos_backward_launch(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out,
-                               const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
-  using P = PosCfg<C>;
+template <int C, int NPL>
+static int pos_backward_launch_m(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out,
+                                 const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
+  using P = PosCfg<C, NPL>;
   static pqn_once_per_device attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_bwd_kernel<C, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)P::lds_bytes());
   }
   if (!g_pos_stamps && getenv("PQN_T1_STAMPS") && pqn_not_capturing(st)) {   // (profiling only; an allocation is illegal under stream capture)
     if (hipMalloc(&g_pos_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_pos_stamps = nullptr;
   }
-  hipLaunchKernelGGL((cnn_pos_bwd_kernel<C>), dim3(8 * nch * nseeds), dim3(POS_THREADS), P::lds_bytes(), st, nb, nch, theta, L, wsx, w1out,
+  hipLaunchKernelGGL((cnn_pos_bwd_kernel<C, NPL>), dim3(8 * nch * nseeds), dim3(POS_THREADS), P::lds_bytes(), st, nb, nch, theta, L, wsx, w1out,
                      W, sg, g_pos_stamps);
   return pqn_check_launch("pqn_cnn_pos_backward");
+}
+template <int C>
+static int pos_backward_launch(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out,
+                               const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
+  return L.pos_f16x2 ? pos_backward_launch_m<C, 2>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, st)
+                     : pos_backward_launch_m<C, 3>(L, nb, nch, theta, wsx, w1out, W, sg, nseeds, st);
 }
 
 int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out, const pos_ws_t &W,
@@ -1390,22 +1555,32 @@ int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float
   }
 }
 
+template <int C, class Env, int NA, int NPL>
+static int pos_rollout_launch_m(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
+                                const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
+                                const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed,
+                                long long theta_stride, int keys_stride) {
+  using R = PosRollCfg<C, NA, NPL>;
+  static pqn_once_per_device attr;
+  if (attr.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_rollout_kernel<C, Env, NA, NPL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::lds_bytes);
+  }
+  hipLaunchKernelGGL((cnn_pos_rollout_kernel<C, Env, NA, NPL>), dim3(n / 256), dim3(POS_THREADS), R::lds_bytes, st, n, t_len, state, bits, theta,
+                     L, action, qmax, rec.reward, rec.done, rec.discount, rec.returned_episode_returns,
+                     rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys, rscale, store_obs, n_per_seed, theta_stride,
+                     keys_stride);
+  return pqn_check_launch("pqn_cnn_pos_rollout");
+}
 template <int C, class Env, int NA>
 static int pos_rollout_launch(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
                               const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
                               const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed,
                               long long theta_stride, int keys_stride) {
-  using R = PosRollCfg<C, NA>;
-  static pqn_once_per_device attr;
-  if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_rollout_kernel<C, Env, NA>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::lds_bytes);
-  }
-  hipLaunchKernelGGL((cnn_pos_rollout_kernel<C, Env, NA>), dim3(n / 256), dim3(POS_THREADS), R::lds_bytes, st, n, t_len, state, bits, theta,
-                     L, action, qmax, rec.reward, rec.done, rec.discount, rec.returned_episode_returns,
-                     rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys, rscale, store_obs, n_per_seed, theta_stride,
-                     keys_stride);
-  return pqn_check_launch("pqn_cnn_pos_rollout");
+  return L.pos_f16x2 ? pos_rollout_launch_m<C, Env, NA, 2>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale,
+                                                           store_obs, st, n_per_seed, theta_stride, keys_stride)
+                     : pos_rollout_launch_m<C, Env, NA, 3>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale,
+                                                           store_obs, st, n_per_seed, theta_stride, keys_stride);
 }
 
 bool pqn_cnn_pos_rollout_supported(int env_id, int c, int a, int n, int n_per_seed) {

@@ -283,6 +283,109 @@ PQN_D void x3_mfma6(const X3Frag &a, const X3Frag &b, f32x4 &acc_b, f32x4 &acc_s
   acc_b = X3_MFMA(a.h, b.h, acc_b);
 }
 
+// ---------------------------------------------------------------------------
+// f16x2 split-operand products (round 6; pqn_cnn_layout_t.pos_f16x2, config MATMUL_DTYPE: f16x2 -- position-parallel kernels only).
+// The same idea on fp16 pieces: s x = hi + lo with hi = f16(s x), lo = f16(s x - hi) -- 11 + 11 significand bits, the subtraction
+// exact in f32 -- and a b ~= (ah bl + al bh) + ah bh: THREE v_mfma_f32_16x16x32_f16 per 32-wide K step instead of six bf16 ones,
+// five VALU instructions per pair of values for the split instead of nine.  What is given up: the representation keeps 22 bits
+// (error <= 2^-22 |x| per operand, the dropped al bl <= 2^-22 |a b|) where bf16x3 keeps 24; measured against float64 on the whole
+// learn phase the mode stays inside the f32 fma-chain kernels' own distance (profiles/r06_v7_f16x2_accuracy.txt).
+// fp16 has 5 exponent bits, so every operand is brought into range by an EXACT power-of-two scale s chosen from a bound that holds by
+// construction -- nothing can overflow, and what falls below fp16's normal range is below 2^-40 of the operand's largest element:
+//   fc1 kernel W1          s = 2^7 (static; |w| < 511 -- beyond that fp16 overflows to inf and the loss goes NaN, loudly)
+//   conv kernel            s from max |w| of the kernel, per workgroup (h2_pow2_below)
+//   h1 (LayerNorm_0, relu) s from 4 max|scale| + max|bias| of LayerNorm_0 (|xhat| <= sqrt(15) < 4), folded into scale / bias
+//   dz                     per SAMPLE, from the row's max |dz| (forward kernel); the backward undoes it per row in the input gradient
+//                          and carries the row factors into the h1 operand of the weight gradient, normalised by the chunk's largest
+// ---------------------------------------------------------------------------
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// (H2_W_SCALE = 2^H2_W_SHIFT = 128, the fc1 planes' scale, and the plane writer live in pqn_common.h: the optimizer kernel keeps them)
+PQN_D void h2_split2(float x0, float x1, unsigned &h, unsigned &l) {
+  const f32x2 x = {x0, x1};
+  const f16x2_t hh = __builtin_convertvector(x, f16x2_t);          // v_cvt_pk_f16_f32 (round to nearest even)
+  h = __builtin_bit_cast(unsigned, hh);
+  const f32x2 r = x - __builtin_convertvector(hh, f32x2);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+struct H2Frag {
+  u32x4 h, l;
+};
+PQN_D H2Frag h2_split8(const f32x4 a, const f32x4 b) {   // (already scaled) k-values 0..3 = a, 4..7 = b
+  unsigned h[4], l[4];
+  h2_split2(a.x, a.y, h[0], l[0]);
+  h2_split2(a.z, a.w, h[1], l[1]);
+  h2_split2(b.x, b.y, h[2], l[2]);
+  h2_split2(b.z, b.w, h[3], l[3]);
+  H2Frag f;
+  f.h = u32x4{h[0], h[1], h[2], h[3]};
+  f.l = u32x4{l[0], l[1], l[2], l[3]};
+  return f;
+}
+// 2^(15 - e) for bound = m 2^e, m in [0.5, 1): bound * result < 2^15 < 65504, whatever the bound (exponent clamped to +-60)
+PQN_D float h2_pow2_below(float bound) {
+  int e = __builtin_amdgcn_frexp_expf(bound);
+  e = e < -45 ? -45 : (e > 75 ? 75 : e);
+  return __int_as_float((127 + 15 - e) << 23);
+}
+// the f16 twins of the grouped MFMA statements above (same operand layout, same pads)
+PQN_D void h2_grp2(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\t"
+               "v_mfma_f32_16x16x32_f16 %1, %4, %5, %1"
+               : "+v"(c0), "+v"(c1)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+PQN_D void h2_grp2_zero(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_f16 %0, %2, %3, 0\n\t"
+               "v_mfma_f32_16x16x32_f16 %1, %4, %5, 0"
+               : "=&v"(c0), "=&v"(c1)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+PQN_D void h2_grp4(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                   const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n\t"
+               "v_mfma_f32_16x16x32_f16 %1, %6, %7, %1\n\t"
+               "v_mfma_f32_16x16x32_f16 %2, %8, %9, %2\n\t"
+               "v_mfma_f32_16x16x32_f16 %3, %10, %11, %3"
+               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+}
+PQN_D void h2_grp4_zero(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                        const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x32_f16 %0, %4, %5, 0\n\t"
+               "v_mfma_f32_16x16x32_f16 %1, %6, %7, 0\n\t"
+               "v_mfma_f32_16x16x32_f16 %2, %8, %9, 0\n\t"
+               "v_mfma_f32_16x16x32_f16 %3, %10, %11, 0"
+               : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+}
+// operand mode of the position-parallel kernels as a type: NPL = planes per operand (3: bf16x3, 2: f16x2)
+template <int NPL>
+struct PosMM {
+  static constexpr bool H2 = NPL == 2;
+  static PQN_D void grp2(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
+    if constexpr (H2) h2_grp2(c0, a0, b0, c1, a1, b1);
+    else x3_grp2(c0, a0, b0, c1, a1, b1);
+  }
+  static PQN_D void grp2_zero(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1) {
+    if constexpr (H2) h2_grp2_zero(c0, a0, b0, c1, a1, b1);
+    else x3_grp2_zero(c0, a0, b0, c1, a1, b1);
+  }
+  static PQN_D void grp4(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                         const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
+    if constexpr (H2) h2_grp4(c0, a0, b0, c1, a1, b1, c2, a2, b2, c3, a3, b3);
+    else x3_grp4(c0, a0, b0, c1, a1, b1, c2, a2, b2, c3, a3, b3);
+  }
+  static PQN_D void grp4_zero(f32x4 &c0, const u32x4 &a0, const u32x4 &b0, f32x4 &c1, const u32x4 &a1, const u32x4 &b1, f32x4 &c2,
+                              const u32x4 &a2, const u32x4 &b2, f32x4 &c3, const u32x4 &a3, const u32x4 &b3) {
+    if constexpr (H2) h2_grp4_zero(c0, a0, b0, c1, a1, b1, c2, a2, b2, c3, a3, b3);
+    else x3_grp4_zero(c0, a0, b0, c1, a1, b1, c2, a2, b2, c3, a3, b3);
+  }
+};
+
 // The same conv on the bf16 matrix core (operand mode 2).  The observation bits are exact in bf16, so the A operand is
 // ONE plane; the kernel Wc is split exactly into three bf16 planes (x3_split2) when the workgroup starts, and
 //   out = sum_k bit_k * (Wh + Wm + Wl)[k]   -- 3 x v_mfma_f32_16x16x32_bf16 per 32 window bits, f32 accumulate

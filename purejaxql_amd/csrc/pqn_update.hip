@@ -268,7 +268,7 @@ static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool
   return pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
                           a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, norm_pass ? 1 : 0,
                           pqn_cnn_grad_reduce_blocks(L.total), st, c.S, c.sd.theta_stride, c.sd.ws_stride, c.sd.w1b_stride,
-                          L.matmul_f16 != 0 ? L.off_w1h : 0, L.matmul_f16);
+                          L.matmul_f16 != 0 ? L.off_w1h : 0, L.matmul_f16 + L.pos_f16x2);
 }
 
 // carry last_obs into the next update; metrics (:329-338); advance the clock

@@ -703,7 +703,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             driver.update()
             if not forms and packed:
                 forms.update(zip(("train", "rollout"), _lib.last_kernel_form()))
-                forms["matmul_dtype"] = ("f32", "f16", "bf16x3")[policy.layout.mode]   # what MATMUL_DTYPE (auto) resolved to
+                forms["matmul_dtype"] = policy.layout.mode_name   # what MATMUL_DTYPE (auto) resolved to
             if shard_world > 1 or metrics_hook is not None:
                 share_metrics_row(driver.metrics[u])     # (waits for the stream first: nothing is enqueued behind a replay in flight)
             if grad_hook is not None and hasattr(grad_hook, "poll"):
@@ -1030,7 +1030,7 @@ def make_train(config: Dict[str, Any], device: Optional[str] = None, grad_hook: 
             if not forms:
                 forms.update(zip(("train", "rollout"), _lib.last_kernel_form()))
                 if packed:
-                    forms["matmul_dtype"] = ("f32", "f16", "bf16x3")[layout.mode]
+                    forms["matmul_dtype"] = layout.mode_name
             counters["timesteps"] += T * N
             counters["n_updates"] += 1
             counters["grad_steps"] += MB * EPOCHS

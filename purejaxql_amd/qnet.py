@@ -20,10 +20,11 @@ class CnnLayoutStruct(C.Structure):
     """pqn_cnn_layout_t"""
     _fields_ = [(n, C.c_int32) for n in ("c", "a", "off_bn", "off_wc", "off_bc", "off_ln0s", "off_ln0b", "off_w1",
                                          "off_b1", "off_ln1s", "off_ln1b", "off_w2", "off_b2", "total", "matmul_f16",
-                                         "off_w1h", "alloc")]
+                                         "off_w1h", "alloc", "pos_f16x2")]
 
 
-MATMUL_MODES = {"f32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "bf16x3": 2}
+MATMUL_MODES = {"f32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "bf16x3": 2, "f16x2": 3}
+MATMUL_MODE_NAMES = ("f32", "f16", "bf16x3", "f16x2")
 # MATMUL_DTYPE: auto (the package default since round 6) picks between the two f32-grade modes by the minibatch size: bf16x3 from 512
 # samples on, f32 below.  Measured whole-loop rates of Breakout (tools/mode_sweep.py, profiles/r06_v1_mode_sweep.txt): minibatch 128 /
 # 256 -> f32 1.74e6 / 3.01e6 vs bf16x3 1.05e6 / 2.14e6 env-steps/s (only the f32 mode has the K-split kernels of the small
@@ -63,6 +64,8 @@ class CnnKernelLayout:
         s = self.struct
         self.c, self.a, self.total = int(s.c), int(s.a), int(s.total)
         self.alloc, self.mode, self.matmul_f16 = int(s.alloc), int(s.matmul_f16), int(s.matmul_f16) == 1
+        self.pos_f16x2 = bool(s.pos_f16x2)     # mode 3: bf16x3 (mode 2) everywhere but the position-parallel kernels, which run f16x2
+        self.mode_name = "f16x2" if self.pos_f16x2 else MATMUL_MODE_NAMES[self.mode]
         c, a = self.c, self.a
         i = torch.arange(1024).view(-1, 1)
         o = torch.arange(128).view(1, -1)

@@ -430,16 +430,19 @@ def _grads_under_options(gpu, c, a, nb, pool, mode, reps=3, **opts):
 
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 4096, 20000), (4, 3, 512, 3000), (4, 5, 1024, 4000), (6, 4, 2048, 6000), (7, 3, 1024, 3000),
                                          (4, 3, 256, 1000), (4, 3, 8192, 20000), (6, 4, 768, 2000)])
-def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool):
+@pytest.mark.parametrize("pmode", [2, 3], ids=["bf16x3", "f16x2"])
+def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool, pmode):
     """bwd_pos=2 routes a minibatch through the position-parallel kernels of pqn_qnet_pos.hip -- minibatch gather +
     bit-transpose, cnn_pos_fwd_kernel (wave = 32 samples, conv on the fly, z in registers, head on the accumulator layout),
     cnn_pos_bwd_kernel (wave = conv position, its dW1 rows in registers, one partial slab per sample chunk) -- and the
     reduction, from ONE forward workgroup (256 samples) over one- and two-chunk backward shapes (512,
     768 / 1024 .. 8192: up to 128 super-tiles per workgroup): the form is reported, repeats are bit-identical (gradient, loss, mean chosen q), loss
     and chosen q equal the f32-MFMA mode of the default kernels, the gradient equals it to f32 rounding and the oracle's numpy
-    backward at the tolerance of test_cnn_grad_vs_oracle.  pqn_minatar.py:271-291."""
+    backward at the tolerance of test_cnn_grad_vs_oracle.  pqn_minatar.py:271-291.
+    Both operand modes of the form -- bf16x3 (three bf16 pieces, 6 matrix instructions per product) and f16x2 (two range-scaled fp16
+    pieces, 3 per product) -- are held to the SAME bounds."""
     g_f32, f0, lq0 = _grads_under_options(gpu, c, a, nb, pool, 0, t1_pair=0, t1_ksplit=0, want_loss=True)
-    g_pos, f1, lq1 = _grads_under_options(gpu, c, a, nb, pool, 2, bwd_pos=2, want_loss=True)
+    g_pos, f1, lq1 = _grads_under_options(gpu, c, a, nb, pool, pmode, bwd_pos=2, want_loss=True)
     assert (f0, f1) == ("single", "pos")
     scale = float(g_f32.abs().max())
     assert abs(lq1[0] - lq0[0]) <= 2e-6 * max(1.0, abs(lq0[0])) and abs(lq1[1] - lq0[1]) <= 2e-6 * max(1.0, abs(lq0[1])), (lq1, lq0)
