@@ -248,10 +248,12 @@ def main():
                          "| masked:<lo>:<hi> (eager, tail stream on CUs [lo, hi), training kernels on the rest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only")
-    ap.add_argument("--matmul-dtype", default="bf16x3", choices=["f32", "bf16x3", "f16x2", "f16"],
-                    help="operand mode of the fc1 / conv products (config MATMUL_DTYPE).  bf16x3 (default here) evaluates "
-                         "every f32 product exactly-split on the bf16 matrix core with f32 accumulation and is held to "
-                         "the same f32 tolerances as the f32-MFMA mode by the parity tests; the package default is auto = this mode from 512-sample minibatches on, f32 below")
+    ap.add_argument("--matmul-dtype", default="f16x2", choices=["f32", "bf16x3", "f16x2", "f16"],
+                    help="operand mode of the fc1 / conv products (config MATMUL_DTYPE).  f16x2 (default here; what the package default "
+                         "`auto` resolves to from 512-sample minibatches on) carries every f32 operand of the position-parallel kernels as two "
+                         "range-scaled fp16 pieces (22 significand bits, 3 matrix instructions per product, f32 accumulate) and is bf16x3 -- "
+                         "three bf16 pieces, 6 instructions -- in every other kernel form; both are held to the same f32 tolerances as the "
+                         "f32-MFMA mode by the parity tests and measured against float64 (tests/test_qnet_gpu.py)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

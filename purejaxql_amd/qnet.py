@@ -25,8 +25,11 @@ class CnnLayoutStruct(C.Structure):
 
 MATMUL_MODES = {"f32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "bf16x3": 2, "f16x2": 3}
 MATMUL_MODE_NAMES = ("f32", "f16", "bf16x3", "f16x2")
-# MATMUL_DTYPE: auto (the package default since round 6) picks between the two f32-grade modes by the minibatch size: bf16x3 from 512
-# samples on, f32 below.  Measured whole-loop rates of Breakout (tools/mode_sweep.py, profiles/r06_v1_mode_sweep.txt): minibatch 128 /
+# MATMUL_DTYPE: auto (the package default since round 6) picks between the f32-grade modes by the minibatch size: f16x2 from 512
+# samples on, f32 below.  f16x2 IS bf16x3 in every kernel form but the position-parallel one (which launches that fill the chip take:
+# >= 160 workgroups of 256 samples, csrc/pqn_qnet.hip pos_form_taken); there the operands travel as two range-scaled fp16 pieces and a
+# product costs 3 matrix instructions instead of 6: 9.9e7 against 7.6e7 env-steps/s at the bench shape in one call, with single
+# gradients NEARER to float64 than bf16x3's (profiles/r06_v7_f16x2_accuracy.txt; tests/test_qnet_gpu.py).  Measured whole-loop rates of Breakout (tools/mode_sweep.py, profiles/r06_v1_mode_sweep.txt): minibatch 128 /
 # 256 -> f32 1.74e6 / 3.01e6 vs bf16x3 1.05e6 / 2.14e6 env-steps/s (only the f32 mode has the K-split kernels of the small
 # launches); 512 / 1024 / 2048 / 4096 -> f32 3.78e6 / 7.46e6 / 1.45e7 / 2.78e7 vs bf16x3 4.28e6 / 8.58e6 / 1.68e7 / 3.05e7 (one seed),
 # and 3.6e7 vs 7.55e7 with 16 seeds in the launches.  Both modes are held to the same tolerances against the oracle.
@@ -34,10 +37,11 @@ AUTO_BF16X3_MIN_MINIBATCH = 512
 
 
 def resolve_matmul_dtype(config_value, minibatch=None) -> str:
-    """config MATMUL_DTYPE -> the operand mode that runs: auto (or unset) = bf16x3 for minibatches of >= 512 samples, else f32."""
+    """config MATMUL_DTYPE -> the operand mode that runs: auto (or unset) = f16x2 (bf16x3 outside the position-parallel kernels) for
+    minibatches of >= 512 samples, else f32."""
     key = str(config_value if config_value is not None else "auto").lower()
     if key == "auto":
-        return "bf16x3" if (minibatch is not None and int(minibatch) >= AUTO_BF16X3_MIN_MINIBATCH) else "f32"
+        return "f16x2" if (minibatch is not None and int(minibatch) >= AUTO_BF16X3_MIN_MINIBATCH) else "f32"
     if key not in MATMUL_MODES:
         raise ValueError(f"MATMUL_DTYPE={config_value!r}: expected auto or one of {sorted(set(MATMUL_MODES))}")
     return key
@@ -45,8 +49,8 @@ def resolve_matmul_dtype(config_value, minibatch=None) -> str:
 
 def matmul_mode(config_value, minibatch=None) -> int:
     """config MATMUL_DTYPE -> pqn_cnn_layout_t.matmul_f16: 0 = f32-input MFMA (exact f32 fma chains), 1 = fp16 operands
-    (opt-in, narrower than the reference's f32), 2 = bf16x3 split operands (f32-grade products on the bf16 matrix core);
-    auto: see resolve_matmul_dtype."""
+    (opt-in, narrower than the reference's f32), 2 = bf16x3 split operands (f32-grade products on the bf16 matrix core), 3 = f16x2
+    (mode 2 + two-piece fp16 operands in the position-parallel kernels); auto: see resolve_matmul_dtype."""
     return MATMUL_MODES[resolve_matmul_dtype(config_value, minibatch)]
 
 

@@ -28,10 +28,10 @@ def _pack_bits(obs):
 GAMES = {"Breakout-MinAtar": (4, 3), "Asterix-MinAtar": (4, 5), "SpaceInvaders-MinAtar": (6, 4), "Freeway-MinAtar": (7, 3)}
 
 
-def _cfg(n_upd, env="Breakout-MinAtar", **extra):
+def _cfg(n_upd, env="Breakout-MinAtar", dtype="bf16x3", **extra):
     from purejaxql_amd.config_loader import flatten, load_config
     cfg = flatten(load_config(["+alg=pqn_minatar", f"alg.ENV_NAME={env}", f"alg.NUM_ENVS={N}",
-                               "alg.TEST_DURING_TRAINING=False", "alg.MATMUL_DTYPE=bf16x3"]))
+                               "alg.TEST_DURING_TRAINING=False", f"alg.MATMUL_DTYPE={dtype}"]))
     assert (cfg["NUM_STEPS"], cfg["NUM_MINIBATCHES"], cfg["NUM_EPOCHS"]) == (T, MB, EP)
     cfg["TOTAL_TIMESTEPS"] = n_upd * N * T
     cfg["TOTAL_TIMESTEPS_DECAY"] = 30 * N * T
@@ -62,9 +62,12 @@ def _assert_grad_close(g, g_ref, shapes, what):
         (what, float(d.max()), float(np.abs(g_ref).max()), int(bad.sum()))
 
 
-@pytest.mark.parametrize("stacked,c,a,form", [(False, 4, 3, "pos"), (True, 4, 3, "pos"), (False, 6, 4, "pos"), (False, 7, 3, "pos"),
-                                              (False, 4, 3, "pair"), (True, 4, 3, "pair"), (False, 6, 4, "pair"), (False, 7, 3, "pair")])
-def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked, c, a, form):
+@pytest.mark.parametrize("stacked,c,a,form,dtype", [(False, 4, 3, "pos", "bf16x3"), (True, 4, 3, "pos", "bf16x3"), (False, 6, 4, "pos", "bf16x3"),
+                                                    (False, 7, 3, "pos", "bf16x3"), (False, 4, 3, "pos", "f16x2"), (True, 4, 3, "pos", "f16x2"),
+                                                    (False, 6, 4, "pos", "f16x2"), (False, 7, 3, "pos", "f16x2"),
+                                                    (False, 4, 3, "pair", "bf16x3"), (True, 4, 3, "pair", "bf16x3"), (False, 6, 4, "pair", "bf16x3"),
+                                                    (False, 7, 3, "pair", "bf16x3"), (False, 4, 3, "pair", "f16x2")])
+def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked, c, a, form, dtype):
     """vmap(value_and_grad(_loss_fn)) at the bench's launch shape -- 16 seeds x 4096-sample minibatches in one launch,
     bf16x3, seeds remapped over the XCDs -- against the oracle's numpy backward, seed by seed (own parameters, own
     minibatch), with the tolerances of test_cnn_grad_vs_oracle; for Breakout (C = 4, 3 actions), SpaceInvaders (C = 6, 4)
@@ -72,7 +75,9 @@ def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked, c, a, form):
     position-parallel kernels (256 forward + 256 backward workgroups); form = "pair" (option bwd_pos = 0): 2048 workgroups
     of the pair kernel + the fc1 weight-gradient kernel, what launches of fewer than 10 seeds take.  stacked=True reads the
     samples out of a stacked [T][S*N] record (the layout pqn_cnn_update_seeds trains from), False from a shared pool.
-    The same seed launched ALONE in the same form gives the same bits (the summation orders do not depend on the launch)."""
+    The same seed launched ALONE in the same form gives the same bits (the summation orders do not depend on the launch).
+    dtype = f16x2: the position-parallel kernels on two fp16 pieces per operand, same bounds; its "pair" case runs bf16x3 (the mode
+    exists in the position form only -- every other kernel form of an f16x2 layout is the bf16x3 one)."""
     from purejaxql_amd import _lib
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.qnet import CnnKernelLayout, cnn_grad_seeds, matmul_mode
@@ -86,7 +91,7 @@ def test_headline_launch_gradient_vs_oracle(gpu, oracle, stacked, c, a, form):
     action = rng.integers(0, a, rows).astype(np.int32)
     target = rng.standard_normal(rows).astype(np.float32)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
-    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode("bf16x3"))
+    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode(dtype))
     stride = (lay.alloc + 3) // 4 * 4
     thetas = [net.init(100 + s) + 0.05 * torch.randn(net.num_params, device=gpu) for s in range(S)]
     theta_k = torch.zeros((S, stride), dtype=torch.float32, device=gpu)
@@ -141,8 +146,8 @@ def test_single_seed_8192_sample_minibatch_takes_the_pair_kernel(gpu, oracle):
     np.testing.assert_allclose(_np(lay.to_flax(g)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
 
 
-@pytest.mark.parametrize("pinned", [True, False])
-def test_headline_16_seeds_bf16x3_against_solo_runs(gpu, pinned):
+@pytest.mark.parametrize("pinned,dtype", [(True, "bf16x3"), (False, "bf16x3"), (True, "f16x2")])
+def test_headline_16_seeds_bf16x3_against_solo_runs(gpu, pinned, dtype):
     """The bench configuration (16 seeds x 4096 envs, bf16x3, hipGraph replay) for 2 updates against the solo runs of seeds
     0 / 7 / 15.  The batch trains through the position-parallel kernels (one workgroup per 256 samples / per 8 conv
     positions: they need >= 10 seeds to fill the chip); a solo run by default takes the single-tile kernels (256 workgroups of
@@ -151,7 +156,7 @@ def test_headline_16_seeds_bf16x3_against_solo_runs(gpu, pinned):
     32 workgroups) and they are bit-identical: metrics, parameters, optimizer state, env state.  pqn_minatar.py:459-461."""
     from purejaxql_amd import _lib
     from purejaxql_amd.pqn import make_train, seed_keys, vmap_train
-    cfg = _cfg(2, SEED_BATCH_BIT_IDENTICAL=pinned)
+    cfg = _cfg(2, dtype=dtype, SEED_BATCH_BIT_IDENTICAL=pinned)
     keys = seed_keys(0, S)
     outs = vmap_train(make_train(dict(cfg), device="cuda:0"), keys)
     assert _lib.last_kernel_form() == ("pos", "pos")
@@ -224,9 +229,11 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
             assert torch.equal(a["runner_state"][k], b["runner_state"][k]), (s, k)
 
 
-@pytest.mark.parametrize("env_name,seeds_checked", [("Breakout-MinAtar", (0, 7, 15)), ("SpaceInvaders-MinAtar", (7,)),
-                                                   ("Freeway-MinAtar", (7,)), ("Asterix-MinAtar", (7,))])
-def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked):
+@pytest.mark.parametrize("env_name,seeds_checked,dtype", [("Breakout-MinAtar", (0, 7, 15), "bf16x3"), ("SpaceInvaders-MinAtar", (7,), "bf16x3"),
+                                                         ("Freeway-MinAtar", (7,), "bf16x3"), ("Asterix-MinAtar", (7,), "bf16x3"),
+                                                         ("Breakout-MinAtar", (0, 15), "f16x2"), ("SpaceInvaders-MinAtar", (7,), "f16x2"),
+                                                         ("Freeway-MinAtar", (7,), "f16x2"), ("Asterix-MinAtar", (7,), "f16x2")])
+def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked, dtype):
     """ONE whole update of the bench workload -- 16 seeds batched into the launches, bf16x3, pair rollout + position-parallel
     training kernels -- against oracle.make_train, for seeds 0 / 7 / 15 of Breakout (first, middle and last XCD group) and
     seed 7 of the other three games of bench.py's minatar_suite (C = 6 / 7 channels, 4 / 3 / 5 actions), from shared
@@ -237,7 +244,7 @@ def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked):
     from purejaxql_amd import _lib
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.pqn import make_train, seed_keys
-    cfg = _cfg(1, env=env_name)
+    cfg = _cfg(1, env=env_name, dtype=dtype)
     ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
     c, a = GAMES[env_name]
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
@@ -278,13 +285,17 @@ def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked):
             u64 = th64 - th0
             rel_hip = float(np.linalg.norm(upd - u64) / np.linalg.norm(u64))
             rel_np = float(np.linalg.norm(oupd - u64) / np.linalg.norm(u64))
-            print(f"\nupdate vector vs the float64 learn phase: HIP rel-L2 {rel_hip:.3e}, numpy-f32 oracle rel-L2 {rel_np:.3e}, HIP vs numpy-f32 {rel:.3e}")
+            print(f"\n[{dtype}] update vector vs the float64 learn phase: HIP rel-L2 {rel_hip:.3e}, numpy-f32 oracle rel-L2 {rel_np:.3e}, HIP vs numpy-f32 {rel:.3e}")
             # measured (round 6, profiles/r06_v4_f64_learn_phase.txt): HIP 2.1e-4, numpy-f32 oracle 3.9e-2 -- the numpy oracle is the
             # outlier (its f32 matmuls sum 4096-sample columns in one f32 chain), not the kernels.  Against the float64 reference the
             # criterion is 30x tighter than the 6e-2 the f32-vs-f32 comparison above has to allow.
             cos64 = float(np.dot(upd, u64) / (np.linalg.norm(upd) * np.linalg.norm(u64)))
             d64 = np.abs(th - th64)
-            assert np.isfinite(th64).all() and rel_hip < 2e-3 and cos64 > 0.999995 and rel_hip < rel_np, (rel_hip, rel_np, rel, cos64)
+            # f16x2 (measured 2.4e-3, cosine 0.999997): where the f32 fma-chain kernels of this library sit (2.4e-3, tests/test_parity_gpu.py,
+            # bound 6e-3) -- 64 RAdam steps amplify WHICH roundings happen, not only how large they are; a single gradient of the mode is
+            # nearer to float64 than bf16x3's (tests/test_qnet_gpu.py::test_operand_modes_of_the_position_form_against_float64)
+            lim, cmin = (2e-3, 0.999995) if dtype == "bf16x3" else (6e-3, 0.99999)
+            assert np.isfinite(th64).all() and rel_hip < lim and cos64 > cmin and rel_hip < 0.2 * rel_np, (rel_hip, rel_np, rel, cos64)
             assert (d64 > 2e-5 + 2e-3 * np.abs(th64)).mean() < 1e-4 and d64.max() < cfg["LR"], (float(d64.max()),)
 
 

@@ -463,6 +463,108 @@ def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool
     np.testing.assert_allclose(_np(lay.to_flax(g_pos)), g_ref, rtol=2e-3, atol=3e-6 * np.abs(g_ref).max() + 1e-9)
 
 
+@pytest.mark.parametrize("c,a,nb,pool,spread", [(4, 3, 4096, 20000, 0.0), (4, 3, 4096, 20000, 6.0), (6, 4, 2048, 6000, 0.0)])
+def test_operand_modes_of_the_position_form_against_float64(gpu, oracle, c, a, nb, pool, spread):
+    """How far is each operand mode from EXACT arithmetic?  One minibatch gradient through the position-parallel kernels in bf16x3
+    and f16x2, and through the single-tile kernels in the f32-MFMA mode, against the float64 backward of oracle/pqn_oracle_f64.py
+    on the same inputs.  f16x2 carries 22 significand bits per operand where bf16x3 carries 24, but runs half the matrix instructions
+    (half the f32 accumulator roundings): both are held to rel-L2 within 4x of the f32 mode's (+1e-7) and under 2e-6 absolutely, the
+    worst entry within 1e-5 of max|g|, and f16x2 to no more than 1.5x bf16x3's distance.  spread > 0 multiplies the targets of a few samples by up to e^spread and shrinks others: rows of dz whose
+    magnitudes differ by orders of magnitude exercise the per-sample scaling of the f16x2 weight gradient.
+    (Numbers: profiles/r06_v7_f16x2_accuracy.txt.)"""
+    import pqn_oracle_f64 as o64
+    from purejaxql_amd import _lib
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer
+    rng = np.random.default_rng(nb + c)
+    torch.manual_seed(1234)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    theta = net.init(11) + 0.05 * torch.randn(net.num_params, device=gpu)
+    obs, words = _random_bits(rng, pool, c, density=0.12)
+    action = rng.integers(0, a, pool).astype(np.int32)
+    target = rng.standard_normal(pool).astype(np.float32)
+    if spread > 0:
+        target = (target * np.exp(rng.uniform(-spread, spread, pool))).astype(np.float32)
+    idx = rng.permutation(pool)[:nb]
+    shapes = oracle.cnn_shapes((10, 10, c), a)
+    _l64, _c64, g64 = o64.cnn_loss_grad(oracle.unflatten(_np(theta).astype(np.float64), shapes), shapes, obs[idx], action[idx], target[idx])
+    bits = torch.from_numpy(words.view(np.int32)).to(gpu)
+    at, tt, it = torch.from_numpy(action).to(gpu), torch.from_numpy(target).to(gpu), torch.from_numpy(idx.astype(np.int64)).to(gpu)
+    err = {}
+    for name, mode, opts, form in (("f32", 0, dict(t1_pair=0, t1_ksplit=0), "single"), ("bf16x3", 2, dict(bwd_pos=2), "pos"), ("f16x2", 3, dict(bwd_pos=2), "pos")):
+        with _lib.options(**opts):
+            lay = CnnKernelLayout(c, a, matmul_f16=mode)
+            tr = CnnTrainer(lay, theta, 5e-4, 10.0, max_minibatch=nb)
+            lo, qv = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+            g = _np(lay.to_flax(tr.compute_grad(it, bits, at, tt, lo, qv)[:lay.total].clone())).astype(np.float64)
+            assert _lib.last_kernel_form()[0] == form
+        assert np.isfinite(g).all()
+        err[name] = (float(np.linalg.norm(g - g64) / np.linalg.norm(g64)), float(np.abs(g - g64).max() / np.abs(g64).max()))
+    print(f"\nC={c} nb={nb} target spread e^+-{spread}: gradient vs float64 (rel-L2, worst entry / max|g|): " +
+          ", ".join(f"{k} {v[0]:.2e} {v[1]:.2e}" for k, v in err.items()))
+    # measured (profiles/r06_v7_f16x2_accuracy.txt): f32 6.0e-8 / 2.0e-7 / 8.8e-8, bf16x3 2.0e-7 / 4.7e-7 / 2.8e-7, f16x2 1.3e-7 / 3.9e-7 / 1.7e-7
+    # -- f16x2 sits BETWEEN the f32 fma chains and bf16x3 (half the matrix instructions = half the accumulator roundings)
+    for m in ("bf16x3", "f16x2"):
+        assert err[m][0] <= 4 * err["f32"][0] + 1e-7 and err[m][0] < 2e-6 and err[m][1] < 1e-5, err
+    assert err["f16x2"][0] <= 1.5 * err["bf16x3"][0], err
+
+
+@pytest.mark.parametrize("case", ["conv_kernel_x1e3", "conv_kernel_x1e-4", "ln0_scale_x60", "ln0_all_zero", "fc1_kernel_x40", "targets_x1e6", "targets_x1e-9",
+                                  "one_sample_dominates", "zero_td_error"])
+def test_f16x2_range_scaling_holds_at_the_extremes(gpu, case):
+    """fp16 has five exponent bits: the f16x2 mode is only as good as its power-of-two scales (pqn_qnet_x3.h).  Parameters and targets
+    pushed orders of magnitude away from an initialised network -- conv kernel x 1e3 / 1e-4, LayerNorm_0 scale x 60 or scale = bias = 0,
+    fc1 kernel x 40 (|w| up to ~8: the static 2^7 plane scale holds to 511), TD errors of 1e6 and 1e-9, one sample 1e8 times the rest, targets
+    equal to the network's own output (dz = 0 rows) -- must give a finite gradient that agrees with bf16x3 (8-bit exponents, no scaling
+    anywhere) as closely as in the benign case."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.networks import QNetwork
+    from purejaxql_amd.qnet import CnnKernelLayout, CnnTrainer, cnn_forward
+    c, a, nb, pool = 4, 3, 1024, 4000
+    rng = np.random.default_rng(77)
+    torch.manual_seed(5)
+    net = QNetwork("cnn", (10, 10, c), a, device=gpu)
+    theta = net.init(3) + 0.05 * torch.randn(net.num_params, device=gpu)
+    lay0 = CnnKernelLayout(c, a, matmul_f16=0)
+    tk = lay0.to_kernel(theta)[:lay0.total].clone()
+    s0 = lay0.struct
+    if case == "conv_kernel_x1e3": tk[s0.off_wc:s0.off_wc + 9 * c * 16] *= 1e3
+    if case == "conv_kernel_x1e-4": tk[s0.off_wc:s0.off_wc + 9 * c * 16] *= 1e-4
+    if case == "ln0_scale_x60": tk[s0.off_ln0s:s0.off_ln0s + 16] *= 60.0
+    if case == "ln0_all_zero": tk[s0.off_ln0s:s0.off_ln0s + 32] = 0.0
+    if case == "fc1_kernel_x40": tk[s0.off_w1:s0.off_w1 + 1024 * 128] *= 40.0
+    theta = lay0.to_flax(tk)
+    _obs, words = _random_bits(rng, pool, c, density=0.12)
+    bits = torch.from_numpy(words.view(np.int32)).to(gpu)
+    action = torch.from_numpy(rng.integers(0, a, pool).astype(np.int32)).to(gpu)
+    target = rng.standard_normal(pool).astype(np.float32)
+    if case == "targets_x1e6": target *= 1e6
+    if case == "targets_x1e-9": target *= 1e-9
+    if case == "one_sample_dominates": target[rng.integers(0, pool, 40)] *= 1e8
+    target = torch.from_numpy(target).to(gpu)
+    if case == "zero_td_error":
+        q, _, _ = cnn_forward(CnnKernelLayout(c, a, matmul_f16=2), bits, CnnKernelLayout(c, a, matmul_f16=2).to_kernel(theta))
+        target = q.gather(1, action.long().view(-1, 1)).view(-1).clone()
+        target[::7] += 1e-3      # most rows of dz exactly (or nearly) zero
+    idx = torch.from_numpy(rng.permutation(pool)[:nb].astype(np.int64)).to(gpu)
+    g = {}
+    with _lib.options(bwd_pos=2):
+        for mode in (2, 3):
+            lay = CnnKernelLayout(c, a, matmul_f16=mode)
+            tr = CnnTrainer(lay, theta, 5e-4, 10.0, max_minibatch=nb)
+            lo, qv = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+            g[mode] = tr.compute_grad(idx, bits, action, target, lo, qv)[:lay.total].double().clone()
+            assert _lib.last_kernel_form()[0] == "pos" and bool(torch.isfinite(g[mode]).all()) and bool(torch.isfinite(lo).all()), (case, mode)
+    if case == "ln0_all_zero":     # h1 = 0 everywhere: the fc1 kernel's gradient is exactly zero in both modes
+        w1 = slice(s0.off_w1, s0.off_w1 + 1024 * 128)
+        assert float(g[2][w1].abs().max()) == 0.0 and float(g[3][w1].abs().max()) == 0.0
+    num, den = float((g[3] - g[2]).norm()), float(g[2].norm())
+    print(f"\n{case}: |g_f16x2 - g_bf16x3| / |g_bf16x3| = {num / max(den, 1e-300):.2e}  (|g| = {den:.3e})")
+    # zero_td_error: six of seven TD errors ARE the two forwards' rounding difference (q - q' ~ 1e-7 against 1e-3 in the others), so the
+    # modes' gradients legitimately differ by that share; the case is there for the all-but-zero dz rows (finite, no 0 * inf)
+    assert num <= (2e-3 if case == "zero_td_error" else 2e-6) * den + 1e-30, (case, num, den)
+
+
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 128, 1000), (4, 3, 16, 64), (6, 4, 256, 600), (7, 3, 96, 300), (10, 6, 48, 100)])
 def test_ksplit_form_of_the_training_kernel_for_small_minibatches(gpu, oracle, c, a, nb, pool):
     """f32 operand mode, minibatches of at most 256 samples (the yaml-default MinAtar run has 128): the K-split kernels

@@ -97,7 +97,7 @@ def test_ten_seed_yaml_default_batch_against_its_solo_runs(gpu):
 
     from purejaxql_amd.qnet import resolve_matmul_dtype
     assert cfg()["NUM_ENVS"] == 128 and str(cfg()["MATMUL_DTYPE"]) == "auto"      # 128-sample minibatches: auto = the f32 mode
-    assert resolve_matmul_dtype(cfg()["MATMUL_DTYPE"], 128) == "f32" and resolve_matmul_dtype("auto", 512) == "bf16x3"
+    assert resolve_matmul_dtype(cfg()["MATMUL_DTYPE"], 128) == "f32" and resolve_matmul_dtype("auto", 512) == "f16x2"
     batch = vmap_train(make_train(cfg(), device="cuda:0"), keys)
     pinned = vmap_train(make_train(cfg(SEED_BATCH_BIT_IDENTICAL=True), device="cuda:0"), keys)
     assert batch["runner_state"][0]["kernel_forms"]["train"] == "single"
