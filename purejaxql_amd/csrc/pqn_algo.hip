@@ -342,9 +342,9 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
       const int frag = (int)(j >> 8), ln = (int)(j >> 2) & 63, sx = (int)j & 3;
       const int gi = frag >> 3, cb = frag & 7, kk = ln >> 4, jj = ln & 15;
       const int jb = (((cb * 64 + gi) * 64 + (jj >> 2) * 16 + 4 * kk + sx) << 2) + (jj & 3);
-      if (half_off && copy_mode >= 2) {   // bf16x3 layout: the six bf16 planes in the tail of the parameter buffer (3: + four f16x2 planes)
-        pqn_x3_store_planes(reinterpret_cast<unsigned short *>(p + half_off), 16 * gi + 4 * kk + sx, 16 * cb + jj, pn);
-        if (copy_mode == 3) pqn_h2_store_planes(reinterpret_cast<_Float16 *>(p + half_off + H2_PLANES_OFF), 16 * gi + 4 * kk + sx, 16 * cb + jj, pn);
+      if (half_off && copy_mode >= 2) {   // bf16x3 layout: the six bf16 planes in the tail of the parameter buffer (3: + four f16x2 planes; 4: only those)
+        if (copy_mode != 4) pqn_x3_store_planes(reinterpret_cast<unsigned short *>(p + half_off), 16 * gi + 4 * kk + sx, 16 * cb + jj, pn);
+        if (copy_mode >= 3) pqn_h2_store_planes(reinterpret_cast<_Float16 *>(p + half_off + H2_PLANES_OFF), 16 * gi + 4 * kk + sx, 16 * cb + jj, pn);
         return;
       }
       w1b[jb] = pn;
@@ -419,11 +419,13 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
         const int i0 = 16 * gi + 4 * kk, o = 16 * cb + jj;
         const int jf = ((((i0 >> 5) * 8 + (o >> 4)) * 64 + ((i0 >> 2) & 3) * 16 + (o & 15)) << 3) + 4 * ((i0 >> 4) & 1);
         u2 H, M, Lo;
-        split4(pa, H, M, Lo);
-        *reinterpret_cast<u2 *>(planes + jf) = H;
-        *reinterpret_cast<u2 *>(planes + P + jf) = M;
-        *reinterpret_cast<u2 *>(planes + 2 * P + jf) = Lo;
-        if (copy_mode == 3) {
+        if (copy_mode != 4) {
+          split4(pa, H, M, Lo);
+          *reinterpret_cast<u2 *>(planes + jf) = H;
+          *reinterpret_cast<u2 *>(planes + P + jf) = M;
+          *reinterpret_cast<u2 *>(planes + 2 * P + jf) = Lo;
+        }
+        if (copy_mode >= 3) {
           split4h(pa, H, Lo);
           *reinterpret_cast<u2 *>(hplanes + jf) = H;
           *reinterpret_cast<u2 *>(hplanes + P + jf) = Lo;
@@ -441,11 +443,13 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
         const int i = 16 * gi + 4 * kk + r, o0 = 16 * cb + (jj & ~3);
         const int jd = (((((i >> 4) * 4 + (o0 >> 5)) * 64) + ((o0 >> 2) & 3) * 16 + (i & 15)) << 3) + 4 * ((o0 >> 4) & 1);
         u2 H, M, Lo;
-        split4(tv, H, M, Lo);
-        *reinterpret_cast<u2 *>(planes + 3 * P + jd) = H;
-        *reinterpret_cast<u2 *>(planes + 4 * P + jd) = M;
-        *reinterpret_cast<u2 *>(planes + 5 * P + jd) = Lo;
-        if (copy_mode == 3) {
+        if (copy_mode != 4) {
+          split4(tv, H, M, Lo);
+          *reinterpret_cast<u2 *>(planes + 3 * P + jd) = H;
+          *reinterpret_cast<u2 *>(planes + 4 * P + jd) = M;
+          *reinterpret_cast<u2 *>(planes + 5 * P + jd) = Lo;
+        }
+        if (copy_mode >= 3) {
           split4h(tv, H, Lo);
           *reinterpret_cast<u2 *>(hplanes + 2 * P + jd) = H;
           *reinterpret_cast<u2 *>(hplanes + 3 * P + jd) = Lo;

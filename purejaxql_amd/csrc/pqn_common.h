@@ -213,7 +213,8 @@ int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, in
                      float *w1b, int norm_pass, int nparts, hipStream_t st, int nseeds = 1, long long pstride = 0,
                      long long sstride = 0, long long w1bstride = 0, int half_off = 0, int copy_mode = 1);
 // half_off: float offset of the operand-copy region behind the parameters (pqn_cnn_layout_t.off_w1h; 0 = none);
-// copy_mode: 1 = two fp16 copies of the fc1 kernel (matmul_f16), 2 = six bf16 planes (bf16x3), 3 = those + the four f16x2 planes
+// copy_mode: 1 = two fp16 copies of the fc1 kernel (matmul_f16), 2 = six bf16 planes (bf16x3), 3 = those + the four f16x2 planes,
+// 4 = the f16x2 planes ONLY (the bf16 planes go stale: pqn_update.hip, for optimizer steps whose successor is a position-parallel step)
 
 // kernel timer of pqn_prof_enable(mode) for kernels outside pqn_qnet.hip (mode 2 = the wide-MLP GEMM kernel)
 bool pqn_prof_begin(int mode, hipStream_t st);
@@ -251,6 +252,7 @@ int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t
                             int epoch_nmb = 0);
 // the position-parallel form's gather once per epoch (pqn_qnet.hip); _applies: pure predicate of shape, options and workspace stride
 bool pqn_qnet_cnn_epoch_applies(const pqn_cnn_layout_t &L, int nb, int nmb, const pqn_seeds_t &sd);
+bool pqn_qnet_cnn_pos_form_taken(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd);   // the training step of this shape takes the position-parallel form
 int pqn_qnet_cnn_epoch_gather(const pqn_cnn_layout_t &L, int nb, int nmb, const int64_t *idx_epoch, const uint32_t *obs_bits,
                               const int32_t *action, const float *target, float *workspace, const pqn_seeds_t &sd, hipStream_t st);
 long long pqn_qnet_cnn_epoch_floats(const pqn_cnn_layout_t &L, int nb, int nmb);

@@ -3515,6 +3515,7 @@ static bool pos_form_taken(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t 
   const bool pos_shape = L.matmul_f16 == 2 && nb % 256 == 0 && pos_shape_ok(nb) && pqn_cnn_pos_forward_supported(L.c, L.a) && L.c != 10;
   return pos_shape && (pos_opt == 2 || (pos_opt == 1 && (sd.pin_form ? nb >= 2048 : (nb / 256) * sd.nseeds >= 160)));
 }
+bool pqn_qnet_cnn_pos_form_taken(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd) { return pos_form_taken(L, nb, sd); }
 long long pqn_qnet_cnn_epoch_floats(const pqn_cnn_layout_t &L, int nb, int nmb) {
   if (L.matmul_f16 != 2 || nb % 256 != 0 || !pos_shape_ok(nb) || !pqn_cnn_pos_forward_supported(L.c, L.a) || L.c == 10) return 0;
   return pos_epoch_layout(nb, nmb, L.c).end;

@@ -608,8 +608,16 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     // ---- dW1p[feature][o] += sum over the 32 samples of h1[sample][feature] dz[sample][o] ----
     // B fragments of column blocks 4 hf .. 4 hf + 3 (sK = cb >> 1, half h = cb & 1 of each quad): K slots 0..3 = the lane group's
     // four samples of tile 0, 4..7 = of tile 1 -- two transposing reads per (column block, plane)
+    // (the four lane addresses are formed ONCE and hidden from the optimiser: it otherwise folds slot base + plane / half offset into
+    // scalar registers and spends a v_add per read pair -- 16 per super-tile -- where the instruction's offset field does it for free)
+    uint32_t trv[4];
+#pragma unroll
+    for (int sK = 0; sK < 4; ++sK) {
+      trv[sK] = trb + tr_sk[sK];
+      asm volatile("" : "+v"(trv[sK]));
+    }
     auto tr_frag = [&](int cb, int pl) {
-      const uint32_t a0 = trb + tr_sk[cb >> 1] + 8u * (cb & 1) + 8192u * pl;
+      const uint32_t a0 = trv[cb >> 1] + 8u * (cb & 1) + 8192u * pl;
       const u32x2_t v0 = pos_tr_read(a0), v1 = pos_tr_read(a0 + 4096u);
       return u32x4{v0.x, v0.y, v1.x, v1.y};
     };

@@ -265,10 +265,16 @@ static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool 
 
 static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool norm_pass, hipStream_t st) {
   const pqn_cnn_layout_t &L = a->layout;
+  // f16x2 layouts carry two plane sets of the fc1 kernel: fp16 for the position-parallel kernels, bf16 for every other form.  Inside
+  // an update whose optimizer steps take the position-parallel form nothing reads the bf16 set until the update is over (the next
+  // consumer is the next step's forward; rollouts, evaluation and whoever reads theta run between updates), so only the LAST step of
+  // the update writes it: 24 MB less store traffic per 16-seed launch, 25 -> 20 us per optimizer kernel.
+  int copy_mode = L.matmul_f16 + L.pos_f16x2;
+  if (L.pos_f16x2 && i_mb + 1 < c.MB * c.EP && pqn_qnet_cnn_pos_form_taken(L, c.B, c.sd)) copy_mode = 4;
   return pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
                           a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, norm_pass ? 1 : 0,
                           pqn_cnn_grad_reduce_blocks(L.total), st, c.S, c.sd.theta_stride, c.sd.ws_stride, c.sd.w1b_stride,
-                          L.matmul_f16 != 0 ? L.off_w1h : 0, L.matmul_f16 + L.pos_f16x2);
+                          L.matmul_f16 != 0 ? L.off_w1h : 0, copy_mode);
 }
 
 // carry last_obs into the next update; metrics (:329-338); advance the clock
