@@ -299,6 +299,42 @@ def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked, d
             assert (d64 > 2e-5 + 2e-3 * np.abs(th64)).mean() < 1e-4 and d64.max() < cfg["LR"], (float(d64.max()),)
 
 
+def test_f16x2_update_leaves_both_plane_sets_of_the_fc1_kernel_valid(gpu):
+    """An f16x2 layout carries the fc1 kernel three times: the f32 parameters, six bf16 planes (every kernel form but the
+    position-parallel one) and four fp16 planes (the position-parallel kernels).  Inside an update only the fp16 set follows the
+    optimizer steps (pqn_update.hip upd_apply: copy_mode 4); the update's LAST step rewrites both.  After two updates of the bench shape
+    (the second a hipGraph replay) every seed's planes must be exactly what pqn_qnet_cnn_pack_w1b derives from its parameters -- i.e.
+    whatever runs between updates (evaluation rollouts in the 16-env form, cnn_forward on the returned parameters) reads current
+    weights -- and a bf16x3-form forward on the driver's buffer equals the forward on a freshly packed copy."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.pqn import make_train, seed_keys
+    from purejaxql_amd.qnet import cnn_forward
+    cfg = _cfg(2, dtype="f16x2")
+    train = make_train(cfg, device="cuda:0")
+    update, finish = train.make_batch_runner(seed_keys(0, S))
+    update(0)
+    update(1)
+    torch.cuda.synchronize()
+    assert _lib.last_kernel_form() == ("pos", "pos")
+    drv = update.driver
+    lay = drv.layout
+    assert lay.pos_f16x2 and lay.alloc == lay.total + 5 * 1024 * 128
+    rng = np.random.default_rng(3)
+    obs = (rng.random((64, 10, 10, 4)) < 0.12).astype(np.float32)
+    bits = torch.from_numpy(_pack_bits(obs).view(np.int32)).to(gpu)
+    for s in (0, 9, 15):
+        tk = drv.theta[s, :lay.alloc].clone()
+        fresh = tk.clone()
+        fresh[lay.total:] = 0
+        lay.refresh_copies(fresh)
+        torch.cuda.synchronize()
+        assert torch.equal(tk[:lay.total], fresh[:lay.total])
+        assert torch.equal(tk[lay.total:].view(torch.int32), fresh[lay.total:].view(torch.int32)), s     # all ten planes, bit for bit
+        q0, _, _ = cnn_forward(lay, bits, tk)
+        q1, _, _ = cnn_forward(lay, bits, fresh)
+        assert torch.equal(q0, q1) and bool(torch.isfinite(q0).all())
+
+
 @pytest.mark.parametrize("nb,seeds", [(4096, 16), (512, 2), (272, 3), (16, 1)])
 def test_fc1_weight_gradient_without_split_k_partials_is_bit_identical(gpu, nb, seeds):
     """qnet_fc1_wgrad_x3_kernel<true> (round 4: one workgroup per (row block, seed) walks over every 256-sample slab and

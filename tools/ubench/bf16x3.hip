@@ -4,6 +4,7 @@
 //      256 workgroups x 512 threads, dwordx4 loads, 12 / 24 in flight per wave, 512 KB and 768 KB buffers
 //  (3) VALU cost of splitting 8 f32 into 3 x 8 bf16 (hi, mid, lo planes), per wave-instruction group
 //  (4) numerics: the 6-product split dot product vs f64 and vs an f32 fma chain, K = 1024
+//  (5) (round 6) the same for the f16x2 split: two fp16 pieces of 2^s x, three v_mfma_f32_16x16x32_f16 per K step
 // build: hipcc -O3 --offload-arch=gfx950 bf16x3.hip -o bf16x3 ; run on an MI355X
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -112,6 +113,28 @@ __global__ void split_gemm(const float *A /*[16][K]*/, const float *B /*[K][16]*
   D[(r0 + 0) * 16 + col] = acc.x; D[(r0 + 1) * 16 + col] = acc.y; D[(r0 + 2) * 16 + col] = acc.z; D[(r0 + 3) * 16 + col] = acc.w;
 }
 
+// f16x2: s x = hi + lo (fp16 each, round to nearest even), products l h + h l + h h; sa / sb = the power-of-two operand scales
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ void split_gemm_h2(const float *A, const float *B, int K, float *D, float sa, float sb) {
+  const int lane = threadIdx.x, i = lane & 15, kg = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < K / 32; ++s) {
+    f16x8 ah, al, bh, bl;
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * s + 8 * kg + j;
+      const float x = A[i * K + k] * sa, y = B[k * 16 + i] * sb;
+      ah[j] = (_Float16)x; al[j] = (_Float16)(x - (float)ah[j]);
+      bh[j] = (_Float16)y; bl[j] = (_Float16)(y - (float)bh[j]);
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+  }
+  const int col = lane & 15, r0 = 4 * (lane >> 4);
+  const float inv = 1.0f / (sa * sb);
+  D[(r0 + 0) * 16 + col] = acc.x * inv; D[(r0 + 1) * 16 + col] = acc.y * inv; D[(r0 + 2) * 16 + col] = acc.z * inv; D[(r0 + 3) * 16 + col] = acc.w * inv;
+}
+
 int main() {
   float *out; unsigned long long *cyc, h;
   hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 8);
@@ -186,6 +209,21 @@ int main() {
         }
       printf("order %d (%s): max |err| / sum|a b| = %.3e   (f32 fma chain: %.3e)\n", order,
              order == 0 ? "6 products, small first" : order == 1 ? "6 products, large first" : "9 products", e_split, e_f32);
+    }
+    printf("== (5) numerics of the f16x2 split (3 products), same data; operand scales 2^11 x 2^11 (max |x| ~ 6 -> < 2^15) and a 2^6 x smaller one\n");
+    for (float sc : {2048.0f, 32.0f}) {
+      hipLaunchKernelGGL(split_gemm_h2, dim3(1), dim3(64), 0, 0, dA, dB, K, dD, sc, sc);
+      hipMemcpy(hD, dD, 256 * 4, hipMemcpyDeviceToHost);
+      double e_split = 0, rms = 0, rms32 = 0;
+      for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+          double ref = 0, sabs = 0; float f = 0.f;
+          for (int k = 0; k < K; ++k) { ref += (double)hA[i * K + k] * hB[k * 16 + j]; sabs += fabs((double)hA[i * K + k] * hB[k * 16 + j]); f = fmaf(hA[i * K + k], hB[k * 16 + j], f); }
+          e_split = fmax(e_split, fabs(hD[i * 16 + j] - ref) / sabs);
+          rms += (hD[i * 16 + j] - ref) * (hD[i * 16 + j] - ref) / (sabs * sabs);
+          rms32 += ((double)f - ref) * ((double)f - ref) / (sabs * sabs);
+        }
+      printf("scale %.0f: max |err| / sum|a b| = %.3e, rms %.3e   (f32 fma chain rms %.3e)\n", sc, e_split, sqrt(rms / 256), sqrt(rms32 / 256));
     }
   }
   return 0;
