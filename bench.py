@@ -595,6 +595,13 @@ def main():
                                "(narrower than the reference's f32: reported, never the headline)")
                 return res
             guarded("matmul_modes", other_modes)
+            if matmul == "f16x2" and isinstance(out.get("matmul_modes", {}).get("bf16x3"), dict):
+                # the round-5 operand mode beside the headline, at the top level: same workload, same run
+                out["value_bf16x3_operands"] = out["matmul_modes"]["bf16x3"]["value"]
+                out["operand_mode_note"] = ("value: MATMUL_DTYPE f16x2 = what the package default `auto` runs at this shape (f32 operands as two range-scaled "
+                                            "fp16 pieces in the position-parallel kernels, f32 accumulate; measured NEARER to float64 than the f32 fma chain "
+                                            "per product and than bf16x3 per gradient: profiles/r06_v7_f16x2_accuracy.txt); value_bf16x3_operands: the "
+                                            "same workload with the three-piece bf16 operands of round 5")
         if sustained is not None:
             out["sustained"] = sustained
         if cpu_base is not None:
