@@ -278,6 +278,22 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
     count += sd;
     if (w1b) w1b += sd * w1bstride;
   }
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t n4 = ((n & 3) == 0 && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0)) ? n / 4 : 0;
+  const bool x3_w1 = w1b && half_off && copy_mode >= 2 && n4 > 0 && (w1_off & 3) == 0;   // fragment-aligned walk over the fc1 kernel (below)
+  // round 6: the fc1 walk's operands are requested BEFORE the norm partials are folded -- the clip decision then arrives while they
+  // are in flight instead of ahead of a second memory round trip (every element is read and written by one thread only)
+  f4 pf_g = {0.f, 0.f, 0.f, 0.f}, pf_m = pf_g, pf_v = pf_g, pf_p = pf_g;
+  if (x3_w1) {
+    const int q0 = (int)blockIdx.x * 256 + threadIdx.x;
+    if (q0 < 1024 * 128 / 4) {
+      const int64_t i4 = (int64_t)(w1_off >> 2) + q0;
+      pf_g = reinterpret_cast<const f4 *>(g)[i4];
+      pf_m = reinterpret_cast<f4 *>(m)[i4];
+      pf_v = reinterpret_cast<f4 *>(v)[i4];
+      pf_p = reinterpret_cast<f4 *>(p)[i4];
+    }
+  }
   // the step-count-dependent scalars (f64: two integer powers, a square root, the schedule) are derived by lane 0 of
   // wave 3 while the norm partials are in flight: the f64 chain is off the critical path
   int32_t c_snap = 0;
@@ -355,14 +371,11 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
       }
     }
   };
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const int64_t n4 = ((n & 3) == 0 && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0)) ? n / 4 : 0;
   // bf16x3 layout: the fc1 kernel is walked fragment-aligned (one 256-element MFMA fragment per wave) so that the six
   // bf16 planes are written with 8-B stores -- four K-consecutive values per lane directly for the forward-order
   // planes, and after a 4 x 4 exchange inside each lane quad (through LDS) for the dgrad-order planes -- instead of
   // 24 two-byte stores per thread (measured: the optimizer kernel took 33 us per 16-seed launch against 18 without
   // the planes).  The generic loops below then skip that range.
-  const bool x3_w1 = w1b && half_off && copy_mode >= 2 && n4 > 0 && (w1_off & 3) == 0;
   if (x3_w1) {
     __shared__ float s_tr[4][256];
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -377,8 +390,11 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
       float pa[4] = {0.f, 0.f, 0.f, 0.f};
       if (on) {
         const int64_t i4 = (int64_t)(w1_off >> 2) + q;
-        const f4 g4 = reinterpret_cast<const f4 *>(g)[i4];
-        const f4 m4 = reinterpret_cast<f4 *>(m)[i4], v4 = reinterpret_cast<f4 *>(v)[i4], p4 = reinterpret_cast<f4 *>(p)[i4];
+        f4 g4 = pf_g, m4 = pf_m, v4 = pf_v, p4 = pf_p;    // first pass: requested at the top of the kernel
+        if (it > 0) {
+          g4 = reinterpret_cast<const f4 *>(g)[i4];
+          m4 = reinterpret_cast<f4 *>(m)[i4]; v4 = reinterpret_cast<f4 *>(v)[i4]; p4 = reinterpret_cast<f4 *>(p)[i4];
+        }
         const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
         float ma[4] = {m4.x, m4.y, m4.z, m4.w}, va[4] = {v4.x, v4.y, v4.z, v4.w};
         pa[0] = p4.x; pa[1] = p4.y; pa[2] = p4.z; pa[3] = p4.w;

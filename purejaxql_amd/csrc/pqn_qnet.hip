@@ -2873,6 +2873,12 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     // 16 slab loads in flight at a time, UNCONDITIONAL (slab index clamped, the surplus masked in the add: a load under
     // a condition makes the compiler wait for the whole queue), added in slab order
+    if (nks <= 2) {   // the position-parallel backward leaves one or two chunk slabs: two loads, not sixteen (the same sums: 0 + a + b)
+      const f32x4 t0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wpart) + j4);
+      const f32x4 t1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wpart + (size_t)(nks - 1) * QN_H1 * QN_HID) + j4);
+      g += t0;
+      g += t1 * (nks > 1 ? 1.0f : 0.0f);
+    } else
     for (int k0 = 0; k0 < nks; k0 += 16) {
       f32x4 t[16];
 #pragma unroll
@@ -2906,6 +2912,13 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t 
     // 16 loads in flight per lane (round 4; 8 before: the fold of 256 records per seed was 8 dependent HBM round trips per
     // wave); the order of the additions -- records wave, wave + 4, wave + 8, ... -- is unchanged
     float g = 0.0f;
+    if (n_all <= 16) {   // at most four records per wave (position-parallel form at the bench shape: 16 + 16): four loads in flight, same order
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = src[(size_t)max(min(wave + 4 * q, n - 1), 0) * stride];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g += v[q] * ((wave + 4 * q < n) ? 1.0f : 0.0f);
+    } else
     for (int t0 = wave; t0 < n_all; t0 += 64) {
       float v[16];
 #pragma unroll
