@@ -447,6 +447,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     };
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) load_az(0, pl);
+
     POSB_STAMP(1);
     x3_drain(cb_[0], cs_[0], cb_[1], cs_[1]);
     float xh[2][4], rs[2][4], dxv[2][4];
@@ -652,16 +653,19 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_bwd_kernel(int nb, int nc
     POSB_STAMP(5);
     // ---- conv weight gradient: dWc[k][ch] += sum over samples of bit(sample, k) dx[sample][ch]; the bits of window
     // element k over the 32 samples are ONE word of T32: nibble kq of each half = this lane's eight K slots ----
-    u32x4 fa[NRB];
+    // (the bit operand is two dependent LDS round trips -- T32 word -> byte -> table row -- right in front of its use.  Round 6 moved the
+    // fetch up into the conv's / the dgrad's shadow: this wave's stamps improved, 4588 -> 4432 cycles per super-tile, and the KERNEL got
+    // slower, 160.5 -> 168.2 / 165.1 us: the early LDS reads queue in front of the operand reads of the MFMA phases.  It stays here.)
+    u32x4 fw[NRB];
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
       const uint32_t wv = t32L[tb[rb]];
       const uint32_t byte = __builtin_amdgcn_ubfe(wv, 4u * kq, 4u) | (__builtin_amdgcn_ubfe(wv, 16u + 4u * kq, 4u) << 4);
-      fa[rb] = pos_expand8<C>(s_lut, byte);
+      fw[rb] = pos_expand8<C>(s_lut, byte);
     }
-    x3_grp_sameb<NRB>(cw, fa, fd.l);   // NRB independent chains per plane: one asm group (one pad) each
-    x3_grp_sameb<NRB>(cw, fa, fd.m);
-    x3_grp_sameb<NRB>(cw, fa, fd.h);
+    x3_grp_sameb<NRB>(cw, fw, fd.l);   // NRB independent chains per plane: one asm group (one pad) each
+    x3_grp_sameb<NRB>(cw, fw, fd.m);
+    x3_grp_sameb<NRB>(cw, fw, fd.h);
     POSB_STAMP(6);
     if (POS_PAIR_SYNC == 0 || (j & 1) != 0) {
       pos_dma_wait();            // this wave's share of the next slot(s) has landed ...

@@ -14,7 +14,7 @@ from purejaxql_amd.pqn import make_train, seed_keys
 def main():
     cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", "alg.NUM_ENVS=4096",
                                "alg.TEST_DURING_TRAINING=False"]))
-    cfg["MATMUL_DTYPE"] = "bf16x3"
+    cfg["MATMUL_DTYPE"] = os.environ.get("MD", "f16x2")
     cfg["TOTAL_TIMESTEPS"] = 8 * 4096 * 32
     train = make_train(dict(cfg), device="cuda:0")
     update, _finish = train.make_batch_runner(seed_keys(0, 16))
