@@ -158,6 +158,8 @@ def kernel_timer_pass(lib, update, first, mb_samples, seeds, mode=1):
 
 
 def t1_roofline(avg_s, launches, mb_samples, seeds, matmul, form, flop_per_sample=T1_FLOP_PER_SAMPLE, channels=4, actions=3):
+    if matmul == "f16x2" and form != "pos":
+        matmul = "bf16x3"     # an f16x2 layout runs bf16x3 in every kernel form but the position-parallel one: priced as what ran
     if form == "pos":     # the timed kernel is the backward of the position-parallel form
         flop_per_sample = pos_flop_per_sample(channels, actions)[0]
     achieved = flop_per_sample * mb_samples * seeds / avg_s / 1e12
