@@ -1,4 +1,4 @@
-"""Whole-loop env-steps/s of Breakout (bf16x3) with the kernel forms the library picks by default against the position-parallel forms forced
+"""Whole-loop env-steps/s of Breakout (operand mode MD, default f16x2) with the kernel forms the library picks by default against the position-parallel forms forced
 (options bwd_pos = rollout_pos = 2): where should the form threshold sit?  python tools/form_sweep.py  (on a GPU box)"""
 import os
 import sys
@@ -15,7 +15,7 @@ def rate(n_envs, seeds, pos, steps, warm=3):
     _lib.set_option("bwd_pos", pos)
     _lib.set_option("rollout_pos", pos)
     cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", f"alg.NUM_ENVS={n_envs}", "alg.TEST_DURING_TRAINING=False"]))
-    cfg["MATMUL_DTYPE"] = "bf16x3"
+    cfg["MATMUL_DTYPE"] = os.environ.get("MD", "f16x2")
     cfg["TOTAL_TIMESTEPS"] = (steps + warm + 2) * n_envs * cfg["NUM_STEPS"]
     tr = make_train(cfg, device="cuda:0")
     upd, _ = tr.make_batch_runner(seed_keys(0, seeds)) if seeds > 1 else tr.make_runner(seed_keys(0, 1)[0])
