@@ -109,6 +109,8 @@ enum {
   PQN_OPT_UPD_OVERLAP,    // PQN_UPD_OVERLAP: pqn_bigmlp_update puts the first epoch's permutation and the last gradient-copy plane refresh on a side stream (bit 0 / bit 1; default 0: a fork / join pair in the graph costs ~30 us)
   PQN_OPT_ROLLOUT_POS,    // PQN_ROLLOUT_POS: position-structure rollout kernel (256 envs per workgroup, pqn_qnet_pos.hip) 0 never / 1 when the launch fills the chip (default) / 2 whenever the shape allows
   PQN_OPT_PIN_FORM,       // PQN_PIN_FORM: pqn_cnn_rollout / pqn_cnn_rollout_seeds choose the rollout kernel from the envs PER SEED alone, never from the number of seeds in the launch (default 0)
+  PQN_OPT_POS_WAVES,      // PQN_POS_WAVES: waves per workgroup of the position-parallel forward / rollout kernels, f16x2 layouts: 0 from the launch (default) / 8 / 4 / 2
+  PQN_OPT_POS_CHUNKS,     // PQN_POS_CHUNKS: sample chunks of the position-parallel backward, f16x2 layouts: 0 from the launch (default) / 1 / 2 / 4 / 8
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);

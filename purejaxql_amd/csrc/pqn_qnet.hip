@@ -34,6 +34,7 @@
 #include "pqn_env_rules.h"
 #include "pqn_qnet_x3.h"
 #include "pqn_qnet_pos.h"
+static bool pos_train_plan(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd, pos_plan_t &plan);   // (defined next to the epoch gather)
 
 struct CnnSmem {
   float *h1;      // [QN_TILE][QN_H1S]
@@ -3042,11 +3043,21 @@ static int launch_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_le
   {
     const int rp = pqn_opt(PQN_OPT_ROLLOUT_POS);
     const int nps = n_per_seed > 0 ? n_per_seed : n;
-    if (rp && L.matmul_f16 == 2 && pqn_cnn_pos_rollout_supported(env_id, C, L.a, n, n_per_seed) &&
-        (rp == 2 || (pin_form ? nps >= 2048 : n / 256 >= 160))) {
+    // waves per workgroup (32 envs each): 8; f16x2 layouts outside pin_form: 4 / 2 when that is what puts >= 160 workgroups on the chip
+    int nw = 0;
+    if (pin_form) nw = nps >= 2048 ? 8 : 0;
+    else if (nps % 256 == 0 && n / 256 >= 160) nw = 8;
+    else if (L.pos_f16x2 && nps % 128 == 0 && n / 128 >= 160) nw = 4;
+    else if (L.pos_f16x2 && nps % 64 == 0 && n / 64 >= 160) nw = 2;
+    if (rp == 2 && nw == 0) nw = nps % 256 == 0 ? 8 : (L.pos_f16x2 ? (nps % 128 == 0 ? 4 : 2) : 0);
+    if (nw != 0 && L.pos_f16x2 && !pin_form) {
+      const int ow = pqn_opt(PQN_OPT_POS_WAVES);
+      if ((ow == 8 || ow == 4 || ow == 2) && nps % (32 * ow) == 0) nw = ow;
+    }
+    if (rp && L.matmul_f16 == 2 && nw != 0 && pqn_cnn_pos_rollout_supported(env_id, C, L.a, n, n_per_seed, nw)) {
       pqn_note_kernel_form(1, PQN_FORM_POS);
       return pqn_cnn_pos_rollout(env_id, L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st,
-                                 n_per_seed, theta_stride, keys_stride);
+                                 n_per_seed, theta_stride, keys_stride, nw);
     }
   }
   const size_t smem = cnn_smem_bytes<C>();
@@ -3320,11 +3331,10 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
   // (backward): 16 seeds x 4096 samples give 256 + 256.  The summation orders depend on the minibatch size only, never on the
   // number of seeds in the launch; sd.pin_form takes the form from the minibatch size alone (a solo run then equals its batch).
   {
-    const int pos_opt = pqn_opt(PQN_OPT_BWD_POS);
-    const bool pos_shape = L.matmul_f16 == 2 && with_reduce && nb % 256 == 0 && pos_shape_ok(nb) && pqn_cnn_pos_forward_supported(C, L.a);
-    const bool pos_full = pos_shape && (pos_opt == 2 || (pos_opt == 1 && (sd.pin_form ? nb >= 2048 : (nb / 256) * sd.nseeds >= 160)));
+    pos_plan_t plan;
+    const bool pos_full = with_reduce && pos_train_plan(L, nb, sd, plan);
     if (pos_full) {
-      const int nch = pos_chunks(nb);
+      const int nch = plan.nch;
       const pos_ws_t PW = pos_ws_layout(nb, C, L.a);
       // the form's buffers live in the region that holds h1^T in the other forms (pqn_qnet_cnn_workspace_floats sizes it)
       PQN_REQUIRE(PW.end <= (long long)QN_H1 * qw_h1_cols(nb), "pqn_qnet_cnn_grad: position-parallel layout (%lld floats) exceeds the h1^T region",
@@ -3349,7 +3359,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
           rc = pqn_cnn_pos_gather(L, nb, idx, bits, action, target, h1T, PW, sd, sd.nseeds, st);
         }
         if (t_fwd) (void)hipEventRecord(g_prof.s[g_prof.n], st);
-        if (rc == PQN_OK) rc = pqn_cnn_pos_forward(L, nb, theta, inv_b, h1T, PM, sd, sd.nseeds, st);
+        if (rc == PQN_OK) rc = pqn_cnn_pos_forward(L, nb, theta, inv_b, h1T, PM, sd, sd.nseeds, st, plan.nw);
         if (t_fwd) (void)hipEventRecord(g_prof.e[g_prof.n++], st);
         if (t_bwd) (void)hipEventRecord(g_prof.s[g_prof.n], st);
         if (rc == PQN_OK) rc = pqn_cnn_pos_backward(L, nb, nch, theta, h1T, wpart, PM, sd, sd.nseeds, st);
@@ -3357,7 +3367,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
         if (rc != PQN_OK) return rc;
       }
       if (part != 1)
-        hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, nb / 256, nch, rec,
+        hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, nb / (32 * plan.nw), nch, rec,
                            h1T + PW.recs, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd, h1T + PW.gpos, 8 * nch);
       return pqn_check_launch("pqn_qnet_cnn_grad");
     }
@@ -3523,14 +3533,32 @@ int pqn_cnn_grad_reduce_blocks(int total) { return grad_reduce_blocks(total); }
 // the epoch region (same bytes at other addresses: results are bit-identical).  The region sits behind the per-minibatch workspace
 // (pqn_qnet_cnn_workspace_floats); pqn_cnn_update_workspace_floats() sizes both.  Callers whose workspace stride is smaller keep
 // the per-minibatch gather.
-static bool pos_form_taken(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd) {
+// Does a training launch of this shape take the position-parallel form, and cut how (waves per forward workgroup, sample chunks of the
+// backward)?  A pure function of its arguments and the options: launch_train, the epoch gather and the optimizer's plane policy all ask it.
+static bool pos_train_plan(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd, pos_plan_t &plan) {
   const int pos_opt = pqn_opt(PQN_OPT_BWD_POS);
-  const bool pos_shape = L.matmul_f16 == 2 && nb % 256 == 0 && pos_shape_ok(nb) && pqn_cnn_pos_forward_supported(L.c, L.a) && L.c != 10;
-  return pos_shape && (pos_opt == 2 || (pos_opt == 1 && (sd.pin_form ? nb >= 2048 : (nb / 256) * sd.nseeds >= 160)));
+  plan = pos_plan(L.pos_f16x2 != 0, nb, sd.nseeds, sd.pin_form != 0);
+  if (!(L.matmul_f16 == 2 && pos_opt != 0 && nb % 64 == 0 && pos_shape_ok(nb) && pqn_cnn_pos_forward_supported(L.c, L.a) && L.c != 10)) return false;
+  bool taken = sd.pin_form ? (nb >= 2048 && nb % 256 == 0) : plan.nw != 0;
+  if (sd.pin_form) plan.nw = 8;
+  if (pos_opt == 2 && !taken) {               // "whenever the shape allows": 8 waves if the minibatch has whole 256-sample blocks, else the finest cut
+    plan.nw = nb % 256 == 0 ? 8 : (L.pos_f16x2 ? (nb % 128 == 0 ? 4 : 2) : 0);
+    taken = plan.nw != 0;
+  }
+  if (taken && L.pos_f16x2 && !sd.pin_form) {  // test / measurement overrides
+    const int ow = pqn_opt(PQN_OPT_POS_WAVES), oc = pqn_opt(PQN_OPT_POS_CHUNKS);
+    if ((ow == 8 || ow == 4 || ow == 2) && nb % (32 * ow) == 0) plan.nw = ow;
+    if (oc >= 1 && oc <= POS_MAX_CHUNKS && (oc & (oc - 1)) == 0 && nb % (64 * oc) == 0 && oc <= (nb + 255) / 256) plan.nch = oc;
+  }
+  return taken;
+}
+static bool pos_form_taken(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd) {
+  pos_plan_t plan;
+  return pos_train_plan(L, nb, sd, plan);
 }
 bool pqn_qnet_cnn_pos_form_taken(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd) { return pos_form_taken(L, nb, sd); }
 long long pqn_qnet_cnn_epoch_floats(const pqn_cnn_layout_t &L, int nb, int nmb) {
-  if (L.matmul_f16 != 2 || nb % 256 != 0 || !pos_shape_ok(nb) || !pqn_cnn_pos_forward_supported(L.c, L.a) || L.c == 10) return 0;
+  if (L.matmul_f16 != 2 || nb % 64 != 0 || !pos_shape_ok(nb) || !pqn_cnn_pos_forward_supported(L.c, L.a) || L.c == 10) return 0;
   return pos_epoch_layout(nb, nmb, L.c).end;
 }
 // true when the update of this shape gathers per epoch: the launch takes the position-parallel form and the caller's workspace stride

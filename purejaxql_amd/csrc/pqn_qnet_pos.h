@@ -9,15 +9,16 @@ __host__ __device__ constexpr int pos_t32_words(int c) { return (100 * c + 1 + 2
 
 // carve-up of the h1^T region of a seed's training workspace in the position-parallel form (float offsets from the region's
 // start; every offset a multiple of 4 floats = 16 B).  dz comes first: the DMA plan addresses everything relative to it.
+#define POS_MAX_CHUNKS 8       // sample chunks of the backward (one partial dW1 slab each)
 struct pos_ws_t {
   long long dz;        // dz as three bf16 planes [3][nb][128] in the dgrad's operand order (dz_planes_a)
   long long mb_bits;   // [nb][OW] packed observation rows in minibatch order
   long long t32;       // [nb / 32][pos_t32_words] bit-transposed rows
   long long stats;     // [nb / 32][64 positions][2][32 samples]: LayerNorm_0 mean | 1/std (forward kernel; round 5: [..][32][2])
-  long long gpos;      // [8 nch][9C*16 + 48] conv-block records of the backward workgroups
+  long long gpos;      // [8 nch][9C*16 + 48] conv-block records of the backward workgroups (nch <= POS_MAX_CHUNKS)
   long long act;       // [nb] i32 (minibatch order)
   long long tgt;       // [nb] f32
-  long long recs;      // [nb / 256][record] head-block records of the forward workgroups
+  long long recs;      // [nb / (32 NW)][record] head-block records of the forward workgroups
   long long end;       // floats used
 };
 inline pos_ws_t pos_ws_layout(int nb, int c, int a) {
@@ -30,10 +31,10 @@ inline pos_ws_t pos_ws_layout(int nb, int c, int a) {
   w.t32 = al(w.mb_bits + (long long)nb * ow);
   w.stats = al(w.t32 + (long long)(nb / 32) * pos_t32_words(c));
   w.gpos = al(w.stats + (long long)nb * 128);
-  w.act = al(w.gpos + 16ll * (9 * c * 16 + 48));
+  w.act = al(w.gpos + 8ll * POS_MAX_CHUNKS * (9 * c * 16 + 48));
   w.tgt = al(w.act + nb);
   w.recs = al(w.tgt + nb);
-  w.end = al(w.recs + (long long)((nb + 255) / 256) * rec);
+  w.end = al(w.recs + (long long)((nb + 63) / 64) * rec);     // one record per forward workgroup: 256 samples, or 128 / 64 (f16x2, round 6)
   return w;
 }
 
@@ -58,6 +59,23 @@ inline pos_epoch_t pos_epoch_layout(int nb, int nmb, int c) {
 // seed's summation order does not depend on how many seeds share the launch
 inline int pos_chunks(int nb) { return nb >= 1024 ? 2 : 1; }
 inline bool pos_shape_ok(int nb) { return nb % (64 * pos_chunks(nb)) == 0; }
+// Round 6 (f16x2 layouts, not under pin_form): launches that would leave CUs idle get finer workgroups -- `nw` waves (32 samples each) per
+// forward / rollout workgroup instead of 8, more sample chunks in the backward -- chosen from the launch so that both kernels put >= 160
+// workgroups on the chip.  nw = 0: the launch does not fill the chip even with the finest cut (the form is not taken in auto mode).
+struct pos_plan_t {
+  int nw, nch;
+};
+inline pos_plan_t pos_plan(bool f16x2, int nb, int nseeds, bool pinned) {
+  pos_plan_t p = {0, pos_chunks(nb)};
+  if (nb % 256 == 0 && (nb / 256) * nseeds >= 160) p.nw = 8;
+  else if (f16x2 && !pinned) {
+    if (nb % 128 == 0 && (nb / 128) * nseeds >= 160) p.nw = 4;
+    else if (nb % 64 == 0 && (nb / 64) * nseeds >= 160) p.nw = 2;
+  }
+  if (f16x2 && !pinned && p.nw != 0)
+    while (8 * p.nch * nseeds < 160 && p.nch < POS_MAX_CHUNKS && nb % (128 * p.nch) == 0 && nb / (64 * p.nch) >= 4 && 2 * p.nch <= (nb + 255) / 256) p.nch *= 2;
+  return p;
+}
 
 // The three launches of the position-parallel form.  wsx = seed 0's h1^T region (carved up by pos_ws_layout), w1out = seed 0's
 // split-K slab region (nch slabs are written); sg.seed_base / nseeds select the seeds of this launch.
@@ -69,14 +87,14 @@ int pqn_cnn_pos_gather(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, co
                        const float *target, float *wsx, const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st);
 bool pqn_cnn_pos_forward_supported(int c, int a);
 int pqn_cnn_pos_forward(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
-                        const pqn_seeds_t &sg, int nseeds, hipStream_t st);
+                        const pqn_seeds_t &sg, int nseeds, hipStream_t st, int nw = 8);
 int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float *theta, float *wsx, float *w1out, const pos_ws_t &W,
                          const pqn_seeds_t &sg, int nseeds, hipStream_t st);
 
 // persistent rollout in the structure of the forward kernel (one workgroup per 256 envs, wave = 32 envs): the scan of
 // pqn_qnet_cnn_rollout for launches whose envs (per seed) come in multiples of 256; same arguments
-bool pqn_cnn_pos_rollout_supported(int env_id, int c, int a, int n, int n_per_seed);
+bool pqn_cnn_pos_rollout_supported(int env_id, int c, int a, int n, int n_per_seed, int nw = 8);
 int pqn_cnn_pos_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
                         const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
                         const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed, long long theta_stride,
-                        int keys_stride);
+                        int keys_stride, int nw = 8);

@@ -750,18 +750,21 @@ PQN_D float pos_quad_sum1(float a) {
 #ifndef POS_PAIR_SYNC_FWD
 #define POS_PAIR_SYNC_FWD 1     // forward kernel: one barrier per two K steps over a four-slot ring (see POS_PAIR_SYNC)
 #endif
-template <int C, int NPL = 3>
+// NW = waves per workgroup of the forward / rollout kernels (32 samples each): 8 in rounds 5-6; 4 and 2 (round 6, f16x2 only) give launches
+// of fewer seeds or smaller minibatches a workgroup on every CU -- a workgroup still streams ALL of the fc1 planes through its LDS ring
+template <int C, int NPL = 3, int NW = 8>
 struct PosFwdCfg {
   using P = PosCfg<C, NPL>;
+  static_assert(NW == 8 || NW == 4 || NW == 2, "waves per forward workgroup");
   static constexpr int N_W = NPL * 512;                             // chunks of one K step's planes: [NPL][8 cb][64]
   static constexpr int ROWW = POS_ST * P::ROWSTRIDE * 4;            // words of a wave's packed rows
   static constexpr int DZS = 132;                                   // LDS row stride of the dz transposition tile
   static constexpr int RS = POS_PAIR_SYNC_FWD ? 4 : 2;              // ring slots
   static constexpr size_t ring_bytes = (size_t)RS * N_W * 16;
-  static constexpr size_t rows_bytes = (size_t)8 * ROWW * 4;
-  static constexpr size_t misc_floats(int a) { return ((P::CONVBLK + 3) & ~3) + ((384 + 128 * a + a + 3) & ~3) + 8 * 64 + 1024; }   // + the pos_expand8 table
+  static constexpr size_t rows_bytes = (size_t)NW * ROWW * 4;
+  static constexpr size_t misc_floats(int a) { return ((P::CONVBLK + 3) & ~3) + ((384 + 128 * a + a + 3) & ~3) + NW * 64 + 1024; }   // + the pos_expand8 table
   static constexpr size_t loop_bytes(int a) { return ring_bytes + rows_bytes + (size_t)P::NCS * NPL * 64 * 16 + sizeof(float) * misc_floats(a); }
-  static constexpr size_t tail_bytes = (size_t)8 * POS_ST * DZS * 4;   // dz tiles of the eight waves (over ring + rows)
+  static constexpr size_t tail_bytes = (size_t)NW * POS_ST * DZS * 4;  // dz tiles of the waves (over ring + rows)
   static constexpr size_t lds_bytes(int a) {
     const size_t fixed = (size_t)P::NCS * NPL * 64 * 16 + sizeof(float) * misc_floats(a);
     const size_t front = ring_bytes + rows_bytes > tail_bytes ? ring_bytes + rows_bytes : tail_bytes;
@@ -813,19 +816,23 @@ PQN_D float pos_fwd_consts(PosFwdCtx<C> &cx, const float *s_wc) {   // returns t
   }
   return sc;
 }
-template <int C, int NPL>
-PQN_D void pos_fwd_dma_step(const PosFwdCtx<C> &cx, int kk) {   // K step kk & 31 -> slot kk % RS; wave w moves column block w of each plane
-  using F = PosFwdCfg<C, NPL>;
+template <int C, int NPL, int NW>
+PQN_D void pos_fwd_dma_step(const PosFwdCtx<C> &cx, int kk) {   // K step kk & 31 -> slot kk % RS; wave w moves column blocks w, w + NW, .. of each plane
+  using F = PosFwdCfg<C, NPL, NW>;
   const uint32_t offW = (uint32_t)(cx.lane * 16);
 #pragma unroll
   for (int pl = 0; pl < NPL; ++pl)
-    pos_dma16(offW, cx.wf + (size_t)pl * (X3_PLANE / 8) + ((kk & 31) * 8 + cx.wave) * 64,
-              cx.ring_lds + (uint32_t)(((kk & (F::RS - 1)) * F::N_W + (pl * 8 + cx.wave) * 64) * 16));
+#pragma unroll
+    for (int cbk = 0; cbk < 8 / NW; ++cbk) {
+      const int cb = cx.wave + NW * cbk;
+      pos_dma16(offW, cx.wf + (size_t)pl * (X3_PLANE / 8) + ((kk & 31) * 8 + cb) * 64,
+                cx.ring_lds + (uint32_t)(((kk & (F::RS - 1)) * F::N_W + (pl * 8 + cb) * 64) * 16));
+    }
 }
-template <int C, int NPL, bool STATS>
+template <int C, int NPL, int NW, bool STATS>
 PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
   using P = PosCfg<C, NPL>;
-  using F = PosFwdCfg<C, NPL>;
+  using F = PosFwdCfg<C, NPL, NW>;
   using M = PosMM<NPL>;
   constexpr bool H2 = NPL == 2;
   constexpr int RB = P::RB, NCS = P::NCS;
@@ -833,7 +840,7 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
   unsigned long long *stamps = cx.stamps;
   const int lane = cx.lane, wave = cx.wave;
   (void)stamps; (void)lane; (void)wave;
-  auto dma_step = [&](int kk) { pos_fwd_dma_step<C, NPL>(cx, kk); };
+  auto dma_step = [&](int kk) { pos_fwd_dma_step<C, NPL, NW>(cx, kk); };
   // window masks of sample (16 t + lane & 15) at the two positions of K step sn: p0 = 8 py + pxb, p1 = p0 + 1 (same window
   // rows, one column apart) -- in two halves: the LDS reads, and (once they have arrived) the shifts
   auto mask_words = [&](int sn, uint32_t (&lo)[3][2], uint32_t (&hi)[3][2]) {
@@ -875,7 +882,7 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
   for (int s = 0; s < 32; ++s) {
     if constexpr (POS_PAIR_SYNC_FWD != 0) {
       if ((s & 1) == 0) { dma_step(kk0 + s + 2); dma_step(kk0 + s + 3); }
-      if ((cx.wave >= 4) == ((s & 1) != 0)) __builtin_amdgcn_s_setprio(1);
+      if ((cx.wave >= NW / 2) == ((s & 1) != 0)) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     } else {
       dma_step(kk0 + s + 1);
@@ -988,12 +995,13 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
   }
 }
 
-template <int C, int NA, int NPL>
-__global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
-                                                                  float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd,
-                                                                  unsigned long long *__restrict__ stamps) {
+template <int C, int NA, int NPL, int NW>
+__global__ __launch_bounds__(64 * NW) void cnn_pos_fwd_kernel(int nb, const float *__restrict__ theta, pqn_cnn_layout_t L, float inv_b,
+                                                              float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd,
+                                                              unsigned long long *__restrict__ stamps) {
   using P = PosCfg<C, NPL>;
-  using F = PosFwdCfg<C, NPL>;
+  using F = PosFwdCfg<C, NPL, NW>;
+  constexpr int NT = 64 * NW;                        // threads of the workgroup
   using Cfg = CnnCfg<C>;
   constexpr bool H2 = NPL == 2;
   constexpr int CONVBLK = P::CONVBLK, NCS = P::NCS;
@@ -1001,14 +1009,14 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   extern __shared__ __attribute__((aligned(16))) char pos_smem[];
   constexpr size_t FRONT = F::ring_bytes + F::rows_bytes > F::tail_bytes ? F::ring_bytes + F::rows_bytes : F::tail_bytes;
   u32x4 *ring = reinterpret_cast<u32x4 *>(pos_smem);                               // [RS][NPL][8][64]
-  uint32_t *s_rows = reinterpret_cast<uint32_t *>(pos_smem + F::ring_bytes);       // [8 waves][32][ROWSTRIDE * 4]
+  uint32_t *s_rows = reinterpret_cast<uint32_t *>(pos_smem + F::ring_bytes);       // [NW waves][32][ROWSTRIDE * 4]
   u32x4 *s_cvw = reinterpret_cast<u32x4 *>(pos_smem + FRONT);                       // conv kernel planes [K step][plane][lane]
   float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * NPL * 64);                  // conv kernel | bias | ln0 scale | ln0 bias
   float *s_hp = s_wc + ((CONVBLK + 3) & ~3);                                        // b1 | ln1 scale | ln1 bias | w2[128][A] | b2
-  float *s_at = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                            // [8 waves][32 act (as int) | 32 tgt]
-  u32x4 *s_lut = reinterpret_cast<u32x4 *>(s_at + 8 * 64);                          // pos_expand8 table
+  float *s_at = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                            // [NW waves][32 act (as int) | 32 tgt]
+  u32x4 *s_lut = reinterpret_cast<u32x4 *>(s_at + NW * 64);                         // pos_expand8 table
   // XCD-aware (seed, block): the blocks of a seed stream the same 768 KB of planes -- one XCD's L2 per seed when possible
-  const int nblk = nb / 256, nsl = gridDim.x / nblk;
+  const int nblk = nb / (POS_ST * NW), nsl = gridDim.x / nblk;
   int seed_l, blk;
   {
     const int lin = blockIdx.x;
@@ -1027,22 +1035,22 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, g = lane >> 4;          // conv phase: sample column, channels 4 g .. 4 g + 3; head: output column, rows 4 g ..
-  const int st = blk * 8 + wave;                     // this wave's super-tile
+  const int st = blk * NW + wave;                    // this wave's super-tile
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(theta + L.off_w1h + (H2 ? H2_PLANES_OFF : 0));   // forward-order planes [NPL][32 steps][8 cb][64]
   const uint32_t ring_lds = pos_lds_addr(ring);
   {   // the first two K steps' planes go out before anything else
     PosFwdCtx<C> c0;
     c0.wf = wf; c0.ring_lds = ring_lds; c0.lane = lane; c0.wave = wave;
-    pos_fwd_dma_step<C, NPL>(c0, 0);
-    if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C, NPL>(c0, 1);
+    pos_fwd_dma_step<C, NPL, NW>(c0, 0);
+    if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C, NPL, NW>(c0, 1);
   }
   // ---- prologue: parameters, this wave's packed rows / actions / targets ----
-  for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
-  for (int i = tid; i < 384; i += POS_THREADS) s_hp[i] = theta[L.off_b1 + i];
-  for (int i = tid; i < 128 * NA; i += POS_THREADS) s_hp[384 + i] = theta[L.off_w2 + i];
+  for (int i = tid; i < CONVBLK; i += NT) s_wc[i] = theta[L.off_wc + i];
+  for (int i = tid; i < 384; i += NT) s_hp[i] = theta[L.off_b1 + i];
+  for (int i = tid; i < 128 * NA; i += NT) s_hp[384 + i] = theta[L.off_w2 + i];
   if (tid < NA) s_hp[384 + 128 * NA + tid] = theta[L.off_b2 + tid];
-  pos_lut_fill(s_lut, tid, POS_THREADS);
+  pos_lut_fill(s_lut, tid, NT);
   {
     const u32x4 *g_rows = reinterpret_cast<const u32x4 *>(wsx + W.mb_bits) + (size_t)st * POS_ST * P::ROWCH;
     u32x4 *rw = reinterpret_cast<u32x4 *>(s_rows + wave * F::ROWW);
@@ -1072,7 +1080,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int c = 0; c < 8; ++c) zacc[t][c] = zero4;
-  pos_fwd_kloop<C, NPL, true>(cx, 0, zacc);
+  pos_fwd_kloop<C, NPL, NW, true>(cx, 0, zacc);
   { const int s = 0; (void)s; POSF_STAMP(8); }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -1230,7 +1238,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   // ---- the workgroup's record of head-parameter gradient sums: rows of the lane -> the 4 row groups -> the 8 waves ----
   __syncthreads();                                       // every wave is done with its dz tile: the front of the LDS becomes the record scratch
   float *recw = reinterpret_cast<float *>(pos_smem) + (size_t)wave * REC;
-  static_assert((size_t)8 * REC * sizeof(float) <= FRONT, "records must fit the front region");
+  static_assert((size_t)NW * REC * sizeof(float) <= FRONT, "records must fit the front region");
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     pos_quad_sum2(a_b1[c], a_sc[c]);
@@ -1261,10 +1269,13 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
   __syncthreads();
   float *rec = wsx + W.recs + (size_t)blk * REC;
   const float *r0 = reinterpret_cast<const float *>(pos_smem);
-  for (int e = tid; e < REC; e += POS_THREADS) {
+  for (int e = tid; e < REC; e += NT) {
     float v = 0.0f;
-    if (e >= CONVBLK)
-      v = ((r0[e] + r0[REC + e]) + (r0[2 * REC + e] + r0[3 * REC + e])) + ((r0[4 * REC + e] + r0[5 * REC + e]) + (r0[6 * REC + e] + r0[7 * REC + e]));
+    if (e >= CONVBLK) {
+      if constexpr (NW == 8) v = ((r0[e] + r0[REC + e]) + (r0[2 * REC + e] + r0[3 * REC + e])) + ((r0[4 * REC + e] + r0[5 * REC + e]) + (r0[6 * REC + e] + r0[7 * REC + e]));
+      else if constexpr (NW == 4) v = (r0[e] + r0[REC + e]) + (r0[2 * REC + e] + r0[3 * REC + e]);
+      else v = r0[e] + r0[REC + e];
+    }
     rec[e] = v;
   }
   { const int s = 0; (void)s; POSF_STAMP(11); }
@@ -1280,25 +1291,26 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_fwd_kernel(int nb, const 
 // barriers synchronises the waves.  q is summed in the K order of the training forward kernel (one chain over the 32 K steps),
 // not in the order of the 16-env kernels of pqn_qnet.hip: the two agree to f32 rounding, not bit for bit.
 // ---------------------------------------------------------------------------
-template <int C, int NA, int NPL>
+template <int C, int NA, int NPL, int NW>
 struct PosRollCfg {
   using P = PosCfg<C, NPL>;
-  using F = PosFwdCfg<C, NPL>;
-  static constexpr size_t fixed_floats = ((P::CONVBLK + 3) & ~3) + ((384 + 128 * NA + NA + 3) & ~3) + 8 * POS_ST * 8 + 1024;
+  using F = PosFwdCfg<C, NPL, NW>;
+  static constexpr size_t fixed_floats = ((P::CONVBLK + 3) & ~3) + ((384 + 128 * NA + NA + 3) & ~3) + NW * POS_ST * 8 + 1024;
   static constexpr size_t lds_bytes = F::ring_bytes + F::rows_bytes + (size_t)P::NCS * NPL * 64 * 16 + sizeof(float) * fixed_floats;
 };
 
-template <int C, class Env, int NA, int NPL>
-__global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
+template <int C, class Env, int NA, int NPL, int NW>
+__global__ __launch_bounds__(64 * NW) void cnn_pos_rollout_kernel(
     int n, int t_len, uint32_t *__restrict__ state, uint32_t *__restrict__ bits_all, const float *__restrict__ theta,
     pqn_cnn_layout_t L, int32_t *__restrict__ action, float *__restrict__ qmax, float *__restrict__ reward,
     uint8_t *__restrict__ done, float *__restrict__ discount, float *__restrict__ rer, int32_t *__restrict__ rel,
     int32_t *__restrict__ ts, float *__restrict__ last_q, const float *__restrict__ eps_dev,
     const uint64_t *__restrict__ keys, float rscale, int store_obs, int n_per_seed, long long theta_stride, int keys_stride) {
   using P = PosCfg<C, NPL>;
-  using F = PosFwdCfg<C, NPL>;
+  using F = PosFwdCfg<C, NPL, NW>;
   using Cfg = CnnCfg<C>;
   constexpr bool H2 = NPL == 2;
+  constexpr int NT = 64 * NW, WGE = POS_ST * NW;     // threads / envs of the workgroup
   static_assert(Cfg::OW == Env::OBS_WORDS, "packed observation width");
   static_assert(NA <= 8, "q exchange buffer");
   constexpr int CONVBLK = P::CONVBLK, NCS = P::NCS;
@@ -1308,10 +1320,10 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
   u32x4 *s_cvw = reinterpret_cast<u32x4 *>(pos_smem + F::ring_bytes + F::rows_bytes);
   float *s_wc = reinterpret_cast<float *>(s_cvw + NCS * NPL * 64);
   float *s_hp = s_wc + ((CONVBLK + 3) & ~3);
-  float *s_q = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                              // [8 waves][32 envs][8]
-  u32x4 *s_lut = reinterpret_cast<u32x4 *>(s_q + 8 * POS_ST * 8);
+  float *s_q = s_hp + ((384 + 128 * NA + NA + 3) & ~3);                              // [NW waves][32 envs][8]
+  u32x4 *s_lut = reinterpret_cast<u32x4 *>(s_q + NW * POS_ST * 8);
   // (seed, block) of this workgroup, XCD-aware as in the training forward: the blocks of a seed share its W1 planes
-  const int nps = n_per_seed > 0 ? n_per_seed : n, nblk = nps / 256, nsl = gridDim.x / nblk;
+  const int nps = n_per_seed > 0 ? n_per_seed : n, nblk = nps / WGE, nsl = gridDim.x / nblk;
   int seed_l, blk;
   {
     const int lin = blockIdx.x;
@@ -1333,7 +1345,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, g = lane >> 4;
-  const int e0 = e_off + blk * 256 + POS_ST * wave;   // first env of this wave
+  const int e0 = e_off + blk * WGE + POS_ST * wave;   // first env of this wave
   const int e = e0 + (lane & 31), e_rng = e - e_off;
   const bool owner = lane < POS_ST;
   const size_t bstride = (size_t)n * Cfg::OW;
@@ -1343,13 +1355,13 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
   cx.ring = ring; cx.ring_lds = pos_lds_addr(ring); cx.s_cvw = s_cvw; cx.s_lut = s_lut;
   cx.rowsW = s_rows + wave * F::ROWW; cx.g_stat = nullptr;
   cx.lane = lane; cx.wave = wave; cx.i16 = i16; cx.g = g; cx.stamps = nullptr;
-  pos_fwd_dma_step<C, NPL>(cx, 0);
-  if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C, NPL>(cx, 1);
-  for (int i = tid; i < CONVBLK; i += POS_THREADS) s_wc[i] = theta[L.off_wc + i];
-  for (int i = tid; i < 384; i += POS_THREADS) s_hp[i] = theta[L.off_b1 + i];
-  for (int i = tid; i < 128 * NA; i += POS_THREADS) s_hp[384 + i] = theta[L.off_w2 + i];
+  pos_fwd_dma_step<C, NPL, NW>(cx, 0);
+  if constexpr (POS_PAIR_SYNC_FWD != 0) pos_fwd_dma_step<C, NPL, NW>(cx, 1);
+  for (int i = tid; i < CONVBLK; i += NT) s_wc[i] = theta[L.off_wc + i];
+  for (int i = tid; i < 384; i += NT) s_hp[i] = theta[L.off_b1 + i];
+  for (int i = tid; i < 128 * NA; i += NT) s_hp[384 + i] = theta[L.off_w2 + i];
   if (tid < NA) s_hp[384 + 128 * NA + tid] = theta[L.off_b2 + tid];
-  pos_lut_fill(s_lut, tid, POS_THREADS);
+  pos_lut_fill(s_lut, tid, NT);
   uint32_t *rowsM = s_rows + wave * F::ROWW;         // (mutable view of cx.rowsW)
   {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(bits_all) + (size_t)e0 * P::ROWCH;   // slot 0 = the current observation
@@ -1384,7 +1396,7 @@ __global__ __launch_bounds__(POS_THREADS) void cnn_pos_rollout_kernel(
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int c = 0; c < 8; ++c) zacc[tt][c] = zero4;
-    pos_fwd_kloop<C, NPL, false>(cx, 32 * t, zacc);
+    pos_fwd_kloop<C, NPL, NW, false>(cx, 32 * t, zacc);
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -1482,38 +1494,44 @@ extern "C" int pqn_debug_pos_stamps(unsigned long long *out /* host, 32 entries 
   return PQN_OK;
 }
 
-template <int C, int NA, int NPL>
+template <int C, int NA, int NPL, int NW>
 static int pos_forward_launch_m(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
                                 const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
-  using F = PosFwdCfg<C, NPL>;
+  using F = PosFwdCfg<C, NPL, NW>;
   static pqn_once_per_device attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_fwd_kernel<C, NA, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_fwd_kernel<C, NA, NPL, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)F::lds_bytes(NA));
   }
   if (!g_pos_stamps && getenv("PQN_T1_STAMPS") && pqn_not_capturing(st)) {   // (profiling only; an allocation is illegal under stream capture)
     if (hipMalloc(&g_pos_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) g_pos_stamps = nullptr;
   }
-  hipLaunchKernelGGL((cnn_pos_fwd_kernel<C, NA, NPL>), dim3((nb / 256) * nseeds), dim3(POS_THREADS), F::lds_bytes(NA), st, nb, theta, L, inv_b,
-                     wsx, W, sg, g_pos_stamps);
+  hipLaunchKernelGGL((cnn_pos_fwd_kernel<C, NA, NPL, NW>), dim3((nb / (POS_ST * NW)) * nseeds), dim3(64 * NW), F::lds_bytes(NA), st, nb, theta, L,
+                     inv_b, wsx, W, sg, g_pos_stamps);
   return pqn_check_launch("pqn_cnn_pos_forward");
 }
 template <int C, int NA>
 static int pos_forward_launch(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
-                              const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
-  return L.pos_f16x2 ? pos_forward_launch_m<C, NA, 2>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st)
-                     : pos_forward_launch_m<C, NA, 3>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+                              const pqn_seeds_t &sg, int nseeds, hipStream_t st, int nw) {
+  if (!L.pos_f16x2) return pos_forward_launch_m<C, NA, 3, 8>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+  if (nw == 4) return pos_forward_launch_m<C, NA, 2, 4>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+  if (nw == 2) return pos_forward_launch_m<C, NA, 2, 2>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+  return pos_forward_launch_m<C, NA, 2, 8>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
 }
 
 // the (channels, actions) pairs of the MinAtar games gymnax implements
 bool pqn_cnn_pos_forward_supported(int c, int a) { return (c == 4 && (a == 3 || a == 5)) || (c == 6 && a == 4) || (c == 7 && a == 3); }
 
 int pqn_cnn_pos_forward(const pqn_cnn_layout_t &L, int nb, const float *theta, float inv_b, float *wsx, const pos_ws_t &W,
-                        const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
-  if (L.c == 4 && L.a == 3) return pos_forward_launch<4, 3>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
-  if (L.c == 4 && L.a == 5) return pos_forward_launch<4, 5>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
-  if (L.c == 6 && L.a == 4) return pos_forward_launch<6, 4>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
-  if (L.c == 7 && L.a == 3) return pos_forward_launch<7, 3>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st);
+                        const pqn_seeds_t &sg, int nseeds, hipStream_t st, int nw) {
+  if ((nw != 8 && nw != 4 && nw != 2) || nb % (POS_ST * nw) != 0 || (nw != 8 && !L.pos_f16x2)) {
+    pqn_set_error("pqn_cnn_pos_forward: %d waves per workgroup with a minibatch of %d (8 always; 4 / 2 for f16x2 layouts)", nw, nb);
+    return PQN_E_INVALID;
+  }
+  if (L.c == 4 && L.a == 3) return pos_forward_launch<4, 3>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st, nw);
+  if (L.c == 4 && L.a == 5) return pos_forward_launch<4, 5>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st, nw);
+  if (L.c == 6 && L.a == 4) return pos_forward_launch<6, 4>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st, nw);
+  if (L.c == 7 && L.a == 3) return pos_forward_launch<7, 3>(L, nb, theta, inv_b, wsx, W, sg, nseeds, st, nw);
   pqn_set_error("pqn_cnn_pos_forward: unsupported (channels, actions) = (%d, %d)", L.c, L.a);
   return PQN_E_UNSUPPORTED;
 }
@@ -1567,19 +1585,19 @@ int pqn_cnn_pos_backward(const pqn_cnn_layout_t &L, int nb, int nch, const float
   }
 }
 
-template <int C, class Env, int NA, int NPL>
+template <int C, class Env, int NA, int NPL, int NW>
 static int pos_rollout_launch_m(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
                                 const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
                                 const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed,
                                 long long theta_stride, int keys_stride) {
-  using R = PosRollCfg<C, NA, NPL>;
+  using R = PosRollCfg<C, NA, NPL, NW>;
   static pqn_once_per_device attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_rollout_kernel<C, Env, NA, NPL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cnn_pos_rollout_kernel<C, Env, NA, NPL, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::lds_bytes);
   }
-  hipLaunchKernelGGL((cnn_pos_rollout_kernel<C, Env, NA, NPL>), dim3(n / 256), dim3(POS_THREADS), R::lds_bytes, st, n, t_len, state, bits, theta,
-                     L, action, qmax, rec.reward, rec.done, rec.discount, rec.returned_episode_returns,
+  hipLaunchKernelGGL((cnn_pos_rollout_kernel<C, Env, NA, NPL, NW>), dim3(n / (POS_ST * NW)), dim3(64 * NW), R::lds_bytes, st, n, t_len, state, bits,
+                     theta, L, action, qmax, rec.reward, rec.done, rec.discount, rec.returned_episode_returns,
                      rec.returned_episode_lengths, rec.timestep, last_q, eps_dev, keys, rscale, store_obs, n_per_seed, theta_stride,
                      keys_stride);
   return pqn_check_launch("pqn_cnn_pos_rollout");
@@ -1588,16 +1606,20 @@ template <int C, class Env, int NA>
 static int pos_rollout_launch(const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
                               const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
                               const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed,
-                              long long theta_stride, int keys_stride) {
-  return L.pos_f16x2 ? pos_rollout_launch_m<C, Env, NA, 2>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale,
-                                                           store_obs, st, n_per_seed, theta_stride, keys_stride)
-                     : pos_rollout_launch_m<C, Env, NA, 3>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale,
-                                                           store_obs, st, n_per_seed, theta_stride, keys_stride);
+                              long long theta_stride, int keys_stride, int nw) {
+#define POS_ROLL_M(NPL_, NW_) \
+  return pos_rollout_launch_m<C, Env, NA, NPL_, NW_>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, \
+                                                     n_per_seed, theta_stride, keys_stride)
+  if (!L.pos_f16x2) POS_ROLL_M(3, 8);
+  if (nw == 4) POS_ROLL_M(2, 4);
+  if (nw == 2) POS_ROLL_M(2, 2);
+  POS_ROLL_M(2, 8);
+#undef POS_ROLL_M
 }
 
-bool pqn_cnn_pos_rollout_supported(int env_id, int c, int a, int n, int n_per_seed) {
+bool pqn_cnn_pos_rollout_supported(int env_id, int c, int a, int n, int n_per_seed, int nw) {
   const int nps = n_per_seed > 0 ? n_per_seed : n;
-  if (nps <= 0 || nps % 256 != 0 || n % nps != 0) return false;
+  if (nps <= 0 || (nw != 8 && nw != 4 && nw != 2) || nps % (POS_ST * nw) != 0 || n % nps != 0) return false;
   return (env_id == PQN_ENV_BREAKOUT && c == 4 && a == 3) || (env_id == PQN_ENV_ASTERIX && c == 4 && a == 5) ||
          (env_id == PQN_ENV_FREEWAY && c == 7 && a == 3) || (env_id == PQN_ENV_SPACEINVADERS && c == 6 && a == 4);
 }
@@ -1605,10 +1627,11 @@ bool pqn_cnn_pos_rollout_supported(int env_id, int c, int a, int n, int n_per_se
 int pqn_cnn_pos_rollout(int env_id, const pqn_cnn_layout_t &L, int n, int t_len, uint32_t *state, uint32_t *bits, const float *theta,
                         const pqn_step_out_t &rec, int32_t *action, float *qmax, float *last_q, const float *eps_dev,
                         const uint64_t *keys, float rscale, int store_obs, hipStream_t st, int n_per_seed, long long theta_stride,
-                        int keys_stride) {
+                        int keys_stride, int nw) {
+  if (nw != 8 && !L.pos_f16x2) nw = 8;
 #define POS_ROLL(CH, ENV, NACT) \
   return pos_rollout_launch<CH, ENV, NACT>(L, n, t_len, state, bits, theta, rec, action, qmax, last_q, eps_dev, keys, rscale, store_obs, st, \
-                                           n_per_seed, theta_stride, keys_stride)
+                                           n_per_seed, theta_stride, keys_stride, nw)
   if (env_id == PQN_ENV_BREAKOUT && L.c == 4 && L.a == 3) POS_ROLL(4, Breakout, 3);
   if (env_id == PQN_ENV_ASTERIX && L.c == 4 && L.a == 5) POS_ROLL(4, Asterix, 5);
   if (env_id == PQN_ENV_FREEWAY && L.c == 7 && L.a == 3) POS_ROLL(7, Freeway, 3);

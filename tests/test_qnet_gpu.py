@@ -242,9 +242,12 @@ def test_cnn_rollout_equals_step_by_step(gpu, name, c, a, n, t, mode):
     assert torch.equal(words_b, st.words) and torch.equal(bits_b[0], bits) and torch.equal(rec_b["done"], rec["done"])
 
 
-@pytest.mark.parametrize("name,c,a,n,t", [("Breakout-MinAtar", 4, 3, 512, 40), ("Asterix-MinAtar", 4, 5, 256, 24),
-                                          ("Freeway-MinAtar", 7, 3, 256, 16), ("SpaceInvaders-MinAtar", 6, 4, 512, 24)])
-def test_position_structure_rollout_is_consistent_step_by_step(gpu, name, c, a, n, t):
+@pytest.mark.parametrize("name,c,a,n,t,dtype,waves", [("Breakout-MinAtar", 4, 3, 512, 40, "bf16x3", 0), ("Asterix-MinAtar", 4, 5, 256, 24, "bf16x3", 0),
+                                                      ("Freeway-MinAtar", 7, 3, 256, 16, "bf16x3", 0), ("SpaceInvaders-MinAtar", 6, 4, 512, 24, "bf16x3", 0),
+                                                      ("Breakout-MinAtar", 4, 3, 512, 40, "f16x2", 0), ("Asterix-MinAtar", 4, 5, 256, 24, "f16x2", 4),
+                                                      ("Freeway-MinAtar", 7, 3, 192, 16, "f16x2", 2), ("SpaceInvaders-MinAtar", 6, 4, 384, 24, "f16x2", 4),
+                                                      ("Breakout-MinAtar", 4, 3, 320, 24, "f16x2", 0)])
+def test_position_structure_rollout_is_consistent_step_by_step(gpu, name, c, a, n, t, dtype, waves):
     """cnn_pos_rollout_kernel (pqn_qnet_pos.hip: one workgroup per 256 envs, the K loop of the training forward kernel per env
     step; option rollout_pos = 2 forces it at these sizes) against the step-by-step pieces of the product: its q values are
     summed in another order than the 16-env kernels', so actions may differ where the two best q values tie to f32 rounding
@@ -252,7 +255,10 @@ def test_position_structure_rollout_is_consistent_step_by_step(gpu, name, c, a, 
     recorded action equals the eps-greedy action of that kernel (same key, same draws) unless the top-two gap of q is below
     1e-5 max|q|; and pqn_env_step from the recorded state with the RECORDED action reproduces reward, done, LogWrapper info and
     the next packed observation bit for bit, as well as the final env state.  Also the evaluation mode (store_obs = 0) and
-    the bootstrap value.  _step_env scan, pqn_minatar.py:181-235."""
+    the bootstrap value.  _step_env scan, pqn_minatar.py:181-235.
+    dtype f16x2: the kernel on two-piece fp16 operands (the step-by-step reference stays the bf16x3 16-env kernel of the same layout);
+    waves = 4 / 2: workgroups of 128 / 64 envs (option pos_waves; 0 = what the launch picks: 8 when the envs come in 256s, else the
+    finest cut that divides them -- 320 envs: 2 waves)."""
     from purejaxql_amd import _lib
     from purejaxql_amd.envs import LogWrapper, make
     from purejaxql_amd.networks import QNetwork
@@ -261,7 +267,7 @@ def test_position_structure_rollout_is_consistent_step_by_step(gpu, name, c, a, 
     env, params = make(name, device=gpu)
     env = LogWrapper(env)
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
-    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode("bf16x3"))
+    lay = CnnKernelLayout(c, a, matmul_f16=matmul_mode(dtype))
     torch.manual_seed(0)
     theta_k = lay.to_kernel(net.init(3) + 0.05 * torch.randn(net.num_params, device=gpu))
     (_o, bits0), state = env.reset(11, params, n, want_obs=False, want_bits=True)
@@ -276,7 +282,7 @@ def test_position_structure_rollout_is_consistent_step_by_step(gpu, name, c, a, 
     words_a = state.words.clone()
     bits_a = torch.zeros((t + 1, n, bits0.shape[1]), dtype=bits0.dtype, device=gpu)
     bits_a[0] = bits0
-    with _lib.options(rollout_pos=2):
+    with _lib.options(rollout_pos=2, pos_waves=waves):
         rec = cnn_rollout(lay, env_id, words_a, bits_a, theta_k, keys, eps)
         assert _lib.last_kernel_form()[1] == "pos"
         rec2 = cnn_rollout(lay, env_id, state.words.clone(), bits_a.clone()[:1].repeat(t + 1, 1, 1).contiguous(), theta_k, keys, eps)
@@ -430,8 +436,8 @@ def _grads_under_options(gpu, c, a, nb, pool, mode, reps=3, **opts):
 
 @pytest.mark.parametrize("c,a,nb,pool", [(4, 3, 4096, 20000), (4, 3, 512, 3000), (4, 5, 1024, 4000), (6, 4, 2048, 6000), (7, 3, 1024, 3000),
                                          (4, 3, 256, 1000), (4, 3, 8192, 20000), (6, 4, 768, 2000)])
-@pytest.mark.parametrize("pmode", [2, 3], ids=["bf16x3", "f16x2"])
-def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool, pmode):
+@pytest.mark.parametrize("pmode,cut", [(2, None), (3, None), (3, (4, 4)), (3, (2, 8)), (3, (4, 1))], ids=["bf16x3", "f16x2", "f16x2-4w4c", "f16x2-2w8c", "f16x2-4w1c"])
+def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool, pmode, cut):
     """bwd_pos=2 routes a minibatch through the position-parallel kernels of pqn_qnet_pos.hip -- minibatch gather +
     bit-transpose, cnn_pos_fwd_kernel (wave = 32 samples, conv on the fly, z in registers, head on the accumulator layout),
     cnn_pos_bwd_kernel (wave = conv position, its dW1 rows in registers, one partial slab per sample chunk) -- and the
@@ -440,9 +446,12 @@ def test_position_parallel_form_of_the_training_step(gpu, oracle, c, a, nb, pool
     and chosen q equal the f32-MFMA mode of the default kernels, the gradient equals it to f32 rounding and the oracle's numpy
     backward at the tolerance of test_cnn_grad_vs_oracle.  pqn_minatar.py:271-291.
     Both operand modes of the form -- bf16x3 (three bf16 pieces, 6 matrix instructions per product) and f16x2 (two range-scaled fp16
-    pieces, 3 per product) -- are held to the SAME bounds."""
+    pieces, 3 per product) -- are held to the SAME bounds; `cut` = (waves per forward workgroup, sample chunks of the backward) forces the
+    finer cuts that f16x2 launches of fewer seeds / smaller minibatches take to fill the chip (options pos_waves / pos_chunks; a cut the
+    minibatch does not divide into falls back to the launch's own plan)."""
     g_f32, f0, lq0 = _grads_under_options(gpu, c, a, nb, pool, 0, t1_pair=0, t1_ksplit=0, want_loss=True)
-    g_pos, f1, lq1 = _grads_under_options(gpu, c, a, nb, pool, pmode, bwd_pos=2, want_loss=True)
+    extra = {} if cut is None else {"pos_waves": cut[0], "pos_chunks": cut[1]}
+    g_pos, f1, lq1 = _grads_under_options(gpu, c, a, nb, pool, pmode, bwd_pos=2, want_loss=True, **extra)
     assert (f0, f1) == ("single", "pos")
     scale = float(g_f32.abs().max())
     assert abs(lq1[0] - lq0[0]) <= 2e-6 * max(1.0, abs(lq0[0])) and abs(lq1[1] - lq0[1]) <= 2e-6 * max(1.0, abs(lq0[1])), (lq1, lq0)
