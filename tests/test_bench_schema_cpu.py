@@ -83,18 +83,15 @@ def test_committed_bench_line_has_the_contract_fields():
     # the reference's yaml defaults (128 envs): the small-minibatch regime runs the K-split training kernels
     yd = d["yaml_default"]
     assert yd["kernel_forms"]["train"] == "ksplit" and yd["value"] > 1.2e6 and yd["seconds_for_1e7_steps"] < 8.0
-    # BASELINE.json configs[2] / configs[1] beside the headline: the suite at 4096 envs on the position-parallel kernels, Breakout at
-    # 1024 envs (64 workgroups per launch: below the form's threshold) on the pair kernels
+    # BASELINE.json configs[2] / configs[1] beside the headline: the suite at 4096 envs on the position-parallel kernels; Breakout at
+    # 1024 envs x 16 seeds (64 workgroups of 256 samples per launch: below round 5's threshold, the pair kernels then) takes the finer cut of
+    # round 6 -- 2-wave forward / rollout workgroups -- and stays in the form
     suite = {(g["env"], g["num_envs"]): g for g in d["minatar_suite"] if g["seeds_per_gpu"] == 16}
     assert set(suite) == {("Asterix-MinAtar", 4096), ("Freeway-MinAtar", 4096), ("SpaceInvaders-MinAtar", 4096),
                           ("Breakout-MinAtar", 4096), ("Breakout-MinAtar", 1024)}
     for g in suite.values():
-        form = "pos" if g["num_envs"] == 4096 else "pair"
-        assert g["kernel_forms"] == {"train": form, "rollout": form} and g["seeds_per_gpu"] == 16 and g["value"] > (9e7 if form == "pos" else 3e7), g
-        if form == "pos":
-            assert g["t1_flop_per_sample"] == 18432 * g["channels"] + 524288 and 0.25 < g["t1_frac"] < 0.6 and g["t1_frac_f32_peak"] > 1.0
-        else:
-            assert g["t1_flop_per_sample"] == 36864 * g["channels"] + 524288 + 768 * g["actions"] and 0.15 < g["t1_frac"] < 0.4   # bf16x3 kernels, bf16 / 6 basis
+        assert g["kernel_forms"] == {"train": "pos", "rollout": "pos"} and g["seeds_per_gpu"] == 16 and g["value"] > (9e7 if g["num_envs"] == 4096 else 4.5e7), g
+        assert g["t1_flop_per_sample"] == 18432 * g["channels"] + 524288 and 0.2 < g["t1_frac"] < 0.6 and g["t1_frac_f32_peak"] > 1.0
     assert d["config"]["seed_groups"] == 1
     # the extras report the other operand modes and the single-seed run beside the headline, never instead of it
     # (the fp16-operand mode has no position-parallel form: since round 5 it is slower than the split-operand modes)

@@ -232,7 +232,9 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
 @pytest.mark.parametrize("env_name,seeds_checked,dtype", [("Breakout-MinAtar", (0, 7, 15), "bf16x3"), ("SpaceInvaders-MinAtar", (7,), "bf16x3"),
                                                          ("Freeway-MinAtar", (7,), "bf16x3"), ("Asterix-MinAtar", (7,), "bf16x3"),
                                                          ("Breakout-MinAtar", (0, 15), "f16x2"), ("SpaceInvaders-MinAtar", (7,), "f16x2"),
-                                                         ("Freeway-MinAtar", (7,), "f16x2"), ("Asterix-MinAtar", (7,), "f16x2")])
+                                                         ("Freeway-MinAtar", (7,), "f16x2"), ("Asterix-MinAtar", (7,), "f16x2"),
+                                                         ("Breakout-MinAtar", (0, 5), "f16x2/8"), ("Breakout-MinAtar", (3,), "f16x2/4"),
+                                                         ("SpaceInvaders-MinAtar", (2,), "f16x2/8")])
 def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked, dtype):
     """ONE whole update of the bench workload -- 16 seeds batched into the launches, bf16x3, pair rollout + position-parallel
     training kernels -- against oracle.make_train, for seeds 0 / 7 / 15 of Breakout (first, middle and last XCD group) and
@@ -240,17 +242,20 @@ def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked, d
     initial parameters: metrics to 1e-3, the update vector by the size-aware criterion of
     test_make_train_end_to_end_vs_oracle (cosine > 0.998, relative L2 < 6e-2, < 1 % of entries outside rtol 2e-3, worst
     entry < 4 lr; backed in the benched operand mode and kernel form by the same-theta trajectory test of
-    tests/test_fullsize_gpu.py)."""
+    tests/test_fullsize_gpu.py).  dtype "f16x2/8", "f16x2/4": the same with 8 / 4 seeds in the launches -- the finer cuts of round 6
+    (4- / 2-wave forward and rollout workgroups, 4 / 8 backward chunks: pos_plan) are what runs there."""
     from purejaxql_amd import _lib
     from purejaxql_amd.networks import QNetwork
     from purejaxql_amd.pqn import make_train, seed_keys
+    dtype, _, ns = dtype.partition("/")
+    ns = int(ns) if ns else S
     cfg = _cfg(1, env=env_name, dtype=dtype)
     ocfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
     c, a = GAMES[env_name]
     net = QNetwork("cnn", (10, 10, c), a, device=gpu)
     theta0 = net.init(123)
     cfg["_INIT_PARAMS"] = theta0
-    keys = seed_keys(0, S)
+    keys = seed_keys(0, ns)
     train = make_train(cfg, device="cuda:0")
     update, finish = train.make_batch_runner(keys)
     update(0)
