@@ -125,8 +125,10 @@ __global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n
 }
 
 // The epoch shuffle's sort: rocPRIM's device radix sort called directly (ROCm-native API, no CUB-compatibility
-// layer), restricted to the significant key bits: 31 random bits + the index bits (+ 7 seed bits when seeds are
-// batched) instead of all 64.  Keys are unique, so the result does not depend on the sort's stability.
+// layer), restricted to the bits that decide the order: 31 random bits (+ 7 seed bits when seeds are batched) -- round 6: NOT the index
+// bits below them.  The keys arrive in index order (key i of a seed carries i in its low bits), and an LSD radix sort is stable: two
+// transitions that drew the same 31 random bits (a handful per epoch at 131,072 per seed) keep their index order, which is exactly the
+// order the full-width sort of the unique keys gave -- two passes of seven less, the same permutation.
 extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
   size_t bytes = 0;
   if (n <= 0) return -1;
@@ -139,14 +141,15 @@ extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
 // n = keys of ALL seeds, n_per_seed = T*N of one seed
 static int pqn_sort_keys(void *temp, size_t temp_bytes, const int64_t *in, int64_t *out, int n, int nseeds, int n_per_seed,
                          hipStream_t st) {
+  const unsigned begin_bit = (unsigned)pqn_index_bits(n_per_seed);
   const unsigned end_bit = (unsigned)(31 + pqn_index_bits(n_per_seed) + (nseeds > 1 ? 7 : 0));
   size_t need = 0;
-  if (rocprim::radix_sort_keys(nullptr, need, (const unsigned long long *)in, (unsigned long long *)out, (unsigned int)n, 0u,
+  if (rocprim::radix_sort_keys(nullptr, need, (const unsigned long long *)in, (unsigned long long *)out, (unsigned int)n, begin_bit,
                                end_bit, st) != hipSuccess || need > temp_bytes) {
     pqn_set_error("radix sort: %llu temp bytes provided, %llu needed", (unsigned long long)temp_bytes, (unsigned long long)need);
     return PQN_E_INVALID;
   }
-  if (rocprim::radix_sort_keys(temp, need, (const unsigned long long *)in, (unsigned long long *)out, (unsigned int)n, 0u, end_bit,
+  if (rocprim::radix_sort_keys(temp, need, (const unsigned long long *)in, (unsigned long long *)out, (unsigned int)n, begin_bit, end_bit,
                                st) != hipSuccess) {
     pqn_set_error("radix sort failed (temp bytes %llu)", (unsigned long long)temp_bytes);
     return PQN_E_HIP;

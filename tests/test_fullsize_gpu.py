@@ -116,6 +116,35 @@ def test_full_size_shuffle_is_a_bijection_and_update_is_deterministic(gpu):
     assert abs(float(m["timestep"][2]) - (64 + 16.5)) < 1e-3 and float(m["returned_episode"][0]) > 0.05
 
 
+@pytest.mark.parametrize("n_envs,seeds", [(128, 1), (4096, 1), (4096, 16), (32768, 4)])
+def test_update_permutation_equals_the_full_width_sort_of_its_keys(gpu, n_envs, seeds):
+    """The update's radix sort covers only the bits that decide the order (31 random bits + seed id, pqn_update.hip pqn_sort_keys) and
+    relies on stability for transitions that drew the same 31 bits (~4 pairs per seed at 131,072 transitions, ~256 at 2^20): the
+    permutation it leaves behind must be the one the full-width sort of the unique keys gives (jax.random.permutation's stand-in,
+    pqn_minatar.py:299-315) -- on the merge-sort path (one seed) and the onesweep path (seed batches) of rocPRIM."""
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys
+    cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", f"alg.NUM_ENVS={n_envs}", "alg.TEST_DURING_TRAINING=False"]))
+    cfg["TOTAL_TIMESTEPS"] = 3 * n_envs * 32
+    tr = make_train(cfg, device="cuda:0")
+    upd, _ = tr.make_batch_runner(seed_keys(3, seeds)) if seeds > 1 else tr.make_runner(seed_keys(3, 1)[0])
+    upd(0)
+    torch.cuda.synchronize()
+    drv = upd.driver
+    tn = n_envs * 32
+    mask = (1 << max(1, (tn - 1).bit_length())) - 1
+    k_in, k_out = drv.sk_in.clone(), drv.sk_out.clone()
+    assert k_in.numel() == seeds * tn
+    ref = torch.sort(k_in).values
+    same_random_bits = int(((ref[1:] >> (tn - 1).bit_length()) == (ref[:-1] >> (tn - 1).bit_length())).sum())
+    if tn * seeds >= 1 << 21:
+        assert same_random_bits > 0        # the case the stability argument is about occurs at this size
+    assert torch.equal(k_out & mask, ref & mask), same_random_bits
+    if seeds > 1:   # every seed's segment is a permutation of its own transitions
+        seg = (k_out & mask).view(seeds, tn)
+        assert torch.equal(torch.sort(seg, dim=1).values, torch.arange(tn, device=gpu).expand(seeds, tn))
+
+
 def test_c_abi_argument_errors(gpu):
     """Bad arguments are rejected on the host with a negative code and a message (no launch)."""
     from purejaxql_amd import _lib
