@@ -7,7 +7,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "pqn_common.h"
+#include "pqn_fold.h"
 
 // ---------------------------------------------------------------------------
 // error channel + host PRNG helpers
@@ -48,6 +51,7 @@ static struct {
     {"t2_acc", "PQN_T2_ACC", 1, 0, false},        {"upd_overlap", "PQN_UPD_OVERLAP", 0, 0, false},
     {"rollout_pos", "PQN_ROLLOUT_POS", 1, 0, false}, {"pin_form", "PQN_PIN_FORM", 0, 0, false},
     {"pos_waves", "PQN_POS_WAVES", 0, 0, false},   {"pos_chunks", "PQN_POS_CHUNKS", 0, 0, false},
+    {"fold_apply", "PQN_FOLD_APPLY", 1, 0, false},
 };
 static int g_forms[2] = {PQN_FORM_NONE, PQN_FORM_NONE};
 
@@ -262,19 +266,28 @@ __global__ __launch_bounds__(256) void radam_norm_kernel(const float *__restrict
   }
 }
 
+// FOLD (round 6, pqn_fold.h): the launch also folds the training step's partials -- block b of a seed folds what block b of
+// qnet_grad_reduce_kernel folds, keeps the result in registers, publishes its sum of squares in a tagged 8-byte slot of the seed's
+// scratch and reads the other blocks' slots until every tag is this launch's (agent-scope loads and stores: no cache-wide fence, no
+// read-modify-write; a seed's blocks are consecutive in dispatch order and fewer than the chip holds, so the wait cannot starve
+// them).  Then it applies the step to exactly those elements.  One launch and one round trip of the gradient less per optimizer step;
+// the same additions in the same order as the two-launch form.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                           float *__restrict__ m, float *__restrict__ v, int64_t n,
                                                           int32_t *__restrict__ count, float lr_init, float lr_end,
                                                           double lr_steps, float max_norm, int nparts,
-                                                          const float *__restrict__ scratch,
+                                                          float *__restrict__ scratch,
                                                           float *__restrict__ gnorm_out, int w1_off,
                                                           float *__restrict__ w1b, long long pstride, long long sstride,
-                                                          long long w1bstride, int half_off, int copy_mode) {
+                                                          long long w1bstride, int half_off, int copy_mode,
+                                                          typename std::conditional<FOLD, pqn_fold_args_t, int>::type fa) {
   __shared__ float s_part[4];
   __shared__ float s_sc[8];
   {  // seed slice (grid.y; all strides 0 for a single seed)
     const long long sd = blockIdx.y;
-    p += sd * pstride; g += sd * pstride; m += sd * pstride; v += sd * pstride;
+    p += sd * pstride; m += sd * pstride; v += sd * pstride;
+    if (g) g += sd * pstride;
     scratch += sd * sstride;
     count += sd;
     if (w1b) w1b += sd * w1bstride;
@@ -285,6 +298,50 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
   // round 6: the fc1 walk's operands are requested BEFORE the norm partials are folded -- the clip decision then arrives while they
   // are in flight instead of ahead of a second memory round trip (every element is read and written by one thread only)
   f4 pf_g = {0.f, 0.f, 0.f, 0.f}, pf_m = pf_g, pf_v = pf_g, pf_p = pf_g;
+  int32_t c_snap = 0;
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float fold_g = 0.0f, fold_m = 0.0f, fold_v = 0.0f, fold_p = 0.0f;   // FOLD: the element of a non-fc1 block's lane
+  [[maybe_unused]] int fold_i = -1;
+  [[maybe_unused]] unsigned fold_tag = 0;
+  __shared__ int32_t s_cnt;
+  if constexpr (FOLD) {
+    __shared__ float s_red[4][64];
+    __shared__ float s_fpart[4];
+    const bool fc1_blk = blockIdx.x < QR_W1_BLOCKS;
+    const int64_t i4 = (int64_t)(w1_off >> 2) + (int)blockIdx.x * 256 + threadIdx.x;
+    if (fc1_blk) {   // this lane's float4 of the fc1 kernel: moments and parameters requested beside the slab loads of the fold
+      pf_m = reinterpret_cast<f4 *>(m)[i4];
+      pf_v = reinterpret_cast<f4 *>(v)[i4];
+      pf_p = reinterpret_cast<f4 *>(p)[i4];
+    }
+    // this launch's tag: the seed's launch serial + 1 (block 0 stores it back at the end; any initial value will do)
+    const unsigned tag = __hip_atomic_load(reinterpret_cast<unsigned *>(scratch) + PQN_FOLD_SERIAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (threadIdx.x == 192) s_cnt = *count;   // read before this block publishes: block 0 bumps it only after every block has
+    float ss;
+    pqn_fold_block(fa, (int)blockIdx.x, (long long)blockIdx.y, const_cast<float *>(g), s_red, pf_g, fold_g, fold_i, ss);
+    if (fold_i >= 0) { fold_m = m[fold_i]; fold_v = v[fold_i]; fold_p = p[fold_i]; }
+    if ((threadIdx.x & 63) == 0) s_fpart[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(scratch + PQN_FOLD_SLOT0);
+    if (threadIdx.x == 0) {
+      const float tot = (s_fpart[0] + s_fpart[1]) + (s_fpart[2] + s_fpart[3]);
+      __hip_atomic_store(slots + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(tot), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 192) c_snap = s_cnt;
+    if ((int)threadIdx.x < nparts) {   // nparts <= PQN_FOLD_MAX_BLOCKS < 256: one slot per lane
+      unsigned long long sv;
+      int spins = 0;
+      for (;;) {
+        sv = __hip_atomic_load(slots + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(sv >> 32) == tag) break;
+        if (++spins > (1 << 24)) { sv = 0x7FC00000ull; break; }   // never seen; a NaN norm is loud, a hung queue is not
+        __builtin_amdgcn_s_sleep(2);
+      }
+      part[0] = __uint_as_float((unsigned)sv);
+    }
+    fold_tag = tag;
+  } else {
   if (x3_w1) {
     const int q0 = (int)blockIdx.x * 256 + threadIdx.x;
     if (q0 < 1024 * 128 / 4) {
@@ -297,13 +354,12 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
   }
   // the step-count-dependent scalars (f64: two integer powers, a square root, the schedule) are derived by lane 0 of
   // wave 3 while the norm partials are in flight: the f64 chain is off the critical path
-  int32_t c_snap = 0;
   if (threadIdx.x == 192) c_snap = reinterpret_cast<const int32_t *>(scratch)[1023];
-  float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {   // nparts <= 1022: all loads of a lane issued before any is consumed
     const int i = threadIdx.x + 256 * q;
     if (i < nparts) part[q] = scratch[i];
+  }
   }
   if (threadIdx.x == 192) {
     const int32_t c = c_snap;
@@ -325,7 +381,7 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
     s_sc[4] = rect ? 1.0f : 0.0f;
     s_sc[5] = r;
     s_sc[6] = lr;
-    if (blockIdx.x == 0) *count = c + 1;
+    if (!FOLD && blockIdx.x == 0) *count = c + 1;
   }
   float acc = ((part[0] + part[1]) + part[2]) + part[3];   // == the strided loop's order
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -336,6 +392,13 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
     s_sc[0] = gnorm;
     s_sc[1] = (gnorm < max_norm) ? 0.0f : 1.0f;
     if (blockIdx.x == 0 && gnorm_out) *gnorm_out = gnorm;
+    if constexpr (FOLD) {
+      // every lane of this block is past its wait: every block of the seed has published, hence has read the serial and the count
+      if (blockIdx.x == 0) {
+        reinterpret_cast<unsigned *>(scratch)[PQN_FOLD_SERIAL] = fold_tag;
+        *count = s_cnt + 1;
+      }
+    }
   }
   __syncthreads();
   const float gnorm = s_sc[0];
@@ -474,6 +537,30 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float *__restrict__ p,
       }
     }
   }
+  if constexpr (FOLD) {   // the elements this block folded; the generic walks below belong to the two-launch form
+    if (!x3_w1 && blockIdx.x < QR_W1_BLOCKS) {   // layouts without operand planes: the lane's float4 of the fc1 kernel (+ its mirrors)
+      const int64_t i4 = (int64_t)(w1_off >> 2) + (int)blockIdx.x * 256 + threadIdx.x;
+      const float ga[4] = {pf_g.x, pf_g.y, pf_g.z, pf_g.w};
+      float ma[4] = {pf_m.x, pf_m.y, pf_m.z, pf_m.w}, va[4] = {pf_v.x, pf_v.y, pf_v.z, pf_v.w}, pa[4] = {pf_p.x, pf_p.y, pf_p.z, pf_p.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pa[c] = step1(ga[c], ma[c], va[c], pa[c]);
+      reinterpret_cast<f4 *>(m)[i4] = f4{ma[0], ma[1], ma[2], ma[3]};
+      reinterpret_cast<f4 *>(v)[i4] = f4{va[0], va[1], va[2], va[3]};
+      reinterpret_cast<f4 *>(p)[i4] = f4{pa[0], pa[1], pa[2], pa[3]};
+      if (w1b) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mirror(4 * i4 + c, pa[c]);
+      }
+    }
+    if (fold_i >= 0) {   // wave 0 of a non-fc1 block: lane = element
+      float mi = fold_m, vi = fold_v;
+      const float pn = step1(fold_g, mi, vi, fold_p);
+      m[fold_i] = mi;
+      v[fold_i] = vi;
+      p[fold_i] = pn;
+    }
+    return;
+  }
   const int64_t w1_lo4 = x3_w1 ? (w1_off >> 2) : 0, w1_hi4 = x3_w1 ? (w1_off >> 2) + 1024 * 128 / 4 : 0;
   for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (int64_t)gridDim.x * 256) {
     if (i4 >= w1_lo4 && i4 < w1_hi4) continue;   // done above
@@ -515,9 +602,25 @@ int pqn_launch_radam(float *p, const float *g, float *m, float *v, int64_t n, in
     hipLaunchKernelGGL(radam_norm_kernel, dim3(blocks), dim3(256), 0, st, g, n, count, scratch);
     nparts = blocks;
   }
-  hipLaunchKernelGGL(radam_apply_kernel, dim3(blocks, nseeds), dim3(256), 0, st, p, g, m, v, n, count, lr_init, lr_end,
-                     lr_steps, max_norm, nparts, scratch, gnorm_out, w1_off, w1b, pstride, sstride, w1bstride, half_off, copy_mode);
+  hipLaunchKernelGGL(radam_apply_kernel<false>, dim3(blocks, nseeds), dim3(256), 0, st, p, g, m, v, n, count, lr_init, lr_end,
+                     lr_steps, max_norm, nparts, scratch, gnorm_out, w1_off, w1b, pstride, sstride, w1bstride, half_off, copy_mode, 0);
   return pqn_check_launch("radam");
+}
+
+// Fold + clip + RAdam of a CNN training step in one launch (radam_apply_kernel<true>; pqn_fold.h).  g: where the folded gradient is
+// ALSO stored (the flat gradient buffer), or NULL.  Option fold_apply = 0 (or a shape it does not cover) -> PQN_E_UNSUPPORTED: the
+// caller then takes the two launches.
+int pqn_launch_radam_fold(const pqn_fold_args_t &fa, float *p, float *g, float *m, float *v, int32_t *count, float lr_init, float lr_end,
+                          double lr_steps, float max_norm, float *scratch, float *w1b, hipStream_t st, int nseeds, long long pstride,
+                          long long sstride, long long w1bstride, int half_off, int copy_mode) {
+  const int blocks = grad_reduce_blocks(fa.L.total);
+  if (!fa.valid || blocks > PQN_FOLD_MAX_BLOCKS || (fa.L.total & 3) || (fa.L.off_w1 & 3) ||
+      ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) || (pstride & 3) || (sstride & 1))
+    return PQN_E_UNSUPPORTED;
+  hipLaunchKernelGGL(radam_apply_kernel<true>, dim3(blocks, nseeds), dim3(256), 0, st, p, g, m, v, (int64_t)fa.L.total, count, lr_init,
+                     lr_end, lr_steps, max_norm, blocks, scratch, (float *)nullptr, fa.L.off_w1, w1b, pstride, sstride, w1bstride, half_off,
+                     copy_mode, fa);
+  return pqn_check_launch("radam (fold)");
 }
 
 extern "C" int pqn_radam_clip_step(float *p, const float *g, float *m, float *v, int64_t n, int32_t *count,

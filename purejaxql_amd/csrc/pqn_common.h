@@ -111,6 +111,7 @@ enum {
   PQN_OPT_PIN_FORM,       // PQN_PIN_FORM: pqn_cnn_rollout / pqn_cnn_rollout_seeds choose the rollout kernel from the envs PER SEED alone, never from the number of seeds in the launch (default 0)
   PQN_OPT_POS_WAVES,      // PQN_POS_WAVES: waves per workgroup of the position-parallel forward / rollout kernels, f16x2 layouts: 0 from the launch (default) / 8 / 4 / 2
   PQN_OPT_POS_CHUNKS,     // PQN_POS_CHUNKS: sample chunks of the position-parallel backward, f16x2 layouts: 0 from the launch (default) / 1 / 2 / 4 / 8
+  PQN_OPT_FOLD_APPLY,     // PQN_FOLD_APPLY: fold of the gradient partials + clip + RAdam of a fused CNN update in ONE launch (radam_apply_kernel<true>, pqn_fold.h): 0 never / 1 (default) for launches of one or two seeds (seeds x blocks <= 400) / 2 always; bit-identical either way
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);
@@ -246,12 +247,14 @@ int pqn_shuffle_keys_dyn(const uint64_t *key_dev, int n, int64_t *keys, hipStrea
 // seed-batched variant: keys[s*n + i] = (s << (31+ib)) | (rand31(i; key_dev[s*key_stride]) << ib) | i  (n <= 2^25,
 // S <= 128): one global radix sort orders every seed's segment exactly as its single-seed keys would be
 int pqn_shuffle_keys_seeds(const uint64_t *key_dev, int key_stride, int nseeds, int n, int64_t *keys, hipStream_t st);
+struct pqn_fold_args_t;
 int pqn_cnn_grad_reduce_blocks(int total);   // number of sum-of-squares partials pqn_qnet_cnn_grad leaves in the scratch
 int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out,
                             const pqn_seeds_t &sd, hipStream_t st, bool with_reduce = true, int part = 0, int epoch_mb = -1,
-                            int epoch_nmb = 0);
+                            int epoch_nmb = 0, struct pqn_fold_args_t *defer = nullptr);
+// defer: the fold of the partials is not launched but described in *defer (pqn_fold.h) for pqn_launch_radam_fold -- fold + clip + RAdam in one launch
 // the position-parallel form's gather once per epoch (pqn_qnet.hip); _applies: pure predicate of shape, options and workspace stride
 bool pqn_qnet_cnn_epoch_applies(const pqn_cnn_layout_t &L, int nb, int nmb, const pqn_seeds_t &sd);
 bool pqn_qnet_cnn_pos_form_taken(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd);   // the training step of this shape takes the position-parallel form

@@ -34,6 +34,7 @@
 #include "pqn_env_rules.h"
 #include "pqn_qnet_x3.h"
 #include "pqn_qnet_pos.h"
+#include "pqn_fold.h"
 static bool pos_train_plan(const pqn_cnn_layout_t &L, int nb, const pqn_seeds_t &sd, pos_plan_t &plan);   // (defined next to the epoch gather)
 
 struct CnnSmem {
@@ -2841,120 +2842,24 @@ __global__ __launch_bounds__(QN_THREADS) void qnet_fc1_wgrad_f16_kernel(int nb, 
 // Blocks [0, QR_W1_BLOCKS): fc1 region, float4 per lane, sum over the K-splits.
 // Remaining blocks: 64 "small" elements each (lane = element), the four waves split the tile records, fixed order.
 // ---------------------------------------------------------------------------
-#define QR_W1_BLOCKS (QN_H1 * QN_HID / 1024)
+static_assert(QN_H1 * QN_HID == PQN_FC1_ELEMS, "pqn_fold.h");   // the fold itself: pqn_fold.h (shared with radam_apply_kernel<true>, pqn_algo.hip)
 
-__host__ __device__ inline int grad_reduce_blocks(int total) { return QR_W1_BLOCKS + (total - QN_H1 * QN_HID + 63) / 64; }
-
-__global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_cnn_layout_t L, int ntiles, int nks, int rec,
-                                                               const float *__restrict__ gpart,
-                                                               const float *__restrict__ wpart, float *__restrict__ grad,
-                                                               const int32_t *__restrict__ count,
-                                                               float *__restrict__ scratch, float *__restrict__ loss_out,
-                                                               float *__restrict__ qv_out, float inv_b, pqn_seeds_t sd,
-                                                               const float *__restrict__ gpos, int npos) {
-  // gpos / npos: the conv-block partials come from the position-parallel backward (npos records of 9C*16+48 floats per
-  // seed) instead of from the per-tile records
+__global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(pqn_fold_args_t fa, float *__restrict__ grad,
+                                                               const int32_t *__restrict__ count, float *__restrict__ scratch,
+                                                               long long theta_stride) {
   __shared__ float s_part[4];
   __shared__ float s_red[4][64];
-  {  // seed slice
-    const long long s = blockIdx.y;
-    gpart += s * sd.ws_stride;
-    if (gpos) gpos += s * sd.ws_stride;
-    wpart += s * sd.ws_stride;
-    scratch += s * sd.ws_stride;
-    grad += s * sd.theta_stride;
-    count += s;
-    if (loss_out) loss_out += s * sd.lq_stride;
-    if (qv_out) qv_out += s * sd.lq_stride;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ss = 0.0f;
-  if (blockIdx.x < QR_W1_BLOCKS) {
-    const int j4 = blockIdx.x * 256 + threadIdx.x;  // float4 index inside the fc1 region
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    // 16 slab loads in flight at a time, UNCONDITIONAL (slab index clamped, the surplus masked in the add: a load under
-    // a condition makes the compiler wait for the whole queue), added in slab order
-    if (nks <= 2) {   // the position-parallel backward leaves one or two chunk slabs: two loads, not sixteen (the same sums: 0 + a + b)
-      const f32x4 t0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wpart) + j4);
-      const f32x4 t1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wpart + (size_t)(nks - 1) * QN_H1 * QN_HID) + j4);
-      g += t0;
-      g += t1 * (nks > 1 ? 1.0f : 0.0f);
-    } else
-    for (int k0 = 0; k0 < nks; k0 += 16) {
-      f32x4 t[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
-        t[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wpart + (size_t)min(k0 + q, nks - 1) * QN_H1 * QN_HID) + j4);   // read once
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float keep = (k0 + q < nks) ? 1.0f : 0.0f;
-        g += t[q] * keep;
-      }
-    }
-    reinterpret_cast<f32x4 *>(grad + L.off_w1)[j4] = g;
-    ss = fmaf(g.x, g.x, fmaf(g.y, g.y, fmaf(g.z, g.z, g.w * g.w)));
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-  } else {
-    // lane = element (64 consecutive non-fc1 elements per block), so that the loads of a wave run along the records
-    // (256 B contiguous) instead of across them; wave w adds records w, w + 4, ... in order, 8 loads in flight
-    // (unconditional: index clamped, surplus masked in the add), and the four waves are folded in fixed order.
-    const int sidx = (blockIdx.x - QR_W1_BLOCKS) * 64 + lane;  // index among the non-fc1 elements
-    const int i = sidx < L.off_w1 ? sidx : sidx + QN_H1 * QN_HID;
-    const int convblk = 9 * L.c * 16 + 48;
-    int r = -1;  // index into the small record (-1: dummy BatchNorm / padding -> zero gradient)
-    if (i >= L.off_wc && i < L.off_wc + convblk) r = i - L.off_wc;
-    else if (i >= L.off_b1 && i < L.off_b1 + 384) r = convblk + (i - L.off_b1);
-    else if (i >= L.off_w2 && i < L.off_w2 + 128 * L.a) r = convblk + 384 + (i - L.off_w2);
-    else if (i >= L.off_b2 && i < L.off_b2 + L.a) r = convblk + 384 + 128 * L.a + (i - L.off_b2);
-    const bool from_pos = gpos && r >= 0 && r < convblk;
-    const float *src = (from_pos ? gpos : gpart) + (r >= 0 ? r : 0);
-    const int stride = from_pos ? convblk : rec, n = r < 0 ? 0 : (from_pos ? npos : ntiles);
-    const int n_all = (gpos && npos > ntiles) ? npos : ntiles;   // uniform loop bound
-    // 16 loads in flight per lane (round 4; 8 before: the fold of 256 records per seed was 8 dependent HBM round trips per
-    // wave); the order of the additions -- records wave, wave + 4, wave + 8, ... -- is unchanged
-    float g = 0.0f;
-    if (n_all <= 16) {   // at most four records per wave (position-parallel form at the bench shape: 16 + 16): four loads in flight, same order
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = src[(size_t)max(min(wave + 4 * q, n - 1), 0) * stride];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) g += v[q] * ((wave + 4 * q < n) ? 1.0f : 0.0f);
-    } else
-    for (int t0 = wave; t0 < n_all; t0 += 64) {
-      float v[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = src[(size_t)max(min(t0 + 4 * q, n - 1), 0) * stride];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) g += v[q] * ((t0 + 4 * q < n) ? 1.0f : 0.0f);
-    }
-    s_red[wave][lane] = g;
-    __syncthreads();
-    if (wave == 0) {
-      g = (s_red[0][lane] + s_red[1][lane]) + (s_red[2][lane] + s_red[3][lane]);
-      if (i < L.total) {
-        grad[i] = g;
-        ss = g * g;
-      }
-      for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-    } else ss = 0.0f;
-    if (blockIdx.x == QR_W1_BLOCKS && wave == 0) {  // metrics td_loss / qvals (pqn_minatar.py:334-335)
-      float l = 0.f, qv = 0.f;
-      for (int t = lane; t < ntiles; t += 64) {
-        l += gpart[(size_t)t * rec + rec - 2];
-        qv += gpart[(size_t)t * rec + rec - 1];
-      }
-      for (int off = 32; off > 0; off >>= 1) { l += __shfl_down(l, off, 64); qv += __shfl_down(qv, off, 64); }
-      if (lane == 0) {
-        if (loss_out) *loss_out = l * inv_b;
-        if (qv_out) *qv_out = qv * inv_b;
-      }
-    }
-  }
-  if (lane == 0) s_part[wave] = ss;
+  const long long s = blockIdx.y;   // seed slice
+  scratch += s * fa.ws_stride;
+  pqn_f4 g4;
+  float g_small, ss;
+  int i_small;
+  pqn_fold_block(fa, (int)blockIdx.x, s, grad + s * theta_stride, s_red, g4, g_small, i_small, ss);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
   __syncthreads();
   if (threadIdx.x == 0) {
     scratch[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    if (blockIdx.x == 0) reinterpret_cast<int32_t *>(scratch)[1023] = *count;
+    if (blockIdx.x == 0) reinterpret_cast<int32_t *>(scratch)[1023] = count[s];
   }
 }
 
@@ -3234,11 +3139,36 @@ extern "C" int pqn_cnn_seed_group(int matmul_mode, int nseeds) {
   return nseeds;   // measured (16 seeds x 4096 samples, bf16x3): groups of 16 / 8 / 4 / 2 -> 50.4 / 50.7 / 51.3 / 55.5 ms per update
 }
 
+// the fold of the partials: its own launch (qnet_grad_reduce_kernel, then radam_apply_kernel), or -- `defer` given -- handed to the
+// optimizer kernel, which folds, clips and applies in one launch (radam_apply_kernel<true>, pqn_algo.hip / pqn_fold.h)
+static void launch_fold(const pqn_cnn_layout_t &L, int ntiles, int nks, int rec, const float *gpart, const float *wpart, float *grad,
+                        const int32_t *count, float *scratch, float *loss_out, float *qv_out, float inv_b, const pqn_seeds_t &sd,
+                        const float *gpos, int npos, hipStream_t st, pqn_fold_args_t *defer) {
+  pqn_fold_args_t fa = {};
+  fa.L = L; fa.ntiles = ntiles; fa.nks = nks; fa.rec = rec; fa.gpart = gpart; fa.wpart = wpart; fa.loss_out = loss_out; fa.qv_out = qv_out;
+  fa.inv_b = inv_b; fa.gpos = gpos; fa.npos = npos; fa.ws_stride = sd.ws_stride; fa.lq_stride = sd.lq_stride; fa.valid = 1;
+  if (defer) {
+    *defer = fa;
+    return;
+  }
+  hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, fa, grad, count, scratch,
+                     sd.theta_stride);
+}
+
+// a deferred fold launched by itself after all (the optimizer kernel's one-launch form did not take the shape)
+int pqn_cnn_fold_launch(const pqn_fold_args_t &fa, float *grad, const int32_t *count, float *scratch, int nseeds, long long theta_stride,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(fa.L.total), nseeds), dim3(256), 0, st, fa, grad, count, scratch,
+                     theta_stride);
+  return pqn_check_launch("pqn_qnet_cnn_grad (fold)");
+}
+
 template <int C>
 static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits,
                         const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                         const int32_t *count, float *ws, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
-                        hipStream_t st, bool with_reduce, int part, int epoch_mb = -1, int epoch_nmb = 0) {
+                        hipStream_t st, bool with_reduce, int part, int epoch_mb = -1, int epoch_nmb = 0,
+                        pqn_fold_args_t *defer = nullptr) {
   // epoch_mb >= 0 (round 6): the rows / actions / targets of ALL epoch_nmb minibatches of this epoch were gathered once, by
   // pqn_qnet_cnn_epoch_gather, into the epoch region behind the workspace; this is minibatch epoch_mb of them
   // part: 0 = the whole gradient; 1 = the compute-bound training kernel(s) only; 2 = the HBM-bound rest (fc1 weight
@@ -3310,8 +3240,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
     else if (ks_ng == 4) KS_LAUNCH(16);
     else KS_LAUNCH(8);
 #undef KS_LAUNCH
-    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles * ks_ng, ntiles,
-                       rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b_ks, sd, (const float *)nullptr, 0);
+    launch_fold(L, ntiles * ks_ng, ntiles, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b_ks, sd, nullptr, 0, st, defer);
     return pqn_check_launch("pqn_qnet_cnn_grad");
   }
   static pqn_once_per_device attr_set;
@@ -3367,8 +3296,8 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
         if (rc != PQN_OK) return rc;
       }
       if (part != 1)
-        hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, nb / (32 * plan.nw), nch, rec,
-                           h1T + PW.recs, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd, h1T + PW.gpos, 8 * nch);
+        launch_fold(L, nb / (32 * plan.nw), nch, rec, h1T + PW.recs, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd, h1T + PW.gpos,
+                    8 * nch, st, defer);
       return pqn_check_launch("pqn_qnet_cnn_grad");
     }
   }
@@ -3450,8 +3379,7 @@ static int launch_train(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, c
                          sd.ws_stride);
   }
   if (with_reduce && part != 1)
-    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(grad_reduce_blocks(L.total), sd.nseeds), dim3(256), 0, st, L, ntiles,
-                       t2_acc ? 1 : nks, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd, (const float *)nullptr, 0);
+    launch_fold(L, ntiles, t2_acc ? 1 : nks, rec, gpart, wpart, grad, count, scratch, loss_out, qv_out, inv_b, sd, nullptr, 0, st, defer);
   return pqn_check_launch("pqn_qnet_cnn_grad");
 }
 
@@ -3514,12 +3442,12 @@ extern "C" int pqn_qnet_cnn_grad_seeds(const pqn_cnn_layout_t *L, int32_t num_se
 int pqn_qnet_cnn_grad_seeds_dyn(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *obs_bits,
                             const int32_t *action, const float *target, const float *theta, const float *w1b, float *grad,
                             const int32_t *count, float *workspace, float *loss_out, float *qv_out, const pqn_seeds_t &sd,
-                            hipStream_t st, bool with_reduce, int part, int epoch_mb, int epoch_nmb) {
+                            hipStream_t st, bool with_reduce, int part, int epoch_mb, int epoch_nmb, pqn_fold_args_t *defer) {
   switch (L.c) {
-    case 4: return launch_train<4>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb);
-    case 6: return launch_train<6>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb);
-    case 7: return launch_train<7>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb);
-    case 10: return launch_train<10>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part);
+    case 4: return launch_train<4>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb, defer);
+    case 6: return launch_train<6>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb, defer);
+    case 7: return launch_train<7>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, epoch_mb, epoch_nmb, defer);
+    case 10: return launch_train<10>(L, nb, idx, obs_bits, action, target, theta, w1b, grad, count, workspace, loss_out, qv_out, sd, st, with_reduce, part, -1, 0, defer);
     default: pqn_set_error("pqn_qnet_cnn_grad: unsupported channel count %d", L.c); return PQN_E_UNSUPPORTED;
   }
 }

@@ -11,6 +11,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "pqn_common.h"
+#include "pqn_fold.h"
 
 // scalar + mean metrics of one update, in the order of pqn_minatar.py:330-338
 enum { M_ENV_STEP, M_UPDATE_STEPS, M_ENV_FRAME, M_GRAD_STEPS, M_TD_LOSS, M_QVALS, M_DISCOUNT, M_RET_RETURNS,
@@ -257,16 +258,18 @@ static int upd_shuffle(const pqn_update_args_t *a, const UpdCtx &c, int ep, hipS
   return PQN_OK;
 }
 
-static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool with_reduce, hipStream_t st, int part = 0) {
+static int upd_grad(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool with_reduce, hipStream_t st, int part = 0,
+                    pqn_fold_args_t *defer = nullptr) {
   const int mb = i_mb % c.MB;
   // low bits of a sorted shuffle key = the transition index inside the seed (kernels mask with sd.idx_mask)
   const bool epoch = with_reduce && pqn_qnet_cnn_epoch_applies(a->layout, c.B, c.MB, c.sd);   // gathered by upd_shuffle
   return pqn_qnet_cnn_grad_seeds_dyn(a->layout, c.B, a->sort_keys_out + (size_t)mb * c.B, a->bits, a->action, a->target, a->theta,
                                  a->w1b, a->grad, a->count, a->workspace, a->loss_buf + i_mb, a->qv_buf + i_mb, c.sd, st,
-                                 with_reduce, part, epoch ? mb : -1, c.MB);
+                                 with_reduce, part, epoch ? mb : -1, c.MB, defer);
 }
 
-static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool norm_pass, hipStream_t st) {
+static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool norm_pass, hipStream_t st,
+                     const pqn_fold_args_t *fold = nullptr) {
   const pqn_cnn_layout_t &L = a->layout;
   // f16x2 layouts carry two plane sets of the fc1 kernel: fp16 for the position-parallel kernels, bf16 for every other form.  Inside
   // an update whose optimizer steps take the position-parallel form nothing reads the bf16 set until the update is over (the next
@@ -274,6 +277,15 @@ static int upd_apply(const pqn_update_args_t *a, const UpdCtx &c, int i_mb, bool
   // the update writes it: 24 MB less store traffic per 16-seed launch, 25 -> 20 us per optimizer kernel.
   int copy_mode = L.matmul_f16 + L.pos_f16x2;
   if (L.pos_f16x2 && i_mb + 1 < c.MB * c.EP && pqn_qnet_cnn_pos_form_taken(L, c.B, c.sd)) copy_mode = 4;
+  if (fold && fold->valid) {
+    // the fold was deferred to the optimizer kernel (pqn_fold.h): one launch folds, clips and applies; a->grad is written by the LAST
+    // step of the update only (it then holds the last minibatch's gradient, as it does after the two-launch form)
+    const int rc = pqn_launch_radam_fold(*fold, a->theta, i_mb + 1 == c.MB * c.EP ? a->grad : nullptr, a->m, a->v, a->count, a->lr_init,
+                                         a->lr_end, a->lr_steps, a->max_grad_norm, a->workspace, a->w1b, st, c.S, c.sd.theta_stride,
+                                         c.sd.ws_stride, c.sd.w1b_stride, L.matmul_f16 != 0 ? L.off_w1h : 0, copy_mode);
+    if (rc != PQN_E_UNSUPPORTED) return rc;
+    UPD_CHECK(pqn_cnn_fold_launch(*fold, a->grad, a->count, a->workspace, c.S, c.sd.theta_stride, st));
+  }
   return pqn_launch_radam(a->theta, a->grad, a->m, a->v, L.total, a->count, a->lr_init, a->lr_end, a->lr_steps,
                           a->max_grad_norm, a->workspace, nullptr, L.off_w1, a->w1b, norm_pass ? 1 : 0,
                           pqn_cnn_grad_reduce_blocks(L.total), st, c.S, c.sd.theta_stride, c.sd.ws_stride, c.sd.w1b_stride,
@@ -306,8 +318,15 @@ static int cnn_update_impl(const pqn_update_args_t *a, int S, const uint64_t *ke
   for (int ep = 0; ep < c.EP; ++ep) {
     UPD_CHECK(upd_shuffle(a, c, ep, st));
     for (int mb = 0; mb < c.MB; ++mb, ++i_mb) {
-      UPD_CHECK(upd_grad(a, c, i_mb, true, st));
-      UPD_CHECK(upd_apply(a, c, i_mb, false, st));
+      // fold + clip + RAdam in one launch (pqn_fold.h) for launches of one or two seeds (seeds x blocks <= 400): measured +2-3 % for
+      // one seed (128 / 1024 / 4096 envs), +0.5-1.2 % for two, -0.5-1 % at four, -4 % at 8 and 16 seeds x 4096 envs and -8 % at 16 x 512,
+      // where blocks wait on their seed's norm in front of blocks that could be streaming (profiles/r06_v8_fold_apply_ab.txt);
+      // option fold_apply: 0 never, 1 by that rule, 2 always
+      pqn_fold_args_t fold = {};
+      const int fold_opt = pqn_opt(PQN_OPT_FOLD_APPLY);
+      const bool fold_on = fold_opt == 2 || (fold_opt == 1 && (long long)c.S * pqn_cnn_grad_reduce_blocks(a->layout.total) <= 400);
+      UPD_CHECK(upd_grad(a, c, i_mb, true, st, 0, fold_on ? &fold : nullptr));
+      UPD_CHECK(upd_apply(a, c, i_mb, false, st, &fold));
     }
   }
   return upd_end(a, c, st);

@@ -145,6 +145,43 @@ def test_update_permutation_equals_the_full_width_sort_of_its_keys(gpu, n_envs, 
         assert torch.equal(torch.sort(seg, dim=1).values, torch.arange(tn, device=gpu).expand(seeds, tn))
 
 
+@pytest.mark.parametrize("env_name,n_envs,seeds,mode,form", [
+    ("Breakout-MinAtar", 128, 1, "auto", "ksplit"),        # yaml default: K-split kernels, f32 operands, 64 + 8 partial records
+    ("Breakout-MinAtar", 1024, 1, "auto", "single"),       # C2: single-tile bf16x3 kernels, split-K slabs of the fc1 weight gradient
+    ("Breakout-MinAtar", 4096, 2, "bf16x3", "pair"),       # pair form, accumulating fc1 weight gradient or slabs
+    ("Breakout-MinAtar", 4096, 4, "f16x2", "pos"),         # position-parallel form: chunk slabs + position records, fp16 planes only until the last step
+    ("SpaceInvaders-MinAtar", 1024, 3, "f32", "single"),   # other channel / action counts: another parameter layout, w1b mirror without planes
+    ("Freeway-MinAtar", 512, 2, "f16", "single"),          # fp16 operand copies
+])
+def test_one_launch_fold_clip_radam_is_bit_identical_to_the_two_launch_form(gpu, env_name, n_envs, seeds, mode, form):
+    """Option fold_apply (2 = at any launch size, 1 = the default rule; pqn_fold.h): the optimizer kernel of a fused update folds the gradient partials itself -- same blocks,
+    loads and order of additions as qnet_grad_reduce_kernel + radam_apply_kernel (optax.chain(clip_by_global_norm, radam),
+    pqn_minatar.py:159-162,293-297): parameters, both moments, the step count, the metrics rows and the last minibatch's gradient
+    must be bit-identical after 3 updates (192 optimizer steps, the last 2 updates as hipGraph replays) in every kernel form."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys
+    outs = []
+    for fold in (0, 2):
+        with _lib.options(fold_apply=fold):
+            cfg = flatten(load_config(["+alg=pqn_minatar", f"alg.ENV_NAME={env_name}", f"alg.NUM_ENVS={n_envs}", "alg.TEST_DURING_TRAINING=False",
+                                       f"alg.MATMUL_DTYPE={mode}"]))
+            cfg["TOTAL_TIMESTEPS"] = 3 * n_envs * 32
+            tr = make_train(cfg, device="cuda:0")
+            upd, fin = tr.make_batch_runner(seed_keys(11, seeds)) if seeds > 1 else tr.make_runner(seed_keys(11, 1)[0])
+            for u in range(3):
+                upd(u)
+            torch.cuda.synchronize()
+            assert _lib.last_kernel_form()[0] == form
+            drv = upd.driver
+            tn = drv if seeds > 1 else drv._keep[0]   # SeedsUpdateDriver holds the stacked buffers itself, UpdateDriver its trainer
+            outs.append({"theta": tn.theta.clone(), "m": tn.m.clone(), "v": tn.v.clone(), "count": tn.count.clone(), "grad": tn.grad.clone(),
+                         "metrics": drv.metrics.clone()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert int(outs[0]["count"].reshape(-1)[0]) == 192 and torch.isfinite(outs[0]["theta"]).all() and float(outs[0]["grad"].abs().max()) > 0
+
+
 def test_c_abi_argument_errors(gpu):
     """Bad arguments are rejected on the host with a negative code and a message (no launch)."""
     from purejaxql_amd import _lib
