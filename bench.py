@@ -603,7 +603,8 @@ def main():
                 out["operand_mode_note"] = ("value: MATMUL_DTYPE f16x2 = what the package default `auto` runs at this shape (f32 operands as two range-scaled "
                                             "fp16 pieces in the position-parallel kernels, f32 accumulate; measured NEARER to float64 than the f32 fma chain "
                                             "per product and than bf16x3 per gradient: profiles/r06_v7_f16x2_accuracy.txt); value_bf16x3_operands: the "
-                                            "same workload with the three-piece bf16 operands of round 5")
+                                            "same workload with the three-piece bf16 operands of round 5.  The reference's own f32 conv / dot run as TF32 (10 significand "
+                                            "bits per operand) under XLA's default precision on the NVIDIA GPUs its numbers come from (SURVEY A.8)")
         if sustained is not None:
             out["sustained"] = sustained
         if cpu_base is not None:
