@@ -405,7 +405,10 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * at most 256 samples: a tile's work cut along the conv positions over many workgroups; 1 (default) = forward partial +
  * head-and-backward as two launches, 2 / 3 / 4 = three launches with 4 / 8 / 16 positions per workgroup, 0 = the
  * single-tile kernel), "t1_ksplit_tiles" (the K-split form is taken while tiles x seeds of a launch stay at or below
- * this; default 48).  Each starts from its PQN_<NAME> environment
+ * this; default 48), "fold_apply" (pqn_cnn_update / pqn_cnn_update_seeds: the fold of the gradient partials, clip_by_global_norm and
+ * RAdam of a minibatch in ONE launch: 0 never, 1 (default) for launches of one or two seeds, 2 always; bit-identical to the two
+ * launches; args->grad then holds the LAST minibatch's gradient after the update -- the only one a caller can observe -- instead of
+ * being rewritten by every optimizer step).  Each starts from its PQN_<NAME> environment
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);
