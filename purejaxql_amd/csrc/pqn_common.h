@@ -112,6 +112,7 @@ enum {
   PQN_OPT_POS_WAVES,      // PQN_POS_WAVES: waves per workgroup of the position-parallel forward / rollout kernels, f16x2 layouts: 0 from the launch (default) / 8 / 4 / 2
   PQN_OPT_POS_CHUNKS,     // PQN_POS_CHUNKS: sample chunks of the position-parallel backward, f16x2 layouts: 0 from the launch (default) / 1 / 2 / 4 / 8
   PQN_OPT_FOLD_APPLY,     // PQN_FOLD_APPLY: fold of the gradient partials + clip + RAdam of a fused CNN update in ONE launch (radam_apply_kernel<true>, pqn_fold.h): 0 never / 1 (default) for launches of one or two seeds (seeds x blocks <= 400) / 2 always; bit-identical either way
+  PQN_OPT_GATHER_GROUP,   // PQN_GATHER_GROUP: super-tiles per workgroup of the position-parallel form's gather 0 (default) from the launch (4 while >= 2048 workgroups remain) / 1 / 4; same bytes either way
   PQN_OPT_COUNT
 };
 int pqn_opt(int id);

@@ -122,38 +122,65 @@ PQN_D int64_t pos_row_of(int64_t key, const pqn_seeds_t &sd, int seed) {
 // ---------------------------------------------------------------------------
 // minibatch gather: rows in minibatch order + the bit-transpose per super-tile
 // ---------------------------------------------------------------------------
-template <int C>
+// G super-tiles per workgroup (round 6: 4 where the launch is large): the workgroup's G x 32 key loads, then its row loads, are all
+// requested before any is consumed -- a super-tile alone is a chain of two dependent memory round trips per 64 + 16 B it moves, and the
+// epoch launch (65,536 super-tiles of 16 seeds) ran 32 such chains back to back per CU slot (180 -> 143 us; 8 per workgroup: 145; profiles/r06_v10_gather_group.txt).
+// Same bytes to the same addresses.
+template <int C, int G>
 __global__ __launch_bounds__(256) void pos_gather_kernel(int nb, const int64_t *__restrict__ idx, const uint32_t *__restrict__ obs_bits,
                                                          const int32_t *__restrict__ action, const float *__restrict__ target,
                                                          float *__restrict__ wsx, pos_ws_t W, pqn_seeds_t sd) {
   using P = PosCfg<C>;
-  __shared__ uint32_t rows[POS_ST * P::OW];
+  constexpr int NW = G * POS_ST * P::OW, NIT = (NW + 255) / 256;
+  __shared__ uint32_t rows[NW];
   const int seed = blockIdx.y + sd.seed_base;
   idx += seed * sd.idx_stride;
   wsx += seed * sd.ws_stride;
   uint32_t *mb_bits = reinterpret_cast<uint32_t *>(wsx + W.mb_bits);
   uint32_t *t32 = reinterpret_cast<uint32_t *>(wsx + W.t32);
-  const int st = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < POS_ST * P::OW; i += 256) {
-    const int smp = i / P::OW, w = i - smp * P::OW;
-    const int64_t src = pos_row_of(idx[st * POS_ST + smp], sd, seed);
-    const uint32_t v = obs_bits[(size_t)src * P::OW + w];
-    rows[i] = v;
-    mb_bits[(size_t)st * POS_ST * P::OW + i] = v;
+  const int st0 = blockIdx.x * G, tid = threadIdx.x;
+  int64_t key[NIT];
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int i = min(tid + 256 * q, NW - 1);
+    key[q] = idx[st0 * POS_ST + i / P::OW];
   }
-  if (tid < POS_ST) {
-    const int64_t src = pos_row_of(idx[st * POS_ST + tid], sd, seed);
-    reinterpret_cast<int32_t *>(wsx + W.act)[st * POS_ST + tid] = action[src];
-    (wsx + W.tgt)[st * POS_ST + tid] = target[src];
+  int64_t akey = 0;
+  if (tid < G * POS_ST) akey = idx[st0 * POS_ST + tid];
+  uint32_t v[NIT];
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int i = min(tid + 256 * q, NW - 1);
+    v[q] = obs_bits[(size_t)pos_row_of(key[q], sd, seed) * P::OW + (i % P::OW)];
+  }
+  int32_t a = 0;
+  float tg = 0.0f;
+  if (tid < G * POS_ST) {
+    const int64_t src = pos_row_of(akey, sd, seed);
+    a = action[src];
+    tg = target[src];
+  }
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int i = tid + 256 * q;
+    if (i < NW) {
+      rows[i] = v[q];
+      mb_bits[(size_t)st0 * POS_ST * P::OW + i] = v[q];
+    }
+  }
+  if (tid < G * POS_ST) {
+    reinterpret_cast<int32_t *>(wsx + W.act)[st0 * POS_ST + tid] = a;
+    (wsx + W.tgt)[st0 * POS_ST + tid] = tg;
   }
   __syncthreads();
-  for (int b = tid; b < P::TW; b += 256) {
+  for (int b = tid; b < G * P::TW; b += 256) {
+    const int g = b / P::TW, bb = b - g * P::TW;
     uint32_t word = 0u;
-    if (b < P::NBITS) {
+    if (bb < P::NBITS) {
 #pragma unroll
-      for (int s = 0; s < POS_ST; ++s) word |= ((rows[s * P::OW + (b >> 5)] >> (b & 31)) & 1u) << s;
+      for (int s = 0; s < POS_ST; ++s) word |= ((rows[(g * POS_ST + s) * P::OW + (bb >> 5)] >> (bb & 31)) & 1u) << s;
     }
-    t32[(size_t)st * P::TW + b] = word;
+    t32[(size_t)(st0 + g) * P::TW + bb] = word;
   }
 }
 
@@ -1539,7 +1566,12 @@ int pqn_cnn_pos_forward(const pqn_cnn_layout_t &L, int nb, const float *theta, f
 template <int C>
 static int pos_gather_launch(int nb, const int64_t *idx, const uint32_t *bits, const int32_t *action, const float *target, float *wsx,
                              const pos_ws_t &W, const pqn_seeds_t &sg, int nseeds, hipStream_t st) {
-  hipLaunchKernelGGL(pos_gather_kernel<C>, dim3(nb / POS_ST, nseeds), dim3(256), 0, st, nb, idx, bits, action, target, wsx, W, sg);
+  const int nst = nb / POS_ST;
+  const int gg = pqn_opt(PQN_OPT_GATHER_GROUP);
+  if (nst % 4 == 0 && (gg == 4 || (gg == 0 && (long long)(nst / 4) * nseeds >= 2048)))   // four super-tiles per workgroup while that still leaves 8 workgroups per CU
+    hipLaunchKernelGGL((pos_gather_kernel<C, 4>), dim3(nst / 4, nseeds), dim3(256), 0, st, nb, idx, bits, action, target, wsx, W, sg);
+  else
+    hipLaunchKernelGGL((pos_gather_kernel<C, 1>), dim3(nst, nseeds), dim3(256), 0, st, nb, idx, bits, action, target, wsx, W, sg);
   return pqn_check_launch("pqn_cnn_pos_gather");
 }
 int pqn_cnn_pos_gather(const pqn_cnn_layout_t &L, int nb, const int64_t *idx, const uint32_t *bits, const int32_t *action,

@@ -182,6 +182,31 @@ def test_one_launch_fold_clip_radam_is_bit_identical_to_the_two_launch_form(gpu,
     assert int(outs[0]["count"].reshape(-1)[0]) == 192 and torch.isfinite(outs[0]["theta"]).all() and float(outs[0]["grad"].abs().max()) > 0
 
 
+@pytest.mark.parametrize("env_name,n_envs,seeds", [("Breakout-MinAtar", 4096, 4), ("SpaceInvaders-MinAtar", 1024, 16), ("Freeway-MinAtar", 2048, 8)])
+def test_grouped_epoch_gather_moves_the_same_bytes(gpu, env_name, n_envs, seeds):
+    """pos_gather_kernel<C, 4> (four 32-sample super-tiles per workgroup, all key and row loads requested before any is consumed) against
+    <C, 1>: the gathered rows / bit transposes / actions / targets feed the position-parallel kernels (the shuffled minibatches of
+    pqn_minatar.py:299-320), so parameters and metrics after 2 updates must be bit-identical (13 / 20 / 24 packed words per row)."""
+    from purejaxql_amd import _lib
+    from purejaxql_amd.config_loader import flatten, load_config
+    from purejaxql_amd.pqn import make_train, seed_keys
+    outs = []
+    for group in (1, 4):
+        with _lib.options(gather_group=group, bwd_pos=2):
+            cfg = flatten(load_config(["+alg=pqn_minatar", f"alg.ENV_NAME={env_name}", f"alg.NUM_ENVS={n_envs}", "alg.TEST_DURING_TRAINING=False",
+                                       "alg.MATMUL_DTYPE=f16x2"]))
+            cfg["TOTAL_TIMESTEPS"] = 2 * n_envs * 32
+            upd, _ = make_train(cfg, device="cuda:0").make_batch_runner(seed_keys(21, seeds))
+            upd(0); upd(1)
+            torch.cuda.synchronize()
+            assert _lib.last_kernel_form()[0] == "pos"
+            drv = upd.driver
+            outs.append((drv.theta.clone(), drv.m.clone(), drv.metrics.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert torch.isfinite(outs[0][0]).all()
+
+
 def test_c_abi_argument_errors(gpu):
     """Bad arguments are rejected on the host with a negative code and a message (no launch)."""
     from purejaxql_amd import _lib
