@@ -457,10 +457,17 @@ def main():
                 c1 = dict(cfg)
                 tr1 = make_train(c1, device=str(dev))
                 upd1, _fin1 = tr1.make_runner(seed_keys(0, 1)[0])
-                d1 = timed_updates(upd1, args.steps, args.warmup)
-                a1, l1 = kernel_timer_pass(lib, upd1, args.warmup + args.steps, mb, 1)
-                v1 = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * args.steps / d1
-                return {"seeds_per_gpu": 1, "value": v1, "unit": "env-steps/s", "ms_per_step": d1 / args.steps * 1e3,
+                d1, n1 = timed_updates(upd1, args.steps, args.warmup), args.steps
+                done1 = args.warmup + args.steps
+                if d1 < 0.2:   # a short region: time ~0.3 s more and keep the faster of the two (a host hiccup only ever adds)
+                    n2 = min(SUSTAIN_MAX // 2, max(n1, int(0.3 / (d1 / n1))))
+                    d2 = timed_updates(upd1, n2, 0, done1)
+                    done1 += n2
+                    if d2 / n2 < d1 / n1:
+                        d1, n1 = d2, n2
+                a1, l1 = kernel_timer_pass(lib, upd1, done1, mb, 1)
+                v1 = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] * n1 / d1
+                return {"seeds_per_gpu": 1, "value": v1, "unit": "env-steps/s", "ms_per_step": d1 / n1 * 1e3, "updates_timed": n1,
                         "loop_frac_f32_peak": v1 * LOOP_FLOP / 1e12 / F32_PEAK_TFLOPS,
                         "roofline": t1_roofline(a1, l1, mb, 1, matmul, _lib.last_kernel_form()[0]),
                         "note": "ONE seed of 4096 envs alone on the GPU (round 1's headline configuration)"}
@@ -480,14 +487,21 @@ def main():
                         cg = flatten(load_config(["+alg=pqn_minatar", f"alg.ENV_NAME={env_name}", f"alg.NUM_ENVS={n_envs}",
                                                   "alg.TEST_DURING_TRAINING=False"]))
                         cg["MATMUL_DTYPE"] = matmul
-                        w_g, s_g = 3, 12
-                        cg["TOTAL_TIMESTEPS"] = (w_g + s_g + 3) * n_envs * cg["NUM_STEPS"]
+                        w_g, s_g, s_more = 3, 12, 120
+                        cg["TOTAL_TIMESTEPS"] = (w_g + s_g + s_more + 3) * n_envs * cg["NUM_STEPS"]
                         trg = make_train(cg, device=str(dev))
                         updg, _fg = trg.make_batch_runner(seed_keys(0, spg_g)) if spg_g > 1 else trg.make_runner(seed_keys(0, 1)[0])
                         dg = timed_updates(updg, s_g, w_g)
+                        n_done_g = w_g + s_g
+                        if dg < 0.2:   # a short region (12 updates of a small launch shape are ~45 ms): one host hiccup would be a third of it --
+                            n2 = min(s_more, max(s_g, int(0.3 / (dg / s_g))))   # time ~0.3 s more and keep the faster of the two regions
+                            d2 = timed_updates(updg, n2, 0, n_done_g)
+                            n_done_g += n2
+                            if d2 / n2 < dg / s_g:
+                                dg, s_g = d2, n2
                         forms = dict(zip(("train", "rollout"), _lib.last_kernel_form()))
                         mbg = n_envs * cg["NUM_STEPS"] // cg["NUM_MINIBATCHES"]
-                        ag, lg = kernel_timer_pass(lib, updg, w_g + s_g, mbg, spg_g)
+                        ag, lg = kernel_timer_pass(lib, updg, n_done_g, mbg, spg_g)
                         env_g, _pg = make(env_name, device=dev)
                         ch, na = int(env_g.obs_shape[-1]), int(env_g.num_actions)
                         rg = t1_roofline(ag, lg, mbg, spg_g, matmul, forms["train"], t1_flop_per_sample(ch, na), ch, na)
