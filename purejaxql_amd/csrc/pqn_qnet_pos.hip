@@ -863,7 +863,6 @@ PQN_D void pos_fwd_kloop(const PosFwdCtx<C> &cx, int kk0, f32x4 (&zacc)[2][8]) {
   using M = PosMM<NPL>;
   constexpr bool H2 = NPL == 2;
   constexpr int RB = P::RB, NCS = P::NCS;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   unsigned long long *stamps = cx.stamps;
   const int lane = cx.lane, wave = cx.wave;
   (void)stamps; (void)lane; (void)wave;
@@ -1029,7 +1028,6 @@ __global__ __launch_bounds__(64 * NW) void cnn_pos_fwd_kernel(int nb, const floa
   using P = PosCfg<C, NPL>;
   using F = PosFwdCfg<C, NPL, NW>;
   constexpr int NT = 64 * NW;                        // threads of the workgroup
-  using Cfg = CnnCfg<C>;
   constexpr bool H2 = NPL == 2;
   constexpr int CONVBLK = P::CONVBLK, NCS = P::NCS;
   constexpr int REC = CONVBLK + 384 + 128 * NA + NA + 2;
