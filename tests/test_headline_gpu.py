@@ -229,6 +229,8 @@ def test_seed_groups_pipeline_is_bit_identical_to_one_batch(gpu, tail):
             assert torch.equal(a["runner_state"][k], b["runner_state"][k]), (s, k)
 
 
+_ORACLE_UPDATES = {}   # (game, seed key) -> the oracle's whole update from net.init(123): metrics, theta, float64 learn phase
+
 @pytest.mark.parametrize("env_name,seeds_checked,dtype", [("Breakout-MinAtar", (0, 7, 15), "bf16x3"), ("SpaceInvaders-MinAtar", (7,), "bf16x3"),
                                                          ("Freeway-MinAtar", (7,), "bf16x3"), ("Asterix-MinAtar", (7,), "bf16x3"),
                                                          ("Breakout-MinAtar", (0, 15), "f16x2"), ("SpaceInvaders-MinAtar", (7,), "f16x2"),
@@ -266,7 +268,21 @@ def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked, d
     otrain = oracle.make_train(ocfg)
     th0 = _np(theta0)
     for s in seeds_checked:
-        oout = otrain(keys[s], th0)
+        # the oracle's update of (game, seed key) does not depend on the operand mode or on how many seeds share the GPU launches: computed
+        # once per session (15 s of numpy each, + 15 s for the float64 learn phase) and shared by the parametrisations
+        want64 = env_name == "Breakout-MinAtar" and s == seeds_checked[0]
+        ck = (env_name, int(keys[s]))
+        if ck not in _ORACLE_UPDATES or (want64 and _ORACLE_UPDATES[ck]["th64"] is None):
+            oo = otrain(keys[s], th0)
+            th64_c = None
+            if want64:
+                import pqn_oracle_f64 as o64
+                sh = oo["shards"][0]
+                th64_c = o64.learn_phase(ocfg, otrain.shapes, th0, sh["of"], sh["af"], sh["tf"], oracle.fold_in(int(keys[s]) & 0xFFFFFFFFFFFFFFFF, 4))[0]
+            _ORACLE_UPDATES[ck] = {"metrics": oo["metrics"], "theta": oo["theta"], "th64": th64_c, "th0": th0.copy()}
+            del oo
+        oout = _ORACLE_UPDATES[ck]
+        assert np.array_equal(oout["th0"], th0)
         om = oout["metrics"][0]
         m = outs[s]["metrics"]
         for k in ("env_step", "update_steps", "grad_steps"):
@@ -287,9 +303,7 @@ def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked, d
             # Which side is nearer to exact arithmetic (VERDICT r5 weak point 2)?  The 64 optimizer steps in FLOAT64 on the oracle's own
             # rollout record (oracle/pqn_oracle_f64.py): the kernels' update must be at least as near to it as the numpy-f32 oracle's
             # is, and inside the band the f32 oracle itself keeps against it.
-            import pqn_oracle_f64 as o64
-            sh = oout["shards"][0]
-            th64, _m64, _v64 = o64.learn_phase(ocfg, otrain.shapes, th0, sh["of"], sh["af"], sh["tf"], oracle.fold_in(int(keys[s]) & 0xFFFFFFFFFFFFFFFF, 4))
+            th64 = oout["th64"]
             u64 = th64 - th0
             rel_hip = float(np.linalg.norm(upd - u64) / np.linalg.norm(u64))
             rel_np = float(np.linalg.norm(oupd - u64) / np.linalg.norm(u64))

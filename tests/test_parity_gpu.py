@@ -331,6 +331,8 @@ def test_product_network_vs_oracle_network(gpu, oracle):
     np.testing.assert_allclose(_np(q), oracle.net_forward("cnn", p, _np(x)), rtol=1e-4, atol=1e-5)
 
 
+_ORACLE_RUNS = {}   # (script, game, shape) -> the oracle loop's result from net.init(123), shared by the operand-mode cases of the 4096-env shapes
+
 @pytest.mark.parametrize("alg,env_name,extra", [
     ("pqn_minatar", "Breakout-MinAtar", {"NUM_ENVS": 64, "NUM_STEPS": 8, "NUM_MINIBATCHES": 4, "NUM_EPOCHS": 2,
                                          "_BACKEND": "fused"}),
@@ -396,7 +398,18 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
     if train.backend == "fused" and extra.get("_DRIVER", True):
         want = "eager" if extra.get("_GRAPH", True) is False else "graph"
         assert out["runner_state"]["driver"] == want, out["runner_state"]["driver_graph_error"]
-    oout = otrain(key, _np(theta0))
+    # the oracle loop does not depend on the operand mode / driver switches of the GPU side: the 4096-env cases (28 s of numpy + float64
+    # each) share one run per (script, game, shape)
+    ck = (alg, env_name, tuple(sorted((k, str(v)) for k, v in extra.items() if not k.startswith("_") and k != "MATMUL_DTYPE")))
+    big = cfg["NUM_ENVS"] * cfg["NUM_STEPS"] >= 100000
+    if big and ck in _ORACLE_RUNS:
+        oout = _ORACLE_RUNS[ck]
+        assert np.array_equal(oout["th0"], _np(theta0))
+    else:
+        oout = otrain(key, _np(theta0))
+        if big:
+            oout = {"metrics": oout["metrics"], "theta": oout["theta"], "shards": oout["shards"][:1], "th0": _np(theta0).copy(), "th64": None}
+            _ORACLE_RUNS[ck] = oout
     assert cfg["NUM_UPDATES"] == n_upd
     for u in range(n_upd):
         om = oout["metrics"][u]
@@ -429,8 +442,13 @@ def test_make_train_end_to_end_vs_oracle(gpu, oracle, alg, env_name, extra):
             # round 6: the numpy-f32 oracle is the outlier of that comparison (profiles/r06_v4_f64_learn_phase.txt); against the float64
             # learn phase on the oracle's own rollout record the kernels are held 30x tighter
             import pqn_oracle_f64 as o64
-            sh = oout["shards"][0]
-            th64, _m, _v = o64.learn_phase(ocfg, otrain.shapes, th0, sh["of"], sh["af"], sh["tf"], oracle.fold_in(int(key) & 0xFFFFFFFFFFFFFFFF, 4))
+            if oout.get("th64") is None:
+                sh = oout["shards"][0]
+                th64 = o64.learn_phase(ocfg, otrain.shapes, th0, sh["of"], sh["af"], sh["tf"], oracle.fold_in(int(key) & 0xFFFFFFFFFFFFFFFF, 4))[0]
+                if big:
+                    oout["th64"], oout["shards"] = th64, None     # the record is not needed again
+            else:
+                th64 = oout["th64"]
             u64 = th64 - th0
             rel64, rel_np = float(np.linalg.norm(upd - u64) / np.linalg.norm(u64)), float(np.linalg.norm(oupd - u64) / np.linalg.norm(u64))
             # (measured: 2.4e-3 for the single-tile kernels of a one-seed launch, 2.1e-4 for the position-parallel kernels, 3.9e-2 numpy-f32)
