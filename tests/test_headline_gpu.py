@@ -235,7 +235,7 @@ _ORACLE_UPDATES = {}   # (game, seed key) -> the oracle's whole update from net.
                                                          ("Freeway-MinAtar", (7,), "bf16x3"), ("Asterix-MinAtar", (7,), "bf16x3"),
                                                          ("Breakout-MinAtar", (0, 15), "f16x2"), ("SpaceInvaders-MinAtar", (7,), "f16x2"),
                                                          ("Freeway-MinAtar", (7,), "f16x2"), ("Asterix-MinAtar", (7,), "f16x2"),
-                                                         ("Breakout-MinAtar", (0, 5), "f16x2/8"), ("Breakout-MinAtar", (3,), "f16x2/4"),
+                                                         ("Breakout-MinAtar", (0, 7), "f16x2/8"), ("Breakout-MinAtar", (0,), "f16x2/4"),   # (seeds the 16-seed cases already ran through the oracle)
                                                          ("SpaceInvaders-MinAtar", (7,), "f16x2/8")])
 def test_headline_whole_update_vs_oracle(gpu, oracle, env_name, seeds_checked, dtype):
     """ONE whole update of the bench workload -- 16 seeds batched into the launches, bf16x3, pair rollout + position-parallel
