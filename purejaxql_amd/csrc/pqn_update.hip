@@ -216,7 +216,8 @@ static int upd_ctx(const pqn_update_args_t *a, int S, const uint64_t *key_roll_d
   c.sd.idx_mask = (1ll << pqn_index_bits(c.TN)) - 1;   // low bits of a sorted shuffle key = the transition index
   // (reserved bit 0 selected a one-kernel fold + clip + RAdam with a grid-wide barrier in rounds 1-4: measured slower in round 1
   // -- 5.47 vs 4.92 ms per update, the barrier costs more than the launch it saves -- and its summation order had drifted
-  // from qnet_grad_reduce_kernel's by round 5; removed, the bit is ignored)
+  // from qnet_grad_reduce_kernel's by round 5; removed, the bit is ignored.  Round 6's one-launch form -- no barrier object, no
+  // fence: tagged slots, pqn_fold.h -- shares the fold's code with the two-launch form and is chosen per launch in cnn_update_impl)
   // reserved bit 1: kernel form of the training launches from the minibatch size alone (pqn_seeds_t.pin_form)
   c.sd.pin_form = (a->reserved & 2) != 0;
   return PQN_OK;
