@@ -52,6 +52,7 @@ static struct {
     {"rollout_pos", "PQN_ROLLOUT_POS", 1, 0, false}, {"pin_form", "PQN_PIN_FORM", 0, 0, false},
     {"pos_waves", "PQN_POS_WAVES", 0, 0, false},   {"pos_chunks", "PQN_POS_CHUNKS", 0, 0, false},
     {"fold_apply", "PQN_FOLD_APPLY", 1, 0, false}, {"gather_group", "PQN_GATHER_GROUP", 0, 0, false},
+    {"sort_impl", "PQN_SORT_IMPL", 1, 0, false},   {"sort_cap", "PQN_SORT_CAP", 0, 0, false},
 };
 static int g_forms[2] = {PQN_FORM_NONE, PQN_FORM_NONE};
 

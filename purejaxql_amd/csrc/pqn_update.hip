@@ -125,25 +125,252 @@ __global__ void update_tick_kernel(int32_t *__restrict__ clock, int t_len, int n
   if (blockIdx.x == 0 && threadIdx.x == 0) clock[0] = u + 1;
 }
 
-// The epoch shuffle's sort: rocPRIM's device radix sort called directly (ROCm-native API, no CUB-compatibility
-// layer), restricted to the bits that decide the order: 31 random bits (+ 7 seed bits when seeds are batched) -- round 6: NOT the index
-// bits below them.  The keys arrive in index order (key i of a seed carries i in its low bits), and an LSD radix sort is stable: two
-// transitions that drew the same 31 random bits (a handful per epoch at 131,072 per seed) keep their index order, which is exactly the
-// order the full-width sort of the unique keys gave -- two passes of seven less, the same permutation.
+// ---------------------------------------------------------------------------------------------------------
+// The epoch shuffle's sort (jax.random.permutation's stand-in, pqn_minatar.py:299-315): every seed's T*N keys
+// `rand31 << ib | index` in ascending order.  Round 6: a sort written for exactly these keys -- uniformly random leading bits,
+// unique, a segment per seed:
+//   n <= 4096 keys per seed: ONE launch, a workgroup per seed sorts its segment in LDS (bitonic network on the full keys);
+//   above: the leading bits of rand31 cut a seed's keys into B = 2^b buckets of ~1024 (b = ceil(log2(n / 1024))) --
+//     count (LDS histogram -> one global atomic per workgroup and bucket), scatter into the bucket ranges of `out` (claimed the same way;
+//     the order inside a bucket is whatever the atomics give), then a workgroup per bucket sorts its <= 4096 keys in LDS, in place.
+//     A bucket holds 1024 +- 32 keys (binomial); one above 4096 is not a practical event, and is still sorted (rank sort through the
+//     dead input buffer).  4 launches and 80 MB of traffic at 16 seeds x 131,072 keys where rocPRIM's onesweep took 5 passes + 11 fills.
+// The keys are unique, so the result is THE sorted order whatever the algorithm: tests/test_fullsize_gpu.py compares it with the
+// full-width sort of the same keys at every shape.  Option sort_impl = 0 keeps rocPRIM's radix sort (restricted to the random + seed
+// bits: the keys enter in index order and an LSD radix sort is stable, so equal draws keep their index order -- 4 passes, not 6).
+// ---------------------------------------------------------------------------------------------------------
+#define SRT_CAP 4096          // keys a workgroup sorts in LDS (32 KB)
+#define SRT_THREADS 256           // (1024: 98 us per 16-seed bucket launch -- barriers of 16 waves, two workgroups per CU; 256: see profiles/r06_v13_sort.txt)
+typedef unsigned long long srt_key_t;
+
+// bitonic network over s[0..P), P a power of two <= SRT_CAP, ascending; every thread of the workgroup calls it
+__device__ inline void srt_bitonic(srt_key_t *s, int P, int tid, int nt) {
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P >> 1); t += nt) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const srt_key_t x = s[i], y = s[l];
+        if ((x > y) == ((i & k) == 0)) { s[i] = y; s[l] = x; }
+      }
+      __syncthreads();
+    }
+}
+
+// one workgroup per (bucket, seed): keys [base, base + cnt) of the seed's segment.  whole != 0: the segment itself (from `in`).
+__global__ __launch_bounds__(SRT_THREADS) void srt_bucket_sort_kernel(const srt_key_t *__restrict__ in, srt_key_t *__restrict__ out,
+                                                                      srt_key_t *__restrict__ spare, int n, int B,
+                                                                      const unsigned *__restrict__ counts,
+                                                                      const unsigned *__restrict__ bases, int whole, int cap, int sub_shift) {
+  __shared__ srt_key_t s[SRT_CAP];
+  const int seed = blockIdx.y, bucket = blockIdx.x, tid = threadIdx.x;
+  unsigned base = 0, cnt = (unsigned)n;
+  if (!whole) {
+    base = bases[(size_t)seed * B + bucket];
+    cnt = counts[(size_t)seed * B + bucket];
+  }
+  const srt_key_t *src = (whole ? in : out) + (size_t)seed * n + base;
+  srt_key_t *dst = out + (size_t)seed * n + base;
+  if (cnt > (unsigned)cap) {   // cap = SRT_CAP; not a practical event (see above; tests lower cap to walk this path): rank sort, the (dead) input buffer as the stable copy
+    srt_key_t *cp = spare + (size_t)seed * n + base;
+    for (unsigned i = tid; i < cnt; i += SRT_THREADS) cp[i] = src[i];
+    __threadfence_block();
+    __syncthreads();
+    for (unsigned i = tid; i < cnt; i += SRT_THREADS) {
+      const srt_key_t k = cp[i];
+      unsigned r = 0;
+      for (unsigned q = 0; q < cnt; ++q) r += cp[q] < k;
+      dst[r] = k;
+    }
+    return;
+  }
+  if (!whole && cnt <= SRT_CAP / 2 && sub_shift >= 0) {
+    // the usual case: ~1024 keys.  A bitonic network over them is bound by LDS bandwidth (66 stages x 48 B per comparator: 90 us per
+    // 16-seed launch).  Instead: the NEXT ten random bits cut the bucket into 1024 sub-buckets of ~1 key -- count (LDS atomics), scan,
+    // place (LDS atomics: unordered inside a sub-bucket), then one thread per sub-bucket insertion-sorts its handful of keys on the
+    // full key.  Three passes over the keys; correct for any key distribution (a crowded sub-bucket only costs time).
+    constexpr int SB = 1024, H = SRT_CAP / 2;
+    __shared__ unsigned s_c[SB], s_off[SB + 1], s_sc[SRT_THREADS];
+    srt_key_t *s_in = s, *s_out = s + H;
+    for (int q = tid; q < SB; q += SRT_THREADS) s_c[q] = 0u;
+    for (int i = tid; i < (int)cnt; i += SRT_THREADS) s_in[i] = src[i];
+    __syncthreads();
+    for (int i = tid; i < (int)cnt; i += SRT_THREADS) atomicAdd(&s_c[(unsigned)(s_in[i] >> sub_shift) & (SB - 1)], 1u);
+    __syncthreads();
+    {
+      constexpr int per = SB / SRT_THREADS;
+      unsigned local = 0;
+#pragma unroll
+      for (int u = 0; u < per; ++u) local += s_c[tid * per + u];
+      s_sc[tid] = local;
+      __syncthreads();
+      for (int off = 1; off < SRT_THREADS; off <<= 1) {
+        const unsigned v = tid >= off ? s_sc[tid - off] : 0u;
+        __syncthreads();
+        s_sc[tid] += v;
+        __syncthreads();
+      }
+      unsigned run = s_sc[tid] - local;
+#pragma unroll
+      for (int u = 0; u < per; ++u) {
+        const unsigned c = s_c[tid * per + u];
+        s_off[tid * per + u] = run;
+        s_c[tid * per + u] = run;     // the placing pass's cursor
+        run += c;
+      }
+      if (tid == SRT_THREADS - 1) s_off[SB] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)cnt; i += SRT_THREADS) {
+      const srt_key_t k = s_in[i];
+      s_out[atomicAdd(&s_c[(unsigned)(k >> sub_shift) & (SB - 1)], 1u)] = k;
+    }
+    __syncthreads();
+    for (int q = tid; q < SB; q += SRT_THREADS) {
+      const int lo = (int)s_off[q], hi = (int)s_off[q + 1];
+      for (int i = lo + 1; i < hi; ++i) {
+        const srt_key_t k = s_out[i];
+        int j = i - 1;
+        while (j >= lo && s_out[j] > k) { s_out[j + 1] = s_out[j]; --j; }
+        s_out[j + 1] = k;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)cnt; i += SRT_THREADS) dst[i] = s_out[i];
+    return;
+  }
+  int P = 2;
+  while (P < (int)cnt) P <<= 1;
+  for (int i = tid; i < P; i += SRT_THREADS) s[i] = i < (int)cnt ? src[i] : ~(srt_key_t)0;
+  __syncthreads();
+  srt_bitonic(s, P, tid, SRT_THREADS);
+  for (int i = tid; i < (int)cnt; i += SRT_THREADS) dst[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void srt_zero_kernel(unsigned *__restrict__ c, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count) c[i] = 0u;
+}
+
+#define SRT_ITEMS 8           // keys per thread of the count / scatter kernels
+// bucket of a key: the leading b bits of its rand31 (bits [ib + 31 - b, ib + 31))
+__global__ __launch_bounds__(256) void srt_count_kernel(const srt_key_t *__restrict__ in, int n, int shift, int B,
+                                                        unsigned *__restrict__ counts) {
+  extern __shared__ unsigned s_cnt[];
+  const int seed = blockIdx.y, tid = threadIdx.x;
+  for (int q = tid; q < B; q += 256) s_cnt[q] = 0u;
+  __syncthreads();
+  const srt_key_t *src = in + (size_t)seed * n;
+  const int i0 = blockIdx.x * (256 * SRT_ITEMS);
+#pragma unroll
+  for (int u = 0; u < SRT_ITEMS; ++u) {
+    const int i = i0 + u * 256 + tid;
+    if (i < n) atomicAdd(&s_cnt[(unsigned)(src[i] >> shift) & (unsigned)(B - 1)], 1u);
+  }
+  __syncthreads();
+  for (int q = tid; q < B; q += 256)
+    if (s_cnt[q]) atomicAdd(&counts[(size_t)seed * B + q], s_cnt[q]);
+}
+
+__global__ __launch_bounds__(256) void srt_scatter_kernel(const srt_key_t *__restrict__ in, srt_key_t *__restrict__ out, int n, int shift,
+                                                          int B, const unsigned *__restrict__ counts, unsigned *__restrict__ cursors,
+                                                          unsigned *__restrict__ bases) {
+  extern __shared__ unsigned s_mem[];   // [B] local counts -> this workgroup's first slot in every bucket, [B] bucket bases
+  unsigned *s_cnt = s_mem, *s_base = s_mem + B;
+  __shared__ unsigned s_scan[256];
+  const int seed = blockIdx.y, tid = threadIdx.x;
+  for (int q = tid; q < B; q += 256) { s_cnt[q] = 0u; s_base[q] = counts[(size_t)seed * B + q]; }
+  __syncthreads();
+  {   // exclusive scan of the seed's bucket counts: thread = a run of `per` consecutive buckets, Hillis-Steele over the 256 run sums
+    const int per = (B + 255) / 256;
+    unsigned local = 0;
+    for (int u = 0; u < per; ++u) { const int q = tid * per + u; if (q < B) local += s_base[q]; }
+    s_scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const unsigned v = tid >= off ? s_scan[tid - off] : 0u;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    unsigned run = s_scan[tid] - local;
+    for (int u = 0; u < per; ++u) {
+      const int q = tid * per + u;
+      if (q < B) { const unsigned c = s_base[q]; s_base[q] = run; run += c; }
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) for (int q = tid; q < B; q += 256) bases[(size_t)seed * B + q] = s_base[q];   // for the bucket sorts
+  const srt_key_t *src = in + (size_t)seed * n;
+  const int i0 = blockIdx.x * (256 * SRT_ITEMS);
+  srt_key_t k[SRT_ITEMS];
+  unsigned pos[SRT_ITEMS];
+#pragma unroll
+  for (int u = 0; u < SRT_ITEMS; ++u) {
+    const int i = i0 + u * 256 + tid;
+    k[u] = i < n ? src[i] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < SRT_ITEMS; ++u) {
+    const int i = i0 + u * 256 + tid;
+    pos[u] = i < n ? atomicAdd(&s_cnt[(unsigned)(k[u] >> shift) & (unsigned)(B - 1)], 1u) : 0u;
+  }
+  __syncthreads();
+  for (int q = tid; q < B; q += 256) {
+    const unsigned c = s_cnt[q];
+    s_cnt[q] = c ? s_base[q] + atomicAdd(&cursors[(size_t)seed * B + q], c) : 0u;
+  }
+  __syncthreads();
+  srt_key_t *dst = out + (size_t)seed * n;
+#pragma unroll
+  for (int u = 0; u < SRT_ITEMS; ++u) {
+    const int i = i0 + u * 256 + tid;
+    if (i < n) dst[s_cnt[(unsigned)(k[u] >> shift) & (unsigned)(B - 1)] + pos[u]] = k[u];
+  }
+}
+
+static size_t srt_counter_bytes(long long n_total) { return (size_t)(n_total / 32 + 8192); }   // 3 x u32 per bucket (count, cursor, base), buckets <= 2 n / 1024 + seeds
+
 extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
   size_t bytes = 0;
   if (n <= 0) return -1;
   if (rocprim::radix_sort_keys(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                (unsigned int)n, 0u, 64u, (hipStream_t) nullptr) != hipSuccess)
     return -1;
-  return (int64_t)bytes;
+  return (int64_t)(bytes + srt_counter_bytes(n));
 }
 
-// n = keys of ALL seeds, n_per_seed = T*N of one seed
+// n = keys of ALL seeds, n_per_seed = T*N of one seed.  `in` is left intact.
 static int pqn_sort_keys(void *temp, size_t temp_bytes, const int64_t *in, int64_t *out, int n, int nseeds, int n_per_seed,
                          hipStream_t st) {
-  const unsigned begin_bit = (unsigned)pqn_index_bits(n_per_seed);
-  const unsigned end_bit = (unsigned)(31 + pqn_index_bits(n_per_seed) + (nseeds > 1 ? 7 : 0));
+  const int ib = pqn_index_bits(n_per_seed);
+  // (segments below 16,384 keys: rocPRIM's block / merge sorts are as fast or faster -- measured at 1024, 4096 and 32,768 keys; option sort_impl = 2 takes
+  //  the library's sort at every size: tests)
+  const int impl = pqn_opt(PQN_OPT_SORT_IMPL);
+  if (impl != 0 && (n_per_seed >= 16384 || impl == 2) && n_per_seed <= (1 << 22) && temp_bytes >= srt_counter_bytes(n)) {
+    const srt_key_t *kin = reinterpret_cast<const srt_key_t *>(in);
+    srt_key_t *kout = reinterpret_cast<srt_key_t *>(out);
+    if (n_per_seed <= SRT_CAP) {
+      hipLaunchKernelGGL(srt_bucket_sort_kernel, dim3(1, nseeds), dim3(SRT_THREADS), 0, st, kin, kout, (srt_key_t *)nullptr, n_per_seed, 1,
+                         (const unsigned *)nullptr, (const unsigned *)nullptr, 1, SRT_CAP, -1);
+      return pqn_check_launch("pqn_sort_keys");
+    }
+    const int cap_opt = pqn_opt(PQN_OPT_SORT_CAP);   // tests only: a lower in-LDS capacity sends every bucket down the rank-sort path
+    int b = 1;
+    while ((1 << b) * 1024 < n_per_seed) ++b;
+    const int B = 1 << b, shift = ib + 31 - b;
+    unsigned *counts = reinterpret_cast<unsigned *>(temp), *cursors = counts + (size_t)nseeds * B, *bases = cursors + (size_t)nseeds * B;
+    const int ctr = 2 * nseeds * B, chunks = (n_per_seed + 256 * SRT_ITEMS - 1) / (256 * SRT_ITEMS);
+    hipLaunchKernelGGL(srt_zero_kernel, dim3((ctr + 255) / 256), dim3(256), 0, st, counts, ctr);
+    hipLaunchKernelGGL(srt_count_kernel, dim3(chunks, nseeds), dim3(256), B * sizeof(unsigned), st, kin, n_per_seed, shift, B, counts);
+    hipLaunchKernelGGL(srt_scatter_kernel, dim3(chunks, nseeds), dim3(256), 2 * B * sizeof(unsigned), st, kin, kout, n_per_seed, shift, B,
+                       counts, cursors, bases);
+    // (the rank-sort path of an oversize bucket copies through `in`: const_cast, see srt_bucket_sort_kernel -- never taken in practice)
+    hipLaunchKernelGGL(srt_bucket_sort_kernel, dim3(B, nseeds), dim3(SRT_THREADS), 0, st, kin, kout, const_cast<srt_key_t *>(kin), n_per_seed,
+                       B, counts, bases, 0, (cap_opt > 0 && cap_opt < SRT_CAP) ? cap_opt : SRT_CAP, shift - 10);
+    return pqn_check_launch("pqn_sort_keys");
+  }
+  const unsigned begin_bit = (unsigned)ib;
+  const unsigned end_bit = (unsigned)(31 + ib + (nseeds > 1 ? 7 : 0));
   size_t need = 0;
   if (rocprim::radix_sort_keys(nullptr, need, (const unsigned long long *)in, (unsigned long long *)out, (unsigned int)n, begin_bit,
                                end_bit, st) != hipSuccess || need > temp_bytes) {

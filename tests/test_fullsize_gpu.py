@@ -116,20 +116,26 @@ def test_full_size_shuffle_is_a_bijection_and_update_is_deterministic(gpu):
     assert abs(float(m["timestep"][2]) - (64 + 16.5)) < 1e-3 and float(m["returned_episode"][0]) > 0.05
 
 
-@pytest.mark.parametrize("n_envs,seeds", [(128, 1), (4096, 1), (4096, 16), (32768, 4)])
-def test_update_permutation_equals_the_full_width_sort_of_its_keys(gpu, n_envs, seeds):
-    """The update's radix sort covers only the bits that decide the order (31 random bits + seed id, pqn_update.hip pqn_sort_keys) and
-    relies on stability for transitions that drew the same 31 bits (~4 pairs per seed at 131,072 transitions, ~256 at 2^20): the
-    permutation it leaves behind must be the one the full-width sort of the unique keys gives (jax.random.permutation's stand-in,
-    pqn_minatar.py:299-315) -- on the merge-sort path (one seed) and the onesweep path (seed batches) of rocPRIM."""
+@pytest.mark.parametrize("impl", [2, 0, 512])   # 512: the library's sort with its in-LDS capacity lowered to 512 keys -- every bucket takes the rank-sort path
+@pytest.mark.parametrize("n_envs,seeds", [(128, 1), (112, 1), (4096, 1), (1008, 2), (4096, 16), (32768, 4)])
+def test_update_permutation_equals_the_full_width_sort_of_its_keys(gpu, n_envs, seeds, impl):
+    """The epoch shuffle's sort (pqn_update.hip pqn_sort_keys; jax.random.permutation's stand-in, pqn_minatar.py:299-315) must leave the
+    permutation the full-width sort of the unique keys gives.  impl 2 (the default rule takes it from 16,384 keys per seed on): the library's own sort -- one workgroup per seed in LDS up
+    to 4096 keys (3584 = not a power of two), above that buckets by the leading random bits + a workgroup per bucket (B = 32 ... 1024).
+    impl 0: rocPRIM's radix sort over the random + seed bits only, which relies on stability for transitions that drew the same 31 bits
+    (~4 pairs per seed at 131,072 transitions, ~256 at 2^20) -- on its merge-sort path (one seed) and its onesweep path (seed batches)."""
+    from purejaxql_amd import _lib
     from purejaxql_amd.config_loader import flatten, load_config
     from purejaxql_amd.pqn import make_train, seed_keys
     cfg = flatten(load_config(["+alg=pqn_minatar", "alg.ENV_NAME=Breakout-MinAtar", f"alg.NUM_ENVS={n_envs}", "alg.TEST_DURING_TRAINING=False"]))
     cfg["TOTAL_TIMESTEPS"] = 3 * n_envs * 32
-    tr = make_train(cfg, device="cuda:0")
-    upd, _ = tr.make_batch_runner(seed_keys(3, seeds)) if seeds > 1 else tr.make_runner(seed_keys(3, 1)[0])
-    upd(0)
-    torch.cuda.synchronize()
+    if impl == 512 and n_envs * 32 * seeds > (1 << 18):
+        pytest.skip("the rank-sort path is quadratic: small shapes only")
+    with _lib.options(sort_impl=2 if impl else 0, sort_cap=impl if impl > 2 else 0):
+        tr = make_train(cfg, device="cuda:0")
+        upd, _ = tr.make_batch_runner(seed_keys(3, seeds)) if seeds > 1 else tr.make_runner(seed_keys(3, 1)[0])
+        upd(0)
+        torch.cuda.synchronize()
     drv = upd.driver
     tn = n_envs * 32
     mask = (1 << max(1, (tn - 1).bit_length())) - 1
