@@ -113,7 +113,7 @@ enum {
   PQN_OPT_POS_CHUNKS,     // PQN_POS_CHUNKS: sample chunks of the position-parallel backward, f16x2 layouts: 0 from the launch (default) / 1 / 2 / 4 / 8
   PQN_OPT_FOLD_APPLY,     // PQN_FOLD_APPLY: fold of the gradient partials + clip + RAdam of a fused CNN update in ONE launch (radam_apply_kernel<true>, pqn_fold.h): 0 never / 1 (default) for launches of one or two seeds (seeds x blocks <= 400) / 2 always; bit-identical either way
   PQN_OPT_GATHER_GROUP,   // PQN_GATHER_GROUP: super-tiles per workgroup of the position-parallel form's gather 0 (default) from the launch (4 while >= 2048 workgroups remain) / 1 / 4; same bytes either way
-  PQN_OPT_SORT_IMPL,      // PQN_SORT_IMPL: the epoch shuffle's sort 1 (default) = the two-level bucket sort of pqn_update.hip from 16,384 keys per seed on, rocPRIM's radix sort below / 0 = rocPRIM always / 2 = the library's sort at every size; the same permutation
+  PQN_OPT_SORT_IMPL,      // PQN_SORT_IMPL: the epoch shuffle's sort 1 (default) = the two-level bucket sort of pqn_update.hip above 4096 keys per seed, rocPRIM's radix sort below / 0 = rocPRIM always / 2 = the library's sort at every size; the same permutation
   PQN_OPT_SORT_CAP,       // PQN_SORT_CAP: tests only -- keys a bucket may hold before its workgroup takes the rank-sort path (0 = 4096, the LDS capacity)
   PQN_OPT_COUNT
 };

@@ -183,6 +183,62 @@ __global__ __launch_bounds__(SRT_THREADS) void srt_bucket_sort_kernel(const srt_
     }
     return;
   }
+  if (whole && cnt <= SRT_CAP && sub_shift >= 0) {
+    // a whole segment of at most 4096 keys (one workgroup per seed): the same two-level idea with the keys in registers -- the leading ten
+    // random bits cut the segment into 1024 sub-buckets of <= ~4 keys (a bitonic network here took ~45 us, rocPRIM's block / merge sort
+    // kernels 25-35 us over six launches)
+    constexpr int SB = 1024, NK = SRT_CAP / SRT_THREADS;
+    __shared__ unsigned w_c[SB], w_off[SB + 1], w_sc[SRT_THREADS];
+    srt_key_t k[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) { const int i = u * SRT_THREADS + tid; k[u] = i < (int)cnt ? src[i] : 0; }
+    for (int q = tid; q < SB; q += SRT_THREADS) w_c[q] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NK; ++u)
+      if (u * SRT_THREADS + tid < (int)cnt) atomicAdd(&w_c[(unsigned)(k[u] >> sub_shift) & (SB - 1)], 1u);
+    __syncthreads();
+    {
+      constexpr int per = SB / SRT_THREADS;
+      unsigned local = 0;
+#pragma unroll
+      for (int u = 0; u < per; ++u) local += w_c[tid * per + u];
+      w_sc[tid] = local;
+      __syncthreads();
+      for (int off = 1; off < SRT_THREADS; off <<= 1) {
+        const unsigned v = tid >= off ? w_sc[tid - off] : 0u;
+        __syncthreads();
+        w_sc[tid] += v;
+        __syncthreads();
+      }
+      unsigned run = w_sc[tid] - local;
+#pragma unroll
+      for (int u = 0; u < per; ++u) {
+        const unsigned c = w_c[tid * per + u];
+        w_off[tid * per + u] = run;
+        w_c[tid * per + u] = run;
+        run += c;
+      }
+      if (tid == SRT_THREADS - 1) w_off[SB] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NK; ++u)
+      if (u * SRT_THREADS + tid < (int)cnt) s[atomicAdd(&w_c[(unsigned)(k[u] >> sub_shift) & (SB - 1)], 1u)] = k[u];
+    __syncthreads();
+    for (int q = tid; q < SB; q += SRT_THREADS) {
+      const int lo = (int)w_off[q], hi = (int)w_off[q + 1];
+      for (int i = lo + 1; i < hi; ++i) {
+        const srt_key_t kk = s[i];
+        int j = i - 1;
+        while (j >= lo && s[j] > kk) { s[j + 1] = s[j]; --j; }
+        s[j + 1] = kk;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)cnt; i += SRT_THREADS) dst[i] = s[i];
+    return;
+  }
   if (!whole && cnt <= SRT_CAP / 2 && sub_shift >= 0) {
     // the usual case: ~1024 keys.  A bitonic network over them is bound by LDS bandwidth (66 stages x 48 B per comparator: 90 us per
     // 16-seed launch).  Instead: the NEXT ten random bits cut the bucket into 1024 sub-buckets of ~1 key -- count (LDS atomics), scan,
@@ -343,15 +399,16 @@ extern "C" int64_t pqn_update_sort_temp_bytes(int32_t n) {
 static int pqn_sort_keys(void *temp, size_t temp_bytes, const int64_t *in, int64_t *out, int n, int nseeds, int n_per_seed,
                          hipStream_t st) {
   const int ib = pqn_index_bits(n_per_seed);
-  // (segments below 16,384 keys: rocPRIM's block / merge sorts are as fast or faster -- measured at 1024, 4096 and 32,768 keys; option sort_impl = 2 takes
-  //  the library's sort at every size: tests)
   const int impl = pqn_opt(PQN_OPT_SORT_IMPL);
-  if (impl != 0 && (n_per_seed >= 16384 || impl == 2) && n_per_seed <= (1 << 22) && temp_bytes >= srt_counter_bytes(n)) {
+  // (segments of <= 4096 keys -- one workgroup per seed -- are no faster than rocPRIM's block / merge sort kernels: yaml default 2.303 vs 2.289 ms per
+  //  update, C5 equal; sort_impl = 2 takes the library's sort at every size: tests)
+  if (impl != 0 && (n_per_seed > SRT_CAP || impl == 2) && n_per_seed <= (1 << 22) && temp_bytes >= srt_counter_bytes(n)) {
     const srt_key_t *kin = reinterpret_cast<const srt_key_t *>(in);
     srt_key_t *kout = reinterpret_cast<srt_key_t *>(out);
     if (n_per_seed <= SRT_CAP) {
       hipLaunchKernelGGL(srt_bucket_sort_kernel, dim3(1, nseeds), dim3(SRT_THREADS), 0, st, kin, kout, (srt_key_t *)nullptr, n_per_seed, 1,
-                         (const unsigned *)nullptr, (const unsigned *)nullptr, 1, SRT_CAP, -1);
+                         (const unsigned *)nullptr, (const unsigned *)nullptr, 1, SRT_CAP,
+                         pqn_opt(PQN_OPT_SORT_CAP) > 0 ? -1 : ib + 31 - 10);   // (sort_cap set: the bitonic network, for the tests)
       return pqn_check_launch("pqn_sort_keys");
     }
     const int cap_opt = pqn_opt(PQN_OPT_SORT_CAP);   // tests only: a lower in-LDS capacity sends every bucket down the rank-sort path
