@@ -408,8 +408,8 @@ int pqn_cnn_seed_group(int matmul_mode, int nseeds);
  * this; default 48), "fold_apply" (pqn_cnn_update / pqn_cnn_update_seeds: the fold of the gradient partials, clip_by_global_norm and
  * RAdam of a minibatch in ONE launch: 0 never, 1 (default) for launches of one or two seeds, 2 always; bit-identical to the two
  * launches; args->grad then holds the LAST minibatch's gradient after the update -- the only one a caller can observe -- instead of
- * being rewritten by every optimizer step), "sort_impl" (the epoch permutation's sort: 0 rocPRIM's radix sort, 1 (default) the library's bucket sort from
- * 16,384 keys per seed on, 2 at every size; the same permutation), "gather_group".  Each starts from its PQN_<NAME> environment
+ * being rewritten by every optimizer step), "sort_impl" (the epoch permutation's sort: 0 rocPRIM's radix sort, 1 (default) the library's bucket sort above
+ * 4096 keys per seed, 2 at every size; the same permutation), "gather_group".  Each starts from its PQN_<NAME> environment
  * variable.  Not thread-safe against concurrent launches; results never depend on them beyond f32 rounding. */
 int pqn_set_option(const char *name, int32_t value);
 int pqn_get_option(const char *name, int32_t *value /* host */);

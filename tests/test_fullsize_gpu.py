@@ -120,7 +120,7 @@ def test_full_size_shuffle_is_a_bijection_and_update_is_deterministic(gpu):
 @pytest.mark.parametrize("n_envs,seeds", [(128, 1), (112, 1), (4096, 1), (1008, 2), (4096, 16), (32768, 4)])
 def test_update_permutation_equals_the_full_width_sort_of_its_keys(gpu, n_envs, seeds, impl):
     """The epoch shuffle's sort (pqn_update.hip pqn_sort_keys; jax.random.permutation's stand-in, pqn_minatar.py:299-315) must leave the
-    permutation the full-width sort of the unique keys gives.  impl 2 (the default rule takes it from 16,384 keys per seed on): the library's own sort -- one workgroup per seed in LDS up
+    permutation the full-width sort of the unique keys gives.  impl 2 (the default rule takes it above 4096 keys per seed): the library's own sort -- one workgroup per seed in LDS up
     to 4096 keys (3584 = not a power of two), above that buckets by the leading random bits + a workgroup per bucket (B = 32 ... 1024).
     impl 0: rocPRIM's radix sort over the random + seed bits only, which relies on stability for transitions that drew the same 31 bits
     (~4 pairs per seed at 131,072 transitions, ~256 at 2^20) -- on its merge-sort path (one seed) and its onesweep path (seed batches)."""
