@@ -161,7 +161,9 @@ __global__ __launch_bounds__(SRT_THREADS) void srt_bucket_sort_kernel(const srt_
                                                                       srt_key_t *__restrict__ spare, int n, int B,
                                                                       const unsigned *__restrict__ counts,
                                                                       const unsigned *__restrict__ bases, int whole, int cap, int sub_shift) {
+  constexpr int SB = 1024;          // sub-buckets of the two-level paths
   __shared__ srt_key_t s[SRT_CAP];
+  __shared__ unsigned s_c[SB], s_off[SB + 1], s_sc[SRT_THREADS];
   const int seed = blockIdx.y, bucket = blockIdx.x, tid = threadIdx.x;
   unsigned base = 0, cnt = (unsigned)n;
   if (!whole) {
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(SRT_THREADS) void srt_bucket_sort_kernel(const srt_
     // a whole segment of at most 4096 keys (one workgroup per seed): the same two-level idea with the keys in registers -- the leading ten
     // random bits cut the segment into 1024 sub-buckets of <= ~4 keys (a bitonic network here took ~45 us, rocPRIM's block / merge sort
     // kernels 25-35 us over six launches)
-    constexpr int SB = 1024, NK = SRT_CAP / SRT_THREADS;
-    __shared__ unsigned w_c[SB], w_off[SB + 1], w_sc[SRT_THREADS];
+    constexpr int NK = SRT_CAP / SRT_THREADS;
+    unsigned *w_c = s_c, *w_off = s_off, *w_sc = s_sc;
     srt_key_t k[NK];
 #pragma unroll
     for (int u = 0; u < NK; ++u) { const int i = u * SRT_THREADS + tid; k[u] = i < (int)cnt ? src[i] : 0; }
@@ -244,8 +246,7 @@ __global__ __launch_bounds__(SRT_THREADS) void srt_bucket_sort_kernel(const srt_
     // 16-seed launch).  Instead: the NEXT ten random bits cut the bucket into 1024 sub-buckets of ~1 key -- count (LDS atomics), scan,
     // place (LDS atomics: unordered inside a sub-bucket), then one thread per sub-bucket insertion-sorts its handful of keys on the
     // full key.  Three passes over the keys; correct for any key distribution (a crowded sub-bucket only costs time).
-    constexpr int SB = 1024, H = SRT_CAP / 2;
-    __shared__ unsigned s_c[SB], s_off[SB + 1], s_sc[SRT_THREADS];
+    constexpr int H = SRT_CAP / 2;
     srt_key_t *s_in = s, *s_out = s + H;
     for (int q = tid; q < SB; q += SRT_THREADS) s_c[q] = 0u;
     for (int i = tid; i < (int)cnt; i += SRT_THREADS) s_in[i] = src[i];
